@@ -1,0 +1,268 @@
+/*
+ * dyros_walk.h -- C-ABI of the MI355X-native DyrosDynamicWalk simulation step.
+ *
+ * This is the drop-in boundary.  The reference task talks to a closed
+ * native engine through the Isaac Gym tensor API; this library stands where that engine (and the
+ * eager torch task logic around it) stood.  Every pointer in DwBuffers is DEVICE memory owned by
+ * the caller (the Python host allocates it with torch), every call is enqueued on the hipStream_t
+ * passed as `stream` (void* so the header needs no HIP include), nothing here synchronises the
+ * device, allocates per call, or throws: all entry points return 0 on success and a negative
+ * DW_E* code otherwise, with dw_last_error() holding the message.
+ *
+ * Reference interface each entry point replaces (paths relative to
+ * python/IsaacGymEnvs/isaacgymenvs unless noted):
+ *
+ *   dw_create / dw_bind      gym.create_sim + load_asset + create_env/create_actor loop + prepare_sim +
+ *                            acquire_{actor_root_state,dof_state,net_contact_force}_tensor
+ *                            (tasks/base/vec_task.py:259-275,196; tasks/dyros_dynamic_walk.py:199-225,
+ *                            272-385,73-107) -- except that state buffers are caller-owned here, so the
+ *                            gymtorch.wrap_tensor aliasing shim (python/isaacgym/_bindings/src/gymtorch/
+ *                            gymtorch.cpp:33-158) has no counterpart.
+ *   dw_simulate              gym.set_dof_actuation_force_tensor + gym.apply_rigid_body_force_tensors +
+ *                            gym.simulate + gym.refresh_{dof_state,actor_root_state,net_contact_force}_tensor
+ *                            (tasks/dyros_dynamic_walk.py:502,520,525-526,547-549): ONE physics substep.
+ *   dw_step                  VecTask.step: pre_physics_step + 2x simulate + post_physics_step
+ *                            (tasks/base/vec_task.py:293-344; tasks/dyros_dynamic_walk.py:449-563,581-669,
+ *                            750-947) fused into one launch.
+ *   dw_reset_idx             DyrosDynamicWalk.reset_idx + set_actor_root_state_tensor_indexed +
+ *                            set_dof_state_tensor_indexed (tasks/dyros_dynamic_walk.py:598-669,720-748),
+ *                            as reached from VecTask.reset_done (tasks/base/vec_task.py:376-391).
+ *   dw_set_dof_properties    gym.set_actor_dof_properties / set_actor_rigid_body_properties as used by the
+ *   (plain buffer writes)    domain randomisation (tasks/base/vec_task.py:655-721): the per-env parameter
+ *                            arrays in DwBuffers ARE the properties; the host writes them directly.
+ *
+ * The CPU oracle (oracle/dw_oracle.c) exports the same functions with the prefix dwo_ and host
+ * pointers, so one host class and one test-suite drive both.
+ */
+#ifndef DYROS_WALK_H
+#define DYROS_WALK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DW_ABI_VERSION 1
+
+/* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
+#define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
+#define DW_NUM_MOVING   34   /* floating base + 33 hinge links (welded feet merged)       */
+#define DW_NUM_DOF      33
+#define DW_NUM_INERT    36   /* bodies that carry an <inertial>                           */
+#define DW_MAX_GEOMS    64
+#define DW_NUM_FOOT_PTS  8   /* 4 sole corners per foot                                   */
+#define DW_NUM_ACT      13   /* 12 leg torques + 1 gait-clock action                      */
+#define DW_NUM_LOWER    12
+#define DW_NUM_OBS1     37   /* single-step observation                                   */
+#define DW_NUM_HIS      10
+#define DW_NUM_SKIP      2
+#define DW_HIST_SLOTS   20   /* NumHis*NumSkip                                            */
+#define DW_NUM_OBS     487   /* (37+13)*(10-1)+37, tasks/dyros_dynamic_walk.py:43         */
+#define DW_NUM_REW      15   /* 14 reward terms + perturbation flag column                */
+#define DW_ALOG_SLOTS    6   /* round(0.01/dt)+1 torque FIFO, tasks/dyros_dynamic_walk.py:166 */
+#define DW_MOCAP_ROWS 3600
+#define DW_MOCAP_COLS   36
+
+#define DW_OK            0
+#define DW_EINVAL       -1
+#define DW_ENOMEM       -2
+#define DW_EHIP         -3
+#define DW_ESTATE       -4
+
+typedef struct DwGeom {
+    int32_t type;        /* 0 box (size = half extents), 1 cylinder (size = radius, half height; axis = local z) */
+    int32_t moving;      /* moving body that carries the primitive */
+    int32_t gym;         /* Gym body the contact force is attributed to */
+    int32_t sole;        /* 1 for the two *_Foot_Link sole boxes (handled by the contact solve) */
+    float   pos[3];      /* primitive centre in the moving body's frame */
+    float   rot[9];      /* primitive axes in the moving body's frame, row-major */
+    float   size[3];
+    float   _pad;
+} DwGeom;
+
+typedef struct DwModel {
+    int32_t mv_parent[DW_NUM_MOVING];
+    int32_t mv_gym[DW_NUM_MOVING];
+    int32_t mv_depth[DW_NUM_MOVING];
+    float   mv_pos[DW_NUM_MOVING][3];    /* body origin in the parent's frame                      */
+    float   mv_rot0[DW_NUM_MOVING][9];   /* fixed body rotation (body coords -> parent coords)     */
+    float   mv_axis[DW_NUM_MOVING][3];   /* hinge axis in body coords (entry 0 unused)             */
+    float   dof_lower[DW_NUM_DOF];
+    float   dof_upper[DW_NUM_DOF];
+    float   dof_vmax[DW_NUM_DOF];        /* dof_prop['velocity'] = 4.03, tasks/dyros_dynamic_walk.py:372 */
+    int32_t inert_mv[DW_NUM_INERT];
+    int32_t inert_gym[DW_NUM_INERT];
+    float   inert_mass[DW_NUM_INERT];
+    float   inert_com[DW_NUM_INERT][3];  /* COM in the moving body's frame                         */
+    float   inert_I[DW_NUM_INERT][6];    /* xx yy zz xy xz yz about the COM, moving body's frame   */
+    int32_t num_geoms;
+    DwGeom  geoms[DW_MAX_GEOMS];
+    int32_t foot_mv[DW_NUM_FOOT_PTS];
+    int32_t foot_gym[DW_NUM_FOOT_PTS];
+    float   foot_pos[DW_NUM_FOOT_PTS][3];
+    int32_t left_foot_gym, right_foot_gym, pelvis_gym;
+} DwModel;
+
+/* Task constants the reference hard-codes (tasks/dyros_dynamic_walk.py:58-70,95-100,296-301) or loads
+ * from data files (:112-113,139-142).  HOST pointers, copied at dw_create. */
+typedef struct DwTaskConst {
+    const float *kp;            /* [33]  already divided by 9  */
+    const float *kv;            /* [33]  already divided by 3  */
+    const float *action_high;   /* [33]                         */
+    const float *initial_dof_pos; /* [33]                       */
+    const float *mocap;         /* [3600*36] float32 rows       */
+    const float *obs_mean;      /* [37]                         */
+    const float *obs_var;       /* [37]                         */
+    const float *dof_armature_nominal; /* [33] tasks/dyros_dynamic_walk.py:366-371 (DR scales these)   */
+    const float *dof_damping_nominal;  /* [33] = 0.1, tasks/dyros_dynamic_walk.py:365 (DR adds to these) */
+} DwTaskConst;
+
+typedef struct DwConfig {
+    double  dt;                         /* sim.dt = 0.002 (cfg/task/DyrosDynamicWalk.yaml:38); double so that the
+                                           python-side constant folding (dt*skipframe, 5*dt_policy, 8/dt_policy) is exact */
+    int32_t num_envs;
+    int32_t control_freq_inv;           /* env.controlFrequencyInv = 2 (:11); only 2 is supported     */
+    float   gravity[3];                 /* sim.gravity (:42)                                          */
+    int32_t solver_iterations;          /* physx.num_position_iterations + num_velocity_iterations    */
+    float   contact_offset;             /* physx.contact_offset = 0.002 (:49)                         */
+    float   max_depenetration_velocity; /* physx.max_depenetration_velocity = 10 (:52)                */
+    float   friction;                   /* TerrainCfg static=dynamic friction = 1 (cfg/terrain/terrain_cfg.py:7-8) */
+    float   erp;                        /* fraction of penetration removed per step (written decision) */
+    float   contact_cfm;                /* relative diagonal regularisation of the Delassus matrix    */
+    float   penalty_stiffness;          /* non-foot ground contact: N/m                               */
+    float   penalty_damping;            /* non-foot ground contact: N s/m                             */
+    float   max_angular_velocity;       /* asset_options.max_angular_velocity = 100 (tasks/dyros_dynamic_walk.py:289) */
+    float   max_episode_length;         /* episodeLength/(dt*controlFrequencyInv) = 8000.0 (:35)      */
+    float   initial_height;             /* env.initialHieght = 0.93                                   */
+    float   death_cost;                 /* env.deathCost = 0                                          */
+    int32_t perturb;                    /* env.perturbation                                           */
+    int32_t force_perturb_start;        /* the commented override at tasks/dyros_dynamic_walk.py:491  */
+    int32_t randomize_dof_on_reset;     /* task.randomize: damping/armature DR at every reset         */
+    float   dr_damping_add[2];          /* [0, 2.9]   (cfg/task/DyrosDynamicWalk.yaml:103-108)        */
+    float   dr_armature_scale[2];       /* [0.8, 1.2] (:109-115)                                      */
+    int32_t randomize_friction_on_reset;/* BASELINE config 5; parameters of the commented block :89-95 */
+    float   dr_friction_scale[2];       /* [0.7, 1.3]                                                 */
+    int32_t timeout_fix;                /* 0 = reproduce SURVEY quirk Q16 (time_outs identically 0)   */
+    int32_t root_vel_at_com;            /* 1 = root linear velocity is the COM's (PhysX convention)   */
+    int32_t torch_gpu_div;              /* 1 = `tensor / python_scalar` is tensor * (1/scalar), as torch's GPU
+                                           kernels compute it; 0 = true division, as torch's CPU kernels do */
+    int32_t debug_freeze_physics;       /* 1 = simulate() leaves the state untouched (task-logic parity tests) */
+    uint64_t seed;                      /* key of the counter-based in-kernel RNG                     */
+} DwConfig;
+
+/* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of
+ * dw_step / dw_reset_idx is NULL the kernel draws the same logical record from Philox4x32-10 keyed by
+ * (seed; env, step).  Slots hold FINAL encoder noise values (already N(0, 0.00016/3)) and raw U[0,1)
+ * draws for everything else, so a recorded reference run can be replayed bit for bit. */
+#define DW_NZ_ENC      0    /* [2][33] encoder noise, substep-major (tasks/dyros_dynamic_walk.py:528)     */
+#define DW_NZ_VEL     66    /* [6]  root velocity noise draw (:766)                                       */
+#define DW_NZ_QPOS_BIAS 72  /* [12] (:615)   */
+#define DW_NZ_QUAT_BIAS 84  /* [3]  (:616)   */
+#define DW_NZ_TARGET_VEL 87 /* [1]  (:624)   */
+#define DW_NZ_INIT_MOCAP 88 /* [1]  (:630)   */
+#define DW_NZ_MOTOR   89    /* [12] (:645)   */
+#define DW_NZ_DELAY  101    /* [1]  (:652)   */
+#define DW_NZ_PTIMING 102   /* [1]  (:665)   */
+#define DW_NZ_DR_DAMP 103   /* [33]          */
+#define DW_NZ_DR_ARM  136   /* [33]          */
+#define DW_NZ_DR_FRIC 169   /* [1]           */
+#define DW_NZ_PERT   170    /* [3] impulse, duration, phase (:440-443) */
+#define DW_NOISE_WORDS 176
+
+/* Per-env task-state record: DW_ES_WORDS 32-bit words, 16-byte aligned, one contiguous row per env
+ * so a wavefront moves it with dwordx4 loads.  Offsets in words; `i:` marks int32 fields. */
+#define DW_ES_QPOS_NOISE      0   /* [33] */
+#define DW_ES_QVEL_NOISE     33   /* [33] */
+#define DW_ES_QPOS_PRE       66   /* [33] */
+#define DW_ES_PRE_QVEL       99   /* [33] pre_joint_velocity_states */
+#define DW_ES_TARGET_QPOS   132   /* [33] target_data_qpos of the last step */
+#define DW_ES_TARGET_FORCE  165   /* [2]  */
+#define DW_ES_TARGET_VEL    167   /* [2]  */
+#define DW_ES_MOTOR_SCALE   169   /* [12] */
+#define DW_ES_QPOS_BIAS     181   /* [12] */
+#define DW_ES_QUAT_BIAS     193   /* [3]  */
+#define DW_ES_ACTION_LOG    196   /* [6][12] */
+#define DW_ES_ACTIONS       268   /* [13] */
+#define DW_ES_ACTIONS_PRE   281   /* [13] */
+#define DW_ES_ACTION_TORQUE 294   /* [12] */
+#define DW_ES_ACTION_TORQUE_PRE 306 /* [12] */
+#define DW_ES_FOOT_FORCE_PRE 318  /* [2][3] contact_forces_pre rows of L_Foot_Link, R_Foot_Link */
+#define DW_ES_TIME          324
+#define DW_ES_EPI_LEN       325
+#define DW_ES_EPI_LEN_LOG   326
+#define DW_ES_CRS           327   /* contact_reward_sum  */
+#define DW_ES_CRM           328   /* contact_reward_mean */
+#define DW_ES_MAGNITUDE     329
+#define DW_ES_PHASE         330
+#define DW_ES_INIT_MOCAP    331   /* i: */
+#define DW_ES_MOCAP_IDX     332   /* i: */
+#define DW_ES_DELAY_IDX     333   /* i: */
+#define DW_ES_SIMUL_LEN     334   /* i: */
+#define DW_ES_PERT_COUNT    335   /* i: */
+#define DW_ES_PERT_DURATION 336   /* i: */
+#define DW_ES_PERT_ON       337   /* i: */
+#define DW_ES_IMPULSE       338   /* i: */
+#define DW_ES_PERT_TIMING   339   /* i: */
+#define DW_ES_PERT_START    340   /* i: */
+#define DW_ES_HIST_HEAD     341   /* i: ring position of the OLDEST history slot */
+#define DW_ES_NAN_RESETS    342   /* i: count of resets forced by a non-finite state */
+#define DW_ES_WARM          344   /* [8][3] contact impulses of the previous substep (warm start) */
+#define DW_ES_WORDS         368
+
+/* Device buffers (caller-owned).  Shapes in [] with N = num_envs; float32 unless noted. */
+typedef struct DwBuffers {
+    /* Gym tensor API state (python/isaacgym docs: programming/tensors) */
+    float   *root_states;     /* [N,13] pos3 quat(xyzw)4 linvel3 angvel3, world frame   */
+    float   *dof_state;       /* [N,33,2] (pos, vel) interleaved                        */
+    float   *contact_forces;  /* [N,38,3] net contact force per body, world frame       */
+    /* per-env physical parameters (domain randomisation targets) */
+    float   *mass_scale;      /* [N,38] per Gym body mass multiplier                    */
+    float   *dof_damping;     /* [N,33]                                                 */
+    float   *dof_armature;    /* [N,33]                                                 */
+    float   *friction_scale;  /* [N]                                                    */
+    float   *total_mass;      /* [N]                                                    */
+    float   *env_origins;     /* [N,3]                                                  */
+    /* VecTask buffers (tasks/base/vec_task.py:233-256) */
+    float   *obs_buf;         /* [N,487]                                                */
+    float   *rew_buf;         /* [N]                                                    */
+    int64_t *reset_buf;       /* [N]                                                    */
+    int64_t *progress_buf;    /* [N]                                                    */
+    int64_t *timeout_buf;     /* [N]                                                    */
+    int64_t *randomize_buf;   /* [N]                                                    */
+    float   *stacked_rewards; /* [N,15] extras["stacked_rewards"]                       */
+    /* task state */
+    float   *env_state;       /* [N,DW_ES_WORDS]                                        */
+    float   *obs_history;     /* [N,20,37] ring, see DW_ES_HIST_HEAD                    */
+    float   *action_history;  /* [N,20,13] ring                                         */
+    /* cross-env statistics for the perturbation gate (tasks/dyros_dynamic_walk.py:489): 3 rotating
+     * slots of {sum epi_len_log, sum contact_reward_mean} as int64 fixed point, + latch word */
+    int64_t *gate_acc;        /* [8]                                                    */
+} DwBuffers;
+
+typedef struct DwHandle DwHandle;
+
+int         dw_abi_version(void);
+const char *dw_last_error(void);
+void        dw_default_config(DwConfig *cfg);
+
+int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task, DwHandle **out);
+int dw_destroy(DwHandle *h);
+int dw_bind(DwHandle *h, const DwBuffers *buffers);
+
+/* One physics substep at the Gym boundary: tau [N,33] joint efforts, push_xy [N,2] world force on
+ * base_link's COM (may be NULL).  Reads and writes root_states/dof_state, writes contact_forces. */
+int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *stream);
+
+/* One VecTask.step.  actions [N,13] (clamped to +-1 inside, vec_task.py:304-307); noise [N,DW_NOISE_WORDS]
+ * or NULL; step_index = number of dw_step calls made before this one. */
+int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream);
+
+/* reset_idx for the env ids listed (int32, device memory). */
+int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise,
+                 int64_t step_index, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYROS_WALK_H */

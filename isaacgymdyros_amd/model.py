@@ -1,0 +1,337 @@
+"""TOCABI model compiler and loader.
+
+Turns the robot description the reference task loads through
+``gym.load_asset`` (reference: tasks/dyros_dynamic_walk.py:276-293, asset
+``assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml``) into the flat arrays the
+HIP kernels and the CPU oracle consume:
+
+* 38 rigid bodies in XML depth-first order (the Gym body index used by
+  ``net_contact_force`` and ``apply_rigid_body_force_tensors``),
+* 34 *moving* bodies (floating base + 33 hinge links; moving body ``b`` is driven
+  by DoF ``b-1``), the four joint-less foot bodies welded into their parent,
+* 36 inertial records (mass, COM, inertia about the COM in the owning moving
+  body's frame), kept separate so the per-body mass randomisation of
+  ``apply_randomizations`` (reference: tasks/base/vec_task.py:519-733) can scale
+  each Gym body on its own,
+* 61 collision primitives (boxes / cylinders, class ``cls``) in moving-body frames,
+* the 8 sole-corner points of the two ``*_Foot_Link`` boxes that enter the contact solve.
+
+The compiled model is committed as ``assets/tocabi_model.json`` (data derived from
+the MJCF; the XML itself is not shipped).  ``compile_mjcf`` only runs where the
+reference checkout is present (``tools/compile_assets.py``).
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, List
+
+import numpy as np
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+MODEL_JSON = os.path.join(ASSET_DIR, "tocabi_model.json")
+
+NUM_BODIES = 38   # Gym rigid bodies (reference: SURVEY appendix A)
+NUM_MOVING = 34   # floating base + 33 hinge links
+NUM_DOF = 33
+NUM_INERT = 36
+MAX_GEOMS = 64
+NUM_FOOT_PTS = 8
+
+# Per-DoF constants the reference hard-codes in the task (not in the MJCF).
+# reference: tasks/dyros_dynamic_walk.py:366-372 (armature, damping, velocity)
+ARMATURE = [0.614, 0.862, 1.09, 1.09, 1.09, 0.360,
+            0.614, 0.862, 1.09, 1.09, 1.09, 0.360,
+            0.078, 0.078, 0.078,
+            0.18, 0.18, 0.18, 0.18, 0.0032, 0.0032, 0.0032, 0.0032,
+            0.0032, 0.0032,
+            0.18, 0.18, 0.18, 0.18, 0.0032, 0.0032, 0.0032, 0.0032]
+DOF_DAMPING = 0.1
+DOF_MAX_VELOCITY = 4.03
+
+
+def _quat_wxyz_to_mat(q) -> np.ndarray:
+    w, x, y, z = [float(v) for v in q]
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _floats(s, n=None, default=None):
+    if s is None:
+        return list(default)
+    v = [float(t) for t in s.split()]
+    if n is not None:
+        assert len(v) == n, (s, n)
+    return v
+
+
+def compile_mjcf(xml_path: str) -> Dict:
+    """Parse the MJCF into the compiled-model dictionary (plain lists, float64)."""
+    import xml.etree.ElementTree as ET
+
+    root = ET.parse(xml_path).getroot()
+    world = root.find("worldbody")
+    top = world.find("body")
+
+    bodies: List[Dict] = []
+
+    def visit(elem, parent38):
+        idx = len(bodies)
+        pos = _floats(elem.get("pos"), 3, (0, 0, 0))
+        quat = _floats(elem.get("quat"), 4, (1, 0, 0, 0))
+        joint = elem.find("joint")
+        jtype = None
+        axis = [0.0, 0.0, 0.0]
+        rng = [0.0, 0.0]
+        jname = None
+        if joint is not None:
+            jtype = joint.get("type", "hinge")
+            jname = joint.get("name")
+            if jtype == "hinge":
+                axis = _floats(joint.get("axis"), 3)
+                assert _floats(joint.get("pos"), 3, (0, 0, 0)) == [0.0, 0.0, 0.0]
+                rng = _floats(joint.get("range"), 2)
+        inertial = elem.find("inertial")
+        inert = None
+        if inertial is not None:
+            m = float(inertial.get("mass"))
+            c = _floats(inertial.get("pos"), 3)
+            ixx, iyy, izz, ixy, ixz, iyz = _floats(inertial.get("fullinertia"), 6)
+            I = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+            iq = inertial.get("quat")
+            if iq is not None:
+                R = _quat_wxyz_to_mat(_floats(iq, 4))
+                I = R @ I @ R.T
+            inert = dict(mass=m, com=c, I=I.tolist())
+        geoms = []
+        for g in elem.findall("geom"):
+            if g.get("class") != "cls":
+                continue
+            gtype = g.get("type")
+            assert gtype in ("box", "cylinder"), gtype
+            size = _floats(g.get("size"))
+            geoms.append(dict(type=gtype, pos=_floats(g.get("pos"), 3, (0, 0, 0)),
+                              quat=_floats(g.get("quat"), 4, (1, 0, 0, 0)), size=size))
+        bodies.append(dict(name=elem.get("name"), parent=parent38, pos=pos, quat=quat,
+                           jtype=jtype, jname=jname, axis=axis, range=rng,
+                           inertial=inert, geoms=geoms))
+        for child in elem.findall("body"):
+            visit(child, idx)
+
+    visit(top, -1)
+    assert len(bodies) == NUM_BODIES, len(bodies)
+
+    # --- moving bodies: the free root and every hinge body, in depth-first order ---
+    moving_of_body = [-1] * NUM_BODIES          # gym body -> moving body that carries it
+    T_in_moving = [None] * NUM_BODIES           # (R, p) of gym body frame in its moving body's frame
+    mv_gym, mv_parent, mv_pos, mv_rot0, mv_axis, mv_range, dof_names = [], [], [], [], [], [], []
+    for i, b in enumerate(bodies):
+        R = _quat_wxyz_to_mat(b["quat"])
+        p = np.array(b["pos"])
+        if b["jtype"] is not None:
+            m = len(mv_gym)
+            moving_of_body[i] = m
+            T_in_moving[i] = (np.eye(3), np.zeros(3))
+            mv_gym.append(i)
+            mv_parent.append(-1 if b["parent"] < 0 else moving_of_body[b["parent"]])
+            if b["parent"] >= 0:
+                # parent gym body may itself be welded: compose
+                Rp, pp = T_in_moving[b["parent"]]
+                mv_pos.append((pp + Rp @ p).tolist())
+                mv_rot0.append((Rp @ R).tolist())
+            else:
+                mv_pos.append(p.tolist())
+                mv_rot0.append(R.tolist())
+            ax = np.array(b["axis"])
+            if b["jtype"] == "hinge":
+                ax = ax / np.linalg.norm(ax)
+                dof_names.append(b["jname"])
+            mv_axis.append(ax.tolist())
+            mv_range.append(b["range"])
+        else:
+            Rp, pp = T_in_moving[b["parent"]]
+            moving_of_body[i] = moving_of_body[b["parent"]]
+            T_in_moving[i] = (Rp @ R, pp + Rp @ p)
+    assert len(mv_gym) == NUM_MOVING and len(dof_names) == NUM_DOF
+
+    # depth of every moving body (root = 0)
+    depth = [0] * NUM_MOVING
+    for m in range(1, NUM_MOVING):
+        depth[m] = depth[mv_parent[m]] + 1
+
+    # --- inertial records ---
+    inert_mv, inert_gym, inert_mass, inert_com, inert_I = [], [], [], [], []
+    for i, b in enumerate(bodies):
+        if b["inertial"] is None:
+            continue
+        R, p = T_in_moving[i]
+        inert_mv.append(moving_of_body[i])
+        inert_gym.append(i)
+        inert_mass.append(b["inertial"]["mass"])
+        inert_com.append((p + R @ np.array(b["inertial"]["com"])).tolist())
+        inert_I.append((R @ np.array(b["inertial"]["I"]) @ R.T).tolist())
+    assert len(inert_mv) == NUM_INERT
+
+    # --- collision primitives ---
+    geoms = []
+    foot_pts = []
+    for i, b in enumerate(bodies):
+        R, p = T_in_moving[i]
+        for g in b["geoms"]:
+            Rg = R @ _quat_wxyz_to_mat(g["quat"])
+            pg = p + R @ np.array(g["pos"])
+            if g["type"] == "box":
+                size = list(g["size"]) + [0.0] * (3 - len(g["size"]))
+                gt = 0
+            else:
+                size = [g["size"][0], g["size"][1], 0.0]   # radius, half height (axis = local z)
+                gt = 1
+            is_sole = b["name"] in ("L_Foot_Link", "R_Foot_Link")
+            geoms.append(dict(type=gt, moving=moving_of_body[i], gym=i, pos=pg.tolist(),
+                              rot=Rg.tolist(), size=size, sole=int(is_sole)))
+            if is_sole:
+                hx, hy, hz = size
+                for sx, sy in ((1, 1), (1, -1), (-1, 1), (-1, -1)):
+                    c = pg + Rg @ np.array([sx * hx, sy * hy, -hz])
+                    foot_pts.append(dict(moving=moving_of_body[i], gym=i, pos=c.tolist()))
+    assert len(foot_pts) == NUM_FOOT_PTS
+
+    names = [b["name"] for b in bodies]
+    model = dict(
+        body_names=names,
+        dof_names=dof_names,
+        body_parent=[b["parent"] for b in bodies],
+        body_moving=moving_of_body,
+        mv_gym=mv_gym, mv_parent=mv_parent, mv_depth=depth,
+        mv_pos=mv_pos, mv_rot0=mv_rot0, mv_axis=mv_axis,
+        dof_lower=[min(r) for r in mv_range[1:]],
+        dof_upper=[max(r) for r in mv_range[1:]],
+        inert_mv=inert_mv, inert_gym=inert_gym, inert_mass=inert_mass,
+        inert_com=inert_com, inert_I=inert_I,
+        geoms=geoms, foot_pts=foot_pts,
+        left_foot_idx=names.index("L_Foot_Link"),
+        right_foot_idx=names.index("R_Foot_Link"),
+        pelvis_idx=names.index("base_link"),
+        root_pos=bodies[0]["pos"],
+    )
+    return model
+
+
+# ---------------------------------------------------------------------------------------
+# C mirror of include/dyros_walk.h :: DwModel
+# ---------------------------------------------------------------------------------------
+class DwGeom(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int), ("moving", ctypes.c_int), ("gym", ctypes.c_int),
+                ("sole", ctypes.c_int),
+                ("pos", ctypes.c_float * 3), ("rot", ctypes.c_float * 9),
+                ("size", ctypes.c_float * 3), ("_pad", ctypes.c_float)]
+
+
+class DwModel(ctypes.Structure):
+    _fields_ = [
+        ("mv_parent", ctypes.c_int * NUM_MOVING),
+        ("mv_gym", ctypes.c_int * NUM_MOVING),
+        ("mv_depth", ctypes.c_int * NUM_MOVING),
+        ("mv_pos", (ctypes.c_float * 3) * NUM_MOVING),
+        ("mv_rot0", (ctypes.c_float * 9) * NUM_MOVING),
+        ("mv_axis", (ctypes.c_float * 3) * NUM_MOVING),
+        ("dof_lower", ctypes.c_float * NUM_DOF),
+        ("dof_upper", ctypes.c_float * NUM_DOF),
+        ("dof_vmax", ctypes.c_float * NUM_DOF),
+        ("inert_mv", ctypes.c_int * NUM_INERT),
+        ("inert_gym", ctypes.c_int * NUM_INERT),
+        ("inert_mass", ctypes.c_float * NUM_INERT),
+        ("inert_com", (ctypes.c_float * 3) * NUM_INERT),
+        ("inert_I", (ctypes.c_float * 6) * NUM_INERT),   # xx yy zz xy xz yz about the COM
+        ("num_geoms", ctypes.c_int),
+        ("geoms", DwGeom * MAX_GEOMS),
+        ("foot_mv", ctypes.c_int * NUM_FOOT_PTS),
+        ("foot_gym", ctypes.c_int * NUM_FOOT_PTS),
+        ("foot_pos", (ctypes.c_float * 3) * NUM_FOOT_PTS),
+        ("left_foot_gym", ctypes.c_int),
+        ("right_foot_gym", ctypes.c_int),
+        ("pelvis_gym", ctypes.c_int),
+    ]
+
+
+@dataclass
+class TocabiModel:
+    """Compiled model with numpy views plus the packed C struct."""
+    d: Dict
+
+    def __getattr__(self, k):
+        try:
+            return self.__dict__["d"][k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    @property
+    def nominal_total_mass(self) -> float:
+        return float(sum(self.d["inert_mass"]))
+
+    def non_feet_idxs(self) -> List[int]:
+        """reference: tasks/dyros_dynamic_walk.py:320-324"""
+        return [i for i in range(NUM_BODIES)
+                if i not in (self.d["left_foot_idx"], self.d["right_foot_idx"])]
+
+    def to_c(self) -> DwModel:
+        d = self.d
+        m = DwModel()
+        for i in range(NUM_MOVING):
+            m.mv_parent[i] = d["mv_parent"][i]
+            m.mv_gym[i] = d["mv_gym"][i]
+            m.mv_depth[i] = d["mv_depth"][i]
+            for k in range(3):
+                m.mv_pos[i][k] = d["mv_pos"][i][k]
+                m.mv_axis[i][k] = d["mv_axis"][i][k]
+            for r in range(3):
+                for c in range(3):
+                    m.mv_rot0[i][3 * r + c] = d["mv_rot0"][i][r][c]
+        for j in range(NUM_DOF):
+            m.dof_lower[j] = d["dof_lower"][j]
+            m.dof_upper[j] = d["dof_upper"][j]
+            m.dof_vmax[j] = DOF_MAX_VELOCITY
+        for i in range(NUM_INERT):
+            m.inert_mv[i] = d["inert_mv"][i]
+            m.inert_gym[i] = d["inert_gym"][i]
+            m.inert_mass[i] = d["inert_mass"][i]
+            I = d["inert_I"][i]
+            for k in range(3):
+                m.inert_com[i][k] = d["inert_com"][i][k]
+            vals = (I[0][0], I[1][1], I[2][2], I[0][1], I[0][2], I[1][2])
+            for k in range(6):
+                m.inert_I[i][k] = vals[k]
+        geoms = d["geoms"]
+        assert len(geoms) <= MAX_GEOMS
+        m.num_geoms = len(geoms)
+        for i, g in enumerate(geoms):
+            cg = m.geoms[i]
+            cg.type, cg.moving, cg.gym, cg.sole = g["type"], g["moving"], g["gym"], g["sole"]
+            for k in range(3):
+                cg.pos[k] = g["pos"][k]
+                cg.size[k] = g["size"][k]
+            for r in range(3):
+                for c in range(3):
+                    cg.rot[3 * r + c] = g["rot"][r][c]
+        for i, f in enumerate(d["foot_pts"]):
+            m.foot_mv[i] = f["moving"]
+            m.foot_gym[i] = f["gym"]
+            for k in range(3):
+                m.foot_pos[i][k] = f["pos"][k]
+        m.left_foot_gym = d["left_foot_idx"]
+        m.right_foot_gym = d["right_foot_idx"]
+        m.pelvis_gym = d["pelvis_idx"]
+        return m
+
+
+def load_model(path: str = MODEL_JSON) -> TocabiModel:
+    with open(path) as f:
+        return TocabiModel(json.load(f))
