@@ -63,6 +63,9 @@ extern "C" {
 #define DW_ALOG_SLOTS    6   /* round(0.01/dt)+1 torque FIFO, tasks/dyros_dynamic_walk.py:166 */
 #define DW_MOCAP_ROWS 3600
 #define DW_MOCAP_COLS   36
+#define DW_GATE_BUCKETS 32
+#define DW_GATE_LATCH  192   /* 3 slots * 32 buckets * 2 words */
+#define DW_GATE_WORDS  256
 
 #define DW_OK            0
 #define DW_EINVAL       -1
@@ -235,9 +238,10 @@ typedef struct DwBuffers {
     float   *env_state;       /* [N,DW_ES_WORDS]                                        */
     float   *obs_history;     /* [N,20,37] ring, see DW_ES_HIST_HEAD                    */
     float   *action_history;  /* [N,20,13] ring                                         */
-    /* cross-env statistics for the perturbation gate (tasks/dyros_dynamic_walk.py:489): 3 rotating
-     * slots of {sum epi_len_log, sum contact_reward_mean} as int64 fixed point, + latch word */
-    int64_t *gate_acc;        /* [8]                                                    */
+    /* cross-env statistics for the perturbation gate (tasks/dyros_dynamic_walk.py:489): 3 rotating slots x
+     * 32 buckets (env % 32) of {sum epi_len_log, sum contact_reward_mean * 2^32} as int64 (integer sums are
+     * order-independent, so the gate is deterministic), latch word at [DW_GATE_LATCH] */
+    int64_t *gate_acc;        /* [DW_GATE_WORDS]                                        */
 } DwBuffers;
 
 typedef struct DwHandle DwHandle;

@@ -132,7 +132,7 @@ BUFFER_SPECS = {
     "action_history": ((K["DW_HIST_SLOTS"], K["DW_NUM_ACT"]), "f4"),
     "gate_acc": (None, "i8"),
 }
-GATE_ACC_WORDS = 8
+GATE_ACC_WORDS = K["DW_GATE_WORDS"]
 
 # env-state record fields: name -> (word offset, shape, 'f' float32 | 'i' int32); see DW_ES_* in the header
 ES_FIELDS = {

@@ -1,0 +1,137 @@
+// dw_devmodel.h -- the model and task constants as the kernels read them (one struct in device memory,
+// ~16 KB, read-only, L2/K$ resident), and the host routine that derives the traversal tables from the
+// C-ABI's DwModel (include/dyros_walk.h).
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/dyros_walk.h"
+
+namespace dw {
+
+constexpr int NB = DW_NUM_MOVING;   // 34 moving bodies
+constexpr int ND = DW_NUM_DOF;      // 33
+constexpr int MAX_LEVELS = 12;      // tree depth 11 below the root
+constexpr int MAX_PER_LEVEL = 5;    // widest level (legs + arms + neck)
+constexpr int MAX_CHILD = 3;
+constexpr int MAX_BODY_GEOMS = 8;
+constexpr int MAX_BODY_INERT = 2;
+
+struct DevModel {
+    // tree
+    int32_t parent[NB];
+    int32_t nchild[NB];
+    int32_t child[NB][MAX_CHILD];
+    int32_t nlevels;                          // levels 1..nlevels hold the bodies below the root
+    int32_t level_count[MAX_LEVELS];
+    int32_t level_body[MAX_LEVELS][MAX_PER_LEVEL];
+    float   pos[NB][3];
+    float   rot0[NB][9];
+    float   axis[NB][3];
+    // dofs
+    float   qlo[ND], qhi[ND], vmax[ND];
+    // inertial records
+    int32_t ninert[NB];
+    int32_t inert_idx[NB][MAX_BODY_INERT];
+    int32_t inert_gym[DW_NUM_INERT];
+    float   inert_mass[DW_NUM_INERT];
+    float   inert_com[DW_NUM_INERT][3];
+    float   inert_I[DW_NUM_INERT][6];
+    // collision primitives
+    int32_t ngeom;
+    DwGeom  geoms[DW_MAX_GEOMS];
+    int32_t body_ngeom[NB];
+    int32_t body_geom[NB][MAX_BODY_GEOMS];
+    // soles
+    int32_t foot_mv[DW_NUM_FOOT_PTS];
+    int32_t foot_gym[DW_NUM_FOOT_PTS];
+    float   foot_pos[DW_NUM_FOOT_PTS][3];
+    int32_t foot_body[2];                     // moving body of the left / right sole
+    int32_t left_foot_gym, right_foot_gym;
+    // task constants
+    float   kp[ND], kv[ND], action_high[ND], q_init[ND];
+    float   obs_mean[DW_NUM_OBS1], obs_inv_std_den[DW_NUM_OBS1];   // second = sqrt(var + 1e-8), the divisor
+    float   arm_nom[ND], damp_nom[ND];
+    int32_t has_task;
+};
+
+// Builds the traversal tables.  Returns 0 or a negative DW_E* code (message in err).
+inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, const char **err) {
+    memset(d, 0, sizeof(*d));
+    for (int b = 0; b < NB; ++b) {
+        d->parent[b] = m->mv_parent[b];
+        for (int i = 0; i < 3; ++i) { d->pos[b][i] = m->mv_pos[b][i]; d->axis[b][i] = m->mv_axis[b][i]; }
+        for (int i = 0; i < 9; ++i) d->rot0[b][i] = m->mv_rot0[b][i];
+        if (b > 0 && (m->mv_parent[b] < 0 || m->mv_parent[b] >= b)) { *err = "model: parent must precede child"; return DW_EINVAL; }
+    }
+    if (m->mv_parent[0] != -1) { *err = "model: body 0 must be the root"; return DW_EINVAL; }
+    int depth[NB];
+    depth[0] = 0;
+    for (int b = 1; b < NB; ++b) {
+        int p = m->mv_parent[b];
+        depth[b] = depth[p] + 1;
+        if (depth[b] >= MAX_LEVELS) { *err = "model: tree deeper than MAX_LEVELS"; return DW_EINVAL; }
+        if (d->nchild[p] >= MAX_CHILD) { *err = "model: more than MAX_CHILD children"; return DW_EINVAL; }
+        d->child[p][d->nchild[p]++] = b;
+        int L = depth[b];
+        if (d->level_count[L] >= MAX_PER_LEVEL) { *err = "model: level wider than MAX_PER_LEVEL"; return DW_EINVAL; }
+        d->level_body[L][d->level_count[L]++] = b;
+        if (L > d->nlevels) d->nlevels = L;
+    }
+    for (int j = 0; j < ND; ++j) { d->qlo[j] = m->dof_lower[j]; d->qhi[j] = m->dof_upper[j]; d->vmax[j] = m->dof_vmax[j]; }
+    for (int k = 0; k < DW_NUM_INERT; ++k) {
+        int b = m->inert_mv[k];
+        if (b < 0 || b >= NB || m->inert_gym[k] < 0 || m->inert_gym[k] >= DW_NUM_BODIES) { *err = "model: inertial index out of range"; return DW_EINVAL; }
+        if (d->ninert[b] >= MAX_BODY_INERT) { *err = "model: too many inertial records on one body"; return DW_EINVAL; }
+        d->inert_idx[b][d->ninert[b]++] = k;
+        d->inert_gym[k] = m->inert_gym[k];
+        d->inert_mass[k] = m->inert_mass[k];
+        for (int i = 0; i < 3; ++i) d->inert_com[k][i] = m->inert_com[k][i];
+        for (int i = 0; i < 6; ++i) d->inert_I[k][i] = m->inert_I[k][i];
+    }
+    if (m->inert_mv[0] != 0) { *err = "model: inertial record 0 must belong to the root"; return DW_EINVAL; }
+    if (m->num_geoms < 0 || m->num_geoms > 64) { *err = "model: num_geoms out of range (kernel maps one lane per primitive)"; return DW_EINVAL; }
+    d->ngeom = m->num_geoms;
+    for (int g = 0; g < m->num_geoms; ++g) {
+        d->geoms[g] = m->geoms[g];
+        int b = m->geoms[g].moving;
+        if (b < 0 || b >= NB || m->geoms[g].gym < 0 || m->geoms[g].gym >= DW_NUM_BODIES) { *err = "model: geom index out of range"; return DW_EINVAL; }
+        if (m->geoms[g].sole) continue;
+        if (d->body_ngeom[b] >= MAX_BODY_GEOMS) { *err = "model: too many primitives on one body"; return DW_EINVAL; }
+        d->body_geom[b][d->body_ngeom[b]++] = g;
+    }
+    for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
+        d->foot_mv[k] = m->foot_mv[k];
+        d->foot_gym[k] = m->foot_gym[k];
+        for (int i = 0; i < 3; ++i) d->foot_pos[k][i] = m->foot_pos[k][i];
+    }
+    d->foot_body[0] = m->foot_mv[0];
+    d->foot_body[1] = m->foot_mv[4];
+    // the contact pipeline walks each leg as the chain 6f+1 .. 6f+6 hanging off the root
+    for (int f = 0; f < 2; ++f) {
+        if (d->foot_body[f] != 6 * f + 6) { *err = "model: sole bodies must be moving bodies 6 and 12"; return DW_EINVAL; }
+        for (int k = 0; k < 4; ++k) if (m->foot_mv[4 * f + k] != d->foot_body[f]) { *err = "model: sole corners must be grouped 4+4"; return DW_EINVAL; }
+        for (int i = 1; i <= 6; ++i) if (m->mv_parent[6 * f + i] != (i == 1 ? 0 : 6 * f + i - 1)) { *err = "model: legs must be serial chains off the root"; return DW_EINVAL; }
+    }
+    d->left_foot_gym = m->left_foot_gym;
+    d->right_foot_gym = m->right_foot_gym;
+    if (t) {
+        for (int j = 0; j < ND; ++j) {
+            d->kp[j] = t->kp[j]; d->kv[j] = t->kv[j]; d->action_high[j] = t->action_high[j];
+            d->q_init[j] = t->initial_dof_pos[j];
+            d->arm_nom[j] = t->dof_armature_nominal[j]; d->damp_nom[j] = t->dof_damping_nominal[j];
+        }
+        for (int i = 0; i < DW_NUM_OBS1; ++i) {
+            d->obs_mean[i] = t->obs_mean[i];
+            // torch: sqrt(obs_var + 1e-8*ones)  (reference: tasks/dyros_dynamic_walk.py:777); host sqrtf is
+            // correctly rounded, as is the device's
+            float v = t->obs_var[i] + 1e-8f * 1.0f;
+            d->obs_inv_std_den[i] = __builtin_sqrtf(v);
+        }
+        d->has_task = 1;
+    }
+    return DW_OK;
+}
+
+}  // namespace dw

@@ -1,0 +1,154 @@
+// dw_hip.hip -- gfx950 kernels and the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so).
+//
+// One workgroup = one wavefront = one environment.  The kernel bodies live in dw_task.h / dw_physics.h as
+// wave regions over a 16.8 KB LDS block per env (9 envs resident per CU by LDS); this file only declares
+// the __global__ entry points, owns the read-only model/mocap tables in device memory and validates
+// arguments.  Nothing here allocates, synchronises or copies per call (graph-capture safe).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dw_params.h"
+
+struct DwHandle {
+    DwConfig        cfg;
+    dw::TaskParams  params;
+    dw::DevModel   *d_model;
+    float          *d_mocap;
+    DwBuffers       buf;
+    int             bound;
+    int             has_task;
+    int             device;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+static int fail_hip(const char *what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return DW_EHIP;
+}
+
+// 256 VGPRs = 2 waves per SIMD; LDS (16.8 KB/env) admits 9 envs per CU, so registers and LDS agree on 8 waves/CU
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_k_step(const dw::DevModel *M, dw::TaskParams C, dw::TaskBuffers T) {
+    __shared__ dw::Lds S;
+    dw::Wave w;
+    dw::step_env(w, S, *M, C, T, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, dw::TaskParams C, DwBuffers B,
+                                                    const float *tau, const float *push) {
+    __shared__ dw::Lds S;
+    dw::Wave w;
+    dw::simulate_env(w, S, *M, C, B, tau, push, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, dw::TaskParams C, dw::TaskBuffers T,
+                                                 const int32_t *ids, int n, int *bad) {
+    __shared__ dw::Lds S;
+    dw::Wave w;
+    const int e = ids[blockIdx.x];
+    if (e < 0 || e >= C.num_envs) {            // wave-uniform: the whole workgroup leaves
+        if (threadIdx.x == 0 && bad) atomicAdd(bad, 1);
+        return;
+    }
+    dw::reset_only_env(w, S, *M, C, T, e);
+}
+
+extern "C" {
+
+int dw_abi_version(void) { return DW_ABI_VERSION; }
+const char *dw_last_error(void) { return g_err; }
+void dw_default_config(DwConfig *c) { if (c) dw::default_config(c); }
+
+int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task, DwHandle **out) {
+    if (!cfg || !model || !out) return fail(DW_EINVAL, "dw_create: null argument");
+    if (const char *m = dw::check_config(cfg)) return fail(DW_EINVAL, m);
+    if (task && (!task->kp || !task->kv || !task->action_high || !task->initial_dof_pos || !task->mocap ||
+                 !task->obs_mean || !task->obs_var || !task->dof_armature_nominal || !task->dof_damping_nominal))
+        return fail(DW_EINVAL, "dw_create: task constants incomplete");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(DW_EHIP, "dw_create: no HIP device visible (this library has no CPU path)");
+    DwHandle *h = (DwHandle *)calloc(1, sizeof(DwHandle));
+    if (!h) return fail(DW_ENOMEM, "dw_create: out of host memory");
+    h->cfg = *cfg;
+    h->params = dw::make_task_params(cfg);
+    dw::DevModel *hm = (dw::DevModel *)malloc(sizeof(dw::DevModel));
+    if (!hm) { free(h); return fail(DW_ENOMEM, "dw_create: out of host memory"); }
+    const char *err = "";
+    int rc = dw::build_devmodel(model, task, hm, &err);
+    if (rc) { free(hm); free(h); return fail(rc, err); }
+    (void)hipGetDevice(&h->device);
+    e = hipMalloc((void **)&h->d_model, sizeof(dw::DevModel));
+    if (e == hipSuccess) e = hipMemcpy(h->d_model, hm, sizeof(dw::DevModel), hipMemcpyHostToDevice);
+    free(hm);
+    if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
+    if (task) {
+        const size_t bytes = sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS;
+        e = hipMalloc((void **)&h->d_mocap, bytes);
+        if (e == hipSuccess) e = hipMemcpy(h->d_mocap, task->mocap, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: mocap upload", e); }
+        h->has_task = 1;
+    }
+    *out = h;
+    return DW_OK;
+}
+
+int dw_destroy(DwHandle *h) {
+    if (!h) return fail(DW_EINVAL, "dw_destroy: null handle");
+    if (h->d_model) (void)hipFree(h->d_model);
+    if (h->d_mocap) (void)hipFree(h->d_mocap);
+    free(h);
+    return DW_OK;
+}
+
+int dw_bind(DwHandle *h, const DwBuffers *b) {
+    if (!h || !b) return fail(DW_EINVAL, "dw_bind: null argument");
+    if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
+    h->buf = *b;
+    h->bound = 1;
+    return DW_OK;
+}
+
+int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *stream) {
+    if (!h || !h->bound) return fail(DW_ESTATE, "dw_simulate: buffers not bound");
+    if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
+    if (h->cfg.debug_freeze_physics) return DW_OK;
+    hipLaunchKernelGGL(dw_k_simulate, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->params,
+                       h->buf, tau, push_xy);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip("dw_simulate: launch", e);
+    return DW_OK;
+}
+
+int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream) {
+    if (!h || !h->bound || !h->has_task) return fail(DW_ESTATE, "dw_step: handle has no task constants or no buffers bound");
+    if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
+    if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
+    if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
+    dw::TaskBuffers T;
+    T.b = h->buf; T.actions = actions; T.noise = noise; T.mocap = h->d_mocap; T.step = step_index;
+    hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->params, T);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip("dw_step: launch", e);
+    return DW_OK;
+}
+
+int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise, int64_t step_index, void *stream) {
+    if (!h || !h->bound || !h->has_task) return fail(DW_ESTATE, "dw_reset_idx: handle has no task constants or no buffers bound");
+    if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
+    if (n < 0 || (n > 0 && !env_ids)) return fail(DW_EINVAL, "dw_reset_idx: bad env id list");
+    if (n == 0) return DW_OK;
+    dw::TaskBuffers T;
+    T.b = h->buf; T.actions = nullptr; T.noise = noise; T.mocap = h->d_mocap; T.step = step_index;
+    hipLaunchKernelGGL(dw_k_reset, dim3(n), dim3(64), 0, (hipStream_t)stream, h->d_model, h->params, T, env_ids, n,
+                       (int *)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip("dw_reset_idx: launch", e);
+    return DW_OK;
+}
+
+int dw_lds_bytes(void) { return (int)sizeof(dw::Lds); }
+
+}  // extern "C"

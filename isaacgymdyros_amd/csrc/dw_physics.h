@@ -1,0 +1,782 @@
+// dw_physics.h -- one physics substep (the stand-in for the reference's closed `gym.simulate`,
+// reference call site tasks/dyros_dynamic_walk.py:525) as wave regions over the env's LDS block.
+//
+// Algorithm = DESIGN.md "Physics model": floating-base Featherstone ABA (armature + implicit joint
+// damping on the diagonal), penalty ground forces for non-sole primitives, velocity-level projected
+// Gauss-Seidel on the 8 sole corners over a Delassus matrix assembled from 12 unit-wrench responses of
+// the two foot bodies, impulse propagation through the tree, semi-implicit Euler.
+//
+// Lane maps: lane = body / dof / primitive for the flat phases; (body-in-level, matrix row) = (lane/6,
+// lane%6) for the inward articulated-inertia sweep; lane = Delassus column for the 12 response sweeps;
+// lane = constraint row for the 24-row Gauss-Seidel.
+#pragma once
+
+#include <math.h>
+
+#include "dw_devmodel.h"
+#include "dw_wave.h"
+
+namespace dw {
+
+struct PhysParams {          // wave-uniform scalars (kernel arguments)
+    float dt;
+    float g[3];
+    int   iters;
+    float contact_offset, max_depen, erp, cfm;
+    float pen_k, pen_c;
+    float max_ang_vel;
+    int   vel_at_com;
+};
+
+struct Lds {
+    // ---- state and inputs of the substep ----
+    float root[13];
+    float q[ND], qd[ND], tau[ND], arm[ND], damp[ND];
+    float mscale[DW_NUM_BODIES];
+    float mu;
+    float push[2];
+    float warm[24];
+    float contact[DW_NUM_BODIES * 3];
+    // ---- kinematics ----
+    float quat[4], ww[3], vow[3];
+    float R[NB][9];       // body -> parent
+    float Rw[NB][9];      // body -> world
+    float pw[NB][3];
+    float v[NB][6];       // body-frame spatial velocity
+    float pA[NB][6];
+    float U[NB][6], Dinv[NB], u[NB];
+    float qdd[ND], qdf[ND], dqd[ND];
+    float wwf[3], vowf[3], dv0[6];
+    float Minv[36];
+    float gF[64][3], gr[64][3];
+    union {
+        struct {          // inward sweep
+            float IA[NB][36];
+            float T[MAX_PER_LEVEL][36];
+            float pa[MAX_PER_LEVEL][6];
+        } in;
+        struct {          // everything after the base solve
+            float a[NB][6];
+            float du[NB];
+            float dpf[2][6];
+            float W[12][12];
+            float A[24][24];
+            float vel[2][24], P[2][24];
+            float rk[8][3], phi[8], vmin[8];
+            int   active[8];
+            int   any_active;
+            float twf[2][6];
+        } out;
+    };
+    // ---- task state (dw_task.h) ----
+    float es[DW_ES_WORDS];
+    float act[DW_NUM_ACT];
+    float normed[DW_NUM_OBS1];
+    float rterm[16];
+    float scratch[40];
+    int   flags[8];
+};
+
+// ------------------------------------------------------------------------------------------------
+// small math on plain float arrays (registers or LDS)
+// ------------------------------------------------------------------------------------------------
+DW_HD void cross3(const float *a, const float *b, float *o) {
+    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+DW_HD float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DW_HD void m3v(const float *M, const float *v, float *o) {
+    float x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    float y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    float z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+DW_HD void m3tv(const float *M, const float *v, float *o) {
+    float x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+    float y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+    float z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+DW_HD void m3m(const float *X, const float *Y, float *O) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) O[3 * r + c] = X[3 * r] * Y[c] + X[3 * r + 1] * Y[3 + c] + X[3 * r + 2] * Y[6 + c];
+}
+DW_HD void quat_to_mat(const float *q, float *R) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+// motion transform parent -> body:  w_b = R' w_p ; v_b = R' (v_p + w_p x p)
+DW_HD void xform_motion(const float *R, const float *p, const float *vp, float *vb) {
+    float t[3], l[3];
+    m3tv(R, vp, vb);
+    cross3(vp, p, t);
+    l[0] = vp[3] + t[0]; l[1] = vp[4] + t[1]; l[2] = vp[5] + t[2];
+    m3tv(R, l, vb + 3);
+}
+// force transform body -> parent: f_p = R f_b ; n_p = R n_b + p x f_p
+DW_HD void xform_force(const float *R, const float *p, const float *fb, float *fp) {
+    float n[3], f[3], t[3];
+    m3v(R, fb, n);
+    m3v(R, fb + 3, f);
+    cross3(p, f, t);
+    fp[0] = n[0] + t[0]; fp[1] = n[1] + t[1]; fp[2] = n[2] + t[2];
+    fp[3] = f[0]; fp[4] = f[1]; fp[5] = f[2];
+}
+// PR = skew(p) * R   (the lower-left block of the force transform; (-E P)_kc = PR[3c+k])
+DW_HD void make_PR(const float *R, const float *p, float *PR) {
+    for (int c = 0; c < 3; ++c) {
+        float col[3] = {R[c], R[3 + c], R[6 + c]}, o[3];
+        cross3(p, col, o);
+        PR[c] = o[0]; PR[3 + c] = o[1]; PR[6 + c] = o[2];
+    }
+}
+// bias acceleration of a hinge: c = v x (S qd)
+DW_HD void joint_bias(const float *v, const float *s, float qd, float *c) {
+    float sq[3] = {s[0] * qd, s[1] * qd, s[2] * qd};
+    cross3(v, sq, c);
+    cross3(v + 3, sq, c + 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the substep.  In: S.root, q, qd, tau, arm, damp, mscale, mu, push, warm.  Out: root, q, qd, warm, contact.
+// ------------------------------------------------------------------------------------------------
+template <class W>
+DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysParams &P) {
+    const float dt = P.dt;
+
+    // ---- K1: base state, joint rotations, clear contact accumulators ----
+    wave.par([&](int l) {
+        for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = 0.0f;
+        if (l == 0) {
+            float qx = S.root[3], qy = S.root[4], qz = S.root[5], qw = S.root[6];
+            float n = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+            float qn[4] = {qx / n, qy / n, qz / n, qw / n};
+            for (int i = 0; i < 4; ++i) S.quat[i] = qn[i];
+            float Rw[9];
+            quat_to_mat(qn, Rw);
+            for (int i = 0; i < 9; ++i) { S.Rw[0][i] = Rw[i]; S.R[0][i] = Rw[i]; }
+            for (int i = 0; i < 3; ++i) S.pw[0][i] = S.root[i];
+            float ww[3] = {S.root[10], S.root[11], S.root[12]};
+            float vo[3] = {S.root[7], S.root[8], S.root[9]};
+            if (P.vel_at_com) {
+                float rc[3], t[3];
+                m3v(Rw, M.inert_com[0], rc);
+                cross3(ww, rc, t);
+                vo[0] -= t[0]; vo[1] -= t[1]; vo[2] -= t[2];
+            }
+            for (int i = 0; i < 3; ++i) { S.ww[i] = ww[i]; S.vow[i] = vo[i]; }
+            float vb[6];
+            m3tv(Rw, ww, vb);
+            m3tv(Rw, vo, vb + 3);
+            for (int i = 0; i < 6; ++i) S.v[0][i] = vb[i];
+        } else if (l < NB) {
+            const int b = l;
+            const float *s = M.axis[b];
+            float q = S.q[b - 1];
+            float sn = sinf(q), cs = cosf(q), oc = 1.0f - cs;
+            float Rj[9] = {cs + oc * s[0] * s[0], oc * s[0] * s[1] - sn * s[2], oc * s[0] * s[2] + sn * s[1],
+                           oc * s[1] * s[0] + sn * s[2], cs + oc * s[1] * s[1], oc * s[1] * s[2] - sn * s[0],
+                           oc * s[2] * s[0] - sn * s[1], oc * s[2] * s[1] + sn * s[0], cs + oc * s[2] * s[2]};
+            float R[9];
+            m3m(M.rot0[b], Rj, R);
+            for (int i = 0; i < 9; ++i) S.R[b][i] = R[i];
+        }
+    });
+
+    // ---- K2: forward kinematics and velocities, level by level ----
+    for (int L = 1; L <= M.nlevels; ++L) {
+        wave.par([&](int l) {
+            if (l < M.level_count[L]) {
+                const int b = M.level_body[L][l], p = M.parent[b];
+                float R[9], Rp[9], Rw[9], t[3], vp[6], vb[6];
+                for (int i = 0; i < 9; ++i) { R[i] = S.R[b][i]; Rp[i] = S.Rw[p][i]; }
+                m3m(Rp, R, Rw);
+                for (int i = 0; i < 9; ++i) S.Rw[b][i] = Rw[i];
+                m3v(Rp, M.pos[b], t);
+                for (int i = 0; i < 3; ++i) S.pw[b][i] = S.pw[p][i] + t[i];
+                for (int i = 0; i < 6; ++i) vp[i] = S.v[p][i];
+                xform_motion(R, M.pos[b], vp, vb);
+                float qd = S.qd[b - 1];
+                vb[0] += M.axis[b][0] * qd; vb[1] += M.axis[b][1] * qd; vb[2] += M.axis[b][2] * qd;
+                for (int i = 0; i < 6; ++i) S.v[b][i] = vb[i];
+            }
+        });
+    }
+
+    // ---- K3: rigid-body inertias, gyroscopic bias; K4: penalty contact of the non-sole primitives ----
+    wave.par([&](int l) {
+        if (l < NB) {
+            const int b = l;
+            float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, h[3] = {0, 0, 0}, mass = 0.0f;
+            for (int k = 0; k < M.ninert[b]; ++k) {
+                const int r = M.inert_idx[b][k];
+                const float ms = S.mscale[M.inert_gym[r]];
+                const float mk = ms * M.inert_mass[r];
+                const float *cm = M.inert_com[r], *I6 = M.inert_I[r];
+                const float cc = dot3(cm, cm);
+                const float Ic[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+                for (int r3 = 0; r3 < 3; ++r3)
+                    for (int c3 = 0; c3 < 3; ++c3)
+                        A[3 * r3 + c3] += ms * Ic[3 * r3 + c3] + mk * ((r3 == c3 ? cc : 0.0f) - cm[r3] * cm[c3]);
+                h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
+                mass += mk;
+            }
+            // 6x6 = [[A, H],[H', m 1]] with H = skew(h)
+            float *I = S.in.IA[b];
+            const float H[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
+            for (int r3 = 0; r3 < 3; ++r3)
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    I[6 * r3 + c3] = A[3 * r3 + c3];
+                    I[6 * r3 + 3 + c3] = H[3 * r3 + c3];
+                    I[6 * (r3 + 3) + c3] = H[3 * c3 + r3];
+                    I[6 * (r3 + 3) + 3 + c3] = (r3 == c3) ? mass : 0.0f;
+                }
+            // pA = v x* (I v)
+            float om[3] = {S.v[b][0], S.v[b][1], S.v[b][2]}, vl[3] = {S.v[b][3], S.v[b][4], S.v[b][5]};
+            float n[3], f[3], t1[3], t2[3];
+            m3v(A, om, n); cross3(h, vl, t1);
+            n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
+            cross3(om, h, t1);                       // H' w = -h x w = w x h
+            f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
+            cross3(om, n, t1); cross3(vl, f, t2);
+            S.pA[b][0] = t1[0] + t2[0]; S.pA[b][1] = t1[1] + t2[1]; S.pA[b][2] = t1[2] + t2[2];
+            cross3(om, f, t1);
+            S.pA[b][3] = t1[0]; S.pA[b][4] = t1[1]; S.pA[b][5] = t1[2];
+        }
+    });
+    wave.par([&](int l) {
+        float F[3] = {0, 0, 0}, rl[3] = {0, 0, 0};
+        if (l < M.ngeom && !M.geoms[l].sole) {
+            const DwGeom &ge = M.geoms[l];
+            const int b = ge.moving;
+            float Rw[9];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[b][i];
+            float zmin;
+            if (ge.type == 0) {
+                zmin = 1e30f;
+                for (int ci = 0; ci < 8; ++ci) {
+                    float e[3] = {(ci & 1 ? 1.0f : -1.0f) * ge.size[0], (ci & 2 ? 1.0f : -1.0f) * ge.size[1],
+                                  (ci & 4 ? 1.0f : -1.0f) * ge.size[2]};
+                    float lc[3], wv[3];
+                    m3v(ge.rot, e, lc);
+                    lc[0] += ge.pos[0]; lc[1] += ge.pos[1]; lc[2] += ge.pos[2];
+                    m3v(Rw, lc, wv);
+                    float z = S.pw[b][2] + wv[2];
+                    if (z < zmin) { zmin = z; rl[0] = lc[0]; rl[1] = lc[1]; rl[2] = lc[2]; }
+                }
+            } else {
+                float al[3] = {ge.rot[2], ge.rot[5], ge.rot[8]}, aw[3];
+                m3v(Rw, al, aw);
+                float sgn = aw[2] >= 0 ? -1.0f : 1.0f;
+                float dw3[3] = {-aw[2] * aw[0], -aw[2] * aw[1], 1.0f - aw[2] * aw[2]};
+                float dn = sqrtf(dot3(dw3, dw3));
+                float off[3] = {0, 0, 0};
+                if (dn > 1e-6f) {
+                    float k = -ge.size[0] / dn;
+                    float ow[3] = {k * dw3[0], k * dw3[1], k * dw3[2]};
+                    m3tv(Rw, ow, off);
+                }
+                for (int i = 0; i < 3; ++i) rl[i] = ge.pos[i] + sgn * ge.size[1] * al[i] + off[i];
+                float wv[3];
+                m3v(Rw, rl, wv);
+                zmin = S.pw[b][2] + wv[2];
+            }
+            if (zmin < 0) {
+                float vb[6], t[3], vl[3], vw[3];
+                for (int i = 0; i < 6; ++i) vb[i] = S.v[b][i];
+                cross3(vb, rl, t);
+                vl[0] = vb[3] + t[0]; vl[1] = vb[4] + t[1]; vl[2] = vb[5] + t[2];
+                m3v(Rw, vl, vw);
+                float fn = P.pen_k * (-zmin) - P.pen_c * vw[2];
+                if (fn < 0) fn = 0;
+                float sp = sqrtf(vw[0] * vw[0] + vw[1] * vw[1]);
+                F[2] = fn;
+                if (sp > 1e-9f) {
+                    float ft = P.pen_c * sp, lim = S.mu * fn;
+                    if (ft > lim) ft = lim;
+                    F[0] = -ft * vw[0] / sp; F[1] = -ft * vw[1] / sp;
+                }
+            }
+        }
+        for (int i = 0; i < 3; ++i) { S.gF[l][i] = F[i]; S.gr[l][i] = rl[i]; }
+    });
+    // K5: external forces into the bias of their bodies; per-body net contact force
+    wave.par([&](int l) {
+        if (l < NB) {
+            const int b = l;
+            float Rw[9];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[b][i];
+            float dn[3] = {0, 0, 0}, df[3] = {0, 0, 0};
+            for (int k = 0; k < M.body_ngeom[b]; ++k) {
+                const int g = M.body_geom[b][k];
+                float F[3] = {S.gF[g][0], S.gF[g][1], S.gF[g][2]};
+                if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                    float rl[3] = {S.gr[g][0], S.gr[g][1], S.gr[g][2]}, fb[3], nb[3];
+                    m3tv(Rw, F, fb);
+                    cross3(rl, fb, nb);
+                    for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
+                    const int gy = M.geoms[g].gym;
+                    for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
+                }
+            }
+            if (b == 0) {
+                float Fw[3] = {S.push[0], S.push[1], 0.0f}, fb[3], nb[3];
+                m3tv(Rw, Fw, fb);
+                cross3(M.inert_com[0], fb, nb);
+                for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
+            }
+            for (int i = 0; i < 3; ++i) { S.pA[b][i] -= dn[i]; S.pA[b][3 + i] -= df[i]; }
+        }
+    });
+
+    // ---- A2: inward sweep of articulated inertias ----
+    for (int L = M.nlevels; L >= 1; --L) {
+        const int cnt = M.level_count[L];
+        // A: projection through the joint, rows of Ia*X
+        wave.par([&](int l) {
+            const int k = l / 6, r = l % 6;
+            if (k < cnt) {
+                const int b = M.level_body[L][k];
+                const float *s = M.axis[b];
+                const float *IA = S.in.IA[b];
+                float U[6];
+                for (int j = 0; j < 6; ++j) U[j] = IA[6 * j] * s[0] + IA[6 * j + 1] * s[1] + IA[6 * j + 2] * s[2];
+                const float damp = S.damp[b - 1], qd = S.qd[b - 1];
+                const float D = dot3(s, U) + S.arm[b - 1] + dt * damp;
+                const float Dinv = 1.0f / D;
+                const float u = S.tau[b - 1] - damp * qd - (s[0] * S.pA[b][0] + s[1] * S.pA[b][1] + s[2] * S.pA[b][2]);
+                float vb[6], cb[6];
+                for (int i = 0; i < 6; ++i) vb[i] = S.v[b][i];
+                joint_bias(vb, s, qd, cb);
+                float Ia[6];
+                const float ur = U[r] * Dinv;
+                for (int c = 0; c < 6; ++c) Ia[c] = IA[6 * r + c] - ur * U[c];
+                float pa = S.pA[b][r] + U[r] * (u * Dinv);
+                for (int c = 0; c < 6; ++c) pa += Ia[c] * cb[c];
+                S.in.pa[k][r] = pa;
+                float R[9], PR[9];
+                for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
+                make_PR(R, M.pos[b], PR);
+                for (int c = 0; c < 3; ++c) {
+                    S.in.T[k][6 * r + c] = Ia[0] * R[3 * c] + Ia[1] * R[3 * c + 1] + Ia[2] * R[3 * c + 2] +
+                                           Ia[3] * PR[3 * c] + Ia[4] * PR[3 * c + 1] + Ia[5] * PR[3 * c + 2];
+                    S.in.T[k][6 * r + 3 + c] = Ia[3] * R[3 * c] + Ia[4] * R[3 * c + 1] + Ia[5] * R[3 * c + 2];
+                }
+                if (r == 0) {
+                    for (int j = 0; j < 6; ++j) S.U[b][j] = U[j];
+                    S.Dinv[b] = Dinv;
+                    S.u[b] = u;
+                }
+            }
+        });
+        // B: X' (Ia X) and X' pa, written over the child's own storage (now "contribution to the parent")
+        wave.par([&](int l) {
+            const int k = l / 6, r = l % 6;
+            if (k < cnt) {
+                const int b = M.level_body[L][k];
+                float R[9], PR[9];
+                for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
+                make_PR(R, M.pos[b], PR);
+                const float *T = S.in.T[k];
+                const float *pa = S.in.pa[k];
+                float out[6], po;
+                if (r < 3) {
+                    for (int c = 0; c < 6; ++c)
+                        out[c] = R[3 * r] * T[c] + R[3 * r + 1] * T[6 + c] + R[3 * r + 2] * T[12 + c] +
+                                 PR[3 * r] * T[18 + c] + PR[3 * r + 1] * T[24 + c] + PR[3 * r + 2] * T[30 + c];
+                    po = R[3 * r] * pa[0] + R[3 * r + 1] * pa[1] + R[3 * r + 2] * pa[2] +
+                         PR[3 * r] * pa[3] + PR[3 * r + 1] * pa[4] + PR[3 * r + 2] * pa[5];
+                } else {
+                    const int q = r - 3;
+                    for (int c = 0; c < 6; ++c) out[c] = R[3 * q] * T[18 + c] + R[3 * q + 1] * T[24 + c] + R[3 * q + 2] * T[30 + c];
+                    po = R[3 * q] * pa[3] + R[3 * q + 1] * pa[4] + R[3 * q + 2] * pa[5];
+                }
+                for (int c = 0; c < 6; ++c) S.in.IA[b][6 * r + c] = out[c];
+                S.pA[b][r] = po;
+            }
+        });
+        // C: parents (one level up) gather their children, fixed order
+        const int pcnt = (L == 1) ? 1 : M.level_count[L - 1];
+        wave.par([&](int l) {
+            const int k = l / 6, r = l % 6;
+            if (k < pcnt) {
+                const int p = (L == 1) ? 0 : M.level_body[L - 1][k];
+                float acc[6], pacc = S.pA[p][r];
+                for (int c = 0; c < 6; ++c) acc[c] = S.in.IA[p][6 * r + c];
+                for (int ci = 0; ci < M.nchild[p]; ++ci) {
+                    const int ch = M.child[p][ci];
+                    for (int c = 0; c < 6; ++c) acc[c] += S.in.IA[ch][6 * r + c];
+                    pacc += S.pA[ch][r];
+                }
+                for (int c = 0; c < 6; ++c) S.in.IA[p][6 * r + c] = acc[c];
+                S.pA[p][r] = pacc;
+            }
+        });
+    }
+
+    // ---- A3: inverse of the base articulated inertia (6 lanes, one column each, Cholesky) ----
+    wave.par([&](int l) {
+        if (l < 6) {
+            float Lc[36];
+            const float *Mx = S.in.IA[0];
+            for (int i = 0; i < 36; ++i) Lc[i] = 0.0f;
+            for (int j = 0; j < 6; ++j) {
+                float d = Mx[6 * j + j];
+                for (int k = 0; k < j; ++k) d -= Lc[6 * j + k] * Lc[6 * j + k];
+                d = sqrtf(d);
+                Lc[6 * j + j] = d;
+                for (int i = j + 1; i < 6; ++i) {
+                    float s = Mx[6 * i + j];
+                    for (int k = 0; k < j; ++k) s -= Lc[6 * i + k] * Lc[6 * j + k];
+                    Lc[6 * i + j] = s / d;
+                }
+            }
+            float y[6], x[6];
+            for (int i = 0; i < 6; ++i) {
+                float s = (i == l) ? 1.0f : 0.0f;
+                for (int k = 0; k < i; ++k) s -= Lc[6 * i + k] * y[k];
+                y[i] = s / Lc[6 * i + i];
+            }
+            for (int i = 5; i >= 0; --i) {
+                float s = y[i];
+                for (int k = i + 1; k < 6; ++k) s -= Lc[6 * k + i] * x[k];
+                x[i] = s / Lc[6 * i + i];
+            }
+            for (int i = 0; i < 6; ++i) S.Minv[6 * i + l] = x[i];
+        }
+    });
+    // from here on S.in is dead and S.out is live
+    wave.par([&](int l) {
+        if (l < 6) {
+            float acc = 0.0f;
+            for (int c = 0; c < 6; ++c) acc -= S.Minv[6 * l + c] * S.pA[0][c];
+            S.out.a[0][l] = acc;
+        }
+        if (l >= 8 && l < 8 + NB) S.out.du[l - 8] = 0.0f;
+    });
+
+    // ---- A4: outward sweep of accelerations ----
+    for (int L = 1; L <= M.nlevels; ++L) {
+        wave.par([&](int l) {
+            if (l < M.level_count[L]) {
+                const int b = M.level_body[L][l], p = M.parent[b];
+                const float *s = M.axis[b];
+                float R[9], apar[6], ap[6], vb[6], cb[6];
+                for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
+                for (int i = 0; i < 6; ++i) { apar[i] = S.out.a[p][i]; vb[i] = S.v[b][i]; }
+                xform_motion(R, M.pos[b], apar, ap);
+                joint_bias(vb, s, S.qd[b - 1], cb);
+                float ua = 0.0f;
+                for (int i = 0; i < 6; ++i) { ap[i] += cb[i]; ua += S.U[b][i] * ap[i]; }
+                const float qdd = (S.u[b] - ua) * S.Dinv[b];
+                S.qdd[b - 1] = qdd;
+                ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
+                for (int i = 0; i < 6; ++i) S.out.a[b][i] = ap[i];
+            }
+        });
+    }
+
+    // ---- V1: unconstrained velocities; sole-corner gaps ----
+    wave.par([&](int l) {
+        if (l < ND) S.qdf[l] = S.qd[l] + dt * S.qdd[l];
+        if (l == 40) {
+            float Rw[9], a0[6], vb0[6], t[3], t2[3], al[3];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[0][i];
+            for (int i = 0; i < 6; ++i) { a0[i] = S.out.a[0][i]; vb0[i] = S.v[0][i]; }
+            m3v(Rw, a0, t);
+            for (int i = 0; i < 3; ++i) S.wwf[i] = S.ww[i] + dt * t[i];
+            cross3(vb0, vb0 + 3, t2);
+            al[0] = a0[3] + t2[0]; al[1] = a0[4] + t2[1]; al[2] = a0[5] + t2[2];
+            m3v(Rw, al, t);
+            for (int i = 0; i < 3; ++i) S.vowf[i] = S.vow[i] + dt * (t[i] + P.g[i]);
+        }
+        if (l >= 48 && l < 48 + DW_NUM_FOOT_PTS) {
+            const int k = l - 48, b = M.foot_mv[k];
+            float r[3];
+            m3v(S.Rw[b], M.foot_pos[k], r);
+            const float phi = S.pw[b][2] + r[2];
+            const int act = phi < P.contact_offset;
+            for (int i = 0; i < 3; ++i) S.out.rk[k][i] = r[i];
+            S.out.phi[k] = phi;
+            S.out.active[k] = act;
+            S.out.vmin[k] = phi >= 0 ? -phi / dt : fminf(P.erp * (-phi) / dt, P.max_depen);
+        }
+        if (l < 6) S.dv0[l] = 0.0f;
+        if (l < ND) S.dqd[l] = 0.0f;
+    });
+    wave.par([&](int l) {
+        if (l == 0) {
+            int any = 0;
+            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) any |= S.out.active[k];
+            S.out.any_active = any;
+        }
+        if (l < 24) S.out.P[0][l] = S.out.active[l / 3] ? S.warm[l] : 0.0f;
+    });
+
+    if (uniform(S.out.any_active)) {
+        // ---- C1: free twists of the two foot bodies (velocity FK down each leg), world aligned ----
+        wave.par([&](int l) {
+            if (l < 2) {
+                float Rw0[9], vcur[6];
+                for (int i = 0; i < 9; ++i) Rw0[i] = S.Rw[0][i];
+                m3tv(Rw0, S.wwf, vcur);
+                m3tv(Rw0, S.vowf, vcur + 3);
+                for (int i = 1; i <= 6; ++i) {
+                    const int b = 6 * l + i;
+                    float R[9], vn[6];
+                    for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
+                    xform_motion(R, M.pos[b], vcur, vn);
+                    const float qd = S.qdf[b - 1];
+                    vn[0] += M.axis[b][0] * qd; vn[1] += M.axis[b][1] * qd; vn[2] += M.axis[b][2] * qd;
+                    for (int j = 0; j < 6; ++j) vcur[j] = vn[j];
+                }
+                const int fb = 6 * l + 6;
+                float o[3];
+                m3v(S.Rw[fb], vcur, o);
+                for (int i = 0; i < 3; ++i) S.out.twf[l][i] = o[i];
+                m3v(S.Rw[fb], vcur + 3, o);
+                for (int i = 0; i < 3; ++i) S.out.twf[l][3 + i] = o[i];
+            }
+        });
+        // ---- C2: 12 unit-wrench responses -> inverse operational inertia W of the two feet ----
+        wave.par([&](int l) {
+            if (l < 12) {
+                const int f = l / 6, comp = l % 6;
+                const int fb = 6 * f + 6;
+                float ew[3] = {0, 0, 0}, eb[3];
+                ew[comp % 3] = 1.0f;
+                m3tv(S.Rw[fb], ew, eb);
+                float dp[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 3; ++i) dp[(comp < 3 ? 0 : 3) + i] = -eb[i];
+                float du[6];
+                for (int i = 6; i >= 1; --i) {
+                    const int b = 6 * f + i;
+                    const float *s = M.axis[b];
+                    const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
+                    du[i - 1] = d;
+                    const float k = d * S.Dinv[b];
+                    float pa[6], R[9], up[6];
+                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * k;
+                    for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
+                    xform_force(R, M.pos[b], pa, up);
+                    for (int j = 0; j < 6; ++j) dp[j] = up[j];
+                }
+                float dv0[6];
+                for (int r = 0; r < 6; ++r) {
+                    float acc = 0.0f;
+                    for (int c = 0; c < 6; ++c) acc -= S.Minv[6 * r + c] * dp[c];
+                    dv0[r] = acc;
+                }
+                for (int g = 0; g < 2; ++g) {
+                    float dv[6];
+                    for (int j = 0; j < 6; ++j) dv[j] = dv0[j];
+                    for (int i = 1; i <= 6; ++i) {
+                        const int b = 6 * g + i;
+                        const float *s = M.axis[b];
+                        float R[9], ap[6];
+                        for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
+                        xform_motion(R, M.pos[b], dv, ap);
+                        float ua = 0.0f;
+                        for (int j = 0; j < 6; ++j) ua += S.U[b][j] * ap[j];
+                        const float qdd = ((g == f ? du[i - 1] : 0.0f) - ua) * S.Dinv[b];
+                        ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
+                        for (int j = 0; j < 6; ++j) dv[j] = ap[j];
+                    }
+                    const int gb = 6 * g + 6;
+                    float o[3];
+                    m3v(S.Rw[gb], dv, o);
+                    for (int i = 0; i < 3; ++i) S.out.W[6 * g + i][l] = o[i];
+                    m3v(S.Rw[gb], dv + 3, o);
+                    for (int i = 0; i < 3; ++i) S.out.W[6 * g + 3 + i][l] = o[i];
+                }
+            }
+        });
+        // ---- C3: Delassus matrix A = J W J', free constraint velocities, warm start ----
+        wave.par([&](int l) {
+            if (l < 24) {
+                const int k = l / 3, ax = l % 3, f = k / 4;
+                const float r[3] = {S.out.rk[k][0], S.out.rk[k][1], S.out.rk[k][2]};
+                // row of J on foot f: angular part = -skew(r)[ax][:] , linear part = e_ax
+                float ja[3];
+                ja[0] = ax == 1 ? -r[2] : (ax == 2 ? r[1] : 0.0f);
+                ja[1] = ax == 0 ? r[2] : (ax == 2 ? -r[0] : 0.0f);
+                ja[2] = ax == 0 ? -r[1] : (ax == 1 ? r[0] : 0.0f);
+                float JW[12];
+                for (int c = 0; c < 12; ++c)
+                    JW[c] = ja[0] * S.out.W[6 * f][c] + ja[1] * S.out.W[6 * f + 1][c] + ja[2] * S.out.W[6 * f + 2][c] +
+                            S.out.W[6 * f + 3 + ax][c];
+                for (int k2 = 0; k2 < DW_NUM_FOOT_PTS; ++k2) {
+                    const int f2 = k2 / 4;
+                    const float r2[3] = {S.out.rk[k2][0], S.out.rk[k2][1], S.out.rk[k2][2]};
+                    const float *w = JW + 6 * f2;
+                    // column (k2, ax2): sum_j JW[6 f2 + j] * (-skew(r2)[ax2][j]) + JW[6 f2 + 3 + ax2]
+                    S.out.A[l][3 * k2 + 0] = w[1] * r2[2] - w[2] * r2[1] + w[3];
+                    S.out.A[l][3 * k2 + 1] = -w[0] * r2[2] + w[2] * r2[0] + w[4];
+                    S.out.A[l][3 * k2 + 2] = w[0] * r2[1] - w[1] * r2[0] + w[5];
+                }
+                const float *tw = S.out.twf[f];
+                float t[3];
+                cross3(tw, r, t);
+                S.out.vel[1][l] = tw[3 + ax] + t[ax];
+            }
+        });
+        wave.par([&](int l) {
+            if (l < 24) {
+                float acc = S.out.vel[1][l];
+                for (int c = 0; c < 24; ++c) acc += S.out.A[l][c] * S.out.P[0][c];
+                S.out.vel[0][l] = acc;
+            }
+        });
+        // ---- C4: projected Gauss-Seidel.  One region per contact update; constraint velocities and
+        //      impulses ping-pong between two LDS copies so no lane reads what another lane writes. ----
+        int cur = 0;
+        for (int it = 0; it < P.iters; ++it) {
+            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
+                if (!uniform(S.out.active[k])) continue;
+                wave.par([&](int l) {
+                    if (l < 24) {
+                        const float *vel = S.out.vel[cur], *Pc = S.out.P[cur];
+                        const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
+                        const float reg = 1.0f + P.cfm;
+                        const float Pz = Pc[rz], Px = Pc[rx], Py = Pc[ry];
+                        float dz = -(vel[rz] - S.out.vmin[k]) / (S.out.A[rz][rz] * reg);
+                        float pz = Pz + dz;
+                        if (pz < 0) pz = 0;
+                        dz = pz - Pz;
+                        const float vx = vel[rx] + S.out.A[rx][rz] * dz;
+                        const float dx = -vx / (S.out.A[rx][rx] * reg);
+                        const float vy = vel[ry] + S.out.A[ry][rz] * dz + S.out.A[ry][rx] * dx;
+                        const float dy = -vy / (S.out.A[ry][ry] * reg);
+                        float px = Px + dx, py = Py + dy;
+                        const float lim = S.mu * pz, nrm = sqrtf(px * px + py * py);
+                        if (nrm > lim) {
+                            const float sc = nrm > 0 ? lim / nrm : 0.0f;
+                            px *= sc; py *= sc;
+                        }
+                        const float Dx = px - Px, Dy = py - Py;
+                        S.out.vel[cur ^ 1][l] = vel[l] + S.out.A[l][rz] * dz + S.out.A[l][rx] * Dx + S.out.A[l][ry] * Dy;
+                        S.out.P[cur ^ 1][l] = l == rx ? px : (l == ry ? py : (l == rz ? pz : Pc[l]));
+                    }
+                });
+                cur ^= 1;
+            }
+        }
+        // ---- C5: impulses -> wrenches on the two foot bodies -> delta-ABA over the whole tree ----
+        wave.par([&](int l) {
+            if (l < 2) {
+                const float *Pc = S.out.P[cur];
+                float F[3] = {0, 0, 0}, Nm[3] = {0, 0, 0};
+                for (int k = 4 * l; k < 4 * l + 4; ++k) {
+                    float t[3];
+                    cross3(S.out.rk[k], Pc + 3 * k, t);
+                    for (int i = 0; i < 3; ++i) { F[i] += Pc[3 * k + i]; Nm[i] += t[i]; }
+                }
+                const int fb = 6 * l + 6;
+                float dp[6], fbv[3], nbv[3];
+                m3tv(S.Rw[fb], F, fbv);
+                m3tv(S.Rw[fb], Nm, nbv);
+                for (int i = 0; i < 3; ++i) { dp[i] = -nbv[i]; dp[3 + i] = -fbv[i]; }
+                for (int i = 6; i >= 1; --i) {
+                    const int b = 6 * l + i;
+                    const float *s = M.axis[b];
+                    const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
+                    S.out.du[b] = d;
+                    const float kk = d * S.Dinv[b];
+                    float pa[6], R[9], up[6];
+                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * kk;
+                    for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
+                    xform_force(R, M.pos[b], pa, up);
+                    for (int j = 0; j < 6; ++j) dp[j] = up[j];
+                }
+                for (int j = 0; j < 6; ++j) S.out.dpf[l][j] = dp[j];
+                const int gy = M.foot_gym[4 * l];
+                for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i] / dt;
+            }
+            if (l >= 32 && l < 32 + 24) S.warm[l - 32] = S.out.P[cur][l - 32];
+        });
+        wave.par([&](int l) {
+            if (l < 6) {
+                float acc = 0.0f;
+                for (int c = 0; c < 6; ++c) acc -= S.Minv[6 * l + c] * (S.out.dpf[0][c] + S.out.dpf[1][c]);
+                S.out.a[0][l] = acc;
+                S.dv0[l] = acc;
+            }
+        });
+        for (int L = 1; L <= M.nlevels; ++L) {
+            wave.par([&](int l) {
+                if (l < M.level_count[L]) {
+                    const int b = M.level_body[L][l], p = M.parent[b];
+                    const float *s = M.axis[b];
+                    float R[9], apar[6], ap[6];
+                    for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
+                    for (int i = 0; i < 6; ++i) apar[i] = S.out.a[p][i];
+                    xform_motion(R, M.pos[b], apar, ap);
+                    float ua = 0.0f;
+                    for (int i = 0; i < 6; ++i) ua += S.U[b][i] * ap[i];
+                    const float dq = (S.out.du[b] - ua) * S.Dinv[b];
+                    S.dqd[b - 1] = dq;
+                    ap[0] += s[0] * dq; ap[1] += s[1] * dq; ap[2] += s[2] * dq;
+                    for (int i = 0; i < 6; ++i) S.out.a[b][i] = ap[i];
+                }
+            });
+        }
+    } else {
+        wave.par([&](int l) {
+            if (l < 24) S.warm[l] = 0.0f;
+        });
+    }
+
+    // ---- V2: final velocities, clamps, semi-implicit Euler ----
+    wave.par([&](int l) {
+        if (l < ND) {
+            float qd = S.qdf[l] + S.dqd[l];
+            const float vm = M.vmax[l];
+            if (qd > vm) qd = vm;
+            if (qd < -vm) qd = -vm;
+            float q = S.q[l] + dt * qd;
+            if (q < M.qlo[l]) { q = M.qlo[l]; if (qd < 0) qd = 0; }
+            if (q > M.qhi[l]) { q = M.qhi[l]; if (qd > 0) qd = 0; }
+            S.q[l] = q;
+            S.qd[l] = qd;
+        }
+        if (l == 40) {
+            float Rw[9], wwn[3], von[3], t[3];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[0][i];
+            m3v(Rw, S.dv0, t);
+            for (int i = 0; i < 3; ++i) wwn[i] = S.wwf[i] + t[i];
+            m3v(Rw, S.dv0 + 3, t);
+            for (int i = 0; i < 3; ++i) von[i] = S.vowf[i] + t[i];
+            const float wn = sqrtf(dot3(wwn, wwn));
+            if (wn > P.max_ang_vel) {
+                const float sc = P.max_ang_vel / wn;
+                wwn[0] *= sc; wwn[1] *= sc; wwn[2] *= sc;
+            }
+            for (int i = 0; i < 3; ++i) S.root[i] += dt * von[i];
+            const float wmag = sqrtf(dot3(wwn, wwn));
+            const float th = wmag * dt;
+            float dq[4] = {0, 0, 0, 1};
+            if (th > 1e-12f) {
+                const float sh = sinf(th * 0.5f) / wmag;
+                dq[0] = wwn[0] * sh; dq[1] = wwn[1] * sh; dq[2] = wwn[2] * sh; dq[3] = cosf(th * 0.5f);
+            }
+            const float x1 = dq[0], y1 = dq[1], z1 = dq[2], w1 = dq[3];
+            const float x2 = S.quat[0], y2 = S.quat[1], z2 = S.quat[2], w2 = S.quat[3];
+            float qn[4] = {w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                           w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2};
+            const float n = sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+            for (int i = 0; i < 4; ++i) { qn[i] /= n; S.root[3 + i] = qn[i]; }
+            if (P.vel_at_com) {
+                float Rn[9], rc[3], tt[3];
+                quat_to_mat(qn, Rn);
+                m3v(Rn, M.inert_com[0], rc);
+                cross3(wwn, rc, tt);
+                for (int i = 0; i < 3; ++i) von[i] += tt[i];
+            }
+            for (int i = 0; i < 3; ++i) { S.root[7 + i] = von[i]; S.root[10 + i] = wwn[i]; }
+        }
+    });
+}
+
+}  // namespace dw

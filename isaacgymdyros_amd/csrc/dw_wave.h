@@ -1,0 +1,38 @@
+// dw_wave.h -- execution-model shim of the DyrosDynamicWalk kernels.
+//
+// The kernels are written for ONE WAVEFRONT (64 lanes) PER ENVIRONMENT: every phase of the step is a
+// "region" executed by all 64 lanes, regions exchange data only through the env's LDS block, and a
+// workgroup is exactly one wave so the barrier between regions costs one s_barrier and an LDS drain.
+// `Wave::par(f)` runs f(lane) for the calling lane and ends the region.  `uniform(x)` turns a value
+// every lane read from the same LDS word into a scalar-register value so that loops and branches that
+// contain regions are provably wave-uniform.
+//
+// The second definition below is NOT a product path: it lets the identical kernel source be compiled
+// by g++ into a lane-loop emulation (tests/emul/), so indexing and synchronisation mistakes are found
+// by the CPU test-suite (and by ASan/UBSan on the host) instead of by a GPU fault that can take a
+// whole node down.  The shipped library (libdyroswalk_hip.so) is built by hipcc from the first one only.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DW_HD __device__ __forceinline__
+namespace dw {
+struct Wave {
+    template <class F> DW_HD void par(F &&f) const {
+        f((int)threadIdx.x);
+        __syncthreads();
+    }
+};
+DW_HD int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+}  // namespace dw
+#else
+#define DW_HD static inline
+namespace dw {
+struct Wave {
+    template <class F> void par(F &&f) const {
+        for (int lane = 0; lane < 64; ++lane) f(lane);
+    }
+};
+static inline int uniform(int x) { return x; }
+}  // namespace dw
+#endif

@@ -359,17 +359,22 @@ static void reward_env(DwHandle *h, int e, int *reset_out) {
     *reset_out = reset;
 }
 
-static void accumulate_gate(DwHandle *h, int64_t step, int64_t sum_epi, int64_t sum_crm) {
+/* gate_acc layout: [slot 0..2][bucket = env % 32][2], latch at DW_GATE_LATCH (include/dyros_walk.h) */
+static void gate_contribution(DwHandle *h, int64_t step, int e, float el, float cm) {
     int64_t *acc = h->buf.gate_acc;
-    int cur = (int)(step % 3), nxt = (int)((step + 1) % 3);
-    acc[2 * cur] += sum_epi;
-    acc[2 * cur + 1] += sum_crm;
-    acc[2 * nxt] = 0;
-    acc[2 * nxt + 1] = 0;
+    const int cur = (int)(step % 3), nxt = (int)((step + 1) % 3), bk = e % DW_GATE_BUCKETS;
+    int64_t de, dc = 0;
+    if (isfinite(el) && isfinite(cm)) { de = (int64_t)el; dc = (int64_t)llrintf(cm * 4294967296.0f); }
+    else de = -((int64_t)1 << 62);
+#pragma omp atomic
+    acc[(cur * DW_GATE_BUCKETS + bk) * 2] += de;
+#pragma omp atomic
+    acc[(cur * DW_GATE_BUCKETS + bk) * 2 + 1] += dc;
+    acc[(nxt * DW_GATE_BUCKETS + bk) * 2] = 0;
+    acc[(nxt * DW_GATE_BUCKETS + bk) * 2 + 1] = 0;
 }
 
-static void step_env(DwHandle *h, int e, const float *actions, const float *noise, int64_t step,
-                     int gate_open, int64_t *g_epi, int64_t *g_crm) {
+static void step_env(DwHandle *h, int e, const float *actions, const float *noise, int64_t step, int gate_open) {
     const DwConfig *cfg = &h->cfg;
     const DwBuffers *b = &h->buf;
     float *es = ES(h, e);
@@ -505,15 +510,7 @@ static void step_env(DwHandle *h, int e, const float *actions, const float *nois
     }
     for (int i = 0; i < DW_NUM_ACT; ++i) es[DW_ES_ACTIONS_PRE + i] = es[DW_ES_ACTIONS + i];
     /* statistics for the next step's perturbation gate */
-    {
-        float el = es[DW_ES_EPI_LEN_LOG], cm = es[DW_ES_CRM];
-        if (isfinite(el) && isfinite(cm)) {
-            *g_epi += (int64_t)el;
-            *g_crm += (int64_t)llrintf(cm * 4294967296.0f);
-        } else {
-            *g_epi -= ((int64_t)1 << 62);
-        }
-    }
+    if (cfg->perturb && !cfg->force_perturb_start) gate_contribution(h, step, e, es[DW_ES_EPI_LEN_LOG], es[DW_ES_CRM]);
 }
 
 /* perturbation gate (tasks/dyros_dynamic_walk.py:489): population means of the previous step */
@@ -522,11 +519,16 @@ static int gate_is_open(const DwHandle *h, int64_t step) {
     if (cfg->force_perturb_start) return 1;
     if (!cfg->perturb) return 0;
     const int64_t *acc = h->buf.gate_acc;
-    if (acc[6]) return 1;
+    if (acc[DW_GATE_LATCH]) return 1;
     int prev = (int)((step + 2) % 3);
+    int64_t se = 0, sc = 0;
+    for (int k = 0; k < DW_GATE_BUCKETS; ++k) {
+        se += acc[(prev * DW_GATE_BUCKETS + k) * 2];
+        sc += acc[(prev * DW_GATE_BUCKETS + k) * 2 + 1];
+    }
     double n = (double)cfg->num_envs;
-    double mean_epi = (double)acc[2 * prev] / n;
-    double mean_crm = (double)acc[2 * prev + 1] / 4294967296.0 / n;
+    double mean_epi = (double)se / n;
+    double mean_crm = (double)sc / 4294967296.0 / n;
     return mean_epi > (double)(cfg->max_episode_length - 2000.0f) && mean_crm > 0.165;
 }
 
@@ -543,11 +545,9 @@ int dwo_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     if (!actions) return dwo_fail(DW_EINVAL, "dwo_step: actions is null");
     const int N = h->cfg.num_envs;
     int open = gate_is_open(h, step_index);
-    if (open) h->buf.gate_acc[6] = 1;
-    int64_t s_epi = 0, s_crm = 0;
-#pragma omp parallel for schedule(static) reduction(+ : s_epi, s_crm)
-    for (int e = 0; e < N; ++e) step_env(h, e, actions, noise, step_index, open, &s_epi, &s_crm);
-    accumulate_gate(h, step_index, s_epi, s_crm);
+    if (open && !h->cfg.force_perturb_start) h->buf.gate_acc[DW_GATE_LATCH] = 1;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < N; ++e) step_env(h, e, actions, noise, step_index, open);
     return DW_OK;
 }
 

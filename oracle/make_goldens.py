@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Mint tests/golden/*.npz from the reference's own Python.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the container where /root/reference is mounted.  The reference's DyrosDynamicWalk class is
+imported from where it lies (oracle/ref_harness.py) and driven over a fake gym; what is committed is DATA:
+inputs (initial state, per-step actions, the injected-noise record rebuilt from the reference's recorded
+RNG draws, per-step injected physics state) and the reference's outputs.
+
+  task_logic_frozen.npz   `gym.simulate` is a no-op and a fresh random physics state is written before every
+                          step, so everything recorded is the reference's torch task logic and nothing else:
+                          mocap target, action/torque/delay pipeline, push perturbation, encoder model,
+                          termination, the 14-term reward, reset_idx, the 487-d observation with history.
+  whole_step_oracle.npz   the same class stepping over the ORACLE's physics (the closed PhysX engine cannot
+                          be run: physics parity is unpinned).  Pins the orchestration
+                          (call order, substep loop, late updates) of dw_step; the HIP library is held to it
+                          within the float tolerance stated in tests/.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from isaacgymdyros_amd import abi                                    # noqa: E402
+from isaacgymdyros_amd.task_constants import load_task_constants     # noqa: E402
+from oracle import parity as P                                       # noqa: E402
+from oracle import ref_harness as RH                                 # noqa: E402
+from oracle.oracle import OracleSim                                  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+PER_STEP = ["obs_buf", "rew_buf", "reset_buf", "progress_buf", "timeout_buf", "stacked_rewards",
+            "root_states", "dof_state", "qpos_noise", "qvel_noise", "target_data_qpos", "target_data_force",
+            "action_torque", "time", "epi_len", "mocap_data_idx", "pert_on", "perturbation_count", "magnitude",
+            "phase", "contact_reward_sum", "contact_reward_mean", "delay_idx", "simul_len", "motor_constant_scale",
+            "qpos_bias", "quat_bias", "target_vel", "init_mocap_data_idx", "perturb_timing", "epi_len_log"]
+FINAL = ["obs_history", "action_history", "action_log", "actions_pre", "pre_joint_velocity_states",
+         "foot_force_pre", "action_torque_pre", "qpos_pre", "contact_forces"]
+
+
+def random_state(rng, N, tc, model):
+    root = np.zeros((N, 13), np.float32)
+    root[:, 0:2] = rng.normal(size=(N, 2)) * 3
+    root[:, 2] = 0.93 + rng.normal(size=N) * 0.02
+    ang = rng.uniform(0, 0.7, size=N) * (rng.uniform(size=N) < 0.5)
+    ang[rng.uniform(size=N) < 0.15] = 0
+    axis = rng.normal(size=(N, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    root[:, 3:6] = axis * np.sin(ang / 2)[:, None]
+    root[:, 6] = np.cos(ang / 2)
+    root[:, 7:13] = rng.normal(size=(N, 6)) * 0.5
+    dof = np.zeros((N, 33, 2), np.float32)
+    dof[:, :, 0] = tc["initial_dof_pos"] + rng.normal(size=(N, 33)) * 0.1
+    dof[:, :, 1] = rng.normal(size=(N, 33)) * 1.0
+    cf = np.zeros((N, 38, 3), np.float32)
+    for foot in (model.left_foot_idx, model.right_foot_idx):
+        on = rng.uniform(size=N) < 0.7
+        cf[:, foot, 2] = on * rng.uniform(0, 1600, size=N)
+        cf[:, foot, 0:2] = on[:, None] * rng.normal(size=(N, 2)) * 50
+    hit = rng.uniform(size=N) < 0.08
+    body = rng.integers(0, 38, size=N)
+    for e in range(N):
+        if hit[e] and body[e] not in (model.left_foot_idx, model.right_foot_idx):
+            cf[e, body[e]] = rng.normal(size=3) * 3
+    return root, dof, cf
+
+
+def run(kind: str, N: int, steps: int, seed: int):
+    tc = load_task_constants()
+    frozen = kind == "frozen"
+    A = OracleSim(N, task_const=tc, debug_freeze_physics=int(frozen))
+    env, fake, mods = RH.make_reference_env(A, N, seed=seed)
+    env.randomize = False     # the numpy-RNG domain randomisation at resets cannot be replayed through U[0,1) words
+    env.reset()
+    B = OracleSim(N, task_const=tc, randomize_dof_on_reset=0, debug_freeze_physics=int(frozen))
+    for k in ("mass_scale", "dof_damping", "dof_armature"):
+        B.buf[k][:] = A.buf[k]
+    if frozen:
+        env.perturb_timing[:] = torch.randint(0, 6, (N,))
+        env.progress_buf[0] = 7990
+        env.progress_buf[1] = 7996
+    P.sync_from_reference(env, B.buf)
+    init = {k: v.copy() for k, v in B.buf.items()}
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    rec_steps = {k: [] for k in PER_STEP}
+    actions_all, noise_all, inj = [], [], {"root": [], "dof": [], "cf": []}
+    force_at = 3 if frozen else 10
+    for t in range(steps):
+        a = torch.rand(N, 13, generator=g) * 2.4 - 1.2       # some outside +-1: exercises the clamp
+        if t == force_at:
+            env.perturb_start[:, 0] = True
+        if frozen:
+            root, dof, cf = random_state(rng, N, tc, A.model)
+            env.root_states[:] = torch.from_numpy(root)
+            env.dof_state.view(N, 33, 2)[:] = torch.from_numpy(dof)
+            env.contact_forces[:] = torch.from_numpy(cf)
+            inj["root"].append(root); inj["dof"].append(dof); inj["cf"].append(cf)
+        pert_ids = None
+        if bool(env.perturb_start[0, 0]):
+            pert_ids = torch.nonzero((env.epi_len % 2000.0) == env.perturb_timing).flatten().numpy()
+        with RH.RngRecorder() as rec:
+            o, r, d, ex = env.step(a.clone())
+        reset_ids = d.nonzero().flatten().numpy()
+        nz = P.noise_from_log(rec.log, N, pert_ids, reset_ids)
+        actions_all.append(a.numpy().copy())
+        noise_all.append(nz)
+        snap = P.snapshot_reference(env, ex)
+        for k in PER_STEP:
+            rec_steps[k].append(snap[k])
+    out = dict(N=N, steps=steps, force_perturb_step=force_at,
+               actions=np.stack(actions_all), noise=np.stack(noise_all))
+    for k, v in init.items():
+        out["init_" + k] = v
+    for k in PER_STEP:
+        out["step_" + k] = np.stack(rec_steps[k])
+    for k in FINAL:
+        out["final_" + k] = snap[k]
+    if frozen:
+        out["inj_root"] = np.stack(inj["root"]); out["inj_dof"] = np.stack(inj["dof"]); out["inj_cf"] = np.stack(inj["cf"])
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "task_logic_frozen.npz" if frozen else "whole_step_oracle.npz")
+    np.savez_compressed(path, **out)
+    nres = int(np.stack(rec_steps["reset_buf"]).sum())
+    npert = int(np.stack(rec_steps["pert_on"]).sum())
+    print(path, "%.1f KB" % (os.path.getsize(path) / 1024), "resets", nres, "pert_on env-steps", npert)
+
+
+if __name__ == "__main__":
+    warnings.filterwarnings("ignore")
+    if not RH.available():
+        sys.exit("reference checkout not present; goldens can only be minted where it is mounted")
+    run("frozen", N=24, steps=20, seed=11)
+    run("oracle", N=8, steps=120, seed=5)

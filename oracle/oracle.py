@@ -69,8 +69,9 @@ def alloc_buffers(num_envs: int):
 class OracleSim:
     """Owns numpy buffers in the DwBuffers layout and a dwo_ handle."""
 
-    def __init__(self, num_envs: int, task_const=None, double: bool = False, cfg: abi.DwConfig = None, **cfg_over):
-        self.lib, self.api = load(double)
+    def __init__(self, num_envs: int, task_const=None, double: bool = False, cfg: abi.DwConfig = None,
+                 lib_api=None, **cfg_over):
+        self.lib, self.api = lib_api if lib_api is not None else load(double)
         self.model = load_model()
         self.cfg = cfg if cfg is not None else default_config(num_envs, **cfg_over)
         self.cfg.num_envs = num_envs

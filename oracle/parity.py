@@ -55,9 +55,13 @@ def sync_from_reference(env, buf):
     buf["action_history"][:] = env.action_history.view(N, 20, 13).numpy()
     abi.es_view(es, "hist_head")[...] = 0
     buf["gate_acc"][:] = 0
-    buf["gate_acc"][4] = int(env.epi_len_log.sum().item())     # slot (step-1)%3 for step 0 is slot 2
-    buf["gate_acc"][5] = int(np.rint(env.contact_reward_mean.double().numpy() * 4294967296.0).sum())
-    buf["gate_acc"][6] = int(bool(env.perturb_start[0, 0]))
+    # slot (step-1)%3 for step 0 is slot 2; bucket = env % 32
+    el = env.epi_len_log.numpy().astype(np.int64)
+    cm = np.rint(env.contact_reward_mean.numpy().astype(np.float32) * np.float32(4294967296.0)).astype(np.int64)
+    for e in range(N):
+        buf["gate_acc"][(2 * K["DW_GATE_BUCKETS"] + e % K["DW_GATE_BUCKETS"]) * 2] += el[e]
+        buf["gate_acc"][(2 * K["DW_GATE_BUCKETS"] + e % K["DW_GATE_BUCKETS"]) * 2 + 1] += cm[e]
+    buf["gate_acc"][K["DW_GATE_LATCH"]] = int(bool(env.perturb_start[0, 0]))
 
 
 def logical_history(hist, head):

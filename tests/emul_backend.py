@@ -1,0 +1,44 @@
+"""Loads the host lane-loop emulation of the kernel body (tests/emul) behind the same driver as the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+from isaacgymdyros_amd import abi
+from oracle.oracle import OracleSim
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
+_cache = {}
+
+
+def load(asan=False):
+    name = "libdw_emul_asan.so" if asan else "libdw_emul.so"
+    if name not in _cache:
+        subprocess.check_call(["make", "-C", HERE, "-s", "_build/" + name])
+        lib = C.CDLL(os.path.join(HERE, "_build", name))
+        _cache[name] = (lib, abi.declare(lib, "dwe_"))
+    return _cache[name]
+
+
+class EmulSim(OracleSim):
+    def __init__(self, num_envs, task_const=None, **cfg_over):
+        super().__init__(num_envs, task_const=task_const, lib_api=load(), **cfg_over)
+
+
+class EmulBackend:
+    def __init__(self, N, task_const, **cfg):
+        self.sim = EmulSim(N, task_const=task_const, **cfg)
+
+    def load_buffers(self, bufs):
+        for k, v in bufs.items():
+            self.sim.buf[k][...] = v
+
+    def write_state(self, root, dof, cf):
+        self.sim.buf["root_states"][...] = root
+        self.sim.buf["dof_state"][...] = dof
+        self.sim.buf["contact_forces"][...] = cf
+
+    def step(self, a, nz, t):
+        self.sim.step(a, nz, t)
+
+    def read_buffers(self):
+        return self.sim.buf

@@ -1,0 +1,51 @@
+"""The shipped library exists in-tree and exports every entry point include/dyros_walk.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from isaacgymdyros_amd import abi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "dyros_walk.h")).read()
+    return sorted(set(re.findall(r"\b(dw_[a-z_]+)\s*\(", src)) - {"dw_set_dof_properties"})
+
+
+def test_header_and_python_mirror_agree():
+    assert set("dw_" + n for n in abi.EXPORTS) == set(declared_functions())
+    assert ctypes.sizeof(abi.DwBuffers) == 8 * len(abi.BUFFER_NAMES)
+    assert abi.K["DW_ES_WORDS"] % 4 == 0                      # record rows stay 16-byte aligned
+    offs = sorted((o, int(max(1, __import__("numpy").prod(s)))) for o, s, _ in abi.ES_FIELDS.values())
+    for (o1, n1), (o2, _) in zip(offs, offs[1:]):
+        assert o1 + n1 <= o2, "overlapping record fields"
+    assert offs[-1][0] + offs[-1][1] <= abi.K["DW_ES_WORDS"]
+
+
+def test_library_builds_and_exports_the_abi():
+    lib_path = build.build()
+    lib = ctypes.CDLL(lib_path)
+    for fn in declared_functions():
+        assert hasattr(lib, fn), fn
+    assert lib.dw_abi_version() == abi.K["DW_ABI_VERSION"]
+
+
+def test_product_refuses_cpu_device():
+    from isaacgymdyros_amd.config import default_cfg
+    from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+    with pytest.raises(ValueError):
+        DyrosDynamicWalk(default_cfg(4, "cpu"), "cpu", 0, True)
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """No file of the package imports or loads anything under oracle/ or tests/."""
+    pkg = os.path.join(ROOT, "isaacgymdyros_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libdw_oracle" not in txt, f
+                assert "libdw_emul" not in txt, f

@@ -1,0 +1,179 @@
+"""Parity tests proper: the HIP library (through the C-ABI) against the reference goldens and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import replay as R
+from oracle import parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_like(env, task_const):
+    from oracle.oracle import OracleSim
+    o = OracleSim(env.num_envs, task_const=task_const, cfg=env._ccfg)
+    for k, t in env._buf.items():
+        o.buf[k][...] = t.cpu().numpy()
+    return o
+
+
+def test_task_logic_vs_reference_goldens(task_const):
+    """Physics frozen: the reference's torch task logic replayed through the HIP kernels.  Integer/flag fields and
+    every float field without a transcendental are bit-identical to the reference's CPU torch run (torch_gpu_div=0
+    selects torch's CPU division semantics); exp/sin/cos/asin/atan2-derived fields within abs 2e-6 + rel 4e-6
+    (OCML vs SLEEF last-bit rounding)."""
+    from hip_backend import HipBackend
+    g = R.load("task_logic_frozen.npz")
+    be = HipBackend(int(g["N"]), randomize=False, debug_freeze_physics=True, torch_gpu_div=False)
+    for t, ref, got in R.replay(g, be):
+        exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
+        if "obs_history" in ref:
+            exact = exact + ["action_history", "action_log", "actions_pre", "pre_joint_velocity_states",
+                             "foot_force_pre", "action_torque_pre", "qpos_pre"]
+        bad = P.compare(ref, got, exact=exact, atol=R.TRANSCENDENTAL)
+        assert not bad, (t, bad)
+    assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
+
+
+def test_whole_step_vs_oracle_goldens(task_const):
+    """Stated float tolerance on q/qd after N steps (contacts active, random torques): after 10 policy steps
+    (20 substeps of 2 ms) |dq| <= 1e-4 rad, |dqd| <= 5e-3 rad/s, root pose <= 1e-4, reward <= 2e-3."""
+    from hip_backend import HipBackend
+    g = R.load("whole_step_oracle.npz")
+    be = HipBackend(int(g["N"]), randomize=False, torch_gpu_div=False)
+    for t, ref, got in R.replay(g, be):
+        if t >= 10:
+            break
+        dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
+        dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
+        assert dq < 1e-4 and dqd < 5e-3, (t, dq, dqd)
+        assert np.abs(ref["root_states"][:, :7] - got["root_states"][:, :7]).max() < 1e-4, t
+        assert np.abs(ref["rew_buf"] - got["rew_buf"]).max() < 2e-3, t
+        assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
+
+
+def test_physics_substep_vs_oracle(task_const):
+    """dw_simulate vs dwo_simulate, random in-flight states with randomised mass/damping/armature and a push:
+    |dq| <= 1e-4 rad after 100 contact-free substeps."""
+    from hip_backend import make_env
+    rng = np.random.default_rng(1)
+    N = 256
+    env = make_env(N)
+    b = env._buf
+    root = np.zeros((N, 13), np.float32)
+    root[:, 0:3] = rng.normal(size=(N, 3)) + np.array([0, 0, 3])
+    q = rng.normal(size=(N, 4))
+    root[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    root[:, 7:13] = rng.normal(size=(N, 6)) * 0.5
+    b["root_states"].copy_(torch.from_numpy(root))
+    b["dof_state"][..., 0] = torch.from_numpy(rng.uniform(-1, 1, size=(N, 33)).astype(np.float32)).cuda()
+    b["dof_state"][..., 1] = torch.from_numpy(rng.uniform(-1, 1, size=(N, 33)).astype(np.float32)).cuda()
+    ora = _oracle_like(env, task_const)
+    tau = rng.uniform(-50, 50, size=(N, 33)).astype(np.float32)
+    push = rng.uniform(-100, 100, size=(N, 2)).astype(np.float32)
+    tg, pg = torch.from_numpy(tau).cuda(), torch.from_numpy(push).cuda()
+    for _ in range(100):
+        env.simulate(tg, pg)
+        ora.simulate(tau, push)
+    torch.cuda.synchronize()
+    assert np.abs(b["dof_state"][..., 0].cpu().numpy() - ora.buf["dof_state"][:, :, 0]).max() < 1e-4
+    assert np.abs(b["root_states"].cpu().numpy() - ora.buf["root_states"]).max() < 1e-4
+
+
+def test_stance_contact_vs_oracle(task_const):
+    """Standing under full-strength PD: sole loads equal m*g within 2 % on both and agree with each other."""
+    from hip_backend import make_env
+    from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS, KP_RAW, KV_RAW
+    env = make_env(64, randomize=False)
+    env._buf["root_states"][:, 0:2] = 0
+    kp = torch.tensor(KP_RAW, device="cuda")
+    kv = torch.tensor(KV_RAW, device="cuda")
+    q0 = torch.tensor(INITIAL_DOF_POS, device="cuda")
+    fz = []
+    for i in range(600):
+        env.simulate(kp * (q0 - env.dof_pos) - kv * env.dof_vel)
+        if i >= 400:
+            cf = env.contact_forces
+            fz.append((cf[:, env.left_foot_idx, 2] + cf[:, env.right_foot_idx, 2]).mean().item())
+    mg = env.model.nominal_total_mass * 9.81
+    assert abs(np.mean(fz) - mg) < 0.02 * mg
+    nonfoot = env.contact_forces[:, env.non_feet_idxs, :]
+    assert float(nonfoot.abs().max()) == 0.0
+    assert 0.90 < float(env.root_states[:, 2].mean()) < 0.94
+
+
+def test_in_kernel_rng_matches_oracle_bitwise(task_const):
+    """Philox4x32-10 is integer work: with physics frozen and noise=None every uniform-derived field of the HIP
+    step equals the oracle's bit for bit (reset draws, DR of damping/armature/friction, vel noise draw)."""
+    from hip_backend import HipBackend
+    from replay import OracleBackend
+    g = R.load("task_logic_frozen.npz")
+    N = int(g["N"])
+    hb = HipBackend(N, randomize=True, debug_freeze_physics=True)
+    ob = OracleBackend(N, task_const, cfg=hb.env._ccfg)
+    init = {k[5:]: v for k, v in g.items() if k.startswith("init_")}
+    hb.load_buffers(init)
+    ob.load_buffers(init)
+    for t in range(8):
+        for be in (hb, ob):
+            be.write_state(g["inj_root"][t], g["inj_dof"][t], g["inj_cf"][t])
+            be.step(g["actions"][t], None, t)
+        a, b = P.snapshot_buffers(ob.read_buffers()), P.snapshot_buffers(hb.read_buffers())
+        exact = ["reset_buf", "progress_buf", "delay_idx", "init_mocap_data_idx", "perturb_timing", "motor_constant_scale",
+                 "target_vel", "mocap_data_idx", "action_torque", "target_data_qpos"]
+        bad = P.compare(a, b, exact=exact, atol={"qpos_bias": (1e-9, 1e-6), "obs_buf": (5e-6, 1e-5), "rew_buf": (2e-6, 4e-6)})
+        assert not bad, (t, bad)
+        for k in ("dof_damping", "dof_armature", "friction_scale"):
+            assert np.array_equal(ob.read_buffers()[k], hb.read_buffers()[k]), k
+
+
+@pytest.mark.parametrize("N", [4096, 16384])
+def test_full_size_properties(N):
+    """BASELINE sizes: size-independent properties of a 60-step random-action rollout with resets, DR and pushes."""
+    from hip_backend import make_env
+    env = make_env(N, force_perturb_start=True)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(42)
+    resets = 0
+    hist = []
+    for t in range(60):
+        a = torch.rand(N, 13, generator=g, device="cuda") * 2 - 1
+        obs, rew, done, extras = env.step(a)
+        resets += int(done.sum())
+        hist.append(obs["obs"][:, 333:370].clone())
+        if t >= 2:
+            # obs_buf slot 8 at step t is slot 9 (the newest) at step t-2 unless the env was reset in between
+            keep = (env.epi_len >= 3)
+            assert torch.equal(obs["obs"][keep, 296:333], hist[t - 2][keep])
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+    assert resets > 0, "random actions must make some robots fall"
+    qn = env.root_states[:, 3:7].norm(dim=1)
+    assert float((qn - 1).abs().max()) < 1e-5
+    assert float(rew.max()) <= 2.0 and float(rew.min()) >= -0.25
+    assert int(env.nan_resets.sum()) == 0
+    assert float(env.dof_vel.abs().max()) <= 4.03 + 1e-6
+    assert extras["stacked_rewards"].shape == (N, 15) and len(extras["reward_names"]) == 15
+    assert int(extras["time_outs"].sum()) == 0
+    # reward decomposition: total == sum of the 14 terms where the episode did not end on this step
+    alive = done == 0
+    assert torch.allclose(extras["stacked_rewards"][alive, :14].sum(1), rew[alive], atol=1e-5)
+
+
+def test_determinism_and_reset_done():
+    from hip_backend import make_env
+    outs = []
+    for _ in range(2):
+        env = make_env(512)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for t in range(30):
+            obs, rew, done, _ = env.step(torch.rand(512, 13, generator=g, device="cuda") * 2 - 1)
+        outs.append((obs["obs"].clone(), rew.clone(), env.root_states.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    env.reset_buf[:] = 0
+    env.reset_buf[5] = 1
+    od, ids = env.reset_done()
+    torch.cuda.synchronize()
+    assert ids.tolist() == [5]
+    assert float(env.root_states[5, 2]) == pytest.approx(0.93)
+    assert int(env.progress_buf[5]) == 0 and float(env.epi_len[5]) == 0.0

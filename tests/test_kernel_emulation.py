@@ -1,0 +1,86 @@
+"""The HIP kernel body, compiled by g++ as a 64-lane loop (tests/emul), against the goldens and the oracle.
+Catches indexing / region-structure mistakes on the CPU; the GPU tests (-m gpu) repeat these through the
+real library."""
+import numpy as np
+import pytest
+
+import replay as R
+from emul_backend import EmulBackend, EmulSim
+from oracle import parity as P
+from oracle.oracle import OracleSim
+
+
+def test_task_logic_bitwise_vs_reference_goldens(task_const):
+    g = R.load("task_logic_frozen.npz")
+    be = EmulBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
+    for t, ref, got in R.replay(g, be):
+        exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
+        if "obs_history" in ref:
+            exact = exact + ["action_history", "action_log", "actions_pre", "pre_joint_velocity_states",
+                             "foot_force_pre", "action_torque_pre", "qpos_pre"]
+        bad = P.compare(ref, got, exact=exact, atol=R.TRANSCENDENTAL)
+        assert not bad, (t, bad)
+    assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
+
+
+def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const):
+    """Same libm on both sides here, so with physics frozen the kernel body and the oracle agree on every bit,
+    in-kernel Philox noise included (noise = None)."""
+    g = R.load("task_logic_frozen.npz")
+    N = int(g["N"])
+    from replay import OracleBackend
+    a = OracleBackend(N, task_const, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
+    b = EmulBackend(N, task_const, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
+    init = {k[5:]: v for k, v in g.items() if k.startswith("init_")}
+    a.load_buffers(init)
+    b.load_buffers(init)
+    for t in range(int(g["steps"])):
+        for be in (a, b):
+            be.write_state(g["inj_root"][t], g["inj_dof"][t], g["inj_cf"][t])
+            be.sim.step(g["actions"][t], None, t)
+        sa, sb = P.snapshot_buffers(a.read_buffers()), P.snapshot_buffers(b.read_buffers())
+        bad = P.compare(sa, sb, exact=list(sa.keys()))
+        assert not bad, (t, bad)
+        for k in ("dof_damping", "dof_armature", "friction_scale", "randomize_buf", "gate_acc"):
+            assert np.array_equal(a.read_buffers()[k], b.read_buffers()[k]), k
+
+
+def test_whole_step_tracks_oracle_goldens(task_const):
+    """Physics differs from the oracle only in summation order (Cholesky solve vs explicit inverse, fused
+    Gauss-Seidel update).  Stated tolerance, contacts active, random torques: after 10 policy steps (20 substeps)
+    |dq| <= 1e-4 rad, |dqd| <= 5e-3 rad/s, root pose <= 1e-4; the trajectories then separate chaotically, so
+    beyond that only a sanity bound and the reset pattern are held."""
+    g = R.load("whole_step_oracle.npz")
+    be = EmulBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, torch_gpu_div=0)
+    for t, ref, got in R.replay(g, be):
+        dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
+        dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
+        if t < 10:
+            assert dq < 1e-4 and dqd < 5e-3, (t, dq, dqd)
+            assert np.abs(ref["root_states"][:, :7] - got["root_states"][:, :7]).max() < 1e-4, t
+            assert np.abs(ref["rew_buf"] - got["rew_buf"]).max() < 2e-3, t
+        assert dq < 5e-2, (t, dq)
+        assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
+
+
+def test_physics_substep_vs_oracle_random_flight():
+    rng = np.random.default_rng(1)
+    N = 16
+    A, B = OracleSim(N), EmulSim(N)
+    A.buf["root_states"][:, 0:3] = rng.normal(size=(N, 3)) + np.array([0, 0, 3])
+    q = rng.normal(size=(N, 4))
+    A.buf["root_states"][:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    A.buf["root_states"][:, 7:13] = rng.normal(size=(N, 6)) * 0.5
+    A.buf["dof_state"][:, :, 0] = rng.uniform(-1, 1, size=(N, 33))
+    A.buf["dof_state"][:, :, 1] = rng.uniform(-1, 1, size=(N, 33))
+    A.buf["mass_scale"][:] = rng.uniform(0.8, 1.2, size=(N, 38))
+    A.buf["dof_damping"][:] = 0.1 + rng.uniform(0, 2.9, size=(N, 33))
+    for k in ("root_states", "dof_state", "mass_scale", "dof_damping", "dof_armature"):
+        B.buf[k][:] = A.buf[k]
+    tau = rng.uniform(-50, 50, size=(N, 33)).astype(np.float32)
+    push = rng.uniform(-100, 100, size=(N, 2)).astype(np.float32)
+    for i in range(100):
+        A.simulate(tau, push)
+        B.simulate(tau, push)
+    assert np.abs(A.buf["dof_state"][:, :, 0] - B.buf["dof_state"][:, :, 0]).max() < 1e-4
+    assert np.abs(A.buf["root_states"] - B.buf["root_states"]).max() < 1e-4
