@@ -210,8 +210,11 @@ typedef struct DwConfig {
 #define DW_ES_PERT_START    340   /* i: */
 #define DW_ES_HIST_HEAD     341   /* i: ring position of the OLDEST history slot */
 #define DW_ES_NAN_RESETS    342   /* i: count of resets forced by a non-finite state */
+#define DW_ES_EPI_RETURN    343   /* sum of rew_buf over the running episode (logging; a2c_common_dyros.py:661-687 keeps it in torch) */
 #define DW_ES_WARM          344   /* [8][3] contact impulses of the previous substep (warm start) */
-#define DW_ES_WORDS         368
+#define DW_ES_LAST_RETURN   368   /* return of the last finished episode */
+#define DW_ES_EPISODES      369   /* i: finished episodes */
+#define DW_ES_WORDS         372
 
 /* Device buffers (caller-owned).  Shapes in [] with N = num_envs; float32 unless noted. */
 typedef struct DwBuffers {

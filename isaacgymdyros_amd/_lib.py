@@ -22,6 +22,14 @@ def load():
             raise DyrosWalkLibraryError(
                 "%s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU or PyTorch fallback." % LIB_PATH)
+        # One HIP runtime per process: torch ships its own libamdhip64 and owns the device memory and streams this
+        # library is handed, so torch's copy must be the one already mapped when libdyroswalk_hip.so resolves its
+        # DT_NEEDED entry (same SONAME -> the loader reuses it).  Loading in the other order maps a second runtime
+        # that sees no device.
+        import torch
+        tlib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tlib):
+            C.CDLL(tlib, mode=C.RTLD_GLOBAL)
         lib = C.CDLL(LIB_PATH)
         try:
             api = abi.declare(lib, "dw_")

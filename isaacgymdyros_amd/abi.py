@@ -172,6 +172,9 @@ ES_FIELDS = {
     "hist_head": (K["DW_ES_HIST_HEAD"], (), "i"),
     "nan_resets": (K["DW_ES_NAN_RESETS"], (), "i"),
     "warm_impulses": (K["DW_ES_WARM"], (8, 3), "f"),
+    "episode_return": (K["DW_ES_EPI_RETURN"], (), "f"),
+    "last_episode_return": (K["DW_ES_LAST_RETURN"], (), "f"),
+    "episodes_finished": (K["DW_ES_EPISODES"], (), "i"),
 }
 
 

@@ -28,7 +28,22 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
     int   vel_at_com;
 };
 
+// The kinematic tree, staged once per launch into the env's LDS block: every sweep region indexes these by lane
+// or by level, and a dependent chain of global loads (level -> body -> parent -> offset/axis) per region is what
+// the first profile of this kernel was made of.
+struct LdsTree {
+    int   parent[NB];
+    int   nchild[NB];
+    int   child[NB][MAX_CHILD];
+    int   level_count[MAX_LEVELS];
+    int   level_body[MAX_LEVELS][MAX_PER_LEVEL];
+    int   nlevels;
+    float pos[NB][3];
+    float axis[NB][3];
+};
+
 struct Lds {
+    LdsTree tree;
     // ---- state and inputs of the substep ----
     float root[13];
     float q[ND], qd[ND], tau[ND], arm[ND], damp[ND];
@@ -142,6 +157,22 @@ DW_HD void joint_bias(const float *v, const float *s, float qd, float *c) {
 // ------------------------------------------------------------------------------------------------
 // the substep.  In: S.root, q, qd, tau, arm, damp, mscale, mu, push, warm.  Out: root, q, qd, warm, contact.
 // ------------------------------------------------------------------------------------------------
+// copies the tree tables from the device-resident model into LDS (one region)
+template <class W>
+DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
+    wave.par([&](int l) {
+        if (l < NB) {
+            S.tree.parent[l] = M.parent[l];
+            S.tree.nchild[l] = M.nchild[l];
+            for (int i = 0; i < MAX_CHILD; ++i) S.tree.child[l][i] = M.child[l][i];
+            for (int i = 0; i < 3; ++i) { S.tree.pos[l][i] = M.pos[l][i]; S.tree.axis[l][i] = M.axis[l][i]; }
+        }
+        if (l < MAX_LEVELS) S.tree.level_count[l] = M.level_count[l];
+        if (l < MAX_LEVELS * MAX_PER_LEVEL) S.tree.level_body[l / MAX_PER_LEVEL][l % MAX_PER_LEVEL] = M.level_body[l / MAX_PER_LEVEL][l % MAX_PER_LEVEL];
+        if (l == 63) S.tree.nlevels = M.nlevels;
+    });
+}
+
 template <class W>
 DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysParams &P) {
     const float dt = P.dt;
@@ -173,7 +204,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 6; ++i) S.v[0][i] = vb[i];
         } else if (l < NB) {
             const int b = l;
-            const float *s = M.axis[b];
+            const float *s = S.tree.axis[b];
             float q = S.q[b - 1];
             float sn = sinf(q), cs = cosf(q), oc = 1.0f - cs;
             float Rj[9] = {cs + oc * s[0] * s[0], oc * s[0] * s[1] - sn * s[2], oc * s[0] * s[2] + sn * s[1],
@@ -186,20 +217,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     // ---- K2: forward kinematics and velocities, level by level ----
-    for (int L = 1; L <= M.nlevels; ++L) {
+    for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
-            if (l < M.level_count[L]) {
-                const int b = M.level_body[L][l], p = M.parent[b];
+            if (l < S.tree.level_count[L]) {
+                const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
                 float R[9], Rp[9], Rw[9], t[3], vp[6], vb[6];
                 for (int i = 0; i < 9; ++i) { R[i] = S.R[b][i]; Rp[i] = S.Rw[p][i]; }
                 m3m(Rp, R, Rw);
                 for (int i = 0; i < 9; ++i) S.Rw[b][i] = Rw[i];
-                m3v(Rp, M.pos[b], t);
+                m3v(Rp, S.tree.pos[b], t);
                 for (int i = 0; i < 3; ++i) S.pw[b][i] = S.pw[p][i] + t[i];
                 for (int i = 0; i < 6; ++i) vp[i] = S.v[p][i];
-                xform_motion(R, M.pos[b], vp, vb);
+                xform_motion(R, S.tree.pos[b], vp, vb);
                 float qd = S.qd[b - 1];
-                vb[0] += M.axis[b][0] * qd; vb[1] += M.axis[b][1] * qd; vb[2] += M.axis[b][2] * qd;
+                vb[0] += S.tree.axis[b][0] * qd; vb[1] += S.tree.axis[b][1] * qd; vb[2] += S.tree.axis[b][2] * qd;
                 for (int i = 0; i < 6; ++i) S.v[b][i] = vb[i];
             }
         });
@@ -332,14 +363,14 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     // ---- A2: inward sweep of articulated inertias ----
-    for (int L = M.nlevels; L >= 1; --L) {
-        const int cnt = M.level_count[L];
+    for (int L = S.tree.nlevels; L >= 1; --L) {
+        const int cnt = S.tree.level_count[L];
         // A: projection through the joint, rows of Ia*X
         wave.par([&](int l) {
             const int k = l / 6, r = l % 6;
             if (k < cnt) {
-                const int b = M.level_body[L][k];
-                const float *s = M.axis[b];
+                const int b = S.tree.level_body[L][k];
+                const float *s = S.tree.axis[b];
                 const float *IA = S.in.IA[b];
                 float U[6];
                 for (int j = 0; j < 6; ++j) U[j] = IA[6 * j] * s[0] + IA[6 * j + 1] * s[1] + IA[6 * j + 2] * s[2];
@@ -358,7 +389,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 S.in.pa[k][r] = pa;
                 float R[9], PR[9];
                 for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                make_PR(R, M.pos[b], PR);
+                make_PR(R, S.tree.pos[b], PR);
                 for (int c = 0; c < 3; ++c) {
                     S.in.T[k][6 * r + c] = Ia[0] * R[3 * c] + Ia[1] * R[3 * c + 1] + Ia[2] * R[3 * c + 2] +
                                            Ia[3] * PR[3 * c] + Ia[4] * PR[3 * c + 1] + Ia[5] * PR[3 * c + 2];
@@ -375,10 +406,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         wave.par([&](int l) {
             const int k = l / 6, r = l % 6;
             if (k < cnt) {
-                const int b = M.level_body[L][k];
+                const int b = S.tree.level_body[L][k];
                 float R[9], PR[9];
                 for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                make_PR(R, M.pos[b], PR);
+                make_PR(R, S.tree.pos[b], PR);
                 const float *T = S.in.T[k];
                 const float *pa = S.in.pa[k];
                 float out[6], po;
@@ -398,15 +429,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             }
         });
         // C: parents (one level up) gather their children, fixed order
-        const int pcnt = (L == 1) ? 1 : M.level_count[L - 1];
+        const int pcnt = (L == 1) ? 1 : S.tree.level_count[L - 1];
         wave.par([&](int l) {
             const int k = l / 6, r = l % 6;
             if (k < pcnt) {
-                const int p = (L == 1) ? 0 : M.level_body[L - 1][k];
+                const int p = (L == 1) ? 0 : S.tree.level_body[L - 1][k];
                 float acc[6], pacc = S.pA[p][r];
                 for (int c = 0; c < 6; ++c) acc[c] = S.in.IA[p][6 * r + c];
-                for (int ci = 0; ci < M.nchild[p]; ++ci) {
-                    const int ch = M.child[p][ci];
+                for (int ci = 0; ci < S.tree.nchild[p]; ++ci) {
+                    const int ch = S.tree.child[p][ci];
                     for (int c = 0; c < 6; ++c) acc[c] += S.in.IA[ch][6 * r + c];
                     pacc += S.pA[ch][r];
                 }
@@ -458,15 +489,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     // ---- A4: outward sweep of accelerations ----
-    for (int L = 1; L <= M.nlevels; ++L) {
+    for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
-            if (l < M.level_count[L]) {
-                const int b = M.level_body[L][l], p = M.parent[b];
-                const float *s = M.axis[b];
+            if (l < S.tree.level_count[L]) {
+                const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
+                const float *s = S.tree.axis[b];
                 float R[9], apar[6], ap[6], vb[6], cb[6];
                 for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
                 for (int i = 0; i < 6; ++i) { apar[i] = S.out.a[p][i]; vb[i] = S.v[b][i]; }
-                xform_motion(R, M.pos[b], apar, ap);
+                xform_motion(R, S.tree.pos[b], apar, ap);
                 joint_bias(vb, s, S.qd[b - 1], cb);
                 float ua = 0.0f;
                 for (int i = 0; i < 6; ++i) { ap[i] += cb[i]; ua += S.U[b][i] * ap[i]; }
@@ -527,9 +558,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     const int b = 6 * l + i;
                     float R[9], vn[6];
                     for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                    xform_motion(R, M.pos[b], vcur, vn);
+                    xform_motion(R, S.tree.pos[b], vcur, vn);
                     const float qd = S.qdf[b - 1];
-                    vn[0] += M.axis[b][0] * qd; vn[1] += M.axis[b][1] * qd; vn[2] += M.axis[b][2] * qd;
+                    vn[0] += S.tree.axis[b][0] * qd; vn[1] += S.tree.axis[b][1] * qd; vn[2] += S.tree.axis[b][2] * qd;
                     for (int j = 0; j < 6; ++j) vcur[j] = vn[j];
                 }
                 const int fb = 6 * l + 6;
@@ -553,14 +584,14 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 float du[6];
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * f + i;
-                    const float *s = M.axis[b];
+                    const float *s = S.tree.axis[b];
                     const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
                     du[i - 1] = d;
                     const float k = d * S.Dinv[b];
                     float pa[6], R[9], up[6];
                     for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * k;
                     for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                    xform_force(R, M.pos[b], pa, up);
+                    xform_force(R, S.tree.pos[b], pa, up);
                     for (int j = 0; j < 6; ++j) dp[j] = up[j];
                 }
                 float dv0[6];
@@ -574,10 +605,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     for (int j = 0; j < 6; ++j) dv[j] = dv0[j];
                     for (int i = 1; i <= 6; ++i) {
                         const int b = 6 * g + i;
-                        const float *s = M.axis[b];
+                        const float *s = S.tree.axis[b];
                         float R[9], ap[6];
                         for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                        xform_motion(R, M.pos[b], dv, ap);
+                        xform_motion(R, S.tree.pos[b], dv, ap);
                         float ua = 0.0f;
                         for (int j = 0; j < 6; ++j) ua += S.U[b][j] * ap[j];
                         const float qdd = ((g == f ? du[i - 1] : 0.0f) - ua) * S.Dinv[b];
@@ -680,14 +711,14 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 for (int i = 0; i < 3; ++i) { dp[i] = -nbv[i]; dp[3 + i] = -fbv[i]; }
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * l + i;
-                    const float *s = M.axis[b];
+                    const float *s = S.tree.axis[b];
                     const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
                     S.out.du[b] = d;
                     const float kk = d * S.Dinv[b];
                     float pa[6], R[9], up[6];
                     for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * kk;
                     for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                    xform_force(R, M.pos[b], pa, up);
+                    xform_force(R, S.tree.pos[b], pa, up);
                     for (int j = 0; j < 6; ++j) dp[j] = up[j];
                 }
                 for (int j = 0; j < 6; ++j) S.out.dpf[l][j] = dp[j];
@@ -704,15 +735,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 S.dv0[l] = acc;
             }
         });
-        for (int L = 1; L <= M.nlevels; ++L) {
+        for (int L = 1; L <= S.tree.nlevels; ++L) {
             wave.par([&](int l) {
-                if (l < M.level_count[L]) {
-                    const int b = M.level_body[L][l], p = M.parent[b];
-                    const float *s = M.axis[b];
+                if (l < S.tree.level_count[L]) {
+                    const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
+                    const float *s = S.tree.axis[b];
                     float R[9], apar[6], ap[6];
                     for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
                     for (int i = 0; i < 6; ++i) apar[i] = S.out.a[p][i];
-                    xform_motion(R, M.pos[b], apar, ap);
+                    xform_motion(R, S.tree.pos[b], apar, ap);
                     float ua = 0.0f;
                     for (int i = 0; i < 6; ++i) ua += S.U[b][i] * ap[i];
                     const float dq = (S.out.du[b] - ua) * S.Dinv[b];

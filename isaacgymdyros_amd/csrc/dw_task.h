@@ -272,6 +272,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
     long long *gate = reinterpret_cast<long long *>(B.gate_acc);
     const int slot_prev = (int)((T.step + 2) % 3), slot_cur = (int)(T.step % 3), slot_next = (int)((T.step + 1) % 3);
 
+    stage_tree(wave, S, M);
     load_env(wave, S, C, B, e, true);
     if (C.freeze_physics) {      // debug mode: simulate() is the identity, so the net contact forces are an input too
         wave.par([&](int l) {
@@ -525,6 +526,13 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             if (S.flags[1]) reset = 1;
             B.reset_buf[e] = reset;
             S.flags[3] = reset;
+            float ret = S.es[DW_ES_EPI_RETURN] + total;
+            if (reset) {
+                S.es[DW_ES_LAST_RETURN] = ret;
+                ESI(DW_ES_EPISODES) += 1;
+                ret = 0.0f;
+            }
+            S.es[DW_ES_EPI_RETURN] = ret;
         }
     });
     const int did_reset = uniform(S.flags[3]);
@@ -645,6 +653,7 @@ DW_HD void reset_only_env(const W &wave, Lds &S, const DevModel &M, const TaskPa
 template <class W>
 DW_HD void simulate_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                         const float *tau, const float *push, int e) {
+    stage_tree(wave, S, M);
     load_env(wave, S, C, B, e, false);
     wave.par([&](int l) {
         if (l < ND) S.tau[l] = tau[ND * e + l];

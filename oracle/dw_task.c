@@ -496,7 +496,11 @@ static void step_env(DwHandle *h, int e, const float *actions, const float *nois
     reward_env(h, e, &reset);
     if (bad) reset = 1;
     b->reset_buf[e] = reset;
+    es[DW_ES_EPI_RETURN] = es[DW_ES_EPI_RETURN] + b->rew_buf[e];
     if (reset) {
+        es[DW_ES_LAST_RETURN] = es[DW_ES_EPI_RETURN];
+        es[DW_ES_EPI_RETURN] = 0.0f;
+        *esi(es, DW_ES_EPISODES) += 1;
         nz.stream = 0;
         reset_env(h, e, &nz);
     }
