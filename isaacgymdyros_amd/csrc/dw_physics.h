@@ -81,6 +81,8 @@ struct Lds {
             int   active[8];
             int   any_active;
             float twf[2][6];
+            float ducol[12][6];
+            float invd[24];
         } out;
     };
     // ---- task state (dw_task.h) ----
@@ -402,28 +404,33 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
             }
         });
-        // B: X' (Ia X) and X' pa, written over the child's own storage (now "contribution to the parent")
+        // B: X' (Ia X) and X' pa, written over the child's own storage (now "contribution to the parent").
+        //    Row q of R and row q of skew(p)*R are read / formed from LDS directly (a register array indexed
+        //    by the lane's row would live in scratch memory).
         wave.par([&](int l) {
             const int k = l / 6, r = l % 6;
             if (k < cnt) {
                 const int b = S.tree.level_body[L][k];
-                float R[9], PR[9];
-                for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                make_PR(R, S.tree.pos[b], PR);
-                const float *T = S.in.T[k];
-                const float *pa = S.in.pa[k];
-                float out[6], po;
+                const int q = r < 3 ? r : r - 3;
+                const int q1 = q == 2 ? 0 : q + 1, q2 = q == 0 ? 2 : q - 1;
+                const float *Rb = S.R[b];
+                const float *pp = S.tree.pos[b];
+                const float Rq[3] = {Rb[3 * q], Rb[3 * q + 1], Rb[3 * q + 2]};
+                float PRq[3] = {0.0f, 0.0f, 0.0f};
                 if (r < 3) {
-                    for (int c = 0; c < 6; ++c)
-                        out[c] = R[3 * r] * T[c] + R[3 * r + 1] * T[6 + c] + R[3 * r + 2] * T[12 + c] +
-                                 PR[3 * r] * T[18 + c] + PR[3 * r + 1] * T[24 + c] + PR[3 * r + 2] * T[30 + c];
-                    po = R[3 * r] * pa[0] + R[3 * r + 1] * pa[1] + R[3 * r + 2] * pa[2] +
-                         PR[3 * r] * pa[3] + PR[3 * r + 1] * pa[4] + PR[3 * r + 2] * pa[5];
-                } else {
-                    const int q = r - 3;
-                    for (int c = 0; c < 6; ++c) out[c] = R[3 * q] * T[18 + c] + R[3 * q + 1] * T[24 + c] + R[3 * q + 2] * T[30 + c];
-                    po = R[3 * q] * pa[3] + R[3 * q + 1] * pa[4] + R[3 * q + 2] * pa[5];
+                    const float p1 = pp[q1], p2 = pp[q2];
+                    for (int c = 0; c < 3; ++c) PRq[c] = p1 * Rb[3 * q2 + c] - p2 * Rb[3 * q1 + c];
                 }
+                const float *T = S.in.T[k] + (r < 3 ? 0 : 18);
+                const float *T2 = S.in.T[k] + 18;
+                const float *pa = S.in.pa[k] + (r < 3 ? 0 : 3);
+                const float *pa2 = S.in.pa[k] + 3;
+                float out[6];
+                for (int c = 0; c < 6; ++c)
+                    out[c] = Rq[0] * T[c] + Rq[1] * T[6 + c] + Rq[2] * T[12 + c] +
+                             PRq[0] * T2[c] + PRq[1] * T2[6 + c] + PRq[2] * T2[12 + c];
+                const float po = Rq[0] * pa[0] + Rq[1] * pa[1] + Rq[2] * pa[2] +
+                                 PRq[0] * pa2[0] + PRq[1] * pa2[1] + PRq[2] * pa2[2];
                 for (int c = 0; c < 6; ++c) S.in.IA[b][6 * r + c] = out[c];
                 S.pA[b][r] = po;
             }
@@ -581,12 +588,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 m3tv(S.Rw[fb], ew, eb);
                 float dp[6] = {0, 0, 0, 0, 0, 0};
                 for (int i = 0; i < 3; ++i) dp[(comp < 3 ? 0 : 3) + i] = -eb[i];
-                float du[6];
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * f + i;
                     const float *s = S.tree.axis[b];
                     const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
-                    du[i - 1] = d;
+                    S.out.ducol[l][i - 1] = d;
                     const float k = d * S.Dinv[b];
                     float pa[6], R[9], up[6];
                     for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * k;
@@ -611,7 +617,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                         xform_motion(R, S.tree.pos[b], dv, ap);
                         float ua = 0.0f;
                         for (int j = 0; j < 6; ++j) ua += S.U[b][j] * ap[j];
-                        const float qdd = ((g == f ? du[i - 1] : 0.0f) - ua) * S.Dinv[b];
+                        const float qdd = ((g == f ? S.out.ducol[l][i - 1] : 0.0f) - ua) * S.Dinv[b];
                         ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
                         for (int j = 0; j < 6; ++j) dv[j] = ap[j];
                     }
@@ -634,18 +640,25 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 ja[0] = ax == 1 ? -r[2] : (ax == 2 ? r[1] : 0.0f);
                 ja[1] = ax == 0 ? r[2] : (ax == 2 ? -r[0] : 0.0f);
                 ja[2] = ax == 0 ? -r[1] : (ax == 1 ? r[0] : 0.0f);
-                float JW[12];
-                for (int c = 0; c < 12; ++c)
-                    JW[c] = ja[0] * S.out.W[6 * f][c] + ja[1] * S.out.W[6 * f + 1][c] + ja[2] * S.out.W[6 * f + 2][c] +
-                            S.out.W[6 * f + 3 + ax][c];
-                for (int k2 = 0; k2 < DW_NUM_FOOT_PTS; ++k2) {
-                    const int f2 = k2 / 4;
-                    const float r2[3] = {S.out.rk[k2][0], S.out.rk[k2][1], S.out.rk[k2][2]};
-                    const float *w = JW + 6 * f2;
+                float JW0[6], JW1[6];
+                for (int c = 0; c < 6; ++c) {
+                    JW0[c] = ja[0] * S.out.W[6 * f][c] + ja[1] * S.out.W[6 * f + 1][c] + ja[2] * S.out.W[6 * f + 2][c] +
+                             S.out.W[6 * f + 3 + ax][c];
+                    JW1[c] = ja[0] * S.out.W[6 * f][6 + c] + ja[1] * S.out.W[6 * f + 1][6 + c] + ja[2] * S.out.W[6 * f + 2][6 + c] +
+                             S.out.W[6 * f + 3 + ax][6 + c];
+                }
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const float *r2 = S.out.rk[k2];
                     // column (k2, ax2): sum_j JW[6 f2 + j] * (-skew(r2)[ax2][j]) + JW[6 f2 + 3 + ax2]
-                    S.out.A[l][3 * k2 + 0] = w[1] * r2[2] - w[2] * r2[1] + w[3];
-                    S.out.A[l][3 * k2 + 1] = -w[0] * r2[2] + w[2] * r2[0] + w[4];
-                    S.out.A[l][3 * k2 + 2] = w[0] * r2[1] - w[1] * r2[0] + w[5];
+                    S.out.A[l][3 * k2 + 0] = JW0[1] * r2[2] - JW0[2] * r2[1] + JW0[3];
+                    S.out.A[l][3 * k2 + 1] = -JW0[0] * r2[2] + JW0[2] * r2[0] + JW0[4];
+                    S.out.A[l][3 * k2 + 2] = JW0[0] * r2[1] - JW0[1] * r2[0] + JW0[5];
+                }
+                for (int k2 = 4; k2 < 8; ++k2) {
+                    const float *r2 = S.out.rk[k2];
+                    S.out.A[l][3 * k2 + 0] = JW1[1] * r2[2] - JW1[2] * r2[1] + JW1[3];
+                    S.out.A[l][3 * k2 + 1] = -JW1[0] * r2[2] + JW1[2] * r2[0] + JW1[4];
+                    S.out.A[l][3 * k2 + 2] = JW1[0] * r2[1] - JW1[1] * r2[0] + JW1[5];
                 }
                 const float *tw = S.out.twf[f];
                 float t[3];
@@ -658,6 +671,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 float acc = S.out.vel[1][l];
                 for (int c = 0; c < 24; ++c) acc += S.out.A[l][c] * S.out.P[0][c];
                 S.out.vel[0][l] = acc;
+                S.out.invd[l] = 1.0f / (S.out.A[l][l] * (1.0f + P.cfm));
             }
         });
         // ---- C4: projected Gauss-Seidel.  One region per contact update; constraint velocities and
@@ -670,16 +684,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     if (l < 24) {
                         const float *vel = S.out.vel[cur], *Pc = S.out.P[cur];
                         const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
-                        const float reg = 1.0f + P.cfm;
                         const float Pz = Pc[rz], Px = Pc[rx], Py = Pc[ry];
-                        float dz = -(vel[rz] - S.out.vmin[k]) / (S.out.A[rz][rz] * reg);
+                        float dz = -(vel[rz] - S.out.vmin[k]) * S.out.invd[rz];
                         float pz = Pz + dz;
                         if (pz < 0) pz = 0;
                         dz = pz - Pz;
                         const float vx = vel[rx] + S.out.A[rx][rz] * dz;
-                        const float dx = -vx / (S.out.A[rx][rx] * reg);
+                        const float dx = -vx * S.out.invd[rx];
                         const float vy = vel[ry] + S.out.A[ry][rz] * dz + S.out.A[ry][rx] * dx;
-                        const float dy = -vy / (S.out.A[ry][ry] * reg);
+                        const float dy = -vy * S.out.invd[ry];
                         float px = Px + dx, py = Py + dy;
                         const float lim = S.mu * pz, nrm = sqrtf(px * px + py * py);
                         if (nrm > lim) {

@@ -111,6 +111,20 @@ DW_HD float norm_t(const float *x, int n) {
     for (; d < n; ++d) b0 = fmaf(x[d], x[d], b0);
     return sqrtf(b0);
 }
+// same summation order, elements produced on the fly (keeps 33-element operands out of the register file)
+template <class F>
+DW_HD float norm_fn(F f, int n) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int d = 0;
+    for (; d < n - (n % 8); d += 8)
+        for (int l = 0; l < 8; ++l) { const float x = f(d + l); acc[l] = fmaf(x, x, acc[l]); }
+    float b0 = acc[0];
+    for (int l = 1; l < 8; ++l) b0 = b0 + acc[l];
+    for (; d + 4 <= n; d += 4)
+        for (int l = 0; l < 4; ++l) { const float x = f(d + l); const float p = x * x; b0 = b0 + p; }
+    for (; d < n; ++d) { const float x = f(d); b0 = fmaf(x, x, b0); }
+    return sqrtf(b0);
+}
 DW_HD float cubic_t(float time, float t0, float tf, float x0, float xf) {
     const float elapsed = time - t0;
     const float total = tf - t0;
@@ -442,32 +456,22 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             S.rterm[0] = 0.3f * expf(-13.2f * aerr);
         }
         if (l == 41) {
-            float d[ND];
-            for (int j = 0; j < ND; ++j) d[j] = S.es[DW_ES_TARGET_QPOS + j] - S.q[j];
-            const float n = norm_t(d, ND);
+            const float n = norm_fn([&](int j) { return S.es[DW_ES_TARGET_QPOS + j] - S.q[j]; }, ND);
             S.rterm[1] = 0.35f * expf(-2.0f * (n * n));
         }
         if (l == 42) {
-            float d[ND];
-            for (int j = 0; j < ND; ++j) d[j] = 0.0f - S.qd[j];
-            const float n = norm_t(d, ND);
+            const float n = norm_fn([&](int j) { return 0.0f - S.qd[j]; }, ND);
             S.rterm[2] = 0.05f * expf(-0.01f * (n * n));
         }
         if (l == 43) {
-            float d[ND];
-            for (int j = 0; j < ND; ++j) d[j] = S.qd[j] - S.es[DW_ES_PRE_QVEL + j];
-            const float n = norm_t(d, ND);
+            const float n = norm_fn([&](int j) { return S.qd[j] - S.es[DW_ES_PRE_QVEL + j]; }, ND);
             S.rterm[7] = 0.05f * expf(-20.0f * (n * n));
         }
         if (l == 44) {
-            float a12[12];
-            for (int i = 0; i < 12; ++i) a12[i] = S.es[DW_ES_ACTIONS + i] * 333.0f;
-            S.rterm[4] = 0.05f * expf(-0.01f * norm_t(a12, 12));
+            S.rterm[4] = 0.05f * expf(-0.01f * norm_fn([&](int i) { return S.es[DW_ES_ACTIONS + i] * 333.0f; }, 12));
         }
         if (l == 45) {
-            float a12[12];
-            for (int i = 0; i < 12; ++i) a12[i] = (S.es[DW_ES_ACTIONS + i] - S.es[DW_ES_ACTIONS_PRE + i]) * 333.0f;
-            S.rterm[5] = 0.6f * expf((-0.01f * 1.0f) * norm_t(a12, 12));
+            S.rterm[5] = 0.6f * expf((-0.01f * 1.0f) * norm_fn([&](int i) { return (S.es[DW_ES_ACTIONS + i] - S.es[DW_ES_ACTIONS_PRE + i]) * 333.0f; }, 12));
         }
         if (l == 46) {
             const float dv[2] = {S.es[DW_ES_TARGET_VEL] - S.root[7], S.es[DW_ES_TARGET_VEL + 1] - S.root[8]};

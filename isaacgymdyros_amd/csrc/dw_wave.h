@@ -2,7 +2,7 @@
 //
 // The kernels are written for ONE WAVEFRONT (64 lanes) PER ENVIRONMENT: every phase of the step is a
 // "region" executed by all 64 lanes, regions exchange data only through the env's LDS block, and a
-// workgroup is exactly one wave so the barrier between regions costs one s_barrier and an LDS drain.
+// workgroup is exactly one wave, so the boundary between regions is a wavefront-scope fence (no instruction).
 // `Wave::par(f)` runs f(lane) for the calling lane and ends the region.  `uniform(x)` turns a value
 // every lane read from the same LDS word into a scalar-register value so that loops and branches that
 // contain regions are provably wave-uniform.
@@ -20,7 +20,16 @@ namespace dw {
 struct Wave {
     template <class F> DW_HD void par(F &&f) const {
         f((int)threadIdx.x);
+        // End of region.  The workgroup IS the wave, and a wave's LDS instructions execute in program order, so
+        // no s_barrier (and no vmcnt drain) is needed: a wavefront-scope fence keeps the compiler from moving
+        // LDS/global accesses across the region boundary and emits no instruction.
+#if defined(DW_REGION_SYNCTHREADS)
         __syncthreads();
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
     }
 };
 DW_HD int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
