@@ -10,7 +10,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdyroswalk_hip.so")
 SOURCES = ["dw_hip.hip"]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing"]
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_* pairs, which costs more
+# v_mov operand shuffling than it saves here (static v_mov count halves without it)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fno-slp-vectorize"]
 
 
 def hipcc() -> str:

@@ -1,7 +1,7 @@
 // dw_hip.hip -- gfx950 kernels and the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so).
 //
 // One workgroup = one wavefront = one environment.  The kernel bodies live in dw_task.h / dw_physics.h as
-// wave regions over a 16.8 KB LDS block per env (9 envs resident per CU by LDS); this file only declares
+// wave regions over a 13.4 KB LDS block per env (12 envs resident per CU); this file only declares
 // the __global__ entry points, owns the read-only model/mocap tables in device memory and validates
 // arguments.  Nothing here allocates, synchronises or copies per call (graph-capture safe).
 #include <hip/hip_runtime.h>
@@ -15,6 +15,7 @@ struct DwHandle {
     DwConfig        cfg;
     dw::TaskParams  params;
     dw::DevModel   *d_model;
+    dw::DevParams  *d_params;
     float          *d_mocap;
     DwBuffers       buf;
     int             bound;
@@ -29,30 +30,33 @@ static int fail_hip(const char *what, hipError_t e) {
     return DW_EHIP;
 }
 
-// 256 VGPRs = 2 waves per SIMD; LDS (16.8 KB/env) admits 9 envs per CU, so registers and LDS agree on 8 waves/CU
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_k_step(const dw::DevModel *M, dw::TaskParams C, dw::TaskBuffers T) {
+// 13.4 KB of LDS per env admits 12 envs per CU = 3 waves per SIMD; cap the registers at 168 to match (the ~60
+// spilled values sit at the substep-loop boundary, measured +16 % over 2 waves/SIMD at 256 registers)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
     __shared__ dw::Lds S;
     dw::Wave w;
-    dw::step_env(w, S, *M, C, T, (int)blockIdx.x);
+    dw::TaskBuffers T;
+    T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
+    dw::step_env(w, S, *M, P->C, T, (int)blockIdx.x);
 }
 
-__global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, dw::TaskParams C, DwBuffers B,
+__global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
                                                     const float *tau, const float *push) {
     __shared__ dw::Lds S;
     dw::Wave w;
-    dw::simulate_env(w, S, *M, C, B, tau, push, (int)blockIdx.x);
+    dw::simulate_env(w, S, *M, P->C, P->B, tau, push, (int)blockIdx.x);
 }
 
-__global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, dw::TaskParams C, dw::TaskBuffers T,
-                                                 const int32_t *ids, int n, int *bad) {
+__global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, const dw::DevParams *P, const float *noise,
+                                                 long long step, const int32_t *ids, int n) {
     __shared__ dw::Lds S;
     dw::Wave w;
     const int e = ids[blockIdx.x];
-    if (e < 0 || e >= C.num_envs) {            // wave-uniform: the whole workgroup leaves
-        if (threadIdx.x == 0 && bad) atomicAdd(bad, 1);
-        return;
-    }
-    dw::reset_only_env(w, S, *M, C, T, e);
+    if (e < 0 || e >= P->C.num_envs) return;     // wave-uniform: the whole workgroup leaves
+    dw::TaskBuffers T;
+    T.b = &P->B; T.actions = nullptr; T.noise = noise; T.mocap = P->mocap; T.step = step;
+    dw::reset_only_env(w, S, *M, P->C, T, e);
 }
 
 extern "C" {
@@ -84,10 +88,15 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     if (e == hipSuccess) e = hipMemcpy(h->d_model, hm, sizeof(dw::DevModel), hipMemcpyHostToDevice);
     free(hm);
     if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
+    e = hipMalloc((void **)&h->d_params, sizeof(dw::DevParams));
+    if (e == hipSuccess) e = hipMemset(h->d_params, 0, sizeof(dw::DevParams));
+    if (e == hipSuccess) e = hipMemcpy(&h->d_params->C, &h->params, sizeof(dw::TaskParams), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: parameter upload", e); }
     if (task) {
         const size_t bytes = sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS;
         e = hipMalloc((void **)&h->d_mocap, bytes);
         if (e == hipSuccess) e = hipMemcpy(h->d_mocap, task->mocap, bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(&h->d_params->mocap, &h->d_mocap, sizeof(float *), hipMemcpyHostToDevice);
         if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: mocap upload", e); }
         h->has_task = 1;
     }
@@ -98,6 +107,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
 int dw_destroy(DwHandle *h) {
     if (!h) return fail(DW_EINVAL, "dw_destroy: null handle");
     if (h->d_model) (void)hipFree(h->d_model);
+    if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_mocap) (void)hipFree(h->d_mocap);
     free(h);
     return DW_OK;
@@ -107,6 +117,9 @@ int dw_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dw_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
     h->buf = *b;
+    // bind time, not step time: one small synchronous copy of the pointer table into the parameter block
+    hipError_t e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip("dw_bind: pointer table upload", e);
     h->bound = 1;
     return DW_OK;
 }
@@ -115,8 +128,8 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!h || !h->bound) return fail(DW_ESTATE, "dw_simulate: buffers not bound");
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
-    hipLaunchKernelGGL(dw_k_simulate, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->params,
-                       h->buf, tau, push_xy);
+    hipLaunchKernelGGL(dw_k_simulate, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
+                       tau, push_xy);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_simulate: launch", e);
     return DW_OK;
@@ -127,9 +140,8 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
-    dw::TaskBuffers T;
-    T.b = h->buf; T.actions = actions; T.noise = noise; T.mocap = h->d_mocap; T.step = step_index;
-    hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->params, T);
+    hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
+                       actions, noise, (long long)step_index);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_step: launch", e);
     return DW_OK;
@@ -140,10 +152,8 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (n < 0 || (n > 0 && !env_ids)) return fail(DW_EINVAL, "dw_reset_idx: bad env id list");
     if (n == 0) return DW_OK;
-    dw::TaskBuffers T;
-    T.b = h->buf; T.actions = nullptr; T.noise = noise; T.mocap = h->d_mocap; T.step = step_index;
-    hipLaunchKernelGGL(dw_k_reset, dim3(n), dim3(64), 0, (hipStream_t)stream, h->d_model, h->params, T, env_ids, n,
-                       (int *)nullptr);
+    hipLaunchKernelGGL(dw_k_reset, dim3(n), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params, noise,
+                       (long long)step_index, env_ids, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_reset_idx: launch", e);
     return DW_OK;

@@ -32,19 +32,29 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
 // or by level, and a dependent chain of global loads (level -> body -> parent -> offset/axis) per region is what
 // the first profile of this kernel was made of.
 struct LdsTree {
-    int   parent[NB];
-    int   nchild[NB];
-    int   child[NB][MAX_CHILD];
-    int   level_count[MAX_LEVELS];
-    int   level_body[MAX_LEVELS][MAX_PER_LEVEL];
-    int   nlevels;
     float pos[NB][3];
     float axis[NB][3];
+    unsigned char parent[NB];
+    unsigned char nchild[NB];
+    unsigned char child[NB][MAX_CHILD];
+    unsigned char level_count[MAX_LEVELS];
+    unsigned char level_body[MAX_LEVELS][MAX_PER_LEVEL];
+    unsigned char nlevels;
 };
 
+// Packed index of entry (r,c) of a symmetric 6x6 (upper triangle, row-major): 21 words instead of 36.
+DW_HD constexpr int sym6(int r, int c) {
+    return r <= c ? (r * (13 - r)) / 2 + (c - r) : (c * (13 - c)) / 2 + (r - c);
+}
+
+// One env's LDS block.  160 KB per CU / 13.5 KB = 12 resident envs (3 waves per SIMD); the first version of this
+// struct was 18.6 KB (8 envs).  The saving comes from overlaying arrays whose lifetimes inside a substep do not
+// intersect (phases in order: K1 K2 kinematics, K3 inertias, K4 K5 primitives, SW inward sweep, A3 base solve,
+// A4 outward sweep, V1 free velocities, C1..C5 contact, V2 integrate) and from packing the symmetric
+// articulated inertias.
 struct Lds {
     LdsTree tree;
-    // ---- state and inputs of the substep ----
+    // ---- state and inputs of the substep (live throughout) ----
     float root[13];
     float q[ND], qd[ND], tau[ND], arm[ND], damp[ND];
     float mscale[DW_NUM_BODIES];
@@ -52,45 +62,46 @@ struct Lds {
     float push[2];
     float warm[24];
     float contact[DW_NUM_BODIES * 3];
-    // ---- kinematics ----
     float quat[4], ww[3], vow[3];
-    float R[NB][9];       // body -> parent
-    float Rw[NB][9];      // body -> world
-    float pw[NB][3];
-    float v[NB][6];       // body-frame spatial velocity
-    float pA[NB][6];
-    float U[NB][6], Dinv[NB], u[NB];
-    float qdd[ND], qdf[ND], dqd[ND];
-    float wwf[3], vowf[3], dv0[6];
-    float Minv[36];
-    float gF[64][3], gr[64][3];
-    union {
-        struct {          // inward sweep
-            float IA[NB][36];
-            float T[MAX_PER_LEVEL][36];
-            float pa[MAX_PER_LEVEL][6];
-        } in;
-        struct {          // everything after the base solve
+    float R[NB][9];                 // body -> parent, K1 .. C5
+    float RwK[3][9], pwK[3][3];     // world pose of the base and the two sole bodies, K5 .. V2
+    union {                         // block B
+        struct { float Rw[NB][9]; float pw[NB][3]; } kin;                       // K2 .. K5
+        struct { float T[MAX_PER_LEVEL][36]; float pa[MAX_PER_LEVEL][6]; } sw;  // SW
+        struct {                                                                // A3 .. V2
             float a[NB][6];
             float du[NB];
-            float dpf[2][6];
+            float qdd[ND], qdf[ND], dqd[ND];
+            float wwf[3], vowf[3], dv0[6];
+            float Minv[36];
+        } post;
+    } B;
+    union {                         // block V
+        struct { float v[NB][6]; float pA[NB][6]; } dyn;                        // K2 .. A4 (v), K3 .. A3 (pA)
+        struct {                                                                // V1 .. C5 (W first: v[0] is read in V1)
             float W[12][12];
-            float A[24][24];
             float vel[2][24], P[2][24];
             float rk[8][3], phi[8], vmin[8];
             int   active[8];
             int   any_active;
             float twf[2][6];
             float ducol[12][6];
-            float invd[24];
-        } out;
-    };
-    // ---- task state (dw_task.h) ----
+        } con;
+    } V;
+    union {                         // block C
+        struct { float gF[64][3], gr[64][3]; } geo;                             // K4 .. K5
+        struct { float U[NB][6], Dinv[NB], u[NB]; } art;                        // SW .. C5
+    } C;
+    union {                         // block A
+        float IA[NB][21];                                                       // K3 .. A3 (packed, sym6)
+        struct { float A[24][24]; float invd[24]; float dpf[2][6]; } lcp;       // C3 .. C5
+    } A;
+    // ---- task state (dw_task.h), live for the whole policy step ----
     float es[DW_ES_WORDS];
     float act[DW_NUM_ACT];
     float normed[DW_NUM_OBS1];
     float rterm[16];
-    float scratch[40];
+    float scratch[8];
     int   flags[8];
 };
 
@@ -175,6 +186,14 @@ DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
     });
 }
 
+// Profiling builds (-DDW_PROFILE_STOP=n) leave the substep after phase n; results are then meaningless, only the
+// launch time is read (tools/phase_costs.sh).  Never defined in the shipped library.
+#if defined(DW_PROFILE_STOP)
+#define DW_CKPT(n) do { if (DW_PROFILE_STOP == (n)) return; } while (0)
+#else
+#define DW_CKPT(n) do { } while (0)
+#endif
+
 template <class W>
 DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysParams &P) {
     const float dt = P.dt;
@@ -189,8 +208,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 4; ++i) S.quat[i] = qn[i];
             float Rw[9];
             quat_to_mat(qn, Rw);
-            for (int i = 0; i < 9; ++i) { S.Rw[0][i] = Rw[i]; S.R[0][i] = Rw[i]; }
-            for (int i = 0; i < 3; ++i) S.pw[0][i] = S.root[i];
+            for (int i = 0; i < 9; ++i) { S.B.kin.Rw[0][i] = Rw[i]; S.R[0][i] = Rw[i]; }
+            for (int i = 0; i < 3; ++i) S.B.kin.pw[0][i] = S.root[i];
             float ww[3] = {S.root[10], S.root[11], S.root[12]};
             float vo[3] = {S.root[7], S.root[8], S.root[9]};
             if (P.vel_at_com) {
@@ -203,7 +222,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             float vb[6];
             m3tv(Rw, ww, vb);
             m3tv(Rw, vo, vb + 3);
-            for (int i = 0; i < 6; ++i) S.v[0][i] = vb[i];
+            for (int i = 0; i < 6; ++i) S.V.dyn.v[0][i] = vb[i];
         } else if (l < NB) {
             const int b = l;
             const float *s = S.tree.axis[b];
@@ -218,26 +237,28 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         }
     });
 
+    DW_CKPT(1);
     // ---- K2: forward kinematics and velocities, level by level ----
     for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
             if (l < S.tree.level_count[L]) {
                 const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
                 float R[9], Rp[9], Rw[9], t[3], vp[6], vb[6];
-                for (int i = 0; i < 9; ++i) { R[i] = S.R[b][i]; Rp[i] = S.Rw[p][i]; }
+                for (int i = 0; i < 9; ++i) { R[i] = S.R[b][i]; Rp[i] = S.B.kin.Rw[p][i]; }
                 m3m(Rp, R, Rw);
-                for (int i = 0; i < 9; ++i) S.Rw[b][i] = Rw[i];
+                for (int i = 0; i < 9; ++i) S.B.kin.Rw[b][i] = Rw[i];
                 m3v(Rp, S.tree.pos[b], t);
-                for (int i = 0; i < 3; ++i) S.pw[b][i] = S.pw[p][i] + t[i];
-                for (int i = 0; i < 6; ++i) vp[i] = S.v[p][i];
+                for (int i = 0; i < 3; ++i) S.B.kin.pw[b][i] = S.B.kin.pw[p][i] + t[i];
+                for (int i = 0; i < 6; ++i) vp[i] = S.V.dyn.v[p][i];
                 xform_motion(R, S.tree.pos[b], vp, vb);
                 float qd = S.qd[b - 1];
                 vb[0] += S.tree.axis[b][0] * qd; vb[1] += S.tree.axis[b][1] * qd; vb[2] += S.tree.axis[b][2] * qd;
-                for (int i = 0; i < 6; ++i) S.v[b][i] = vb[i];
+                for (int i = 0; i < 6; ++i) S.V.dyn.v[b][i] = vb[i];
             }
         });
     }
 
+    DW_CKPT(2);
     // ---- K3: rigid-body inertias, gyroscopic bias; K4: penalty contact of the non-sole primitives ----
     wave.par([&](int l) {
         if (l < NB) {
@@ -256,27 +277,28 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
                 mass += mk;
             }
-            // 6x6 = [[A, H],[H', m 1]] with H = skew(h)
-            float *I = S.in.IA[b];
+            // 6x6 = [[A, H],[H', m 1]] with H = skew(h), stored packed (upper triangle)
+            float *I = S.A.IA[b];
             const float H[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
             for (int r3 = 0; r3 < 3; ++r3)
                 for (int c3 = 0; c3 < 3; ++c3) {
-                    I[6 * r3 + c3] = A[3 * r3 + c3];
-                    I[6 * r3 + 3 + c3] = H[3 * r3 + c3];
-                    I[6 * (r3 + 3) + c3] = H[3 * c3 + r3];
-                    I[6 * (r3 + 3) + 3 + c3] = (r3 == c3) ? mass : 0.0f;
+                    if (c3 >= r3) {
+                        I[sym6(r3, c3)] = A[3 * r3 + c3];
+                        I[sym6(r3 + 3, c3 + 3)] = (r3 == c3) ? mass : 0.0f;
+                    }
+                    I[sym6(r3, 3 + c3)] = H[3 * r3 + c3];
                 }
             // pA = v x* (I v)
-            float om[3] = {S.v[b][0], S.v[b][1], S.v[b][2]}, vl[3] = {S.v[b][3], S.v[b][4], S.v[b][5]};
+            float om[3] = {S.V.dyn.v[b][0], S.V.dyn.v[b][1], S.V.dyn.v[b][2]}, vl[3] = {S.V.dyn.v[b][3], S.V.dyn.v[b][4], S.V.dyn.v[b][5]};
             float n[3], f[3], t1[3], t2[3];
             m3v(A, om, n); cross3(h, vl, t1);
             n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
             cross3(om, h, t1);                       // H' w = -h x w = w x h
             f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
             cross3(om, n, t1); cross3(vl, f, t2);
-            S.pA[b][0] = t1[0] + t2[0]; S.pA[b][1] = t1[1] + t2[1]; S.pA[b][2] = t1[2] + t2[2];
+            S.V.dyn.pA[b][0] = t1[0] + t2[0]; S.V.dyn.pA[b][1] = t1[1] + t2[1]; S.V.dyn.pA[b][2] = t1[2] + t2[2];
             cross3(om, f, t1);
-            S.pA[b][3] = t1[0]; S.pA[b][4] = t1[1]; S.pA[b][5] = t1[2];
+            S.V.dyn.pA[b][3] = t1[0]; S.V.dyn.pA[b][4] = t1[1]; S.V.dyn.pA[b][5] = t1[2];
         }
     });
     wave.par([&](int l) {
@@ -285,7 +307,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             const DwGeom &ge = M.geoms[l];
             const int b = ge.moving;
             float Rw[9];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[b][i];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
             float zmin;
             if (ge.type == 0) {
                 zmin = 1e30f;
@@ -296,7 +318,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     m3v(ge.rot, e, lc);
                     lc[0] += ge.pos[0]; lc[1] += ge.pos[1]; lc[2] += ge.pos[2];
                     m3v(Rw, lc, wv);
-                    float z = S.pw[b][2] + wv[2];
+                    float z = S.B.kin.pw[b][2] + wv[2];
                     if (z < zmin) { zmin = z; rl[0] = lc[0]; rl[1] = lc[1]; rl[2] = lc[2]; }
                 }
             } else {
@@ -314,11 +336,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 for (int i = 0; i < 3; ++i) rl[i] = ge.pos[i] + sgn * ge.size[1] * al[i] + off[i];
                 float wv[3];
                 m3v(Rw, rl, wv);
-                zmin = S.pw[b][2] + wv[2];
+                zmin = S.B.kin.pw[b][2] + wv[2];
             }
             if (zmin < 0) {
                 float vb[6], t[3], vl[3], vw[3];
-                for (int i = 0; i < 6; ++i) vb[i] = S.v[b][i];
+                for (int i = 0; i < 6; ++i) vb[i] = S.V.dyn.v[b][i];
                 cross3(vb, rl, t);
                 vl[0] = vb[3] + t[0]; vl[1] = vb[4] + t[1]; vl[2] = vb[5] + t[2];
                 m3v(Rw, vl, vw);
@@ -333,20 +355,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
             }
         }
-        for (int i = 0; i < 3; ++i) { S.gF[l][i] = F[i]; S.gr[l][i] = rl[i]; }
+        for (int i = 0; i < 3; ++i) { S.C.geo.gF[l][i] = F[i]; S.C.geo.gr[l][i] = rl[i]; }
     });
     // K5: external forces into the bias of their bodies; per-body net contact force
     wave.par([&](int l) {
         if (l < NB) {
             const int b = l;
             float Rw[9];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[b][i];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
             float dn[3] = {0, 0, 0}, df[3] = {0, 0, 0};
             for (int k = 0; k < M.body_ngeom[b]; ++k) {
                 const int g = M.body_geom[b][k];
-                float F[3] = {S.gF[g][0], S.gF[g][1], S.gF[g][2]};
+                float F[3] = {S.C.geo.gF[g][0], S.C.geo.gF[g][1], S.C.geo.gF[g][2]};
                 if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
-                    float rl[3] = {S.gr[g][0], S.gr[g][1], S.gr[g][2]}, fb[3], nb[3];
+                    float rl[3] = {S.C.geo.gr[g][0], S.C.geo.gr[g][1], S.C.geo.gr[g][2]}, fb[3], nb[3];
                     m3tv(Rw, F, fb);
                     cross3(rl, fb, nb);
                     for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
@@ -360,47 +382,54 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 cross3(M.inert_com[0], fb, nb);
                 for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
             }
-            for (int i = 0; i < 3; ++i) { S.pA[b][i] -= dn[i]; S.pA[b][3 + i] -= df[i]; }
+            for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] -= dn[i]; S.V.dyn.pA[b][3 + i] -= df[i]; }
+            if (b == 0 || b == 6 || b == 12) {      // block B is recycled by the sweep: keep what the contact phases need
+                const int slot = b / 6;
+                for (int i = 0; i < 9; ++i) S.RwK[slot][i] = Rw[i];
+                for (int i = 0; i < 3; ++i) S.pwK[slot][i] = S.B.kin.pw[b][i];
+            }
         }
     });
 
+    DW_CKPT(3);
     // ---- A2: inward sweep of articulated inertias ----
     for (int L = S.tree.nlevels; L >= 1; --L) {
         const int cnt = S.tree.level_count[L];
+        // (packed index of entry (r, c) for this lane's row r = lane % 6 is recomputed per region: six selects)
         // A: projection through the joint, rows of Ia*X
         wave.par([&](int l) {
             const int k = l / 6, r = l % 6;
             if (k < cnt) {
                 const int b = S.tree.level_body[L][k];
                 const float *s = S.tree.axis[b];
-                const float *IA = S.in.IA[b];
+                const float *IA = S.A.IA[b];
                 float U[6];
-                for (int j = 0; j < 6; ++j) U[j] = IA[6 * j] * s[0] + IA[6 * j + 1] * s[1] + IA[6 * j + 2] * s[2];
+                for (int j = 0; j < 6; ++j) U[j] = IA[sym6(j, 0)] * s[0] + IA[sym6(j, 1)] * s[1] + IA[sym6(j, 2)] * s[2];
                 const float damp = S.damp[b - 1], qd = S.qd[b - 1];
                 const float D = dot3(s, U) + S.arm[b - 1] + dt * damp;
                 const float Dinv = 1.0f / D;
-                const float u = S.tau[b - 1] - damp * qd - (s[0] * S.pA[b][0] + s[1] * S.pA[b][1] + s[2] * S.pA[b][2]);
+                const float u = S.tau[b - 1] - damp * qd - (s[0] * S.V.dyn.pA[b][0] + s[1] * S.V.dyn.pA[b][1] + s[2] * S.V.dyn.pA[b][2]);
                 float vb[6], cb[6];
-                for (int i = 0; i < 6; ++i) vb[i] = S.v[b][i];
+                for (int i = 0; i < 6; ++i) vb[i] = S.V.dyn.v[b][i];
                 joint_bias(vb, s, qd, cb);
                 float Ia[6];
                 const float ur = U[r] * Dinv;
-                for (int c = 0; c < 6; ++c) Ia[c] = IA[6 * r + c] - ur * U[c];
-                float pa = S.pA[b][r] + U[r] * (u * Dinv);
+                for (int c = 0; c < 6; ++c) Ia[c] = IA[sym6(r, c)] - ur * U[c];
+                float pa = S.V.dyn.pA[b][r] + U[r] * (u * Dinv);
                 for (int c = 0; c < 6; ++c) pa += Ia[c] * cb[c];
-                S.in.pa[k][r] = pa;
+                S.B.sw.pa[k][r] = pa;
                 float R[9], PR[9];
                 for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
                 make_PR(R, S.tree.pos[b], PR);
                 for (int c = 0; c < 3; ++c) {
-                    S.in.T[k][6 * r + c] = Ia[0] * R[3 * c] + Ia[1] * R[3 * c + 1] + Ia[2] * R[3 * c + 2] +
+                    S.B.sw.T[k][6 * r + c] = Ia[0] * R[3 * c] + Ia[1] * R[3 * c + 1] + Ia[2] * R[3 * c + 2] +
                                            Ia[3] * PR[3 * c] + Ia[4] * PR[3 * c + 1] + Ia[5] * PR[3 * c + 2];
-                    S.in.T[k][6 * r + 3 + c] = Ia[3] * R[3 * c] + Ia[4] * R[3 * c + 1] + Ia[5] * R[3 * c + 2];
+                    S.B.sw.T[k][6 * r + 3 + c] = Ia[3] * R[3 * c] + Ia[4] * R[3 * c + 1] + Ia[5] * R[3 * c + 2];
                 }
                 if (r == 0) {
-                    for (int j = 0; j < 6; ++j) S.U[b][j] = U[j];
-                    S.Dinv[b] = Dinv;
-                    S.u[b] = u;
+                    for (int j = 0; j < 6; ++j) S.C.art.U[b][j] = U[j];
+                    S.C.art.Dinv[b] = Dinv;
+                    S.C.art.u[b] = u;
                 }
             }
         });
@@ -421,18 +450,19 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     const float p1 = pp[q1], p2 = pp[q2];
                     for (int c = 0; c < 3; ++c) PRq[c] = p1 * Rb[3 * q2 + c] - p2 * Rb[3 * q1 + c];
                 }
-                const float *T = S.in.T[k] + (r < 3 ? 0 : 18);
-                const float *T2 = S.in.T[k] + 18;
-                const float *pa = S.in.pa[k] + (r < 3 ? 0 : 3);
-                const float *pa2 = S.in.pa[k] + 3;
+                const float *T = S.B.sw.T[k] + (r < 3 ? 0 : 18);
+                const float *T2 = S.B.sw.T[k] + 18;
+                const float *pa = S.B.sw.pa[k] + (r < 3 ? 0 : 3);
+                const float *pa2 = S.B.sw.pa[k] + 3;
                 float out[6];
                 for (int c = 0; c < 6; ++c)
                     out[c] = Rq[0] * T[c] + Rq[1] * T[6 + c] + Rq[2] * T[12 + c] +
                              PRq[0] * T2[c] + PRq[1] * T2[6 + c] + PRq[2] * T2[12 + c];
                 const float po = Rq[0] * pa[0] + Rq[1] * pa[1] + Rq[2] * pa[2] +
                                  PRq[0] * pa2[0] + PRq[1] * pa2[1] + PRq[2] * pa2[2];
-                for (int c = 0; c < 6; ++c) S.in.IA[b][6 * r + c] = out[c];
-                S.pA[b][r] = po;
+                for (int c = 0; c < 6; ++c)
+                    if (c >= r) S.A.IA[b][sym6(r, c)] = out[c];
+                S.V.dyn.pA[b][r] = po;
             }
         });
         // C: parents (one level up) gather their children, fixed order
@@ -441,32 +471,34 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             const int k = l / 6, r = l % 6;
             if (k < pcnt) {
                 const int p = (L == 1) ? 0 : S.tree.level_body[L - 1][k];
-                float acc[6], pacc = S.pA[p][r];
-                for (int c = 0; c < 6; ++c) acc[c] = S.in.IA[p][6 * r + c];
+                float acc[6], pacc = S.V.dyn.pA[p][r];
+                for (int c = 0; c < 6; ++c) acc[c] = S.A.IA[p][sym6(r, c)];
                 for (int ci = 0; ci < S.tree.nchild[p]; ++ci) {
                     const int ch = S.tree.child[p][ci];
-                    for (int c = 0; c < 6; ++c) acc[c] += S.in.IA[ch][6 * r + c];
-                    pacc += S.pA[ch][r];
+                    for (int c = 0; c < 6; ++c) acc[c] += S.A.IA[ch][sym6(r, c)];
+                    pacc += S.V.dyn.pA[ch][r];
                 }
-                for (int c = 0; c < 6; ++c) S.in.IA[p][6 * r + c] = acc[c];
-                S.pA[p][r] = pacc;
+                for (int c = 0; c < 6; ++c)
+                    if (c >= r) S.A.IA[p][sym6(r, c)] = acc[c];
+                S.V.dyn.pA[p][r] = pacc;
             }
         });
     }
 
+    DW_CKPT(4);
     // ---- A3: inverse of the base articulated inertia (6 lanes, one column each, Cholesky) ----
     wave.par([&](int l) {
         if (l < 6) {
             float Lc[36];
-            const float *Mx = S.in.IA[0];
+            const float *Mx = S.A.IA[0];
             for (int i = 0; i < 36; ++i) Lc[i] = 0.0f;
             for (int j = 0; j < 6; ++j) {
-                float d = Mx[6 * j + j];
+                float d = Mx[sym6(j, j)];
                 for (int k = 0; k < j; ++k) d -= Lc[6 * j + k] * Lc[6 * j + k];
                 d = sqrtf(d);
                 Lc[6 * j + j] = d;
                 for (int i = j + 1; i < 6; ++i) {
-                    float s = Mx[6 * i + j];
+                    float s = Mx[sym6(i, j)];
                     for (int k = 0; k < j; ++k) s -= Lc[6 * i + k] * Lc[6 * j + k];
                     Lc[6 * i + j] = s / d;
                 }
@@ -482,19 +514,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 for (int k = i + 1; k < 6; ++k) s -= Lc[6 * k + i] * x[k];
                 x[i] = s / Lc[6 * i + i];
             }
-            for (int i = 0; i < 6; ++i) S.Minv[6 * i + l] = x[i];
+            for (int i = 0; i < 6; ++i) S.B.post.Minv[6 * i + l] = x[i];
         }
     });
     // from here on S.in is dead and S.out is live
     wave.par([&](int l) {
         if (l < 6) {
             float acc = 0.0f;
-            for (int c = 0; c < 6; ++c) acc -= S.Minv[6 * l + c] * S.pA[0][c];
-            S.out.a[0][l] = acc;
+            for (int c = 0; c < 6; ++c) acc -= S.B.post.Minv[6 * l + c] * S.V.dyn.pA[0][c];
+            S.B.post.a[0][l] = acc;
         }
-        if (l >= 8 && l < 8 + NB) S.out.du[l - 8] = 0.0f;
+        if (l >= 8 && l < 8 + NB) S.B.post.du[l - 8] = 0.0f;
     });
 
+    DW_CKPT(5);
     // ---- A4: outward sweep of accelerations ----
     for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
@@ -503,99 +536,99 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float *s = S.tree.axis[b];
                 float R[9], apar[6], ap[6], vb[6], cb[6];
                 for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                for (int i = 0; i < 6; ++i) { apar[i] = S.out.a[p][i]; vb[i] = S.v[b][i]; }
+                for (int i = 0; i < 6; ++i) { apar[i] = S.B.post.a[p][i]; vb[i] = S.V.dyn.v[b][i]; }
                 xform_motion(R, S.tree.pos[b], apar, ap);
                 joint_bias(vb, s, S.qd[b - 1], cb);
                 float ua = 0.0f;
-                for (int i = 0; i < 6; ++i) { ap[i] += cb[i]; ua += S.U[b][i] * ap[i]; }
-                const float qdd = (S.u[b] - ua) * S.Dinv[b];
-                S.qdd[b - 1] = qdd;
+                for (int i = 0; i < 6; ++i) { ap[i] += cb[i]; ua += S.C.art.U[b][i] * ap[i]; }
+                const float qdd = (S.C.art.u[b] - ua) * S.C.art.Dinv[b];
+                S.B.post.qdd[b - 1] = qdd;
                 ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
-                for (int i = 0; i < 6; ++i) S.out.a[b][i] = ap[i];
+                for (int i = 0; i < 6; ++i) S.B.post.a[b][i] = ap[i];
             }
         });
     }
 
+    DW_CKPT(6);
     // ---- V1: unconstrained velocities; sole-corner gaps ----
     wave.par([&](int l) {
-        if (l < ND) S.qdf[l] = S.qd[l] + dt * S.qdd[l];
+        if (l < ND) S.B.post.qdf[l] = S.qd[l] + dt * S.B.post.qdd[l];
         if (l == 40) {
             float Rw[9], a0[6], vb0[6], t[3], t2[3], al[3];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[0][i];
-            for (int i = 0; i < 6; ++i) { a0[i] = S.out.a[0][i]; vb0[i] = S.v[0][i]; }
+            for (int i = 0; i < 9; ++i) Rw[i] = S.RwK[0][i];
+            for (int i = 0; i < 6; ++i) { a0[i] = S.B.post.a[0][i]; vb0[i] = S.V.dyn.v[0][i]; }
             m3v(Rw, a0, t);
-            for (int i = 0; i < 3; ++i) S.wwf[i] = S.ww[i] + dt * t[i];
+            for (int i = 0; i < 3; ++i) S.B.post.wwf[i] = S.ww[i] + dt * t[i];
             cross3(vb0, vb0 + 3, t2);
             al[0] = a0[3] + t2[0]; al[1] = a0[4] + t2[1]; al[2] = a0[5] + t2[2];
             m3v(Rw, al, t);
-            for (int i = 0; i < 3; ++i) S.vowf[i] = S.vow[i] + dt * (t[i] + P.g[i]);
+            for (int i = 0; i < 3; ++i) S.B.post.vowf[i] = S.vow[i] + dt * (t[i] + P.g[i]);
         }
         if (l >= 48 && l < 48 + DW_NUM_FOOT_PTS) {
-            const int k = l - 48, b = M.foot_mv[k];
+            const int k = l - 48;
             float r[3];
-            m3v(S.Rw[b], M.foot_pos[k], r);
-            const float phi = S.pw[b][2] + r[2];
+            m3v(S.RwK[1 + k / 4], M.foot_pos[k], r);
+            const float phi = S.pwK[1 + k / 4][2] + r[2];
             const int act = phi < P.contact_offset;
-            for (int i = 0; i < 3; ++i) S.out.rk[k][i] = r[i];
-            S.out.phi[k] = phi;
-            S.out.active[k] = act;
-            S.out.vmin[k] = phi >= 0 ? -phi / dt : fminf(P.erp * (-phi) / dt, P.max_depen);
+            for (int i = 0; i < 3; ++i) S.V.con.rk[k][i] = r[i];
+            S.V.con.phi[k] = phi;
+            S.V.con.active[k] = act;
+            S.V.con.vmin[k] = phi >= 0 ? -phi / dt : fminf(P.erp * (-phi) / dt, P.max_depen);
         }
-        if (l < 6) S.dv0[l] = 0.0f;
-        if (l < ND) S.dqd[l] = 0.0f;
+        if (l < 6) S.B.post.dv0[l] = 0.0f;
+        if (l < ND) S.B.post.dqd[l] = 0.0f;
     });
     wave.par([&](int l) {
         if (l == 0) {
             int any = 0;
-            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) any |= S.out.active[k];
-            S.out.any_active = any;
+            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) any |= S.V.con.active[k];
+            S.V.con.any_active = any;
         }
-        if (l < 24) S.out.P[0][l] = S.out.active[l / 3] ? S.warm[l] : 0.0f;
+        if (l < 24) S.V.con.P[0][l] = S.V.con.active[l / 3] ? S.warm[l] : 0.0f;
     });
 
-    if (uniform(S.out.any_active)) {
+    if (uniform(S.V.con.any_active)) {
         // ---- C1: free twists of the two foot bodies (velocity FK down each leg), world aligned ----
         wave.par([&](int l) {
             if (l < 2) {
                 float Rw0[9], vcur[6];
-                for (int i = 0; i < 9; ++i) Rw0[i] = S.Rw[0][i];
-                m3tv(Rw0, S.wwf, vcur);
-                m3tv(Rw0, S.vowf, vcur + 3);
+                for (int i = 0; i < 9; ++i) Rw0[i] = S.RwK[0][i];
+                m3tv(Rw0, S.B.post.wwf, vcur);
+                m3tv(Rw0, S.B.post.vowf, vcur + 3);
                 for (int i = 1; i <= 6; ++i) {
                     const int b = 6 * l + i;
                     float R[9], vn[6];
                     for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
                     xform_motion(R, S.tree.pos[b], vcur, vn);
-                    const float qd = S.qdf[b - 1];
+                    const float qd = S.B.post.qdf[b - 1];
                     vn[0] += S.tree.axis[b][0] * qd; vn[1] += S.tree.axis[b][1] * qd; vn[2] += S.tree.axis[b][2] * qd;
                     for (int j = 0; j < 6; ++j) vcur[j] = vn[j];
                 }
-                const int fb = 6 * l + 6;
                 float o[3];
-                m3v(S.Rw[fb], vcur, o);
-                for (int i = 0; i < 3; ++i) S.out.twf[l][i] = o[i];
-                m3v(S.Rw[fb], vcur + 3, o);
-                for (int i = 0; i < 3; ++i) S.out.twf[l][3 + i] = o[i];
+                m3v(S.RwK[1 + l], vcur, o);
+                for (int i = 0; i < 3; ++i) S.V.con.twf[l][i] = o[i];
+                m3v(S.RwK[1 + l], vcur + 3, o);
+                for (int i = 0; i < 3; ++i) S.V.con.twf[l][3 + i] = o[i];
             }
         });
+        DW_CKPT(7);
         // ---- C2: 12 unit-wrench responses -> inverse operational inertia W of the two feet ----
         wave.par([&](int l) {
             if (l < 12) {
                 const int f = l / 6, comp = l % 6;
-                const int fb = 6 * f + 6;
                 float ew[3] = {0, 0, 0}, eb[3];
                 ew[comp % 3] = 1.0f;
-                m3tv(S.Rw[fb], ew, eb);
+                m3tv(S.RwK[1 + f], ew, eb);
                 float dp[6] = {0, 0, 0, 0, 0, 0};
                 for (int i = 0; i < 3; ++i) dp[(comp < 3 ? 0 : 3) + i] = -eb[i];
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * f + i;
                     const float *s = S.tree.axis[b];
                     const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
-                    S.out.ducol[l][i - 1] = d;
-                    const float k = d * S.Dinv[b];
+                    S.V.con.ducol[l][i - 1] = d;
+                    const float k = d * S.C.art.Dinv[b];
                     float pa[6], R[9], up[6];
-                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * k;
+                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.C.art.U[b][j] * k;
                     for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
                     xform_force(R, S.tree.pos[b], pa, up);
                     for (int j = 0; j < 6; ++j) dp[j] = up[j];
@@ -603,7 +636,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 float dv0[6];
                 for (int r = 0; r < 6; ++r) {
                     float acc = 0.0f;
-                    for (int c = 0; c < 6; ++c) acc -= S.Minv[6 * r + c] * dp[c];
+                    for (int c = 0; c < 6; ++c) acc -= S.B.post.Minv[6 * r + c] * dp[c];
                     dv0[r] = acc;
                 }
                 for (int g = 0; g < 2; ++g) {
@@ -616,25 +649,25 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                         for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
                         xform_motion(R, S.tree.pos[b], dv, ap);
                         float ua = 0.0f;
-                        for (int j = 0; j < 6; ++j) ua += S.U[b][j] * ap[j];
-                        const float qdd = ((g == f ? S.out.ducol[l][i - 1] : 0.0f) - ua) * S.Dinv[b];
+                        for (int j = 0; j < 6; ++j) ua += S.C.art.U[b][j] * ap[j];
+                        const float qdd = ((g == f ? S.V.con.ducol[l][i - 1] : 0.0f) - ua) * S.C.art.Dinv[b];
                         ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
                         for (int j = 0; j < 6; ++j) dv[j] = ap[j];
                     }
-                    const int gb = 6 * g + 6;
                     float o[3];
-                    m3v(S.Rw[gb], dv, o);
-                    for (int i = 0; i < 3; ++i) S.out.W[6 * g + i][l] = o[i];
-                    m3v(S.Rw[gb], dv + 3, o);
-                    for (int i = 0; i < 3; ++i) S.out.W[6 * g + 3 + i][l] = o[i];
+                    m3v(S.RwK[1 + g], dv, o);
+                    for (int i = 0; i < 3; ++i) S.V.con.W[6 * g + i][l] = o[i];
+                    m3v(S.RwK[1 + g], dv + 3, o);
+                    for (int i = 0; i < 3; ++i) S.V.con.W[6 * g + 3 + i][l] = o[i];
                 }
             }
         });
+        DW_CKPT(8);
         // ---- C3: Delassus matrix A = J W J', free constraint velocities, warm start ----
         wave.par([&](int l) {
             if (l < 24) {
                 const int k = l / 3, ax = l % 3, f = k / 4;
-                const float r[3] = {S.out.rk[k][0], S.out.rk[k][1], S.out.rk[k][2]};
+                const float r[3] = {S.V.con.rk[k][0], S.V.con.rk[k][1], S.V.con.rk[k][2]};
                 // row of J on foot f: angular part = -skew(r)[ax][:] , linear part = e_ax
                 float ja[3];
                 ja[0] = ax == 1 ? -r[2] : (ax == 2 ? r[1] : 0.0f);
@@ -642,57 +675,58 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 ja[2] = ax == 0 ? -r[1] : (ax == 1 ? r[0] : 0.0f);
                 float JW0[6], JW1[6];
                 for (int c = 0; c < 6; ++c) {
-                    JW0[c] = ja[0] * S.out.W[6 * f][c] + ja[1] * S.out.W[6 * f + 1][c] + ja[2] * S.out.W[6 * f + 2][c] +
-                             S.out.W[6 * f + 3 + ax][c];
-                    JW1[c] = ja[0] * S.out.W[6 * f][6 + c] + ja[1] * S.out.W[6 * f + 1][6 + c] + ja[2] * S.out.W[6 * f + 2][6 + c] +
-                             S.out.W[6 * f + 3 + ax][6 + c];
+                    JW0[c] = ja[0] * S.V.con.W[6 * f][c] + ja[1] * S.V.con.W[6 * f + 1][c] + ja[2] * S.V.con.W[6 * f + 2][c] +
+                             S.V.con.W[6 * f + 3 + ax][c];
+                    JW1[c] = ja[0] * S.V.con.W[6 * f][6 + c] + ja[1] * S.V.con.W[6 * f + 1][6 + c] + ja[2] * S.V.con.W[6 * f + 2][6 + c] +
+                             S.V.con.W[6 * f + 3 + ax][6 + c];
                 }
                 for (int k2 = 0; k2 < 4; ++k2) {
-                    const float *r2 = S.out.rk[k2];
+                    const float *r2 = S.V.con.rk[k2];
                     // column (k2, ax2): sum_j JW[6 f2 + j] * (-skew(r2)[ax2][j]) + JW[6 f2 + 3 + ax2]
-                    S.out.A[l][3 * k2 + 0] = JW0[1] * r2[2] - JW0[2] * r2[1] + JW0[3];
-                    S.out.A[l][3 * k2 + 1] = -JW0[0] * r2[2] + JW0[2] * r2[0] + JW0[4];
-                    S.out.A[l][3 * k2 + 2] = JW0[0] * r2[1] - JW0[1] * r2[0] + JW0[5];
+                    S.A.lcp.A[l][3 * k2 + 0] = JW0[1] * r2[2] - JW0[2] * r2[1] + JW0[3];
+                    S.A.lcp.A[l][3 * k2 + 1] = -JW0[0] * r2[2] + JW0[2] * r2[0] + JW0[4];
+                    S.A.lcp.A[l][3 * k2 + 2] = JW0[0] * r2[1] - JW0[1] * r2[0] + JW0[5];
                 }
                 for (int k2 = 4; k2 < 8; ++k2) {
-                    const float *r2 = S.out.rk[k2];
-                    S.out.A[l][3 * k2 + 0] = JW1[1] * r2[2] - JW1[2] * r2[1] + JW1[3];
-                    S.out.A[l][3 * k2 + 1] = -JW1[0] * r2[2] + JW1[2] * r2[0] + JW1[4];
-                    S.out.A[l][3 * k2 + 2] = JW1[0] * r2[1] - JW1[1] * r2[0] + JW1[5];
+                    const float *r2 = S.V.con.rk[k2];
+                    S.A.lcp.A[l][3 * k2 + 0] = JW1[1] * r2[2] - JW1[2] * r2[1] + JW1[3];
+                    S.A.lcp.A[l][3 * k2 + 1] = -JW1[0] * r2[2] + JW1[2] * r2[0] + JW1[4];
+                    S.A.lcp.A[l][3 * k2 + 2] = JW1[0] * r2[1] - JW1[1] * r2[0] + JW1[5];
                 }
-                const float *tw = S.out.twf[f];
+                const float *tw = S.V.con.twf[f];
                 float t[3];
                 cross3(tw, r, t);
-                S.out.vel[1][l] = tw[3 + ax] + t[ax];
+                S.V.con.vel[1][l] = tw[3 + ax] + t[ax];
             }
         });
         wave.par([&](int l) {
             if (l < 24) {
-                float acc = S.out.vel[1][l];
-                for (int c = 0; c < 24; ++c) acc += S.out.A[l][c] * S.out.P[0][c];
-                S.out.vel[0][l] = acc;
-                S.out.invd[l] = 1.0f / (S.out.A[l][l] * (1.0f + P.cfm));
+                float acc = S.V.con.vel[1][l];
+                for (int c = 0; c < 24; ++c) acc += S.A.lcp.A[l][c] * S.V.con.P[0][c];
+                S.V.con.vel[0][l] = acc;
+                S.A.lcp.invd[l] = 1.0f / (S.A.lcp.A[l][l] * (1.0f + P.cfm));
             }
         });
+        DW_CKPT(9);
         // ---- C4: projected Gauss-Seidel.  One region per contact update; constraint velocities and
         //      impulses ping-pong between two LDS copies so no lane reads what another lane writes. ----
         int cur = 0;
         for (int it = 0; it < P.iters; ++it) {
             for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
-                if (!uniform(S.out.active[k])) continue;
+                if (!uniform(S.V.con.active[k])) continue;
                 wave.par([&](int l) {
                     if (l < 24) {
-                        const float *vel = S.out.vel[cur], *Pc = S.out.P[cur];
+                        const float *vel = S.V.con.vel[cur], *Pc = S.V.con.P[cur];
                         const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
                         const float Pz = Pc[rz], Px = Pc[rx], Py = Pc[ry];
-                        float dz = -(vel[rz] - S.out.vmin[k]) * S.out.invd[rz];
+                        float dz = -(vel[rz] - S.V.con.vmin[k]) * S.A.lcp.invd[rz];
                         float pz = Pz + dz;
                         if (pz < 0) pz = 0;
                         dz = pz - Pz;
-                        const float vx = vel[rx] + S.out.A[rx][rz] * dz;
-                        const float dx = -vx * S.out.invd[rx];
-                        const float vy = vel[ry] + S.out.A[ry][rz] * dz + S.out.A[ry][rx] * dx;
-                        const float dy = -vy * S.out.invd[ry];
+                        const float vx = vel[rx] + S.A.lcp.A[rx][rz] * dz;
+                        const float dx = -vx * S.A.lcp.invd[rx];
+                        const float vy = vel[ry] + S.A.lcp.A[ry][rz] * dz + S.A.lcp.A[ry][rx] * dx;
+                        const float dy = -vy * S.A.lcp.invd[ry];
                         float px = Px + dx, py = Py + dy;
                         const float lim = S.mu * pz, nrm = sqrtf(px * px + py * py);
                         if (nrm > lim) {
@@ -700,52 +734,52 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                             px *= sc; py *= sc;
                         }
                         const float Dx = px - Px, Dy = py - Py;
-                        S.out.vel[cur ^ 1][l] = vel[l] + S.out.A[l][rz] * dz + S.out.A[l][rx] * Dx + S.out.A[l][ry] * Dy;
-                        S.out.P[cur ^ 1][l] = l == rx ? px : (l == ry ? py : (l == rz ? pz : Pc[l]));
+                        S.V.con.vel[cur ^ 1][l] = vel[l] + S.A.lcp.A[l][rz] * dz + S.A.lcp.A[l][rx] * Dx + S.A.lcp.A[l][ry] * Dy;
+                        S.V.con.P[cur ^ 1][l] = l == rx ? px : (l == ry ? py : (l == rz ? pz : Pc[l]));
                     }
                 });
                 cur ^= 1;
             }
         }
+        DW_CKPT(10);
         // ---- C5: impulses -> wrenches on the two foot bodies -> delta-ABA over the whole tree ----
         wave.par([&](int l) {
             if (l < 2) {
-                const float *Pc = S.out.P[cur];
+                const float *Pc = S.V.con.P[cur];
                 float F[3] = {0, 0, 0}, Nm[3] = {0, 0, 0};
                 for (int k = 4 * l; k < 4 * l + 4; ++k) {
                     float t[3];
-                    cross3(S.out.rk[k], Pc + 3 * k, t);
+                    cross3(S.V.con.rk[k], Pc + 3 * k, t);
                     for (int i = 0; i < 3; ++i) { F[i] += Pc[3 * k + i]; Nm[i] += t[i]; }
                 }
-                const int fb = 6 * l + 6;
                 float dp[6], fbv[3], nbv[3];
-                m3tv(S.Rw[fb], F, fbv);
-                m3tv(S.Rw[fb], Nm, nbv);
+                m3tv(S.RwK[1 + l], F, fbv);
+                m3tv(S.RwK[1 + l], Nm, nbv);
                 for (int i = 0; i < 3; ++i) { dp[i] = -nbv[i]; dp[3 + i] = -fbv[i]; }
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * l + i;
                     const float *s = S.tree.axis[b];
                     const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
-                    S.out.du[b] = d;
-                    const float kk = d * S.Dinv[b];
+                    S.B.post.du[b] = d;
+                    const float kk = d * S.C.art.Dinv[b];
                     float pa[6], R[9], up[6];
-                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.U[b][j] * kk;
+                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.C.art.U[b][j] * kk;
                     for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
                     xform_force(R, S.tree.pos[b], pa, up);
                     for (int j = 0; j < 6; ++j) dp[j] = up[j];
                 }
-                for (int j = 0; j < 6; ++j) S.out.dpf[l][j] = dp[j];
+                for (int j = 0; j < 6; ++j) S.A.lcp.dpf[l][j] = dp[j];
                 const int gy = M.foot_gym[4 * l];
                 for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i] / dt;
             }
-            if (l >= 32 && l < 32 + 24) S.warm[l - 32] = S.out.P[cur][l - 32];
+            if (l >= 32 && l < 32 + 24) S.warm[l - 32] = S.V.con.P[cur][l - 32];
         });
         wave.par([&](int l) {
             if (l < 6) {
                 float acc = 0.0f;
-                for (int c = 0; c < 6; ++c) acc -= S.Minv[6 * l + c] * (S.out.dpf[0][c] + S.out.dpf[1][c]);
-                S.out.a[0][l] = acc;
-                S.dv0[l] = acc;
+                for (int c = 0; c < 6; ++c) acc -= S.B.post.Minv[6 * l + c] * (S.A.lcp.dpf[0][c] + S.A.lcp.dpf[1][c]);
+                S.B.post.a[0][l] = acc;
+                S.B.post.dv0[l] = acc;
             }
         });
         for (int L = 1; L <= S.tree.nlevels; ++L) {
@@ -755,14 +789,14 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     const float *s = S.tree.axis[b];
                     float R[9], apar[6], ap[6];
                     for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                    for (int i = 0; i < 6; ++i) apar[i] = S.out.a[p][i];
+                    for (int i = 0; i < 6; ++i) apar[i] = S.B.post.a[p][i];
                     xform_motion(R, S.tree.pos[b], apar, ap);
                     float ua = 0.0f;
-                    for (int i = 0; i < 6; ++i) ua += S.U[b][i] * ap[i];
-                    const float dq = (S.out.du[b] - ua) * S.Dinv[b];
-                    S.dqd[b - 1] = dq;
+                    for (int i = 0; i < 6; ++i) ua += S.C.art.U[b][i] * ap[i];
+                    const float dq = (S.B.post.du[b] - ua) * S.C.art.Dinv[b];
+                    S.B.post.dqd[b - 1] = dq;
                     ap[0] += s[0] * dq; ap[1] += s[1] * dq; ap[2] += s[2] * dq;
-                    for (int i = 0; i < 6; ++i) S.out.a[b][i] = ap[i];
+                    for (int i = 0; i < 6; ++i) S.B.post.a[b][i] = ap[i];
                 }
             });
         }
@@ -772,10 +806,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         });
     }
 
+    DW_CKPT(11);
     // ---- V2: final velocities, clamps, semi-implicit Euler ----
     wave.par([&](int l) {
         if (l < ND) {
-            float qd = S.qdf[l] + S.dqd[l];
+            float qd = S.B.post.qdf[l] + S.B.post.dqd[l];
             const float vm = M.vmax[l];
             if (qd > vm) qd = vm;
             if (qd < -vm) qd = -vm;
@@ -787,11 +822,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         }
         if (l == 40) {
             float Rw[9], wwn[3], von[3], t[3];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.Rw[0][i];
-            m3v(Rw, S.dv0, t);
-            for (int i = 0; i < 3; ++i) wwn[i] = S.wwf[i] + t[i];
-            m3v(Rw, S.dv0 + 3, t);
-            for (int i = 0; i < 3; ++i) von[i] = S.vowf[i] + t[i];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.RwK[0][i];
+            m3v(Rw, S.B.post.dv0, t);
+            for (int i = 0; i < 3; ++i) wwn[i] = S.B.post.wwf[i] + t[i];
+            m3v(Rw, S.B.post.dv0 + 3, t);
+            for (int i = 0; i < 3; ++i) von[i] = S.B.post.vowf[i] + t[i];
             const float wn = sqrtf(dot3(wwn, wwn));
             if (wn > P.max_ang_vel) {
                 const float sc = P.max_ang_vel / wn;

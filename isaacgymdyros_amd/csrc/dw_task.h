@@ -43,12 +43,20 @@ struct TaskParams {                  // wave-uniform scalars (kernel arguments)
     unsigned long long seed;
 };
 
-struct TaskBuffers {                 // device pointers (DwBuffers) + per-call pointers
-    DwBuffers b;
+struct TaskBuffers {                 // device pointers (DwBuffers, read through memory) + per-call pointers
+    const DwBuffers *b;
     const float *actions;
     const float *noise;              // [N, DW_NOISE_WORDS] or nullptr
     const float *mocap;              // [3600, 36]
     long long    step;
+};
+
+// Launch-invariant parameters, resident in device memory: the kernels take ONE pointer instead of ~45 by-value
+// words, which is what kept the scalar register file spilling in the first version of dw_k_step.
+struct DevParams {
+    TaskParams C;
+    DwBuffers  B;
+    const float *mocap;
 };
 
 constexpr int GATE_BUCKETS = 32;     // gate_acc layout: [slot 0..2][bucket 0..31][2] int64, latch at [192]
@@ -277,7 +285,7 @@ DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskPara
 // ---------------------------------------------------------------------------------------------- the step
 template <class W>
 DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
-    const DwBuffers &B = T.b;
+    const DwBuffers &B = *T.b;
     NoiseSrc nz;
     nz.rec = T.noise ? T.noise + (size_t)DW_NOISE_WORDS * e : nullptr;
     nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)T.step; nz.stream = 0;
@@ -637,7 +645,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
 // reset_done path (tasks/base/vec_task.py:376-391 -> reset_idx): one env
 template <class W>
 DW_HD void reset_only_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
-    const DwBuffers &B = T.b;
+    const DwBuffers &B = *T.b;
     NoiseSrc nz;
     nz.rec = T.noise ? T.noise + (size_t)DW_NOISE_WORDS * e : nullptr;
     nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)T.step; nz.stream = 1;

@@ -68,7 +68,7 @@ int dwe_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "actions is null");
     dw::TaskBuffers T;
-    T.b = h->buf; T.actions = actions; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
+    T.b = &h->buf; T.actions = actions; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
     dw::Lds *S = new dw::Lds;
     dw::Wave w;
     for (int e = 0; e < h->cfg.num_envs; ++e) dw::step_env(w, *S, h->model, h->params, T, e);
@@ -79,7 +79,7 @@ int dwe_reset_idx(DwHandle *h, const int32_t *ids, int32_t n, const float *noise
     if (!h || !h->bound || !h->model.has_task) return fail(DW_ESTATE, "not ready");
     if (n < 0 || (n > 0 && !ids)) return fail(DW_EINVAL, "bad env id list");
     dw::TaskBuffers T;
-    T.b = h->buf; T.actions = nullptr; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
+    T.b = &h->buf; T.actions = nullptr; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
     dw::Lds *S = new dw::Lds;
     dw::Wave w;
     for (int i = 0; i < n; ++i) {
