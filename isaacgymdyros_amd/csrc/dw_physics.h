@@ -708,6 +708,59 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             }
         });
         DW_CKPT(9);
+#if defined(__HIPCC__)
+        // ---- C4 (device form): projected Gauss-Seidel with each constraint row resident in registers.  Lane r < 24
+        //      owns row r of A (24 registers), its constraint velocity and its impulse; a contact update broadcasts
+        //      the 12 scalars it needs with v_readlane (lane indices are compile-time) instead of a round trip
+        //      through LDS per update.  Same arithmetic, same update order as the LDS form below, which is what the
+        //      host emulation runs and what documents the algorithm.
+        int cur = 0;
+        {
+            int act[DW_NUM_FOOT_PTS];
+            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) act[k] = uniform(S.V.con.active[k]);
+            const int l = (int)threadIdx.x;
+            const int row = l < 24 ? l : 0;
+            float Arow[24];
+            for (int c = 0; c < 24; ++c) Arow[c] = S.A.lcp.A[row][c];
+            float vel = S.V.con.vel[0][row], Pl = S.V.con.P[0][row];
+            const float invd = S.A.lcp.invd[row];
+            float vminr[DW_NUM_FOOT_PTS];
+            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) vminr[k] = S.V.con.vmin[k];
+            const float mu = S.mu;
+            auto bc = [](float x, int lane) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+            };
+            for (int it = 0; it < P.iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
+                    if (!act[k]) continue;
+                    const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
+                    const float Pz = bc(Pl, rz), Px = bc(Pl, rx), Py = bc(Pl, ry);
+                    float dz = -(bc(vel, rz) - vminr[k]) * bc(invd, rz);
+                    float pz = Pz + dz;
+                    if (pz < 0) pz = 0;
+                    dz = pz - Pz;
+                    const float vx = bc(vel, rx) + bc(Arow[rz], rx) * dz;
+                    const float dx = -vx * bc(invd, rx);
+                    const float vy = bc(vel, ry) + bc(Arow[rz], ry) * dz + bc(Arow[rx], ry) * dx;
+                    const float dy = -vy * bc(invd, ry);
+                    float px = Px + dx, py = Py + dy;
+                    const float lim = mu * pz, nrm = sqrtf(px * px + py * py);
+                    if (nrm > lim) {
+                        const float sc = nrm > 0 ? lim / nrm : 0.0f;
+                        px *= sc; py *= sc;
+                    }
+                    const float Dx = px - Px, Dy = py - Py;
+                    vel = vel + Arow[rz] * dz + Arow[rx] * Dx + Arow[ry] * Dy;
+                    Pl = l == rx ? px : (l == ry ? py : (l == rz ? pz : Pl));
+                }
+            }
+            if (l < 24) S.V.con.P[0][l] = Pl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#else
         // ---- C4: projected Gauss-Seidel.  One region per contact update; constraint velocities and
         //      impulses ping-pong between two LDS copies so no lane reads what another lane writes. ----
         int cur = 0;
@@ -741,6 +794,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 cur ^= 1;
             }
         }
+#endif
         DW_CKPT(10);
         // ---- C5: impulses -> wrenches on the two foot bodies -> delta-ABA over the whole tree ----
         wave.par([&](int l) {
