@@ -30,6 +30,7 @@ inline TaskParams make_task_params(const DwConfig *c) {
     t.phys.vel_at_com = c->root_vel_at_com;
     t.num_envs = c->num_envs;
     const double dtp = c->dt * c->control_freq_inv;          // python: self.dt * self.skipframe
+    t.inv_dt_f = (float)(1.0 / c->dt);
     t.dt_policy_f = (float)dtp;
     t.clock_gain_f = (float)(5 * dtp);                       // 5*self.dt_policy
     t.pert_period_f = (float)(8 / dtp);                      // 8/self.dt_policy

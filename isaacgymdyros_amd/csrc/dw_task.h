@@ -26,6 +26,7 @@ namespace dw {
 struct TaskParams {                  // wave-uniform scalars (kernel arguments)
     PhysParams phys;
     int     num_envs;
+    float   inv_dt_f;                // (float)(1.0 / dt): torch-GPU form of `x / self.dt`
     float   dt_policy_f;             // (float)(dt * controlFrequencyInv)
     float   clock_gain_f;            // (float)(5 * dt_policy)
     float   pert_period_f;           // (float)(8 / dt_policy)
@@ -99,7 +100,9 @@ DW_HD float noise_word(const NoiseSrc &nz, int w) {
 }
 
 // ---------------------------------------------------------------------------------------------- torch-flavoured scalars
-DW_HD float divs(int recip, float x, float s) { return recip ? x * (1.0f / s) : x / s; }
+// `tensor / python_scalar`: torch's CPU kernels divide by float(s); its GPU kernels multiply by float(1.0 / s) with the
+// reciprocal formed in double (probed on MI355X: x / 0.0005 == x * 2000.0f for every x)
+DW_HD float divs(int recip, float x, double s) { return recip ? x * (float)(1.0 / s) : x / (float)s; }
 DW_HD float remainder_t(float a, float b) {
     float m = fmodf(a, b);
     if (m != 0 && ((b < 0) != (m < 0))) m += b;
@@ -226,11 +229,11 @@ DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskPara
             S.qd[l] = 0.0f;
         }
         if (l < 12) {
-            S.es[DW_ES_QPOS_BIAS + l] = divs(C.gpu_div, noise_word(nz, DW_NZ_QPOS_BIAS + l) * 6.28f, 100.0f) - (float)(3.14 / 100);
+            S.es[DW_ES_QPOS_BIAS + l] = divs(C.gpu_div, noise_word(nz, DW_NZ_QPOS_BIAS + l) * 6.28f, 100.0) - (float)(3.14 / 100);
             S.es[DW_ES_MOTOR_SCALE + l] = noise_word(nz, DW_NZ_MOTOR + l) * 0.4f + 0.8f;
             S.es[DW_ES_ACTION_TORQUE_PRE + l] = 0.0f;
         }
-        if (l < 3) S.es[DW_ES_QUAT_BIAS + l] = divs(C.gpu_div, noise_word(nz, DW_NZ_QUAT_BIAS + l) * 6.28f, 150.0f) - (float)(3.14 / 150);
+        if (l < 3) S.es[DW_ES_QUAT_BIAS + l] = divs(C.gpu_div, noise_word(nz, DW_NZ_QUAT_BIAS + l) * 6.28f, 150.0) - (float)(3.14 / 150);
         if (l >= 16 && l < 29) {
             const int i = l - 16;
             const float r0[13] = {0, 0, C.initial_height, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
@@ -291,6 +294,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
     nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)T.step; nz.stream = 0;
     const float period = (float)(3599 * 0.0005), cdt = 0.0005f;
     const float dt = C.phys.dt;
+    const double cdt_d = 0.0005;
     long long *gate = reinterpret_cast<long long *>(B.gate_acc);
     const int slot_prev = (int)((T.step + 2) % 3), slot_cur = (int)(T.step % 3), slot_next = (int)((T.step + 1) % 3);
 
@@ -316,7 +320,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             const int init_idx = ESI(DW_ES_INIT_MOCAP);
             const float local_time = remainder_t(time, period);
             S.scratch[0] = remainder_t(local_time + (float)init_idx * cdt, period);
-            const int midx = (int)(((long long)init_idx + (long long)divs(C.gpu_div, local_time, cdt)) % 3599);
+            const int midx = (int)(((long long)init_idx + (long long)divs(C.gpu_div, local_time, cdt_d)) % 3599);
             ESI(DW_ES_MOCAP_IDX) = midx;
         }
         if (l == 33) {
@@ -409,7 +413,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             if (l < ND) {
                 const float n = noise_word(nz, DW_NZ_ENC + ND * sub + l);
                 const float qn = S.q[l] + fminf(fmaxf(n, -0.00016f), 0.00016f);
-                S.es[DW_ES_QVEL_NOISE + l] = divs(C.gpu_div, qn - S.es[DW_ES_QPOS_PRE + l], dt);
+                S.es[DW_ES_QVEL_NOISE + l] = C.gpu_div ? (qn - S.es[DW_ES_QPOS_PRE + l]) * C.inv_dt_f : (qn - S.es[DW_ES_QPOS_PRE + l]) / dt;
                 S.es[DW_ES_QPOS_NOISE + l] = qn;
                 S.es[DW_ES_QPOS_PRE + l] = qn;
             }
@@ -514,7 +518,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
             const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
             S.rterm[12] = dd ? -0.05f * 1.0f : 0.0f;
-            const float ws = divs(C.gpu_div, tm, 104.48f);
+            const float ws = divs(C.gpu_div, tm, 104.48);
             const float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * S.es[DW_ES_TARGET_FORCE]));
             const float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * S.es[DW_ES_TARGET_FORCE + 1]));
             S.rterm[13] = tl + tr;
@@ -574,8 +578,8 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             } else if (l < 27) {
                 o = S.es[DW_ES_QVEL_NOISE + (l - 15)];
             } else if (l < 29) {
-                const float time2idx = divs(C.gpu_div, remainder_t(S.es[DW_ES_TIME], period), cdt);
-                const float phase = divs(C.gpu_div, remainder_t((float)ESI(DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0f);
+                const float time2idx = divs(C.gpu_div, remainder_t(S.es[DW_ES_TIME], period), cdt_d);
+                const float phase = divs(C.gpu_div, remainder_t((float)ESI(DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
                 const float ang = (float)(2 * 3.14159265358979) * phase;
                 o = l == 27 ? sinf(ang) : cosf(ang);
             } else if (l < 31) {

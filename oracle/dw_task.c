@@ -61,8 +61,9 @@ static float noise_word(const Noise *nz, int w) {
 }
 
 /* ------------------------------------------------------------------ torch-flavoured scalar helpers */
-/* tensor / python_scalar: true division in torch's CPU kernels, tensor * (1/scalar) in its GPU kernels */
-static inline float divs_(int recip, float x, float s) { return recip ? x * (1.0f / s) : x / s; }
+/* tensor / python_scalar: division by float(s) in torch's CPU kernels, multiplication by float(1.0/s) (reciprocal
+ * formed in double) in its GPU kernels -- probed on MI355X: x / 0.0005 == x * 2000.0f */
+static inline float divs_(int recip, float x, double s) { return recip ? x * (float)(1.0 / s) : x / (float)s; }
 #define divs(x, s) divs_(h->cfg.torch_gpu_div, (x), (s))
 
 /* torch.remainder for floats: fmod, then shifted into the sign of the divisor */
@@ -165,9 +166,9 @@ static void reset_env(DwHandle *h, int e, const Noise *nz) {
         es[DW_ES_QVEL_NOISE + j] = 0.0f;
     }
     for (int i = 0; i < 12; ++i)
-        es[DW_ES_QPOS_BIAS + i] = divs(noise_word(nz, DW_NZ_QPOS_BIAS + i) * 6.28f, 100.0f) - (float)(3.14 / 100);
+        es[DW_ES_QPOS_BIAS + i] = divs(noise_word(nz, DW_NZ_QPOS_BIAS + i) * 6.28f, 100.0) - (float)(3.14 / 100);
     for (int i = 0; i < 3; ++i)
-        es[DW_ES_QUAT_BIAS + i] = divs(noise_word(nz, DW_NZ_QUAT_BIAS + i) * 6.28f, 150.0f) - (float)(3.14 / 150);
+        es[DW_ES_QUAT_BIAS + i] = divs(noise_word(nz, DW_NZ_QUAT_BIAS + i) * 6.28f, 150.0) - (float)(3.14 / 150);
     /* root and dof state */
     float *root = b->root_states + 13 * e;
     const float init_root[13] = {0, 0, cfg->initial_height, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
@@ -242,9 +243,9 @@ static void observe_env(DwHandle *h, int e, const Noise *nz) {
     obs[2] = ez + es[DW_ES_QUAT_BIAS + 2];
     for (int i = 0; i < 12; ++i) obs[3 + i] = es[DW_ES_QPOS_NOISE + i] + es[DW_ES_QPOS_BIAS + i];
     for (int i = 0; i < 12; ++i) obs[15 + i] = es[DW_ES_QVEL_NOISE + i];
-    const float period = (float)(3599 * 0.0005), cdt = 0.0005f;
-    float time2idx = divs(remainder_t(es[DW_ES_TIME], period), cdt);
-    float phase = divs(remainder_t((float)*esi(es, DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0f);
+    const float period = (float)(3599 * 0.0005);
+    float time2idx = divs(remainder_t(es[DW_ES_TIME], period), 0.0005);
+    float phase = divs(remainder_t((float)*esi(es, DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
     float ang = (float)(2 * 3.14159265358979) * phase;
     obs[27] = sinf(ang);
     obs[28] = cosf(ang);
@@ -340,7 +341,7 @@ static void reward_env(DwHandle *h, int e, int *reset_out) {
         r[12] = (ld || rd) ? -0.05f * 1.0f : 0.0f;
     }
     {
-        float ws = divs(tm, 104.48f);
+        float ws = divs(tm, 104.48);
         float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * es[DW_ES_TARGET_FORCE]));
         float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * es[DW_ES_TARGET_FORCE + 1]));
         r[13] = tl + tr;
@@ -380,7 +381,6 @@ static void step_env(DwHandle *h, int e, const float *actions, const float *nois
     float *es = ES(h, e);
     Noise nz = {noise ? noise + (size_t)DW_NOISE_WORDS * e : NULL, cfg->seed, (uint32_t)e, (uint64_t)step, 0};
     const float period = (float)(3599 * 0.0005), cdt = 0.0005f;
-    const float dt = (float)cfg->dt;
     const double dt_policy_d = cfg->dt * cfg->control_freq_inv;     /* python: self.dt * self.skipframe */
 
     /* ---------------- pre_physics_step ---------------- */
@@ -388,7 +388,7 @@ static void step_env(DwHandle *h, int e, const float *actions, const float *nois
     int init_idx = *esi(es, DW_ES_INIT_MOCAP);
     float local_time = remainder_t(time, period);
     float lt_plus = remainder_t(local_time + (float)init_idx * cdt, period);
-    int mocap_idx = (int)(((int64_t)init_idx + (int64_t)divs(local_time, cdt)) % 3599);
+    int mocap_idx = (int)(((int64_t)init_idx + (int64_t)divs(local_time, 0.0005)) % 3599);
     int next_idx = mocap_idx + 1;
     *esi(es, DW_ES_MOCAP_IDX) = mocap_idx;
     const float *row0 = h->mocap + (size_t)mocap_idx * DW_MOCAP_COLS, *row1 = h->mocap + (size_t)next_idx * DW_MOCAP_COLS;
@@ -459,7 +459,7 @@ static void step_env(DwHandle *h, int e, const float *actions, const float *nois
         for (int j = 0; j < 33; ++j) {
             float nzv = noise_word(&nz, DW_NZ_ENC + 33 * sub + j);
             float qn = (float)io.q[j] + fminf(fmaxf(nzv, -0.00016f), 0.00016f);
-            es[DW_ES_QVEL_NOISE + j] = divs(qn - es[DW_ES_QPOS_PRE + j], dt);
+            es[DW_ES_QVEL_NOISE + j] = divs(qn - es[DW_ES_QPOS_PRE + j], cfg->dt);
             es[DW_ES_QPOS_NOISE + j] = qn;
             es[DW_ES_QPOS_PRE + j] = qn;
         }

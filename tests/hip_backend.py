@@ -11,6 +11,9 @@ def make_env(N, **mi):
     cfg = default_cfg(N, "cuda:0")
     dr = mi.pop("randomize", True)
     cfg["task"]["randomize"] = dr
+    if mi.pop("friction_dr", False):
+        from isaacgymdyros_amd.config import with_friction_randomization
+        cfg = with_friction_randomization(cfg)
     cfg["sim"]["mi355"].update(mi)
     return DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 
