@@ -160,6 +160,15 @@ DW_HD void make_PR(const float *R, const float *p, float *PR) {
         PR[c] = o[0]; PR[3 + c] = o[1]; PR[6 + c] = o[2];
     }
 }
+// 1/sqrt(x) for x > 0: hardware estimate refined by one Newton step on the device (~1 ulp), exact on the host
+DW_HD float rsqrt_nr(float x) {
+#if defined(__HIPCC__)
+    float y = __builtin_amdgcn_rsqf(x);
+    return y * (1.5f - 0.5f * x * y * y);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
 // bias acceleration of a hinge: c = v x (S qd)
 DW_HD void joint_bias(const float *v, const float *s, float qd, float *c) {
     float sq[3] = {s[0] * qd, s[1] * qd, s[2] * qd};
@@ -227,7 +236,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             const int b = l;
             const float *s = S.tree.axis[b];
             float q = S.q[b - 1];
-            float sn = sinf(q), cs = cosf(q), oc = 1.0f - cs;
+            float sn, cs;
+            sincosf(q, &sn, &cs);
+            const float oc = 1.0f - cs;
             float Rj[9] = {cs + oc * s[0] * s[0], oc * s[0] * s[1] - sn * s[2], oc * s[0] * s[2] + sn * s[1],
                            oc * s[1] * s[0] + sn * s[2], cs + oc * s[1] * s[1], oc * s[1] * s[2] - sn * s[0],
                            oc * s[2] * s[0] - sn * s[1], oc * s[2] * s[1] + sn * s[0], cs + oc * s[2] * s[2]};
@@ -310,17 +321,16 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
             float zmin;
             if (ge.type == 0) {
-                zmin = 1e30f;
-                for (int ci = 0; ci < 8; ++ci) {
-                    float e[3] = {(ci & 1 ? 1.0f : -1.0f) * ge.size[0], (ci & 2 ? 1.0f : -1.0f) * ge.size[1],
-                                  (ci & 4 ? 1.0f : -1.0f) * ge.size[2]};
-                    float lc[3], wv[3];
-                    m3v(ge.rot, e, lc);
-                    lc[0] += ge.pos[0]; lc[1] += ge.pos[1]; lc[2] += ge.pos[2];
-                    m3v(Rw, lc, wv);
-                    float z = S.B.kin.pw[b][2] + wv[2];
-                    if (z < zmin) { zmin = z; rl[0] = lc[0]; rl[1] = lc[1]; rl[2] = lc[2]; }
-                }
+                // deepest corner: along each box axis take the end that points down (world z component of the axis)
+                float Rg[9], e[3];
+                m3m(Rw, ge.rot, Rg);
+                for (int i = 0; i < 3; ++i) e[i] = (Rg[6 + i] > 0.0f ? -1.0f : 1.0f) * ge.size[i];
+                float lc[3], wv[3];
+                m3v(ge.rot, e, lc);
+                lc[0] += ge.pos[0]; lc[1] += ge.pos[1]; lc[2] += ge.pos[2];
+                m3v(Rw, lc, wv);
+                zmin = S.B.kin.pw[b][2] + wv[2];
+                rl[0] = lc[0]; rl[1] = lc[1]; rl[2] = lc[2];
             } else {
                 float al[3] = {ge.rot[2], ge.rot[5], ge.rot[8]}, aw[3];
                 m3v(Rw, al, aw);
@@ -392,13 +402,13 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     DW_CKPT(3);
-    // ---- A2: inward sweep of articulated inertias ----
+    // ---- A2: inward sweep of articulated inertias.  Twelve lanes per body: lane = (body-in-level k, row r, half h),
+    //      each lane owns the three columns 3h..3h+2 of row r (5 bodies x 12 = 60 lanes on the widest level). ----
     for (int L = S.tree.nlevels; L >= 1; --L) {
         const int cnt = S.tree.level_count[L];
-        // (packed index of entry (r, c) for this lane's row r = lane % 6 is recomputed per region: six selects)
-        // A: projection through the joint, rows of Ia*X
+        // A: projection through the joint, Ia = IA - U U'/D, rows of Ia*X
         wave.par([&](int l) {
-            const int k = l / 6, r = l % 6;
+            const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
             if (k < cnt) {
                 const int b = S.tree.level_body[L][k];
                 const float *s = S.tree.axis[b];
@@ -409,35 +419,38 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float D = dot3(s, U) + S.arm[b - 1] + dt * damp;
                 const float Dinv = 1.0f / D;
                 const float u = S.tau[b - 1] - damp * qd - (s[0] * S.V.dyn.pA[b][0] + s[1] * S.V.dyn.pA[b][1] + s[2] * S.V.dyn.pA[b][2]);
-                float vb[6], cb[6];
-                for (int i = 0; i < 6; ++i) vb[i] = S.V.dyn.v[b][i];
-                joint_bias(vb, s, qd, cb);
                 float Ia[6];
                 const float ur = U[r] * Dinv;
                 for (int c = 0; c < 6; ++c) Ia[c] = IA[sym6(r, c)] - ur * U[c];
-                float pa = S.V.dyn.pA[b][r] + U[r] * (u * Dinv);
-                for (int c = 0; c < 6; ++c) pa += Ia[c] * cb[c];
-                S.B.sw.pa[k][r] = pa;
                 float R[9], PR[9];
                 for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
                 make_PR(R, S.tree.pos[b], PR);
-                for (int c = 0; c < 3; ++c) {
-                    S.B.sw.T[k][6 * r + c] = Ia[0] * R[3 * c] + Ia[1] * R[3 * c + 1] + Ia[2] * R[3 * c + 2] +
-                                           Ia[3] * PR[3 * c] + Ia[4] * PR[3 * c + 1] + Ia[5] * PR[3 * c + 2];
-                    S.B.sw.T[k][6 * r + 3 + c] = Ia[3] * R[3 * c] + Ia[4] * R[3 * c + 1] + Ia[5] * R[3 * c + 2];
-                }
-                if (r == 0) {
-                    for (int j = 0; j < 6; ++j) S.C.art.U[b][j] = U[j];
-                    S.C.art.Dinv[b] = Dinv;
-                    S.C.art.u[b] = u;
+                // half 0: T[r][c] = Ia[0:3].R_c + Ia[3:6].PR_c ; half 1: T[r][3+c] = Ia[3:6].R_c
+                const float a0 = h ? Ia[3] : Ia[0], a1 = h ? Ia[4] : Ia[1], a2 = h ? Ia[5] : Ia[2];
+                const float b0 = h ? 0.0f : Ia[3], b1 = h ? 0.0f : Ia[4], b2 = h ? 0.0f : Ia[5];
+                for (int c = 0; c < 3; ++c)
+                    S.B.sw.T[k][6 * r + 3 * h + c] = a0 * R[3 * c] + a1 * R[3 * c + 1] + a2 * R[3 * c + 2] +
+                                                     b0 * PR[3 * c] + b1 * PR[3 * c + 1] + b2 * PR[3 * c + 2];
+                if (h == 0) {
+                    float vb[6], cb[6];
+                    for (int i = 0; i < 6; ++i) vb[i] = S.V.dyn.v[b][i];
+                    joint_bias(vb, s, qd, cb);
+                    float pa = S.V.dyn.pA[b][r] + U[r] * (u * Dinv);
+                    for (int c = 0; c < 6; ++c) pa += Ia[c] * cb[c];
+                    S.B.sw.pa[k][r] = pa;
+                    if (r == 0) {
+                        for (int j = 0; j < 6; ++j) S.C.art.U[b][j] = U[j];
+                        S.C.art.Dinv[b] = Dinv;
+                        S.C.art.u[b] = u;
+                    }
                 }
             }
         });
         // B: X' (Ia X) and X' pa, written over the child's own storage (now "contribution to the parent").
-        //    Row q of R and row q of skew(p)*R are read / formed from LDS directly (a register array indexed
-        //    by the lane's row would live in scratch memory).
+        //    Row q of R and of skew(p)*R come straight from LDS (a register array indexed by the lane's row would
+        //    live in scratch memory).
         wave.par([&](int l) {
-            const int k = l / 6, r = l % 6;
+            const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
             if (k < cnt) {
                 const int b = S.tree.level_body[L][k];
                 const int q = r < 3 ? r : r - 3;
@@ -445,42 +458,42 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float *Rb = S.R[b];
                 const float *pp = S.tree.pos[b];
                 const float Rq[3] = {Rb[3 * q], Rb[3 * q + 1], Rb[3 * q + 2]};
-                float PRq[3] = {0.0f, 0.0f, 0.0f};
-                if (r < 3) {
-                    const float p1 = pp[q1], p2 = pp[q2];
-                    for (int c = 0; c < 3; ++c) PRq[c] = p1 * Rb[3 * q2 + c] - p2 * Rb[3 * q1 + c];
+                const float p1 = r < 3 ? pp[q1] : 0.0f, p2 = r < 3 ? pp[q2] : 0.0f;
+                float PRq[3];
+                for (int c = 0; c < 3; ++c) PRq[c] = p1 * Rb[3 * q2 + c] - p2 * Rb[3 * q1 + c];
+                const float *T = S.B.sw.T[k] + (r < 3 ? 0 : 18) + 3 * h;
+                const float *T2 = S.B.sw.T[k] + 18 + 3 * h;
+                for (int c = 0; c < 3; ++c) {
+                    const float o = Rq[0] * T[c] + Rq[1] * T[6 + c] + Rq[2] * T[12 + c] +
+                                    PRq[0] * T2[c] + PRq[1] * T2[6 + c] + PRq[2] * T2[12 + c];
+                    if (3 * h + c >= r) S.A.IA[b][sym6(r, 3 * h + c)] = o;
                 }
-                const float *T = S.B.sw.T[k] + (r < 3 ? 0 : 18);
-                const float *T2 = S.B.sw.T[k] + 18;
-                const float *pa = S.B.sw.pa[k] + (r < 3 ? 0 : 3);
-                const float *pa2 = S.B.sw.pa[k] + 3;
-                float out[6];
-                for (int c = 0; c < 6; ++c)
-                    out[c] = Rq[0] * T[c] + Rq[1] * T[6 + c] + Rq[2] * T[12 + c] +
-                             PRq[0] * T2[c] + PRq[1] * T2[6 + c] + PRq[2] * T2[12 + c];
-                const float po = Rq[0] * pa[0] + Rq[1] * pa[1] + Rq[2] * pa[2] +
-                                 PRq[0] * pa2[0] + PRq[1] * pa2[1] + PRq[2] * pa2[2];
-                for (int c = 0; c < 6; ++c)
-                    if (c >= r) S.A.IA[b][sym6(r, c)] = out[c];
-                S.V.dyn.pA[b][r] = po;
+                if (h == 0) {
+                    const float *pa = S.B.sw.pa[k] + (r < 3 ? 0 : 3);
+                    const float *pa2 = S.B.sw.pa[k] + 3;
+                    S.V.dyn.pA[b][r] = Rq[0] * pa[0] + Rq[1] * pa[1] + Rq[2] * pa[2] +
+                                       PRq[0] * pa2[0] + PRq[1] * pa2[1] + PRq[2] * pa2[2];
+                }
             }
         });
-        // C: parents (one level up) gather their children, fixed order
+        // C: parents (one level up) gather their children, fixed order (three slots, absent children add zero)
         const int pcnt = (L == 1) ? 1 : S.tree.level_count[L - 1];
         wave.par([&](int l) {
-            const int k = l / 6, r = l % 6;
+            const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
             if (k < pcnt) {
                 const int p = (L == 1) ? 0 : S.tree.level_body[L - 1][k];
-                float acc[6], pacc = S.V.dyn.pA[p][r];
-                for (int c = 0; c < 6; ++c) acc[c] = S.A.IA[p][sym6(r, c)];
-                for (int ci = 0; ci < S.tree.nchild[p]; ++ci) {
-                    const int ch = S.tree.child[p][ci];
-                    for (int c = 0; c < 6; ++c) acc[c] += S.A.IA[ch][sym6(r, c)];
-                    pacc += S.V.dyn.pA[ch][r];
+                const int nch = S.tree.nchild[p];
+                const int c0 = S.tree.child[p][0], c1 = nch > 1 ? S.tree.child[p][1] : c0, c2 = nch > 2 ? S.tree.child[p][2] : c0;
+                const float w1 = nch > 1 ? 1.0f : 0.0f, w2 = nch > 2 ? 1.0f : 0.0f;
+                if (nch > 0) {
+                    for (int c = 3 * h; c < 3 * h + 3; ++c) {
+                        const int ix = sym6(r, c);
+                        if (c >= r)
+                            S.A.IA[p][ix] = S.A.IA[p][ix] + S.A.IA[c0][ix] + w1 * S.A.IA[c1][ix] + w2 * S.A.IA[c2][ix];
+                    }
+                    if (h == 0)
+                        S.V.dyn.pA[p][r] = S.V.dyn.pA[p][r] + S.V.dyn.pA[c0][r] + w1 * S.V.dyn.pA[c1][r] + w2 * S.V.dyn.pA[c2][r];
                 }
-                for (int c = 0; c < 6; ++c)
-                    if (c >= r) S.A.IA[p][sym6(r, c)] = acc[c];
-                S.V.dyn.pA[p][r] = pacc;
             }
         });
     }
@@ -492,27 +505,28 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             float Lc[36];
             const float *Mx = S.A.IA[0];
             for (int i = 0; i < 36; ++i) Lc[i] = 0.0f;
+            float dinv[6];                         // 1 / L_jj
             for (int j = 0; j < 6; ++j) {
                 float d = Mx[sym6(j, j)];
                 for (int k = 0; k < j; ++k) d -= Lc[6 * j + k] * Lc[6 * j + k];
-                d = sqrtf(d);
-                Lc[6 * j + j] = d;
+                dinv[j] = rsqrt_nr(d);
+                Lc[6 * j + j] = d * dinv[j];
                 for (int i = j + 1; i < 6; ++i) {
                     float s = Mx[sym6(i, j)];
                     for (int k = 0; k < j; ++k) s -= Lc[6 * i + k] * Lc[6 * j + k];
-                    Lc[6 * i + j] = s / d;
+                    Lc[6 * i + j] = s * dinv[j];
                 }
             }
             float y[6], x[6];
             for (int i = 0; i < 6; ++i) {
                 float s = (i == l) ? 1.0f : 0.0f;
                 for (int k = 0; k < i; ++k) s -= Lc[6 * i + k] * y[k];
-                y[i] = s / Lc[6 * i + i];
+                y[i] = s * dinv[i];
             }
             for (int i = 5; i >= 0; --i) {
                 float s = y[i];
                 for (int k = i + 1; k < 6; ++k) s -= Lc[6 * k + i] * x[k];
-                x[i] = s / Lc[6 * i + i];
+                x[i] = s * dinv[i];
             }
             for (int i = 0; i < 6; ++i) S.B.post.Minv[6 * i + l] = x[i];
         }
@@ -745,9 +759,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     const float vy = bc(vel, ry) + bc(Arow[rz], ry) * dz + bc(Arow[rx], ry) * dx;
                     const float dy = -vy * bc(invd, ry);
                     float px = Px + dx, py = Py + dy;
-                    const float lim = mu * pz, nrm = sqrtf(px * px + py * py);
-                    if (nrm > lim) {
-                        const float sc = nrm > 0 ? lim / nrm : 0.0f;
+                    const float lim = mu * pz, n2 = px * px + py * py;
+                    if (n2 > lim * lim) {                      // |p_t| > mu p_n: scale onto the cone, lim / |p_t|
+                        const float sc = lim * rsqrt_nr(n2);
                         px *= sc; py *= sc;
                     }
                     const float Dx = px - Px, Dy = py - Py;
@@ -881,25 +895,30 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 3; ++i) wwn[i] = S.B.post.wwf[i] + t[i];
             m3v(Rw, S.B.post.dv0 + 3, t);
             for (int i = 0; i < 3; ++i) von[i] = S.B.post.vowf[i] + t[i];
-            const float wn = sqrtf(dot3(wwn, wwn));
-            if (wn > P.max_ang_vel) {
-                const float sc = P.max_ang_vel / wn;
-                wwn[0] *= sc; wwn[1] *= sc; wwn[2] *= sc;
+            {
+                const float wn2 = dot3(wwn, wwn);
+                if (wn2 > P.max_ang_vel * P.max_ang_vel) {
+                    const float sc = P.max_ang_vel * rsqrt_nr(wn2);
+                    wwn[0] *= sc; wwn[1] *= sc; wwn[2] *= sc;
+                }
             }
             for (int i = 0; i < 3; ++i) S.root[i] += dt * von[i];
-            const float wmag = sqrtf(dot3(wwn, wwn));
-            const float th = wmag * dt;
-            float dq[4] = {0, 0, 0, 1};
-            if (th > 1e-12f) {
-                const float sh = sinf(th * 0.5f) / wmag;
-                dq[0] = wwn[0] * sh; dq[1] = wwn[1] * sh; dq[2] = wwn[2] * sh; dq[3] = cosf(th * 0.5f);
+            // dq = [w_hat sin(th/2), cos(th/2)], th = |w| dt <= 0.2 rad: sin(th/2)/|w| = (dt/2) * sinc(th/2)
+            const float w2 = dot3(wwn, wwn);
+            const float hx = 0.5f * dt;
+            float sh, ch;
+            {   // sinc and cos of x = |w| dt / 2 from x^2 only (no square root needed)
+                const float x2 = w2 * hx * hx;
+                sh = hx * (1.0f + x2 * (-1.0f / 6 + x2 * (1.0f / 120 + x2 * (-1.0f / 5040 + x2 * (1.0f / 362880)))));
+                ch = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24 + x2 * (-1.0f / 720 + x2 * (1.0f / 40320))));
             }
+            const float dq[4] = {wwn[0] * sh, wwn[1] * sh, wwn[2] * sh, ch};
             const float x1 = dq[0], y1 = dq[1], z1 = dq[2], w1 = dq[3];
-            const float x2 = S.quat[0], y2 = S.quat[1], z2 = S.quat[2], w2 = S.quat[3];
-            float qn[4] = {w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
-                           w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2};
-            const float n = sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
-            for (int i = 0; i < 4; ++i) { qn[i] /= n; S.root[3 + i] = qn[i]; }
+            const float x2q = S.quat[0], y2 = S.quat[1], z2 = S.quat[2], w2q = S.quat[3];
+            float qn[4] = {w1 * x2q + x1 * w2q + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2q + z1 * x2q,
+                           w1 * z2 + x1 * y2 - y1 * x2q + z1 * w2q, w1 * w2q - x1 * x2q - y1 * y2 - z1 * z2};
+            const float ninv = rsqrt_nr(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+            for (int i = 0; i < 4; ++i) { qn[i] *= ninv; S.root[3 + i] = qn[i]; }
             if (P.vel_at_com) {
                 float Rn[9], rc[3], tt[3];
                 quat_to_mat(qn, Rn);

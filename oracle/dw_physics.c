@@ -306,17 +306,15 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
         real rl[3] = {0, 0, 0};   /* deepest point, body coords */
         real zmin;
         if (ge->type == 0) {
-            zmin = 1e30f;
-            for (int cidx = 0; cidx < 8; ++cidx) {
-                real e[3] = {(cidx & 1 ? 1 : -1) * ge->size[0], (cidx & 2 ? 1 : -1) * ge->size[1],
-                             (cidx & 4 ? 1 : -1) * ge->size[2]};
-                real l[3], wv[3];
-                m3v(ge->rot, e, l);
-                l[0] += ge->pos[0]; l[1] += ge->pos[1]; l[2] += ge->pos[2];
-                m3v(w.Rw[b], l, wv);
-                real z = w.pw[b][2] + wv[2];
-                if (z < zmin) { zmin = z; rl[0] = l[0]; rl[1] = l[1]; rl[2] = l[2]; }
-            }
+            /* deepest corner of the box: along each box axis take the end that points down */
+            real Rg[9], e[3], l[3], wv[3];
+            m3m(w.Rw[b], ge->rot, Rg);
+            for (int i = 0; i < 3; ++i) e[i] = (Rg[6 + i] > 0 ? (real)-1 : (real)1) * ge->size[i];
+            m3v(ge->rot, e, l);
+            l[0] += ge->pos[0]; l[1] += ge->pos[1]; l[2] += ge->pos[2];
+            m3v(w.Rw[b], l, wv);
+            zmin = w.pw[b][2] + wv[2];
+            rl[0] = l[0]; rl[1] = l[1]; rl[2] = l[2];
         } else {
             /* cylinder: lowest point of the lower cap rim */
             real al[3] = {ge->rot[2], ge->rot[5], ge->rot[8]};   /* axis, body coords */
