@@ -722,12 +722,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             }
         });
         DW_CKPT(9);
+        // ---- C4: projected Gauss-Seidel, block-Jacobi across the feet.  Corner kk of the left sole (rows 3kk..) and
+        //      corner kk of the right sole (rows 12+3kk..) are updated together from the same velocity snapshot --
+        //      the feet only couple through the trunk -- and the four corners of a sole sequentially: 4 updates per
+        //      sweep instead of 8.  Per contact: normal row, friction rows with the normal's effect folded in,
+        //      projection onto the Coulomb cone.
 #if defined(__HIPCC__)
-        // ---- C4 (device form): projected Gauss-Seidel with each constraint row resident in registers.  Lane r < 24
-        //      owns row r of A (24 registers), its constraint velocity and its impulse; a contact update broadcasts
-        //      the 12 scalars it needs with v_readlane (lane indices are compile-time) instead of a round trip
-        //      through LDS per update.  Same arithmetic, same update order as the LDS form below, which is what the
-        //      host emulation runs and what documents the algorithm.
+        //      Device form: lane r < 24 keeps row r of A (24 registers), its velocity and impulse in registers; the
+        //      scalars of both contacts of a pair are broadcast with v_readlane (compile-time lane ids) and the
+        //      impulse arithmetic runs wave-uniformly, so there is no LDS traffic inside the solver at all.
         int cur = 0;
         {
             int act[DW_NUM_FOOT_PTS];
@@ -746,27 +749,39 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             };
             for (int it = 0; it < P.iters; ++it) {
 #pragma unroll
-                for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
-                    if (!act[k]) continue;
-                    const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
-                    const float Pz = bc(Pl, rz), Px = bc(Pl, rx), Py = bc(Pl, ry);
-                    float dz = -(bc(vel, rz) - vminr[k]) * bc(invd, rz);
-                    float pz = Pz + dz;
-                    if (pz < 0) pz = 0;
-                    dz = pz - Pz;
-                    const float vx = bc(vel, rx) + bc(Arow[rz], rx) * dz;
-                    const float dx = -vx * bc(invd, rx);
-                    const float vy = bc(vel, ry) + bc(Arow[rz], ry) * dz + bc(Arow[rx], ry) * dx;
-                    const float dy = -vy * bc(invd, ry);
-                    float px = Px + dx, py = Py + dy;
-                    const float lim = mu * pz, n2 = px * px + py * py;
-                    if (n2 > lim * lim) {                      // |p_t| > mu p_n: scale onto the cone, lim / |p_t|
-                        const float sc = lim * rsqrt_nr(n2);
-                        px *= sc; py *= sc;
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (!(act[kk] | act[kk + 4])) continue;
+                    float D[2][3], pn[2][3];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int k = kk + 4 * f;
+                        const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
+                        const float Pz = bc(Pl, rz), Px = bc(Pl, rx), Py = bc(Pl, ry);
+                        float dz = -(bc(vel, rz) - vminr[k]) * bc(invd, rz);
+                        float pz = Pz + dz;
+                        if (pz < 0) pz = 0;
+                        dz = pz - Pz;
+                        const float vx = bc(vel, rx) + bc(Arow[rz], rx) * dz;
+                        const float dx = -vx * bc(invd, rx);
+                        const float vy = bc(vel, ry) + bc(Arow[rz], ry) * dz + bc(Arow[rx], ry) * dx;
+                        const float dy = -vy * bc(invd, ry);
+                        float px = Px + dx, py = Py + dy;
+                        const float lim = mu * pz, n2 = px * px + py * py;
+                        if (n2 > lim * lim) {
+                            const float sc = lim * rsqrt_nr(n2);
+                            px *= sc; py *= sc;
+                        }
+                        const bool on = act[k] != 0;
+                        D[f][0] = on ? px - Px : 0.0f; D[f][1] = on ? py - Py : 0.0f; D[f][2] = on ? dz : 0.0f;
+                        pn[f][0] = on ? px : Px; pn[f][1] = on ? py : Py; pn[f][2] = on ? pz : Pz;
                     }
-                    const float Dx = px - Px, Dy = py - Py;
-                    vel = vel + Arow[rz] * dz + Arow[rx] * Dx + Arow[ry] * Dy;
-                    Pl = l == rx ? px : (l == ry ? py : (l == rz ? pz : Pl));
+                    vel = vel + Arow[3 * kk + 2] * D[0][2] + Arow[3 * kk] * D[0][0] + Arow[3 * kk + 1] * D[0][1]
+                              + Arow[12 + 3 * kk + 2] * D[1][2] + Arow[12 + 3 * kk] * D[1][0] + Arow[12 + 3 * kk + 1] * D[1][1];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int r0 = 3 * (kk + 4 * f);
+                        Pl = l == r0 ? pn[f][0] : (l == r0 + 1 ? pn[f][1] : (l == r0 + 2 ? pn[f][2] : Pl));
+                    }
                 }
             }
             if (l < 24) S.V.con.P[0][l] = Pl;
@@ -775,34 +790,47 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #else
-        // ---- C4: projected Gauss-Seidel.  One region per contact update; constraint velocities and
-        //      impulses ping-pong between two LDS copies so no lane reads what another lane writes. ----
+        //      Host-emulation form (and the readable statement of the algorithm): one region per pair of contacts,
+        //      velocities and impulses ping-pong between two LDS copies so no lane reads what another lane writes.
         int cur = 0;
         for (int it = 0; it < P.iters; ++it) {
-            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
-                if (!uniform(S.V.con.active[k])) continue;
+            for (int kk = 0; kk < 4; ++kk) {
+                if (!(uniform(S.V.con.active[kk]) | uniform(S.V.con.active[kk + 4]))) continue;
                 wave.par([&](int l) {
                     if (l < 24) {
                         const float *vel = S.V.con.vel[cur], *Pc = S.V.con.P[cur];
-                        const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
-                        const float Pz = Pc[rz], Px = Pc[rx], Py = Pc[ry];
-                        float dz = -(vel[rz] - S.V.con.vmin[k]) * S.A.lcp.invd[rz];
-                        float pz = Pz + dz;
-                        if (pz < 0) pz = 0;
-                        dz = pz - Pz;
-                        const float vx = vel[rx] + S.A.lcp.A[rx][rz] * dz;
-                        const float dx = -vx * S.A.lcp.invd[rx];
-                        const float vy = vel[ry] + S.A.lcp.A[ry][rz] * dz + S.A.lcp.A[ry][rx] * dx;
-                        const float dy = -vy * S.A.lcp.invd[ry];
-                        float px = Px + dx, py = Py + dy;
-                        const float lim = S.mu * pz, nrm = sqrtf(px * px + py * py);
-                        if (nrm > lim) {
-                            const float sc = nrm > 0 ? lim / nrm : 0.0f;
-                            px *= sc; py *= sc;
+                        float d[2][3] = {{0, 0, 0}, {0, 0, 0}}, pn[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                        for (int f = 0; f < 2; ++f) {
+                            const int k = kk + 4 * f;
+                            const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
+                            const float Pz = Pc[rz], Px = Pc[rx], Py = Pc[ry];
+                            pn[f][0] = Px; pn[f][1] = Py; pn[f][2] = Pz;
+                            if (!S.V.con.active[k]) continue;
+                            float dz = -(vel[rz] - S.V.con.vmin[k]) * S.A.lcp.invd[rz];
+                            float pz = Pz + dz;
+                            if (pz < 0) pz = 0;
+                            dz = pz - Pz;
+                            const float vx = vel[rx] + S.A.lcp.A[rx][rz] * dz;
+                            const float dx = -vx * S.A.lcp.invd[rx];
+                            const float vy = vel[ry] + S.A.lcp.A[ry][rz] * dz + S.A.lcp.A[ry][rx] * dx;
+                            const float dy = -vy * S.A.lcp.invd[ry];
+                            float px = Px + dx, py = Py + dy;
+                            const float lim = S.mu * pz, n2 = px * px + py * py;
+                            if (n2 > lim * lim) {
+                                const float sc = lim * rsqrt_nr(n2);
+                                px *= sc; py *= sc;
+                            }
+                            d[f][0] = px - Px; d[f][1] = py - Py; d[f][2] = dz;
+                            pn[f][0] = px; pn[f][1] = py; pn[f][2] = pz;
                         }
-                        const float Dx = px - Px, Dy = py - Py;
-                        S.V.con.vel[cur ^ 1][l] = vel[l] + S.A.lcp.A[l][rz] * dz + S.A.lcp.A[l][rx] * Dx + S.A.lcp.A[l][ry] * Dy;
-                        S.V.con.P[cur ^ 1][l] = l == rx ? px : (l == ry ? py : (l == rz ? pz : Pc[l]));
+                        S.V.con.vel[cur ^ 1][l] = vel[l] + S.A.lcp.A[l][3 * kk + 2] * d[0][2] + S.A.lcp.A[l][3 * kk] * d[0][0] +
+                                                  S.A.lcp.A[l][3 * kk + 1] * d[0][1] + S.A.lcp.A[l][12 + 3 * kk + 2] * d[1][2] +
+                                                  S.A.lcp.A[l][12 + 3 * kk] * d[1][0] + S.A.lcp.A[l][12 + 3 * kk + 1] * d[1][1];
+                        float pv = Pc[l];
+                        for (int f = 0; f < 2; ++f)
+                            for (int i = 0; i < 3; ++i)
+                                if (l == 3 * (kk + 4 * f) + i) pv = pn[f][i];
+                        S.V.con.P[cur ^ 1][l] = pv;
                     }
                 });
                 cur ^= 1;

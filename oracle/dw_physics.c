@@ -542,33 +542,42 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
             vel[r] += sacc;
         }
         const real mu = io->mu;
+        /* Projected Gauss-Seidel, block-Jacobi across the feet: corner kk of the left sole and corner kk of the right
+         * sole are updated together from the same velocity snapshot (the feet only couple through the trunk), corners
+         * of one sole sequentially.  Per contact: normal row, then the two friction rows with the normal's effect
+         * folded in, then projection onto the Coulomb cone. */
+        real invd[24];
+        for (int r = 0; r < 24; ++r) invd[r] = 1 / (Amat[r][r] * (1 + cfg->contact_cfm));
         for (int it = 0; it < cfg->solver_iterations; ++it)
-            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
-                if (!active[k]) continue;
-                const int rz = 3 * k + 2, rx = 3 * k, ry = 3 * k + 1;
-                /* normal */
-                real dz = -(vel[rz] - vmin[k]) / (Amat[rz][rz] * (1 + cfg->contact_cfm));
-                real pz = P[k][2] + dz;
-                if (pz < 0) pz = 0;
-                dz = pz - P[k][2];
-                P[k][2] = pz;
-                for (int r = 0; r < 24; ++r) vel[r] += Amat[r][rz] * dz;
-                /* friction, one axis at a time, then cone projection */
-                real dx = -vel[rx] / (Amat[rx][rx] * (1 + cfg->contact_cfm));
-                for (int r = 0; r < 24; ++r) vel[r] += Amat[r][rx] * dx;
-                real px = P[k][0] + dx;
-                real dy = -vel[ry] / (Amat[ry][ry] * (1 + cfg->contact_cfm));
-                for (int r = 0; r < 24; ++r) vel[r] += Amat[r][ry] * dy;
-                real py = P[k][1] + dy;
-                real lim = mu * pz, nrm = RSQRT(px * px + py * py);
-                real cx = px, cy = py;
-                if (nrm > lim) {
-                    real sc = nrm > 0 ? lim / nrm : 0;
-                    cx = px * sc; cy = py * sc;
-                    real ex = cx - px, ey = cy - py;
-                    for (int r = 0; r < 24; ++r) vel[r] += Amat[r][rx] * ex + Amat[r][ry] * ey;
+            for (int kk = 0; kk < 4; ++kk) {
+                real d[2][3] = {{0, 0, 0}, {0, 0, 0}};       /* (Dx, Dy, dz) of the left / right contact */
+                real pn[2][3];
+                for (int f = 0; f < 2; ++f) {
+                    const int k = kk + 4 * f;
+                    if (!active[k]) continue;
+                    const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
+                    real dz = -(vel[rz] - vmin[k]) * invd[rz];
+                    real pz = P[k][2] + dz;
+                    if (pz < 0) pz = 0;
+                    dz = pz - P[k][2];
+                    real vx = vel[rx] + Amat[rx][rz] * dz;
+                    real dx = -vx * invd[rx];
+                    real vy = vel[ry] + Amat[ry][rz] * dz + Amat[ry][rx] * dx;
+                    real dy = -vy * invd[ry];
+                    real px = P[k][0] + dx, py = P[k][1] + dy;
+                    real lim = mu * pz, n2 = px * px + py * py;
+                    if (n2 > lim * lim) {
+                        real sc = lim / RSQRT(n2);
+                        px *= sc; py *= sc;
+                    }
+                    d[f][0] = px - P[k][0]; d[f][1] = py - P[k][1]; d[f][2] = dz;
+                    pn[f][0] = px; pn[f][1] = py; pn[f][2] = pz;
                 }
-                P[k][0] = cx; P[k][1] = cy;
+                for (int r = 0; r < 24; ++r)
+                    vel[r] = vel[r] + Amat[r][3 * kk + 2] * d[0][2] + Amat[r][3 * kk] * d[0][0] + Amat[r][3 * kk + 1] * d[0][1]
+                                    + Amat[r][12 + 3 * kk + 2] * d[1][2] + Amat[r][12 + 3 * kk] * d[1][0] + Amat[r][12 + 3 * kk + 1] * d[1][1];
+                for (int f = 0; f < 2; ++f)
+                    if (active[kk + 4 * f]) for (int i = 0; i < 3; ++i) P[kk + 4 * f][i] = pn[f][i];
             }
         /* propagate the impulses through the whole tree */
         real dp[NB][6], dv[NB][6];
