@@ -74,6 +74,7 @@ struct Lds {
             float qdd[ND], qdf[ND], dqd[ND];
             float wwf[3], vowf[3], dv0[6];
             float Minv[36];
+            float part[MAX_PER_LEVEL][3];   // per-column partial sums of U'a in the outward sweeps
         } post;
     } B;
     union {                         // block V
@@ -249,22 +250,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     DW_CKPT(1);
-    // ---- K2: forward kinematics and velocities, level by level ----
+    // ---- K2: forward kinematics and velocities, level by level; three lanes per body (lane = body-in-level, column) ----
     for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
-            if (l < S.tree.level_count[L]) {
-                const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
-                float R[9], Rp[9], Rw[9], t[3], vp[6], vb[6];
-                for (int i = 0; i < 9; ++i) { R[i] = S.R[b][i]; Rp[i] = S.B.kin.Rw[p][i]; }
-                m3m(Rp, R, Rw);
-                for (int i = 0; i < 9; ++i) S.B.kin.Rw[b][i] = Rw[i];
-                m3v(Rp, S.tree.pos[b], t);
-                for (int i = 0; i < 3; ++i) S.B.kin.pw[b][i] = S.B.kin.pw[p][i] + t[i];
-                for (int i = 0; i < 6; ++i) vp[i] = S.V.dyn.v[p][i];
-                xform_motion(R, S.tree.pos[b], vp, vb);
-                float qd = S.qd[b - 1];
-                vb[0] += S.tree.axis[b][0] * qd; vb[1] += S.tree.axis[b][1] * qd; vb[2] += S.tree.axis[b][2] * qd;
-                for (int i = 0; i < 6; ++i) S.V.dyn.v[b][i] = vb[i];
+            const int k = l / 3, c = l - 3 * k;
+            if (k < S.tree.level_count[L]) {
+                const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
+                const float *Rp = S.B.kin.Rw[p], *Rb = S.R[b], *pos = S.tree.pos[b], *vp = S.V.dyn.v[p];
+                const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];           // column c of R
+                for (int i = 0; i < 3; ++i) S.B.kin.Rw[b][3 * i + c] = Rp[3 * i] * r0 + Rp[3 * i + 1] * r1 + Rp[3 * i + 2] * r2;
+                S.B.kin.pw[b][c] = S.B.kin.pw[p][c] + Rp[3 * c] * pos[0] + Rp[3 * c + 1] * pos[1] + Rp[3 * c + 2] * pos[2];
+                // w_b = R' w_p + s qd ; v_b = R' (v_p + w_p x p): component c uses column c of R
+                const float t0 = vp[1] * pos[2] - vp[2] * pos[1], t1 = vp[2] * pos[0] - vp[0] * pos[2], t2 = vp[0] * pos[1] - vp[1] * pos[0];
+                S.V.dyn.v[b][c] = r0 * vp[0] + r1 * vp[1] + r2 * vp[2] + S.tree.axis[b][c] * S.qd[b - 1];
+                S.V.dyn.v[b][3 + c] = r0 * (vp[3] + t0) + r1 * (vp[4] + t1) + r2 * (vp[5] + t2);
             }
         });
     }
@@ -542,23 +541,34 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     DW_CKPT(5);
-    // ---- A4: outward sweep of accelerations ----
+    // ---- A4: outward sweep of accelerations; three lanes per body (column c of the transform), two regions per level:
+    //      a' = X a_parent + c_b and the per-column part of U'a', then qdd = (u - U'a') / D and a = a' + S qdd ----
     for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
-            if (l < S.tree.level_count[L]) {
-                const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
-                const float *s = S.tree.axis[b];
-                float R[9], apar[6], ap[6], vb[6], cb[6];
-                for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                for (int i = 0; i < 6; ++i) { apar[i] = S.B.post.a[p][i]; vb[i] = S.V.dyn.v[b][i]; }
-                xform_motion(R, S.tree.pos[b], apar, ap);
-                joint_bias(vb, s, S.qd[b - 1], cb);
-                float ua = 0.0f;
-                for (int i = 0; i < 6; ++i) { ap[i] += cb[i]; ua += S.C.art.U[b][i] * ap[i]; }
+            const int k = l / 3, c = l - 3 * k;
+            if (k < S.tree.level_count[L]) {
+                const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
+                const int c1 = c == 2 ? 0 : c + 1, c2 = c == 0 ? 2 : c - 1;
+                const float *Rb = S.R[b], *pos = S.tree.pos[b], *ap = S.B.post.a[p], *vb = S.V.dyn.v[b], *ax = S.tree.axis[b];
+                const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];
+                const float t0 = ap[1] * pos[2] - ap[2] * pos[1], t1 = ap[2] * pos[0] - ap[0] * pos[2], t2 = ap[0] * pos[1] - ap[1] * pos[0];
+                const float qd = S.qd[b - 1];
+                const float s1 = ax[c1] * qd, s2 = ax[c2] * qd;
+                const float ang = r0 * ap[0] + r1 * ap[1] + r2 * ap[2] + (vb[c1] * s2 - vb[c2] * s1);
+                const float lin = r0 * (ap[3] + t0) + r1 * (ap[4] + t1) + r2 * (ap[5] + t2) + (vb[3 + c1] * s2 - vb[3 + c2] * s1);
+                S.B.post.a[b][c] = ang;
+                S.B.post.a[b][3 + c] = lin;
+                S.B.post.part[k][c] = S.C.art.U[b][c] * ang + S.C.art.U[b][3 + c] * lin;
+            }
+        });
+        wave.par([&](int l) {
+            const int k = l / 3, c = l - 3 * k;
+            if (k < S.tree.level_count[L]) {
+                const int b = S.tree.level_body[L][k];
+                const float ua = S.B.post.part[k][0] + S.B.post.part[k][1] + S.B.post.part[k][2];
                 const float qdd = (S.C.art.u[b] - ua) * S.C.art.Dinv[b];
-                S.B.post.qdd[b - 1] = qdd;
-                ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
-                for (int i = 0; i < 6; ++i) S.B.post.a[b][i] = ap[i];
+                if (c == 0) S.B.post.qdd[b - 1] = qdd;
+                S.B.post.a[b][c] += S.tree.axis[b][c] * qdd;
             }
         });
     }
@@ -878,21 +888,29 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 S.B.post.dv0[l] = acc;
             }
         });
-        for (int L = 1; L <= S.tree.nlevels; ++L) {
+        for (int L = 1; L <= S.tree.nlevels; ++L) {       // same two-region, three-lane form as A4, without the bias term
             wave.par([&](int l) {
-                if (l < S.tree.level_count[L]) {
-                    const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
-                    const float *s = S.tree.axis[b];
-                    float R[9], apar[6], ap[6];
-                    for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                    for (int i = 0; i < 6; ++i) apar[i] = S.B.post.a[p][i];
-                    xform_motion(R, S.tree.pos[b], apar, ap);
-                    float ua = 0.0f;
-                    for (int i = 0; i < 6; ++i) ua += S.C.art.U[b][i] * ap[i];
+                const int k = l / 3, c = l - 3 * k;
+                if (k < S.tree.level_count[L]) {
+                    const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
+                    const float *Rb = S.R[b], *pos = S.tree.pos[b], *ap = S.B.post.a[p];
+                    const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];
+                    const float t0 = ap[1] * pos[2] - ap[2] * pos[1], t1 = ap[2] * pos[0] - ap[0] * pos[2], t2 = ap[0] * pos[1] - ap[1] * pos[0];
+                    const float ang = r0 * ap[0] + r1 * ap[1] + r2 * ap[2];
+                    const float lin = r0 * (ap[3] + t0) + r1 * (ap[4] + t1) + r2 * (ap[5] + t2);
+                    S.B.post.a[b][c] = ang;
+                    S.B.post.a[b][3 + c] = lin;
+                    S.B.post.part[k][c] = S.C.art.U[b][c] * ang + S.C.art.U[b][3 + c] * lin;
+                }
+            });
+            wave.par([&](int l) {
+                const int k = l / 3, c = l - 3 * k;
+                if (k < S.tree.level_count[L]) {
+                    const int b = S.tree.level_body[L][k];
+                    const float ua = S.B.post.part[k][0] + S.B.post.part[k][1] + S.B.post.part[k][2];
                     const float dq = (S.B.post.du[b] - ua) * S.C.art.Dinv[b];
-                    S.B.post.dqd[b - 1] = dq;
-                    ap[0] += s[0] * dq; ap[1] += s[1] * dq; ap[2] += s[2] * dq;
-                    for (int i = 0; i < 6; ++i) S.B.post.a[b][i] = ap[i];
+                    if (c == 0) S.B.post.dqd[b - 1] = dq;
+                    S.B.post.a[b][c] += S.tree.axis[b][c] * dq;
                 }
             });
         }
