@@ -390,7 +390,11 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
     // ---- P3: two physics substeps with the actuator model around them ----
     // unrolled on purpose: as a loop, ~45 lane-constant model loads were hoisted out of it and kept live across the
     // whole substep body, which at the 168-register cap meant spilling them (188 B/lane of scratch)
+#if !defined(DW_ROLL_SUBSTEPS)
 #pragma unroll
+#else
+#pragma clang loop unroll(disable)
+#endif
     for (int sub = 0; sub < 2; ++sub) {
         wave.par([&](int l) {
             if (l < 12) {

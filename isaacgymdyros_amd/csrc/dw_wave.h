@@ -19,7 +19,10 @@
 namespace dw {
 struct Wave {
     template <class F> DW_HD void par(F &&f) const {
-        f((int)threadIdx.x);
+        // (tried: laundering the lane id through an empty asm per region, to stop lane-derived LDS addresses
+        //  from being kept live across regions -- fewer registers, but the recomputed address arithmetic cost 8 %)
+        const int lane = (int)threadIdx.x;
+        f(lane);
         // End of region.  The workgroup IS the wave, and a wave's LDS instructions execute in program order, so
         // no s_barrier (and no vmcnt drain) is needed: a wavefront-scope fence keeps the compiler from moving
         // LDS/global accesses across the region boundary and emits no instruction.
