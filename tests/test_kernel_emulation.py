@@ -84,3 +84,32 @@ def test_physics_substep_vs_oracle_random_flight():
         B.simulate(tau, push)
     assert np.abs(A.buf["dof_state"][:, :, 0] - B.buf["dof_state"][:, :, 0]).max() < 1e-4
     assert np.abs(A.buf["root_states"] - B.buf["root_states"]).max() < 1e-4
+
+
+def _gate_roundtrip(make, N=40):
+    """Population gate (tasks/dyros_dynamic_walk.py:489): means of epi_len_log and contact_reward_mean over ALL envs
+    decide whether pushes start; here via deterministic int64 bucket sums written by step t and read by step t+1."""
+    from isaacgymdyros_amd import abi
+    sim = make(N)
+    es = sim.buf["env_state"]
+    acts = np.zeros((N, 13), np.float32)
+    sim.step(acts, None, 0)
+    assert not abi.es_view(es, "perturb_start").any() and sim.buf["gate_acc"][abi.K["DW_GATE_LATCH"]] == 0
+    # pretend the population has learned to walk: long episodes, synchronised contacts
+    abi.es_view(es, "epi_len_log")[:] = 7000.0
+    abi.es_view(es, "contact_reward_mean")[:] = 0.18
+    sim.step(acts, None, 1)              # accumulates the statistics of step 1
+    assert not abi.es_view(es, "perturb_start").any()
+    sim.step(acts, None, 2)              # reads them: gate opens, latch is set
+    assert abi.es_view(es, "perturb_start").all() and sim.buf["gate_acc"][abi.K["DW_GATE_LATCH"]] == 1
+    abi.es_view(es, "epi_len_log")[:] = 0.0
+    sim.step(acts, None, 3)
+    sim.step(acts, None, 4)              # statistics dropped, the latch keeps the pushes on
+    assert abi.es_view(es, "perturb_start").all()
+    return sim.buf["gate_acc"].copy()
+
+
+def test_perturbation_gate_latches_identically(task_const):
+    a = _gate_roundtrip(lambda N: OracleSim(N, task_const=task_const, debug_freeze_physics=1))
+    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, debug_freeze_physics=1))
+    assert np.array_equal(a, b)
