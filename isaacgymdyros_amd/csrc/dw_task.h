@@ -474,17 +474,18 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             S.rterm[14] = aerr;
             S.rterm[0] = 0.3f * expf(-13.2f * aerr);
         }
-        if (l == 41) {
-            const float n = norm_fn([&](int j) { return S.es[DW_ES_TARGET_QPOS + j] - S.q[j]; }, ND);
-            S.rterm[1] = 0.35f * expf(-2.0f * (n * n));
-        }
-        if (l == 42) {
-            const float n = norm_fn([&](int j) { return 0.0f - S.qd[j]; }, ND);
-            S.rterm[2] = 0.05f * expf(-0.01f * (n * n));
-        }
-        if (l == 43) {
-            const float n = norm_fn([&](int j) { return S.qd[j] - S.es[DW_ES_PRE_QVEL + j]; }, ND);
-            S.rterm[7] = 0.05f * expf(-20.0f * (n * n));
+        if (l >= 8 && l < 32) {
+            // three 33-element norms at once: lanes 8..15 / 16..23 / 24..31 hold the 8 fused accumulators of
+            // torch's CPU reduction for qpos error / qvel / qacc; the combine happens in Q3
+            const int which = (l - 8) >> 3, a = (l - 8) & 7;
+            float acc = 0.0f;
+            for (int d = 0; d < 32; d += 8) {
+                const int j = d + a;
+                const float x = which == 0 ? S.es[DW_ES_TARGET_QPOS + j] - S.q[j]
+                              : (which == 1 ? 0.0f - S.qd[j] : S.qd[j] - S.es[DW_ES_PRE_QVEL + j]);
+                acc = fmaf(x, x, acc);
+            }
+            S.normed[(which << 3) + a] = acc; // normed[] is free until Q4
         }
         if (l == 44) {
             S.rterm[4] = 0.05f * expf(-0.01f * norm_fn([&](int i) { return S.es[DW_ES_ACTIONS + i] * 333.0f; }, 12));
@@ -529,6 +530,20 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             const float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * S.es[DW_ES_TARGET_FORCE]));
             const float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * S.es[DW_ES_TARGET_FORCE + 1]));
             S.rterm[13] = tl + tr;
+        }
+    });
+    // ---- Q2b: combine the partial sums (lanes in order, then the 33rd element fused), exp ----
+    wave.par([&](int l) {
+        if (l >= 41 && l < 44) {
+            const int which = l - 41;
+            float b0 = S.normed[which << 3];
+            for (int a = 1; a < 8; ++a) b0 = b0 + S.normed[(which << 3) + a];
+            const float x = which == 0 ? S.es[DW_ES_TARGET_QPOS + 32] - S.q[32]
+                          : (which == 1 ? 0.0f - S.qd[32] : S.qd[32] - S.es[DW_ES_PRE_QVEL + 32]);
+            b0 = fmaf(x, x, b0);
+            const float n = sqrtf(b0);
+            const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
+            S.rterm[which == 0 ? 1 : (which == 1 ? 2 : 7)] = coef * expf(rate * (n * n));
         }
     });
     // ---- Q3: total reward, termination ----
@@ -576,9 +591,11 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
                 const float m22 = w * w - x * x - y * y + z * z;
                 const float cy = sqrtf(m00 * m00 + m10 * m10);
                 const bool cond = cy > (float)(2.220446049250313e-16 * 4);
-                if (l == 0) o = cond ? atan2f(m21, m22) : 0.0f;
-                else if (l == 1) o = atan2f(-m20, cy);
-                else o = cond ? atan2f(m10, m00) : atan2f(-m01, m11);
+                // one atan2 call for the three lanes: (num, den) per Euler angle (mat2euler, torch_utils.py:248-269)
+                const float num = l == 0 ? m21 : (l == 1 ? -m20 : (cond ? m10 : -m01));
+                const float den = l == 0 ? m22 : (l == 1 ? cy : (cond ? m00 : m11));
+                o = atan2f(num, den);
+                if (l == 0 && !cond) o = 0.0f;
                 o = o + S.es[DW_ES_QUAT_BIAS + l];
             } else if (l < 15) {
                 o = S.es[DW_ES_QPOS_NOISE + (l - 3)] + S.es[DW_ES_QPOS_BIAS + (l - 3)];
@@ -588,7 +605,9 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
                 const float time2idx = divs(C.gpu_div, remainder_t(S.es[DW_ES_TIME], period), cdt_d);
                 const float phase = divs(C.gpu_div, remainder_t((float)ESI(DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
                 const float ang = (float)(2 * 3.14159265358979) * phase;
-                o = l == 27 ? sinf(ang) : cosf(ang);
+                float sn, cs;
+                sincosf(ang, &sn, &cs);
+                o = l == 27 ? sn : cs;
             } else if (l < 31) {
                 o = S.es[DW_ES_TARGET_VEL + (l - 29)];
             } else {
