@@ -313,6 +313,20 @@ class DyrosDynamicWalk(VecTask):
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
         _lib.check(self._api, self._api["simulate"](self._h, t.data_ptr(), p, stream))
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything the next step() depends on: the device buffers and the step counter that keys the in-kernel
+        RNG.  The reference never checkpoints simulation state (rl_games only saves the policy); here it is free."""
+        torch.cuda.synchronize(self._tdev)
+        d = {k: v.detach().clone() for k, v in self._buf.items()}
+        d["_step_count"] = self._step_count
+        return d
+
+    def load_state_dict(self, d):
+        for k, v in self._buf.items():
+            v.copy_(d[k].to(v.device))
+        self._step_count = int(d["_step_count"])
+
     def close(self):
         if getattr(self, "_h", None) is not None:
             torch.cuda.synchronize(self._tdev)

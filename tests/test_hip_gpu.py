@@ -292,3 +292,19 @@ def test_perturbation_gate_on_device():
     slot = 1
     tot_epi = acc[slot * 64: slot * 64 + 64: 2].sum()
     assert tot_epi == 7000 * N
+
+
+def test_state_dict_roundtrip_resumes_bitwise():
+    from hip_backend import make_env
+    env = make_env(256)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    acts = [torch.rand(256, 13, generator=g, device="cuda") * 2 - 1 for _ in range(20)]
+    for a in acts[:10]:
+        env.step(a)
+    ck = env.state_dict()
+    ref = [tuple(t.clone() for t in (env.step(a)[0]["obs"], env.rew_buf, env.reset_buf)) for a in acts[10:]]
+    env2 = make_env(256)
+    env2.load_state_dict(ck)
+    for a, r in zip(acts[10:], ref):
+        o = env2.step(a)
+        assert torch.equal(o[0]["obs"], r[0]) and torch.equal(env2.rew_buf, r[1]) and torch.equal(env2.reset_buf, r[2])
