@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 1
+#define DW_ABI_VERSION 2
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -52,6 +52,8 @@ extern "C" {
 #define DW_NUM_INERT    36   /* bodies that carry an <inertial>                           */
 #define DW_MAX_GEOMS    64
 #define DW_NUM_FOOT_PTS  8   /* 4 sole corners per foot                                   */
+#define DW_MAX_SC_PROXIES 16  /* capsule proxies for self-collision                        */
+#define DW_MAX_SC_PAIRS   16  /* proxy pairs tested each substep                           */
 #define DW_NUM_ACT      13   /* 12 leg torques + 1 gait-clock action                      */
 #define DW_NUM_LOWER    12
 #define DW_NUM_OBS1     37   /* single-step observation                                   */
@@ -84,6 +86,15 @@ typedef struct DwGeom {
     float   _pad;
 } DwGeom;
 
+/* Capsule proxy of a link for self-collision (the reference collides every primitive with every other one:
+ * create_actor(..., group=i, filter=0), tasks/dyros_dynamic_walk.py:354).  Segment end points in the moving body's
+ * frame. */
+typedef struct DwCapsule {
+    int32_t moving, gym;
+    float   p0[3], p1[3];
+    float   radius;
+} DwCapsule;
+
 typedef struct DwModel {
     int32_t mv_parent[DW_NUM_MOVING];
     int32_t mv_gym[DW_NUM_MOVING];
@@ -105,6 +116,10 @@ typedef struct DwModel {
     int32_t foot_gym[DW_NUM_FOOT_PTS];
     float   foot_pos[DW_NUM_FOOT_PTS][3];
     int32_t left_foot_gym, right_foot_gym, pelvis_gym;
+    int32_t num_sc_proxies;
+    DwCapsule sc_proxy[DW_MAX_SC_PROXIES];
+    int32_t num_sc_pairs;
+    int32_t sc_pair[DW_MAX_SC_PAIRS][2];   /* indices into sc_proxy */
 } DwModel;
 
 /* Task constants the reference hard-codes (tasks/dyros_dynamic_walk.py:58-70,95-100,296-301) or loads
@@ -150,6 +165,7 @@ typedef struct DwConfig {
     int32_t root_vel_at_com;            /* 1 = root linear velocity is the COM's (PhysX convention)   */
     int32_t torch_gpu_div;              /* 1 = `tensor / python_scalar` is tensor * (1/scalar), as torch's GPU
                                            kernels compute it; 0 = true division, as torch's CPU kernels do */
+    int32_t self_collision;             /* 1 = leg-vs-leg capsule self-collision; 0 = ground contacts only */
     int32_t debug_freeze_physics;       /* 1 = simulate() leaves the state untouched (task-logic parity tests) */
     uint64_t seed;                      /* key of the counter-based in-kernel RNG                     */
 } DwConfig;

@@ -63,6 +63,7 @@ class DwConfig(C.Structure):
         ("timeout_fix", C.c_int32),
         ("root_vel_at_com", C.c_int32),
         ("torch_gpu_div", C.c_int32),
+        ("self_collision", C.c_int32),
         ("debug_freeze_physics", C.c_int32),
         ("seed", C.c_uint64),
     ]

@@ -38,7 +38,7 @@ def default_cfg(num_envs: int = 4096, sim_device: str = "cuda:0") -> dict:
             # knobs of THIS simulator's contact model (no PhysX counterpart; DESIGN.md "Physics model")
             "mi355": {"erp": 0.2, "contact_cfm": 1e-3, "penalty_stiffness": 1.0e5, "penalty_damping": 1.0e3,
                       "plane_friction": 1.0,             # cfg/terrain/terrain_cfg.py:7-8
-                      "root_vel_at_com": True, "torch_gpu_div": True, "timeout_fix": False,
+                      "self_collision": True, "root_vel_at_com": True, "torch_gpu_div": True, "timeout_fix": False,
                       "force_perturb_start": False},
         },
         "task": {

@@ -17,6 +17,7 @@ constexpr int MAX_PER_LEVEL = 5;    // widest level (legs + arms + neck)
 constexpr int MAX_CHILD = 3;
 constexpr int MAX_BODY_GEOMS = 8;
 constexpr int MAX_BODY_INERT = 2;
+constexpr int MAX_BODY_PAIRS = 4;    // self-collision pairs one body takes part in
 
 struct DevModel {
     // tree
@@ -49,6 +50,12 @@ struct DevModel {
     float   foot_pos[DW_NUM_FOOT_PTS][3];
     int32_t foot_body[2];                     // moving body of the left / right sole
     int32_t left_foot_gym, right_foot_gym;
+    // self-collision capsule proxies and pairs; per body the pairs it takes part in (entry = pair*2 + side)
+    int32_t num_sc_pairs;
+    DwCapsule sc_proxy[DW_MAX_SC_PROXIES];
+    int32_t sc_pair[DW_MAX_SC_PAIRS][2];
+    int32_t body_npair[NB];
+    int32_t body_pair[NB][MAX_BODY_PAIRS];
     // task constants
     float   kp[ND], kv[ND], action_high[ND], q_init[ND];
     float   obs_mean[DW_NUM_OBS1], obs_inv_std_den[DW_NUM_OBS1];   // second = sqrt(var + 1e-8), the divisor
@@ -116,6 +123,25 @@ inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, c
     }
     d->left_foot_gym = m->left_foot_gym;
     d->right_foot_gym = m->right_foot_gym;
+    if (m->num_sc_proxies < 0 || m->num_sc_proxies > DW_MAX_SC_PROXIES || m->num_sc_pairs < 0 || m->num_sc_pairs > DW_MAX_SC_PAIRS) {
+        *err = "model: self-collision tables out of range"; return DW_EINVAL;
+    }
+    d->num_sc_pairs = m->num_sc_pairs;
+    for (int k = 0; k < m->num_sc_proxies; ++k) {
+        d->sc_proxy[k] = m->sc_proxy[k];
+        if (m->sc_proxy[k].moving < 0 || m->sc_proxy[k].moving >= NB || m->sc_proxy[k].gym < 0 || m->sc_proxy[k].gym >= DW_NUM_BODIES) {
+            *err = "model: self-collision proxy index out of range"; return DW_EINVAL;
+        }
+    }
+    for (int k = 0; k < m->num_sc_pairs; ++k)
+        for (int side = 0; side < 2; ++side) {
+            const int pr = m->sc_pair[k][side];
+            if (pr < 0 || pr >= m->num_sc_proxies) { *err = "model: self-collision pair index out of range"; return DW_EINVAL; }
+            d->sc_pair[k][side] = pr;
+            const int b = m->sc_proxy[pr].moving;
+            if (d->body_npair[b] >= MAX_BODY_PAIRS) { *err = "model: too many self-collision pairs on one body"; return DW_EINVAL; }
+            d->body_pair[b][d->body_npair[b]++] = 2 * k + side;
+        }
     if (t) {
         for (int j = 0; j < ND; ++j) {
             d->kp[j] = t->kp[j]; d->kv[j] = t->kv[j]; d->action_high[j] = t->action_high[j];

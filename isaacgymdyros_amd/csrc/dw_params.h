@@ -28,6 +28,7 @@ inline TaskParams make_task_params(const DwConfig *c) {
     t.phys.pen_c = c->penalty_damping;
     t.phys.max_ang_vel = c->max_angular_velocity;
     t.phys.vel_at_com = c->root_vel_at_com;
+    t.phys.self_collision = c->self_collision;
     t.num_envs = c->num_envs;
     const double dtp = c->dt * c->control_freq_inv;          // python: self.dt * self.skipframe
     t.inv_dt_f = (float)(1.0 / c->dt);
@@ -81,6 +82,7 @@ inline void default_config(DwConfig *c) {
     c->dr_friction_scale[0] = 0.7f; c->dr_friction_scale[1] = 1.3f;
     c->root_vel_at_com = 1;
     c->torch_gpu_div = 1;
+    c->self_collision = 1;
     c->seed = 42;
 }
 

@@ -26,6 +26,7 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
     float pen_k, pen_c;
     float max_ang_vel;
     int   vel_at_com;
+    int   self_collision;
 };
 
 // The kinematic tree, staged once per launch into the env's LDS block: every sweep region indexes these by lane
@@ -49,7 +50,7 @@ DW_HD constexpr int sym6(int r, int c) {
 
 // One env's LDS block.  160 KB per CU / 13.5 KB = 12 resident envs (3 waves per SIMD); the first version of this
 // struct was 18.6 KB (8 envs).  The saving comes from overlaying arrays whose lifetimes inside a substep do not
-// intersect (phases in order: K1 K2 kinematics, K3 inertias, K4 K5 primitives, SW inward sweep, A3 base solve,
+// intersect (phases in order: K1 K2 kinematics, K4 K5 primitives and self-collision, K3 inertias, SW inward sweep, A3 base solve,
 // A4 outward sweep, V1 free velocities, C1..C5 contact, V2 integrate) and from packing the symmetric
 // articulated inertias.
 struct Lds {
@@ -89,11 +90,14 @@ struct Lds {
             float ducol[12][6];
         } con;
     } V;
-    union {                         // block C
-        struct { float gF[64][3], gr[64][3]; } geo;                             // K4 .. K5
+    struct {                        // block C
         struct { float U[NB][6], Dinv[NB], u[NB]; } art;                        // SW .. C5
     } C;
     union {                         // block A
+        struct {                                                                // K4 .. K5 (before the inertias are built)
+            float gF[64][3], gr[64][3];                                         //   ground penalty: world force, body-frame point
+            float pF[DW_MAX_SC_PAIRS][3], pa[DW_MAX_SC_PAIRS][3], pb[DW_MAX_SC_PAIRS][3];   // self-collision: force on A, points on A / B
+        } geo;
         float IA[NB][21];                                                       // K3 .. A3 (packed, sym6)
         struct { float A[24][24]; float invd[24]; float dpf[2][6]; } lcp;       // C3 .. C5
     } A;
@@ -269,48 +273,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     }
 
     DW_CKPT(2);
-    // ---- K3: rigid-body inertias, gyroscopic bias; K4: penalty contact of the non-sole primitives ----
-    wave.par([&](int l) {
-        if (l < NB) {
-            const int b = l;
-            float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, h[3] = {0, 0, 0}, mass = 0.0f;
-            for (int k = 0; k < M.ninert[b]; ++k) {
-                const int r = M.inert_idx[b][k];
-                const float ms = S.mscale[M.inert_gym[r]];
-                const float mk = ms * M.inert_mass[r];
-                const float *cm = M.inert_com[r], *I6 = M.inert_I[r];
-                const float cc = dot3(cm, cm);
-                const float Ic[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
-                for (int r3 = 0; r3 < 3; ++r3)
-                    for (int c3 = 0; c3 < 3; ++c3)
-                        A[3 * r3 + c3] += ms * Ic[3 * r3 + c3] + mk * ((r3 == c3 ? cc : 0.0f) - cm[r3] * cm[c3]);
-                h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
-                mass += mk;
-            }
-            // 6x6 = [[A, H],[H', m 1]] with H = skew(h), stored packed (upper triangle)
-            float *I = S.A.IA[b];
-            const float H[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
-            for (int r3 = 0; r3 < 3; ++r3)
-                for (int c3 = 0; c3 < 3; ++c3) {
-                    if (c3 >= r3) {
-                        I[sym6(r3, c3)] = A[3 * r3 + c3];
-                        I[sym6(r3 + 3, c3 + 3)] = (r3 == c3) ? mass : 0.0f;
-                    }
-                    I[sym6(r3, 3 + c3)] = H[3 * r3 + c3];
-                }
-            // pA = v x* (I v)
-            float om[3] = {S.V.dyn.v[b][0], S.V.dyn.v[b][1], S.V.dyn.v[b][2]}, vl[3] = {S.V.dyn.v[b][3], S.V.dyn.v[b][4], S.V.dyn.v[b][5]};
-            float n[3], f[3], t1[3], t2[3];
-            m3v(A, om, n); cross3(h, vl, t1);
-            n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
-            cross3(om, h, t1);                       // H' w = -h x w = w x h
-            f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
-            cross3(om, n, t1); cross3(vl, f, t2);
-            S.V.dyn.pA[b][0] = t1[0] + t2[0]; S.V.dyn.pA[b][1] = t1[1] + t2[1]; S.V.dyn.pA[b][2] = t1[2] + t2[2];
-            cross3(om, f, t1);
-            S.V.dyn.pA[b][3] = t1[0]; S.V.dyn.pA[b][4] = t1[1]; S.V.dyn.pA[b][5] = t1[2];
-        }
-    });
+    // ---- K4: penalty contact of the non-sole primitives against the ground (one lane per primitive) ----
     wave.par([&](int l) {
         float F[3] = {0, 0, 0}, rl[3] = {0, 0, 0};
         if (l < M.ngeom && !M.geoms[l].sole) {
@@ -364,7 +327,65 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
             }
         }
-        for (int i = 0; i < 3; ++i) { S.C.geo.gF[l][i] = F[i]; S.C.geo.gr[l][i] = rl[i]; }
+        for (int i = 0; i < 3; ++i) { S.A.geo.gF[l][i] = F[i]; S.A.geo.gr[l][i] = rl[i]; }
+    });
+    // ---- K4b: self-collision, one lane per capsule pair: closest points of the two segments, penalty force along the
+    //      normal when the capsules overlap (force on A; B gets the opposite) ----
+    wave.par([&](int l) {
+        if (l < DW_MAX_SC_PAIRS) for (int i = 0; i < 3; ++i) S.A.geo.pF[l][i] = 0.0f;
+        if (P.self_collision && l < M.num_sc_pairs) {
+            const DwCapsule &ca = M.sc_proxy[M.sc_pair[l][0]], &cb = M.sc_proxy[M.sc_pair[l][1]];
+            const int ba = ca.moving, bb = cb.moving;
+            float Ra[9], Rb[9], a0[3], a1[3], b0[3], b1[3], t3[3];
+            for (int i = 0; i < 9; ++i) { Ra[i] = S.B.kin.Rw[ba][i]; Rb[i] = S.B.kin.Rw[bb][i]; }
+            m3v(Ra, ca.p0, t3); for (int i = 0; i < 3; ++i) a0[i] = S.B.kin.pw[ba][i] + t3[i];
+            m3v(Ra, ca.p1, t3); for (int i = 0; i < 3; ++i) a1[i] = S.B.kin.pw[ba][i] + t3[i];
+            m3v(Rb, cb.p0, t3); for (int i = 0; i < 3; ++i) b0[i] = S.B.kin.pw[bb][i] + t3[i];
+            m3v(Rb, cb.p1, t3); for (int i = 0; i < 3; ++i) b1[i] = S.B.kin.pw[bb][i] + t3[i];
+            const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+            // closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9)
+            const float r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
+            const float aa = dot3(da, da), ee = dot3(db, db), ff = dot3(db, r), eps = 1e-12f;
+            float sa, sb;
+            auto c01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
+            if (aa <= eps && ee <= eps) { sa = 0.0f; sb = 0.0f; }
+            else if (aa <= eps) { sa = 0.0f; sb = c01(ff / ee); }
+            else {
+                const float cc = dot3(da, r);
+                if (ee <= eps) { sb = 0.0f; sa = c01(-cc / aa); }
+                else {
+                    const float bbv = dot3(da, db), den = aa * ee - bbv * bbv;
+                    sa = den > eps ? c01((bbv * ff - cc * ee) / den) : 0.0f;
+                    sb = (bbv * sa + ff) / ee;
+                    if (sb < 0.0f) { sb = 0.0f; sa = c01(-cc / aa); }
+                    else if (sb > 1.0f) { sb = 1.0f; sa = c01((bbv - cc) / aa); }
+                }
+            }
+            float pa[3], pb[3], n[3];
+            for (int i = 0; i < 3; ++i) { pa[i] = a0[i] + sa * da[i]; pb[i] = b0[i] + sb * db[i]; n[i] = pa[i] - pb[i]; }
+            const float dist = sqrtf(dot3(n, n));
+            const float depth = ca.radius + cb.radius - dist;
+            float F[3] = {0, 0, 0}, ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+            if (depth > 0.0f && dist > 1e-6f) {
+                for (int i = 0; i < 3; ++i) n[i] /= dist;
+                float va[3], vb[3], tt[3], vl[3];
+                for (int i = 0; i < 3; ++i) t3[i] = pa[i] - S.B.kin.pw[ba][i];
+                m3tv(Ra, t3, ra);
+                cross3(S.V.dyn.v[ba], ra, tt);
+                for (int i = 0; i < 3; ++i) vl[i] = S.V.dyn.v[ba][3 + i] + tt[i];
+                m3v(Ra, vl, va);
+                for (int i = 0; i < 3; ++i) t3[i] = pb[i] - S.B.kin.pw[bb][i];
+                m3tv(Rb, t3, rb);
+                cross3(S.V.dyn.v[bb], rb, tt);
+                for (int i = 0; i < 3; ++i) vl[i] = S.V.dyn.v[bb][3 + i] + tt[i];
+                m3v(Rb, vl, vb);
+                const float vn = (va[0] - vb[0]) * n[0] + (va[1] - vb[1]) * n[1] + (va[2] - vb[2]) * n[2];
+                float fn = P.pen_k * depth - P.pen_c * vn;
+                if (fn < 0.0f) fn = 0.0f;
+                F[0] = fn * n[0]; F[1] = fn * n[1]; F[2] = fn * n[2];
+            }
+            for (int i = 0; i < 3; ++i) { S.A.geo.pF[l][i] = F[i]; S.A.geo.pa[l][i] = ra[i]; S.A.geo.pb[l][i] = rb[i]; }
+        }
     });
     // K5: external forces into the bias of their bodies; per-body net contact force
     wave.par([&](int l) {
@@ -375,13 +396,27 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             float dn[3] = {0, 0, 0}, df[3] = {0, 0, 0};
             for (int k = 0; k < M.body_ngeom[b]; ++k) {
                 const int g = M.body_geom[b][k];
-                float F[3] = {S.C.geo.gF[g][0], S.C.geo.gF[g][1], S.C.geo.gF[g][2]};
+                float F[3] = {S.A.geo.gF[g][0], S.A.geo.gF[g][1], S.A.geo.gF[g][2]};
                 if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
-                    float rl[3] = {S.C.geo.gr[g][0], S.C.geo.gr[g][1], S.C.geo.gr[g][2]}, fb[3], nb[3];
+                    float rl[3] = {S.A.geo.gr[g][0], S.A.geo.gr[g][1], S.A.geo.gr[g][2]}, fb[3], nb[3];
                     m3tv(Rw, F, fb);
                     cross3(rl, fb, nb);
                     for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
                     const int gy = M.geoms[g].gym;
+                    for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
+                }
+            }
+            for (int k = 0; k < M.body_npair[b]; ++k) {         // self-collision pairs this body takes part in
+                const int code = M.body_pair[b][k], pr = code >> 1, side = code & 1;
+                const float sg = side ? -1.0f : 1.0f;
+                float F[3] = {sg * S.A.geo.pF[pr][0], sg * S.A.geo.pF[pr][1], sg * S.A.geo.pF[pr][2]};
+                if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                    const float *rp = side ? S.A.geo.pb[pr] : S.A.geo.pa[pr];
+                    float rl[3] = {rp[0], rp[1], rp[2]}, fb[3], nb[3];
+                    m3tv(Rw, F, fb);
+                    cross3(rl, fb, nb);
+                    for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
+                    const int gy = M.sc_proxy[M.sc_pair[pr][side]].gym;
                     for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
                 }
             }
@@ -391,7 +426,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 cross3(M.inert_com[0], fb, nb);
                 for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
             }
-            for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] -= dn[i]; S.V.dyn.pA[b][3 + i] -= df[i]; }
+            for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] = -dn[i]; S.V.dyn.pA[b][3 + i] = -df[i]; }   // K3 adds the gyroscopic part
             if (b == 0 || b == 6 || b == 12) {      // block B is recycled by the sweep: keep what the contact phases need
                 const int slot = b / 6;
                 for (int i = 0; i < 9; ++i) S.RwK[slot][i] = Rw[i];
@@ -400,6 +435,48 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         }
     });
 
+    // ---- K3: rigid-body inertias (packed into block A, whose primitive scratch is dead now), gyroscopic bias ----
+    wave.par([&](int l) {
+        if (l < NB) {
+            const int b = l;
+            float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, h[3] = {0, 0, 0}, mass = 0.0f;
+            for (int k = 0; k < M.ninert[b]; ++k) {
+                const int r = M.inert_idx[b][k];
+                const float ms = S.mscale[M.inert_gym[r]];
+                const float mk = ms * M.inert_mass[r];
+                const float *cm = M.inert_com[r], *I6 = M.inert_I[r];
+                const float cc = dot3(cm, cm);
+                const float Ic[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+                for (int r3 = 0; r3 < 3; ++r3)
+                    for (int c3 = 0; c3 < 3; ++c3)
+                        A[3 * r3 + c3] += ms * Ic[3 * r3 + c3] + mk * ((r3 == c3 ? cc : 0.0f) - cm[r3] * cm[c3]);
+                h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
+                mass += mk;
+            }
+            // 6x6 = [[A, H],[H', m 1]] with H = skew(h), stored packed (upper triangle)
+            float *I = S.A.IA[b];
+            const float H[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
+            for (int r3 = 0; r3 < 3; ++r3)
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    if (c3 >= r3) {
+                        I[sym6(r3, c3)] = A[3 * r3 + c3];
+                        I[sym6(r3 + 3, c3 + 3)] = (r3 == c3) ? mass : 0.0f;
+                    }
+                    I[sym6(r3, 3 + c3)] = H[3 * r3 + c3];
+                }
+            // pA = v x* (I v)
+            float om[3] = {S.V.dyn.v[b][0], S.V.dyn.v[b][1], S.V.dyn.v[b][2]}, vl[3] = {S.V.dyn.v[b][3], S.V.dyn.v[b][4], S.V.dyn.v[b][5]};
+            float n[3], f[3], t1[3], t2[3];
+            m3v(A, om, n); cross3(h, vl, t1);
+            n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
+            cross3(om, h, t1);                       // H' w = -h x w = w x h
+            f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
+            cross3(om, n, t1); cross3(vl, f, t2);
+            S.V.dyn.pA[b][0] += t1[0] + t2[0]; S.V.dyn.pA[b][1] += t1[1] + t2[1]; S.V.dyn.pA[b][2] += t1[2] + t2[2];
+            cross3(om, f, t1);
+            S.V.dyn.pA[b][3] += t1[0]; S.V.dyn.pA[b][4] += t1[1]; S.V.dyn.pA[b][5] += t1[2];
+        }
+    });
     DW_CKPT(3);
     // ---- A2: inward sweep of articulated inertias.  Twelve lanes per body: lane = (body-in-level k, row r, half h),
     //      each lane owns the three columns 3h..3h+2 of row r (5 bodies x 12 = 60 lanes on the widest level). ----

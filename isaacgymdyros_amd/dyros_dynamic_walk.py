@@ -121,6 +121,7 @@ class DyrosDynamicWalk(VecTask):
         c.timeout_fix = int(bool(mi.get("timeout_fix", False)))
         c.root_vel_at_com = int(bool(mi.get("root_vel_at_com", True)))
         c.torch_gpu_div = int(bool(mi.get("torch_gpu_div", True)))
+        c.self_collision = int(bool(mi.get("self_collision", True)))
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
         self._ccfg = c

@@ -40,6 +40,10 @@ NUM_DOF = 33
 NUM_INERT = 36
 MAX_GEOMS = 64
 NUM_FOOT_PTS = 8
+MAX_SC_PROXIES = 16
+MAX_SC_PAIRS = 16
+# links that get a self-collision capsule: (left, right) chains thigh / shank / ankle / foot assembly
+SC_LEG_BODIES = ("Thigh_Link", "Knee_Link", "AnkleCenter_Link", "Foot_Redundant_Link")
 
 # Per-DoF constants the reference hard-codes in the task (not in the MJCF).
 # reference: tasks/dyros_dynamic_walk.py:366-372 (armature, damping, velocity)
@@ -205,6 +209,35 @@ def compile_mjcf(xml_path: str) -> Dict:
     assert len(foot_pts) == NUM_FOOT_PTS
 
     names = [b["name"] for b in bodies]
+    # --- self-collision capsule proxies: the largest collision primitive of each listed link.  cylinder -> capsule
+    #     (same radius, same half length); box -> capsule along its longest axis, radius = second-longest half
+    #     extent, half length = longest - radius.  Pairs: every left-leg proxy against every right-leg proxy.
+    sc_proxies, side_of = [], []
+    for side in ("L_", "R_"):
+        for suffix in SC_LEG_BODIES:
+            i = names.index(side + suffix)
+            R, p = T_in_moving[i]
+            best, vol = None, -1.0
+            for g in bodies[i]["geoms"]:
+                sz = g["size"]
+                v = (8 * sz[0] * sz[1] * sz[2]) if g["type"] == "box" else (3.14159 * sz[0] * sz[0] * 2 * sz[1])
+                if v > vol:
+                    best, vol = g, v
+            Rg = R @ _quat_wxyz_to_mat(best["quat"])
+            pg = p + R @ np.array(best["pos"])
+            if best["type"] == "cylinder":
+                rad, half, ax = best["size"][0], best["size"][1], Rg[:, 2]
+            else:
+                order = np.argsort(best["size"])[::-1]
+                rad = best["size"][order[1]]
+                half = max(best["size"][order[0]] - rad, 0.0)
+                ax = Rg[:, order[0]]
+            sc_proxies.append(dict(moving=moving_of_body[i], gym=i, p0=(pg - half * ax).tolist(), p1=(pg + half * ax).tolist(),
+                                   radius=float(rad)))
+            side_of.append(side)
+    nl = len(SC_LEG_BODIES)
+    sc_pairs = [[a, nl + b] for a in range(nl) for b in range(nl)]
+
     model = dict(
         body_names=names,
         dof_names=dof_names,
@@ -221,6 +254,7 @@ def compile_mjcf(xml_path: str) -> Dict:
         right_foot_idx=names.index("R_Foot_Link"),
         pelvis_idx=names.index("base_link"),
         root_pos=bodies[0]["pos"],
+        sc_proxies=sc_proxies, sc_pairs=sc_pairs,
     )
     return model
 
@@ -233,6 +267,11 @@ class DwGeom(ctypes.Structure):
                 ("sole", ctypes.c_int),
                 ("pos", ctypes.c_float * 3), ("rot", ctypes.c_float * 9),
                 ("size", ctypes.c_float * 3), ("_pad", ctypes.c_float)]
+
+
+class DwCapsule(ctypes.Structure):
+    _fields_ = [("moving", ctypes.c_int), ("gym", ctypes.c_int), ("p0", ctypes.c_float * 3), ("p1", ctypes.c_float * 3),
+                ("radius", ctypes.c_float)]
 
 
 class DwModel(ctypes.Structure):
@@ -259,6 +298,10 @@ class DwModel(ctypes.Structure):
         ("left_foot_gym", ctypes.c_int),
         ("right_foot_gym", ctypes.c_int),
         ("pelvis_gym", ctypes.c_int),
+        ("num_sc_proxies", ctypes.c_int),
+        ("sc_proxy", DwCapsule * MAX_SC_PROXIES),
+        ("num_sc_pairs", ctypes.c_int),
+        ("sc_pair", (ctypes.c_int * 2) * MAX_SC_PAIRS),
     ]
 
 
@@ -329,6 +372,16 @@ class TocabiModel:
         m.left_foot_gym = d["left_foot_idx"]
         m.right_foot_gym = d["right_foot_idx"]
         m.pelvis_gym = d["pelvis_idx"]
+        prox, pairs = d.get("sc_proxies", []), d.get("sc_pairs", [])
+        assert len(prox) <= MAX_SC_PROXIES and len(pairs) <= MAX_SC_PAIRS
+        m.num_sc_proxies, m.num_sc_pairs = len(prox), len(pairs)
+        for i, c in enumerate(prox):
+            m.sc_proxy[i].moving, m.sc_proxy[i].gym, m.sc_proxy[i].radius = c["moving"], c["gym"], c["radius"]
+            for k in range(3):
+                m.sc_proxy[i].p0[k] = c["p0"][k]
+                m.sc_proxy[i].p1[k] = c["p1"][k]
+        for i, (a, b) in enumerate(pairs):
+            m.sc_pair[i][0], m.sc_pair[i][1] = a, b
         return m
 
 

@@ -56,6 +56,7 @@ void dwo_default_config(DwConfig *c) {
     c->timeout_fix = 0;
     c->root_vel_at_com = 1;
     c->torch_gpu_div = 0;
+    c->self_collision = 1;
     c->seed = 42;
 }
 

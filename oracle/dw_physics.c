@@ -202,6 +202,36 @@ void dwo_model_to_real(const DwModel *m, DwoModelR *r) {
         r->foot_mv[k] = m->foot_mv[k]; r->foot_gym[k] = m->foot_gym[k];
         for (int i = 0; i < 3; ++i) r->foot_pos[k][i] = m->foot_pos[k][i];
     }
+    r->num_sc_proxies = m->num_sc_proxies; r->num_sc_pairs = m->num_sc_pairs;
+    for (int k = 0; k < m->num_sc_proxies; ++k) {
+        r->sc_moving[k] = m->sc_proxy[k].moving; r->sc_gym[k] = m->sc_proxy[k].gym; r->sc_radius[k] = m->sc_proxy[k].radius;
+        for (int i = 0; i < 3; ++i) { r->sc_p0[k][i] = m->sc_proxy[k].p0[i]; r->sc_p1[k][i] = m->sc_proxy[k].p1[i]; }
+    }
+    for (int k = 0; k < m->num_sc_pairs; ++k) { r->sc_pair[k][0] = m->sc_pair[k][0]; r->sc_pair[k][1] = m->sc_pair[k][1]; }
+}
+
+static inline real clamp01(real x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+
+/* closest points of segments p1 + s d1 and p2 + t d2, s, t in [0,1] (Ericson, Real-Time Collision Detection 5.1.9) */
+static void seg_seg(const real p1[3], const real d1[3], const real p2[3], const real d2[3], real *so, real *to) {
+    real r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    real a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r);
+    const real eps = (real)1e-12;
+    real s, t;
+    if (a <= eps && e <= eps) { s = 0; t = 0; }
+    else if (a <= eps) { s = 0; t = clamp01(f / e); }
+    else {
+        real c = dot3(d1, r);
+        if (e <= eps) { t = 0; s = clamp01(-c / a); }
+        else {
+            real b = dot3(d1, d2), den = a * e - b * b;
+            s = den > eps ? clamp01((b * f - c * e) / den) : 0;
+            t = (b * s + f) / e;
+            if (t < 0) { t = 0; s = clamp01(-c / a); }
+            else if (t > 1) { t = 1; s = clamp01((b - c) / a); }
+        }
+    }
+    *so = s; *to = t;
 }
 
 void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
@@ -354,6 +384,50 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
             cross3(rl, fb, nb);
             for (int i = 0; i < 3; ++i) { pA[b][i] -= nb[i]; pA[b][3 + i] -= fb[i]; }
             for (int i = 0; i < 3; ++i) io->contact[3 * ge->gym + i] += Fw[i];
+        }
+    }
+
+    /* ---- 3b. self-collision: capsule proxies of the two legs, penalty force along the closest-point normal ---- */
+    for (int pi = 0; cfg->self_collision && pi < m->num_sc_pairs; ++pi) {
+        const int ia = m->sc_pair[pi][0], ib = m->sc_pair[pi][1];
+        const int ba = m->sc_moving[ia], bb = m->sc_moving[ib];
+        real a0[3], a1[3], b0[3], b1[3], t3[3];
+        m3v(w.Rw[ba], m->sc_p0[ia], t3); for (int i = 0; i < 3; ++i) a0[i] = w.pw[ba][i] + t3[i];
+        m3v(w.Rw[ba], m->sc_p1[ia], t3); for (int i = 0; i < 3; ++i) a1[i] = w.pw[ba][i] + t3[i];
+        m3v(w.Rw[bb], m->sc_p0[ib], t3); for (int i = 0; i < 3; ++i) b0[i] = w.pw[bb][i] + t3[i];
+        m3v(w.Rw[bb], m->sc_p1[ib], t3); for (int i = 0; i < 3; ++i) b1[i] = w.pw[bb][i] + t3[i];
+        real da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+        real sa, sb;
+        seg_seg(a0, da, b0, db, &sa, &sb);
+        real ca[3], cb[3], n[3];
+        for (int i = 0; i < 3; ++i) { ca[i] = a0[i] + sa * da[i]; cb[i] = b0[i] + sb * db[i]; n[i] = ca[i] - cb[i]; }
+        real dist = RSQRT(dot3(n, n));
+        real depth = m->sc_radius[ia] + m->sc_radius[ib] - dist;
+        if (depth > 0 && dist > (real)1e-6) {
+            for (int i = 0; i < 3; ++i) n[i] /= dist;
+            /* contact points in body coordinates, their world velocities */
+            real ra[3], rb[3], va[3], vb[3], tt[3], vl[3];
+            for (int i = 0; i < 3; ++i) t3[i] = ca[i] - w.pw[ba][i];
+            m3tv(w.Rw[ba], t3, ra);
+            cross3(w.v[ba], ra, tt);
+            for (int i = 0; i < 3; ++i) vl[i] = w.v[ba][3 + i] + tt[i];
+            m3v(w.Rw[ba], vl, va);
+            for (int i = 0; i < 3; ++i) t3[i] = cb[i] - w.pw[bb][i];
+            m3tv(w.Rw[bb], t3, rb);
+            cross3(w.v[bb], rb, tt);
+            for (int i = 0; i < 3; ++i) vl[i] = w.v[bb][3 + i] + tt[i];
+            m3v(w.Rw[bb], vl, vb);
+            real vn = (va[0] - vb[0]) * n[0] + (va[1] - vb[1]) * n[1] + (va[2] - vb[2]) * n[2];
+            real fn = cfg->penalty_stiffness * depth - cfg->penalty_damping * vn;
+            if (fn < 0) fn = 0;
+            real Fw[3] = {fn * n[0], fn * n[1], fn * n[2]}, fb3[3], nb3[3];
+            m3tv(w.Rw[ba], Fw, fb3);
+            cross3(ra, fb3, nb3);
+            for (int i = 0; i < 3; ++i) { pA[ba][i] -= nb3[i]; pA[ba][3 + i] -= fb3[i]; io->contact[3 * m->sc_gym[ia] + i] += Fw[i]; }
+            real Fm[3] = {-Fw[0], -Fw[1], -Fw[2]};
+            m3tv(w.Rw[bb], Fm, fb3);
+            cross3(rb, fb3, nb3);
+            for (int i = 0; i < 3; ++i) { pA[bb][i] -= nb3[i]; pA[bb][3 + i] -= fb3[i]; io->contact[3 * m->sc_gym[ib] + i] += Fm[i]; }
         }
     }
 

@@ -16,7 +16,8 @@
  *
  * Algorithm per env and substep (dt = 2 ms):
  *   1. forward kinematics + body-frame spatial velocities (floating base + 33 hinges)
- *   2. penalty ground forces for every non-sole collision primitive (deepest point of each)
+ *   2. penalty ground forces for every non-sole collision primitive (deepest point of each), and penalty
+ *      self-collision forces between capsule proxies of the two legs (closest points of the two segments)
  *   3. Featherstone articulated-body algorithm, armature and implicit joint damping on the
  *      diagonal (D = S'IaS + armature + dt*damping), gravity as a uniform field
  *   4. velocity-level contact solve for the 8 sole corners: Delassus matrix from 12 unit-wrench
@@ -71,6 +72,10 @@ typedef struct DwoModelR {
     DwoGeomR geoms[DW_MAX_GEOMS];
     int  foot_mv[DW_NUM_FOOT_PTS], foot_gym[DW_NUM_FOOT_PTS];
     real foot_pos[DW_NUM_FOOT_PTS][3];
+    int  num_sc_proxies, num_sc_pairs;
+    int  sc_moving[DW_MAX_SC_PROXIES], sc_gym[DW_MAX_SC_PROXIES];
+    real sc_p0[DW_MAX_SC_PROXIES][3], sc_p1[DW_MAX_SC_PROXIES][3], sc_radius[DW_MAX_SC_PROXIES];
+    int  sc_pair[DW_MAX_SC_PAIRS][2];
 } DwoModelR;
 
 void dwo_model_to_real(const DwModel *m, DwoModelR *r);

@@ -25,7 +25,7 @@ def test_aba_matches_dense_jacobian_formulation(model, double, tol):
     """Recursive body-frame ABA (oracle) vs world-frame M = sum J'IJ + dense solve (numpy fp64), random states and
     randomised mass / damping / armature."""
     rng = np.random.default_rng(0)
-    sim = OracleSim(6, double=double)
+    sim = OracleSim(6, double=double, self_collision=0)      # random joint angles interpenetrate the legs
     _randomise(sim, rng)
     sim.buf["mass_scale"][:] = rng.uniform(0.8, 1.2, size=(6, 38))
     sim.buf["dof_damping"][:] = 0.1 + rng.uniform(0, 2.9, size=(6, 33))
@@ -64,7 +64,7 @@ def test_momentum_and_energy_in_flight(model):
     """No gravity, no contact, no joint damping, zero torque: linear and angular momentum about the world origin
     are invariants of the exact dynamics and total energy too; semi-implicit Euler keeps them to O(dt)."""
     rng = np.random.default_rng(3)
-    sim = OracleSim(1, double=True, gravity=(0.0, 0.0, 0.0))
+    sim = OracleSim(1, double=True, gravity=(0.0, 0.0, 0.0), self_collision=0)
     _randomise(sim, rng, z=10.0)
     sim.buf["root_states"][:, 7:13] *= 0.5
     sim.buf["dof_state"][:, :, 1] *= 0.25
@@ -137,7 +137,7 @@ def test_joint_velocity_clamp_and_limits(model):
 def test_fp32_vs_fp64_divergence_budget(model):
     """Same inputs through the fp32 and fp64 builds: |dq| <= 1e-4 rad after 100 contact-free substeps."""
     rng = np.random.default_rng(5)
-    a, b = OracleSim(4), OracleSim(4, double=True)
+    a, b = OracleSim(4, self_collision=0), OracleSim(4, double=True, self_collision=0)
     _randomise(a, rng)
     a.buf["dof_state"][:, :, 1] *= 0.5
     for k in ("root_states", "dof_state"):
@@ -147,3 +147,28 @@ def test_fp32_vs_fp64_divergence_budget(model):
         a.simulate(tau)
         b.simulate(tau)
     assert np.abs(a.buf["dof_state"][:, :, 0] - b.buf["dof_state"][:, :, 0]).max() < 1e-4
+
+
+def test_crossed_legs_report_self_collision(model):
+    """the reference collides every primitive with every other (filter 0) and ends the episode on any
+    non-foot contact above 1 N.  Leg-vs-leg capsule proxies: nothing at the rest pose, both legs' links loaded with
+    equal and opposite forces once the hips roll inwards."""
+    sim = OracleSim(2)
+    sim.buf["root_states"][:, 2] = 3.0
+    sim.buf["dof_state"][:, :, 0] = np.asarray(INITIAL_DOF_POS, np.float32)
+    sim.buf["dof_state"][1, 1, 0] = -0.2
+    sim.buf["dof_state"][1, 7, 0] = 0.2
+    sim.simulate(np.zeros((2, 33), np.float32))
+    cf = sim.buf["contact_forces"]
+    assert np.abs(cf[0]).max() == 0
+    hit = np.linalg.norm(cf[1], axis=1) > 1.0
+    assert hit[[3, 4, 11, 12]].all()                       # thighs and shanks of both legs
+    assert not hit[[model.left_foot_idx, model.right_foot_idx]].any()
+    assert np.abs(cf[1].sum(axis=0)).max() < 1e-2          # internal forces cancel
+    off = OracleSim(1, self_collision=0)
+    off.buf["root_states"][:, 2] = 3.0
+    off.buf["dof_state"][:, :, 0] = sim.buf["dof_state"][1:2, :, 0] * 0 + np.asarray(INITIAL_DOF_POS, np.float32)
+    off.buf["dof_state"][0, 1, 0] = -0.2
+    off.buf["dof_state"][0, 7, 0] = 0.2
+    off.simulate(np.zeros((1, 33), np.float32))
+    assert np.abs(off.buf["contact_forces"]).max() == 0
