@@ -27,9 +27,12 @@ struct DevModel {
     int32_t nlevels;                          // levels 1..nlevels hold the bodies below the root
     int32_t level_count[MAX_LEVELS];
     int32_t level_body[MAX_LEVELS][MAX_PER_LEVEL];
+    int32_t level_direct[MAX_LEVELS];         // 1: every body of the level is an only child (the inward sweep adds into the parent in place)
+    int32_t level_slot[NB];                   // position of a body inside its level
     float   pos[NB][3];
     float   rot0[NB][9];
     float   axis[NB][3];
+    float   pax[NB][3];                       // hinge axis in the parent's frame (rot0 * axis)
     // dofs
     float   qlo[ND], qhi[ND], vmax[ND];
     // inertial records
@@ -83,9 +86,18 @@ inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, c
         d->child[p][d->nchild[p]++] = b;
         int L = depth[b];
         if (d->level_count[L] >= MAX_PER_LEVEL) { *err = "model: level wider than MAX_PER_LEVEL"; return DW_EINVAL; }
+        d->level_slot[b] = d->level_count[L];
         d->level_body[L][d->level_count[L]++] = b;
         if (L > d->nlevels) d->nlevels = L;
     }
+    for (int L = 1; L <= d->nlevels; ++L) {
+        d->level_direct[L] = 1;
+        for (int k = 0; k < d->level_count[L]; ++k)
+            if (d->nchild[d->parent[d->level_body[L][k]]] != 1) d->level_direct[L] = 0;
+    }
+    for (int b = 1; b < NB; ++b)
+        for (int i = 0; i < 3; ++i)
+            d->pax[b][i] = d->rot0[b][3 * i] * d->axis[b][0] + d->rot0[b][3 * i + 1] * d->axis[b][1] + d->rot0[b][3 * i + 2] * d->axis[b][2];
     for (int j = 0; j < ND; ++j) { d->qlo[j] = m->dof_lower[j]; d->qhi[j] = m->dof_upper[j]; d->vmax[j] = m->dof_vmax[j]; }
     for (int k = 0; k < DW_NUM_INERT; ++k) {
         int b = m->inert_mv[k];

@@ -6,9 +6,18 @@
 // Gauss-Seidel on the 8 sole corners over a Delassus matrix assembled from 12 unit-wrench responses of
 // the two foot bodies, impulse propagation through the tree, semi-implicit Euler.
 //
-// Lane maps: lane = body / dof / primitive for the flat phases; (body-in-level, matrix row) = (lane/6,
-// lane%6) for the inward articulated-inertia sweep; lane = Delassus column for the 12 response sweeps;
-// lane = constraint row for the 24-row Gauss-Seidel.
+// Coordinates: every spatial quantity of the substep (twists [w; v_O], wrenches [n_O; f], joint subspaces,
+// rigid and articulated inertias) is expressed in ONE frame -- world-aligned axes, reference point O = the base
+// origin at the start of the substep.  With a common frame the tree recursions need no link-to-link transforms:
+// a child's articulated inertia is *added* to its parent's, accelerations and impulses pass down a chain as
+// a' = a_parent + c, and a unit wrench on a foot climbs its leg with one dot product and one axpy per joint.
+// (The oracle states the same algorithm in link coordinates; the two agree to rounding -- all links stay within
+// ~1 m of O, so moving the reference point costs about two digits of the 1e-7, see DESIGN.md.)
+//
+// Lane maps: lane = body / dof / primitive for the flat phases; (body-in-level, column) = (lane/3, lane%3) for
+// forward kinematics; (body-in-level, row, half) = 12 lanes per body for the inward articulated-inertia sweep;
+// lane = body-in-level for the outward sweeps; lane = Delassus column for the 12 response sweeps; lane =
+// constraint row for the 24-row Gauss-Seidel.
 #pragma once
 
 #include <math.h>
@@ -35,10 +44,13 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
 struct LdsTree {
     float pos[NB][3];
     float axis[NB][3];
+    float pax[NB][3];
     unsigned char parent[NB];
     unsigned char nchild[NB];
     unsigned char child[NB][MAX_CHILD];
+    unsigned char level_slot[NB];
     unsigned char level_count[MAX_LEVELS];
+    unsigned char level_direct[MAX_LEVELS];
     unsigned char level_body[MAX_LEVELS][MAX_PER_LEVEL];
     unsigned char nlevels;
 };
@@ -48,11 +60,11 @@ DW_HD constexpr int sym6(int r, int c) {
     return r <= c ? (r * (13 - r)) / 2 + (c - r) : (c * (13 - c)) / 2 + (r - c);
 }
 
-// One env's LDS block.  160 KB per CU / 13.5 KB = 12 resident envs (3 waves per SIMD); the first version of this
+// One env's LDS block.  160 KB per CU / 13.3 KB = 12 resident envs (3 waves per SIMD); the first version of this
 // struct was 18.6 KB (8 envs).  The saving comes from overlaying arrays whose lifetimes inside a substep do not
-// intersect (phases in order: K1 K2 kinematics, K4 K5 primitives and self-collision, K3 inertias, SW inward sweep, A3 base solve,
-// A4 outward sweep, V1 free velocities, C1..C5 contact, V2 integrate) and from packing the symmetric
-// articulated inertias.
+// intersect (phases in order: K1 K2 kinematics, K4 K5 primitives and self-collision, K3 inertias, SW inward sweep,
+// A3 base solve, A4 outward sweep, V1 free velocities, C1..C5 contact, V2 integrate) and from packing the
+// symmetric articulated inertias.
 struct Lds {
     LdsTree tree;
     // ---- state and inputs of the substep (live throughout) ----
@@ -64,38 +76,37 @@ struct Lds {
     float warm[24];
     float contact[DW_NUM_BODIES * 3];
     float quat[4], ww[3], vow[3];
-    float R[NB][9];                 // body -> parent, K1 .. C5
-    float RwK[3][9], pwK[3][3];     // world pose of the base and the two sole bodies, K5 .. V2
+    float RwK[3][9], pwK[3][3];     // world rotation / position relative to O of the base and the two sole bodies, K5 .. V1
+    float Sj[NB][6];                // joint motion subspaces [a_w; r x a_w], K2 .. C5
     union {                         // block B
-        struct { float Rw[NB][9]; float pw[NB][3]; } kin;                       // K2 .. K5
-        struct { float T[MAX_PER_LEVEL][36]; float pa[MAX_PER_LEVEL][6]; } sw;  // SW
+        struct { float Rw[NB][9]; float pr[NB][3]; } kin;                       // K2 .. K3 (pr = position relative to O)
+        struct { float T[MAX_PER_LEVEL][21]; float pa[MAX_PER_LEVEL][6]; } sw;  // SW (levels whose parents gather)
         struct {                                                                // A3 .. V2
             float a[NB][6];
             float du[NB];
             float qdd[ND], qdf[ND], dqd[ND];
             float wwf[3], vowf[3], dv0[6];
             float Minv[36];
-            float part[MAX_PER_LEVEL][3];   // per-column partial sums of U'a in the outward sweeps
         } post;
     } B;
     union {                         // block V
-        struct { float v[NB][6]; float pA[NB][6]; } dyn;                        // K2 .. A4 (v), K3 .. A3 (pA)
-        struct {                                                                // V1 .. C5 (W first: v[0] is read in V1)
+        struct { float v[NB][6]; float pA[NB][6]; } dyn;                        // K2 .. A4 (v), K5 .. A3 (pA)
+        struct {                                                                // V1 .. C5
             float W[12][12];
             float vel[2][24], P[2][24];
-            float rk[8][3], phi[8], vmin[8];
+            float rk[8][3], phi[8], vmin[8];                                    //   rk = sole corner relative to O
             int   active[8];
             int   any_active;
             float twf[2][6];
-            float ducol[12][6];
         } con;
     } V;
     struct {                        // block C
         struct { float U[NB][6], Dinv[NB], u[NB]; } art;                        // SW .. C5
     } C;
     union {                         // block A
+        float R[NB][9];                                                         // K1 .. K2: body -> parent rotations
         struct {                                                                // K4 .. K5 (before the inertias are built)
-            float gF[64][3], gr[64][3];                                         //   ground penalty: world force, body-frame point
+            float gF[64][3], gr[64][3];                                         //   ground penalty: world force, point relative to O
             float pF[DW_MAX_SC_PAIRS][3], pa[DW_MAX_SC_PAIRS][3], pb[DW_MAX_SC_PAIRS][3];   // self-collision: force on A, points on A / B
         } geo;
         float IA[NB][21];                                                       // K3 .. A3 (packed, sym6)
@@ -140,31 +151,6 @@ DW_HD void quat_to_mat(const float *q, float *R) {
     R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
     R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
 }
-// motion transform parent -> body:  w_b = R' w_p ; v_b = R' (v_p + w_p x p)
-DW_HD void xform_motion(const float *R, const float *p, const float *vp, float *vb) {
-    float t[3], l[3];
-    m3tv(R, vp, vb);
-    cross3(vp, p, t);
-    l[0] = vp[3] + t[0]; l[1] = vp[4] + t[1]; l[2] = vp[5] + t[2];
-    m3tv(R, l, vb + 3);
-}
-// force transform body -> parent: f_p = R f_b ; n_p = R n_b + p x f_p
-DW_HD void xform_force(const float *R, const float *p, const float *fb, float *fp) {
-    float n[3], f[3], t[3];
-    m3v(R, fb, n);
-    m3v(R, fb + 3, f);
-    cross3(p, f, t);
-    fp[0] = n[0] + t[0]; fp[1] = n[1] + t[1]; fp[2] = n[2] + t[2];
-    fp[3] = f[0]; fp[4] = f[1]; fp[5] = f[2];
-}
-// PR = skew(p) * R   (the lower-left block of the force transform; (-E P)_kc = PR[3c+k])
-DW_HD void make_PR(const float *R, const float *p, float *PR) {
-    for (int c = 0; c < 3; ++c) {
-        float col[3] = {R[c], R[3 + c], R[6 + c]}, o[3];
-        cross3(p, col, o);
-        PR[c] = o[0]; PR[3 + c] = o[1]; PR[6 + c] = o[2];
-    }
-}
 // 1/sqrt(x) for x > 0: hardware estimate refined by one Newton step on the device (~1 ulp), exact on the host
 DW_HD float rsqrt_nr(float x) {
 #if defined(__HIPCC__)
@@ -174,11 +160,25 @@ DW_HD float rsqrt_nr(float x) {
     return 1.0f / sqrtf(x);
 #endif
 }
-// bias acceleration of a hinge: c = v x (S qd)
-DW_HD void joint_bias(const float *v, const float *s, float qd, float *c) {
-    float sq[3] = {s[0] * qd, s[1] * qd, s[2] * qd};
-    cross3(v, sq, c);
-    cross3(v + 3, sq, c + 3);
+// 1/x for x > 0: hardware estimate refined by one Newton step on the device (~1 ulp), exact on the host
+DW_HD float rcp_nr(float x) {
+#if defined(__HIPCC__)
+    const float y = __builtin_amdgcn_rcpf(x);
+    return y * (2.0f - x * y);
+#else
+    return 1.0f / x;
+#endif
+}
+// spatial motion cross product c = v x m  (v, m = [angular; linear])
+DW_HD void motion_cross(const float *v, const float *m, float *c) {
+    float t[3];
+    cross3(v, m, c);
+    cross3(v, m + 3, c + 3);
+    cross3(v + 3, m, t);
+    c[3] += t[0]; c[4] += t[1]; c[5] += t[2];
+}
+DW_HD float dot6(const float *a, const float *b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,9 +192,10 @@ DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
             S.tree.parent[l] = M.parent[l];
             S.tree.nchild[l] = M.nchild[l];
             for (int i = 0; i < MAX_CHILD; ++i) S.tree.child[l][i] = M.child[l][i];
-            for (int i = 0; i < 3; ++i) { S.tree.pos[l][i] = M.pos[l][i]; S.tree.axis[l][i] = M.axis[l][i]; }
+            for (int i = 0; i < 3; ++i) { S.tree.pos[l][i] = M.pos[l][i]; S.tree.axis[l][i] = M.axis[l][i]; S.tree.pax[l][i] = M.pax[l][i]; }
+            S.tree.level_slot[l] = M.level_slot[l];
         }
-        if (l < MAX_LEVELS) S.tree.level_count[l] = M.level_count[l];
+        if (l < MAX_LEVELS) { S.tree.level_count[l] = M.level_count[l]; S.tree.level_direct[l] = M.level_direct[l]; }
         if (l < MAX_LEVELS * MAX_PER_LEVEL) S.tree.level_body[l / MAX_PER_LEVEL][l % MAX_PER_LEVEL] = M.level_body[l / MAX_PER_LEVEL][l % MAX_PER_LEVEL];
         if (l == 63) S.tree.nlevels = M.nlevels;
     });
@@ -222,8 +223,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 4; ++i) S.quat[i] = qn[i];
             float Rw[9];
             quat_to_mat(qn, Rw);
-            for (int i = 0; i < 9; ++i) { S.B.kin.Rw[0][i] = Rw[i]; S.R[0][i] = Rw[i]; }
-            for (int i = 0; i < 3; ++i) S.B.kin.pw[0][i] = S.root[i];
+            for (int i = 0; i < 9; ++i) S.B.kin.Rw[0][i] = Rw[i];
+            for (int i = 0; i < 3; ++i) S.B.kin.pr[0][i] = 0.0f;
             float ww[3] = {S.root[10], S.root[11], S.root[12]};
             float vo[3] = {S.root[7], S.root[8], S.root[9]};
             if (P.vel_at_com) {
@@ -232,11 +233,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 cross3(ww, rc, t);
                 vo[0] -= t[0]; vo[1] -= t[1]; vo[2] -= t[2];
             }
-            for (int i = 0; i < 3; ++i) { S.ww[i] = ww[i]; S.vow[i] = vo[i]; }
-            float vb[6];
-            m3tv(Rw, ww, vb);
-            m3tv(Rw, vo, vb + 3);
-            for (int i = 0; i < 6; ++i) S.V.dyn.v[0][i] = vb[i];
+            for (int i = 0; i < 3; ++i) { S.ww[i] = ww[i]; S.vow[i] = vo[i]; S.V.dyn.v[0][i] = ww[i]; S.V.dyn.v[0][3 + i] = vo[i]; }
+            for (int i = 0; i < 6; ++i) S.Sj[0][i] = 0.0f;
         } else if (l < NB) {
             const int b = l;
             const float *s = S.tree.axis[b];
@@ -249,25 +247,35 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                            oc * s[2] * s[0] - sn * s[1], oc * s[2] * s[1] + sn * s[0], cs + oc * s[2] * s[2]};
             float R[9];
             m3m(M.rot0[b], Rj, R);
-            for (int i = 0; i < 9; ++i) S.R[b][i] = R[i];
+            for (int i = 0; i < 9; ++i) S.A.R[b][i] = R[i];
         }
     });
 
     DW_CKPT(1);
-    // ---- K2: forward kinematics and velocities, level by level; three lanes per body (lane = body-in-level, column) ----
+    // ---- K2: forward kinematics, joint subspaces and velocities, level by level; three lanes per body
+    //      (lane = body-in-level, column c).  S = [a_w; r x a_w] with a_w = R_parent * (axis in the parent frame) ----
     for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
             const int k = l / 3, c = l - 3 * k;
             if (k < S.tree.level_count[L]) {
                 const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
-                const float *Rp = S.B.kin.Rw[p], *Rb = S.R[b], *pos = S.tree.pos[b], *vp = S.V.dyn.v[p];
+                const float *Rp = S.B.kin.Rw[p], *Rb = S.A.R[b], *pos = S.tree.pos[b], *pax = S.tree.pax[b], *vp = S.V.dyn.v[p], *prp = S.B.kin.pr[p];
                 const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];           // column c of R
                 for (int i = 0; i < 3; ++i) S.B.kin.Rw[b][3 * i + c] = Rp[3 * i] * r0 + Rp[3 * i + 1] * r1 + Rp[3 * i + 2] * r2;
-                S.B.kin.pw[b][c] = S.B.kin.pw[p][c] + Rp[3 * c] * pos[0] + Rp[3 * c + 1] * pos[1] + Rp[3 * c + 2] * pos[2];
-                // w_b = R' w_p + s qd ; v_b = R' (v_p + w_p x p): component c uses column c of R
-                const float t0 = vp[1] * pos[2] - vp[2] * pos[1], t1 = vp[2] * pos[0] - vp[0] * pos[2], t2 = vp[0] * pos[1] - vp[1] * pos[0];
-                S.V.dyn.v[b][c] = r0 * vp[0] + r1 * vp[1] + r2 * vp[2] + S.tree.axis[b][c] * S.qd[b - 1];
-                S.V.dyn.v[b][3 + c] = r0 * (vp[3] + t0) + r1 * (vp[4] + t1) + r2 * (vp[5] + t2);
+                float aw[3], x[3];
+                m3v(Rp, pax, aw);
+                m3v(Rp, pos, x);
+                x[0] += prp[0]; x[1] += prp[1]; x[2] += prp[2];
+                const float sx = x[1] * aw[2] - x[2] * aw[1], sy = x[2] * aw[0] - x[0] * aw[2], sz = x[0] * aw[1] - x[1] * aw[0];
+                const float ac = c == 0 ? aw[0] : (c == 1 ? aw[1] : aw[2]);
+                const float sc = c == 0 ? sx : (c == 1 ? sy : sz);
+                const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+                const float qd = S.qd[b - 1];
+                S.B.kin.pr[b][c] = xc;
+                S.Sj[b][c] = ac;
+                S.Sj[b][3 + c] = sc;
+                S.V.dyn.v[b][c] = vp[c] + ac * qd;
+                S.V.dyn.v[b][3 + c] = vp[3 + c] + sc * qd;
             }
         });
     }
@@ -275,24 +283,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     DW_CKPT(2);
     // ---- K4: penalty contact of the non-sole primitives against the ground (one lane per primitive) ----
     wave.par([&](int l) {
-        float F[3] = {0, 0, 0}, rl[3] = {0, 0, 0};
+        float F[3] = {0, 0, 0}, xr[3] = {0, 0, 0};
         if (l < M.ngeom && !M.geoms[l].sole) {
             const DwGeom &ge = M.geoms[l];
             const int b = ge.moving;
             float Rw[9];
             for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
-            float zmin;
+            float rl[3];
             if (ge.type == 0) {
                 // deepest corner: along each box axis take the end that points down (world z component of the axis)
                 float Rg[9], e[3];
                 m3m(Rw, ge.rot, Rg);
                 for (int i = 0; i < 3; ++i) e[i] = (Rg[6 + i] > 0.0f ? -1.0f : 1.0f) * ge.size[i];
-                float lc[3], wv[3];
-                m3v(ge.rot, e, lc);
-                lc[0] += ge.pos[0]; lc[1] += ge.pos[1]; lc[2] += ge.pos[2];
-                m3v(Rw, lc, wv);
-                zmin = S.B.kin.pw[b][2] + wv[2];
-                rl[0] = lc[0]; rl[1] = lc[1]; rl[2] = lc[2];
+                m3v(ge.rot, e, rl);
+                rl[0] += ge.pos[0]; rl[1] += ge.pos[1]; rl[2] += ge.pos[2];
             } else {
                 float al[3] = {ge.rot[2], ge.rot[5], ge.rot[8]}, aw[3];
                 m3v(Rw, al, aw);
@@ -306,16 +310,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     m3tv(Rw, ow, off);
                 }
                 for (int i = 0; i < 3; ++i) rl[i] = ge.pos[i] + sgn * ge.size[1] * al[i] + off[i];
-                float wv[3];
-                m3v(Rw, rl, wv);
-                zmin = S.B.kin.pw[b][2] + wv[2];
             }
+            float wv[3];
+            m3v(Rw, rl, wv);
+            for (int i = 0; i < 3; ++i) xr[i] = S.B.kin.pr[b][i] + wv[i];
+            const float zmin = S.root[2] + xr[2];
             if (zmin < 0) {
-                float vb[6], t[3], vl[3], vw[3];
-                for (int i = 0; i < 6; ++i) vb[i] = S.V.dyn.v[b][i];
-                cross3(vb, rl, t);
-                vl[0] = vb[3] + t[0]; vl[1] = vb[4] + t[1]; vl[2] = vb[5] + t[2];
-                m3v(Rw, vl, vw);
+                float t[3], vw[3];
+                cross3(S.V.dyn.v[b], xr, t);
+                for (int i = 0; i < 3; ++i) vw[i] = S.V.dyn.v[b][3 + i] + t[i];
                 float fn = P.pen_k * (-zmin) - P.pen_c * vw[2];
                 if (fn < 0) fn = 0;
                 float sp = sqrtf(vw[0] * vw[0] + vw[1] * vw[1]);
@@ -327,10 +330,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
             }
         }
-        for (int i = 0; i < 3; ++i) { S.A.geo.gF[l][i] = F[i]; S.A.geo.gr[l][i] = rl[i]; }
+        for (int i = 0; i < 3; ++i) { S.A.geo.gF[l][i] = F[i]; S.A.geo.gr[l][i] = xr[i]; }
     });
     // ---- K4b: self-collision, one lane per capsule pair: closest points of the two segments, penalty force along the
-    //      normal when the capsules overlap (force on A; B gets the opposite) ----
+    //      normal when the capsules overlap (force on A; B gets the opposite).  All points relative to O. ----
     wave.par([&](int l) {
         if (l < DW_MAX_SC_PAIRS) for (int i = 0; i < 3; ++i) S.A.geo.pF[l][i] = 0.0f;
         if (P.self_collision && l < M.num_sc_pairs) {
@@ -338,70 +341,64 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             const int ba = ca.moving, bb = cb.moving;
             float Ra[9], Rb[9], a0[3], a1[3], b0[3], b1[3], t3[3];
             for (int i = 0; i < 9; ++i) { Ra[i] = S.B.kin.Rw[ba][i]; Rb[i] = S.B.kin.Rw[bb][i]; }
-            m3v(Ra, ca.p0, t3); for (int i = 0; i < 3; ++i) a0[i] = S.B.kin.pw[ba][i] + t3[i];
-            m3v(Ra, ca.p1, t3); for (int i = 0; i < 3; ++i) a1[i] = S.B.kin.pw[ba][i] + t3[i];
-            m3v(Rb, cb.p0, t3); for (int i = 0; i < 3; ++i) b0[i] = S.B.kin.pw[bb][i] + t3[i];
-            m3v(Rb, cb.p1, t3); for (int i = 0; i < 3; ++i) b1[i] = S.B.kin.pw[bb][i] + t3[i];
+            m3v(Ra, ca.p0, t3); for (int i = 0; i < 3; ++i) a0[i] = S.B.kin.pr[ba][i] + t3[i];
+            m3v(Ra, ca.p1, t3); for (int i = 0; i < 3; ++i) a1[i] = S.B.kin.pr[ba][i] + t3[i];
+            m3v(Rb, cb.p0, t3); for (int i = 0; i < 3; ++i) b0[i] = S.B.kin.pr[bb][i] + t3[i];
+            m3v(Rb, cb.p1, t3); for (int i = 0; i < 3; ++i) b1[i] = S.B.kin.pr[bb][i] + t3[i];
             const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
-            // closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9)
-            const float r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
-            const float aa = dot3(da, da), ee = dot3(db, db), ff = dot3(db, r), eps = 1e-12f;
-            float sa, sb;
-            auto c01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
-            if (aa <= eps && ee <= eps) { sa = 0.0f; sb = 0.0f; }
-            else if (aa <= eps) { sa = 0.0f; sb = c01(ff / ee); }
-            else {
-                const float cc = dot3(da, r);
-                if (ee <= eps) { sb = 0.0f; sa = c01(-cc / aa); }
+            // (a pair whose segment midpoints are further apart than half lengths + radii cannot touch; when that holds
+            //  for all sixteen lanes the closest-point code below is skipped by the wave)
+            const float mid[3] = {0.5f * (a0[0] + a1[0] - b0[0] - b1[0]), 0.5f * (a0[1] + a1[1] - b0[1] - b1[1]), 0.5f * (a0[2] + a1[2] - b0[2] - b1[2])};
+            const float reach = 0.5f * (sqrtf(dot3(da, da)) + sqrtf(dot3(db, db))) + ca.radius + cb.radius;
+            if (dot3(mid, mid) <= reach * reach) {
+                // closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9)
+                const float r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
+                const float aa = dot3(da, da), ee = dot3(db, db), ff = dot3(db, r), eps = 1e-12f;
+                float sa, sb;
+                auto c01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
+                if (aa <= eps && ee <= eps) { sa = 0.0f; sb = 0.0f; }
+                else if (aa <= eps) { sa = 0.0f; sb = c01(ff / ee); }
                 else {
-                    const float bbv = dot3(da, db), den = aa * ee - bbv * bbv;
-                    sa = den > eps ? c01((bbv * ff - cc * ee) / den) : 0.0f;
-                    sb = (bbv * sa + ff) / ee;
-                    if (sb < 0.0f) { sb = 0.0f; sa = c01(-cc / aa); }
-                    else if (sb > 1.0f) { sb = 1.0f; sa = c01((bbv - cc) / aa); }
+                    const float cc = dot3(da, r);
+                    if (ee <= eps) { sb = 0.0f; sa = c01(-cc / aa); }
+                    else {
+                        const float bbv = dot3(da, db), den = aa * ee - bbv * bbv;
+                        sa = den > eps ? c01((bbv * ff - cc * ee) / den) : 0.0f;
+                        sb = (bbv * sa + ff) / ee;
+                        if (sb < 0.0f) { sb = 0.0f; sa = c01(-cc / aa); }
+                        else if (sb > 1.0f) { sb = 1.0f; sa = c01((bbv - cc) / aa); }
+                    }
+                }
+                float pa[3], pb[3], n[3];
+                for (int i = 0; i < 3; ++i) { pa[i] = a0[i] + sa * da[i]; pb[i] = b0[i] + sb * db[i]; n[i] = pa[i] - pb[i]; }
+                const float dist = sqrtf(dot3(n, n));
+                const float depth = ca.radius + cb.radius - dist;
+                if (depth > 0.0f && dist > 1e-6f) {
+                    for (int i = 0; i < 3; ++i) n[i] /= dist;
+                    float ta[3], tb[3];
+                    cross3(S.V.dyn.v[ba], pa, ta);
+                    cross3(S.V.dyn.v[bb], pb, tb);
+                    float vn = 0.0f;
+                    for (int i = 0; i < 3; ++i) vn += ((S.V.dyn.v[ba][3 + i] + ta[i]) - (S.V.dyn.v[bb][3 + i] + tb[i])) * n[i];
+                    float fn = P.pen_k * depth - P.pen_c * vn;
+                    if (fn < 0.0f) fn = 0.0f;
+                    for (int i = 0; i < 3; ++i) { S.A.geo.pF[l][i] = fn * n[i]; S.A.geo.pa[l][i] = pa[i]; S.A.geo.pb[l][i] = pb[i]; }
                 }
             }
-            float pa[3], pb[3], n[3];
-            for (int i = 0; i < 3; ++i) { pa[i] = a0[i] + sa * da[i]; pb[i] = b0[i] + sb * db[i]; n[i] = pa[i] - pb[i]; }
-            const float dist = sqrtf(dot3(n, n));
-            const float depth = ca.radius + cb.radius - dist;
-            float F[3] = {0, 0, 0}, ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
-            if (depth > 0.0f && dist > 1e-6f) {
-                for (int i = 0; i < 3; ++i) n[i] /= dist;
-                float va[3], vb[3], tt[3], vl[3];
-                for (int i = 0; i < 3; ++i) t3[i] = pa[i] - S.B.kin.pw[ba][i];
-                m3tv(Ra, t3, ra);
-                cross3(S.V.dyn.v[ba], ra, tt);
-                for (int i = 0; i < 3; ++i) vl[i] = S.V.dyn.v[ba][3 + i] + tt[i];
-                m3v(Ra, vl, va);
-                for (int i = 0; i < 3; ++i) t3[i] = pb[i] - S.B.kin.pw[bb][i];
-                m3tv(Rb, t3, rb);
-                cross3(S.V.dyn.v[bb], rb, tt);
-                for (int i = 0; i < 3; ++i) vl[i] = S.V.dyn.v[bb][3 + i] + tt[i];
-                m3v(Rb, vl, vb);
-                const float vn = (va[0] - vb[0]) * n[0] + (va[1] - vb[1]) * n[1] + (va[2] - vb[2]) * n[2];
-                float fn = P.pen_k * depth - P.pen_c * vn;
-                if (fn < 0.0f) fn = 0.0f;
-                F[0] = fn * n[0]; F[1] = fn * n[1]; F[2] = fn * n[2];
-            }
-            for (int i = 0; i < 3; ++i) { S.A.geo.pF[l][i] = F[i]; S.A.geo.pa[l][i] = ra[i]; S.A.geo.pb[l][i] = rb[i]; }
         }
     });
-    // K5: external forces into the bias of their bodies; per-body net contact force
+    // K5: external forces into the bias of their bodies (wrench about O: [x x F; F]); per-body net contact force
     wave.par([&](int l) {
         if (l < NB) {
             const int b = l;
-            float Rw[9];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
             float dn[3] = {0, 0, 0}, df[3] = {0, 0, 0};
             for (int k = 0; k < M.body_ngeom[b]; ++k) {
                 const int g = M.body_geom[b][k];
                 float F[3] = {S.A.geo.gF[g][0], S.A.geo.gF[g][1], S.A.geo.gF[g][2]};
                 if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
-                    float rl[3] = {S.A.geo.gr[g][0], S.A.geo.gr[g][1], S.A.geo.gr[g][2]}, fb[3], nb[3];
-                    m3tv(Rw, F, fb);
-                    cross3(rl, fb, nb);
-                    for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
+                    float nb[3];
+                    cross3(S.A.geo.gr[g], F, nb);
+                    for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += F[i]; }
                     const int gy = M.geoms[g].gym;
                     for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
                 }
@@ -411,31 +408,31 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float sg = side ? -1.0f : 1.0f;
                 float F[3] = {sg * S.A.geo.pF[pr][0], sg * S.A.geo.pF[pr][1], sg * S.A.geo.pF[pr][2]};
                 if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
-                    const float *rp = side ? S.A.geo.pb[pr] : S.A.geo.pa[pr];
-                    float rl[3] = {rp[0], rp[1], rp[2]}, fb[3], nb[3];
-                    m3tv(Rw, F, fb);
-                    cross3(rl, fb, nb);
-                    for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
+                    float nb[3];
+                    cross3(side ? S.A.geo.pb[pr] : S.A.geo.pa[pr], F, nb);
+                    for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += F[i]; }
                     const int gy = M.sc_proxy[M.sc_pair[pr][side]].gym;
                     for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
                 }
             }
             if (b == 0) {
-                float Fw[3] = {S.push[0], S.push[1], 0.0f}, fb[3], nb[3];
-                m3tv(Rw, Fw, fb);
-                cross3(M.inert_com[0], fb, nb);
-                for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += fb[i]; }
+                float Fw[3] = {S.push[0], S.push[1], 0.0f}, xc[3], nb[3];
+                m3v(S.B.kin.Rw[0], M.inert_com[0], xc);
+                cross3(xc, Fw, nb);
+                for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += Fw[i]; }
             }
             for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] = -dn[i]; S.V.dyn.pA[b][3 + i] = -df[i]; }   // K3 adds the gyroscopic part
             if (b == 0 || b == 6 || b == 12) {      // block B is recycled by the sweep: keep what the contact phases need
                 const int slot = b / 6;
-                for (int i = 0; i < 9; ++i) S.RwK[slot][i] = Rw[i];
-                for (int i = 0; i < 3; ++i) S.pwK[slot][i] = S.B.kin.pw[b][i];
+                for (int i = 0; i < 9; ++i) S.RwK[slot][i] = S.B.kin.Rw[b][i];
+                for (int i = 0; i < 3; ++i) S.pwK[slot][i] = S.B.kin.pr[b][i];
             }
         }
     });
 
-    // ---- K3: rigid-body inertias (packed into block A, whose primitive scratch is dead now), gyroscopic bias ----
+    // ---- K3: rigid-body inertias about O in world axes (packed into block A, whose primitive scratch is dead now),
+    //      gyroscopic bias.  Link-frame moments (A about the link origin, first moment h, mass) as before, then
+    //      A_O = R A R' + m(|r|^2 1 - r r') + 2 (r.hy) 1 - (r hy' + hy r'),  h_O = hy + m r,  hy = R h ----
     wave.par([&](int l) {
         if (l < NB) {
             const int b = l;
@@ -453,23 +450,37 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
                 mass += mk;
             }
-            // 6x6 = [[A, H],[H', m 1]] with H = skew(h), stored packed (upper triangle)
+            float Rw[9], T[9], hy[3], x[3];
+            for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
+            for (int i = 0; i < 3; ++i) x[i] = S.B.kin.pr[b][i];
+            m3m(Rw, A, T);
+            m3v(Rw, h, hy);
+            const float xx = dot3(x, x), xh = dot3(x, hy);
+            float Ao[9];
+            for (int r3 = 0; r3 < 3; ++r3)
+                for (int c3 = r3; c3 < 3; ++c3) {
+                    float v = T[3 * r3] * Rw[3 * c3] + T[3 * r3 + 1] * Rw[3 * c3 + 1] + T[3 * r3 + 2] * Rw[3 * c3 + 2];
+                    v += (r3 == c3 ? mass * xx + 2.0f * xh : 0.0f) - mass * x[r3] * x[c3] - (x[r3] * hy[c3] + hy[r3] * x[c3]);
+                    Ao[3 * r3 + c3] = v; Ao[3 * c3 + r3] = v;
+                }
+            const float ho[3] = {hy[0] + mass * x[0], hy[1] + mass * x[1], hy[2] + mass * x[2]};
+            // 6x6 = [[A_O, H],[H', m 1]] with H = skew(h_O), stored packed (upper triangle)
             float *I = S.A.IA[b];
-            const float H[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
+            const float H[9] = {0, -ho[2], ho[1], ho[2], 0, -ho[0], -ho[1], ho[0], 0};
             for (int r3 = 0; r3 < 3; ++r3)
                 for (int c3 = 0; c3 < 3; ++c3) {
                     if (c3 >= r3) {
-                        I[sym6(r3, c3)] = A[3 * r3 + c3];
+                        I[sym6(r3, c3)] = Ao[3 * r3 + c3];
                         I[sym6(r3 + 3, c3 + 3)] = (r3 == c3) ? mass : 0.0f;
                     }
                     I[sym6(r3, 3 + c3)] = H[3 * r3 + c3];
                 }
-            // pA = v x* (I v)
+            // pA += v x* (I v)
             float om[3] = {S.V.dyn.v[b][0], S.V.dyn.v[b][1], S.V.dyn.v[b][2]}, vl[3] = {S.V.dyn.v[b][3], S.V.dyn.v[b][4], S.V.dyn.v[b][5]};
             float n[3], f[3], t1[3], t2[3];
-            m3v(A, om, n); cross3(h, vl, t1);
+            m3v(Ao, om, n); cross3(ho, vl, t1);
             n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
-            cross3(om, h, t1);                       // H' w = -h x w = w x h
+            cross3(om, ho, t1);                      // H' w = -h x w = w x h
             f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
             cross3(om, n, t1); cross3(vl, f, t2);
             S.V.dyn.pA[b][0] += t1[0] + t2[0]; S.V.dyn.pA[b][1] += t1[1] + t2[1]; S.V.dyn.pA[b][2] += t1[2] + t2[2];
@@ -478,42 +489,50 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         }
     });
     DW_CKPT(3);
-    // ---- A2: inward sweep of articulated inertias.  Twelve lanes per body: lane = (body-in-level k, row r, half h),
-    //      each lane owns the three columns 3h..3h+2 of row r (5 bodies x 12 = 60 lanes on the widest level). ----
+    // ---- SW: inward sweep of articulated inertias.  Twelve lanes per body: lane = (body-in-level k, row r, half h),
+    //      each lane owns the three columns 3h..3h+2 of row r (5 bodies x 12 = 60 lanes on the widest level).
+    //      Ia = IA - U U'/D and pa = pA + Ia c + U u/D go to the parent as they are (common frame): added in place
+    //      when every body of the level is an only child, through a per-level buffer and a gather region otherwise. ----
     for (int L = S.tree.nlevels; L >= 1; --L) {
         const int cnt = S.tree.level_count[L];
-        // A: projection through the joint, Ia = IA - U U'/D, rows of Ia*X
+        const bool direct = S.tree.level_direct[L] != 0;
         wave.par([&](int l) {
             const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
             if (k < cnt) {
-                const int b = S.tree.level_body[L][k];
-                const float *s = S.tree.axis[b];
+                const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
                 const float *IA = S.A.IA[b];
-                float U[6];
-                for (int j = 0; j < 6; ++j) U[j] = IA[sym6(j, 0)] * s[0] + IA[sym6(j, 1)] * s[1] + IA[sym6(j, 2)] * s[2];
+                float s[6], U[6];
+                for (int j = 0; j < 6; ++j) s[j] = S.Sj[b][j];
+                for (int j = 0; j < 6; ++j) {
+                    float acc = 0.0f;
+                    for (int c = 0; c < 6; ++c) acc += IA[sym6(j, c)] * s[c];
+                    U[j] = acc;
+                }
                 const float damp = S.damp[b - 1], qd = S.qd[b - 1];
-                const float D = dot3(s, U) + S.arm[b - 1] + dt * damp;
-                const float Dinv = 1.0f / D;
-                const float u = S.tau[b - 1] - damp * qd - (s[0] * S.V.dyn.pA[b][0] + s[1] * S.V.dyn.pA[b][1] + s[2] * S.V.dyn.pA[b][2]);
+                const float D = dot6(s, U) + S.arm[b - 1] + dt * damp;
+                const float Dinv = rcp_nr(D);
+                const float u = S.tau[b - 1] - damp * qd - dot6(s, S.V.dyn.pA[b]);
+                const float ur = S.A.IA[b][sym6(r, 0)] * s[0] + S.A.IA[b][sym6(r, 1)] * s[1] + S.A.IA[b][sym6(r, 2)] * s[2] +
+                                 S.A.IA[b][sym6(r, 3)] * s[3] + S.A.IA[b][sym6(r, 4)] * s[4] + S.A.IA[b][sym6(r, 5)] * s[5];   // U[r]
+                const float urd = ur * Dinv;
                 float Ia[6];
-                const float ur = U[r] * Dinv;
-                for (int c = 0; c < 6; ++c) Ia[c] = IA[sym6(r, c)] - ur * U[c];
-                float R[9], PR[9];
-                for (int i = 0; i < 9; ++i) R[i] = S.R[b][i];
-                make_PR(R, S.tree.pos[b], PR);
-                // half 0: T[r][c] = Ia[0:3].R_c + Ia[3:6].PR_c ; half 1: T[r][3+c] = Ia[3:6].R_c
-                const float a0 = h ? Ia[3] : Ia[0], a1 = h ? Ia[4] : Ia[1], a2 = h ? Ia[5] : Ia[2];
-                const float b0 = h ? 0.0f : Ia[3], b1 = h ? 0.0f : Ia[4], b2 = h ? 0.0f : Ia[5];
-                for (int c = 0; c < 3; ++c)
-                    S.B.sw.T[k][6 * r + 3 * h + c] = a0 * R[3 * c] + a1 * R[3 * c + 1] + a2 * R[3 * c + 2] +
-                                                     b0 * PR[3 * c] + b1 * PR[3 * c + 1] + b2 * PR[3 * c + 2];
+                for (int c = 0; c < 6; ++c) Ia[c] = IA[sym6(r, c)] - urd * U[c];
+                float *dst = direct ? S.A.IA[p] : S.B.sw.T[k];
+                for (int c = 0; c < 3; ++c) {
+                    const int cc = 3 * h + c;
+                    if (cc >= r) {
+                        const float o = h ? Ia[3 + c] : Ia[c];
+                        const int ix = sym6(r, cc);
+                        dst[ix] = direct ? dst[ix] + o : o;
+                    }
+                }
                 if (h == 0) {
-                    float vb[6], cb[6];
-                    for (int i = 0; i < 6; ++i) vb[i] = S.V.dyn.v[b][i];
-                    joint_bias(vb, s, qd, cb);
-                    float pa = S.V.dyn.pA[b][r] + U[r] * (u * Dinv);
+                    float m[6], cb[6];
+                    for (int j = 0; j < 6; ++j) m[j] = s[j] * qd;
+                    motion_cross(S.V.dyn.v[b], m, cb);
+                    float pa = S.V.dyn.pA[b][r] + ur * (u * Dinv);
                     for (int c = 0; c < 6; ++c) pa += Ia[c] * cb[c];
-                    S.B.sw.pa[k][r] = pa;
+                    if (direct) S.V.dyn.pA[p][r] += pa; else S.B.sw.pa[k][r] = pa;
                     if (r == 0) {
                         for (int j = 0; j < 6; ++j) S.C.art.U[b][j] = U[j];
                         S.C.art.Dinv[b] = Dinv;
@@ -522,56 +541,25 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
             }
         });
-        // B: X' (Ia X) and X' pa, written over the child's own storage (now "contribution to the parent").
-        //    Row q of R and of skew(p)*R come straight from LDS (a register array indexed by the lane's row would
-        //    live in scratch memory).
-        wave.par([&](int l) {
-            const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
-            if (k < cnt) {
-                const int b = S.tree.level_body[L][k];
-                const int q = r < 3 ? r : r - 3;
-                const int q1 = q == 2 ? 0 : q + 1, q2 = q == 0 ? 2 : q - 1;
-                const float *Rb = S.R[b];
-                const float *pp = S.tree.pos[b];
-                const float Rq[3] = {Rb[3 * q], Rb[3 * q + 1], Rb[3 * q + 2]};
-                const float p1 = r < 3 ? pp[q1] : 0.0f, p2 = r < 3 ? pp[q2] : 0.0f;
-                float PRq[3];
-                for (int c = 0; c < 3; ++c) PRq[c] = p1 * Rb[3 * q2 + c] - p2 * Rb[3 * q1 + c];
-                const float *T = S.B.sw.T[k] + (r < 3 ? 0 : 18) + 3 * h;
-                const float *T2 = S.B.sw.T[k] + 18 + 3 * h;
-                for (int c = 0; c < 3; ++c) {
-                    const float o = Rq[0] * T[c] + Rq[1] * T[6 + c] + Rq[2] * T[12 + c] +
-                                    PRq[0] * T2[c] + PRq[1] * T2[6 + c] + PRq[2] * T2[12 + c];
-                    if (3 * h + c >= r) S.A.IA[b][sym6(r, 3 * h + c)] = o;
-                }
-                if (h == 0) {
-                    const float *pa = S.B.sw.pa[k] + (r < 3 ? 0 : 3);
-                    const float *pa2 = S.B.sw.pa[k] + 3;
-                    S.V.dyn.pA[b][r] = Rq[0] * pa[0] + Rq[1] * pa[1] + Rq[2] * pa[2] +
-                                       PRq[0] * pa2[0] + PRq[1] * pa2[1] + PRq[2] * pa2[2];
-                }
-            }
-        });
-        // C: parents (one level up) gather their children, fixed order (three slots, absent children add zero)
-        const int pcnt = (L == 1) ? 1 : S.tree.level_count[L - 1];
-        wave.par([&](int l) {
-            const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
-            if (k < pcnt) {
-                const int p = (L == 1) ? 0 : S.tree.level_body[L - 1][k];
-                const int nch = S.tree.nchild[p];
-                const int c0 = S.tree.child[p][0], c1 = nch > 1 ? S.tree.child[p][1] : c0, c2 = nch > 2 ? S.tree.child[p][2] : c0;
-                const float w1 = nch > 1 ? 1.0f : 0.0f, w2 = nch > 2 ? 1.0f : 0.0f;
-                if (nch > 0) {
-                    for (int c = 3 * h; c < 3 * h + 3; ++c) {
-                        const int ix = sym6(r, c);
-                        if (c >= r)
-                            S.A.IA[p][ix] = S.A.IA[p][ix] + S.A.IA[c0][ix] + w1 * S.A.IA[c1][ix] + w2 * S.A.IA[c2][ix];
+        if (!direct) {
+            // parents (one level up) gather their children from the level buffer in child order
+            const int pcnt = (L == 1) ? 1 : S.tree.level_count[L - 1];
+            wave.par([&](int l) {
+                const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
+                if (k < pcnt) {
+                    const int p = (L == 1) ? 0 : S.tree.level_body[L - 1][k];
+                    const int nch = S.tree.nchild[p];
+                    for (int i = 0; i < MAX_CHILD; ++i) {
+                        if (i < nch) {
+                            const int kc = S.tree.level_slot[S.tree.child[p][i]];
+                            for (int c = 3 * h; c < 3 * h + 3; ++c)
+                                if (c >= r) S.A.IA[p][sym6(r, c)] += S.B.sw.T[kc][sym6(r, c)];
+                            if (h == 0) S.V.dyn.pA[p][r] += S.B.sw.pa[kc][r];
+                        }
                     }
-                    if (h == 0)
-                        S.V.dyn.pA[p][r] = S.V.dyn.pA[p][r] + S.V.dyn.pA[c0][r] + w1 * S.V.dyn.pA[c1][r] + w2 * S.V.dyn.pA[c2][r];
                 }
-            }
-        });
+            });
+        }
     }
 
     DW_CKPT(4);
@@ -607,7 +595,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 6; ++i) S.B.post.Minv[6 * i + l] = x[i];
         }
     });
-    // from here on S.in is dead and S.out is live
+    // from here on block B holds the "post" arrays
     wave.par([&](int l) {
         if (l < 6) {
             float acc = 0.0f;
@@ -618,34 +606,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     DW_CKPT(5);
-    // ---- A4: outward sweep of accelerations; three lanes per body (column c of the transform), two regions per level:
-    //      a' = X a_parent + c_b and the per-column part of U'a', then qdd = (u - U'a') / D and a = a' + S qdd ----
+    // ---- A4: outward sweep of accelerations, one lane per body of the level:
+    //      a' = a_parent + v x S qd,  qdd = (u - U'a') / D,  a = a' + S qdd ----
     for (int L = 1; L <= S.tree.nlevels; ++L) {
         wave.par([&](int l) {
-            const int k = l / 3, c = l - 3 * k;
-            if (k < S.tree.level_count[L]) {
-                const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
-                const int c1 = c == 2 ? 0 : c + 1, c2 = c == 0 ? 2 : c - 1;
-                const float *Rb = S.R[b], *pos = S.tree.pos[b], *ap = S.B.post.a[p], *vb = S.V.dyn.v[b], *ax = S.tree.axis[b];
-                const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];
-                const float t0 = ap[1] * pos[2] - ap[2] * pos[1], t1 = ap[2] * pos[0] - ap[0] * pos[2], t2 = ap[0] * pos[1] - ap[1] * pos[0];
+            if (l < S.tree.level_count[L]) {
+                const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
                 const float qd = S.qd[b - 1];
-                const float s1 = ax[c1] * qd, s2 = ax[c2] * qd;
-                const float ang = r0 * ap[0] + r1 * ap[1] + r2 * ap[2] + (vb[c1] * s2 - vb[c2] * s1);
-                const float lin = r0 * (ap[3] + t0) + r1 * (ap[4] + t1) + r2 * (ap[5] + t2) + (vb[3 + c1] * s2 - vb[3 + c2] * s1);
-                S.B.post.a[b][c] = ang;
-                S.B.post.a[b][3 + c] = lin;
-                S.B.post.part[k][c] = S.C.art.U[b][c] * ang + S.C.art.U[b][3 + c] * lin;
-            }
-        });
-        wave.par([&](int l) {
-            const int k = l / 3, c = l - 3 * k;
-            if (k < S.tree.level_count[L]) {
-                const int b = S.tree.level_body[L][k];
-                const float ua = S.B.post.part[k][0] + S.B.post.part[k][1] + S.B.post.part[k][2];
-                const float qdd = (S.C.art.u[b] - ua) * S.C.art.Dinv[b];
-                if (c == 0) S.B.post.qdd[b - 1] = qdd;
-                S.B.post.a[b][c] += S.tree.axis[b][c] * qdd;
+                float s[6], m[6], a[6];
+                for (int j = 0; j < 6; ++j) { s[j] = S.Sj[b][j]; m[j] = s[j] * qd; }
+                motion_cross(S.V.dyn.v[b], m, a);
+                for (int j = 0; j < 6; ++j) a[j] += S.B.post.a[p][j];
+                const float qdd = (S.C.art.u[b] - dot6(S.C.art.U[b], a)) * S.C.art.Dinv[b];
+                S.B.post.qdd[b - 1] = qdd;
+                for (int j = 0; j < 6; ++j) S.B.post.a[b][j] = a[j] + s[j] * qdd;
             }
         });
     }
@@ -655,21 +629,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     wave.par([&](int l) {
         if (l < ND) S.B.post.qdf[l] = S.qd[l] + dt * S.B.post.qdd[l];
         if (l == 40) {
-            float Rw[9], a0[6], vb0[6], t[3], t2[3], al[3];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.RwK[0][i];
-            for (int i = 0; i < 6; ++i) { a0[i] = S.B.post.a[0][i]; vb0[i] = S.V.dyn.v[0][i]; }
-            m3v(Rw, a0, t);
-            for (int i = 0; i < 3; ++i) S.B.post.wwf[i] = S.ww[i] + dt * t[i];
-            cross3(vb0, vb0 + 3, t2);
-            al[0] = a0[3] + t2[0]; al[1] = a0[4] + t2[1]; al[2] = a0[5] + t2[2];
-            m3v(Rw, al, t);
-            for (int i = 0; i < 3; ++i) S.B.post.vowf[i] = S.vow[i] + dt * (t[i] + P.g[i]);
+            // classical acceleration of the base origin = spatial linear part + w x v; gravity enters as a uniform field
+            float t2[3];
+            cross3(S.ww, S.vow, t2);
+            for (int i = 0; i < 3; ++i) {
+                S.B.post.wwf[i] = S.ww[i] + dt * S.B.post.a[0][i];
+                S.B.post.vowf[i] = S.vow[i] + dt * (S.B.post.a[0][3 + i] + t2[i] + P.g[i]);
+            }
         }
         if (l >= 48 && l < 48 + DW_NUM_FOOT_PTS) {
             const int k = l - 48;
             float r[3];
             m3v(S.RwK[1 + k / 4], M.foot_pos[k], r);
-            const float phi = S.pwK[1 + k / 4][2] + r[2];
+            for (int i = 0; i < 3; ++i) r[i] += S.pwK[1 + k / 4][i];
+            const float phi = S.root[2] + r[2];
             const int act = phi < P.contact_offset;
             for (int i = 0; i < 3; ++i) S.V.con.rk[k][i] = r[i];
             S.V.con.phi[k] = phi;
@@ -686,53 +659,31 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             S.V.con.any_active = any;
         }
         if (l < 24) S.V.con.P[0][l] = S.V.con.active[l / 3] ? S.warm[l] : 0.0f;
+        // C1: free twists of the two foot bodies = base twist + sum over the leg of S qd
+        if (l >= 32 && l < 44) {
+            const int f = (l - 32) / 6, j = (l - 32) % 6;
+            float acc = j < 3 ? S.B.post.wwf[j] : S.B.post.vowf[j - 3];
+            for (int i = 1; i <= 6; ++i) acc += S.Sj[6 * f + i][j] * S.B.post.qdf[6 * f + i - 1];
+            S.V.con.twf[f][j] = acc;
+        }
     });
 
     if (uniform(S.V.con.any_active)) {
-        // ---- C1: free twists of the two foot bodies (velocity FK down each leg), world aligned ----
-        wave.par([&](int l) {
-            if (l < 2) {
-                float Rw0[9], vcur[6];
-                for (int i = 0; i < 9; ++i) Rw0[i] = S.RwK[0][i];
-                m3tv(Rw0, S.B.post.wwf, vcur);
-                m3tv(Rw0, S.B.post.vowf, vcur + 3);
-                for (int i = 1; i <= 6; ++i) {
-                    const int b = 6 * l + i;
-                    float R[9], vn[6];
-                    for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                    xform_motion(R, S.tree.pos[b], vcur, vn);
-                    const float qd = S.B.post.qdf[b - 1];
-                    vn[0] += S.tree.axis[b][0] * qd; vn[1] += S.tree.axis[b][1] * qd; vn[2] += S.tree.axis[b][2] * qd;
-                    for (int j = 0; j < 6; ++j) vcur[j] = vn[j];
-                }
-                float o[3];
-                m3v(S.RwK[1 + l], vcur, o);
-                for (int i = 0; i < 3; ++i) S.V.con.twf[l][i] = o[i];
-                m3v(S.RwK[1 + l], vcur + 3, o);
-                for (int i = 0; i < 3; ++i) S.V.con.twf[l][3 + i] = o[i];
-            }
-        });
         DW_CKPT(7);
-        // ---- C2: 12 unit-wrench responses -> inverse operational inertia W of the two feet ----
+        // ---- C2: 12 unit-wrench responses -> inverse operational inertia W of the two feet (twists and wrenches about O).
+        //      Up the leg: d = -S'p, p += U d/D; base: dv = -Minv p; down both legs: qdd = (d - U'dv)/D, dv += S qdd ----
         wave.par([&](int l) {
             if (l < 12) {
                 const int f = l / 6, comp = l % 6;
-                float ew[3] = {0, 0, 0}, eb[3];
-                ew[comp % 3] = 1.0f;
-                m3tv(S.RwK[1 + f], ew, eb);
-                float dp[6] = {0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < 3; ++i) dp[(comp < 3 ? 0 : 3) + i] = -eb[i];
+                float dp[6], dc[6];
+                for (int j = 0; j < 6; ++j) dp[j] = (j == comp) ? -1.0f : 0.0f;
+#pragma unroll
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * f + i;
-                    const float *s = S.tree.axis[b];
-                    const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
-                    S.V.con.ducol[l][i - 1] = d;
+                    const float d = -dot6(S.Sj[b], dp);
+                    dc[i - 1] = d;
                     const float k = d * S.C.art.Dinv[b];
-                    float pa[6], R[9], up[6];
-                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.C.art.U[b][j] * k;
-                    for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                    xform_force(R, S.tree.pos[b], pa, up);
-                    for (int j = 0; j < 6; ++j) dp[j] = up[j];
+                    for (int j = 0; j < 6; ++j) dp[j] += S.C.art.U[b][j] * k;
                 }
                 float dv0[6];
                 for (int r = 0; r < 6; ++r) {
@@ -740,26 +691,18 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     for (int c = 0; c < 6; ++c) acc -= S.B.post.Minv[6 * r + c] * dp[c];
                     dv0[r] = acc;
                 }
+#pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float dv[6];
                     for (int j = 0; j < 6; ++j) dv[j] = dv0[j];
+#pragma unroll
                     for (int i = 1; i <= 6; ++i) {
                         const int b = 6 * g + i;
-                        const float *s = S.tree.axis[b];
-                        float R[9], ap[6];
-                        for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                        xform_motion(R, S.tree.pos[b], dv, ap);
-                        float ua = 0.0f;
-                        for (int j = 0; j < 6; ++j) ua += S.C.art.U[b][j] * ap[j];
-                        const float qdd = ((g == f ? S.V.con.ducol[l][i - 1] : 0.0f) - ua) * S.C.art.Dinv[b];
-                        ap[0] += s[0] * qdd; ap[1] += s[1] * qdd; ap[2] += s[2] * qdd;
-                        for (int j = 0; j < 6; ++j) dv[j] = ap[j];
+                        const float ua = dot6(S.C.art.U[b], dv);
+                        const float qdd = ((g == f ? dc[i - 1] : 0.0f) - ua) * S.C.art.Dinv[b];
+                        for (int j = 0; j < 6; ++j) dv[j] += S.Sj[b][j] * qdd;
                     }
-                    float o[3];
-                    m3v(S.RwK[1 + g], dv, o);
-                    for (int i = 0; i < 3; ++i) S.V.con.W[6 * g + i][l] = o[i];
-                    m3v(S.RwK[1 + g], dv + 3, o);
-                    for (int i = 0; i < 3; ++i) S.V.con.W[6 * g + 3 + i][l] = o[i];
+                    for (int j = 0; j < 6; ++j) S.V.con.W[6 * g + j][l] = dv[j];
                 }
             }
         });
@@ -925,7 +868,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         }
 #endif
         DW_CKPT(10);
-        // ---- C5: impulses -> wrenches on the two foot bodies -> delta-ABA over the whole tree ----
+        // ---- C5: impulses -> wrenches about O on the two foot bodies -> delta-ABA over the whole tree ----
         wave.par([&](int l) {
             if (l < 2) {
                 const float *Pc = S.V.con.P[cur];
@@ -935,21 +878,14 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     cross3(S.V.con.rk[k], Pc + 3 * k, t);
                     for (int i = 0; i < 3; ++i) { F[i] += Pc[3 * k + i]; Nm[i] += t[i]; }
                 }
-                float dp[6], fbv[3], nbv[3];
-                m3tv(S.RwK[1 + l], F, fbv);
-                m3tv(S.RwK[1 + l], Nm, nbv);
-                for (int i = 0; i < 3; ++i) { dp[i] = -nbv[i]; dp[3 + i] = -fbv[i]; }
+                float dp[6];
+                for (int i = 0; i < 3; ++i) { dp[i] = -Nm[i]; dp[3 + i] = -F[i]; }
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * l + i;
-                    const float *s = S.tree.axis[b];
-                    const float d = -(s[0] * dp[0] + s[1] * dp[1] + s[2] * dp[2]);
+                    const float d = -dot6(S.Sj[b], dp);
                     S.B.post.du[b] = d;
                     const float kk = d * S.C.art.Dinv[b];
-                    float pa[6], R[9], up[6];
-                    for (int j = 0; j < 6; ++j) pa[j] = dp[j] + S.C.art.U[b][j] * kk;
-                    for (int j = 0; j < 9; ++j) R[j] = S.R[b][j];
-                    xform_force(R, S.tree.pos[b], pa, up);
-                    for (int j = 0; j < 6; ++j) dp[j] = up[j];
+                    for (int j = 0; j < 6; ++j) dp[j] += S.C.art.U[b][j] * kk;
                 }
                 for (int j = 0; j < 6; ++j) S.A.lcp.dpf[l][j] = dp[j];
                 const int gy = M.foot_gym[4 * l];
@@ -965,29 +901,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 S.B.post.dv0[l] = acc;
             }
         });
-        for (int L = 1; L <= S.tree.nlevels; ++L) {       // same two-region, three-lane form as A4, without the bias term
+        for (int L = 1; L <= S.tree.nlevels; ++L) {       // velocity jumps down the tree, one lane per body of the level
             wave.par([&](int l) {
-                const int k = l / 3, c = l - 3 * k;
-                if (k < S.tree.level_count[L]) {
-                    const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
-                    const float *Rb = S.R[b], *pos = S.tree.pos[b], *ap = S.B.post.a[p];
-                    const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];
-                    const float t0 = ap[1] * pos[2] - ap[2] * pos[1], t1 = ap[2] * pos[0] - ap[0] * pos[2], t2 = ap[0] * pos[1] - ap[1] * pos[0];
-                    const float ang = r0 * ap[0] + r1 * ap[1] + r2 * ap[2];
-                    const float lin = r0 * (ap[3] + t0) + r1 * (ap[4] + t1) + r2 * (ap[5] + t2);
-                    S.B.post.a[b][c] = ang;
-                    S.B.post.a[b][3 + c] = lin;
-                    S.B.post.part[k][c] = S.C.art.U[b][c] * ang + S.C.art.U[b][3 + c] * lin;
-                }
-            });
-            wave.par([&](int l) {
-                const int k = l / 3, c = l - 3 * k;
-                if (k < S.tree.level_count[L]) {
-                    const int b = S.tree.level_body[L][k];
-                    const float ua = S.B.post.part[k][0] + S.B.post.part[k][1] + S.B.post.part[k][2];
-                    const float dq = (S.B.post.du[b] - ua) * S.C.art.Dinv[b];
-                    if (c == 0) S.B.post.dqd[b - 1] = dq;
-                    S.B.post.a[b][c] += S.tree.axis[b][c] * dq;
+                if (l < S.tree.level_count[L]) {
+                    const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
+                    float a[6];
+                    for (int j = 0; j < 6; ++j) a[j] = S.B.post.a[p][j];
+                    const float dq = (S.B.post.du[b] - dot6(S.C.art.U[b], a)) * S.C.art.Dinv[b];
+                    S.B.post.dqd[b - 1] = dq;
+                    for (int j = 0; j < 6; ++j) S.B.post.a[b][j] = a[j] + S.Sj[b][j] * dq;
                 }
             });
         }
@@ -1012,12 +934,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             S.qd[l] = qd;
         }
         if (l == 40) {
-            float Rw[9], wwn[3], von[3], t[3];
-            for (int i = 0; i < 9; ++i) Rw[i] = S.RwK[0][i];
-            m3v(Rw, S.B.post.dv0, t);
-            for (int i = 0; i < 3; ++i) wwn[i] = S.B.post.wwf[i] + t[i];
-            m3v(Rw, S.B.post.dv0 + 3, t);
-            for (int i = 0; i < 3; ++i) von[i] = S.B.post.vowf[i] + t[i];
+            float wwn[3], von[3];
+            for (int i = 0; i < 3; ++i) { wwn[i] = S.B.post.wwf[i] + S.B.post.dv0[i]; von[i] = S.B.post.vowf[i] + S.B.post.dv0[3 + i]; }
             {
                 const float wn2 = dot3(wwn, wwn);
                 if (wn2 > P.max_ang_vel * P.max_ang_vel) {
