@@ -43,7 +43,6 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
 // the first profile of this kernel was made of.
 struct LdsTree {
     float pos[NB][3];
-    float axis[NB][3];
     float pax[NB][3];
     unsigned char parent[NB];
     unsigned char nchild[NB];
@@ -65,7 +64,12 @@ DW_HD constexpr int sym6(int r, int c) {
 // intersect (phases in order: K1 K2 kinematics, K4 K5 primitives and self-collision, K3 inertias, SW inward sweep,
 // A3 base solve, A4 outward sweep, V1 free velocities, C1..C5 contact, V2 integrate) and from packing the
 // symmetric articulated inertias.
-struct Lds {
+// Rows that regions read whole are 8- or 16-byte aligned (and padded: Rw 9 -> 12, IA 21 -> 24 words) so that the
+// reads become ds_read_b64 / ds_read_b128: the CU's one LDS pipeline, shared by its twelve resident waves, is what
+// the sweeps saturate, and a b128 read moves four words for the price of two b32 reads.
+constexpr int RW_STRIDE = 12, IA_STRIDE = 24;
+
+struct alignas(16) Lds {
     LdsTree tree;
     // ---- state and inputs of the substep (live throughout) ----
     float root[13];
@@ -76,20 +80,21 @@ struct Lds {
     float warm[24];
     float contact[DW_NUM_BODIES * 3];
     float quat[4], ww[3], vow[3];
-    float RwK[3][9], pwK[3][3];     // world rotation / position relative to O of the base and the two sole bodies, K5 .. V1
-    float Sj[NB][6];                // joint motion subspaces [a_w; r x a_w], K2 .. C5
-    union {                         // block B
-        struct { float Rw[NB][9]; float pr[NB][3]; } kin;                       // K2 .. K3 (pr = position relative to O)
-        struct { float T[MAX_PER_LEVEL][21]; float pa[MAX_PER_LEVEL][6]; } sw;  // SW (levels whose parents gather)
+    alignas(16) float RwK[3][RW_STRIDE];
+    float pwK[3][3];     // world rotation / position relative to O of the base and the two sole bodies, K5 .. V1
+    alignas(16) float Sj[NB][6];                // joint motion subspaces [a_w; r x a_w], K2 .. C5
+    union alignas(16) {             // block B
+        struct { float Rw[NB][RW_STRIDE]; float pr[NB][3]; } kin;                       // K2 .. K3 (pr = position relative to O)
+        struct { float T[MAX_PER_LEVEL][IA_STRIDE]; float pa[MAX_PER_LEVEL][6]; } sw;  // SW (levels whose parents gather)
         struct {                                                                // A3 .. V2
             float a[NB][6];
+            float Minv[36];
             float du[NB];
             float qdd[ND], qdf[ND], dqd[ND];
             float wwf[3], vowf[3], dv0[6];
-            float Minv[36];
         } post;
     } B;
-    union {                         // block V
+    union alignas(16) {             // block V
         struct { float v[NB][6]; float pA[NB][6]; } dyn;                        // K2 .. A4 (v), K5 .. A3 (pA)
         struct {                                                                // V1 .. C5
             float W[12][12];
@@ -100,16 +105,16 @@ struct Lds {
             float twf[2][6];
         } con;
     } V;
-    struct {                        // block C
+    struct alignas(16) {            // block C
         struct { float U[NB][6], Dinv[NB], u[NB]; } art;                        // SW .. C5
     } C;
-    union {                         // block A
+    union alignas(16) {             // block A
         float R[NB][9];                                                         // K1 .. K2: body -> parent rotations
         struct {                                                                // K4 .. K5 (before the inertias are built)
             float gF[64][3], gr[64][3];                                         //   ground penalty: world force, point relative to O
             float pF[DW_MAX_SC_PAIRS][3], pa[DW_MAX_SC_PAIRS][3], pb[DW_MAX_SC_PAIRS][3];   // self-collision: force on A, points on A / B
         } geo;
-        float IA[NB][21];                                                       // K3 .. A3 (packed, sym6)
+        float IA[NB][IA_STRIDE];                                                    // K3 .. A3 (packed, sym6)
         struct { float A[24][24]; float invd[24]; float dpf[2][6]; } lcp;       // C3 .. C5
     } A;
     // ---- task state (dw_task.h), live for the whole policy step ----
@@ -192,7 +197,7 @@ DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
             S.tree.parent[l] = M.parent[l];
             S.tree.nchild[l] = M.nchild[l];
             for (int i = 0; i < MAX_CHILD; ++i) S.tree.child[l][i] = M.child[l][i];
-            for (int i = 0; i < 3; ++i) { S.tree.pos[l][i] = M.pos[l][i]; S.tree.axis[l][i] = M.axis[l][i]; S.tree.pax[l][i] = M.pax[l][i]; }
+            for (int i = 0; i < 3; ++i) { S.tree.pos[l][i] = M.pos[l][i]; S.tree.pax[l][i] = M.pax[l][i]; }
             S.tree.level_slot[l] = M.level_slot[l];
         }
         if (l < MAX_LEVELS) { S.tree.level_count[l] = M.level_count[l]; S.tree.level_direct[l] = M.level_direct[l]; }
@@ -237,7 +242,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 6; ++i) S.Sj[0][i] = 0.0f;
         } else if (l < NB) {
             const int b = l;
-            const float *s = S.tree.axis[b];
+            const float *s = M.axis[b];
             float q = S.q[b - 1];
             float sn, cs;
             sincosf(q, &sn, &cs);
