@@ -17,7 +17,10 @@ constexpr int MAX_PER_LEVEL = 5;    // widest level (legs + arms + neck)
 constexpr int MAX_CHILD = 3;
 constexpr int MAX_BODY_GEOMS = 8;
 constexpr int MAX_BODY_INERT = 2;
-constexpr int MAX_BODY_PAIRS = 4;    // self-collision pairs one body takes part in
+constexpr int MAX_BODY_PAIRS = 4;
+constexpr int MAX_CHAINS = 8;        // unbranched runs of the tree (legs, torso, arms, neck)
+constexpr int MAX_CHAIN_LEN = 8;
+constexpr int MAX_PHASES = 3;        // chains hanging off chains: base -> torso -> arms    // self-collision pairs one body takes part in
 
 struct DevModel {
     // tree
@@ -29,6 +32,10 @@ struct DevModel {
     int32_t level_body[MAX_LEVELS][MAX_PER_LEVEL];
     int32_t level_direct[MAX_LEVELS];         // 1: every body of the level is an only child (the inward sweep adds into the parent in place)
     int32_t level_slot[NB];                   // position of a body inside its level
+    // unbranched chains: the outward sweeps walk one chain per lane, chains of one phase in parallel
+    int32_t nchains, nphases;
+    int32_t chain_len[MAX_CHAINS], chain_phase[MAX_CHAINS];
+    int32_t chain_body[MAX_CHAINS][MAX_CHAIN_LEN];
     float   pos[NB][3];
     float   rot0[NB][9];
     float   axis[NB][3];
@@ -94,6 +101,29 @@ inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, c
         d->level_direct[L] = 1;
         for (int k = 0; k < d->level_count[L]; ++k)
             if (d->nchild[d->parent[d->level_body[L][k]]] != 1) d->level_direct[L] = 0;
+    }
+    // chain decomposition: a chain starts at a child of the root or of a branching body and runs while bodies have one child
+    {
+        int chain_of[NB];
+        chain_of[0] = -1;
+        for (int b = 1; b < NB; ++b) {
+            const int p = d->parent[b];
+            if (p != 0 && d->nchild[p] == 1) {
+                const int c = chain_of[p];
+                if (d->chain_len[c] >= MAX_CHAIN_LEN) { *err = "model: chain longer than MAX_CHAIN_LEN"; return DW_EINVAL; }
+                d->chain_body[c][d->chain_len[c]++] = b;
+                chain_of[b] = c;
+            } else {
+                if (d->nchains >= MAX_CHAINS) { *err = "model: more than MAX_CHAINS chains"; return DW_EINVAL; }
+                const int c = d->nchains++;
+                d->chain_phase[c] = (p == 0) ? 0 : d->chain_phase[chain_of[p]] + 1;
+                if (d->chain_phase[c] >= MAX_PHASES) { *err = "model: chains nested deeper than MAX_PHASES"; return DW_EINVAL; }
+                if (d->chain_phase[c] + 1 > d->nphases) d->nphases = d->chain_phase[c] + 1;
+                d->chain_body[c][0] = b;
+                d->chain_len[c] = 1;
+                chain_of[b] = c;
+            }
+        }
     }
     for (int b = 1; b < NB; ++b)
         for (int i = 0; i < 3; ++i)

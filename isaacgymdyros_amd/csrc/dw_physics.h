@@ -52,6 +52,9 @@ struct LdsTree {
     unsigned char level_direct[MAX_LEVELS];
     unsigned char level_body[MAX_LEVELS][MAX_PER_LEVEL];
     unsigned char nlevels;
+    unsigned char nchains, nphases;
+    unsigned char chain_len[MAX_CHAINS], chain_phase[MAX_CHAINS];
+    unsigned char chain_body[MAX_CHAINS][MAX_CHAIN_LEN];
 };
 
 // Packed index of entry (r,c) of a symmetric 6x6 (upper triangle, row-major): 21 words instead of 36.
@@ -190,9 +193,8 @@ DW_HD float dot6(const float *a, const float *b) {
 // the substep.  In: S.root, q, qd, tau, arm, damp, mscale, mu, push, warm.  Out: root, q, qd, warm, contact.
 // ------------------------------------------------------------------------------------------------
 // copies the tree tables from the device-resident model into LDS (one region)
-template <class W>
-DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
-    wave.par([&](int l) {
+DW_HD void stage_tree_lane(int l, Lds &S, const DevModel &M) {
+    {
         if (l < NB) {
             S.tree.parent[l] = M.parent[l];
             S.tree.nchild[l] = M.nchild[l];
@@ -202,8 +204,14 @@ DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
         }
         if (l < MAX_LEVELS) { S.tree.level_count[l] = M.level_count[l]; S.tree.level_direct[l] = M.level_direct[l]; }
         if (l < MAX_LEVELS * MAX_PER_LEVEL) S.tree.level_body[l / MAX_PER_LEVEL][l % MAX_PER_LEVEL] = M.level_body[l / MAX_PER_LEVEL][l % MAX_PER_LEVEL];
-        if (l == 63) S.tree.nlevels = M.nlevels;
-    });
+        if (l == 63) { S.tree.nlevels = M.nlevels; S.tree.nchains = M.nchains; S.tree.nphases = M.nphases; }
+        if (l < MAX_CHAINS) { S.tree.chain_len[l] = M.chain_len[l]; S.tree.chain_phase[l] = M.chain_phase[l]; }
+        if (l < MAX_CHAINS * MAX_CHAIN_LEN) S.tree.chain_body[l / MAX_CHAIN_LEN][l % MAX_CHAIN_LEN] = M.chain_body[l / MAX_CHAIN_LEN][l % MAX_CHAIN_LEN];
+    }
+}
+template <class W>
+DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
+    wave.par([&](int l) { stage_tree_lane(l, S, M); });
 }
 
 // Profiling builds (-DDW_PROFILE_STOP=n) leave the substep after phase n; results are then meaningless, only the
@@ -611,20 +619,28 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     });
 
     DW_CKPT(5);
-    // ---- A4: outward sweep of accelerations, one lane per body of the level:
+    // ---- A4: outward sweep of accelerations.  One lane per unbranched chain walks it with the parent acceleration in
+    //      registers (no region boundary between the bodies of a chain); chains of one phase run side by side:
     //      a' = a_parent + v x S qd,  qdd = (u - U'a') / D,  a = a' + S qdd ----
-    for (int L = 1; L <= S.tree.nlevels; ++L) {
+    for (int ph = 0; ph < S.tree.nphases; ++ph) {
         wave.par([&](int l) {
-            if (l < S.tree.level_count[L]) {
-                const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
-                const float qd = S.qd[b - 1];
-                float s[6], m[6], a[6];
-                for (int j = 0; j < 6; ++j) { s[j] = S.Sj[b][j]; m[j] = s[j] * qd; }
-                motion_cross(S.V.dyn.v[b], m, a);
-                for (int j = 0; j < 6; ++j) a[j] += S.B.post.a[p][j];
-                const float qdd = (S.C.art.u[b] - dot6(S.C.art.U[b], a)) * S.C.art.Dinv[b];
-                S.B.post.qdd[b - 1] = qdd;
-                for (int j = 0; j < 6; ++j) S.B.post.a[b][j] = a[j] + s[j] * qdd;
+            if (l < S.tree.nchains && S.tree.chain_phase[l] == ph) {
+                const int n = S.tree.chain_len[l];
+                const int p0 = S.tree.parent[S.tree.chain_body[l][0]];
+                float a[6];
+                for (int j = 0; j < 6; ++j) a[j] = S.B.post.a[p0][j];
+                for (int i = 0; i < n; ++i) {
+                    const int b = S.tree.chain_body[l][i];
+                    const float qd = S.qd[b - 1];
+                    float s[6], m[6], c[6];
+                    for (int j = 0; j < 6; ++j) { s[j] = S.Sj[b][j]; m[j] = s[j] * qd; }
+                    motion_cross(S.V.dyn.v[b], m, c);
+                    for (int j = 0; j < 6; ++j) a[j] += c[j];
+                    const float qdd = (S.C.art.u[b] - dot6(S.C.art.U[b], a)) * S.C.art.Dinv[b];
+                    S.B.post.qdd[b - 1] = qdd;
+                    for (int j = 0; j < 6; ++j) a[j] += s[j] * qdd;
+                    if (i == n - 1 && S.tree.nchild[b] > 0) for (int j = 0; j < 6; ++j) S.B.post.a[b][j] = a[j];     // only a branching body's acceleration is read again
+                }
             }
         });
     }
@@ -753,7 +769,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 float acc = S.V.con.vel[1][l];
                 for (int c = 0; c < 24; ++c) acc += S.A.lcp.A[l][c] * S.V.con.P[0][c];
                 S.V.con.vel[0][l] = acc;
-                S.A.lcp.invd[l] = 1.0f / (S.A.lcp.A[l][l] * (1.0f + P.cfm));
+                // (0 for the rows of an inactive corner: its Gauss-Seidel update is then the identity)
+                S.A.lcp.invd[l] = S.V.con.active[l / 3] ? 1.0f / (S.A.lcp.A[l][l] * (1.0f + P.cfm)) : 0.0f;
             }
         });
         DW_CKPT(9);
@@ -763,63 +780,66 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         //      sweep instead of 8.  Per contact: normal row, friction rows with the normal's effect folded in,
         //      projection onto the Coulomb cone.
 #if defined(__HIPCC__)
-        //      Device form: lane r < 24 keeps row r of A (24 registers), its velocity and impulse in registers; the
-        //      scalars of both contacts of a pair are broadcast with v_readlane (compile-time lane ids) and the
-        //      impulse arithmetic runs wave-uniformly, so there is no LDS traffic inside the solver at all.
+        //      Device form: the rows of the left sole live in lanes 0..11, those of the right sole in lanes 32..43, each
+        //      with its row of A (24 registers), velocity and impulse in registers.  Every lane runs the impulse
+        //      arithmetic of ITS half's corner, so the two corners of a pair are solved by one instruction stream; the
+        //      scalars a corner needs come from its three row lanes by ds_swizzle broadcasts inside the 32-lane half
+        //      (cross-lane only, no LDS memory), the impulse changes cross halves with v_readlane.  Rows of inactive
+        //      corners have invd = 0 (C3), which makes their update the identity without a branch.
         int cur = 0;
         {
             int act[DW_NUM_FOOT_PTS];
             for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) act[k] = uniform(S.V.con.active[k]);
-            const int l = (int)threadIdx.x;
-            const int row = l < 24 ? l : 0;
+            const int l = (int)threadIdx.x, half = l >> 5, lj = l & 31;
+            const int row = lj < 12 ? 12 * half + lj : 0;
             float Arow[24];
             for (int c = 0; c < 24; ++c) Arow[c] = S.A.lcp.A[row][c];
             float vel = S.V.con.vel[0][row], Pl = S.V.con.P[0][row];
             const float invd = S.A.lcp.invd[row];
-            float vminr[DW_NUM_FOOT_PTS];
-            for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) vminr[k] = S.V.con.vmin[k];
             const float mu = S.mu;
+#define DW_SWZ(x, j) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (x)), (j) << 5))   /* lane j of the own half */
             auto bc = [](float x, int lane) {
                 return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
             };
+            // per pair kk (own corner = kk + 4 half): iteration-invariant scalars.  (The swizzle pattern is an immediate, so
+            // the four pairs are written out by macro rather than by an unrolled loop.)
+            float iz[4], ix[4], iy[4], azx[4], azy[4], axy[4], vminr[4];
+#define DW_PGS_SETUP(KK) { \
+                const float cz = half ? Arow[12 + 3 * KK + 2] : Arow[3 * KK + 2];     /* column z of the own corner */ \
+                const float cx = half ? Arow[12 + 3 * KK] : Arow[3 * KK]; \
+                iz[KK] = DW_SWZ(invd, 3 * KK + 2); ix[KK] = DW_SWZ(invd, 3 * KK); iy[KK] = DW_SWZ(invd, 3 * KK + 1); \
+                azx[KK] = DW_SWZ(cz, 3 * KK); azy[KK] = DW_SWZ(cz, 3 * KK + 1); axy[KK] = DW_SWZ(cx, 3 * KK + 1); \
+                vminr[KK] = S.V.con.vmin[4 * half + KK]; }
+            DW_PGS_SETUP(0) DW_PGS_SETUP(1) DW_PGS_SETUP(2) DW_PGS_SETUP(3)
+#undef DW_PGS_SETUP
+#define DW_PGS_PAIR(KK) if (act[KK] | act[KK + 4]) { \
+                    const float Pz = DW_SWZ(Pl, 3 * KK + 2), Px = DW_SWZ(Pl, 3 * KK), Py = DW_SWZ(Pl, 3 * KK + 1); \
+                    const float vz = DW_SWZ(vel, 3 * KK + 2), vx0 = DW_SWZ(vel, 3 * KK), vy0 = DW_SWZ(vel, 3 * KK + 1); \
+                    float dz = -(vz - vminr[KK]) * iz[KK]; \
+                    float pz = Pz + dz; \
+                    if (pz < 0) pz = 0; \
+                    dz = pz - Pz; \
+                    const float vx = vx0 + azx[KK] * dz; \
+                    const float dx = -vx * ix[KK]; \
+                    const float vy = vy0 + azy[KK] * dz + axy[KK] * dx; \
+                    const float dy = -vy * iy[KK]; \
+                    float px = Px + dx, py = Py + dy; \
+                    const float lim = mu * pz, n2 = px * px + py * py; \
+                    if (n2 > lim * lim) { \
+                        const float sc = lim * rsqrt_nr(n2); \
+                        px *= sc; py *= sc; \
+                    } \
+                    const float Dx = px - Px, Dy = py - Py; \
+                    const float L0 = bc(dz, 0), L1 = bc(Dx, 0), L2 = bc(Dy, 0), R0 = bc(dz, 32), R1 = bc(Dx, 32), R2 = bc(Dy, 32); \
+                    vel = vel + Arow[3 * KK + 2] * L0 + Arow[3 * KK] * L1 + Arow[3 * KK + 1] * L2 \
+                              + Arow[12 + 3 * KK + 2] * R0 + Arow[12 + 3 * KK] * R1 + Arow[12 + 3 * KK + 1] * R2; \
+                    Pl = lj == 3 * KK ? px : (lj == 3 * KK + 1 ? py : (lj == 3 * KK + 2 ? pz : Pl)); }
             for (int it = 0; it < P.iters; ++it) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (!(act[kk] | act[kk + 4])) continue;
-                    float D[2][3], pn[2][3];
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        const int k = kk + 4 * f;
-                        const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
-                        const float Pz = bc(Pl, rz), Px = bc(Pl, rx), Py = bc(Pl, ry);
-                        float dz = -(bc(vel, rz) - vminr[k]) * bc(invd, rz);
-                        float pz = Pz + dz;
-                        if (pz < 0) pz = 0;
-                        dz = pz - Pz;
-                        const float vx = bc(vel, rx) + bc(Arow[rz], rx) * dz;
-                        const float dx = -vx * bc(invd, rx);
-                        const float vy = bc(vel, ry) + bc(Arow[rz], ry) * dz + bc(Arow[rx], ry) * dx;
-                        const float dy = -vy * bc(invd, ry);
-                        float px = Px + dx, py = Py + dy;
-                        const float lim = mu * pz, n2 = px * px + py * py;
-                        if (n2 > lim * lim) {
-                            const float sc = lim * rsqrt_nr(n2);
-                            px *= sc; py *= sc;
-                        }
-                        const bool on = act[k] != 0;
-                        D[f][0] = on ? px - Px : 0.0f; D[f][1] = on ? py - Py : 0.0f; D[f][2] = on ? dz : 0.0f;
-                        pn[f][0] = on ? px : Px; pn[f][1] = on ? py : Py; pn[f][2] = on ? pz : Pz;
-                    }
-                    vel = vel + Arow[3 * kk + 2] * D[0][2] + Arow[3 * kk] * D[0][0] + Arow[3 * kk + 1] * D[0][1]
-                              + Arow[12 + 3 * kk + 2] * D[1][2] + Arow[12 + 3 * kk] * D[1][0] + Arow[12 + 3 * kk + 1] * D[1][1];
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        const int r0 = 3 * (kk + 4 * f);
-                        Pl = l == r0 ? pn[f][0] : (l == r0 + 1 ? pn[f][1] : (l == r0 + 2 ? pn[f][2] : Pl));
-                    }
-                }
+                DW_PGS_PAIR(0) DW_PGS_PAIR(1) DW_PGS_PAIR(2) DW_PGS_PAIR(3)
             }
-            if (l < 24) S.V.con.P[0][l] = Pl;
+#undef DW_PGS_PAIR
+#undef DW_SWZ
+            if (lj < 12) S.V.con.P[0][row] = Pl;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -906,15 +926,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 S.B.post.dv0[l] = acc;
             }
         });
-        for (int L = 1; L <= S.tree.nlevels; ++L) {       // velocity jumps down the tree, one lane per body of the level
+        for (int ph = 0; ph < S.tree.nphases; ++ph) {     // velocity jumps down the tree, one lane per chain as in A4
             wave.par([&](int l) {
-                if (l < S.tree.level_count[L]) {
-                    const int b = S.tree.level_body[L][l], p = S.tree.parent[b];
+                if (l < S.tree.nchains && S.tree.chain_phase[l] == ph) {
+                    const int n = S.tree.chain_len[l];
+                    const int p0 = S.tree.parent[S.tree.chain_body[l][0]];
                     float a[6];
-                    for (int j = 0; j < 6; ++j) a[j] = S.B.post.a[p][j];
-                    const float dq = (S.B.post.du[b] - dot6(S.C.art.U[b], a)) * S.C.art.Dinv[b];
-                    S.B.post.dqd[b - 1] = dq;
-                    for (int j = 0; j < 6; ++j) S.B.post.a[b][j] = a[j] + S.Sj[b][j] * dq;
+                    for (int j = 0; j < 6; ++j) a[j] = S.B.post.a[p0][j];
+                    for (int i = 0; i < n; ++i) {
+                        const int b = S.tree.chain_body[l][i];
+                        const float dq = (S.B.post.du[b] - dot6(S.C.art.U[b], a)) * S.C.art.Dinv[b];
+                        S.B.post.dqd[b - 1] = dq;
+                        for (int j = 0; j < 6; ++j) a[j] += S.Sj[b][j] * dq;
+                        if (i == n - 1 && S.tree.nchild[b] > 0) for (int j = 0; j < 6; ++j) S.B.post.a[b][j] = a[j];
+                    }
                 }
             });
         }

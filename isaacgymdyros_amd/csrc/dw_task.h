@@ -171,9 +171,8 @@ DW_HD bool finitef(float x) { return fabsf(x) <= 3.4028234663852886e38f; }   // 
 #define ESI(off) (*reinterpret_cast<int *>(&S.es[(off)]))
 
 // ---------------------------------------------------------------------------------------------- load / store
-template <class W>
-DW_HD void load_env(const W &wave, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {
-    wave.par([&](int l) {
+DW_HD void load_env_lane(int l, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {
+    {
         if (with_task)
             for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
         if (l < 13) S.root[l] = B.root_states[13 * e + l];
@@ -185,8 +184,12 @@ DW_HD void load_env(const W &wave, Lds &S, const TaskParams &C, const DwBuffers 
         }
         if (l < DW_NUM_BODIES) S.mscale[l] = B.mass_scale[DW_NUM_BODIES * e + l];
         if (l == 40) S.mu = C.friction * B.friction_scale[e];
-        if (l < 8) S.flags[l] = 0;
-    });
+        if (l < 4) S.flags[l] = 0;
+    }
+}
+template <class W>
+DW_HD void load_env(const W &wave, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {
+    wave.par([&](int l) { load_env_lane(l, S, C, B, e, with_task); });
 }
 
 template <class W>
@@ -298,8 +301,40 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
     long long *gate = reinterpret_cast<long long *>(B.gate_acc);
     const int slot_prev = (int)((T.step + 2) % 3), slot_cur = (int)(T.step % 3), slot_next = (int)((T.step + 1) % 3);
 
-    stage_tree(wave, S, M);
-    load_env(wave, S, C, B, e, true);
+    // One region issues every global load whose address does not depend on this step's arithmetic -- tree tables,
+    // the env's record and state, its actions, counters, mass and the gate sums -- so the wave waits for HBM/L2 once
+    // here instead of once per phase that needs a scalar.
+    wave.par([&](int l) {
+        stage_tree_lane(l, S, M);
+        load_env_lane(l, S, C, B, e, true);
+        if (l < DW_NUM_ACT) {
+            float a = fminf(fmaxf(T.actions[DW_NUM_ACT * e + l], -1.0f), 1.0f);
+            if (l == 12) a = (a > 0 ? 1.0f : 0.0f) * a;
+            S.act[l] = a;
+        }
+        if (l == 33) {
+            // population statistics of the previous step (tasks/dyros_dynamic_walk.py:489)
+            int open = C.force_perturb_start;
+            if (!open && C.perturb) {
+                const long long latch = gate[GATE_LATCH];
+                long long se = 0, sc = 0;
+                for (int k = 0; k < GATE_BUCKETS; ++k) {
+                    se += gate[(slot_prev * GATE_BUCKETS + k) * 2];
+                    sc += gate[(slot_prev * GATE_BUCKETS + k) * 2 + 1];
+                }
+                const double n = (double)C.num_envs;
+                const double mean_epi = (double)se / n, mean_crm = (double)sc / 4294967296.0 / n;
+                open = latch ? 1 : (mean_epi > (double)(C.max_episode_length - C.pert_period_f) && mean_crm > 0.165);
+            }
+            S.flags[6] = open;
+        }
+        if (l == 34) {
+            const long long p = B.progress_buf[e], rb = B.randomize_buf[e];
+            S.flags[5] = (int)p;
+            S.flags[4] = (int)(rb > 0x7ffffffe ? 0x7ffffffe : rb);
+            S.scratch[3] = B.total_mass[e];
+        }
+    });
     if (C.freeze_physics) {      // debug mode: simulate() is the identity, so the net contact forces are an input too
         wave.par([&](int l) {
             for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
@@ -309,9 +344,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
     // ---- P1: clamp actions, mocap phase, perturbation gate and schedule (scalar work on single lanes) ----
     wave.par([&](int l) {
         if (l < DW_NUM_ACT) {
-            float a = fminf(fmaxf(T.actions[DW_NUM_ACT * e + l], -1.0f), 1.0f);
-            if (l == 12) a = (a > 0 ? 1.0f : 0.0f) * a;
-            S.act[l] = a;
+            const float a = S.act[l];
             S.es[DW_ES_ACTIONS + l] = a;
             B.action_history[((size_t)e * DW_HIST_SLOTS + ESI(DW_ES_HIST_HEAD)) * DW_NUM_ACT + l] = a;
         }
@@ -324,21 +357,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             ESI(DW_ES_MOCAP_IDX) = midx;
         }
         if (l == 33) {
-            // population statistics of the previous step (tasks/dyros_dynamic_walk.py:489)
-            int open = C.force_perturb_start;
-            if (!open && C.perturb) {
-                if (gate[GATE_LATCH]) open = 1;
-                else {
-                    long long se = 0, sc = 0;
-                    for (int k = 0; k < GATE_BUCKETS; ++k) {
-                        se += gate[(slot_prev * GATE_BUCKETS + k) * 2];
-                        sc += gate[(slot_prev * GATE_BUCKETS + k) * 2 + 1];
-                    }
-                    const double n = (double)C.num_envs;
-                    const double mean_epi = (double)se / n, mean_crm = (double)sc / 4294967296.0 / n;
-                    open = mean_epi > (double)(C.max_episode_length - C.pert_period_f) && mean_crm > 0.165;
-                }
-            }
+            const int open = S.flags[6];
             if (open) {
                 ESI(DW_ES_PERT_START) = 1;
                 if (!C.force_perturb_start) gate[GATE_LATCH] = 1;
@@ -440,13 +459,13 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             time = time + C.dt_policy_f;
             time = time + C.clock_gain_f * S.act[12];
             S.es[DW_ES_TIME] = time;
-            const long long p = B.progress_buf[e];
+            const long long p = S.flags[5];
             B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
             B.progress_buf[e] = p + 1;
             S.flags[5] = (int)(p + 1);
-            const long long rb = B.randomize_buf[e] + 1;
+            const int rb = S.flags[4] + 1;           // steps since the last parameter randomisation, saturating
             B.randomize_buf[e] = rb;
-            S.flags[4] = (int)(rb > 0x7fffffff ? 0x7fffffff : rb);
+            S.flags[4] = rb;
             for (int i = 0; i < 24; ++i) S.es[DW_ES_WARM + i] = S.warm[i];
         }
         bool bad = false;
@@ -516,7 +535,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             S.rterm[8] = fcr;
             S.es[DW_ES_CRS] = S.es[DW_ES_CRS] + fcr;
             S.rterm[10] = 0.0f;
-            const float tm = B.total_mass[e];
+            const float tm = S.scratch[3];
             const float thr = (float)(1.4 * 9.81) * tm;
             const bool th = (lf[2] > thr) || (rf[2] > thr);
             S.rterm[11] = th ? -0.2f * 1.0f : 0.0f;

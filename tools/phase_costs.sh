@@ -7,7 +7,7 @@ sys.path.insert(0, os.getcwd())
 from isaacgymdyros_amd.config import default_cfg
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
-N = 16384
+N = int(__import__("os").environ.get("DW_PC_N", "16384"))
 cfg = default_cfg(N, "cuda:0"); cfg["task"]["randomize"] = False
 env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 env._buf["root_states"][:, 2] = 0.928          # soles touching: contact pipeline active

@@ -1,0 +1,13 @@
+"""Profiling workload: dw_step with the physics frozen (task logic + record traffic only)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from isaacgymdyros_amd.config import default_cfg
+from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+cfg = default_cfg(N, "cuda:0"); cfg["sim"]["mi355"]["debug_freeze_physics"] = 1
+env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
+g = torch.Generator(device="cuda").manual_seed(42)
+acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
+for i in range(12): env.step(acts[i % 8])
+torch.cuda.synchronize(); env.close()
