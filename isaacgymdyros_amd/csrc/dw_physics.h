@@ -801,28 +801,27 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             auto bc = [](float x, int lane) {
                 return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
             };
-            // per pair kk (own corner = kk + 4 half): iteration-invariant scalars.  (The swizzle pattern is an immediate, so
-            // the four pairs are written out by macro rather than by an unrolled loop.)
-            float iz[4], ix[4], iy[4], azx[4], azy[4], axy[4], vminr[4];
-#define DW_PGS_SETUP(KK) { \
-                const float cz = half ? Arow[12 + 3 * KK + 2] : Arow[3 * KK + 2];     /* column z of the own corner */ \
-                const float cx = half ? Arow[12 + 3 * KK] : Arow[3 * KK]; \
-                iz[KK] = DW_SWZ(invd, 3 * KK + 2); ix[KK] = DW_SWZ(invd, 3 * KK); iy[KK] = DW_SWZ(invd, 3 * KK + 1); \
-                azx[KK] = DW_SWZ(cz, 3 * KK); azy[KK] = DW_SWZ(cz, 3 * KK + 1); axy[KK] = DW_SWZ(cx, 3 * KK + 1); \
-                vminr[KK] = S.V.con.vmin[4 * half + KK]; }
-            DW_PGS_SETUP(0) DW_PGS_SETUP(1) DW_PGS_SETUP(2) DW_PGS_SETUP(3)
-#undef DW_PGS_SETUP
+            // (The swizzle pattern is an immediate, so the four pairs are written out by macro rather than by an unrolled
+            // loop.  The iteration-invariant scalars of a corner -- diagonal inverses, in-corner couplings -- are broadcast
+            // again in every sweep: keeping the 24 of them in registers across the solver costs more in spills than the
+            // six extra cross-lane operations per update.)
+            float vminr[4];
+            for (int kk = 0; kk < 4; ++kk) vminr[kk] = S.V.con.vmin[4 * half + kk];
 #define DW_PGS_PAIR(KK) if (act[KK] | act[KK + 4]) { \
+                    const float cz = half ? Arow[12 + 3 * KK + 2] : Arow[3 * KK + 2];     /* column z of the own corner */ \
+                    const float cx = half ? Arow[12 + 3 * KK] : Arow[3 * KK]; \
+                    const float izk = DW_SWZ(invd, 3 * KK + 2), ixk = DW_SWZ(invd, 3 * KK), iyk = DW_SWZ(invd, 3 * KK + 1); \
+                    const float azxk = DW_SWZ(cz, 3 * KK), azyk = DW_SWZ(cz, 3 * KK + 1), axyk = DW_SWZ(cx, 3 * KK + 1); \
                     const float Pz = DW_SWZ(Pl, 3 * KK + 2), Px = DW_SWZ(Pl, 3 * KK), Py = DW_SWZ(Pl, 3 * KK + 1); \
                     const float vz = DW_SWZ(vel, 3 * KK + 2), vx0 = DW_SWZ(vel, 3 * KK), vy0 = DW_SWZ(vel, 3 * KK + 1); \
-                    float dz = -(vz - vminr[KK]) * iz[KK]; \
+                    float dz = -(vz - vminr[KK]) * izk; \
                     float pz = Pz + dz; \
                     if (pz < 0) pz = 0; \
                     dz = pz - Pz; \
-                    const float vx = vx0 + azx[KK] * dz; \
-                    const float dx = -vx * ix[KK]; \
-                    const float vy = vy0 + azy[KK] * dz + axy[KK] * dx; \
-                    const float dy = -vy * iy[KK]; \
+                    const float vx = vx0 + azxk * dz; \
+                    const float dx = -vx * ixk; \
+                    const float vy = vy0 + azyk * dz + axyk * dx; \
+                    const float dy = -vy * iyk; \
                     float px = Px + dx, py = Py + dy; \
                     const float lim = mu * pz, n2 = px * px + py * py; \
                     if (n2 > lim * lim) { \
