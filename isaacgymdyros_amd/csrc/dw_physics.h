@@ -403,7 +403,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     // K5: external forces into the bias of their bodies (wrench about O: [x x F; F]); per-body net contact force
     wave.par([&](int l) {
         if (l < NB) {
-            const int b = l;
+            int b = l;
+            DW_OPAQUE(b);
             float dn[3] = {0, 0, 0}, df[3] = {0, 0, 0};
             for (int k = 0; k < M.body_ngeom[b]; ++k) {
                 const int g = M.body_geom[b][k];

@@ -17,6 +17,12 @@
 #include <hip/hip_runtime.h>
 #define DW_HD __device__ __forceinline__
 namespace dw {
+
+// Makes an index opaque to the optimiser at this point.  Used where a lane's addresses into the device-resident model
+// (64-bit pointers) would otherwise be computed once at kernel entry for both substeps and then live -- i.e. be spilled
+// to scratch -- across the whole kernel; recomputing them costs two instructions.
+#define DW_OPAQUE(i) asm volatile("" : "+v"(i))
+
 struct Wave {
     template <class F> DW_HD void par(F &&f) const {
         // (tried: laundering the lane id through an empty asm per region, to stop lane-derived LDS addresses
@@ -39,6 +45,7 @@ DW_HD int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 }  // namespace dw
 #else
 #define DW_HD static inline
+#define DW_OPAQUE(i) ((void)0)
 namespace dw {
 struct Wave {
     template <class F> void par(F &&f) const {
