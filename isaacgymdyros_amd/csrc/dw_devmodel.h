@@ -49,11 +49,17 @@ struct DevModel {
     float   inert_mass[DW_NUM_INERT];
     float   inert_com[DW_NUM_INERT][3];
     float   inert_I[DW_NUM_INERT][6];
+    // the same records laid out per body (slot k of body b) so that a lane reads them without first reading an index
+    int32_t bi_gym[NB][MAX_BODY_INERT];
+    float   bi_mass[NB][MAX_BODY_INERT];
+    float   bi_com[NB][MAX_BODY_INERT][3];
+    float   bi_I[NB][MAX_BODY_INERT][6];
     // collision primitives
     int32_t ngeom;
     DwGeom  geoms[DW_MAX_GEOMS];
     int32_t body_ngeom[NB];
     int32_t body_geom[NB][MAX_BODY_GEOMS];
+    int32_t body_geom_gym[NB][MAX_BODY_GEOMS];    // Gym body that reports the primitive's contact force
     // soles
     int32_t foot_mv[DW_NUM_FOOT_PTS];
     int32_t foot_gym[DW_NUM_FOOT_PTS];
@@ -66,6 +72,8 @@ struct DevModel {
     int32_t sc_pair[DW_MAX_SC_PAIRS][2];
     int32_t body_npair[NB];
     int32_t body_pair[NB][MAX_BODY_PAIRS];
+    int32_t body_pair_gym[NB][MAX_BODY_PAIRS];
+    struct ScPair { int32_t ba, bb; float a0[3], a1[3], b0[3], b1[3], ra, rb; } scp[DW_MAX_SC_PAIRS];   // pairs with their capsules inlined
     // task constants
     float   kp[ND], kv[ND], action_high[ND], q_init[ND];
     float   obs_mean[DW_NUM_OBS1], obs_inv_std_den[DW_NUM_OBS1];   // second = sqrt(var + 1e-8), the divisor
@@ -133,6 +141,13 @@ inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, c
         int b = m->inert_mv[k];
         if (b < 0 || b >= NB || m->inert_gym[k] < 0 || m->inert_gym[k] >= DW_NUM_BODIES) { *err = "model: inertial index out of range"; return DW_EINVAL; }
         if (d->ninert[b] >= MAX_BODY_INERT) { *err = "model: too many inertial records on one body"; return DW_EINVAL; }
+        {
+            const int sl = d->ninert[b];
+            d->bi_gym[b][sl] = m->inert_gym[k];
+            d->bi_mass[b][sl] = m->inert_mass[k];
+            for (int i = 0; i < 3; ++i) d->bi_com[b][sl][i] = m->inert_com[k][i];
+            for (int i = 0; i < 6; ++i) d->bi_I[b][sl][i] = m->inert_I[k][i];
+        }
         d->inert_idx[b][d->ninert[b]++] = k;
         d->inert_gym[k] = m->inert_gym[k];
         d->inert_mass[k] = m->inert_mass[k];
@@ -148,6 +163,7 @@ inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, c
         if (b < 0 || b >= NB || m->geoms[g].gym < 0 || m->geoms[g].gym >= DW_NUM_BODIES) { *err = "model: geom index out of range"; return DW_EINVAL; }
         if (m->geoms[g].sole) continue;
         if (d->body_ngeom[b] >= MAX_BODY_GEOMS) { *err = "model: too many primitives on one body"; return DW_EINVAL; }
+        d->body_geom_gym[b][d->body_ngeom[b]] = m->geoms[g].gym;
         d->body_geom[b][d->body_ngeom[b]++] = g;
     }
     for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
@@ -182,8 +198,15 @@ inline int build_devmodel(const DwModel *m, const DwTaskConst *t, DevModel *d, c
             d->sc_pair[k][side] = pr;
             const int b = m->sc_proxy[pr].moving;
             if (d->body_npair[b] >= MAX_BODY_PAIRS) { *err = "model: too many self-collision pairs on one body"; return DW_EINVAL; }
+            d->body_pair_gym[b][d->body_npair[b]] = m->sc_proxy[pr].gym;
             d->body_pair[b][d->body_npair[b]++] = 2 * k + side;
         }
+    for (int k = 0; k < m->num_sc_pairs; ++k) {
+        const DwCapsule &ca = m->sc_proxy[m->sc_pair[k][0]], &cb = m->sc_proxy[m->sc_pair[k][1]];
+        DevModel::ScPair &q = d->scp[k];
+        q.ba = ca.moving; q.bb = cb.moving; q.ra = ca.radius; q.rb = cb.radius;
+        for (int i = 0; i < 3; ++i) { q.a0[i] = ca.p0[i]; q.a1[i] = ca.p1[i]; q.b0[i] = cb.p0[i]; q.b1[i] = cb.p1[i]; }
+    }
     if (t) {
         for (int j = 0; j < ND; ++j) {
             d->kp[j] = t->kp[j]; d->kv[j] = t->kv[j]; d->action_high[j] = t->action_high[j];

@@ -350,19 +350,21 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     wave.par([&](int l) {
         if (l < DW_MAX_SC_PAIRS) for (int i = 0; i < 3; ++i) S.A.geo.pF[l][i] = 0.0f;
         if (P.self_collision && l < M.num_sc_pairs) {
-            const DwCapsule &ca = M.sc_proxy[M.sc_pair[l][0]], &cb = M.sc_proxy[M.sc_pair[l][1]];
-            const int ba = ca.moving, bb = cb.moving;
+            int pi = l;
+            DW_OPAQUE(pi);
+            const DevModel::ScPair &sp = M.scp[pi];
+            const int ba = sp.ba, bb = sp.bb;
             float Ra[9], Rb[9], a0[3], a1[3], b0[3], b1[3], t3[3];
             for (int i = 0; i < 9; ++i) { Ra[i] = S.B.kin.Rw[ba][i]; Rb[i] = S.B.kin.Rw[bb][i]; }
-            m3v(Ra, ca.p0, t3); for (int i = 0; i < 3; ++i) a0[i] = S.B.kin.pr[ba][i] + t3[i];
-            m3v(Ra, ca.p1, t3); for (int i = 0; i < 3; ++i) a1[i] = S.B.kin.pr[ba][i] + t3[i];
-            m3v(Rb, cb.p0, t3); for (int i = 0; i < 3; ++i) b0[i] = S.B.kin.pr[bb][i] + t3[i];
-            m3v(Rb, cb.p1, t3); for (int i = 0; i < 3; ++i) b1[i] = S.B.kin.pr[bb][i] + t3[i];
+            m3v(Ra, sp.a0, t3); for (int i = 0; i < 3; ++i) a0[i] = S.B.kin.pr[ba][i] + t3[i];
+            m3v(Ra, sp.a1, t3); for (int i = 0; i < 3; ++i) a1[i] = S.B.kin.pr[ba][i] + t3[i];
+            m3v(Rb, sp.b0, t3); for (int i = 0; i < 3; ++i) b0[i] = S.B.kin.pr[bb][i] + t3[i];
+            m3v(Rb, sp.b1, t3); for (int i = 0; i < 3; ++i) b1[i] = S.B.kin.pr[bb][i] + t3[i];
             const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
             // (a pair whose segment midpoints are further apart than half lengths + radii cannot touch; when that holds
             //  for all sixteen lanes the closest-point code below is skipped by the wave)
             const float mid[3] = {0.5f * (a0[0] + a1[0] - b0[0] - b1[0]), 0.5f * (a0[1] + a1[1] - b0[1] - b1[1]), 0.5f * (a0[2] + a1[2] - b0[2] - b1[2])};
-            const float reach = 0.5f * (sqrtf(dot3(da, da)) + sqrtf(dot3(db, db))) + ca.radius + cb.radius;
+            const float reach = 0.5f * (sqrtf(dot3(da, da)) + sqrtf(dot3(db, db))) + sp.ra + sp.rb;
             if (dot3(mid, mid) <= reach * reach) {
                 // closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9)
                 const float r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
@@ -385,7 +387,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 float pa[3], pb[3], n[3];
                 for (int i = 0; i < 3; ++i) { pa[i] = a0[i] + sa * da[i]; pb[i] = b0[i] + sb * db[i]; n[i] = pa[i] - pb[i]; }
                 const float dist = sqrtf(dot3(n, n));
-                const float depth = ca.radius + cb.radius - dist;
+                const float depth = sp.ra + sp.rb - dist;
                 if (depth > 0.0f && dist > 1e-6f) {
                     for (int i = 0; i < 3; ++i) n[i] /= dist;
                     float ta[3], tb[3];
@@ -413,7 +415,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     float nb[3];
                     cross3(S.A.geo.gr[g], F, nb);
                     for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += F[i]; }
-                    const int gy = M.geoms[g].gym;
+                    const int gy = M.body_geom_gym[b][k];
                     for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
                 }
             }
@@ -425,7 +427,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     float nb[3];
                     cross3(side ? S.A.geo.pb[pr] : S.A.geo.pa[pr], F, nb);
                     for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += F[i]; }
-                    const int gy = M.sc_proxy[M.sc_pair[pr][side]].gym;
+                    const int gy = M.body_pair_gym[b][k];
                     for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i];
                 }
             }
@@ -449,13 +451,13 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     //      A_O = R A R' + m(|r|^2 1 - r r') + 2 (r.hy) 1 - (r hy' + hy r'),  h_O = hy + m r,  hy = R h ----
     wave.par([&](int l) {
         if (l < NB) {
-            const int b = l;
+            int b = l;
+            DW_OPAQUE(b);
             float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, h[3] = {0, 0, 0}, mass = 0.0f;
             for (int k = 0; k < M.ninert[b]; ++k) {
-                const int r = M.inert_idx[b][k];
-                const float ms = S.mscale[M.inert_gym[r]];
-                const float mk = ms * M.inert_mass[r];
-                const float *cm = M.inert_com[r], *I6 = M.inert_I[r];
+                const float ms = S.mscale[M.bi_gym[b][k]];
+                const float mk = ms * M.bi_mass[b][k];
+                const float *cm = M.bi_com[b][k], *I6 = M.bi_I[b][k];
                 const float cc = dot3(cm, cm);
                 const float Ic[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
                 for (int r3 = 0; r3 < 3; ++r3)
