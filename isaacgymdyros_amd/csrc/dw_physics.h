@@ -222,8 +222,26 @@ DW_HD void stage_tree(const W &wave, Lds &S, const DevModel &M) {
 #define DW_CKPT(n) do { } while (0)
 #endif
 
+// Wave-uniform loop bounds of the tree sweeps, read once per launch through the scalar cache and kept in SGPRs (as LDS
+// bytes each loop test is an LDS round trip plus a v_readfirstlane in front of every region).
+struct TreeUniform {
+    int nlevels, nphases, nchains;
+    unsigned direct_mask;              // bit L: level L adds into its parents in place
+    unsigned long long counts;         // 4 bits per level: bodies in the level
+};
+DW_HD TreeUniform make_tree_uniform(const DevModel &M) {
+    TreeUniform t;
+    t.nlevels = M.nlevels; t.nphases = M.nphases; t.nchains = M.nchains;
+    t.direct_mask = 0; t.counts = 0;
+    for (int L = 0; L < MAX_LEVELS; ++L) {
+        t.direct_mask |= (unsigned)(M.level_direct[L] != 0) << L;
+        t.counts |= (unsigned long long)(M.level_count[L] & 15) << (4 * L);
+    }
+    return t;
+}
+
 template <class W>
-DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysParams &P) {
+DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysParams &P, const TreeUniform &TU) {
     const float dt = P.dt;
 
     // ---- K1: base state, joint rotations, clear contact accumulators ----
@@ -267,10 +285,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     DW_CKPT(1);
     // ---- K2: forward kinematics, joint subspaces and velocities, level by level; three lanes per body
     //      (lane = body-in-level, column c).  S = [a_w; r x a_w] with a_w = R_parent * (axis in the parent frame) ----
-    for (int L = 1; L <= S.tree.nlevels; ++L) {
+    for (int L = 1; L <= TU.nlevels; ++L) {
+        const int cnt = (int)((TU.counts >> (4 * L)) & 15);
         wave.par([&](int l) {
             const int k = l / 3, c = l - 3 * k;
-            if (k < S.tree.level_count[L]) {
+            if (k < cnt) {
                 const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
                 const float *Rp = S.B.kin.Rw[p], *Rb = S.A.R[b], *pos = S.tree.pos[b], *pax = S.tree.pax[b], *vp = S.V.dyn.v[p], *prp = S.B.kin.pr[p];
                 const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];           // column c of R
@@ -440,8 +459,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] = -dn[i]; S.V.dyn.pA[b][3 + i] = -df[i]; }   // K3 adds the gyroscopic part
             if (b == 0 || b == 6 || b == 12) {      // block B is recycled by the sweep: keep what the contact phases need
                 const int slot = b / 6;
-                for (int i = 0; i < 9; ++i) S.RwK[slot][i] = S.B.kin.Rw[b][i];
-                for (int i = 0; i < 3; ++i) S.pwK[slot][i] = S.B.kin.pr[b][i];
+                float t[12];                         // (all reads, then all writes: an LDS-to-LDS copy written element by
+                for (int i = 0; i < 9; ++i) t[i] = S.B.kin.Rw[b][i];     //  element waits for each read before its write)
+                for (int i = 0; i < 3; ++i) t[9 + i] = S.B.kin.pr[b][i];
+                for (int i = 0; i < 9; ++i) S.RwK[slot][i] = t[i];
+                for (int i = 0; i < 3; ++i) S.pwK[slot][i] = t[9 + i];
             }
         }
     });
@@ -509,9 +531,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     //      each lane owns the three columns 3h..3h+2 of row r (5 bodies x 12 = 60 lanes on the widest level).
     //      Ia = IA - U U'/D and pa = pA + Ia c + U u/D go to the parent as they are (common frame): added in place
     //      when every body of the level is an only child, through a per-level buffer and a gather region otherwise. ----
-    for (int L = S.tree.nlevels; L >= 1; --L) {
-        const int cnt = S.tree.level_count[L];
-        const bool direct = S.tree.level_direct[L] != 0;
+    for (int L = TU.nlevels; L >= 1; --L) {
+        const int cnt = (int)((TU.counts >> (4 * L)) & 15);
+        const bool direct = (TU.direct_mask >> L) & 1;
         wave.par([&](int l) {
             const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
             if (k < cnt) {
@@ -534,13 +556,11 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 float Ia[6];
                 for (int c = 0; c < 6; ++c) Ia[c] = IA[sym6(r, c)] - urd * U[c];
                 float *dst = direct ? S.A.IA[p] : S.B.sw.T[k];
+                float old[3] = {0.0f, 0.0f, 0.0f};
+                if (direct) for (int c = 0; c < 3; ++c) old[c] = dst[sym6(r, 3 * h + c)];        // reads first, writes after
                 for (int c = 0; c < 3; ++c) {
                     const int cc = 3 * h + c;
-                    if (cc >= r) {
-                        const float o = h ? Ia[3 + c] : Ia[c];
-                        const int ix = sym6(r, cc);
-                        dst[ix] = direct ? dst[ix] + o : o;
-                    }
+                    if (cc >= r) dst[sym6(r, cc)] = old[c] + (h ? Ia[3 + c] : Ia[c]);
                 }
                 if (h == 0) {
                     float m[6], cb[6];
@@ -559,20 +579,24 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         });
         if (!direct) {
             // parents (one level up) gather their children from the level buffer in child order
-            const int pcnt = (L == 1) ? 1 : S.tree.level_count[L - 1];
+            const int pcnt = (L == 1) ? 1 : (int)((TU.counts >> (4 * (L - 1))) & 15);
             wave.par([&](int l) {
                 const int k = l / 12, r = (l % 12) >> 1, h = l & 1;
                 if (k < pcnt) {
                     const int p = (L == 1) ? 0 : S.tree.level_body[L - 1][k];
                     const int nch = S.tree.nchild[p];
+                    float acc[3], accp = S.V.dyn.pA[p][r];
+                    for (int c = 0; c < 3; ++c) acc[c] = S.A.IA[p][sym6(r, 3 * h + c)];
                     for (int i = 0; i < MAX_CHILD; ++i) {
                         if (i < nch) {
                             const int kc = S.tree.level_slot[S.tree.child[p][i]];
-                            for (int c = 3 * h; c < 3 * h + 3; ++c)
-                                if (c >= r) S.A.IA[p][sym6(r, c)] += S.B.sw.T[kc][sym6(r, c)];
-                            if (h == 0) S.V.dyn.pA[p][r] += S.B.sw.pa[kc][r];
+                            for (int c = 0; c < 3; ++c) acc[c] += S.B.sw.T[kc][sym6(r, 3 * h + c)];
+                            accp += S.B.sw.pa[kc][r];
                         }
                     }
+                    for (int c = 0; c < 3; ++c)
+                        if (3 * h + c >= r) S.A.IA[p][sym6(r, 3 * h + c)] = acc[c];
+                    if (h == 0) S.V.dyn.pA[p][r] = accp;
                 }
             });
         }
@@ -625,9 +649,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
     // ---- A4: outward sweep of accelerations.  One lane per unbranched chain walks it with the parent acceleration in
     //      registers (no region boundary between the bodies of a chain); chains of one phase run side by side:
     //      a' = a_parent + v x S qd,  qdd = (u - U'a') / D,  a = a' + S qdd ----
-    for (int ph = 0; ph < S.tree.nphases; ++ph) {
+    for (int ph = 0; ph < TU.nphases; ++ph) {
         wave.par([&](int l) {
-            if (l < S.tree.nchains && S.tree.chain_phase[l] == ph) {
+            if (l < TU.nchains && S.tree.chain_phase[l] == ph) {
                 const int n = S.tree.chain_len[l];
                 const int p0 = S.tree.parent[S.tree.chain_body[l][0]];
                 float a[6];
@@ -916,7 +940,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
                 for (int j = 0; j < 6; ++j) S.A.lcp.dpf[l][j] = dp[j];
                 const int gy = M.foot_gym[4 * l];
-                for (int i = 0; i < 3; ++i) S.contact[3 * gy + i] += F[i] / dt;
+                const float c0 = S.contact[3 * gy], c1 = S.contact[3 * gy + 1], c2 = S.contact[3 * gy + 2];
+                S.contact[3 * gy] = c0 + F[0] / dt; S.contact[3 * gy + 1] = c1 + F[1] / dt; S.contact[3 * gy + 2] = c2 + F[2] / dt;
             }
             if (l >= 32 && l < 32 + 24) S.warm[l - 32] = S.V.con.P[cur][l - 32];
         });
@@ -928,9 +953,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 S.B.post.dv0[l] = acc;
             }
         });
-        for (int ph = 0; ph < S.tree.nphases; ++ph) {     // velocity jumps down the tree, one lane per chain as in A4
+        for (int ph = 0; ph < TU.nphases; ++ph) {     // velocity jumps down the tree, one lane per chain as in A4
             wave.par([&](int l) {
-                if (l < S.tree.nchains && S.tree.chain_phase[l] == ph) {
+                if (l < TU.nchains && S.tree.chain_phase[l] == ph) {
                     const int n = S.tree.chain_len[l];
                     const int p0 = S.tree.parent[S.tree.chain_body[l][0]];
                     float a[6];
@@ -975,7 +1000,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     wwn[0] *= sc; wwn[1] *= sc; wwn[2] *= sc;
                 }
             }
-            for (int i = 0; i < 3; ++i) S.root[i] += dt * von[i];
+            {
+                const float p0 = S.root[0], p1 = S.root[1], p2 = S.root[2];
+                S.root[0] = p0 + dt * von[0]; S.root[1] = p1 + dt * von[1]; S.root[2] = p2 + dt * von[2];
+            }
             // dq = [w_hat sin(th/2), cos(th/2)], th = |w| dt <= 0.2 rad: sin(th/2)/|w| = (dt/2) * sinc(th/2)
             const float w2 = dot3(wwn, wwn);
             const float hx = 0.5f * dt;

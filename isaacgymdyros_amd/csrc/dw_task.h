@@ -299,6 +299,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
     const float dt = C.phys.dt;
     const double cdt_d = 0.0005;
     long long *gate = reinterpret_cast<long long *>(B.gate_acc);
+    const TreeUniform TU = make_tree_uniform(M);
     const int slot_prev = (int)((T.step + 2) % 3), slot_cur = (int)(T.step % 3), slot_next = (int)((T.step + 1) % 3);
 
     // One region issues every global load whose address does not depend on this step's arithmetic -- tree tables,
@@ -434,7 +435,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             }
             if (l == 40) { S.push[0] = sub == 0 ? S.scratch[1] : 0.0f; S.push[1] = sub == 0 ? S.scratch[2] : 0.0f; }
         });
-        if (!C.freeze_physics) physics_substep(wave, S, M, C.phys);
+        if (!C.freeze_physics) physics_substep(wave, S, M, C.phys, TU);
         wave.par([&](int l) {
             if (l < ND) {
                 const float n = noise_word(nz, DW_NZ_ENC + ND * sub + l);
@@ -466,8 +467,8 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             const int rb = S.flags[4] + 1;           // steps since the last parameter randomisation, saturating
             B.randomize_buf[e] = rb;
             S.flags[4] = rb;
-            for (int i = 0; i < 24; ++i) S.es[DW_ES_WARM + i] = S.warm[i];
         }
+        if (l < 24) S.es[DW_ES_WARM + l] = S.warm[l];
         bool bad = false;
         if (l < 13) bad |= !finitef(S.root[l]);
         if (l < ND) bad |= !finitef(S.q[l]) || !finitef(S.qd[l]);
@@ -650,16 +651,30 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
         const float *oh = B.obs_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_OBS1;
         const float *ah = B.action_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_ACT;
         float *ob = B.obs_buf + (size_t)DW_NUM_OBS * e;
-        for (int f = l; f < DW_NUM_OBS1 * DW_NUM_HIS; f += 64) {
-            const int i = f / DW_NUM_OBS1, k = f - i * DW_NUM_OBS1;
-            const int slot = (head + DW_NUM_SKIP * (i + 1) - 1) % DW_HIST_SLOTS;
-            ob[f] = (fill || slot == newest) ? S.normed[k] : oh[slot * DW_NUM_OBS1 + k];
+        // all tap loads are issued before the first store (the two buffers may alias as far as the compiler knows, so a
+        // load-store-load-store loop would pay one memory round trip per tap)
+        constexpr int NO = (DW_NUM_OBS1 * DW_NUM_HIS + 63) / 64, NA = (DW_NUM_ACT * (DW_NUM_HIS - 1) + 63) / 64;
+        float vo[NO], va[NA];
+        for (int j = 0; j < NO; ++j) {
+            const int f = l + 64 * j;
+            vo[j] = 0.0f;
+            if (f < DW_NUM_OBS1 * DW_NUM_HIS) {
+                const int i = f / DW_NUM_OBS1, k = f - i * DW_NUM_OBS1;
+                const int slot = (head + DW_NUM_SKIP * (i + 1) - 1) % DW_HIST_SLOTS;
+                vo[j] = (fill || slot == newest) ? S.normed[k] : oh[slot * DW_NUM_OBS1 + k];
+            }
         }
-        for (int f = l; f < DW_NUM_ACT * (DW_NUM_HIS - 1); f += 64) {
-            const int i = f / DW_NUM_ACT, k = f - i * DW_NUM_ACT;
-            const int slot = (head + DW_NUM_SKIP * (i + 1)) % DW_HIST_SLOTS;
-            ob[DW_NUM_OBS1 * DW_NUM_HIS + f] = did_reset ? 0.0f : (slot == newest ? S.act[k] : ah[slot * DW_NUM_ACT + k]);
+        for (int j = 0; j < NA; ++j) {
+            const int f = l + 64 * j;
+            va[j] = 0.0f;
+            if (f < DW_NUM_ACT * (DW_NUM_HIS - 1)) {
+                const int i = f / DW_NUM_ACT, k = f - i * DW_NUM_ACT;
+                const int slot = (head + DW_NUM_SKIP * (i + 1)) % DW_HIST_SLOTS;
+                va[j] = did_reset ? 0.0f : (slot == newest ? S.act[k] : ah[slot * DW_NUM_ACT + k]);
+            }
         }
+        for (int j = 0; j < NO; ++j) { const int f = l + 64 * j; if (f < DW_NUM_OBS1 * DW_NUM_HIS) ob[f] = vo[j]; }
+        for (int j = 0; j < NA; ++j) { const int f = l + 64 * j; if (f < DW_NUM_ACT * (DW_NUM_HIS - 1)) ob[DW_NUM_OBS1 * DW_NUM_HIS + f] = va[j]; }
     });
     // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
     wave.par([&](int l) {
@@ -721,7 +736,7 @@ DW_HD void simulate_env(const W &wave, Lds &S, const DevModel &M, const TaskPara
         if (l == 40) { S.push[0] = push ? push[2 * e] : 0.0f; S.push[1] = push ? push[2 * e + 1] : 0.0f; }
         if (l < 24) S.warm[l] = B.env_state ? B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + l] : 0.0f;
     });
-    physics_substep(wave, S, M, C.phys);
+    physics_substep(wave, S, M, C.phys, make_tree_uniform(M));
     wave.par([&](int l) {
         if (l < 24 && B.env_state) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + l] = S.warm[l];
     });
