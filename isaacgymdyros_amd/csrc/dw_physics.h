@@ -291,9 +291,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             const int k = l / 3, c = l - 3 * k;
             if (k < cnt) {
                 const int b = S.tree.level_body[L][k], p = S.tree.parent[b];
-                const float *Rp = S.B.kin.Rw[p], *Rb = S.A.R[b], *pos = S.tree.pos[b], *pax = S.tree.pax[b], *vp = S.V.dyn.v[p], *prp = S.B.kin.pr[p];
+                // every input into registers before the first write: the child's rows live in the same arrays as the
+                // parent's, so a store between two loads would order them (and cost an LDS round trip each)
+                float Rp[9], prp[3], pos[3], pax[3];
+                for (int i = 0; i < 9; ++i) Rp[i] = S.B.kin.Rw[p][i];
+                for (int i = 0; i < 3; ++i) { prp[i] = S.B.kin.pr[p][i]; pos[i] = S.tree.pos[b][i]; pax[i] = S.tree.pax[b][i]; }
+                const float *Rb = S.A.R[b];
                 const float r0 = Rb[c], r1 = Rb[3 + c], r2 = Rb[6 + c];           // column c of R
-                for (int i = 0; i < 3; ++i) S.B.kin.Rw[b][3 * i + c] = Rp[3 * i] * r0 + Rp[3 * i + 1] * r1 + Rp[3 * i + 2] * r2;
+                const float vpa = S.V.dyn.v[p][c], vpl = S.V.dyn.v[p][3 + c];
+                const float qd = S.qd[b - 1];
                 float aw[3], x[3];
                 m3v(Rp, pax, aw);
                 m3v(Rp, pos, x);
@@ -302,12 +308,12 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float ac = c == 0 ? aw[0] : (c == 1 ? aw[1] : aw[2]);
                 const float sc = c == 0 ? sx : (c == 1 ? sy : sz);
                 const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
-                const float qd = S.qd[b - 1];
+                for (int i = 0; i < 3; ++i) S.B.kin.Rw[b][3 * i + c] = Rp[3 * i] * r0 + Rp[3 * i + 1] * r1 + Rp[3 * i + 2] * r2;
                 S.B.kin.pr[b][c] = xc;
                 S.Sj[b][c] = ac;
                 S.Sj[b][3 + c] = sc;
-                S.V.dyn.v[b][c] = vp[c] + ac * qd;
-                S.V.dyn.v[b][3 + c] = vp[3 + c] + sc * qd;
+                S.V.dyn.v[b][c] = vpa + ac * qd;
+                S.V.dyn.v[b][3 + c] = vpl + sc * qd;
             }
         });
     }
