@@ -462,12 +462,15 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 cross3(xc, Fw, nb);
                 for (int i = 0; i < 3; ++i) { dn[i] += nb[i]; df[i] += Fw[i]; }
             }
-            for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] = -dn[i]; S.V.dyn.pA[b][3 + i] = -df[i]; }   // K3 adds the gyroscopic part
-            if (b == 0 || b == 6 || b == 12) {      // block B is recycled by the sweep: keep what the contact phases need
-                const int slot = b / 6;
-                float t[12];                         // (all reads, then all writes: an LDS-to-LDS copy written element by
-                for (int i = 0; i < 9; ++i) t[i] = S.B.kin.Rw[b][i];     //  element waits for each read before its write)
+            const bool keep = (b == 0 || b == 6 || b == 12);     // block B is recycled by the sweep: keep what the contact phases need
+            float t[12];                             // (all reads, then all writes: an LDS-to-LDS copy written element by
+            if (keep) {                              //  element waits for each read before its write)
+                for (int i = 0; i < 9; ++i) t[i] = S.B.kin.Rw[b][i];
                 for (int i = 0; i < 3; ++i) t[9 + i] = S.B.kin.pr[b][i];
+            }
+            for (int i = 0; i < 3; ++i) { S.V.dyn.pA[b][i] = -dn[i]; S.V.dyn.pA[b][3 + i] = -df[i]; }   // K3 adds the gyroscopic part
+            if (keep) {
+                const int slot = b / 6;
                 for (int i = 0; i < 9; ++i) S.RwK[slot][i] = t[i];
                 for (int i = 0; i < 3; ++i) S.pwK[slot][i] = t[9 + i];
             }
@@ -494,9 +497,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
                 mass += mk;
             }
-            float Rw[9], T[9], hy[3], x[3];
+            float Rw[9], T[9], hy[3], x[3], vin[6], pin[6];
             for (int i = 0; i < 9; ++i) Rw[i] = S.B.kin.Rw[b][i];
             for (int i = 0; i < 3; ++i) x[i] = S.B.kin.pr[b][i];
+            for (int i = 0; i < 6; ++i) { vin[i] = S.V.dyn.v[b][i]; pin[i] = S.V.dyn.pA[b][i]; }      // read before the stores below
             m3m(Rw, A, T);
             m3v(Rw, h, hy);
             const float xx = dot3(x, x), xh = dot3(x, hy);
@@ -520,16 +524,16 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     I[sym6(r3, 3 + c3)] = H[3 * r3 + c3];
                 }
             // pA += v x* (I v)
-            float om[3] = {S.V.dyn.v[b][0], S.V.dyn.v[b][1], S.V.dyn.v[b][2]}, vl[3] = {S.V.dyn.v[b][3], S.V.dyn.v[b][4], S.V.dyn.v[b][5]};
+            float om[3] = {vin[0], vin[1], vin[2]}, vl[3] = {vin[3], vin[4], vin[5]};
             float n[3], f[3], t1[3], t2[3];
             m3v(Ao, om, n); cross3(ho, vl, t1);
             n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
             cross3(om, ho, t1);                      // H' w = -h x w = w x h
             f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
             cross3(om, n, t1); cross3(vl, f, t2);
-            S.V.dyn.pA[b][0] += t1[0] + t2[0]; S.V.dyn.pA[b][1] += t1[1] + t2[1]; S.V.dyn.pA[b][2] += t1[2] + t2[2];
+            S.V.dyn.pA[b][0] = pin[0] + (t1[0] + t2[0]); S.V.dyn.pA[b][1] = pin[1] + (t1[1] + t2[1]); S.V.dyn.pA[b][2] = pin[2] + (t1[2] + t2[2]);
             cross3(om, f, t1);
-            S.V.dyn.pA[b][3] += t1[0]; S.V.dyn.pA[b][4] += t1[1]; S.V.dyn.pA[b][5] += t1[2];
+            S.V.dyn.pA[b][3] = pin[3] + t1[0]; S.V.dyn.pA[b][4] = pin[4] + t1[1]; S.V.dyn.pA[b][5] = pin[5] + t1[2];
         }
     });
     DW_CKPT(3);
@@ -561,9 +565,13 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float urd = ur * Dinv;
                 float Ia[6];
                 for (int c = 0; c < 6; ++c) Ia[c] = IA[sym6(r, c)] - urd * U[c];
+                // (every LDS input is read before the first store of the region: a store with a run-time index orders all
+                //  later loads behind it, and each such load then costs its own round trip)
                 float *dst = direct ? S.A.IA[p] : S.B.sw.T[k];
-                float old[3] = {0.0f, 0.0f, 0.0f};
-                if (direct) for (int c = 0; c < 3; ++c) old[c] = dst[sym6(r, 3 * h + c)];        // reads first, writes after
+                float old[3] = {0.0f, 0.0f, 0.0f}, vb[6];
+                if (direct) for (int c = 0; c < 3; ++c) old[c] = dst[sym6(r, 3 * h + c)];
+                for (int j = 0; j < 6; ++j) vb[j] = S.V.dyn.v[b][j];
+                const float pAr = S.V.dyn.pA[b][r], pAp = direct ? S.V.dyn.pA[p][r] : 0.0f;
                 for (int c = 0; c < 3; ++c) {
                     const int cc = 3 * h + c;
                     if (cc >= r) dst[sym6(r, cc)] = old[c] + (h ? Ia[3 + c] : Ia[c]);
@@ -571,10 +579,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 if (h == 0) {
                     float m[6], cb[6];
                     for (int j = 0; j < 6; ++j) m[j] = s[j] * qd;
-                    motion_cross(S.V.dyn.v[b], m, cb);
-                    float pa = S.V.dyn.pA[b][r] + ur * (u * Dinv);
+                    motion_cross(vb, m, cb);
+                    float pa = pAr + ur * (u * Dinv);
                     for (int c = 0; c < 6; ++c) pa += Ia[c] * cb[c];
-                    if (direct) S.V.dyn.pA[p][r] += pa; else S.B.sw.pa[k][r] = pa;
+                    if (direct) S.V.dyn.pA[p][r] = pAp + pa; else S.B.sw.pa[k][r] = pa;
                     if (r == 0) {
                         for (int j = 0; j < 6; ++j) S.C.art.U[b][j] = U[j];
                         S.C.art.Dinv[b] = Dinv;
@@ -771,6 +779,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 ja[0] = ax == 1 ? -r[2] : (ax == 2 ? r[1] : 0.0f);
                 ja[1] = ax == 0 ? r[2] : (ax == 2 ? -r[0] : 0.0f);
                 ja[2] = ax == 0 ? -r[1] : (ax == 1 ? r[0] : 0.0f);
+                float twv[6];
+                for (int i = 0; i < 6; ++i) twv[i] = S.V.con.twf[f][i];
                 float JW0[6], JW1[6];
                 for (int c = 0; c < 6; ++c) {
                     JW0[c] = ja[0] * S.V.con.W[6 * f][c] + ja[1] * S.V.con.W[6 * f + 1][c] + ja[2] * S.V.con.W[6 * f + 2][c] +
@@ -778,23 +788,22 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     JW1[c] = ja[0] * S.V.con.W[6 * f][6 + c] + ja[1] * S.V.con.W[6 * f + 1][6 + c] + ja[2] * S.V.con.W[6 * f + 2][6 + c] +
                              S.V.con.W[6 * f + 3 + ax][6 + c];
                 }
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    const float *r2 = S.V.con.rk[k2];
-                    // column (k2, ax2): sum_j JW[6 f2 + j] * (-skew(r2)[ax2][j]) + JW[6 f2 + 3 + ax2]
-                    S.A.lcp.A[l][3 * k2 + 0] = JW0[1] * r2[2] - JW0[2] * r2[1] + JW0[3];
-                    S.A.lcp.A[l][3 * k2 + 1] = -JW0[0] * r2[2] + JW0[2] * r2[0] + JW0[4];
-                    S.A.lcp.A[l][3 * k2 + 2] = JW0[0] * r2[1] - JW0[1] * r2[0] + JW0[5];
+                // the corners of one sole are read together before that half of the row is stored (2 round trips, not 8)
+                for (int half = 0; half < 2; ++half) {
+                    float rh[4][3];
+                    for (int k2 = 0; k2 < 4; ++k2) for (int i = 0; i < 3; ++i) rh[k2][i] = S.V.con.rk[4 * half + k2][i];
+                    const float *JW = half ? JW1 : JW0;
+                    for (int k2 = 0; k2 < 4; ++k2) {
+                        const float *r2 = rh[k2];
+                        // column (k2, ax2): sum_j JW[j] * (-skew(r2)[ax2][j]) + JW[3 + ax2]
+                        S.A.lcp.A[l][12 * half + 3 * k2 + 0] = JW[1] * r2[2] - JW[2] * r2[1] + JW[3];
+                        S.A.lcp.A[l][12 * half + 3 * k2 + 1] = -JW[0] * r2[2] + JW[2] * r2[0] + JW[4];
+                        S.A.lcp.A[l][12 * half + 3 * k2 + 2] = JW[0] * r2[1] - JW[1] * r2[0] + JW[5];
+                    }
                 }
-                for (int k2 = 4; k2 < 8; ++k2) {
-                    const float *r2 = S.V.con.rk[k2];
-                    S.A.lcp.A[l][3 * k2 + 0] = JW1[1] * r2[2] - JW1[2] * r2[1] + JW1[3];
-                    S.A.lcp.A[l][3 * k2 + 1] = -JW1[0] * r2[2] + JW1[2] * r2[0] + JW1[4];
-                    S.A.lcp.A[l][3 * k2 + 2] = JW1[0] * r2[1] - JW1[1] * r2[0] + JW1[5];
-                }
-                const float *tw = S.V.con.twf[f];
                 float t[3];
-                cross3(tw, r, t);
-                S.V.con.vel[1][l] = tw[3 + ax] + t[ax];
+                cross3(twv, r, t);
+                S.V.con.vel[1][l] = (ax == 0 ? twv[3] : (ax == 1 ? twv[4] : twv[5])) + (ax == 0 ? t[0] : (ax == 1 ? t[1] : t[2]));
             }
         });
         wave.par([&](int l) {
@@ -937,13 +946,17 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 }
                 float dp[6];
                 for (int i = 0; i < 3; ++i) { dp[i] = -Nm[i]; dp[3 + i] = -F[i]; }
+                float dus[6];
+#pragma unroll
                 for (int i = 6; i >= 1; --i) {
                     const int b = 6 * l + i;
                     const float d = -dot6(S.Sj[b], dp);
-                    S.B.post.du[b] = d;
+                    dus[i - 1] = d;
                     const float kk = d * S.C.art.Dinv[b];
                     for (int j = 0; j < 6; ++j) dp[j] += S.C.art.U[b][j] * kk;
                 }
+#pragma unroll
+                for (int i = 1; i <= 6; ++i) S.B.post.du[6 * l + i] = dus[i - 1];
                 for (int j = 0; j < 6; ++j) S.A.lcp.dpf[l][j] = dp[j];
                 const int gy = M.foot_gym[4 * l];
                 const float c0 = S.contact[3 * gy], c1 = S.contact[3 * gy + 1], c2 = S.contact[3 * gy + 2];
@@ -999,6 +1012,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         if (l == 40) {
             float wwn[3], von[3];
             for (int i = 0; i < 3; ++i) { wwn[i] = S.B.post.wwf[i] + S.B.post.dv0[i]; von[i] = S.B.post.vowf[i] + S.B.post.dv0[3 + i]; }
+            const float qin[4] = {S.quat[0], S.quat[1], S.quat[2], S.quat[3]};      // read before the position is stored
             {
                 const float wn2 = dot3(wwn, wwn);
                 if (wn2 > P.max_ang_vel * P.max_ang_vel) {
@@ -1021,7 +1035,7 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             }
             const float dq[4] = {wwn[0] * sh, wwn[1] * sh, wwn[2] * sh, ch};
             const float x1 = dq[0], y1 = dq[1], z1 = dq[2], w1 = dq[3];
-            const float x2q = S.quat[0], y2 = S.quat[1], z2 = S.quat[2], w2q = S.quat[3];
+            const float x2q = qin[0], y2 = qin[1], z2 = qin[2], w2q = qin[3];
             float qn[4] = {w1 * x2q + x1 * w2q + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2q + z1 * x2q,
                            w1 * z2 + x1 * y2 - y1 * x2q + z1 * w2q, w1 * w2q - x1 * x2q - y1 * y2 - z1 * z2};
             const float ninv = rsqrt_nr(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
