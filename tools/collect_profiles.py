@@ -5,14 +5,16 @@ import glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+traffic_only = "--traffic-only" in sys.argv      # on the GPU box, between the PMC passes and the bench run
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
-shutil.copy(os.path.join(src, "bench_torchrun1.json"), os.path.join(dst, "%s_bench_torchrun_1rank.json" % tag))
-stats = glob.glob(os.path.join(src, "prof", "**", "*kernel_stats.csv"), recursive=True)[0]
-with open(stats) as f:
+if not traffic_only:
+  shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % tag))
+  shutil.copy(os.path.join(src, "bench_torchrun1.json"), os.path.join(dst, "%s_bench_torchrun_1rank.json" % tag))
+  stats = glob.glob(os.path.join(src, "prof", "**", "*kernel_stats.csv"), recursive=True)[0]
+  with open(stats) as f:
     lines = f.readlines()
-with open(os.path.join(dst, "%s_kernel_stats_bench_16384.csv" % tag), "w") as f:
+  with open(os.path.join(dst, "%s_kernel_stats_bench_16384.csv" % tag), "w") as f:
     f.writelines(lines[:12])                     # header + the ten largest rows; the rest are torch fill/copy kernels
 summ = json.loads(open(os.path.join(src, "pmc", "summary.txt")).read())
 name = "%s_pmc_summary_step_16384.json" % tag
