@@ -1,7 +1,7 @@
 // dw_hip.hip -- gfx950 kernels and the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so).
 //
 // One workgroup = one wavefront = one environment.  The kernel bodies live in dw_task.h / dw_physics.h as
-// wave regions over a 13.4 KB LDS block per env (12 envs resident per CU); this file only declares
+// wave regions over a 13.5 KB LDS block per env (12 envs resident per CU); this file only declares
 // the __global__ entry points, owns the read-only model/mocap tables in device memory and validates
 // arguments.  Nothing here allocates, synchronises or copies per call (graph-capture safe).
 #include <hip/hip_runtime.h>
@@ -30,8 +30,8 @@ static int fail_hip(const char *what, hipError_t e) {
     return DW_EHIP;
 }
 
-// 13.4 KB of LDS per env admits 12 envs per CU = 3 waves per SIMD; cap the registers at 168 to match (the ~60
-// spilled values sit at the substep-loop boundary, measured +16 % over 2 waves/SIMD at 256 registers)
+// 13.5 KB of LDS per env admits 12 envs per CU = 3 waves per SIMD; cap the registers at 168 to match (measured +16 %
+// over 2 waves/SIMD at 256 registers; the kernel fits the cap without scratch)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
     __shared__ dw::Lds S;
