@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 2
+#define DW_ABI_VERSION 3
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -168,6 +168,19 @@ typedef struct DwConfig {
     int32_t self_collision;             /* 1 = leg-vs-leg capsule self-collision; 0 = ground contacts only */
     int32_t debug_freeze_physics;       /* 1 = simulate() leaves the state untouched (task-logic parity tests) */
     uint64_t seed;                      /* key of the counter-based in-kernel RNG                     */
+    /* Terrain (reference cfg/terrain/terrain_cfg.py:1-22, tasks/dyros_dynamic_walk.py:203-270 create,
+     * :671-691 curriculum, :693-708 origins, :729-732 spawn jitter).  terrain = 0 is the ground plane z = 0. */
+    int32_t terrain;                    /* 1 = height field in DwBuffers.height_samples ('heightfield' and 'trimesh') */
+    int32_t terrain_rows, terrain_cols; /* samples along x / y (Terrain.tot_rows, tot_cols)           */
+    float   terrain_hscale;             /* horizontal_scale: sample spacing [m]                       */
+    float   terrain_vscale;             /* vertical_scale: height per sample unit [m]                 */
+    float   terrain_border;             /* border_size [m]: world (x,y) = index * hscale - border     */
+    int32_t terrain_curriculum;         /* TerrainCfg.curriculum: change level at reset (:671-691)    */
+    int32_t terrain_num_levels;         /* num_rows of the tile grid = max_terrain_level              */
+    int32_t terrain_num_types;          /* num_cols of the tile grid                                  */
+    float   terrain_env_length;         /* terrain_length [m]: walked more than half of it => level up */
+    float   max_episode_length_s;       /* env.episodeLength as the curriculum uses it (:34, :685)    */
+    int32_t custom_origins;             /* 1 = reset adds U(-1,1) m of xy jitter to the origin (:729-732) */
 } DwConfig;
 
 /* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of
@@ -187,6 +200,8 @@ typedef struct DwConfig {
 #define DW_NZ_DR_ARM  136   /* [33]          */
 #define DW_NZ_DR_FRIC 169   /* [1]           */
 #define DW_NZ_PERT   170    /* [3] impulse, duration, phase (:440-443) */
+#define DW_NZ_TERRAIN_LVL 173 /* [1] randint_like for robots that solved the last level (:689) */
+#define DW_NZ_ROOT_JITTER 174 /* [2] spawn jitter on terrain (:732)                            */
 #define DW_NOISE_WORDS 176
 
 /* Per-env task-state record: DW_ES_WORDS 32-bit words, 16-byte aligned, one contiguous row per env
@@ -261,6 +276,11 @@ typedef struct DwBuffers {
      * 32 buckets (env % 32) of {sum epi_len_log, sum contact_reward_mean * 2^32} as int64 (integer sums are
      * order-independent, so the gate is deterministic), latch word at [DW_GATE_LATCH] */
     int64_t *gate_acc;        /* [DW_GATE_WORDS]                                        */
+    /* terrain (may be NULL when DwConfig.terrain == 0) */
+    int16_t *height_samples;  /* [terrain_rows, terrain_cols] Terrain.heightsamples      */
+    float   *terrain_origins; /* [terrain_num_levels, terrain_num_types, 3] tile spawn origins */
+    int64_t *terrain_levels;  /* [N] current difficulty level of each env                */
+    int64_t *terrain_types;   /* [N] terrain type (column) of each env, fixed            */
 } DwBuffers;
 
 typedef struct DwHandle DwHandle;

@@ -66,6 +66,18 @@ class DwConfig(C.Structure):
         ("self_collision", C.c_int32),
         ("debug_freeze_physics", C.c_int32),
         ("seed", C.c_uint64),
+        ("terrain", C.c_int32),
+        ("terrain_rows", C.c_int32),
+        ("terrain_cols", C.c_int32),
+        ("terrain_hscale", C.c_float),
+        ("terrain_vscale", C.c_float),
+        ("terrain_border", C.c_float),
+        ("terrain_curriculum", C.c_int32),
+        ("terrain_num_levels", C.c_int32),
+        ("terrain_num_types", C.c_int32),
+        ("terrain_env_length", C.c_float),
+        ("max_episode_length_s", C.c_float),
+        ("custom_origins", C.c_int32),
     ]
 
 
@@ -77,7 +89,8 @@ class DwBuffers(C.Structure):
         "root_states", "dof_state", "contact_forces",
         "mass_scale", "dof_damping", "dof_armature", "friction_scale", "total_mass", "env_origins",
         "obs_buf", "rew_buf", "reset_buf", "progress_buf", "timeout_buf", "randomize_buf",
-        "stacked_rewards", "env_state", "obs_history", "action_history", "gate_acc")]
+        "stacked_rewards", "env_state", "obs_history", "action_history", "gate_acc",
+        "height_samples", "terrain_origins", "terrain_levels", "terrain_types")]
 
 
 BUFFER_NAMES = [n for n, _ in DwBuffers._fields_]
@@ -132,8 +145,16 @@ BUFFER_SPECS = {
     "obs_history": ((K["DW_HIST_SLOTS"], K["DW_NUM_OBS1"]), "f4"),
     "action_history": ((K["DW_HIST_SLOTS"], K["DW_NUM_ACT"]), "f4"),
     "gate_acc": (None, "i8"),
+    # terrain (row f-4): two tables shared by all envs (one-element placeholders on the ground plane) and two per-env words
+    "height_samples": (None, "i2"),
+    "terrain_origins": (None, "f4"),
+    "terrain_levels": ((), "i8"),
+    "terrain_types": ((), "i8"),
 }
 GATE_ACC_WORDS = K["DW_GATE_WORDS"]
+# element counts of the buffers that are not per-env (shape None above); the terrain tables are re-allocated by the
+# host class when a height field is configured
+GLOBAL_WORDS = {"gate_acc": GATE_ACC_WORDS, "height_samples": 4, "terrain_origins": 3}
 
 # env-state record fields: name -> (word offset, shape, 'f' float32 | 'i' int32); see DW_ES_* in the header
 ES_FIELDS = {

@@ -38,14 +38,31 @@ void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actio
     dw::Wave w;
     dw::TaskBuffers T;
     T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
-    dw::step_env(w, S, *M, P->C, T, (int)blockIdx.x);
+    dw::step_env<false>(w, S, *M, P->C, T, (int)blockIdx.x);
+}
+
+// the same step on a height field (DwConfig.terrain = 1): every contact point samples the terrain
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
+    __shared__ dw::Lds S;
+    dw::Wave w;
+    dw::TaskBuffers T;
+    T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
+    dw::step_env<true>(w, S, *M, P->C, T, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
                                                     const float *tau, const float *push) {
     __shared__ dw::Lds S;
     dw::Wave w;
-    dw::simulate_env(w, S, *M, P->C, P->B, tau, push, (int)blockIdx.x);
+    dw::simulate_env<false>(w, S, *M, P->C, P->B, tau, push, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void dw_k_simulate_terrain(const dw::DevModel *M, const dw::DevParams *P,
+                                                            const float *tau, const float *push) {
+    __shared__ dw::Lds S;
+    dw::Wave w;
+    dw::simulate_env<true>(w, S, *M, P->C, P->B, tau, push, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, const dw::DevParams *P, const float *noise,
@@ -116,10 +133,14 @@ int dw_destroy(DwHandle *h) {
 int dw_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dw_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
+    if (const char *m = dw::check_terrain_buffers(&h->cfg, b)) return fail(DW_EINVAL, m);
     h->buf = *b;
     // bind time, not step time: one small synchronous copy of the pointer table into the parameter block
     hipError_t e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip("dw_bind: pointer table upload", e);
+    const int16_t *hs = h->cfg.terrain ? b->height_samples : nullptr;
+    e = hipMemcpy(&h->d_params->C.phys.hs, &hs, sizeof(hs), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip("dw_bind: terrain pointer upload", e);
     h->bound = 1;
     return DW_OK;
 }
@@ -128,8 +149,12 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!h || !h->bound) return fail(DW_ESTATE, "dw_simulate: buffers not bound");
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
-    hipLaunchKernelGGL(dw_k_simulate, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
-                       tau, push_xy);
+    if (h->cfg.terrain)
+        hipLaunchKernelGGL(dw_k_simulate_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
+                           h->d_params, tau, push_xy);
+    else
+        hipLaunchKernelGGL(dw_k_simulate, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
+                           tau, push_xy);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_simulate: launch", e);
     return DW_OK;
@@ -140,8 +165,12 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
-    hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
-                       actions, noise, (long long)step_index);
+    if (h->cfg.terrain)
+        hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
+                           h->d_params, actions, noise, (long long)step_index);
+    else
+        hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
+                           actions, noise, (long long)step_index);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_step: launch", e);
     return DW_OK;

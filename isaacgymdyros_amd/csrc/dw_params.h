@@ -11,6 +11,10 @@ inline const char *check_config(const DwConfig *c) {
     if (!(c->dt > 0)) return "dt must be positive";
     if (c->solver_iterations < 1 || c->solver_iterations > 64) return "solver_iterations out of range";
     if (!(c->friction >= 0)) return "friction must be non-negative";
+    if (c->terrain && (c->terrain_rows < 2 || c->terrain_cols < 2 || !(c->terrain_hscale > 0) || !(c->terrain_vscale > 0)))
+        return "terrain: rows/cols >= 2 and positive scales required";
+    if (c->terrain_curriculum && (c->terrain_num_levels < 1 || c->terrain_num_types < 1))
+        return "terrain curriculum: num_levels and num_types must be positive";
     return nullptr;
 }
 
@@ -54,6 +58,15 @@ inline TaskParams make_task_params(const DwConfig *c) {
     t.gpu_div = c->torch_gpu_div;
     t.freeze_physics = c->debug_freeze_physics;
     t.seed = c->seed;
+    t.phys.hs = nullptr;                                      // set at bind
+    t.phys.t_rows = c->terrain_rows; t.phys.t_cols = c->terrain_cols;
+    t.phys.t_inv_h = c->terrain ? 1.0f / c->terrain_hscale : 0.0f;
+    t.phys.t_vs = c->terrain_vscale; t.phys.t_border = c->terrain_border;
+    t.terrain_curriculum = c->terrain_curriculum;
+    t.custom_origins = c->custom_origins;
+    t.terrain_num_levels = c->terrain_num_levels; t.terrain_num_types = c->terrain_num_types;
+    t.terrain_half_length = (float)(c->terrain_env_length / 2.0);
+    t.max_episode_length_s = c->max_episode_length_s;
     return t;
 }
 
@@ -84,6 +97,13 @@ inline void default_config(DwConfig *c) {
     c->torch_gpu_div = 1;
     c->self_collision = 1;
     c->seed = 42;
+}
+
+inline const char *check_terrain_buffers(const DwConfig *c, const DwBuffers *b) {
+    if (c->terrain && !b->height_samples) return "terrain configured but height_samples is null";
+    if (c->terrain_curriculum && (!b->terrain_origins || !b->terrain_levels || !b->terrain_types))
+        return "terrain curriculum configured but terrain_origins / terrain_levels / terrain_types is null";
+    return nullptr;
 }
 
 inline const char *check_buffers(const DwBuffers *b, bool task) {

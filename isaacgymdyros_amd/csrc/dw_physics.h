@@ -36,6 +36,10 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
     float max_ang_vel;
     int   vel_at_com;
     int   self_collision;
+    // height field (row f-4); hs == nullptr on the ground plane
+    const int16_t *hs;
+    int   t_rows, t_cols;
+    float t_inv_h, t_vs, t_border;
 };
 
 // The kinematic tree, staged once per launch into the env's LDS block: every sweep region indexes these by lane
@@ -106,6 +110,7 @@ struct alignas(16) Lds {
             int   active[8];
             int   any_active;
             float twf[2][6];
+            float frame[8][9];                                                  //   contact frames t1, t2, n (height field only)
         } con;
     } V;
     struct alignas(16) {            // block C
@@ -189,6 +194,30 @@ DW_HD float dot6(const float *a, const float *b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 
+// Height field under a world point (row f-4): bilinear height of the four samples around it, unit normal from that
+// patch's gradient, contact frame (t1, t2, n) with t1 = world x projected into the tangent plane (oracle/dw_physics.c
+// terrain_sample; grid convention of the reference, tasks/dyros_dynamic_walk.py:240-253).
+DW_HD void terrain_sample(const PhysParams &P, float x, float y, float *h, float *fr) {
+    float u = (x + P.t_border) * P.t_inv_h, v = (y + P.t_border) * P.t_inv_h;
+    const float umax = (float)(P.t_rows - 1) - 1e-3f, vmax = (float)(P.t_cols - 1) - 1e-3f;
+    u = u < 0.0f ? 0.0f : (u > umax ? umax : u);
+    v = v < 0.0f ? 0.0f : (v > vmax ? vmax : v);
+    const int i = (int)u, j = (int)v;
+    const float a = u - (float)i, b = v - (float)j;
+    const int16_t *p = P.hs + (size_t)i * P.t_cols + j;
+    const float h00 = p[0], h01 = p[1], h10 = p[P.t_cols], h11 = p[P.t_cols + 1];
+    *h = P.t_vs * ((1.0f - a) * ((1.0f - b) * h00 + b * h01) + a * ((1.0f - b) * h10 + b * h11));
+    const float gx = P.t_vs * P.t_inv_h * ((1.0f - b) * (h10 - h00) + b * (h11 - h01));
+    const float gy = P.t_vs * P.t_inv_h * ((1.0f - a) * (h01 - h00) + a * (h11 - h10));
+    const float nn = rsqrt_nr(gx * gx + gy * gy + 1.0f);
+    float *t1 = fr, *t2 = fr + 3, *n = fr + 6;
+    n[0] = -gx * nn; n[1] = -gy * nn; n[2] = nn;
+    const float a1[3] = {1.0f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+    const float tn = rsqrt_nr(dot3(a1, a1));
+    t1[0] = a1[0] * tn; t1[1] = a1[1] * tn; t1[2] = a1[2] * tn;
+    cross3(n, t1, t2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // the substep.  In: S.root, q, qd, tau, arm, damp, mscale, mu, push, warm.  Out: root, q, qd, warm, contact.
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +269,8 @@ DW_HD TreeUniform make_tree_uniform(const DevModel &M) {
     return t;
 }
 
-template <class W>
+// TERRAIN = false is the ground plane z = 0 (the benchmark path); true samples the height field under every contact.
+template <bool TERRAIN, class W>
 DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysParams &P, const TreeUniform &TU) {
     const float dt = P.dt;
 
@@ -353,7 +383,28 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             m3v(Rw, rl, wv);
             for (int i = 0; i < 3; ++i) xr[i] = S.B.kin.pr[b][i] + wv[i];
             const float zmin = S.root[2] + xr[2];
-            if (zmin < 0) {
+            if (TERRAIN) {
+                float hh, fr[9];
+                terrain_sample(P, S.root[0] + xr[0], S.root[1] + xr[1], &hh, fr);
+                const float *nrm = fr + 6;
+                const float dist = (zmin - hh) * nrm[2];
+                if (dist < 0) {
+                    float t[3], vw[3];
+                    cross3(S.V.dyn.v[b], xr, t);
+                    for (int i = 0; i < 3; ++i) vw[i] = S.V.dyn.v[b][3 + i] + t[i];
+                    const float vn = dot3(vw, nrm);
+                    float fn = P.pen_k * (-dist) - P.pen_c * vn;
+                    if (fn < 0) fn = 0;
+                    const float vt[3] = {vw[0] - vn * nrm[0], vw[1] - vn * nrm[1], vw[2] - vn * nrm[2]};
+                    const float sp = sqrtf(dot3(vt, vt));
+                    for (int i = 0; i < 3; ++i) F[i] = fn * nrm[i];
+                    if (sp > 1e-9f) {
+                        float ft = P.pen_c * sp, lim = S.mu * fn;
+                        if (ft > lim) ft = lim;
+                        for (int i = 0; i < 3; ++i) F[i] -= ft * vt[i] / sp;
+                    }
+                }
+            } else if (zmin < 0) {
                 float t[3], vw[3];
                 cross3(S.V.dyn.v[b], xr, t);
                 for (int i = 0; i < 3; ++i) vw[i] = S.V.dyn.v[b][3 + i] + t[i];
@@ -704,7 +755,13 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
             float r[3];
             m3v(S.RwK[1 + k / 4], M.foot_pos[k], r);
             for (int i = 0; i < 3; ++i) r[i] += S.pwK[1 + k / 4][i];
-            const float phi = S.root[2] + r[2];
+            float phi = S.root[2] + r[2];
+            if (TERRAIN) {
+                float hh, fr[9];
+                terrain_sample(P, S.root[0] + r[0], S.root[1] + r[1], &hh, fr);
+                phi = (phi - hh) * fr[8];
+                for (int i = 0; i < 9; ++i) S.V.con.frame[k][i] = fr[i];
+            }
             const int act = phi < P.contact_offset;
             for (int i = 0; i < 3; ++i) S.V.con.rk[k][i] = r[i];
             S.V.con.phi[k] = phi;
@@ -779,31 +836,55 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 ja[0] = ax == 1 ? -r[2] : (ax == 2 ? r[1] : 0.0f);
                 ja[1] = ax == 0 ? r[2] : (ax == 2 ? -r[0] : 0.0f);
                 ja[2] = ax == 0 ? -r[1] : (ax == 1 ? r[0] : 0.0f);
+                float dd[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f};
+                if (TERRAIN) {      // row direction d = frame vector ax of the corner: J = [r x d, d]
+                    for (int i = 0; i < 3; ++i) dd[i] = S.V.con.frame[k][3 * ax + i];
+                    cross3(r, dd, ja);
+                }
                 float twv[6];
                 for (int i = 0; i < 6; ++i) twv[i] = S.V.con.twf[f][i];
                 float JW0[6], JW1[6];
                 for (int c = 0; c < 6; ++c) {
-                    JW0[c] = ja[0] * S.V.con.W[6 * f][c] + ja[1] * S.V.con.W[6 * f + 1][c] + ja[2] * S.V.con.W[6 * f + 2][c] +
-                             S.V.con.W[6 * f + 3 + ax][c];
-                    JW1[c] = ja[0] * S.V.con.W[6 * f][6 + c] + ja[1] * S.V.con.W[6 * f + 1][6 + c] + ja[2] * S.V.con.W[6 * f + 2][6 + c] +
-                             S.V.con.W[6 * f + 3 + ax][6 + c];
+                    if (TERRAIN) {
+                        JW0[c] = ja[0] * S.V.con.W[6 * f][c] + ja[1] * S.V.con.W[6 * f + 1][c] + ja[2] * S.V.con.W[6 * f + 2][c] +
+                                 dd[0] * S.V.con.W[6 * f + 3][c] + dd[1] * S.V.con.W[6 * f + 4][c] + dd[2] * S.V.con.W[6 * f + 5][c];
+                        JW1[c] = ja[0] * S.V.con.W[6 * f][6 + c] + ja[1] * S.V.con.W[6 * f + 1][6 + c] + ja[2] * S.V.con.W[6 * f + 2][6 + c] +
+                                 dd[0] * S.V.con.W[6 * f + 3][6 + c] + dd[1] * S.V.con.W[6 * f + 4][6 + c] + dd[2] * S.V.con.W[6 * f + 5][6 + c];
+                    } else {
+                        JW0[c] = ja[0] * S.V.con.W[6 * f][c] + ja[1] * S.V.con.W[6 * f + 1][c] + ja[2] * S.V.con.W[6 * f + 2][c] +
+                                 S.V.con.W[6 * f + 3 + ax][c];
+                        JW1[c] = ja[0] * S.V.con.W[6 * f][6 + c] + ja[1] * S.V.con.W[6 * f + 1][6 + c] + ja[2] * S.V.con.W[6 * f + 2][6 + c] +
+                                 S.V.con.W[6 * f + 3 + ax][6 + c];
+                    }
                 }
                 // the corners of one sole are read together before that half of the row is stored (2 round trips, not 8)
                 for (int half = 0; half < 2; ++half) {
                     float rh[4][3];
                     for (int k2 = 0; k2 < 4; ++k2) for (int i = 0; i < 3; ++i) rh[k2][i] = S.V.con.rk[4 * half + k2][i];
                     const float *JW = half ? JW1 : JW0;
+                    float fh[4][9];
+                    if (TERRAIN) for (int k2 = 0; k2 < 4; ++k2) for (int i = 0; i < 9; ++i) fh[k2][i] = S.V.con.frame[4 * half + k2][i];
                     for (int k2 = 0; k2 < 4; ++k2) {
                         const float *r2 = rh[k2];
-                        // column (k2, ax2): sum_j JW[j] * (-skew(r2)[ax2][j]) + JW[3 + ax2]
-                        S.A.lcp.A[l][12 * half + 3 * k2 + 0] = JW[1] * r2[2] - JW[2] * r2[1] + JW[3];
-                        S.A.lcp.A[l][12 * half + 3 * k2 + 1] = -JW[0] * r2[2] + JW[2] * r2[0] + JW[4];
-                        S.A.lcp.A[l][12 * half + 3 * k2 + 2] = JW[0] * r2[1] - JW[1] * r2[0] + JW[5];
+                        // column (k2, ax2): sum_j JW[j] * (-skew(r2)[ax2][j]) + JW[3 + ax2]; in world axes the three columns
+                        // of a corner are the vector JW_lin + JW_ang x r2, on terrain projected on the corner's frame
+                        const float c0 = JW[1] * r2[2] - JW[2] * r2[1] + JW[3];
+                        const float c1 = -JW[0] * r2[2] + JW[2] * r2[0] + JW[4];
+                        const float c2 = JW[0] * r2[1] - JW[1] * r2[0] + JW[5];
+                        if (TERRAIN) {
+                            for (int a2 = 0; a2 < 3; ++a2)
+                                S.A.lcp.A[l][12 * half + 3 * k2 + a2] = fh[k2][3 * a2] * c0 + fh[k2][3 * a2 + 1] * c1 + fh[k2][3 * a2 + 2] * c2;
+                        } else {
+                            S.A.lcp.A[l][12 * half + 3 * k2 + 0] = c0;
+                            S.A.lcp.A[l][12 * half + 3 * k2 + 1] = c1;
+                            S.A.lcp.A[l][12 * half + 3 * k2 + 2] = c2;
+                        }
                     }
                 }
                 float t[3];
                 cross3(twv, r, t);
-                S.V.con.vel[1][l] = (ax == 0 ? twv[3] : (ax == 1 ? twv[4] : twv[5])) + (ax == 0 ? t[0] : (ax == 1 ? t[1] : t[2]));
+                if (TERRAIN) S.V.con.vel[1][l] = dd[0] * (twv[3] + t[0]) + dd[1] * (twv[4] + t[1]) + dd[2] * (twv[5] + t[2]);
+                else S.V.con.vel[1][l] = (ax == 0 ? twv[3] : (ax == 1 ? twv[4] : twv[5])) + (ax == 0 ? t[0] : (ax == 1 ? t[1] : t[2]));
             }
         });
         wave.par([&](int l) {
@@ -940,9 +1021,14 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 const float *Pc = S.V.con.P[cur];
                 float F[3] = {0, 0, 0}, Nm[3] = {0, 0, 0};
                 for (int k = 4 * l; k < 4 * l + 4; ++k) {
-                    float t[3];
-                    cross3(S.V.con.rk[k], Pc + 3 * k, t);
-                    for (int i = 0; i < 3; ++i) { F[i] += Pc[3 * k + i]; Nm[i] += t[i]; }
+                    float t[3], pw[3] = {Pc[3 * k], Pc[3 * k + 1], Pc[3 * k + 2]};
+                    if (TERRAIN) {      // impulse components are along the corner's frame: back to world axes
+                        const float *fr = S.V.con.frame[k];
+                        const float p0 = pw[0], p1 = pw[1], p2 = pw[2];
+                        for (int i = 0; i < 3; ++i) pw[i] = p0 * fr[i] + p1 * fr[3 + i] + p2 * fr[6 + i];
+                    }
+                    cross3(S.V.con.rk[k], pw, t);
+                    for (int i = 0; i < 3; ++i) { F[i] += pw[i]; Nm[i] += t[i]; }
                 }
                 float dp[6];
                 for (int i = 0; i < 3; ++i) { dp[i] = -Nm[i]; dp[3 + i] = -F[i]; }

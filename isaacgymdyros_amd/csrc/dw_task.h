@@ -42,6 +42,11 @@ struct TaskParams {                  // wave-uniform scalars (kernel arguments)
     int     gpu_div;
     int     freeze_physics;
     unsigned long long seed;
+    // terrain curriculum and spawn (row f-4)
+    int     terrain_curriculum, custom_origins;
+    int     terrain_num_levels, terrain_num_types;
+    float   terrain_half_length;       // (float)(terrain_length / 2)
+    float   max_episode_length_s;
 };
 
 struct TaskBuffers {                 // device pointers (DwBuffers, read through memory) + per-call pointers
@@ -214,6 +219,28 @@ DW_HD void store_env(const W &wave, Lds &S, const DwBuffers &B, int e, bool with
 template <class W>
 DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                         const NoiseSrc &nz, int e) {
+    // terrain curriculum (tasks/dyros_dynamic_walk.py:603-604,671-691): from the position the robot reached and the
+    // target velocity of the episode that ended; the new origin goes to S.scratch[4..6] for the spawn below
+    if (C.terrain_curriculum) {
+        wave.par([&](int l) {
+            if (l == 0) {
+                const float d[2] = {S.root[0] - B.env_origins[3 * e], S.root[1] - B.env_origins[3 * e + 1]};
+                const float distance = norm_t(d, 2);
+                const bool move_up = distance > C.terrain_half_length;
+                const float need = norm_t(&S.es[DW_ES_TARGET_VEL], 2) * C.max_episode_length_s * 0.5f;
+                const bool move_down = (distance < need) && !move_up;
+                long long lvl = B.terrain_levels[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
+                if (lvl >= C.terrain_num_levels) {
+                    int k = (int)(noise_word(nz, DW_NZ_TERRAIN_LVL) * (float)C.terrain_num_levels);     // randint_like
+                    if (k > C.terrain_num_levels - 1) k = C.terrain_num_levels - 1;
+                    lvl = k;
+                } else if (lvl < 0) lvl = 0;
+                B.terrain_levels[e] = lvl;
+                const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + B.terrain_types[e]) * 3;
+                for (int i = 0; i < 3; ++i) { const float o = org[i]; B.env_origins[3 * e + i] = o; S.scratch[4 + i] = o; }
+            }
+        });
+    }
     wave.par([&](int l) {
         const bool do_dr = (C.dr_dof || C.dr_friction) && S.flags[4] >= 1;
         if (l < ND) {
@@ -241,7 +268,9 @@ DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskPara
             const int i = l - 16;
             const float r0[13] = {0, 0, C.initial_height, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
             float v = r0[i];
-            if (i < 3) v += B.env_origins[3 * e + i];
+            if (i < 3) v += C.terrain_curriculum ? S.scratch[4 + i] : B.env_origins[3 * e + i];
+            // xy position within 1 m of the tile centre (:729-732; torch_rand_float = 2 u + (-1))
+            if (i < 2 && C.custom_origins) v += 2.0f * noise_word(nz, DW_NZ_ROOT_JITTER + i) + (-1.0f);
             S.root[i] = v;
         }
         for (int i = l; i < DW_ALOG_SLOTS * 12; i += 64) S.es[DW_ES_ACTION_LOG + i] = 0.0f;
@@ -289,7 +318,7 @@ DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskPara
 }
 
 // ---------------------------------------------------------------------------------------------- the step
-template <class W>
+template <bool TERRAIN, class W>
 DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
     const DwBuffers &B = *T.b;
     NoiseSrc nz;
@@ -435,7 +464,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             }
             if (l == 40) { S.push[0] = sub == 0 ? S.scratch[1] : 0.0f; S.push[1] = sub == 0 ? S.scratch[2] : 0.0f; }
         });
-        if (!C.freeze_physics) physics_substep(wave, S, M, C.phys, TU);
+        if (!C.freeze_physics) physics_substep<TERRAIN>(wave, S, M, C.phys, TU);
         wave.par([&](int l) {
             if (l < ND) {
                 const float n = noise_word(nz, DW_NZ_ENC + ND * sub + l);
@@ -726,7 +755,7 @@ DW_HD void reset_only_env(const W &wave, Lds &S, const DevModel &M, const TaskPa
 }
 
 // Gym-boundary substep: tau [N,33], push [N,2] or nullptr
-template <class W>
+template <bool TERRAIN, class W>
 DW_HD void simulate_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                         const float *tau, const float *push, int e) {
     stage_tree(wave, S, M);
@@ -736,7 +765,7 @@ DW_HD void simulate_env(const W &wave, Lds &S, const DevModel &M, const TaskPara
         if (l == 40) { S.push[0] = push ? push[2 * e] : 0.0f; S.push[1] = push ? push[2 * e + 1] : 0.0f; }
         if (l < 24) S.warm[l] = B.env_state ? B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + l] : 0.0f;
     });
-    physics_substep(wave, S, M, C.phys, make_tree_uniform(M));
+    physics_substep<TERRAIN>(wave, S, M, C.phys, make_tree_uniform(M));
     wave.par([&](int l) {
         if (l < 24 && B.env_state) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + l] = S.warm[l];
     });

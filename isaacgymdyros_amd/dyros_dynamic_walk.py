@@ -20,7 +20,7 @@ from .model import NUM_BODIES, NUM_DOF, load_model
 from .task_constants import REWARD_NAMES, load_task_constants
 from .vec_task import VecTask
 
-_TORCH_DT = {"f4": torch.float32, "i8": torch.int64}
+_TORCH_DT = {"f4": torch.float32, "i8": torch.int64, "i2": torch.int16}
 
 
 def _u(gen, shape, device):
@@ -70,6 +70,15 @@ class DyrosDynamicWalk(VecTask):
         self.mocap_cycle_dt = 0.0005
         self.mocap_cycle_period = self.mocap_data_num * self.mocap_cycle_dt
 
+        # terrain (reference :47, :203-213): a TerrainCfg with the reference's defaults ('plane'), overridden by an
+        # optional cfg["terrain"] mapping since this package has no class to edit
+        from .terrain import Terrain, TerrainCfg
+        self.terrain_cfg = TerrainCfg(**dict(cfg.get("terrain", {}) or {}))
+        if self.terrain_cfg.mesh_type not in (None, "none", "plane", "heightfield", "trimesh"):
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
+        self.custom_origins = self.terrain_cfg.mesh_type in ("heightfield", "trimesh")
+        if self.custom_origins:
+            self.terrain = Terrain(self.terrain_cfg, self.num_envs, seed=int(cfg.get("seed", 42)))
         self._tc = load_task_constants()
         self._make_config()
         self._create_native()
@@ -124,6 +133,18 @@ class DyrosDynamicWalk(VecTask):
         c.self_collision = int(bool(mi.get("self_collision", True)))
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
+        tc = self.terrain_cfg
+        c.terrain = int(self.custom_origins)
+        c.custom_origins = int(self.custom_origins)
+        if self.custom_origins:
+            c.terrain_rows, c.terrain_cols = int(self.terrain.tot_rows), int(self.terrain.tot_cols)
+            c.terrain_hscale, c.terrain_vscale = float(tc.horizontal_scale), float(tc.vertical_scale)
+            c.terrain_border = float(tc.border_size)
+            c.terrain_curriculum = int(bool(tc.curriculum))
+            c.terrain_num_levels, c.terrain_num_types = int(tc.num_rows), int(tc.num_cols)
+            c.terrain_env_length = float(self.terrain.env_length)
+            c.max_episode_length_s = float(self.max_episode_length_s)
+            c.friction = float(mi.get("plane_friction", tc.static_friction))
         self._ccfg = c
 
     def _create_native(self):
@@ -142,7 +163,7 @@ class DyrosDynamicWalk(VecTask):
         N, dev = self.num_envs, self._tdev
         self._buf = {}
         for name, (shape, dt) in abi.BUFFER_SPECS.items():
-            full = (abi.GATE_ACC_WORDS,) if shape is None else (N,) + tuple(shape)
+            full = (abi.GLOBAL_WORDS[name],) if shape is None else (N,) + tuple(shape)
             self._buf[name] = torch.zeros(full, dtype=_TORCH_DT[dt], device=dev)
         b = self._buf
         # VecTask.allocate_buffers (reference vec_task.py:233-256)
@@ -159,6 +180,13 @@ class DyrosDynamicWalk(VecTask):
         self.contact_forces = b["contact_forces"]
         self.total_mass = b["total_mass"].view(N, 1)
         self.env_origins = b["env_origins"]
+        if self.custom_origins:         # the two terrain tables replace their one-element placeholders (reference :253-254, :703)
+            b["height_samples"] = torch.from_numpy(np.ascontiguousarray(self.terrain.heightsamples)).to(dev)
+            b["terrain_origins"] = torch.from_numpy(self.terrain.env_origins).to(dev).to(torch.float).contiguous()
+            self.height_samples = b["height_samples"].view(self.terrain.tot_rows, self.terrain.tot_cols)
+            self.terrain_origins = b["terrain_origins"]
+            self.terrain_levels, self.terrain_types = b["terrain_levels"], b["terrain_types"]
+            self.max_terrain_level = self.terrain_cfg.num_rows
 
     def _bind(self):
         db = abi.DwBuffers()
@@ -181,15 +209,25 @@ class DyrosDynamicWalk(VecTask):
         self.initial_dof_vel = torch.zeros((N, NUM_DOF), device=dev)
         self.dof_limits_lower = torch.tensor(self.model.dof_lower, device=dev, dtype=torch.float)
         self.dof_limits_upper = torch.tensor(self.model.dof_upper, device=dev, dtype=torch.float)
-        # env origins: grid (reference :709-718), robots start at origin + U(-1,1) xy jitter (:350-353)
-        num_cols = np.floor(np.sqrt(N))
-        num_rows = np.ceil(N / num_cols)
-        xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
-        spacing = self.cfg["env"]["envSpacing"]
-        org = torch.zeros((N, 3))
-        org[:, 0] = spacing * xx.flatten()[:N]
-        org[:, 1] = spacing * yy.flatten()[:N]
-        b["env_origins"].copy_(org.to(dev))
+        if self.custom_origins:
+            # origins on the terrain tiles (reference :697-707): a random starting level, the type from the env index
+            tcf = self.terrain_cfg
+            max_init_level = tcf.max_init_terrain_level if tcf.curriculum else tcf.num_rows - 1
+            lv = torch.randint(0, max_init_level + 1, (N,), generator=gen, device=dev)
+            ty = torch.div(torch.arange(N, device=dev), (N / tcf.num_cols), rounding_mode="floor").to(torch.long)
+            b["terrain_levels"].copy_(lv)
+            b["terrain_types"].copy_(ty)
+            b["env_origins"].copy_(b["terrain_origins"].view(tcf.num_rows, tcf.num_cols, 3)[lv, ty])
+        else:
+            # env origins: grid (reference :709-718), robots start at origin + U(-1,1) xy jitter (:350-353)
+            num_cols = np.floor(np.sqrt(N))
+            num_rows = np.ceil(N / num_cols)
+            xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+            spacing = self.cfg["env"]["envSpacing"]
+            org = torch.zeros((N, 3))
+            org[:, 0] = spacing * xx.flatten()[:N]
+            org[:, 1] = spacing * yy.flatten()[:N]
+            b["env_origins"].copy_(org.to(dev))
         root = b["root_states"]
         root.zero_()
         root[:, 0:3] = b["env_origins"]
@@ -290,6 +328,13 @@ class DyrosDynamicWalk(VecTask):
         self._step_count += 1
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.extras["stacked_rewards"] = self._buf["stacked_rewards"]
+        if self.custom_origins and self.terrain_cfg.curriculum:
+            # logging columns of the curriculum (reference :417-426): mean level of the envs of each terrain type
+            lv, ty = self.terrain_levels, self.terrain_types
+            cols = [torch.sum(lv[ty == i]) / max(int((ty == i).sum()), 1) * torch.ones_like(lv).unsqueeze(-1)
+                    for i in range(self.terrain_cfg.num_cols)]
+            self.extras["stacked_rewards"] = torch.cat([self._buf["stacked_rewards"]] + cols, 1)
+            self.extras["reward_names"] = list(REWARD_NAMES) + ["terrain %d level" % i for i in range(self.terrain_cfg.num_cols)]
         self.obs_dict["obs"] = self._clip_obs(self.obs_buf).to(self.rl_device)
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 

@@ -99,6 +99,10 @@ int dwo_bind(DwHandle *h, const DwBuffers *b) {
     if (!b->root_states || !b->dof_state || !b->contact_forces || !b->mass_scale || !b->dof_damping ||
         !b->dof_armature || !b->friction_scale)
         return fail(DW_EINVAL, "dwo_bind: physics buffers missing");
+    if (h->cfg.terrain && (!b->height_samples || h->cfg.terrain_rows < 2 || h->cfg.terrain_cols < 2 || !(h->cfg.terrain_hscale > 0)))
+        return fail(DW_EINVAL, "dwo_bind: terrain configured without height samples / grid");
+    if (h->cfg.terrain_curriculum && (!b->terrain_origins || !b->terrain_levels || !b->terrain_types))
+        return fail(DW_EINVAL, "dwo_bind: terrain curriculum without level/type/origin buffers");
     h->buf = *b;
     h->bound = 1;
     return DW_OK;
@@ -115,6 +119,7 @@ void dwo_load_phys(const DwHandle *h, int e, DwoPhysIO *io) {
     }
     for (int k = 0; k < DW_NUM_BODIES; ++k) io->mass_scale[k] = b->mass_scale[DW_NUM_BODIES * e + k];
     io->mu = h->cfg.friction * b->friction_scale[e];
+    io->height_samples = h->cfg.terrain ? b->height_samples : NULL;
 }
 
 void dwo_store_phys(const DwHandle *h, int e, const DwoPhysIO *io) {

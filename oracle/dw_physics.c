@@ -234,6 +234,34 @@ static void seg_seg(const real p1[3], const real d1[3], const real p2[3], const 
     *so = s; *to = t;
 }
 
+/* Height field (row f-4).  The ground under a world point: bilinear interpolation of the four samples around it
+ * (world x = row * hscale - border, y = col * hscale - border, reference tasks/dyros_dynamic_walk.py:240-253), unit
+ * normal from the gradient of that patch, and a contact frame (t1, t2, n) with t1 = the world x axis projected into the
+ * tangent plane.  On the plane: h = 0, n = z, t1 = x, t2 = y. */
+static void terrain_sample(const DwConfig *cfg, const int16_t *hs, real x, real y, real *h, real fr[9]) {
+    const real inv = (real)1 / cfg->terrain_hscale;
+    real u = (x + cfg->terrain_border) * inv, v = (y + cfg->terrain_border) * inv;
+    const real umax = (real)(cfg->terrain_rows - 1) - (real)1e-3, vmax = (real)(cfg->terrain_cols - 1) - (real)1e-3;
+    if (u < 0) u = 0; if (u > umax) u = umax;
+    if (v < 0) v = 0; if (v > vmax) v = vmax;
+    const int i = (int)u, j = (int)v;
+    const real a = u - (real)i, b = v - (real)j;
+    const int16_t *p = hs + (size_t)i * cfg->terrain_cols + j;
+    const real h00 = p[0], h01 = p[1], h10 = p[cfg->terrain_cols], h11 = p[cfg->terrain_cols + 1];
+    const real vs = cfg->terrain_vscale;
+    *h = vs * (((real)1 - a) * (((real)1 - b) * h00 + b * h01) + a * (((real)1 - b) * h10 + b * h11));
+    const real gx = vs * inv * (((real)1 - b) * (h10 - h00) + b * (h11 - h01));
+    const real gy = vs * inv * (((real)1 - a) * (h01 - h00) + a * (h11 - h10));
+    const real nn = (real)1 / RSQRT(gx * gx + gy * gy + (real)1);
+    real *t1 = fr, *t2 = fr + 3, *n = fr + 6;
+    n[0] = -gx * nn; n[1] = -gy * nn; n[2] = nn;
+    /* t1 = normalize(x - (x.n) n) */
+    real a1[3] = {(real)1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+    const real tn = (real)1 / RSQRT(dot3(a1, a1));
+    t1[0] = a1[0] * tn; t1[1] = a1[1] * tn; t1[2] = a1[2] * tn;
+    cross3(n, t1, t2);
+}
+
 void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
     Work w;
     SI IA[NB];
@@ -364,7 +392,37 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
             m3v(w.Rw[b], rl, wv);
             zmin = w.pw[b][2] + wv[2];
         }
-        if (zmin < 0) {
+        if (cfg->terrain && io->height_samples) {
+            /* height field: signed distance along the local normal, force along it, friction in the tangent plane */
+            real wv[3], hh, fr[9];
+            m3v(w.Rw[b], rl, wv);
+            terrain_sample(cfg, io->height_samples, w.pw[b][0] + wv[0], w.pw[b][1] + wv[1], &hh, fr);
+            const real *nrm = fr + 6;
+            const real dist = (zmin - hh) * nrm[2];
+            if (dist < 0) {
+                real vl[3], t[3], vw[3];
+                cross3(w.v[b], rl, t);
+                vl[0] = w.v[b][3] + t[0]; vl[1] = w.v[b][4] + t[1]; vl[2] = w.v[b][5] + t[2];
+                m3v(w.Rw[b], vl, vw);
+                const real vn = dot3(vw, nrm);
+                real fn = cfg->penalty_stiffness * (-dist) - cfg->penalty_damping * vn;
+                if (fn < 0) fn = 0;
+                real vt[3] = {vw[0] - vn * nrm[0], vw[1] - vn * nrm[1], vw[2] - vn * nrm[2]};
+                real sp = RSQRT(dot3(vt, vt));
+                real Fw[3] = {fn * nrm[0], fn * nrm[1], fn * nrm[2]};
+                if (sp > (real)1e-9) {
+                    real ft = cfg->penalty_damping * sp;
+                    real lim = io->mu * fn;
+                    if (ft > lim) ft = lim;
+                    for (int i = 0; i < 3; ++i) Fw[i] -= ft * vt[i] / sp;
+                }
+                real fb[3], nb[3];
+                m3tv(w.Rw[b], Fw, fb);
+                cross3(rl, fb, nb);
+                for (int i = 0; i < 3; ++i) { pA[b][i] -= nb[i]; pA[b][3 + i] -= fb[i]; }
+                for (int i = 0; i < 3; ++i) io->contact[3 * ge->gym + i] += Fw[i];
+            }
+        } else if (zmin < 0) {
             real vl[3], t[3], vw[3];
             cross3(w.v[b], rl, t);
             vl[0] = w.v[b][3] + t[0]; vl[1] = w.v[b][4] + t[1]; vl[2] = w.v[b][5] + t[2];
@@ -523,10 +581,18 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
     real phi[DW_NUM_FOOT_PTS], rk[DW_NUM_FOOT_PTS][3];
     int active[DW_NUM_FOOT_PTS], any_active = 0;
     const int footb[2] = {m->foot_mv[0], m->foot_mv[4]};
+    const int on_terrain = cfg->terrain && io->height_samples;
+    real frame[DW_NUM_FOOT_PTS][9];      /* rows: t1, t2, n (world); identity on the plane */
     for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) {
         const int b = m->foot_mv[k];
         m3v(w.Rw[b], m->foot_pos[k], rk[k]);
         phi[k] = w.pw[b][2] + rk[k][2];
+        for (int i = 0; i < 9; ++i) frame[k][i] = (i % 4 == 0) ? (real)1 : (real)0;
+        if (on_terrain) {
+            real hh;
+            terrain_sample(cfg, io->height_samples, w.pw[b][0] + rk[k][0], w.pw[b][1] + rk[k][1], &hh, frame[k]);
+            phi[k] = (phi[k] - hh) * frame[k][8];
+        }
         active[k] = phi[k] < cfg->contact_offset;
         any_active |= active[k];
     }
@@ -580,8 +646,15 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
             real S[9];
             skew3(rk[k], S);
             for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c) J[3 * k + r][6 * f + c] = -S[3 * r + c];
-                J[3 * k + r][6 * f + 3 + r] = 1;
+                if (on_terrain) {      /* velocity along d at lever r: d.v_o + w.(r x d) */
+                    const real *d = frame[k] + 3 * r;
+                    real rxd[3];
+                    cross3(rk[k], d, rxd);
+                    for (int c = 0; c < 3; ++c) { J[3 * k + r][6 * f + c] = rxd[c]; J[3 * k + r][6 * f + 3 + c] = d[c]; }
+                } else {
+                    for (int c = 0; c < 3; ++c) J[3 * k + r][6 * f + c] = -S[3 * r + c];
+                    J[3 * k + r][6 * f + 3 + r] = 1;
+                }
             }
         }
         real JW[24][12], Amat[24][24], vel[24], vmin[DW_NUM_FOOT_PTS];
@@ -602,6 +675,10 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
             real t[3];
             cross3(tw_free[f], rk[k], t);
             for (int i = 0; i < 3; ++i) vel[3 * k + i] = tw_free[f][3 + i] + t[i];
+            if (on_terrain) {
+                real vp[3] = {vel[3 * k], vel[3 * k + 1], vel[3 * k + 2]};
+                for (int i = 0; i < 3; ++i) vel[3 * k + i] = dot3(frame[k] + 3 * i, vp);
+            }
             if (phi[k] >= 0) vmin[k] = -phi[k] / dt;
             else {
                 real vb = cfg->erp * (-phi[k]) / dt;
@@ -656,12 +733,16 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
         /* propagate the impulses through the whole tree */
         real dp[NB][6], dv[NB][6];
         memset(dp, 0, sizeof(dp));
+        real Pw[DW_NUM_FOOT_PTS][3];      /* impulses in world axes */
+        for (int k = 0; k < DW_NUM_FOOT_PTS; ++k)
+            for (int i = 0; i < 3; ++i)
+                Pw[k][i] = on_terrain ? P[k][0] * frame[k][i] + P[k][1] * frame[k][3 + i] + P[k][2] * frame[k][6 + i] : P[k][i];
         for (int f = 0; f < 2; ++f) {
             real F[3] = {0, 0, 0}, Nm[3] = {0, 0, 0};
             for (int k = 4 * f; k < 4 * f + 4; ++k) {
                 real t[3];
-                cross3(rk[k], P[k], t);
-                for (int i = 0; i < 3; ++i) { F[i] += P[k][i]; Nm[i] += t[i]; }
+                cross3(rk[k], Pw[k], t);
+                for (int i = 0; i < 3; ++i) { F[i] += Pw[k][i]; Nm[i] += t[i]; }
             }
             real fb[3], nb[3];
             m3tv(w.Rw[footb[f]], F, fb);
@@ -671,7 +752,7 @@ void dwo_phys_substep(const DwConfig *cfg, const DwoModelR *m, DwoPhysIO *io) {
         delta_aba(m, &w, dp, 1, footb[1], NB - 1, dv, dqd_c);
         for (int i = 0; i < 6; ++i) dv0_c[i] = dv[0][i];
         for (int k = 0; k < DW_NUM_FOOT_PTS; ++k)
-            for (int i = 0; i < 3; ++i) io->contact[3 * m->foot_gym[k] + i] += P[k][i] / dt;
+            for (int i = 0; i < 3; ++i) io->contact[3 * m->foot_gym[k] + i] += Pw[k][i] / dt;
     }
     for (int k = 0; k < DW_NUM_FOOT_PTS; ++k)
         for (int i = 0; i < 3; ++i) io->warm[3 * k + i] = P[k][i];

@@ -48,8 +48,10 @@ typedef struct DwoPhysIO {
     real mass_scale[DW_NUM_BODIES];
     real damping[DW_NUM_DOF], armature[DW_NUM_DOF];
     real mu;
-    /* warm start, in/out: impulses [8][3] (x,y,z) */
+    /* warm start, in/out: impulses [8][3] (x,y,z; on terrain: tangent 1, tangent 2, normal) */
     real warm[DW_NUM_FOOT_PTS * 3];
+    /* terrain: Terrain.heightsamples [terrain_rows, terrain_cols] or NULL for the plane z = 0 (row f-4) */
+    const int16_t *height_samples;
     /* outputs */
     real contact[DW_NUM_BODIES * 3];
     /* debug outputs of the unconstrained dynamics */

@@ -160,6 +160,25 @@ static void reset_env(DwHandle *h, int e, const Noise *nz) {
         }
         b->randomize_buf[e] = 0;
     }
+    /* terrain curriculum (tasks/dyros_dynamic_walk.py:603-604,671-691): uses the position the robot reached and the
+     * target velocity of the episode that just ended */
+    if (cfg->terrain_curriculum) {
+        const float *root_old = b->root_states + 13 * e;
+        float d[2] = {root_old[0] - b->env_origins[3 * e], root_old[1] - b->env_origins[3 * e + 1]};
+        const float distance = norm_t(d, 2);
+        const int move_up = distance > (float)(cfg->terrain_env_length / 2.0);
+        const float need = norm_t(&es[DW_ES_TARGET_VEL], 2) * cfg->max_episode_length_s * 0.5f;
+        const int move_down = (distance < need) && !move_up;
+        int64_t lvl = b->terrain_levels[e] + (1 * move_up - 1 * move_down);
+        if (lvl >= cfg->terrain_num_levels) {
+            int k = (int)(noise_word(nz, DW_NZ_TERRAIN_LVL) * (float)cfg->terrain_num_levels);   /* randint_like */
+            if (k > cfg->terrain_num_levels - 1) k = cfg->terrain_num_levels - 1;
+            lvl = k;
+        } else if (lvl < 0) lvl = 0;
+        b->terrain_levels[e] = lvl;
+        const float *org = b->terrain_origins + ((size_t)lvl * cfg->terrain_num_types + b->terrain_types[e]) * 3;
+        for (int i = 0; i < 3; ++i) b->env_origins[3 * e + i] = org[i];
+    }
     for (int j = 0; j < DW_NUM_DOF; ++j) {
         es[DW_ES_QPOS_NOISE + j] = h->initial_dof_pos[j];
         es[DW_ES_QPOS_PRE + j] = h->initial_dof_pos[j];
@@ -174,6 +193,8 @@ static void reset_env(DwHandle *h, int e, const Noise *nz) {
     const float init_root[13] = {0, 0, cfg->initial_height, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 13; ++i) root[i] = init_root[i];
     for (int i = 0; i < 3; ++i) root[i] += b->env_origins[3 * e + i];
+    if (cfg->custom_origins)      /* xy position within 1 m of the tile centre (:729-732; torch_rand_float = 2 u + (-1)) */
+        for (int i = 0; i < 2; ++i) root[i] += 2.0f * noise_word(nz, DW_NZ_ROOT_JITTER + i) + (-1.0f);
     for (int j = 0; j < DW_NUM_DOF; ++j) {
         float q = fmaxf(fminf(h->initial_dof_pos[j], h->model.dof_upper[j]), h->model.dof_lower[j]);
         b->dof_state[(DW_NUM_DOF * e + j) * 2] = q;

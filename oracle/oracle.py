@@ -56,11 +56,21 @@ def default_config(num_envs: int, **over) -> abi.DwConfig:
     return cfg
 
 
+def terrain_config(terrain, max_episode_length_s: float = 32.0) -> dict:
+    """DwConfig fields of a isaacgymdyros_amd.terrain.Terrain (height field)."""
+    c = terrain.cfg
+    return dict(terrain=1, custom_origins=1, terrain_rows=int(terrain.tot_rows), terrain_cols=int(terrain.tot_cols),
+                terrain_hscale=float(c.horizontal_scale), terrain_vscale=float(c.vertical_scale),
+                terrain_border=float(c.border_size), terrain_curriculum=int(bool(c.curriculum)),
+                terrain_num_levels=int(c.num_rows), terrain_num_types=int(c.num_cols),
+                terrain_env_length=float(terrain.env_length), max_episode_length_s=float(max_episode_length_s))
+
+
 def alloc_buffers(num_envs: int):
     bufs = {}
     for name, (shape, dt) in abi.BUFFER_SPECS.items():
         if shape is None:
-            bufs[name] = np.zeros((abi.GATE_ACC_WORDS,), dtype=dt)
+            bufs[name] = np.zeros((abi.GLOBAL_WORDS[name],), dtype=dt)
         else:
             bufs[name] = np.zeros((num_envs,) + tuple(shape), dtype=dt)
     return bufs
@@ -70,7 +80,9 @@ class OracleSim:
     """Owns numpy buffers in the DwBuffers layout and a dwo_ handle."""
 
     def __init__(self, num_envs: int, task_const=None, double: bool = False, cfg: abi.DwConfig = None,
-                 lib_api=None, **cfg_over):
+                 lib_api=None, terrain=None, **cfg_over):
+        if terrain is not None:
+            cfg_over = dict(terrain_config(terrain), **cfg_over)
         self.lib, self.api = lib_api if lib_api is not None else load(double)
         self.model = load_model()
         self.cfg = cfg if cfg is not None else default_config(num_envs, **cfg_over)
@@ -103,6 +115,9 @@ class OracleSim:
         self.buf["root_states"][:, 6] = 1.0
         self.buf["root_states"][:, 2] = self.cfg.initial_height
         self.buf["total_mass"][:] = np.float32(self.model.nominal_total_mass)
+        if terrain is not None:
+            self.buf["height_samples"] = np.ascontiguousarray(terrain.heightsamples, dtype=np.int16)
+            self.buf["terrain_origins"] = np.ascontiguousarray(terrain.env_origins, dtype=np.float32)
         self.bind()
 
     def bind(self):

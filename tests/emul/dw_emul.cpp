@@ -50,7 +50,9 @@ int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); fr
 int dwe_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dwe_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
+    if (const char *m = dw::check_terrain_buffers(&h->cfg, b)) return fail(DW_EINVAL, m);
     h->buf = *b; h->bound = 1;
+    h->params.phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
     return DW_OK;
 }
 int dwe_simulate(DwHandle *h, const float *tau, const float *push_xy, void *) {
@@ -59,7 +61,10 @@ int dwe_simulate(DwHandle *h, const float *tau, const float *push_xy, void *) {
     if (h->cfg.debug_freeze_physics) return DW_OK;
     dw::Lds *S = new dw::Lds;
     dw::Wave w;
-    for (int e = 0; e < h->cfg.num_envs; ++e) dw::simulate_env(w, *S, h->model, h->params, h->buf, tau, push_xy, e);
+    for (int e = 0; e < h->cfg.num_envs; ++e) {
+        if (h->cfg.terrain) dw::simulate_env<true>(w, *S, h->model, h->params, h->buf, tau, push_xy, e);
+        else dw::simulate_env<false>(w, *S, h->model, h->params, h->buf, tau, push_xy, e);
+    }
     delete S;
     return DW_OK;
 }
@@ -71,7 +76,10 @@ int dwe_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     T.b = &h->buf; T.actions = actions; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
     dw::Lds *S = new dw::Lds;
     dw::Wave w;
-    for (int e = 0; e < h->cfg.num_envs; ++e) dw::step_env(w, *S, h->model, h->params, T, e);
+    for (int e = 0; e < h->cfg.num_envs; ++e) {
+        if (h->cfg.terrain) dw::step_env<true>(w, *S, h->model, h->params, T, e);
+        else dw::step_env<false>(w, *S, h->model, h->params, T, e);
+    }
     delete S;
     return DW_OK;
 }
