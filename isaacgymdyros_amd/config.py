@@ -65,3 +65,12 @@ def with_friction_randomization(cfg: dict) -> dict:
     cfg["task"]["randomization_params"]["actor_params"]["humanoid"]["rigid_shape_properties"] = {
         "friction": {"range": [0.7, 1.3], "operation": "scaling", "distribution": "uniform"}}
     return cfg
+
+
+def with_terrain(cfg: dict, **terrain) -> dict:
+    """Height-field terrain.  The reference selects it by editing its `TerrainCfg` class
+    (cfg/terrain/terrain_cfg.py:1-22); here the same fields travel in cfg["terrain"], e.g.
+    `with_terrain(cfg, mesh_type="heightfield", curriculum=True)`."""
+    cfg = copy.deepcopy(cfg)
+    cfg["terrain"] = dict(cfg.get("terrain") or {}, **terrain)
+    return cfg

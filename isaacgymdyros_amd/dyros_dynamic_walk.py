@@ -213,6 +213,8 @@ class DyrosDynamicWalk(VecTask):
             # origins on the terrain tiles (reference :697-707): a random starting level, the type from the env index
             tcf = self.terrain_cfg
             max_init_level = tcf.max_init_terrain_level if tcf.curriculum else tcf.num_rows - 1
+            if not 0 <= max_init_level < tcf.num_rows:       # the reference would index terrain_origins out of range here
+                raise ValueError("TerrainCfg.max_init_terrain_level (%d) must be below num_rows (%d)" % (max_init_level, tcf.num_rows))
             lv = torch.randint(0, max_init_level + 1, (N,), generator=gen, device=dev)
             ty = torch.div(torch.arange(N, device=dev), (N / tcf.num_cols), rounding_mode="floor").to(torch.long)
             b["terrain_levels"].copy_(lv)

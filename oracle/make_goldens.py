@@ -71,14 +71,22 @@ def random_state(rng, N, tc, model):
     return root, dof, cf
 
 
+# reference TerrainCfg class attributes of the "terrain" fixture (row f-4): a small curriculum map without the tile type
+# whose reference code needs scipy's removed interp2d
+TERRAIN_CASE = dict(mesh_type="heightfield", curriculum=True, num_rows=3, num_cols=4, border_size=2,
+                    max_init_terrain_level=2, terrain_proportions=[0.3, 0.0, 0.3, 0.2, 0.2])
+
+
 def run(kind: str, N: int, steps: int, seed: int):
     tc = load_task_constants()
-    frozen = kind == "frozen"
+    terr = kind == "terrain"
+    frozen = kind == "frozen" or terr
     A = OracleSim(N, task_const=tc, debug_freeze_physics=int(frozen))
-    env, fake, mods = RH.make_reference_env(A, N, seed=seed)
+    env, fake, mods = RH.make_reference_env(A, N, seed=seed, terrain=TERRAIN_CASE if terr else None)
     env.randomize = False     # the numpy-RNG domain randomisation at resets cannot be replayed through U[0,1) words
     env.reset()
-    B = OracleSim(N, task_const=tc, randomize_dof_on_reset=0, debug_freeze_physics=int(frozen))
+    B = OracleSim(N, task_const=tc, randomize_dof_on_reset=0, debug_freeze_physics=int(frozen),
+                  terrain=env.terrain if terr else None, **(dict(max_episode_length_s=float(env.max_episode_length_s)) if terr else {}))
     for k in ("mass_scale", "dof_damping", "dof_armature"):
         B.buf[k][:] = A.buf[k]
     if frozen:
@@ -92,12 +100,16 @@ def run(kind: str, N: int, steps: int, seed: int):
     rec_steps = {k: [] for k in PER_STEP}
     actions_all, noise_all, inj = [], [], {"root": [], "dof": [], "cf": []}
     force_at = 3 if frozen else 10
+    lvl_steps, org_steps = [], []
     for t in range(steps):
         a = torch.rand(N, 13, generator=g) * 2.4 - 1.2       # some outside +-1: exercises the clamp
         if t == force_at:
             env.perturb_start[:, 0] = True
         if frozen:
             root, dof, cf = random_state(rng, N, tc, A.model)
+            if terr:          # around the tile origin: some robots have "walked" past half a tile, some hardly moved
+                root[:, 0:2] = env.env_origins[:, 0:2].numpy() + rng.normal(size=(N, 2)) * 3
+                root[:, 2] += env.env_origins[:, 2].numpy()
             env.root_states[:] = torch.from_numpy(root)
             env.dof_state.view(N, 33, 2)[:] = torch.from_numpy(dof)
             env.contact_forces[:] = torch.from_numpy(cf)
@@ -108,12 +120,15 @@ def run(kind: str, N: int, steps: int, seed: int):
         with RH.RngRecorder() as rec:
             o, r, d, ex = env.step(a.clone())
         reset_ids = d.nonzero().flatten().numpy()
-        nz = P.noise_from_log(rec.log, N, pert_ids, reset_ids)
+        nz = P.noise_from_log(rec.log, N, pert_ids, reset_ids, terrain_levels=TERRAIN_CASE["num_rows"] if terr else 0,
+                              terrain_curriculum=terr)
         actions_all.append(a.numpy().copy())
         noise_all.append(nz)
         snap = P.snapshot_reference(env, ex)
         for k in PER_STEP:
             rec_steps[k].append(snap[k])
+        if terr:
+            lvl_steps.append(snap["terrain_levels"]); org_steps.append(snap["env_origins"])
     out = dict(N=N, steps=steps, force_perturb_step=force_at,
                actions=np.stack(actions_all), noise=np.stack(noise_all))
     for k, v in init.items():
@@ -125,7 +140,12 @@ def run(kind: str, N: int, steps: int, seed: int):
     if frozen:
         out["inj_root"] = np.stack(inj["root"]); out["inj_dof"] = np.stack(inj["dof"]); out["inj_cf"] = np.stack(inj["cf"])
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, "task_logic_frozen.npz" if frozen else "whole_step_oracle.npz")
+    if terr:
+        for k in ("terrain", "custom_origins", "terrain_rows", "terrain_cols", "terrain_hscale", "terrain_vscale", "terrain_border",
+                  "terrain_curriculum", "terrain_num_levels", "terrain_num_types", "terrain_env_length", "max_episode_length_s"):
+            out["cfg_" + k] = getattr(B.cfg, k)
+        out["step_terrain_levels"] = np.stack(lvl_steps); out["step_env_origins"] = np.stack(org_steps)
+    path = os.path.join(OUT, "terrain_logic_frozen.npz" if terr else ("task_logic_frozen.npz" if frozen else "whole_step_oracle.npz"))
     np.savez_compressed(path, **out)
     nres = int(np.stack(rec_steps["reset_buf"]).sum())
     npert = int(np.stack(rec_steps["pert_on"]).sum())
@@ -136,5 +156,10 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     if not RH.available():
         sys.exit("reference checkout not present; goldens can only be minted where it is mounted")
-    run("frozen", N=24, steps=20, seed=11)
-    run("oracle", N=8, steps=120, seed=5)
+    only = sys.argv[1] if len(sys.argv) > 1 else None        # "frozen" | "oracle" | "terrain": mint one fixture only
+    if only in (None, "frozen"):
+        run("frozen", N=24, steps=20, seed=11)
+    if only in (None, "oracle"):
+        run("oracle", N=8, steps=120, seed=5)
+    if only in (None, "terrain"):
+        run("terrain", N=24, steps=24, seed=17)

@@ -32,6 +32,11 @@ def sync_from_reference(env, buf):
     buf["contact_forces"][:] = env.contact_forces.numpy()
     buf["total_mass"][:] = env.total_mass[:, 0].numpy()
     buf["env_origins"][:] = env.env_origins.numpy()
+    if getattr(env, "custom_origins", False):
+        buf["terrain_levels"][:] = env.terrain_levels.numpy()
+        buf["terrain_types"][:] = env.terrain_types.numpy()
+        buf["terrain_origins"][...] = env.terrain_origins.numpy().astype(np.float32).reshape(buf["terrain_origins"].shape)
+        buf["height_samples"][...] = np.asarray(env.terrain.heightsamples, dtype=np.int16).reshape(buf["height_samples"].shape)
     buf["friction_scale"][:] = 1.0
     buf["obs_buf"][:] = env.obs_buf.numpy()
     buf["rew_buf"][:] = env.rew_buf.numpy()
@@ -71,8 +76,9 @@ def logical_history(hist, head):
     return np.take_along_axis(hist, idx[:, :, None], axis=1)
 
 
-def noise_from_log(log, N, pert_ids, reset_ids):
-    """log: list of (kind, tensor) in call order for ONE reference step()."""
+def noise_from_log(log, N, pert_ids, reset_ids, terrain_levels: int = 0, terrain_curriculum: bool = False):
+    """log: list of (kind, tensor) in call order for ONE reference step().  terrain_levels > 0: the env runs on a
+    height field (spawn jitter is drawn at reset); terrain_curriculum: the level draw of :689 precedes the other resets."""
     nz = np.zeros((N, K["DW_NOISE_WORDS"]), dtype=np.float32)
     it = iter(log)
 
@@ -91,10 +97,14 @@ def noise_from_log(log, N, pert_ids, reset_ids):
     for sub in range(2):
         nz[:, K["DW_NZ_ENC"] + 33 * sub: K["DW_NZ_ENC"] + 33 * (sub + 1)] = nxt("normal")
     if len(reset_ids) > 0:
+        if terrain_curriculum:
+            nz[reset_ids, K["DW_NZ_TERRAIN_LVL"]] = (nxt("randint_like").reshape(-1) + 0.5) / float(terrain_levels)
         nz[reset_ids, K["DW_NZ_QPOS_BIAS"]:K["DW_NZ_QPOS_BIAS"] + 12] = nxt("rand")
         nz[reset_ids, K["DW_NZ_QUAT_BIAS"]:K["DW_NZ_QUAT_BIAS"] + 3] = nxt("rand")
         nxt("rand")      # ft_bias (never read)
         nxt("rand")      # m_bias
+        if terrain_levels > 0:
+            nz[reset_ids, K["DW_NZ_ROOT_JITTER"]:K["DW_NZ_ROOT_JITTER"] + 2] = nxt("rand")    # torch_rand_float(-1, 1, (n, 2))
         nz[reset_ids, K["DW_NZ_TARGET_VEL"]] = nxt("rand").reshape(-1)
         nxt("rand")      # vel_theta * 0.0
         nz[reset_ids, K["DW_NZ_INIT_MOCAP"]] = nxt("rand").reshape(-1)
@@ -129,6 +139,9 @@ def snapshot_reference(env, extras):
         a = t.numpy().copy()
         off, shape, kind = abi.ES_FIELDS[name]
         d[name] = a.reshape((N,) + tuple(shape)).astype(np.int32 if kind == "i" else np.float32)
+    if getattr(env, "custom_origins", False):
+        d["terrain_levels"] = env.terrain_levels.numpy().astype(np.int64).copy()
+        d["env_origins"] = env.env_origins.numpy().astype(np.float32).copy()
     return d
 
 
@@ -156,6 +169,8 @@ def snapshot_buffers(buf):
     )
     for name in STATE_FIELDS:
         d[name] = abi.es_view(es, name).copy()
+    d["terrain_levels"] = np.array(buf["terrain_levels"], dtype=np.int64, copy=True)
+    d["env_origins"] = np.array(buf["env_origins"], dtype=np.float32, copy=True)
     return d
 
 

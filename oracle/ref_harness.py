@@ -109,6 +109,8 @@ class FakeGym:
     # ---- setup ----
     def create_sim(self, *a): return "sim"
     def add_ground(self, *a): pass
+    def add_heightfield(self, *a): pass
+    def add_triangle_mesh(self, *a): pass
     def load_asset(self, *a): return "asset"
     def find_asset_rigid_body_index(self, asset, name): return self.model.body_names.index(name)
     def get_asset_rigid_body_count(self, a): return 38
@@ -204,8 +206,10 @@ def load_reference(fake_gym_factory):
     sys.modules["isaacgym.gymtorch"] = gymtorch
     isaacgym.gymapi, isaacgym.gymtorch = gymapi, gymtorch
     gymapi.Vec3, gymapi.Quat, gymapi.Transform, gymapi.SimParams = _Vec3, _Quat, _Transform, _SimParams
-    for n in ("PlaneParams", "AssetOptions", "CameraProperties", "HeightFieldParams", "TriangleMeshParams"):
+    for n in ("PlaneParams", "AssetOptions", "CameraProperties"):
         setattr(gymapi, n, type(n, (_Bag,), {}))
+    for n in ("HeightFieldParams", "TriangleMeshParams"):      # these carry a transform (tasks/dyros_dynamic_walk.py:246-248)
+        setattr(gymapi, n, type(n, (_Bag,), {"__init__": lambda self, **kw: (_Bag.__init__(self, **kw), setattr(self, "transform", _Transform()))[0]}))
     for i, n in enumerate(("SIM_PHYSX", "SIM_FLEX", "UP_AXIS_Y", "UP_AXIS_Z", "DOF_MODE_NONE", "MESH_VISUAL",
                            "ENV_SPACE")):
         setattr(gymapi, n, i)
@@ -267,7 +271,7 @@ class RngRecorder:
         self._orig = {}
 
     def __enter__(self):
-        for name in ("rand", "randint", "normal"):
+        for name in ("rand", "randint", "normal", "randint_like"):
             self._orig[name] = getattr(torch, name)
 
             def make(n):
@@ -277,24 +281,44 @@ class RngRecorder:
                     return out
                 return wrapped
             setattr(torch, name, make(name))
+        # `torch_rand_float` (python/isaacgym/torch_utils.py:50-52) is TorchScript: its draw never passes through the
+        # python-level torch.rand above.  While recording, the task module calls an eager function with the same
+        # arithmetic, (upper - lower) * rand(shape) + lower, so the spawn jitter of :732 shows up in the log.
+        self._task = _loaded.get("task")
+        if self._task is not None:
+            self._jit_rand_float = self._task.torch_rand_float
+            self._task.torch_rand_float = lambda lower, upper, shape, device: (upper - lower) * torch.rand(*shape, device=device) + lower
         return self
 
     def __exit__(self, *exc):
         for name, f in self._orig.items():
             setattr(torch, name, f)
+        if self._task is not None:
+            self._task.torch_rand_float = self._jit_rand_float
 
 
-def make_reference_env(osim, num_envs: int, seed: int = 42, randomize: bool = True, perturbation: bool = True):
-    """Construct the reference DyrosDynamicWalk on top of `osim` (an oracle.OracleSim with N envs)."""
+def make_reference_env(osim, num_envs: int, seed: int = 42, randomize: bool = True, perturbation: bool = True,
+                       terrain: dict = None):
+    """Construct the reference DyrosDynamicWalk on top of `osim` (an oracle.OracleSim with N envs).  `terrain`:
+    values for the reference's TerrainCfg class attributes (the reference selects its terrain by editing that class,
+    cfg/terrain/terrain_cfg.py:1-22); they are restored afterwards."""
     fake = FakeGym(osim)
     mods = load_reference(lambda: fake)
     cfg = reference_cfg(num_envs, randomize, perturbation)
     torch.manual_seed(seed)
     np.random.seed(seed)
+    tcls = sys.modules["isaacgymenvs.cfg.terrain.terrain_cfg"].TerrainCfg
+    saved = {k: getattr(tcls, k) for k in (terrain or {})}
+    for k, v in (terrain or {}).items():
+        setattr(tcls, k, v)
     cwd = os.getcwd()
     os.chdir(IGE)
     try:
         env = mods["task"].DyrosDynamicWalk(cfg, "cpu", 0, True)
+        for k, v in (terrain or {}).items():       # the env reads its TerrainCfg instance later (:603): pin the values on it
+            setattr(env.terrain_cfg, k, v)
     finally:
         os.chdir(cwd)
+        for k, v in saved.items():
+            setattr(tcls, k, v)
     return env, fake, mods

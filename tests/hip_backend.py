@@ -14,6 +14,13 @@ def make_env(N, **mi):
     if mi.pop("friction_dr", False):
         from isaacgymdyros_amd.config import with_friction_randomization
         cfg = with_friction_randomization(cfg)
+    terrain = mi.pop("terrain", None)
+    if terrain:
+        from isaacgymdyros_amd.config import with_terrain
+        cfg = with_terrain(cfg, **terrain)
+    seed = mi.pop("seed", None)
+    if seed is not None:
+        cfg["seed"] = seed
     cfg["sim"]["mi355"].update(mi)
     return DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 

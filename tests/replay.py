@@ -19,6 +19,22 @@ TRANSCENDENTAL = {"rew_buf": (1e-6, 2e-6), "stacked_rewards": (1e-6, 2e-6), "obs
                   "magnitude": (0.0, 0.0), "phase": (0.0, 0.0)}
 
 
+class GoldenTerrain:
+    """The height field of a terrain fixture, with the attributes OracleSim(terrain=...) reads."""
+
+    def __init__(self, g):
+        import types
+        rows, cols = int(g["cfg_terrain_rows"]), int(g["cfg_terrain_cols"])
+        lv, ty = int(g["cfg_terrain_num_levels"]), int(g["cfg_terrain_num_types"])
+        self.heightsamples = g["init_height_samples"].reshape(rows, cols)
+        self.env_origins = g["init_terrain_origins"].reshape(lv, ty, 3)
+        self.tot_rows, self.tot_cols = rows, cols
+        self.env_length = float(g["cfg_terrain_env_length"])
+        self.cfg = types.SimpleNamespace(horizontal_scale=float(g["cfg_terrain_hscale"]), vertical_scale=float(g["cfg_terrain_vscale"]),
+                                         border_size=float(g["cfg_terrain_border"]), curriculum=bool(g["cfg_terrain_curriculum"]),
+                                         num_rows=lv, num_cols=ty)
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN, name))
     return {k: z[k] for k in z.files}

@@ -344,3 +344,84 @@ def test_self_collision_vs_oracle(task_const, model):
         ora.simulate(tau.numpy())
     torch.cuda.synchronize()
     assert np.abs(env.dof_pos.cpu().numpy() - ora.buf["dof_state"][:, :, 0]).max() < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------- terrain (row f-4)
+@pytest.mark.gpu
+def test_terrain_curriculum_vs_reference_golden_on_gpu(task_const):
+    """The reference's curriculum fixture through the HIP library: levels, tile origins and spawn positions are
+    bit-identical; the host class generates the same map as the reference did for that seed."""
+    from hip_backend import HipBackend
+    from oracle.make_goldens import TERRAIN_CASE
+    g = R.load("terrain_logic_frozen.npz")
+    hb = HipBackend(int(g["N"]), randomize=False, debug_freeze_physics=True, torch_gpu_div=False, terrain=dict(TERRAIN_CASE), seed=17)
+    assert np.array_equal(hb.env.height_samples.cpu().numpy().ravel(), g["init_height_samples"].ravel())
+    assert np.array_equal(hb.env.terrain_origins.cpu().numpy().ravel(), g["init_terrain_origins"].ravel())
+    for t, ref, got in R.replay(g, hb):
+        ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
+        bad = P.compare(ref, got, exact=["reset_buf", "progress_buf", "target_vel", "root_states", "dof_state"],
+                        atol=dict(R.TRANSCENDENTAL, obs_buf=(5e-6, 1e-5)))
+        assert not bad, (t, bad)
+        assert np.array_equal(g["step_terrain_levels"][t], got["terrain_levels"]), t
+        assert np.array_equal(g["step_env_origins"][t], got["env_origins"]), t
+
+
+@pytest.mark.gpu
+def test_terrain_physics_vs_oracle_on_gpu(task_const):
+    """One substep and a short rollout on a generated map: HIP kernel (height-field variant) against the oracle."""
+    from hip_backend import make_env
+    from isaacgymdyros_amd.terrain import Terrain, TerrainCfg
+    from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
+    from oracle.oracle import OracleSim
+    tdict = dict(mesh_type="heightfield", curriculum=True, num_rows=2, num_cols=4, border_size=2, max_init_terrain_level=1,
+                 terrain_proportions=[0.2, 0.2, 0.3, 0.3, 0.0])
+    N = 64
+    env = make_env(N, randomize=False, terrain=tdict, seed=3)
+    t = Terrain(TerrainCfg(**tdict), N, seed=3)
+    assert np.array_equal(env.height_samples.cpu().numpy(), t.heightsamples)
+    A = OracleSim(N, terrain=t)
+    rng = np.random.default_rng(5)
+    org = t.env_origins.reshape(-1, 3)[rng.integers(0, 8, size=N)]
+    A.buf["root_states"][:, 0:2] = org[:, 0:2] + rng.uniform(-3, 3, size=(N, 2))
+    A.buf["root_states"][:, 2] = t.height_at(A.buf["root_states"][:, 0], A.buf["root_states"][:, 1]) + 0.93 + rng.uniform(-0.03, 0.05, size=N)
+    A.buf["root_states"][:, 6] = 1.0
+    A.buf["root_states"][:, 7:13] = rng.normal(size=(N, 6)) * 0.3
+    A.buf["dof_state"][:, :, 0] = np.asarray(INITIAL_DOF_POS) + rng.normal(size=(N, 33)) * 0.05
+    A.buf["dof_state"][:, :, 1] = rng.normal(size=(N, 33)) * 0.5
+    env.root_states.copy_(torch.from_numpy(A.buf["root_states"]).cuda())
+    env._buf["dof_state"].copy_(torch.from_numpy(A.buf["dof_state"]).cuda())
+    tau = rng.uniform(-30, 30, size=(N, 33)).astype(np.float32)
+    A.simulate(tau); env.simulate(torch.from_numpy(tau).cuda()); torch.cuda.synchronize()
+    cfa, cfb = A.buf["contact_forces"], env.contact_forces.cpu().numpy()
+    assert np.abs(cfa).max() > 100.0
+    assert np.abs(cfa - cfb).max() <= 2e-3 * np.abs(cfa).max() + 0.05
+    ds = env._buf["dof_state"].cpu().numpy()
+    assert np.abs(A.buf["dof_state"][..., 0] - ds[..., 0]).max() < 1e-5           # positions after one substep
+    assert np.abs(A.buf["dof_state"][..., 1] - ds[..., 1]).max() < 2e-3           # rates right after stiff first contacts (|qd| up to 4 rad/s)
+    assert np.abs(A.buf["root_states"] - env.root_states.cpu().numpy()).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_terrain_full_size_rollout_properties():
+    """4096 envs on the default 10 x 20 curriculum map: finite, deterministic, robots spawn on their tiles, levels move."""
+    from hip_backend import make_env
+    tdict = dict(mesh_type="trimesh", curriculum=True)
+    outs = []
+    for rep in range(2):
+        env = make_env(4096, terrain=tdict, force_perturb_start=True)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        lv0 = env.terrain_levels.clone()
+        for t in range(80):
+            obs, rew, done, extras = env.step(torch.rand(4096, 13, generator=g, device="cuda") * 2 - 1)
+        torch.cuda.synchronize()
+        outs.append((obs["obs"].clone(), env.root_states.clone(), env.terrain_levels.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all() and int(env.nan_resets.sum()) == 0
+    assert extras["stacked_rewards"].shape == (4096, 15 + 20) and len(extras["reward_names"]) == 35
+    lv = env.terrain_levels
+    assert int(lv.min()) >= 0 and int(lv.max()) < 10 and int((lv != lv0).sum()) > 0          # random actions: robots fall early, levels go down
+    d = (env.root_states[:, :2] - env.env_origins[:, :2]).norm(dim=1)
+    fresh = env.progress_buf <= 1
+    assert float(d[fresh].max()) < 1.5                                                          # spawned within 1 m (each axis) of the tile origin
+    ground = torch.from_numpy(env.terrain.height_at(env.root_states[:, 0].cpu().numpy(), env.root_states[:, 1].cpu().numpy())).cuda()
+    assert float((env.root_states[fresh, 2] - ground[fresh]).min()) > 0.5                       # above the terrain, not inside it

@@ -23,6 +23,20 @@ def test_task_logic_bitwise_vs_reference_goldens(task_const):
     assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
 
 
+def test_terrain_curriculum_bitwise_vs_reference_golden(task_const):
+    """Row f-4 through the kernel source: level changes, tile origins and spawn jitter of the reference's curriculum."""
+    g = R.load("terrain_logic_frozen.npz")
+    be = EmulBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
+                     terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]))
+    for t, ref, got in R.replay(g, be):
+        ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
+        bad = P.compare(ref, got, exact=R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"],
+                        atol=R.TRANSCENDENTAL)
+        assert not bad, (t, bad)
+        assert np.array_equal(g["step_terrain_levels"][t], got["terrain_levels"]), t
+        assert np.array_equal(g["step_env_origins"][t], got["env_origins"]), t
+
+
 def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const):
     """Same libm on both sides here, so with physics frozen the kernel body and the oracle agree on every bit,
     in-kernel Philox noise included (noise = None)."""

@@ -55,3 +55,31 @@ def test_torch_gpu_division_mode_changes_only_last_bits(task_const):
         worst = max(worst, float(np.abs(ref["qvel_noise"] - got["qvel_noise"]).max()))
         assert np.allclose(ref["qvel_noise"], got["qvel_noise"], rtol=1e-6, atol=1e-6)
     assert worst >= 0.0
+
+
+def test_terrain_curriculum_and_spawn_match_reference_bitwise(task_const):
+    """Row f-4: the reference class on a height-field curriculum map (TerrainCfg edited as tests/golden says), physics
+    frozen, robots teleported around their tile each step.  Level changes (:671-691, including the random level after the
+    last one), the new tile origin, the spawn jitter (:729-732) and everything downstream are bit-identical."""
+    g = R.load("terrain_logic_frozen.npz")
+    be = R.OracleBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, debug_freeze_physics=1,
+                         terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]))
+    ups = downs = resets = 0
+    prev = g["init_terrain_levels"].copy()
+    types = g["init_terrain_types"]
+    for t, ref, got in R.replay(g, be):
+        exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
+        # the reference appends one logging column per terrain type to stacked_rewards (:417-426): the mean level of that
+        # type's envs before this step's resets; the kernel's buffer holds the 15 reward terms, the host class adds these
+        extra = ref["stacked_rewards"][:, 15:]
+        ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
+        for i in range(extra.shape[1]):
+            assert np.allclose(extra[:, i], prev[types == i].sum() / max((types == i).sum(), 1))
+        bad = P.compare(ref, got, exact=exact, atol=R.TRANSCENDENTAL)
+        assert not bad, (t, bad)
+        assert np.array_equal(g["step_terrain_levels"][t], got["terrain_levels"]), t
+        assert np.array_equal(g["step_env_origins"][t], got["env_origins"]), t
+        ups += int((got["terrain_levels"] > prev).sum()); downs += int((got["terrain_levels"] < prev).sum())
+        prev = got["terrain_levels"].copy()
+        resets += int(ref["reset_buf"].sum())
+    assert resets > 50 and ups > 5 and downs > 5      # the fixture moves robots both ways
