@@ -331,12 +331,14 @@ class DyrosDynamicWalk(VecTask):
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.extras["stacked_rewards"] = self._buf["stacked_rewards"]
         if self.custom_origins and self.terrain_cfg.curriculum:
-            # logging columns of the curriculum (reference :417-426): mean level of the envs of each terrain type
-            lv, ty = self.terrain_levels, self.terrain_types
-            cols = [torch.sum(lv[ty == i]) / max(int((ty == i).sum()), 1) * torch.ones_like(lv).unsqueeze(-1)
-                    for i in range(self.terrain_cfg.num_cols)]
-            self.extras["stacked_rewards"] = torch.cat([self._buf["stacked_rewards"]] + cols, 1)
-            self.extras["reward_names"] = list(REWARD_NAMES) + ["terrain %d level" % i for i in range(self.terrain_cfg.num_cols)]
+            # logging columns of the curriculum (reference :417-426): mean level of the envs of each terrain type, as
+            # three device ops and no host sync (the reference loops over the types with a nonzero() each)
+            nc = self.terrain_cfg.num_cols
+            if not hasattr(self, "_type_counts"):
+                self._type_counts = torch.bincount(self.terrain_types, minlength=nc).clamp(min=1).to(torch.float)
+                self.extras["reward_names"] = list(REWARD_NAMES) + ["terrain %d level" % i for i in range(nc)]
+            means = torch.zeros(nc, device=self._tdev).index_add_(0, self.terrain_types, self.terrain_levels.to(torch.float)) / self._type_counts
+            self.extras["stacked_rewards"] = torch.cat([self._buf["stacked_rewards"], means.unsqueeze(0).expand(self.num_envs, nc)], 1)
         self.obs_dict["obs"] = self._clip_obs(self.obs_buf).to(self.rl_device)
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 
