@@ -242,8 +242,10 @@ static void terrain_sample(const DwConfig *cfg, const int16_t *hs, real x, real 
     const real inv = (real)1 / cfg->terrain_hscale;
     real u = (x + cfg->terrain_border) * inv, v = (y + cfg->terrain_border) * inv;
     const real umax = (real)(cfg->terrain_rows - 1) - (real)1e-3, vmax = (real)(cfg->terrain_cols - 1) - (real)1e-3;
-    if (u < 0) u = 0; if (u > umax) u = umax;
-    if (v < 0) v = 0; if (v > vmax) v = vmax;
+    if (u < 0) u = 0;
+    if (u > umax) u = umax;
+    if (v < 0) v = 0;
+    if (v > vmax) v = vmax;
     const int i = (int)u, j = (int)v;
     const real a = u - (real)i, b = v - (real)j;
     const int16_t *p = hs + (size_t)i * cfg->terrain_cols + j;
