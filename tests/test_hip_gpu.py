@@ -425,3 +425,37 @@ def test_terrain_full_size_rollout_properties():
     assert float(d[fresh].max()) < 1.5                                                          # spawned within 1 m (each axis) of the tile origin
     ground = torch.from_numpy(env.terrain.height_at(env.root_states[:, 0].cpu().numpy(), env.root_states[:, 1].cpu().numpy())).cuda()
     assert float((env.root_states[fresh, 2] - ground[fresh]).min()) > 0.5                       # above the terrain, not inside it
+
+
+@pytest.mark.gpu
+def test_terrain_checkpoint_and_reset_done():
+    """On terrain: a checkpoint resumes bit for bit (levels and origins are part of the state), and the reset_done path
+    (dw_reset_idx) runs the curriculum for the listed envs only."""
+    from hip_backend import make_env
+    tdict = dict(mesh_type="heightfield", curriculum=True, num_rows=4, num_cols=5, border_size=2, max_init_terrain_level=3)
+    env = make_env(200, terrain=tdict)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    acts = [torch.rand(200, 13, generator=g, device="cuda") * 2 - 1 for _ in range(40)]
+    for a in acts[:25]:
+        env.step(a)
+    ck = env.state_dict()
+    ref = [tuple(t.clone() for t in (env.step(a)[0]["obs"], env.rew_buf, env.terrain_levels, env.env_origins)) for a in acts[25:]]
+    env2 = make_env(200, terrain=tdict)
+    env2.load_state_dict(ck)
+    for a, r in zip(acts[25:], ref):
+        o = env2.step(a)
+        assert torch.equal(o[0]["obs"], r[0]) and torch.equal(env2.rew_buf, r[1])
+        assert torch.equal(env2.terrain_levels, r[2]) and torch.equal(env2.env_origins, r[3])
+    # reset_done: env 7 has "walked" 6 m from its tile centre -> one level up (or a random level from the top one); env 8 stays
+    lv = env2.terrain_levels.clone()
+    env2.root_states[7, 0] = env2.env_origins[7, 0] + 6.0
+    env2.reset_buf[:] = 0
+    env2.reset_buf[7] = 1
+    env2.reset_done()
+    torch.cuda.synchronize()
+    expect_up = int(lv[7]) + 1
+    assert int(env2.terrain_levels[7]) == expect_up if expect_up < 4 else 0 <= int(env2.terrain_levels[7]) < 4
+    assert torch.equal(env2.terrain_levels[8:], lv[8:]) and torch.equal(env2.terrain_levels[:7], lv[:7])
+    org = env2.terrain_origins.view(4, 5, 3)[env2.terrain_levels[7], env2.terrain_types[7]]
+    assert torch.equal(env2.env_origins[7], org)
+    assert float((env2.root_states[7, :2] - org[:2]).abs().max()) <= 1.0 and float(env2.root_states[7, 2]) == pytest.approx(float(org[2]) + 0.93, abs=1e-6)
