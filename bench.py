@@ -41,8 +41,26 @@ def cpu_baseline(seconds_budget: float = 15.0):
         sim.step(acts[k % 8], None, 3 + k)
         k += 1
     dt = time.perf_counter() - t0
-    return {"value": N * k / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d envs x %d steps of the C oracle (oracle/dw_oracle.c, OpenMP over envs), %.1f s" % (N, k, dt)}
+    out = {"value": N * k / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": "%d envs x %d steps of the C oracle (oracle/dw_oracle.c, OpenMP over envs), %.1f s" % (N, k, dt)}
+    # the same code on ONE core (SURVEY 8d asks for both ends), a 5 s sample of 128 envs
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        one = OracleSim(128, task_const=load_task_constants(), torch_gpu_div=1)
+        one.buf["dof_state"][:, :, 0] = load_task_constants()["initial_dof_pos"]
+        a1 = [a[:128].copy() for a in acts]
+        one.step(a1[0], None, 0)
+        t1, k1 = time.perf_counter(), 0
+        while time.perf_counter() - t1 < 5.0:
+            one.step(a1[k1 % 8], None, 1 + k1)
+            k1 += 1
+        out["single_core_value"] = 128 * k1 / (time.perf_counter() - t1)
+        gomp.omp_set_num_threads(threads)
+    except Exception:
+        pass
+    return out
 
 
 def main():
