@@ -74,3 +74,81 @@ def with_terrain(cfg: dict, **terrain) -> dict:
     cfg = copy.deepcopy(cfg)
     cfg["terrain"] = dict(cfg.get("terrain") or {}, **terrain)
     return cfg
+
+
+# ---------------------------------------------------------------------------------------------- reference YAML
+# The reference hands its task constructor `omegaconf_to_dict(cfg.task)` (train.py:104-110): the task YAML with Hydra /
+# OmegaConf interpolations resolved against the root config (cfg/config.yaml) by four custom resolvers
+# (train.py:58-63).  Hydra and OmegaConf are not needed for that: the loader below resolves the same expressions.
+ROOT_DEFAULTS = {            # cfg/config.yaml:6-32
+    "num_envs": "", "seed": 42, "physics_engine": "physx", "pipeline": "gpu", "sim_device": "cuda:0",
+    "rl_device": "cuda:0", "graphics_device_id": 0, "num_threads": 4, "solver_type": 1, "num_subscenes": 4,
+    "headless": True,
+}
+
+
+def _split_args(s: str):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+            continue
+        depth += ch == "{"
+        depth -= ch == "}"
+        cur += ch
+    out.append(cur)
+    return [a.strip() for a in out]
+
+
+def _resolve(value, root: dict):
+    """One scalar of the task YAML: `${..key}` (any number of dots: a key of the root config), `${eq:a,b}`,
+    `${contains:a,b}`, `${if:c,a,b}`, `${resolve_default:d,v}`, nested."""
+    if not isinstance(value, str) or "${" not in value:
+        return value
+    s = value.strip()
+    if not (s.startswith("${") and s.endswith("}")):
+        raise ValueError("unsupported interpolation inside a string: %r" % value)
+    body = s[2:-1]
+    name, sep, rest = body.partition(":")
+    if not sep or name.startswith("."):
+        key = body.lstrip(".")
+        if key not in root:
+            raise KeyError("interpolation %r: the root config has no key %r" % (value, key))
+        return root[key]
+    args = [_resolve(a.strip('"').strip("'") if "${" not in a else a, root) for a in _split_args(rest)]
+    if name == "eq":
+        return str(args[0]).lower() == str(args[1]).lower()
+    if name == "contains":
+        return str(args[0]).lower() in str(args[1]).lower()
+    if name == "if":
+        return args[1] if args[0] else args[2]
+    if name == "resolve_default":
+        d = args[0]
+        if args[1] != "":
+            return args[1]
+        try:
+            return int(d)
+        except (TypeError, ValueError):
+            return d
+    raise ValueError("unknown resolver %r in %r" % (name, value))
+
+
+def load_task_yaml(path_or_text: str, **root_overrides) -> dict:
+    """The constructor argument of `DyrosDynamicWalk` from the reference's own task YAML
+    (cfg/task/DyrosDynamicWalk.yaml), with its `${...}` expressions resolved against cfg/config.yaml's defaults and
+    `root_overrides` (e.g. `num_envs=16384, sim_device="cuda:1"`), as Hydra would on the reference's command line."""
+    import os
+    import yaml
+    text = open(path_or_text).read() if os.path.exists(path_or_text) else path_or_text
+    root = dict(ROOT_DEFAULTS, **root_overrides)
+
+    def walk(x):
+        if isinstance(x, dict):
+            return {k: walk(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [walk(v) for v in x]
+        return _resolve(x, root)
+    cfg = walk(yaml.safe_load(text))
+    cfg.setdefault("rl_device", root["rl_device"])
+    cfg.setdefault("seed", root["seed"])
+    return cfg

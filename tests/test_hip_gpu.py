@@ -459,3 +459,17 @@ def test_terrain_checkpoint_and_reset_done():
     org = env2.terrain_origins.view(4, 5, 3)[env2.terrain_levels[7], env2.terrain_types[7]]
     assert torch.equal(env2.env_origins[7], org)
     assert float((env2.root_states[7, :2] - org[:2]).abs().max()) <= 1.0 and float(env2.root_states[7, 2]) == pytest.approx(float(org[2]) + 0.93, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_env_from_yaml_config():
+    """The constructor takes the nested dict a task YAML yields (config.load_task_yaml): round trip through YAML text."""
+    import yaml
+    from isaacgymdyros_amd.config import default_cfg, load_task_yaml
+    from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+    text = yaml.safe_dump(default_cfg(64, "cuda:0")).replace("numEnvs: 64", "numEnvs: ${resolve_default:64,${...num_envs}}")
+    env = DyrosDynamicWalk(load_task_yaml(text, num_envs=96), "cuda:0", 0, True)
+    assert env.num_envs == 96
+    obs, rew, done, extras = env.step(torch.zeros(96, 13, device="cuda"))
+    torch.cuda.synchronize()
+    assert obs["obs"].shape == (96, 487) and torch.isfinite(obs["obs"]).all()
