@@ -185,6 +185,38 @@ def pit(t: Tile, depth: float, platform_size: float = 1.0) -> None:
     t.height_field_raw[x1:x2, y1:y2] = -d
 
 
+def heightfield_to_trimesh(samples: np.ndarray, horizontal_scale: float, vertical_scale: float,
+                           slope_threshold: float | None = None):
+    """Vertices [rows*cols, 3] (float32, metres) and triangles [2(rows-1)(cols-1), 3] (uint32) of the grid, two triangles
+    per cell split along the (i,j)-(i+1,j+1) diagonal; with a slope threshold, the lower vertex of every edge or cell
+    diagonal steeper than it is pushed under the upper one, which turns steep ramps into vertical faces
+    (terrain_utils.py:286-330).  Only exposed for viewers and exporters: the kernels collide with the samples."""
+    hf = samples
+    rows, cols = hf.shape
+    yy, xx = np.meshgrid(np.linspace(0, (cols - 1) * horizontal_scale, cols), np.linspace(0, (rows - 1) * horizontal_scale, rows))
+    if slope_threshold is not None:
+        thr = slope_threshold * horizontal_scale / vertical_scale
+        mx, my, mc = np.zeros((rows, cols)), np.zeros((rows, cols)), np.zeros((rows, cols))
+        dx = hf[1:, :] - hf[:-1, :]
+        dy = hf[:, 1:] - hf[:, :-1]
+        dd = hf[1:, 1:] - hf[:-1, :-1]
+        mx[:-1, :] += dx > thr
+        mx[1:, :] -= -dx > thr
+        my[:, :-1] += dy > thr
+        my[:, 1:] -= -dy > thr
+        mc[:-1, :-1] += dd > thr
+        mc[1:, 1:] -= -dd > thr
+        xx += (mx + mc * (mx == 0)) * horizontal_scale
+        yy += (my + mc * (my == 0)) * horizontal_scale
+    vertices = np.zeros((rows * cols, 3), dtype=np.float32)
+    vertices[:, 0], vertices[:, 1], vertices[:, 2] = xx.ravel(), yy.ravel(), hf.ravel() * vertical_scale
+    i0 = (np.arange(rows - 1)[:, None] * cols + np.arange(cols - 1)[None, :]).ravel()
+    tri = np.empty((2 * (rows - 1) * (cols - 1), 3), dtype=np.uint32)
+    tri[0::2] = np.stack([i0, i0 + cols + 1, i0 + 1], 1)
+    tri[1::2] = np.stack([i0, i0 + cols, i0 + cols + 1], 1)
+    return vertices, tri
+
+
 # ---------------------------------------------------------------------------------------------- the map
 class Terrain:
     """The tiled map (reference: utils/terrain.py:40-165).  Attributes follow the reference: `heightsamples`
@@ -218,6 +250,9 @@ class Terrain:
                 difficulty = self.rs.choice([0.5, 0.75, 0.9])
                 self._place(self.make_tile(choice, difficulty), i, j)
         self.heightsamples = self.height_field_raw
+        if self.type == "trimesh":
+            self.vertices, self.triangles = heightfield_to_trimesh(self.height_field_raw, cfg.horizontal_scale,
+                                                                   cfg.vertical_scale, cfg.slope_treshold)
 
     def make_tile(self, choice: float, difficulty: float) -> Tile:
         """Tile type from `choice` against the cumulative proportions, size of its features from `difficulty`

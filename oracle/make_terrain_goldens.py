@@ -33,6 +33,12 @@ def main():
         t = ref_terrain.Terrain(cfg, 64)
         out[name + "/heightsamples"] = np.asarray(t.heightsamples, dtype=np.int16)
         out[name + "/env_origins"] = np.asarray(t.env_origins, dtype=np.float64)
+        if cfg.mesh_type == "trimesh":       # the mesh is large: keep digests and a few rows
+            import hashlib
+            out[name + "/vertices_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(t.vertices).tobytes()).digest(), dtype=np.uint8)
+            out[name + "/triangles_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(t.triangles).tobytes()).digest(), dtype=np.uint8)
+            out[name + "/vertices_shape"] = np.asarray(t.vertices.shape); out[name + "/triangles_shape"] = np.asarray(t.triangles.shape)
+            out[name + "/vertices_dtype"] = np.asarray(str(t.vertices.dtype)); out[name + "/triangles_dtype"] = np.asarray(str(t.triangles.dtype))
         print(name, t.heightsamples.shape, int(t.heightsamples.min()), int(t.heightsamples.max()))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "terrain_ref.npz"), **out)
 

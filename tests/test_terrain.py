@@ -21,6 +21,13 @@ def test_matches_reference_samples(name, seed, ov):
     assert np.array_equal(t.heightsamples, ref_h)
     assert np.array_equal(t.env_origins, ref_o)
     assert (t.tot_rows, t.tot_cols) == ref_h.shape
+    if ov["mesh_type"] == "trimesh":          # triangle mesh with straightened steep faces: digests of the reference's arrays
+        import hashlib
+        assert tuple(GOLD[name + "/vertices_shape"]) == t.vertices.shape and str(GOLD[name + "/vertices_dtype"]) == str(t.vertices.dtype)
+        assert tuple(GOLD[name + "/triangles_shape"]) == t.triangles.shape and str(GOLD[name + "/triangles_dtype"]) == str(t.triangles.dtype)
+        for arr, key in ((t.vertices, "vertices"), (t.triangles, "triangles")):
+            dg = np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).digest(), dtype=np.uint8)
+            assert np.array_equal(dg, GOLD[name + "/" + key + "_sha256"]), key
 
 
 def test_live_against_reference_when_present():
