@@ -76,6 +76,18 @@ __global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, const dw
     dw::reset_only_env(w, S, *M, P->C, T, e);
 }
 
+// The handle's tables, parameter block and the caller's buffers live on the device that was current at dw_create.
+// Entry points that touch the device make that device current for the duration of the call (one process may drive
+// several GPUs, or torch may have switched devices in between) and restore the caller's choice afterwards.
+struct DeviceGuard {
+    int prev = -1, want;
+    explicit DeviceGuard(int dev) : want(dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
 extern "C" {
 
 int dw_abi_version(void) { return DW_ABI_VERSION; }
@@ -123,6 +135,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
 
 int dw_destroy(DwHandle *h) {
     if (!h) return fail(DW_EINVAL, "dw_destroy: null handle");
+    DeviceGuard guard(h->device);
     if (h->d_model) (void)hipFree(h->d_model);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_mocap) (void)hipFree(h->d_mocap);
@@ -134,6 +147,7 @@ int dw_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dw_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
     if (const char *m = dw::check_terrain_buffers(&h->cfg, b)) return fail(DW_EINVAL, m);
+    DeviceGuard guard(h->device);
     h->buf = *b;
     // bind time, not step time: one small synchronous copy of the pointer table into the parameter block
     hipError_t e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
@@ -149,6 +163,7 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!h || !h->bound) return fail(DW_ESTATE, "dw_simulate: buffers not bound");
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
+    DeviceGuard guard(h->device);
     if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_simulate_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, tau, push_xy);
@@ -165,6 +180,7 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
+    DeviceGuard guard(h->device);
     if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, actions, noise, (long long)step_index);
@@ -181,6 +197,7 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (n < 0 || (n > 0 && !env_ids)) return fail(DW_EINVAL, "dw_reset_idx: bad env id list");
     if (n == 0) return DW_OK;
+    DeviceGuard guard(h->device);
     hipLaunchKernelGGL(dw_k_reset, dim3(n), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params, noise,
                        (long long)step_index, env_ids, n);
     hipError_t e = hipGetLastError();

@@ -473,3 +473,15 @@ def test_env_from_yaml_config():
     obs, rew, done, extras = env.step(torch.zeros(96, 13, device="cuda"))
     torch.cuda.synchronize()
     assert obs["obs"].shape == (96, 487) and torch.isfinite(obs["obs"]).all()
+
+
+@pytest.mark.gpu
+def test_entry_points_do_not_depend_on_the_current_device():
+    """The library makes the handle's device current for the call and restores the caller's (several GPUs per process,
+    or torch switching devices in between).  On a one-GPU box: the current device is unchanged by a step."""
+    from hip_backend import make_env
+    env = make_env(64)
+    before = torch.cuda.current_device()
+    env.step(torch.zeros(64, 13, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before
