@@ -12,7 +12,11 @@ SOURCES = ["dw_hip.hip"]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_* pairs, which costs more
 # v_mov operand shuffling than it saves here (static v_mov count halves without it)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fno-slp-vectorize"]
+# -amdgpu-sched-strategy=iterative-ilp: the kernel is a chain of short dependent regions at 3 waves/SIMD, so a machine
+# scheduler that lengthens the distance between an LDS load and its first use pays directly (measured -4.5 % step time,
+# -7 % lone-wave latency against the default max-occupancy scheduler; max-ilp, max-memory-clause and iterative-minreg lose)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fno-slp-vectorize",
+         "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def hipcc() -> str:
