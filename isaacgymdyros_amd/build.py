@@ -15,7 +15,8 @@ HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params
 # -amdgpu-sched-strategy=iterative-ilp: the kernel is a chain of short dependent regions at 3 waves/SIMD, so a machine
 # scheduler that lengthens the distance between an LDS load and its first use pays directly (measured -4.5 % step time,
 # -7 % lone-wave latency against the default max-occupancy scheduler; max-ilp, max-memory-clause and iterative-minreg lose)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fno-slp-vectorize",
+# -O2 rather than -O3: 1 % faster with this scheduler (less aggressive unrolling, same zero scratch)
+FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fno-slp-vectorize",
          "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 

@@ -3,5 +3,5 @@
 set -e
 cd $(dirname $0)/../isaacgymdyros_amd/csrc
 sed "$1" dw_hip.hip > _ab.hip
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-strict-aliasing -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp $2 -o ../libdyroswalk_hip.so _ab.hip
+hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared -fno-strict-aliasing -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp $2 -o ../libdyroswalk_hip.so _ab.hip
 rm -f _ab.hip
