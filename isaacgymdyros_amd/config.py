@@ -76,6 +76,59 @@ def with_terrain(cfg: dict, **terrain) -> dict:
     return cfg
 
 
+def validate_cfg(cfg: dict) -> None:
+    """Pure-Python range checks of everything the constructor later turns into device indices or kernel sizes.  Called
+    BEFORE the native library is loaded or a byte of device memory is allocated, so a bad configuration is a ValueError
+    on the host, never an out-of-range gather on the GPU (a device-side assert aborts the process; round-1 post-mortem).
+    The reference has no such checks: `terrain_origins[levels, types]` (tasks/dyros_dynamic_walk.py:703-707) indexes out
+    of range for max_init_terrain_level >= num_rows."""
+    env, sim = cfg["env"], cfg["sim"]
+    n = env["numEnvs"]
+    if not isinstance(n, int) or n < 1:
+        raise ValueError("env.numEnvs must be a positive integer, got %r" % (n,))
+    if (env.get("NumHis"), env.get("NumSkip"), env.get("NumSingleStepObs"), env.get("NumAction")) != (10, 2, 37, 13):
+        raise ValueError("the MI355X step kernel is specialised for NumHis=10, NumSkip=2, NumSingleStepObs=37, NumAction=13")
+    if env.get("controlFrequencyInv", 2) != 2:
+        raise ValueError("only env.controlFrequencyInv = 2 is supported (DyrosDynamicWalk.yaml:11)")
+    if not float(sim["dt"]) > 0:
+        raise ValueError("sim.dt must be positive")
+    if len(sim.get("gravity", [0, 0, -9.81])) != 3:
+        raise ValueError("sim.gravity must have three components")
+    px = sim.get("physx", {})
+    iters = int(px.get("num_position_iterations", 4)) + int(px.get("num_velocity_iterations", 1))
+    if not 1 <= iters <= 64:
+        raise ValueError("physx.num_position_iterations + num_velocity_iterations must be in 1..64")
+    t = dict(cfg.get("terrain") or {})
+    mesh = t.get("mesh_type", "plane")
+    if mesh not in (None, "none", "plane", "heightfield", "trimesh"):
+        raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
+    if mesh in ("heightfield", "trimesh"):
+        from .terrain import TerrainCfg
+        tc = TerrainCfg(**t)                           # AttributeError for unknown fields
+        if tc.selected:
+            raise ValueError("TerrainCfg.selected is not supported (it cannot run in the reference either, DESIGN.md section 9)")
+        if not (isinstance(tc.num_rows, int) and isinstance(tc.num_cols, int) and tc.num_rows >= 1 and tc.num_cols >= 1):
+            raise ValueError("TerrainCfg.num_rows and num_cols must be positive integers")
+        if tc.curriculum and not 0 <= int(tc.max_init_terrain_level) < tc.num_rows:
+            raise ValueError("TerrainCfg.max_init_terrain_level (%d) must be in [0, num_rows = %d)"
+                             % (tc.max_init_terrain_level, tc.num_rows))
+        if not (tc.horizontal_scale > 0 and tc.vertical_scale > 0):
+            raise ValueError("TerrainCfg.horizontal_scale and vertical_scale must be positive")
+        if tc.border_size < 0:
+            raise ValueError("TerrainCfg.border_size must be non-negative")
+        if tc.terrain_length < 2 * tc.horizontal_scale or tc.terrain_width < 2 * tc.horizontal_scale:
+            raise ValueError("TerrainCfg.terrain_length / terrain_width must span at least two samples")
+        if abs(tc.terrain_length - tc.terrain_width) > 1e-9:
+            raise ValueError("TerrainCfg tiles must be square (the reference builds every tile width x width, utils/terrain.py:108)")
+        props = list(tc.terrain_proportions)
+        if not props or any(p < 0 for p in props) or sum(props) > 1.0 + 1e-6:
+            raise ValueError("TerrainCfg.terrain_proportions must be non-negative and sum to at most 1")
+        rows = int(tc.num_rows * int(tc.terrain_length / tc.horizontal_scale)) + 2 * int(tc.border_size / tc.horizontal_scale)
+        cols = int(tc.num_cols * int(tc.terrain_width / tc.horizontal_scale)) + 2 * int(tc.border_size / tc.horizontal_scale)
+        if rows < 2 or cols < 2 or rows * cols > 2 ** 31 - 1:
+            raise ValueError("terrain sample grid %d x %d is out of range" % (rows, cols))
+
+
 # ---------------------------------------------------------------------------------------------- reference YAML
 # The reference hands its task constructor `omegaconf_to_dict(cfg.task)` (train.py:104-110): the task YAML with Hydra /
 # OmegaConf interpolations resolved against the root config (cfg/config.yaml) by four custom resolvers

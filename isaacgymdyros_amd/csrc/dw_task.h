@@ -236,7 +236,9 @@ DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskPara
                     lvl = k;
                 } else if (lvl < 0) lvl = 0;
                 B.terrain_levels[e] = lvl;
-                const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + B.terrain_types[e]) * 3;
+                long long ty = B.terrain_types[e];          // user-writable buffer (load_state_dict): never index past the table
+                ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
+                const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + ty) * 3;
                 for (int i = 0; i < 3; ++i) { const float o = org[i]; B.env_origins[3 * e + i] = o; S.scratch[4 + i] = o; }
             }
         });

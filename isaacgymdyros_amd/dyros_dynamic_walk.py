@@ -30,6 +30,8 @@ def _u(gen, shape, device):
 class DyrosDynamicWalk(VecTask):
 
     def __init__(self, cfg: Dict[str, Any], sim_device: str, graphics_device_id: int = 0, headless: bool = True):
+        from .config import validate_cfg
+        validate_cfg(cfg)                       # host-side range checks before the library is loaded or memory allocated
         self.cfg = cfg
         env_cfg = cfg["env"]
         self.randomization_params = cfg["task"]["randomization_params"]
@@ -212,11 +214,10 @@ class DyrosDynamicWalk(VecTask):
         if self.custom_origins:
             # origins on the terrain tiles (reference :697-707): a random starting level, the type from the env index
             tcf = self.terrain_cfg
-            max_init_level = tcf.max_init_terrain_level if tcf.curriculum else tcf.num_rows - 1
-            if not 0 <= max_init_level < tcf.num_rows:       # the reference would index terrain_origins out of range here
-                raise ValueError("TerrainCfg.max_init_terrain_level (%d) must be below num_rows (%d)" % (max_init_level, tcf.num_rows))
+            max_init_level = tcf.max_init_terrain_level if tcf.curriculum else tcf.num_rows - 1   # range: validate_cfg
             lv = torch.randint(0, max_init_level + 1, (N,), generator=gen, device=dev)
             ty = torch.div(torch.arange(N, device=dev), (N / tcf.num_cols), rounding_mode="floor").to(torch.long)
+            ty = ty.clamp_(0, tcf.num_cols - 1)               # float rounding of N / num_cols must not index past the last column
             b["terrain_levels"].copy_(lv)
             b["terrain_types"].copy_(ty)
             b["env_origins"].copy_(b["terrain_origins"].view(tcf.num_rows, tcf.num_cols, 3)[lv, ty])
@@ -373,6 +374,25 @@ class DyrosDynamicWalk(VecTask):
         return d
 
     def load_state_dict(self, d):
+        """Restores a state_dict().  Shapes, dtypes and every field the kernels use as an index are checked on the host
+        first: the buffers are restored verbatim and the step kernel gathers with them."""
+        for k, v in self._buf.items():
+            if k not in d:
+                raise ValueError("state dict lacks buffer %r" % k)
+            if tuple(d[k].shape) != tuple(v.shape) or d[k].dtype != v.dtype:
+                raise ValueError("state dict buffer %r is %s %s, expected %s %s" % (k, tuple(d[k].shape), d[k].dtype, tuple(v.shape), v.dtype))
+        if self.custom_origins:
+            lv, ty = d["terrain_levels"], d["terrain_types"]
+            if lv.numel() and (int(lv.min()) < 0 or int(lv.max()) >= self.terrain_cfg.num_rows):
+                raise ValueError("state dict terrain_levels out of range [0, %d)" % self.terrain_cfg.num_rows)
+            if ty.numel() and (int(ty.min()) < 0 or int(ty.max()) >= self.terrain_cfg.num_cols):
+                raise ValueError("state dict terrain_types out of range [0, %d)" % self.terrain_cfg.num_cols)
+        es = d["env_state"]
+        for name, lo, hi in (("hist_head", 0, 19), ("delay_idx", 0, 5), ("init_mocap_data_idx", 0, 3599)):
+            if name in abi.ES_FIELDS:
+                f = abi.es_view(es, name)
+                if f.numel() and (int(f.min()) < lo or int(f.max()) > hi):
+                    raise ValueError("state dict env_state field %r out of range [%d, %d]" % (name, lo, hi))
         for k, v in self._buf.items():
             v.copy_(d[k].to(v.device))
         self._step_count = int(d["_step_count"])

@@ -101,15 +101,17 @@ class VecTask(Env):
         if config["sim"]["up_axis"] not in ["z"]:
             raise ValueError(f"Invalid physics up-axis: {config['sim']['up_axis']}")              # vec_task.py:435-438
         self.viewer = None
+        self.alias_obs = bool(config["sim"].get("mi355", {}).get("alias_obs", False))
         self.obs_dict: Dict[str, torch.Tensor] = {}
         self.extras: Dict[str, Any] = {}
 
     def _clip_obs(self, t: torch.Tensor) -> torch.Tensor:
-        # reference: torch.clamp(obs_buf, -clip_obs, clip_obs) (vec_task.py:338).  With the task's clip of +-inf
-        # that is a 32 MB identity copy per step at 16384 envs, so the buffer itself is returned; callers must
-        # copy what they keep (rl_games does, a2c_common_dyros.py:642-661) -- same rule as for rew/reset.
+        # reference: torch.clamp(obs_buf, -clip_obs, clip_obs) (vec_task.py:338) -- always a FRESH tensor, also with the
+        # task's clip of +-inf.  That contract is the default here.  cfg["sim"]["mi355"]["alias_obs"] = True opts into
+        # returning the persistent buffer itself (saves a 32 MB copy per step at 16384 envs; the caller must then copy
+        # what it keeps across steps -- rl_games does, a2c_common_dyros.py:642-661; bench.py sets it).
         if np.isinf(self.clip_obs):
-            return t
+            return t if self.alias_obs else t.clone()
         return torch.clamp(t, -self.clip_obs, self.clip_obs)
 
     def zero_actions(self) -> torch.Tensor:

@@ -41,15 +41,23 @@ def test_whole_step_vs_oracle_goldens(task_const):
     from hip_backend import HipBackend
     g = R.load("whole_step_oracle.npz")
     be = HipBackend(int(g["N"]), randomize=False, torch_gpu_div=False)
+    ref_rew, got_rew, ref_res, got_res = [], [], 0, 0
     for t, ref, got in R.replay(g, be):
-        if t >= 10:
-            break
-        dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
-        dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
-        assert dq < 1e-4 and dqd < 2e-2, (t, dq, dqd)
-        assert np.abs(ref["root_states"][:, :7] - got["root_states"][:, :7]).max() < 1e-4, t
-        assert np.abs(ref["rew_buf"] - got["rew_buf"]).max() < 5e-3, t     # ~1e-4 of reward per newton of sole load
-        assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
+        if t < 10:
+            dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
+            dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
+            assert dq < 1e-4 and dqd < 2e-2, (t, dq, dqd)
+            assert np.abs(ref["root_states"][:, :7] - got["root_states"][:, :7]).max() < 1e-4, t
+            assert np.abs(ref["rew_buf"] - got["rew_buf"]).max() < 5e-3, t     # ~1e-4 of reward per newton of sole load
+            assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
+        else:
+            # past ~10 steps of contact the two fp32 trajectories separate chaotically (measured growth 1e-5 rad per 10
+            # steps, then a contact flips); what must still agree is the statistics of the rollout
+            ref_rew.append(ref["rew_buf"].mean()); got_rew.append(got["rew_buf"].mean())
+            ref_res += int(ref["reset_buf"].sum()); got_res += int(got["reset_buf"].sum())
+        assert np.isfinite(got["obs_buf"]).all() and np.isfinite(got["rew_buf"]).all(), t
+    assert abs(np.mean(ref_rew) - np.mean(got_rew)) < 0.05, (np.mean(ref_rew), np.mean(got_rew))
+    assert abs(ref_res - got_res) <= max(3, 0.3 * ref_res), (ref_res, got_res)
 
 
 def test_physics_substep_vs_oracle(task_const):
@@ -146,6 +154,14 @@ def test_full_size_properties(N, friction_dr):
         obs, rew, done, extras = env.step(a)
         resets += int(done.sum())
         hist.append(obs["obs"][:, 333:370].clone())
+        if t == 3:
+            # pushes forced on (config 5): perturb_timing starts at 1, so every env that has not been reset since is inside
+            # its push (durations are 25..249 policy steps) with a running count and a force of impulse / (duration * 0.004)
+            fresh = env.epi_len >= 4
+            assert int(fresh.sum()) > 0.5 * N
+            assert bool((env.pert_on[fresh] == 1).all()) and bool((env.perturbation_count[fresh] == 3).all())
+            mag = env.magnitude[fresh]
+            assert float(mag.min()) >= 50 / (249 * 0.004) - 1e-3 and float(mag.max()) <= 249 / (25 * 0.004) + 1e-3
         if t >= 2:
             # obs_buf slot 8 at step t is slot 9 (the newest) at step t-2 unless the env was reset in between
             keep = (env.epi_len >= 3)
@@ -163,10 +179,46 @@ def test_full_size_properties(N, friction_dr):
     if friction_dr:
         fs = env._buf["friction_scale"]
         assert 0.7 <= float(fs.min()) and float(fs.max()) <= 1.3 and float(fs.std()) > 0.1
-    assert int(env.pert_on.sum()) > 0 or int(env.perturbation_count.sum()) >= 0
     # reward decomposition: total == sum of the 14 terms where the episode did not end on this step
     alive = done == 0
     assert torch.allclose(extras["stacked_rewards"][alive, :14].sum(1), rew[alive], atol=1e-5)
+
+
+def test_push_moves_the_base():
+    """A pushed env's base responds by impulse / effective mass: two runs that differ only in the perturbation switch,
+    robots in free fall 3 m up (no contacts), zero actions.  Identical up to the step the push starts
+    (perturb_timing = 1); after it the base velocity differs along the push direction by F*dt/m_eff with m_eff between
+    the pelvis' own mass and the whole robot's (the push acts for the first 2 ms substep of the policy step only)."""
+    from hip_backend import make_env
+    N = 256
+    envs = []
+    for pert in (True, False):
+        env = make_env(N, randomize=False, force_perturb_start=pert, seed=11)
+        if not pert:
+            env.perturb_start[:] = 0
+        env._buf["root_states"][:, 2] = 3.0
+        envs.append(env)
+    a = torch.zeros(N, 13, device="cuda")
+    A, B = envs
+    # gravity stays on; both runs fall identically (3 m up, no contact within two steps), the difference isolates the push
+    A.step(a); B.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(A.root_states, B.root_states)             # no push yet: bitwise the same kernel, same inputs
+    A.step(a); B.step(a)
+    torch.cuda.synchronize()
+    assert bool((A.pert_on == 1).all()) and int(B.pert_on.sum()) == 0
+    F = torch.stack([A.magnitude * torch.cos(A.phase), A.magnitude * torch.sin(A.phase)], 1)      # world x/y force [N]
+    dv = (A.root_states[:, 7:9] - B.root_states[:, 7:9])
+    J = F * 0.002                                                   # one substep of force
+    along = (dv * J).sum(1) / J.norm(dim=1)                        # velocity change along the push
+    m_total = float(A.total_mass.mean())
+    m_pelvis = float(A.model.inert_mass[0])
+    jn = J.norm(dim=1)
+    assert bool((along > 0.9 * jn / m_total).all()), (float((along * m_total / jn).min()))
+    assert bool((along < 1.1 * jn / m_pelvis).all()), (float((along * m_pelvis / jn).max()))
+    # and it is a push, not a twist: the lateral part is small against the part along the force
+    lateral = (dv - along[:, None] * J / jn[:, None]).norm(dim=1)
+    assert float((lateral / along).max()) < 0.5
 
 
 def test_determinism_and_reset_done():
