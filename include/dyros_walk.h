@@ -23,7 +23,9 @@
  *                            (tasks/dyros_dynamic_walk.py:502,520,525-526,547-549): ONE physics substep.
  *   dw_step                  VecTask.step: pre_physics_step + 2x simulate + post_physics_step
  *                            (tasks/base/vec_task.py:293-344; tasks/dyros_dynamic_walk.py:449-563,581-669,
- *                            750-947) fused into one launch.
+ *                            750-947): three launches on the caller's stream (task logic before the substeps,
+ *                            the two substeps with the actuator model, task logic after them) or, with
+ *                            DwConfig.pipeline = 1, one fused launch.
  *   dw_reset_idx             DyrosDynamicWalk.reset_idx + set_actor_root_state_tensor_indexed +
  *                            set_dof_state_tensor_indexed (tasks/dyros_dynamic_walk.py:598-669,720-748),
  *                            as reached from VecTask.reset_done (tasks/base/vec_task.py:376-391).
@@ -43,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 3
+#define DW_ABI_VERSION 4
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -181,6 +183,9 @@ typedef struct DwConfig {
     float   terrain_env_length;         /* terrain_length [m]: walked more than half of it => level up */
     float   max_episode_length_s;       /* env.episodeLength as the curriculum uses it (:34, :685)    */
     int32_t custom_origins;             /* 1 = reset adds U(-1,1) m of xy jitter to the origin (:729-732) */
+    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate: 0 = default (2), 1 = the fused wave-per-env
+                                           kernel (one wavefront per env), 2 = the split pipeline around the quad physics
+                                           kernel (4 lanes per env, 16 envs per wavefront) */
 } DwConfig;
 
 /* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of

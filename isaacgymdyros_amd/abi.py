@@ -78,6 +78,7 @@ class DwConfig(C.Structure):
         ("terrain_env_length", C.c_float),
         ("max_episode_length_s", C.c_float),
         ("custom_origins", C.c_int32),
+        ("pipeline", C.c_int32),
     ]
 
 

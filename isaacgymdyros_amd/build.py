@@ -9,7 +9,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdyroswalk_hip.so")
 SOURCES = ["dw_hip.hip"]
-HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h"]
+HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
+           "dw_quad.h", "dw_quad_kernels.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_* pairs, which costs more
 # v_mov operand shuffling than it saves here (static v_mov count halves without it)
 # -amdgpu-sched-strategy=iterative-ilp: the kernel is a chain of short dependent regions at 3 waves/SIMD, so a machine

@@ -453,11 +453,20 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                     const float cc = dot3(da, r);
                     if (ee <= eps) { sb = 0.0f; sa = c01(-cc / aa); }
                     else {
+                        // (blended with the mid-overlap answer for nearly parallel capsules: oracle/dw_physics.c seg_seg)
                         const float bbv = dot3(da, db), den = aa * ee - bbv * bbv;
-                        sa = den > eps ? c01((bbv * ff - cc * ee) / den) : 0.0f;
-                        sb = (bbv * sa + ff) / ee;
-                        if (sb < 0.0f) { sb = 0.0f; sa = c01(-cc / aa); }
-                        else if (sb > 1.0f) { sb = 1.0f; sa = c01((bbv - cc) / aa); }
+                        float se = den > eps ? c01((bbv * ff - cc * ee) / den) : 0.0f;
+                        float te = (bbv * se + ff) / ee;
+                        if (te < 0.0f) { te = 0.0f; se = c01(-cc / aa); }
+                        else if (te > 1.0f) { te = 1.0f; se = c01((bbv - cc) / aa); }
+                        const float t0 = -cc / aa, t1 = t0 + bbv / aa;
+                        float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+                        if (lo < 0.0f) lo = 0.0f;
+                        if (hi > 1.0f) hi = 1.0f;
+                        const float sp = c01(0.5f * (lo + hi)), tp = c01((bbv * sp + ff) / ee), reg = 1e-3f * aa * ee;
+                        const float w = den > eps ? den * den / (den * den + reg * reg) : 0.0f;
+                        sa = w * se + (1.0f - w) * sp;
+                        sb = w * te + (1.0f - w) * tp;
                     }
                 }
                 float pa[3], pb[3], n[3];

@@ -1,0 +1,1061 @@
+// dw_quad.h -- one physics substep (stand-in for the reference's closed `gym.simulate`, call site
+// tasks/dyros_dynamic_walk.py:525) in the QUAD layout: 4 lanes per env, 16 envs per wavefront (dw_quad_wave.h,
+// schedule and tables: dw_quad_model.h).  Same physics, same order of the contact iterations and the same written
+// decisions as dw_physics.h / oracle/dw_physics.c (DESIGN.md "Physics model"); what changes is who computes what:
+//
+//   * a lane owns a limb and walks it body by body with the running quantity in registers -- pose and velocity outward,
+//     articulated inertia (21 words) and bias force inward, acceleration / velocity jump outward again -- so every
+//     instruction does useful arithmetic for 64 lanes (the wave-per-env kernel ran these recursions on 6-12 lanes);
+//   * all spatial quantities live in one frame (world axes, origin O = base origin at the start of the substep), so a
+//     child's articulated inertia is ADDED to its parent's: continuing a chain costs nothing, limbs meet through DPP adds;
+//   * per body only 16 words survive a pass, in an LDS slot private to the owner lane (4 x ds_read/write_b128,
+//     bank-conflict free): orientation quaternion, position, velocity, joint inputs after the kinematics pass;
+//     joint subspace S, U = IA S, 1/D, u after the inward pass.  34 bodies x 64 B x 16 envs = 34 KB per wave, which with the
+//     proxy table stays under 40 KB: 4 waves per CU, one per SIMD, 64 envs resident per CU (the wave-per-env kernel: 12);
+//   * the sole contacts are solved in foot-twist space: the 12x12 inverse operational inertia W of the two feet is held one
+//     3-row slab per lane (12 unit-wrench responses, 3 per lane), the projected Gauss-Seidel keeps the two foot twists
+//     tw = tw_free + W lambda in registers and updates them with 36 FMAs per lane and corner pair.  v_k = J_k tw and
+//     lambda += J_k' dp reproduce the 24-row velocity-level iteration of dw_physics.h exactly (same pairs, same order).
+#pragma once
+
+#include "dw_physics.h"
+#include "dw_quad_model.h"
+#include "dw_quad_wave.h"
+
+#if defined(__HIPCC__)
+#define DQ_UNROLL _Pragma("unroll")
+#else
+#define DQ_UNROLL
+#endif
+
+namespace dwq {
+
+using dw::DevModel; using dw::PhysParams; using dw::NB; using dw::ND;
+using dw::cross3; using dw::dot3; using dw::m3v; using dw::m3tv; using dw::dot6; using dw::quat_to_mat; using dw::sym6;
+
+#if defined(__HIPCC__)
+typedef float4 F4;
+#else
+struct alignas(16) F4 { float x, y, z, w; };
+#endif
+DQ_HD F4 mk4(float x, float y, float z, float w) { F4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+// One wave's LDS: body slots [body][quad][position], position = (env + 4 * owner lane) & 15 so that the four lanes of a
+// quad, which work on four different bodies, fall on different banks for 16-byte accesses.
+struct alignas(16) QLds {
+    F4 slot[NB * 4][EPW];
+    F4 prox[8 * 2][EPW];          // self-collision proxy end points (common frame), written during kinematics
+};
+
+// What a lane keeps in registers across the phases of a step.
+struct QLane {
+    int   lane, j, el, env, valid, pos;     // quad lane, env within the wave, global env (clamped), position in the slot rows
+    float root[13];
+    float mu;
+    float warm[12];                          // impulses of the 4 corners of "my" foot (foot j & 1), from the previous substep
+    float footF[3];                          // non-sole contact force on my foot's sole Gym body (lanes 0, 1)
+};
+
+DQ_HD void qmul(const float *a, const float *b, float *o) {     // xyzw
+    const float x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    const float y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    const float z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    const float w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+
+// x[i] of quad lane xl (wave-uniform xl) for a small register array
+template <int N> DQ_HD void quad_bcast_arr(int xl, const float (&s)[N], float (&d)[N]) {
+    if (xl == 0) { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<0>(s[i]); }
+    else if (xl == 1) { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<1>(s[i]); }
+    else if (xl == 2) { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<2>(s[i]); }
+    else { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<3>(s[i]); }
+}
+// lanes whose running state some lane of the quad fetches in outward step s (bit xl), from the tables: wave-uniform
+DQ_HD int fetch_mask(const QuadModel &QM, int s) {
+    int m = 0;
+    DQ_UNROLL for (int l = 0; l < 4; ++l) { const int p = QM.fk[s][l].body >= 0 ? QM.fk[s][l].psrc : 0; if (p >= 2) m |= 1 << (p - 2); }
+    return m;
+}
+
+#define DQ_SLOT(b, q, p) L.slot[(b) * 4 + (q)][(p)]
+
+// Ground penalty force of one primitive of body b (dw_physics.h K4).  R, x: body rotation / origin relative to O; v: body
+// twist about O.  Returns the force in F and the contact point relative to O in xr.
+template <bool TERRAIN>
+DQ_HD void geom_force(const DwGeom &ge, const PhysParams &P, const float *R, const float *x, const float *v, float rootx, float rooty,
+                      float rootz, float mu, float *F, float *xr) {
+    F[0] = F[1] = F[2] = 0.0f;
+    float rl[3];
+    if (ge.type == 0) {
+        float e[3];
+        DQ_UNROLL for (int i = 0; i < 3; ++i) {
+            const float rg = R[6] * ge.rot[i] + R[7] * ge.rot[3 + i] + R[8] * ge.rot[6 + i];      // world z of box axis i
+            e[i] = (rg > 0.0f ? -1.0f : 1.0f) * ge.size[i];
+        }
+        m3v(ge.rot, e, rl);
+        rl[0] += ge.pos[0]; rl[1] += ge.pos[1]; rl[2] += ge.pos[2];
+    } else {
+        const float al[3] = {ge.rot[2], ge.rot[5], ge.rot[8]};
+        float aw[3];
+        m3v(R, al, aw);
+        const float sgn = aw[2] >= 0 ? -1.0f : 1.0f;
+        const float dw3[3] = {-aw[2] * aw[0], -aw[2] * aw[1], 1.0f - aw[2] * aw[2]};
+        const float dn = sqrtf(dot3(dw3, dw3));
+        float off[3] = {0, 0, 0};
+        if (dn > 1e-6f) {
+            const float k = -ge.size[0] / dn;
+            const float ow[3] = {k * dw3[0], k * dw3[1], k * dw3[2]};
+            m3tv(R, ow, off);
+        }
+        DQ_UNROLL for (int i = 0; i < 3; ++i) rl[i] = ge.pos[i] + sgn * ge.size[1] * al[i] + off[i];
+    }
+    float wv[3];
+    m3v(R, rl, wv);
+    DQ_UNROLL for (int i = 0; i < 3; ++i) xr[i] = x[i] + wv[i];
+    const float zmin = rootz + xr[2];
+    if (TERRAIN) {
+        float hh, fr[9];
+        dw::terrain_sample(P, rootx + xr[0], rooty + xr[1], &hh, fr);
+        const float *nrm = fr + 6;
+        const float dist = (zmin - hh) * nrm[2];
+        if (dist < 0) {
+            float t[3], vw[3];
+            cross3(v, xr, t);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) vw[i] = v[3 + i] + t[i];
+            const float vn = dot3(vw, nrm);
+            float fn = P.pen_k * (-dist) - P.pen_c * vn;
+            if (fn < 0) fn = 0;
+            const float vt[3] = {vw[0] - vn * nrm[0], vw[1] - vn * nrm[1], vw[2] - vn * nrm[2]};
+            const float sp = sqrtf(dot3(vt, vt));
+            DQ_UNROLL for (int i = 0; i < 3; ++i) F[i] = fn * nrm[i];
+            if (sp > 1e-9f) {
+                float ft = P.pen_c * sp;
+                const float lim = mu * fn;
+                if (ft > lim) ft = lim;
+                DQ_UNROLL for (int i = 0; i < 3; ++i) F[i] -= ft * vt[i] / sp;
+            }
+        }
+    } else if (zmin < 0) {
+        float t[3], vw[3];
+        cross3(v, xr, t);
+        DQ_UNROLL for (int i = 0; i < 3; ++i) vw[i] = v[3 + i] + t[i];
+        float fn = P.pen_k * (-zmin) - P.pen_c * vw[2];
+        if (fn < 0) fn = 0;
+        const float sp = sqrtf(vw[0] * vw[0] + vw[1] * vw[1]);
+        F[2] = fn;
+        if (sp > 1e-9f) {
+            float ft = P.pen_c * sp;
+            const float lim = mu * fn;
+            if (ft > lim) ft = lim;
+            F[0] = -ft * vw[0] / sp; F[1] = -ft * vw[1] / sp;
+        }
+    }
+}
+
+// Rigid-body inertia of a body about O in world axes from its (<= 2) inertial records (dw_physics.h K3):
+// Ao (symmetric 3x3, 6 words: 00 01 02 11 12 22), ho = first moment, mass.
+DQ_HD void rigid_inertia(int nin, const float *com0, float m0, const float *I0, float ms0, const float *com1, float m1, const float *I1,
+                         float ms1, const float *R, const float *x, float *Ao, float *ho, float *mass_out) {
+    float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, h[3] = {0, 0, 0}, mass = 0.0f;
+    DQ_UNROLL for (int k = 0; k < 2; ++k) {
+        if (k < nin) {
+            const float *cm = k ? com1 : com0, *I6 = k ? I1 : I0;
+            const float ms = k ? ms1 : ms0;
+            const float mk = ms * (k ? m1 : m0);
+            const float cc = dot3(cm, cm);
+            const float Ic[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+            DQ_UNROLL for (int r3 = 0; r3 < 3; ++r3)
+                DQ_UNROLL for (int c3 = 0; c3 < 3; ++c3)
+                    A[3 * r3 + c3] += ms * Ic[3 * r3 + c3] + mk * ((r3 == c3 ? cc : 0.0f) - cm[r3] * cm[c3]);
+            h[0] += mk * cm[0]; h[1] += mk * cm[1]; h[2] += mk * cm[2];
+            mass += mk;
+        }
+    }
+    float T[9], hy[3];
+    dw::m3m(R, A, T);
+    m3v(R, h, hy);
+    const float xx = dot3(x, x), xh = dot3(x, hy);
+    int o = 0;
+    DQ_UNROLL for (int r3 = 0; r3 < 3; ++r3)
+        DQ_UNROLL for (int c3 = r3; c3 < 3; ++c3) {
+            float v = T[3 * r3] * R[3 * c3] + T[3 * r3 + 1] * R[3 * c3 + 1] + T[3 * r3 + 2] * R[3 * c3 + 2];
+            v += (r3 == c3 ? mass * xx + 2.0f * xh : 0.0f) - mass * x[r3] * x[c3] - (x[r3] * hy[c3] + hy[r3] * x[c3]);
+            Ao[o++] = v;
+        }
+    DQ_UNROLL for (int i = 0; i < 3; ++i) ho[i] = hy[i] + mass * x[i];
+    *mass_out = mass;
+}
+DQ_HD float ao(const float *Ao, int r, int c) {      // symmetric 3x3 from 6 words
+    return Ao[r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : (c == 0 ? r : (c == 1 ? 2 + r : 5))];
+}
+// IA += rigid inertia [[Ao, H], [H', m 1]], H = skew(ho);  pA += v x* (I v)
+DQ_HD void add_rigid(float *IA, float *pA, const float *Ao, const float *ho, float mass, const float *v) {
+    DQ_UNROLL for (int r = 0; r < 3; ++r)
+        DQ_UNROLL for (int c = r; c < 3; ++c) IA[sym6(r, c)] += ao(Ao, r, c);
+    IA[sym6(0, 4)] += -ho[2]; IA[sym6(0, 5)] += ho[1];
+    IA[sym6(1, 3)] += ho[2];  IA[sym6(1, 5)] += -ho[0];
+    IA[sym6(2, 3)] += -ho[1]; IA[sym6(2, 4)] += ho[0];
+    IA[sym6(3, 3)] += mass; IA[sym6(4, 4)] += mass; IA[sym6(5, 5)] += mass;
+    const float *om = v, *vl = v + 3;
+    float n[3], f[3], t1[3], t2[3];
+    DQ_UNROLL for (int r = 0; r < 3; ++r) n[r] = ao(Ao, r, 0) * om[0] + ao(Ao, r, 1) * om[1] + ao(Ao, r, 2) * om[2];
+    cross3(ho, vl, t1);
+    n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
+    cross3(om, ho, t1);
+    f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
+    cross3(om, n, t1); cross3(vl, f, t2);
+    pA[0] += t1[0] + t2[0]; pA[1] += t1[1] + t2[1]; pA[2] += t1[2] + t2[2];
+    cross3(om, f, t1);
+    pA[3] += t1[0]; pA[4] += t1[1]; pA[5] += t1[2];
+}
+
+// Closest points a0 + sa da, b0 + sb db of two segments (Ericson, Real-Time Collision Detection 5.1.9), with the quotient of
+// the nearly parallel case blended with the mid-overlap answer (written decision: oracle/dw_physics.c seg_seg).
+DQ_HD void seg_seg(const float *da, const float *db, const float *r, float *so, float *to) {
+    const float aa = dot3(da, da), ee = dot3(db, db), ff = dot3(db, r), eps = 1e-12f;
+    float sa, sb;
+    auto c01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
+    if (aa <= eps && ee <= eps) { sa = 0.0f; sb = 0.0f; }
+    else if (aa <= eps) { sa = 0.0f; sb = c01(ff / ee); }
+    else {
+        const float cc = dot3(da, r);
+        if (ee <= eps) { sb = 0.0f; sa = c01(-cc / aa); }
+        else {
+            const float bbv = dot3(da, db), den = aa * ee - bbv * bbv;
+            float se = den > eps ? c01((bbv * ff - cc * ee) / den) : 0.0f;
+            float te = (bbv * se + ff) / ee;
+            if (te < 0.0f) { te = 0.0f; se = c01(-cc / aa); }
+            else if (te > 1.0f) { te = 1.0f; se = c01((bbv - cc) / aa); }
+            const float t0 = -cc / aa, t1 = t0 + bbv / aa;
+            float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+            if (lo < 0.0f) lo = 0.0f;
+            if (hi > 1.0f) hi = 1.0f;
+            const float sp = c01(0.5f * (lo + hi)), tp = c01((bbv * sp + ff) / ee), reg = 1e-3f * aa * ee;
+            const float w = den > eps ? den * den / (den * den + reg * reg) : 0.0f;
+            sa = w * se + (1.0f - w) * sp;
+            sb = w * te + (1.0f - w) * tp;
+        }
+    }
+    *so = sa; *to = sb;
+}
+
+// Penalty force of two capsules (dw_physics.h K4b).  Returns true and fills F (force on A), pa, pb when they overlap.
+DQ_HD bool capsule_pair(const float *a0, const float *a1, float ra, const float *b0, const float *b1, float rb, const float *va,
+                        const float *vb, const PhysParams &P, float *F, float *pa, float *pb) {
+    const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+    const float mid[3] = {0.5f * (a0[0] + a1[0] - b0[0] - b1[0]), 0.5f * (a0[1] + a1[1] - b0[1] - b1[1]), 0.5f * (a0[2] + a1[2] - b0[2] - b1[2])};
+    const float reach = 0.5f * (sqrtf(dot3(da, da)) + sqrtf(dot3(db, db))) + ra + rb;
+    if (!(dot3(mid, mid) <= reach * reach)) return false;
+    const float r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
+    float sa, sb;
+    seg_seg(da, db, r, &sa, &sb);
+    float n[3];
+    DQ_UNROLL for (int i = 0; i < 3; ++i) { pa[i] = a0[i] + sa * da[i]; pb[i] = b0[i] + sb * db[i]; n[i] = pa[i] - pb[i]; }
+    const float dist = sqrtf(dot3(n, n));
+    const float depth = ra + rb - dist;
+    if (!(depth > 0.0f && dist > 1e-6f)) return false;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) n[i] /= dist;
+    float ta[3], tb[3];
+    cross3(va, pa, ta);
+    cross3(vb, pb, tb);
+    float vn = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) vn += ((va[3 + i] + ta[i]) - (vb[3 + i] + tb[i])) * n[i];
+    float fn = P.pen_k * depth - P.pen_c * vn;
+    if (fn < 0.0f) fn = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) F[i] = fn * n[i];
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The substep.  On entry every body's slot holds quad 0 = {q, qd, tt, dd} with tt = tau - damping * qd and
+// dd = armature + dt * damping (the caller's prologue), X.root the base state, X.warm the warm-start impulses.
+// On exit: slot quad 0 = {q, qd, *, *} of the new state, X.root, X.warm updated; with `last`, the net contact forces of
+// the substep are written to B.contact_forces.  push: world x/y force on the base COM.
+// ------------------------------------------------------------------------------------------------
+template <bool TERRAIN>
+DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const PhysParams &P, QLane &X, const DwBuffers &B,
+                        float push_x, float push_y, bool last) {
+    const float dt = P.dt;
+    const int j = X.j, T = QM.nsteps;
+    const int e = X.env;
+
+    // ---- base kinematics (every lane of the quad, redundantly) ----
+    float qn[4], R0[9], ww[3], vo[3];
+    {
+        const float qx = X.root[3], qy = X.root[4], qz = X.root[5], qw = X.root[6];
+        const float n = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+        qn[0] = qx / n; qn[1] = qy / n; qn[2] = qz / n; qn[3] = qw / n;
+        quat_to_mat(qn, R0);
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { ww[i] = X.root[10 + i]; vo[i] = X.root[7 + i]; }
+        if (P.vel_at_com) {
+            float rc[3], t[3];
+            m3v(R0, QM.base_com, rc);
+            cross3(ww, rc, t);
+            vo[0] -= t[0]; vo[1] -= t[1]; vo[2] -= t[2];
+        }
+    }
+
+    // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist. ----
+    float footR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, footx[3] = {0, 0, 0};      // pose of my sole body (lanes 0, 1)
+    {
+        float qr[4] = {0, 0, 0, 1}, Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xr_[3] = {0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < T; ++s) {
+            const QFkRec &rc = QM.fk[s][j];
+            const int b = rc.body, psrc = rc.psrc;
+            // limbs that start below another lane's body fetch that lane's running state (still in its registers)
+            float fq[4], fx[3], fv[6];
+            bool fetched = false;
+            const int fm = fetch_mask(QM, s);
+            if (fm) {
+                for (int xl = 0; xl < 4; ++xl)
+                    if ((fm >> xl) & 1) {
+                        float tq[4], tx[3], tv[6];
+                        quad_bcast_arr(xl, qr, tq); quad_bcast_arr(xl, xr_, tx); quad_bcast_arr(xl, vr, tv);
+                        if (b >= 0 && psrc == 2 + xl) {
+                            fetched = true;
+                            DQ_UNROLL for (int i = 0; i < 4; ++i) fq[i] = tq[i];
+                            DQ_UNROLL for (int i = 0; i < 3; ++i) fx[i] = tx[i];
+                            DQ_UNROLL for (int i = 0; i < 6; ++i) fv[i] = tv[i];
+                        }
+                    }
+            }
+            if (b >= 0) {
+                if (psrc == 1) {
+                    DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = qn[i];
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0[i];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = 0.0f; vr[i] = ww[i]; vr[3 + i] = vo[i]; }
+                } else if (fetched) {
+                    DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fq[i];
+                    quat_to_mat(qr, Rr);
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) xr_[i] = fx[i];
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
+                }
+                const F4 in = DQ_SLOT(b, 0, X.pos);            // {q, qd, tt, dd}
+                float sn, cs;
+                sincosf(0.5f * in.x, &sn, &cs);
+                float qj[4] = {rc.axis[0] * sn, rc.axis[1] * sn, rc.axis[2] * sn, cs};
+                if (rc.flags & 1) qmul(rc.q0, qj, qj);
+                float x[3], t[3];
+                m3v(Rr, rc.pos, t);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) x[i] = xr_[i] + t[i];
+                qmul(qr, qj, qr);
+                quat_to_mat(qr, Rr);
+                float aw[3], sl[3];
+                m3v(Rr, rc.axis, aw);
+                cross3(x, aw, sl);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { vr[i] += aw[i] * in.y; vr[3 + i] += sl[i] * in.y; xr_[i] = x[i]; }
+                DQ_SLOT(b, 0, X.pos) = mk4(qr[0], qr[1], qr[2], qr[3]);
+                DQ_SLOT(b, 1, X.pos) = mk4(x[0], x[1], x[2], in.y);
+                DQ_SLOT(b, 2, X.pos) = mk4(vr[0], vr[1], vr[2], in.z);
+                DQ_SLOT(b, 3, X.pos) = mk4(vr[3], vr[4], vr[5], in.w);
+                if (rc.flags & 2) {
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) footR[i] = Rr[i];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) footx[i] = x[i];
+                }
+                const int scm = rc.flags >> 8;
+                if (scm) {
+                    for (int p = 0; p < 8; ++p)
+                        if ((scm >> p) & 1) {
+                            float p0[3], p1[3];
+                            m3v(Rr, QM.proxy_p0[p], p0);
+                            m3v(Rr, QM.proxy_p1[p], p1);
+                            L.prox[2 * p][X.el] = mk4(x[0] + p0[0], x[1] + p0[1], x[2] + p0[2], 0.0f);
+                            L.prox[2 * p + 1][X.el] = mk4(x[0] + p1[0], x[1] + p1[1], x[2] + p1[2], 0.0f);
+                        }
+                }
+            }
+        }
+    }
+    wave_sync();
+
+    // ---- self-collision (leg against leg): lane a tests left proxy a against the right-leg proxies.  The common case is
+    //      "nothing touches": then the only cost is the distance tests.  If any env of the wave has a touching pair, the
+    //      two leg lanes of every env recompute all pairs and keep the wrenches on their own bodies. ----
+    bool sc_any = false;
+    float scW[4][6], scF[4][3];
+    DQ_UNROLL for (int p = 0; p < 4; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) scF[p][i] = 0.0f; }
+    if (P.self_collision && QM.nproxy_l > 0) {
+        bool hit = false;
+        if (j < QM.nproxy_l) {
+            const F4 a0 = L.prox[2 * j][X.el], a1 = L.prox[2 * j + 1][X.el];
+            const float A0[3] = {a0.x, a0.y, a0.z}, A1[3] = {a1.x, a1.y, a1.z};
+            const float da[3] = {A1[0] - A0[0], A1[1] - A0[1], A1[2] - A0[2]};
+            for (int pb = 0; pb < QM.nproxy_r; ++pb) {
+                const F4 b0 = L.prox[2 * (4 + pb)][X.el], b1 = L.prox[2 * (4 + pb) + 1][X.el];
+                const float B0[3] = {b0.x, b0.y, b0.z}, B1[3] = {b1.x, b1.y, b1.z};
+                // squared distance of the two segments against (ra + rb)^2
+                const float db[3] = {B1[0] - B0[0], B1[1] - B0[1], B1[2] - B0[2]};
+                const float r[3] = {A0[0] - B0[0], A0[1] - B0[1], A0[2] - B0[2]};
+                float sa, sb;
+                seg_seg(da, db, r, &sa, &sb);
+                float d2 = 0.0f;
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { const float n = (A0[i] + sa * da[i]) - (B0[i] + sb * db[i]); d2 += n * n; }
+                const float rr = QM.proxy_r[j] + QM.proxy_r[4 + pb] + 1e-4f;       // margin: the exact test follows
+                hit = hit || (d2 < rr * rr);
+            }
+        }
+        sc_any = wave_any(hit);
+        if (sc_any && j < 2) {
+            // my side: j = 0 left (force on A), j = 1 right (force on B = -F)
+            for (int pa = 0; pa < QM.nproxy_l; ++pa) {
+                const int ba = QM.proxy_body[pa];
+                const int posa = (X.el + 4 * QM.owner[ba]) & 15;
+                const F4 a0 = L.prox[2 * pa][X.el], a1 = L.prox[2 * pa + 1][X.el];
+                const F4 va2 = DQ_SLOT(ba, 2, posa), va3 = DQ_SLOT(ba, 3, posa);
+                const float A0[3] = {a0.x, a0.y, a0.z}, A1[3] = {a1.x, a1.y, a1.z}, va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z};
+                for (int pb = 0; pb < QM.nproxy_r; ++pb) {
+                    const int bb = QM.proxy_body[4 + pb];
+                    const int posb = (X.el + 4 * QM.owner[bb]) & 15;
+                    const F4 b0 = L.prox[2 * (4 + pb)][X.el], b1 = L.prox[2 * (4 + pb) + 1][X.el];
+                    const F4 vb2 = DQ_SLOT(bb, 2, posb), vb3 = DQ_SLOT(bb, 3, posb);
+                    const float B0[3] = {b0.x, b0.y, b0.z}, B1[3] = {b1.x, b1.y, b1.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
+                    float F[3], ca[3], cb[3];
+                    if (capsule_pair(A0, A1, QM.proxy_r[pa], B0, B1, QM.proxy_r[4 + pb], va, vb, P, F, ca, cb)) {
+                        const int mine = j == 0 ? pa : pb;
+                        const float sg = j == 0 ? 1.0f : -1.0f;
+                        const float Fs[3] = {sg * F[0], sg * F[1], sg * F[2]};
+                        float nb[3];
+                        cross3(j == 0 ? ca : cb, Fs, nb);
+                        DQ_UNROLL for (int p = 0; p < 4; ++p)
+                            if (p == mine) {
+                                DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[p][i] += nb[i]; scW[p][3 + i] += Fs[i]; scF[p][i] += Fs[i]; }
+                            }
+                    }
+                }
+            }
+        }
+    }
+
+    wave_sync();      // the leg lanes read each other's slots above; the inward pass below overwrites them
+
+    // ---- inward pass: articulated inertias and bias forces, in reverse schedule order ----
+    float IA[21], pA[6], IP[21], pP[6];          // running and parked reflected inertia / bias
+    DQ_UNROLL for (int i = 0; i < 21; ++i) { IA[i] = 0.0f; IP[i] = 0.0f; }
+    DQ_UNROLL for (int i = 0; i < 6; ++i) { pA[i] = 0.0f; pP[i] = 0.0f; }
+    X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
+    const int my_sole_gym = (j == 0) ? M.left_foot_gym : (j == 1 ? M.right_foot_gym : -1);
+    for (int s = 0; s < T; ++s) {
+        const QInRec &rc = QM.in[s][j];
+        const int b = rc.body;
+        const int flags = b >= 0 ? rc.flags : 0;
+        if (flags & 2) {                    // a finished chain is still waiting for its parent: park it
+            DQ_UNROLL for (int i = 0; i < 21; ++i) IP[i] = IA[i];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) pP[i] = pA[i];
+        }
+        if (flags & 1) {
+            DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
+            DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
+        }
+        // gathers (wave-uniform per step): child chains that ended on other lanes
+        {
+            const int g0 = QM.in[s][0].body >= 0 ? QM.in[s][0].gather : 0, g1 = QM.in[s][1].body >= 0 ? QM.in[s][1].gather : 0;
+            const int g2 = QM.in[s][2].body >= 0 ? QM.in[s][2].gather : 0, g3 = QM.in[s][3].body >= 0 ? QM.in[s][3].gather : 0;
+            if (g0 | g1 | g2 | g3) {
+                const int mine = b >= 0 ? rc.gather : 0;
+                DQ_UNROLL for (int src = 0; src < 4; ++src)
+                    DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
+                        const int code = src | (pk << 2) | 8;
+                        bool used = false, want = false;
+                        DQ_UNROLL for (int k = 0; k < 3; ++k) {
+                            used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
+                                   (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
+                            want = want || (((mine >> (4 * k)) & 15) == code);
+                        }
+                        if (used) {
+                            DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                                const float v = pk ? IP[i] : IA[i];
+                                const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                                if (want) IA[i] += t;
+                            }
+                            DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                                const float v = pk ? pP[i] : pA[i];
+                                const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                                if (want) pA[i] += t;
+                            }
+                        }
+                    }
+            }
+        }
+        if (b >= 0) {
+            const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+            const float ms0 = B.mass_scale[(size_t)DW_NUM_BODIES * e + rc.in0_gym];
+            const float ms1 = rc.nin > 1 ? B.mass_scale[(size_t)DW_NUM_BODIES * e + rc.in1_gym] : 0.0f;
+            const float qb[4] = {s0.x, s0.y, s0.z, s0.w}, x[3] = {s1.x, s1.y, s1.z}, v[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+            const float qd = s1.w, tt = s2.w, dd = s3.w;
+            float R[9];
+            quat_to_mat(qb, R);
+            float S[6];
+            m3v(R, rc.axis, S);
+            cross3(x, S, S + 3);
+            // rigid inertia, gyroscopic bias
+            float Ao[6], ho[3], mass;
+            rigid_inertia(rc.nin, rc.in0_com, rc.in0_mass, rc.in0_I, ms0, rc.in1_com, rc.in1_mass, rc.in1_I, ms1, R, x, Ao, ho, &mass);
+            add_rigid(IA, pA, Ao, ho, mass, v);
+            // external forces: ground penalty of the non-sole primitives, self-collision; per Gym body for the report
+            float cf[QMAX_GYM][3];
+            DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
+            bool near_ground = rc.ngeom > 0 && (X.root[2] + x[2] < rc.bound);
+            if (TERRAIN) near_ground = rc.ngeom > 0;
+            if (near_ground) {
+                for (int k = 0; k < rc.ngeom; ++k) {
+                    float F[3], xr[3];
+                    geom_force<TERRAIN>(M.geoms[rc.geom[k]], P, R, x, v, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
+                    if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                        float nb[3];
+                        cross3(xr, F, nb);
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) { pA[i] -= nb[i]; pA[3 + i] -= F[i]; }
+                        const int t = (rc.geom_slot >> (2 * k)) & 3;
+                        DQ_UNROLL for (int tt2 = 0; tt2 < QMAX_GYM; ++tt2)
+                            if (tt2 == t) { cf[tt2][0] += F[0]; cf[tt2][1] += F[1]; cf[tt2][2] += F[2]; }
+                    }
+                }
+            }
+            if (sc_any && rc.sc_mask && j < 2) {
+                DQ_UNROLL for (int p = 0; p < 4; ++p)
+                    if ((rc.sc_mask >> (p + 4 * j)) & 1) {
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
+                        const int gy = QM.proxy_gym[p + 4 * j];
+                        DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
+                            if (t < rc.ngym && rc.gyms[t] == gy) { cf[t][0] += scF[p][0]; cf[t][1] += scF[p][1]; cf[t][2] += scF[p][2]; }
+                    }
+            }
+            if (last) {
+                DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
+                    if (t < rc.ngym) {
+                        if (rc.gyms[t] == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
+                        else if (X.valid) {
+                            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + rc.gyms[t]) * 3;
+                            dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
+                        }
+                    }
+            }
+            // articulated-body step
+            float U[6];
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                float acc = 0.0f;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * S[c];
+                U[r] = acc;
+            }
+            const float D = dot6(S, U) + dd;
+            const float Dinv = dw::rcp_nr(D);
+            const float u = tt - dot6(S, pA);
+            float m[6], cb[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = S[i] * qd;
+            dw::motion_cross(v, m, cb);
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                const float urd = U[r] * Dinv;
+                DQ_UNROLL for (int c = r; c < 6; ++c) IA[sym6(r, c)] -= urd * U[c];
+            }
+            const float ud = u * Dinv;
+            float pa[6];
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                float acc = pA[r] + U[r] * ud;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * cb[c];
+                pa[r] = acc;
+            }
+            DQ_UNROLL for (int r = 0; r < 6; ++r) pA[r] = pa[r];
+            DQ_SLOT(b, 0, X.pos) = mk4(S[0], S[1], S[2], Dinv);
+            DQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], u);
+            DQ_SLOT(b, 2, X.pos) = mk4(U[0], U[1], U[2], qd);
+            DQ_SLOT(b, 3, X.pos) = mk4(U[3], U[4], U[5], 0.0f);
+        }
+    }
+
+    // ---- base: gather the chains below the root, own inertia, external forces, inverse ----
+    float Minv[36], a0[6];
+    {
+        float I0[21], p0[6];
+        DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = 0.0f;
+        DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = 0.0f;
+        const int g = QM.base_gather;
+        DQ_UNROLL for (int src = 0; src < 4; ++src)
+            DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
+                const int code = src | (pk << 2) | 8;
+                const bool used = ((g & 15) == code) || (((g >> 4) & 15) == code) || (((g >> 8) & 15) == code) || (((g >> 12) & 15) == code);
+                if (used) {
+                    DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                        const float v = pk ? IP[i] : IA[i];
+                        I0[i] += src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                    }
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                        const float v = pk ? pP[i] : pA[i];
+                        p0[i] += src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                    }
+                }
+            }
+        const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
+        float Ao[6], ho[3], mass;
+        const float ms = B.mass_scale[(size_t)DW_NUM_BODIES * e + QM.base_gym];
+        rigid_inertia(1, QM.base_com, QM.base_mass, QM.base_I, ms, QM.base_com, 0.0f, QM.base_I, 0.0f, R0, x0, Ao, ho, &mass);
+        add_rigid(I0, p0, Ao, ho, mass, v0);
+        float cfb[3] = {0, 0, 0};
+        bool near_ground = QM.base_ngeom > 0 && (X.root[2] < QM.base_bound);
+        if (TERRAIN) near_ground = QM.base_ngeom > 0;
+        if (near_ground) {
+            for (int k = 0; k < QM.base_ngeom; ++k) {
+                float F[3], xr[3];
+                geom_force<TERRAIN>(M.geoms[QM.base_geom[k]], P, R0, x0, v0, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
+                if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                    float nb[3];
+                    cross3(xr, F, nb);
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { p0[i] -= nb[i]; p0[3 + i] -= F[i]; cfb[i] += F[i]; }
+                }
+            }
+        }
+        if (last && j == 3 && X.valid) {
+            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + QM.base_gym) * 3;
+            dst[0] = cfb[0]; dst[1] = cfb[1]; dst[2] = cfb[2];
+        }
+        {   // push on the base COM
+            const float Fw[3] = {push_x, push_y, 0.0f};
+            float xc[3], nb[3];
+            m3v(R0, QM.base_com, xc);
+            cross3(xc, Fw, nb);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { p0[i] -= nb[i]; p0[3 + i] -= Fw[i]; }
+        }
+        // Cholesky I0 = L L', Minv by six pairs of triangular solves (dw_physics.h A3)
+        float Lc[36], dinv[6];
+        DQ_UNROLL for (int i = 0; i < 36; ++i) Lc[i] = 0.0f;
+        DQ_UNROLL for (int c = 0; c < 6; ++c) {
+            float d = I0[sym6(c, c)];
+            DQ_UNROLL for (int k = 0; k < c; ++k) d -= Lc[6 * c + k] * Lc[6 * c + k];
+            dinv[c] = dw::rsqrt_nr(d);
+            Lc[6 * c + c] = d * dinv[c];
+            DQ_UNROLL for (int i = c + 1; i < 6; ++i) {
+                float sacc = I0[sym6(i, c)];
+                DQ_UNROLL for (int k = 0; k < c; ++k) sacc -= Lc[6 * i + k] * Lc[6 * c + k];
+                Lc[6 * i + c] = sacc * dinv[c];
+            }
+        }
+        DQ_UNROLL for (int col = 0; col < 6; ++col) {
+            float y[6], xx[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                float sacc = (i == col) ? 1.0f : 0.0f;
+                DQ_UNROLL for (int k = 0; k < i; ++k) sacc -= Lc[6 * i + k] * y[k];
+                y[i] = sacc * dinv[i];
+            }
+            DQ_UNROLL for (int i = 5; i >= 0; --i) {
+                float sacc = y[i];
+                DQ_UNROLL for (int k = i + 1; k < 6; ++k) sacc -= Lc[6 * k + i] * xx[k];
+                xx[i] = sacc * dinv[i];
+            }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) Minv[6 * i + col] = xx[i];
+        }
+        DQ_UNROLL for (int r = 0; r < 6; ++r) {
+            float acc = 0.0f;
+            DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[6 * r + c] * p0[c];
+            a0[r] = acc;
+        }
+    }
+
+    // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot ----
+    {
+        float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < T; ++s) {
+            const QFkRec &rc = QM.fk[s][j];
+            const int b = rc.body, psrc = rc.psrc;
+            float fa[6], fv[6];
+            bool fetched = false;
+            const int fm = fetch_mask(QM, s);
+            if (fm) {
+                for (int xl = 0; xl < 4; ++xl)
+                    if ((fm >> xl) & 1) {
+                        float ta[6], tv[6];
+                        quad_bcast_arr(xl, ar, ta); quad_bcast_arr(xl, vr, tv);
+                        if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) { fa[i] = ta[i]; fv[i] = tv[i]; } }
+                    }
+            }
+            if (b >= 0) {
+                if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = a0[i]; ar[3 + i] = a0[3 + i]; vr[i] = ww[i]; vr[3 + i] = vo[i]; } }
+                else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] = fa[i]; vr[i] = fv[i]; } }
+                const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                const float Dinv = s0.w, u = s1.w, qd = s2.w;
+                float m[6], c[6];
+                DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = S[i] * qd;
+                dw::motion_cross(vr, m, c);                  // parent twist x S qd  (= body twist x S qd)
+                DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] += c[i]; vr[i] += m[i]; }
+                const float qdd = (u - dot6(U, ar)) * Dinv;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * qdd;
+                DQ_SLOT(b, 2, X.pos) = mk4(U[0], U[1], U[2], qd + dt * qdd);      // free velocity
+                DQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], 0.0f);                // u is dead: the word becomes the impulse-sweep d
+            }
+        }
+    }
+    wave_sync();
+
+    // ---- free base velocity; sole-corner gaps of my foot (foot f = j & 1; lanes f and f + 2 work on it together) ----
+    float wwf[3], vowf[3];
+    {
+        float t2[3];
+        cross3(ww, vo, t2);
+        DQ_UNROLL for (int i = 0; i < 3; ++i) {
+            wwf[i] = ww[i] + dt * a0[i];
+            vowf[i] = vo[i] + dt * (a0[3 + i] + t2[i] + P.g[i]);
+        }
+    }
+    const int f = j & 1, part = j >> 1;
+    float rk[4][3], vminr[4], frame[4][9];
+    int act[4];
+    {
+        // the pose of foot f lives in lane f: lanes 2, 3 fetch it from their partner (l ^ 2)
+        float fR[9], fx[3];
+        DQ_UNROLL for (int i = 0; i < 9; ++i) { const float o = quad_xor2(footR[i]); fR[i] = part ? o : footR[i]; }
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = quad_xor2(footx[i]); fx[i] = part ? o : footx[i]; }
+        DQ_UNROLL for (int k = 0; k < 4; ++k) {
+            float r[3];
+            m3v(fR, M.foot_pos[4 * f + k], r);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) r[i] += fx[i];
+            float phi = X.root[2] + r[2];
+            if (TERRAIN) {
+                float hh;
+                dw::terrain_sample(P, X.root[0] + r[0], X.root[1] + r[1], &hh, frame[k]);
+                phi = (phi - hh) * frame[k][8];
+            } else {
+                DQ_UNROLL for (int i = 0; i < 9; ++i) frame[k][i] = (i % 4 == 0) ? 1.0f : 0.0f;
+            }
+            act[k] = phi < P.contact_offset;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) rk[k][i] = r[i];
+            vminr[k] = phi >= 0 ? -phi / dt : fminf(P.erp * (-phi) / dt, P.max_depen);
+        }
+    }
+    const bool any_active = wave_any(act[0] | act[1] | act[2] | act[3]);
+    float dqb[6] = {0, 0, 0, 0, 0, 0};              // base velocity jump
+    float Pk[4][3];
+    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) Pk[k][i] = act[k] ? X.warm[3 * k + i] : 0.0f;
+
+    if (any_active) {
+        // ---- free twist of foot f: base + sum over the leg of S qdf (leg lane), shared with the partner ----
+        float twf[6];
+        {
+            float acc[6] = {wwf[0], wwf[1], wwf[2], vowf[0], vowf[1], vowf[2]};
+            const int posf = (X.el + 4 * f) & 15;
+            DQ_UNROLL for (int i = 1; i <= 6; ++i) {
+                const int b = 6 * f + i;
+                const F4 s0 = DQ_SLOT(b, 0, posf), s1 = DQ_SLOT(b, 1, posf), s2 = DQ_SLOT(b, 2, posf);
+                acc[0] += s0.x * s2.w; acc[1] += s0.y * s2.w; acc[2] += s0.z * s2.w;
+                acc[3] += s1.x * s2.w; acc[4] += s1.y * s2.w; acc[5] += s1.z * s2.w;
+            }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) twf[i] = acc[i];
+        }
+        // ---- my 3 rows of W: responses of both feet to unit wrenches (components 3 part .. 3 part + 2) on foot f.
+        //      Up the leg: d = -S'p, p += U d / D;  base: dv = -Minv p;  down both legs: qdd = (d - U'dv) / D, dv += S qdd ----
+        float Wr[3][12];
+        {
+            float dp[3][6], dc[3][6];
+            DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int i = 0; i < 6; ++i) dp[c][i] = (i == 3 * part + c) ? -1.0f : 0.0f;
+            const int posf = (X.el + 4 * f) & 15;
+            DQ_UNROLL for (int i = 6; i >= 1; --i) {
+                const int b = 6 * f + i;
+                const F4 s0 = DQ_SLOT(b, 0, posf), s1 = DQ_SLOT(b, 1, posf), s2 = DQ_SLOT(b, 2, posf), s3 = DQ_SLOT(b, 3, posf);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float d = -dot6(S, dp[c]);
+                    dc[c][i - 1] = d;
+                    const float k = d * s0.w;
+                    DQ_UNROLL for (int r = 0; r < 6; ++r) dp[c][r] += U[r] * k;
+                }
+            }
+            float dv0[3][6];
+            DQ_UNROLL for (int c = 0; c < 3; ++c)
+                DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                    float acc = 0.0f;
+                    DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[6 * r + k] * dp[c][k];
+                    dv0[c][r] = acc;
+                }
+            DQ_UNROLL for (int g = 0; g < 2; ++g) {
+                float dv[3][6];
+                DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) dv[c][r] = dv0[c][r];
+                const int posg = (X.el + 4 * g) & 15;
+                DQ_UNROLL for (int i = 1; i <= 6; ++i) {
+                    const int b = 6 * g + i;
+                    const F4 s0 = DQ_SLOT(b, 0, posg), s1 = DQ_SLOT(b, 1, posg), s2 = DQ_SLOT(b, 2, posg), s3 = DQ_SLOT(b, 3, posg);
+                    const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                        const float ua = dot6(U, dv[c]);
+                        const float qdd = ((g == f ? dc[c][i - 1] : 0.0f) - ua) * s0.w;
+                        DQ_UNROLL for (int r = 0; r < 6; ++r) dv[c][r] += S[r] * qdd;
+                    }
+                }
+                DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) Wr[c][6 * g + r] = dv[c][r];
+            }
+        }
+        // ---- 3x3 diagonal blocks of the Delassus matrix of my foot's corners: A_kk = J_k W_ff J_k' (frame-projected on
+        //      terrain); what the solver needs of them: the three diagonal inverses and the couplings zx, zy, xy ----
+        float invd[4][3], cpl[4][3];
+        {
+            float Wff[6][6];       // rows 3 part.. are mine, the other three come from the partner lane (l ^ 2)
+            DQ_UNROLL for (int r = 0; r < 3; ++r)
+                DQ_UNROLL for (int c = 0; c < 6; ++c) {
+                    const float mine = Wr[r][6 * f + c];
+                    const float o = quad_xor2(mine);
+                    Wff[r][c] = part ? o : mine;
+                    Wff[3 + r][c] = part ? mine : o;
+                }
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                const float *r = rk[k];
+                float G[3][6];        // J_k W_ff, world axes: row a = W_lin row a + (-skew(r)) row a . W_ang
+                DQ_UNROLL for (int c = 0; c < 6; ++c) {
+                    G[0][c] = Wff[3][c] + r[2] * Wff[1][c] - r[1] * Wff[2][c];
+                    G[1][c] = Wff[4][c] - r[2] * Wff[0][c] + r[0] * Wff[2][c];
+                    G[2][c] = Wff[5][c] + r[1] * Wff[0][c] - r[0] * Wff[1][c];
+                }
+                float Ak[3][3];       // G J_k': column b = G_lin col b + G_ang . (-skew(r)) row b
+                DQ_UNROLL for (int a = 0; a < 3; ++a) {
+                    Ak[a][0] = G[a][3] + r[2] * G[a][1] - r[1] * G[a][2];
+                    Ak[a][1] = G[a][4] - r[2] * G[a][0] + r[0] * G[a][2];
+                    Ak[a][2] = G[a][5] + r[1] * G[a][0] - r[0] * G[a][1];
+                }
+                if (TERRAIN) {        // rows / columns along the corner's frame (t1, t2, n)
+                    float Tm[3][3];
+                    DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
+                        Tm[a][c] = frame[k][3 * a] * Ak[0][c] + frame[k][3 * a + 1] * Ak[1][c] + frame[k][3 * a + 2] * Ak[2][c];
+                    DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
+                        Ak[a][c] = Tm[a][0] * frame[k][3 * c] + Tm[a][1] * frame[k][3 * c + 1] + Tm[a][2] * frame[k][3 * c + 2];
+                }
+                const float reg = 1.0f + P.cfm;
+                invd[k][0] = act[k] ? 1.0f / (Ak[0][0] * reg) : 0.0f;
+                invd[k][1] = act[k] ? 1.0f / (Ak[1][1] * reg) : 0.0f;
+                invd[k][2] = act[k] ? 1.0f / (Ak[2][2] * reg) : 0.0f;
+                cpl[k][0] = Ak[0][2];     // x row, z column
+                cpl[k][1] = Ak[1][2];     // y row, z column
+                cpl[k][2] = Ak[1][0];     // y row, x column
+            }
+        }
+        // ---- start: tw = tw_free + W lambda0, lambda0 = warm-start impulses as foot wrenches ----
+        float tw3[3];
+        {
+            float lam[6] = {0, 0, 0, 0, 0, 0};
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                float pw[3] = {Pk[k][0], Pk[k][1], Pk[k][2]};
+                if (TERRAIN) {
+                    const float p0 = pw[0], p1 = pw[1], p2 = pw[2];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) pw[i] = p0 * frame[k][i] + p1 * frame[k][3 + i] + p2 * frame[k][6 + i];
+                }
+                float t[3];
+                cross3(rk[k], pw, t);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { lam[i] += t[i]; lam[3 + i] += pw[i]; }
+            }
+            float lo[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
+            DQ_UNROLL for (int r = 0; r < 3; ++r) {
+                float acc = twf[3 * part + r];
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wr[r][6 * f + c] * lam[c] + Wr[r][6 * (1 - f) + c] * lo[c];
+                tw3[r] = acc;
+            }
+        }
+        // ---- projected Gauss-Seidel, block-Jacobi across the feet: corner kk of the left sole and corner kk of the right
+        //      sole are updated together from the same snapshot, the four corners of a sole one after the other ----
+        bool pair_on[4];
+        DQ_UNROLL for (int kk = 0; kk < 4; ++kk) pair_on[kk] = wave_any(act[kk] != 0);
+        for (int it = 0; it < P.iters; ++it) {
+            DQ_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                if (pair_on[kk]) {
+                    float o3[3];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) o3[i] = quad_xor2(tw3[i]);
+                    const float *wv = part ? o3 : tw3, *lv = part ? tw3 : o3;
+                    const float *r = rk[kk];
+                    float vwld[3] = {lv[0] + wv[1] * r[2] - wv[2] * r[1], lv[1] + wv[2] * r[0] - wv[0] * r[2], lv[2] + wv[0] * r[1] - wv[1] * r[0]};
+                    float vx0 = vwld[0], vy0 = vwld[1], vz = vwld[2];
+                    if (TERRAIN) {
+                        const float *fr = frame[kk];
+                        vx0 = fr[0] * vwld[0] + fr[1] * vwld[1] + fr[2] * vwld[2];
+                        vy0 = fr[3] * vwld[0] + fr[4] * vwld[1] + fr[5] * vwld[2];
+                        vz = fr[6] * vwld[0] + fr[7] * vwld[1] + fr[8] * vwld[2];
+                    }
+                    const float Px = Pk[kk][0], Py = Pk[kk][1], Pz = Pk[kk][2];
+                    float dz = -(vz - vminr[kk]) * invd[kk][2];
+                    float pz = Pz + dz;
+                    if (pz < 0) pz = 0;
+                    dz = pz - Pz;
+                    const float vx = vx0 + cpl[kk][0] * dz;
+                    const float dx = -vx * invd[kk][0];
+                    const float vy = vy0 + cpl[kk][1] * dz + cpl[kk][2] * dx;
+                    const float dy = -vy * invd[kk][1];
+                    float px = Px + dx, py = Py + dy;
+                    const float lim = X.mu * pz, n2 = px * px + py * py;
+                    if (n2 > lim * lim) {
+                        const float sc = lim * dw::rsqrt_nr(n2);
+                        px *= sc; py *= sc;
+                    }
+                    float d[3] = {px - Px, py - Py, dz};
+                    Pk[kk][0] = px; Pk[kk][1] = py; Pk[kk][2] = pz;
+                    if (TERRAIN) {
+                        const float *fr = frame[kk];
+                        const float d0 = d[0], d1 = d[1], d2 = d[2];
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) d[i] = d0 * fr[i] + d1 * fr[3 + i] + d2 * fr[6 + i];
+                    }
+                    float lam[6], lo[6];
+                    cross3(r, d, lam);
+                    lam[3] = d[0]; lam[4] = d[1]; lam[5] = d[2];
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
+                    DQ_UNROLL for (int rr = 0; rr < 3; ++rr) {
+                        float acc = tw3[rr];
+                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wr[rr][6 * f + c] * lam[c] + Wr[rr][6 * (1 - f) + c] * lo[c];
+                        tw3[rr] = acc;
+                    }
+                }
+            }
+        }
+        // ---- impulses -> wrench on my foot -> up my leg (leg lanes), base jump ----
+        float dpb[6] = {0, 0, 0, 0, 0, 0};
+        float Fs[3] = {0, 0, 0};
+        if (part == 0) {
+            float Nm[3] = {0, 0, 0};
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                float pw[3] = {Pk[k][0], Pk[k][1], Pk[k][2]};
+                if (TERRAIN) {
+                    const float p0 = pw[0], p1 = pw[1], p2 = pw[2];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) pw[i] = p0 * frame[k][i] + p1 * frame[k][3 + i] + p2 * frame[k][6 + i];
+                }
+                float t[3];
+                cross3(rk[k], pw, t);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { Fs[i] += pw[i]; Nm[i] += t[i]; }
+            }
+            float dp[6] = {-Nm[0], -Nm[1], -Nm[2], -Fs[0], -Fs[1], -Fs[2]};
+            DQ_UNROLL for (int i = 6; i >= 1; --i) {
+                const int b = 6 * f + i;
+                const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                const float d = -dot6(S, dp);
+                const float k = d * s0.w;
+                DQ_UNROLL for (int r = 0; r < 6; ++r) dp[r] += U[r] * k;
+                DQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], d);
+            }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) dpb[i] = dp[i];
+        }
+        {
+            float tot[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                const float a = quad_bcast<0>(dpb[i]), b2 = quad_bcast<1>(dpb[i]);
+                tot[i] = a + b2;
+            }
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                float acc = 0.0f;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[6 * r + c] * tot[c];
+                dqb[r] = acc;
+            }
+        }
+        if (last && part == 0 && X.valid) {
+            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+            dst[0] = X.footF[0] + Fs[0] / dt; dst[1] = X.footF[1] + Fs[1] / dt; dst[2] = X.footF[2] + Fs[2] / dt;
+        }
+    } else if (last && part == 0 && X.valid) {
+        float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+        dst[0] = X.footF[0]; dst[1] = X.footF[1]; dst[2] = X.footF[2];
+    }
+    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) X.warm[3 * k + i] = Pk[k][i];
+
+    // ---- outward pass 3: velocity jumps down the tree, final joint velocities, limits, semi-implicit Euler ----
+    {
+        float ar[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < T; ++s) {
+            const QFkRec &rc = QM.fk[s][j];
+            const int b = rc.body, psrc = rc.psrc;
+            float fa[6];
+            bool fetched = false;
+            const int fm = fetch_mask(QM, s);
+            if (fm) {
+                for (int xl = 0; xl < 4; ++xl)
+                    if ((fm >> xl) & 1) {
+                        float ta[6];
+                        quad_bcast_arr(xl, ar, ta);
+                        if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) fa[i] = ta[i]; }
+                    }
+            }
+            if (b >= 0) {
+                if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = dqb[i]; }
+                else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fa[i]; }
+                const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                const float dq = (s1.w - dot6(U, ar)) * s0.w;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * dq;
+                float qd = s2.w + dq;
+                if (qd > rc.vmax) qd = rc.vmax;
+                if (qd < -rc.vmax) qd = -rc.vmax;
+                float q = B.dof_state[((size_t)ND * e + (b - 1)) * 2] ;
+                q = q + dt * qd;
+                if (q < rc.qlo) { q = rc.qlo; if (qd < 0) qd = 0; }
+                if (q > rc.qhi) { q = rc.qhi; if (qd > 0) qd = 0; }
+                DQ_SLOT(b, 0, X.pos) = mk4(q, qd, 0.0f, 0.0f);
+                if (X.valid) {
+                    B.dof_state[((size_t)ND * e + (b - 1)) * 2] = q;
+                    B.dof_state[((size_t)ND * e + (b - 1)) * 2 + 1] = qd;
+                }
+            }
+        }
+    }
+    // ---- base: final velocity, clamps, pose update (dw_physics.h V2) ----
+    {
+        float wwn[3], von[3];
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { wwn[i] = wwf[i] + dqb[i]; von[i] = vowf[i] + dqb[3 + i]; }
+        const float wn2 = dot3(wwn, wwn);
+        if (wn2 > P.max_ang_vel * P.max_ang_vel) {
+            const float sc = P.max_ang_vel * dw::rsqrt_nr(wn2);
+            wwn[0] *= sc; wwn[1] *= sc; wwn[2] *= sc;
+        }
+        X.root[0] += dt * von[0]; X.root[1] += dt * von[1]; X.root[2] += dt * von[2];
+        const float w2 = dot3(wwn, wwn);
+        const float hx = 0.5f * dt;
+        const float x2 = w2 * hx * hx;
+        const float sh = hx * (1.0f + x2 * (-1.0f / 6 + x2 * (1.0f / 120 + x2 * (-1.0f / 5040 + x2 * (1.0f / 362880)))));
+        const float ch = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24 + x2 * (-1.0f / 720 + x2 * (1.0f / 40320))));
+        const float x1 = wwn[0] * sh, y1 = wwn[1] * sh, z1 = wwn[2] * sh, w1 = ch;
+        const float x2q = qn[0], y2 = qn[1], z2 = qn[2], w2q = qn[3];
+        float qo[4] = {w1 * x2q + x1 * w2q + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2q + z1 * x2q,
+                       w1 * z2 + x1 * y2 - y1 * x2q + z1 * w2q, w1 * w2q - x1 * x2q - y1 * y2 - z1 * z2};
+        const float ninv = dw::rsqrt_nr(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+        DQ_UNROLL for (int i = 0; i < 4; ++i) { qo[i] *= ninv; X.root[3 + i] = qo[i]; }
+        if (P.vel_at_com) {
+            float Rn[9], rcom[3], tt[3];
+            quat_to_mat(qo, Rn);
+            m3v(Rn, QM.base_com, rcom);
+            cross3(wwn, rcom, tt);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) von[i] += tt[i];
+        }
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { X.root[7 + i] = von[i]; X.root[10 + i] = wwn[i]; }
+    }
+}
+
+// Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
+DQ_HD void quad_lane_init(QLane &X, int wave_index, int num_envs, const PhysParams &P, float friction, const DwBuffers &B) {
+    X.lane = lane_id();
+    X.j = X.lane & 3;
+    X.el = X.lane >> 2;
+    const int eg = wave_index * EPW + X.el;
+    X.valid = eg < num_envs;
+    X.env = X.valid ? eg : num_envs - 1;
+    X.pos = (X.el + 4 * X.j) & 15;
+    DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = B.root_states[(size_t)13 * X.env + i];
+    X.mu = friction * B.friction_scale[X.env];
+    DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = 0.0f;
+    X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
+    (void)P;
+}
+
+// Gym-boundary substep for 16 envs: tau [N,33], push [N,2] or nullptr (replaces dw::simulate_env)
+template <bool TERRAIN>
+DQ_HD void quad_simulate(QLds &L, const QuadModel &QM, const DevModel &M, const PhysParams &P, float friction, int num_envs,
+                         const DwBuffers &B, const float *tau, const float *push, int wave_index) {
+    QLane X;
+    quad_lane_init(X, wave_index, num_envs, P, friction, B);
+    const int e = X.env, f = X.j & 1;
+    if (B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i]; }
+    for (int s = 0; s < QM.nsteps; ++s) {
+        const int b = QM.fk[s][X.j].body;
+        if (b >= 0) {
+            const int d = b - 1;
+            const float q = B.dof_state[((size_t)ND * e + d) * 2], qd = B.dof_state[((size_t)ND * e + d) * 2 + 1];
+            const float damp = B.dof_damping[(size_t)ND * e + d], arm = B.dof_armature[(size_t)ND * e + d];
+            DQ_SLOT(b, 0, X.pos) = mk4(q, qd, tau[(size_t)ND * e + d] - damp * qd, arm + P.dt * damp);
+        }
+    }
+    quad_substep<TERRAIN>(L, QM, M, P, X, B, push ? push[2 * e] : 0.0f, push ? push[2 * e + 1] : 0.0f, true);
+    if (X.valid) {
+        if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
+        if (X.j < 2 && B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i] = X.warm[i]; }
+    }
+}
+
+}  // namespace dwq

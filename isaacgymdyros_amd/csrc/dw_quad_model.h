@@ -1,0 +1,363 @@
+// dw_quad_model.h -- limb schedule and per-(step, lane) constant tables of the quad kernels (dw_quad.h), and the host
+// routine that derives them from the traversal tables of dw_devmodel.h.
+//
+// A quad = the 4 lanes of one env.  Every lane owns a list of unbranched chains of the kinematic tree and walks them body
+// by body: outward passes (kinematics, accelerations, velocity jumps) in schedule order, the inward pass (articulated
+// inertias) in exactly the reverse order.  For TOCABI the derived schedule is
+//     step     0   1   2   3   4   5   6   7   8   9  10
+//     lane 0   .   .   .  24  25   1   2   3   4   5   6     neck, head, left leg
+//     lane 1   .   .   .   .   .   7   8   9  10  11  12     right leg
+//     lane 2  13  14  15  16  17  18  19  20  21  22  23     waist, left arm
+//     lane 3   .   .   .  26  27  28  29  30  31  32  33     right arm
+// Where limbs meet, data moves between the lanes of the quad with DPP permutes, under these scheduling rules (checked
+// here; dw_create fails if a model cannot be scheduled):
+//   outward: a chain whose parent body belongs to another lane starts in the step right after that parent's step, so the
+//            parent's running state is still in the owner's registers when it is fetched;
+//   inward:  when a chain ends and its parent body is not the lane's next body, its reflected inertia stays in the lane's
+//            running registers until the parent's lane gathers it, or is parked (one parking slot per lane) if the lane
+//            starts another chain first.
+// The two leg chains are right-aligned (they end in the last step) so that both sole bodies are handled in the same
+// inward step; the contact pipeline needs the left leg on lane 0 and the right leg on lane 1.
+#pragma once
+
+#include "dw_devmodel.h"
+
+namespace dwq {
+
+constexpr int EPW = 16;          // environments per wavefront
+constexpr int QS_MAX = 12;       // schedule length bound
+constexpr int QMAX_GEOM = 6;     // ground primitives per moving body the inward step handles
+constexpr int QMAX_GYM = 3;      // Gym bodies welded into one moving body
+
+struct alignas(16) QFkRec {      // outward constants of one (step, lane): 4 x 16 B
+    float pos[3]; int body;      // body origin in the parent frame; body = -1: the lane idles in this step
+    float axis[3]; int psrc;     // hinge axis in body coordinates; parent state: 0 running, 1 base, 2+X from lane X (DPP)
+    float q0[4];                 // quaternion (xyzw) of the fixed rotation body -> parent
+    float qlo, qhi, vmax; int flags;   // bit 0: q0 is not the identity, bit 1: sole body (keep its pose for the contact phase),
+                                       // bits 8..15: self-collision proxies on this body
+};
+
+struct alignas(16) QInRec {      // inward constants of one (step, lane): 11 x 16 B
+    int body, flags, gather, nin;            // flags bit 0: fresh (no running contribution yet), bit 1: park the running
+                                             // state before this body, bit 2: last body of a chain whose parent is elsewhere
+                                             // gather: 4 bits per source (up to 3): lane | parked << 2 | valid << 3
+    float in0_com[3]; float in0_mass;
+    float in0_I[6];   int in0_gym; int ngym;
+    float in1_com[3]; float in1_mass;
+    float in1_I[6];   int in1_gym; int ngeom;
+    int   gyms[QMAX_GYM]; float bound;       // Gym bodies of this moving body (contact attribution); ground test radius
+    int   geom[QMAX_GEOM]; int geom_slot;    // primitive ids; 2 bits per primitive: index into gyms[]
+    int   pad0;
+    float axis[3]; int sc_mask;              // hinge axis in body coordinates; bit p: self-collision proxy p sits on this body
+};
+
+struct QuadModel {
+    int   nsteps;
+    int   owner[dw::NB];         // lane of each body (body 0: all)
+    int   step_of[dw::NB];
+    int   base_gather;           // as QInRec.gather, for the root
+    int   pad[2];
+    QFkRec fk[QS_MAX][4];
+    QInRec in[QS_MAX][4];        // in[s] = inward step s (= outward step nsteps-1-s)
+    // base body
+    float base_com[3]; float base_mass; float base_I[6]; int base_gym; int base_ngeom; int base_geom[QMAX_GEOM]; float base_bound;
+    // self-collision proxies in leg order: 0..3 on the left leg (lane 0), 4..7 on the right (lane 1); pairs = L x R
+    int   nproxy_l, nproxy_r;
+    int   proxy_body[8]; int proxy_gym[8];
+    float proxy_p0[8][3], proxy_p1[8][3], proxy_r[8];
+};
+
+static inline void quat_of_rot(const float *R, float *q) {     // row-major rotation -> unit quaternion xyzw (host only)
+    const double m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7], m22 = R[8];
+    double x, y, z, w;
+    const double tr = m00 + m11 + m22;
+    if (tr > 0) { double s = __builtin_sqrt(tr + 1.0) * 2; w = 0.25 * s; x = (m21 - m12) / s; y = (m02 - m20) / s; z = (m10 - m01) / s; }
+    else if (m00 > m11 && m00 > m22) { double s = __builtin_sqrt(1.0 + m00 - m11 - m22) * 2; w = (m21 - m12) / s; x = 0.25 * s; y = (m01 + m10) / s; z = (m02 + m20) / s; }
+    else if (m11 > m22) { double s = __builtin_sqrt(1.0 + m11 - m00 - m22) * 2; w = (m02 - m20) / s; x = (m01 + m10) / s; y = 0.25 * s; z = (m12 + m21) / s; }
+    else { double s = __builtin_sqrt(1.0 + m22 - m00 - m11) * 2; w = (m10 - m01) / s; x = (m02 + m20) / s; y = (m12 + m21) / s; z = 0.25 * s; }
+    q[0] = (float)x; q[1] = (float)y; q[2] = (float)z; q[3] = (float)w;
+}
+
+// Builds the schedule and the constant tables.  Returns 0 or DW_EINVAL with a message.
+inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *Q, const char **err) {
+    using namespace dw;
+    memset(Q, 0, sizeof(*Q));
+    const int nc = d->nchains;
+    int chain_of[NB]; chain_of[0] = -1;
+    for (int c = 0; c < nc; ++c) for (int i = 0; i < d->chain_len[c]; ++i) chain_of[d->chain_body[c][i]] = c;
+    int lane_of_chain[MAX_CHAINS], cparent[MAX_CHAINS];
+    for (int c = 0; c < nc; ++c) { lane_of_chain[c] = -1; cparent[c] = d->parent[d->chain_body[c][0]]; }
+    int load[4] = {0, 0, 0, 0};
+    int legc[2] = {-1, -1};
+    for (int c = 0; c < nc; ++c) {
+        if (d->chain_body[c][0] == 1) legc[0] = c;
+        if (d->chain_body[c][0] == 7) legc[1] = c;
+    }
+    if (legc[0] < 0 || legc[1] < 0 || d->chain_len[legc[0]] != 6 || d->chain_len[legc[1]] != 6) { *err = "quad schedule: leg chains not found"; return DW_EINVAL; }
+    lane_of_chain[legc[0]] = 0; lane_of_chain[legc[1]] = 1;
+    load[0] = load[1] = 6;
+    // the other chains, by phase: a chain hanging off the END of a chain continues on that chain's lane if it is the
+    // longest such child; everything else goes to the least loaded lane (ties: 3, 2, 0, 1 so trunk/arms fill lanes 2, 3 first)
+    for (int ph = 0; ph < d->nphases; ++ph) {
+        bool cont_taken[MAX_CHAINS] = {};
+        for (int pass = 0; pass < 2; ++pass) {
+            for (;;) {
+                int best = -1;
+                for (int c = 0; c < nc; ++c)
+                    if (lane_of_chain[c] < 0 && d->chain_phase[c] == ph && (best < 0 || d->chain_len[c] > d->chain_len[best])) best = c;
+                if (best < 0) break;
+                int lane = -1;
+                const int pb = cparent[best];
+                if (pb != 0) {
+                    const int pc = chain_of[pb];
+                    if (pass == 0 && !cont_taken[pc] && d->chain_body[pc][d->chain_len[pc] - 1] == pb && lane_of_chain[pc] >= 2) {
+                        lane = lane_of_chain[pc]; cont_taken[pc] = true;
+                    }
+                }
+                if (lane < 0) {
+                    const int pref[4] = {3, 2, 0, 1};
+                    for (int k = 0; k < 4; ++k) if (lane < 0 || load[pref[k]] < load[lane]) lane = pref[k];
+                    if (ph == 0) lane = load[2] <= load[3] ? 2 : 3;
+                }
+                lane_of_chain[best] = lane;
+                load[lane] += d->chain_len[best];
+            }
+        }
+    }
+    // outward timing: per lane the chains in dependency order, legs last; cross-lane starts exactly one step after the parent
+    int start[MAX_CHAINS]; for (int c = 0; c < nc; ++c) start[c] = -1;
+    int step_of[NB]; for (int b = 0; b < NB; ++b) step_of[b] = -1;
+    int lane_free[4] = {0, 0, 0, 0};
+    for (int round = 0; round < nc; ++round) {
+        bool progress = false;
+        for (int ph = 0; ph < d->nphases; ++ph)
+            for (int c = 0; c < nc; ++c) {
+                if (start[c] >= 0 || d->chain_phase[c] != ph || c == legc[0] || c == legc[1]) continue;
+                const int pb = cparent[c], lane = lane_of_chain[c];
+                int t = lane_free[lane];
+                if (pb != 0) {
+                    if (step_of[pb] < 0) continue;
+                    const int need = step_of[pb] + 1;
+                    if (t > need && lane_of_chain[chain_of[pb]] != lane) { *err = "quad schedule: a cross-lane chain cannot start right after its parent"; return DW_EINVAL; }
+                    if (t < need) t = need;
+                    if (lane_of_chain[chain_of[pb]] == lane && t != need) { *err = "quad schedule: same-lane child does not follow its parent"; return DW_EINVAL; }
+                }
+                start[c] = t;
+                for (int i = 0; i < d->chain_len[c]; ++i) step_of[d->chain_body[c][i]] = t + i;
+                lane_free[lane] = t + d->chain_len[c];
+                progress = true;
+            }
+        if (!progress) break;
+    }
+    for (int c = 0; c < nc; ++c) if (start[c] < 0 && c != legc[0] && c != legc[1]) { *err = "quad schedule: unschedulable chain"; return DW_EINVAL; }
+    int T = 0;
+    for (int l = 0; l < 4; ++l) if (lane_free[l] > T) T = lane_free[l];
+    for (int f = 0; f < 2; ++f) if (lane_free[f] + 6 > T) T = lane_free[f] + 6;
+    if (T > QS_MAX) { *err = "quad schedule: longer than QS_MAX steps"; return DW_EINVAL; }
+    for (int f = 0; f < 2; ++f) {          // legs right-aligned
+        start[legc[f]] = T - 6;
+        for (int i = 0; i < 6; ++i) step_of[d->chain_body[legc[f]][i]] = T - 6 + i;
+    }
+    Q->nsteps = T;
+    int body_at[QS_MAX][4];
+    for (int s = 0; s < QS_MAX; ++s) for (int l = 0; l < 4; ++l) body_at[s][l] = -1;
+    Q->owner[0] = -1; Q->step_of[0] = -1;
+    for (int b = 1; b < NB; ++b) {
+        const int l = lane_of_chain[chain_of[b]];
+        if (body_at[step_of[b]][l] >= 0) { *err = "quad schedule: two bodies in one slot"; return DW_EINVAL; }
+        body_at[step_of[b]][l] = b; Q->owner[b] = l; Q->step_of[b] = step_of[b];
+    }
+    // ---- outward records ----
+    for (int s = 0; s < QS_MAX; ++s)
+        for (int l = 0; l < 4; ++l) {
+            QFkRec &r = Q->fk[s][l];
+            r.body = -1; r.q0[3] = 1.0f; r.qlo = -1e30f; r.qhi = 1e30f; r.vmax = 1e30f;
+            const int b = s < T ? body_at[s][l] : -1;
+            if (b < 0) continue;
+            r.body = b;
+            for (int i = 0; i < 3; ++i) { r.pos[i] = d->pos[b][i]; r.axis[i] = d->axis[b][i]; }
+            quat_of_rot(d->rot0[b], r.q0);
+            bool ident = true;
+            for (int i = 0; i < 9; ++i) if (fabsf(d->rot0[b][i] - ((i % 4) == 0 ? 1.0f : 0.0f)) > 1e-7f) ident = false;
+            if (ident) { r.q0[0] = r.q0[1] = r.q0[2] = 0.0f; r.q0[3] = 1.0f; }
+            r.flags = (ident ? 0 : 1) | ((b == d->foot_body[0] || b == d->foot_body[1]) ? 2 : 0);
+            r.qlo = d->qlo[b - 1]; r.qhi = d->qhi[b - 1]; r.vmax = d->vmax[b - 1];
+            const int p = d->parent[b];
+            if (p == 0) r.psrc = 1;
+            else if (Q->owner[p] == l) {
+                if (step_of[p] != s - 1) { *err = "quad schedule: same-lane parent is not the previous step"; return DW_EINVAL; }
+                r.psrc = 0;
+            } else {
+                if (step_of[p] != s - 1) { *err = "quad schedule: cross-lane parent is not the previous step"; return DW_EINVAL; }
+                r.psrc = 2 + Q->owner[p];
+            }
+        }
+    // ---- inward records (reverse order), hand-over bookkeeping ----
+    // state per lane while simulating the inward pass: what its running registers / parking slot hold
+    int running_chain[4] = {-1, -1, -1, -1}, parked_chain[4] = {-1, -1, -1, -1};
+    bool gathered[MAX_CHAINS] = {};
+    for (int s = 0; s < T; ++s) {
+        // all lanes execute: (park) -> (gather) -> body.  Decide parks first for this step.
+        for (int l = 0; l < 4; ++l) {
+            QInRec &r = Q->in[s][l];
+            const int b = body_at[T - 1 - s][l];
+            r.body = b; r.in0_gym = 0; r.in1_gym = 0;
+            if (b < 0) continue;
+            const int c = chain_of[b];
+            const bool tip = (b == d->chain_body[c][d->chain_len[c] - 1]);
+            bool fresh = false;
+            if (tip) {
+                // does a child chain continue in this lane's running registers?  (its root was the previous inward body)
+                bool cont = false;
+                if (running_chain[l] >= 0 && !gathered[running_chain[l]] && cparent[running_chain[l]] == b) cont = true;
+                if (!cont) {
+                    fresh = true;
+                    if (running_chain[l] >= 0 && !gathered[running_chain[l]]) {
+                        if (parked_chain[l] >= 0 && !gathered[parked_chain[l]]) { *err = "quad schedule: two ungathered chains on one lane"; return DW_EINVAL; }
+                        parked_chain[l] = running_chain[l];
+                        r.flags |= 2;
+                    }
+                } else gathered[running_chain[l]] = true;
+                running_chain[l] = -1;
+            }
+            if (fresh) r.flags |= 1;
+        }
+        for (int l = 0; l < 4; ++l) {
+            QInRec &r = Q->in[s][l];
+            const int b = r.body;
+            if (b < 0) continue;
+            // gather the other child chains of b
+            int ng = 0;
+            for (int c = 0; c < nc; ++c) {
+                if (cparent[c] != b || gathered[c]) continue;
+                int src = -1, parked = 0;
+                for (int x = 0; x < 4; ++x) {
+                    if (running_chain[x] == c) { src = x; parked = 0; }
+                    if (parked_chain[x] == c) { src = x; parked = 1; }
+                }
+                if (src < 0 || src == l) { *err = "quad schedule: child chain not available at its parent"; return DW_EINVAL; }
+                if (ng >= 3) { *err = "quad schedule: more than 3 gathers at one body"; return DW_EINVAL; }
+                r.gather |= (src | (parked << 2) | 8) << (4 * ng++);
+                gathered[c] = true;
+            }
+        }
+        for (int l = 0; l < 4; ++l) {      // after the body: which chain do the running registers hold now
+            const int b = Q->in[s][l].body;
+            if (b < 0) continue;
+            const int c = chain_of[b];
+            if (b == d->chain_body[c][0]) { running_chain[l] = c; Q->in[s][l].flags |= 4; }
+        }
+    }
+    {   // the root gathers what is left
+        int ng = 0;
+        for (int c = 0; c < nc; ++c) {
+            if (gathered[c]) continue;
+            if (cparent[c] != 0) { *err = "quad schedule: ungathered chain below the root"; return DW_EINVAL; }
+            int src = -1, parked = 0;
+            for (int x = 0; x < 4; ++x) { if (running_chain[x] == c) { src = x; parked = 0; } if (parked_chain[x] == c) { src = x; parked = 1; } }
+            if (src < 0) { *err = "quad schedule: root child chain lost"; return DW_EINVAL; }
+            if (ng >= 4) { *err = "quad schedule: more than 4 chains at the root"; return DW_EINVAL; }
+            Q->base_gather |= (src | (parked << 2) | 8) << (4 * ng++);
+        }
+    }
+    // ---- per-body constants of the inward records ----
+    auto fill_inert = [&](int b, int k, float *com, float *mass, float *I, int *gym) {
+        *mass = d->bi_mass[b][k]; *gym = d->bi_gym[b][k];
+        for (int i = 0; i < 3; ++i) com[i] = d->bi_com[b][k][i];
+        for (int i = 0; i < 6; ++i) I[i] = d->bi_I[b][k][i];
+    };
+    auto geom_bound = [&](int b, int ng, const int *gl) {
+        float bound = 0.0f;
+        for (int k = 0; k < ng; ++k) {
+            const DwGeom &g = d->geoms[gl[k]];
+            const float pn = sqrtf(g.pos[0] * g.pos[0] + g.pos[1] * g.pos[1] + g.pos[2] * g.pos[2]);
+            const float ext = g.type == 0 ? sqrtf(g.size[0] * g.size[0] + g.size[1] * g.size[1] + g.size[2] * g.size[2])
+                                          : sqrtf(g.size[0] * g.size[0] + g.size[1] * g.size[1]);
+            if (pn + ext > bound) bound = pn + ext;
+        }
+        (void)b;
+        return bound * 1.01f + 1e-3f;
+    };
+    for (int s = 0; s < T; ++s)
+        for (int l = 0; l < 4; ++l) {
+            QInRec &r = Q->in[s][l];
+            const int b = r.body;
+            if (b < 0) continue;
+            r.nin = d->ninert[b];
+            if (r.nin > 2) { *err = "quad model: more than two inertial records on a body"; return DW_EINVAL; }
+            if (r.nin >= 1) fill_inert(b, 0, r.in0_com, &r.in0_mass, r.in0_I, &r.in0_gym);
+            if (r.nin >= 2) fill_inert(b, 1, r.in1_com, &r.in1_mass, r.in1_I, &r.in1_gym);
+            for (int i = 0; i < 3; ++i) r.axis[i] = d->axis[b][i];
+            if (d->body_ngeom[b] > QMAX_GEOM) { *err = "quad model: too many ground primitives on one body"; return DW_EINVAL; }
+            r.ngeom = d->body_ngeom[b];
+            r.ngym = 0;
+            for (int k = 0; k < r.ngeom; ++k) {
+                r.geom[k] = d->body_geom[b][k];
+                const int gy = d->body_geom_gym[b][k];
+                int t = -1;
+                for (int i = 0; i < r.ngym; ++i) if (r.gyms[i] == gy) t = i;
+                if (t < 0) { if (r.ngym >= QMAX_GYM) { *err = "quad model: too many Gym bodies on one moving body"; return DW_EINVAL; } t = r.ngym; r.gyms[r.ngym++] = gy; }
+                r.geom_slot |= t << (2 * k);
+            }
+            r.bound = geom_bound(b, r.ngeom, r.geom);
+        }
+    // Gym bodies that report forces without carrying a ground primitive (sole bodies, self-collision proxies) are added below
+    auto add_gym = [&](int b, int gy) -> int {
+        QInRec &r = Q->in[T - 1 - step_of[b]][Q->owner[b]];
+        for (int i = 0; i < r.ngym; ++i) if (r.gyms[i] == gy) return i;
+        if (r.ngym >= QMAX_GYM) return -1;
+        r.gyms[r.ngym] = gy;
+        return r.ngym++;
+    };
+    for (int f = 0; f < 2; ++f) if (add_gym(d->foot_body[f], f == 0 ? d->left_foot_gym : d->right_foot_gym) < 0) { *err = "quad model: sole Gym body does not fit"; return DW_EINVAL; }
+    // base
+    if (d->ninert[0] != 1) { *err = "quad model: the root must carry exactly one inertial record"; return DW_EINVAL; }
+    fill_inert(0, 0, Q->base_com, &Q->base_mass, Q->base_I, &Q->base_gym);
+    if (d->body_ngeom[0] > QMAX_GEOM) { *err = "quad model: too many ground primitives on the root"; return DW_EINVAL; }
+    Q->base_ngeom = d->body_ngeom[0];
+    for (int k = 0; k < Q->base_ngeom; ++k) {
+        Q->base_geom[k] = d->body_geom[0][k];
+        if (d->body_geom_gym[0][k] != Q->base_gym) { *err = "quad model: root primitives must report on the root's Gym body"; return DW_EINVAL; }
+    }
+    Q->base_bound = geom_bound(0, Q->base_ngeom, Q->base_geom);
+    // self-collision proxies: pairs must be {left-leg proxy} x {right-leg proxy}
+    for (int k = 0; k < d->num_sc_pairs; ++k) {
+        const int pa = d->sc_pair[k][0], pb = d->sc_pair[k][1];
+        const int ba = d->sc_proxy[pa].moving, bb = d->sc_proxy[pb].moving;
+        if (!(ba >= 1 && ba <= 6 && bb >= 7 && bb <= 12)) { *err = "quad model: self-collision pairs must be left-leg x right-leg"; return DW_EINVAL; }
+    }
+    int lmap[DW_MAX_SC_PROXIES], rmap[DW_MAX_SC_PROXIES];
+    for (int i = 0; i < DW_MAX_SC_PROXIES; ++i) lmap[i] = rmap[i] = -1;
+    auto put = [&](int pr, int slot) {
+        const DwCapsule &c = d->sc_proxy[pr];
+        Q->proxy_body[slot] = c.moving; Q->proxy_gym[slot] = c.gym; Q->proxy_r[slot] = c.radius;
+        for (int i = 0; i < 3; ++i) { Q->proxy_p0[slot][i] = c.p0[i]; Q->proxy_p1[slot][i] = c.p1[i]; }
+    };
+    for (int k = 0; k < d->num_sc_pairs; ++k) {
+        const int pa = d->sc_pair[k][0], pb = d->sc_pair[k][1];
+        if (lmap[pa] < 0) { if (Q->nproxy_l >= 4) { *err = "quad model: more than 4 proxies on the left leg"; return DW_EINVAL; } lmap[pa] = Q->nproxy_l; put(pa, Q->nproxy_l++); }
+        if (rmap[pb] < 0) { if (Q->nproxy_r >= 4) { *err = "quad model: more than 4 proxies on the right leg"; return DW_EINVAL; } rmap[pb] = Q->nproxy_r; put(pb, 4 + Q->nproxy_r++); }
+    }
+    if (d->num_sc_pairs != Q->nproxy_l * Q->nproxy_r) { *err = "quad model: self-collision pairs must be the full left x right product"; return DW_EINVAL; }
+    for (int p = 0; p < 8; ++p) {
+        const bool used = p < 4 ? p < Q->nproxy_l : (p - 4) < Q->nproxy_r;
+        if (!used) continue;
+        const int b = Q->proxy_body[p];
+        Q->in[T - 1 - step_of[b]][Q->owner[b]].sc_mask |= 1 << p;
+        Q->fk[step_of[b]][Q->owner[b]].flags |= (1 << p) << 8;
+        if (add_gym(b, Q->proxy_gym[p]) < 0) { *err = "quad model: proxy Gym body does not fit"; return DW_EINVAL; }
+    }
+    // every Gym body must be reported by exactly one moving body (the kernels write, never accumulate, contact forces)
+    for (int b = 1; b < NB; ++b) if (add_gym(b, dm->mv_gym[b]) < 0) { *err = "quad model: Gym body of a moving body does not fit"; return DW_EINVAL; }
+    for (int k = 0; k < DW_NUM_INERT; ++k)
+        if (dm->inert_mv[k] > 0 && add_gym(dm->inert_mv[k], dm->inert_gym[k]) < 0) { *err = "quad model: Gym body of an inertial record does not fit"; return DW_EINVAL; }
+    {
+        int seen[DW_NUM_BODIES] = {};
+        seen[Q->base_gym] += 1;
+        for (int s2 = 0; s2 < T; ++s2) for (int l = 0; l < 4; ++l) { const QInRec &r = Q->in[s2][l]; if (r.body >= 0) for (int i = 0; i < r.ngym; ++i) seen[r.gyms[i]] += 1; }
+        for (int g = 0; g < DW_NUM_BODIES; ++g) if (seen[g] != 1) { *err = "quad model: a Gym body is reported by no moving body or by several"; return DW_EINVAL; }
+    }
+    return DW_OK;
+}
+
+}  // namespace dwq

@@ -175,8 +175,27 @@ DW_HD bool finitef(float x) { return fabsf(x) <= 3.4028234663852886e38f; }   // 
 
 #define ESI(off) (*reinterpret_cast<int *>(&S.es[(off)]))
 
+// LDS block of the split task kernels (dw_k_pre / dw_k_post, one wave per env around the quad physics kernel): the task
+// record and the Gym state of one env, 3.6 KB, so the task logic runs at full occupancy instead of behind the 13.5 KB
+// physics block of the fused kernel.
+struct alignas(16) TaskLds {
+    float root[13];
+    float q[ND], qd[ND];
+    float contact[DW_NUM_BODIES * 3];
+    float es[DW_ES_WORDS];
+    float act[DW_NUM_ACT];
+    float normed[DW_NUM_OBS1];
+    float rterm[16];
+    float scratch[8];
+    int   flags[8];
+    float warm[24];              // unused by the split kernels (the physics kernel moves the warm start itself)
+};
+// spare words of the task record carry the push force of the step from dw_k_pre to the physics kernel
+constexpr int ES_PUSH_X = DW_ES_WORDS - 2, ES_PUSH_Y = DW_ES_WORDS - 1;
+static_assert(DW_ES_EPISODES < ES_PUSH_X, "task record has no spare words for the push force");
+
 // ---------------------------------------------------------------------------------------------- load / store
-DW_HD void load_env_lane(int l, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {
+DW_HD void load_env_lane(int l, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {   // fused kernels
     {
         if (with_task)
             for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
@@ -197,8 +216,8 @@ DW_HD void load_env(const W &wave, Lds &S, const TaskParams &C, const DwBuffers 
     wave.par([&](int l) { load_env_lane(l, S, C, B, e, with_task); });
 }
 
-template <class W>
-DW_HD void store_env(const W &wave, Lds &S, const DwBuffers &B, int e, bool with_task, bool with_state) {
+template <class W, class LT>
+DW_HD void store_env(const W &wave, LT &S, const DwBuffers &B, int e, bool with_task, bool with_state) {
     wave.par([&](int l) {
         if (with_task)
             for (int i = l; i < DW_ES_WORDS; i += 64) B.env_state[(size_t)DW_ES_WORDS * e + i] = S.es[i];
@@ -216,8 +235,8 @@ DW_HD void store_env(const W &wave, Lds &S, const DwBuffers &B, int e, bool with
 // ---------------------------------------------------------------------------------------------- reset_idx (one env)
 // Expects: S.es, S.contact (current net contact forces), S.flags[4] = randomize_buf value.  Writes S.root, S.q,
 // S.qd, record fields, per-env DR'd parameters and the zeroed action ring.
-template <class W>
-DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const DwBuffers &B,
+template <class W, class LT>
+DW_HD void reset_region(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                         const NoiseSrc &nz, int e) {
     // terrain curriculum (tasks/dyros_dynamic_walk.py:603-604,671-691): from the position the robot reached and the
     // target velocity of the episode that ended; the new origin goes to S.scratch[4..6] for the spawn below
@@ -320,59 +339,62 @@ DW_HD void reset_region(const W &wave, Lds &S, const DevModel &M, const TaskPara
 }
 
 // ---------------------------------------------------------------------------------------------- the step
-template <bool TERRAIN, class W>
-DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
-    const DwBuffers &B = *T.b;
+// Per-step constants shared by the regions below.
+struct StepCtx {
     NoiseSrc nz;
-    nz.rec = T.noise ? T.noise + (size_t)DW_NOISE_WORDS * e : nullptr;
-    nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)T.step; nz.stream = 0;
-    const float period = (float)(3599 * 0.0005), cdt = 0.0005f;
-    const float dt = C.phys.dt;
-    const double cdt_d = 0.0005;
-    long long *gate = reinterpret_cast<long long *>(B.gate_acc);
-    const TreeUniform TU = make_tree_uniform(M);
-    const int slot_prev = (int)((T.step + 2) % 3), slot_cur = (int)(T.step % 3), slot_next = (int)((T.step + 1) % 3);
-
-    // One region issues every global load whose address does not depend on this step's arithmetic -- tree tables,
-    // the env's record and state, its actions, counters, mass and the gate sums -- so the wave waits for HBM/L2 once
-    // here instead of once per phase that needs a scalar.
-    wave.par([&](int l) {
-        stage_tree_lane(l, S, M);
-        load_env_lane(l, S, C, B, e, true);
-        if (l < DW_NUM_ACT) {
-            float a = fminf(fmaxf(T.actions[DW_NUM_ACT * e + l], -1.0f), 1.0f);
-            if (l == 12) a = (a > 0 ? 1.0f : 0.0f) * a;
-            S.act[l] = a;
+    float period, cdt, dt;
+    double cdt_d;
+    long long *gate;
+    int slot_prev, slot_cur, slot_next;
+};
+DW_HD StepCtx make_step_ctx(const TaskParams &C, const TaskBuffers &T, int e) {
+    StepCtx K;
+    K.nz.rec = T.noise ? T.noise + (size_t)DW_NOISE_WORDS * e : nullptr;
+    K.nz.seed = C.seed; K.nz.env = (unsigned int)e; K.nz.step = (unsigned long long)T.step; K.nz.stream = 0;
+    K.period = (float)(3599 * 0.0005); K.cdt = 0.0005f; K.dt = C.phys.dt; K.cdt_d = 0.0005;
+    K.gate = reinterpret_cast<long long *>(T.b->gate_acc);
+    K.slot_prev = (int)((T.step + 2) % 3); K.slot_cur = (int)(T.step % 3); K.slot_next = (int)((T.step + 1) % 3);
+    return K;
+}
+// population statistics of the previous step (tasks/dyros_dynamic_walk.py:489): is the perturbation gate open
+DW_HD int gate_open(const TaskParams &C, const StepCtx &K) {
+    int open = C.force_perturb_start;
+    if (!open && C.perturb) {
+        const long long latch = K.gate[GATE_LATCH];
+        long long se = 0, sc = 0;
+        for (int k = 0; k < GATE_BUCKETS; ++k) {
+            se += K.gate[(K.slot_prev * GATE_BUCKETS + k) * 2];
+            sc += K.gate[(K.slot_prev * GATE_BUCKETS + k) * 2 + 1];
         }
-        if (l == 33) {
-            // population statistics of the previous step (tasks/dyros_dynamic_walk.py:489)
-            int open = C.force_perturb_start;
-            if (!open && C.perturb) {
-                const long long latch = gate[GATE_LATCH];
-                long long se = 0, sc = 0;
-                for (int k = 0; k < GATE_BUCKETS; ++k) {
-                    se += gate[(slot_prev * GATE_BUCKETS + k) * 2];
-                    sc += gate[(slot_prev * GATE_BUCKETS + k) * 2 + 1];
-                }
-                const double n = (double)C.num_envs;
-                const double mean_epi = (double)se / n, mean_crm = (double)sc / 4294967296.0 / n;
-                open = latch ? 1 : (mean_epi > (double)(C.max_episode_length - C.pert_period_f) && mean_crm > 0.165);
-            }
-            S.flags[6] = open;
-        }
-        if (l == 34) {
-            const long long p = B.progress_buf[e], rb = B.randomize_buf[e];
-            S.flags[5] = (int)p;
-            S.flags[4] = (int)(rb > 0x7ffffffe ? 0x7ffffffe : rb);
-            S.scratch[3] = B.total_mass[e];
-        }
-    });
-    if (C.freeze_physics) {      // debug mode: simulate() is the identity, so the net contact forces are an input too
-        wave.par([&](int l) {
-            for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
-        });
+        const double n = (double)C.num_envs;
+        const double mean_epi = (double)se / n, mean_crm = (double)sc / 4294967296.0 / n;
+        open = latch ? 1 : (mean_epi > (double)(C.max_episode_length - C.pert_period_f) && mean_crm > 0.165);
     }
+    return open;
+}
+// VecTask counters and the env's mass into the flag / scratch words the post regions read
+template <class LT>
+DW_HD void load_counters(LT &S, const DwBuffers &B, int e) {
+    const long long p = B.progress_buf[e], rb = B.randomize_buf[e];
+    S.flags[5] = (int)p;
+    S.flags[4] = (int)(rb > 0x7ffffffe ? 0x7ffffffe : rb);
+    S.scratch[3] = B.total_mass[e];
+}
+DW_HD float clamp_action(const float *actions, int e, int l) {
+    float a = fminf(fmaxf(actions[DW_NUM_ACT * e + l], -1.0f), 1.0f);
+    if (l == 12) a = (a > 0 ? 1.0f : 0.0f) * a;
+    return a;
+}
 
+// Regions P1, P2 (pre_physics_step up to the substep loop).  Expects S.es, S.act, S.flags[6] (gate).  FUSED: the warm-start
+// impulses are copied into the physics block (the split pipeline's physics kernel reads them from the record itself).
+template <bool FUSED, class W, class LT>
+DW_HD void task_p1p2(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e, const StepCtx &K) {
+    const DwBuffers &B = *T.b;
+    const NoiseSrc &nz = K.nz;
+    const float period = K.period, cdt = K.cdt;
+    const double cdt_d = K.cdt_d;
+    long long *gate = K.gate;
     // ---- P1: clamp actions, mocap phase, perturbation gate and schedule (scalar work on single lanes) ----
     wave.par([&](int l) {
         if (l < DW_NUM_ACT) {
@@ -420,7 +442,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             S.scratch[1] = px;
             S.scratch[2] = py;
         }
-        if (l >= 40 && l < 40 + 24) S.warm[l - 40] = S.es[DW_ES_WARM + (l - 40)];
+        if (FUSED) { if (l >= 40 && l < 40 + 24) S.warm[l - 40] = S.es[DW_ES_WARM + (l - 40)]; }
     });
     // ---- P2: mocap target (cubic between two table rows), leg torques from the actions ----
     wave.par([&](int l) {
@@ -437,52 +459,18 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             S.es[DW_ES_ACTION_TORQUE + i] = S.act[i] * S.es[DW_ES_MOTOR_SCALE + i] * M.action_high[i];
         }
     });
+}
 
-    // ---- P3: two physics substeps with the actuator model around them ----
-    // unrolled on purpose: as a loop, ~45 lane-constant model loads were hoisted out of it and kept live across the
-    // whole substep body, which at the 168-register cap meant spilling them (188 B/lane of scratch)
-#if !defined(DW_ROLL_SUBSTEPS)
-#pragma unroll
-#else
-#pragma clang loop unroll(disable)
-#endif
-    for (int sub = 0; sub < 2; ++sub) {
-        wave.par([&](int l) {
-            if (l < 12) {
-                // torque FIFO, column l (tasks/dyros_dynamic_walk.py:511-519)
-                float col[DW_ALOG_SLOTS];
-                for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = S.es[DW_ES_ACTION_LOG + 12 * (s + 1) + l];
-                col[DW_ALOG_SLOTS - 1] = S.es[DW_ES_ACTION_TORQUE + l];
-                for (int s = 0; s < DW_ALOG_SLOTS; ++s) S.es[DW_ES_ACTION_LOG + 12 * s + l] = col[s];
-                int sl = ESI(DW_ES_SIMUL_LEN) + 1;
-                if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
-                const int dl = ESI(DW_ES_DELAY_IDX);
-                const int src = sl > dl ? dl : DW_ALOG_SLOTS - sl;
-                float t = col[0];
-                for (int s = 1; s < DW_ALOG_SLOTS; ++s) t = (s == src) ? col[s] : t;
-                S.tau[l] = t;
-            } else if (l < ND) {
-                S.tau[l] = M.kp[l] * (S.es[DW_ES_TARGET_QPOS + l] - S.q[l]) + M.kv[l] * (-S.qd[l]);
-            }
-            if (l == 40) { S.push[0] = sub == 0 ? S.scratch[1] : 0.0f; S.push[1] = sub == 0 ? S.scratch[2] : 0.0f; }
-        });
-        if (!C.freeze_physics) physics_substep<TERRAIN>(wave, S, M, C.phys, TU);
-        wave.par([&](int l) {
-            if (l < ND) {
-                const float n = noise_word(nz, DW_NZ_ENC + ND * sub + l);
-                const float qn = S.q[l] + fminf(fmaxf(n, -0.00016f), 0.00016f);
-                S.es[DW_ES_QVEL_NOISE + l] = C.gpu_div ? (qn - S.es[DW_ES_QPOS_PRE + l]) * C.inv_dt_f : (qn - S.es[DW_ES_QPOS_PRE + l]) / dt;
-                S.es[DW_ES_QPOS_NOISE + l] = qn;
-                S.es[DW_ES_QPOS_PRE + l] = qn;
-            }
-            if (l == 40) {
-                int sl = ESI(DW_ES_SIMUL_LEN) + 1;
-                if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
-                ESI(DW_ES_SIMUL_LEN) = sl;
-            }
-        });
-    }
-
+// Regions Q1..Q6 (post_physics_step).  Expects S.es, S.root, S.q, S.qd, S.contact, S.act, S.flags[4], S.flags[5], S.scratch[3],
+// S.flags[0..3] = 0.  Returns whether the env was reset or hit the non-finite guard (its Gym state changed).
+template <bool FUSED, class W, class LT>
+DW_HD int task_post(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e, const StepCtx &K) {
+    const DwBuffers &B = *T.b;
+    const NoiseSrc &nz = K.nz;
+    const float period = K.period;
+    const double cdt_d = K.cdt_d;
+    long long *gate = K.gate;
+    const int slot_cur = K.slot_cur, slot_next = K.slot_next;
     // ---- Q1: clocks, VecTask counters, non-finite guard ----
     wave.par([&](int l) {
         if (l == 40) {
@@ -499,7 +487,7 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             B.randomize_buf[e] = rb;
             S.flags[4] = rb;
         }
-        if (l < 24) S.es[DW_ES_WARM + l] = S.warm[l];
+        if (FUSED) { if (l < 24) S.es[DW_ES_WARM + l] = S.warm[l]; }
         bool bad = false;
         if (l < 13) bad |= !finitef(S.root[l]);
         if (l < ND) bad |= !finitef(S.q[l]) || !finitef(S.qd[l]);
@@ -734,18 +722,131 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
             gate[(slot_next * GATE_BUCKETS + bk) * 2 + 1] = 0;
         }
     });
+    return did_reset | uniform(S.flags[1]);
+}
+
+// The fused wave-per-env step (first-generation kernel; still the one that runs on height fields)
+template <bool TERRAIN, class W>
+DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
+    const DwBuffers &B = *T.b;
+    const StepCtx K = make_step_ctx(C, T, e);
+    const NoiseSrc &nz = K.nz;
+    const float dt = K.dt;
+    const TreeUniform TU = make_tree_uniform(M);
+
+    // One region issues every global load whose address does not depend on this step's arithmetic -- tree tables,
+    // the env's record and state, its actions, counters, mass and the gate sums -- so the wave waits for HBM/L2 once
+    // here instead of once per phase that needs a scalar.
+    wave.par([&](int l) {
+        stage_tree_lane(l, S, M);
+        load_env_lane(l, S, C, B, e, true);
+        if (l < DW_NUM_ACT) S.act[l] = clamp_action(T.actions, e, l);
+        if (l == 33) S.flags[6] = gate_open(C, K);
+        if (l == 34) load_counters(S, B, e);
+    });
+    if (C.freeze_physics) {      // debug mode: simulate() is the identity, so the net contact forces are an input too
+        wave.par([&](int l) {
+            for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
+        });
+    }
+    task_p1p2<true>(wave, S, M, C, T, e, K);
+
+    // ---- P3: two physics substeps with the actuator model around them ----
+    // unrolled on purpose: as a loop, ~45 lane-constant model loads were hoisted out of it and kept live across the
+    // whole substep body, which at the 168-register cap meant spilling them (188 B/lane of scratch)
+#if !defined(DW_ROLL_SUBSTEPS)
+#pragma unroll
+#else
+#pragma clang loop unroll(disable)
+#endif
+    for (int sub = 0; sub < 2; ++sub) {
+        wave.par([&](int l) {
+            if (l < 12) {
+                // torque FIFO, column l (tasks/dyros_dynamic_walk.py:511-519)
+                float col[DW_ALOG_SLOTS];
+                for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = S.es[DW_ES_ACTION_LOG + 12 * (s + 1) + l];
+                col[DW_ALOG_SLOTS - 1] = S.es[DW_ES_ACTION_TORQUE + l];
+                for (int s = 0; s < DW_ALOG_SLOTS; ++s) S.es[DW_ES_ACTION_LOG + 12 * s + l] = col[s];
+                int sl = ESI(DW_ES_SIMUL_LEN) + 1;
+                if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
+                const int dl = ESI(DW_ES_DELAY_IDX);
+                const int src = sl > dl ? dl : DW_ALOG_SLOTS - sl;
+                float t = col[0];
+                for (int s = 1; s < DW_ALOG_SLOTS; ++s) t = (s == src) ? col[s] : t;
+                S.tau[l] = t;
+            } else if (l < ND) {
+                S.tau[l] = M.kp[l] * (S.es[DW_ES_TARGET_QPOS + l] - S.q[l]) + M.kv[l] * (-S.qd[l]);
+            }
+            if (l == 40) { S.push[0] = sub == 0 ? S.scratch[1] : 0.0f; S.push[1] = sub == 0 ? S.scratch[2] : 0.0f; }
+        });
+        if (!C.freeze_physics) physics_substep<TERRAIN>(wave, S, M, C.phys, TU);
+        wave.par([&](int l) {
+            if (l < ND) {
+                const float n = noise_word(nz, DW_NZ_ENC + ND * sub + l);
+                const float qn = S.q[l] + fminf(fmaxf(n, -0.00016f), 0.00016f);
+                S.es[DW_ES_QVEL_NOISE + l] = C.gpu_div ? (qn - S.es[DW_ES_QPOS_PRE + l]) * C.inv_dt_f : (qn - S.es[DW_ES_QPOS_PRE + l]) / dt;
+                S.es[DW_ES_QPOS_NOISE + l] = qn;
+                S.es[DW_ES_QPOS_PRE + l] = qn;
+            }
+            if (l == 40) {
+                int sl = ESI(DW_ES_SIMUL_LEN) + 1;
+                if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
+                ESI(DW_ES_SIMUL_LEN) = sl;
+            }
+        });
+    }
+
+    task_post<true>(wave, S, M, C, T, e, K);
     store_env(wave, S, B, e, true, true);
 }
 
-// reset_done path (tasks/base/vec_task.py:376-391 -> reset_idx): one env
+// ---- the split pipeline: dw_k_pre (this), the quad physics kernel (dw_quad_kernels.h), dw_k_post ----
 template <class W>
-DW_HD void reset_only_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
+DW_HD void step_pre_env(const W &wave, TaskLds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
+    const DwBuffers &B = *T.b;
+    const StepCtx K = make_step_ctx(C, T, e);
+    wave.par([&](int l) {
+        for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
+        if (l < DW_NUM_ACT) S.act[l] = clamp_action(T.actions, e, l);
+        if (l == 33) S.flags[6] = gate_open(C, K);
+    });
+    task_p1p2<false>(wave, S, M, C, T, e, K);
+    wave.par([&](int l) {
+        if (l == 0) { S.es[ES_PUSH_X] = S.scratch[1]; S.es[ES_PUSH_Y] = S.scratch[2]; }
+    });
+    wave.par([&](int l) {
+        for (int i = l; i < DW_ES_WORDS; i += 64) B.env_state[(size_t)DW_ES_WORDS * e + i] = S.es[i];
+    });
+}
+
+template <class W>
+DW_HD void step_post_env(const W &wave, TaskLds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
+    const DwBuffers &B = *T.b;
+    const StepCtx K = make_step_ctx(C, T, e);
+    wave.par([&](int l) {
+        for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
+        if (l < 13) S.root[l] = B.root_states[13 * e + l];
+        if (l < ND) { S.q[l] = B.dof_state[(ND * e + l) * 2]; S.qd[l] = B.dof_state[(ND * e + l) * 2 + 1]; }
+        for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
+        if (l < 4) S.flags[l] = 0;
+        if (l == 34) load_counters(S, B, e);
+    });
+    wave.par([&](int l) {
+        if (l < DW_NUM_ACT) S.act[l] = S.es[DW_ES_ACTIONS + l];
+    });
+    const int state_changed = task_post<false>(wave, S, M, C, T, e, K);
+    store_env(wave, S, B, e, true, state_changed != 0);
+}
+
+// reset_done path (tasks/base/vec_task.py:376-391 -> reset_idx): one env
+template <class W, class LT>
+DW_HD void reset_only_env(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
     const DwBuffers &B = *T.b;
     NoiseSrc nz;
     nz.rec = T.noise ? T.noise + (size_t)DW_NOISE_WORDS * e : nullptr;
     nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)T.step; nz.stream = 1;
-    load_env(wave, S, C, B, e, true);
-    wave.par([&](int l) {
+    wave.par([&](int l) {        // reset_region rewrites root, q and qd completely; it needs the record and the contact forces
+        for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
         for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
         if (l == 40) {
             const long long rb = B.randomize_buf[e];

@@ -10,8 +10,8 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
 _cache = {}
 
 
-def load(asan=False):
-    name = "libdw_emul_asan.so" if asan else "libdw_emul.so"
+def load(asan=False, quad=False):
+    name = ("libdw_emul_quad" if quad else "libdw_emul") + ("_asan.so" if asan else ".so")
     if name not in _cache:
         subprocess.check_call(["make", "-C", HERE, "-s", "_build/" + name])
         lib = C.CDLL(os.path.join(HERE, "_build", name))
@@ -20,13 +20,13 @@ def load(asan=False):
 
 
 class EmulSim(OracleSim):
-    def __init__(self, num_envs, task_const=None, **cfg_over):
-        super().__init__(num_envs, task_const=task_const, lib_api=load(), **cfg_over)
+    def __init__(self, num_envs, task_const=None, quad=False, **cfg_over):
+        super().__init__(num_envs, task_const=task_const, lib_api=load(quad=quad), **cfg_over)
 
 
 class EmulBackend:
-    def __init__(self, N, task_const, **cfg):
-        self.sim = EmulSim(N, task_const=task_const, **cfg)
+    def __init__(self, N, task_const, quad=False, **cfg):
+        self.sim = EmulSim(N, task_const=task_const, quad=quad, **cfg)
 
     def load_buffers(self, bufs):
         for k, v in bufs.items():

@@ -9,6 +9,13 @@ from oracle import parity as P
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[2, 1], ids=["quad", "fused"])
+def pipeline(request):
+    """Both kernel generations behind the same C-ABI: 2 = split pipeline around the quad physics kernel (the default),
+    1 = the fused wave-per-env kernel."""
+    return request.param
+
+
 def _oracle_like(env, task_const):
     from oracle.oracle import OracleSim
     o = OracleSim(env.num_envs, task_const=task_const, cfg=env._ccfg)
@@ -17,14 +24,14 @@ def _oracle_like(env, task_const):
     return o
 
 
-def test_task_logic_vs_reference_goldens(task_const):
+def test_task_logic_vs_reference_goldens(task_const, pipeline):
     """Physics frozen: the reference's torch task logic replayed through the HIP kernels.  Integer/flag fields and
     every float field without a transcendental are bit-identical to the reference's CPU torch run (torch_gpu_div=0
     selects torch's CPU division semantics); exp/sin/cos/asin/atan2-derived fields within abs 2e-6 + rel 4e-6
     (OCML vs SLEEF last-bit rounding)."""
     from hip_backend import HipBackend
     g = R.load("task_logic_frozen.npz")
-    be = HipBackend(int(g["N"]), randomize=False, debug_freeze_physics=True, torch_gpu_div=False)
+    be = HipBackend(int(g["N"]), randomize=False, debug_freeze_physics=True, torch_gpu_div=False, pipeline=pipeline)
     for t, ref, got in R.replay(g, be):
         exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
         if "obs_history" in ref:
@@ -35,12 +42,12 @@ def test_task_logic_vs_reference_goldens(task_const):
     assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
 
 
-def test_whole_step_vs_oracle_goldens(task_const):
+def test_whole_step_vs_oracle_goldens(task_const, pipeline):
     """Stated float tolerance on q/qd after N steps (contacts active, random torques): after 10 policy steps
     (20 substeps of 2 ms) |dq| <= 1e-4 rad, |dqd| <= 2e-2 rad/s (0.5 % of the 4.03 rad/s joint-speed limit), root pose <= 1e-4, reward <= 5e-3."""
     from hip_backend import HipBackend
     g = R.load("whole_step_oracle.npz")
-    be = HipBackend(int(g["N"]), randomize=False, torch_gpu_div=False)
+    be = HipBackend(int(g["N"]), randomize=False, torch_gpu_div=False, pipeline=pipeline)
     ref_rew, got_rew, ref_res, got_res = [], [], 0, 0
     for t, ref, got in R.replay(g, be):
         if t < 10:
@@ -60,13 +67,13 @@ def test_whole_step_vs_oracle_goldens(task_const):
     assert abs(ref_res - got_res) <= max(3, 0.3 * ref_res), (ref_res, got_res)
 
 
-def test_physics_substep_vs_oracle(task_const):
+def test_physics_substep_vs_oracle(task_const, pipeline):
     """dw_simulate vs dwo_simulate, random in-flight states with randomised mass/damping/armature and a push:
     |dq| <= 1e-4 rad, root pose <= 1e-4, |dqd| and root velocity <= 1e-3 after 100 contact-free substeps."""
     from hip_backend import make_env
     rng = np.random.default_rng(1)
     N = 256
-    env = make_env(N, self_collision=False)      # random joint angles interpenetrate the legs; see the dedicated test
+    env = make_env(N, self_collision=False, pipeline=pipeline)      # random joint angles interpenetrate the legs; see the dedicated test
     b = env._buf
     root = np.zeros((N, 13), np.float32)
     root[:, 0:3] = rng.normal(size=(N, 3)) + np.array([0, 0, 3])
@@ -91,11 +98,11 @@ def test_physics_substep_vs_oracle(task_const):
     assert droot[:, 7:].max() < 1e-3           # velocities (|v| up to ~5 m/s after 0.2 s of random pushes)
 
 
-def test_stance_contact_vs_oracle(task_const):
+def test_stance_contact_vs_oracle(task_const, pipeline):
     """Standing under full-strength PD: sole loads equal m*g within 2 % on both and agree with each other."""
     from hip_backend import make_env
     from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS, KP_RAW, KV_RAW
-    env = make_env(64, randomize=False)
+    env = make_env(64, randomize=False, pipeline=pipeline)
     env._buf["root_states"][:, 0:2] = 0
     kp = torch.tensor(KP_RAW, device="cuda")
     kv = torch.tensor(KV_RAW, device="cuda")
@@ -113,14 +120,14 @@ def test_stance_contact_vs_oracle(task_const):
     assert 0.90 < float(env.root_states[:, 2].mean()) < 0.94
 
 
-def test_in_kernel_rng_matches_oracle_bitwise(task_const):
+def test_in_kernel_rng_matches_oracle_bitwise(task_const, pipeline):
     """Philox4x32-10 is integer work: with physics frozen and noise=None every uniform-derived field of the HIP
     step equals the oracle's bit for bit (reset draws, DR of damping/armature/friction, vel noise draw)."""
     from hip_backend import HipBackend
     from replay import OracleBackend
     g = R.load("task_logic_frozen.npz")
     N = int(g["N"])
-    hb = HipBackend(N, randomize=True, debug_freeze_physics=True)
+    hb = HipBackend(N, randomize=True, debug_freeze_physics=True, pipeline=pipeline)
     ob = OracleBackend(N, task_const, cfg=hb.env._ccfg)
     init = {k[5:]: v for k, v in g.items() if k.startswith("init_")}
     hb.load_buffers(init)
@@ -139,12 +146,12 @@ def test_in_kernel_rng_matches_oracle_bitwise(task_const):
 
 
 @pytest.mark.parametrize("N,friction_dr", [(4096, False), (16384, False), (16384, True)])
-def test_full_size_properties(N, friction_dr):
+def test_full_size_properties(N, friction_dr, pipeline):
     """BASELINE sizes (configs 2 and 5): size-independent properties of a 60-step random-action rollout with resets,
     mass/damping/armature DR, push perturbations forced on, and -- config 5 -- friction DR (divergent per-env
     contact sets)."""
     from hip_backend import make_env
-    env = make_env(N, force_perturb_start=True, friction_dr=friction_dr)
+    env = make_env(N, force_perturb_start=True, friction_dr=friction_dr, pipeline=pipeline)
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(42)
     resets = 0
@@ -308,11 +315,11 @@ def test_ppo_consumer_drives_the_env():
         assert 0.0 <= s["mean_reward"] <= 2.0
 
 
-@pytest.mark.parametrize("N", [1, 3, 100])
-def test_small_and_odd_env_counts(N, task_const):
-    """Ragged sizes: the grid is exactly N one-wave workgroups; compare with the oracle after a few steps."""
+@pytest.mark.parametrize("N", [1, 3, 17, 100])
+def test_small_and_odd_env_counts(N, task_const, pipeline):
+    """Ragged sizes (the quad kernel's last wave is partly empty: 16 envs per wave); compare with the oracle after a few steps."""
     from hip_backend import make_env
-    env = make_env(N)
+    env = make_env(N, pipeline=pipeline)
     ora = _oracle_like(env, task_const)
     g = torch.Generator().manual_seed(N)
     for t in range(5):
@@ -362,24 +369,33 @@ def test_state_dict_roundtrip_resumes_bitwise():
         assert torch.equal(o[0]["obs"], r[0]) and torch.equal(env2.rew_buf, r[1]) and torch.equal(env2.reset_buf, r[2])
 
 
-def test_self_collision_vs_oracle(task_const, model):
-    """SURVEY row f-1 on the device: legs rolled inwards by 0.05..0.25 rad in flight (up to centimetres of overlap, i.e.
-    kilonewtons from the 1e5 N/m penalty).  After one substep the net contact forces of the colliding links agree
-    with the oracle to 1e-3 relative and the joint state to 1e-5; the stiff explicit penalty then amplifies rounding
-    differences, so four more substeps are only held to 2e-2 rad (in the task such a contact ends the episode at
-    once)."""
-    from hip_backend import make_env
+def _crossed_legs(N, symmetric):
+    """Joint angles of the self-collision sweeps: hips rolled inwards by 0.05..0.25 rad."""
     from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
-    N = 64
-    env = make_env(N, randomize=False)
-    b = env._buf
-    b["root_states"][:, 0:2] = 0
-    b["root_states"][:, 2] = 3.0
     q = torch.tensor(INITIAL_DOF_POS).repeat(N, 1)
     roll = torch.linspace(0.05, 0.25, N)
     q[:, 1] = -roll
     q[:, 7] = roll
-    b["dof_state"][..., 0] = q.cuda()
+    if not symmetric:
+        q[:, 6] = 0.15            # right hip yawed and pitched: the two legs' capsule axes are skew lines at >= 8 cm
+        q[:, 8] += 0.25
+    return q
+
+
+def test_self_collision_vs_oracle(task_const, model, pipeline):
+    """SURVEY row f-1 on the device: legs rolled inwards in flight (centimetres of overlap, i.e. kilonewtons from the
+    1e5 N/m penalty), the right leg yawed and pitched so that no two capsule axes are parallel or intersect (those cases
+    are ill-conditioned by nature: see the symmetric test below).  After one substep the net contact forces of the colliding
+    links agree with the oracle to 1e-3 relative and the joint state to 1e-5; the stiff explicit penalty then amplifies
+    rounding differences, so four more substeps are only held to 2e-2 rad (in the task such a contact ends the episode at
+    once)."""
+    from hip_backend import make_env
+    N = 64
+    env = make_env(N, randomize=False, pipeline=pipeline)
+    b = env._buf
+    b["root_states"][:, 0:2] = 0
+    b["root_states"][:, 2] = 3.0
+    b["dof_state"][..., 0] = _crossed_legs(N, symmetric=False).cuda()
     b["dof_state"][..., 1] = 0
     ora = _oracle_like(env, task_const)
     tau = torch.zeros(N, 33)
@@ -396,6 +412,33 @@ def test_self_collision_vs_oracle(task_const, model):
         ora.simulate(tau.numpy())
     torch.cuda.synchronize()
     assert np.abs(env.dof_pos.cpu().numpy() - ora.buf["dof_state"][:, :, 0]).max() < 2e-2
+
+
+def test_self_collision_of_mirrored_legs_is_mirrored(pipeline):
+    """The degenerate case: exactly mirror-symmetric legs make the two foot capsules (and the two ankle capsules) exactly
+    parallel.  The written decision puts the contact of parallel capsules in the middle of their overlap, so a mirrored
+    pose gets a mirrored response on every platform: left and right joint rates are mirror images and the base does not
+    yaw.  (With the textbook closest-point rule the contact sat at whichever end rounding chose.)  Envs whose shank axes
+    intersect (roll > ~0.17 rad: normal direction undefined) are left out."""
+    from hip_backend import make_env
+    N = 64
+    env = make_env(N, randomize=False, pipeline=pipeline)
+    b = env._buf
+    b["root_states"][:, 0:2] = 0
+    b["root_states"][:, 2] = 3.0
+    b["dof_state"][..., 0] = _crossed_legs(N, symmetric=True).cuda()
+    b["dof_state"][..., 1] = 0
+    env.simulate(torch.zeros(N, 33, device="cuda"))
+    torch.cuda.synchronize()
+    keep = torch.linspace(0.05, 0.25, N) < 0.16
+    qd = env.dof_vel.cpu()[keep]
+    cf = env.contact_forces.cpu()[keep]
+    assert float(cf.norm(dim=2).max()) > 1000.0                     # feet and ankles are pressed into each other
+    # TOCABI's leg joints: yaw, roll, pitch, pitch, pitch, roll; a mirrored motion flips the sign of yaw and roll rates
+    sign = torch.tensor([-1.0, -1.0, 1.0, 1.0, 1.0, -1.0])
+    assert float((qd[:, 0:6] - sign * qd[:, 6:12]).abs().max()) < 5e-2      # (the model is mirror-symmetric to ~1 % only; the end-point rule gave 0.9 rad/s)
+    assert float(env.root_states.cpu()[keep][:, 12].abs().max()) < 2e-2        # no yaw rate of the base
+    assert float(env.root_states.cpu()[keep][:, 8].abs().max()) < 2e-2         # no sideways velocity either
 
 
 # ---------------------------------------------------------------------------------------------- terrain (row f-4)

@@ -10,9 +10,16 @@ from oracle import parity as P
 from oracle.oracle import OracleSim
 
 
-def test_task_logic_bitwise_vs_reference_goldens(task_const):
+@pytest.fixture(params=[False, True], ids=["wave-per-env", "quad"])
+def quad(request):
+    """Both kernel generations run the same checks: the fused wave-per-env kernel (dw_task.h + dw_physics.h) and the split
+    pipeline around the quad physics kernel (dw_quad*.h, 4 lanes per env, one fiber per lane on the host)."""
+    return request.param
+
+
+def test_task_logic_bitwise_vs_reference_goldens(task_const, quad):
     g = R.load("task_logic_frozen.npz")
-    be = EmulBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
+    be = EmulBackend(int(g["N"]), task_const, quad=quad, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
     for t, ref, got in R.replay(g, be):
         exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
         if "obs_history" in ref:
@@ -23,10 +30,10 @@ def test_task_logic_bitwise_vs_reference_goldens(task_const):
     assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
 
 
-def test_terrain_curriculum_bitwise_vs_reference_golden(task_const):
+def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, quad):
     """Row f-4 through the kernel source: level changes, tile origins and spawn jitter of the reference's curriculum."""
     g = R.load("terrain_logic_frozen.npz")
-    be = EmulBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
+    be = EmulBackend(int(g["N"]), task_const, quad=quad, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
                      terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]))
     for t, ref, got in R.replay(g, be):
         ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
@@ -37,14 +44,14 @@ def test_terrain_curriculum_bitwise_vs_reference_golden(task_const):
         assert np.array_equal(g["step_env_origins"][t], got["env_origins"]), t
 
 
-def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const):
+def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, quad):
     """Same libm on both sides here, so with physics frozen the kernel body and the oracle agree on every bit,
     in-kernel Philox noise included (noise = None)."""
     g = R.load("task_logic_frozen.npz")
     N = int(g["N"])
     from replay import OracleBackend
     a = OracleBackend(N, task_const, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
-    b = EmulBackend(N, task_const, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
+    b = EmulBackend(N, task_const, quad=quad, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
     init = {k[5:]: v for k, v in g.items() if k.startswith("init_")}
     a.load_buffers(init)
     b.load_buffers(init)
@@ -59,13 +66,13 @@ def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const):
             assert np.array_equal(a.read_buffers()[k], b.read_buffers()[k]), k
 
 
-def test_whole_step_tracks_oracle_goldens(task_const):
+def test_whole_step_tracks_oracle_goldens(task_const, quad):
     """Physics differs from the oracle only in summation order (Cholesky solve vs explicit inverse, fused
     Gauss-Seidel update).  Stated tolerance, contacts active, random torques: after 10 policy steps (20 substeps)
     |dq| <= 1e-4 rad, |dqd| <= 2e-2 rad/s (0.5 % of the 4.03 rad/s joint-speed limit), root pose <= 1e-4; the trajectories then separate chaotically, so
     beyond that only a sanity bound and the reset pattern are held."""
     g = R.load("whole_step_oracle.npz")
-    be = EmulBackend(int(g["N"]), task_const, randomize_dof_on_reset=0, torch_gpu_div=0)
+    be = EmulBackend(int(g["N"]), task_const, quad=quad, randomize_dof_on_reset=0, torch_gpu_div=0)
     for t, ref, got in R.replay(g, be):
         dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
         dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
@@ -77,10 +84,10 @@ def test_whole_step_tracks_oracle_goldens(task_const):
         assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
 
 
-def test_physics_substep_vs_oracle_random_flight():
+def test_physics_substep_vs_oracle_random_flight(quad):
     rng = np.random.default_rng(1)
     N = 16
-    A, B = OracleSim(N), EmulSim(N)
+    A, B = OracleSim(N), EmulSim(N, quad=quad)
     A.buf["root_states"][:, 0:3] = rng.normal(size=(N, 3)) + np.array([0, 0, 3])
     q = rng.normal(size=(N, 4))
     A.buf["root_states"][:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
@@ -123,7 +130,55 @@ def _gate_roundtrip(make, N=40):
     return sim.buf["gate_acc"].copy()
 
 
-def test_perturbation_gate_latches_identically(task_const):
+def test_perturbation_gate_latches_identically(task_const, quad):
     a = _gate_roundtrip(lambda N: OracleSim(N, task_const=task_const, debug_freeze_physics=1))
-    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, debug_freeze_physics=1))
+    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, quad=quad, debug_freeze_physics=1))
     assert np.array_equal(a, b)
+
+
+def _crossed(N, symmetric):
+    from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
+    q = np.tile(np.asarray(INITIAL_DOF_POS, np.float32), (N, 1))
+    roll = np.linspace(0.05, 0.25, N).astype(np.float32)
+    q[:, 1] = -roll
+    q[:, 7] = roll
+    if not symmetric:
+        q[:, 6] = 0.15
+        q[:, 8] += 0.25
+    return q
+
+
+def test_self_collision_vs_oracle(quad):
+    """Row f-1 through the kernel source: skew capsule axes (well-conditioned), one substep: forces 1e-3 relative, state 1e-5."""
+    N = 48
+    A, B = OracleSim(N), EmulSim(N, quad=quad)
+    for s in (A, B):
+        s.buf["root_states"][:, 0:2] = 0
+        s.buf["root_states"][:, 2] = 3.0
+        s.buf["dof_state"][:, :, 0] = _crossed(N, False)
+    tau = np.zeros((N, 33), np.float32)
+    A.simulate(tau); B.simulate(tau)
+    ca, cb = A.buf["contact_forces"], B.buf["contact_forces"]
+    assert (np.linalg.norm(ca, axis=2) > 1.0).any(axis=1).sum() > N // 2
+    assert np.abs(ca - cb).max() <= 1e-3 * np.abs(ca).max()
+    assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 0].max() < 1e-5
+
+
+@pytest.mark.parametrize("which", ["oracle", "wave-per-env", "quad"])
+def test_mirrored_legs_get_a_mirrored_response(which):
+    """Exactly parallel capsules (mirror-symmetric legs): contact in the middle of the overlap, so the response is mirrored
+    -- joint rates of the two legs are mirror images, the base neither yaws nor drifts sideways (the textbook closest-point
+    rule put the contact at whichever end rounding chose).  Envs whose shank axes intersect are left out."""
+    N = 40
+    sim = OracleSim(N) if which == "oracle" else EmulSim(N, quad=(which == "quad"))
+    sim.buf["root_states"][:, 0:2] = 0
+    sim.buf["root_states"][:, 2] = 3.0
+    sim.buf["dof_state"][:, :, 0] = _crossed(N, True)
+    sim.simulate(np.zeros((N, 33), np.float32))
+    keep = np.linspace(0.05, 0.25, N) < 0.16
+    qd = sim.buf["dof_state"][keep][:, :, 1]
+    assert np.linalg.norm(sim.buf["contact_forces"][keep], axis=2).max() > 1000.0
+    sign = np.array([-1.0, -1.0, 1.0, 1.0, 1.0, -1.0], np.float32)
+    assert np.abs(qd[:, 0:6] - sign * qd[:, 6:12]).max() < 5e-2        # (the model itself is mirror-symmetric to ~1 % only; the end-point rule gave 0.9 rad/s)
+    assert np.abs(sim.buf["root_states"][keep][:, 12]).max() < 2e-2
+    assert np.abs(sim.buf["root_states"][keep][:, 8]).max() < 2e-2
