@@ -41,11 +41,36 @@ struct alignas(16) F4 { float x, y, z, w; };
 DQ_HD F4 mk4(float x, float y, float z, float w) { F4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 // One wave's LDS: body slots [body][quad][position], position = (env + 4 * owner lane) & 15 so that the four lanes of a
-// quad, which work on four different bodies, fall on different banks for 16-byte accesses.
+// quad, which work on four different bodies, fall on different banks for 16-byte accesses; and the hot tables.
 struct alignas(16) QLds {
-    F4 slot[NB * 4][EPW];
-    F4 prox[8 * 2][EPW];          // self-collision proxy end points (common frame), written during kinematics
+    F4   slot[NB * 4][EPW];
+    QHot hot;
 };
+static_assert(sizeof(QLds) <= 40960, "QLds must leave room for 4 waves per CU (160 KB of LDS)");
+
+// 16-byte LDS accesses that stay 16 bytes wide: without the opaque touch the compiler narrows a load whose .w is unused to
+// ds_read_b96, which costs twice the LDS cycles of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
+#if defined(__HIPCC__)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+DQ_HD F4 ld4(const F4 &p) {
+    v4f_t r = *reinterpret_cast<const v4f_t *>(&p);
+    asm volatile("" : "+v"(r));
+    return mk4(r.x, r.y, r.z, r.w);
+}
+#else
+DQ_HD F4 ld4(const F4 &p) { return p; }
+#endif
+DQ_HD int f2i(float f) { return __builtin_bit_cast(int, f); }
+
+// copies the hot tables from the device-resident model into LDS (once per kernel)
+DQ_HD void stage_hot(QLds &L, const QuadModel &QM) {
+    const int l = lane_id();
+    const F4 *src = reinterpret_cast<const F4 *>(&QM.hot);
+    F4 *dst = reinterpret_cast<F4 *>(&L.hot);
+    constexpr int NQ = (int)(sizeof(QHot) / 16);
+    for (int i = l; i < NQ; i += 64) dst[i] = src[i];
+    wave_sync();
+}
 
 // What a lane keeps in registers across the phases of a step.
 struct QLane {
@@ -54,7 +79,24 @@ struct QLane {
     float mu;
     float warm[12];                          // impulses of the 4 corners of "my" foot (foot j & 1), from the previous substep
     float footF[3];                          // non-sole contact force on my foot's sole Gym body (lanes 0, 1)
+    int   stamp_base;                        // profiling builds only
 };
+
+// sin and cos for |x| up to a few turns (joint half-angles): Cody-Waite reduction to [-pi/4, pi/4], the classic single-
+// precision minimax polynomials there (~1 ulp).  libm's sincosf spends >100 instructions on arguments this code never sees.
+DQ_HD void sincos_fast(float x, float *s, float *c) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.5707962512969971f, x);
+    r = fmaf(k, -7.5497894158615964e-08f, r);
+    const float r2 = r * r;
+    const float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * (-1.9515295891e-4f)));
+    const float cp = 1.0f + r2 * (-0.5f + r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f)));
+    const int q = (int)k & 3;
+    float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    if (q & 2) ss = -ss;
+    if ((q + 1) & 2) cc = -cc;
+    *s = ss; *c = cc;
+}
 
 DQ_HD void qmul(const float *a, const float *b, float *o) {     // xyzw
     const float x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
@@ -71,14 +113,16 @@ template <int N> DQ_HD void quad_bcast_arr(int xl, const float (&s)[N], float (&
     else if (xl == 2) { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<2>(s[i]); }
     else { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<3>(s[i]); }
 }
-// lanes whose running state some lane of the quad fetches in outward step s (bit xl), from the tables: wave-uniform
-DQ_HD int fetch_mask(const QuadModel &QM, int s) {
-    int m = 0;
-    DQ_UNROLL for (int l = 0; l < 4; ++l) { const int p = QM.fk[s][l].body >= 0 ? QM.fk[s][l].psrc : 0; if (p >= 2) m |= 1 << (p - 2); }
-    return m;
-}
 
+// Profiling builds (-DDQ_STAMPS) record the clock at phase boundaries of wave 0 into the free tail of gate_acc (words
+// 200..): tools/phase_stamps.py.  Never defined in the shipped library.
+#if defined(DQ_STAMPS) && defined(__HIPCC__)
+#define DQ_STAMP(B, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) (B).gate_acc[200 + (n)] = (int64_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define DQ_STAMP(B, n) do { } while (0)
+#endif
 #define DQ_SLOT(b, q, p) L.slot[(b) * 4 + (q)][(p)]
+#define DQ_LD(b, q, p) ld4(L.slot[(b) * 4 + (q)][(p)])
 
 // Ground penalty force of one primitive of body b (dw_physics.h K4).  R, x: body rotation / origin relative to O; v: body
 // twist about O.  Returns the force in F and the contact point relative to O in xr.
@@ -269,44 +313,67 @@ DQ_HD bool capsule_pair(const float *a0, const float *a1, float ra, const float 
 
 // ------------------------------------------------------------------------------------------------
 // The substep.  On entry every body's slot holds quad 0 = {q, qd, tt, dd} with tt = tau - damping * qd and
-// dd = armature + dt * damping (the caller's prologue), X.root the base state, X.warm the warm-start impulses.
-// On exit: slot quad 0 = {q, qd, *, *} of the new state, X.root, X.warm updated; with `last`, the net contact forces of
-// the substep are written to B.contact_forces.  push: world x/y force on the base COM.
+// dd = armature + dt * damping (the caller's prologue), X.root the base state, X.warm the warm-start impulses, and the hot
+// tables are staged (stage_hot).  On exit: slot quad 0 = {q, qd, *, *} of the new state, X.root, X.warm updated; with `last`,
+// the net contact forces of the substep are written to B.contact_forces.  push: world x/y force on the base COM.
 // ------------------------------------------------------------------------------------------------
+struct FkHot { float pos[3], axis[3], vmax, qlo, qhi; int body, psrc, flags, scm; };
+DQ_HD FkHot fk_hot(const QLds &L, int s, int j) {
+    const F4 *r = reinterpret_cast<const F4 *>(L.hot.fk[s][j]);
+    const F4 a = ld4(r[0]), b = ld4(r[1]), c = ld4(r[2]);
+    FkHot h;
+    h.pos[0] = a.x; h.pos[1] = a.y; h.pos[2] = a.z;
+    const int bits = f2i(a.w);
+    h.body = (bits & 255) == 255 ? -1 : (bits & 255);
+    h.psrc = (bits >> 8) & 15; h.flags = (bits >> 12) & 3; h.scm = (bits >> 16) & 255;
+    h.axis[0] = b.x; h.axis[1] = b.y; h.axis[2] = b.z; h.vmax = b.w;
+    h.qlo = c.x; h.qhi = c.y;
+    return h;
+}
+
+DQ_HD int sched_body(const QLds &L, int s, int j) {
+    const int bits = f2i(L.hot.fk[s][j][3]);
+    return (bits & 255) == 255 ? -1 : (bits & 255);
+}
+
 template <bool TERRAIN>
 DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const PhysParams &P, QLane &X, const DwBuffers &B,
                         float push_x, float push_y, bool last) {
-    const float dt = P.dt;
-    const int j = X.j, T = QM.nsteps;
+    const float dt = P.dt, inv_dt = 1.0f / P.dt;
+    const int j = X.j, T = L.hot.misc[0];
+    const int SB = X.stamp_base; (void)SB;
+    DQ_STAMP(B, SB + 0);
     const int e = X.env;
+    const float *mscale_e = B.mass_scale + (size_t)DW_NUM_BODIES * e;
 
     // ---- base kinematics (every lane of the quad, redundantly) ----
-    float qn[4], R0[9], ww[3], vo[3];
+    float qn[4], R0[9], ww[3], vo[3], bcom[3];
     {
         const float qx = X.root[3], qy = X.root[4], qz = X.root[5], qw = X.root[6];
-        const float n = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
-        qn[0] = qx / n; qn[1] = qy / n; qn[2] = qz / n; qn[3] = qw / n;
+        const float ninv = dw::rsqrt_nr(qx * qx + qy * qy + qz * qz + qw * qw);
+        qn[0] = qx * ninv; qn[1] = qy * ninv; qn[2] = qz * ninv; qn[3] = qw * ninv;
         quat_to_mat(qn, R0);
-        DQ_UNROLL for (int i = 0; i < 3; ++i) { ww[i] = X.root[10 + i]; vo[i] = X.root[7 + i]; }
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { ww[i] = X.root[10 + i]; vo[i] = X.root[7 + i]; bcom[i] = L.hot.base[i]; }
         if (P.vel_at_com) {
             float rc[3], t[3];
-            m3v(R0, QM.base_com, rc);
+            m3v(R0, bcom, rc);
             cross3(ww, rc, t);
             vo[0] -= t[0]; vo[1] -= t[1]; vo[2] -= t[2];
         }
     }
 
+    DQ_STAMP(B, SB + 1);
     // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist. ----
     float footR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, footx[3] = {0, 0, 0};      // pose of my sole body (lanes 0, 1)
     {
         float qr[4] = {0, 0, 0, 1}, Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xr_[3] = {0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
         for (int s = 0; s < T; ++s) {
-            const QFkRec &rc = QM.fk[s][j];
+            const FkHot rc = fk_hot(L, s, j);
             const int b = rc.body, psrc = rc.psrc;
             // limbs that start below another lane's body fetch that lane's running state (still in its registers)
             float fq[4], fx[3], fv[6];
             bool fetched = false;
-            const int fm = fetch_mask(QM, s);
+            const int fm = L.hot.fmask[s];
             if (fm) {
                 for (int xl = 0; xl < 4; ++xl)
                     if ((fm >> xl) & 1) {
@@ -331,11 +398,11 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     DQ_UNROLL for (int i = 0; i < 3; ++i) xr_[i] = fx[i];
                     DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
                 }
-                const F4 in = DQ_SLOT(b, 0, X.pos);            // {q, qd, tt, dd}
+                const F4 in = DQ_LD(b, 0, X.pos);            // {q, qd, tt, dd}
                 float sn, cs;
-                sincosf(0.5f * in.x, &sn, &cs);
+                sincos_fast(0.5f * in.x, &sn, &cs);
                 float qj[4] = {rc.axis[0] * sn, rc.axis[1] * sn, rc.axis[2] * sn, cs};
-                if (rc.flags & 1) qmul(rc.q0, qj, qj);
+                if (rc.flags & 1) qmul(QM.fk[s][j].q0, qj, qj);          // (two bodies of the model: the hands)
                 float x[3], t[3];
                 m3v(Rr, rc.pos, t);
                 DQ_UNROLL for (int i = 0; i < 3; ++i) x[i] = xr_[i] + t[i];
@@ -353,92 +420,130 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     DQ_UNROLL for (int i = 0; i < 9; ++i) footR[i] = Rr[i];
                     DQ_UNROLL for (int i = 0; i < 3; ++i) footx[i] = x[i];
                 }
-                const int scm = rc.flags >> 8;
-                if (scm) {
-                    for (int p = 0; p < 8; ++p)
-                        if ((scm >> p) & 1) {
-                            float p0[3], p1[3];
-                            m3v(Rr, QM.proxy_p0[p], p0);
-                            m3v(Rr, QM.proxy_p1[p], p1);
-                            L.prox[2 * p][X.el] = mk4(x[0] + p0[0], x[1] + p0[1], x[2] + p0[2], 0.0f);
-                            L.prox[2 * p + 1][X.el] = mk4(x[0] + p1[0], x[1] + p1[1], x[2] + p1[2], 0.0f);
-                        }
-                }
             }
         }
     }
     wave_sync();
 
-    // ---- self-collision (leg against leg): lane a tests left proxy a against the right-leg proxies.  The common case is
-    //      "nothing touches": then the only cost is the distance tests.  If any env of the wave has a touching pair, the
-    //      two leg lanes of every env recompute all pairs and keep the wrenches on their own bodies. ----
+    DQ_STAMP(B, SB + 2);
+    // ---- self-collision (leg against leg).  Lane k builds the end points of left proxy k and right proxy k from their
+    //      bodies' slots; left proxy k is then tested against the four right proxies (DPP broadcasts).  The common case is
+    //      "nothing touches": then the only cost is the distance tests.  If any env of the wave has a touching pair, the two
+    //      leg lanes of every env recompute all pairs and keep the wrenches on their own bodies. ----
     bool sc_any = false;
     float scW[4][6], scF[4][3];
     DQ_UNROLL for (int p = 0; p < 4; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) scF[p][i] = 0.0f; }
-    if (P.self_collision && QM.nproxy_l > 0) {
+    const int npl = L.hot.misc[2], npr = L.hot.misc[3];
+    auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
+        const F4 *pr = reinterpret_cast<const F4 *>(L.hot.prox[p]);
+        const F4 c0 = ld4(pr[0]), c1 = ld4(pr[1]);
+        const int bits = f2i(c1.w);
+        const int bp = bits & 255, posp = (X.el + 4 * ((bits >> 16) & 3)) & 15;
+        const F4 q4 = DQ_LD(bp, 0, posp), x4 = DQ_LD(bp, 1, posp);
+        const float qb[4] = {q4.x, q4.y, q4.z, q4.w}, l0[3] = {c0.x, c0.y, c0.z}, l1[3] = {c1.x, c1.y, c1.z};
+        float Rb[9], t0[3], t1[3];
+        quat_to_mat(qb, Rb);
+        m3v(Rb, l0, t0);
+        m3v(Rb, l1, t1);
+        p0w[0] = x4.x + t0[0]; p0w[1] = x4.y + t0[1]; p0w[2] = x4.z + t0[2];
+        p1w[0] = x4.x + t1[0]; p1w[1] = x4.y + t1[1]; p1w[2] = x4.z + t1[2];
+    };
+    auto proxy_body = [&](int p) { return f2i(L.hot.prox[p][7]) & 255; };
+    auto proxy_gym = [&](int p) { return (f2i(L.hot.prox[p][7]) >> 8) & 255; };
+    auto proxy_pos = [&](int p) { return (X.el + 4 * ((f2i(L.hot.prox[p][7]) >> 16) & 3)) & 15; };
+    if (P.self_collision && npl > 0) {
+        float A0[3] = {0, 0, 0}, A1[3] = {0, 0, 0}, B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0};
+        float ra = 0.0f, rb = 0.0f;
+        if (j < npl) { proxy_ends(j, A0, A1); ra = L.hot.prox[j][3]; }
+        if (j < npr) { proxy_ends(4 + j, B0, B1); rb = L.hot.prox[4 + j][3]; }
+        const float da[3] = {A1[0] - A0[0], A1[1] - A0[1], A1[2] - A0[2]};
+        // wrench and force on my left proxy (WA) and, from my pairs, on each right proxy (WB[pb])
+        float WA[6] = {0, 0, 0, 0, 0, 0}, FA[3] = {0, 0, 0}, WB[4][6], FB[4][3];
+        DQ_UNROLL for (int p = 0; p < 4; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) WB[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) FB[p][i] = 0.0f; }
         bool hit = false;
-        if (j < QM.nproxy_l) {
-            const F4 a0 = L.prox[2 * j][X.el], a1 = L.prox[2 * j + 1][X.el];
-            const float A0[3] = {a0.x, a0.y, a0.z}, A1[3] = {a1.x, a1.y, a1.z};
-            const float da[3] = {A1[0] - A0[0], A1[1] - A0[1], A1[2] - A0[2]};
-            for (int pb = 0; pb < QM.nproxy_r; ++pb) {
-                const F4 b0 = L.prox[2 * (4 + pb)][X.el], b1 = L.prox[2 * (4 + pb) + 1][X.el];
-                const float B0[3] = {b0.x, b0.y, b0.z}, B1[3] = {b1.x, b1.y, b1.z};
-                // squared distance of the two segments against (ra + rb)^2
-                const float db[3] = {B1[0] - B0[0], B1[1] - B0[1], B1[2] - B0[2]};
-                const float r[3] = {A0[0] - B0[0], A0[1] - B0[1], A0[2] - B0[2]};
+        DQ_UNROLL for (int pb = 0; pb < 4; ++pb) {
+            float b0[3], b1[3];
+            const float rbb = pb == 0 ? quad_bcast<0>(rb) : (pb == 1 ? quad_bcast<1>(rb) : (pb == 2 ? quad_bcast<2>(rb) : quad_bcast<3>(rb)));
+            DQ_UNROLL for (int i = 0; i < 3; ++i) {
+                b0[i] = pb == 0 ? quad_bcast<0>(B0[i]) : (pb == 1 ? quad_bcast<1>(B0[i]) : (pb == 2 ? quad_bcast<2>(B0[i]) : quad_bcast<3>(B0[i])));
+                b1[i] = pb == 0 ? quad_bcast<0>(B1[i]) : (pb == 1 ? quad_bcast<1>(B1[i]) : (pb == 2 ? quad_bcast<2>(B1[i]) : quad_bcast<3>(B1[i])));
+            }
+            if (j < npl && pb < npr) {
+                const float db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+                const float r[3] = {A0[0] - b0[0], A0[1] - b0[1], A0[2] - b0[2]};
                 float sa, sb;
                 seg_seg(da, db, r, &sa, &sb);
-                float d2 = 0.0f;
-                DQ_UNROLL for (int i = 0; i < 3; ++i) { const float n = (A0[i] + sa * da[i]) - (B0[i] + sb * db[i]); d2 += n * n; }
-                const float rr = QM.proxy_r[j] + QM.proxy_r[4 + pb] + 1e-4f;       // margin: the exact test follows
-                hit = hit || (d2 < rr * rr);
+                float ca[3], cb[3], n[3];
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { ca[i] = A0[i] + sa * da[i]; cb[i] = b0[i] + sb * db[i]; n[i] = ca[i] - cb[i]; }
+                const float d2 = dot3(n, n), rr = ra + rbb;
+                if (d2 < rr * rr && d2 > 1e-12f) {            // overlap (and a defined normal): penalty force along it, dw_physics.h K4b
+                    const float dist = sqrtf(d2), depth = rr - dist;
+                    const int ba = proxy_body(j), posa = proxy_pos(j), bb = proxy_body(4 + pb), posb = proxy_pos(4 + pb);
+                    const F4 va2 = DQ_LD(ba, 2, posa), va3 = DQ_LD(ba, 3, posa), vb2 = DQ_LD(bb, 2, posb), vb3 = DQ_LD(bb, 3, posb);
+                    const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) n[i] /= dist;
+                    float ta[3], tb[3];
+                    cross3(va, ca, ta);
+                    cross3(vb, cb, tb);
+                    float vn = 0.0f;
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) vn += ((va[3 + i] + ta[i]) - (vb[3 + i] + tb[i])) * n[i];
+                    float fn = P.pen_k * depth - P.pen_c * vn;
+                    if (fn < 0.0f) fn = 0.0f;
+                    const float F[3] = {fn * n[0], fn * n[1], fn * n[2]}, Fm[3] = {-F[0], -F[1], -F[2]};
+                    float na[3], nb[3];
+                    cross3(ca, F, na);
+                    cross3(cb, Fm, nb);
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) {
+                        WA[i] += na[i]; WA[3 + i] += F[i]; FA[i] += F[i];
+                        WB[pb][i] += nb[i]; WB[pb][3 + i] += Fm[i]; FB[pb][i] += Fm[i];
+                    }
+                    hit = hit || fn > 0.0f;
+                }
             }
         }
         sc_any = wave_any(hit);
-        if (sc_any && j < 2) {
-            // my side: j = 0 left (force on A), j = 1 right (force on B = -F)
-            for (int pa = 0; pa < QM.nproxy_l; ++pa) {
-                const int ba = QM.proxy_body[pa];
-                const int posa = (X.el + 4 * QM.owner[ba]) & 15;
-                const F4 a0 = L.prox[2 * pa][X.el], a1 = L.prox[2 * pa + 1][X.el];
-                const F4 va2 = DQ_SLOT(ba, 2, posa), va3 = DQ_SLOT(ba, 3, posa);
-                const float A0[3] = {a0.x, a0.y, a0.z}, A1[3] = {a1.x, a1.y, a1.z}, va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z};
-                for (int pb = 0; pb < QM.nproxy_r; ++pb) {
-                    const int bb = QM.proxy_body[4 + pb];
-                    const int posb = (X.el + 4 * QM.owner[bb]) & 15;
-                    const F4 b0 = L.prox[2 * (4 + pb)][X.el], b1 = L.prox[2 * (4 + pb) + 1][X.el];
-                    const F4 vb2 = DQ_SLOT(bb, 2, posb), vb3 = DQ_SLOT(bb, 3, posb);
-                    const float B0[3] = {b0.x, b0.y, b0.z}, B1[3] = {b1.x, b1.y, b1.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
-                    float F[3], ca[3], cb[3];
-                    if (capsule_pair(A0, A1, QM.proxy_r[pa], B0, B1, QM.proxy_r[4 + pb], va, vb, P, F, ca, cb)) {
-                        const int mine = j == 0 ? pa : pb;
-                        const float sg = j == 0 ? 1.0f : -1.0f;
-                        const float Fs[3] = {sg * F[0], sg * F[1], sg * F[2]};
-                        float nb[3];
-                        cross3(j == 0 ? ca : cb, Fs, nb);
-                        DQ_UNROLL for (int p = 0; p < 4; ++p)
-                            if (p == mine) {
-                                DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[p][i] += nb[i]; scW[p][3 + i] += Fs[i]; scF[p][i] += Fs[i]; }
-                            }
-                    }
+        if (sc_any) {
+            // hand the wrenches to the owners: lane 0 takes the four left proxies' (one per lane), lane 1 the right proxies'
+            // (each the sum of the four lanes' pairs)
+            DQ_UNROLL for (int p = 0; p < 4; ++p) {
+                DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                    const float a = p == 0 ? quad_bcast<0>(WA[i]) : (p == 1 ? quad_bcast<1>(WA[i]) : (p == 2 ? quad_bcast<2>(WA[i]) : quad_bcast<3>(WA[i])));
+                    float t = WB[p][i];
+                    t += quad_xor1(t);
+                    t += quad_xor2(t);
+                    scW[p][i] = j == 0 ? a : t;
+                }
+                DQ_UNROLL for (int i = 0; i < 3; ++i) {
+                    const float a = p == 0 ? quad_bcast<0>(FA[i]) : (p == 1 ? quad_bcast<1>(FA[i]) : (p == 2 ? quad_bcast<2>(FA[i]) : quad_bcast<3>(FA[i])));
+                    float t = FB[p][i];
+                    t += quad_xor1(t);
+                    t += quad_xor2(t);
+                    scF[p][i] = j == 0 ? a : t;
                 }
             }
         }
     }
-
     wave_sync();      // the leg lanes read each other's slots above; the inward pass below overwrites them
 
+    DQ_STAMP(B, SB + 3);
     // ---- inward pass: articulated inertias and bias forces, in reverse schedule order ----
     float IA[21], pA[6], IP[21], pP[6];          // running and parked reflected inertia / bias
     DQ_UNROLL for (int i = 0; i < 21; ++i) { IA[i] = 0.0f; IP[i] = 0.0f; }
     DQ_UNROLL for (int i = 0; i < 6; ++i) { pA[i] = 0.0f; pP[i] = 0.0f; }
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     const int my_sole_gym = (j == 0) ? M.left_foot_gym : (j == 1 ? M.right_foot_gym : -1);
+    // the one per-env global value a step needs (the mass scale of the body's Gym body) is requested a step ahead
+    float ms_next = mscale_e[(f2i(L.hot.in[0][j][2]) >> 24) & 255];
     for (int s = 0; s < T; ++s) {
-        const QInRec &rc = QM.in[s][j];
-        const int b = rc.body;
-        const int flags = b >= 0 ? rc.flags : 0;
+        const F4 *hr = reinterpret_cast<const F4 *>(L.hot.in[s][j]);
+        const F4 h0 = ld4(hr[0]), h1 = ld4(hr[1]), h2 = ld4(hr[2]), h3 = ld4(hr[3]);
+        const int bits = f2i(h0.x);
+        const int b = (bits & 255) - 1;
+        const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
+        const int nin = (bits >> 12) & 3, ngym = (bits >> 14) & 3, ngeom = (bits >> 16) & 15, scm = (bits >> 24) & 255;
+        const int gymbits = f2i(h0.z);
+        const float ms0 = ms_next;
+        if (s + 1 < T) ms_next = mscale_e[(f2i(L.hot.in[s + 1][j][2]) >> 24) & 255];
         if (flags & 2) {                    // a finished chain is still waiting for its parent: park it
             DQ_UNROLL for (int i = 0; i < 21; ++i) IP[i] = IA[i];
             DQ_UNROLL for (int i = 0; i < 6; ++i) pP[i] = pA[i];
@@ -448,57 +553,64 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
         }
         // gathers (wave-uniform per step): child chains that ended on other lanes
-        {
-            const int g0 = QM.in[s][0].body >= 0 ? QM.in[s][0].gather : 0, g1 = QM.in[s][1].body >= 0 ? QM.in[s][1].gather : 0;
-            const int g2 = QM.in[s][2].body >= 0 ? QM.in[s][2].gather : 0, g3 = QM.in[s][3].body >= 0 ? QM.in[s][3].gather : 0;
-            if (g0 | g1 | g2 | g3) {
-                const int mine = b >= 0 ? rc.gather : 0;
-                DQ_UNROLL for (int src = 0; src < 4; ++src)
-                    DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
-                        const int code = src | (pk << 2) | 8;
-                        bool used = false, want = false;
-                        DQ_UNROLL for (int k = 0; k < 3; ++k) {
-                            used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
-                                   (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
-                            want = want || (((mine >> (4 * k)) & 15) == code);
+        if (L.hot.gany[s]) {
+            const int g0 = f2i(L.hot.in[s][0][1]), g1 = f2i(L.hot.in[s][1][1]), g2 = f2i(L.hot.in[s][2][1]), g3 = f2i(L.hot.in[s][3][1]);
+            const int mine = f2i(h0.y);
+            DQ_UNROLL for (int src = 0; src < 4; ++src)
+                DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
+                    const int code = src | (pk << 2) | 8;
+                    bool used = false, want = false;
+                    DQ_UNROLL for (int k = 0; k < 3; ++k) {
+                        used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
+                               (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
+                        want = want || (((mine >> (4 * k)) & 15) == code);
+                    }
+                    if (used) {
+                        DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                            const float v = pk ? IP[i] : IA[i];
+                            const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                            if (want) IA[i] += t;
                         }
-                        if (used) {
-                            DQ_UNROLL for (int i = 0; i < 21; ++i) {
-                                const float v = pk ? IP[i] : IA[i];
-                                const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-                                if (want) IA[i] += t;
-                            }
-                            DQ_UNROLL for (int i = 0; i < 6; ++i) {
-                                const float v = pk ? pP[i] : pA[i];
-                                const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-                                if (want) pA[i] += t;
-                            }
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                            const float v = pk ? pP[i] : pA[i];
+                            const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                            if (want) pA[i] += t;
                         }
                     }
-            }
+                }
         }
         if (b >= 0) {
-            const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
-            const float ms0 = B.mass_scale[(size_t)DW_NUM_BODIES * e + rc.in0_gym];
-            const float ms1 = rc.nin > 1 ? B.mass_scale[(size_t)DW_NUM_BODIES * e + rc.in1_gym] : 0.0f;
+            const F4 s0 = DQ_LD(b, 0, X.pos), s1 = DQ_LD(b, 1, X.pos), s2 = DQ_LD(b, 2, X.pos), s3 = DQ_LD(b, 3, X.pos);
+            const F4 ax4 = ld4(reinterpret_cast<const F4 *>(L.hot.fk[T - 1 - s][j])[1]);
+            const float axis[3] = {ax4.x, ax4.y, ax4.z};
             const float qb[4] = {s0.x, s0.y, s0.z, s0.w}, x[3] = {s1.x, s1.y, s1.z}, v[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
             const float qd = s1.w, tt = s2.w, dd = s3.w;
             float R[9];
             quat_to_mat(qb, R);
             float S[6];
-            m3v(R, rc.axis, S);
+            m3v(R, axis, S);
             cross3(x, S, S + 3);
             // rigid inertia, gyroscopic bias
             float Ao[6], ho[3], mass;
-            rigid_inertia(rc.nin, rc.in0_com, rc.in0_mass, rc.in0_I, ms0, rc.in1_com, rc.in1_mass, rc.in1_I, ms1, R, x, Ao, ho, &mass);
+            {
+                const float com0[3] = {h1.x, h1.y, h1.z}, I0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
+                if (nin > 1) {          // the two sole bodies carry a second (welded) inertial record
+                    const QInRec &rc = QM.in[s][j];
+                    const float ms1 = mscale_e[rc.in1_gym];
+                    rigid_inertia(2, com0, h1.w, I0, ms0, rc.in1_com, rc.in1_mass, rc.in1_I, ms1, R, x, Ao, ho, &mass);
+                } else {
+                    rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Ao, ho, &mass);
+                }
+            }
             add_rigid(IA, pA, Ao, ho, mass, v);
             // external forces: ground penalty of the non-sole primitives, self-collision; per Gym body for the report
             float cf[QMAX_GYM][3];
             DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
-            bool near_ground = rc.ngeom > 0 && (X.root[2] + x[2] < rc.bound);
-            if (TERRAIN) near_ground = rc.ngeom > 0;
+            bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
+            if (TERRAIN) near_ground = ngeom > 0;
             if (near_ground) {
-                for (int k = 0; k < rc.ngeom; ++k) {
+                const QInRec &rc = QM.in[s][j];
+                for (int k = 0; k < ngeom; ++k) {
                     float F[3], xr[3];
                     geom_force<TERRAIN>(M.geoms[rc.geom[k]], P, R, x, v, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
                     if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
@@ -511,21 +623,22 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     }
                 }
             }
-            if (sc_any && rc.sc_mask && j < 2) {
+            if (sc_any && scm && j < 2) {
                 DQ_UNROLL for (int p = 0; p < 4; ++p)
-                    if ((rc.sc_mask >> (p + 4 * j)) & 1) {
+                    if ((scm >> (p + 4 * j)) & 1) {
                         DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
-                        const int gy = QM.proxy_gym[p + 4 * j];
+                        const int gy = proxy_gym(p + 4 * j);
                         DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
-                            if (t < rc.ngym && rc.gyms[t] == gy) { cf[t][0] += scF[p][0]; cf[t][1] += scF[p][1]; cf[t][2] += scF[p][2]; }
+                            if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scF[p][0]; cf[t][1] += scF[p][1]; cf[t][2] += scF[p][2]; }
                     }
             }
             if (last) {
                 DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
-                    if (t < rc.ngym) {
-                        if (rc.gyms[t] == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
+                    if (t < ngym) {
+                        const int gy = (gymbits >> (8 * t)) & 255;
+                        if (gy == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
                         else if (X.valid) {
-                            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + rc.gyms[t]) * 3;
+                            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
                             dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
                         }
                     }
@@ -562,13 +675,14 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         }
     }
 
+    DQ_STAMP(B, SB + 4);
     // ---- base: gather the chains below the root, own inertia, external forces, inverse ----
     float Minv[36], a0[6];
     {
         float I0[21], p0[6];
         DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = 0.0f;
         DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = 0.0f;
-        const int g = QM.base_gather;
+        const int g = L.hot.misc[1];
         DQ_UNROLL for (int src = 0; src < 4; ++src)
             DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
                 const int code = src | (pk << 2) | 8;
@@ -586,14 +700,18 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             }
         const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
         float Ao[6], ho[3], mass;
-        const float ms = B.mass_scale[(size_t)DW_NUM_BODIES * e + QM.base_gym];
-        rigid_inertia(1, QM.base_com, QM.base_mass, QM.base_I, ms, QM.base_com, 0.0f, QM.base_I, 0.0f, R0, x0, Ao, ho, &mass);
+        const int base_gym = f2i(L.hot.base[10]), base_ngeom = f2i(L.hot.base[11]);
+        const float ms = mscale_e[base_gym];
+        {
+            const float bI[6] = {L.hot.base[4], L.hot.base[5], L.hot.base[6], L.hot.base[7], L.hot.base[8], L.hot.base[9]};
+            rigid_inertia(1, bcom, L.hot.base[3], bI, ms, bcom, 0.0f, bI, 0.0f, R0, x0, Ao, ho, &mass);
+        }
         add_rigid(I0, p0, Ao, ho, mass, v0);
         float cfb[3] = {0, 0, 0};
-        bool near_ground = QM.base_ngeom > 0 && (X.root[2] < QM.base_bound);
-        if (TERRAIN) near_ground = QM.base_ngeom > 0;
+        bool near_ground = base_ngeom > 0 && (X.root[2] < L.hot.base[12]);
+        if (TERRAIN) near_ground = base_ngeom > 0;
         if (near_ground) {
-            for (int k = 0; k < QM.base_ngeom; ++k) {
+            for (int k = 0; k < base_ngeom; ++k) {
                 float F[3], xr[3];
                 geom_force<TERRAIN>(M.geoms[QM.base_geom[k]], P, R0, x0, v0, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
                 if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
@@ -604,13 +722,13 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             }
         }
         if (last && j == 3 && X.valid) {
-            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + QM.base_gym) * 3;
+            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + base_gym) * 3;
             dst[0] = cfb[0]; dst[1] = cfb[1]; dst[2] = cfb[2];
         }
         {   // push on the base COM
             const float Fw[3] = {push_x, push_y, 0.0f};
             float xc[3], nb[3];
-            m3v(R0, QM.base_com, xc);
+            m3v(R0, bcom, xc);
             cross3(xc, Fw, nb);
             DQ_UNROLL for (int i = 0; i < 3; ++i) { p0[i] -= nb[i]; p0[3 + i] -= Fw[i]; }
         }
@@ -649,15 +767,16 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         }
     }
 
+    DQ_STAMP(B, SB + 5);
     // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
         for (int s = 0; s < T; ++s) {
-            const QFkRec &rc = QM.fk[s][j];
-            const int b = rc.body, psrc = rc.psrc;
+            const int bits = f2i(L.hot.fk[s][j][3]);
+            const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
             float fa[6], fv[6];
             bool fetched = false;
-            const int fm = fetch_mask(QM, s);
+            const int fm = L.hot.fmask[s];
             if (fm) {
                 for (int xl = 0; xl < 4; ++xl)
                     if ((fm >> xl) & 1) {
@@ -669,7 +788,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             if (b >= 0) {
                 if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = a0[i]; ar[3 + i] = a0[3 + i]; vr[i] = ww[i]; vr[3 + i] = vo[i]; } }
                 else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] = fa[i]; vr[i] = fv[i]; } }
-                const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+                const F4 s0 = DQ_LD(b, 0, X.pos), s1 = DQ_LD(b, 1, X.pos), s2 = DQ_LD(b, 2, X.pos), s3 = DQ_LD(b, 3, X.pos);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 const float Dinv = s0.w, u = s1.w, qd = s2.w;
                 float m[6], c[6];
@@ -684,7 +803,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         }
     }
     wave_sync();
-
+    DQ_STAMP(B, SB + 6);
     // ---- free base velocity; sole-corner gaps of my foot (foot f = j & 1; lanes f and f + 2 work on it together) ----
     float wwf[3], vowf[3];
     {
@@ -717,7 +836,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             }
             act[k] = phi < P.contact_offset;
             DQ_UNROLL for (int i = 0; i < 3; ++i) rk[k][i] = r[i];
-            vminr[k] = phi >= 0 ? -phi / dt : fminf(P.erp * (-phi) / dt, P.max_depen);
+            vminr[k] = phi >= 0 ? -phi * inv_dt : fminf(P.erp * (-phi) * inv_dt, P.max_depen);
         }
     }
     const bool any_active = wave_any(act[0] | act[1] | act[2] | act[3]);
@@ -733,12 +852,13 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             const int posf = (X.el + 4 * f) & 15;
             DQ_UNROLL for (int i = 1; i <= 6; ++i) {
                 const int b = 6 * f + i;
-                const F4 s0 = DQ_SLOT(b, 0, posf), s1 = DQ_SLOT(b, 1, posf), s2 = DQ_SLOT(b, 2, posf);
+                const F4 s0 = DQ_LD(b, 0, posf), s1 = DQ_LD(b, 1, posf), s2 = DQ_LD(b, 2, posf);
                 acc[0] += s0.x * s2.w; acc[1] += s0.y * s2.w; acc[2] += s0.z * s2.w;
                 acc[3] += s1.x * s2.w; acc[4] += s1.y * s2.w; acc[5] += s1.z * s2.w;
             }
             DQ_UNROLL for (int i = 0; i < 6; ++i) twf[i] = acc[i];
         }
+        DQ_STAMP(B, SB + 7);
         // ---- my 3 rows of W: responses of both feet to unit wrenches (components 3 part .. 3 part + 2) on foot f.
         //      Up the leg: d = -S'p, p += U d / D;  base: dv = -Minv p;  down both legs: qdd = (d - U'dv) / D, dv += S qdd ----
         float Wr[3][12];
@@ -748,7 +868,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             const int posf = (X.el + 4 * f) & 15;
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
                 const int b = 6 * f + i;
-                const F4 s0 = DQ_SLOT(b, 0, posf), s1 = DQ_SLOT(b, 1, posf), s2 = DQ_SLOT(b, 2, posf), s3 = DQ_SLOT(b, 3, posf);
+                const F4 s0 = DQ_LD(b, 0, posf), s1 = DQ_LD(b, 1, posf), s2 = DQ_LD(b, 2, posf), s3 = DQ_LD(b, 3, posf);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 DQ_UNROLL for (int c = 0; c < 3; ++c) {
                     const float d = -dot6(S, dp[c]);
@@ -770,7 +890,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 const int posg = (X.el + 4 * g) & 15;
                 DQ_UNROLL for (int i = 1; i <= 6; ++i) {
                     const int b = 6 * g + i;
-                    const F4 s0 = DQ_SLOT(b, 0, posg), s1 = DQ_SLOT(b, 1, posg), s2 = DQ_SLOT(b, 2, posg), s3 = DQ_SLOT(b, 3, posg);
+                    const F4 s0 = DQ_LD(b, 0, posg), s1 = DQ_LD(b, 1, posg), s2 = DQ_LD(b, 2, posg), s3 = DQ_LD(b, 3, posg);
                     const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                     DQ_UNROLL for (int c = 0; c < 3; ++c) {
                         const float ua = dot6(U, dv[c]);
@@ -781,6 +901,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) Wr[c][6 * g + r] = dv[c][r];
             }
         }
+        DQ_STAMP(B, SB + 8);
         // ---- 3x3 diagonal blocks of the Delassus matrix of my foot's corners: A_kk = J_k W_ff J_k' (frame-projected on
         //      terrain); what the solver needs of them: the three diagonal inverses and the couplings zx, zy, xy ----
         float invd[4][3], cpl[4][3];
@@ -788,11 +909,12 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             float Wff[6][6];       // rows 3 part.. are mine, the other three come from the partner lane (l ^ 2)
             DQ_UNROLL for (int r = 0; r < 3; ++r)
                 DQ_UNROLL for (int c = 0; c < 6; ++c) {
-                    const float mine = Wr[r][6 * f + c];
+                    const float mine = f ? Wr[r][6 + c] : Wr[r][c];
                     const float o = quad_xor2(mine);
                     Wff[r][c] = part ? o : mine;
                     Wff[3 + r][c] = part ? mine : o;
                 }
+            const float rreg = 1.0f / (1.0f + P.cfm);
             DQ_UNROLL for (int k = 0; k < 4; ++k) {
                 const float *r = rk[k];
                 float G[3][6];        // J_k W_ff, world axes: row a = W_lin row a + (-skew(r)) row a . W_ang
@@ -814,15 +936,17 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
                         Ak[a][c] = Tm[a][0] * frame[k][3 * c] + Tm[a][1] * frame[k][3 * c + 1] + Tm[a][2] * frame[k][3 * c + 2];
                 }
-                const float reg = 1.0f + P.cfm;
-                invd[k][0] = act[k] ? 1.0f / (Ak[0][0] * reg) : 0.0f;
-                invd[k][1] = act[k] ? 1.0f / (Ak[1][1] * reg) : 0.0f;
-                invd[k][2] = act[k] ? 1.0f / (Ak[2][2] * reg) : 0.0f;
+                invd[k][0] = act[k] ? dw::rcp_nr(Ak[0][0]) * rreg : 0.0f;
+                invd[k][1] = act[k] ? dw::rcp_nr(Ak[1][1]) * rreg : 0.0f;
+                invd[k][2] = act[k] ? dw::rcp_nr(Ak[2][2]) * rreg : 0.0f;
                 cpl[k][0] = Ak[0][2];     // x row, z column
                 cpl[k][1] = Ak[1][2];     // y row, z column
                 cpl[k][2] = Ak[1][0];     // y row, x column
             }
         }
+        // my rows of W as [own foot | other foot] so that the updates below index registers statically
+        float Wo[3][6], Wx[3][6];
+        DQ_UNROLL for (int r = 0; r < 3; ++r) DQ_UNROLL for (int c = 0; c < 6; ++c) { Wo[r][c] = f ? Wr[r][6 + c] : Wr[r][c]; Wx[r][c] = f ? Wr[r][c] : Wr[r][6 + c]; }
         // ---- start: tw = tw_free + W lambda0, lambda0 = warm-start impulses as foot wrenches ----
         float tw3[3];
         {
@@ -840,11 +964,12 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             float lo[6];
             DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
             DQ_UNROLL for (int r = 0; r < 3; ++r) {
-                float acc = twf[3 * part + r];
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wr[r][6 * f + c] * lam[c] + Wr[r][6 * (1 - f) + c] * lo[c];
+                float acc = part ? twf[3 + r] : twf[r];
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wo[r][c] * lam[c] + Wx[r][c] * lo[c];
                 tw3[r] = acc;
             }
         }
+        DQ_STAMP(B, SB + 9);
         // ---- projected Gauss-Seidel, block-Jacobi across the feet: corner kk of the left sole and corner kk of the right
         //      sole are updated together from the same snapshot, the four corners of a sole one after the other ----
         bool pair_on[4];
@@ -854,7 +979,8 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 if (pair_on[kk]) {
                     float o3[3];
                     DQ_UNROLL for (int i = 0; i < 3; ++i) o3[i] = quad_xor2(tw3[i]);
-                    const float *wv = part ? o3 : tw3, *lv = part ? tw3 : o3;
+                    float wv[3], lv[3];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { wv[i] = part ? o3[i] : tw3[i]; lv[i] = part ? tw3[i] : o3[i]; }
                     const float *r = rk[kk];
                     float vwld[3] = {lv[0] + wv[1] * r[2] - wv[2] * r[1], lv[1] + wv[2] * r[0] - wv[0] * r[2], lv[2] + wv[0] * r[1] - wv[1] * r[0]};
                     float vx0 = vwld[0], vy0 = vwld[1], vz = vwld[2];
@@ -892,12 +1018,13 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
                     DQ_UNROLL for (int rr = 0; rr < 3; ++rr) {
                         float acc = tw3[rr];
-                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wr[rr][6 * f + c] * lam[c] + Wr[rr][6 * (1 - f) + c] * lo[c];
+                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wo[rr][c] * lam[c] + Wx[rr][c] * lo[c];
                         tw3[rr] = acc;
                     }
                 }
             }
         }
+        DQ_STAMP(B, SB + 10);
         // ---- impulses -> wrench on my foot -> up my leg (leg lanes), base jump ----
         float dpb[6] = {0, 0, 0, 0, 0, 0};
         float Fs[3] = {0, 0, 0};
@@ -916,7 +1043,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             float dp[6] = {-Nm[0], -Nm[1], -Nm[2], -Fs[0], -Fs[1], -Fs[2]};
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
                 const int b = 6 * f + i;
-                const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+                const F4 s0 = DQ_LD(b, 0, X.pos), s1 = DQ_LD(b, 1, X.pos), s2 = DQ_LD(b, 2, X.pos), s3 = DQ_LD(b, 3, X.pos);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 const float d = -dot6(S, dp);
                 const float k = d * s0.w;
@@ -939,7 +1066,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         }
         if (last && part == 0 && X.valid) {
             float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
-            dst[0] = X.footF[0] + Fs[0] / dt; dst[1] = X.footF[1] + Fs[1] / dt; dst[2] = X.footF[2] + Fs[2] / dt;
+            dst[0] = X.footF[0] + Fs[0] * inv_dt; dst[1] = X.footF[1] + Fs[1] * inv_dt; dst[2] = X.footF[2] + Fs[2] * inv_dt;
         }
     } else if (last && part == 0 && X.valid) {
         float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
@@ -947,15 +1074,16 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
     }
     DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) X.warm[3 * k + i] = Pk[k][i];
 
-    // ---- outward pass 3: velocity jumps down the tree, final joint velocities, limits, semi-implicit Euler ----
+    DQ_STAMP(B, SB + 11);
+    // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0};
         for (int s = 0; s < T; ++s) {
-            const QFkRec &rc = QM.fk[s][j];
+            const FkHot rc = fk_hot(L, s, j);
             const int b = rc.body, psrc = rc.psrc;
             float fa[6];
             bool fetched = false;
-            const int fm = fetch_mask(QM, s);
+            const int fm = L.hot.fmask[s];
             if (fm) {
                 for (int xl = 0; xl < 4; ++xl)
                     if ((fm >> xl) & 1) {
@@ -967,25 +1095,18 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             if (b >= 0) {
                 if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = dqb[i]; }
                 else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fa[i]; }
-                const F4 s0 = DQ_SLOT(b, 0, X.pos), s1 = DQ_SLOT(b, 1, X.pos), s2 = DQ_SLOT(b, 2, X.pos), s3 = DQ_SLOT(b, 3, X.pos);
+                const F4 s0 = DQ_LD(b, 0, X.pos), s1 = DQ_LD(b, 1, X.pos), s2 = DQ_LD(b, 2, X.pos), s3 = DQ_LD(b, 3, X.pos);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 const float dq = (s1.w - dot6(U, ar)) * s0.w;
                 DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * dq;
                 float qd = s2.w + dq;
                 if (qd > rc.vmax) qd = rc.vmax;
                 if (qd < -rc.vmax) qd = -rc.vmax;
-                float q = B.dof_state[((size_t)ND * e + (b - 1)) * 2] ;
-                q = q + dt * qd;
-                if (q < rc.qlo) { q = rc.qlo; if (qd < 0) qd = 0; }
-                if (q > rc.qhi) { q = rc.qhi; if (qd > 0) qd = 0; }
-                DQ_SLOT(b, 0, X.pos) = mk4(q, qd, 0.0f, 0.0f);
-                if (X.valid) {
-                    B.dof_state[((size_t)ND * e + (b - 1)) * 2] = q;
-                    B.dof_state[((size_t)ND * e + (b - 1)) * 2 + 1] = qd;
-                }
+                DQ_SLOT(b, 0, X.pos) = mk4(rc.qlo, qd, rc.qhi, 0.0f);        // joint range and new velocity for integrate_joints
             }
         }
     }
+    DQ_STAMP(B, SB + 12);
     // ---- base: final velocity, clamps, pose update (dw_physics.h V2) ----
     {
         float wwn[3], von[3];
@@ -1010,12 +1131,13 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         if (P.vel_at_com) {
             float Rn[9], rcom[3], tt[3];
             quat_to_mat(qo, Rn);
-            m3v(Rn, QM.base_com, rcom);
+            m3v(Rn, bcom, rcom);
             cross3(wwn, rcom, tt);
             DQ_UNROLL for (int i = 0; i < 3; ++i) von[i] += tt[i];
         }
         DQ_UNROLL for (int i = 0; i < 3; ++i) { X.root[7 + i] = von[i]; X.root[10 + i] = wwn[i]; }
     }
+    DQ_STAMP(B, SB + 13);
 }
 
 // Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
@@ -1031,7 +1153,33 @@ DQ_HD void quad_lane_init(QLane &X, int wave_index, int num_envs, const PhysPara
     X.mu = friction * B.friction_scale[X.env];
     DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = 0.0f;
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
+    X.stamp_base = 0;
     (void)P;
+}
+
+// ---- joint-parallel phases.  Per-joint work that touches the Gym tensors runs over ITEMS (env, dof) = lane + 64 k of the
+// wave's 16 x 33 joints, so that a wave-instruction reads or writes consecutive addresses (the limb-per-lane mapping would
+// touch 64 different rows with 4-byte accesses); the item's lane reaches the owner's slot through the owner table. ----
+constexpr int QNI = (EPW * ND + 63) / 64;      // 9 items per lane
+struct JointItem { int ok, el, d, b, pos, env; };
+DQ_HD JointItem joint_item(const QLds &L, int wave_index, int num_envs, int lane, int k) {
+    JointItem it;
+    const int i = lane + 64 * k;
+    it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
+    const int eg = wave_index * EPW + it.el;
+    it.ok = (i < EPW * ND) && (eg < num_envs);
+    if (!(i < EPW * ND)) { it.el = 0; it.d = 0; it.b = 1; }
+    it.env = eg < num_envs ? eg : num_envs - 1;
+    it.pos = (it.el + 4 * L.hot.owner[it.b]) & 15;
+    return it;
+}
+// semi-implicit Euler of one joint from the slot the final pass left: q = q_old + dt qd, joint range (outward rate zeroed)
+DQ_HD void joint_integrate(QLds &L, const JointItem &it, float dt, float q_old, float *q_out, float *qd_out) {
+    const F4 o = DQ_LD(it.b, 0, it.pos);        // {qlo, qd, qhi, *}
+    float qd = o.y, q = q_old + dt * qd;
+    if (q < o.x) { q = o.x; if (qd < 0) qd = 0; }
+    if (q > o.z) { q = o.z; if (qd > 0) qd = 0; }
+    *q_out = q; *qd_out = qd;
 }
 
 // Gym-boundary substep for 16 envs: tau [N,33], push [N,2] or nullptr (replaces dw::simulate_env)
@@ -1040,18 +1188,30 @@ DQ_HD void quad_simulate(QLds &L, const QuadModel &QM, const DevModel &M, const 
                          const DwBuffers &B, const float *tau, const float *push, int wave_index) {
     QLane X;
     quad_lane_init(X, wave_index, num_envs, P, friction, B);
+    stage_hot(L, QM);
     const int e = X.env, f = X.j & 1;
     if (B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i]; }
-    for (int s = 0; s < QM.nsteps; ++s) {
-        const int b = QM.fk[s][X.j].body;
-        if (b >= 0) {
-            const int d = b - 1;
-            const float q = B.dof_state[((size_t)ND * e + d) * 2], qd = B.dof_state[((size_t)ND * e + d) * 2 + 1];
-            const float damp = B.dof_damping[(size_t)ND * e + d], arm = B.dof_armature[(size_t)ND * e + d];
-            DQ_SLOT(b, 0, X.pos) = mk4(q, qd, tau[(size_t)ND * e + d] - damp * qd, arm + P.dt * damp);
+    float qkeep[QNI];
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const JointItem it = joint_item(L, wave_index, num_envs, X.lane, k);
+        const size_t g = (size_t)ND * it.env + it.d;
+        const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
+        const float damp = B.dof_damping[g], arm = B.dof_armature[g];
+        qkeep[k] = q;
+        if (it.ok || lane_id() + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau[g] - damp * qd, arm + P.dt * damp);
+    }
+    wave_sync();
+    quad_substep<TERRAIN>(L, QM, M, P, X, B, push ? push[2 * e] : 0.0f, push ? push[2 * e + 1] : 0.0f, true);
+    wave_sync();
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const JointItem it = joint_item(L, wave_index, num_envs, X.lane, k);
+        float q, qd;
+        joint_integrate(L, it, P.dt, qkeep[k], &q, &qd);
+        if (it.ok) {
+            const size_t g = (size_t)ND * it.env + it.d;
+            B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd;
         }
     }
-    quad_substep<TERRAIN>(L, QM, M, P, X, B, push ? push[2 * e] : 0.0f, push ? push[2 * e + 1] : 0.0f, true);
     if (X.valid) {
         if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
         if (X.j < 2 && B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i] = X.warm[i]; }

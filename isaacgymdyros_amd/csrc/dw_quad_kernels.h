@@ -24,69 +24,97 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
                              const float *noise, long long step, int wave_index) {
     QLane X;
     quad_lane_init(X, wave_index, C.num_envs, C.phys, C.friction, B);
+    stage_hot(L, QM);
     const int e = X.env, f = X.j & 1;
     float *es = B.env_state + (size_t)DW_ES_WORDS * e;
-    dw::NoiseSrc nz;
-    nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * e : nullptr;
-    nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)step; nz.stream = 0;
     DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = es[DW_ES_WARM + 12 * f + i];
     const float push_x = es[dw::ES_PUSH_X], push_y = es[dw::ES_PUSH_Y];
-    const int dl = *reinterpret_cast<const int *>(&es[DW_ES_DELAY_IDX]);
-    int simul_len = *reinterpret_cast<const int *>(&es[DW_ES_SIMUL_LEN]);
     const float dt = C.phys.dt;
 
+    // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps from one pass over the
+    //      Gym tensors and the task record.  Kept per item in registers: the joint angle (integrated after each substep),
+    //      the delayed leg torque of the second substep, the encoder reading of the first. ----
+    float qkeep[QNI], tau2[QNI], qnprev[QNI];
+    // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
+    const int simul_len0 = *reinterpret_cast<const int *>(&es[DW_ES_SIMUL_LEN]);
+    DQ_STAMP(B, 0);
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const JointItem it = joint_item(L, wave_index, C.num_envs, X.lane, k);
+        const size_t g = (size_t)ND * it.env + it.d;
+        float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
+        const int d = it.d;
+        const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
+        const float damp = B.dof_damping[g], arm = B.dof_armature[g];
+        qkeep[k] = q;
+        qnprev[k] = ei[DW_ES_QPOS_PRE + d];
+        float tau;
+        if (d < 12) {
+            // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
+            // the two substeps (the action torque of the step is appended both times); the record gets the final column
+            const int dl = *reinterpret_cast<const int *>(&ei[DW_ES_DELAY_IDX]);
+            const int sl0 = *reinterpret_cast<const int *>(&ei[DW_ES_SIMUL_LEN]);
+            float col[DW_ALOG_SLOTS + 1];
+            DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = ei[DW_ES_ACTION_LOG + 12 * (s + 1) + d];
+            col[DW_ALOG_SLOTS - 1] = ei[DW_ES_ACTION_TORQUE + d];
+            col[DW_ALOG_SLOTS] = col[DW_ALOG_SLOTS - 1];
+            int sl1 = sl0 + 1; if (sl1 > DW_ALOG_SLOTS) sl1 = DW_ALOG_SLOTS;
+            int sl2 = sl1 + 1; if (sl2 > DW_ALOG_SLOTS) sl2 = DW_ALOG_SLOTS;
+            const int src1 = sl1 > dl ? dl : DW_ALOG_SLOTS - sl1, src2 = sl2 > dl ? dl : DW_ALOG_SLOTS - sl2;
+            float t1 = col[0], t2 = col[1];
+            DQ_UNROLL for (int s = 1; s < DW_ALOG_SLOTS; ++s) { t1 = (s == src1) ? col[s] : t1; t2 = (s == src2) ? col[s + 1] : t2; }
+            tau = t1; tau2[k] = t2;
+            if (it.ok) { DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS; ++s) ei[DW_ES_ACTION_LOG + 12 * s + d] = col[s + 1]; }
+        } else {
+            tau = M.kp[d] * (ei[DW_ES_TARGET_QPOS + d] - q) + M.kv[d] * (-qd);
+            tau2[k] = ei[DW_ES_TARGET_QPOS + d];          // the PD target: the second substep forms its own torque from the new state
+        }
+        if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
+    }
+    wave_sync();
+
     for (int sub = 0; sub < 2; ++sub) {
-        // ---- actuator model: joint efforts of this substep (dw_task.h P3), slot quad 0 = {q, qd, tau - damping qd, armature + dt damping} ----
-        int sl = simul_len + 1;
-        if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
-        for (int s = 0; s < QM.nsteps; ++s) {
-            const int b = QM.fk[s][X.j].body;
-            if (b >= 0) {
-                const int d = b - 1;
-                float q, qd;
-                if (sub == 0) { q = B.dof_state[((size_t)ND * e + d) * 2]; qd = B.dof_state[((size_t)ND * e + d) * 2 + 1]; }
-                else { const F4 o = DQ_SLOT(b, 0, X.pos); q = o.x; qd = o.y; }
-                float tau;
-                if (d < 12) {
-                    // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot
-                    float col[DW_ALOG_SLOTS];
-                    DQ_UNROLL for (int k = 0; k < DW_ALOG_SLOTS - 1; ++k) col[k] = es[DW_ES_ACTION_LOG + 12 * (k + 1) + d];
-                    col[DW_ALOG_SLOTS - 1] = es[DW_ES_ACTION_TORQUE + d];
-                    if (X.valid) { DQ_UNROLL for (int k = 0; k < DW_ALOG_SLOTS; ++k) es[DW_ES_ACTION_LOG + 12 * k + d] = col[k]; }
-                    const int src = sl > dl ? dl : DW_ALOG_SLOTS - sl;
-                    float t = col[0];
-                    DQ_UNROLL for (int k = 1; k < DW_ALOG_SLOTS; ++k) t = (k == src) ? col[k] : t;
-                    tau = t;
-                } else {
-                    tau = M.kp[d] * (es[DW_ES_TARGET_QPOS + d] - q) + M.kv[d] * (-qd);
-                }
-                const float damp = B.dof_damping[(size_t)ND * e + d], arm = B.dof_armature[(size_t)ND * e + d];
-                DQ_SLOT(b, 0, X.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
-            }
-        }
+        X.stamp_base = 1 + 16 * sub;
         if (!C.freeze_physics) quad_substep<TERRAIN>(L, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
-        // ---- encoder model (tasks/dyros_dynamic_walk.py:527-530) ----
-        for (int s = 0; s < QM.nsteps; ++s) {
-            const int b = QM.fk[s][X.j].body;
-            if (b >= 0) {
-                const int d = b - 1;
-                const float qnew = C.freeze_physics ? B.dof_state[((size_t)ND * e + d) * 2] : DQ_SLOT(b, 0, X.pos).x;
-                const float n = dw::noise_word(nz, DW_NZ_ENC + ND * sub + d);
-                const float qn = qnew + fminf(fmaxf(n, -0.00016f), 0.00016f);
-                const float pre = es[DW_ES_QPOS_PRE + d];
-                const float qv = C.gpu_div ? (qn - pre) * C.inv_dt_f : (qn - pre) / dt;
-                if (X.valid) { es[DW_ES_QVEL_NOISE + d] = qv; es[DW_ES_QPOS_NOISE + d] = qn; es[DW_ES_QPOS_PRE + d] = qn; }
+        wave_sync();
+        // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep ----
+        DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+            const JointItem it = joint_item(L, wave_index, C.num_envs, X.lane, k);
+            const size_t g = (size_t)ND * it.env + it.d;
+            float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
+            const int d = it.d;
+            float q = qkeep[k], qd = 0.0f;
+            if (!C.freeze_physics) {
+                joint_integrate(L, it, dt, qkeep[k], &q, &qd);
+                qkeep[k] = q;
+                if (it.ok && sub == 1) { B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd; }
+            }
+            dw::NoiseSrc nz;
+            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * it.env : nullptr;
+            nz.seed = C.seed; nz.env = (unsigned int)it.env; nz.step = (unsigned long long)step; nz.stream = 0;
+            const float n = dw::noise_word(nz, DW_NZ_ENC + ND * sub + d);
+            const float qn = q + fminf(fmaxf(n, -0.00016f), 0.00016f);
+            const float qv = C.gpu_div ? (qn - qnprev[k]) * C.inv_dt_f : (qn - qnprev[k]) / dt;
+            qnprev[k] = qn;
+            if (it.ok && sub == 1) { ei[DW_ES_QVEL_NOISE + d] = qv; ei[DW_ES_QPOS_NOISE + d] = qn; ei[DW_ES_QPOS_PRE + d] = qn; }
+            if (sub == 0 && !C.freeze_physics) {
+                const float damp = B.dof_damping[g], arm = B.dof_armature[g];
+                const float tau = d < 12 ? tau2[k] : M.kp[d] * (tau2[k] - q) + M.kv[d] * (-qd);
+                if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
             }
         }
-        simul_len = sl;
+        wave_sync();
+        DQ_STAMP(B, 1 + 16 * sub + 14);
     }
-    if (X.valid) {
-        if (X.j == 0) {
-            *reinterpret_cast<int *>(&es[DW_ES_SIMUL_LEN]) = simul_len;
-            if (!C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
-        }
-        if (X.j < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) es[DW_ES_WARM + 12 * f + i] = X.warm[i]; }
+    if (X.valid && X.j == 0) {
+        int sl = simul_len0 + 2;
+        if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
+        *reinterpret_cast<int *>(&es[DW_ES_SIMUL_LEN]) = sl;
     }
+    if (X.valid && !C.freeze_physics) {
+        if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
+        if (X.j < 2) { DQ_UNROLL for (int i = 0; i < 12; ++i) es[DW_ES_WARM + 12 * f + i] = X.warm[i]; }
+    }
+    DQ_STAMP(B, 40);
 }
 
 }  // namespace dwq

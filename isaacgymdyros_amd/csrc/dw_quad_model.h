@@ -51,7 +51,24 @@ struct alignas(16) QInRec {      // inward constants of one (step, lane): 11 x 1
     float axis[3]; int sc_mask;              // hinge axis in body coordinates; bit p: self-collision proxy p sits on this body
 };
 
+// The part of the tables every step of every pass reads, staged into LDS when a kernel starts (5.4 KB): compact
+// per-(step, lane) records and the wave-uniform masks.  Integer fields travel as bit patterns in float words.
+//   fk[s][l]: [0..2] pos, [3] body | psrc << 8 | flags << 12 | proxies << 16, [4..6] axis, [7] vmax, [8] qlo, [9] qhi
+//   in[s][l]: [0] body + 1 | flags << 8 | nin << 12 | ngym << 14 | ngeom << 16 | proxies << 24, [1] gather,
+//             [2] gyms[0] | gyms[1] << 8 | gyms[2] << 16 | in0_gym << 24, [3] bound, [4..6] in0_com, [7] in0_mass, [8..13] in0_I
+struct alignas(16) QHot {
+    float fk[QS_MAX][4][12];
+    float in[QS_MAX][4][16];
+    float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound
+    int   fmask[QS_MAX];         // outward step s: bit X set = some lane fetches lane X's running state
+    int   gany[QS_MAX];          // inward step s: some lane gathers
+    int   misc[8];               // [0] nsteps, [1] base_gather, [2] nproxy_l, [3] nproxy_r
+    int   owner[36];             // lane that owns each body (slot position = (env + 4 * owner) & 15)
+    float prox[8][8];            // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner << 16
+};
+
 struct QuadModel {
+    QHot  hot;
     int   nsteps;
     int   owner[dw::NB];         // lane of each body (body 0: all)
     int   step_of[dw::NB];
@@ -356,6 +373,43 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         seen[Q->base_gym] += 1;
         for (int s2 = 0; s2 < T; ++s2) for (int l = 0; l < 4; ++l) { const QInRec &r = Q->in[s2][l]; if (r.body >= 0) for (int i = 0; i < r.ngym; ++i) seen[r.gyms[i]] += 1; }
         for (int g = 0; g < DW_NUM_BODIES; ++g) if (seen[g] != 1) { *err = "quad model: a Gym body is reported by no moving body or by several"; return DW_EINVAL; }
+    }
+    // ---- the LDS-resident copy ----
+    {
+        QHot &H = Q->hot;
+        auto fi = [](int v) { float f; memcpy(&f, &v, 4); return f; };
+        for (int s2 = 0; s2 < QS_MAX; ++s2)
+            for (int l = 0; l < 4; ++l) {
+                const QFkRec &r = Q->fk[s2][l];
+                float *o = H.fk[s2][l];
+                for (int i = 0; i < 3; ++i) { o[i] = r.pos[i]; o[4 + i] = r.axis[i]; }
+                o[3] = fi((r.body & 255) | ((r.psrc & 15) << 8) | ((r.flags & 3) << 12) | (((r.flags >> 8) & 255) << 16));
+                o[7] = r.vmax; o[8] = r.qlo; o[9] = r.qhi;
+                if (r.body >= 0 && r.psrc >= 2) H.fmask[s2] |= 1 << (r.psrc - 2);
+                const QInRec &n = Q->in[s2][l];
+                float *p = H.in[s2][l];
+                p[0] = fi(((n.body + 1) & 255) | ((n.flags & 7) << 8) | ((n.nin & 3) << 12) | ((n.ngym & 3) << 14) | ((n.ngeom & 15) << 16) |
+                          ((n.sc_mask & 255) << 24));
+                p[1] = fi(n.body >= 0 ? n.gather : 0);
+                p[2] = fi((n.gyms[0] & 255) | ((n.gyms[1] & 255) << 8) | ((n.gyms[2] & 255) << 16) | ((n.in0_gym & 255) << 24));
+                p[3] = n.bound;
+                for (int i = 0; i < 3; ++i) p[4 + i] = n.in0_com[i];
+                p[7] = n.in0_mass;
+                for (int i = 0; i < 6; ++i) p[8 + i] = n.in0_I[i];
+                if (n.body >= 0 && n.gather) H.gany[s2] = 1;
+            }
+        for (int i = 0; i < 3; ++i) H.base[i] = Q->base_com[i];
+        H.base[3] = Q->base_mass;
+        for (int i = 0; i < 6; ++i) H.base[4 + i] = Q->base_I[i];
+        H.base[10] = fi(Q->base_gym); H.base[11] = fi(Q->base_ngeom); H.base[12] = Q->base_bound;
+        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nproxy_l; H.misc[3] = Q->nproxy_r;
+        for (int b = 0; b < NB; ++b) H.owner[b] = Q->owner[b] < 0 ? 0 : Q->owner[b];
+        for (int p2 = 0; p2 < 8; ++p2) {
+            for (int i = 0; i < 3; ++i) { H.prox[p2][i] = Q->proxy_p0[p2][i]; H.prox[p2][4 + i] = Q->proxy_p1[p2][i]; }
+            H.prox[p2][3] = Q->proxy_r[p2];
+            const int pbody = Q->proxy_body[p2];
+            H.prox[p2][7] = fi((pbody & 255) | ((Q->proxy_gym[p2] & 255) << 8) | (((pbody > 0 ? Q->owner[pbody] : 0) & 3) << 16));
+        }
     }
     return DW_OK;
 }

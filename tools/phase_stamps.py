@@ -1,0 +1,34 @@
+"""Per-phase latency of the quad physics kernel for wave 0 (profiling build: tools/phase_stamps.sh builds the library with
+-DDQ_STAMPS into isaacgymdyros_amd/_ab/ and runs this).  Prints cycles between the stamps."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from isaacgymdyros_amd import _lib
+_lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
+from isaacgymdyros_amd.config import default_cfg
+from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+env = DyrosDynamicWalk(default_cfg(N, "cuda:0"), "cuda:0", 0, True)
+g = torch.Generator(device="cuda").manual_seed(42)
+acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
+names = {0: "substep entry", 1: "base kin -> FK", 2: "FK", 3: "self-collision", 4: "inward", 5: "base solve", 6: "outward", 7: "corners, free twist",
+         8: "W rows", 9: "A_kk, start", 10: "PGS", 11: "impulse up-sweep", 12: "final pass", 13: "base integrate"}
+acc = None
+K = 20
+for i in range(30 + K):
+    env.step(acts[i % 8])
+    if i >= 30:
+        torch.cuda.synchronize()
+        st = env._buf["gate_acc"][200:256].cpu().numpy().astype("int64")
+        acc = st.copy() if acc is None else acc
+        d = {}
+        tot = st[40] - st[0]
+        if i == 30 + K - 1:
+            print("kernel total (wave 0): %d cycles" % tot)
+            for sub in (0, 1):
+                base = 1 + 16 * sub
+                print("substep %d: prologue %d" % (sub, st[base + 0] - (st[0] if sub == 0 else st[1 + 14])))
+                for n in range(1, 14):
+                    print("   %-22s %7d" % (names[n], st[base + n] - st[base + n - 1]))
+                print("   %-22s %7d" % ("encoder epilogue", st[base + 14] - st[base + 13]))
+            print("kernel epilogue %d" % (st[40] - st[1 + 16 + 14]))
