@@ -67,9 +67,10 @@ void dw_k_pre(const dw::DevModel *M, const dw::DevParams *P, const float *action
 // 38 KB of LDS per wave: 4 waves per CU, one per SIMD, so the whole 512-register file belongs to the wave ...
 template <bool TERRAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_phys(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *noise, long long step) {
+void dw_k_phys(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise,
+               long long step) {
     __shared__ dwq::QLds L;
-    dwq::quad_physics_step<TERRAIN>(L, *QM, *M, P->C, P->B, noise, step, (int)blockIdx.x);
+    dwq::quad_physics_step<TERRAIN, true>(L, *QM, *M, P->C, P->B, actions, P->mocap, noise, step, (int)blockIdx.x);
 }
 // ... and the task logic after them (termination, reward, reset, observation), one wave per env.
 __global__ __launch_bounds__(64)
@@ -239,12 +240,10 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     DeviceGuard guard(h->device);
     if (h->pipeline == 2) {
         const dim3 grid((h->cfg.num_envs + dwq::EPW - 1) / dwq::EPW);
-        hipLaunchKernelGGL(dw_k_pre, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params, actions, noise,
-                           (long long)step_index);
         if (h->cfg.terrain)
-            hipLaunchKernelGGL(dw_k_phys<true>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, noise, (long long)step_index);
+            hipLaunchKernelGGL(dw_k_phys<true>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise, (long long)step_index);
         else
-            hipLaunchKernelGGL(dw_k_phys<false>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, noise, (long long)step_index);
+            hipLaunchKernelGGL(dw_k_phys<false>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise, (long long)step_index);
         hipLaunchKernelGGL(dw_k_post, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params, actions, noise,
                            (long long)step_index);
     } else if (h->cfg.terrain)

@@ -19,17 +19,108 @@ namespace dwq {
 
 using dw::TaskParams;
 
-template <bool TERRAIN>
+// per-env scratch of the task phases: the four slot rows of body 0 (the base has no slot) = 16 words per env
+#define DQ_ENVW(el, w) (reinterpret_cast<float *>(&L.slot[(w) >> 2][(el)])[(w) & 3])
+constexpr int EW_LTP = 0, EW_MIDX = 1;       // mocap phase time, mocap row (int bits)
+constexpr int WW_GATE = 15;                  // wave-wide word: perturbation gate open (env 0's scratch)
+
+// PRE = true: the kernel also runs pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
+// mocap phase and target, perturbation gate and schedule) -- the fused step; false: dw_k_pre has done that.
+template <bool TERRAIN, bool PRE>
 DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
-                             const float *noise, long long step, int wave_index) {
+                             const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     QLane X;
     quad_lane_init(X, wave_index, C.num_envs, C.phys, C.friction, B);
     stage_hot(L, QM);
     const int e = X.env, f = X.j & 1;
     float *es = B.env_state + (size_t)DW_ES_WORDS * e;
     DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = es[DW_ES_WARM + 12 * f + i];
-    const float push_x = es[dw::ES_PUSH_X], push_y = es[dw::ES_PUSH_Y];
+    float push_x = 0.0f, push_y = 0.0f;
     const float dt = C.phys.dt;
+    if (!PRE) { push_x = es[dw::ES_PUSH_X]; push_y = es[dw::ES_PUSH_Y]; }
+    else {
+        // ---- pre_physics_step, per-env scalar parts on the quad's lanes (dw_task.h P1): lane 0 the mocap phase, lane 1 the
+        //      push schedule; every fp32 expression as there ----
+        dw::TaskBuffers TB;
+        TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = mocap; TB.step = step;
+        const dw::StepCtx K = dw::make_step_ctx(C, TB, e);
+        if (X.lane == 1) DQ_ENVW(0, WW_GATE) = __builtin_bit_cast(float, dw::gate_open(C, K));
+        wave_sync();
+        const int open = f2i(DQ_ENVW(0, WW_GATE));
+        float px = 0.0f, py = 0.0f;
+        if (X.j == 0) {
+            const float time = es[DW_ES_TIME];
+            const int init_idx = *reinterpret_cast<const int *>(&es[DW_ES_INIT_MOCAP]);
+            const float local_time = dw::remainder_t(time, K.period);
+            const float ltp = dw::remainder_t(local_time + (float)init_idx * K.cdt, K.period);
+            const int midx = (int)(((long long)init_idx + (long long)dw::divs(C.gpu_div, local_time, K.cdt_d)) % 3599);
+            DQ_ENVW(X.el, EW_LTP) = ltp;
+            DQ_ENVW(X.el, EW_MIDX) = __builtin_bit_cast(float, midx);
+            const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
+            const float tf0 = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + 33], row1[1 + 33]);
+            const float tf1 = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + 34], row1[1 + 34]);
+            if (X.valid) {
+                *reinterpret_cast<int *>(&es[DW_ES_MOCAP_IDX]) = midx;
+                es[DW_ES_TARGET_FORCE] = tf0; es[DW_ES_TARGET_FORCE + 1] = tf1;
+            }
+        }
+        if (X.j == 1) {
+#define DQ_ESI(off) (*reinterpret_cast<int *>(&es[(off)]))
+            // (tasks/dyros_dynamic_walk.py:438-447,489-502; values land in locals and are stored at the end: an env beyond the
+            //  last one shares the last env's record and must not write it)
+            int pert_start = DQ_ESI(DW_ES_PERT_START), pert_on = DQ_ESI(DW_ES_PERT_ON), pert_count = DQ_ESI(DW_ES_PERT_COUNT);
+            int impulse = DQ_ESI(DW_ES_IMPULSE), duration = DQ_ESI(DW_ES_PERT_DURATION);
+            float magnitude = es[DW_ES_MAGNITUDE], phase = es[DW_ES_PHASE];
+            if (open) {
+                pert_start = 1;
+                if (!C.force_perturb_start && X.valid) K.gate[dw::GATE_LATCH] = 1;
+            }
+            if (pert_start) {
+                if (dw::remainder_t(es[DW_ES_EPI_LEN], C.pert_period_f) == (float)DQ_ESI(DW_ES_PERT_TIMING)) {
+                    pert_on = 1;
+                    int imp = 50 + (int)(dw::noise_word(K.nz, DW_NZ_PERT + 0) * 200.0f);
+                    if (imp > 249) imp = 249;
+                    int dur = C.pert_dur_lo + (int)(dw::noise_word(K.nz, DW_NZ_PERT + 1) * (float)(C.pert_dur_hi - C.pert_dur_lo));
+                    if (dur > C.pert_dur_hi - 1) dur = C.pert_dur_hi - 1;
+                    impulse = imp;
+                    duration = dur;
+                    magnitude = (float)imp / ((float)dur * C.dt_policy_f);
+                    phase = dw::noise_word(K.nz, DW_NZ_PERT + 2) * 2.0f * (float)3.14159265358979;
+                }
+                if (pert_on) {
+                    pert_count += 1;
+                    px = magnitude * cosf(phase);
+                    py = magnitude * sinf(phase);
+                }
+                if (pert_count == duration) {
+                    pert_on = 0;
+                    pert_count = 0;
+                }
+            }
+            if (X.valid) {
+                DQ_ESI(DW_ES_PERT_START) = pert_start; DQ_ESI(DW_ES_PERT_ON) = pert_on; DQ_ESI(DW_ES_PERT_COUNT) = pert_count;
+                DQ_ESI(DW_ES_IMPULSE) = impulse; DQ_ESI(DW_ES_PERT_DURATION) = duration;
+                es[DW_ES_MAGNITUDE] = magnitude; es[DW_ES_PHASE] = phase;
+            }
+#undef DQ_ESI
+        }
+        push_x = quad_bcast<1>(px);
+        push_y = quad_bcast<1>(py);
+        wave_sync();
+        // ---- actions: clamp, the record, the newest slot of the action ring; items (env, action) ----
+        DQ_UNROLL for (int k = 0; k < (EPW * DW_NUM_ACT + 63) / 64; ++k) {
+            const int i = X.lane + 64 * k;
+            const int el = i / DW_NUM_ACT, a = i - DW_NUM_ACT * el;
+            const int eg = wave_index * EPW + el;
+            if (i < EPW * DW_NUM_ACT && eg < C.num_envs) {
+                float *ei = B.env_state + (size_t)DW_ES_WORDS * eg;
+                const float v = dw::clamp_action(actions, eg, a);
+                const int head = *reinterpret_cast<const int *>(&ei[DW_ES_HIST_HEAD]);
+                ei[DW_ES_ACTIONS + a] = v;
+                B.action_history[((size_t)eg * DW_HIST_SLOTS + head) * DW_NUM_ACT + a] = v;
+            }
+        }
+    }
 
     // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps from one pass over the
     //      Gym tensors and the task record.  Kept per item in registers: the joint angle (integrated after each substep),
@@ -48,6 +139,22 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
         qkeep[k] = q;
         qnprev[k] = ei[DW_ES_QPOS_PRE + d];
         float tau;
+        float target = 0.0f, atq = 0.0f;
+        if (PRE) {
+            // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
+            const float ltp = DQ_ENVW(it.el, EW_LTP);
+            const int midx = f2i(DQ_ENVW(it.el, EW_MIDX));
+            const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
+            target = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + d], row1[1 + d]);
+            if (it.ok) ei[DW_ES_TARGET_QPOS + d] = target;
+            if (d < 12) {
+                atq = dw::clamp_action(actions, it.env, d) * ei[DW_ES_MOTOR_SCALE + d] * M.action_high[d];
+                if (it.ok) ei[DW_ES_ACTION_TORQUE + d] = atq;
+            }
+        } else {
+            target = d < 12 ? 0.0f : ei[DW_ES_TARGET_QPOS + d];
+            atq = d < 12 ? ei[DW_ES_ACTION_TORQUE + d] : 0.0f;
+        }
         if (d < 12) {
             // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
             // the two substeps (the action torque of the step is appended both times); the record gets the final column
@@ -55,7 +162,7 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
             const int sl0 = *reinterpret_cast<const int *>(&ei[DW_ES_SIMUL_LEN]);
             float col[DW_ALOG_SLOTS + 1];
             DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = ei[DW_ES_ACTION_LOG + 12 * (s + 1) + d];
-            col[DW_ALOG_SLOTS - 1] = ei[DW_ES_ACTION_TORQUE + d];
+            col[DW_ALOG_SLOTS - 1] = atq;
             col[DW_ALOG_SLOTS] = col[DW_ALOG_SLOTS - 1];
             int sl1 = sl0 + 1; if (sl1 > DW_ALOG_SLOTS) sl1 = DW_ALOG_SLOTS;
             int sl2 = sl1 + 1; if (sl2 > DW_ALOG_SLOTS) sl2 = DW_ALOG_SLOTS;
@@ -65,8 +172,8 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
             tau = t1; tau2[k] = t2;
             if (it.ok) { DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS; ++s) ei[DW_ES_ACTION_LOG + 12 * s + d] = col[s + 1]; }
         } else {
-            tau = M.kp[d] * (ei[DW_ES_TARGET_QPOS + d] - q) + M.kv[d] * (-qd);
-            tau2[k] = ei[DW_ES_TARGET_QPOS + d];          // the PD target: the second substep forms its own torque from the new state
+            tau = M.kp[d] * (target - q) + M.kv[d] * (-qd);
+            tau2[k] = target;          // the PD target: the second substep forms its own torque from the new state
         }
         if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
     }
