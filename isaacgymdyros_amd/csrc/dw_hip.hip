@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void dw_k_phys(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise,
                long long step) {
     __shared__ dwq::QLds L;
-    dwq::quad_physics_step<TERRAIN, true>(L, *QM, *M, P->C, P->B, actions, P->mocap, noise, step, (int)blockIdx.x);
+    dwq::quad_physics_step<TERRAIN, true, true>(L, *QM, *M, P->C, P->B, actions, P->mocap, noise, step, (int)blockIdx.x);
 }
 // ... and the task logic after them (termination, reward, reset, observation), one wave per env.
 __global__ __launch_bounds__(64)
@@ -244,8 +244,6 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
             hipLaunchKernelGGL(dw_k_phys<true>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise, (long long)step_index);
         else
             hipLaunchKernelGGL(dw_k_phys<false>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise, (long long)step_index);
-        hipLaunchKernelGGL(dw_k_post, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params, actions, noise,
-                           (long long)step_index);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, actions, noise, (long long)step_index);

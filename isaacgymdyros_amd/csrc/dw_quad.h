@@ -79,6 +79,8 @@ struct QLane {
     float mu;
     float warm[12];                          // impulses of the 4 corners of "my" foot (foot j & 1), from the previous substep
     float footF[3];                          // non-sole contact force on my foot's sole Gym body (lanes 0, 1)
+    int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
+    float footT[3];                          // last substep: net contact force on my sole body (lanes 0, 1)
     int   stamp_base;                        // profiling builds only
 };
 
@@ -123,6 +125,14 @@ template <int N> DQ_HD void quad_bcast_arr(int xl, const float (&s)[N], float (&
 #endif
 #define DQ_SLOT(b, q, p) L.slot[(b) * 4 + (q)][(p)]
 #define DQ_LD(b, q, p) ld4(L.slot[(b) * 4 + (q)][(p)])
+
+// |F| > 1 N with torch.norm's summation order for 3 elements (the termination test of tasks/dyros_dynamic_walk.py:590)
+DQ_HD bool over_1n(const float *F) {
+    float b0 = fmaf(F[0], F[0], 0.0f);
+    b0 = fmaf(F[1], F[1], b0);
+    b0 = fmaf(F[2], F[2], b0);
+    return sqrtf(b0) > 1.0f;
+}
 
 // Ground penalty force of one primitive of body b (dw_physics.h K4).  R, x: body rotation / origin relative to O; v: body
 // twist about O.  Returns the force in F and the contact point relative to O in xr.
@@ -637,9 +647,12 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     if (t < ngym) {
                         const int gy = (gymbits >> (8 * t)) & 255;
                         if (gy == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
-                        else if (X.valid) {
-                            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
-                            dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
+                        else {
+                            if (over_1n(cf[t])) X.coll = 1;
+                            if (X.valid) {
+                                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
+                                dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
+                            }
                         }
                     }
             }
@@ -721,9 +734,12 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 }
             }
         }
-        if (last && j == 3 && X.valid) {
-            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + base_gym) * 3;
-            dst[0] = cfb[0]; dst[1] = cfb[1]; dst[2] = cfb[2];
+        if (last && j == 3) {
+            if (over_1n(cfb)) X.coll = 1;
+            if (X.valid) {
+                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + base_gym) * 3;
+                dst[0] = cfb[0]; dst[1] = cfb[1]; dst[2] = cfb[2];
+            }
         }
         {   // push on the base COM
             const float Fw[3] = {push_x, push_y, 0.0f};
@@ -1064,13 +1080,19 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 dqb[r] = acc;
             }
         }
-        if (last && part == 0 && X.valid) {
-            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
-            dst[0] = X.footF[0] + Fs[0] * inv_dt; dst[1] = X.footF[1] + Fs[1] * inv_dt; dst[2] = X.footF[2] + Fs[2] * inv_dt;
+        if (last && part == 0) {
+            DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i] + Fs[i] * inv_dt;
+            if (X.valid) {
+                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+                dst[0] = X.footT[0]; dst[1] = X.footT[1]; dst[2] = X.footT[2];
+            }
         }
-    } else if (last && part == 0 && X.valid) {
-        float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
-        dst[0] = X.footF[0]; dst[1] = X.footF[1]; dst[2] = X.footF[2];
+    } else if (last && part == 0) {
+        DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i];
+        if (X.valid) {
+            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+            dst[0] = X.footF[0]; dst[1] = X.footF[1]; dst[2] = X.footF[2];
+        }
     }
     DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) X.warm[3 * k + i] = Pk[k][i];
 
@@ -1154,6 +1176,8 @@ DQ_HD void quad_lane_init(QLane &X, int wave_index, int num_envs, const PhysPara
     DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = 0.0f;
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     X.stamp_base = 0;
+    X.coll = 0;
+    X.footT[0] = X.footT[1] = X.footT[2] = 0.0f;
     (void)P;
 }
 

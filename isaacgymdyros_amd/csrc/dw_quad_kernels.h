@@ -10,6 +10,7 @@
 
 #include "dw_quad.h"
 #include "dw_task.h"
+#include "dw_quad_post.h"
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
@@ -26,7 +27,8 @@ constexpr int WW_GATE = 15;                  // wave-wide word: perturbation gat
 
 // PRE = true: the kernel also runs pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
 // mocap phase and target, perturbation gate and schedule) -- the fused step; false: dw_k_pre has done that.
-template <bool TERRAIN, bool PRE>
+// POST = true: ... and post_physics_step after them (dw_quad_post.h): the whole VecTask.step in one launch.
+template <bool TERRAIN, bool PRE, bool POST>
 DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     QLane X;
@@ -125,7 +127,7 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
     // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps from one pass over the
     //      Gym tensors and the task record.  Kept per item in registers: the joint angle (integrated after each substep),
     //      the delayed leg torque of the second substep, the encoder reading of the first. ----
-    float qkeep[QNI], tau2[QNI], qnprev[QNI];
+    float qkeep[QNI], qdkeep[QNI], tau2[QNI], qnprev[QNI];
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
     const int simul_len0 = *reinterpret_cast<const int *>(&es[DW_ES_SIMUL_LEN]);
     DQ_STAMP(B, 0);
@@ -136,7 +138,7 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
         const int d = it.d;
         const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
         const float damp = B.dof_damping[g], arm = B.dof_armature[g];
-        qkeep[k] = q;
+        qkeep[k] = q; qdkeep[k] = qd;
         qnprev[k] = ei[DW_ES_QPOS_PRE + d];
         float tau;
         float target = 0.0f, atq = 0.0f;
@@ -192,7 +194,7 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
             float q = qkeep[k], qd = 0.0f;
             if (!C.freeze_physics) {
                 joint_integrate(L, it, dt, qkeep[k], &q, &qd);
-                qkeep[k] = q;
+                qkeep[k] = q; qdkeep[k] = qd;
                 if (it.ok && sub == 1) { B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd; }
             }
             dw::NoiseSrc nz;
@@ -222,6 +224,18 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
         if (X.j < 2) { DQ_UNROLL for (int i = 0; i < 12; ++i) es[DW_ES_WARM + 12 * f + i] = X.warm[i]; }
     }
     DQ_STAMP(B, 40);
+    if (POST) {
+        // every lane of the quad may have seen a non-sole body in contact: one flag per env
+        {
+            float c = X.coll ? 1.0f : 0.0f;
+            c += quad_xor1(c);
+            c += quad_xor2(c);
+            X.coll = c > 0.0f;
+        }
+        wave_sync_global();        // the records and tensors this kernel has written are read back below, by other lanes
+        quad_task_post<TERRAIN>(L, M, C, B, actions, noise, step, wave_index, X, qkeep, qdkeep);
+        DQ_STAMP(B, 41);
+    }
 }
 
 }  // namespace dwq

@@ -1,0 +1,602 @@
+// dw_quad_post.h -- post_physics_step of DyrosDynamicWalk for the 16 envs of a quad wave, run at the end of the fused step
+// kernel (dw_quad_kernels.h) when the physics is done and the wave's 34 KB of body slots are free.
+//
+// Mirrors dw_task.h regions Q1..Q6 and reset_region -- the same fp32 expressions in the same order (fp contraction off), so
+// the reference goldens (tests/golden/task_logic_frozen.npz, terrain_logic_frozen.npz) hold bit for bit -- with the lanes
+// mapped for 16 envs per wave:
+//   * the 16 task records (372 words each) are staged into LDS with contiguous loads and written back the same way;
+//   * per-env scalar work (clocks, termination, the reward terms, the reset draws) runs on the env's quad, one group of
+//     terms per lane: 16 envs share every instruction (the wave-per-env kernel spent a whole wave on one lane's scalar code);
+//   * per-joint / per-observation / per-history-word work runs over ITEMS (env, index) = lane + 64 k so that loads and
+//     stores of a wave-instruction are contiguous (obs_buf: 16 rows of 487 words are one 31 KB run).
+// Reference: tasks/dyros_dynamic_walk.py:543-563 (post_physics_step), :581-596 (check_termination), :802-947 (reward),
+// :598-669,720-748 (reset_idx), :750-796 (observations); vec_task.py:519-733 (dof-property randomisation).
+#pragma once
+
+#include "dw_quad.h"
+#include "dw_task.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace dwq {
+
+using dw::TaskParams;
+
+// flat LDS layout of the post phase (float words of QLds::slot)
+constexpr int PL_ES_STRIDE = DW_ES_WORDS;                // = the global layout: the 16 records move as one 23.8 KB run of 16-byte pieces
+constexpr int PL_ES = 0;                                 // [16][373] task records
+constexpr int PL_Q = 5984;                               // [16][33][2] joint state
+constexpr int PL_ROOT = PL_Q + EPW * ND * 2;             // [16][13]
+constexpr int PL_NORMED = PL_ROOT + EPW * 13 + 16;       // [16][37] normalised observation of this step
+constexpr int PL_PS = PL_NORMED + EPW * DW_NUM_OBS1;     // [16][32] per-env scratch
+static_assert(PL_ES + EPW * PL_ES_STRIDE <= PL_Q, "post layout: records overlap the joint state");
+static_assert(PL_PS + EPW * 32 <= NB * 4 * EPW * 4, "post layout does not fit the slot area");
+// per-env scratch words
+constexpr int PS_RTERM = 0;      // [16] reward terms, [14] = |orientation error|
+constexpr int PS_BAD = 16, PS_COLL = 17, PS_RESET = 18, PS_PROGRESS = 19, PS_RANDOMIZE = 20, PS_MASS = 21;
+constexpr int PS_FOOT = 22;      // [2][3] net contact force on the two sole bodies
+constexpr int PS_ORG = 28;       // [3] new tile origin (terrain curriculum)
+
+#define PQ_LF(i) LF[(i)]
+#define PQ_ES(el, off) LF[PL_ES + (el) * PL_ES_STRIDE + (off)]
+#define PQ_ESI(el, off) (*reinterpret_cast<int *>(&LF[PL_ES + (el) * PL_ES_STRIDE + (off)]))
+#define PQ_Q(el, d) LF[PL_Q + ((el) * ND + (d)) * 2]
+#define PQ_QD(el, d) LF[PL_Q + ((el) * ND + (d)) * 2 + 1]
+#define PQ_ROOT(el, i) LF[PL_ROOT + (el) * 13 + (i)]
+#define PQ_NORMED(el, k) LF[PL_NORMED + (el) * DW_NUM_OBS1 + (k)]
+#define PQ_PS(el, w) LF[PL_PS + (el) * 32 + (w)]
+#define PQ_PSI(el, w) (*reinterpret_cast<int *>(&LF[PL_PS + (el) * 32 + (w)]))
+
+// torch.norm of 3 elements on the CPU reference (dw_task.h norm_t with n = 3: fused scalar tail)
+DQ_HD float norm3_t(float x, float y, float z) {
+    float b0 = fmaf(x, x, 0.0f);
+    b0 = fmaf(y, y, b0);
+    b0 = fmaf(z, z, b0);
+    return sqrtf(b0);
+}
+
+// Inputs from the physics part of the kernel: qv/qdv = the item lanes' new joint state (items as joint_item()), X.root,
+// X.coll / X.footT (collision flag of my bodies, net force on my sole body).  With physics frozen (tests) the state and
+// the contact forces are the Gym tensors as they are.
+template <bool TERRAIN>
+DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const DwBuffers &B, const float *actions,
+                          const float *noise, long long step, int wave_index, QLane &X, const float (&qv)[QNI], const float (&qdv)[QNI]) {
+    float *LF = reinterpret_cast<float *>(&L.slot[0][0]);
+    const int lane = X.lane, j = X.j, el = X.el, e = X.env;
+    const int N = C.num_envs;
+    dw::TaskBuffers TB;
+    TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
+    const dw::StepCtx K = dw::make_step_ctx(C, TB, e);        // (nz of MY env; items build their own)
+    const float period = K.period;
+    const double cdt_d = K.cdt_d;
+    const int LFG = M.left_foot_gym, RFG = M.right_foot_gym;
+
+    // ---- stage: joint state, base state, contact summary, the 16 task records ----
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPW * ND) { LF[PL_Q + 2 * i] = qv[k]; LF[PL_Q + 2 * i + 1] = qdv[k]; }
+    }
+    if (j == 0) {
+        DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = X.root[i];
+        PQ_PSI(el, PS_BAD) = 0; PQ_PSI(el, PS_COLL) = 0; PQ_PSI(el, PS_RESET) = 0;
+    }
+    {
+        // 16 records = 1488 pieces of 16 bytes, contiguous in HBM and in LDS: every lane requests its 24 pieces before the
+        // first one is stored (one memory latency for the lot)
+        static_assert((EPW * DW_ES_WORDS) % 4 == 0 && (DW_ES_WORDS * 4) % 16 == 0, "record block must be a whole number of 16-byte pieces");
+        constexpr int NP = EPW * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
+        const int nvalid = N - wave_index * EPW;                          // envs of this wave that exist (>= 1)
+        const int np_ok = (nvalid >= EPW ? EPW : nvalid) * (DW_ES_WORDS / 4);
+        const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)wave_index * EPW * DW_ES_WORDS);
+        F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
+        F4 t[PER];
+        DQ_UNROLL for (int u = 0; u < PER; ++u) {
+            const int pi = lane + 64 * u;
+            // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
+            const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
+            t[u] = src[pi < NP ? ps : 0];
+        }
+        DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < NP) dst[pi] = t[u]; }
+    }
+    wave_sync();
+    if (C.freeze_physics) {
+        // debug mode: simulate() was the identity, so the net contact forces are an input (dw_task.h step_env)
+        if (j == 0) {
+            const float *cf = B.contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { PQ_PS(el, PS_FOOT + i) = cf[3 * LFG + i]; PQ_PS(el, PS_FOOT + 3 + i) = cf[3 * RFG + i]; }
+        }
+        for (int i = lane; i < EPW * DW_NUM_BODIES; i += 64) {
+            const int ee = i / DW_NUM_BODIES, g = i - DW_NUM_BODIES * ee;
+            const int eg = wave_index * EPW + ee < N ? wave_index * EPW + ee : N - 1;
+            const float *cf = B.contact_forces + ((size_t)DW_NUM_BODIES * eg + g) * 3;
+            if (g != LFG && g != RFG && norm3_t(cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
+        }
+    } else {
+        if (X.coll) PQ_PSI(el, PS_COLL) = 1;
+        if (j < 2) { DQ_UNROLL for (int i = 0; i < 3; ++i) PQ_PS(el, PS_FOOT + 3 * j + i) = X.footT[i]; }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 42);
+    // ---- Q1: clocks, VecTask counters, non-finite guard ----
+    if (j == 0) {
+        const long long p = B.progress_buf[e], rbl = B.randomize_buf[e];
+        int rb = (int)(rbl > 0x7ffffffe ? 0x7ffffffe : rbl);
+        PQ_PS(el, PS_MASS) = B.total_mass[e];
+        PQ_ES(el, DW_ES_EPI_LEN) += 1.0f;
+        float time = PQ_ES(el, DW_ES_TIME);
+        time = time + C.dt_policy_f;
+        time = time + C.clock_gain_f * dw::clamp_action(actions, e, 12);
+        PQ_ES(el, DW_ES_TIME) = time;
+        if (X.valid) {
+            B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
+            B.progress_buf[e] = p + 1;
+        }
+        PQ_PSI(el, PS_PROGRESS) = (int)(p + 1);
+        rb = rb + 1;
+        if (X.valid) B.randomize_buf[e] = rb;
+        PQ_PSI(el, PS_RANDOMIZE) = rb;
+        bool bad = false;
+        DQ_UNROLL for (int i = 0; i < 13; ++i) bad = bad || !dw::finitef(PQ_ROOT(el, i));
+        if (bad) PQ_PSI(el, PS_BAD) = 1;
+    }
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPW * ND && (!dw::finitef(LF[PL_Q + 2 * i]) || !dw::finitef(LF[PL_Q + 2 * i + 1]))) PQ_PSI(i / ND, PS_BAD) = 1;
+    }
+    wave_sync();
+    if (wave_any(PQ_PSI(el, PS_BAD) != 0)) {
+        if (j == 0 && PQ_PSI(el, PS_BAD)) {
+            DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = (i == 2) ? C.initial_height : (i == 6 ? 1.0f : 0.0f);
+            PQ_ESI(el, DW_ES_NAN_RESETS) += 1;
+            PQ_PSI(el, PS_COLL) = 0;
+            DQ_UNROLL for (int i = 0; i < 6; ++i) PQ_PS(el, PS_FOOT + i) = 0.0f;
+        }
+        DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+            const int i = lane + 64 * k;
+            if (i < EPW * ND && PQ_PSI(i / ND, PS_BAD)) { LF[PL_Q + 2 * i] = 0.0f; LF[PL_Q + 2 * i + 1] = 0.0f; }
+        }
+        for (int i = lane; i < EPW * DW_NUM_BODIES * 3; i += 64) {
+            const int ee = i / (DW_NUM_BODIES * 3), w = i - DW_NUM_BODIES * 3 * ee, eg = wave_index * EPW + ee;
+            if (eg < N && PQ_PSI(ee, PS_BAD)) B.contact_forces[(size_t)DW_NUM_BODIES * 3 * eg + w] = 0.0f;
+        }
+        wave_sync();
+    }
+
+    DQ_STAMP(B, 43);
+    // ---- Q2: reward terms, one group per lane of the quad ----
+    {
+        // the three 33-element norms in torch's CPU order: 8 fused accumulators over elements a, a+8, a+16, a+24, added in
+        // order, then the 33rd element fused (dw_task.h Q2 / Q2b)
+        auto norm33 = [&](int which) {
+            float acc[8];
+            DQ_UNROLL for (int a = 0; a < 8; ++a) {
+                float s = 0.0f;
+                DQ_UNROLL for (int d0 = 0; d0 < 32; d0 += 8) {
+                    const int jj = d0 + a;
+                    const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
+                                  : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
+                    s = fmaf(x, x, s);
+                }
+                acc[a] = s;
+            }
+            float b0 = acc[0];
+            DQ_UNROLL for (int a = 1; a < 8; ++a) b0 = b0 + acc[a];
+            const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + 32) - PQ_Q(el, 32)
+                          : (which == 1 ? 0.0f - PQ_QD(el, 32) : PQ_QD(el, 32) - PQ_ES(el, DW_ES_PRE_QVEL + 32));
+            b0 = fmaf(x, x, b0);
+            const float n = sqrtf(b0);
+            const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
+            return coef * expf(rate * (n * n));
+        };
+        if (j == 0) {
+            const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
+            const float aerr = fabsf(dw::quat_err(qq));
+            PQ_PS(el, PS_RTERM + 14) = aerr;
+            PQ_PS(el, PS_RTERM + 0) = 0.3f * expf(-13.2f * aerr);
+            const float dv[2] = {PQ_ES(el, DW_ES_TARGET_VEL) - PQ_ROOT(el, 7), PQ_ES(el, DW_ES_TARGET_VEL + 1) - PQ_ROOT(el, 8)};
+            const float n = dw::norm_t(dv, 2);
+            PQ_PS(el, PS_RTERM + 6) = 0.3f * expf(-3.0f * (n * n));
+        }
+        if (j == 1) {
+            PQ_PS(el, PS_RTERM + 1) = norm33(0);
+            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_fn([&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }, 12));
+        }
+        if (j == 2) {
+            PQ_PS(el, PS_RTERM + 2) = norm33(1);
+            PQ_PS(el, PS_RTERM + 7) = norm33(2);
+        }
+        if (j == 3) {
+            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_fn([&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }, 12));
+            const float lf[3] = {PQ_PS(el, PS_FOOT), PQ_PS(el, PS_FOOT + 1), PQ_PS(el, PS_FOOT + 2)};
+            const float rf[3] = {PQ_PS(el, PS_FOOT + 3), PQ_PS(el, PS_FOOT + 4), PQ_PS(el, PS_FOOT + 5)};
+            const float lfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 1), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 2)};
+            const float rfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 3), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 4), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 5)};
+            float dl[3], dr[3];
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
+            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_t(dl, 3) + dw::norm_t(dr, 3)));
+            const bool lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
+            const int idx = PQ_ESI(el, DW_ES_MOCAP_IDX);
+            const bool DSP = (3300 <= idx && idx < 3600) || (idx < 300) || (1500 <= idx && idx < 2100);
+            const bool RSSP = 300 <= idx && idx < 1500;
+            const bool LSSP = 2100 <= idx && idx < 3300;
+            float fcr = 0.0f;
+            if (DSP && rcon && lcon) fcr = 0.2f;
+            if (RSSP && rcon && !lcon) fcr = 0.2f;
+            if (LSSP && !rcon && lcon) fcr = 0.2f;
+            PQ_PS(el, PS_RTERM + 8) = fcr;
+            PQ_ES(el, DW_ES_CRS) = PQ_ES(el, DW_ES_CRS) + fcr;
+            PQ_PS(el, PS_RTERM + 10) = 0.0f;
+            const float tm = PQ_PS(el, PS_MASS);
+            const float thr = (float)(1.4 * 9.81) * tm;
+            const bool th = (lf[2] > thr) || (rf[2] > thr);
+            PQ_PS(el, PS_RTERM + 11) = th ? -0.2f * 1.0f : 0.0f;
+            const float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
+            const float pen = 0.1f * expf(-0.007f * (dw::norm_t(&cl, 1) + dw::norm_t(&cr, 1)));
+            PQ_PS(el, PS_RTERM + 3) = th ? pen : 0.1f * 1.0f;
+            const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
+            const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
+            PQ_PS(el, PS_RTERM + 12) = dd ? -0.05f * 1.0f : 0.0f;
+            const float ws = dw::divs(C.gpu_div, tm, 104.48);
+            const float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * PQ_ES(el, DW_ES_TARGET_FORCE)));
+            const float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * PQ_ES(el, DW_ES_TARGET_FORCE + 1)));
+            PQ_PS(el, PS_RTERM + 13) = tl + tr;
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 44);
+    // ---- Q3: total reward, termination ----
+    {
+        const bool collision = PQ_PSI(el, PS_COLL) != 0;
+        const float aerr = PQ_PS(el, PS_RTERM + 14);
+        // stacked_rewards: 15 words per env, the quad writes them (lane j takes 4 j .. 4 j + 3)
+        if (X.valid) {
+            DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                const int l = 4 * j + i;
+                if (l < 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
+                if (l == 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + 14] = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
+            }
+        }
+        if (j == 0) {
+            const float *r = &PQ_PS(el, PS_RTERM);
+            float total = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + r[10] + r[11] + r[12] + r[13];
+            if (collision) total = 1.0f * C.death_cost;
+            if (aerr > 0.5f) total = 1.0f * C.death_cost;
+            int reset = aerr > 0.5f ? 1 : 0;
+            if ((float)PQ_PSI(el, PS_PROGRESS) >= C.max_episode_length - 1.0f) reset = 1;
+            if (collision) reset = 1;
+            if (PQ_PSI(el, PS_BAD)) reset = 1;
+            if (X.valid) { B.rew_buf[e] = total; B.reset_buf[e] = reset; }
+            PQ_PSI(el, PS_RESET) = reset;
+            float ret = PQ_ES(el, DW_ES_EPI_RETURN) + total;
+            if (reset) {
+                PQ_ES(el, DW_ES_LAST_RETURN) = ret;
+                PQ_ESI(el, DW_ES_EPISODES) += 1;
+                ret = 0.0f;
+            }
+            PQ_ES(el, DW_ES_EPI_RETURN) = ret;
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 45);
+    // ---- reset_idx for the envs that ended (dw_task.h reset_region) ----
+    const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
+    if (any_reset) {
+        const bool mine = PQ_PSI(el, PS_RESET) != 0;
+        if (C.terrain_curriculum && j == 0 && mine) {
+            const float d[2] = {PQ_ROOT(el, 0) - B.env_origins[3 * e], PQ_ROOT(el, 1) - B.env_origins[3 * e + 1]};
+            const float distance = dw::norm_t(d, 2);
+            const bool move_up = distance > C.terrain_half_length;
+            const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
+            const float need = dw::norm_t(tv, 2) * C.max_episode_length_s * 0.5f;
+            const bool move_down = (distance < need) && !move_up;
+            long long lvl = B.terrain_levels[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
+            if (lvl >= C.terrain_num_levels) {
+                int k = (int)(dw::noise_word(K.nz, DW_NZ_TERRAIN_LVL) * (float)C.terrain_num_levels);
+                if (k > C.terrain_num_levels - 1) k = C.terrain_num_levels - 1;
+                lvl = k;
+            } else if (lvl < 0) lvl = 0;
+            long long ty = B.terrain_types[e];
+            ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
+            const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + ty) * 3;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (X.valid) B.env_origins[3 * e + i] = o; }
+            if (X.valid) B.terrain_levels[e] = lvl;
+        }
+        wave_sync();
+        // per joint
+        DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+            const int i = lane + 64 * k;
+            const int ee = i < EPW * ND ? i / ND : 0, l = i < EPW * ND ? i - ND * ee : 0;
+            const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+            if (i < EPW * ND && PQ_PSI(ee, PS_RESET)) {
+                dw::NoiseSrc nz = K.nz;
+                nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+                const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(ee, PS_RANDOMIZE) >= 1;
+                if (do_dr && C.dr_dof) {
+                    const float ud = dw::noise_word(nz, DW_NZ_DR_DAMP + l), ua = dw::noise_word(nz, DW_NZ_DR_ARM + l);
+                    const float sd = C.dr_damp[0] + ud * (C.dr_damp[1] - C.dr_damp[0]);
+                    const float sa = C.dr_arm[0] + ua * (C.dr_arm[1] - C.dr_arm[0]);
+                    if (egr < N) { B.dof_damping[(size_t)ND * eg + l] = M.damp_nom[l] + sd; B.dof_armature[(size_t)ND * eg + l] = M.arm_nom[l] * sa; }
+                }
+                PQ_ES(ee, DW_ES_QPOS_NOISE + l) = M.q_init[l];
+                PQ_ES(ee, DW_ES_QPOS_PRE + l) = M.q_init[l];
+                PQ_ES(ee, DW_ES_QVEL_NOISE + l) = 0.0f;
+                PQ_ES(ee, DW_ES_PRE_QVEL + l) = 0.0f;
+                PQ_Q(ee, l) = fmaxf(fminf(M.q_init[l], M.qhi[l]), M.qlo[l]);
+                PQ_QD(ee, l) = 0.0f;
+                if (l < 12) {
+                    PQ_ES(ee, DW_ES_QPOS_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QPOS_BIAS + l) * 6.28f, 100.0) - (float)(3.14 / 100);
+                    PQ_ES(ee, DW_ES_MOTOR_SCALE + l) = dw::noise_word(nz, DW_NZ_MOTOR + l) * 0.4f + 0.8f;
+                    PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = 0.0f;
+                }
+                if (l < 3) PQ_ES(ee, DW_ES_QUAT_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QUAT_BIAS + l) * 6.28f, 150.0) - (float)(3.14 / 150);
+                if (l < 24) PQ_ES(ee, DW_ES_WARM + l) = 0.0f;
+                if (l < 6) PQ_ES(ee, DW_ES_FOOT_FORCE_PRE + l) = PQ_PS(ee, PS_FOOT + l);
+                if (l >= 16 && l < 29) {
+                    const int ii = l - 16;
+                    float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
+                    if (ii < 3) v += C.terrain_curriculum ? PQ_PS(ee, PS_ORG + ii) : B.env_origins[3 * eg + ii];
+                    if (ii < 2 && C.custom_origins) v += 2.0f * dw::noise_word(nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
+                    PQ_ROOT(ee, ii) = v;
+                }
+            }
+        }
+        // torque FIFO and action ring, zeroed
+        for (int i = lane; i < EPW * DW_ALOG_SLOTS * 12; i += 64) {
+            const int ee = i / (DW_ALOG_SLOTS * 12), w = i - DW_ALOG_SLOTS * 12 * ee;
+            if (PQ_PSI(ee, PS_RESET)) PQ_ES(ee, DW_ES_ACTION_LOG + w) = 0.0f;
+        }
+        for (int i = lane; i < EPW * DW_HIST_SLOTS * DW_NUM_ACT; i += 64) {
+            const int ee = i / (DW_HIST_SLOTS * DW_NUM_ACT), w = i - DW_HIST_SLOTS * DW_NUM_ACT * ee, eg = wave_index * EPW + ee;
+            if (eg < N && PQ_PSI(ee, PS_RESET)) B.action_history[(size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + w] = 0.0f;
+        }
+        // per-env scalars (dw_task.h reset_region, lane 40)
+        if (j == 0 && mine) {
+            const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
+            if (do_dr) {
+                if (C.dr_friction && X.valid) {
+                    const float uf = dw::noise_word(K.nz, DW_NZ_DR_FRIC);
+                    B.friction_scale[e] = C.dr_fric[0] + uf * (C.dr_fric[1] - C.dr_fric[0]);
+                }
+                if (X.valid) B.randomize_buf[e] = 0;
+            }
+            const float vel_mag = dw::noise_word(K.nz, DW_NZ_TARGET_VEL) * 0.8f;
+            PQ_ES(el, DW_ES_TARGET_VEL) = vel_mag * 1.0f;
+            PQ_ES(el, DW_ES_TARGET_VEL + 1) = vel_mag * 0.0f;
+            PQ_ESI(el, DW_ES_INIT_MOCAP) = dw::noise_word(K.nz, DW_NZ_INIT_MOCAP) > 0.5f ? 0 : 1800;
+            PQ_ES(el, DW_ES_TIME) = 0.0f;
+            if (X.valid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
+            int k = (int)(dw::noise_word(K.nz, DW_NZ_DELAY) * 4.0f);
+            if (k > 3) k = 3;
+            PQ_ESI(el, DW_ES_DELAY_IDX) = 2 + k;
+            PQ_ES(el, DW_ES_CRM) = PQ_ES(el, DW_ES_CRS) / PQ_ES(el, DW_ES_EPI_LEN);
+            PQ_ES(el, DW_ES_CRS) = 0.0f;
+            PQ_ESI(el, DW_ES_SIMUL_LEN) = 0;
+            PQ_ES(el, DW_ES_EPI_LEN_LOG) = PQ_ES(el, DW_ES_EPI_LEN);
+            PQ_ES(el, DW_ES_EPI_LEN) = 0.0f;
+            PQ_ESI(el, DW_ES_PERT_COUNT) = 0;
+            PQ_ESI(el, DW_ES_PERT_ON) = 0;
+            int kt = (int)(dw::noise_word(K.nz, DW_NZ_PTIMING) * 2000.0f);
+            if (kt > 1999) kt = 1999;
+            PQ_ESI(el, DW_ES_PERT_TIMING) = kt;
+        }
+        wave_sync();
+    }
+
+    DQ_STAMP(B, 46);
+    // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
+    //      expensive functions (atan2, sincos, the noise draw) is executed by one or two wave passes, not by all ten ----
+    {
+        auto finish = [&](int ee, int l, float o) {
+            const int egr = wave_index * EPW + ee;
+            const float nrm = (o - M.obs_mean[l]) / M.obs_inv_std_den[l];
+            PQ_NORMED(ee, l) = nrm;
+            if (egr < N) {
+                float *oh = B.obs_history + (size_t)egr * DW_HIST_SLOTS * DW_NUM_OBS1;
+                if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {
+                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2) oh[s2 * DW_NUM_OBS1 + l] = nrm;
+                } else {
+                    oh[PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l] = nrm;
+                }
+            }
+        };
+        // joint angles / rates of the legs with their biases, target velocity: 26 plain entries per env
+        for (int i = lane; i < EPW * 26; i += 64) {
+            const int ee = i / 26, t = i - 26 * ee;
+            const int l = t < 24 ? 3 + t : 29 + (t - 24);
+            float o;
+            if (l < 15) o = PQ_ES(ee, DW_ES_QPOS_NOISE + (l - 3)) + PQ_ES(ee, DW_ES_QPOS_BIAS + (l - 3));
+            else if (l < 27) o = PQ_ES(ee, DW_ES_QVEL_NOISE + (l - 15));
+            else o = PQ_ES(ee, DW_ES_TARGET_VEL + (l - 29));
+            finish(ee, l, o);
+        }
+        // Euler angles of the base (quat2euler / mat2euler, python/isaacgym/torch_utils.py:227-273): 3 per env
+        if (lane < EPW * 3) {
+            const int ee = lane / 3, l = lane - 3 * ee;
+            const float x = PQ_ROOT(ee, 3), y = PQ_ROOT(ee, 4), z = PQ_ROOT(ee, 5), w = PQ_ROOT(ee, 6);
+            const float m00 = w * w + x * x - y * y - z * z;
+            const float m01 = 2 * x * y - 2 * w * z;
+            const float m10 = 2 * x * y + 2 * w * z;
+            const float m11 = w * w - x * x + y * y - z * z;
+            const float m20 = 2 * x * z - 2 * w * y;
+            const float m21 = 2 * y * z + 2 * w * x;
+            const float m22 = w * w - x * x - y * y + z * z;
+            const float cy = sqrtf(m00 * m00 + m10 * m10);
+            const bool cond = cy > (float)(2.220446049250313e-16 * 4);
+            const float num = l == 0 ? m21 : (l == 1 ? -m20 : (cond ? m10 : -m01));
+            const float den = l == 0 ? m22 : (l == 1 ? cy : (cond ? m00 : m11));
+            float o = atan2f(num, den);
+            if (l == 0 && !cond) o = 0.0f;
+            o = o + PQ_ES(ee, DW_ES_QUAT_BIAS + l);
+            finish(ee, l, o);
+        }
+        // gait phase as sin / cos: 2 per env
+        if (lane < EPW * 2) {
+            const int ee = lane >> 1, l = 27 + (lane & 1);
+            const float time2idx = dw::divs(C.gpu_div, dw::remainder_t(PQ_ES(ee, DW_ES_TIME), period), cdt_d);
+            const float phase = dw::divs(C.gpu_div, dw::remainder_t((float)PQ_ESI(ee, DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
+            const float ang = (float)(2 * 3.14159265358979) * phase;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            finish(ee, l, l == 27 ? sn : cs);
+        }
+        // base velocity with its noise draw: 6 per env
+        for (int i = lane; i < EPW * 6; i += 64) {
+            const int ee = i / 6, l = 31 + (i - 6 * ee);
+            const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+            dw::NoiseSrc nz = K.nz;
+            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+            finish(ee, l, PQ_ROOT(ee, 7 + (l - 31)) + (dw::noise_word(nz, DW_NZ_VEL + (l - 31)) * 0.05f - 0.025f));
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 47);
+    // ---- Q5: 487-d observation buffer from the ring taps.  The wave's 16 obs rows are one 31 KB run; items (env, word of
+    //      a 37- or 13-word block) are decomposed once and reused for every tap, two taps' loads in flight per wait ----
+    {
+        float *ob = B.obs_buf + (size_t)wave_index * EPW * DW_NUM_OBS;
+        {
+            constexpr int PO = (EPW * DW_NUM_OBS1 + 63) / 64;             // 10 passes cover the 16 x 37 words of one tap
+            int ee_[PO], k_[PO];
+            DQ_UNROLL for (int u = 0; u < PO; ++u) {
+                const int i = lane + 64 * u;
+                ee_[u] = i < EPW * DW_NUM_OBS1 ? i / DW_NUM_OBS1 : -1;
+                k_[u] = i < EPW * DW_NUM_OBS1 ? i - DW_NUM_OBS1 * ee_[u] : 0;
+            }
+            for (int ii = 0; ii < DW_NUM_HIS; ii += 2) {
+                float v0[PO], v1[PO];
+                DQ_UNROLL for (int u = 0; u < PO; ++u) {
+                    v0[u] = v1[u] = 0.0f;
+                    const int ee = ee_[u];
+                    if (ee >= 0) {
+                        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+                        const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD), head = (newest + 1) % DW_HIST_SLOTS;
+                        const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f;
+                        const float nv = PQ_NORMED(ee, k_[u]);
+                        const float *oh = B.obs_history + (size_t)eg * DW_HIST_SLOTS * DW_NUM_OBS1 + k_[u];
+                        const int s0 = (head + DW_NUM_SKIP * (ii + 1) - 1) % DW_HIST_SLOTS, s1 = (head + DW_NUM_SKIP * (ii + 2) - 1) % DW_HIST_SLOTS;
+                        v0[u] = (fill || s0 == newest) ? nv : oh[s0 * DW_NUM_OBS1];
+                        v1[u] = (fill || s1 == newest) ? nv : oh[s1 * DW_NUM_OBS1];
+                    }
+                }
+                DQ_UNROLL for (int u = 0; u < PO; ++u) {
+                    const int ee = ee_[u];
+                    if (ee >= 0 && wave_index * EPW + ee < N) {
+                        ob[ee * DW_NUM_OBS + ii * DW_NUM_OBS1 + k_[u]] = v0[u];
+                        ob[ee * DW_NUM_OBS + (ii + 1) * DW_NUM_OBS1 + k_[u]] = v1[u];
+                    }
+                }
+            }
+        }
+        {
+            constexpr int PA = (EPW * DW_NUM_ACT + 63) / 64;              // 4 passes cover the 16 x 13 words of one action tap
+            static_assert((DW_NUM_HIS - 1) % 3 == 0, "action taps are gathered three at a time");
+            int ee_[PA], k_[PA];
+            DQ_UNROLL for (int u = 0; u < PA; ++u) {
+                const int i = lane + 64 * u;
+                ee_[u] = i < EPW * DW_NUM_ACT ? i / DW_NUM_ACT : -1;
+                k_[u] = i < EPW * DW_NUM_ACT ? i - DW_NUM_ACT * ee_[u] : 0;
+            }
+            for (int ii = 0; ii < DW_NUM_HIS - 1; ii += 3) {
+                float v[3][PA];
+                DQ_UNROLL for (int u = 0; u < PA; ++u) {
+                    const int ee = ee_[u];
+                    DQ_UNROLL for (int t = 0; t < 3; ++t) v[t][u] = 0.0f;
+                    if (ee >= 0) {
+                        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+                        const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD), head = (newest + 1) % DW_HIST_SLOTS;
+                        const bool rs = PQ_PSI(ee, PS_RESET) != 0;
+                        const float av = PQ_ES(ee, DW_ES_ACTIONS + k_[u]);
+                        const float *ah = B.action_history + (size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + k_[u];
+                        DQ_UNROLL for (int t = 0; t < 3; ++t) {
+                            const int sl = (head + DW_NUM_SKIP * (ii + t + 1)) % DW_HIST_SLOTS;
+                            v[t][u] = rs ? 0.0f : (sl == newest ? av : ah[sl * DW_NUM_ACT]);
+                        }
+                    }
+                }
+                DQ_UNROLL for (int u = 0; u < PA; ++u) {
+                    const int ee = ee_[u];
+                    if (ee >= 0 && wave_index * EPW + ee < N) {
+                        DQ_UNROLL for (int t = 0; t < 3; ++t) ob[ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + (ii + t) * DW_NUM_ACT + k_[u]] = v[t][u];
+                    }
+                }
+            }
+        }
+    }
+
+    DQ_STAMP(B, 48);
+    // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPW * ND) {
+            const int ee = i / ND, l = i - ND * ee;
+            PQ_ES(ee, DW_ES_PRE_QVEL + l) = PQ_QD(ee, l);
+            if (l < 12) PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = PQ_ES(ee, DW_ES_ACTION_TORQUE + l);
+            if (l < DW_NUM_ACT) PQ_ES(ee, DW_ES_ACTIONS_PRE + l) = PQ_ES(ee, DW_ES_ACTIONS + l);
+            if (l >= 20 && l < 26) PQ_ES(ee, DW_ES_FOOT_FORCE_PRE + (l - 20)) = PQ_PS(ee, PS_FOOT + (l - 20));
+        }
+    }
+    wave_sync();
+    if (j == 0) {
+        PQ_ESI(el, DW_ES_HIST_HEAD) = (PQ_ESI(el, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+        if (C.perturb && !C.force_perturb_start && X.valid) {
+            const float eln = PQ_ES(el, DW_ES_EPI_LEN_LOG), cm = PQ_ES(el, DW_ES_CRM);
+            const int bk = e % dw::GATE_BUCKETS;
+            long long de, dc = 0;
+            if (dw::finitef(eln) && dw::finitef(cm)) { de = (long long)eln; dc = (long long)llrintf(cm * 4294967296.0f); }
+            else de = -((long long)1 << 62);
+            atomic_add_u64(reinterpret_cast<unsigned long long *>(&K.gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2]), (unsigned long long)de);
+            atomic_add_u64(reinterpret_cast<unsigned long long *>(&K.gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2 + 1]), (unsigned long long)dc);
+            K.gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2] = 0;
+            K.gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2 + 1] = 0;
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 49);
+    // ---- write back: the records (contiguous), and the Gym state of the envs whose state the task changed ----
+    {
+        constexpr int NP = EPW * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
+        const int nvalid = N - wave_index * EPW;
+        const int np_ok = (nvalid >= EPW ? EPW : nvalid) * (DW_ES_WORDS / 4);
+        F4 *dstg = reinterpret_cast<F4 *>(B.env_state + (size_t)wave_index * EPW * DW_ES_WORDS);
+        const F4 *srcl = reinterpret_cast<const F4 *>(LF + PL_ES);
+        DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
+        const bool changed = PQ_PSI(el, PS_RESET) != 0 || PQ_PSI(el, PS_BAD) != 0;
+        if (wave_any(changed)) {
+            if (j == 0 && changed && X.valid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
+            DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+                const int i = lane + 64 * k;
+                if (i < EPW * ND) {
+                    const int ee = i / ND, eg = wave_index * EPW + ee;
+                    if (eg < N && (PQ_PSI(ee, PS_RESET) || PQ_PSI(ee, PS_BAD))) {
+                        B.dof_state[((size_t)ND * wave_index * EPW) * 2 + 2 * i] = LF[PL_Q + 2 * i];
+                        B.dof_state[((size_t)ND * wave_index * EPW) * 2 + 2 * i + 1] = LF[PL_Q + 2 * i + 1];
+                    }
+                }
+            }
+        }
+    }
+    DQ_STAMP(B, 50);
+}
+
+#undef PQ_LF
+#undef PQ_ES
+#undef PQ_ESI
+#undef PQ_Q
+#undef PQ_QD
+#undef PQ_ROOT
+#undef PQ_NORMED
+#undef PQ_PS
+#undef PQ_PSI
+
+}  // namespace dwq
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

@@ -11,6 +11,7 @@
 //   quad_bcast<J>(x)       value of x in lane J of the caller's quad            (v_mov_dpp quad_perm:[J,J,J,J])
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
+//   wave_sync_global()     as wave_sync, for global memory too (workgroup-scope release / acquire).
 //   wave_sync()            LDS written before it by any lane is visible to every lane after it.  One wave = one
 //                          workgroup and a wave's LDS operations complete in order, so on the device this is a compiler
 //                          fence and no instruction.
@@ -40,6 +41,13 @@ DQ_HD void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// as wave_sync, and global-memory writes of any lane before it are visible to every lane's loads after it (one wave =
+// one workgroup on one CU: workgroup scope)
+DQ_HD void wave_sync_global() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 DQ_HD float rsqrt_nr(float x) { const float y = __builtin_amdgcn_rsqf(x); return y * (1.5f - 0.5f * x * y * y); }
 DQ_HD float rcp_nr(float x) { const float y = __builtin_amdgcn_rcpf(x); return y * (2.0f - x * y); }
@@ -198,6 +206,7 @@ DQ_HD bool wave_any(bool p) {
     return any != 0;
 }
 DQ_HD void wave_sync() { emu_barrier(); }
+DQ_HD void wave_sync_global() { emu_barrier(); }
 DQ_HD float rsqrt_nr(float x) { return 1.0f / sqrtf(x); }
 DQ_HD float rcp_nr(float x) { return 1.0f / x; }
 DQ_HD void atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }

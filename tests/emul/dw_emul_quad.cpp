@@ -33,8 +33,8 @@ void wave_body(void *p, int) {
         else dwq::quad_simulate<false>(*w->lds, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
         break;
     case 1:
-        if (h->cfg.terrain) dwq::quad_physics_step<true, true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else dwq::quad_physics_step<false, true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        if (h->cfg.terrain) dwq::quad_physics_step<true, true, true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else dwq::quad_physics_step<false, true, true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
         break;
     }
 }
@@ -102,8 +102,7 @@ int dwe_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     dw::Wave w;
     int rc = DW_OK;       // (pre_physics_step runs inside the quad kernel: quad_physics_step<.., PRE = true>)
     rc = run_waves(h, 1, actions, noise, step_index);     // with physics frozen it still runs the actuator and encoder models
-    if (rc == DW_OK)
-        for (int e = 0; e < h->cfg.num_envs; ++e) dw::step_post_env(w, *S, h->model, h->dp.C, T, e);
+    // (post_physics_step runs inside the quad kernel too: quad_physics_step<.., POST = true>)
     delete S;
     return rc;
 }

@@ -32,3 +32,10 @@ for i in range(30 + K):
                     print("   %-22s %7d" % (names[n], st[base + n] - st[base + n - 1]))
                 print("   %-22s %7d" % ("encoder epilogue", st[base + 14] - st[base + 13]))
             print("kernel epilogue %d" % (st[40] - st[1 + 16 + 14]))
+            if st[41] > st[40]:
+                print("post_physics_step %d" % (st[41] - st[40]))
+                pn = {42: "stage", 43: "Q1 + guard", 44: "Q2 reward", 45: "Q3", 46: "reset", 47: "Q4 obs", 48: "Q5 obs_buf", 49: "Q6", 50: "write back"}
+                prev = st[40]
+                for n in range(42, 51):
+                    if st[n] > 0:
+                        print("   %-22s %7d" % (pn[n], st[n] - prev)); prev = st[n]
