@@ -8,17 +8,17 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdyroswalk_hip.so")
-SOURCES = ["dw_hip.hip"]
+# (source, extra flags): the wave-per-env kernels want the ILP machine scheduler, the quad kernels the default one
+SOURCES = [("dw_hip.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_quad_kernels.hip", [])]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
-           "dw_quad.h", "dw_quad_kernels.h"]
+           "dw_quad.h", "dw_quad_kernels.h", "dw_quad_post.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_* pairs, which costs more
 # v_mov operand shuffling than it saves here (static v_mov count halves without it)
 # -amdgpu-sched-strategy=iterative-ilp: the kernel is a chain of short dependent regions at 3 waves/SIMD, so a machine
 # scheduler that lengthens the distance between an LDS load and its first use pays directly (measured -4.5 % step time,
 # -7 % lone-wave latency against the default max-occupancy scheduler; max-ilp, max-memory-clause and iterative-minreg lose)
 # -O2 rather than -O3: 1 % faster with this scheduler (less aggressive unrolling, same zero scratch)
-FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fno-slp-vectorize",
-         "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-fno-slp-vectorize"]
 
 
 def hipcc() -> str:
@@ -32,16 +32,22 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(os.path.dirname(PKG), "include", "dyros_walk.h")]
+    deps = [os.path.join(CSRC, f) for f in [s for s, _ in SOURCES] + HEADERS] + [os.path.join(os.path.dirname(PKG), "include", "dyros_walk.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or stale():
-        cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd, cwd=CSRC)
+        objs = []
+        os.makedirs(os.path.join(PKG, "_obj"), exist_ok=True)
+        for src, extra in SOURCES:
+            obj = os.path.join(PKG, "_obj", os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc()] + FLAGS + extra + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            subprocess.check_call(cmd, cwd=CSRC)
+            objs.append(obj)
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, cwd=CSRC)
     return LIB
 
 

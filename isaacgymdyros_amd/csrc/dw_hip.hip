@@ -10,7 +10,8 @@
 #include <string.h>
 
 #include "dw_params.h"
-#include "dw_quad_kernels.h"
+
+namespace dwq { struct QuadModel; }
 
 struct DwHandle {
     DwConfig        cfg;
@@ -54,39 +55,19 @@ void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const floa
     dw::step_env<true>(w, S, *M, P->C, T, (int)blockIdx.x);
 }
 
-// ---- the split pipeline (DwConfig.pipeline = 2, the default): task logic before the substeps, one wave per env ... ----
-__global__ __launch_bounds__(64)
-void dw_k_pre(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
-    __shared__ dw::TaskLds S;
-    dw::Wave w;
-    dw::TaskBuffers T;
-    T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
-    dw::step_pre_env(w, S, *M, P->C, T, (int)blockIdx.x);
-}
-// ... the two physics substeps with the actuator model, 4 lanes per env and 16 envs per wave (grid = ceil(N / 16)).
-// 38 KB of LDS per wave: 4 waves per CU, one per SIMD, so the whole 512-register file belongs to the wave ...
-template <bool TERRAIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_phys(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise,
-               long long step) {
-    __shared__ dwq::QLds L;
-    dwq::quad_physics_step<TERRAIN, true, true>(L, *QM, *M, P->C, P->B, actions, P->mocap, noise, step, (int)blockIdx.x);
-}
-// ... and the task logic after them (termination, reward, reset, observation), one wave per env.
-__global__ __launch_bounds__(64)
-void dw_k_post(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
-    __shared__ dw::TaskLds S;
-    dw::Wave w;
-    dw::TaskBuffers T;
-    T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
-    dw::step_post_env(w, S, *M, P->C, T, (int)blockIdx.x);
-}
-template <bool TERRAIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_simulate_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *tau, const float *push) {
-    __shared__ dwq::QLds L;
-    dwq::quad_simulate<TERRAIN>(L, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, P->B, tau, push, (int)blockIdx.x);
-}
+// The quad kernels (DwConfig.pipeline = 2, the default) are compiled in their own translation unit, dw_quad_kernels.hip,
+// with the compiler's default machine scheduler: the ILP scheduler that pays for the wave-per-env kernels below costs the
+// quad step 7 % (its long unrolled joint loops then keep every iteration's temporaries alive at once and spill).
+namespace dwq {
+struct QuadModel;
+void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                 const float *actions, const float *noise, long long step);
+void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                     const float *tau, const float *push);
+int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err);      // malloc'ed
+size_t quadmodel_bytes();
+int  quad_lds_bytes();
+}  // namespace dwq
 
 __global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
                                                     const float *tau, const float *push) {
@@ -152,18 +133,16 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     h->pipeline = cfg->pipeline == 0 ? 2 : cfg->pipeline;
     dwq::QuadModel *hq = nullptr;
     if (h->pipeline == 2) {
-        hq = (dwq::QuadModel *)malloc(sizeof(dwq::QuadModel));
-        if (!hq) { free(hm); free(h); return fail(DW_ENOMEM, "dw_create: out of host memory"); }
-        rc = dwq::build_quadmodel(hm, model, hq, &err);
-        if (rc) { free(hq); free(hm); free(h); return fail(rc, err); }
+        rc = dwq::build_quadmodel_host(hm, model, &hq, &err);
+        if (rc) { free(hm); free(h); return fail(rc, err); }
     }
     (void)hipGetDevice(&h->device);
     e = hipMalloc((void **)&h->d_model, sizeof(dw::DevModel));
     if (e == hipSuccess) e = hipMemcpy(h->d_model, hm, sizeof(dw::DevModel), hipMemcpyHostToDevice);
     free(hm);
     if (e == hipSuccess && hq) {
-        e = hipMalloc((void **)&h->d_qmodel, sizeof(dwq::QuadModel));
-        if (e == hipSuccess) e = hipMemcpy(h->d_qmodel, hq, sizeof(dwq::QuadModel), hipMemcpyHostToDevice);
+        e = hipMalloc((void **)&h->d_qmodel, dwq::quadmodel_bytes());
+        if (e == hipSuccess) e = hipMemcpy(h->d_qmodel, hq, dwq::quadmodel_bytes(), hipMemcpyHostToDevice);
     }
     free(hq);
     if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
@@ -216,11 +195,7 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (h->cfg.debug_freeze_physics) return DW_OK;
     DeviceGuard guard(h->device);
     if (h->pipeline == 2) {
-        const dim3 grid((h->cfg.num_envs + dwq::EPW - 1) / dwq::EPW);
-        if (h->cfg.terrain)
-            hipLaunchKernelGGL(dw_k_simulate_quad<true>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, tau, push_xy);
-        else
-            hipLaunchKernelGGL(dw_k_simulate_quad<false>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, tau, push_xy);
+        dwq::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, tau, push_xy);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_simulate_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, tau, push_xy);
@@ -239,11 +214,8 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
     DeviceGuard guard(h->device);
     if (h->pipeline == 2) {
-        const dim3 grid((h->cfg.num_envs + dwq::EPW - 1) / dwq::EPW);
-        if (h->cfg.terrain)
-            hipLaunchKernelGGL(dw_k_phys<true>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise, (long long)step_index);
-        else
-            hipLaunchKernelGGL(dw_k_phys<false>, grid, dim3(64), 0, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise, (long long)step_index);
+        dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise,
+                         (long long)step_index);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, actions, noise, (long long)step_index);
@@ -269,6 +241,6 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
 }
 
 int dw_lds_bytes(void) { return (int)sizeof(dw::Lds); }
-int dw_quad_lds_bytes(void) { return (int)sizeof(dwq::QLds); }
+int dw_quad_lds_bytes(void) { return dwq::quad_lds_bytes(); }
 
 }  // extern "C"

@@ -25,11 +25,12 @@ using dw::TaskParams;
 constexpr int EW_LTP = 0, EW_MIDX = 1;       // mocap phase time, mocap row (int bits)
 constexpr int WW_GATE = 15;                  // wave-wide word: perturbation gate open (env 0's scratch)
 
-// PRE = true: the kernel also runs pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
-// mocap phase and target, perturbation gate and schedule) -- the fused step; false: dw_k_pre has done that.
-// POST = true: ... and post_physics_step after them (dw_quad_post.h): the whole VecTask.step in one launch.
-template <bool TERRAIN, bool PRE, bool POST>
-DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
+// The whole VecTask.step for 16 envs: pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
+// mocap phase and target, perturbation gate and schedule), the two substeps with the actuator and encoder models, and
+// post_physics_step (dw_quad_post.h).  The task record is read where needed and written ONCE, by the post phase, from its
+// LDS image: what the earlier phases produce for it stays in registers (StepKeep) until the image exists.
+template <bool TERRAIN>
+DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     QLane X;
     quad_lane_init(X, wave_index, C.num_envs, C.phys, C.friction, B);
@@ -39,8 +40,8 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
     DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = es[DW_ES_WARM + 12 * f + i];
     float push_x = 0.0f, push_y = 0.0f;
     const float dt = C.phys.dt;
-    if (!PRE) { push_x = es[dw::ES_PUSH_X]; push_y = es[dw::ES_PUSH_Y]; }
-    else {
+    StepKeep KP;
+    {
         // ---- pre_physics_step, per-env scalar parts on the quad's lanes (dw_task.h P1): lane 0 the mocap phase, lane 1 the
         //      push schedule; every fp32 expression as there ----
         dw::TaskBuffers TB;
@@ -61,15 +62,11 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
             const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
             const float tf0 = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + 33], row1[1 + 33]);
             const float tf1 = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + 34], row1[1 + 34]);
-            if (X.valid) {
-                *reinterpret_cast<int *>(&es[DW_ES_MOCAP_IDX]) = midx;
-                es[DW_ES_TARGET_FORCE] = tf0; es[DW_ES_TARGET_FORCE + 1] = tf1;
-            }
+            KP.midx = midx; KP.tf0 = tf0; KP.tf1 = tf1;
         }
         if (X.j == 1) {
 #define DQ_ESI(off) (*reinterpret_cast<int *>(&es[(off)]))
-            // (tasks/dyros_dynamic_walk.py:438-447,489-502; values land in locals and are stored at the end: an env beyond the
-            //  last one shares the last env's record and must not write it)
+            // (tasks/dyros_dynamic_walk.py:438-447,489-502)
             int pert_start = DQ_ESI(DW_ES_PERT_START), pert_on = DQ_ESI(DW_ES_PERT_ON), pert_count = DQ_ESI(DW_ES_PERT_COUNT);
             int impulse = DQ_ESI(DW_ES_IMPULSE), duration = DQ_ESI(DW_ES_PERT_DURATION);
             float magnitude = es[DW_ES_MAGNITUDE], phase = es[DW_ES_PHASE];
@@ -99,11 +96,8 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
                     pert_count = 0;
                 }
             }
-            if (X.valid) {
-                DQ_ESI(DW_ES_PERT_START) = pert_start; DQ_ESI(DW_ES_PERT_ON) = pert_on; DQ_ESI(DW_ES_PERT_COUNT) = pert_count;
-                DQ_ESI(DW_ES_IMPULSE) = impulse; DQ_ESI(DW_ES_PERT_DURATION) = duration;
-                es[DW_ES_MAGNITUDE] = magnitude; es[DW_ES_PHASE] = phase;
-            }
+            KP.pert_start = pert_start; KP.pert_on = pert_on; KP.pert_count = pert_count; KP.impulse = impulse; KP.duration = duration;
+            KP.magnitude = magnitude; KP.phase = phase;
 #undef DQ_ESI
         }
         push_x = quad_bcast<1>(px);
@@ -118,7 +112,6 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
                 float *ei = B.env_state + (size_t)DW_ES_WORDS * eg;
                 const float v = dw::clamp_action(actions, eg, a);
                 const int head = *reinterpret_cast<const int *>(&ei[DW_ES_HIST_HEAD]);
-                ei[DW_ES_ACTIONS + a] = v;
                 B.action_history[((size_t)eg * DW_HIST_SLOTS + head) * DW_NUM_ACT + a] = v;
             }
         }
@@ -128,8 +121,10 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
     //      Gym tensors and the task record.  Kept per item in registers: the joint angle (integrated after each substep),
     //      the delayed leg torque of the second substep, the encoder reading of the first. ----
     float qkeep[QNI], qdkeep[QNI], tau2[QNI], qnprev[QNI];
+    float (&tgt)[QNI] = KP.tgt, (&qvk)[QNI] = KP.qv;
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
     const int simul_len0 = *reinterpret_cast<const int *>(&es[DW_ES_SIMUL_LEN]);
+    (void)f;
     DQ_STAMP(B, 0);
     DQ_UNROLL for (int k = 0; k < QNI; ++k) {
         const JointItem it = joint_item(L, wave_index, C.num_envs, X.lane, k);
@@ -141,22 +136,16 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
         qkeep[k] = q; qdkeep[k] = qd;
         qnprev[k] = ei[DW_ES_QPOS_PRE + d];
         float tau;
-        float target = 0.0f, atq = 0.0f;
-        if (PRE) {
-            // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
+        // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
+        float target, atq = 0.0f;
+        {
             const float ltp = DQ_ENVW(it.el, EW_LTP);
             const int midx = f2i(DQ_ENVW(it.el, EW_MIDX));
             const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
             target = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + d], row1[1 + d]);
-            if (it.ok) ei[DW_ES_TARGET_QPOS + d] = target;
-            if (d < 12) {
-                atq = dw::clamp_action(actions, it.env, d) * ei[DW_ES_MOTOR_SCALE + d] * M.action_high[d];
-                if (it.ok) ei[DW_ES_ACTION_TORQUE + d] = atq;
-            }
-        } else {
-            target = d < 12 ? 0.0f : ei[DW_ES_TARGET_QPOS + d];
-            atq = d < 12 ? ei[DW_ES_ACTION_TORQUE + d] : 0.0f;
+            if (d < 12) atq = dw::clamp_action(actions, it.env, d) * ei[DW_ES_MOTOR_SCALE + d] * M.action_high[d];
         }
+        tgt[k] = target;
         if (d < 12) {
             // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
             // the two substeps (the action torque of the step is appended both times); the record gets the final column
@@ -172,7 +161,6 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
             float t1 = col[0], t2 = col[1];
             DQ_UNROLL for (int s = 1; s < DW_ALOG_SLOTS; ++s) { t1 = (s == src1) ? col[s] : t1; t2 = (s == src2) ? col[s + 1] : t2; }
             tau = t1; tau2[k] = t2;
-            if (it.ok) { DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS; ++s) ei[DW_ES_ACTION_LOG + 12 * s + d] = col[s + 1]; }
         } else {
             tau = M.kp[d] * (target - q) + M.kv[d] * (-qd);
             tau2[k] = target;          // the PD target: the second substep forms its own torque from the new state
@@ -189,7 +177,6 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
         DQ_UNROLL for (int k = 0; k < QNI; ++k) {
             const JointItem it = joint_item(L, wave_index, C.num_envs, X.lane, k);
             const size_t g = (size_t)ND * it.env + it.d;
-            float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
             const int d = it.d;
             float q = qkeep[k], qd = 0.0f;
             if (!C.freeze_physics) {
@@ -204,7 +191,7 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
             const float qn = q + fminf(fmaxf(n, -0.00016f), 0.00016f);
             const float qv = C.gpu_div ? (qn - qnprev[k]) * C.inv_dt_f : (qn - qnprev[k]) / dt;
             qnprev[k] = qn;
-            if (it.ok && sub == 1) { ei[DW_ES_QVEL_NOISE + d] = qv; ei[DW_ES_QPOS_NOISE + d] = qn; ei[DW_ES_QPOS_PRE + d] = qn; }
+            qvk[k] = qv;
             if (sub == 0 && !C.freeze_physics) {
                 const float damp = B.dof_damping[g], arm = B.dof_armature[g];
                 const float tau = d < 12 ? tau2[k] : M.kp[d] * (tau2[k] - q) + M.kv[d] * (-qd);
@@ -214,28 +201,20 @@ DQ_HD void quad_physics_step(QLds &L, const QuadModel &QM, const DevModel &M, co
         wave_sync();
         DQ_STAMP(B, 1 + 16 * sub + 14);
     }
-    if (X.valid && X.j == 0) {
-        int sl = simul_len0 + 2;
-        if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
-        *reinterpret_cast<int *>(&es[DW_ES_SIMUL_LEN]) = sl;
-    }
-    if (X.valid && !C.freeze_physics) {
-        if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
-        if (X.j < 2) { DQ_UNROLL for (int i = 0; i < 12; ++i) es[DW_ES_WARM + 12 * f + i] = X.warm[i]; }
-    }
+    if (X.valid && !C.freeze_physics && X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
+    KP.simul_len = simul_len0 + 2 > DW_ALOG_SLOTS ? DW_ALOG_SLOTS : simul_len0 + 2;
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) KP.qn[k] = qnprev[k];
     DQ_STAMP(B, 40);
-    if (POST) {
+    {
         // every lane of the quad may have seen a non-sole body in contact: one flag per env
-        {
-            float c = X.coll ? 1.0f : 0.0f;
-            c += quad_xor1(c);
-            c += quad_xor2(c);
-            X.coll = c > 0.0f;
-        }
-        wave_sync_global();        // the records and tensors this kernel has written are read back below, by other lanes
-        quad_task_post<TERRAIN>(L, M, C, B, actions, noise, step, wave_index, X, qkeep, qdkeep);
-        DQ_STAMP(B, 41);
+        float c = X.coll ? 1.0f : 0.0f;
+        c += quad_xor1(c);
+        c += quad_xor2(c);
+        X.coll = c > 0.0f;
     }
+    wave_sync();
+    quad_task_post<TERRAIN>(L, M, C, B, actions, noise, step, wave_index, X, qkeep, qdkeep, KP);
+    DQ_STAMP(B, 41);
 }
 
 }  // namespace dwq

@@ -1,0 +1,52 @@
+// dw_quad_kernels.hip -- the gfx950 entry points of the quad kernels (bodies: dw_quad_kernels.h, dw_quad.h, dw_quad_post.h)
+// and their launchers.  A translation unit of its own so that it is compiled with the default machine scheduler (see
+// dw_hip.hip and isaacgymdyros_amd/build.py); linked into libdyroswalk_hip.so next to dw_hip.hip, which owns the C-ABI.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "dw_params.h"
+#include "dw_quad_kernels.h"
+
+// The whole VecTask.step of 16 envs per wavefront (grid = ceil(N / 16)): 4 lanes per env.  40 KB of LDS per wave: 4 waves
+// per CU, one per SIMD, so the whole register file (256 VGPRs + 256 AGPRs) belongs to the wave.
+template <bool TERRAIN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise,
+                    long long step) {
+    __shared__ dwq::QLds L;
+    dwq::quad_step<TERRAIN>(L, *QM, *M, P->C, P->B, actions, P->mocap, noise, step, (int)blockIdx.x);
+}
+// One physics substep at the Gym boundary, same layout.
+template <bool TERRAIN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void dw_k_simulate_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *tau, const float *push) {
+    __shared__ dwq::QLds L;
+    dwq::quad_simulate<TERRAIN>(L, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, P->B, tau, push, (int)blockIdx.x);
+}
+
+namespace dwq {
+
+void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                 const float *actions, const float *noise, long long step) {
+    const dim3 grid((num_envs + EPW - 1) / EPW);
+    if (terrain) hipLaunchKernelGGL(dw_k_step_quad<true>, grid, dim3(64), 0, stream, QM, M, P, actions, noise, step);
+    else hipLaunchKernelGGL(dw_k_step_quad<false>, grid, dim3(64), 0, stream, QM, M, P, actions, noise, step);
+}
+void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                     const float *tau, const float *push) {
+    const dim3 grid((num_envs + EPW - 1) / EPW);
+    if (terrain) hipLaunchKernelGGL(dw_k_simulate_quad<true>, grid, dim3(64), 0, stream, QM, M, P, tau, push);
+    else hipLaunchKernelGGL(dw_k_simulate_quad<false>, grid, dim3(64), 0, stream, QM, M, P, tau, push);
+}
+int build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err) {
+    QuadModel *q = (QuadModel *)malloc(sizeof(QuadModel));
+    if (!q) { *err = "out of host memory"; return DW_ENOMEM; }
+    const int rc = build_quadmodel(hm, model, q, err);
+    if (rc) { free(q); return rc; }
+    *out = q;
+    return DW_OK;
+}
+size_t quadmodel_bytes() { return sizeof(QuadModel); }
+int quad_lds_bytes() { return (int)sizeof(QLds); }
+
+}  // namespace dwq

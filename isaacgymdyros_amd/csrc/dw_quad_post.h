@@ -49,6 +49,16 @@ constexpr int PS_ORG = 28;       // [3] new tile origin (terrain curriculum)
 #define PQ_PS(el, w) LF[PL_PS + (el) * 32 + (w)]
 #define PQ_PSI(el, w) (*reinterpret_cast<int *>(&LF[PL_PS + (el) * 32 + (w)]))
 
+// What the phases before post_physics_step produce for the task record, kept in registers until the record's LDS image
+// exists (no global round trip): per-env scalars on the quad's lanes 0 / 1, per-joint values on the item lanes.
+struct StepKeep {
+    int   midx; float tf0, tf1;                                        // lane 0: mocap row, target forces
+    int   pert_start, pert_on, pert_count, impulse, duration;          // lane 1: push schedule
+    float magnitude, phase;
+    int   simul_len;                                                   // all lanes: torque FIFO fill after the two substeps
+    float tgt[QNI], qn[QNI], qv[QNI];                                  // items: mocap target, encoder angle and rate
+};
+
 // torch.norm of 3 elements on the CPU reference (dw_task.h norm_t with n = 3: fused scalar tail)
 DQ_HD float norm3_t(float x, float y, float z) {
     float b0 = fmaf(x, x, 0.0f);
@@ -62,7 +72,8 @@ DQ_HD float norm3_t(float x, float y, float z) {
 // the contact forces are the Gym tensors as they are.
 template <bool TERRAIN>
 DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const DwBuffers &B, const float *actions,
-                          const float *noise, long long step, int wave_index, QLane &X, const float (&qv)[QNI], const float (&qdv)[QNI]) {
+                          const float *noise, long long step, int wave_index, QLane &X, const float (&qv)[QNI], const float (&qdv)[QNI],
+                          const StepKeep &KP) {
     float *LF = reinterpret_cast<float *>(&L.slot[0][0]);
     const int lane = X.lane, j = X.j, el = X.el, e = X.env;
     const int N = C.num_envs;
@@ -91,14 +102,56 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
         const int np_ok = (nvalid >= EPW ? EPW : nvalid) * (DW_ES_WORDS / 4);
         const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)wave_index * EPW * DW_ES_WORDS);
         F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
-        F4 t[PER];
-        DQ_UNROLL for (int u = 0; u < PER; ++u) {
-            const int pi = lane + 64 * u;
-            // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
-            const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
-            t[u] = src[pi < NP ? ps : 0];
+        // (in groups of 8 pieces: 8 requests in flight per lane, registers the compiler keeps as registers)
+        static_assert(PER % 8 == 0, "record block pieces per lane must be a multiple of the group size");
+        for (int g8 = 0; g8 < PER; g8 += 8) {
+            float tx[8], ty[8], tz[8], tw[8];
+            DQ_UNROLL for (int u = 0; u < 8; ++u) {
+                const int pi = lane + 64 * (g8 + u);
+                // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
+                const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
+                const F4 v = src[pi < NP ? ps : 0];
+                tx[u] = v.x; ty[u] = v.y; tz[u] = v.z; tw[u] = v.w;
+            }
+            DQ_UNROLL for (int u = 0; u < 8; ++u) { const int pi = lane + 64 * (g8 + u); if (pi < NP) dst[pi] = mk4(tx[u], ty[u], tz[u], tw[u]); }
         }
-        DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < NP) dst[pi] = t[u]; }
+    }
+    wave_sync();
+    // ---- the record fields this step has produced so far (dw_task.h P1..P3), from the lanes that hold them ----
+    if (j == 0) {
+        PQ_ESI(el, DW_ES_MOCAP_IDX) = KP.midx;
+        PQ_ES(el, DW_ES_TARGET_FORCE) = KP.tf0; PQ_ES(el, DW_ES_TARGET_FORCE + 1) = KP.tf1;
+        PQ_ESI(el, DW_ES_SIMUL_LEN) = KP.simul_len;
+    }
+    if (j == 1) {
+        PQ_ESI(el, DW_ES_PERT_START) = KP.pert_start; PQ_ESI(el, DW_ES_PERT_ON) = KP.pert_on; PQ_ESI(el, DW_ES_PERT_COUNT) = KP.pert_count;
+        PQ_ESI(el, DW_ES_IMPULSE) = KP.impulse; PQ_ESI(el, DW_ES_PERT_DURATION) = KP.duration;
+        PQ_ES(el, DW_ES_MAGNITUDE) = KP.magnitude; PQ_ES(el, DW_ES_PHASE) = KP.phase;
+    }
+    if (j < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * j + i) = X.warm[i]; }
+    for (int i = lane; i < EPW * DW_NUM_ACT; i += 64) {
+        const int ee = i / DW_NUM_ACT, a = i - DW_NUM_ACT * ee;
+        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+        PQ_ES(ee, DW_ES_ACTIONS + a) = dw::clamp_action(actions, eg, a);
+    }
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPW * ND) {
+            const int ee = i / ND, d = i - ND * ee;
+            const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+            PQ_ES(ee, DW_ES_TARGET_QPOS + d) = KP.tgt[k];
+            PQ_ES(ee, DW_ES_QPOS_NOISE + d) = KP.qn[k];
+            PQ_ES(ee, DW_ES_QPOS_PRE + d) = KP.qn[k];
+            PQ_ES(ee, DW_ES_QVEL_NOISE + d) = KP.qv[k];
+            if (d < 12) {
+                // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
+                const float at = dw::clamp_action(actions, eg, d) * PQ_ES(ee, DW_ES_MOTOR_SCALE + d) * M.action_high[d];
+                PQ_ES(ee, DW_ES_ACTION_TORQUE + d) = at;
+                float col[DW_ALOG_SLOTS];
+                DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(ee, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;
+                DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) PQ_ES(ee, DW_ES_ACTION_LOG + 12 * s2 + d) = col[s2];
+            }
+        }
     }
     wave_sync();
     if (C.freeze_physics) {
@@ -480,8 +533,10 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
                         const float nv = PQ_NORMED(ee, k_[u]);
                         const float *oh = B.obs_history + (size_t)eg * DW_HIST_SLOTS * DW_NUM_OBS1 + k_[u];
                         const int s0 = (head + DW_NUM_SKIP * (ii + 1) - 1) % DW_HIST_SLOTS, s1 = (head + DW_NUM_SKIP * (ii + 2) - 1) % DW_HIST_SLOTS;
-                        v0[u] = (fill || s0 == newest) ? nv : oh[s0 * DW_NUM_OBS1];
-                        v1[u] = (fill || s1 == newest) ? nv : oh[s1 * DW_NUM_OBS1];
+                        // (unconditional loads, selected afterwards: a load under a lane condition would be waited for in place)
+                        const float l0 = oh[s0 * DW_NUM_OBS1], l1 = oh[s1 * DW_NUM_OBS1];
+                        v0[u] = (fill || s0 == newest) ? nv : l0;
+                        v1[u] = (fill || s1 == newest) ? nv : l1;
                     }
                 }
                 DQ_UNROLL for (int u = 0; u < PO; ++u) {
@@ -515,7 +570,8 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
                         const float *ah = B.action_history + (size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + k_[u];
                         DQ_UNROLL for (int t = 0; t < 3; ++t) {
                             const int sl = (head + DW_NUM_SKIP * (ii + t + 1)) % DW_HIST_SLOTS;
-                            v[t][u] = rs ? 0.0f : (sl == newest ? av : ah[sl * DW_NUM_ACT]);
+                            const float ld = ah[sl * DW_NUM_ACT];
+                            v[t][u] = rs ? 0.0f : (sl == newest ? av : ld);
                         }
                     }
                 }

@@ -33,8 +33,8 @@ void wave_body(void *p, int) {
         else dwq::quad_simulate<false>(*w->lds, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
         break;
     case 1:
-        if (h->cfg.terrain) dwq::quad_physics_step<true, true, true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else dwq::quad_physics_step<false, true, true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        if (h->cfg.terrain) dwq::quad_step<true>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else dwq::quad_step<false>(*w->lds, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
         break;
     }
 }
