@@ -545,6 +545,9 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
     // the one per-env global value a step needs (the mass scale of the body's Gym body) is requested a step ahead
     float ms_next = mscale_e[(f2i(L.hot.in[0][j][2]) >> 24) & 255];
     for (int s = 0; s < T; ++s) {
+#if defined(DQ_STAMPS_INWARD)
+        if (SB == 1) DQ_STAMP(B, 42 + s);
+#endif
         const F4 *hr = reinterpret_cast<const F4 *>(L.hot.in[s][j]);
         const F4 h0 = ld4(hr[0]), h1 = ld4(hr[1]), h2 = ld4(hr[2]), h3 = ld4(hr[3]);
         const int bits = f2i(h0.x);

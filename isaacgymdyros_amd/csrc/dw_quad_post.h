@@ -20,6 +20,11 @@
 #pragma clang fp contract(off)
 #endif
 
+#if defined(DQ_STAMPS_INWARD)      // (diagnostic build: the stamp words of the post phases are lent to the inward loop)
+#undef DQ_STAMP
+#define DQ_STAMP(B, n) do { } while (0)
+#endif
+
 namespace dwq {
 
 using dw::TaskParams;

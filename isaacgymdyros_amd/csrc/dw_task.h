@@ -98,7 +98,13 @@ DW_HD float noise_word(const NoiseSrc &nz, int w) {
     if (w < DW_NZ_VEL) {
         const float u1 = (float)((c[0] >> 8) + 1u) * 5.9604644775390625e-08f;
         const float u2 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;
+#if defined(__HIPCC__)
+        // the hardware log2 / cos (arguments in (0, 1] and [0, 2 pi)): relative error ~1e-6 of a 5e-5 rad draw, against ~250
+        // instructions of libm range reduction per draw and 66 draws per env-step
+        const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+#else
         const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+#endif
         return z * (float)(0.00016 / 3.0);
     }
     return (float)(c[0] >> 8) * 5.9604644775390625e-08f;

@@ -462,16 +462,24 @@ def test_terrain_curriculum_vs_reference_golden_on_gpu(task_const):
 
 
 @pytest.mark.gpu
-def test_terrain_physics_vs_oracle_on_gpu(task_const):
-    """One substep and a short rollout on a generated map: HIP kernel (height-field variant) against the oracle."""
+def test_terrain_physics_vs_oracle_on_gpu(task_const, pipeline):
+    """One substep on a generated map: HIP kernels (height-field variants) against the oracle.
+
+    Round 1 saw joint rates differ by up to 5e-4 here where flat ground agrees to 1e-5.  Cause (tools/diag_terrain.py, run
+    on the MI355X against the fp32 AND the fp64 oracle): not the height-field sampling or the contact frames -- the sets of
+    loaded bodies are identical in all envs -- but conditioning.  The random poses of this test start up to centimetres
+    inside rough terrain, the first substep answers with contact forces of up to 1e5 N (100 x the robot's weight), and every
+    env above 2e-4 has a joint rate at the 4.03 rad/s clamp.  fp32 rounding scales with the force: the kernels are CLOSER
+    to the fp64 oracle (7e-4) than the fp32 oracle itself is (1e-3).  So the bound scales with the load: 1.5e-4 rad/s plus
+    3e-4 per 5 kN of peak contact force (an env standing on its feet, 1 kN, is held to 2.1e-4), 3e-5 without contact."""
     from hip_backend import make_env
     from isaacgymdyros_amd.terrain import Terrain, TerrainCfg
     from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
     from oracle.oracle import OracleSim
     tdict = dict(mesh_type="heightfield", curriculum=True, num_rows=2, num_cols=4, border_size=2, max_init_terrain_level=1,
                  terrain_proportions=[0.2, 0.2, 0.3, 0.3, 0.0])
-    N = 64
-    env = make_env(N, randomize=False, terrain=tdict, seed=3)
+    N = 256
+    env = make_env(N, randomize=False, terrain=tdict, seed=3, pipeline=pipeline)
     t = Terrain(TerrainCfg(**tdict), N, seed=3)
     assert np.array_equal(env.height_samples.cpu().numpy(), t.heightsamples)
     A = OracleSim(N, terrain=t)
@@ -488,11 +496,17 @@ def test_terrain_physics_vs_oracle_on_gpu(task_const):
     tau = rng.uniform(-30, 30, size=(N, 33)).astype(np.float32)
     A.simulate(tau); env.simulate(torch.from_numpy(tau).cuda()); torch.cuda.synchronize()
     cfa, cfb = A.buf["contact_forces"], env.contact_forces.cpu().numpy()
-    assert np.abs(cfa).max() > 100.0
+    fmax = np.linalg.norm(cfa, axis=2).max(axis=1)                       # peak contact force per env [N]
+    assert (fmax > 100.0).sum() > N // 2                                  # the terrain is being touched
+    assert np.array_equal(np.linalg.norm(cfa, axis=2) > 0, np.linalg.norm(cfb, axis=2) > 0)      # same bodies loaded
     assert np.abs(cfa - cfb).max() <= 2e-3 * np.abs(cfa).max() + 0.05
     ds = env._buf["dof_state"].cpu().numpy()
     assert np.abs(A.buf["dof_state"][..., 0] - ds[..., 0]).max() < 1e-5           # positions after one substep
-    assert np.abs(A.buf["dof_state"][..., 1] - ds[..., 1]).max() < 2e-3           # rates right after stiff first contacts (|qd| up to 4 rad/s)
+    err = np.abs(A.buf["dof_state"][..., 1] - ds[..., 1]).max(axis=1)
+    assert (fmax < 5e3).sum() > N // 3                                    # a third of the envs carry realistic loads
+    bound = 1.5e-4 + 3e-4 * fmax / 5e3                                    # measured on the MI355X: max err / bound = 0.87
+    assert (err <= bound).all(), (err / bound).max()
+    assert err[fmax == 0].max() < 3e-5                                    # no contact: the flat-ground figure
     assert np.abs(A.buf["root_states"] - env.root_states.cpu().numpy()).max() < 1e-3
 
 
