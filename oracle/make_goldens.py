@@ -10,6 +10,13 @@ RNG draws, per-step injected physics state) and the reference's outputs.
                           step, so everything recorded is the reference's torch task logic and nothing else:
                           mocap target, action/torque/delay pipeline, push perturbation, encoder model,
                           termination, the 14-term reward, reset_idx, the 487-d observation with history.
+  dr_reset.npz            as task_logic_frozen, but with the reference's domain randomisation ON (`env.randomize = True`):
+                          every reset runs the reference's `apply_randomizations` (tasks/base/vec_task.py:519-733) with the
+                          real `isaacgym/gymutil.py` helpers over the fake gym.  Recorded: the numpy samples each call drew
+                          (as U[0,1) words of the noise record: u = (sample - lo) / (hi - lo)), and the damping / armature
+                          the fake gym was handed by `set_actor_dof_properties`, plus randomize_buf.  Pins: additive /
+                          scaling FROM THE ORIGINAL value, independent per DoF, only for envs with reset_buf set and
+                          randomize_buf >= frequency, randomize_buf zeroed for exactly those.
   whole_step_oracle.npz   the same class stepping over the ORACLE's physics (the closed PhysX engine cannot
                           be run: physics parity is unpinned).  Pins the orchestration
                           (call order, substep loop, late updates) of dw_step; the HIP library is held to it
@@ -77,15 +84,37 @@ TERRAIN_CASE = dict(mesh_type="heightfield", curriculum=True, num_rows=3, num_co
                     max_init_terrain_level=2, terrain_proportions=[0.3, 0.0, 0.3, 0.2, 0.2])
 
 
+class DrRecorder:
+    """Records the float64 samples `generate_random_samples` hands `apply_random_samples` (python/isaacgym/gymutil.py:
+    584-607), in call order, while active."""
+
+    def __init__(self, gymutil):
+        self.gu, self.log = gymutil, []
+
+    def __enter__(self):
+        self._orig = self.gu.generate_random_samples
+
+        def wrapped(params, shape, *a, **k):
+            out = self._orig(params, shape, *a, **k)
+            self.log.append((tuple(params["range"]), params["operation"], np.array(out, dtype=np.float64, copy=True)))
+            return out
+        self.gu.generate_random_samples = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.gu.generate_random_samples = self._orig
+
+
 def run(kind: str, N: int, steps: int, seed: int):
     tc = load_task_constants()
     terr = kind == "terrain"
-    frozen = kind == "frozen" or terr
+    dr = kind == "dr"
+    frozen = kind == "frozen" or terr or dr
     A = OracleSim(N, task_const=tc, debug_freeze_physics=int(frozen))
     env, fake, mods = RH.make_reference_env(A, N, seed=seed, terrain=TERRAIN_CASE if terr else None)
-    env.randomize = False     # the numpy-RNG domain randomisation at resets cannot be replayed through U[0,1) words
+    env.randomize = dr        # (other fixtures: off, so that they pin the task logic alone)
     env.reset()
-    B = OracleSim(N, task_const=tc, randomize_dof_on_reset=0, debug_freeze_physics=int(frozen),
+    B = OracleSim(N, task_const=tc, randomize_dof_on_reset=int(dr), debug_freeze_physics=int(frozen),
                   terrain=env.terrain if terr else None, **(dict(max_episode_length_s=float(env.max_episode_length_s)) if terr else {}))
     for k in ("mass_scale", "dof_damping", "dof_armature"):
         B.buf[k][:] = A.buf[k]
@@ -101,6 +130,7 @@ def run(kind: str, N: int, steps: int, seed: int):
     actions_all, noise_all, inj = [], [], {"root": [], "dof": [], "cf": []}
     force_at = 3 if frozen else 10
     lvl_steps, org_steps = [], []
+    dr_steps = {"dof_damping": [], "dof_armature": [], "randomize_buf": [], "dr_envs": []}
     for t in range(steps):
         a = torch.rand(N, 13, generator=g) * 2.4 - 1.2       # some outside +-1: exercises the clamp
         if t == force_at:
@@ -117,11 +147,28 @@ def run(kind: str, N: int, steps: int, seed: int):
         pert_ids = None
         if bool(env.perturb_start[0, 0]):
             pert_ids = torch.nonzero((env.epi_len % 2000.0) == env.perturb_timing).flatten().numpy()
-        with RH.RngRecorder() as rec:
+        rb_before = env.randomize_buf.numpy().copy()
+        with RH.RngRecorder() as rec, DrRecorder(mods["gymutil"]) as drrec:
             o, r, d, ex = env.step(a.clone())
         reset_ids = d.nonzero().flatten().numpy()
         nz = P.noise_from_log(rec.log, N, pert_ids, reset_ids, terrain_levels=TERRAIN_CASE["num_rows"] if terr else 0,
                               terrain_curriculum=terr)
+        if dr:
+            # apply_randomizations walks the randomised envs in index order and draws, per env, damping then armature
+            # (cfg/task/DyrosDynamicWalk.yaml:103-115); the mass is setup-only (:82-88) and draws nothing here
+            dr_ids = [int(i) for i in reset_ids if rb_before[i] + 1 >= 1]
+            assert len(drrec.log) == 2 * len(dr_ids), (len(drrec.log), len(dr_ids))
+            for n_, i in enumerate(dr_ids):
+                (lo, hi), op, smp = drrec.log[2 * n_]
+                assert op == "additive" and smp.shape == (33,)
+                nz[i, abi.K["DW_NZ_DR_DAMP"]:abi.K["DW_NZ_DR_DAMP"] + 33] = (smp - lo) / (hi - lo)
+                (lo, hi), op, smp = drrec.log[2 * n_ + 1]
+                assert op == "scaling" and smp.shape == (33,)
+                nz[i, abi.K["DW_NZ_DR_ARM"]:abi.K["DW_NZ_DR_ARM"] + 33] = (smp - lo) / (hi - lo)
+            dr_steps["dof_damping"].append(A.buf["dof_damping"].copy()); dr_steps["dof_armature"].append(A.buf["dof_armature"].copy())
+            dr_steps["randomize_buf"].append(env.randomize_buf.numpy().copy())
+            mask = np.zeros(N, np.int64); mask[dr_ids] = 1
+            dr_steps["dr_envs"].append(mask)
         actions_all.append(a.numpy().copy())
         noise_all.append(nz)
         snap = P.snapshot_reference(env, ex)
@@ -145,7 +192,10 @@ def run(kind: str, N: int, steps: int, seed: int):
                   "terrain_curriculum", "terrain_num_levels", "terrain_num_types", "terrain_env_length", "max_episode_length_s"):
             out["cfg_" + k] = getattr(B.cfg, k)
         out["step_terrain_levels"] = np.stack(lvl_steps); out["step_env_origins"] = np.stack(org_steps)
-    path = os.path.join(OUT, "terrain_logic_frozen.npz" if terr else ("task_logic_frozen.npz" if frozen else "whole_step_oracle.npz"))
+    if dr:
+        for k, v in dr_steps.items():
+            out["step_" + k] = np.stack(v)
+    path = os.path.join(OUT, "dr_reset.npz" if dr else ("terrain_logic_frozen.npz" if terr else ("task_logic_frozen.npz" if frozen else "whole_step_oracle.npz")))
     np.savez_compressed(path, **out)
     nres = int(np.stack(rec_steps["reset_buf"]).sum())
     npert = int(np.stack(rec_steps["pert_on"]).sum())
@@ -156,10 +206,12 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     if not RH.available():
         sys.exit("reference checkout not present; goldens can only be minted where it is mounted")
-    only = sys.argv[1] if len(sys.argv) > 1 else None        # "frozen" | "oracle" | "terrain": mint one fixture only
+    only = sys.argv[1] if len(sys.argv) > 1 else None        # "frozen" | "oracle" | "terrain" | "dr": mint one fixture only
     if only in (None, "frozen"):
         run("frozen", N=24, steps=20, seed=11)
     if only in (None, "oracle"):
         run("oracle", N=8, steps=120, seed=5)
     if only in (None, "terrain"):
         run("terrain", N=24, steps=24, seed=17)
+    if only in (None, "dr"):
+        run("dr", N=24, steps=24, seed=23)

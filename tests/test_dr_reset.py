@@ -1,0 +1,53 @@
+"""Reset-time domain randomisation against the REFERENCE: tests/golden/dr_reset.npz was recorded from
+the reference's `apply_randomizations` (tasks/base/vec_task.py:519-733) + `isaacgym/gymutil.py:584-619` running over the
+fake gym with `randomize = True` (oracle/make_goldens.py "dr").  Held here: damping = original + U(0, 2.9) and armature =
+original x U(0.8, 1.2), independent per DoF, from the ORIGINAL values (not compounding), only for envs that are reset while
+randomize_buf >= frequency, and randomize_buf zeroed for exactly those.  The reference forms the new value in float64 and
+rounds once to the float32 property array; the kernels work in float32 from the same U[0,1) word: <= 2 ulp."""
+import numpy as np
+import pytest
+
+import replay as R
+from oracle import parity as P
+
+
+def check_dr_replay(backend, steps=None):
+    g = R.load("dr_reset.npz")
+    prev_d, prev_a = g["init_dof_damping"].copy(), g["init_dof_armature"].copy()
+    n_dr = 0
+    for t, ref, got in R.replay(g, backend):
+        bufs = backend.read_buffers()
+        d, a = np.asarray(bufs["dof_damping"]), np.asarray(bufs["dof_armature"])
+        mask = g["step_dr_envs"][t].astype(bool)
+        # randomised envs: the reference's values to 2 ulp
+        assert P.ulp_diff(g["step_dof_damping"][t][mask], d[mask]).max(initial=0) <= 2, t
+        assert P.ulp_diff(g["step_dof_armature"][t][mask], a[mask]).max(initial=0) <= 2, t
+        # everybody else: untouched, bit for bit (the gate of vec_task.py:540-544)
+        assert np.array_equal(d[~mask], prev_d[~mask]) and np.array_equal(a[~mask], prev_a[~mask]), t
+        assert np.array_equal(np.asarray(bufs["randomize_buf"]), g["step_randomize_buf"][t]), t
+        assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
+        # and the task logic around it is the reference's, as in the other frozen fixtures
+        bad = P.compare(ref, got, exact=R.EXACT_LOGIC + ["qpos_noise", "qvel_noise"], atol=R.TRANSCENDENTAL)
+        assert not bad, (t, bad)
+        prev_d, prev_a = d.copy(), a.copy()
+        n_dr += int(mask.sum())
+        if steps is not None and t + 1 >= steps:
+            break
+    assert n_dr > 50           # the fixture exercises the path (107 resets in 24 steps)
+    # the draws are from the ORIGINAL values: damping stays within 0.1 + [0, 2.9], armature within nominal x [0.8, 1.2]
+    from isaacgymdyros_amd.model import ARMATURE
+    assert prev_d.min() >= 0.1 - 1e-6 and prev_d.max() <= 3.0 + 1e-5
+    assert (prev_a >= 0.8 * np.asarray(ARMATURE, np.float32) - 1e-6).all() and (prev_a <= 1.2 * np.asarray(ARMATURE, np.float32) + 1e-5).all()
+
+
+@pytest.mark.parametrize("which", ["oracle", "wave-per-env", "quad"])
+def test_reset_time_dr_matches_the_reference(which, task_const):
+    g = R.load("dr_reset.npz")
+    N = int(g["N"])
+    kw = dict(randomize_dof_on_reset=1, debug_freeze_physics=1, torch_gpu_div=0)
+    if which == "oracle":
+        be = R.OracleBackend(N, task_const, **kw)
+    else:
+        from emul_backend import EmulBackend
+        be = EmulBackend(N, task_const, quad=(which == "quad"), **kw)
+    check_dr_replay(be)

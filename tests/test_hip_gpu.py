@@ -145,6 +145,15 @@ def test_in_kernel_rng_matches_oracle_bitwise(task_const, pipeline):
             assert np.array_equal(ob.read_buffers()[k], hb.read_buffers()[k]), k
 
 
+def test_reset_time_dr_vs_reference_on_gpu(pipeline):
+    """The reference's apply_randomizations at reset (recorded over the fake gym with randomize = True) replayed through the
+    HIP kernels: damping / armature to 2 ulp, the randomize_buf gate exact (tests/test_dr_reset.py has the details)."""
+    from hip_backend import HipBackend
+    from test_dr_reset import check_dr_replay
+    g = R.load("dr_reset.npz")
+    check_dr_replay(HipBackend(int(g["N"]), randomize=True, debug_freeze_physics=True, torch_gpu_div=False, pipeline=pipeline))
+
+
 @pytest.mark.parametrize("N,friction_dr", [(4096, False), (16384, False), (16384, True)])
 def test_full_size_properties(N, friction_dr, pipeline):
     """BASELINE sizes (configs 2 and 5): size-independent properties of a 60-step random-action rollout with resets,
