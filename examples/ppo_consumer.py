@@ -1,17 +1,32 @@
 #!/usr/bin/env python3
-"""Minimal PPO loop that consumes the env exactly the way the reference's rl_games fork does (BASELINE config 3).
+"""The consumer side of the drop-in boundary: the DYROS PPO of the reference's rl_games fork, restated in plain torch
+(BASELINE config 3: 16384 envs with the PPO training loop attached).
 
-Call pattern mirrored from learning/rl_games_custom/a2c_common_dyros.py: env_reset (:480-483), then per epoch
-play_steps (:629-703: policy forward, env_step (:467-478), time-out bootstrap (:656-659), done bookkeeping), GAE
-(:485-500), and mini-epochs of the clipped PPO loss (common_losses.py:4-30) with SEPARATE actor / critic optimisers
-(a2c_continuous_seperate.py:50-54).  Network and hyper-parameters from cfg/train/DyrosDynamicWalkPPO.yaml
-(MLP 256-256, horizon 128, minibatch = whole batch, 5 mini-epochs).  rl_games itself is not a dependency; this
-is the consumer side of the drop-in boundary, not part of the simulation step.  Reports step_fps / total_fps as
-a2c_common_dyros.py:1005-1008 does.
+rl_games 1.1.4 is not installed here and is not part of the simulation step, so this file restates what the reference's
+`learning/` code adds to it, with the YAML it is configured by (paths relative to python/IsaacGymEnvs/isaacgymenvs):
+
+  network            separate actor / critic MLPs 256-256 relu, orthogonal init gain 0.01, linear mu / value heads, a FIXED
+                     (non-trainable) log-sigma                           cfg/train/DyrosDynamicWalkPPO.yaml:10-38
+  sigma schedule     log-sigma from -2.3026 to -2.9957 over the first half of training
+                                                                          learning/rl_games_custom/models_dyros.py:64-70
+  neglogp, forward   learning/rl_games_custom/models_dyros.py:27-62
+  losses             clipped surrogate on exp(old_neglogp - neglogp), squared value error, bound loss on |mu| > 1.1
+                     learning/rl_games_custom/common_losses.py:4-30, a2c_continuous_seperate.py:233-241
+  optimisers         Adam(actor, lr schedule) and Adam(critic, 5e-4) stepped from ONE backward of
+                     a_loss + 0.5 c_loss critic_coef - entropy entropy_coef + b_loss bounds_loss_coef; gradient-norm
+                     clipping on the ACTOR parameters only                a2c_continuous_seperate.py:50-54,150-190
+  rollout            play_steps with value bootstrap on time-outs, GAE, per-term reward logging from
+                     extras["stacked_rewards"]                             a2c_common_dyros.py:485-500,629-703,1019-1030
+  schedule           linear learning rate 1e-5 -> 3e-6 over max_epochs (rl_games common/schedulers.py LinearScheduler, a
+                     dependency absent from the checkout: lr = min + (start - min) * max(0, max_steps - epoch) / max_steps)
+  sharded training   one process per GPU, env shards, gradients averaged with an RCCL all-reduce (the reference:
+                     Horovod, utils/rlgames_utils.py:71-81, a2c_continuous_seperate.py:171-180)
+Reports step_fps / step-and-inference fps / total fps as a2c_common_dyros.py:1005-1008 does.
 """
 from __future__ import annotations
 
 import argparse
+import math
 import os
 import sys
 import time
@@ -20,90 +35,309 @@ import torch
 import torch.nn as nn
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from isaacgymdyros_amd.config import default_cfg                      # noqa: E402
-from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk     # noqa: E402
+
+# cfg/train/DyrosDynamicWalkPPO.yaml, the values this loop reads (line numbers of that file)
+TRAIN_CFG = {
+    "network": {"separate": True, "mlp_units": [256, 256], "activation": "relu", "init_gain": 0.01,        # :12, :27-33
+                "sigma_init": -2.302585, "sigma_last": -2.9957, "fixed_sigma": True},                      # :19-25
+    "config": {
+        "mixed_precision": True, "normalize_input": False, "normalize_value": False, "value_bootstrap": True,   # :57-60
+        "clip_actions": True, "reward_scale": 1.0, "normalize_advantage": True, "gamma": 0.99, "tau": 0.95,     # :61-67
+        "learning_rate": 1e-5, "learning_rate_min": 3e-6, "lr_schedule": "linear", "kl_threshold": 0.008,       # :68-71
+        "max_epochs": 5000, "grad_norm": 0.5, "entropy_coef": 0.0, "truncate_grads": True, "e_clip": 0.2,       # :73-83
+        "horizon_length": 128, "minibatch_size": 4096, "mini_epochs": 5, "critic_coef": 0.5, "clip_value": False,   # :84-88
+        "bounds_loss_coef": 0.0, "num_rewards": 14, "separate_opt": True, "critic_lr": 5e-4,                    # :90, :94, :96; a2c_continuous_seperate.py:53
+    },
+}
 
 
-def mlp(i, o):
-    return nn.Sequential(nn.Linear(i, 256), nn.ELU(), nn.Linear(256, 256), nn.ELU(), nn.Linear(256, o))
+def load_train_yaml(path: str, **root_overrides) -> dict:
+    """TRAIN_CFG from the reference's own YAML (Hydra interpolations resolved like isaacgymdyros_amd.config.load_task_yaml)."""
+    import yaml
+    from isaacgymdyros_amd.config import ROOT_DEFAULTS, _resolve
+    root = dict(ROOT_DEFAULTS, checkpoint="", experiment="", max_iterations="", **root_overrides)
+    root["task"] = {"env": {"numEnvs": root.get("num_envs") or 4096}}
+
+    def walk(x):
+        if isinstance(x, dict):
+            return {k: walk(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [walk(v) for v in x]
+        if isinstance(x, str) and "task.env.numEnvs" in x:
+            return root["task"]["env"]["numEnvs"]
+        if isinstance(x, str) and (".name}" in x):
+            return x
+        return _resolve(x, root)
+    p = walk(yaml.safe_load(open(path)))["params"]
+    net, c = p["network"], p["config"]
+    sp = net["space"]["continuous"]
+    return {
+        "network": {"separate": net["separate"], "mlp_units": net["mlp"]["units"], "activation": net["mlp"]["activation"],
+                    "init_gain": net["mlp"]["initializer"]["gain"], "sigma_init": sp["sigma_init"]["val"],
+                    "sigma_last": sp["sigma_last"]["val"], "fixed_sigma": sp["fixed_sigma"]},
+        "config": {
+            "mixed_precision": c["mixed_precision"], "normalize_input": c["normalize_input"], "normalize_value": c["normalize_value"],
+            "value_bootstrap": c["value_bootstrap"], "clip_actions": c["clip_actions"], "reward_scale": c["reward_shaper"]["scale_value"],
+            "normalize_advantage": c["normalize_advantage"], "gamma": c["gamma"], "tau": c["tau"],
+            "learning_rate": float(c["learning_rate"]), "learning_rate_min": float(c["learning_rate_min"]), "lr_schedule": c["lr_schedule"],
+            "kl_threshold": c["kl_threshold"], "max_epochs": c["max_epochs"], "grad_norm": c["grad_norm"],
+            "entropy_coef": c["entropy_coef"], "truncate_grads": c["truncate_grads"], "e_clip": c["e_clip"],
+            "horizon_length": c["horizon_length"], "minibatch_size": c["minibatch_size"], "mini_epochs": c["mini_epochs"],
+            "critic_coef": c["critic_coef"], "clip_value": c["clip_value"], "bounds_loss_coef": float(c["bounds_loss_coef"]),
+            "num_rewards": c["num_rewards"], "separate_opt": c["separate_opt"], "critic_lr": 5e-4,
+        },
+    }
 
 
-class ActorCritic(nn.Module):
-    def __init__(self, num_obs, num_act):
+# ------------------------------------------------------------------------------------------------ model
+def _mlp(inp, units, gain):
+    layers, d = [], inp
+    for u in units:
+        lin = nn.Linear(d, u)
+        nn.init.orthogonal_(lin.weight, gain=gain)           # orthogonal_initializer, gain 0.01 (yaml:31-33)
+        nn.init.zeros_(lin.bias)
+        layers += [lin, nn.ReLU()]
+        d = u
+    return nn.Sequential(*layers), d
+
+
+class DyrosActorCritic(nn.Module):
+    """network_builder_dyros.py `actor_critic_dyros` with `separate: True`: two MLP trunks, mu and value heads, a fixed
+    log-sigma parameter (requires_grad False, :104) moved by update_action_noise."""
+
+    def __init__(self, num_obs, num_act, net_cfg=None):
         super().__init__()
-        self.actor, self.critic = mlp(num_obs, num_act), mlp(num_obs, 1)
-        self.log_std = nn.Parameter(torch.zeros(num_act))
+        nc = net_cfg or TRAIN_CFG["network"]
+        self.actor_mlp, d = _mlp(num_obs, nc["mlp_units"], nc["init_gain"])
+        self.critic_mlp, _ = _mlp(num_obs, nc["mlp_units"], nc["init_gain"])
+        self.mu, self.value = nn.Linear(d, num_act), nn.Linear(d, 1)
+        self.sigma_init, self.sigma_last = float(nc["sigma_init"]), float(nc["sigma_last"])
+        self.sigma = nn.Parameter(torch.full((num_act,), self.sigma_init), requires_grad=False)
 
-    def dist(self, obs):
-        return torch.distributions.Normal(self.actor(obs), self.log_std.exp())
+    def forward(self, obs):
+        mu = self.mu(self.actor_mlp(obs))
+        value = self.value(self.critic_mlp(obs))
+        return mu, mu * 0.0 + self.sigma, value
+
+    def update_action_noise(self, progress_remaining: float):
+        """models_dyros.py:64-70: sigma_init -> sigma_last over the first half of training, constant afterwards."""
+        b = 2 * progress_remaining - 1 if progress_remaining > 0.5 else 0.0
+        self.sigma[:] = self.sigma_init * b + self.sigma_last * (1 - b)
+
+    def actor_parameters(self):
+        return list(self.actor_mlp.parameters()) + list(self.mu.parameters())
+
+    def critic_parameters(self):
+        return list(self.critic_mlp.parameters()) + list(self.value.parameters())
 
 
-def train(num_envs=16384, epochs=2, horizon=128, mini_epochs=5, gamma=0.99, lam=0.95, clip=0.2, lr=1e-4, device="cuda:0",
-          log=print):
-    env = DyrosDynamicWalk(default_cfg(num_envs, device), device, 0, True)
-    net = ActorCritic(env.num_obs, env.num_acts).to(device)
-    opt_a = torch.optim.Adam(list(net.actor.parameters()) + [net.log_std], lr=lr)
-    opt_c = torch.optim.Adam(net.critic.parameters(), lr=lr)
-    N, H = num_envs, horizon
+def neglogp(x, mean, std, logstd):
+    """models_dyros.py:59-62"""
+    return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * x.size()[-1] + logstd.sum(dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------ losses, returns, schedules
+def actor_loss(old_neglogp, new_neglogp, advantage, e_clip):
+    """common_losses.py:17-26 (ppo branch): returns (per-sample loss, clip fraction)."""
+    ratio = torch.exp(old_neglogp - new_neglogp)
+    surr1 = advantage * ratio
+    surr2 = advantage * torch.clamp(ratio, 1.0 - e_clip, 1.0 + e_clip)
+    return torch.max(-surr1, -surr2), torch.mean((torch.abs(ratio - 1) > e_clip).float())
+
+
+def critic_loss(value_preds, values, e_clip, returns, clip_value):
+    """common_losses.py:4-14"""
+    if clip_value:
+        clipped = value_preds + (values - value_preds).clamp(-e_clip, e_clip)
+        return torch.max((values - returns) ** 2, (clipped - returns) ** 2)
+    return (returns - values) ** 2
+
+
+def bound_loss(mu, soft_bound=1.1):
+    """a2c_continuous_seperate.py:233-241"""
+    hi = torch.clamp_max(mu - soft_bound, 0.0) ** 2
+    lo = torch.clamp_max(-mu + soft_bound, 0.0) ** 2
+    return (lo + hi).sum(dim=-1)
+
+
+def discount_values(fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma, tau):
+    """GAE exactly as a2c_common_dyros.py:485-500.  Shapes: [H, N, 1] for the mb_* value tensors, [H, N] for mb_fdones."""
+    H = mb_rewards.shape[0]
+    lastgaelam = 0
+    advs = torch.zeros_like(mb_rewards)
+    for t in reversed(range(H)):
+        if t == H - 1:
+            nextnonterminal, nextvalues = 1.0 - fdones, last_values
+        else:
+            nextnonterminal, nextvalues = 1.0 - mb_fdones[t + 1], mb_values[t + 1]
+        nextnonterminal = nextnonterminal.unsqueeze(1)
+        delta = mb_rewards[t] + gamma * nextvalues * nextnonterminal - mb_values[t]
+        advs[t] = lastgaelam = delta + gamma * tau * nextnonterminal * lastgaelam
+    return advs
+
+
+def policy_kl(mu, sigma, old_mu, old_sigma):
+    """rl_games torch_ext.policy_kl (mean over the batch)."""
+    c1 = torch.log(sigma / old_sigma + 1e-5)
+    c2 = (old_sigma ** 2 + (old_mu - mu) ** 2) / (2.0 * (sigma ** 2 + 1e-5))
+    return (c1 + c2 - 0.5).sum(dim=-1).mean()
+
+
+class LinearLR:
+    """rl_games common/schedulers.py LinearScheduler (schedule_type legacy: by epoch)."""
+
+    def __init__(self, start_lr, min_lr, max_steps):
+        self.start_lr, self.min_lr, self.max_steps = float(start_lr), float(min_lr), int(max_steps)
+
+    def __call__(self, epoch):
+        mul = max(0, self.max_steps - epoch) / self.max_steps
+        return self.min_lr + (self.start_lr - self.min_lr) * mul
+
+
+def allreduce_grads(params, world: int, group=None):
+    """Average the gradients over the ranks with ONE collective on a flat bucket (RCCL over xGMI on the GPUs, gloo in the
+    CPU test): what Horovod's optimizer.synchronize() does in the reference (a2c_continuous_seperate.py:171-173)."""
+    if world <= 1:
+        return
+    import torch.distributed as dist
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    flat /= world
+    o = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[o:o + n].view_as(g))
+        o += n
+
+
+# ------------------------------------------------------------------------------------------------ the loop
+def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
+          rank=0, world=1, seed=42):
+    """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch."""
+    from isaacgymdyros_amd.config import default_cfg
+    from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+    cfg = cfg or TRAIN_CFG
+    c = cfg["config"]
+    H = int(horizon or c["horizon_length"])
+    max_epochs = int(max_epochs or c["max_epochs"])
+    own_env = env is None
+    if own_env:
+        ecfg = default_cfg(num_envs, device)
+        ecfg["seed"] = seed + rank
+        env = DyrosDynamicWalk(ecfg, device, 0, True)
+    N = env.num_envs
+    torch.manual_seed(seed)                          # same initial weights on every rank
+    net = DyrosActorCritic(env.num_obs, env.num_acts, cfg["network"]).to(device)
+    opt_a = torch.optim.Adam(net.actor_parameters(), lr=c["learning_rate"], eps=1e-8)
+    opt_c = torch.optim.Adam(net.critic_parameters(), lr=c["critic_lr"], eps=1e-8)
+    sched = LinearLR(c["learning_rate"], c["learning_rate_min"], max_epochs)
+    amp = bool(c["mixed_precision"]) and str(device).startswith("cuda")
+    scaler = torch.amp.GradScaler("cuda", enabled=amp)
+    names = list(env.extras.get("reward_names", []))
     obs = env.reset()["obs"].clone()
-    buf = dict(obs=torch.zeros(H, N, env.num_obs, device=device), act=torch.zeros(H, N, env.num_acts, device=device),
-               logp=torch.zeros(H, N, device=device), val=torch.zeros(H, N, device=device),
-               rew=torch.zeros(H, N, device=device), done=torch.zeros(H, N, device=device))
+    dones = torch.zeros(N, device=device)
+    mb = dict(obs=torch.zeros(H, N, env.num_obs, device=device), act=torch.zeros(H, N, env.num_acts, device=device),
+              neglogp=torch.zeros(H, N, device=device), val=torch.zeros(H, N, 1, device=device), rew=torch.zeros(H, N, 1, device=device),
+              done=torch.zeros(H, N, device=device), mu=torch.zeros(H, N, env.num_acts, device=device))
+    batch = H * N
+    mbs = min(int(c["minibatch_size"]), batch)
+    assert batch % mbs == 0, "horizon * num_envs must be a multiple of minibatch_size (a2c_common_dyros.py:192)"
     stats = []
-    for ep in range(epochs):
+    for ep in range(1, epochs + 1):
+        net.update_action_noise((max_epochs - ep) / max_epochs)                 # a2c_common_dyros.py:985
+        lr = sched(ep)
+        for g in opt_a.param_groups:                                           # update_lr touches the actor only (:293-295)
+            g["lr"] = lr
         t0 = time.perf_counter()
         step_time = 0.0
-        with torch.no_grad():                                   # a2c_common_dyros.py:842
+        terms = torch.zeros(len(names) or 15, device=device)
+        with torch.no_grad():                                                   # a2c_common_dyros.py:842
             for n in range(H):
-                d = net.dist(obs)
-                a = d.sample()
-                buf["obs"][n], buf["act"][n] = obs, a
-                buf["logp"][n], buf["val"][n] = d.log_prob(a).sum(-1), net.critic(obs).squeeze(-1)
+                mu, logstd, value = net(obs)
+                sigma = torch.exp(logstd)
+                a = torch.distributions.Normal(mu, sigma).sample()
+                mb["obs"][n], mb["act"][n], mb["mu"][n] = obs, a, mu
+                mb["neglogp"][n], mb["val"][n], mb["done"][n] = neglogp(a, mu, sigma, logstd), value, dones
                 torch.cuda.synchronize(); ts = time.perf_counter()
-                o, r, dones, infos = env.step(torch.clamp(a, -1.0, 1.0))
+                o, r, d, infos = env.step(torch.clamp(a, -1.0, 1.0))            # clip_actions (:467-478)
                 torch.cuda.synchronize(); step_time += time.perf_counter() - ts
-                r = r.clone()
-                if "time_outs" in infos:                         # value bootstrap on time-outs (:656-659)
-                    r += gamma * buf["val"][n] * infos["time_outs"].float()
-                buf["rew"][n], buf["done"][n] = r, dones.float()
+                r = r.unsqueeze(1) * c["reward_scale"]
+                if c["value_bootstrap"] and "time_outs" in infos:               # :656-659
+                    r = r + c["gamma"] * value * infos["time_outs"].unsqueeze(1).float()
+                mb["rew"][n] = r
+                if "stacked_rewards" in infos:                                  # :667-669 -> per-term means for the logger
+                    terms += infos["stacked_rewards"][:, :terms.numel()].mean(0)
+                dones = d.float()
                 obs = o["obs"].clone()
-            last_val = net.critic(obs).squeeze(-1)
-            adv = torch.zeros(H, N, device=device)
-            gae = torch.zeros(N, device=device)
-            for n in reversed(range(H)):                         # :485-500
-                nv = last_val if n == H - 1 else buf["val"][n + 1]
-                nonterm = 1.0 - buf["done"][n]
-                delta = buf["rew"][n] + gamma * nv * nonterm - buf["val"][n]
-                gae = delta + gamma * lam * nonterm * gae
-                adv[n] = gae
-            ret = adv + buf["val"]
+            last_values = net(obs)[2]
+            advs = discount_values(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
+            returns = advs + mb["val"]
         play_time = time.perf_counter() - t0
-        B = {k: v.reshape(H * N, *v.shape[2:]) for k, v in buf.items()}
-        A, Rt = adv.reshape(-1), ret.reshape(-1)
-        A = (A - A.mean()) / (A.std() + 1e-8)
-        for _ in range(mini_epochs):
-            d = net.dist(B["obs"])
-            ratio = (d.log_prob(B["act"]).sum(-1) - B["logp"]).exp()
-            a_loss = torch.max(-A * ratio, -A * ratio.clamp(1 - clip, 1 + clip)).mean()
-            opt_a.zero_grad(); a_loss.backward(); opt_a.step()
-            c_loss = ((net.critic(B["obs"]).squeeze(-1) - Rt) ** 2).mean()
-            opt_c.zero_grad(); c_loss.backward(); opt_c.step()
+        # swap_and_flatten01: env-major flat batch, minibatches are contiguous slices (no shuffling in rl_games' dataset)
+        flat = lambda x: x.transpose(0, 1).reshape(batch, *x.shape[2:])        # noqa: E731
+        B = {k: flat(v) for k, v in mb.items()}
+        ret, val = flat(returns), B["val"]
+        adv = (ret - val).sum(dim=1)
+        if c["normalize_advantage"]:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)                       # :945
+        a_l = c_l = b_l = cf = kl = torch.zeros((), device=device)
+        for _ in range(int(c["mini_epochs"])):
+            for i in range(batch // mbs):
+                s = slice(i * mbs, (i + 1) * mbs)
+                with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                    mu, logstd, value = net(B["obs"][s])
+                    sigma = torch.exp(logstd)
+                    nlp = neglogp(B["act"][s], mu, sigma, logstd)
+                    a_loss, cf = actor_loss(B["neglogp"][s], nlp, adv[s], c["e_clip"])
+                    c_loss = critic_loss(val[s], value, c["e_clip"], ret[s], c["clip_value"])
+                    b_loss = bound_loss(mu)
+                    entropy = torch.distributions.Normal(mu, sigma).entropy().sum(dim=-1)
+                    a_l, c_l, b_l = a_loss.mean(), c_loss.mean(), b_loss.mean()
+                    loss = a_l + 0.5 * c_l * c["critic_coef"] - entropy.mean() * c["entropy_coef"] + b_l * c["bounds_loss_coef"]
+                for p in net.parameters():
+                    p.grad = None
+                scaler.scale(loss).backward()
+                scaler.unscale_(opt_a); scaler.unscale_(opt_c)
+                allreduce_grads(net.actor_parameters() + net.critic_parameters(), world)
+                if c["truncate_grads"]:
+                    nn.utils.clip_grad_norm_(net.actor_parameters(), c["grad_norm"])       # the actor only (:178)
+                scaler.step(opt_a); scaler.step(opt_c); scaler.update()
+                with torch.no_grad():
+                    kl = policy_kl(mu.detach().float(), sigma.detach().float(), B["mu"][s], torch.exp(net.sigma).expand_as(mu))
         torch.cuda.synchronize()
         total = time.perf_counter() - t0
+        fin = env.episodes_finished > 0
         s = dict(epoch=ep, step_fps=H * N / step_time, play_fps=H * N / play_time, total_fps=H * N / total,
-                 mean_reward=float(buf["rew"].mean()), a_loss=float(a_loss.detach()), c_loss=float(c_loss.detach()),
-                 mean_episode_length=float(env.epi_len_log[env.episodes_finished > 0].mean()) if int((env.episodes_finished > 0).sum()) else 0.0)
+                 mean_reward=float(mb["rew"].mean()), a_loss=float(a_l), c_loss=float(c_l), b_loss=float(b_l), clip_frac=float(cf),
+                 kl=float(kl), lr=lr, sigma=float(net.sigma[0]),
+                 reward_terms={(names[i] if i < len(names) else "term%d" % i): float(terms[i] / H) for i in range(terms.numel())},
+                 mean_episode_length=float(env.epi_len_log[fin].mean()) if int(fin.sum()) else 0.0)
         stats.append(s)
-        log("epoch %(epoch)d: fps step %(step_fps).3g  step+inference %(play_fps).3g  total %(total_fps).3g  "
-            "mean reward %(mean_reward).3f  episode length %(mean_episode_length).1f" % s)
-    env.close()
+        if rank == 0:
+            log("epoch %(epoch)d: fps step %(step_fps).3g  step+inference %(play_fps).3g  total %(total_fps).3g  mean reward %(mean_reward).3f  "
+                "a_loss %(a_loss).3g  c_loss %(c_loss).3g  kl %(kl).2g  lr %(lr).2g  log-sigma %(sigma).3f  episode length %(mean_episode_length).1f" % s)
+    if own_env:
+        env.close()
     return stats
 
 
-if __name__ == "__main__":
+def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--num-envs", type=int, default=16384)
+    ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU")
     ap.add_argument("--epochs", type=int, default=3)
-    ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--horizon", type=int, default=None)
     a = ap.parse_args()
-    train(a.num_envs, a.epochs, a.horizon)
+    from isaacgymdyros_amd import dist as dwdist
+    rank, local_rank, world = dwdist.init_from_env("nccl")
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+    train(a.num_envs, a.epochs, a.horizon, device=dev, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

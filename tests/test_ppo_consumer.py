@@ -1,0 +1,132 @@
+"""The DYROS PPO pieces of examples/ppo_consumer.py against closed forms and the reference's YAML (VERDICT r1
+item 8).  CPU only; the rollout against the real env is a GPU test (tests/test_hip_gpu.py)."""
+import importlib.util
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _mod():
+    spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(ROOT, "examples", "ppo_consumer.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_gae_closed_form_and_done_masking():
+    m = _mod()
+    H, N, g, lam = 6, 3, 0.99, 0.95
+    # constant reward 1, zero values, no terminations: A_t = sum_k (g lam)^k
+    z = torch.zeros(H, N, 1)
+    adv = m.discount_values(torch.zeros(N), torch.zeros(N, 1), torch.zeros(H, N), z, torch.ones(H, N, 1), g, lam)
+    for t in range(H):
+        assert adv[t, 0, 0].item() == pytest.approx(sum((g * lam) ** k for k in range(H - t)), rel=1e-6)
+    # a termination recorded at t = 3 (mb_fdones[3] = the done flag BEFORE step 3) cuts the sum for t < 3
+    d = torch.zeros(H, N); d[3, 1] = 1.0
+    adv2 = m.discount_values(torch.zeros(N), torch.zeros(N, 1), d, z, torch.ones(H, N, 1), g, lam)
+    assert adv2[2, 1, 0].item() == pytest.approx(1.0) and adv2[1, 1, 0].item() == pytest.approx(1 + g * lam)
+    assert torch.equal(adv2[:, 0], adv[:, 0]) and torch.equal(adv2[3:, 1], adv[3:, 1])
+    # bootstrap from the last value and from stored values
+    v = torch.full((H, N, 1), 2.0)
+    adv3 = m.discount_values(torch.zeros(N), torch.full((N, 1), 2.0), torch.zeros(H, N), v, torch.zeros(H, N, 1), g, 0.0)
+    assert torch.allclose(adv3, torch.full((H, N, 1), g * 2.0 - 2.0))
+
+
+def test_losses_match_hand_computed_values():
+    m = _mod()
+    old, new, adv = torch.tensor([1.0, 1.0, 1.0, 1.0]), torch.tensor([1.0, 0.5, 1.5, 0.9]), torch.tensor([2.0, 2.0, -1.0, -3.0])
+    loss, frac = m.actor_loss(old, new, adv, 0.2)
+    ratio = torch.exp(old - new)
+    exp = torch.stack([torch.max(-a * r, -a * min(max(r, 0.8), 1.2)) for a, r in zip(adv, ratio)])
+    assert torch.allclose(loss, exp)
+    assert loss[1].item() == pytest.approx(-2.0 * 1.2)                       # positive advantage, ratio clipped at 1 + e
+    assert loss[2].item() == pytest.approx(1.0 * 0.8)                        # negative advantage, ratio clipped at 1 - e
+    assert frac.item() == pytest.approx(0.5)
+    assert torch.equal(m.critic_loss(torch.zeros(2), torch.tensor([1.0, 3.0]), 0.2, torch.tensor([2.0, 2.0]), False), torch.tensor([1.0, 1.0]))
+    cl = m.critic_loss(torch.tensor([0.0]), torch.tensor([1.0]), 0.2, torch.tensor([2.0]), True)
+    assert cl.item() == pytest.approx(max((1.0 - 2.0) ** 2, (0.2 - 2.0) ** 2))
+    # bound loss as the reference writes it (a2c_continuous_seperate.py:233-241): clamp_MAX, so it penalises mu INSIDE the
+    # bound and is 0 outside -- harmless upstream because bounds_loss_coef = 0 (yaml:90); restated literally, not "fixed"
+    mu = torch.tensor([[0.0, 1.2, -1.5], [1.1, -1.1, 2.0]])
+    exp = torch.tensor([1.21 + 6.76 + 0.01, 4.84 + 0.81])
+    lit = (torch.clamp_max(mu - 1.1, 0.0) ** 2 + torch.clamp_max(-mu + 1.1, 0.0) ** 2).sum(-1)
+    assert torch.allclose(m.bound_loss(mu), lit) and torch.allclose(lit, exp)
+    x, mean, ls = torch.tensor([[0.3, -0.2]]), torch.tensor([[0.1, 0.0]]), torch.tensor([[-1.0, -2.0]])
+    ref = -torch.distributions.Normal(mean, ls.exp()).log_prob(x).sum(-1)
+    assert torch.allclose(m.neglogp(x, mean, ls.exp(), ls), ref, atol=1e-6)
+
+
+def test_sigma_and_lr_schedules():
+    m = _mod()
+    net = m.DyrosActorCritic(487, 13)
+    assert not net.sigma.requires_grad and all(p.requires_grad for p in net.actor_parameters() + net.critic_parameters())
+    ids = {id(p) for p in net.actor_parameters()} & {id(p) for p in net.critic_parameters()}
+    assert not ids                                                           # separate trunks: separate optimisers
+    net.update_action_noise(1.0)
+    assert net.sigma[0].item() == pytest.approx(-2.302585)
+    net.update_action_noise(0.75)
+    assert net.sigma[0].item() == pytest.approx(0.5 * -2.302585 + 0.5 * -2.9957)
+    for pr in (0.5, 0.2, 0.0):
+        net.update_action_noise(pr)
+        assert net.sigma[0].item() == pytest.approx(-2.9957)
+    mu, logstd, value = net(torch.zeros(4, 487))
+    assert mu.shape == (4, 13) and logstd.shape == (4, 13) and value.shape == (4, 1)
+    assert float(mu.abs().max()) < 0.5                                       # orthogonal init, gain 0.01: a near-zero start
+    lr = m.LinearLR(1e-5, 3e-6, 5000)
+    assert lr(0) == pytest.approx(1e-5) and lr(5000) == pytest.approx(3e-6) and lr(2500) == pytest.approx(6.5e-6) and lr(9999) == pytest.approx(3e-6)
+
+
+def test_built_in_train_cfg_equals_the_reference_yaml():
+    path = "/root/reference/python/IsaacGymEnvs/isaacgymenvs/cfg/train/DyrosDynamicWalkPPO.yaml"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present (GPU box)")
+    m = _mod()
+    ref = m.load_train_yaml(path)
+    assert ref["network"] == m.TRAIN_CFG["network"]
+    for k, v in ref["config"].items():
+        assert m.TRAIN_CFG["config"][k] == v, (k, m.TRAIN_CFG["config"][k], v)
+
+
+def test_gradient_allreduce_averages_over_two_ranks(tmp_path):
+    """Sharded training: the N>1 path of train() is one all-reduce of the flat gradient bucket; here on gloo, world 2."""
+    worker = tmp_path / "w.py"
+    worker.write_text('''
+import importlib.util, json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from isaacgymdyros_amd import dist as dwdist
+spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(%r, "examples", "ppo_consumer.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+rank, _, world = dwdist.init_from_env("gloo")
+torch.manual_seed(0)
+net = m.DyrosActorCritic(8, 3, dict(m.TRAIN_CFG["network"], mlp_units=[16]))
+x = torch.full((4, 8), float(rank + 1))
+mu, _, v = net(x)
+(mu.sum() + v.sum()).backward()
+ps = net.actor_parameters() + net.critic_parameters()
+local = [p.grad.clone() for p in ps]
+m.allreduce_grads(ps, world)
+others = [torch.zeros_like(g) for g in local]
+for i, g in enumerate(local):
+    t = [torch.zeros_like(g) for _ in range(world)]
+    dist.all_gather(t, g)
+    others[i] = sum(t) / world
+ok = all(torch.allclose(p.grad, o, atol=1e-7) for p, o in zip(ps, others))
+json.dump({"ok": bool(ok), "world": world}, open(os.path.join(sys.argv[1], "r%%d.json" %% rank), "w"))
+dist.barrier(); dist.destroy_process_group()
+''' % (ROOT, ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29733", str(worker), str(tmp_path)], check=True, timeout=300, env=env,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for r in range(2):
+        o = json.load(open(tmp_path / ("r%d.json" % r)))
+        assert o["ok"] and o["world"] == 2
