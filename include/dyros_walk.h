@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 4
+#define DW_ABI_VERSION 5
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -55,7 +55,7 @@ extern "C" {
 #define DW_MAX_GEOMS    64
 #define DW_NUM_FOOT_PTS  8   /* 4 sole corners per foot                                   */
 #define DW_MAX_SC_PROXIES 16  /* capsule proxies for self-collision                        */
-#define DW_MAX_SC_PAIRS   16  /* proxy pairs tested each substep                           */
+#define DW_MAX_SC_PAIRS   32  /* proxy pairs tested each substep                           */
 #define DW_NUM_ACT      13   /* 12 leg torques + 1 gait-clock action                      */
 #define DW_NUM_LOWER    12
 #define DW_NUM_OBS1     37   /* single-step observation                                   */
@@ -90,7 +90,8 @@ typedef struct DwGeom {
 
 /* Capsule proxy of a link for self-collision (the reference collides every primitive with every other one:
  * create_actor(..., group=i, filter=0), tasks/dyros_dynamic_walk.py:354).  Segment end points in the moving body's
- * frame. */
+ * frame.  Shipped model: 4 proxies per leg (all 16 left x right pairs), upper arm / forearm / hand per arm and the torso
+ * (forearm and hand against torso and same-side thigh, upper arm against torso, arm against arm): 15 proxies, 30 pairs. */
 typedef struct DwCapsule {
     int32_t moving, gym;
     float   p0[3], p1[3];

@@ -436,14 +436,17 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
     wave_sync();
 
     DQ_STAMP(B, SB + 2);
-    // ---- self-collision (leg against leg).  Lane k builds the end points of left proxy k and right proxy k from their
-    //      bodies' slots; left proxy k is then tested against the four right proxies (DPP broadcasts).  The common case is
-    //      "nothing touches": then the only cost is the distance tests.  If any env of the wave has a touching pair, the two
-    //      leg lanes of every env recompute all pairs and keep the wrenches on their own bodies. ----
+    // ---- self-collision: capsule proxies (legs, arms, torso), pairs from the model.  Detection: lane p & 3 evaluates proxy p
+    //      from its body's slot; the pairs are tested in passes -- one proxy broadcast to the quad (DPP), every lane tests one
+    //      of its own against it -- and the touching pairs of the env are ORed into a mask.  The common case is "nothing
+    //      touches": then that is all.  Resolution, if any env of the wave has a touching pair: the lane that owns a proxy's
+    //      body recomputes the proxy's touching pairs from the slots and keeps the wrench (both sides of a pair compute the
+    //      same force from the same data: no hand-over between lanes). ----
     bool sc_any = false;
-    float scW[4][6], scF[4][3];
-    DQ_UNROLL for (int p = 0; p < 4; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) scF[p][i] = 0.0f; }
-    const int npl = L.hot.misc[2], npr = L.hot.misc[3];
+    float scW[QMAX_OWN][6], scF[QMAX_OWN][3];
+    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) scF[p][i] = 0.0f; }
+    const int nprox = L.hot.misc[2], ncombo = L.hot.misc[3];
+    auto proxy_bits = [&](int p) { return f2i(L.hot.prox[p][7]); };
     auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
         const F4 *pr = reinterpret_cast<const F4 *>(L.hot.prox[p]);
         const F4 c0 = ld4(pr[0]), c1 = ld4(pr[1]);
@@ -458,77 +461,68 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         p0w[0] = x4.x + t0[0]; p0w[1] = x4.y + t0[1]; p0w[2] = x4.z + t0[2];
         p1w[0] = x4.x + t1[0]; p1w[1] = x4.y + t1[1]; p1w[2] = x4.z + t1[2];
     };
-    auto proxy_body = [&](int p) { return f2i(L.hot.prox[p][7]) & 255; };
-    auto proxy_gym = [&](int p) { return (f2i(L.hot.prox[p][7]) >> 8) & 255; };
-    auto proxy_pos = [&](int p) { return (X.el + 4 * ((f2i(L.hot.prox[p][7]) >> 16) & 3)) & 15; };
-    if (P.self_collision && npl > 0) {
-        float A0[3] = {0, 0, 0}, A1[3] = {0, 0, 0}, B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0};
-        float ra = 0.0f, rb = 0.0f;
-        if (j < npl) { proxy_ends(j, A0, A1); ra = L.hot.prox[j][3]; }
-        if (j < npr) { proxy_ends(4 + j, B0, B1); rb = L.hot.prox[4 + j][3]; }
-        const float da[3] = {A1[0] - A0[0], A1[1] - A0[1], A1[2] - A0[2]};
-        // wrench and force on my left proxy (WA) and, from my pairs, on each right proxy (WB[pb])
-        float WA[6] = {0, 0, 0, 0, 0, 0}, FA[3] = {0, 0, 0}, WB[4][6], FB[4][3];
-        DQ_UNROLL for (int p = 0; p < 4; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) WB[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) FB[p][i] = 0.0f; }
-        bool hit = false;
-        DQ_UNROLL for (int pb = 0; pb < 4; ++pb) {
-            float b0[3], b1[3];
-            const float rbb = pb == 0 ? quad_bcast<0>(rb) : (pb == 1 ? quad_bcast<1>(rb) : (pb == 2 ? quad_bcast<2>(rb) : quad_bcast<3>(rb)));
-            DQ_UNROLL for (int i = 0; i < 3; ++i) {
-                b0[i] = pb == 0 ? quad_bcast<0>(B0[i]) : (pb == 1 ? quad_bcast<1>(B0[i]) : (pb == 2 ? quad_bcast<2>(B0[i]) : quad_bcast<3>(B0[i])));
-                b1[i] = pb == 0 ? quad_bcast<0>(B1[i]) : (pb == 1 ? quad_bcast<1>(B1[i]) : (pb == 2 ? quad_bcast<2>(B1[i]) : quad_bcast<3>(B1[i])));
+    if (P.self_collision && ncombo > 0) {
+        float Pe[4][7];                    // my proxies (register set r = proxy j + 4 r): p0, p1, radius
+        DQ_UNROLL for (int r = 0; r < 4; ++r) {
+            DQ_UNROLL for (int i = 0; i < 7; ++i) Pe[r][i] = 0.0f;
+            if (j + 4 * r < nprox) { proxy_ends(j + 4 * r, &Pe[r][0], &Pe[r][3]); Pe[r][6] = L.hot.prox[j + 4 * r][3]; }
+        }
+        int hits = 0;
+        for (int c = 0; c < ncombo; ++c) {
+            const int c0 = L.hot.combo[c][0], c1 = L.hot.combo[c][1];
+            const int pb = c0 & 255, reg = (c0 >> 8) & 3;
+            float src[7], bq[7], mine[7];
+            DQ_UNROLL for (int i = 0; i < 7; ++i) {
+                const int rb = pb >> 2;
+                src[i] = rb == 0 ? Pe[0][i] : (rb == 1 ? Pe[1][i] : (rb == 2 ? Pe[2][i] : Pe[3][i]));
+                mine[i] = reg == 0 ? Pe[0][i] : (reg == 1 ? Pe[1][i] : (reg == 2 ? Pe[2][i] : Pe[3][i]));
             }
-            if (j < npl && pb < npr) {
-                const float db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
-                const float r[3] = {A0[0] - b0[0], A0[1] - b0[1], A0[2] - b0[2]};
+            quad_bcast_arr(pb & 3, src, bq);
+            if ((c0 >> (12 + j)) & 1) {
+                const float da[3] = {mine[3] - mine[0], mine[4] - mine[1], mine[5] - mine[2]};
+                const float db[3] = {bq[3] - bq[0], bq[4] - bq[1], bq[5] - bq[2]};
+                const float r[3] = {mine[0] - bq[0], mine[1] - bq[1], mine[2] - bq[2]};
                 float sa, sb;
                 seg_seg(da, db, r, &sa, &sb);
-                float ca[3], cb[3], n[3];
-                DQ_UNROLL for (int i = 0; i < 3; ++i) { ca[i] = A0[i] + sa * da[i]; cb[i] = b0[i] + sb * db[i]; n[i] = ca[i] - cb[i]; }
-                const float d2 = dot3(n, n), rr = ra + rbb;
-                if (d2 < rr * rr && d2 > 1e-12f) {            // overlap (and a defined normal): penalty force along it, dw_physics.h K4b
-                    const float dist = sqrtf(d2), depth = rr - dist;
-                    const int ba = proxy_body(j), posa = proxy_pos(j), bb = proxy_body(4 + pb), posb = proxy_pos(4 + pb);
-                    const F4 va2 = DQ_LD(ba, 2, posa), va3 = DQ_LD(ba, 3, posa), vb2 = DQ_LD(bb, 2, posb), vb3 = DQ_LD(bb, 3, posb);
-                    const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) n[i] /= dist;
-                    float ta[3], tb[3];
-                    cross3(va, ca, ta);
-                    cross3(vb, cb, tb);
-                    float vn = 0.0f;
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) vn += ((va[3 + i] + ta[i]) - (vb[3 + i] + tb[i])) * n[i];
-                    float fn = P.pen_k * depth - P.pen_c * vn;
-                    if (fn < 0.0f) fn = 0.0f;
-                    const float F[3] = {fn * n[0], fn * n[1], fn * n[2]}, Fm[3] = {-F[0], -F[1], -F[2]};
-                    float na[3], nb[3];
-                    cross3(ca, F, na);
-                    cross3(cb, Fm, nb);
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) {
-                        WA[i] += na[i]; WA[3 + i] += F[i]; FA[i] += F[i];
-                        WB[pb][i] += nb[i]; WB[pb][3 + i] += Fm[i]; FB[pb][i] += Fm[i];
-                    }
-                    hit = hit || fn > 0.0f;
-                }
+                float d2 = 0.0f;
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { const float n = (mine[i] + sa * da[i]) - (bq[i] + sb * db[i]); d2 += n * n; }
+                const float rr = mine[6] + bq[6];
+                if (d2 < rr * rr) hits |= 1 << ((c1 >> (8 * j)) & 255);
             }
         }
-        sc_any = wave_any(hit);
+        {   // the env's mask: OR over the quad (bit patterns through the DPP moves)
+            int m = hits;
+            m |= f2i(quad_xor1(__builtin_bit_cast(float, m)));
+            m |= f2i(quad_xor2(__builtin_bit_cast(float, m)));
+            hits = m;
+        }
+        sc_any = wave_any(hits != 0);
         if (sc_any) {
-            // hand the wrenches to the owners: lane 0 takes the four left proxies' (one per lane), lane 1 the right proxies'
-            // (each the sum of the four lanes' pairs)
-            DQ_UNROLL for (int p = 0; p < 4; ++p) {
-                DQ_UNROLL for (int i = 0; i < 6; ++i) {
-                    const float a = p == 0 ? quad_bcast<0>(WA[i]) : (p == 1 ? quad_bcast<1>(WA[i]) : (p == 2 ? quad_bcast<2>(WA[i]) : quad_bcast<3>(WA[i])));
-                    float t = WB[p][i];
-                    t += quad_xor1(t);
-                    t += quad_xor2(t);
-                    scW[p][i] = j == 0 ? a : t;
-                }
-                DQ_UNROLL for (int i = 0; i < 3; ++i) {
-                    const float a = p == 0 ? quad_bcast<0>(FA[i]) : (p == 1 ? quad_bcast<1>(FA[i]) : (p == 2 ? quad_bcast<2>(FA[i]) : quad_bcast<3>(FA[i])));
-                    float t = FB[p][i];
-                    t += quad_xor1(t);
-                    t += quad_xor2(t);
-                    scF[p][i] = j == 0 ? a : t;
+            DQ_UNROLL for (int k = 0; k < QMAX_OWN; ++k) {
+                const int p = QM.own_proxy[j][k];
+                for (int t = 0; t < QMAX_OWN; ++t) {
+                    const int ent = p >= 0 ? QM.own_part[j][k][t] : -1;
+                    const bool need = ent >= 0 && ((hits >> ((ent >> 8) & 255)) & 1);
+                    if (!wave_any(need)) continue;
+                    if (need) {
+                        const int q = ent & 255, side = (ent >> 16) & 1;
+                        const int pa = side ? q : p, pbx = side ? p : q;          // the pair in the model's orientation
+                        float a0[3], a1[3], b0[3], b1[3];
+                        proxy_ends(pa, a0, a1);
+                        proxy_ends(pbx, b0, b1);
+                        const int ba = proxy_bits(pa) & 255, posa = (X.el + 4 * ((proxy_bits(pa) >> 16) & 3)) & 15;
+                        const int bb = proxy_bits(pbx) & 255, posb = (X.el + 4 * ((proxy_bits(pbx) >> 16) & 3)) & 15;
+                        const F4 va2 = DQ_LD(ba, 2, posa), va3 = DQ_LD(ba, 3, posa), vb2 = DQ_LD(bb, 2, posb), vb3 = DQ_LD(bb, 3, posb);
+                        const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
+                        float F[3], ca[3], cb[3];
+                        if (capsule_pair(a0, a1, L.hot.prox[pa][3], b0, b1, L.hot.prox[pbx][3], va, vb, P, F, ca, cb)) {
+                            const float sg = side ? -1.0f : 1.0f;
+                            const float Fs[3] = {sg * F[0], sg * F[1], sg * F[2]};
+                            float nb[3];
+                            cross3(side ? cb : ca, Fs, nb);
+                            DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[k][i] += nb[i]; scW[k][3 + i] += Fs[i]; scF[k][i] += Fs[i]; }
+                        }
+                    }
                 }
             }
         }
@@ -636,11 +630,11 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                     }
                 }
             }
-            if (sc_any && scm && j < 2) {
-                DQ_UNROLL for (int p = 0; p < 4; ++p)
-                    if ((scm >> (p + 4 * j)) & 1) {
+            if (sc_any && scm) {
+                DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
+                    if ((scm >> p) & 1) {
                         DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
-                        const int gy = proxy_gym(p + 4 * j);
+                        const int gy = (proxy_bits(QM.own_proxy[j][p]) >> 8) & 255;
                         DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
                             if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scF[p][0]; cf[t][1] += scF[p][1]; cf[t][2] += scF[p][2]; }
                     }

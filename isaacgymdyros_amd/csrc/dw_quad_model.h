@@ -25,7 +25,10 @@
 namespace dwq {
 
 constexpr int EPW = 16;          // environments per wavefront
-constexpr int QS_MAX = 12;       // schedule length bound
+constexpr int QS_MAX = 11;       // schedule length bound (TOCABI needs 11; every step costs 448 B of LDS)
+constexpr int QMAX_PROX = 16;    // self-collision proxies
+constexpr int QMAX_COMBO = 16;   // detection passes (see QHot::combo)
+constexpr int QMAX_OWN = 6;      // proxies on the bodies of one lane; partners of one proxy
 constexpr int QMAX_GEOM = 6;     // ground primitives per moving body the inward step handles
 constexpr int QMAX_GYM = 3;      // Gym bodies welded into one moving body
 
@@ -48,7 +51,7 @@ struct alignas(16) QInRec {      // inward constants of one (step, lane): 11 x 1
     int   gyms[QMAX_GYM]; float bound;       // Gym bodies of this moving body (contact attribution); ground test radius
     int   geom[QMAX_GEOM]; int geom_slot;    // primitive ids; 2 bits per primitive: index into gyms[]
     int   pad0;
-    float axis[3]; int sc_mask;              // hinge axis in body coordinates; bit p: self-collision proxy p sits on this body
+    float axis[3]; int sc_mask;              // hinge axis in body coordinates; bit k: the lane's k-th own proxy sits on this body
 };
 
 // The part of the tables every step of every pass reads, staged into LDS when a kernel starts (5.4 KB): compact
@@ -62,9 +65,15 @@ struct alignas(16) QHot {
     float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound
     int   fmask[QS_MAX];         // outward step s: bit X set = some lane fetches lane X's running state
     int   gany[QS_MAX];          // inward step s: some lane gathers
-    int   misc[8];               // [0] nsteps, [1] base_gather, [2] nproxy_l, [3] nproxy_r
+    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] number of detection passes
     int   owner[36];             // lane that owns each body (slot position = (env + 4 * owner) & 15)
-    float prox[8][8];            // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner << 16
+    // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner lane << 16 | index among the
+    // owner's proxies << 18.  Detection: proxy p is evaluated by lane p & 3 (its register set p >> 2), and the pairs are
+    // tested in PASSES: pass c broadcasts proxy b = combo[c][0] & 255 to the quad and every lane whose bit is set in
+    // (combo[c][0] >> 12) & 15 tests its proxy of register set (combo[c][0] >> 8) & 3 against it; combo[c][1] holds the
+    // four lanes' pair ids (one byte each) for the hit mask.
+    float prox[QMAX_PROX][8];
+    int   combo[QMAX_COMBO][2];
 };
 
 struct QuadModel {
@@ -78,10 +87,11 @@ struct QuadModel {
     QInRec in[QS_MAX][4];        // in[s] = inward step s (= outward step nsteps-1-s)
     // base body
     float base_com[3]; float base_mass; float base_I[6]; int base_gym; int base_ngeom; int base_geom[QMAX_GEOM]; float base_bound;
-    // self-collision proxies in leg order: 0..3 on the left leg (lane 0), 4..7 on the right (lane 1); pairs = L x R
-    int   nproxy_l, nproxy_r;
-    int   proxy_body[8]; int proxy_gym[8];
-    float proxy_p0[8][3], proxy_p1[8][3], proxy_r[8];
+    // self-collision, resolution of the pairs that touch (rare path, read from device memory): per lane its own proxies and,
+    // per own proxy, the pairs it takes part in: partner proxy | pair id << 8 | (1 if I am the pair's second proxy) << 16
+    int   nprox, npair;
+    int   own_proxy[4][QMAX_OWN];            // proxy index or -1
+    int   own_part[4][QMAX_OWN][QMAX_OWN];   // -1 = none
 };
 
 static inline void quat_of_rot(const float *R, float *q) {     // row-major rotation -> unit quaternion xyzw (host only)
@@ -337,32 +347,50 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         if (d->body_geom_gym[0][k] != Q->base_gym) { *err = "quad model: root primitives must report on the root's Gym body"; return DW_EINVAL; }
     }
     Q->base_bound = geom_bound(0, Q->base_ngeom, Q->base_geom);
-    // self-collision proxies: pairs must be {left-leg proxy} x {right-leg proxy}
-    for (int k = 0; k < d->num_sc_pairs; ++k) {
-        const int pa = d->sc_pair[k][0], pb = d->sc_pair[k][1];
-        const int ba = d->sc_proxy[pa].moving, bb = d->sc_proxy[pb].moving;
-        if (!(ba >= 1 && ba <= 6 && bb >= 7 && bb <= 12)) { *err = "quad model: self-collision pairs must be left-leg x right-leg"; return DW_EINVAL; }
+    // self-collision: proxies keep the model's order (the model compiler lists a pair as [tested proxy, broadcast proxy] and
+    // orders the proxies so that the tested proxies of the pairs sharing a partner sit on different lanes, model.py)
+    if (d->num_sc_pairs > 0 && (d->num_sc_pairs > 32 || DW_MAX_SC_PROXIES > QMAX_PROX)) { *err = "quad model: too many self-collision pairs or proxies"; return DW_EINVAL; }
+    Q->npair = d->num_sc_pairs;
+    Q->nprox = 0;
+    for (int k = 0; k < d->num_sc_pairs; ++k) for (int side = 0; side < 2; ++side) if (d->sc_pair[k][side] + 1 > Q->nprox) Q->nprox = d->sc_pair[k][side] + 1;
+    for (int l = 0; l < 4; ++l) for (int k = 0; k < QMAX_OWN; ++k) { Q->own_proxy[l][k] = -1; for (int t2 = 0; t2 < QMAX_OWN; ++t2) Q->own_part[l][k][t2] = -1; }
+    int local_of[QMAX_PROX];
+    for (int p2 = 0; p2 < QMAX_PROX; ++p2) local_of[p2] = -1;
+    for (int p2 = 0; p2 < Q->nprox; ++p2) {
+        const int pb = d->sc_proxy[p2].moving;
+        if (pb < 1 || pb >= NB) { *err = "quad model: a self-collision proxy must sit on a jointed body"; return DW_EINVAL; }
+        const int l = Q->owner[pb];
+        int k = 0;
+        while (k < QMAX_OWN && Q->own_proxy[l][k] >= 0) ++k;
+        if (k >= QMAX_OWN) { *err = "quad model: too many self-collision proxies on one lane's bodies"; return DW_EINVAL; }
+        Q->own_proxy[l][k] = p2; local_of[p2] = k;
+        Q->in[T - 1 - step_of[pb]][l].sc_mask |= 1 << k;
+        if (add_gym(pb, d->sc_proxy[p2].gym) < 0) { *err = "quad model: proxy Gym body does not fit"; return DW_EINVAL; }
     }
-    int lmap[DW_MAX_SC_PROXIES], rmap[DW_MAX_SC_PROXIES];
-    for (int i = 0; i < DW_MAX_SC_PROXIES; ++i) lmap[i] = rmap[i] = -1;
-    auto put = [&](int pr, int slot) {
-        const DwCapsule &c = d->sc_proxy[pr];
-        Q->proxy_body[slot] = c.moving; Q->proxy_gym[slot] = c.gym; Q->proxy_r[slot] = c.radius;
-        for (int i = 0; i < 3; ++i) { Q->proxy_p0[slot][i] = c.p0[i]; Q->proxy_p1[slot][i] = c.p1[i]; }
-    };
+    for (int k = 0; k < d->num_sc_pairs; ++k)
+        for (int side = 0; side < 2; ++side) {
+            const int me = d->sc_pair[k][side], other = d->sc_pair[k][1 - side];
+            const int l = Q->owner[d->sc_proxy[me].moving], kl = local_of[me];
+            int t2 = 0;
+            while (t2 < QMAX_OWN && Q->own_part[l][kl][t2] >= 0) ++t2;
+            if (t2 >= QMAX_OWN) { *err = "quad model: a proxy takes part in too many self-collision pairs"; return DW_EINVAL; }
+            Q->own_part[l][kl][t2] = other | (k << 8) | (side << 16);
+        }
+    int ncombo = 0;
+    int combo0[QMAX_COMBO], combo1[QMAX_COMBO];
     for (int k = 0; k < d->num_sc_pairs; ++k) {
-        const int pa = d->sc_pair[k][0], pb = d->sc_pair[k][1];
-        if (lmap[pa] < 0) { if (Q->nproxy_l >= 4) { *err = "quad model: more than 4 proxies on the left leg"; return DW_EINVAL; } lmap[pa] = Q->nproxy_l; put(pa, Q->nproxy_l++); }
-        if (rmap[pb] < 0) { if (Q->nproxy_r >= 4) { *err = "quad model: more than 4 proxies on the right leg"; return DW_EINVAL; } rmap[pb] = Q->nproxy_r; put(pb, 4 + Q->nproxy_r++); }
-    }
-    if (d->num_sc_pairs != Q->nproxy_l * Q->nproxy_r) { *err = "quad model: self-collision pairs must be the full left x right product"; return DW_EINVAL; }
-    for (int p = 0; p < 8; ++p) {
-        const bool used = p < 4 ? p < Q->nproxy_l : (p - 4) < Q->nproxy_r;
-        if (!used) continue;
-        const int b = Q->proxy_body[p];
-        Q->in[T - 1 - step_of[b]][Q->owner[b]].sc_mask |= 1 << p;
-        Q->fk[step_of[b]][Q->owner[b]].flags |= (1 << p) << 8;
-        if (add_gym(b, Q->proxy_gym[p]) < 0) { *err = "quad model: proxy Gym body does not fit"; return DW_EINVAL; }
+        const int a = d->sc_pair[k][0], b2 = d->sc_pair[k][1];
+        const int lane = a & 3, reg = a >> 2;
+        int c = -1;
+        for (int i = 0; i < ncombo; ++i) if ((combo0[i] & 255) == b2 && ((combo0[i] >> 8) & 3) == reg) c = i;
+        if (c < 0) {
+            if (ncombo >= QMAX_COMBO) { *err = "quad model: self-collision pairs need more detection passes than QMAX_COMBO"; return DW_EINVAL; }
+            c = ncombo++;
+            combo0[c] = b2 | (reg << 8); combo1[c] = 0;
+        }
+        if ((combo0[c] >> (12 + lane)) & 1) { *err = "quad model: two pairs of one detection pass on the same lane"; return DW_EINVAL; }
+        combo0[c] |= 1 << (12 + lane);
+        combo1[c] |= k << (8 * lane);
     }
     // every Gym body must be reported by exactly one moving body (the kernels write, never accumulate, contact forces)
     for (int b = 1; b < NB; ++b) if (add_gym(b, dm->mv_gym[b]) < 0) { *err = "quad model: Gym body of a moving body does not fit"; return DW_EINVAL; }
@@ -402,14 +430,15 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         H.base[3] = Q->base_mass;
         for (int i = 0; i < 6; ++i) H.base[4 + i] = Q->base_I[i];
         H.base[10] = fi(Q->base_gym); H.base[11] = fi(Q->base_ngeom); H.base[12] = Q->base_bound;
-        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nproxy_l; H.misc[3] = Q->nproxy_r;
+        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nprox; H.misc[3] = ncombo;
         for (int b = 0; b < NB; ++b) H.owner[b] = Q->owner[b] < 0 ? 0 : Q->owner[b];
-        for (int p2 = 0; p2 < 8; ++p2) {
-            for (int i = 0; i < 3; ++i) { H.prox[p2][i] = Q->proxy_p0[p2][i]; H.prox[p2][4 + i] = Q->proxy_p1[p2][i]; }
-            H.prox[p2][3] = Q->proxy_r[p2];
-            const int pbody = Q->proxy_body[p2];
-            H.prox[p2][7] = fi((pbody & 255) | ((Q->proxy_gym[p2] & 255) << 8) | (((pbody > 0 ? Q->owner[pbody] : 0) & 3) << 16));
+        for (int p2 = 0; p2 < Q->nprox; ++p2) {
+            const DwCapsule &cp = d->sc_proxy[p2];
+            for (int i = 0; i < 3; ++i) { H.prox[p2][i] = cp.p0[i]; H.prox[p2][4 + i] = cp.p1[i]; }
+            H.prox[p2][3] = cp.radius;
+            H.prox[p2][7] = fi((cp.moving & 255) | ((cp.gym & 255) << 8) | ((Q->owner[cp.moving] & 3) << 16) | ((local_of[p2] & 7) << 18));
         }
+        for (int c = 0; c < ncombo; ++c) { H.combo[c][0] = combo0[c]; H.combo[c][1] = combo1[c]; }
     }
     return DW_OK;
 }

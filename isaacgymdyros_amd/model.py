@@ -41,9 +41,12 @@ NUM_INERT = 36
 MAX_GEOMS = 64
 NUM_FOOT_PTS = 8
 MAX_SC_PROXIES = 16
-MAX_SC_PAIRS = 16
-# links that get a self-collision capsule: (left, right) chains thigh / shank / ankle / foot assembly
+MAX_SC_PAIRS = 32
+# links that get a self-collision capsule: (left, right) chains thigh / shank / ankle / foot assembly ...
 SC_LEG_BODIES = ("Thigh_Link", "Knee_Link", "AnkleCenter_Link", "Foot_Redundant_Link")
+# ... and, second tranche ("leg<->leg, arm<->torso/leg"): upper arm, forearm, hand of each arm and the torso
+SC_ARM_BODIES = ("Armlink_Link", "Forearm_Link", "Wrist2_Link")
+SC_TORSO_BODY = "Upperbody_Link"
 
 # Per-DoF constants the reference hard-codes in the task (not in the MJCF).
 # reference: tasks/dyros_dynamic_walk.py:366-372 (armature, damping, velocity)
@@ -237,6 +240,61 @@ def compile_mjcf(xml_path: str) -> Dict:
             side_of.append(side)
     nl = len(SC_LEG_BODIES)
     sc_pairs = [[a, nl + b] for a in range(nl) for b in range(nl)]
+
+    # second tranche: arms and torso.  A link with several primitives strung along one line (forearm: two cylinders; torso:
+    # a stack of boxes) gets ONE capsule around all of them: axis = the line through the two outermost primitive centres,
+    # half length to the outermost primitive ends, radius = the largest cross-section radius.
+    def span_capsule(i):
+        R, p = T_in_moving[i]
+        cs, rads, ext = [], [], []
+        for g in bodies[i]["geoms"]:
+            Rg = R @ _quat_wxyz_to_mat(g["quat"])
+            cs.append(p + R @ np.array(g["pos"]))
+            sz = list(g["size"]) + [0.0] * (3 - len(g["size"]))
+            if g["type"] == "cylinder":
+                rads.append((sz[0], sz[1], Rg[:, 2]))
+            else:
+                rads.append((None, sz, Rg))
+        cs = np.array(cs)
+        if len(cs) == 1:
+            ax = rads[0][2] if rads[0][0] is not None else rads[0][2][:, int(np.argmax(rads[0][1]))]
+        else:
+            d = cs[:, None, :] - cs[None, :, :]
+            i0, i1 = np.unravel_index(np.argmax((d ** 2).sum(-1)), d.shape[:2])
+            ax = cs[i1] - cs[i0]
+        ax = ax / np.linalg.norm(ax)
+        lo, hi, rad = np.inf, -np.inf, 0.0
+        for c, (r, h, A) in zip(cs, rads):
+            t = float((c - cs[0]) @ ax)
+            if r is not None:                       # cylinder: half height along its own axis, projected
+                e = abs(float(A @ ax)) * h + np.sqrt(max(0.0, 1 - float(A @ ax) ** 2)) * r
+                rr = r
+            else:                                   # box: extent along the capsule axis, radius = second-largest half extent across it
+                e = float(sum(abs(float(A[:, k] @ ax)) * h[k] for k in range(3)))
+                across = sorted((h[k] for k in range(3) if abs(float(A[:, k] @ ax)) < 0.9), reverse=True)
+                rr = across[0] if len(across) < 2 else across[1] if len(across) == 3 else across[0]
+                rr = max(across[-1], min(across[0], rr))
+            lo, hi, rad = min(lo, t - e), max(hi, t + e), max(rad, rr)
+        lo, hi = lo + rad, hi - rad                 # the caps take one radius at each end
+        if hi < lo:
+            lo = hi = 0.5 * (lo + hi)
+        return dict(moving=moving_of_body[i], gym=i, p0=(cs[0] + lo * ax).tolist(), p1=(cs[0] + hi * ax).tolist(), radius=float(rad))
+
+    idx = {}
+    for side in ("L_", "R_"):
+        for suffix in SC_ARM_BODIES:
+            idx[side + suffix] = len(sc_proxies)
+            sc_proxies.append(span_capsule(names.index(side + suffix)))
+    idx[SC_TORSO_BODY] = len(sc_proxies)
+    sc_proxies.append(span_capsule(names.index(SC_TORSO_BODY)))
+    thigh = {"L_": 0, "R_": nl}
+    for side in ("L_", "R_"):
+        for part in ("Forearm_Link", "Wrist2_Link"):
+            sc_pairs.append([idx[side + part], idx[SC_TORSO_BODY]])          # forearm / hand against the torso
+            sc_pairs.append([idx[side + part], thigh[side]])                 # ... and against the thigh of the same side
+        sc_pairs.append([idx[side + "Armlink_Link"], idx[SC_TORSO_BODY]])    # upper arm against the torso
+    sc_pairs += [[idx["L_Forearm_Link"], idx["R_Forearm_Link"]], [idx["L_Wrist2_Link"], idx["R_Wrist2_Link"]],
+                 [idx["L_Wrist2_Link"], idx["R_Forearm_Link"]], [idx["L_Forearm_Link"], idx["R_Wrist2_Link"]]]
 
     model = dict(
         body_names=names,

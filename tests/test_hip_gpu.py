@@ -450,6 +450,43 @@ def test_self_collision_vs_oracle(task_const, model, pipeline):
     assert np.abs(env.dof_pos.cpu().numpy() - ora.buf["dof_state"][:, :, 0]).max() < 2e-2
 
 
+def test_arms_into_torso_vs_oracle(task_const, model, pipeline):
+    """Row f-1, second tranche, on the device: arm poses inside the joint limits that press upper arms, forearms and hands
+    into the torso, a thigh or the other arm.  Same bars as the leg sweep: forces 1e-3 relative and the same set of loaded
+    links after one substep, joint positions 1e-5; the whole step then sees the non-foot contact and ends the episode."""
+    from hip_backend import make_env
+    from test_oracle_physics import _arms_in
+    N = 64
+    env = make_env(N, randomize=False, pipeline=pipeline)
+    b = env._buf
+    b["root_states"][:, 0:2] = 0
+    b["root_states"][:, 2] = 3.0
+    b["dof_state"][..., 0] = torch.from_numpy(_arms_in(N)).cuda()
+    b["dof_state"][..., 1] = 0
+    ora = _oracle_like(env, task_const)
+    tau = torch.zeros(N, 33)
+    env.simulate(tau.cuda())
+    ora.simulate(tau.numpy())
+    torch.cuda.synchronize()
+    cg, co = env.contact_forces.cpu().numpy(), ora.buf["contact_forces"]
+    loaded = np.linalg.norm(co, axis=2) > 1.0
+    assert loaded[:, 19].sum() > N // 2 and loaded[:, [25, 27, 35, 37]].any(axis=1).sum() >= 4
+    assert np.abs(cg - co).max() <= 1e-3 * np.abs(co).max()
+    assert np.array_equal(np.linalg.norm(cg, axis=2) > 1.0, loaded)
+    assert np.abs(env.dof_pos.cpu().numpy() - ora.buf["dof_state"][:, :, 0]).max() < 1e-5
+    assert np.abs(env.dof_vel.cpu().numpy() - ora.buf["dof_state"][:, :, 1]).max() < 2e-2
+    # through the task: a loaded torso / arm is a non-foot contact, the episode ends on the next step
+    env2 = make_env(N, randomize=False, pipeline=pipeline)
+    env2.reset()
+    env2._buf["dof_state"][..., 0] = torch.from_numpy(_arms_in(N)).cuda()
+    ora2 = _oracle_like(env2, task_const)
+    _, _, done, _ = env2.step(torch.zeros(N, env2.num_actions, device="cuda"))
+    ora2.step(np.zeros((N, env2.num_actions), np.float32), None, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(done.cpu().numpy() != 0, ora2.buf["reset_buf"] != 0)
+    assert int(done.sum()) >= N // 4
+
+
 def test_self_collision_of_mirrored_legs_is_mirrored(pipeline):
     """The degenerate case: exactly mirror-symmetric legs make the two foot capsules (and the two ankle capsules) exactly
     parallel.  The written decision puts the contact of parallel capsules in the middle of their overlap, so a mirrored

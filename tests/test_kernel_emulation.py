@@ -182,3 +182,24 @@ def test_mirrored_legs_get_a_mirrored_response(which):
     assert np.abs(qd[:, 0:6] - sign * qd[:, 6:12]).max() < 5e-2        # (the model itself is mirror-symmetric to ~1 % only; the end-point rule gave 0.9 rad/s)
     assert np.abs(sim.buf["root_states"][keep][:, 12]).max() < 2e-2
     assert np.abs(sim.buf["root_states"][keep][:, 8]).max() < 2e-2
+
+
+def test_arms_into_torso_vs_oracle(quad):
+    """Row f-1, second tranche (forearm / hand against torso and thigh, arm against arm) through the kernel source: the
+    arm poses of tests/test_oracle_physics.py (inside the joint limits), one substep: forces 1e-3 relative, state 1e-5."""
+    from test_oracle_physics import _arms_in
+    N = 48
+    A, B = OracleSim(N), EmulSim(N, quad=quad)
+    for s in (A, B):
+        s.buf["root_states"][:, 0:2] = 0
+        s.buf["root_states"][:, 2] = 3.0
+        s.buf["dof_state"][:, :, 0] = _arms_in(N)
+    tau = np.zeros((N, 33), np.float32)
+    A.simulate(tau); B.simulate(tau)
+    ca, cb = A.buf["contact_forces"], B.buf["contact_forces"]
+    loaded = np.linalg.norm(ca, axis=2) > 1.0
+    assert loaded[:, 19].sum() > N // 2 and loaded[:, [23, 25, 27, 33, 35, 37]].any(axis=1).sum() > N // 2
+    assert loaded[:, [25, 27, 35, 37]].any(axis=1).sum() >= 4              # forearms and hands too
+    assert np.abs(ca - cb).max() <= 1e-3 * np.abs(ca).max()
+    assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 0].max() < 1e-5
+    assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 1].max() < 2e-2

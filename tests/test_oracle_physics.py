@@ -172,3 +172,104 @@ def test_crossed_legs_report_self_collision(model):
     off.buf["dof_state"][0, 7, 0] = 0.2
     off.simulate(np.zeros((1, 33), np.float32))
     assert np.abs(off.buf["contact_forces"]).max() == 0
+
+
+_ARMS_IN = {}
+
+
+def _arms_in(N):
+    """Arm poses INSIDE the joint limits that press upper arm, forearm or hand into the torso or a thigh (a few reach the
+    other arm): seeded excursions of up to 1.2 rad on all 16 arm joints, the right arm 0.8 as far as the left so that no two
+    capsule axes are parallel; three quarters of the returned envs collide, the rest are clear."""
+    if N in _ARMS_IN:
+        return _ARMS_IN[N].copy()
+    from isaacgymdyros_amd.model import load_model
+    m = load_model()
+    lo, hi = np.asarray(m.d["dof_lower"], np.float32), np.asarray(m.d["dof_upper"], np.float32)
+    pool = 32 * N
+    rng = np.random.default_rng(17)
+    q = np.tile(np.asarray(INITIAL_DOF_POS, np.float32), (pool, 1))
+    d = rng.uniform(-1.2, 1.2, size=(pool, 8)).astype(np.float32)
+    q[:, 15:23] += d
+    q[:, 25:33] -= 0.8 * d * rng.choice([1.0, -0.5], size=(pool, 1)).astype(np.float32)
+    q = np.clip(q, lo, hi)
+    sim = OracleSim(pool)
+    sim.buf["root_states"][:, 2] = 3.0
+    sim.buf["dof_state"][:, :, 0] = q
+    sim.simulate(np.zeros((pool, 33), np.float32))
+    hit = (np.linalg.norm(sim.buf["contact_forces"], axis=2) > 1.0).any(axis=1)
+    nh = (3 * N) // 4
+    sel = np.concatenate([np.nonzero(hit)[0][:nh], np.nonzero(~hit)[0][:N - nh]])
+    assert len(sel) == N
+    _ARMS_IN[N] = q[np.sort(sel)]
+    return _ARMS_IN[N].copy()
+
+
+def _brute_capsule_gap(a0, a1, b0, b1, n=400):
+    """Distance between two segments by exhaustive sampling, refined twice: independent of the closed-form rule."""
+    sa = np.linspace(0, 1, n)[:, None, None]
+    sb = np.linspace(0, 1, n)[None, :, None]
+    lo_a, hi_a, lo_b, hi_b = 0.0, 1.0, 0.0, 1.0
+    for _ in range(3):
+        sa = np.linspace(lo_a, hi_a, n)
+        sb = np.linspace(lo_b, hi_b, n)
+        d = np.linalg.norm((a0 + sa[:, None, None] * (a1 - a0)) - (b0 + sb[None, :, None] * (b1 - b0)), axis=2)
+        i, k = np.unravel_index(d.argmin(), d.shape)
+        wa, wb = (hi_a - lo_a) * 2 / n, (hi_b - lo_b) * 2 / n
+        lo_a, hi_a = max(0.0, sa[i] - wa), min(1.0, sa[i] + wa)
+        lo_b, hi_b = max(0.0, sb[k] - wb), min(1.0, sb[k] + wb)
+    return d.min(), a0 + sa[i] * (a1 - a0), b0 + sb[k] * (b1 - b0)
+
+
+def test_arm_into_torso_known_answer(model):
+    """Second tranche of row f-1 (forearm / hand against torso and thigh, arm against arm).  At rest in flight the first
+    substep sees zero velocities, so each touching pair loads its two bodies with exactly k * depth along the line between
+    the closest points -- recomputed here from the compiled proxies with numpy kinematics and brute-force distances."""
+    from isaacgymdyros_amd import abi
+    N = 12
+    sim = OracleSim(N, double=True)
+    sim.buf["root_states"][:, 0:2] = 0
+    sim.buf["root_states"][:, 2] = 3.0
+    sim.buf["dof_state"][:, :, 0] = _arms_in(N)
+    q = sim.buf["dof_state"][:, :, 0].astype(float).copy()
+    sim.simulate(np.zeros((N, 33), np.float32))
+    cf = sim.buf["contact_forces"].astype(float)
+    k = float(sim.cfg.penalty_stiffness)
+    dd = DenseDynamics(model)
+    prox, pairs = model.d["sc_proxies"], model.d["sc_pairs"]
+    touching = 0
+    for e in range(N):
+        Rw, pw = dd.kinematics([0, 0, 3.0], [0, 0, 0, 1], q[e])
+        want = np.zeros_like(cf[e])
+        for ia, ib in pairs:
+            A, B = prox[ia], prox[ib]
+            a0, a1 = (pw[A["moving"]] + Rw[A["moving"]] @ np.array(A[p]) for p in ("p0", "p1"))
+            b0, b1 = (pw[B["moving"]] + Rw[B["moving"]] @ np.array(B[p]) for p in ("p0", "p1"))
+            gap, ca, cb = _brute_capsule_gap(a0, a1, b0, b1)
+            depth = A["radius"] + B["radius"] - gap
+            if depth > 0:
+                touching += 1
+                want[A["gym"]] += k * depth * (ca - cb) / gap
+                want[B["gym"]] -= k * depth * (ca - cb) / gap
+        assert np.abs(cf[e] - want).max() <= 2e-3 * max(1.0, np.abs(want).max()), e
+        assert np.abs(cf[e].sum(axis=0)).max() < 1e-6 * max(1.0, np.abs(cf[e]).max())
+    assert touching >= (3 * N) // 4                         # the poses do reach the torso
+
+
+def test_reset_poses_are_clear_of_self_collision(model):
+    """The proxies must not fire where the reference's robot stands freely: nothing at all at the rest pose and +-0.03 rad
+    around it (wider than any reset draw); at +-0.1 rad the feet may brush each other (first tranche, real geometry), but no
+    arm or torso proxy reports anything."""
+    rng = np.random.default_rng(5)
+    N = 128
+    for amp in (0.03, 0.1):
+        sim = OracleSim(N)
+        sim.buf["root_states"][:, 2] = 3.0
+        q = np.tile(np.asarray(INITIAL_DOF_POS, np.float32), (N, 1))
+        q[1:] += rng.uniform(-amp, amp, size=(N - 1, 33)).astype(np.float32)
+        sim.buf["dof_state"][:, :, 0] = q
+        sim.simulate(np.zeros((N, 33), np.float32))
+        cf = sim.buf["contact_forces"]
+        assert np.abs(cf[:, 17:]).max() == 0, amp
+        if amp == 0.03:
+            assert np.abs(cf).max() == 0
