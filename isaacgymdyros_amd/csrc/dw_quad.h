@@ -294,6 +294,23 @@ DQ_HD void seg_seg(const float *da, const float *db, const float *r, float *so, 
     *so = sa; *to = sb;
 }
 
+// Squared least distance of two segments a(s) = r + s da, b(t) = t db (Ericson 5.1.9 without the blend), reciprocals by
+// v_rcp_f32: for the self-collision DETECTION only (the force recomputes the touching pairs exactly).
+DQ_HD float seg_dist2_fast(const float *da, const float *db, const float *r) {
+    const float aa = dot3(da, da), ee = dot3(db, db), ff = dot3(db, r), cc = dot3(da, r), bbv = dot3(da, db);
+    const float den = aa * ee - bbv * bbv;
+    const float ia = rcp_fast(fmaxf(aa, 1e-12f)), ie = rcp_fast(fmaxf(ee, 1e-12f)), id = rcp_fast(fmaxf(den, 1e-12f));
+    auto c01 = [](float x) { return fminf(fmaxf(x, 0.0f), 1.0f); };
+    float se = den > 1e-12f ? c01((bbv * ff - cc * ee) * id) : 0.0f;
+    float te = ee > 1e-12f ? (bbv * se + ff) * ie : -1.0f;        // b is a point: t = 0, s = the foot of the perpendicular
+    const float s_lo = c01(-cc * ia), s_hi = c01((bbv - cc) * ia);
+    se = te < 0.0f ? s_lo : (te > 1.0f ? s_hi : se);
+    te = c01(te);
+    float d2 = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) { const float n = r[i] + se * da[i] - te * db[i]; d2 = fmaf(n, n, d2); }
+    return d2;
+}
+
 // Penalty force of two capsules (dw_physics.h K4b).  Returns true and fills F (force on A), pa, pb when they overlap.
 DQ_HD bool capsule_pair(const float *a0, const float *a1, float ra, const float *b0, const float *b1, float rb, const float *va,
                         const float *vb, const PhysParams &P, float *F, float *pa, float *pb) {
@@ -443,8 +460,9 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
     //      body recomputes the proxy's touching pairs from the slots and keeps the wrench (both sides of a pair compute the
     //      same force from the same data: no hand-over between lanes). ----
     bool sc_any = false;
-    float scW[QMAX_OWN][6], scF[QMAX_OWN][3];
-    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; DQ_UNROLL for (int i = 0; i < 3; ++i) scF[p][i] = 0.0f; }
+    float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
+    int scGym0 = 0, scGym1 = 0;          // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
+    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
     const int nprox = L.hot.misc[2], ncombo = L.hot.misc[3];
     auto proxy_bits = [&](int p) { return f2i(L.hot.prox[p][7]); };
     auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
@@ -462,32 +480,39 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
         p1w[0] = x4.x + t1[0]; p1w[1] = x4.y + t1[1]; p1w[2] = x4.z + t1[2];
     };
     if (P.self_collision && ncombo > 0) {
-        float Pe[4][7];                    // my proxies (register set r = proxy j + 4 r): p0, p1, radius
+        float Pe[4][7];                    // my proxies (register set r = proxy j + 4 r): p0, p1 - p0, radius
         DQ_UNROLL for (int r = 0; r < 4; ++r) {
             DQ_UNROLL for (int i = 0; i < 7; ++i) Pe[r][i] = 0.0f;
-            if (j + 4 * r < nprox) { proxy_ends(j + 4 * r, &Pe[r][0], &Pe[r][3]); Pe[r][6] = L.hot.prox[j + 4 * r][3]; }
+            if (j + 4 * r < nprox) {
+                float e1[3];
+                proxy_ends(j + 4 * r, &Pe[r][0], e1);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) Pe[r][3 + i] = e1[i] - Pe[r][i];
+                Pe[r][6] = L.hot.prox[j + 4 * r][3];
+            }
         }
+        DQ_STAMP(B, 51);
         int hits = 0;
         for (int c = 0; c < ncombo; ++c) {
-            const int c0 = L.hot.combo[c][0], c1 = L.hot.combo[c][1];
-            const int pb = c0 & 255, reg = (c0 >> 8) & 3;
-            float src[7], bq[7], mine[7];
-            DQ_UNROLL for (int i = 0; i < 7; ++i) {
-                const int rb = pb >> 2;
-                src[i] = rb == 0 ? Pe[0][i] : (rb == 1 ? Pe[1][i] : (rb == 2 ? Pe[2][i] : Pe[3][i]));
-                mine[i] = reg == 0 ? Pe[0][i] : (reg == 1 ? Pe[1][i] : (reg == 2 ? Pe[2][i] : Pe[3][i]));
+            const int *cw = L.hot.combo[c];
+            const int c0 = cw[0], pb = c0 & 255;
+            float bq[7];
+            // proxy pb to the whole quad: register set and lane are wave-uniform, so this is a scalar branch around 7 DPP moves
+#define DQ_BC(R_, L_) case (R_) * 4 + (L_): { DQ_UNROLL for (int i = 0; i < 7; ++i) bq[i] = quad_bcast<L_>(Pe[R_][i]); } break;
+            switch (pb) {
+                DQ_BC(0, 0) DQ_BC(0, 1) DQ_BC(0, 2) DQ_BC(0, 3) DQ_BC(1, 0) DQ_BC(1, 1) DQ_BC(1, 2) DQ_BC(1, 3)
+                DQ_BC(2, 0) DQ_BC(2, 1) DQ_BC(2, 2) DQ_BC(2, 3) DQ_BC(3, 0) DQ_BC(3, 1) DQ_BC(3, 2)
+                default: { DQ_UNROLL for (int i = 0; i < 7; ++i) bq[i] = quad_bcast<3>(Pe[3][i]); } break;
             }
-            quad_bcast_arr(pb & 3, src, bq);
-            if ((c0 >> (12 + j)) & 1) {
-                const float da[3] = {mine[3] - mine[0], mine[4] - mine[1], mine[5] - mine[2]};
-                const float db[3] = {bq[3] - bq[0], bq[4] - bq[1], bq[5] - bq[2]};
-                const float r[3] = {mine[0] - bq[0], mine[1] - bq[1], mine[2] - bq[2]};
-                float sa, sb;
-                seg_seg(da, db, r, &sa, &sb);
-                float d2 = 0.0f;
-                DQ_UNROLL for (int i = 0; i < 3; ++i) { const float n = (mine[i] + sa * da[i]) - (bq[i] + sb * db[i]); d2 += n * n; }
-                const float rr = mine[6] + bq[6];
-                if (d2 < rr * rr) hits |= 1 << ((c1 >> (8 * j)) & 255);
+#undef DQ_BC
+            DQ_UNROLL for (int r = 0; r < 4; ++r) {
+                const int lm = (c0 >> (8 + 4 * r)) & 15;
+                if (lm == 0) continue;
+                if ((lm >> j) & 1) {
+                    const float rr = Pe[r][6] + bq[6];
+                    const float rv[3] = {Pe[r][0] - bq[0], Pe[r][1] - bq[1], Pe[r][2] - bq[2]};
+                    // conservative: the least distance of the axes (the force uses the blended points, never closer), 0.2 % slack
+                    if (seg_dist2_fast(&Pe[r][3], &bq[3], rv) < 1.004f * rr * rr) hits |= 1 << ((cw[1 + r] >> (8 * j)) & 255);
+                }
             }
         }
         {   // the env's mask: OR over the quad (bit patterns through the DPP moves)
@@ -497,30 +522,39 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             hits = m;
         }
         sc_any = wave_any(hits != 0);
+        DQ_STAMP(B, 52);
+#if defined(DQ_STAMPS) && defined(__HIPCC__)
+        if (blockIdx.x == 0 && threadIdx.x == 0) B.gate_acc[200 + 53] = sc_any;
+#endif
         if (sc_any) {
-            DQ_UNROLL for (int k = 0; k < QMAX_OWN; ++k) {
-                const int p = QM.own_proxy[j][k];
-                for (int t = 0; t < QMAX_OWN; ++t) {
-                    const int ent = p >= 0 ? QM.own_part[j][k][t] : -1;
-                    const bool need = ent >= 0 && ((hits >> ((ent >> 8) & 255)) & 1);
-                    if (!wave_any(need)) continue;
-                    if (need) {
-                        const int q = ent & 255, side = (ent >> 16) & 1;
-                        const int pa = side ? q : p, pbx = side ? p : q;          // the pair in the model's orientation
-                        float a0[3], a1[3], b0[3], b1[3];
-                        proxy_ends(pa, a0, a1);
-                        proxy_ends(pbx, b0, b1);
-                        const int ba = proxy_bits(pa) & 255, posa = (X.el + 4 * ((proxy_bits(pa) >> 16) & 3)) & 15;
-                        const int bb = proxy_bits(pbx) & 255, posb = (X.el + 4 * ((proxy_bits(pbx) >> 16) & 3)) & 15;
-                        const F4 va2 = DQ_LD(ba, 2, posa), va3 = DQ_LD(ba, 3, posa), vb2 = DQ_LD(bb, 2, posb), vb3 = DQ_LD(bb, 3, posb);
-                        const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
-                        float F[3], ca[3], cb[3];
-                        if (capsule_pair(a0, a1, L.hot.prox[pa][3], b0, b1, L.hot.prox[pbx][3], va, vb, P, F, ca, cb)) {
+            // every lane works through the touching pairs that involve one of its bodies
+            int mine = hits & (j == 0 ? L.hot.misc[4] : (j == 1 ? L.hot.misc[5] : (j == 2 ? L.hot.misc[6] : L.hot.misc[7])));
+            while (wave_any(mine != 0)) {
+                if (mine != 0) {
+                    const int pid = __builtin_ctz(mine);
+                    mine &= mine - 1;
+                    const int pr = (L.hot.pairs[pid >> 2] >> (8 * (pid & 3))) & 255, pa = pr & 15, pbx = pr >> 4;
+                    const int bita = proxy_bits(pa), bitb = proxy_bits(pbx);
+                    float a0[3], a1[3], b0[3], b1[3];
+                    proxy_ends(pa, a0, a1);
+                    proxy_ends(pbx, b0, b1);
+                    const int ba = bita & 255, posa = (X.el + 4 * ((bita >> 16) & 3)) & 15;
+                    const int bb = bitb & 255, posb = (X.el + 4 * ((bitb >> 16) & 3)) & 15;
+                    const F4 va2 = DQ_LD(ba, 2, posa), va3 = DQ_LD(ba, 3, posa), vb2 = DQ_LD(bb, 2, posb), vb3 = DQ_LD(bb, 3, posb);
+                    const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
+                    float F[3], ca[3], cb[3];
+                    if (capsule_pair(a0, a1, L.hot.prox[pa][3], b0, b1, L.hot.prox[pbx][3], va, vb, P, F, ca, cb)) {
+                        DQ_UNROLL for (int side = 0; side < 2; ++side) {
+                            const int bits = side ? bitb : bita;
+                            if (((bits >> 16) & 3) != j) continue;
+                            const int k = (bits >> 18) & 7, gy = (bits >> 8) & 255;
                             const float sg = side ? -1.0f : 1.0f;
                             const float Fs[3] = {sg * F[0], sg * F[1], sg * F[2]};
                             float nb[3];
                             cross3(side ? cb : ca, Fs, nb);
-                            DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[k][i] += nb[i]; scW[k][3 + i] += Fs[i]; scF[k][i] += Fs[i]; }
+                            DQ_UNROLL for (int kk = 0; kk < QMAX_OWN; ++kk)
+                                if (kk == k) { DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[kk][i] += nb[i]; scW[kk][3 + i] += Fs[i]; } }
+                            if (k < 4) scGym0 |= gy << (8 * k); else scGym1 |= gy << (8 * (k - 4));
                         }
                     }
                 }
@@ -634,9 +668,9 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
                     if ((scm >> p) & 1) {
                         DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
-                        const int gy = (proxy_bits(QM.own_proxy[j][p]) >> 8) & 255;
+                        const int gy = ((p < 4 ? scGym0 >> (8 * p) : scGym1 >> (8 * (p - 4)))) & 255;     // (0 where unloaded: adds nothing)
                         DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
-                            if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scF[p][0]; cf[t][1] += scF[p][1]; cf[t][2] += scF[p][2]; }
+                            if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
                     }
             }
             if (last) {

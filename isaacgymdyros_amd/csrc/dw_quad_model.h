@@ -28,7 +28,7 @@ constexpr int EPW = 16;          // environments per wavefront
 constexpr int QS_MAX = 11;       // schedule length bound (TOCABI needs 11; every step costs 448 B of LDS)
 constexpr int QMAX_PROX = 16;    // self-collision proxies
 constexpr int QMAX_COMBO = 16;   // detection passes (see QHot::combo)
-constexpr int QMAX_OWN = 6;      // proxies on the bodies of one lane; partners of one proxy
+constexpr int QMAX_OWN = 6;      // proxies on the bodies of one lane
 constexpr int QMAX_GEOM = 6;     // ground primitives per moving body the inward step handles
 constexpr int QMAX_GYM = 3;      // Gym bodies welded into one moving body
 
@@ -65,15 +65,17 @@ struct alignas(16) QHot {
     float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound
     int   fmask[QS_MAX];         // outward step s: bit X set = some lane fetches lane X's running state
     int   gany[QS_MAX];          // inward step s: some lane gathers
-    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] number of detection passes
+    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] number of detection passes, [4..7] pairs of lane l
     int   owner[36];             // lane that owns each body (slot position = (env + 4 * owner) & 15)
     // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner lane << 16 | index among the
     // owner's proxies << 18.  Detection: proxy p is evaluated by lane p & 3 (its register set p >> 2), and the pairs are
     // tested in PASSES: pass c broadcasts proxy b = combo[c][0] & 255 to the quad and every lane whose bit is set in
-    // (combo[c][0] >> 12) & 15 tests its proxy of register set (combo[c][0] >> 8) & 3 against it; combo[c][1] holds the
-    // four lanes' pair ids (one byte each) for the hit mask.
+    // (combo[c][0] >> (8 + 4 r)) & 15 tests its proxy of register set r against it; combo[c][1 + r] holds the four lanes'
+    // pair ids (one byte each) for the hit mask.  pairs: byte k = proxies of pair k (a | b << 4); misc[4 + l]: the pairs lane
+    // l resolves (one of the two proxies sits on one of its bodies).
     float prox[QMAX_PROX][8];
-    int   combo[QMAX_COMBO][2];
+    int   combo[QMAX_COMBO][5];
+    int   pairs[8];
 };
 
 struct QuadModel {
@@ -87,11 +89,8 @@ struct QuadModel {
     QInRec in[QS_MAX][4];        // in[s] = inward step s (= outward step nsteps-1-s)
     // base body
     float base_com[3]; float base_mass; float base_I[6]; int base_gym; int base_ngeom; int base_geom[QMAX_GEOM]; float base_bound;
-    // self-collision, resolution of the pairs that touch (rare path, read from device memory): per lane its own proxies and,
-    // per own proxy, the pairs it takes part in: partner proxy | pair id << 8 | (1 if I am the pair's second proxy) << 16
-    int   nprox, npair;
-    int   own_proxy[4][QMAX_OWN];            // proxy index or -1
-    int   own_part[4][QMAX_OWN][QMAX_OWN];   // -1 = none
+    int   nprox, npair;                      // self-collision
+    int   own_proxy[4][QMAX_OWN];            // per lane the proxies on its bodies (index or -1): bit k of QInRec.sc_mask
 };
 
 static inline void quat_of_rot(const float *R, float *q) {     // row-major rotation -> unit quaternion xyzw (host only)
@@ -353,7 +352,7 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
     Q->npair = d->num_sc_pairs;
     Q->nprox = 0;
     for (int k = 0; k < d->num_sc_pairs; ++k) for (int side = 0; side < 2; ++side) if (d->sc_pair[k][side] + 1 > Q->nprox) Q->nprox = d->sc_pair[k][side] + 1;
-    for (int l = 0; l < 4; ++l) for (int k = 0; k < QMAX_OWN; ++k) { Q->own_proxy[l][k] = -1; for (int t2 = 0; t2 < QMAX_OWN; ++t2) Q->own_part[l][k][t2] = -1; }
+    for (int l = 0; l < 4; ++l) for (int k = 0; k < QMAX_OWN; ++k) Q->own_proxy[l][k] = -1;
     int local_of[QMAX_PROX];
     for (int p2 = 0; p2 < QMAX_PROX; ++p2) local_of[p2] = -1;
     for (int p2 = 0; p2 < Q->nprox; ++p2) {
@@ -367,30 +366,24 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         Q->in[T - 1 - step_of[pb]][l].sc_mask |= 1 << k;
         if (add_gym(pb, d->sc_proxy[p2].gym) < 0) { *err = "quad model: proxy Gym body does not fit"; return DW_EINVAL; }
     }
-    for (int k = 0; k < d->num_sc_pairs; ++k)
-        for (int side = 0; side < 2; ++side) {
-            const int me = d->sc_pair[k][side], other = d->sc_pair[k][1 - side];
-            const int l = Q->owner[d->sc_proxy[me].moving], kl = local_of[me];
-            int t2 = 0;
-            while (t2 < QMAX_OWN && Q->own_part[l][kl][t2] >= 0) ++t2;
-            if (t2 >= QMAX_OWN) { *err = "quad model: a proxy takes part in too many self-collision pairs"; return DW_EINVAL; }
-            Q->own_part[l][kl][t2] = other | (k << 8) | (side << 16);
-        }
+    // detection passes: one per broadcast proxy b; word 0 = b | lanes of register set r << (8 + 4 r), words 1 + r = the four
+    // lanes' pair ids of register set r (one byte each)
     int ncombo = 0;
-    int combo0[QMAX_COMBO], combo1[QMAX_COMBO];
+    int combo[QMAX_COMBO][5];
     for (int k = 0; k < d->num_sc_pairs; ++k) {
         const int a = d->sc_pair[k][0], b2 = d->sc_pair[k][1];
         const int lane = a & 3, reg = a >> 2;
         int c = -1;
-        for (int i = 0; i < ncombo; ++i) if ((combo0[i] & 255) == b2 && ((combo0[i] >> 8) & 3) == reg) c = i;
+        for (int i = 0; i < ncombo; ++i) if ((combo[i][0] & 255) == b2) c = i;
         if (c < 0) {
             if (ncombo >= QMAX_COMBO) { *err = "quad model: self-collision pairs need more detection passes than QMAX_COMBO"; return DW_EINVAL; }
             c = ncombo++;
-            combo0[c] = b2 | (reg << 8); combo1[c] = 0;
+            combo[c][0] = b2;
+            for (int i = 1; i < 5; ++i) combo[c][i] = 0;
         }
-        if ((combo0[c] >> (12 + lane)) & 1) { *err = "quad model: two pairs of one detection pass on the same lane"; return DW_EINVAL; }
-        combo0[c] |= 1 << (12 + lane);
-        combo1[c] |= k << (8 * lane);
+        if ((combo[c][0] >> (8 + 4 * reg + lane)) & 1) { *err = "quad model: two pairs of one detection pass on the same lane"; return DW_EINVAL; }
+        combo[c][0] |= 1 << (8 + 4 * reg + lane);
+        combo[c][1 + reg] |= k << (8 * lane);
     }
     // every Gym body must be reported by exactly one moving body (the kernels write, never accumulate, contact forces)
     for (int b = 1; b < NB; ++b) if (add_gym(b, dm->mv_gym[b]) < 0) { *err = "quad model: Gym body of a moving body does not fit"; return DW_EINVAL; }
@@ -438,7 +431,15 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
             H.prox[p2][3] = cp.radius;
             H.prox[p2][7] = fi((cp.moving & 255) | ((cp.gym & 255) << 8) | ((Q->owner[cp.moving] & 3) << 16) | ((local_of[p2] & 7) << 18));
         }
-        for (int c = 0; c < ncombo; ++c) { H.combo[c][0] = combo0[c]; H.combo[c][1] = combo1[c]; }
+        for (int c = 0; c < ncombo; ++c) for (int i = 0; i < 5; ++i) H.combo[c][i] = combo[c][i];
+        for (int i = 0; i < 8; ++i) H.pairs[i] = 0;
+        for (int i = 4; i < 8; ++i) H.misc[i] = 0;
+        for (int k = 0; k < d->num_sc_pairs; ++k) {
+            const int a = d->sc_pair[k][0], b2 = d->sc_pair[k][1];
+            H.pairs[k >> 2] |= (a | (b2 << 4)) << (8 * (k & 3));
+            H.misc[4 + Q->owner[d->sc_proxy[a].moving]] |= 1 << k;
+            H.misc[4 + Q->owner[d->sc_proxy[b2].moving]] |= 1 << k;
+        }
     }
     return DW_OK;
 }

@@ -51,6 +51,7 @@ DQ_HD void wave_sync_global() {
 }
 DQ_HD float rsqrt_nr(float x) { const float y = __builtin_amdgcn_rsqf(x); return y * (1.5f - 0.5f * x * y * y); }
 DQ_HD float rcp_nr(float x) { const float y = __builtin_amdgcn_rcpf(x); return y * (2.0f - x * y); }
+DQ_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }          // 1 ulp
 DQ_HD void atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 
 }  // namespace dwq
@@ -209,6 +210,7 @@ DQ_HD void wave_sync() { emu_barrier(); }
 DQ_HD void wave_sync_global() { emu_barrier(); }
 DQ_HD float rsqrt_nr(float x) { return 1.0f / sqrtf(x); }
 DQ_HD float rcp_nr(float x) { return 1.0f / x; }
+DQ_HD float rcp_fast(float x) { return 1.0f / x; }
 DQ_HD void atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
 
 }  // namespace dwq

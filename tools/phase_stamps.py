@@ -31,6 +31,7 @@ for i in range(30 + K):
                 for n in range(1, 14):
                     print("   %-22s %7d" % (names[n], st[base + n] - st[base + n - 1]))
                 print("   %-22s %7d" % ("encoder epilogue", st[base + 14] - st[base + 13]))
+            print("self-collision of substep 1: proxies %d, detection %d, resolution %d (any hit in the wave: %d)" % (st[51] - st[1 + 16 + 2], st[52] - st[51], st[1 + 16 + 3] - st[52], st[53]))
             print("kernel epilogue %d" % (st[40] - st[1 + 16 + 14]))
             if st[41] > st[40]:
                 print("post_physics_step %d" % (st[41] - st[40]))
