@@ -911,28 +911,25 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
         //      the feet only couple through the trunk -- and the four corners of a sole sequentially: 4 updates per
         //      sweep instead of 8.  Per contact: normal row, friction rows with the normal's effect folded in,
         //      projection onto the Coulomb cone.
-#if defined(__HIPCC__)
-        //      Device form: the rows of the left sole live in lanes 0..11, those of the right sole in lanes 32..43, each
-        //      with its row of A (24 registers), velocity and impulse in registers.  Every lane runs the impulse
-        //      arithmetic of ITS half's corner, so the two corners of a pair are solved by one instruction stream; the
-        //      scalars a corner needs come from its three row lanes by ds_swizzle broadcasts inside the 32-lane half
-        //      (cross-lane only, no LDS memory), the impulse changes cross halves with v_readlane.  Rows of inactive
-        //      corners have invd = 0 (C3), which makes their update the identity without a branch.
-        int cur = 0;
+        //      The rows of the left sole live in lanes 0..11, those of the right sole in lanes 32..43, each with its row
+        //      of A (24 registers), velocity and impulse in registers.  Every lane runs the impulse arithmetic of ITS
+        //      half's corner, so the two corners of a pair are solved by one instruction stream; the scalars a corner needs
+        //      come from its three row lanes by ds_swizzle broadcasts inside the 32-lane half (cross-lane only, no LDS
+        //      memory), the impulse changes cross halves with v_readlane.  Rows of inactive corners have invd = 0 (C3),
+        //      which makes their update the identity without a branch.  (The host suite runs this very code with one
+        //      fiber per lane: Wave::simt.)
+        const int cur = 0;
         {
             int act[DW_NUM_FOOT_PTS];
             for (int k = 0; k < DW_NUM_FOOT_PTS; ++k) act[k] = uniform(S.V.con.active[k]);
-            const int l = (int)threadIdx.x, half = l >> 5, lj = l & 31;
+            wave.simt([&](int l) {
+            const int half = l >> 5, lj = l & 31;
             const int row = lj < 12 ? 12 * half + lj : 0;
             float Arow[24];
             for (int c = 0; c < 24; ++c) Arow[c] = S.A.lcp.A[row][c];
             float vel = S.V.con.vel[0][row], Pl = S.V.con.P[0][row];
             const float invd = S.A.lcp.invd[row];
             const float mu = S.mu;
-#define DW_SWZ(x, j) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (x)), (j) << 5))   /* lane j of the own half */
-            auto bc = [](float x, int lane) {
-                return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
-            };
             // (The swizzle pattern is an immediate, so the four pairs are written out by macro rather than by an unrolled
             // loop.  The iteration-invariant scalars of a corner -- diagonal inverses, in-corner couplings -- are broadcast
             // again in every sweep: keeping the 24 of them in registers across the solver costs more in spills than the
@@ -942,10 +939,10 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
 #define DW_PGS_PAIR(KK) if (act[KK] | act[KK + 4]) { \
                     const float cz = half ? Arow[12 + 3 * KK + 2] : Arow[3 * KK + 2];     /* column z of the own corner */ \
                     const float cx = half ? Arow[12 + 3 * KK] : Arow[3 * KK]; \
-                    const float izk = DW_SWZ(invd, 3 * KK + 2), ixk = DW_SWZ(invd, 3 * KK), iyk = DW_SWZ(invd, 3 * KK + 1); \
-                    const float azxk = DW_SWZ(cz, 3 * KK), azyk = DW_SWZ(cz, 3 * KK + 1), axyk = DW_SWZ(cx, 3 * KK + 1); \
-                    const float Pz = DW_SWZ(Pl, 3 * KK + 2), Px = DW_SWZ(Pl, 3 * KK), Py = DW_SWZ(Pl, 3 * KK + 1); \
-                    const float vz = DW_SWZ(vel, 3 * KK + 2), vx0 = DW_SWZ(vel, 3 * KK), vy0 = DW_SWZ(vel, 3 * KK + 1); \
+                    const float izk = half_bcast<3 * KK + 2>(invd), ixk = half_bcast<3 * KK>(invd), iyk = half_bcast<3 * KK + 1>(invd); \
+                    const float azxk = half_bcast<3 * KK>(cz), azyk = half_bcast<3 * KK + 1>(cz), axyk = half_bcast<3 * KK + 1>(cx); \
+                    const float Pz = half_bcast<3 * KK + 2>(Pl), Px = half_bcast<3 * KK>(Pl), Py = half_bcast<3 * KK + 1>(Pl); \
+                    const float vz = half_bcast<3 * KK + 2>(vel), vx0 = half_bcast<3 * KK>(vel), vy0 = half_bcast<3 * KK + 1>(vel); \
                     float dz = -(vz - vminr[KK]) * izk; \
                     float pz = Pz + dz; \
                     if (pz < 0) pz = 0; \
@@ -961,7 +958,8 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                         px *= sc; py *= sc; \
                     } \
                     const float Dx = px - Px, Dy = py - Py; \
-                    const float L0 = bc(dz, 0), L1 = bc(Dx, 0), L2 = bc(Dy, 0), R0 = bc(dz, 32), R1 = bc(Dx, 32), R2 = bc(Dy, 32); \
+                    const float L0 = lane_bcast(dz, 0), L1 = lane_bcast(Dx, 0), L2 = lane_bcast(Dy, 0); \
+                    const float R0 = lane_bcast(dz, 32), R1 = lane_bcast(Dx, 32), R2 = lane_bcast(Dy, 32); \
                     vel = vel + Arow[3 * KK + 2] * L0 + Arow[3 * KK] * L1 + Arow[3 * KK + 1] * L2 \
                               + Arow[12 + 3 * KK + 2] * R0 + Arow[12 + 3 * KK] * R1 + Arow[12 + 3 * KK + 1] * R2; \
                     Pl = lj == 3 * KK ? px : (lj == 3 * KK + 1 ? py : (lj == 3 * KK + 2 ? pz : Pl)); }
@@ -969,60 +967,9 @@ DW_HD void physics_substep(const W &wave, Lds &S, const DevModel &M, const PhysP
                 DW_PGS_PAIR(0) DW_PGS_PAIR(1) DW_PGS_PAIR(2) DW_PGS_PAIR(3)
             }
 #undef DW_PGS_PAIR
-#undef DW_SWZ
             if (lj < 12) S.V.con.P[0][row] = Pl;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            });
         }
-#else
-        //      Host-emulation form (and the readable statement of the algorithm): one region per pair of contacts,
-        //      velocities and impulses ping-pong between two LDS copies so no lane reads what another lane writes.
-        int cur = 0;
-        for (int it = 0; it < P.iters; ++it) {
-            for (int kk = 0; kk < 4; ++kk) {
-                if (!(uniform(S.V.con.active[kk]) | uniform(S.V.con.active[kk + 4]))) continue;
-                wave.par([&](int l) {
-                    if (l < 24) {
-                        const float *vel = S.V.con.vel[cur], *Pc = S.V.con.P[cur];
-                        float d[2][3] = {{0, 0, 0}, {0, 0, 0}}, pn[2][3] = {{0, 0, 0}, {0, 0, 0}};
-                        for (int f = 0; f < 2; ++f) {
-                            const int k = kk + 4 * f;
-                            const int rx = 3 * k, ry = 3 * k + 1, rz = 3 * k + 2;
-                            const float Pz = Pc[rz], Px = Pc[rx], Py = Pc[ry];
-                            pn[f][0] = Px; pn[f][1] = Py; pn[f][2] = Pz;
-                            if (!S.V.con.active[k]) continue;
-                            float dz = -(vel[rz] - S.V.con.vmin[k]) * S.A.lcp.invd[rz];
-                            float pz = Pz + dz;
-                            if (pz < 0) pz = 0;
-                            dz = pz - Pz;
-                            const float vx = vel[rx] + S.A.lcp.A[rx][rz] * dz;
-                            const float dx = -vx * S.A.lcp.invd[rx];
-                            const float vy = vel[ry] + S.A.lcp.A[ry][rz] * dz + S.A.lcp.A[ry][rx] * dx;
-                            const float dy = -vy * S.A.lcp.invd[ry];
-                            float px = Px + dx, py = Py + dy;
-                            const float lim = S.mu * pz, n2 = px * px + py * py;
-                            if (n2 > lim * lim) {
-                                const float sc = lim * rsqrt_nr(n2);
-                                px *= sc; py *= sc;
-                            }
-                            d[f][0] = px - Px; d[f][1] = py - Py; d[f][2] = dz;
-                            pn[f][0] = px; pn[f][1] = py; pn[f][2] = pz;
-                        }
-                        S.V.con.vel[cur ^ 1][l] = vel[l] + S.A.lcp.A[l][3 * kk + 2] * d[0][2] + S.A.lcp.A[l][3 * kk] * d[0][0] +
-                                                  S.A.lcp.A[l][3 * kk + 1] * d[0][1] + S.A.lcp.A[l][12 + 3 * kk + 2] * d[1][2] +
-                                                  S.A.lcp.A[l][12 + 3 * kk] * d[1][0] + S.A.lcp.A[l][12 + 3 * kk + 1] * d[1][1];
-                        float pv = Pc[l];
-                        for (int f = 0; f < 2; ++f)
-                            for (int i = 0; i < 3; ++i)
-                                if (l == 3 * (kk + 4 * f) + i) pv = pn[f][i];
-                        S.V.con.P[cur ^ 1][l] = pv;
-                    }
-                });
-                cur ^= 1;
-            }
-        }
-#endif
         DW_CKPT(10);
         // ---- C5: impulses -> wrenches about O on the two foot bodies -> delta-ABA over the whole tree ----
         wave.par([&](int l) {

@@ -73,7 +73,7 @@ struct alignas(16) QHot {
     // (combo[c][0] >> (8 + 4 r)) & 15 tests its proxy of register set r against it; combo[c][1 + r] holds the four lanes'
     // pair ids (one byte each) for the hit mask.  pairs: byte k = proxies of pair k (a | b << 4); misc[4 + l]: the pairs lane
     // l resolves (one of the two proxies sits on one of its bodies).
-    float prox[QMAX_PROX][8];
+    alignas(16) float prox[QMAX_PROX][8];
     int   combo[QMAX_COMBO][5];
     int   pairs[8];
 };

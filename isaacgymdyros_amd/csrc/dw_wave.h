@@ -3,7 +3,9 @@
 // The kernels are written for ONE WAVEFRONT (64 lanes) PER ENVIRONMENT: every phase of the step is a
 // "region" executed by all 64 lanes, regions exchange data only through the env's LDS block, and a
 // workgroup is exactly one wave, so the boundary between regions is a wavefront-scope fence (no instruction).
-// `Wave::par(f)` runs f(lane) for the calling lane and ends the region.  `uniform(x)` turns a value
+// `Wave::par(f)` runs f(lane) for the calling lane and ends the region.  `Wave::simt(f)` is a region whose lanes also
+// talk to each other in registers (swz / readlane below), which a lane loop cannot express: the host runs it with one
+// fiber per lane (dw_quad_wave.h).  `uniform(x)` turns a value
 // every lane read from the same LDS word into a scalar-register value so that loops and branches that
 // contain regions are provably wave-uniform.
 //
@@ -40,18 +42,30 @@ struct Wave {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
     }
+    template <class F> DW_HD void simt(F &&f) const { par(f); }
 };
 DW_HD int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// x of lane J of the caller's 32-lane half (ds_swizzle broadcast: cross-lane only, no LDS memory); x of lane `lane`
+template <int J> DW_HD float half_bcast(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), J << 5)); }
+DW_HD float lane_bcast(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
 }  // namespace dw
 #else
+#include <type_traits>
 #define DW_HD static inline
 #define DW_OPAQUE(i) ((void)0)
+#include "dw_quad_wave.h"          // host half: one fiber per lane, run_wave / emu_xchg
 namespace dw {
 struct Wave {
     template <class F> void par(F &&f) const {
         for (int lane = 0; lane < 64; ++lane) f(lane);
     }
+    template <class F> void simt(F &&f) const {
+        using Fn = typename std::remove_reference<F>::type;
+        if (!dwq::run_wave([](void *a, int lane) { (*static_cast<Fn *>(a))(lane); }, (void *)&f)) abort();
+    }
 };
 static inline int uniform(int x) { return x; }
+template <int J> static inline float half_bcast(float x) { return dwq::emu_xchg(x, (dwq::lane_id() & 32) | J); }
+static inline float lane_bcast(float x, int lane) { return dwq::emu_xchg(x, lane); }
 }  // namespace dw
 #endif

@@ -6,20 +6,32 @@ import numpy as np
 import emul_backend, replay as R
 from isaacgymdyros_amd import abi
 from isaacgymdyros_amd.task_constants import load_task_constants
-lib = C.CDLL(os.path.join(HERE, 'emul', '_build', 'libdw_emul_asan.so'))
-emul_backend._cache['libdw_emul.so'] = (lib, abi.declare(lib, 'dwe_'))
+QUAD = len(sys.argv) > 1 and sys.argv[1] == 'quad'
+stem = 'libdw_emul_quad' if QUAD else 'libdw_emul'
+lib = C.CDLL(os.path.join(HERE, 'emul', '_build', stem + '_asan.so'))
+emul_backend._cache[stem + '.so'] = (lib, abi.declare(lib, 'dwe_'))
 tc = load_task_constants()
 for name, kw in (('task_logic_frozen.npz', dict(debug_freeze_physics=1)), ('whole_step_oracle.npz', {})):
     g = R.load(name)
-    be = emul_backend.EmulBackend(int(g['N']), tc, randomize_dof_on_reset=0, torch_gpu_div=0, **kw)
+    be = emul_backend.EmulBackend(int(g['N']), tc, quad=QUAD, randomize_dof_on_reset=0, torch_gpu_div=0, **kw)
     n = 0
     for t, ref, got in R.replay(g, be):
         n += 1
         if n >= 40: break
     print(name, 'replayed', n, 'steps under ASan/UBSan')
 # reset_idx + simulate paths
-sim = emul_backend.EmulSim(8, task_const=tc)
+sim = emul_backend.EmulSim(8, task_const=tc, quad=QUAD)
 sim.simulate(np.zeros((8,33),np.float32), np.ones((8,2),np.float32))
 sim.reset_idx(np.array([0,3,7],np.int32))
 sim.step(np.zeros((8,13),np.float32), None, 0)
+# self-collision resolution paths (legs crossed, arms pressed into the torso) and a ragged last wave (17 envs)
+from test_oracle_physics import _arms_in
+sim = emul_backend.EmulSim(17, task_const=tc, quad=QUAD)
+q = _arms_in(17)
+q[::2, 1] = -0.2
+q[::2, 7] = 0.2
+sim.buf['root_states'][:, 2] = 3.0
+sim.buf['dof_state'][:, :, 0] = q
+sim.simulate(np.zeros((17,33),np.float32))
+assert (np.linalg.norm(sim.buf['contact_forces'], axis=2) > 1).any(axis=1).sum() >= 8
 print('simulate / reset_idx / step(noise=None) ok')

@@ -5,6 +5,7 @@
 // prefix dwe_ and HOST pointers.  It is not a fallback of the product -- nothing in isaacgymdyros_amd/
 // can load it -- it exists so that the CPU test-suite (and ASan/UBSan) exercises the kernels' indexing
 // and region structure before any GPU time is spent.
+#define DWQ_EMUL_IMPLEMENTATION
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -40,7 +40,7 @@ void wave_body(void *p, int) {
 }
 int run_waves(DwHandle *h, int kind, const float *a0, const float *a1, long long step) {
     const int nw = (h->cfg.num_envs + dwq::EPW - 1) / dwq::EPW;
-    dwq::QLds *lds = (dwq::QLds *)aligned_alloc(64, sizeof(dwq::QLds));
+    dwq::QLds *lds = (dwq::QLds *)aligned_alloc(64, (sizeof(dwq::QLds) + 63) / 64 * 64);
     int rc = DW_OK;
     for (int w = 0; w < nw && rc == DW_OK; ++w) {
         memset(lds, 0xff, sizeof(*lds));           // NaN-fill: a read of a never-written slot poisons the result

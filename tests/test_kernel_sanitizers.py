@@ -1,6 +1,8 @@
 """GPU AddressSanitizer is not available on the pool, so the kernel body is sanitised on the CPU: the lane-loop
 emulation (tests/emul) is built with -fsanitize=address,undefined and replays both golden fixtures plus the
-simulate / reset_idx / in-kernel-RNG paths.  Any out-of-bounds LDS or buffer index in the shared kernel source
+simulate / reset_idx / in-kernel-RNG / self-collision paths -- for both kernel generations: the wave-per-env kernels (lane
+loop; the register-resident Gauss-Seidel runs with one fiber per lane) and the quad kernels (one fiber per lane throughout,
+the fibers' stacks announced to ASan).  Any out-of-bounds LDS or buffer index in the shared kernel source
 aborts the worker."""
 import os
 import subprocess
@@ -19,14 +21,15 @@ def _lib(name):
         return None
 
 
-def test_kernel_body_under_asan_ubsan():
+@pytest.mark.parametrize("quad", [False, True], ids=["wave-per-env", "quad"])
+def test_kernel_body_under_asan_ubsan(quad):
     asan, ubsan = _lib("libasan.so"), _lib("libubsan.so")
     if not asan or not ubsan:
         pytest.skip("libasan/libubsan not found")
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "emul"), "-s", "_build/libdw_emul_asan.so"])
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emul"), "-s", "_build/libdw_emul_quad_asan.so" if quad else "_build/libdw_emul_asan.so"])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                LD_PRELOAD=asan + ":" + ubsan, OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, os.path.join(HERE, "_asan_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_asan_worker.py")] + (["quad"] if quad else []), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "replayed 40 steps" in out.stdout and "simulate / reset_idx / step(noise=None) ok" in out.stdout
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
