@@ -175,6 +175,10 @@ def main():
         env.reset()
         for i in range(warmup):
             env.step(pool[i % len(pool)])
+        # everything the timed loop calls must have run once before it: the logging gather's torch kernels are loaded on
+        # first use, which on a fresh box costs ~15 ms of host time (measured r02: 0.285 instead of 0.257 ms/step over 512
+        # steps whenever --warmup was shorter than one logging horizon)
+        dwdist.gather_episode_stats(env._buf["env_state"])
         if world > 1:
             dist.barrier()
         sync()
@@ -221,13 +225,16 @@ def main():
     out = None
     if rank == 0:
         achieved = A_STEP_BYTES * args.envs_per_gpu / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, lane_slots = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(str(args.envs_per_gpu), {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(str(args.envs_per_gpu), {})
+                if rec.get("kernel", kinfo.get("kernels")) == kinfo.get("kernels"):      # counters of THIS kernel only
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    lane_slots = rec.get("lane_slots_per_env_step")
             except Exception:
-                traffic = None
+                traffic, lane_slots = None, None
         useful_flops = FLOPS_PER_ENV_STEP * args.envs_per_gpu
         valu = useful_flops / (kernel_ms * 1e-3) / 1e12
         out = {
@@ -247,7 +254,7 @@ def main():
             # the fp32 vector peak; lane_slots_per_env_step comes from the SQ_INSTS_VALU PMC pass when one is committed
             "roofline_valu": {"bound": "valu_f32", "achieved": valu, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": valu / VALU_PEAK_TF, "useful_flops_per_env_step": FLOPS_PER_ENV_STEP,
-                              "lane_slots_per_env_step": kinfo.get("lane_slots_per_env_step")},
+                              "lane_slots_per_env_step": lane_slots},
             "episodes": dict(epi, finished_total=resets),
         }
         if plumbing:

@@ -353,6 +353,14 @@ class DyrosDynamicWalk(VecTask):
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
         _lib.check(self._api, self._api["reset_idx"](self._h, ids.data_ptr(), int(ids.numel()), nz, self._step_count, stream))
 
+    def kernel_info(self) -> dict:
+        """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
+        profiles/ carry the same name)."""
+        fused = int(self._ccfg.pipeline) == 1
+        name = "dw_k_step" if fused else "dw_k_step_quad"
+        return {"kernels": name, "pipeline": "fused wave-per-env" if fused else "quad (4 lanes per env)",
+                "launches_per_step": 1}
+
     def simulate(self, tau: torch.Tensor, push_xy: torch.Tensor = None):
         """One physics substep at the Gym boundary: set_dof_actuation_force_tensor + apply_rigid_body_force_tensors
         (base_link x/y) + simulate + the three refreshes (reference :502,520,525-526,547-549)."""

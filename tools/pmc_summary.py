@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[0]
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()     # template kernels: "void dw_k_step_quad<false>(...)"
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, d in acc.items():

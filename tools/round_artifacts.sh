@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 # PMC passes first: bench.py reports the HBM traffic of THIS build (profiles/pmc_traffic.json) in its roofline object
-tools/pmc_passes.sh gpurun_out/$TAG/pmc 16384 12 > /dev/null 2>&1
+tools/pmc_passes.sh gpurun_out/$TAG/pmc 16384 40 > /dev/null 2>&1
 python tools/collect_profiles.py $TAG --traffic-only
 timeout -k 10 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?"; cat $OUT/bench.json | cut -c1-400
