@@ -64,6 +64,18 @@ struct StepKeep {
     float tgt[QNI], qn[QNI], qv[QNI];                                  // items: mocap target, encoder angle and rate
 };
 
+// Rows of NW consecutive floats at any 4-byte alignment, moved in 16-byte pieces (global_load/store_dwordx4 take dword-aligned
+// addresses): a 37-word history row is 10 requests instead of 37.
+struct __attribute__((packed, aligned(4))) U4 { float x, y, z, w; };
+template <int NW> DQ_HD void ld_row(const float *p, float (&v)[NW]) {
+    DQ_UNROLL for (int i = 0; i + 4 <= NW; i += 4) { const U4 t = *reinterpret_cast<const U4 *>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+    DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) v[i] = p[i];
+}
+template <int NW> DQ_HD void st_row(float *p, const float (&v)[NW]) {
+    DQ_UNROLL for (int i = 0; i + 4 <= NW; i += 4) { U4 t; t.x = v[i]; t.y = v[i + 1]; t.z = v[i + 2]; t.w = v[i + 3]; *reinterpret_cast<U4 *>(p + i) = t; }
+    DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) p[i] = v[i];
+}
+
 // torch.norm of 3 elements on the CPU reference (dw_task.h norm_t with n = 3: fused scalar tail)
 DQ_HD float norm3_t(float x, float y, float z) {
     float b0 = fmaf(x, x, 0.0f);
@@ -446,6 +458,22 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     }
 
     DQ_STAMP(B, 46);
+    // ---- Q5, first half: request the history taps now, use them after Q4 (one memory latency, spent computing the new
+    //      observation).  A lane takes ROWS (env, tap): 37 observation words and 13 action words, consecutive in the rings and
+    //      in obs_buf, so a row is 10 + 4 requests with constant offsets and no per-word index arithmetic.  The newest
+    //      observation tap is this step's own (Q4, still in LDS) and is not read back. ----
+    constexpr int NTAP = DW_NUM_HIS - 1, NPAIR = EPW * NTAP, RPL = (NPAIR + 63) / 64;
+    static_assert((DW_NUM_SKIP * DW_NUM_HIS) % DW_HIST_SLOTS == 0, "the last observation tap must be the newest slot");
+    float tapo[RPL][DW_NUM_OBS1], tapa[RPL][DW_NUM_ACT];
+    DQ_UNROLL for (int r = 0; r < RPL; ++r) {
+        const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
+        const int ee = pc / NTAP, tap = pc - NTAP * ee;
+        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
+        const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+        const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
+        ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, tapo[r]);
+        ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, tapa[r]);
+    }
     // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
     //      expensive functions (atan2, sincos, the noise draw) is executed by one or two wave passes, not by all ten ----
     {
@@ -514,78 +542,35 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     wave_sync();
 
     DQ_STAMP(B, 47);
-    // ---- Q5: 487-d observation buffer from the ring taps.  The wave's 16 obs rows are one 31 KB run; items (env, word of
-    //      a 37- or 13-word block) are decomposed once and reused for every tap, two taps' loads in flight per wait ----
+    // ---- Q5, second half: the 487-d observation buffer.  Rows requested above go out as they came (an env that was just
+    //      reset shows its first observation in every tap and zeros in the action taps, tasks/dyros_dynamic_walk.py:655-669);
+    //      the newest tap is copied from LDS, items (env, word). ----
     {
         float *ob = B.obs_buf + (size_t)wave_index * EPW * DW_NUM_OBS;
-        {
-            constexpr int PO = (EPW * DW_NUM_OBS1 + 63) / 64;             // 10 passes cover the 16 x 37 words of one tap
-            int ee_[PO], k_[PO];
-            DQ_UNROLL for (int u = 0; u < PO; ++u) {
-                const int i = lane + 64 * u;
-                ee_[u] = i < EPW * DW_NUM_OBS1 ? i / DW_NUM_OBS1 : -1;
-                k_[u] = i < EPW * DW_NUM_OBS1 ? i - DW_NUM_OBS1 * ee_[u] : 0;
+        DQ_UNROLL for (int r = 0; r < RPL; ++r) {
+            const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
+            const int ee = pc / NTAP, tap = pc - NTAP * ee;
+            const bool ok = p < NPAIR && wave_index * EPW + ee < N;
+            const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
+            if (wave_any(fill)) {
+                if (fill) { DQ_UNROLL for (int k = 0; k < DW_NUM_OBS1; ++k) tapo[r][k] = PQ_NORMED(ee, k); }
             }
-            for (int ii = 0; ii < DW_NUM_HIS; ii += 2) {
-                float v0[PO], v1[PO];
-                DQ_UNROLL for (int u = 0; u < PO; ++u) {
-                    v0[u] = v1[u] = 0.0f;
-                    const int ee = ee_[u];
-                    if (ee >= 0) {
-                        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
-                        const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD), head = (newest + 1) % DW_HIST_SLOTS;
-                        const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f;
-                        const float nv = PQ_NORMED(ee, k_[u]);
-                        const float *oh = B.obs_history + (size_t)eg * DW_HIST_SLOTS * DW_NUM_OBS1 + k_[u];
-                        const int s0 = (head + DW_NUM_SKIP * (ii + 1) - 1) % DW_HIST_SLOTS, s1 = (head + DW_NUM_SKIP * (ii + 2) - 1) % DW_HIST_SLOTS;
-                        // (unconditional loads, selected afterwards: a load under a lane condition would be waited for in place)
-                        const float l0 = oh[s0 * DW_NUM_OBS1], l1 = oh[s1 * DW_NUM_OBS1];
-                        v0[u] = (fill || s0 == newest) ? nv : l0;
-                        v1[u] = (fill || s1 == newest) ? nv : l1;
-                    }
-                }
-                DQ_UNROLL for (int u = 0; u < PO; ++u) {
-                    const int ee = ee_[u];
-                    if (ee >= 0 && wave_index * EPW + ee < N) {
-                        ob[ee * DW_NUM_OBS + ii * DW_NUM_OBS1 + k_[u]] = v0[u];
-                        ob[ee * DW_NUM_OBS + (ii + 1) * DW_NUM_OBS1 + k_[u]] = v1[u];
-                    }
-                }
+            const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD);
+            const bool own = ((newest + 1) % DW_HIST_SLOTS + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS == newest;    // (never, with 2 x 10 slots)
+            if (wave_any(rs || own)) {
+                if (rs) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = 0.0f; }
+                else if (own) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = PQ_ES(ee, DW_ES_ACTIONS + k); }
+            }
+            if (ok) {
+                st_row(ob + ee * DW_NUM_OBS + tap * DW_NUM_OBS1, tapo[r]);
+                st_row(ob + ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + tap * DW_NUM_ACT, tapa[r]);
             }
         }
-        {
-            constexpr int PA = (EPW * DW_NUM_ACT + 63) / 64;              // 4 passes cover the 16 x 13 words of one action tap
-            static_assert((DW_NUM_HIS - 1) % 3 == 0, "action taps are gathered three at a time");
-            int ee_[PA], k_[PA];
-            DQ_UNROLL for (int u = 0; u < PA; ++u) {
-                const int i = lane + 64 * u;
-                ee_[u] = i < EPW * DW_NUM_ACT ? i / DW_NUM_ACT : -1;
-                k_[u] = i < EPW * DW_NUM_ACT ? i - DW_NUM_ACT * ee_[u] : 0;
-            }
-            for (int ii = 0; ii < DW_NUM_HIS - 1; ii += 3) {
-                float v[3][PA];
-                DQ_UNROLL for (int u = 0; u < PA; ++u) {
-                    const int ee = ee_[u];
-                    DQ_UNROLL for (int t = 0; t < 3; ++t) v[t][u] = 0.0f;
-                    if (ee >= 0) {
-                        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
-                        const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD), head = (newest + 1) % DW_HIST_SLOTS;
-                        const bool rs = PQ_PSI(ee, PS_RESET) != 0;
-                        const float av = PQ_ES(ee, DW_ES_ACTIONS + k_[u]);
-                        const float *ah = B.action_history + (size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + k_[u];
-                        DQ_UNROLL for (int t = 0; t < 3; ++t) {
-                            const int sl = (head + DW_NUM_SKIP * (ii + t + 1)) % DW_HIST_SLOTS;
-                            const float ld = ah[sl * DW_NUM_ACT];
-                            v[t][u] = rs ? 0.0f : (sl == newest ? av : ld);
-                        }
-                    }
-                }
-                DQ_UNROLL for (int u = 0; u < PA; ++u) {
-                    const int ee = ee_[u];
-                    if (ee >= 0 && wave_index * EPW + ee < N) {
-                        DQ_UNROLL for (int t = 0; t < 3; ++t) ob[ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + (ii + t) * DW_NUM_ACT + k_[u]] = v[t][u];
-                    }
-                }
+        DQ_UNROLL for (int u = 0; u < (EPW * DW_NUM_OBS1 + 63) / 64; ++u) {
+            const int i = lane + 64 * u;
+            if (i < EPW * DW_NUM_OBS1) {
+                const int ee = i / DW_NUM_OBS1, k = i - DW_NUM_OBS1 * ee;
+                if (wave_index * EPW + ee < N) ob[ee * DW_NUM_OBS + NTAP * DW_NUM_OBS1 + k] = PQ_NORMED(ee, k);
             }
         }
     }
