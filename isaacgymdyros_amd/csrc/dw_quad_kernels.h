@@ -108,9 +108,11 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
             const int i = X.lane + 64 * k;
             const int el = i / DW_NUM_ACT, a = i - DW_NUM_ACT * el;
             const int eg = wave_index * EPW + el;
+            KP.act[k] = 0.0f;
+            if (i < EPW * DW_NUM_ACT) KP.act[k] = dw::clamp_action(actions, eg < C.num_envs ? eg : C.num_envs - 1, a);
             if (i < EPW * DW_NUM_ACT && eg < C.num_envs) {
                 float *ei = B.env_state + (size_t)DW_ES_WORDS * eg;
-                const float v = dw::clamp_action(actions, eg, a);
+                const float v = KP.act[k];
                 const int head = *reinterpret_cast<const int *>(&ei[DW_ES_HIST_HEAD]);
                 B.action_history[((size_t)eg * DW_HIST_SLOTS + head) * DW_NUM_ACT + a] = v;
             }
@@ -146,6 +148,7 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
             if (d < 12) atq = dw::clamp_action(actions, it.env, d) * ei[DW_ES_MOTOR_SCALE + d] * M.action_high[d];
         }
         tgt[k] = target;
+        KP.atq[k] = atq;
         if (d < 12) {
             // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
             // the two substeps (the action torque of the step is appended both times); the record gets the final column

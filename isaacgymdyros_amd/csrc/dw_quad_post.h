@@ -62,6 +62,8 @@ struct StepKeep {
     float magnitude, phase;
     int   simul_len;                                                   // all lanes: torque FIFO fill after the two substeps
     float tgt[QNI], qn[QNI], qv[QNI];                                  // items: mocap target, encoder angle and rate
+    float atq[QNI];                                                    // items (env, leg joint): action torque of the step
+    float act[(EPW * DW_NUM_ACT + 63) / 64];                           // items (env, action): the clamped action
 };
 
 // Rows of NW consecutive floats at any 4-byte alignment, moved in 16-byte pieces (global_load/store_dwordx4 take dword-aligned
@@ -110,6 +112,9 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
         DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = X.root[i];
         PQ_PSI(el, PS_BAD) = 0; PQ_PSI(el, PS_COLL) = 0; PQ_PSI(el, PS_RESET) = 0;
     }
+    // (the VecTask counters and the clock action of Q1, requested together with the records: one memory latency for all)
+    const long long q1_progress = B.progress_buf[e], q1_randomize = B.randomize_buf[e];
+    const float q1_mass = B.total_mass[e], q1_clock = dw::clamp_action(actions, e, 12);
     {
         // 16 records = 1488 pieces of 16 bytes, contiguous in HBM and in LDS: every lane requests its 24 pieces before the
         // first one is stored (one memory latency for the lot)
@@ -119,18 +124,17 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
         const int np_ok = (nvalid >= EPW ? EPW : nvalid) * (DW_ES_WORDS / 4);
         const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)wave_index * EPW * DW_ES_WORDS);
         F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
-        // (in groups of 8 pieces: 8 requests in flight per lane, registers the compiler keeps as registers)
-        static_assert(PER % 8 == 0, "record block pieces per lane must be a multiple of the group size");
-        for (int g8 = 0; g8 < PER; g8 += 8) {
-            float tx[8], ty[8], tz[8], tw[8];
-            DQ_UNROLL for (int u = 0; u < 8; ++u) {
+        constexpr int GRP = PER;
+        DQ_UNROLL for (int g8 = 0; g8 < PER; g8 += GRP) {
+            float tx[GRP], ty[GRP], tz[GRP], tw[GRP];
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) {
                 const int pi = lane + 64 * (g8 + u);
                 // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
                 const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
                 const F4 v = src[pi < NP ? ps : 0];
                 tx[u] = v.x; ty[u] = v.y; tz[u] = v.z; tw[u] = v.w;
             }
-            DQ_UNROLL for (int u = 0; u < 8; ++u) { const int pi = lane + 64 * (g8 + u); if (pi < NP) dst[pi] = mk4(tx[u], ty[u], tz[u], tw[u]); }
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) { const int pi = lane + 64 * (g8 + u); if (pi < NP) dst[pi] = mk4(tx[u], ty[u], tz[u], tw[u]); }
         }
     }
     wave_sync();
@@ -146,10 +150,9 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
         PQ_ES(el, DW_ES_MAGNITUDE) = KP.magnitude; PQ_ES(el, DW_ES_PHASE) = KP.phase;
     }
     if (j < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * j + i) = X.warm[i]; }
-    for (int i = lane; i < EPW * DW_NUM_ACT; i += 64) {
-        const int ee = i / DW_NUM_ACT, a = i - DW_NUM_ACT * ee;
-        const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
-        PQ_ES(ee, DW_ES_ACTIONS + a) = dw::clamp_action(actions, eg, a);
+    DQ_UNROLL for (int k = 0; k < (EPW * DW_NUM_ACT + 63) / 64; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPW * DW_NUM_ACT) PQ_ES(i / DW_NUM_ACT, DW_ES_ACTIONS + (i - DW_NUM_ACT * (i / DW_NUM_ACT))) = KP.act[k];
     }
     DQ_UNROLL for (int k = 0; k < QNI; ++k) {
         const int i = lane + 64 * k;
@@ -162,7 +165,7 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
             PQ_ES(ee, DW_ES_QVEL_NOISE + d) = KP.qv[k];
             if (d < 12) {
                 // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
-                const float at = dw::clamp_action(actions, eg, d) * PQ_ES(ee, DW_ES_MOTOR_SCALE + d) * M.action_high[d];
+                const float at = KP.atq[k];
                 PQ_ES(ee, DW_ES_ACTION_TORQUE + d) = at;
                 float col[DW_ALOG_SLOTS];
                 DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(ee, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;
@@ -192,13 +195,13 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     DQ_STAMP(B, 42);
     // ---- Q1: clocks, VecTask counters, non-finite guard ----
     if (j == 0) {
-        const long long p = B.progress_buf[e], rbl = B.randomize_buf[e];
+        const long long p = q1_progress, rbl = q1_randomize;
         int rb = (int)(rbl > 0x7ffffffe ? 0x7ffffffe : rbl);
-        PQ_PS(el, PS_MASS) = B.total_mass[e];
+        PQ_PS(el, PS_MASS) = q1_mass;
         PQ_ES(el, DW_ES_EPI_LEN) += 1.0f;
         float time = PQ_ES(el, DW_ES_TIME);
         time = time + C.dt_policy_f;
-        time = time + C.clock_gain_f * dw::clamp_action(actions, e, 12);
+        time = time + C.clock_gain_f * q1_clock;
         PQ_ES(el, DW_ES_TIME) = time;
         if (X.valid) {
             B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
@@ -377,12 +380,12 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
             if (X.valid) B.terrain_levels[e] = lvl;
         }
         wave_sync();
-        // per joint
-        DQ_UNROLL for (int k = 0; k < QNI; ++k) {
-            const int i = lane + 64 * k;
-            const int ee = i < EPW * ND ? i / ND : 0, l = i < EPW * ND ? i - ND * ee : 0;
+        // one pass per env that ended (a wave-uniform loop over the ballot: resets are rare, and a pass over all 16 x 33
+        // items with most lanes idle cost nine times as much): lane = joint
+        for (unsigned long long rbits = wave_ballot(j == 0 && mine); rbits != 0ull; rbits &= rbits - 1ull) {
+            const int ee = __builtin_ctzll(rbits) >> 2, l = lane < ND ? lane : 0;
             const int egr = wave_index * EPW + ee, eg = egr < N ? egr : N - 1;
-            if (i < EPW * ND && PQ_PSI(ee, PS_RESET)) {
+            if (lane < ND) {
                 dw::NoiseSrc nz = K.nz;
                 nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
                 const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(ee, PS_RANDOMIZE) >= 1;
@@ -414,15 +417,9 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
                     PQ_ROOT(ee, ii) = v;
                 }
             }
-        }
-        // torque FIFO and action ring, zeroed
-        for (int i = lane; i < EPW * DW_ALOG_SLOTS * 12; i += 64) {
-            const int ee = i / (DW_ALOG_SLOTS * 12), w = i - DW_ALOG_SLOTS * 12 * ee;
-            if (PQ_PSI(ee, PS_RESET)) PQ_ES(ee, DW_ES_ACTION_LOG + w) = 0.0f;
-        }
-        for (int i = lane; i < EPW * DW_HIST_SLOTS * DW_NUM_ACT; i += 64) {
-            const int ee = i / (DW_HIST_SLOTS * DW_NUM_ACT), w = i - DW_HIST_SLOTS * DW_NUM_ACT * ee, eg = wave_index * EPW + ee;
-            if (eg < N && PQ_PSI(ee, PS_RESET)) B.action_history[(size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + w] = 0.0f;
+            // torque FIFO and action ring, zeroed
+            for (int i = lane; i < DW_ALOG_SLOTS * 12; i += 64) PQ_ES(ee, DW_ES_ACTION_LOG + i) = 0.0f;
+            if (egr < N) { for (int i = lane; i < DW_HIST_SLOTS * DW_NUM_ACT; i += 64) B.action_history[(size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + i] = 0.0f; }
         }
         // per-env scalars (dw_task.h reset_region, lane 40)
         if (j == 0 && mine) {

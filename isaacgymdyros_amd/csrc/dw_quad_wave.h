@@ -11,6 +11,7 @@
 //   quad_bcast<J>(x)       value of x in lane J of the caller's quad            (v_mov_dpp quad_perm:[J,J,J,J])
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
+//   wave_ballot(p)         64-bit mask of p over the lanes, the same in every lane (v_cmp into an SGPR pair)
 //   wave_sync_global()     as wave_sync, for global memory too (workgroup-scope release / acquire).
 //   wave_sync()            LDS written before it by any lane is visible to every lane after it.  One wave = one
 //                          workgroup and a wave's LDS operations complete in order, so on the device this is a compiler
@@ -37,6 +38,7 @@ template <int J> DQ_HD float quad_bcast(float x) { return dpp_quad<J | (J << 2) 
 DQ_HD float quad_xor1(float x) { return dpp_quad<1 | (0 << 2) | (3 << 4) | (2 << 6)>(x); }
 DQ_HD float quad_xor2(float x) { return dpp_quad<2 | (3 << 2) | (0 << 4) | (1 << 6)>(x); }
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
 DQ_HD void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -205,6 +207,15 @@ DQ_HD bool wave_any(bool p) {
     int any = 0;
     for (int k = 0; k < WaveEmu::NL; ++k) any |= e->xi[par][k];
     return any != 0;
+}
+DQ_HD unsigned long long wave_ballot(bool p) {
+    WaveEmu *e = g_emu;
+    const int l = e->cur, par = (int)(e->nsync[l] & 1);
+    e->xi[par][l] = p ? 1 : 0;
+    emu_barrier();
+    unsigned long long m = 0;
+    for (int k = 0; k < WaveEmu::NL; ++k) if (!e->done[k] && e->xi[par][k]) m |= 1ull << k;
+    return m;
 }
 DQ_HD void wave_sync() { emu_barrier(); }
 DQ_HD void wave_sync_global() { emu_barrier(); }
