@@ -61,9 +61,9 @@ void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const floa
 namespace dwq {
 struct QuadModel;
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const float *actions, const float *noise, long long step);
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step);
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                     const float *tau, const float *push);
+                     const DwBuffers &B, const float *tau, const float *push);
 int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err);      // malloc'ed
 size_t quadmodel_bytes();
 int  quad_lds_bytes();
@@ -195,7 +195,7 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (h->cfg.debug_freeze_physics) return DW_OK;
     DeviceGuard guard(h->device);
     if (h->pipeline == 2) {
-        dwq::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, tau, push_xy);
+        dwq::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_simulate_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, tau, push_xy);
@@ -214,8 +214,8 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
     DeviceGuard guard(h->device);
     if (h->pipeline == 2) {
-        dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, actions, noise,
-                         (long long)step_index);
+        dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
+                         actions, noise, (long long)step_index);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
                            h->d_params, actions, noise, (long long)step_index);

@@ -23,6 +23,8 @@ using dw::TaskParams;
 // per-env scratch of the task phases: the four slot rows of body 0 (the base has no slot) = 16 words per env
 #define DQ_ENVW(el, w) (reinterpret_cast<float *>(&L.slot[(w) >> 2][(el)])[(w) & 3])
 constexpr int EW_LTP = 0, EW_MIDX = 1;       // mocap phase time, mocap row (int bits)
+constexpr int EW_T0 = 2, EW_T1 = 3;          // time stamps of the two mocap rows
+constexpr int EW_DL = 4, EW_SL = 5;          // torque FIFO: delay index, fill (int bits)
 constexpr int WW_GATE = 15;                  // wave-wide word: perturbation gate open (env 0's scratch)
 
 // The whole VecTask.step for 16 envs: pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
@@ -60,8 +62,13 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
             DQ_ENVW(X.el, EW_LTP) = ltp;
             DQ_ENVW(X.el, EW_MIDX) = __builtin_bit_cast(float, midx);
             const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
-            const float tf0 = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + 33], row1[1 + 33]);
-            const float tf1 = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + 34], row1[1 + 34]);
+            const float t0 = row0[0], t1 = row1[0];
+            DQ_ENVW(X.el, EW_T0) = t0;
+            DQ_ENVW(X.el, EW_T1) = t1;
+            DQ_ENVW(X.el, EW_DL) = es[DW_ES_DELAY_IDX];          // (int bits, moved as they are)
+            DQ_ENVW(X.el, EW_SL) = es[DW_ES_SIMUL_LEN];
+            const float tf0 = dw::cubic_t(ltp, t0, t1, row0[1 + 33], row1[1 + 33]);
+            const float tf1 = dw::cubic_t(ltp, t0, t1, row0[1 + 34], row1[1 + 34]);
             KP.midx = midx; KP.tf0 = tf0; KP.tf1 = tf1;
         }
         if (X.j == 1) {
@@ -122,40 +129,64 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
     // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps from one pass over the
     //      Gym tensors and the task record.  Kept per item in registers: the joint angle (integrated after each substep),
     //      the delayed leg torque of the second substep, the encoder reading of the first. ----
-    float qkeep[QNI], qdkeep[QNI], tau2[QNI], qnprev[QNI];
+    float qkeep[QNI], qdkeep[QNI], tau2[QNI], qnprev[QNI], dampk[QNI], ddk[QNI], kpk[QNI], kvk[QNI];
     float (&tgt)[QNI] = KP.tgt, (&qvk)[QNI] = KP.qv;
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
     const int simul_len0 = *reinterpret_cast<const int *>(&es[DW_ES_SIMUL_LEN]);
     (void)f;
+    // items of this lane, fixed for the kernel: slot position of each (owner lookup) kept in a register
+    int ipos[QNI];
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) ipos[k] = joint_item(L, wave_index, C.num_envs, X.lane, k).pos;
+    auto item = [&](int k) {
+        JointItem it;
+        const int i = X.lane + 64 * k;
+        it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
+        const int eg = wave_index * EPW + it.el;
+        it.ok = (i < EPW * ND) && (eg < C.num_envs);
+        if (!(i < EPW * ND)) { it.el = 0; it.d = 0; it.b = 1; }
+        it.env = eg < C.num_envs ? eg : C.num_envs - 1;
+        it.pos = ipos[k];
+        return it;
+    };
     DQ_STAMP(B, 0);
-    DQ_UNROLL for (int k = 0; k < QNI; ++k) {
-        const JointItem it = joint_item(L, wave_index, C.num_envs, X.lane, k);
-        const size_t g = (size_t)ND * it.env + it.d;
-        float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
-        const int d = it.d;
-        const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
-        const float damp = B.dof_damping[g], arm = B.dof_armature[g];
-        qkeep[k] = q; qdkeep[k] = qd;
-        qnprev[k] = ei[DW_ES_QPOS_PRE + d];
-        float tau;
-        // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
-        float target, atq = 0.0f;
-        {
-            const float ltp = DQ_ENVW(it.el, EW_LTP);
+    // In groups of three items: every request of the group first -- Gym state, record fields, mocap rows, gains; leg-only
+    // fields with the joint index clamped instead of a branch, which would end the run of requests -- then the arithmetic.
+    DQ_UNROLL for (int g3 = 0; g3 < QNI; g3 += 3) {
+        float rq[3], rqd[3], rdamp[3], rarm[3], rqpre[3], rm0[3], rm1[3], rms[3], rah[3], rac[3], rkp[3], rkv[3], rcol[3][DW_ALOG_SLOTS - 1];
+        DQ_UNROLL for (int u = 0; u < 3; ++u) {
+            const JointItem it = item(g3 + u);
+            const size_t g = (size_t)ND * it.env + it.d;
+            const float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
+            const int d = it.d, dc = d < 12 ? d : 11;
             const int midx = f2i(DQ_ENVW(it.el, EW_MIDX));
-            const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
-            target = dw::cubic_t(ltp, row0[0], row1[0], row0[1 + d], row1[1 + d]);
-            if (d < 12) atq = dw::clamp_action(actions, it.env, d) * ei[DW_ES_MOTOR_SCALE + d] * M.action_high[d];
+            const float *row0 = mocap + (size_t)midx * DW_MOCAP_COLS;
+            rq[u] = B.dof_state[g * 2]; rqd[u] = B.dof_state[g * 2 + 1];
+            rdamp[u] = B.dof_damping[g]; rarm[u] = B.dof_armature[g];
+            rqpre[u] = ei[DW_ES_QPOS_PRE + d];
+            rm0[u] = row0[1 + d]; rm1[u] = row0[DW_MOCAP_COLS + 1 + d];
+            rms[u] = ei[DW_ES_MOTOR_SCALE + dc]; rah[u] = M.action_high[dc];
+            rac[u] = actions[DW_NUM_ACT * it.env + dc];
+            rkp[u] = M.kp[d]; rkv[u] = M.kv[d];
+            DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) rcol[u][s] = ei[DW_ES_ACTION_LOG + 12 * (s + 1) + dc];
         }
-        tgt[k] = target;
-        KP.atq[k] = atq;
-        if (d < 12) {
+        DQ_UNROLL for (int u = 0; u < 3; ++u) {
+            const int k = g3 + u;
+            const JointItem it = item(k);
+            const int d = it.d;
+            const float q = rq[u], qd = rqd[u], damp = rdamp[u], arm = rarm[u];
+            qkeep[k] = q; qdkeep[k] = qd;
+            qnprev[k] = rqpre[u];
+            dampk[k] = damp; ddk[k] = arm + dt * damp; kpk[k] = rkp[u]; kvk[k] = rkv[u];
+            // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
+            const float target = dw::cubic_t(DQ_ENVW(it.el, EW_LTP), DQ_ENVW(it.el, EW_T0), DQ_ENVW(it.el, EW_T1), rm0[u], rm1[u]);
+            const float atq = d < 12 ? fminf(fmaxf(rac[u], -1.0f), 1.0f) * rms[u] * rah[u] : 0.0f;
+            tgt[k] = target;
+            KP.atq[k] = atq;
             // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
             // the two substeps (the action torque of the step is appended both times); the record gets the final column
-            const int dl = *reinterpret_cast<const int *>(&ei[DW_ES_DELAY_IDX]);
-            const int sl0 = *reinterpret_cast<const int *>(&ei[DW_ES_SIMUL_LEN]);
+            const int dl = f2i(DQ_ENVW(it.el, EW_DL)), sl0 = f2i(DQ_ENVW(it.el, EW_SL));
             float col[DW_ALOG_SLOTS + 1];
-            DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = ei[DW_ES_ACTION_LOG + 12 * (s + 1) + d];
+            DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = rcol[u][s];
             col[DW_ALOG_SLOTS - 1] = atq;
             col[DW_ALOG_SLOTS] = col[DW_ALOG_SLOTS - 1];
             int sl1 = sl0 + 1; if (sl1 > DW_ALOG_SLOTS) sl1 = DW_ALOG_SLOTS;
@@ -163,12 +194,11 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
             const int src1 = sl1 > dl ? dl : DW_ALOG_SLOTS - sl1, src2 = sl2 > dl ? dl : DW_ALOG_SLOTS - sl2;
             float t1 = col[0], t2 = col[1];
             DQ_UNROLL for (int s = 1; s < DW_ALOG_SLOTS; ++s) { t1 = (s == src1) ? col[s] : t1; t2 = (s == src2) ? col[s + 1] : t2; }
-            tau = t1; tau2[k] = t2;
-        } else {
-            tau = M.kp[d] * (target - q) + M.kv[d] * (-qd);
-            tau2[k] = target;          // the PD target: the second substep forms its own torque from the new state
+            // upper body: PD to the mocap target; the second substep forms its own torque from the new state
+            const float tau = d < 12 ? t1 : rkp[u] * (target - q) + rkv[u] * (-qd);
+            tau2[k] = d < 12 ? t2 : target;
+            if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, ddk[k]);
         }
-        if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
     }
     wave_sync();
 
@@ -176,29 +206,40 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
         X.stamp_base = 1 + 16 * sub;
         if (!C.freeze_physics) quad_substep<TERRAIN>(L, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
         wave_sync();
-        // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep ----
+        // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep: the
+        //      slot reads and the noise of all items first, then the arithmetic, then the stores ----
+        F4 fin[QNI];
+        float nzw[QNI];
+        DQ_UNROLL for (int k = 0; k < QNI; ++k) { const JointItem it = item(k); fin[k] = DQ_LD(it.b, 0, it.pos); }      // {qlo, qd, qhi, *}
+        if (noise) {
+            DQ_UNROLL for (int k = 0; k < QNI; ++k) { const JointItem it = item(k); nzw[k] = noise[(size_t)DW_NOISE_WORDS * it.env + DW_NZ_ENC + ND * sub + it.d]; }
+        } else {
+            DQ_UNROLL for (int k = 0; k < QNI; ++k) {
+                const JointItem it = item(k);
+                dw::NoiseSrc nz;
+                nz.rec = nullptr; nz.seed = C.seed; nz.env = (unsigned int)it.env; nz.step = (unsigned long long)step; nz.stream = 0;
+                nzw[k] = dw::noise_word(nz, DW_NZ_ENC + ND * sub + it.d);
+            }
+        }
         DQ_UNROLL for (int k = 0; k < QNI; ++k) {
-            const JointItem it = joint_item(L, wave_index, C.num_envs, X.lane, k);
+            const JointItem it = item(k);
             const size_t g = (size_t)ND * it.env + it.d;
             const int d = it.d;
             float q = qkeep[k], qd = 0.0f;
             if (!C.freeze_physics) {
-                joint_integrate(L, it, dt, qkeep[k], &q, &qd);
+                qd = fin[k].y; q = qkeep[k] + dt * qd;
+                if (q < fin[k].x) { q = fin[k].x; if (qd < 0) qd = 0; }
+                if (q > fin[k].z) { q = fin[k].z; if (qd > 0) qd = 0; }
                 qkeep[k] = q; qdkeep[k] = qd;
                 if (it.ok && sub == 1) { B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd; }
             }
-            dw::NoiseSrc nz;
-            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * it.env : nullptr;
-            nz.seed = C.seed; nz.env = (unsigned int)it.env; nz.step = (unsigned long long)step; nz.stream = 0;
-            const float n = dw::noise_word(nz, DW_NZ_ENC + ND * sub + d);
-            const float qn = q + fminf(fmaxf(n, -0.00016f), 0.00016f);
+            const float qn = q + fminf(fmaxf(nzw[k], -0.00016f), 0.00016f);
             const float qv = C.gpu_div ? (qn - qnprev[k]) * C.inv_dt_f : (qn - qnprev[k]) / dt;
             qnprev[k] = qn;
             qvk[k] = qv;
             if (sub == 0 && !C.freeze_physics) {
-                const float damp = B.dof_damping[g], arm = B.dof_armature[g];
-                const float tau = d < 12 ? tau2[k] : M.kp[d] * (tau2[k] - q) + M.kv[d] * (-qd);
-                if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
+                const float tau = d < 12 ? tau2[k] : kpk[k] * (tau2[k] - q) + kvk[k] * (-qd);
+                if (X.lane + 64 * k < EPW * ND) DQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - dampk[k] * qd, ddk[k]);
             }
         }
         wave_sync();

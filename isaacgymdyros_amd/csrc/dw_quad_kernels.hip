@@ -9,34 +9,38 @@
 
 // The whole VecTask.step of 16 envs per wavefront (grid = ceil(N / 16)): 4 lanes per env.  40 KB of LDS per wave: 4 waves
 // per CU, one per SIMD, so the whole register file (256 VGPRs + 256 AGPRs) belongs to the wave.
+// (DwBuffers travels BY VALUE: pointer members of a by-value kernel argument are known to be global addresses, whereas
+//  pointers loaded from a parameter block in memory are generic and every access through them is a FLAT instruction --
+//  counted on the LDS counter as well, so that each wait for an LDS read also waited for all global requests in flight.)
 template <bool TERRAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise,
-                    long long step) {
+void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
+                    const float *actions, const float *noise, long long step) {
     __shared__ dwq::QLds L;
-    dwq::quad_step<TERRAIN>(L, *QM, *M, P->C, P->B, actions, P->mocap, noise, step, (int)blockIdx.x);
+    dwq::quad_step<TERRAIN>(L, *QM, *M, P->C, B, actions, mocap, noise, step, (int)blockIdx.x);
 }
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_simulate_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const float *tau, const float *push) {
+void dw_k_simulate_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *tau,
+                        const float *push) {
     __shared__ dwq::QLds L;
-    dwq::quad_simulate<TERRAIN>(L, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, P->B, tau, push, (int)blockIdx.x);
+    dwq::quad_simulate<TERRAIN>(L, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, B, tau, push, (int)blockIdx.x);
 }
 
 namespace dwq {
 
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const float *actions, const float *noise, long long step) {
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step) {
     const dim3 grid((num_envs + EPW - 1) / EPW);
-    if (terrain) hipLaunchKernelGGL(dw_k_step_quad<true>, grid, dim3(64), 0, stream, QM, M, P, actions, noise, step);
-    else hipLaunchKernelGGL(dw_k_step_quad<false>, grid, dim3(64), 0, stream, QM, M, P, actions, noise, step);
+    if (terrain) hipLaunchKernelGGL(dw_k_step_quad<true>, grid, dim3(64), 0, stream, QM, M, P, B, mocap, actions, noise, step);
+    else hipLaunchKernelGGL(dw_k_step_quad<false>, grid, dim3(64), 0, stream, QM, M, P, B, mocap, actions, noise, step);
 }
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                     const float *tau, const float *push) {
+                     const DwBuffers &B, const float *tau, const float *push) {
     const dim3 grid((num_envs + EPW - 1) / EPW);
-    if (terrain) hipLaunchKernelGGL(dw_k_simulate_quad<true>, grid, dim3(64), 0, stream, QM, M, P, tau, push);
-    else hipLaunchKernelGGL(dw_k_simulate_quad<false>, grid, dim3(64), 0, stream, QM, M, P, tau, push);
+    if (terrain) hipLaunchKernelGGL(dw_k_simulate_quad<true>, grid, dim3(64), 0, stream, QM, M, P, B, tau, push);
+    else hipLaunchKernelGGL(dw_k_simulate_quad<false>, grid, dim3(64), 0, stream, QM, M, P, B, tau, push);
 }
 int build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err) {
     QuadModel *q = (QuadModel *)malloc(sizeof(QuadModel));
