@@ -24,7 +24,7 @@ for i in range(30 + K):
         d = {}
         tot = st[40] - st[0]
         if i == 30 + K - 1:
-            print("kernel total (wave 0): %d cycles" % tot)
+            print("kernel total (wave 0): %d cycles; before that, pre_physics_step up to the actuator pass: %d" % (tot, st[0] - st[54]))
             for sub in (0, 1):
                 base = 1 + 16 * sub
                 print("substep %d: prologue %d" % (sub, st[base + 0] - (st[0] if sub == 0 else st[1 + 14])))
