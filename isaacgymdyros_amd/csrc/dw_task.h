@@ -181,9 +181,8 @@ DW_HD bool finitef(float x) { return fabsf(x) <= 3.4028234663852886e38f; }   // 
 
 #define ESI(off) (*reinterpret_cast<int *>(&S.es[(off)]))
 
-// LDS block of the split task kernels (dw_k_pre / dw_k_post, one wave per env around the quad physics kernel): the task
-// record and the Gym state of one env, 3.6 KB, so the task logic runs at full occupancy instead of behind the 13.5 KB
-// physics block of the fused kernel.
+// LDS block of dw_k_reset (reset_idx of listed envs, one wave per env, both pipelines): the task record and the Gym state
+// of one env, 3.6 KB.
 struct alignas(16) TaskLds {
     float root[13];
     float q[ND], qd[ND];
@@ -194,11 +193,8 @@ struct alignas(16) TaskLds {
     float rterm[16];
     float scratch[8];
     int   flags[8];
-    float warm[24];              // unused by the split kernels (the physics kernel moves the warm start itself)
+    float warm[24];
 };
-// spare words of the task record carry the push force of the step from dw_k_pre to the physics kernel
-constexpr int ES_PUSH_X = DW_ES_WORDS - 2, ES_PUSH_Y = DW_ES_WORDS - 1;
-static_assert(DW_ES_EPISODES < ES_PUSH_X, "task record has no spare words for the push force");
 
 // ---------------------------------------------------------------------------------------------- load / store
 DW_HD void load_env_lane(int l, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {   // fused kernels
@@ -804,44 +800,6 @@ DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &
 
     task_post<true>(wave, S, M, C, T, e, K);
     store_env(wave, S, B, e, true, true);
-}
-
-// ---- the split pipeline: dw_k_pre (this), the quad physics kernel (dw_quad_kernels.h), dw_k_post ----
-template <class W>
-DW_HD void step_pre_env(const W &wave, TaskLds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
-    const DwBuffers &B = *T.b;
-    const StepCtx K = make_step_ctx(C, T, e);
-    wave.par([&](int l) {
-        for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
-        if (l < DW_NUM_ACT) S.act[l] = clamp_action(T.actions, e, l);
-        if (l == 33) S.flags[6] = gate_open(C, K);
-    });
-    task_p1p2<false>(wave, S, M, C, T, e, K);
-    wave.par([&](int l) {
-        if (l == 0) { S.es[ES_PUSH_X] = S.scratch[1]; S.es[ES_PUSH_Y] = S.scratch[2]; }
-    });
-    wave.par([&](int l) {
-        for (int i = l; i < DW_ES_WORDS; i += 64) B.env_state[(size_t)DW_ES_WORDS * e + i] = S.es[i];
-    });
-}
-
-template <class W>
-DW_HD void step_post_env(const W &wave, TaskLds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
-    const DwBuffers &B = *T.b;
-    const StepCtx K = make_step_ctx(C, T, e);
-    wave.par([&](int l) {
-        for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
-        if (l < 13) S.root[l] = B.root_states[13 * e + l];
-        if (l < ND) { S.q[l] = B.dof_state[(ND * e + l) * 2]; S.qd[l] = B.dof_state[(ND * e + l) * 2 + 1]; }
-        for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
-        if (l < 4) S.flags[l] = 0;
-        if (l == 34) load_counters(S, B, e);
-    });
-    wave.par([&](int l) {
-        if (l < DW_NUM_ACT) S.act[l] = S.es[DW_ES_ACTIONS + l];
-    });
-    const int state_changed = task_post<false>(wave, S, M, C, T, e, K);
-    store_env(wave, S, B, e, true, state_changed != 0);
 }
 
 // reset_done path (tasks/base/vec_task.py:376-391 -> reset_idx): one env
