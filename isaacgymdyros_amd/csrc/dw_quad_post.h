@@ -103,6 +103,17 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     const double cdt_d = K.cdt_d;
     const int LFG = M.left_foot_gym, RFG = M.right_foot_gym;
 
+    // (the VecTask counters and the clock action of Q1, the per-joint constants of the reset path and the observation's mean /
+    //  scale, requested together with the records: one memory latency for all.  The hot tables of the physics are dead by now:
+    //  the observation constants go where they were.)
+    const long long q1_progress = B.progress_buf[e], q1_randomize = B.randomize_buf[e];
+    const float q1_mass = B.total_mass[e], q1_clock = dw::clamp_action(actions, e, 12);
+    const int lj = lane < ND ? lane : 0, lo1 = lane < DW_NUM_OBS1 ? lane : 0;
+    const float c_qinit = M.q_init[lj], c_qhi = M.qhi[lj], c_qlo = M.qlo[lj], c_damp = M.damp_nom[lj], c_arm = M.arm_nom[lj];
+    const float c_org0 = B.env_origins[3 * e], c_org1 = B.env_origins[3 * e + 1], c_org2 = B.env_origins[3 * e + 2];
+    float *OBN = reinterpret_cast<float *>(&L.hot);            // [2][37] mean, divisor
+    static_assert(sizeof(QHot) >= 2 * DW_NUM_OBS1 * sizeof(float), "observation constants do not fit the hot-table area");
+    const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
     // ---- stage: joint state, base state, contact summary, the 16 task records ----
     DQ_UNROLL for (int k = 0; k < QNI; ++k) {
         const int i = lane + 64 * k;
@@ -111,10 +122,8 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     if (j == 0) {
         DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = X.root[i];
         PQ_PSI(el, PS_BAD) = 0; PQ_PSI(el, PS_COLL) = 0; PQ_PSI(el, PS_RESET) = 0;
+        PQ_PS(el, PS_ORG) = c_org0; PQ_PS(el, PS_ORG + 1) = c_org1; PQ_PS(el, PS_ORG + 2) = c_org2;
     }
-    // (the VecTask counters and the clock action of Q1, requested together with the records: one memory latency for all)
-    const long long q1_progress = B.progress_buf[e], q1_randomize = B.randomize_buf[e];
-    const float q1_mass = B.total_mass[e], q1_clock = dw::clamp_action(actions, e, 12);
     {
         // 16 records = 1488 pieces of 16 bytes, contiguous in HBM and in LDS: every lane requests its 24 pieces before the
         // first one is stored (one memory latency for the lot)
@@ -137,6 +146,7 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
             DQ_UNROLL for (int u = 0; u < GRP; ++u) { const int pi = lane + 64 * (g8 + u); if (pi < NP) dst[pi] = mk4(tx[u], ty[u], tz[u], tw[u]); }
         }
     }
+    if (lane < DW_NUM_OBS1) { OBN[lane] = c_om; OBN[DW_NUM_OBS1 + lane] = c_od; }
     wave_sync();
     // ---- the record fields this step has produced so far (dw_task.h P1..P3), from the lanes that hold them ----
     if (j == 0) {
@@ -361,7 +371,7 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     if (any_reset) {
         const bool mine = PQ_PSI(el, PS_RESET) != 0;
         if (C.terrain_curriculum && j == 0 && mine) {
-            const float d[2] = {PQ_ROOT(el, 0) - B.env_origins[3 * e], PQ_ROOT(el, 1) - B.env_origins[3 * e + 1]};
+            const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
             const float distance = dw::norm_t(d, 2);
             const bool move_up = distance > C.terrain_half_length;
             const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
@@ -393,13 +403,13 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
                     const float ud = dw::noise_word(nz, DW_NZ_DR_DAMP + l), ua = dw::noise_word(nz, DW_NZ_DR_ARM + l);
                     const float sd = C.dr_damp[0] + ud * (C.dr_damp[1] - C.dr_damp[0]);
                     const float sa = C.dr_arm[0] + ua * (C.dr_arm[1] - C.dr_arm[0]);
-                    if (egr < N) { B.dof_damping[(size_t)ND * eg + l] = M.damp_nom[l] + sd; B.dof_armature[(size_t)ND * eg + l] = M.arm_nom[l] * sa; }
+                    if (egr < N) { B.dof_damping[(size_t)ND * eg + l] = c_damp + sd; B.dof_armature[(size_t)ND * eg + l] = c_arm * sa; }
                 }
-                PQ_ES(ee, DW_ES_QPOS_NOISE + l) = M.q_init[l];
-                PQ_ES(ee, DW_ES_QPOS_PRE + l) = M.q_init[l];
+                PQ_ES(ee, DW_ES_QPOS_NOISE + l) = c_qinit;
+                PQ_ES(ee, DW_ES_QPOS_PRE + l) = c_qinit;
                 PQ_ES(ee, DW_ES_QVEL_NOISE + l) = 0.0f;
                 PQ_ES(ee, DW_ES_PRE_QVEL + l) = 0.0f;
-                PQ_Q(ee, l) = fmaxf(fminf(M.q_init[l], M.qhi[l]), M.qlo[l]);
+                PQ_Q(ee, l) = fmaxf(fminf(c_qinit, c_qhi), c_qlo);
                 PQ_QD(ee, l) = 0.0f;
                 if (l < 12) {
                     PQ_ES(ee, DW_ES_QPOS_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QPOS_BIAS + l) * 6.28f, 100.0) - (float)(3.14 / 100);
@@ -412,7 +422,7 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
                 if (l >= 16 && l < 29) {
                     const int ii = l - 16;
                     float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
-                    if (ii < 3) v += C.terrain_curriculum ? PQ_PS(ee, PS_ORG + ii) : B.env_origins[3 * eg + ii];
+                    if (ii < 3) v += PQ_PS(ee, PS_ORG + ii);          // (the env's origin; the curriculum has put the new one there)
                     if (ii < 2 && C.custom_origins) v += 2.0f * dw::noise_word(nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
                     PQ_ROOT(ee, ii) = v;
                 }
@@ -476,7 +486,7 @@ DQ_HD void quad_task_post(QLds &L, const DevModel &M, const TaskParams &C, const
     {
         auto finish = [&](int ee, int l, float o) {
             const int egr = wave_index * EPW + ee;
-            const float nrm = (o - M.obs_mean[l]) / M.obs_inv_std_den[l];
+            const float nrm = (o - OBN[l]) / OBN[DW_NUM_OBS1 + l];
             PQ_NORMED(ee, l) = nrm;
             if (egr < N) {
                 float *oh = B.obs_history + (size_t)egr * DW_HIST_SLOTS * DW_NUM_OBS1;
