@@ -82,6 +82,9 @@ struct QLane {
     int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
     float footT[3];                          // last substep: net contact force on my sole body (lanes 0, 1)
     int   stamp_base;                        // profiling builds only
+    // second (welded) inertial record of my sole body and its mass scale, fetched once per kernel (quad_lane_second_inertial):
+    // read where the inward pass needs them they cost two dependent memory round trips per substep
+    float in1[10], ms1;                      // com[3], mass, I[6]
 };
 
 // sin and cos for |x| up to a few turns (joint half-angles): Cody-Waite reduction to [-pi/4, pi/4], the classic single-
@@ -636,9 +639,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             {
                 const float com0[3] = {h1.x, h1.y, h1.z}, I0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
                 if (nin > 1) {          // the two sole bodies carry a second (welded) inertial record
-                    const QInRec &rc = QM.in[s][j];
-                    const float ms1 = mscale_e[rc.in1_gym];
-                    rigid_inertia(2, com0, h1.w, I0, ms0, rc.in1_com, rc.in1_mass, rc.in1_I, ms1, R, x, Ao, ho, &mass);
+                    rigid_inertia(2, com0, h1.w, I0, ms0, &X.in1[0], X.in1[3], &X.in1[4], X.ms1, R, x, Ao, ho, &mass);
                 } else {
                     rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Ao, ho, &mass);
                 }
@@ -1212,6 +1213,18 @@ DQ_HD void quad_lane_init(QLane &X, int wave_index, int num_envs, const PhysPara
     (void)P;
 }
 
+// after stage_hot: the lane's step with two inertial records (the sole bodies; at most one per lane)
+DQ_HD void quad_lane_second_inertial(QLane &X, const QLds &L, const QuadModel &QM, const DwBuffers &B) {
+    int s2 = 0;
+    DQ_UNROLL for (int s = 0; s < QS_MAX; ++s) if (s < L.hot.misc[0] && ((f2i(L.hot.in[s][X.j][0]) >> 12) & 3) > 1) s2 = s;
+    const QInRec &rc = QM.in[s2][X.j];
+    DQ_UNROLL for (int i = 0; i < 3; ++i) X.in1[i] = rc.in1_com[i];
+    X.in1[3] = rc.in1_mass;
+    DQ_UNROLL for (int i = 0; i < 6; ++i) X.in1[4 + i] = rc.in1_I[i];
+    const int g1 = rc.in1_gym;
+    X.ms1 = B.mass_scale[(size_t)DW_NUM_BODIES * X.env + (g1 >= 0 && g1 < DW_NUM_BODIES ? g1 : 0)];
+}
+
 // ---- joint-parallel phases.  Per-joint work that touches the Gym tensors runs over ITEMS (env, dof) = lane + 64 k of the
 // wave's 16 x 33 joints, so that a wave-instruction reads or writes consecutive addresses (the limb-per-lane mapping would
 // touch 64 different rows with 4-byte accesses); the item's lane reaches the owner's slot through the owner table. ----
@@ -1244,6 +1257,7 @@ DQ_HD void quad_simulate(QLds &L, const QuadModel &QM, const DevModel &M, const 
     QLane X;
     quad_lane_init(X, wave_index, num_envs, P, friction, B);
     stage_hot(L, QM);
+    quad_lane_second_inertial(X, L, QM, B);
     const int e = X.env, f = X.j & 1;
     if (B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i]; }
     float qkeep[QNI];
