@@ -650,6 +650,9 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
             DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
             bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
             if (TERRAIN) near_ground = ngeom > 0;
+#if defined(DQ_KO_GEOM)          // (timing experiment only)
+            near_ground = false;
+#endif
             if (near_ground) {
                 const QInRec &rc = QM.in[s][j];
                 for (int k = 0; k < ngeom; ++k) {
