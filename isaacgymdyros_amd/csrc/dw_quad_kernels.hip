@@ -17,6 +17,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
                     const float *actions, const float *noise, long long step) {
     __shared__ dwq::QLds L;
+#if defined(DQ_STAGGER)
+#ifndef DQ_STAGGER_MULT
+#define DQ_STAGGER_MULT 1
+#endif
+          // (timing experiment: de-phase the waves' memory bursts; DQ_STAGGER = groups, DQ_STAGGER_SLEEP = s_sleep units)
+    for (int i = 0; i < (int)(blockIdx.x % DQ_STAGGER) * DQ_STAGGER_MULT; ++i) __builtin_amdgcn_s_sleep(DQ_STAGGER_SLEEP);
+#endif
     dwq::quad_step<TERRAIN>(L, *QM, *M, P->C, B, actions, mocap, noise, step, (int)blockIdx.x);
 }
 // One physics substep at the Gym boundary, same layout.
