@@ -239,6 +239,14 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     names = list(env.extras.get("reward_names", []))
     obs = env.reset()["obs"].clone()
     dones = torch.zeros(N, device=device)
+    if str(device).startswith("cuda"):
+        # one untimed policy + env step: the first use of every torch kernel in the loop loads its code object, which on a
+        # fresh process costs tens of milliseconds and would otherwise be booked as env-step time of the first epoch
+        with torch.no_grad():
+            mu, logstd, _ = net(obs)
+            a = torch.distributions.Normal(mu, torch.exp(logstd)).sample()
+            obs = env.step(torch.clamp(a, -1.0, 1.0))[0]["obs"].clone()
+        torch.cuda.synchronize()
     mb = dict(obs=torch.zeros(H, N, env.num_obs, device=device), act=torch.zeros(H, N, env.num_acts, device=device),
               neglogp=torch.zeros(H, N, device=device), val=torch.zeros(H, N, 1, device=device), rew=torch.zeros(H, N, 1, device=device),
               done=torch.zeros(H, N, device=device), mu=torch.zeros(H, N, env.num_acts, device=device))
