@@ -218,6 +218,8 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
     }
     wave_sync();
 
+    float nzw1[QNI];          // the second substep's encoder draws (generated with the first's)
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) nzw1[k] = 0.0f;
     for (int sub = 0; sub < 2; ++sub) {
         X.stamp_base = 1 + 16 * sub;
         if (!C.freeze_physics) quad_substep<TERRAIN>(L, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
@@ -229,13 +231,15 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
         DQ_UNROLL for (int k = 0; k < QNI; ++k) { const JointItem it = item(k); fin[k] = DQ_LD(it.b, 0, ipos[k]); }      // {qlo, qd, qhi, *}
         if (noise) {
             DQ_UNROLL for (int k = 0; k < QNI; ++k) { const JointItem it = item(k); nzw[k] = noise[(size_t)DW_NOISE_WORDS * it.env + DW_NZ_ENC + ND * sub + it.d]; }
-        } else {
+        } else if (sub == 0) {          // one generator call per joint gives the draws of both substeps
             DQ_UNROLL for (int k = 0; k < QNI; ++k) {
                 const JointItem it = item(k);
                 dw::NoiseSrc nz;
                 nz.rec = nullptr; nz.seed = C.seed; nz.env = (unsigned int)it.env; nz.step = (unsigned long long)step; nz.stream = 0;
-                nzw[k] = dw::noise_word(nz, DW_NZ_ENC + ND * sub + it.d);
+                dw::noise_enc_pair(nz, it.d, &nzw[k], &nzw1[k]);
             }
+        } else {
+            DQ_UNROLL for (int k = 0; k < QNI; ++k) nzw[k] = nzw1[k];
         }
         DQ_UNROLL for (int k = 0; k < QNI; ++k) {
             const JointItem it = item(k);

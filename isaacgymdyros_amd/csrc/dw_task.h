@@ -90,24 +90,35 @@ struct NoiseSrc {
     unsigned int stream;
 };
 
+// Box-Muller normal of the encoder model from two Philox outputs (oracle/dw_task.c noise_word)
+DW_HD float enc_normal(unsigned int a, unsigned int b) {
+    const float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-08f;
+    const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;
+#if defined(__HIPCC__)
+    // the hardware log2 / cos (arguments in (0, 1] and [0, 2 pi)): relative error ~1e-6 of a 5e-5 rad draw, against ~250
+    // instructions of libm range reduction per draw and 66 draws per env-step
+    const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+#else
+    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+#endif
+    return z * (float)(0.00016 / 3.0);
+}
 DW_HD float noise_word(const NoiseSrc &nz, int w) {
     if (nz.rec) return nz.rec[w];
-    unsigned int c[4] = {(unsigned int)w, nz.env, (unsigned int)nz.step,
+    // the two encoder draws of a joint (one per substep) share one Philox block: outputs 0,1 and 2,3
+    const int pair = (w < DW_NZ_VEL && w >= DW_NZ_ENC + DW_NUM_DOF) ? 1 : 0;
+    unsigned int c[4] = {(unsigned int)(pair ? w - DW_NUM_DOF : w), nz.env, (unsigned int)nz.step,
                          (unsigned int)(nz.step >> 32) | (nz.stream << 31)};
     philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));
-    if (w < DW_NZ_VEL) {
-        const float u1 = (float)((c[0] >> 8) + 1u) * 5.9604644775390625e-08f;
-        const float u2 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;
-#if defined(__HIPCC__)
-        // the hardware log2 / cos (arguments in (0, 1] and [0, 2 pi)): relative error ~1e-6 of a 5e-5 rad draw, against ~250
-        // instructions of libm range reduction per draw and 66 draws per env-step
-        const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
-#else
-        const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-#endif
-        return z * (float)(0.00016 / 3.0);
-    }
+    if (w < DW_NZ_VEL) return pair ? enc_normal(c[2], c[3]) : enc_normal(c[0], c[1]);
     return (float)(c[0] >> 8) * 5.9604644775390625e-08f;
+}
+// both encoder draws of joint d in one generator call (the quad kernels keep the second for the second substep)
+DW_HD void noise_enc_pair(const NoiseSrc &nz, int d, float *z0, float *z1) {
+    unsigned int c[4] = {(unsigned int)(DW_NZ_ENC + d), nz.env, (unsigned int)nz.step, (unsigned int)(nz.step >> 32) | (nz.stream << 31)};
+    philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));
+    *z0 = enc_normal(c[0], c[1]);
+    *z1 = enc_normal(c[2], c[3]);
 }
 
 // ---------------------------------------------------------------------------------------------- torch-flavoured scalars

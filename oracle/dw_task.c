@@ -49,11 +49,15 @@ typedef struct {
 
 static float noise_word(const Noise *nz, int w) {
     if (nz->rec) return nz->rec[w];
-    uint32_t c[4] = {(uint32_t)w, nz->env, (uint32_t)nz->step, (uint32_t)(nz->step >> 32) | (nz->stream << 31)};
+    /* The two encoder draws of a joint (one per substep) share ONE Philox block: counter word = the joint's word of the
+     * first substep, outputs 0,1 for the first substep and 2,3 for the second (half the generator calls of the hot path). */
+    const int pair = (w < DW_NZ_VEL && w >= DW_NZ_ENC + DW_NUM_DOF) ? 1 : 0;
+    const int cw = pair ? w - DW_NUM_DOF : w;
+    uint32_t c[4] = {(uint32_t)cw, nz->env, (uint32_t)nz->step, (uint32_t)(nz->step >> 32) | (nz->stream << 31)};
     philox4x32_10(c, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32));
     if (w < DW_NZ_VEL) {   /* encoder noise ~ N(0, 0.00016/3): Box-Muller */
-        float u1 = (float)((c[0] >> 8) + 1u) * 5.9604644775390625e-08f;   /* (0,1] */
-        float u2 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;          /* [0,1) */
+        float u1 = (float)((c[2 * pair] >> 8) + 1u) * 5.9604644775390625e-08f;   /* (0,1] */
+        float u2 = (float)(c[2 * pair + 1] >> 8) * 5.9604644775390625e-08f;      /* [0,1) */
         float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
         return z * (float)(0.00016 / 3.0);
     }
