@@ -6,8 +6,9 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p isaacgymdyros_amd/_ab
-F="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fno-strict-aliasing -fno-slp-vectorize"
-[ -f isaacgymdyros_amd/_ab/base_a.o ] || hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp -c -o isaacgymdyros_amd/_ab/base_a.o isaacgymdyros_amd/csrc/dw_hip.hip
-hipcc $F "$@" -c -o isaacgymdyros_amd/_ab/${NAME}_b.o isaacgymdyros_amd/csrc/dw_quad_kernels.hip
+F="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fno-strict-aliasing"
+SLP=${DW_AB_SLP:--fno-slp-vectorize}
+[ -f isaacgymdyros_amd/_ab/base_a.o ] || hipcc $F -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -c -o isaacgymdyros_amd/_ab/base_a.o isaacgymdyros_amd/csrc/dw_hip.hip
+hipcc $F $SLP "$@" -Rpass-analysis=kernel-resource-usage -c -o isaacgymdyros_amd/_ab/${NAME}_b.o isaacgymdyros_amd/csrc/dw_quad_kernels.hip
 hipcc --offload-arch=gfx950 -shared -fPIC -o isaacgymdyros_amd/_ab/${NAME}.so isaacgymdyros_amd/_ab/base_a.o isaacgymdyros_amd/_ab/${NAME}_b.o
 echo isaacgymdyros_amd/_ab/${NAME}.so
