@@ -35,6 +35,9 @@ template <bool TERRAIN>
 DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     DQ_STAMP(B, 54);
+#if defined(DQ_WAVE_TIME) && defined(__HIPCC__)          // (timing experiment: the life of every wave, tools/wave_times.py)
+    const long long dq_t0 = (long long)__builtin_readcyclecounter();
+#endif
     // ==== round 1 of requests: everything whose address is known at entry -- the base state, the scalars of the record the
     //      pre-physics phase reads, the actions, the inputs of the actuator model for this lane's nine (env, joint) items,
     //      the hot tables -- in one straight run, so that the wave waits for memory once.  (Each request a lone wave waits
@@ -277,8 +280,17 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
         X.coll = c > 0.0f;
     }
     wave_sync();
+#if defined(DQ_WAVE_TIME) && defined(__HIPCC__)
+    const long long dq_t1 = (long long)__builtin_readcyclecounter();
+#endif
     quad_task_post<TERRAIN>(L, M, C, B, actions, noise, step, wave_index, X, qkeep, qdkeep, KP);
     DQ_STAMP(B, 41);
+#if defined(DQ_WAVE_TIME) && defined(__HIPCC__)
+    if (X.lane == 0) {
+        B.stacked_rewards[(size_t)wave_index * EPW * DW_NUM_REW + 14] = (float)((long long)__builtin_readcyclecounter() - dq_t0);
+        B.stacked_rewards[(size_t)wave_index * EPW * DW_NUM_REW + 13] = (float)(dq_t1 - dq_t0);          // physics part
+    }
+#endif
 }
 
 }  // namespace dwq
