@@ -32,6 +32,12 @@ def test_bare_invocation_spawns_two_ranks_and_relays_one_line():
     assert out["episodes"]["envs_with_episode"] == 32          # the all-gather saw both ranks' blocks
     assert abs(out["episodes"]["mean_episode_length"] - 1.5) < 1e-9     # rank 0 wrote 1.0, rank 1 wrote 2.0
     assert out["value"] > 0 and abs(out["value"] - 32 * 6 / (out["ms_per_step"] * 6e-3)) / out["value"] < 1e-6
+    # the contract's two roofline objects are always there (numbers mean nothing on the plumbing env)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} <= set(out["roofline"])
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0 and out["roofline"]["unit"] == "GB/s"
+    assert {"bound", "achieved", "peak", "frac", "useful_flops_per_env_step", "lane_slots_per_env_step"} <= set(out["roofline_valu"])
+    assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["dtype"] == "f32"
+    assert out["higher_is_better"] is True and out["vs_baseline"] is None
 
 
 def test_single_rank_needs_no_launcher():
