@@ -184,9 +184,9 @@ typedef struct DwConfig {
     float   terrain_env_length;         /* terrain_length [m]: walked more than half of it => level up */
     float   max_episode_length_s;       /* env.episodeLength as the curriculum uses it (:34, :685)    */
     int32_t custom_origins;             /* 1 = reset adds U(-1,1) m of xy jitter to the origin (:729-732) */
-    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate: 0 = default (2), 1 = the fused wave-per-env
-                                           kernel (one wavefront per env), 2 = the split pipeline around the quad physics
-                                           kernel (4 lanes per env, 16 envs per wavefront) */
+    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate: 0 = default (2), 1 = the wave-per-env
+                                           kernels of round 1 (one wavefront per env), 2 = the quad kernels (4 lanes per
+                                           env, 16 envs per wavefront, one launch per policy step) */
 } DwConfig;
 
 /* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of

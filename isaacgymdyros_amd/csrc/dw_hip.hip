@@ -1,9 +1,11 @@
 // dw_hip.hip -- gfx950 kernels and the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so).
 //
-// One workgroup = one wavefront = one environment.  The kernel bodies live in dw_task.h / dw_physics.h as
-// wave regions over a 13.5 KB LDS block per env (12 envs resident per CU); this file only declares
-// the __global__ entry points, owns the read-only model/mocap tables in device memory and validates
-// arguments.  Nothing here allocates, synchronises or copies per call (graph-capture safe).
+// Two kernel generations sit behind the C-ABI (DwConfig.pipeline).  The default is the quad generation (4 lanes per env,
+// 16 envs per wavefront: dw_quad*.h, entry points in dw_quad_kernels.hip, launched from here).  This file also holds the
+// wave-per-env generation of round 1 (one workgroup = one wavefront = one environment; bodies in dw_task.h / dw_physics.h as
+// wave regions over a 13.5 KB LDS block per env) and dw_k_reset, which both use for reset_idx.  It owns the read-only
+// model / mocap tables in device memory and validates arguments.  Nothing here allocates, synchronises or copies per call
+// (graph-capture safe).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -135,7 +135,7 @@ class DyrosDynamicWalk(VecTask):
         c.self_collision = int(bool(mi.get("self_collision", True)))
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
-        # which kernels: 0/2 = split pipeline around the quad physics kernel (default), 1 = fused wave-per-env kernel
+        # which kernels: 0/2 = quad kernels, 4 lanes per env, one launch per step (default), 1 = wave-per-env kernels of round 1
         c.pipeline = {"auto": 0, "fused": 1, "quad": 2}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
         tc = self.terrain_cfg
         c.terrain = int(self.custom_origins)
