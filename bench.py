@@ -70,13 +70,10 @@ def _launch_ranks(args, argv) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves as fresh child processes
     (the reference maps rank -> device itself, utils/rlgames_utils.py:71-81).  This parent never imports torch.cuda nor
     touches the GPU, so nothing is re-exec'ed from a process that has initialised HIP; rank 0's JSON line is relayed."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: torchrun's own c10d rendezvous picks the port (no bind-close-reuse race on a port chosen here)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
@@ -134,6 +131,8 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(_launch_ranks(args, sys.argv[1:]))
+    if env_world is not None and "--gpus" not in " ".join(sys.argv[1:]):
+        args.gpus = int(env_world)          # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world counts
     if env_world is not None and int(env_world) != args.gpus:
         print("bench.py: --gpus %d contradicts WORLD_SIZE=%s" % (args.gpus, env_world), file=sys.stderr)
         sys.exit(2)

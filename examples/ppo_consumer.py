@@ -213,6 +213,11 @@ def allreduce_grads(params, world: int, group=None):
         o += n
 
 
+def _sync(device):
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ the loop
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
           rank=0, world=1, seed=42):
@@ -231,6 +236,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     N = env.num_envs
     torch.manual_seed(seed)                          # same initial weights on every rank
     net = DyrosActorCritic(env.num_obs, env.num_acts, cfg["network"]).to(device)
+    torch.manual_seed(seed + 7919 * rank)            # ... but its own exploration noise (Normal.sample draws from the global generator)
     opt_a = torch.optim.Adam(net.actor_parameters(), lr=c["learning_rate"], eps=1e-8)
     opt_c = torch.optim.Adam(net.critic_parameters(), lr=c["critic_lr"], eps=1e-8)
     sched = LinearLR(c["learning_rate"], c["learning_rate_min"], max_epochs)
@@ -269,9 +275,9 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 a = torch.distributions.Normal(mu, sigma).sample()
                 mb["obs"][n], mb["act"][n], mb["mu"][n] = obs, a, mu
                 mb["neglogp"][n], mb["val"][n], mb["done"][n] = neglogp(a, mu, sigma, logstd), value, dones
-                torch.cuda.synchronize(); ts = time.perf_counter()
+                _sync(device); ts = time.perf_counter()
                 o, r, d, infos = env.step(torch.clamp(a, -1.0, 1.0))            # clip_actions (:467-478)
-                torch.cuda.synchronize(); step_time += time.perf_counter() - ts
+                _sync(device); step_time += time.perf_counter() - ts
                 r = r.unsqueeze(1) * c["reward_scale"]
                 if c["value_bootstrap"] and "time_outs" in infos:               # :656-659
                     r = r + c["gamma"] * value * infos["time_outs"].unsqueeze(1).float()
@@ -308,14 +314,17 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 for p in net.parameters():
                     p.grad = None
                 scaler.scale(loss).backward()
-                scaler.unscale_(opt_a); scaler.unscale_(opt_c)
+                # synchronise first, unscale after (a2c_continuous_seperate.py:171-175): the still-scaled gradients are averaged
+                # (the loss scale is the same on every rank), so an overflow on one rank reaches every rank through the sum,
+                # every rank's unscale_ finds it, every rank skips the step and backs its scale off alike
                 allreduce_grads(net.actor_parameters() + net.critic_parameters(), world)
+                scaler.unscale_(opt_a); scaler.unscale_(opt_c)
                 if c["truncate_grads"]:
                     nn.utils.clip_grad_norm_(net.actor_parameters(), c["grad_norm"])       # the actor only (:178)
                 scaler.step(opt_a); scaler.step(opt_c); scaler.update()
                 with torch.no_grad():
                     kl = policy_kl(mu.detach().float(), sigma.detach().float(), B["mu"][s], torch.exp(net.sigma).expand_as(mu))
-        torch.cuda.synchronize()
+        _sync(device)
         total = time.perf_counter() - t0
         fin = env.episodes_finished > 0
         s = dict(epoch=ep, step_fps=H * N / step_time, play_fps=H * N / play_time, total_fps=H * N / total,

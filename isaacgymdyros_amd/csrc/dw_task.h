@@ -820,7 +820,10 @@ DW_HD void reset_only_env(const W &wave, LT &S, const DevModel &M, const TaskPar
     NoiseSrc nz;
     nz.rec = T.noise ? T.noise + (size_t)DW_NOISE_WORDS * e : nullptr;
     nz.seed = C.seed; nz.env = (unsigned int)e; nz.step = (unsigned long long)T.step; nz.stream = 1;
-    wave.par([&](int l) {        // reset_region rewrites root, q and qd completely; it needs the record and the contact forces
+    // reset_region rewrites root, q and qd, but with the terrain curriculum it first reads root[0..1] (the distance walked
+    // from the tile origin decides the level change): the base state is loaded too, next to the record and the contact forces
+    wave.par([&](int l) {
+        if (l < 13) S.root[l] = B.root_states[13 * e + l];
         for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
         for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
         if (l == 40) {

@@ -93,6 +93,7 @@ int dwe_reset_idx(DwHandle *h, const int32_t *ids, int32_t n, const float *noise
     dw::Wave w;
     for (int i = 0; i < n; ++i) {
         if (ids[i] < 0 || ids[i] >= h->cfg.num_envs) { delete S; return fail(DW_EINVAL, "env id out of range"); }
+        memset((void *)S, 0xff, sizeof(*S));      // NaN-fill per id: nothing may be read that this call did not load
         dw::reset_only_env(w, *S, h->model, h->params, T, ids[i]);
     }
     delete S;

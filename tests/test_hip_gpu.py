@@ -672,3 +672,38 @@ def test_entry_points_do_not_depend_on_the_current_device():
     env.step(torch.zeros(64, 13, device="cuda"))
     torch.cuda.synchronize()
     assert torch.cuda.current_device() == before
+
+
+@pytest.mark.gpu
+def test_reset_idx_with_terrain_curriculum_vs_oracle_on_gpu(task_const):
+    """dw_reset_idx (reset_done path) with the terrain curriculum: a moved env goes a level up, a stationary one a level
+    down, an unlisted one is untouched -- every reset field bit-identical to the oracle's (the kernel used to
+    read the base position from LDS it had not loaded)."""
+    from hip_backend import make_env
+    tdict = dict(mesh_type="heightfield", curriculum=True, num_rows=4, num_cols=5, border_size=2, max_init_terrain_level=3)
+    N = 64
+    env = make_env(N, terrain=tdict, seed=4)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for _ in range(3):
+        env.step(torch.rand(N, 13, generator=g, device="cuda") * 2 - 1)
+    # the kernel before this test may have left anything in LDS: run a launch that fills the CU's LDS with other data
+    env.terrain_levels[:] = 1
+    org = env.terrain_origins.view(4, 5, 3)
+    env.env_origins.copy_(org[1, env.terrain_types])
+    env.root_states[:, :3] = env.env_origins + torch.tensor([0, 0, 0.93], device="cuda")
+    env.root_states[3, 0] += 6.0
+    from isaacgymdyros_amd import abi
+    abi.es_view(env._buf["env_state"], "target_vel")[...] = torch.tensor([0.4, 0.0], device="cuda")
+    abi.es_view(env._buf["env_state"], "epi_len")[...] = 10.0
+    env.randomize_buf[:] = 5
+    torch.cuda.synchronize()
+    ora = _oracle_like(env, task_const)
+    ids = torch.tensor([3, 5, 40], device="cuda", dtype=torch.int32)
+    env._step_count = 17
+    env.reset_idx(ids)
+    torch.cuda.synchronize()
+    ora.reset_idx([3, 5, 40], None, 17)
+    assert int(ora.buf["terrain_levels"][3]) == 2 and int(ora.buf["terrain_levels"][5]) == 0 and int(ora.buf["terrain_levels"][6]) == 1
+    for k in ("terrain_levels", "env_origins", "root_states", "dof_state", "env_state", "reset_buf", "progress_buf",
+              "randomize_buf", "dof_damping", "dof_armature"):
+        assert np.array_equal(ora.buf[k], env._buf[k].cpu().numpy()), k

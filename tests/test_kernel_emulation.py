@@ -203,3 +203,41 @@ def test_arms_into_torso_vs_oracle(quad):
     assert np.abs(ca - cb).max() <= 1e-3 * np.abs(ca).max()
     assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 0].max() < 1e-5
     assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 1].max() < 2e-2
+
+
+def _terrain_reset_case(sim, g):
+    """All envs at level 1 of the golden's curriculum map; env 3 has walked 6 m from its tile origin (level up), env 5 has
+    not moved (level down), env 6 is not in the id list.  Returns the buffers after reset_idx([3, 5])."""
+    N = sim.N
+    for k, v in g.items():
+        if k.startswith("init_") and k[5:] in sim.buf and sim.buf[k[5:]].shape == v.shape:
+            sim.buf[k[5:]][...] = v
+    types = sim.buf["terrain_types"]
+    sim.buf["terrain_levels"][:] = 1
+    org = sim.buf["terrain_origins"].reshape(int(g["cfg_terrain_num_levels"]), int(g["cfg_terrain_num_types"]), 3)
+    for e in range(N):
+        sim.buf["env_origins"][e] = org[1, int(types[e])]
+        sim.buf["root_states"][e, :3] = sim.buf["env_origins"][e] + np.array([0, 0, 0.93], dtype=np.float32)
+    sim.buf["root_states"][3, 0] += 6.0
+    from isaacgymdyros_amd import abi
+    abi.es_view(sim.buf["env_state"], "target_vel")[...] = np.array([0.4, 0.0], dtype=np.float32)
+    abi.es_view(sim.buf["env_state"], "epi_len")[...] = 10.0
+    sim.buf["randomize_buf"][:] = 5
+    sim.reset_idx([3, 5], None, 17)
+    return {k: np.array(v, copy=True) for k, v in sim.buf.items()}
+
+
+def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, quad):
+    """the reset_done path read the base position from uninitialised LDS when the curriculum decided the
+    level change.  A moved env, a stationary env and an untouched env, several ids in one call, against the oracle; the
+    emulation NaN-fills its LDS block per id, so stale contents cannot pass."""
+    g = R.load("terrain_logic_frozen.npz")
+    N = int(g["N"])
+    kw = dict(terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]), torch_gpu_div=1)
+    ora = _terrain_reset_case(OracleSim(N, task_const=task_const, **kw), g)
+    emu = _terrain_reset_case(EmulSim(N, task_const=task_const, quad=quad, **kw), g)
+    assert int(ora["terrain_levels"][3]) == 2 and int(ora["terrain_levels"][5]) == 0 and int(ora["terrain_levels"][6]) == 1
+    for k in ("terrain_levels", "env_origins", "root_states", "dof_state", "env_state", "reset_buf", "progress_buf",
+              "randomize_buf", "dof_damping", "dof_armature"):
+        assert np.array_equal(ora[k], emu[k]), k
+    assert np.isfinite(emu["root_states"]).all() and np.isfinite(emu["env_state"]).all()

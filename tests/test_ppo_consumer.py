@@ -130,3 +130,59 @@ dist.barrier(); dist.destroy_process_group()
     for r in range(2):
         o = json.load(open(tmp_path / ("r%d.json" % r)))
         assert o["ok"] and o["world"] == 2
+
+
+def test_sharded_train_keeps_ranks_in_step_on_gloo(tmp_path):
+    """train() with world = 2 (gloo, CPU, a plumbing env that runs no kernel): gradients are averaged BEFORE they are
+    unscaled / clipped / applied, so both ranks end with identical weights although their envs and their
+    exploration noise differ."""
+    worker = tmp_path / "w.py"
+    worker.write_text('''
+import importlib.util, json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from isaacgymdyros_amd import dist as dwdist
+spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(%r, "examples", "ppo_consumer.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+rank, _, world = dwdist.init_from_env("gloo")
+
+class Env:                      # VecTask surface train() touches; dynamics = noise that depends on the rank
+    num_envs, num_obs, num_acts = 32, 12, 3
+    def __init__(self):
+        self.g = torch.Generator().manual_seed(100 + rank)
+        self.extras = {}
+        self.episodes_finished = torch.zeros(32)
+        self.epi_len_log = torch.zeros(32)
+        self.first_actions = None
+    def reset(self):
+        return {"obs": torch.zeros(32, 12)}
+    def step(self, a):
+        if self.first_actions is None: self.first_actions = a.clone()
+        o = torch.randn(32, 12, generator=self.g) + a.sum(1, keepdim=True)
+        return {"obs": o}, o[:, 0].tanh(), (torch.rand(32, generator=self.g) < 0.05).long(), {}
+cfg = {"network": dict(m.TRAIN_CFG["network"], mlp_units=[16]), "config": dict(m.TRAIN_CFG["config"], horizon_length=8, minibatch_size=64, mini_epochs=2)}
+nets = []
+orig = m.DyrosActorCritic
+class Spy(orig):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k); nets.append(self)
+m.DyrosActorCritic = Spy
+env = Env()
+st = m.train(epochs=2, device="cpu", cfg=cfg, env=env, rank=rank, world=world, log=lambda s: None)
+flat = torch.cat([p.detach().reshape(-1) for p in nets[0].parameters()])
+t = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(t, flat)
+fa = [torch.zeros_like(env.first_actions) for _ in range(world)]
+dist.all_gather(fa, env.first_actions)
+json.dump({"same_weights": bool(torch.equal(t[0], t[1])), "moved": bool((flat - flat.mean()).abs().sum() > 0), "finite": bool(torch.isfinite(flat).all()),
+           "same_noise": bool(torch.equal(fa[0], fa[1])), "epochs": len(st)}, open(os.path.join(sys.argv[1], "t%%d.json" %% rank), "w"))
+dist.barrier(); dist.destroy_process_group()
+''' % (ROOT, ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", str(worker), str(tmp_path)], timeout=600, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for k in range(2):
+        o = json.load(open(tmp_path / ("t%d.json" % k)))
+        assert o["same_weights"] and o["finite"] and o["epochs"] == 2, o
+        assert not o["same_noise"], "every rank drew the same exploration noise"
