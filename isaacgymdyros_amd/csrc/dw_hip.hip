@@ -21,7 +21,7 @@ struct DwHandle {
     dw::DevModel   *d_model;
     dwq::QuadModel *d_qmodel;
     dw::DevParams  *d_params;
-    int             pipeline;       // 1 fused wave-per-env, 2 split with quad physics
+    int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env); one launch per step in all three
     float          *d_mocap;
     DwBuffers       buf;
     int             bound;
@@ -70,6 +70,14 @@ int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadMode
 size_t quadmodel_bytes();
 int  quad_lds_bytes();
 }  // namespace dwq
+// The octet kernels (DwConfig.pipeline = 3): dw_oct_kernels.hip; they take the quad generation's schedule and tables.
+namespace dwo {
+void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step);
+void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                     const DwBuffers &B, const float *tau, const float *push);
+int  oct_lds_bytes();
+}  // namespace dwo
 
 __global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
                                                     const float *tau, const float *push) {
@@ -134,7 +142,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     if (rc) { free(hm); free(h); return fail(rc, err); }
     h->pipeline = cfg->pipeline == 0 ? 2 : cfg->pipeline;
     dwq::QuadModel *hq = nullptr;
-    if (h->pipeline == 2) {
+    if (h->pipeline >= 2) {
         rc = dwq::build_quadmodel_host(hm, model, &hq, &err);
         if (rc) { free(hm); free(h); return fail(rc, err); }
     }
@@ -196,7 +204,9 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
     DeviceGuard guard(h->device);
-    if (h->pipeline == 2) {
+    if (h->pipeline == 3) {
+        dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
+    } else if (h->pipeline == 2) {
         dwq::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_simulate_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
@@ -215,7 +225,10 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
     DeviceGuard guard(h->device);
-    if (h->pipeline == 2) {
+    if (h->pipeline == 3) {
+        dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
+                         actions, noise, (long long)step_index);
+    } else if (h->pipeline == 2) {
         dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
                          actions, noise, (long long)step_index);
     } else if (h->cfg.terrain)
@@ -244,5 +257,6 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
 
 int dw_lds_bytes(void) { return (int)sizeof(dw::Lds); }
 int dw_quad_lds_bytes(void) { return dwq::quad_lds_bytes(); }
+int dw_oct_lds_bytes(void) { return dwo::oct_lds_bytes(); }
 
 }  // extern "C"

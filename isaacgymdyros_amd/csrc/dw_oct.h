@@ -1,0 +1,1034 @@
+// dw_oct.h -- one physics substep (stand-in for the reference's closed `gym.simulate`, call site
+// tasks/dyros_dynamic_walk.py:525) in the OCTET layout: 8 lanes per env, 8 envs per wavefront, two wavefronts per
+// workgroup that share one copy of the hot tables.  Same physics, same order of the contact iterations and the same
+// written decisions as dw_quad.h / dw_physics.h / oracle/dw_physics.c (DESIGN.md "Physics model").
+//
+// Why octets.  A body-env slot is 64 bytes, so 160 KB of LDS hold 64 envs per CU whatever the lane mapping.  The quad
+// kernels (4 lanes per env, 16 envs per wave) therefore run ONE wave per SIMD -- and one wave alone issues a vector
+// instruction every 4 cycles where the SIMD could take one every 2 (MI355X_MICROARCH.md, constants table), and nothing
+// covers its LDS / memory round trips.  Here the same 64 envs per CU are 8 waves of 8 envs: two waves per SIMD, each with
+// half the envs' joint-parallel work per lane and at most 256 registers, and the phases with two-way data parallelism
+// inside an env (self-collision pairs, the 12 unit-wrench responses of the contact phase, the corner blocks) use the
+// second quad of the octet for it.
+//
+// Lane l of a wave: env el = l >> 3, octet lane o = l & 7 = 4 h + j: limb j (as in dw_quad_model.h: 0 neck + left leg,
+// 1 right leg, 2 waist + left arm, 3 right arm) and half h.  The DPP quads of a wave are the (env, half) groups, so every
+// quad_perm exchange of dw_quad.h means the same thing here; the two halves of a limb exchange with oct_xor4().  Where a
+// phase has nothing to split, both halves run it redundantly (in a SIMD machine that costs nothing) and only half 0 has
+// side effects in global memory.
+#pragma once
+
+#include "dw_quad.h"
+
+namespace dwo {
+
+using namespace dw;       // DevModel, PhysParams, small vector helpers
+using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::wave_sync; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::over_1n;
+using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
+using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
+
+constexpr int LPE = 8;               // lanes per env
+constexpr int EPO = 64 / LPE;        // envs per wavefront
+constexpr int WPG = 2;               // wavefronts per workgroup (they share the hot tables, nothing else)
+
+// One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env as in dw_quad.h.  A row is 8 envs x 16 B
+// = 128 B, half the width of the LDS (64 banks x 4 B), so a limb's position code p = pos | flip << 3 also swaps the rows of
+// odd-numbered owner lanes pairwise: the four limbs of a 16-lane group (2 envs) then read 8 different 16-byte columns.
+struct alignas(16) OSlots { F4 slot[NB * 4][EPO]; };
+struct alignas(16) OLds {
+    OSlots w[WPG];
+    QHot   hot;
+};
+static_assert(sizeof(OLds) <= 40960, "OLds: 4 workgroups (8 waves) per CU must fit 160 KB of LDS");
+DQ_HD int pcode(int el, int owner) { return ((el + 4 * (owner >> 1)) & 7) | ((owner & 1) << 3); }
+#define OQ_SLOT(b, q, p) L.slot[(b) * 4 + ((q) ^ ((p) >> 3))][(p) & 7]
+#define OQ_LD(b, q, p) ld4(L.slot[(b) * 4 + ((q) ^ ((p) >> 3))][(p) & 7])
+
+// copies the hot tables from the device-resident model into LDS.  Both waves of the workgroup copy all of it (identical
+// bytes), so neither has to wait for the other: no workgroup barrier anywhere in these kernels.
+DQ_HD void stage_hot(QHot &HW, const QuadModel &QM) {
+    const int l = lane_id();
+    const F4 *src = reinterpret_cast<const F4 *>(&QM.hot);
+    F4 *dst = reinterpret_cast<F4 *>(&HW);
+    constexpr int NQ = (int)(sizeof(QHot) / 16);
+    for (int i = l; i < NQ; i += 64) dst[i] = src[i];
+    wave_sync();
+}
+
+// What a lane keeps in registers across the phases of a step.
+struct OLane {
+    int   lane, o, j, h, el, env, valid, pos;   // octet lane, limb, half, env within the wave, global env (clamped), slot position code
+    float root[13];
+    float mu;
+    float warm[12];                          // impulses of the 4 corners of "my" foot (foot j & 1), from the previous substep
+    float footF[3];                          // non-sole contact force on my foot's sole Gym body (lanes 0, 1)
+    int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
+    float footT[3];                          // last substep: net contact force on my sole body (lanes 0, 1)
+    int   stamp_base;                        // profiling builds only
+    float in1[10], ms1;                      // second (welded) inertial record of my sole body: com[3], mass, I[6]; its mass scale
+};
+
+// ------------------------------------------------------------------------------------------------
+// The substep.  On entry every body's slot holds quad 0 = {q, qd, tt, dd} with tt = tau - damping * qd and
+// dd = armature + dt * damping (the caller's prologue), X.root the base state, X.warm the warm-start impulses, and the hot
+// tables are staged (stage_hot).  On exit: slot quad 0 = {q, qd, *, *} of the new state, X.root, X.warm updated; with `last`,
+// the net contact forces of the substep are written to B.contact_forces.  push: world x/y force on the base COM.
+// ------------------------------------------------------------------------------------------------
+struct FkHot { float pos[3], axis[3], vmax, qlo, qhi; int body, psrc, flags, scm; };
+DQ_HD FkHot fk_hot(const QHot &H, int s, int j) {
+    const F4 *r = reinterpret_cast<const F4 *>(H.fk[s][j]);
+    const F4 a = ld4(r[0]), b = ld4(r[1]), c = ld4(r[2]);
+    FkHot h;
+    h.pos[0] = a.x; h.pos[1] = a.y; h.pos[2] = a.z;
+    const int bits = f2i(a.w);
+    h.body = (bits & 255) == 255 ? -1 : (bits & 255);
+    h.psrc = (bits >> 8) & 15; h.flags = (bits >> 12) & 3; h.scm = (bits >> 16) & 255;
+    h.axis[0] = b.x; h.axis[1] = b.y; h.axis[2] = b.z; h.vmax = b.w;
+    h.qlo = c.x; h.qhi = c.y;
+    return h;
+}
+
+DQ_HD int sched_body(const QHot &H, int s, int j) {
+    const int bits = f2i(H.fk[s][j][3]);
+    return (bits & 255) == 255 ? -1 : (bits & 255);
+}
+
+template <bool TERRAIN>
+DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevModel &M, const PhysParams &P, OLane &X, const DwBuffers &B,
+                        float push_x, float push_y, bool last) {
+    const float dt = P.dt, inv_dt = 1.0f / P.dt;
+    const int j = X.j, T = H.misc[0];
+    const int SB = X.stamp_base; (void)SB;
+    DQ_STAMP(B, SB + 0);
+    const int e = X.env;
+    const bool wr = X.valid && X.h == 0;          // global side effects: half 0 only (half 1 mirrors it)
+    const float *mscale_e = B.mass_scale + (size_t)DW_NUM_BODIES * e;
+
+    // ---- base kinematics (every lane of the quad, redundantly) ----
+    float qn[4], R0[9], ww[3], vo[3], bcom[3];
+    {
+        const float qx = X.root[3], qy = X.root[4], qz = X.root[5], qw = X.root[6];
+        const float ninv = dw::rsqrt_nr(qx * qx + qy * qy + qz * qz + qw * qw);
+        qn[0] = qx * ninv; qn[1] = qy * ninv; qn[2] = qz * ninv; qn[3] = qw * ninv;
+        quat_to_mat(qn, R0);
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { ww[i] = X.root[10 + i]; vo[i] = X.root[7 + i]; bcom[i] = H.base[i]; }
+        if (P.vel_at_com) {
+            float rc[3], t[3];
+            m3v(R0, bcom, rc);
+            cross3(ww, rc, t);
+            vo[0] -= t[0]; vo[1] -= t[1]; vo[2] -= t[2];
+        }
+    }
+
+    DQ_STAMP(B, SB + 1);
+    // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist. ----
+    float footR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, footx[3] = {0, 0, 0};      // pose of my sole body (lanes 0, 1)
+    {
+        float qr[4] = {0, 0, 0, 1}, Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xr_[3] = {0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < T; ++s) {
+            const FkHot rc = fk_hot(H, s, j);
+            const int b = rc.body, psrc = rc.psrc;
+            // limbs that start below another lane's body fetch that lane's running state (still in its registers)
+            float fq[4], fx[3], fv[6];
+            bool fetched = false;
+            const int fm = H.fmask[s];
+            if (fm) {
+                for (int xl = 0; xl < 4; ++xl)
+                    if ((fm >> xl) & 1) {
+                        float tq[4], tx[3], tv[6];
+                        quad_bcast_arr(xl, qr, tq); quad_bcast_arr(xl, xr_, tx); quad_bcast_arr(xl, vr, tv);
+                        if (b >= 0 && psrc == 2 + xl) {
+                            fetched = true;
+                            DQ_UNROLL for (int i = 0; i < 4; ++i) fq[i] = tq[i];
+                            DQ_UNROLL for (int i = 0; i < 3; ++i) fx[i] = tx[i];
+                            DQ_UNROLL for (int i = 0; i < 6; ++i) fv[i] = tv[i];
+                        }
+                    }
+            }
+            // (both halves of a limb walk it: every lane reads its slot rows before any lane overwrites them)
+            F4 in = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (b >= 0) in = OQ_LD(b, 0, X.pos);            // {q, qd, tt, dd}
+            wave_sync();
+            if (b >= 0) {
+                if (psrc == 1) {
+                    DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = qn[i];
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0[i];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = 0.0f; vr[i] = ww[i]; vr[3 + i] = vo[i]; }
+                } else if (fetched) {
+                    DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fq[i];
+                    quat_to_mat(qr, Rr);
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) xr_[i] = fx[i];
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
+                }
+                float sn, cs;
+                sincos_fast(0.5f * in.x, &sn, &cs);
+                float qj[4] = {rc.axis[0] * sn, rc.axis[1] * sn, rc.axis[2] * sn, cs};
+                if (rc.flags & 1) qmul(QM.fk[s][j].q0, qj, qj);          // (two bodies of the model: the hands)
+                float x[3], t[3];
+                m3v(Rr, rc.pos, t);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) x[i] = xr_[i] + t[i];
+                qmul(qr, qj, qr);
+                quat_to_mat(qr, Rr);
+                float aw[3], sl[3];
+                m3v(Rr, rc.axis, aw);
+                cross3(x, aw, sl);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { vr[i] += aw[i] * in.y; vr[3 + i] += sl[i] * in.y; xr_[i] = x[i]; }
+                OQ_SLOT(b, 0, X.pos) = mk4(qr[0], qr[1], qr[2], qr[3]);
+                OQ_SLOT(b, 1, X.pos) = mk4(x[0], x[1], x[2], in.y);
+                OQ_SLOT(b, 2, X.pos) = mk4(vr[0], vr[1], vr[2], in.z);
+                OQ_SLOT(b, 3, X.pos) = mk4(vr[3], vr[4], vr[5], in.w);
+                if (rc.flags & 2) {
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) footR[i] = Rr[i];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) footx[i] = x[i];
+                }
+            }
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, SB + 2);
+    // ---- self-collision: capsule proxies (legs, arms, torso), pairs from the model.  Detection: lane p & 3 evaluates proxy p
+    //      from its body's slot; the pairs are tested in passes -- one proxy broadcast to the quad (DPP), every lane tests one
+    //      of its own against it -- and the touching pairs of the env are ORed into a mask.  The common case is "nothing
+    //      touches": then that is all.  Resolution, if any env of the wave has a touching pair: the lane that owns a proxy's
+    //      body recomputes the proxy's touching pairs from the slots and keeps the wrench (both sides of a pair compute the
+    //      same force from the same data: no hand-over between lanes). ----
+    bool sc_any = false;
+    float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
+    int scGym0 = 0, scGym1 = 0;          // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
+    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
+    const int nprox = H.misc[2], ncombo = H.misc[3];
+    auto proxy_bits = [&](int p) { return f2i(H.prox[p][7]); };
+    auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
+        const F4 *pr = reinterpret_cast<const F4 *>(H.prox[p]);
+        const F4 c0 = ld4(pr[0]), c1 = ld4(pr[1]);
+        const int bits = f2i(c1.w);
+        const int bp = bits & 255, posp = pcode(X.el, (bits >> 16) & 3);
+        const F4 q4 = OQ_LD(bp, 0, posp), x4 = OQ_LD(bp, 1, posp);
+        const float qb[4] = {q4.x, q4.y, q4.z, q4.w}, l0[3] = {c0.x, c0.y, c0.z}, l1[3] = {c1.x, c1.y, c1.z};
+        float Rb[9], t0[3], t1[3];
+        quat_to_mat(qb, Rb);
+        m3v(Rb, l0, t0);
+        m3v(Rb, l1, t1);
+        p0w[0] = x4.x + t0[0]; p0w[1] = x4.y + t0[1]; p0w[2] = x4.z + t0[2];
+        p1w[0] = x4.x + t1[0]; p1w[1] = x4.y + t1[1]; p1w[2] = x4.z + t1[2];
+    };
+    if (P.self_collision && ncombo > 0) {
+        float Pe[4][7];                    // my proxies (register set r = proxy j + 4 r): p0, p1 - p0, radius
+        DQ_UNROLL for (int r = 0; r < 4; ++r) {
+            DQ_UNROLL for (int i = 0; i < 7; ++i) Pe[r][i] = 0.0f;
+            if (j + 4 * r < nprox) {
+                float e1[3];
+                proxy_ends(j + 4 * r, &Pe[r][0], e1);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) Pe[r][3 + i] = e1[i] - Pe[r][i];
+                Pe[r][6] = H.prox[j + 4 * r][3];
+            }
+        }
+        DQ_STAMP(B, 51);
+        int hits = 0;
+        for (int c = 0; c < ncombo; ++c) {
+            const int *cw = H.combo[c];
+            const int c0 = cw[0], pb = c0 & 255;
+            float bq[7];
+            // proxy pb to the whole quad: register set and lane are wave-uniform, so this is a scalar branch around 7 DPP moves
+#define DQ_BC(R_, L_) case (R_) * 4 + (L_): { DQ_UNROLL for (int i = 0; i < 7; ++i) bq[i] = quad_bcast<L_>(Pe[R_][i]); } break;
+            switch (pb) {
+                DQ_BC(0, 0) DQ_BC(0, 1) DQ_BC(0, 2) DQ_BC(0, 3) DQ_BC(1, 0) DQ_BC(1, 1) DQ_BC(1, 2) DQ_BC(1, 3)
+                DQ_BC(2, 0) DQ_BC(2, 1) DQ_BC(2, 2) DQ_BC(2, 3) DQ_BC(3, 0) DQ_BC(3, 1) DQ_BC(3, 2)
+                default: { DQ_UNROLL for (int i = 0; i < 7; ++i) bq[i] = quad_bcast<3>(Pe[3][i]); } break;
+            }
+#undef DQ_BC
+            DQ_UNROLL for (int r = 0; r < 4; ++r) {
+                const int lm = (c0 >> (8 + 4 * r)) & 15;
+                if (lm == 0) continue;
+                if ((lm >> j) & 1) {
+                    const float rr = Pe[r][6] + bq[6];
+                    const float rv[3] = {Pe[r][0] - bq[0], Pe[r][1] - bq[1], Pe[r][2] - bq[2]};
+                    // conservative: the least distance of the axes (the force uses the blended points, never closer), 0.2 % slack
+                    if (seg_dist2_fast(&Pe[r][3], &bq[3], rv) < 1.004f * rr * rr) hits |= 1 << ((cw[1 + r] >> (8 * j)) & 255);
+                }
+            }
+        }
+        {   // the env's mask: OR over the quad (bit patterns through the DPP moves)
+            int m = hits;
+            m |= f2i(quad_xor1(__builtin_bit_cast(float, m)));
+            m |= f2i(quad_xor2(__builtin_bit_cast(float, m)));
+            hits = m;
+        }
+        sc_any = wave_any(hits != 0);
+        DQ_STAMP(B, 52);
+#if defined(DQ_STAMPS) && defined(__HIPCC__)
+        if (blockIdx.x == 0 && threadIdx.x == 0) B.gate_acc[200 + 53] = sc_any;
+#endif
+        if (sc_any) {
+            // every lane works through the touching pairs that involve one of its bodies
+            int mine = hits & (j == 0 ? H.misc[4] : (j == 1 ? H.misc[5] : (j == 2 ? H.misc[6] : H.misc[7])));
+            while (wave_any(mine != 0)) {
+                if (mine != 0) {
+                    const int pid = __builtin_ctz(mine);
+                    mine &= mine - 1;
+                    const int pr = (H.pairs[pid >> 2] >> (8 * (pid & 3))) & 255, pa = pr & 15, pbx = pr >> 4;
+                    const int bita = proxy_bits(pa), bitb = proxy_bits(pbx);
+                    float a0[3], a1[3], b0[3], b1[3];
+                    proxy_ends(pa, a0, a1);
+                    proxy_ends(pbx, b0, b1);
+                    const int ba = bita & 255, posa = pcode(X.el, (bita >> 16) & 3);
+                    const int bb = bitb & 255, posb = pcode(X.el, (bitb >> 16) & 3);
+                    const F4 va2 = OQ_LD(ba, 2, posa), va3 = OQ_LD(ba, 3, posa), vb2 = OQ_LD(bb, 2, posb), vb3 = OQ_LD(bb, 3, posb);
+                    const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
+                    float F[3], ca[3], cb[3];
+                    if (capsule_pair(a0, a1, H.prox[pa][3], b0, b1, H.prox[pbx][3], va, vb, P, F, ca, cb)) {
+                        DQ_UNROLL for (int side = 0; side < 2; ++side) {
+                            const int bits = side ? bitb : bita;
+                            if (((bits >> 16) & 3) != j) continue;
+                            const int k = (bits >> 18) & 7, gy = (bits >> 8) & 255;
+                            const float sg = side ? -1.0f : 1.0f;
+                            const float Fs[3] = {sg * F[0], sg * F[1], sg * F[2]};
+                            float nb[3];
+                            cross3(side ? cb : ca, Fs, nb);
+                            DQ_UNROLL for (int kk = 0; kk < QMAX_OWN; ++kk)
+                                if (kk == k) { DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[kk][i] += nb[i]; scW[kk][3 + i] += Fs[i]; } }
+                            if (k < 4) scGym0 |= gy << (8 * k); else scGym1 |= gy << (8 * (k - 4));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    wave_sync();      // the leg lanes read each other's slots above; the inward pass below overwrites them
+
+    DQ_STAMP(B, SB + 3);
+    // ---- inward pass: articulated inertias and bias forces, in reverse schedule order ----
+    float IA[21], pA[6], IP[21], pP[6];          // running and parked reflected inertia / bias
+    DQ_UNROLL for (int i = 0; i < 21; ++i) { IA[i] = 0.0f; IP[i] = 0.0f; }
+    DQ_UNROLL for (int i = 0; i < 6; ++i) { pA[i] = 0.0f; pP[i] = 0.0f; }
+    X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
+    const int my_sole_gym = (j == 0) ? M.left_foot_gym : (j == 1 ? M.right_foot_gym : -1);
+    // the one per-env global value a step needs (the mass scale of the body's Gym body) is requested a step ahead
+    float ms_next = mscale_e[(f2i(H.in[0][j][2]) >> 24) & 255];
+    for (int s = 0; s < T; ++s) {
+#if defined(DQ_STAMPS_INWARD)
+        if (SB == 1) DQ_STAMP(B, 42 + s);
+#endif
+        const F4 *hr = reinterpret_cast<const F4 *>(H.in[s][j]);
+        const F4 h0 = ld4(hr[0]), h1 = ld4(hr[1]), h2 = ld4(hr[2]), h3 = ld4(hr[3]);
+        const int bits = f2i(h0.x);
+        const int b = (bits & 255) - 1;
+        const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
+        const int nin = (bits >> 12) & 3, ngym = (bits >> 14) & 3, ngeom = (bits >> 16) & 15, scm = (bits >> 24) & 255;
+        const int gymbits = f2i(h0.z);
+        const float ms0 = ms_next;
+        if (s + 1 < T) ms_next = mscale_e[(f2i(H.in[s + 1][j][2]) >> 24) & 255];
+        if (flags & 2) {                    // a finished chain is still waiting for its parent: park it
+            DQ_UNROLL for (int i = 0; i < 21; ++i) IP[i] = IA[i];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) pP[i] = pA[i];
+        }
+        if (flags & 1) {
+            DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
+            DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
+        }
+        // gathers (wave-uniform per step): child chains that ended on other lanes
+        if (H.gany[s]) {
+            const int g0 = f2i(H.in[s][0][1]), g1 = f2i(H.in[s][1][1]), g2 = f2i(H.in[s][2][1]), g3 = f2i(H.in[s][3][1]);
+            const int mine = f2i(h0.y);
+            DQ_UNROLL for (int src = 0; src < 4; ++src)
+                DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
+                    const int code = src | (pk << 2) | 8;
+                    bool used = false, want = false;
+                    DQ_UNROLL for (int k = 0; k < 3; ++k) {
+                        used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
+                               (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
+                        want = want || (((mine >> (4 * k)) & 15) == code);
+                    }
+                    if (used) {
+                        DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                            const float v = pk ? IP[i] : IA[i];
+                            const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                            if (want) IA[i] += t;
+                        }
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                            const float v = pk ? pP[i] : pA[i];
+                            const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                            if (want) pA[i] += t;
+                        }
+                    }
+                }
+        }
+        F4 s0 = mk4(0.0f, 0.0f, 0.0f, 1.0f), s1 = s0, s2 = s0, s3 = s0;
+        if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
+        wave_sync();          // (mirrored halves: reads before overwrites)
+        if (b >= 0) {
+            const F4 ax4 = ld4(reinterpret_cast<const F4 *>(H.fk[T - 1 - s][j])[1]);
+            const float axis[3] = {ax4.x, ax4.y, ax4.z};
+            const float qb[4] = {s0.x, s0.y, s0.z, s0.w}, x[3] = {s1.x, s1.y, s1.z}, v[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+            const float qd = s1.w, tt = s2.w, dd = s3.w;
+            float R[9];
+            quat_to_mat(qb, R);
+            float S[6];
+            m3v(R, axis, S);
+            cross3(x, S, S + 3);
+            // rigid inertia, gyroscopic bias
+            float Ao[6], ho[3], mass;
+            {
+                const float com0[3] = {h1.x, h1.y, h1.z}, I0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
+                if (nin > 1) {          // the two sole bodies carry a second (welded) inertial record
+                    rigid_inertia(2, com0, h1.w, I0, ms0, &X.in1[0], X.in1[3], &X.in1[4], X.ms1, R, x, Ao, ho, &mass);
+                } else {
+                    rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Ao, ho, &mass);
+                }
+            }
+            add_rigid(IA, pA, Ao, ho, mass, v);
+            // external forces: ground penalty of the non-sole primitives, self-collision; per Gym body for the report
+            float cf[QMAX_GYM][3];
+            DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
+            bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
+            if (TERRAIN) near_ground = ngeom > 0;
+#if defined(DQ_KO_GEOM)          // (timing experiment only)
+            near_ground = false;
+#endif
+            if (near_ground) {
+                const QInRec &rc = QM.in[s][j];
+                for (int k = 0; k < ngeom; ++k) {
+                    float F[3], xr[3];
+                    geom_force<TERRAIN>(M.geoms[rc.geom[k]], P, R, x, v, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
+                    if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                        float nb[3];
+                        cross3(xr, F, nb);
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) { pA[i] -= nb[i]; pA[3 + i] -= F[i]; }
+                        const int t = (rc.geom_slot >> (2 * k)) & 3;
+                        DQ_UNROLL for (int tt2 = 0; tt2 < QMAX_GYM; ++tt2)
+                            if (tt2 == t) { cf[tt2][0] += F[0]; cf[tt2][1] += F[1]; cf[tt2][2] += F[2]; }
+                    }
+                }
+            }
+            if (sc_any && scm) {
+                DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
+                    if ((scm >> p) & 1) {
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
+                        const int gy = ((p < 4 ? scGym0 >> (8 * p) : scGym1 >> (8 * (p - 4)))) & 255;     // (0 where unloaded: adds nothing)
+                        DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
+                            if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
+                    }
+            }
+            if (last) {
+                DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
+                    if (t < ngym) {
+                        const int gy = (gymbits >> (8 * t)) & 255;
+                        if (gy == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
+                        else {
+                            if (over_1n(cf[t])) X.coll = 1;
+                            if (wr) {
+                                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
+                                dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
+                            }
+                        }
+                    }
+            }
+            // articulated-body step
+            float U[6];
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                float acc = 0.0f;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * S[c];
+                U[r] = acc;
+            }
+            const float D = dot6(S, U) + dd;
+            const float Dinv = dw::rcp_nr(D);
+            const float u = tt - dot6(S, pA);
+            float m[6], cb[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = S[i] * qd;
+            dw::motion_cross(v, m, cb);
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                const float urd = U[r] * Dinv;
+                DQ_UNROLL for (int c = r; c < 6; ++c) IA[sym6(r, c)] -= urd * U[c];
+            }
+            const float ud = u * Dinv;
+            float pa[6];
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                float acc = pA[r] + U[r] * ud;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * cb[c];
+                pa[r] = acc;
+            }
+            DQ_UNROLL for (int r = 0; r < 6; ++r) pA[r] = pa[r];
+            OQ_SLOT(b, 0, X.pos) = mk4(S[0], S[1], S[2], Dinv);
+            OQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], u);
+            OQ_SLOT(b, 2, X.pos) = mk4(U[0], U[1], U[2], qd);
+            OQ_SLOT(b, 3, X.pos) = mk4(U[3], U[4], U[5], 0.0f);
+        }
+    }
+
+    DQ_STAMP(B, SB + 4);
+    // ---- base: gather the chains below the root, own inertia, external forces, inverse ----
+    float Minv[36], a0[6];
+    {
+        float I0[21], p0[6];
+        DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = 0.0f;
+        DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = 0.0f;
+        const int g = H.misc[1];
+        DQ_UNROLL for (int src = 0; src < 4; ++src)
+            DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
+                const int code = src | (pk << 2) | 8;
+                const bool used = ((g & 15) == code) || (((g >> 4) & 15) == code) || (((g >> 8) & 15) == code) || (((g >> 12) & 15) == code);
+                if (used) {
+                    DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                        const float v = pk ? IP[i] : IA[i];
+                        I0[i] += src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                    }
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                        const float v = pk ? pP[i] : pA[i];
+                        p0[i] += src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+                    }
+                }
+            }
+        const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
+        float Ao[6], ho[3], mass;
+        const int base_gym = f2i(H.base[10]), base_ngeom = f2i(H.base[11]);
+        const float ms = mscale_e[base_gym];
+        {
+            const float bI[6] = {H.base[4], H.base[5], H.base[6], H.base[7], H.base[8], H.base[9]};
+            rigid_inertia(1, bcom, H.base[3], bI, ms, bcom, 0.0f, bI, 0.0f, R0, x0, Ao, ho, &mass);
+        }
+        add_rigid(I0, p0, Ao, ho, mass, v0);
+        float cfb[3] = {0, 0, 0};
+        bool near_ground = base_ngeom > 0 && (X.root[2] < H.base[12]);
+        if (TERRAIN) near_ground = base_ngeom > 0;
+        if (near_ground) {
+            for (int k = 0; k < base_ngeom; ++k) {
+                float F[3], xr[3];
+                geom_force<TERRAIN>(M.geoms[QM.base_geom[k]], P, R0, x0, v0, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
+                if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                    float nb[3];
+                    cross3(xr, F, nb);
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { p0[i] -= nb[i]; p0[3 + i] -= F[i]; cfb[i] += F[i]; }
+                }
+            }
+        }
+        if (last && j == 3) {
+            if (over_1n(cfb)) X.coll = 1;
+            if (wr) {
+                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + base_gym) * 3;
+                dst[0] = cfb[0]; dst[1] = cfb[1]; dst[2] = cfb[2];
+            }
+        }
+        {   // push on the base COM
+            const float Fw[3] = {push_x, push_y, 0.0f};
+            float xc[3], nb[3];
+            m3v(R0, bcom, xc);
+            cross3(xc, Fw, nb);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { p0[i] -= nb[i]; p0[3 + i] -= Fw[i]; }
+        }
+        // Cholesky I0 = L L', Minv by six pairs of triangular solves (dw_physics.h A3)
+        float Lc[36], dinv[6];
+        DQ_UNROLL for (int i = 0; i < 36; ++i) Lc[i] = 0.0f;
+        DQ_UNROLL for (int c = 0; c < 6; ++c) {
+            float d = I0[sym6(c, c)];
+            DQ_UNROLL for (int k = 0; k < c; ++k) d -= Lc[6 * c + k] * Lc[6 * c + k];
+            dinv[c] = dw::rsqrt_nr(d);
+            Lc[6 * c + c] = d * dinv[c];
+            DQ_UNROLL for (int i = c + 1; i < 6; ++i) {
+                float sacc = I0[sym6(i, c)];
+                DQ_UNROLL for (int k = 0; k < c; ++k) sacc -= Lc[6 * i + k] * Lc[6 * c + k];
+                Lc[6 * i + c] = sacc * dinv[c];
+            }
+        }
+        DQ_UNROLL for (int col = 0; col < 6; ++col) {
+            float y[6], xx[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                float sacc = (i == col) ? 1.0f : 0.0f;
+                DQ_UNROLL for (int k = 0; k < i; ++k) sacc -= Lc[6 * i + k] * y[k];
+                y[i] = sacc * dinv[i];
+            }
+            DQ_UNROLL for (int i = 5; i >= 0; --i) {
+                float sacc = y[i];
+                DQ_UNROLL for (int k = i + 1; k < 6; ++k) sacc -= Lc[6 * k + i] * xx[k];
+                xx[i] = sacc * dinv[i];
+            }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) Minv[6 * i + col] = xx[i];
+        }
+        DQ_UNROLL for (int r = 0; r < 6; ++r) {
+            float acc = 0.0f;
+            DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[6 * r + c] * p0[c];
+            a0[r] = acc;
+        }
+    }
+
+    DQ_STAMP(B, SB + 5);
+    // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot ----
+    {
+        float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < T; ++s) {
+            const int bits = f2i(H.fk[s][j][3]);
+            const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
+            float fa[6], fv[6];
+            bool fetched = false;
+            const int fm = H.fmask[s];
+            if (fm) {
+                for (int xl = 0; xl < 4; ++xl)
+                    if ((fm >> xl) & 1) {
+                        float ta[6], tv[6];
+                        quad_bcast_arr(xl, ar, ta); quad_bcast_arr(xl, vr, tv);
+                        if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) { fa[i] = ta[i]; fv[i] = tv[i]; } }
+                    }
+            }
+            F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
+            if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
+            wave_sync();
+            if (b >= 0) {
+                if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = a0[i]; ar[3 + i] = a0[3 + i]; vr[i] = ww[i]; vr[3 + i] = vo[i]; } }
+                else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] = fa[i]; vr[i] = fv[i]; } }
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                const float Dinv = s0.w, u = s1.w, qd = s2.w;
+                float m[6], c[6];
+                DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = S[i] * qd;
+                dw::motion_cross(vr, m, c);                  // parent twist x S qd  (= body twist x S qd)
+                DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] += c[i]; vr[i] += m[i]; }
+                const float qdd = (u - dot6(U, ar)) * Dinv;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * qdd;
+                OQ_SLOT(b, 2, X.pos) = mk4(U[0], U[1], U[2], qd + dt * qdd);      // free velocity
+                OQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], 0.0f);                // u is dead: the word becomes the impulse-sweep d
+            }
+        }
+    }
+    wave_sync();
+    DQ_STAMP(B, SB + 6);
+    // ---- free base velocity; sole-corner gaps of my foot (foot f = j & 1; lanes f and f + 2 work on it together) ----
+    float wwf[3], vowf[3];
+    {
+        float t2[3];
+        cross3(ww, vo, t2);
+        DQ_UNROLL for (int i = 0; i < 3; ++i) {
+            wwf[i] = ww[i] + dt * a0[i];
+            vowf[i] = vo[i] + dt * (a0[3 + i] + t2[i] + P.g[i]);
+        }
+    }
+    const int f = j & 1, part = j >> 1;
+    float rk[4][3], vminr[4], frame[4][9];
+    int act[4];
+    {
+        // the pose of foot f lives in lane f: lanes 2, 3 fetch it from their partner (l ^ 2)
+        float fR[9], fx[3];
+        DQ_UNROLL for (int i = 0; i < 9; ++i) { const float o = quad_xor2(footR[i]); fR[i] = part ? o : footR[i]; }
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = quad_xor2(footx[i]); fx[i] = part ? o : footx[i]; }
+        DQ_UNROLL for (int k = 0; k < 4; ++k) {
+            float r[3];
+            m3v(fR, M.foot_pos[4 * f + k], r);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) r[i] += fx[i];
+            float phi = X.root[2] + r[2];
+            if (TERRAIN) {
+                float hh;
+                dw::terrain_sample(P, X.root[0] + r[0], X.root[1] + r[1], &hh, frame[k]);
+                phi = (phi - hh) * frame[k][8];
+            } else {
+                DQ_UNROLL for (int i = 0; i < 9; ++i) frame[k][i] = (i % 4 == 0) ? 1.0f : 0.0f;
+            }
+            act[k] = phi < P.contact_offset;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) rk[k][i] = r[i];
+            vminr[k] = phi >= 0 ? -phi * inv_dt : fminf(P.erp * (-phi) * inv_dt, P.max_depen);
+        }
+    }
+    const bool any_active = wave_any(act[0] | act[1] | act[2] | act[3]);
+    float dqb[6] = {0, 0, 0, 0, 0, 0};              // base velocity jump
+    float Pk[4][3];
+    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) Pk[k][i] = act[k] ? X.warm[3 * k + i] : 0.0f;
+
+    if (any_active) {
+        // ---- free twist of foot f: base + sum over the leg of S qdf (leg lane), shared with the partner ----
+        float twf[6];
+        {
+            float acc[6] = {wwf[0], wwf[1], wwf[2], vowf[0], vowf[1], vowf[2]};
+            const int posf = pcode(X.el, f);
+            DQ_UNROLL for (int i = 1; i <= 6; ++i) {
+                const int b = 6 * f + i;
+                const F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf);
+                acc[0] += s0.x * s2.w; acc[1] += s0.y * s2.w; acc[2] += s0.z * s2.w;
+                acc[3] += s1.x * s2.w; acc[4] += s1.y * s2.w; acc[5] += s1.z * s2.w;
+            }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) twf[i] = acc[i];
+        }
+        DQ_STAMP(B, SB + 7);
+        // ---- my 3 rows of W: responses of both feet to unit wrenches (components 3 part .. 3 part + 2) on foot f.
+        //      Up the leg: d = -S'p, p += U d / D;  base: dv = -Minv p;  down both legs: qdd = (d - U'dv) / D, dv += S qdd ----
+        float Wr[3][12];
+        {
+            float dp[3][6], dc[3][6];
+            DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int i = 0; i < 6; ++i) dp[c][i] = (i == 3 * part + c) ? -1.0f : 0.0f;
+            const int posf = pcode(X.el, f);
+            DQ_UNROLL for (int i = 6; i >= 1; --i) {
+                const int b = 6 * f + i;
+                const F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf), s3 = OQ_LD(b, 3, posf);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float d = -dot6(S, dp[c]);
+                    dc[c][i - 1] = d;
+                    const float k = d * s0.w;
+                    DQ_UNROLL for (int r = 0; r < 6; ++r) dp[c][r] += U[r] * k;
+                }
+            }
+            float dv0[3][6];
+            DQ_UNROLL for (int c = 0; c < 3; ++c)
+                DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                    float acc = 0.0f;
+                    DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[6 * r + k] * dp[c][k];
+                    dv0[c][r] = acc;
+                }
+            DQ_UNROLL for (int g = 0; g < 2; ++g) {
+                float dv[3][6];
+                DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) dv[c][r] = dv0[c][r];
+                const int posg = pcode(X.el, g);
+                DQ_UNROLL for (int i = 1; i <= 6; ++i) {
+                    const int b = 6 * g + i;
+                    const F4 s0 = OQ_LD(b, 0, posg), s1 = OQ_LD(b, 1, posg), s2 = OQ_LD(b, 2, posg), s3 = OQ_LD(b, 3, posg);
+                    const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                        const float ua = dot6(U, dv[c]);
+                        const float qdd = ((g == f ? dc[c][i - 1] : 0.0f) - ua) * s0.w;
+                        DQ_UNROLL for (int r = 0; r < 6; ++r) dv[c][r] += S[r] * qdd;
+                    }
+                }
+                DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) Wr[c][6 * g + r] = dv[c][r];
+            }
+        }
+        DQ_STAMP(B, SB + 8);
+        // ---- 3x3 diagonal blocks of the Delassus matrix of my foot's corners: A_kk = J_k W_ff J_k' (frame-projected on
+        //      terrain); what the solver needs of them: the three diagonal inverses and the couplings zx, zy, xy ----
+        float invd[4][3], cpl[4][3];
+        {
+            float Wff[6][6];       // rows 3 part.. are mine, the other three come from the partner lane (l ^ 2)
+            DQ_UNROLL for (int r = 0; r < 3; ++r)
+                DQ_UNROLL for (int c = 0; c < 6; ++c) {
+                    const float mine = f ? Wr[r][6 + c] : Wr[r][c];
+                    const float o = quad_xor2(mine);
+                    Wff[r][c] = part ? o : mine;
+                    Wff[3 + r][c] = part ? mine : o;
+                }
+            const float rreg = 1.0f / (1.0f + P.cfm);
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                const float *r = rk[k];
+                float G[3][6];        // J_k W_ff, world axes: row a = W_lin row a + (-skew(r)) row a . W_ang
+                DQ_UNROLL for (int c = 0; c < 6; ++c) {
+                    G[0][c] = Wff[3][c] + r[2] * Wff[1][c] - r[1] * Wff[2][c];
+                    G[1][c] = Wff[4][c] - r[2] * Wff[0][c] + r[0] * Wff[2][c];
+                    G[2][c] = Wff[5][c] + r[1] * Wff[0][c] - r[0] * Wff[1][c];
+                }
+                float Ak[3][3];       // G J_k': column b = G_lin col b + G_ang . (-skew(r)) row b
+                DQ_UNROLL for (int a = 0; a < 3; ++a) {
+                    Ak[a][0] = G[a][3] + r[2] * G[a][1] - r[1] * G[a][2];
+                    Ak[a][1] = G[a][4] - r[2] * G[a][0] + r[0] * G[a][2];
+                    Ak[a][2] = G[a][5] + r[1] * G[a][0] - r[0] * G[a][1];
+                }
+                if (TERRAIN) {        // rows / columns along the corner's frame (t1, t2, n)
+                    float Tm[3][3];
+                    DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
+                        Tm[a][c] = frame[k][3 * a] * Ak[0][c] + frame[k][3 * a + 1] * Ak[1][c] + frame[k][3 * a + 2] * Ak[2][c];
+                    DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
+                        Ak[a][c] = Tm[a][0] * frame[k][3 * c] + Tm[a][1] * frame[k][3 * c + 1] + Tm[a][2] * frame[k][3 * c + 2];
+                }
+                invd[k][0] = act[k] ? dw::rcp_nr(Ak[0][0]) * rreg : 0.0f;
+                invd[k][1] = act[k] ? dw::rcp_nr(Ak[1][1]) * rreg : 0.0f;
+                invd[k][2] = act[k] ? dw::rcp_nr(Ak[2][2]) * rreg : 0.0f;
+                cpl[k][0] = Ak[0][2];     // x row, z column
+                cpl[k][1] = Ak[1][2];     // y row, z column
+                cpl[k][2] = Ak[1][0];     // y row, x column
+            }
+        }
+        // my rows of W as [own foot | other foot] so that the updates below index registers statically
+        float Wo[3][6], Wx[3][6];
+        DQ_UNROLL for (int r = 0; r < 3; ++r) DQ_UNROLL for (int c = 0; c < 6; ++c) { Wo[r][c] = f ? Wr[r][6 + c] : Wr[r][c]; Wx[r][c] = f ? Wr[r][c] : Wr[r][6 + c]; }
+        // ---- start: tw = tw_free + W lambda0, lambda0 = warm-start impulses as foot wrenches ----
+        float tw3[3];
+        {
+            float lam[6] = {0, 0, 0, 0, 0, 0};
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                float pw[3] = {Pk[k][0], Pk[k][1], Pk[k][2]};
+                if (TERRAIN) {
+                    const float p0 = pw[0], p1 = pw[1], p2 = pw[2];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) pw[i] = p0 * frame[k][i] + p1 * frame[k][3 + i] + p2 * frame[k][6 + i];
+                }
+                float t[3];
+                cross3(rk[k], pw, t);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { lam[i] += t[i]; lam[3 + i] += pw[i]; }
+            }
+            float lo[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
+            DQ_UNROLL for (int r = 0; r < 3; ++r) {
+                float acc = part ? twf[3 + r] : twf[r];
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wo[r][c] * lam[c] + Wx[r][c] * lo[c];
+                tw3[r] = acc;
+            }
+        }
+        DQ_STAMP(B, SB + 9);
+        // ---- projected Gauss-Seidel, block-Jacobi across the feet: corner kk of the left sole and corner kk of the right
+        //      sole are updated together from the same snapshot, the four corners of a sole one after the other ----
+        bool pair_on[4];
+        DQ_UNROLL for (int kk = 0; kk < 4; ++kk) pair_on[kk] = wave_any(act[kk] != 0);
+        for (int it = 0; it < P.iters; ++it) {
+            DQ_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                if (pair_on[kk]) {
+                    float o3[3];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) o3[i] = quad_xor2(tw3[i]);
+                    float wv[3], lv[3];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { wv[i] = part ? o3[i] : tw3[i]; lv[i] = part ? tw3[i] : o3[i]; }
+                    const float *r = rk[kk];
+                    float vwld[3] = {lv[0] + wv[1] * r[2] - wv[2] * r[1], lv[1] + wv[2] * r[0] - wv[0] * r[2], lv[2] + wv[0] * r[1] - wv[1] * r[0]};
+                    float vx0 = vwld[0], vy0 = vwld[1], vz = vwld[2];
+                    if (TERRAIN) {
+                        const float *fr = frame[kk];
+                        vx0 = fr[0] * vwld[0] + fr[1] * vwld[1] + fr[2] * vwld[2];
+                        vy0 = fr[3] * vwld[0] + fr[4] * vwld[1] + fr[5] * vwld[2];
+                        vz = fr[6] * vwld[0] + fr[7] * vwld[1] + fr[8] * vwld[2];
+                    }
+                    const float Px = Pk[kk][0], Py = Pk[kk][1], Pz = Pk[kk][2];
+                    float dz = -(vz - vminr[kk]) * invd[kk][2];
+                    float pz = Pz + dz;
+                    if (pz < 0) pz = 0;
+                    dz = pz - Pz;
+                    const float vx = vx0 + cpl[kk][0] * dz;
+                    const float dx = -vx * invd[kk][0];
+                    const float vy = vy0 + cpl[kk][1] * dz + cpl[kk][2] * dx;
+                    const float dy = -vy * invd[kk][1];
+                    float px = Px + dx, py = Py + dy;
+                    const float lim = X.mu * pz, n2 = px * px + py * py;
+                    if (n2 > lim * lim) {
+                        const float sc = lim * dw::rsqrt_nr(n2);
+                        px *= sc; py *= sc;
+                    }
+                    float d[3] = {px - Px, py - Py, dz};
+                    Pk[kk][0] = px; Pk[kk][1] = py; Pk[kk][2] = pz;
+                    if (TERRAIN) {
+                        const float *fr = frame[kk];
+                        const float d0 = d[0], d1 = d[1], d2 = d[2];
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) d[i] = d0 * fr[i] + d1 * fr[3 + i] + d2 * fr[6 + i];
+                    }
+                    float lam[6], lo[6];
+                    cross3(r, d, lam);
+                    lam[3] = d[0]; lam[4] = d[1]; lam[5] = d[2];
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
+                    DQ_UNROLL for (int rr = 0; rr < 3; ++rr) {
+                        float acc = tw3[rr];
+                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wo[rr][c] * lam[c] + Wx[rr][c] * lo[c];
+                        tw3[rr] = acc;
+                    }
+                }
+            }
+        }
+        DQ_STAMP(B, SB + 10);
+        // ---- impulses -> wrench on my foot -> up my leg (leg lanes), base jump ----
+        float dpb[6] = {0, 0, 0, 0, 0, 0};
+        float Fs[3] = {0, 0, 0};
+        if (part == 0) {
+            float Nm[3] = {0, 0, 0};
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                float pw[3] = {Pk[k][0], Pk[k][1], Pk[k][2]};
+                if (TERRAIN) {
+                    const float p0 = pw[0], p1 = pw[1], p2 = pw[2];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) pw[i] = p0 * frame[k][i] + p1 * frame[k][3 + i] + p2 * frame[k][6 + i];
+                }
+                float t[3];
+                cross3(rk[k], pw, t);
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { Fs[i] += pw[i]; Nm[i] += t[i]; }
+            }
+            float dp[6] = {-Nm[0], -Nm[1], -Nm[2], -Fs[0], -Fs[1], -Fs[2]};
+            DQ_UNROLL for (int i = 6; i >= 1; --i) {
+                const int b = 6 * f + i;
+                const F4 s0 = OQ_LD(b, 0, X.pos), s1 = OQ_LD(b, 1, X.pos), s2 = OQ_LD(b, 2, X.pos), s3 = OQ_LD(b, 3, X.pos);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                const float d = -dot6(S, dp);
+                const float k = d * s0.w;
+                DQ_UNROLL for (int r = 0; r < 6; ++r) dp[r] += U[r] * k;
+                OQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], d);
+            }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) dpb[i] = dp[i];
+        }
+        {
+            float tot[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                const float a = quad_bcast<0>(dpb[i]), b2 = quad_bcast<1>(dpb[i]);
+                tot[i] = a + b2;
+            }
+            DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                float acc = 0.0f;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[6 * r + c] * tot[c];
+                dqb[r] = acc;
+            }
+        }
+        if (last && part == 0) {
+            DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i] + Fs[i] * inv_dt;
+            if (wr) {
+                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+                dst[0] = X.footT[0]; dst[1] = X.footT[1]; dst[2] = X.footT[2];
+            }
+        }
+    } else if (last && part == 0) {
+        DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i];
+        if (wr) {
+            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+            dst[0] = X.footF[0]; dst[1] = X.footF[1]; dst[2] = X.footF[2];
+        }
+    }
+    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) X.warm[3 * k + i] = Pk[k][i];
+
+    DQ_STAMP(B, SB + 11);
+    // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
+    {
+        float ar[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < T; ++s) {
+            const FkHot rc = fk_hot(H, s, j);
+            const int b = rc.body, psrc = rc.psrc;
+            float fa[6];
+            bool fetched = false;
+            const int fm = H.fmask[s];
+            if (fm) {
+                for (int xl = 0; xl < 4; ++xl)
+                    if ((fm >> xl) & 1) {
+                        float ta[6];
+                        quad_bcast_arr(xl, ar, ta);
+                        if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) fa[i] = ta[i]; }
+                    }
+            }
+            F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
+            if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
+            wave_sync();
+            if (b >= 0) {
+                if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = dqb[i]; }
+                else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fa[i]; }
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                const float dq = (s1.w - dot6(U, ar)) * s0.w;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * dq;
+                float qd = s2.w + dq;
+                if (qd > rc.vmax) qd = rc.vmax;
+                if (qd < -rc.vmax) qd = -rc.vmax;
+                OQ_SLOT(b, 0, X.pos) = mk4(rc.qlo, qd, rc.qhi, 0.0f);        // joint range and new velocity for integrate_joints
+            }
+        }
+    }
+    DQ_STAMP(B, SB + 12);
+    // ---- base: final velocity, clamps, pose update (dw_physics.h V2) ----
+    {
+        float wwn[3], von[3];
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { wwn[i] = wwf[i] + dqb[i]; von[i] = vowf[i] + dqb[3 + i]; }
+        const float wn2 = dot3(wwn, wwn);
+        if (wn2 > P.max_ang_vel * P.max_ang_vel) {
+            const float sc = P.max_ang_vel * dw::rsqrt_nr(wn2);
+            wwn[0] *= sc; wwn[1] *= sc; wwn[2] *= sc;
+        }
+        X.root[0] += dt * von[0]; X.root[1] += dt * von[1]; X.root[2] += dt * von[2];
+        const float w2 = dot3(wwn, wwn);
+        const float hx = 0.5f * dt;
+        const float x2 = w2 * hx * hx;
+        const float sh = hx * (1.0f + x2 * (-1.0f / 6 + x2 * (1.0f / 120 + x2 * (-1.0f / 5040 + x2 * (1.0f / 362880)))));
+        const float ch = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24 + x2 * (-1.0f / 720 + x2 * (1.0f / 40320))));
+        const float x1 = wwn[0] * sh, y1 = wwn[1] * sh, z1 = wwn[2] * sh, w1 = ch;
+        const float x2q = qn[0], y2 = qn[1], z2 = qn[2], w2q = qn[3];
+        float qo[4] = {w1 * x2q + x1 * w2q + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2q + z1 * x2q,
+                       w1 * z2 + x1 * y2 - y1 * x2q + z1 * w2q, w1 * w2q - x1 * x2q - y1 * y2 - z1 * z2};
+        const float ninv = dw::rsqrt_nr(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+        DQ_UNROLL for (int i = 0; i < 4; ++i) { qo[i] *= ninv; X.root[3 + i] = qo[i]; }
+        if (P.vel_at_com) {
+            float Rn[9], rcom[3], tt[3];
+            quat_to_mat(qo, Rn);
+            m3v(Rn, bcom, rcom);
+            cross3(wwn, rcom, tt);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) von[i] += tt[i];
+        }
+        DQ_UNROLL for (int i = 0; i < 3; ++i) { X.root[7 + i] = von[i]; X.root[10 + i] = wwn[i]; }
+    }
+    DQ_STAMP(B, SB + 13);
+}
+
+// Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
+DQ_HD void oct_lane_init(OLane &X, int wave_index, int num_envs, const PhysParams &P, float friction, const DwBuffers &B) {
+    X.lane = lane_id();
+    X.o = X.lane & 7; X.j = X.lane & 3; X.h = (X.lane >> 2) & 1;
+    X.el = X.lane >> 3;
+    const int eg = wave_index * EPO + X.el;
+    X.valid = eg < num_envs;
+    X.env = X.valid ? eg : num_envs - 1;
+    X.pos = pcode(X.el, X.j);
+    DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = B.root_states[(size_t)13 * X.env + i];
+    X.mu = friction * B.friction_scale[X.env];
+    DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = 0.0f;
+    X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
+    X.stamp_base = 0;
+    X.coll = 0;
+    X.footT[0] = X.footT[1] = X.footT[2] = 0.0f;
+    (void)P;
+}
+
+// after stage_hot: the lane's step with two inertial records (the sole bodies; at most one per lane)
+DQ_HD void oct_lane_second_inertial(OLane &X, const QHot &H, const QuadModel &QM, const DwBuffers &B) {
+    int s2 = 0;
+    DQ_UNROLL for (int s = 0; s < QS_MAX; ++s) if (s < H.misc[0] && ((f2i(H.in[s][X.j][0]) >> 12) & 3) > 1) s2 = s;
+    const QInRec &rc = QM.in[s2][X.j];
+    DQ_UNROLL for (int i = 0; i < 3; ++i) X.in1[i] = rc.in1_com[i];
+    X.in1[3] = rc.in1_mass;
+    DQ_UNROLL for (int i = 0; i < 6; ++i) X.in1[4 + i] = rc.in1_I[i];
+    const int g1 = rc.in1_gym;
+    X.ms1 = B.mass_scale[(size_t)DW_NUM_BODIES * X.env + (g1 >= 0 && g1 < DW_NUM_BODIES ? g1 : 0)];
+}
+
+// ---- joint-parallel phases.  Per-joint work that touches the Gym tensors runs over ITEMS (env, dof) = lane + 64 k of the
+// wave's 16 x 33 joints, so that a wave-instruction reads or writes consecutive addresses (the limb-per-lane mapping would
+// touch 64 different rows with 4-byte accesses); the item's lane reaches the owner's slot through the owner table. ----
+constexpr int ONI = (EPO * ND + 63) / 64;      // 5 items per lane
+struct JointItem { int ok, el, d, b, pos, env; };
+DQ_HD JointItem joint_item(const QHot &H, int wave_index, int num_envs, int lane, int k) {
+    JointItem it;
+    const int i = lane + 64 * k;
+    it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
+    const int eg = wave_index * EPO + it.el;
+    it.ok = (i < EPO * ND) && (eg < num_envs);
+    if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }
+    it.env = eg < num_envs ? eg : num_envs - 1;
+    it.pos = pcode(it.el, H.owner[it.b]);
+    return it;
+}
+// semi-implicit Euler of one joint from the slot the final pass left: q = q_old + dt qd, joint range (outward rate zeroed)
+DQ_HD void joint_integrate(OSlots &L, const JointItem &it, float dt, float q_old, float *q_out, float *qd_out) {
+    const F4 o = OQ_LD(it.b, 0, it.pos);        // {qlo, qd, qhi, *}
+    float qd = o.y, q = q_old + dt * qd;
+    if (q < o.x) { q = o.x; if (qd < 0) qd = 0; }
+    if (q > o.z) { q = o.z; if (qd > 0) qd = 0; }
+    *q_out = q; *qd_out = qd;
+}
+
+// Gym-boundary substep for 8 envs: tau [N,33], push [N,2] or nullptr (replaces dw::simulate_env)
+template <bool TERRAIN>
+DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const PhysParams &P, float friction, int num_envs,
+                        const DwBuffers &B, const float *tau, const float *push, int wave_index) {
+    if (wave_index * EPO >= num_envs) return;        // the second wave of the last workgroup may have no env at all
+    OLane X;
+    oct_lane_init(X, wave_index, num_envs, P, friction, B);
+    stage_hot(HW, QM);
+    const QHot &H = HW;
+    oct_lane_second_inertial(X, H, QM, B);
+    const int e = X.env, f = X.j & 1;
+    if (B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i]; }
+    float qkeep[ONI];
+    DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+        const JointItem it = joint_item(H, wave_index, num_envs, X.lane, k);
+        const size_t g = (size_t)ND * it.env + it.d;
+        const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
+        const float damp = B.dof_damping[g], arm = B.dof_armature[g];
+        qkeep[k] = q;
+        if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau[g] - damp * qd, arm + P.dt * damp);
+    }
+    wave_sync();
+    oct_substep<TERRAIN>(L, H, QM, M, P, X, B, push ? push[2 * e] : 0.0f, push ? push[2 * e + 1] : 0.0f, true);
+    wave_sync();
+    DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+        const JointItem it = joint_item(H, wave_index, num_envs, X.lane, k);
+        float q, qd;
+        joint_integrate(L, it, P.dt, qkeep[k], &q, &qd);
+        if (it.ok) {
+            const size_t g = (size_t)ND * it.env + it.d;
+            B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd;
+        }
+    }
+    if (X.valid && X.h == 0) {
+        if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
+        if (X.j < 2 && B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i] = X.warm[i]; }
+    }
+}
+
+}  // namespace dwo

@@ -1,0 +1,50 @@
+// dw_oct_kernels.hip -- the gfx950 entry points of the octet kernels (bodies: dw_oct_kernels.h, dw_oct.h, dw_oct_post.h) and
+// their launchers.  A translation unit of its own (default machine scheduler, like dw_quad_kernels.hip); linked into
+// libdyroswalk_hip.so next to dw_hip.hip, which owns the C-ABI.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "dw_params.h"
+#include "dw_oct_kernels.h"
+
+// The whole VecTask.step of 8 envs per wavefront, 8 lanes per env; a workgroup is two wavefronts that share one copy of the
+// hot tables and nothing else (grid = ceil(N / 16) workgroups of 128 threads).  40 KB of LDS per workgroup: 4 workgroups =
+// 8 waves per CU, TWO per SIMD, so a wave may use 256 registers (VGPRs + AGPRs; the register file is unified on gfx950).
+// (DwBuffers travels BY VALUE: see dw_quad_kernels.hip.)
+template <bool TERRAIN>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
+                   const float *actions, const float *noise, long long step) {
+    __shared__ dwo::OLds L;
+    const int w = (int)(threadIdx.x >> 6);
+    dwo::oct_step<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C, B, actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
+}
+// One physics substep at the Gym boundary, same layout.
+template <bool TERRAIN>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dw_k_simulate_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *tau,
+                       const float *push) {
+    __shared__ dwo::OLds L;
+    const int w = (int)(threadIdx.x >> 6);
+    dwo::oct_simulate<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, B, tau, push, (int)blockIdx.x * dwo::WPG + w);
+}
+
+namespace dwo {
+
+static int groups(int num_envs) { return (num_envs + EPO * WPG - 1) / (EPO * WPG); }
+
+void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step) {
+    const dim3 grid(groups(num_envs));
+    if (terrain) hipLaunchKernelGGL(dw_k_step_oct<true>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, mocap, actions, noise, step);
+    else hipLaunchKernelGGL(dw_k_step_oct<false>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, mocap, actions, noise, step);
+}
+void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                     const DwBuffers &B, const float *tau, const float *push) {
+    const dim3 grid(groups(num_envs));
+    if (terrain) hipLaunchKernelGGL(dw_k_simulate_oct<true>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, tau, push);
+    else hipLaunchKernelGGL(dw_k_simulate_oct<false>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, tau, push);
+}
+int oct_lds_bytes() { return (int)sizeof(OLds); }
+
+}  // namespace dwo

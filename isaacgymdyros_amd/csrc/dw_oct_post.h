@@ -1,0 +1,645 @@
+// dw_oct_post.h -- post_physics_step of DyrosDynamicWalk for the 8 envs of an octet wave (dw_oct.h), run at the end of the
+// fused step kernel (dw_oct_kernels.h) when the physics is done and the wave's 17 KB of body slots are free.  The same
+// fp32 expressions in the same order as dw_quad_post.h / dw_task.h regions Q1..Q6 and reset_region (fp contraction off), so
+// the reference goldens hold bit for bit; the lanes are mapped for 8 envs per wave: per-env scalar work on octet lanes
+// 0..3 (one group of reward terms each), per-word work over ITEMS (env, index) = lane + 64 k.
+// Reference: tasks/dyros_dynamic_walk.py:543-563 (post_physics_step), :581-596 (check_termination), :802-947 (reward),
+// :598-669,720-748 (reset_idx), :750-796 (observations); vec_task.py:519-733 (dof-property randomisation).
+#pragma once
+
+#include "dw_oct.h"
+#include "dw_task.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace dwo {
+
+
+using dw::TaskParams;
+
+// flat LDS layout of the post phase (float words of OSlots::slot)
+constexpr int PL_ES_STRIDE = DW_ES_WORDS;                // = the global layout: the 8 records move as one 11.9 KB run of 16-byte pieces
+constexpr int PL_ES = 0;                                 // [8][372] task records
+constexpr int PL_Q = EPO * DW_ES_WORDS;                  // [8][33][2] joint state
+constexpr int PL_ROOT = PL_Q + EPO * ND * 2;             // [8][13]
+constexpr int PL_NORMED = PL_ROOT + EPO * 13 + 16;       // [8][37] normalised observation of this step
+constexpr int PL_PS = PL_NORMED + EPO * DW_NUM_OBS1;     // [8][32] per-env scratch
+constexpr int PL_OBN = PL_PS + EPO * 32;                 // [2][37] observation mean, divisor (the hot tables belong to both waves of the workgroup)
+static_assert((PL_Q * 4) % 16 == 0, "post layout: the record block must end on a 16-byte boundary");
+static_assert(PL_OBN + 2 * DW_NUM_OBS1 <= NB * 4 * EPO * 4, "post layout does not fit the slot area");
+// per-env scratch words
+constexpr int PS_RTERM = 0;      // [16] reward terms, [14] = |orientation error|
+constexpr int PS_BAD = 16, PS_COLL = 17, PS_RESET = 18, PS_PROGRESS = 19, PS_RANDOMIZE = 20, PS_MASS = 21;
+constexpr int PS_FOOT = 22;      // [2][3] net contact force on the two sole bodies
+constexpr int PS_ORG = 28;       // [3] new tile origin (terrain curriculum)
+
+#define PQ_LF(i) LF[(i)]
+#define PQ_ES(el, off) LF[PL_ES + (el) * PL_ES_STRIDE + (off)]
+#define PQ_ESI(el, off) (*reinterpret_cast<int *>(&LF[PL_ES + (el) * PL_ES_STRIDE + (off)]))
+#define PQ_Q(el, d) LF[PL_Q + ((el) * ND + (d)) * 2]
+#define PQ_QD(el, d) LF[PL_Q + ((el) * ND + (d)) * 2 + 1]
+#define PQ_ROOT(el, i) LF[PL_ROOT + (el) * 13 + (i)]
+#define PQ_NORMED(el, k) LF[PL_NORMED + (el) * DW_NUM_OBS1 + (k)]
+#define PQ_PS(el, w) LF[PL_PS + (el) * 32 + (w)]
+#define PQ_PSI(el, w) (*reinterpret_cast<int *>(&LF[PL_PS + (el) * 32 + (w)]))
+
+// What the phases before post_physics_step produce for the task record, kept in registers until the record's LDS image
+// exists (no global round trip): per-env scalars on the quad's lanes 0 / 1, per-joint values on the item lanes.
+struct StepKeep {
+    int   midx; float tf0, tf1;                                        // lane 0: mocap row, target forces
+    int   pert_start, pert_on, pert_count, impulse, duration;          // lane 1: push schedule
+    float magnitude, phase;
+    int   simul_len;                                                   // all lanes: torque FIFO fill after the two substeps
+    float tgt[ONI], qn[ONI], qv[ONI];                                  // items: mocap target, encoder angle and rate
+    float atq[ONI];                                                    // items (env, leg joint): action torque of the step
+    float act[(EPO * DW_NUM_ACT + 63) / 64];                           // items (env, action): the clamped action
+};
+
+// Rows of NW consecutive floats at any 4-byte alignment, moved in 16-byte pieces (global_load/store_dwordx4 take dword-aligned
+// addresses): a 37-word history row is 10 requests instead of 37.
+struct __attribute__((packed, aligned(4))) U4 { float x, y, z, w; };
+template <int NW> DQ_HD void ld_row(const float *p, float (&v)[NW]) {
+    DQ_UNROLL for (int i = 0; i + 4 <= NW; i += 4) { const U4 t = *reinterpret_cast<const U4 *>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+    DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) v[i] = p[i];
+}
+template <int NW> DQ_HD void st_row(float *p, const float (&v)[NW]) {
+    DQ_UNROLL for (int i = 0; i + 4 <= NW; i += 4) { U4 t; t.x = v[i]; t.y = v[i + 1]; t.z = v[i + 2]; t.w = v[i + 3]; *reinterpret_cast<U4 *>(p + i) = t; }
+    DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) p[i] = v[i];
+}
+
+// torch.norm of 3 elements on the CPU reference (dw_task.h norm_t with n = 3: fused scalar tail)
+DQ_HD float norm3_t(float x, float y, float z) {
+    float b0 = fmaf(x, x, 0.0f);
+    b0 = fmaf(y, y, b0);
+    b0 = fmaf(z, z, b0);
+    return sqrtf(b0);
+}
+
+// Inputs from the physics part of the kernel: qv/qdv = the item lanes' new joint state (items as joint_item()), X.root,
+// X.coll / X.footT (collision flag of my bodies, net force on my sole body).  With physics frozen (tests) the state and
+// the contact forces are the Gym tensors as they are.
+template <bool TERRAIN>
+DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, const DwBuffers &B, const float *actions,
+                          const float *noise, long long step, int wave_index, OLane &X, const float (&qv)[ONI], const float (&qdv)[ONI],
+                          const StepKeep &KP) {
+    float *LF = reinterpret_cast<float *>(&L.slot[0][0]);
+    const int lane = X.lane, j = X.o, el = X.el, e = X.env;      // j: octet lane (0..7); lanes 4..7 idle in the per-env scalar groups
+    const int N = C.num_envs;
+    dw::TaskBuffers TB;
+    TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
+    const dw::StepCtx K = dw::make_step_ctx(C, TB, e);        // (nz of MY env; items build their own)
+    const float period = K.period;
+    const double cdt_d = K.cdt_d;
+    const int LFG = M.left_foot_gym, RFG = M.right_foot_gym;
+
+    // (the VecTask counters and the clock action of Q1, the per-joint constants of the reset path and the observation's mean /
+    //  scale, requested together with the records: one memory latency for all.  The hot tables of the physics are dead by now:
+    //  the observation constants go where they were.)
+    const long long q1_progress = B.progress_buf[e], q1_randomize = B.randomize_buf[e];
+    const float q1_mass = B.total_mass[e], q1_clock = dw::clamp_action(actions, e, 12);
+    const int lj = lane < ND ? lane : 0, lo1 = lane < DW_NUM_OBS1 ? lane : 0;
+    const float c_qinit = M.q_init[lj], c_qhi = M.qhi[lj], c_qlo = M.qlo[lj], c_damp = M.damp_nom[lj], c_arm = M.arm_nom[lj];
+    const float c_org0 = B.env_origins[3 * e], c_org1 = B.env_origins[3 * e + 1], c_org2 = B.env_origins[3 * e + 2];
+    float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
+    const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
+    // ---- stage: joint state, base state, contact summary, the 16 task records ----
+    DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPO * ND) { LF[PL_Q + 2 * i] = qv[k]; LF[PL_Q + 2 * i + 1] = qdv[k]; }
+    }
+    if (j == 0) {
+        DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = X.root[i];
+        PQ_PSI(el, PS_BAD) = 0; PQ_PSI(el, PS_COLL) = 0; PQ_PSI(el, PS_RESET) = 0;
+        PQ_PS(el, PS_ORG) = c_org0; PQ_PS(el, PS_ORG + 1) = c_org1; PQ_PS(el, PS_ORG + 2) = c_org2;
+    }
+    {
+        // 16 records = 1488 pieces of 16 bytes, contiguous in HBM and in LDS: every lane requests its 24 pieces before the
+        // first one is stored (one memory latency for the lot)
+        static_assert((EPO * DW_ES_WORDS) % 4 == 0 && (DW_ES_WORDS * 4) % 16 == 0, "record block must be a whole number of 16-byte pieces");
+        constexpr int NP = EPO * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
+        const int nvalid = N - wave_index * EPO;                          // envs of this wave that exist (>= 1)
+        const int np_ok = (nvalid >= EPO ? EPO : nvalid) * (DW_ES_WORDS / 4);
+        const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)wave_index * EPO * DW_ES_WORDS);
+        F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
+        constexpr int GRP = PER;
+        DQ_UNROLL for (int g8 = 0; g8 < PER; g8 += GRP) {
+            float tx[GRP], ty[GRP], tz[GRP], tw[GRP];
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) {
+                const int pi = lane + 64 * (g8 + u);
+                // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
+                const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
+                const F4 v = src[pi < NP ? ps : 0];
+                tx[u] = v.x; ty[u] = v.y; tz[u] = v.z; tw[u] = v.w;
+            }
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) { const int pi = lane + 64 * (g8 + u); if (pi < NP) dst[pi] = mk4(tx[u], ty[u], tz[u], tw[u]); }
+        }
+    }
+    if (lane < DW_NUM_OBS1) { OBN[lane] = c_om; OBN[DW_NUM_OBS1 + lane] = c_od; }
+    wave_sync();
+    // ---- the record fields this step has produced so far (dw_task.h P1..P3), from the lanes that hold them ----
+    if (j == 0) {
+        PQ_ESI(el, DW_ES_MOCAP_IDX) = KP.midx;
+        PQ_ES(el, DW_ES_TARGET_FORCE) = KP.tf0; PQ_ES(el, DW_ES_TARGET_FORCE + 1) = KP.tf1;
+        PQ_ESI(el, DW_ES_SIMUL_LEN) = KP.simul_len;
+    }
+    if (j == 1) {
+        PQ_ESI(el, DW_ES_PERT_START) = KP.pert_start; PQ_ESI(el, DW_ES_PERT_ON) = KP.pert_on; PQ_ESI(el, DW_ES_PERT_COUNT) = KP.pert_count;
+        PQ_ESI(el, DW_ES_IMPULSE) = KP.impulse; PQ_ESI(el, DW_ES_PERT_DURATION) = KP.duration;
+        PQ_ES(el, DW_ES_MAGNITUDE) = KP.magnitude; PQ_ES(el, DW_ES_PHASE) = KP.phase;
+    }
+    if (j < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * j + i) = X.warm[i]; }
+    DQ_UNROLL for (int k = 0; k < (EPO * DW_NUM_ACT + 63) / 64; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPO * DW_NUM_ACT) PQ_ES(i / DW_NUM_ACT, DW_ES_ACTIONS + (i - DW_NUM_ACT * (i / DW_NUM_ACT))) = KP.act[k];
+    }
+    DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPO * ND) {
+            const int ee = i / ND, d = i - ND * ee;
+            const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
+            PQ_ES(ee, DW_ES_TARGET_QPOS + d) = KP.tgt[k];
+            PQ_ES(ee, DW_ES_QPOS_NOISE + d) = KP.qn[k];
+            PQ_ES(ee, DW_ES_QPOS_PRE + d) = KP.qn[k];
+            PQ_ES(ee, DW_ES_QVEL_NOISE + d) = KP.qv[k];
+            if (d < 12) {
+                // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
+                const float at = KP.atq[k];
+                PQ_ES(ee, DW_ES_ACTION_TORQUE + d) = at;
+                float col[DW_ALOG_SLOTS];
+                DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(ee, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;
+                DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) PQ_ES(ee, DW_ES_ACTION_LOG + 12 * s2 + d) = col[s2];
+            }
+        }
+    }
+    wave_sync();
+    if (C.freeze_physics) {
+        // debug mode: simulate() was the identity, so the net contact forces are an input (dw_task.h step_env)
+        if (j == 0) {
+            const float *cf = B.contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { PQ_PS(el, PS_FOOT + i) = cf[3 * LFG + i]; PQ_PS(el, PS_FOOT + 3 + i) = cf[3 * RFG + i]; }
+        }
+        for (int i = lane; i < EPO * DW_NUM_BODIES; i += 64) {
+            const int ee = i / DW_NUM_BODIES, g = i - DW_NUM_BODIES * ee;
+            const int eg = wave_index * EPO + ee < N ? wave_index * EPO + ee : N - 1;
+            const float *cf = B.contact_forces + ((size_t)DW_NUM_BODIES * eg + g) * 3;
+            if (g != LFG && g != RFG && norm3_t(cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
+        }
+    } else {
+        if (X.coll) PQ_PSI(el, PS_COLL) = 1;
+        if (j < 2) { DQ_UNROLL for (int i = 0; i < 3; ++i) PQ_PS(el, PS_FOOT + 3 * j + i) = X.footT[i]; }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 42);
+    // ---- Q1: clocks, VecTask counters, non-finite guard ----
+    if (j == 0) {
+        const long long p = q1_progress, rbl = q1_randomize;
+        int rb = (int)(rbl > 0x7ffffffe ? 0x7ffffffe : rbl);
+        PQ_PS(el, PS_MASS) = q1_mass;
+        PQ_ES(el, DW_ES_EPI_LEN) += 1.0f;
+        float time = PQ_ES(el, DW_ES_TIME);
+        time = time + C.dt_policy_f;
+        time = time + C.clock_gain_f * q1_clock;
+        PQ_ES(el, DW_ES_TIME) = time;
+        if (X.valid) {
+            B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
+            B.progress_buf[e] = p + 1;
+        }
+        PQ_PSI(el, PS_PROGRESS) = (int)(p + 1);
+        rb = rb + 1;
+        if (X.valid) B.randomize_buf[e] = rb;
+        PQ_PSI(el, PS_RANDOMIZE) = rb;
+        bool bad = false;
+        DQ_UNROLL for (int i = 0; i < 13; ++i) bad = bad || !dw::finitef(PQ_ROOT(el, i));
+        if (bad) PQ_PSI(el, PS_BAD) = 1;
+    }
+    DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPO * ND && (!dw::finitef(LF[PL_Q + 2 * i]) || !dw::finitef(LF[PL_Q + 2 * i + 1]))) PQ_PSI(i / ND, PS_BAD) = 1;
+    }
+    wave_sync();
+    if (wave_any(PQ_PSI(el, PS_BAD) != 0)) {
+        if (j == 0 && PQ_PSI(el, PS_BAD)) {
+            DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = (i == 2) ? C.initial_height : (i == 6 ? 1.0f : 0.0f);
+            PQ_ESI(el, DW_ES_NAN_RESETS) += 1;
+            PQ_PSI(el, PS_COLL) = 0;
+            DQ_UNROLL for (int i = 0; i < 6; ++i) PQ_PS(el, PS_FOOT + i) = 0.0f;
+        }
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+            const int i = lane + 64 * k;
+            if (i < EPO * ND && PQ_PSI(i / ND, PS_BAD)) { LF[PL_Q + 2 * i] = 0.0f; LF[PL_Q + 2 * i + 1] = 0.0f; }
+        }
+        for (int i = lane; i < EPO * DW_NUM_BODIES * 3; i += 64) {
+            const int ee = i / (DW_NUM_BODIES * 3), w = i - DW_NUM_BODIES * 3 * ee, eg = wave_index * EPO + ee;
+            if (eg < N && PQ_PSI(ee, PS_BAD)) B.contact_forces[(size_t)DW_NUM_BODIES * 3 * eg + w] = 0.0f;
+        }
+        wave_sync();
+    }
+
+    DQ_STAMP(B, 43);
+    // ---- Q2: reward terms, one group per lane of the quad ----
+    {
+        // the three 33-element norms in torch's CPU order: 8 fused accumulators over elements a, a+8, a+16, a+24, added in
+        // order, then the 33rd element fused (dw_task.h Q2 / Q2b)
+        auto norm33 = [&](int which) {
+            float acc[8];
+            DQ_UNROLL for (int a = 0; a < 8; ++a) {
+                float s = 0.0f;
+                DQ_UNROLL for (int d0 = 0; d0 < 32; d0 += 8) {
+                    const int jj = d0 + a;
+                    const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
+                                  : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
+                    s = fmaf(x, x, s);
+                }
+                acc[a] = s;
+            }
+            float b0 = acc[0];
+            DQ_UNROLL for (int a = 1; a < 8; ++a) b0 = b0 + acc[a];
+            const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + 32) - PQ_Q(el, 32)
+                          : (which == 1 ? 0.0f - PQ_QD(el, 32) : PQ_QD(el, 32) - PQ_ES(el, DW_ES_PRE_QVEL + 32));
+            b0 = fmaf(x, x, b0);
+            const float n = sqrtf(b0);
+            const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
+            return coef * expf(rate * (n * n));
+        };
+        if (j == 0) {
+            const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
+            const float aerr = fabsf(dw::quat_err(qq));
+            PQ_PS(el, PS_RTERM + 14) = aerr;
+            PQ_PS(el, PS_RTERM + 0) = 0.3f * expf(-13.2f * aerr);
+            const float dv[2] = {PQ_ES(el, DW_ES_TARGET_VEL) - PQ_ROOT(el, 7), PQ_ES(el, DW_ES_TARGET_VEL + 1) - PQ_ROOT(el, 8)};
+            const float n = dw::norm_t(dv, 2);
+            PQ_PS(el, PS_RTERM + 6) = 0.3f * expf(-3.0f * (n * n));
+        }
+        if (j == 1) {
+            PQ_PS(el, PS_RTERM + 1) = norm33(0);
+            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_fn([&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }, 12));
+        }
+        if (j == 2) {
+            PQ_PS(el, PS_RTERM + 2) = norm33(1);
+            PQ_PS(el, PS_RTERM + 7) = norm33(2);
+        }
+        if (j == 3) {
+            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_fn([&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }, 12));
+            const float lf[3] = {PQ_PS(el, PS_FOOT), PQ_PS(el, PS_FOOT + 1), PQ_PS(el, PS_FOOT + 2)};
+            const float rf[3] = {PQ_PS(el, PS_FOOT + 3), PQ_PS(el, PS_FOOT + 4), PQ_PS(el, PS_FOOT + 5)};
+            const float lfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 1), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 2)};
+            const float rfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 3), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 4), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 5)};
+            float dl[3], dr[3];
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
+            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_t(dl, 3) + dw::norm_t(dr, 3)));
+            const bool lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
+            const int idx = PQ_ESI(el, DW_ES_MOCAP_IDX);
+            const bool DSP = (3300 <= idx && idx < 3600) || (idx < 300) || (1500 <= idx && idx < 2100);
+            const bool RSSP = 300 <= idx && idx < 1500;
+            const bool LSSP = 2100 <= idx && idx < 3300;
+            float fcr = 0.0f;
+            if (DSP && rcon && lcon) fcr = 0.2f;
+            if (RSSP && rcon && !lcon) fcr = 0.2f;
+            if (LSSP && !rcon && lcon) fcr = 0.2f;
+            PQ_PS(el, PS_RTERM + 8) = fcr;
+            PQ_ES(el, DW_ES_CRS) = PQ_ES(el, DW_ES_CRS) + fcr;
+            PQ_PS(el, PS_RTERM + 10) = 0.0f;
+            const float tm = PQ_PS(el, PS_MASS);
+            const float thr = (float)(1.4 * 9.81) * tm;
+            const bool th = (lf[2] > thr) || (rf[2] > thr);
+            PQ_PS(el, PS_RTERM + 11) = th ? -0.2f * 1.0f : 0.0f;
+            const float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
+            const float pen = 0.1f * expf(-0.007f * (dw::norm_t(&cl, 1) + dw::norm_t(&cr, 1)));
+            PQ_PS(el, PS_RTERM + 3) = th ? pen : 0.1f * 1.0f;
+            const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
+            const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
+            PQ_PS(el, PS_RTERM + 12) = dd ? -0.05f * 1.0f : 0.0f;
+            const float ws = dw::divs(C.gpu_div, tm, 104.48);
+            const float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * PQ_ES(el, DW_ES_TARGET_FORCE)));
+            const float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * PQ_ES(el, DW_ES_TARGET_FORCE + 1)));
+            PQ_PS(el, PS_RTERM + 13) = tl + tr;
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 44);
+    // ---- Q3: total reward, termination ----
+    {
+        const bool collision = PQ_PSI(el, PS_COLL) != 0;
+        const float aerr = PQ_PS(el, PS_RTERM + 14);
+        // stacked_rewards: 15 words per env, the quad writes them (lane j takes 4 j .. 4 j + 3)
+        if (X.valid) {
+            DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                const int l = 4 * j + i;
+                if (l < 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
+                if (l == 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + 14] = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
+            }
+        }
+        if (j == 0) {
+            const float *r = &PQ_PS(el, PS_RTERM);
+            float total = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + r[10] + r[11] + r[12] + r[13];
+            if (collision) total = 1.0f * C.death_cost;
+            if (aerr > 0.5f) total = 1.0f * C.death_cost;
+            int reset = aerr > 0.5f ? 1 : 0;
+            if ((float)PQ_PSI(el, PS_PROGRESS) >= C.max_episode_length - 1.0f) reset = 1;
+            if (collision) reset = 1;
+            if (PQ_PSI(el, PS_BAD)) reset = 1;
+            if (X.valid) { B.rew_buf[e] = total; B.reset_buf[e] = reset; }
+            PQ_PSI(el, PS_RESET) = reset;
+            float ret = PQ_ES(el, DW_ES_EPI_RETURN) + total;
+            if (reset) {
+                PQ_ES(el, DW_ES_LAST_RETURN) = ret;
+                PQ_ESI(el, DW_ES_EPISODES) += 1;
+                ret = 0.0f;
+            }
+            PQ_ES(el, DW_ES_EPI_RETURN) = ret;
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 45);
+    // ---- reset_idx for the envs that ended (dw_task.h reset_region) ----
+    const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
+    if (any_reset) {
+        const bool mine = PQ_PSI(el, PS_RESET) != 0;
+        if (C.terrain_curriculum && j == 0 && mine) {
+            const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
+            const float distance = dw::norm_t(d, 2);
+            const bool move_up = distance > C.terrain_half_length;
+            const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
+            const float need = dw::norm_t(tv, 2) * C.max_episode_length_s * 0.5f;
+            const bool move_down = (distance < need) && !move_up;
+            long long lvl = B.terrain_levels[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
+            if (lvl >= C.terrain_num_levels) {
+                int k = (int)(dw::noise_word(K.nz, DW_NZ_TERRAIN_LVL) * (float)C.terrain_num_levels);
+                if (k > C.terrain_num_levels - 1) k = C.terrain_num_levels - 1;
+                lvl = k;
+            } else if (lvl < 0) lvl = 0;
+            long long ty = B.terrain_types[e];
+            ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
+            const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + ty) * 3;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (X.valid) B.env_origins[3 * e + i] = o; }
+            if (X.valid) B.terrain_levels[e] = lvl;
+        }
+        wave_sync();
+        // one pass per env that ended (a wave-uniform loop over the ballot: resets are rare, and a pass over all 16 x 33
+        // items with most lanes idle cost nine times as much): lane = joint
+        for (unsigned long long rbits = wave_ballot(j == 0 && mine); rbits != 0ull; rbits &= rbits - 1ull) {
+            const int ee = __builtin_ctzll(rbits) >> 3, l = lane < ND ? lane : 0;
+            const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
+            if (lane < ND) {
+                dw::NoiseSrc nz = K.nz;
+                nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+                const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(ee, PS_RANDOMIZE) >= 1;
+                if (do_dr && C.dr_dof) {
+                    const float ud = dw::noise_word(nz, DW_NZ_DR_DAMP + l), ua = dw::noise_word(nz, DW_NZ_DR_ARM + l);
+                    const float sd = C.dr_damp[0] + ud * (C.dr_damp[1] - C.dr_damp[0]);
+                    const float sa = C.dr_arm[0] + ua * (C.dr_arm[1] - C.dr_arm[0]);
+                    if (egr < N) { B.dof_damping[(size_t)ND * eg + l] = c_damp + sd; B.dof_armature[(size_t)ND * eg + l] = c_arm * sa; }
+                }
+                PQ_ES(ee, DW_ES_QPOS_NOISE + l) = c_qinit;
+                PQ_ES(ee, DW_ES_QPOS_PRE + l) = c_qinit;
+                PQ_ES(ee, DW_ES_QVEL_NOISE + l) = 0.0f;
+                PQ_ES(ee, DW_ES_PRE_QVEL + l) = 0.0f;
+                PQ_Q(ee, l) = fmaxf(fminf(c_qinit, c_qhi), c_qlo);
+                PQ_QD(ee, l) = 0.0f;
+                if (l < 12) {
+                    PQ_ES(ee, DW_ES_QPOS_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QPOS_BIAS + l) * 6.28f, 100.0) - (float)(3.14 / 100);
+                    PQ_ES(ee, DW_ES_MOTOR_SCALE + l) = dw::noise_word(nz, DW_NZ_MOTOR + l) * 0.4f + 0.8f;
+                    PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = 0.0f;
+                }
+                if (l < 3) PQ_ES(ee, DW_ES_QUAT_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QUAT_BIAS + l) * 6.28f, 150.0) - (float)(3.14 / 150);
+                if (l < 24) PQ_ES(ee, DW_ES_WARM + l) = 0.0f;
+                if (l < 6) PQ_ES(ee, DW_ES_FOOT_FORCE_PRE + l) = PQ_PS(ee, PS_FOOT + l);
+                if (l >= 16 && l < 29) {
+                    const int ii = l - 16;
+                    float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
+                    if (ii < 3) v += PQ_PS(ee, PS_ORG + ii);          // (the env's origin; the curriculum has put the new one there)
+                    if (ii < 2 && C.custom_origins) v += 2.0f * dw::noise_word(nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
+                    PQ_ROOT(ee, ii) = v;
+                }
+            }
+            // torque FIFO and action ring, zeroed
+            for (int i = lane; i < DW_ALOG_SLOTS * 12; i += 64) PQ_ES(ee, DW_ES_ACTION_LOG + i) = 0.0f;
+            if (egr < N) { for (int i = lane; i < DW_HIST_SLOTS * DW_NUM_ACT; i += 64) B.action_history[(size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + i] = 0.0f; }
+        }
+        // per-env scalars (dw_task.h reset_region, lane 40)
+        if (j == 0 && mine) {
+            const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
+            if (do_dr) {
+                if (C.dr_friction && X.valid) {
+                    const float uf = dw::noise_word(K.nz, DW_NZ_DR_FRIC);
+                    B.friction_scale[e] = C.dr_fric[0] + uf * (C.dr_fric[1] - C.dr_fric[0]);
+                }
+                if (X.valid) B.randomize_buf[e] = 0;
+            }
+            const float vel_mag = dw::noise_word(K.nz, DW_NZ_TARGET_VEL) * 0.8f;
+            PQ_ES(el, DW_ES_TARGET_VEL) = vel_mag * 1.0f;
+            PQ_ES(el, DW_ES_TARGET_VEL + 1) = vel_mag * 0.0f;
+            PQ_ESI(el, DW_ES_INIT_MOCAP) = dw::noise_word(K.nz, DW_NZ_INIT_MOCAP) > 0.5f ? 0 : 1800;
+            PQ_ES(el, DW_ES_TIME) = 0.0f;
+            if (X.valid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
+            int k = (int)(dw::noise_word(K.nz, DW_NZ_DELAY) * 4.0f);
+            if (k > 3) k = 3;
+            PQ_ESI(el, DW_ES_DELAY_IDX) = 2 + k;
+            PQ_ES(el, DW_ES_CRM) = PQ_ES(el, DW_ES_CRS) / PQ_ES(el, DW_ES_EPI_LEN);
+            PQ_ES(el, DW_ES_CRS) = 0.0f;
+            PQ_ESI(el, DW_ES_SIMUL_LEN) = 0;
+            PQ_ES(el, DW_ES_EPI_LEN_LOG) = PQ_ES(el, DW_ES_EPI_LEN);
+            PQ_ES(el, DW_ES_EPI_LEN) = 0.0f;
+            PQ_ESI(el, DW_ES_PERT_COUNT) = 0;
+            PQ_ESI(el, DW_ES_PERT_ON) = 0;
+            int kt = (int)(dw::noise_word(K.nz, DW_NZ_PTIMING) * 2000.0f);
+            if (kt > 1999) kt = 1999;
+            PQ_ESI(el, DW_ES_PERT_TIMING) = kt;
+        }
+        wave_sync();
+    }
+
+    DQ_STAMP(B, 46);
+    // ---- Q5, first half: request the history taps now, use them after Q4 (one memory latency, spent computing the new
+    //      observation).  A lane takes ROWS (env, tap): 37 observation words and 13 action words, consecutive in the rings and
+    //      in obs_buf, so a row is 10 + 4 requests with constant offsets and no per-word index arithmetic.  The newest
+    //      observation tap is this step's own (Q4, still in LDS) and is not read back. ----
+    constexpr int NTAP = DW_NUM_HIS - 1, NPAIR = EPO * NTAP, RPL = (NPAIR + 63) / 64;
+    static_assert((DW_NUM_SKIP * DW_NUM_HIS) % DW_HIST_SLOTS == 0, "the last observation tap must be the newest slot");
+    float tapo[RPL][DW_NUM_OBS1], tapa[RPL][DW_NUM_ACT];
+    DQ_UNROLL for (int r = 0; r < RPL; ++r) {
+        const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
+        const int ee = pc / NTAP, tap = pc - NTAP * ee;
+        const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
+        const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+        const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
+        ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, tapo[r]);
+        ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, tapa[r]);
+    }
+    // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
+    //      expensive functions (atan2, sincos, the noise draw) is executed by one or two wave passes, not by all ten ----
+    {
+        auto finish = [&](int ee, int l, float o) {
+            const int egr = wave_index * EPO + ee;
+            const float nrm = (o - OBN[l]) / OBN[DW_NUM_OBS1 + l];
+            PQ_NORMED(ee, l) = nrm;
+            if (egr < N) {
+                float *oh = B.obs_history + (size_t)egr * DW_HIST_SLOTS * DW_NUM_OBS1;
+                if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {
+                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2) oh[s2 * DW_NUM_OBS1 + l] = nrm;
+                } else {
+                    oh[PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l] = nrm;
+                }
+            }
+        };
+        // joint angles / rates of the legs with their biases, target velocity: 26 plain entries per env
+        for (int i = lane; i < EPO * 26; i += 64) {
+            const int ee = i / 26, t = i - 26 * ee;
+            const int l = t < 24 ? 3 + t : 29 + (t - 24);
+            float o;
+            if (l < 15) o = PQ_ES(ee, DW_ES_QPOS_NOISE + (l - 3)) + PQ_ES(ee, DW_ES_QPOS_BIAS + (l - 3));
+            else if (l < 27) o = PQ_ES(ee, DW_ES_QVEL_NOISE + (l - 15));
+            else o = PQ_ES(ee, DW_ES_TARGET_VEL + (l - 29));
+            finish(ee, l, o);
+        }
+        // Euler angles of the base (quat2euler / mat2euler, python/isaacgym/torch_utils.py:227-273): 3 per env
+        if (lane < EPO * 3) {
+            const int ee = lane / 3, l = lane - 3 * ee;
+            const float x = PQ_ROOT(ee, 3), y = PQ_ROOT(ee, 4), z = PQ_ROOT(ee, 5), w = PQ_ROOT(ee, 6);
+            const float m00 = w * w + x * x - y * y - z * z;
+            const float m01 = 2 * x * y - 2 * w * z;
+            const float m10 = 2 * x * y + 2 * w * z;
+            const float m11 = w * w - x * x + y * y - z * z;
+            const float m20 = 2 * x * z - 2 * w * y;
+            const float m21 = 2 * y * z + 2 * w * x;
+            const float m22 = w * w - x * x - y * y + z * z;
+            const float cy = sqrtf(m00 * m00 + m10 * m10);
+            const bool cond = cy > (float)(2.220446049250313e-16 * 4);
+            const float num = l == 0 ? m21 : (l == 1 ? -m20 : (cond ? m10 : -m01));
+            const float den = l == 0 ? m22 : (l == 1 ? cy : (cond ? m00 : m11));
+            float o = atan2f(num, den);
+            if (l == 0 && !cond) o = 0.0f;
+            o = o + PQ_ES(ee, DW_ES_QUAT_BIAS + l);
+            finish(ee, l, o);
+        }
+        // gait phase as sin / cos: 2 per env
+        if (lane < EPO * 2) {
+            const int ee = lane >> 1, l = 27 + (lane & 1);
+            const float time2idx = dw::divs(C.gpu_div, dw::remainder_t(PQ_ES(ee, DW_ES_TIME), period), cdt_d);
+            const float phase = dw::divs(C.gpu_div, dw::remainder_t((float)PQ_ESI(ee, DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
+            const float ang = (float)(2 * 3.14159265358979) * phase;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            finish(ee, l, l == 27 ? sn : cs);
+        }
+        // base velocity with its noise draw: 6 per env
+        for (int i = lane; i < EPO * 6; i += 64) {
+            const int ee = i / 6, l = 31 + (i - 6 * ee);
+            const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
+            dw::NoiseSrc nz = K.nz;
+            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+            finish(ee, l, PQ_ROOT(ee, 7 + (l - 31)) + (dw::noise_word(nz, DW_NZ_VEL + (l - 31)) * 0.05f - 0.025f));
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 47);
+    // ---- Q5, second half: the 487-d observation buffer.  Rows requested above go out as they came (an env that was just
+    //      reset shows its first observation in every tap and zeros in the action taps, tasks/dyros_dynamic_walk.py:655-669);
+    //      the newest tap is copied from LDS, items (env, word). ----
+    {
+        float *ob = B.obs_buf + (size_t)wave_index * EPO * DW_NUM_OBS;
+        DQ_UNROLL for (int r = 0; r < RPL; ++r) {
+            const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
+            const int ee = pc / NTAP, tap = pc - NTAP * ee;
+            const bool ok = p < NPAIR && wave_index * EPO + ee < N;
+            const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
+            if (wave_any(fill)) {
+                if (fill) { DQ_UNROLL for (int k = 0; k < DW_NUM_OBS1; ++k) tapo[r][k] = PQ_NORMED(ee, k); }
+            }
+            const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD);
+            const bool own = ((newest + 1) % DW_HIST_SLOTS + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS == newest;    // (never, with 2 x 10 slots)
+            if (wave_any(rs || own)) {
+                if (rs) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = 0.0f; }
+                else if (own) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = PQ_ES(ee, DW_ES_ACTIONS + k); }
+            }
+            if (ok) {
+                st_row(ob + ee * DW_NUM_OBS + tap * DW_NUM_OBS1, tapo[r]);
+                st_row(ob + ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + tap * DW_NUM_ACT, tapa[r]);
+            }
+        }
+        DQ_UNROLL for (int u = 0; u < (EPO * DW_NUM_OBS1 + 63) / 64; ++u) {
+            const int i = lane + 64 * u;
+            if (i < EPO * DW_NUM_OBS1) {
+                const int ee = i / DW_NUM_OBS1, k = i - DW_NUM_OBS1 * ee;
+                if (wave_index * EPO + ee < N) ob[ee * DW_NUM_OBS + NTAP * DW_NUM_OBS1 + k] = PQ_NORMED(ee, k);
+            }
+        }
+    }
+
+    DQ_STAMP(B, 48);
+    // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
+    DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < EPO * ND) {
+            const int ee = i / ND, l = i - ND * ee;
+            PQ_ES(ee, DW_ES_PRE_QVEL + l) = PQ_QD(ee, l);
+            if (l < 12) PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = PQ_ES(ee, DW_ES_ACTION_TORQUE + l);
+            if (l < DW_NUM_ACT) PQ_ES(ee, DW_ES_ACTIONS_PRE + l) = PQ_ES(ee, DW_ES_ACTIONS + l);
+            if (l >= 20 && l < 26) PQ_ES(ee, DW_ES_FOOT_FORCE_PRE + (l - 20)) = PQ_PS(ee, PS_FOOT + (l - 20));
+        }
+    }
+    wave_sync();
+    if (j == 0) {
+        PQ_ESI(el, DW_ES_HIST_HEAD) = (PQ_ESI(el, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+        if (C.perturb && !C.force_perturb_start && X.valid) {
+            const float eln = PQ_ES(el, DW_ES_EPI_LEN_LOG), cm = PQ_ES(el, DW_ES_CRM);
+            const int bk = e % dw::GATE_BUCKETS;
+            long long de, dc = 0;
+            if (dw::finitef(eln) && dw::finitef(cm)) { de = (long long)eln; dc = (long long)llrintf(cm * 4294967296.0f); }
+            else de = -((long long)1 << 62);
+            atomic_add_u64(reinterpret_cast<unsigned long long *>(&K.gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2]), (unsigned long long)de);
+            atomic_add_u64(reinterpret_cast<unsigned long long *>(&K.gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2 + 1]), (unsigned long long)dc);
+            K.gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2] = 0;
+            K.gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2 + 1] = 0;
+        }
+    }
+    wave_sync();
+
+    DQ_STAMP(B, 49);
+    // ---- write back: the records (contiguous), and the Gym state of the envs whose state the task changed ----
+    {
+        constexpr int NP = EPO * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
+        const int nvalid = N - wave_index * EPO;
+        const int np_ok = (nvalid >= EPO ? EPO : nvalid) * (DW_ES_WORDS / 4);
+        F4 *dstg = reinterpret_cast<F4 *>(B.env_state + (size_t)wave_index * EPO * DW_ES_WORDS);
+        const F4 *srcl = reinterpret_cast<const F4 *>(LF + PL_ES);
+        DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
+        const bool changed = PQ_PSI(el, PS_RESET) != 0 || PQ_PSI(el, PS_BAD) != 0;
+        if (wave_any(changed)) {
+            if (j == 0 && changed && X.valid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
+            DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+                const int i = lane + 64 * k;
+                if (i < EPO * ND) {
+                    const int ee = i / ND, eg = wave_index * EPO + ee;
+                    if (eg < N && (PQ_PSI(ee, PS_RESET) || PQ_PSI(ee, PS_BAD))) {
+                        B.dof_state[((size_t)ND * wave_index * EPO) * 2 + 2 * i] = LF[PL_Q + 2 * i];
+                        B.dof_state[((size_t)ND * wave_index * EPO) * 2 + 2 * i + 1] = LF[PL_Q + 2 * i + 1];
+                    }
+                }
+            }
+        }
+    }
+    DQ_STAMP(B, 50);
+}
+
+#undef PQ_LF
+#undef PQ_ES
+#undef PQ_ESI
+#undef PQ_Q
+#undef PQ_QD
+#undef PQ_ROOT
+#undef PQ_NORMED
+#undef PQ_PS
+#undef PQ_PSI
+
+}  // namespace dwo
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

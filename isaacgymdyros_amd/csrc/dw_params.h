@@ -15,7 +15,7 @@ inline const char *check_config(const DwConfig *c) {
         return "terrain: rows/cols >= 2 and positive scales required";
     if (c->terrain_curriculum && (c->terrain_num_levels < 1 || c->terrain_num_types < 1))
         return "terrain curriculum: num_levels and num_types must be positive";
-    if (c->pipeline < 0 || c->pipeline > 2) return "pipeline must be 0 (default), 1 (fused wave-per-env) or 2 (split, quad physics)";
+    if (c->pipeline < 0 || c->pipeline > 3) return "pipeline must be 0 (default), 1 (wave per env), 2 (quad: 4 lanes per env) or 3 (octet: 8 lanes per env)";
     return nullptr;
 }
 

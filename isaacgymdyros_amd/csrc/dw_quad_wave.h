@@ -10,6 +10,7 @@
 // Cross-lane vocabulary (all of it must be called in wave-uniform control flow):
 //   quad_bcast<J>(x)       value of x in lane J of the caller's quad            (v_mov_dpp quad_perm:[J,J,J,J])
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
+//   oct_xor4(x)            value of x in lane (l ^ 4)  (octet kernels)           (row_shl:4 / row_shr:4, complementary bank masks)
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
 //   wave_ballot(p)         64-bit mask of p over the lanes, the same in every lane (v_cmp into an SGPR pair)
 //   wave_sync_global()     as wave_sync, for global memory too (workgroup-scope release / acquire).
@@ -29,7 +30,7 @@
 #define DQ_OPAQUE(i) asm volatile("" : "+v"(i))
 namespace dwq {
 
-DQ_HD int lane_id() { return (int)threadIdx.x; }
+DQ_HD int lane_id() { return (int)(threadIdx.x & 63u); }      // (the octet kernels run two waves per workgroup)
 
 template <int CTRL> DQ_HD float dpp_quad(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
@@ -37,6 +38,15 @@ template <int CTRL> DQ_HD float dpp_quad(float x) {
 template <int J> DQ_HD float quad_bcast(float x) { return dpp_quad<J | (J << 2) | (J << 4) | (J << 6)>(x); }
 DQ_HD float quad_xor1(float x) { return dpp_quad<1 | (0 << 2) | (3 << 4) | (2 << 6)>(x); }
 DQ_HD float quad_xor2(float x) { return dpp_quad<2 | (3 << 2) | (0 << 4) | (1 << 6)>(x); }
+// value of x in lane (l ^ 4): the other quad of an 8-lane octet (dw_oct.h).  gfx9 DPP has no xor across quads; the low quads
+// of a 16-lane row (banks 0, 2) take the value 4 lanes up (row_shl:4), the high quads (banks 1, 3) 4 lanes down (row_shr:4):
+// two moves with complementary bank masks.
+DQ_HD float oct_xor4(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    int r = __builtin_amdgcn_update_dpp(xi, xi, 0x104, 0xF, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);
+    return __builtin_bit_cast(float, r);
+}
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
 DQ_HD void wave_sync() {
@@ -199,6 +209,7 @@ static inline float emu_xchg(float x, int src_lane) {
 template <int J> DQ_HD float quad_bcast(float x) { return emu_xchg(x, (g_emu->cur & ~3) | J); }
 DQ_HD float quad_xor1(float x) { return emu_xchg(x, g_emu->cur ^ 1); }
 DQ_HD float quad_xor2(float x) { return emu_xchg(x, g_emu->cur ^ 2); }
+DQ_HD float oct_xor4(float x) { return emu_xchg(x, g_emu->cur ^ 4); }
 DQ_HD bool wave_any(bool p) {
     WaveEmu *e = g_emu;
     const int l = e->cur, par = (int)(e->nsync[l] & 1);

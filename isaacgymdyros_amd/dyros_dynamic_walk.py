@@ -136,7 +136,7 @@ class DyrosDynamicWalk(VecTask):
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
         # which kernels: 0/2 = quad kernels, 4 lanes per env, one launch per step (default), 1 = wave-per-env kernels of round 1
-        c.pipeline = {"auto": 0, "fused": 1, "quad": 2}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
+        c.pipeline = {"auto": 0, "fused": 1, "quad": 2, "oct": 3}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
         tc = self.terrain_cfg
         c.terrain = int(self.custom_origins)
         c.custom_origins = int(self.custom_origins)
@@ -356,10 +356,10 @@ class DyrosDynamicWalk(VecTask):
     def kernel_info(self) -> dict:
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
         profiles/ carry the same name)."""
-        fused = int(self._ccfg.pipeline) == 1
-        name = "dw_k_step" if fused else "dw_k_step_quad"
-        return {"kernels": name, "pipeline": "fused wave-per-env" if fused else "quad (4 lanes per env)",
-                "launches_per_step": 1}
+        pl = int(self._ccfg.pipeline) or 2
+        name = {1: "dw_k_step", 2: "dw_k_step_quad", 3: "dw_k_step_oct"}[pl]
+        desc = {1: "wave per env", 2: "quad (4 lanes per env, 16 envs per wave)", 3: "octet (8 lanes per env, 8 envs per wave, 2 waves per SIMD)"}[pl]
+        return {"kernels": name, "pipeline": desc, "launches_per_step": 1}
 
     def simulate(self, tau: torch.Tensor, push_xy: torch.Tensor = None):
         """One physics substep at the Gym boundary: set_dof_actuation_force_tensor + apply_rigid_body_force_tensors

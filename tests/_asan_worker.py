@@ -6,8 +6,9 @@ import numpy as np
 import emul_backend, replay as R
 from isaacgymdyros_amd import abi
 from isaacgymdyros_amd.task_constants import load_task_constants
-QUAD = len(sys.argv) > 1 and sys.argv[1] == 'quad'
-stem = 'libdw_emul_quad' if QUAD else 'libdw_emul'
+KIND = sys.argv[1] if len(sys.argv) > 1 else ''
+QUAD = {'': False, 'quad': True, 'oct': 'oct'}[KIND]
+stem = {'': 'libdw_emul', 'quad': 'libdw_emul_quad', 'oct': 'libdw_emul_oct'}[KIND]
 lib = C.CDLL(os.path.join(HERE, 'emul', '_build', stem + '_asan.so'))
 emul_backend._cache[stem + '.so'] = (lib, abi.declare(lib, 'dwe_'))
 tc = load_task_constants()

@@ -1,0 +1,140 @@
+// dw_emul_oct.cpp -- host emulation of the OCTET kernels (isaacgymdyros_amd/csrc/dw_oct.h, dw_oct_kernels.h, dw_oct_post.h): the exact
+// kernel source, one fiber per lane, 64 fibers per wave, switching at every cross-lane operation (dw_quad_wave.h).
+// TEST INFRASTRUCTURE ONLY: nothing in isaacgymdyros_amd/ can load it.  Exports the C-ABI with the prefix dwe_ and HOST
+// pointers, like dw_emul.cpp does for the wave-per-env kernels.
+#define DWQ_EMUL_IMPLEMENTATION
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../isaacgymdyros_amd/csrc/dw_params.h"
+#include "../../isaacgymdyros_amd/csrc/dw_oct_kernels.h"
+
+struct DwHandle {
+    DwConfig cfg;
+    dw::DevModel model;
+    dwq::QuadModel qmodel;
+    dw::DevParams dp;
+    float *mocap;
+    int bound;
+};
+
+static char g_err[256] = "";
+static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+
+namespace {
+struct WaveArgs { DwHandle *h; const float *a0; const float *a1; long long step; int wave; int kind; dwo::OLds *lds; dw::TaskLds *tlds; };
+void wave_body(void *p, int) {
+    WaveArgs *w = (WaveArgs *)p;
+    DwHandle *h = w->h;
+    switch (w->kind) {
+    case 0:
+        if (h->cfg.terrain) dwo::oct_simulate<true>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
+        else dwo::oct_simulate<false>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
+        break;
+    case 1:
+        if (h->cfg.terrain) dwo::oct_step<true>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else dwo::oct_step<false>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        break;
+    }
+}
+int run_waves(DwHandle *h, int kind, const float *a0, const float *a1, long long step) {
+    // a workgroup = two waves with one copy of the hot tables; the waves are independent (each stages the tables itself), so
+    // they run one after the other here.  Odd env counts leave the last workgroup's second wave without envs: it still runs.
+    const int nw = (h->cfg.num_envs + dwo::EPO * dwo::WPG - 1) / (dwo::EPO * dwo::WPG) * dwo::WPG;
+    dwo::OLds *lds = (dwo::OLds *)aligned_alloc(64, (sizeof(dwo::OLds) + 63) / 64 * 64);
+    int rc = DW_OK;
+    for (int w = 0; w < nw && rc == DW_OK; ++w) {
+        if ((w & 1) == 0) memset(lds, 0xff, sizeof(*lds));           // NaN-fill per workgroup: a read of a never-written slot poisons the result
+        WaveArgs a{h, a0, a1, step, w, kind, lds, nullptr};
+        if (!dwq::run_wave(wave_body, &a)) rc = fail(DW_ESTATE, "octet emulation: lanes disagree on the number of cross-lane operations");
+    }
+    free(lds);
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int dwe_abi_version(void) { return DW_ABI_VERSION; }
+const char *dwe_last_error(void) { return g_err; }
+void dwe_default_config(DwConfig *c) { dw::default_config(c); }
+
+int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task, DwHandle **out) {
+    if (!cfg || !model || !out) return fail(DW_EINVAL, "dwe_create: null argument");
+    if (const char *m = dw::check_config(cfg)) return fail(DW_EINVAL, m);
+    DwHandle *h = (DwHandle *)calloc(1, sizeof(DwHandle));
+    if (!h) return fail(DW_ENOMEM, "out of memory");
+    h->cfg = *cfg;
+    const char *err = "";
+    int rc = dw::build_devmodel(model, task, &h->model, &err);
+    if (rc == DW_OK) rc = dwq::build_quadmodel(&h->model, model, &h->qmodel, &err);
+    if (rc) { free(h); return fail(rc, err); }
+    h->dp.C = dw::make_task_params(cfg);
+    if (task) {
+        h->mocap = (float *)malloc(sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
+        memcpy(h->mocap, task->mocap, sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
+        h->dp.mocap = h->mocap;
+    }
+    *out = h;
+    return DW_OK;
+}
+int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h); return DW_OK; }
+int dwe_bind(DwHandle *h, const DwBuffers *b) {
+    if (!h || !b) return fail(DW_EINVAL, "dwe_bind: null argument");
+    if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
+    if (const char *m = dw::check_terrain_buffers(&h->cfg, b)) return fail(DW_EINVAL, m);
+    h->dp.B = *b; h->bound = 1;
+    h->dp.C.phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
+    return DW_OK;
+}
+int dwe_simulate(DwHandle *h, const float *tau, const float *push_xy, void *) {
+    if (!h || !h->bound) return fail(DW_ESTATE, "buffers not bound");
+    if (!tau) return fail(DW_EINVAL, "tau is null");
+    if (h->cfg.debug_freeze_physics) return DW_OK;
+    return run_waves(h, 0, tau, push_xy, 0);
+}
+int dwe_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *) {
+    if (!h || !h->bound || !h->model.has_task) return fail(DW_ESTATE, "not ready");
+    if (const char *m = dw::check_buffers(&h->dp.B, true)) return fail(DW_ESTATE, m);
+    if (!actions) return fail(DW_EINVAL, "actions is null");
+    dw::TaskBuffers T;
+    T.b = &h->dp.B; T.actions = actions; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
+    dw::TaskLds *S = new dw::TaskLds;
+    dw::Wave w;
+    int rc = DW_OK;       // (pre_physics_step runs inside the quad kernel: quad_physics_step<.., PRE = true>)
+    rc = run_waves(h, 1, actions, noise, step_index);     // with physics frozen it still runs the actuator and encoder models
+    // (post_physics_step runs inside the quad kernel too: quad_physics_step<.., POST = true>)
+    delete S;
+    return rc;
+}
+int dwe_reset_idx(DwHandle *h, const int32_t *ids, int32_t n, const float *noise, int64_t step_index, void *) {
+    if (!h || !h->bound || !h->model.has_task) return fail(DW_ESTATE, "not ready");
+    if (n < 0 || (n > 0 && !ids)) return fail(DW_EINVAL, "bad env id list");
+    dw::TaskBuffers T;
+    T.b = &h->dp.B; T.actions = nullptr; T.noise = noise; T.mocap = h->mocap; T.step = step_index;
+    dw::TaskLds *S = new dw::TaskLds;
+    dw::Wave w;
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= h->cfg.num_envs) { delete S; return fail(DW_EINVAL, "env id out of range"); }
+        memset((void *)S, 0xff, sizeof(*S));      // NaN-fill per id: nothing may be read that this call did not load
+        dw::reset_only_env(w, *S, h->model, h->dp.C, T, ids[i]);
+    }
+    delete S;
+    return DW_OK;
+}
+int dwe_lds_bytes(void) { return (int)sizeof(dwo::OLds); }
+
+// the derived schedule, for tests/test_quad_schedule.py: out[0] = nsteps, then [step][lane] bodies (outward order)
+int dwe_quad_schedule(DwHandle *h, int32_t *out, int32_t cap) {
+    if (!h || !out || cap < 1 + dwq::QS_MAX * 4 * 3 + 1) return fail(DW_EINVAL, "dwe_quad_schedule: buffer too small");
+    int k = 0;
+    out[k++] = h->qmodel.nsteps;
+    for (int s = 0; s < dwq::QS_MAX; ++s) for (int l = 0; l < 4; ++l) out[k++] = h->qmodel.fk[s][l].body;
+    for (int s = 0; s < dwq::QS_MAX; ++s) for (int l = 0; l < 4; ++l) out[k++] = h->qmodel.fk[s][l].psrc;
+    for (int s = 0; s < dwq::QS_MAX; ++s) for (int l = 0; l < 4; ++l) out[k++] = (h->qmodel.in[s][l].flags << 16) | h->qmodel.in[s][l].gather;
+    out[k++] = h->qmodel.base_gather;
+    return k;
+}
+
+}  // extern "C"

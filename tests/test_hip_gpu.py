@@ -9,10 +9,10 @@ from oracle import parity as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[2, 1], ids=["quad", "fused"])
+@pytest.fixture(params=[3, 2, 1], ids=["oct", "quad", "wave-per-env"])
 def pipeline(request):
-    """Both kernel generations behind the same C-ABI: 2 = split pipeline around the quad physics kernel (the default),
-    1 = the fused wave-per-env kernel."""
+    """The three kernel generations behind the same C-ABI (one launch per policy step each): 3 = octet kernels (8 lanes per
+    env, two waves per SIMD), 2 = quad kernels (4 lanes per env), 1 = the wave-per-env kernels of round 1."""
     return request.param
 
 

@@ -21,15 +21,15 @@ def _lib(name):
         return None
 
 
-@pytest.mark.parametrize("quad", [False, True], ids=["wave-per-env", "quad"])
+@pytest.mark.parametrize("quad", ["", "quad", "oct"], ids=["wave-per-env", "quad", "oct"])
 def test_kernel_body_under_asan_ubsan(quad):
     asan, ubsan = _lib("libasan.so"), _lib("libubsan.so")
     if not asan or not ubsan:
         pytest.skip("libasan/libubsan not found")
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "emul"), "-s", "_build/libdw_emul_quad_asan.so" if quad else "_build/libdw_emul_asan.so"])
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emul"), "-s", "_build/libdw_emul%s_asan.so" % ("_" + quad if quad else "")])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                LD_PRELOAD=asan + ":" + ubsan, OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, os.path.join(HERE, "_asan_worker.py")] + (["quad"] if quad else []), env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_asan_worker.py")] + ([quad] if quad else []), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "replayed 40 steps" in out.stdout and "simulate / reset_idx / step(noise=None) ok" in out.stdout
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr

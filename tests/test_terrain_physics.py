@@ -88,7 +88,7 @@ def test_forces_follow_the_slope_normal(model):
     assert -0.05 < sim.buf["root_states"][0, 4] < 0.0            # still pitched back by about the slope angle
 
 
-@pytest.mark.parametrize("quad", [False, True], ids=["wave-per-env", "quad"])
+@pytest.mark.parametrize("quad", [False, True, "oct"], ids=["wave-per-env", "quad", "oct"])
 def test_kernel_body_matches_oracle_on_generated_terrain(quad):
     """Same inputs through the oracle and through the kernel source (host emulation of either kernel generation) on a
     generated map: random poses near the ground so that sole corners and primitives touch rough terrain."""
