@@ -23,6 +23,7 @@ struct DwHandle {
     dw::DevParams  *d_params;
     int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env); one launch per step in all three
     float          *d_mocap;
+    float          *d_sc_park;      // octet kernels: PhysParams::sc_park
     DwBuffers       buf;
     int             bound;
     int             has_task;
@@ -66,7 +67,7 @@ void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step);
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
-int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err);      // malloc'ed
+int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err, bool octet);      // malloc'ed
 size_t quadmodel_bytes();
 int  quad_lds_bytes();
 }  // namespace dwq
@@ -77,6 +78,7 @@ void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::Quad
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
 int  oct_lds_bytes();
+int  sc_park_words();
 }  // namespace dwo
 
 __global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
@@ -143,7 +145,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     h->pipeline = cfg->pipeline == 0 ? 2 : cfg->pipeline;
     dwq::QuadModel *hq = nullptr;
     if (h->pipeline >= 2) {
-        rc = dwq::build_quadmodel_host(hm, model, &hq, &err);
+        rc = dwq::build_quadmodel_host(hm, model, &hq, &err, h->pipeline == 3);
         if (rc) { free(hm); free(h); return fail(rc, err); }
     }
     (void)hipGetDevice(&h->device);
@@ -156,6 +158,12 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     }
     free(hq);
     if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
+    if (h->pipeline == 3) {
+        const size_t waves = (size_t)(cfg->num_envs + 15) / 16 * 2;
+        e = hipMalloc((void **)&h->d_sc_park, waves * 64 * dwo::sc_park_words() * sizeof(float));
+        if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: self-collision park buffer", e); }
+        h->params.phys.sc_park = h->d_sc_park;
+    }
     e = hipMalloc((void **)&h->d_params, sizeof(dw::DevParams));
     if (e == hipSuccess) e = hipMemset(h->d_params, 0, sizeof(dw::DevParams));
     if (e == hipSuccess) e = hipMemcpy(&h->d_params->C, &h->params, sizeof(dw::TaskParams), hipMemcpyHostToDevice);
@@ -179,6 +187,7 @@ int dw_destroy(DwHandle *h) {
     if (h->d_qmodel) (void)hipFree(h->d_qmodel);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_mocap) (void)hipFree(h->d_mocap);
+    if (h->d_sc_park) (void)hipFree(h->d_sc_park);
     free(h);
     return DW_OK;
 }
@@ -193,7 +202,7 @@ int dw_bind(DwHandle *h, const DwBuffers *b) {
     hipError_t e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip("dw_bind: pointer table upload", e);
     const int16_t *hs = h->cfg.terrain ? b->height_samples : nullptr;
-    e = hipMemcpy(&h->d_params->C.phys.hs, &hs, sizeof(hs), hipMemcpyHostToDevice);
+    e = hipMemcpy(&h->d_params->C.phys.hs, &hs, sizeof(hs), hipMemcpyHostToDevice);      // (C.phys.sc_park was uploaded with the block at dw_create)
     if (e != hipSuccess) return fail_hip("dw_bind: terrain pointer upload", e);
     h->bound = 1;
     return DW_OK;

@@ -24,14 +24,15 @@ namespace dwo {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::wave_any; using dwq::wave_ballot;
-using dwq::wave_sync; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::over_1n;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::oct_lo; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
 
 constexpr int LPE = 8;               // lanes per env
 constexpr int EPO = 64 / LPE;        // envs per wavefront
 constexpr int WPG = 2;               // wavefronts per workgroup (they share the hot tables, nothing else)
+constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 1;      // per lane: PhysParams::sc_park
 
 // One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env as in dw_quad.h.  A row is 8 envs x 16 B
 // = 128 B, half the width of the LDS (64 banks x 4 B), so a limb's position code p = pos | flip << 3 also swaps the rows of
@@ -42,9 +43,16 @@ struct alignas(16) OLds {
     QHot   hot;
 };
 static_assert(sizeof(OLds) <= 40960, "OLds: 4 workgroups (8 waves) per CU must fit 160 KB of LDS");
-DQ_HD int pcode(int el, int owner) { return ((el + 4 * (owner >> 1)) & 7) | ((owner & 1) << 3); }
-#define OQ_SLOT(b, q, p) L.slot[(b) * 4 + ((q) ^ ((p) >> 3))][(p) & 7]
-#define OQ_LD(b, q, p) ld4(L.slot[(b) * 4 + ((q) ^ ((p) >> 3))][(p) & 7])
+// (as byte offsets: even rows of a flipped limb lie one row up, odd rows one row down -- two lane-dependent bases, so that every
+//  access is base + a compile-time offset and the compiler need not keep one address register per body and row)
+struct OPos { int e, o; };
+DQ_HD OPos pcode(int el, int owner) {
+    const int pos = (el + 4 * (owner >> 1)) & 7, flip = owner & 1;
+    OPos p; p.e = pos * 16 + flip * 128; p.o = pos * 16 - flip * 128;
+    return p;
+}
+#define OQ_SLOT(b, q, p) (*reinterpret_cast<F4 *>(reinterpret_cast<char *>(&L.slot[0][0]) + (((q) & 1) ? (p).o : (p).e) + ((b) * 4 + (q)) * 128))
+#define OQ_LD(b, q, p) ld4(OQ_SLOT(b, q, p))
 
 // copies the hot tables from the device-resident model into LDS.  Both waves of the workgroup copy all of it (identical
 // bytes), so neither has to wait for the other: no workgroup barrier anywhere in these kernels.
@@ -59,21 +67,22 @@ DQ_HD void stage_hot(QHot &HW, const QuadModel &QM) {
 
 // What a lane keeps in registers across the phases of a step.
 struct OLane {
-    int   lane, o, j, h, el, env, valid, pos;   // octet lane, limb, half, env within the wave, global env (clamped), slot position code
+    int   lane, o, j, h, el, env, valid;     // octet lane, limb, half, env within the wave, global env (clamped)
+    OPos  pos;                               // position code of my limb's slots
+    int   wave;                              // wave index in the launch (wave-uniform)
     float root[13];
     float mu;
-    float warm[12];                          // impulses of the 4 corners of "my" foot (foot j & 1), from the previous substep
     float footF[3];                          // non-sole contact force on my foot's sole Gym body (lanes 0, 1)
     int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
     float footT[3];                          // last substep: net contact force on my sole body (lanes 0, 1)
     int   stamp_base;                        // profiling builds only
-    float in1[10], ms1;                      // second (welded) inertial record of my sole body: com[3], mass, I[6]; its mass scale
 };
 
 // ------------------------------------------------------------------------------------------------
 // The substep.  On entry every body's slot holds quad 0 = {q, qd, tt, dd} with tt = tau - damping * qd and
-// dd = armature + dt * damping (the caller's prologue), X.root the base state, X.warm the warm-start impulses, and the hot
-// tables are staged (stage_hot).  On exit: slot quad 0 = {q, qd, *, *} of the new state, X.root, X.warm updated; with `last`,
+// dd = armature + dt * damping (the caller's prologue), X.root the base state, and the hot tables are staged (stage_hot).  The
+// warm-start impulses of the sole corners live in the task record (DW_ES_WARM): read after the inward pass, written back after
+// the contact solve.  On exit: slot quad 0 = {q, qd, *, *} of the new state, X.root updated; with `last`,
 // the net contact forces of the substep are written to B.contact_forces.  push: world x/y force on the base COM.
 // ------------------------------------------------------------------------------------------------
 struct FkHot { float pos[3], axis[3], vmax, qlo, qhi; int body, psrc, flags, scm; };
@@ -106,9 +115,13 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     const bool wr = X.valid && X.h == 0;          // global side effects: half 0 only (half 1 mirrors it)
     const float *mscale_e = B.mass_scale + (size_t)DW_NUM_BODIES * e;
 
+    // the mass scale of the second (welded) inertial record of my sole body: requested here, consumed by the inward pass (the
+    // record itself sits in the hot tables)
+    const float ms1 = mscale_e[f2i(H.in1[j & 1][10])];
     // ---- base kinematics (every lane of the quad, redundantly) ----
-    float qn[4], R0[9], ww[3], vo[3], bcom[3];
+    float qn[4], R0k[9], ww[3], vo[3], bcom[3];
     {
+        float (&R0)[9] = R0k;
         const float qx = X.root[3], qy = X.root[4], qz = X.root[5], qw = X.root[6];
         const float ninv = dw::rsqrt_nr(qx * qx + qy * qy + qz * qz + qw * qw);
         qn[0] = qx * ninv; qn[1] = qy * ninv; qn[2] = qz * ninv; qn[3] = qw * ninv;
@@ -124,7 +137,6 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 
     DQ_STAMP(B, SB + 1);
     // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist. ----
-    float footR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, footx[3] = {0, 0, 0};      // pose of my sole body (lanes 0, 1)
     {
         float qr[4] = {0, 0, 0, 1}, Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xr_[3] = {0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
         for (int s = 0; s < T; ++s) {
@@ -154,7 +166,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             if (b >= 0) {
                 if (psrc == 1) {
                     DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = qn[i];
-                    DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0[i];
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0k[i];
                     DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = 0.0f; vr[i] = ww[i]; vr[3 + i] = vo[i]; }
                 } else if (fetched) {
                     DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fq[i];
@@ -180,8 +192,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 OQ_SLOT(b, 2, X.pos) = mk4(vr[0], vr[1], vr[2], in.z);
                 OQ_SLOT(b, 3, X.pos) = mk4(vr[3], vr[4], vr[5], in.w);
                 if (rc.flags & 2) {
-                    DQ_UNROLL for (int i = 0; i < 9; ++i) footR[i] = Rr[i];
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) footx[i] = x[i];
+                    // pose of the sole body for the contact phase, in the four slot rows of body 0 (the base has no slot; the
+                    // step kernel's per-env scratch there is dead once the substeps run): foot f = j in rows 2 f, 2 f + 1
+                    L.slot[2 * j][X.el] = mk4(qr[0], qr[1], qr[2], qr[3]);
+                    L.slot[2 * j + 1][X.el] = mk4(x[0], x[1], x[2], 0.0f);
                 }
             }
         }
@@ -189,23 +203,24 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     wave_sync();
 
     DQ_STAMP(B, SB + 2);
-    // ---- self-collision: capsule proxies (legs, arms, torso), pairs from the model.  Detection: lane p & 3 evaluates proxy p
-    //      from its body's slot; the pairs are tested in passes -- one proxy broadcast to the quad (DPP), every lane tests one
-    //      of its own against it -- and the touching pairs of the env are ORed into a mask.  The common case is "nothing
-    //      touches": then that is all.  Resolution, if any env of the wave has a touching pair: the lane that owns a proxy's
-    //      body recomputes the proxy's touching pairs from the slots and keeps the wrench (both sides of a pair compute the
-    //      same force from the same data: no hand-over between lanes). ----
+    // ---- self-collision: capsule proxies (legs, arms, torso), pairs from the model.  Detection is pair-parallel: octet
+    //      lane o tests pairs o, o + 8, o + 16, o + 24 -- both proxies' axes from their bodies' slots, the division-free
+    //      conservative distance of dw_quad.h -- and the touching pairs of the env are ORed into a mask over the octet.  The
+    //      common case is "nothing touches": then that is all.  Resolution, if any env of the wave has a touching pair: the
+    //      lane that owns a proxy's body recomputes the proxy's touching pairs exactly and keeps the wrench (both sides of a
+    //      pair compute the same force from the same data: no hand-over between lanes; the two halves of a limb do the same). ----
     bool sc_any = false;
-    float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
-    int scGym0 = 0, scGym1 = 0;          // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
-    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
-    const int nprox = H.misc[2], ncombo = H.misc[3];
+    // (the wrenches of my own proxies, found by the resolution, wait for the inward pass in global memory: touching pairs are
+    //  rare, and 25 registers held through the inward pass for them are what the two-waves-per-SIMD budget cannot afford)
+    float *park = P.sc_park + ((size_t)X.wave * 64 + X.lane) * SC_PARK_WORDS;
+    const int npair = (H.misc[3] >> 8) & 255;
     auto proxy_bits = [&](int p) { return f2i(H.prox[p][7]); };
     auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
         const F4 *pr = reinterpret_cast<const F4 *>(H.prox[p]);
         const F4 c0 = ld4(pr[0]), c1 = ld4(pr[1]);
         const int bits = f2i(c1.w);
-        const int bp = bits & 255, posp = pcode(X.el, (bits >> 16) & 3);
+        const int bp = bits & 255;
+        const OPos posp = pcode(X.el, (bits >> 16) & 3);
         const F4 q4 = OQ_LD(bp, 0, posp), x4 = OQ_LD(bp, 1, posp);
         const float qb[4] = {q4.x, q4.y, q4.z, q4.w}, l0[3] = {c0.x, c0.y, c0.z}, l1[3] = {c1.x, c1.y, c1.z};
         float Rb[9], t0[3], t1[3];
@@ -215,46 +230,30 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         p0w[0] = x4.x + t0[0]; p0w[1] = x4.y + t0[1]; p0w[2] = x4.z + t0[2];
         p1w[0] = x4.x + t1[0]; p1w[1] = x4.y + t1[1]; p1w[2] = x4.z + t1[2];
     };
-    if (P.self_collision && ncombo > 0) {
-        float Pe[4][7];                    // my proxies (register set r = proxy j + 4 r): p0, p1 - p0, radius
-        DQ_UNROLL for (int r = 0; r < 4; ++r) {
-            DQ_UNROLL for (int i = 0; i < 7; ++i) Pe[r][i] = 0.0f;
-            if (j + 4 * r < nprox) {
-                float e1[3];
-                proxy_ends(j + 4 * r, &Pe[r][0], e1);
-                DQ_UNROLL for (int i = 0; i < 3; ++i) Pe[r][3 + i] = e1[i] - Pe[r][i];
-                Pe[r][6] = H.prox[j + 4 * r][3];
-            }
-        }
+#if defined(OCT_ABL_SC)
+    if (false) {
+#else
+    if (P.self_collision && npair > 0) {
+#endif
         DQ_STAMP(B, 51);
         int hits = 0;
-        for (int c = 0; c < ncombo; ++c) {
-            const int *cw = H.combo[c];
-            const int c0 = cw[0], pb = c0 & 255;
-            float bq[7];
-            // proxy pb to the whole quad: register set and lane are wave-uniform, so this is a scalar branch around 7 DPP moves
-#define DQ_BC(R_, L_) case (R_) * 4 + (L_): { DQ_UNROLL for (int i = 0; i < 7; ++i) bq[i] = quad_bcast<L_>(Pe[R_][i]); } break;
-            switch (pb) {
-                DQ_BC(0, 0) DQ_BC(0, 1) DQ_BC(0, 2) DQ_BC(0, 3) DQ_BC(1, 0) DQ_BC(1, 1) DQ_BC(1, 2) DQ_BC(1, 3)
-                DQ_BC(2, 0) DQ_BC(2, 1) DQ_BC(2, 2) DQ_BC(2, 3) DQ_BC(3, 0) DQ_BC(3, 1) DQ_BC(3, 2)
-                default: { DQ_UNROLL for (int i = 0; i < 7; ++i) bq[i] = quad_bcast<3>(Pe[3][i]); } break;
-            }
-#undef DQ_BC
-            DQ_UNROLL for (int r = 0; r < 4; ++r) {
-                const int lm = (c0 >> (8 + 4 * r)) & 15;
-                if (lm == 0) continue;
-                if ((lm >> j) & 1) {
-                    const float rr = Pe[r][6] + bq[6];
-                    const float rv[3] = {Pe[r][0] - bq[0], Pe[r][1] - bq[1], Pe[r][2] - bq[2]};
-                    // conservative: the least distance of the axes (the force uses the blended points, never closer), 0.2 % slack
-                    if (seg_dist2_fast(&Pe[r][3], &bq[3], rv) < 1.004f * rr * rr) hits |= 1 << ((cw[1 + r] >> (8 * j)) & 255);
-                }
-            }
+        for (int k0 = 0; k0 < npair; k0 += LPE) {           // (wave-uniform trip count; a lane past the last pair tests pair 0 again)
+            const int pid = k0 + X.o, pidc = pid < npair ? pid : 0;
+            const int pr = (H.pairs[pidc >> 2] >> (8 * (pidc & 3))) & 255, pa = pr & 15, pbx = pr >> 4;
+            float a0[3], a1[3], b0[3], b1[3];
+            proxy_ends(pa, a0, a1);
+            proxy_ends(pbx, b0, b1);
+            const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+            const float rv[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
+            const float rr = H.prox[pa][3] + H.prox[pbx][3];
+            // conservative: the least distance of the axes (the force uses the blended points, never closer), 0.2 % slack
+            if (pid < npair && seg_dist2_fast(da, db, rv) < 1.004f * rr * rr) hits |= 1 << pid;
         }
-        {   // the env's mask: OR over the quad (bit patterns through the DPP moves)
+        {   // the env's mask: OR over the octet (bit patterns through the DPP moves)
             int m = hits;
             m |= f2i(quad_xor1(__builtin_bit_cast(float, m)));
             m |= f2i(quad_xor2(__builtin_bit_cast(float, m)));
+            m |= f2i(oct_xor4(__builtin_bit_cast(float, m)));
             hits = m;
         }
         sc_any = wave_any(hits != 0);
@@ -263,6 +262,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         if (blockIdx.x == 0 && threadIdx.x == 0) B.gate_acc[200 + 53] = sc_any;
 #endif
         if (sc_any) {
+            float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
+            int scGym0 = 0;                      // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
+            DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
             // every lane works through the touching pairs that involve one of its bodies
             int mine = hits & (j == 0 ? H.misc[4] : (j == 1 ? H.misc[5] : (j == 2 ? H.misc[6] : H.misc[7])));
             while (wave_any(mine != 0)) {
@@ -274,8 +276,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     float a0[3], a1[3], b0[3], b1[3];
                     proxy_ends(pa, a0, a1);
                     proxy_ends(pbx, b0, b1);
-                    const int ba = bita & 255, posa = pcode(X.el, (bita >> 16) & 3);
-                    const int bb = bitb & 255, posb = pcode(X.el, (bitb >> 16) & 3);
+                    const int ba = bita & 255, bb = bitb & 255;
+                    const OPos posa = pcode(X.el, (bita >> 16) & 3), posb = pcode(X.el, (bitb >> 16) & 3);
                     const F4 va2 = OQ_LD(ba, 2, posa), va3 = OQ_LD(ba, 3, posa), vb2 = OQ_LD(bb, 2, posb), vb3 = OQ_LD(bb, 3, posb);
                     const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
                     float F[3], ca[3], cb[3];
@@ -290,20 +292,23 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                             cross3(side ? cb : ca, Fs, nb);
                             DQ_UNROLL for (int kk = 0; kk < QMAX_OWN; ++kk)
                                 if (kk == k) { DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[kk][i] += nb[i]; scW[kk][3 + i] += Fs[i]; } }
-                            if (k < 4) scGym0 |= gy << (8 * k); else scGym1 |= gy << (8 * (k - 4));
+                            scGym0 |= gy << (8 * k);
                         }
                     }
                 }
             }
+            DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) park[6 * p + i] = scW[p][i];
+            park[6 * QMAX_OWN] = __builtin_bit_cast(float, scGym0);
+            wave_sync_global();
         }
     }
     wave_sync();      // the leg lanes read each other's slots above; the inward pass below overwrites them
 
     DQ_STAMP(B, SB + 3);
     // ---- inward pass: articulated inertias and bias forces, in reverse schedule order ----
-    float IA[21], pA[6], IP[21], pP[6];          // running and parked reflected inertia / bias
-    DQ_UNROLL for (int i = 0; i < 21; ++i) { IA[i] = 0.0f; IP[i] = 0.0f; }
-    DQ_UNROLL for (int i = 0; i < 6; ++i) { pA[i] = 0.0f; pP[i] = 0.0f; }
+    float IA[21], pA[6];          // running reflected inertia / bias (no lane parks a second one: build_quadmodel(accumulate))
+    DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     const int my_sole_gym = (j == 0) ? M.left_foot_gym : (j == 1 ? M.right_foot_gym : -1);
     // the one per-env global value a step needs (the mass scale of the body's Gym body) is requested a step ahead
@@ -321,40 +326,44 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         const int gymbits = f2i(h0.z);
         const float ms0 = ms_next;
         if (s + 1 < T) ms_next = mscale_e[(f2i(H.in[s + 1][j][2]) >> 24) & 255];
-        if (flags & 2) {                    // a finished chain is still waiting for its parent: park it
-            DQ_UNROLL for (int i = 0; i < 21; ++i) IP[i] = IA[i];
-            DQ_UNROLL for (int i = 0; i < 6; ++i) pP[i] = pA[i];
+        const int gw = H.gany[s];
+        if (gw >> 8) {                      // a finished chain joins the finished chain of an idle lane (same parent) before its lane starts afresh
+            const int src = (gw >> 9) & 3, dst = (gw >> 11) & 3;
+            float tI[21], tp[6];
+            quad_bcast_arr(src, IA, tI);
+            quad_bcast_arr(src, pA, tp);
+            if (j == dst) {
+                DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] += tI[i];
+                DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] += tp[i];
+            }
         }
         if (flags & 1) {
             DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
             DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
         }
         // gathers (wave-uniform per step): child chains that ended on other lanes
-        if (H.gany[s]) {
+        if (gw & 1) {
             const int g0 = f2i(H.in[s][0][1]), g1 = f2i(H.in[s][1][1]), g2 = f2i(H.in[s][2][1]), g3 = f2i(H.in[s][3][1]);
             const int mine = f2i(h0.y);
-            DQ_UNROLL for (int src = 0; src < 4; ++src)
-                DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
-                    const int code = src | (pk << 2) | 8;
-                    bool used = false, want = false;
-                    DQ_UNROLL for (int k = 0; k < 3; ++k) {
-                        used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
-                               (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
-                        want = want || (((mine >> (4 * k)) & 15) == code);
+            DQ_UNROLL for (int src = 0; src < 4; ++src) {
+                const int code = src | 8;
+                bool used = false, want = false;
+                DQ_UNROLL for (int k = 0; k < 3; ++k) {
+                    used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
+                           (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
+                    want = want || (((mine >> (4 * k)) & 15) == code);
+                }
+                if (used) {
+                    DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                        const float t = src == 0 ? quad_bcast<0>(IA[i]) : (src == 1 ? quad_bcast<1>(IA[i]) : (src == 2 ? quad_bcast<2>(IA[i]) : quad_bcast<3>(IA[i])));
+                        if (want) IA[i] += t;
                     }
-                    if (used) {
-                        DQ_UNROLL for (int i = 0; i < 21; ++i) {
-                            const float v = pk ? IP[i] : IA[i];
-                            const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-                            if (want) IA[i] += t;
-                        }
-                        DQ_UNROLL for (int i = 0; i < 6; ++i) {
-                            const float v = pk ? pP[i] : pA[i];
-                            const float t = src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-                            if (want) pA[i] += t;
-                        }
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                        const float t = src == 0 ? quad_bcast<0>(pA[i]) : (src == 1 ? quad_bcast<1>(pA[i]) : (src == 2 ? quad_bcast<2>(pA[i]) : quad_bcast<3>(pA[i])));
+                        if (want) pA[i] += t;
                     }
                 }
+            }
         }
         F4 s0 = mk4(0.0f, 0.0f, 0.0f, 1.0f), s1 = s0, s2 = s0, s3 = s0;
         if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
@@ -374,7 +383,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             {
                 const float com0[3] = {h1.x, h1.y, h1.z}, I0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
                 if (nin > 1) {          // the two sole bodies carry a second (welded) inertial record
-                    rigid_inertia(2, com0, h1.w, I0, ms0, &X.in1[0], X.in1[3], &X.in1[4], X.ms1, R, x, Ao, ho, &mass);
+                    const F4 *ir = reinterpret_cast<const F4 *>(H.in1[j & 1]);
+                    const F4 i0 = ld4(ir[0]), i1 = ld4(ir[1]), i2 = ld4(ir[2]);
+                    const float com1[3] = {i0.x, i0.y, i0.z}, I1[6] = {i1.x, i1.y, i1.z, i1.w, i2.x, i2.y};
+                    rigid_inertia(2, com0, h1.w, I0, ms0, com1, i0.w, I1, ms1, R, x, Ao, ho, &mass);
                 } else {
                     rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Ao, ho, &mass);
                 }
@@ -385,7 +397,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
             bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
             if (TERRAIN) near_ground = ngeom > 0;
-#if defined(DQ_KO_GEOM)          // (timing experiment only)
+#if defined(DQ_KO_GEOM) || defined(OCT_ABL_GEOM)          // (timing experiment only)
             near_ground = false;
 #endif
             if (near_ground) {
@@ -404,10 +416,13 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
             }
             if (sc_any && scm) {
+                float scW[QMAX_OWN][6];
+                DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = park[6 * p + i];
+                const int scGym0 = f2i(park[6 * QMAX_OWN]);
                 DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
                     if ((scm >> p) & 1) {
                         DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
-                        const int gy = ((p < 4 ? scGym0 >> (8 * p) : scGym1 >> (8 * (p - 4)))) & 255;     // (0 where unloaded: adds nothing)
+                        const int gy = (scGym0 >> (8 * p)) & 255;     // (0 where unloaded: adds nothing)
                         DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
                             if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
                     }
@@ -459,28 +474,39 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 4);
+    // the warm-start impulses of my foot's corners (previous substep): requested here, used by the contact solve below -- held in
+    // registers from one contact solve to the next they would sit through the inward pass, where the register budget is tightest
+    float warm[12];
+    {
+        wave_sync_global();          // (the previous substep of this launch stored them)
+        const float *wsrc = B.env_state ? B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * (j & 1) : nullptr;
+        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = wsrc ? wsrc[i] : 0.0f;
+    }
     // ---- base: gather the chains below the root, own inertia, external forces, inverse ----
-    float Minv[36], a0[6];
+    float Minv[21], a0[6];            // inverse of the base's articulated inertia, symmetric storage (sym6)
     {
         float I0[21], p0[6];
         DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = 0.0f;
         DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = 0.0f;
         const int g = H.misc[1];
-        DQ_UNROLL for (int src = 0; src < 4; ++src)
-            DQ_UNROLL for (int pk = 0; pk < 2; ++pk) {
-                const int code = src | (pk << 2) | 8;
-                const bool used = ((g & 15) == code) || (((g >> 4) & 15) == code) || (((g >> 8) & 15) == code) || (((g >> 12) & 15) == code);
-                if (used) {
-                    DQ_UNROLL for (int i = 0; i < 21; ++i) {
-                        const float v = pk ? IP[i] : IA[i];
-                        I0[i] += src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-                    }
-                    DQ_UNROLL for (int i = 0; i < 6; ++i) {
-                        const float v = pk ? pP[i] : pA[i];
-                        p0[i] += src == 0 ? quad_bcast<0>(v) : (src == 1 ? quad_bcast<1>(v) : (src == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-                    }
-                }
+        DQ_UNROLL for (int src = 0; src < 4; ++src) {
+            const int code = src | 8;
+            const bool used = ((g & 15) == code) || (((g >> 4) & 15) == code) || (((g >> 8) & 15) == code) || (((g >> 12) & 15) == code);
+            if (used) {
+                DQ_UNROLL for (int i = 0; i < 21; ++i)
+                    I0[i] += src == 0 ? quad_bcast<0>(IA[i]) : (src == 1 ? quad_bcast<1>(IA[i]) : (src == 2 ? quad_bcast<2>(IA[i]) : quad_bcast<3>(IA[i])));
+                DQ_UNROLL for (int i = 0; i < 6; ++i)
+                    p0[i] += src == 0 ? quad_bcast<0>(pA[i]) : (src == 1 ? quad_bcast<1>(pA[i]) : (src == 2 ? quad_bcast<2>(pA[i]) : quad_bcast<3>(pA[i])));
             }
+        }
+        // (the base's rotation matrix again from its quaternion: kept from the top of the substep it would cost 9 registers
+        //  through the inward pass)
+        float R0[9];
+        {
+            float qo4[4] = {qn[0], qn[1], qn[2], qn[3]};
+            DQ_OPAQUE(qo4[0]);
+            quat_to_mat(qo4, R0);
+        }
         const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
         float Ao[6], ho[3], mass;
         const int base_gym = f2i(H.base[10]), base_ngeom = f2i(H.base[11]);
@@ -544,11 +570,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 DQ_UNROLL for (int k = i + 1; k < 6; ++k) sacc -= Lc[6 * k + i] * xx[k];
                 xx[i] = sacc * dinv[i];
             }
-            DQ_UNROLL for (int i = 0; i < 6; ++i) Minv[6 * i + col] = xx[i];
+            DQ_UNROLL for (int i = 0; i <= col; ++i) Minv[sym6(i, col)] = xx[i];
         }
         DQ_UNROLL for (int r = 0; r < 6; ++r) {
             float acc = 0.0f;
-            DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[6 * r + c] * p0[c];
+            DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[sym6(r, c)] * p0[c];
             a0[r] = acc;
         }
     }
@@ -608,8 +634,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     {
         // the pose of foot f lives in lane f: lanes 2, 3 fetch it from their partner (l ^ 2)
         float fR[9], fx[3];
-        DQ_UNROLL for (int i = 0; i < 9; ++i) { const float o = quad_xor2(footR[i]); fR[i] = part ? o : footR[i]; }
-        DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = quad_xor2(footx[i]); fx[i] = part ? o : footx[i]; }
+        {
+            const F4 fq4 = ld4(L.slot[2 * f][X.el]), fx4 = ld4(L.slot[2 * f + 1][X.el]);
+            const float fq[4] = {fq4.x, fq4.y, fq4.z, fq4.w};
+            quat_to_mat(fq, fR);
+            fx[0] = fx4.x; fx[1] = fx4.y; fx[2] = fx4.z;
+        }
         DQ_UNROLL for (int k = 0; k < 4; ++k) {
             float r[3];
             m3v(fR, M.foot_pos[4 * f + k], r);
@@ -630,14 +660,18 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     const bool any_active = wave_any(act[0] | act[1] | act[2] | act[3]);
     float dqb[6] = {0, 0, 0, 0, 0, 0};              // base velocity jump
     float Pk[4][3];
-    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) Pk[k][i] = act[k] ? X.warm[3 * k + i] : 0.0f;
+    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) Pk[k][i] = act[k] ? warm[3 * k + i] : 0.0f;
 
+#if defined(OCT_ABL_CONTACT)
+    if (false) {
+#else
     if (any_active) {
+#endif
         // ---- free twist of foot f: base + sum over the leg of S qdf (leg lane), shared with the partner ----
         float twf[6];
         {
             float acc[6] = {wwf[0], wwf[1], wwf[2], vowf[0], vowf[1], vowf[2]};
-            const int posf = pcode(X.el, f);
+            const OPos posf = pcode(X.el, f);
             DQ_UNROLL for (int i = 1; i <= 6; ++i) {
                 const int b = 6 * f + i;
                 const F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf);
@@ -647,95 +681,97 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             DQ_UNROLL for (int i = 0; i < 6; ++i) twf[i] = acc[i];
         }
         DQ_STAMP(B, SB + 7);
-        // ---- my 3 rows of W: responses of both feet to unit wrenches (components 3 part .. 3 part + 2) on foot f.
-        //      Up the leg: d = -S'p, p += U d / D;  base: dv = -Minv p;  down both legs: qdd = (d - U'dv) / D, dv += S qdd ----
-        float Wr[3][12];
+        // ---- my block of W: the response of ONE foot (leg g: half 0 of the octet takes its own foot f, half 1 the other foot)
+        //      to my 3 unit wrenches (components 3 part .. 3 part + 2) on foot f.  Up leg f: d = -S'p, p += U d / D (both
+        //      halves); base: dv = -Minv p; down leg g: qdd = (d - U'dv) / D, dv += S qdd ----
+        const int g = X.h ^ f;
+        float Wg[3][6];
         {
             float dp[3][6], dc[3][6];
             DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int i = 0; i < 6; ++i) dp[c][i] = (i == 3 * part + c) ? -1.0f : 0.0f;
-            const int posf = pcode(X.el, f);
+            const OPos posf = pcode(X.el, f);
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
+                DQ_SCHED_FENCE();
                 const int b = 6 * f + i;
                 const F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf), s3 = OQ_LD(b, 3, posf);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 DQ_UNROLL for (int c = 0; c < 3; ++c) {
                     const float d = -dot6(S, dp[c]);
-                    dc[c][i - 1] = d;
+                    dc[c][i - 1] = (g == f) ? d : 0.0f;          // (the other leg carries no wrench of its own)
                     const float k = d * s0.w;
                     DQ_UNROLL for (int r = 0; r < 6; ++r) dp[c][r] += U[r] * k;
                 }
             }
-            float dv0[3][6];
             DQ_UNROLL for (int c = 0; c < 3; ++c)
                 DQ_UNROLL for (int r = 0; r < 6; ++r) {
                     float acc = 0.0f;
-                    DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[6 * r + k] * dp[c][k];
-                    dv0[c][r] = acc;
+                    DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[sym6(r, k)] * dp[c][k];
+                    Wg[c][r] = acc;
                 }
-            DQ_UNROLL for (int g = 0; g < 2; ++g) {
-                float dv[3][6];
-                DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) dv[c][r] = dv0[c][r];
-                const int posg = pcode(X.el, g);
-                DQ_UNROLL for (int i = 1; i <= 6; ++i) {
-                    const int b = 6 * g + i;
-                    const F4 s0 = OQ_LD(b, 0, posg), s1 = OQ_LD(b, 1, posg), s2 = OQ_LD(b, 2, posg), s3 = OQ_LD(b, 3, posg);
-                    const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
-                    DQ_UNROLL for (int c = 0; c < 3; ++c) {
-                        const float ua = dot6(U, dv[c]);
-                        const float qdd = ((g == f ? dc[c][i - 1] : 0.0f) - ua) * s0.w;
-                        DQ_UNROLL for (int r = 0; r < 6; ++r) dv[c][r] += S[r] * qdd;
-                    }
+            const OPos posg = pcode(X.el, g);
+            DQ_UNROLL for (int i = 1; i <= 6; ++i) {
+                DQ_SCHED_FENCE();
+                const int b = 6 * g + i;
+                const F4 s0 = OQ_LD(b, 0, posg), s1 = OQ_LD(b, 1, posg), s2 = OQ_LD(b, 2, posg), s3 = OQ_LD(b, 3, posg);
+                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float ua = dot6(U, Wg[c]);
+                    const float qdd = (dc[c][i - 1] - ua) * s0.w;
+                    DQ_UNROLL for (int r = 0; r < 6; ++r) Wg[c][r] += S[r] * qdd;
                 }
-                DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int r = 0; r < 6; ++r) Wr[c][6 * g + r] = dv[c][r];
             }
         }
         DQ_STAMP(B, SB + 8);
         // ---- 3x3 diagonal blocks of the Delassus matrix of my foot's corners: A_kk = J_k W_ff J_k' (frame-projected on
-        //      terrain); what the solver needs of them: the three diagonal inverses and the couplings zx, zy, xy ----
+        //      terrain); what the solver needs of them: the three diagonal inverses and the couplings zx, zy, xy.  W_ff is
+        //      spread over the half-0 lanes of the foot (rows 3 part ..): they compute, half 1 takes the results over ----
         float invd[4][3], cpl[4][3];
         {
-            float Wff[6][6];       // rows 3 part.. are mine, the other three come from the partner lane (l ^ 2)
-            DQ_UNROLL for (int r = 0; r < 3; ++r)
-                DQ_UNROLL for (int c = 0; c < 6; ++c) {
-                    const float mine = f ? Wr[r][6 + c] : Wr[r][c];
-                    const float o = quad_xor2(mine);
-                    Wff[r][c] = part ? o : mine;
-                    Wff[3 + r][c] = part ? mine : o;
-                }
+            // Per corner k, J_k = [-skew(r) | 1]: A_kk = J_k W_ff J_k' = sum over the two row blocks of W_ff.  The lane with the
+            // angular rows (part 0) and the lane with the linear rows (part 1) each form T = W_rows J_k' (row t: w_lin + w_ang x r)
+            // and their share of J_k T -- part 0: every column of T crossed with r, part 1: T itself -- and add the shares over
+            // the pair (l ^ 2): the 6 x 6 block W_ff is never assembled in one lane (it cost 36 registers at the kernel's peak).
             const float rreg = 1.0f / (1.0f + P.cfm);
             DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                DQ_SCHED_FENCE();
                 const float *r = rk[k];
-                float G[3][6];        // J_k W_ff, world axes: row a = W_lin row a + (-skew(r)) row a . W_ang
-                DQ_UNROLL for (int c = 0; c < 6; ++c) {
-                    G[0][c] = Wff[3][c] + r[2] * Wff[1][c] - r[1] * Wff[2][c];
-                    G[1][c] = Wff[4][c] - r[2] * Wff[0][c] + r[0] * Wff[2][c];
-                    G[2][c] = Wff[5][c] + r[1] * Wff[0][c] - r[0] * Wff[1][c];
+                float Tm[3][3];
+                DQ_UNROLL for (int t = 0; t < 3; ++t) {
+                    const float *w = Wg[t];
+                    Tm[t][0] = w[3] + (w[1] * r[2] - w[2] * r[1]);
+                    Tm[t][1] = w[4] + (w[2] * r[0] - w[0] * r[2]);
+                    Tm[t][2] = w[5] + (w[0] * r[1] - w[1] * r[0]);
                 }
-                float Ak[3][3];       // G J_k': column b = G_lin col b + G_ang . (-skew(r)) row b
-                DQ_UNROLL for (int a = 0; a < 3; ++a) {
-                    Ak[a][0] = G[a][3] + r[2] * G[a][1] - r[1] * G[a][2];
-                    Ak[a][1] = G[a][4] - r[2] * G[a][0] + r[0] * G[a][2];
-                    Ak[a][2] = G[a][5] + r[1] * G[a][0] - r[0] * G[a][1];
+                float Ak[3][3];
+                DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                    // column c of T crossed with r (part 0) or taken as it is (part 1)
+                    const float x0 = Tm[1][c] * r[2] - Tm[2][c] * r[1], x1 = Tm[2][c] * r[0] - Tm[0][c] * r[2], x2 = Tm[0][c] * r[1] - Tm[1][c] * r[0];
+                    Ak[0][c] = part ? Tm[0][c] : x0; Ak[1][c] = part ? Tm[1][c] : x1; Ak[2][c] = part ? Tm[2][c] : x2;
                 }
-                if (TERRAIN) {        // rows / columns along the corner's frame (t1, t2, n)
-                    float Tm[3][3];
+                if (TERRAIN) {
+                    DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c) Ak[a][c] += quad_xor2(Ak[a][c]);
+                    // rows / columns along the corner's frame (t1, t2, n)
+                    float Fm[3][3];
                     DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
-                        Tm[a][c] = frame[k][3 * a] * Ak[0][c] + frame[k][3 * a + 1] * Ak[1][c] + frame[k][3 * a + 2] * Ak[2][c];
+                        Fm[a][c] = frame[k][3 * a] * Ak[0][c] + frame[k][3 * a + 1] * Ak[1][c] + frame[k][3 * a + 2] * Ak[2][c];
                     DQ_UNROLL for (int a = 0; a < 3; ++a) DQ_UNROLL for (int c = 0; c < 3; ++c)
-                        Ak[a][c] = Tm[a][0] * frame[k][3 * c] + Tm[a][1] * frame[k][3 * c + 1] + Tm[a][2] * frame[k][3 * c + 2];
+                        Ak[a][c] = Fm[a][0] * frame[k][3 * c] + Fm[a][1] * frame[k][3 * c + 1] + Fm[a][2] * frame[k][3 * c + 2];
+                } else {
+                    // (only the diagonal and the couplings zx, zy, xy are used)
+                    Ak[0][0] += quad_xor2(Ak[0][0]); Ak[1][1] += quad_xor2(Ak[1][1]); Ak[2][2] += quad_xor2(Ak[2][2]);
+                    Ak[0][2] += quad_xor2(Ak[0][2]); Ak[1][2] += quad_xor2(Ak[1][2]); Ak[1][0] += quad_xor2(Ak[1][0]);
                 }
-                invd[k][0] = act[k] ? dw::rcp_nr(Ak[0][0]) * rreg : 0.0f;
-                invd[k][1] = act[k] ? dw::rcp_nr(Ak[1][1]) * rreg : 0.0f;
-                invd[k][2] = act[k] ? dw::rcp_nr(Ak[2][2]) * rreg : 0.0f;
-                cpl[k][0] = Ak[0][2];     // x row, z column
-                cpl[k][1] = Ak[1][2];     // y row, z column
-                cpl[k][2] = Ak[1][0];     // y row, x column
+                // (half 1 holds the other foot's block in Wg: what it computes here is overwritten by half 0's result)
+                invd[k][0] = oct_lo(act[k] ? dw::rcp_nr(Ak[0][0]) * rreg : 0.0f);
+                invd[k][1] = oct_lo(act[k] ? dw::rcp_nr(Ak[1][1]) * rreg : 0.0f);
+                invd[k][2] = oct_lo(act[k] ? dw::rcp_nr(Ak[2][2]) * rreg : 0.0f);
+                cpl[k][0] = oct_lo(Ak[0][2]);     // x row, z column
+                cpl[k][1] = oct_lo(Ak[1][2]);     // y row, z column
+                cpl[k][2] = oct_lo(Ak[1][0]);     // y row, x column
             }
         }
-        // my rows of W as [own foot | other foot] so that the updates below index registers statically
-        float Wo[3][6], Wx[3][6];
-        DQ_UNROLL for (int r = 0; r < 3; ++r) DQ_UNROLL for (int c = 0; c < 6; ++c) { Wo[r][c] = f ? Wr[r][6 + c] : Wr[r][c]; Wx[r][c] = f ? Wr[r][c] : Wr[r][6 + c]; }
-        // ---- start: tw = tw_free + W lambda0, lambda0 = warm-start impulses as foot wrenches ----
+        // ---- start: tw = tw_free + W lambda0, lambda0 = warm-start impulses as foot wrenches.  A lane's share of a product
+        //      W lambda: half 0 its own foot's wrench through W_ff, half 1 the other foot's wrench through W_f,other ----
         float tw3[3];
         {
             float lam[6] = {0, 0, 0, 0, 0, 0};
@@ -749,12 +785,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 cross3(rk[k], pw, t);
                 DQ_UNROLL for (int i = 0; i < 3; ++i) { lam[i] += t[i]; lam[3 + i] += pw[i]; }
             }
-            float lo[6];
-            DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
+            float lv[6];
+            DQ_UNROLL for (int i = 0; i < 6; ++i) { const float lo = quad_xor1(lam[i]); lv[i] = X.h ? lo : lam[i]; }
             DQ_UNROLL for (int r = 0; r < 3; ++r) {
-                float acc = part ? twf[3 + r] : twf[r];
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wo[r][c] * lam[c] + Wx[r][c] * lo[c];
-                tw3[r] = acc;
+                float acc = 0.0f;
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wg[r][c] * lv[c];
+                tw3[r] = (part ? twf[3 + r] : twf[r]) + (acc + oct_xor4(acc));
             }
         }
         DQ_STAMP(B, SB + 9);
@@ -800,14 +836,14 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                         const float d0 = d[0], d1 = d[1], d2 = d[2];
                         DQ_UNROLL for (int i = 0; i < 3; ++i) d[i] = d0 * fr[i] + d1 * fr[3 + i] + d2 * fr[6 + i];
                     }
-                    float lam[6], lo[6];
+                    float lam[6], lmv[6];
                     cross3(r, d, lam);
                     lam[3] = d[0]; lam[4] = d[1]; lam[5] = d[2];
-                    DQ_UNROLL for (int i = 0; i < 6; ++i) lo[i] = quad_xor1(lam[i]);
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) { const float lo = quad_xor1(lam[i]); lmv[i] = X.h ? lo : lam[i]; }
                     DQ_UNROLL for (int rr = 0; rr < 3; ++rr) {
-                        float acc = tw3[rr];
-                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wo[rr][c] * lam[c] + Wx[rr][c] * lo[c];
-                        tw3[rr] = acc;
+                        float acc = 0.0f;
+                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wg[rr][c] * lmv[c];
+                        tw3[rr] += acc + oct_xor4(acc);
                     }
                 }
             }
@@ -848,7 +884,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
             DQ_UNROLL for (int r = 0; r < 6; ++r) {
                 float acc = 0.0f;
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[6 * r + c] * tot[c];
+                DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[sym6(r, c)] * tot[c];
                 dqb[r] = acc;
             }
         }
@@ -866,7 +902,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             dst[0] = X.footF[0]; dst[1] = X.footF[1]; dst[2] = X.footF[2];
         }
     }
-    DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) X.warm[3 * k + i] = Pk[k][i];
+    if (wr && j < 2 && B.env_state) {
+        float *wdst = B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * j;
+        DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) wdst[3 * k + i] = Pk[k][i];
+    }
 
     DQ_STAMP(B, SB + 11);
     // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
@@ -939,6 +978,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 // Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
 DQ_HD void oct_lane_init(OLane &X, int wave_index, int num_envs, const PhysParams &P, float friction, const DwBuffers &B) {
     X.lane = lane_id();
+    X.wave = wave_index;
     X.o = X.lane & 7; X.j = X.lane & 3; X.h = (X.lane >> 2) & 1;
     X.el = X.lane >> 3;
     const int eg = wave_index * EPO + X.el;
@@ -947,7 +987,6 @@ DQ_HD void oct_lane_init(OLane &X, int wave_index, int num_envs, const PhysParam
     X.pos = pcode(X.el, X.j);
     DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = B.root_states[(size_t)13 * X.env + i];
     X.mu = friction * B.friction_scale[X.env];
-    DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = 0.0f;
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     X.stamp_base = 0;
     X.coll = 0;
@@ -955,23 +994,11 @@ DQ_HD void oct_lane_init(OLane &X, int wave_index, int num_envs, const PhysParam
     (void)P;
 }
 
-// after stage_hot: the lane's step with two inertial records (the sole bodies; at most one per lane)
-DQ_HD void oct_lane_second_inertial(OLane &X, const QHot &H, const QuadModel &QM, const DwBuffers &B) {
-    int s2 = 0;
-    DQ_UNROLL for (int s = 0; s < QS_MAX; ++s) if (s < H.misc[0] && ((f2i(H.in[s][X.j][0]) >> 12) & 3) > 1) s2 = s;
-    const QInRec &rc = QM.in[s2][X.j];
-    DQ_UNROLL for (int i = 0; i < 3; ++i) X.in1[i] = rc.in1_com[i];
-    X.in1[3] = rc.in1_mass;
-    DQ_UNROLL for (int i = 0; i < 6; ++i) X.in1[4 + i] = rc.in1_I[i];
-    const int g1 = rc.in1_gym;
-    X.ms1 = B.mass_scale[(size_t)DW_NUM_BODIES * X.env + (g1 >= 0 && g1 < DW_NUM_BODIES ? g1 : 0)];
-}
-
 // ---- joint-parallel phases.  Per-joint work that touches the Gym tensors runs over ITEMS (env, dof) = lane + 64 k of the
 // wave's 16 x 33 joints, so that a wave-instruction reads or writes consecutive addresses (the limb-per-lane mapping would
 // touch 64 different rows with 4-byte accesses); the item's lane reaches the owner's slot through the owner table. ----
 constexpr int ONI = (EPO * ND + 63) / 64;      // 5 items per lane
-struct JointItem { int ok, el, d, b, pos, env; };
+struct JointItem { int ok, el, d, b, env; OPos pos; };
 DQ_HD JointItem joint_item(const QHot &H, int wave_index, int num_envs, int lane, int k) {
     JointItem it;
     const int i = lane + 64 * k;
@@ -1001,9 +1028,7 @@ DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel
     oct_lane_init(X, wave_index, num_envs, P, friction, B);
     stage_hot(HW, QM);
     const QHot &H = HW;
-    oct_lane_second_inertial(X, H, QM, B);
     const int e = X.env, f = X.j & 1;
-    if (B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i]; }
     float qkeep[ONI];
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = joint_item(H, wave_index, num_envs, X.lane, k);
@@ -1027,7 +1052,6 @@ DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel
     }
     if (X.valid && X.h == 0) {
         if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
-        if (X.j < 2 && B.env_state) { DQ_UNROLL for (int i = 0; i < 12; ++i) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * f + i] = X.warm[i]; }
     }
 }
 

@@ -26,6 +26,7 @@ constexpr int EW_LTP = 0, EW_MIDX = 1;       // mocap phase time, mocap row (int
 constexpr int EW_T0 = 2, EW_T1 = 3;          // time stamps of the two mocap rows
 constexpr int EW_DL = 4, EW_SL = 5;          // torque FIFO: delay index, fill (int bits)
 constexpr int WW_GATE = 15;                  // wave-wide word: perturbation gate open (env 0's scratch)
+constexpr int PK_TAU2 = 0, PK_NZ1 = 64;      // words of the env's obs_buf row used as scratch during the step
 
 // The whole VecTask.step for 16 envs: pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
 // mocap phase and target, perturbation gate and schedule), the two substeps with the actuator and encoder models, and
@@ -47,7 +48,6 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     oct_lane_init(X, wave_index, C.num_envs, C.phys, C.friction, B);
     const int e = X.env, f = X.j & 1;
     float *es = B.env_state + (size_t)DW_ES_WORDS * e;
-    DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = es[DW_ES_WARM + 12 * f + i];
     const float r_time = es[DW_ES_TIME], r_epi = es[DW_ES_EPI_LEN], r_mag = es[DW_ES_MAGNITUDE], r_phase = es[DW_ES_PHASE];
     const float r_init = es[DW_ES_INIT_MOCAP], r_pstart = es[DW_ES_PERT_START], r_pon = es[DW_ES_PERT_ON], r_pcount = es[DW_ES_PERT_COUNT];
     const float r_imp = es[DW_ES_IMPULSE], r_dur = es[DW_ES_PERT_DURATION], r_ptim = es[DW_ES_PERT_TIMING];
@@ -63,15 +63,18 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     }
     auto item = [&](int k) {          // this lane's k-th (env, joint) item; pos is filled in below
         JointItem it;
-        const int i = X.lane + 64 * k;
+        int i = X.lane + 64 * k;
+        DQ_OPAQUE(i);                 // (recomputed at every use: five sets of derived indices held across the physics cost 20 registers)
         it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
         const int eg = wave_index * EPO + it.el;
         it.ok = (i < EPO * ND) && (eg < C.num_envs);
         if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }
         it.env = eg < C.num_envs ? eg : C.num_envs - 1;
-        it.pos = 0;
+        it.pos = pcode(0, 0);
         return it;
     };
+    // (an item's slot position: from the owner table in LDS at every use, not held across the physics)
+#define OQ_IPOS(it) pcode((it).el, HW.owner[(it).b])
     float rq[ONI], rqd[ONI], rdamp[ONI], rarm[ONI], rqpre[ONI], rms[ONI], rah[ONI], rac[ONI], rkp[ONI], rkv[ONI], rcol[ONI][DW_ALOG_SLOTS - 1];
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = item(k);
@@ -88,14 +91,17 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     }
     stage_hot(HW, QM);
     const QHot &H = HW;
-    oct_lane_second_inertial(X, H, QM, B);
-    int ipos[ONI];
-    DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); ipos[k] = pcode(it.el, H.owner[it.b]); }
     float push_x = 0.0f, push_y = 0.0f;
     const float dt = C.phys.dt;
+    // What the pre-physics phase produces for the task record goes to the record in global memory right away (the post phase
+    // stages the records after the physics and finds it there): carried in registers across two substeps it is what made the
+    // first form of this kernel spill.  Across the physics a lane keeps, per item: the joint angle and the previous encoder
+    // reading.  The second substep's torque input and encoder draw wait in the env's row of obs_buf, which is scratch until the
+    // post phase writes the new observation into it (words PK_TAU2.., PK_NZ1..).
     StepKeep KP;
-    float qkeep[ONI], qdkeep[ONI], tau2[ONI], qnprev[ONI], dampk[ONI], ddk[ONI], kpk[ONI], kvk[ONI];
+    float qkeep[ONI], qdkeep[ONI], qnprev[ONI];
     float (&qvk)[ONI] = KP.qv;
+    const bool wr_env = X.valid && X.h == 0;          // per-env scalars: half 0 writes
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
     const int simul_len0 = f2i(r_sl);
     (void)f;
@@ -116,7 +122,11 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             OQ_ENVW(X.el, EW_MIDX) = __builtin_bit_cast(float, midx);
             OQ_ENVW(X.el, EW_DL) = r_dl;
             OQ_ENVW(X.el, EW_SL) = r_sl;
-            KP.midx = midx;
+            if (wr_env) {
+                es[DW_ES_MOCAP_IDX] = __builtin_bit_cast(float, midx);
+                const int sl2 = simul_len0 + 2 > DW_ALOG_SLOTS ? DW_ALOG_SLOTS : simul_len0 + 2;
+                es[DW_ES_SIMUL_LEN] = __builtin_bit_cast(float, sl2);
+            }
         }
         wave_sync();
         const int open = f2i(OQ_ENVW(0, WW_GATE));
@@ -165,8 +175,12 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
                     pert_count = 0;
                 }
             }
-            KP.pert_start = pert_start; KP.pert_on = pert_on; KP.pert_count = pert_count; KP.impulse = impulse; KP.duration = duration;
-            KP.magnitude = magnitude; KP.phase = phase;
+            if (wr_env) {
+                es[DW_ES_PERT_START] = __builtin_bit_cast(float, pert_start); es[DW_ES_PERT_ON] = __builtin_bit_cast(float, pert_on);
+                es[DW_ES_PERT_COUNT] = __builtin_bit_cast(float, pert_count); es[DW_ES_IMPULSE] = __builtin_bit_cast(float, impulse);
+                es[DW_ES_PERT_DURATION] = __builtin_bit_cast(float, duration);
+                es[DW_ES_MAGNITUDE] = magnitude; es[DW_ES_PHASE] = phase;
+            }
         }
         push_x = quad_bcast<1>(px);
         push_y = quad_bcast<1>(py);
@@ -177,13 +191,14 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             const int eg = wave_index * EPO + el;
             float v = fminf(fmaxf(r_act[k], -1.0f), 1.0f);
             if (a == 12) v = (v > 0 ? 1.0f : 0.0f) * v;
-            KP.act[k] = i < EPO * DW_NUM_ACT ? v : 0.0f;
-            if (i < EPO * DW_NUM_ACT && eg < C.num_envs)
+            if (i < EPO * DW_NUM_ACT && eg < C.num_envs) {
                 B.action_history[((size_t)eg * DW_HIST_SLOTS + f2i(r_head[k])) * DW_NUM_ACT + a] = v;
+                B.env_state[(size_t)DW_ES_WORDS * eg + DW_ES_ACTIONS + a] = v;
+            }
         }
-        if (X.j == 0) {
-            KP.tf0 = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[2], rtf[3]);
-            KP.tf1 = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[4], rtf[5]);
+        if (X.j == 0 && wr_env) {
+            es[DW_ES_TARGET_FORCE] = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[2], rtf[3]);
+            es[DW_ES_TARGET_FORCE + 1] = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[4], rtf[5]);
         }
 
         // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps.  Kept per item in
@@ -192,17 +207,19 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         DQ_STAMP(B, 0);
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             JointItem it = item(k);
-            it.pos = ipos[k];
+            it.pos = OQ_IPOS(it);
             const int d = it.d;
             const float q = rq[k], qd = rqd[k], damp = rdamp[k], arm = rarm[k];
             qkeep[k] = q; qdkeep[k] = qd;
             qnprev[k] = rqpre[k];
-            dampk[k] = damp; ddk[k] = arm + dt * damp; kpk[k] = rkp[k]; kvk[k] = rkv[k];
             // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
             const float target = dw::cubic_t(OQ_ENVW(it.el, EW_LTP), rt0[k], rt1[k], rm0[k], rm1[k]);
             const float atq = d < 12 ? fminf(fmaxf(rac[k], -1.0f), 1.0f) * rms[k] * rah[k] : 0.0f;
-            KP.tgt[k] = target;
-            KP.atq[k] = atq;
+            if (it.ok) {
+                float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
+                ei[DW_ES_TARGET_QPOS + d] = target;
+                if (d < 12) ei[DW_ES_ACTION_TORQUE + d] = atq;
+            }
             // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
             // the two substeps (the action torque of the step is appended both times); the record gets the final column
             const int dl = f2i(OQ_ENVW(it.el, EW_DL)), sl0 = f2i(OQ_ENVW(it.el, EW_SL));
@@ -217,14 +234,12 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             DQ_UNROLL for (int s = 1; s < DW_ALOG_SLOTS; ++s) { t1 = (s == src1) ? col[s] : t1; t2 = (s == src2) ? col[s + 1] : t2; }
             // upper body: PD to the mocap target; the second substep forms its own torque from the new state
             const float tau = d < 12 ? t1 : rkp[k] * (target - q) + rkv[k] * (-qd);
-            tau2[k] = d < 12 ? t2 : target;
-            if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, ddk[k]);
+            if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_TAU2 + d] = d < 12 ? t2 : target;
+            if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
         }
     }
     wave_sync();
 
-    float nzw1[ONI];          // the second substep's encoder draws (generated with the first's)
-    DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw1[k] = 0.0f;
     for (int sub = 0; sub < 2; ++sub) {
         X.stamp_base = 1 + 16 * sub;
         if (!C.freeze_physics) oct_substep<TERRAIN>(L, H, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
@@ -233,7 +248,17 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         //      slot reads and the noise of all items first, then the arithmetic, then the stores ----
         F4 fin[ONI];
         float nzw[ONI];
-        DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); fin[k] = OQ_LD(it.b, 0, ipos[k]); }      // {qlo, qd, qhi, *}
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); fin[k] = OQ_LD(it.b, 0, OQ_IPOS(it)); }      // {qlo, qd, qhi, *}
+        // damping, armature and the PD gains of the upper body for the second substep's inputs: requested again here (their
+        // latency passes behind the noise generation) rather than held in 20 registers through the first substep
+        float rdamp2[ONI], rarm2[ONI], rkp2[ONI], rkv2[ONI], tau2[ONI], nzw1[ONI];
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+            const JointItem it = item(k);
+            const size_t g = (size_t)ND * it.env + it.d;
+            const float *pk = B.obs_buf + (size_t)DW_NUM_OBS * it.env;
+            if (sub == 0) { rdamp2[k] = B.dof_damping[g]; rarm2[k] = B.dof_armature[g]; rkp2[k] = M.kp[it.d]; rkv2[k] = M.kv[it.d]; tau2[k] = pk[PK_TAU2 + it.d]; }
+            else nzw1[k] = noise ? 0.0f : pk[PK_NZ1 + it.d];
+        }
         if (noise) {
             DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); nzw[k] = noise[(size_t)DW_NOISE_WORDS * it.env + DW_NZ_ENC + ND * sub + it.d]; }
         } else if (sub == 0) {          // one generator call per joint gives the draws of both substeps
@@ -241,7 +266,9 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
                 const JointItem it = item(k);
                 dw::NoiseSrc nz;
                 nz.rec = nullptr; nz.seed = C.seed; nz.env = (unsigned int)it.env; nz.step = (unsigned long long)step; nz.stream = 0;
-                dw::noise_enc_pair(nz, it.d, &nzw[k], &nzw1[k]);
+                float n1;
+                dw::noise_enc_pair(nz, it.d, &nzw[k], &n1);
+                if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_NZ1 + it.d] = n1;
             }
         } else {
             DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = nzw1[k];
@@ -263,15 +290,14 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             qnprev[k] = qn;
             qvk[k] = qv;
             if (sub == 0 && !C.freeze_physics) {
-                const float tau = d < 12 ? tau2[k] : kpk[k] * (tau2[k] - q) + kvk[k] * (-qd);
-                if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, ipos[k]) = mk4(q, qd, tau - dampk[k] * qd, ddk[k]);
+                const float tau = d < 12 ? tau2[k] : rkp2[k] * (tau2[k] - q) + rkv2[k] * (-qd);
+                if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, OQ_IPOS(it)) = mk4(q, qd, tau - rdamp2[k] * qd, rarm2[k] + dt * rdamp2[k]);
             }
         }
         wave_sync();
         DQ_STAMP(B, 1 + 16 * sub + 14);
     }
     if (X.valid && !C.freeze_physics && X.o == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
-    KP.simul_len = simul_len0 + 2 > DW_ALOG_SLOTS ? DW_ALOG_SLOTS : simul_len0 + 2;
     DQ_UNROLL for (int k = 0; k < ONI; ++k) KP.qn[k] = qnprev[k];
     DQ_STAMP(B, 40);
     {

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
                    const float *actions, const float *noise, long long step) {
     __shared__ dwo::OLds L;
-    const int w = (int)(threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));          // (wave-uniform: keep it in a scalar register)
     dwo::oct_step<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C, B, actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
 }
 // One physics substep at the Gym boundary, same layout.
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dw_k_simulate_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *tau,
                        const float *push) {
     __shared__ dwo::OLds L;
-    const int w = (int)(threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     dwo::oct_simulate<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, B, tau, push, (int)blockIdx.x * dwo::WPG + w);
 }
 
@@ -46,5 +46,6 @@ void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::
     else hipLaunchKernelGGL(dw_k_simulate_oct<false>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, tau, push);
 }
 int oct_lds_bytes() { return (int)sizeof(OLds); }
+int sc_park_words() { return SC_PARK_WORDS; }
 
 }  // namespace dwo

@@ -45,16 +45,11 @@ constexpr int PS_ORG = 28;       // [3] new tile origin (terrain curriculum)
 #define PQ_PS(el, w) LF[PL_PS + (el) * 32 + (w)]
 #define PQ_PSI(el, w) (*reinterpret_cast<int *>(&LF[PL_PS + (el) * 32 + (w)]))
 
-// What the phases before post_physics_step produce for the task record, kept in registers until the record's LDS image
-// exists (no global round trip): per-env scalars on the quad's lanes 0 / 1, per-joint values on the item lanes.
+// What the substeps produce for the task record, kept in registers until the record's LDS image exists.  (What the
+// pre-physics phase produces -- mocap row and targets, push schedule, clamped actions, action torques -- is already in the
+// records in global memory when they are staged: dw_oct_kernels.h.)
 struct StepKeep {
-    int   midx; float tf0, tf1;                                        // lane 0: mocap row, target forces
-    int   pert_start, pert_on, pert_count, impulse, duration;          // lane 1: push schedule
-    float magnitude, phase;
-    int   simul_len;                                                   // all lanes: torque FIFO fill after the two substeps
-    float tgt[ONI], qn[ONI], qv[ONI];                                  // items: mocap target, encoder angle and rate
-    float atq[ONI];                                                    // items (env, leg joint): action torque of the step
-    float act[(EPO * DW_NUM_ACT + 63) / 64];                           // items (env, action): the clamped action
+    float qn[ONI], qv[ONI];                                            // items: encoder angle and rate after the second substep
 };
 
 // Rows of NW consecutive floats at any 4-byte alignment, moved in 16-byte pieces (global_load/store_dwordx4 take dword-aligned
@@ -85,7 +80,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
                           const float *noise, long long step, int wave_index, OLane &X, const float (&qv)[ONI], const float (&qdv)[ONI],
                           const StepKeep &KP) {
     float *LF = reinterpret_cast<float *>(&L.slot[0][0]);
-    const int lane = X.lane, j = X.o, el = X.el, e = X.env;      // j: octet lane (0..7); lanes 4..7 idle in the per-env scalar groups
+    // (the lane id again, opaque to the optimiser: index arithmetic shared with the pre-physics phase would otherwise be kept in
+    //  registers across the two substeps)
+    int lane = X.lane;
+    DQ_OPAQUE(lane);
+    const int j = lane & 7, el = lane >> 3, e = X.env;      // j: octet lane (0..7); lanes 4..7 idle in the per-env scalar groups
     const int N = C.num_envs;
     dw::TaskBuffers TB;
     TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
@@ -121,6 +120,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         constexpr int NP = EPO * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
         const int nvalid = N - wave_index * EPO;                          // envs of this wave that exist (>= 1)
         const int np_ok = (nvalid >= EPO ? EPO : nvalid) * (DW_ES_WORDS / 4);
+        wave_sync_global();           // (the pre-physics phase of this wave wrote fields of these records)
         const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)wave_index * EPO * DW_ES_WORDS);
         F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
         constexpr int GRP = PER;
@@ -139,34 +139,17 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     if (lane < DW_NUM_OBS1) { OBN[lane] = c_om; OBN[DW_NUM_OBS1 + lane] = c_od; }
     wave_sync();
     // ---- the record fields this step has produced so far (dw_task.h P1..P3), from the lanes that hold them ----
-    if (j == 0) {
-        PQ_ESI(el, DW_ES_MOCAP_IDX) = KP.midx;
-        PQ_ES(el, DW_ES_TARGET_FORCE) = KP.tf0; PQ_ES(el, DW_ES_TARGET_FORCE + 1) = KP.tf1;
-        PQ_ESI(el, DW_ES_SIMUL_LEN) = KP.simul_len;
-    }
-    if (j == 1) {
-        PQ_ESI(el, DW_ES_PERT_START) = KP.pert_start; PQ_ESI(el, DW_ES_PERT_ON) = KP.pert_on; PQ_ESI(el, DW_ES_PERT_COUNT) = KP.pert_count;
-        PQ_ESI(el, DW_ES_IMPULSE) = KP.impulse; PQ_ESI(el, DW_ES_PERT_DURATION) = KP.duration;
-        PQ_ES(el, DW_ES_MAGNITUDE) = KP.magnitude; PQ_ES(el, DW_ES_PHASE) = KP.phase;
-    }
-    if (j < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * j + i) = X.warm[i]; }
-    DQ_UNROLL for (int k = 0; k < (EPO * DW_NUM_ACT + 63) / 64; ++k) {
-        const int i = lane + 64 * k;
-        if (i < EPO * DW_NUM_ACT) PQ_ES(i / DW_NUM_ACT, DW_ES_ACTIONS + (i - DW_NUM_ACT * (i / DW_NUM_ACT))) = KP.act[k];
-    }
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
         if (i < EPO * ND) {
             const int ee = i / ND, d = i - ND * ee;
             const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
-            PQ_ES(ee, DW_ES_TARGET_QPOS + d) = KP.tgt[k];
             PQ_ES(ee, DW_ES_QPOS_NOISE + d) = KP.qn[k];
             PQ_ES(ee, DW_ES_QPOS_PRE + d) = KP.qn[k];
             PQ_ES(ee, DW_ES_QVEL_NOISE + d) = KP.qv[k];
             if (d < 12) {
                 // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
-                const float at = KP.atq[k];
-                PQ_ES(ee, DW_ES_ACTION_TORQUE + d) = at;
+                const float at = PQ_ES(ee, DW_ES_ACTION_TORQUE + d);
                 float col[DW_ALOG_SLOTS];
                 DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(ee, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;
                 DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) PQ_ES(ee, DW_ES_ACTION_LOG + 12 * s2 + d) = col[s2];

@@ -38,6 +38,9 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
     int   self_collision;
     // height field (row f-4); hs == nullptr on the ground plane
     const int16_t *hs;
+    // octet kernels: where a lane parks the self-collision wrenches of its proxies between the resolution and the inward pass
+    // (rare path; [waves][64][DW_SC_PARK_WORDS], allocated at dw_create)
+    float *sc_park;
     int   t_rows, t_cols;
     float t_inv_h, t_vs, t_border;
 };

@@ -46,6 +46,7 @@ struct alignas(16) QLds {
     F4   slot[NB * 4][EPW];
     QHot hot;
 };
+static_assert(QMAX_OWN <= 4, "scGym0 holds one byte per own proxy");
 static_assert(sizeof(QLds) <= 40960, "QLds must leave room for 4 waves per CU (160 KB of LDS)");
 
 // 16-byte LDS accesses that stay 16 bytes wide: without the opaque touch the compiler narrows a load whose .w is unused to
@@ -464,9 +465,9 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
     //      same force from the same data: no hand-over between lanes). ----
     bool sc_any = false;
     float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
-    int scGym0 = 0, scGym1 = 0;          // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
+    int scGym0 = 0;                      // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
     DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
-    const int nprox = L.hot.misc[2], ncombo = L.hot.misc[3];
+    const int nprox = L.hot.misc[2], ncombo = L.hot.misc[3] & 255;
     auto proxy_bits = [&](int p) { return f2i(L.hot.prox[p][7]); };
     auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
         const F4 *pr = reinterpret_cast<const F4 *>(L.hot.prox[p]);
@@ -557,7 +558,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                             cross3(side ? cb : ca, Fs, nb);
                             DQ_UNROLL for (int kk = 0; kk < QMAX_OWN; ++kk)
                                 if (kk == k) { DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[kk][i] += nb[i]; scW[kk][3 + i] += Fs[i]; } }
-                            if (k < 4) scGym0 |= gy << (8 * k); else scGym1 |= gy << (8 * (k - 4));
+                            scGym0 |= gy << (8 * k);
                         }
                     }
                 }
@@ -672,7 +673,7 @@ DQ_HD void quad_substep(QLds &L, const QuadModel &QM, const DevModel &M, const P
                 DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
                     if ((scm >> p) & 1) {
                         DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
-                        const int gy = ((p < 4 ? scGym0 >> (8 * p) : scGym1 >> (8 * (p - 4)))) & 255;     // (0 where unloaded: adds nothing)
+                        const int gy = (scGym0 >> (8 * p)) & 255;     // (0 where unloaded: adds nothing)
                         DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
                             if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
                     }

@@ -49,10 +49,14 @@ void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadM
     if (terrain) hipLaunchKernelGGL(dw_k_simulate_quad<true>, grid, dim3(64), 0, stream, QM, M, P, B, tau, push);
     else hipLaunchKernelGGL(dw_k_simulate_quad<false>, grid, dim3(64), 0, stream, QM, M, P, B, tau, push);
 }
-int build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err) {
+int build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err, bool octet) {
     QuadModel *q = (QuadModel *)malloc(sizeof(QuadModel));
     if (!q) { *err = "out of host memory"; return DW_ENOMEM; }
-    const int rc = build_quadmodel(hm, model, q, err);
+    int rc = build_quadmodel(hm, model, q, err, octet);
+    // (the octet kernels carry no parking registers: build_quadmodel(accumulate) must have scheduled every hand-over)
+    if (rc == DW_OK && octet)
+        for (int s = 0; s < QS_MAX; ++s) for (int l = 0; l < 4; ++l)
+            if (q->in[s][l].body >= 0 && (q->in[s][l].flags & 2)) { rc = DW_EINVAL; *err = "octet kernels: the schedule parks a chain"; }
     if (rc) { free(q); return rc; }
     *out = q;
     return DW_OK;

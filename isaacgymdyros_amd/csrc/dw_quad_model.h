@@ -28,7 +28,7 @@ constexpr int EPW = 16;          // environments per wavefront
 constexpr int QS_MAX = 11;       // schedule length bound (TOCABI needs 11; every step costs 448 B of LDS)
 constexpr int QMAX_PROX = 16;    // self-collision proxies
 constexpr int QMAX_COMBO = 16;   // detection passes (see QHot::combo)
-constexpr int QMAX_OWN = 6;      // proxies on the bodies of one lane
+constexpr int QMAX_OWN = 4;      // proxies on the bodies of one lane (TOCABI: 4 per leg, torso + 3 on the left arm's lane, 3 on the right arm's)
 constexpr int QMAX_GEOM = 6;     // ground primitives per moving body the inward step handles
 constexpr int QMAX_GYM = 3;      // Gym bodies welded into one moving body
 
@@ -64,9 +64,10 @@ struct alignas(16) QHot {
     float in[QS_MAX][4][16];
     float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound
     int   fmask[QS_MAX];         // outward step s: bit X set = some lane fetches lane X's running state
-    int   gany[QS_MAX];          // inward step s: some lane gathers
-    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] number of detection passes, [4..7] pairs of lane l
-    int   owner[36];             // lane that owns each body (slot position = (env + 4 * owner) & 15)
+    int   gany[QS_MAX];          // inward step s: bit 0 some lane gathers; bits 8.. accumulation (valid | source lane << 1 | destination lane << 3)
+    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] detection passes | pairs << 8, [4..7] pairs of lane l
+    unsigned char owner[36];     // lane that owns each body (slot position = (env + 4 * owner) & 15)
+    alignas(16) float in1[2][12];   // second (welded) inertial record of the sole bodies, per leg lane: com[3], mass, I[6], [10] its Gym body (int bits), [11] its inward step (int bits)
     // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner lane << 16 | index among the
     // owner's proxies << 18.  Detection: proxy p is evaluated by lane p & 3 (its register set p >> 2), and the pairs are
     // tested in PASSES: pass c broadcasts proxy b = combo[c][0] & 255 to the quad and every lane whose bit is set in
@@ -105,7 +106,10 @@ static inline void quat_of_rot(const float *R, float *q) {     // row-major rota
 }
 
 // Builds the schedule and the constant tables.  Returns 0 or DW_EINVAL with a message.
-inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *Q, const char **err) {
+// accumulate = true (octet kernels): a finished chain that would have to be parked is instead ADDED into the running registers
+// of an idle lane whose own finished chain waits for the same parent (TOCABI: the left leg joins the right leg's lane when
+// the left leg's lane starts the neck chain), so no lane ever carries a second, parked articulated inertia.
+inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *Q, const char **err, bool accumulate = false) {
     using namespace dw;
     memset(Q, 0, sizeof(*Q));
     const int nc = d->nchains;
@@ -221,6 +225,7 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
     // ---- inward records (reverse order), hand-over bookkeeping ----
     // state per lane while simulating the inward pass: what its running registers / parking slot hold
     int running_chain[4] = {-1, -1, -1, -1}, parked_chain[4] = {-1, -1, -1, -1};
+    int acc_step[QS_MAX] = {};
     bool gathered[MAX_CHAINS] = {};
     for (int s = 0; s < T; ++s) {
         // all lanes execute: (park) -> (gather) -> body.  Decide parks first for this step.
@@ -239,9 +244,20 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
                 if (!cont) {
                     fresh = true;
                     if (running_chain[l] >= 0 && !gathered[running_chain[l]]) {
-                        if (parked_chain[l] >= 0 && !gathered[parked_chain[l]]) { *err = "quad schedule: two ungathered chains on one lane"; return DW_EINVAL; }
-                        parked_chain[l] = running_chain[l];
-                        r.flags |= 2;
+                        int x = -1;
+                        if (accumulate)
+                            for (int c2 = 0; c2 < 4; ++c2)
+                                if (c2 != l && body_at[T - 1 - s][c2] < 0 && running_chain[c2] >= 0 && !gathered[running_chain[c2]] &&
+                                    cparent[running_chain[c2]] == cparent[running_chain[l]]) x = c2;
+                        if (x >= 0) {
+                            if (acc_step[s]) { *err = "quad schedule: two accumulations in one step"; return DW_EINVAL; }
+                            acc_step[s] = 1 | (l << 1) | (x << 3);          // valid | source lane | destination lane
+                            gathered[running_chain[l]] = true;              // (it travels with lane x's chain from here on)
+                        } else {
+                            if (parked_chain[l] >= 0 && !gathered[parked_chain[l]]) { *err = "quad schedule: two ungathered chains on one lane"; return DW_EINVAL; }
+                            parked_chain[l] = running_chain[l];
+                            r.flags |= 2;
+                        }
                     }
                 } else gathered[running_chain[l]] = true;
                 running_chain[l] = -1;
@@ -417,14 +433,25 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
                 for (int i = 0; i < 3; ++i) p[4 + i] = n.in0_com[i];
                 p[7] = n.in0_mass;
                 for (int i = 0; i < 6; ++i) p[8 + i] = n.in0_I[i];
-                if (n.body >= 0 && n.gather) H.gany[s2] = 1;
+                if (n.body >= 0 && n.gather) H.gany[s2] |= 1;
             }
+        for (int s2 = 0; s2 < QS_MAX; ++s2) H.gany[s2] |= acc_step[s2] << 8;
         for (int i = 0; i < 3; ++i) H.base[i] = Q->base_com[i];
         H.base[3] = Q->base_mass;
         for (int i = 0; i < 6; ++i) H.base[4 + i] = Q->base_I[i];
         H.base[10] = fi(Q->base_gym); H.base[11] = fi(Q->base_ngeom); H.base[12] = Q->base_bound;
-        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nprox; H.misc[3] = ncombo;
-        for (int b = 0; b < NB; ++b) H.owner[b] = Q->owner[b] < 0 ? 0 : Q->owner[b];
+        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nprox; H.misc[3] = ncombo | (Q->npair << 8);
+        for (int b = 0; b < NB; ++b) H.owner[b] = (unsigned char)(Q->owner[b] < 0 ? 0 : Q->owner[b]);
+        for (int l = 0; l < 2; ++l) {
+            int s2k = 0;
+            for (int s2 = 0; s2 < Q->nsteps; ++s2) if (Q->in[s2][l].body >= 0 && Q->in[s2][l].nin > 1) s2k = s2;
+            const QInRec &n = Q->in[s2k][l];
+            for (int i = 0; i < 3; ++i) H.in1[l][i] = n.in1_com[i];
+            H.in1[l][3] = n.in1_mass;
+            for (int i = 0; i < 6; ++i) H.in1[l][4 + i] = n.in1_I[i];
+            H.in1[l][10] = fi(n.in1_gym >= 0 && n.in1_gym < DW_NUM_BODIES ? n.in1_gym : 0);
+            H.in1[l][11] = fi(s2k);
+        }
         for (int p2 = 0; p2 < Q->nprox; ++p2) {
             const DwCapsule &cp = d->sc_proxy[p2];
             for (int i = 0; i < 3; ++i) { H.prox[p2][i] = cp.p0[i]; H.prox[p2][4 + i] = cp.p1[i]; }

@@ -11,6 +11,7 @@
 //   quad_bcast<J>(x)       value of x in lane J of the caller's quad            (v_mov_dpp quad_perm:[J,J,J,J])
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   oct_xor4(x)            value of x in lane (l ^ 4)  (octet kernels)           (row_shl:4 / row_shr:4, complementary bank masks)
+//   oct_lo(x)              value of x in lane (l & ~4) (octet kernels)           (row_shr:4 into the high quads)
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
 //   wave_ballot(p)         64-bit mask of p over the lanes, the same in every lane (v_cmp into an SGPR pair)
 //   wave_sync_global()     as wave_sync, for global memory too (workgroup-scope release / acquire).
@@ -28,6 +29,9 @@
 #include <hip/hip_runtime.h>
 #define DQ_HD __device__ __forceinline__
 #define DQ_OPAQUE(i) asm volatile("" : "+v"(i))
+// the machine scheduler moves nothing across this point: bounds how many iterations of an unrolled loop it overlaps (and with
+// them the registers their loads occupy)
+#define DQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 namespace dwq {
 
 DQ_HD int lane_id() { return (int)(threadIdx.x & 63u); }      // (the octet kernels run two waves per workgroup)
@@ -46,6 +50,11 @@ DQ_HD float oct_xor4(float x) {
     int r = __builtin_amdgcn_update_dpp(xi, xi, 0x104, 0xF, 0x5, false);
     r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);
     return __builtin_bit_cast(float, r);
+}
+// value of x in the half-0 lane of my limb (lane l & ~4): one move, the high quads take the value 4 lanes down
+DQ_HD float oct_lo(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x114, 0xF, 0xA, false));
 }
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
@@ -76,6 +85,7 @@ DQ_HD void atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicA
 #include <string.h>
 #define DQ_HD static inline
 #define DQ_OPAQUE(i) ((void)0)
+#define DQ_SCHED_FENCE() ((void)0)
 #if defined(__SANITIZE_ADDRESS__)
 extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
 extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
@@ -210,6 +220,7 @@ template <int J> DQ_HD float quad_bcast(float x) { return emu_xchg(x, (g_emu->cu
 DQ_HD float quad_xor1(float x) { return emu_xchg(x, g_emu->cur ^ 1); }
 DQ_HD float quad_xor2(float x) { return emu_xchg(x, g_emu->cur ^ 2); }
 DQ_HD float oct_xor4(float x) { return emu_xchg(x, g_emu->cur ^ 4); }
+DQ_HD float oct_lo(float x) { return emu_xchg(x, g_emu->cur & ~4); }
 DQ_HD bool wave_any(bool p) {
     WaveEmu *e = g_emu;
     const int l = e->cur, par = (int)(e->nsync[l] & 1);

@@ -16,6 +16,7 @@ struct DwHandle {
     dwq::QuadModel qmodel;
     dw::DevParams dp;
     float *mocap;
+    float *sc_park;
     int bound;
 };
 
@@ -68,9 +69,12 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     h->cfg = *cfg;
     const char *err = "";
     int rc = dw::build_devmodel(model, task, &h->model, &err);
-    if (rc == DW_OK) rc = dwq::build_quadmodel(&h->model, model, &h->qmodel, &err);
+    if (rc == DW_OK) rc = dwq::build_quadmodel(&h->model, model, &h->qmodel, &err, true);
+    if (rc == DW_OK) for (int s = 0; s < dwq::QS_MAX; ++s) for (int l = 0; l < 4; ++l) if (h->qmodel.in[s][l].body >= 0 && (h->qmodel.in[s][l].flags & 2)) { rc = DW_EINVAL; err = "octet kernels: the schedule parks a chain"; }
     if (rc) { free(h); return fail(rc, err); }
     h->dp.C = dw::make_task_params(cfg);
+    h->sc_park = (float *)calloc((size_t)(cfg->num_envs + 15) / 16 * 2 * 64 * dwo::SC_PARK_WORDS, sizeof(float));
+    h->dp.C.phys.sc_park = h->sc_park;
     if (task) {
         h->mocap = (float *)malloc(sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
         memcpy(h->mocap, task->mocap, sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
@@ -79,7 +83,7 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     *out = h;
     return DW_OK;
 }
-int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h); return DW_OK; }
+int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h->sc_park); free(h); return DW_OK; }
 int dwe_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dwe_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);

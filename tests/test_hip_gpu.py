@@ -18,9 +18,9 @@ def pipeline(request):
 
 def _oracle_like(env, task_const):
     from oracle.oracle import OracleSim
-    o = OracleSim(env.num_envs, task_const=task_const, cfg=env._ccfg)
+    o = OracleSim(env.num_envs, task_const=task_const, cfg=env._ccfg, terrain=getattr(env, "terrain", None))
     for k, t in env._buf.items():
-        o.buf[k][...] = t.cpu().numpy()
+        o.buf[k][...] = t.cpu().numpy().reshape(o.buf[k].shape)
     return o
 
 
