@@ -24,7 +24,7 @@ namespace dwo {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::oct_lo; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
@@ -45,14 +45,46 @@ struct alignas(16) OLds {
 static_assert(sizeof(OLds) <= 40960, "OLds: 4 workgroups (8 waves) per CU must fit 160 KB of LDS");
 // (as byte offsets: even rows of a flipped limb lie one row up, odd rows one row down -- two lane-dependent bases, so that every
 //  access is base + a compile-time offset and the compiler need not keep one address register per body and row)
+// A body's slot is its CELL: cellbase[owner lane] + outward step (dw_quad_model.h), so a limb's bodies lie in schedule order and
+// the chain passes, unrolled over the steps, address them as lane base + compile-time offset: no slot address depends on a
+// table read.  OQ_SLOT(st, q, p): row q of the body that the limb of position code p visits in outward step st; item lanes
+// and cross-limb reads reach a body through icode() (cell from the owner table) with st = 0.
 struct OPos { int e, o; };
-DQ_HD OPos pcode(int el, int owner) {
+DQ_HD OPos pcode_cell(int el, int owner, int cell) {
     const int pos = (el + 4 * (owner >> 1)) & 7, flip = owner & 1;
-    OPos p; p.e = pos * 16 + flip * 128; p.o = pos * 16 - flip * 128;
+    OPos p; p.e = cell * 512 + pos * 16 + flip * 128; p.o = cell * 512 + pos * 16 - flip * 128;
     return p;
 }
-#define OQ_SLOT(b, q, p) (*reinterpret_cast<F4 *>(reinterpret_cast<char *>(&L.slot[0][0]) + (((q) & 1) ? (p).o : (p).e) + ((b) * 4 + (q)) * 128))
-#define OQ_LD(b, q, p) ld4(OQ_SLOT(b, q, p))
+DQ_HD OPos pcode(const QHot &H, int el, int owner) {          // a limb: cell = cellbase + step
+    return pcode_cell(el, owner, (int)(signed char)((f2i(H.base[13]) >> (8 * owner)) & 255));
+}
+DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
+    const int co = H.owner[b];
+    return pcode_cell(el, co >> 6, co & 63);
+}
+#define OQ_SLOT(st, q, p) (*reinterpret_cast<F4 *>(reinterpret_cast<char *>(&L.slot[0][0]) + (((q) & 1) ? (p).o : (p).e) + ((st) * 4 + (q)) * 128))
+#define OQ_LD(b, q, p) ldp(OQ_SLOT(b, q, p))
+// the loops over the schedule steps stay loops: unrolled, one substep is 100 KB of straight-line code that every wave streams
+// through the 64 KB instruction cache (measured: +5 % step time)
+#if defined(__HIPCC__)
+#define DQ_ROLLED _Pragma("clang loop unroll(disable)")
+#else
+#define DQ_ROLLED
+#endif
+// 16-byte LDS loads that stay 16 bytes wide.  A load whose .w is unused is narrowed to ds_read_b96 (twice the LDS cycles of
+// ds_read_b128, MI355X_MICROARCH.md); dw_quad.h's ld4() prevents that with an opaque touch after EVERY load, which also makes
+// the wave wait for every load by itself.  Here loads are plain and ONE touch of the unused .w components follows a group of
+// them: the group is in flight together and waited for once.
+#if defined(__HIPCC__)
+#define OQ_KEEP1(a) asm volatile("" : "+v"((a).w))
+#define OQ_KEEP2(a, b) asm volatile("" : "+v"((a).w), "+v"((b).w))
+#define OQ_KEEP3(a, b, c) asm volatile("" : "+v"((a).w), "+v"((b).w), "+v"((c).w))
+#else
+#define OQ_KEEP1(a) ((void)0)
+#define OQ_KEEP2(a, b) ((void)0)
+#define OQ_KEEP3(a, b, c) ((void)0)
+#endif
+DQ_HD F4 ldp(const F4 &p) { return p; }
 
 // copies the hot tables from the device-resident model into LDS.  Both waves of the workgroup copy all of it (identical
 // bytes), so neither has to wait for the other: no workgroup barrier anywhere in these kernels.
@@ -78,6 +110,30 @@ struct OLane {
     int   stamp_base;                        // profiling builds only
 };
 
+// add_rigid of dw_quad.h in two parts: IA += rigid inertia [[Ao, H], [H', m 1]], H = skew(ho) ...
+DQ_HD void add_rigid_inertia(float *IA, const float *Ao, const float *ho, float mass) {
+    DQ_UNROLL for (int r = 0; r < 3; ++r)
+        DQ_UNROLL for (int c = r; c < 3; ++c) IA[sym6(r, c)] += dwq::ao(Ao, r, c);
+    IA[sym6(0, 4)] += -ho[2]; IA[sym6(0, 5)] += ho[1];
+    IA[sym6(1, 3)] += ho[2];  IA[sym6(1, 5)] += -ho[0];
+    IA[sym6(2, 3)] += -ho[1]; IA[sym6(2, 4)] += ho[0];
+    IA[sym6(3, 3)] += mass; IA[sym6(4, 4)] += mass; IA[sym6(5, 5)] += mass;
+}
+// ... and the gyroscopic bias pv = v x* (I v)
+DQ_HD void rigid_bias(const float *Ao, const float *ho, float mass, const float *v, float *pv) {
+    const float *om = v, *vl = v + 3;
+    float n[3], f[3], t1[3], t2[3];
+    DQ_UNROLL for (int r = 0; r < 3; ++r) n[r] = dwq::ao(Ao, r, 0) * om[0] + dwq::ao(Ao, r, 1) * om[1] + dwq::ao(Ao, r, 2) * om[2];
+    cross3(ho, vl, t1);
+    n[0] += t1[0]; n[1] += t1[1]; n[2] += t1[2];
+    cross3(om, ho, t1);
+    f[0] = t1[0] + mass * vl[0]; f[1] = t1[1] + mass * vl[1]; f[2] = t1[2] + mass * vl[2];
+    cross3(om, n, t1); cross3(vl, f, t2);
+    pv[0] = t1[0] + t2[0]; pv[1] = t1[1] + t2[1]; pv[2] = t1[2] + t2[2];
+    cross3(om, f, t1);
+    pv[3] = t1[0]; pv[4] = t1[1]; pv[5] = t1[2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // The substep.  On entry every body's slot holds quad 0 = {q, qd, tt, dd} with tt = tau - damping * qd and
 // dd = armature + dt * damping (the caller's prologue), X.root the base state, and the hot tables are staged (stage_hot).  The
@@ -88,7 +144,7 @@ struct OLane {
 struct FkHot { float pos[3], axis[3], vmax, qlo, qhi; int body, psrc, flags, scm; };
 DQ_HD FkHot fk_hot(const QHot &H, int s, int j) {
     const F4 *r = reinterpret_cast<const F4 *>(H.fk[s][j]);
-    const F4 a = ld4(r[0]), b = ld4(r[1]), c = ld4(r[2]);
+    const F4 a = ldp(r[0]), b = ldp(r[1]), c = ldp(r[2]);
     FkHot h;
     h.pos[0] = a.x; h.pos[1] = a.y; h.pos[2] = a.z;
     const int bits = f2i(a.w);
@@ -108,7 +164,8 @@ template <bool TERRAIN>
 DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevModel &M, const PhysParams &P, OLane &X, const DwBuffers &B,
                         float push_x, float push_y, bool last) {
     const float dt = P.dt, inv_dt = 1.0f / P.dt;
-    const int j = X.j, T = H.misc[0];
+    const int j = X.j;
+    constexpr int T = QS_MAX;         // (the octet kernels are built for a schedule of exactly QS_MAX steps: checked at dw_create)
     const int SB = X.stamp_base; (void)SB;
     DQ_STAMP(B, SB + 0);
     const int e = X.env;
@@ -136,67 +193,83 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 1);
-    // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist. ----
+    // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist.  A step comes in two forms,
+    //      chosen by a wave-uniform bit of the schedule: in most steps no lane starts a chain, every lane's parent is the body
+    //      of its previous step, and the lean form updates the running state unconditionally (lanes that idle compute on
+    //      zeros and store nothing); the three steps in which some chain starts -- at the base or below another lane's body,
+    //      whose running state is fetched from that lane's registers -- take the general form with its selects. ----
+    const int startmask = f2i(H.base[15]);
     {
         float qr[4] = {0, 0, 0, 1}, Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xr_[3] = {0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < T; ++s) {
-            const FkHot rc = fk_hot(H, s, j);
-            const int b = rc.body, psrc = rc.psrc;
-            // limbs that start below another lane's body fetch that lane's running state (still in its registers)
-            float fq[4], fx[3], fv[6];
-            bool fetched = false;
-            const int fm = H.fmask[s];
-            if (fm) {
-                for (int xl = 0; xl < 4; ++xl)
-                    if ((fm >> xl) & 1) {
-                        float tq[4], tx[3], tv[6];
-                        quad_bcast_arr(xl, qr, tq); quad_bcast_arr(xl, xr_, tx); quad_bcast_arr(xl, vr, tv);
-                        if (b >= 0 && psrc == 2 + xl) {
-                            fetched = true;
-                            DQ_UNROLL for (int i = 0; i < 4; ++i) fq[i] = tq[i];
-                            DQ_UNROLL for (int i = 0; i < 3; ++i) fx[i] = tx[i];
-                            DQ_UNROLL for (int i = 0; i < 6; ++i) fv[i] = tv[i];
-                        }
-                    }
-            }
-            // (both halves of a limb walk it: every lane reads its slot rows before any lane overwrites them)
-            F4 in = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (b >= 0) in = OQ_LD(b, 0, X.pos);            // {q, qd, tt, dd}
-            wave_sync();
+        auto fk_body = [&](int s, const FkHot &rc, const F4 &in) {          // the arithmetic of a step and its stores
+            const int b = rc.body;
+            float sn, cs;
+            sincos_fast(0.5f * in.x, &sn, &cs);
+            float qj[4] = {rc.axis[0] * sn, rc.axis[1] * sn, rc.axis[2] * sn, cs};
+            if (rc.flags & 1) qmul(QM.fk[s][j].q0, qj, qj);          // (two bodies of the model: the hands)
+            float x[3], t[3];
+            m3v(Rr, rc.pos, t);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) x[i] = xr_[i] + t[i];
+            qmul(qr, qj, qr);
+            quat_to_mat(qr, Rr);
+            float aw[3], sl[3];
+            m3v(Rr, rc.axis, aw);
+            cross3(x, aw, sl);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { vr[i] += aw[i] * in.y; vr[3 + i] += sl[i] * in.y; xr_[i] = x[i]; }
             if (b >= 0) {
-                if (psrc == 1) {
-                    DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = qn[i];
-                    DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0k[i];
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = 0.0f; vr[i] = ww[i]; vr[3 + i] = vo[i]; }
-                } else if (fetched) {
-                    DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fq[i];
-                    quat_to_mat(qr, Rr);
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) xr_[i] = fx[i];
-                    DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
-                }
-                float sn, cs;
-                sincos_fast(0.5f * in.x, &sn, &cs);
-                float qj[4] = {rc.axis[0] * sn, rc.axis[1] * sn, rc.axis[2] * sn, cs};
-                if (rc.flags & 1) qmul(QM.fk[s][j].q0, qj, qj);          // (two bodies of the model: the hands)
-                float x[3], t[3];
-                m3v(Rr, rc.pos, t);
-                DQ_UNROLL for (int i = 0; i < 3; ++i) x[i] = xr_[i] + t[i];
-                qmul(qr, qj, qr);
-                quat_to_mat(qr, Rr);
-                float aw[3], sl[3];
-                m3v(Rr, rc.axis, aw);
-                cross3(x, aw, sl);
-                DQ_UNROLL for (int i = 0; i < 3; ++i) { vr[i] += aw[i] * in.y; vr[3 + i] += sl[i] * in.y; xr_[i] = x[i]; }
-                OQ_SLOT(b, 0, X.pos) = mk4(qr[0], qr[1], qr[2], qr[3]);
-                OQ_SLOT(b, 1, X.pos) = mk4(x[0], x[1], x[2], in.y);
-                OQ_SLOT(b, 2, X.pos) = mk4(vr[0], vr[1], vr[2], in.z);
-                OQ_SLOT(b, 3, X.pos) = mk4(vr[3], vr[4], vr[5], in.w);
+                OQ_SLOT(s, 0, X.pos) = mk4(qr[0], qr[1], qr[2], qr[3]);
+                OQ_SLOT(s, 1, X.pos) = mk4(x[0], x[1], x[2], in.y);
+                OQ_SLOT(s, 2, X.pos) = mk4(vr[0], vr[1], vr[2], in.z);
+                OQ_SLOT(s, 3, X.pos) = mk4(vr[3], vr[4], vr[5], in.w);
                 if (rc.flags & 2) {
                     // pose of the sole body for the contact phase, in the four slot rows of body 0 (the base has no slot; the
                     // step kernel's per-env scratch there is dead once the substeps run): foot f = j in rows 2 f, 2 f + 1
                     L.slot[2 * j][X.el] = mk4(qr[0], qr[1], qr[2], qr[3]);
                     L.slot[2 * j + 1][X.el] = mk4(x[0], x[1], x[2], 0.0f);
                 }
+            }
+        };
+        DQ_ROLLED for (int s = 0; s < T; ++s) {
+            const FkHot rc = fk_hot(H, s, j);
+            const int b = rc.body, psrc = rc.psrc;
+            // (both halves of a limb walk it: every lane reads its slot row before any lane overwrites it)
+            F4 in = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (b >= 0) in = OQ_LD(s, 0, X.pos);            // {q, qd, tt, dd}
+            if ((startmask >> s) & 1) {
+                // limbs that start below another lane's body fetch that lane's running state (still in its registers)
+                float fq[4], fx[3], fv[6];
+                bool fetched = false;
+                const int fm = H.fmask[s];
+                if (fm) {
+                    for (int xl = 0; xl < 4; ++xl)
+                        if ((fm >> xl) & 1) {
+                            float tq[4], tx[3], tv[6];
+                            quad_bcast_arr(xl, qr, tq); quad_bcast_arr(xl, xr_, tx); quad_bcast_arr(xl, vr, tv);
+                            if (b >= 0 && psrc == 2 + xl) {
+                                fetched = true;
+                                DQ_UNROLL for (int i = 0; i < 4; ++i) fq[i] = tq[i];
+                                DQ_UNROLL for (int i = 0; i < 3; ++i) fx[i] = tx[i];
+                                DQ_UNROLL for (int i = 0; i < 6; ++i) fv[i] = tv[i];
+                            }
+                        }
+                }
+                if (b >= 0) {
+                    if (psrc == 1) {
+                        DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = qn[i];
+                        DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0k[i];
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = 0.0f; vr[i] = ww[i]; vr[3 + i] = vo[i]; }
+                    } else if (fetched) {
+                        DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fq[i];
+                        quat_to_mat(qr, Rr);
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) xr_[i] = fx[i];
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
+                    }
+                }
+                wave_sync();
+                fk_body(s, rc, in);
+            } else {
+                wave_sync();
+                fk_body(s, rc, in);
             }
         }
     }
@@ -217,11 +290,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     auto proxy_bits = [&](int p) { return f2i(H.prox[p][7]); };
     auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
         const F4 *pr = reinterpret_cast<const F4 *>(H.prox[p]);
-        const F4 c0 = ld4(pr[0]), c1 = ld4(pr[1]);
+        F4 c0 = ldp(pr[0]), c1 = ldp(pr[1]);
         const int bits = f2i(c1.w);
         const int bp = bits & 255;
-        const OPos posp = pcode(X.el, (bits >> 16) & 3);
-        const F4 q4 = OQ_LD(bp, 0, posp), x4 = OQ_LD(bp, 1, posp);
+        const OPos posp = icode(H, X.el, bp);
+        F4 q4 = OQ_LD(0, 0, posp), x4 = OQ_LD(0, 1, posp);
+        OQ_KEEP2(c0, x4);
         const float qb[4] = {q4.x, q4.y, q4.z, q4.w}, l0[3] = {c0.x, c0.y, c0.z}, l1[3] = {c1.x, c1.y, c1.z};
         float Rb[9], t0[3], t1[3];
         quat_to_mat(qb, Rb);
@@ -277,8 +351,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     proxy_ends(pa, a0, a1);
                     proxy_ends(pbx, b0, b1);
                     const int ba = bita & 255, bb = bitb & 255;
-                    const OPos posa = pcode(X.el, (bita >> 16) & 3), posb = pcode(X.el, (bitb >> 16) & 3);
-                    const F4 va2 = OQ_LD(ba, 2, posa), va3 = OQ_LD(ba, 3, posa), vb2 = OQ_LD(bb, 2, posb), vb3 = OQ_LD(bb, 3, posb);
+                    const OPos posa = icode(H, X.el, ba), posb = icode(H, X.el, bb);
+                    F4 va2 = OQ_LD(0, 2, posa), va3 = OQ_LD(0, 3, posa), vb2 = OQ_LD(0, 2, posb), vb3 = OQ_LD(0, 3, posb);
+                    OQ_KEEP2(va2, va3); OQ_KEEP2(vb2, vb3);
                     const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
                     float F[3], ca[3], cb[3];
                     if (capsule_pair(a0, a1, H.prox[pa][3], b0, b1, H.prox[pbx][3], va, vb, P, F, ca, cb)) {
@@ -305,173 +380,221 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     wave_sync();      // the leg lanes read each other's slots above; the inward pass below overwrites them
 
     DQ_STAMP(B, SB + 3);
-    // ---- inward pass: articulated inertias and bias forces, in reverse schedule order ----
+    // ---- inward pass: articulated inertias and bias forces, in reverse schedule order, TWO steps per round.  What a body
+    //      contributes by itself -- joint subspace, rigid inertia about O, gyroscopic bias, external forces, velocity-product
+    //      acceleration: more than half of a step's arithmetic, and no recursion in it -- is a MAP over bodies: half 0 of a limb
+    //      maps the body of step 2 r, half 1 the body of step 2 r + 1, at the same time.  The recursion proper (add into the
+    //      running inertia, U = IA S, rank-1 downdate, bias) then runs for step 2 r on half 0's result, takes half 1's result
+    //      over (31 words, one DPP move each) and runs for step 2 r + 1.  Half 1 executes the recursion's instructions on
+    //      values nobody reads (its stores are masked); it gets the base's inertia back before the base solve. ----
     float IA[21], pA[6];          // running reflected inertia / bias (no lane parks a second one: build_quadmodel(accumulate))
     DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
     DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     const int my_sole_gym = (j == 0) ? M.left_foot_gym : (j == 1 ? M.right_foot_gym : -1);
-    // the one per-env global value a step needs (the mass scale of the body's Gym body) is requested a step ahead
-    float ms_next = mscale_e[(f2i(H.in[0][j][2]) >> 24) & 255];
-    for (int s = 0; s < T; ++s) {
+    struct BodyMap { float Ao[6], ho[3], mass, pv[6], S[6], cb[6], tt, dd, qd; };       // 31 words
+    auto step_clamped = [&](int s) { return s < T ? s : T - 1; };
+    // the one per-env global value a map needs (the mass scale of the body's Gym body) is requested a round ahead
+    float ms_next = mscale_e[(f2i(H.in[step_clamped(X.h)][j][2]) >> 24) & 255];
+#if defined(DQ_STAMPS) && defined(__HIPCC__)
+    long long tq_map = 0, tq_rec = 0, tq_t0 = 0;
+#define OQ_TICK() (tq_t0 = (long long)__builtin_readcyclecounter())
+#define OQ_TOCK(acc) (acc += (long long)__builtin_readcyclecounter() - tq_t0)
+#else
+#define OQ_TICK() ((void)0)
+#define OQ_TOCK(acc) ((void)0)
+#endif
+    const OPos posM = {X.pos.e - X.h * 512, X.pos.o - X.h * 512};          // my map's body of a round: outward step T - 1 - s - h
+    DQ_ROLLED for (int s = 0; s < T; s += 2) {
+        OQ_TICK();
 #if defined(DQ_STAMPS_INWARD)
         if (SB == 1) DQ_STAMP(B, 42 + s);
 #endif
-        const F4 *hr = reinterpret_cast<const F4 *>(H.in[s][j]);
-        const F4 h0 = ld4(hr[0]), h1 = ld4(hr[1]), h2 = ld4(hr[2]), h3 = ld4(hr[3]);
-        const int bits = f2i(h0.x);
-        const int b = (bits & 255) - 1;
-        const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
-        const int nin = (bits >> 12) & 3, ngym = (bits >> 14) & 3, ngeom = (bits >> 16) & 15, scm = (bits >> 24) & 255;
-        const int gymbits = f2i(h0.z);
-        const float ms0 = ms_next;
-        if (s + 1 < T) ms_next = mscale_e[(f2i(H.in[s + 1][j][2]) >> 24) & 255];
-        const int gw = H.gany[s];
-        if (gw >> 8) {                      // a finished chain joins the finished chain of an idle lane (same parent) before its lane starts afresh
-            const int src = (gw >> 9) & 3, dst = (gw >> 11) & 3;
-            float tI[21], tp[6];
-            quad_bcast_arr(src, IA, tI);
-            quad_bcast_arr(src, pA, tp);
-            if (j == dst) {
-                DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] += tI[i];
-                DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] += tp[i];
-            }
-        }
-        if (flags & 1) {
-            DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
-            DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
-        }
-        // gathers (wave-uniform per step): child chains that ended on other lanes
-        if (gw & 1) {
-            const int g0 = f2i(H.in[s][0][1]), g1 = f2i(H.in[s][1][1]), g2 = f2i(H.in[s][2][1]), g3 = f2i(H.in[s][3][1]);
-            const int mine = f2i(h0.y);
-            DQ_UNROLL for (int src = 0; src < 4; ++src) {
-                const int code = src | 8;
-                bool used = false, want = false;
-                DQ_UNROLL for (int k = 0; k < 3; ++k) {
-                    used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
-                           (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
-                    want = want || (((mine >> (4 * k)) & 15) == code);
-                }
-                if (used) {
-                    DQ_UNROLL for (int i = 0; i < 21; ++i) {
-                        const float t = src == 0 ? quad_bcast<0>(IA[i]) : (src == 1 ? quad_bcast<1>(IA[i]) : (src == 2 ? quad_bcast<2>(IA[i]) : quad_bcast<3>(IA[i])));
-                        if (want) IA[i] += t;
-                    }
-                    DQ_UNROLL for (int i = 0; i < 6; ++i) {
-                        const float t = src == 0 ? quad_bcast<0>(pA[i]) : (src == 1 ? quad_bcast<1>(pA[i]) : (src == 2 ? quad_bcast<2>(pA[i]) : quad_bcast<3>(pA[i])));
-                        if (want) pA[i] += t;
-                    }
-                }
-            }
-        }
-        F4 s0 = mk4(0.0f, 0.0f, 0.0f, 1.0f), s1 = s0, s2 = s0, s3 = s0;
-        if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
-        wave_sync();          // (mirrored halves: reads before overwrites)
-        if (b >= 0) {
-            const F4 ax4 = ld4(reinterpret_cast<const F4 *>(H.fk[T - 1 - s][j])[1]);
+        BodyMap Mb;
+        {   // ---- map: my body of this round (step s + h) ----
+            const int sm = step_clamped(s + X.h);
+            const F4 *hr = reinterpret_cast<const F4 *>(H.in[sm][j]);
+            const F4 h0 = ldp(hr[0]), h1 = ldp(hr[1]), h2 = ldp(hr[2]), h3 = ldp(hr[3]);
+            const int bits = f2i(h0.x);
+            const int b = (s + X.h < T) ? (bits & 255) - 1 : -1;
+            const int nin = (bits >> 12) & 3, ngym = (bits >> 14) & 3, ngeom = (bits >> 16) & 15, scm = (bits >> 24) & 255;
+            const int gymbits = f2i(h0.z);
+            const float ms0 = ms_next;
+            ms_next = mscale_e[(f2i(H.in[step_clamped(s + 2 + X.h)][j][2]) >> 24) & 255];
+            F4 s0 = mk4(0.0f, 0.0f, 0.0f, 1.0f), s1 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s2 = s1, s3 = s1;
+            if (b >= 0) { s0 = OQ_LD(T - 1 - s, 0, posM); s1 = OQ_LD(T - 1 - s, 1, posM); s2 = OQ_LD(T - 1 - s, 2, posM); s3 = OQ_LD(T - 1 - s, 3, posM); }
+            F4 ax4 = ldp(reinterpret_cast<const F4 *>(H.fk[T - 1 - sm][j])[1]);
+            OQ_KEEP1(ax4);
             const float axis[3] = {ax4.x, ax4.y, ax4.z};
             const float qb[4] = {s0.x, s0.y, s0.z, s0.w}, x[3] = {s1.x, s1.y, s1.z}, v[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
-            const float qd = s1.w, tt = s2.w, dd = s3.w;
+            Mb.qd = s1.w; Mb.tt = s2.w; Mb.dd = s3.w;
             float R[9];
             quat_to_mat(qb, R);
-            float S[6];
-            m3v(R, axis, S);
-            cross3(x, S, S + 3);
-            // rigid inertia, gyroscopic bias
-            float Ao[6], ho[3], mass;
+            m3v(R, axis, Mb.S);
+            cross3(x, Mb.S, Mb.S + 3);
             {
                 const float com0[3] = {h1.x, h1.y, h1.z}, I0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
                 if (nin > 1) {          // the two sole bodies carry a second (welded) inertial record
                     const F4 *ir = reinterpret_cast<const F4 *>(H.in1[j & 1]);
-                    const F4 i0 = ld4(ir[0]), i1 = ld4(ir[1]), i2 = ld4(ir[2]);
+                    const F4 i0 = ldp(ir[0]), i1 = ldp(ir[1]), i2 = ldp(ir[2]);
                     const float com1[3] = {i0.x, i0.y, i0.z}, I1[6] = {i1.x, i1.y, i1.z, i1.w, i2.x, i2.y};
-                    rigid_inertia(2, com0, h1.w, I0, ms0, com1, i0.w, I1, ms1, R, x, Ao, ho, &mass);
+                    rigid_inertia(2, com0, h1.w, I0, ms0, com1, i0.w, I1, ms1, R, x, Mb.Ao, Mb.ho, &Mb.mass);
                 } else {
-                    rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Ao, ho, &mass);
+                    rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Mb.Ao, Mb.ho, &Mb.mass);
                 }
             }
-            add_rigid(IA, pA, Ao, ho, mass, v);
-            // external forces: ground penalty of the non-sole primitives, self-collision; per Gym body for the report
-            float cf[QMAX_GYM][3];
-            DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
-            bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
-            if (TERRAIN) near_ground = ngeom > 0;
+            rigid_bias(Mb.Ao, Mb.ho, Mb.mass, v, Mb.pv);
+            {
+                float m[6];
+                DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = Mb.S[i] * Mb.qd;
+                dw::motion_cross(v, m, Mb.cb);
+            }
+            if (b >= 0) {
+                // external forces: ground penalty of the non-sole primitives, self-collision; per Gym body for the report
+                float cf[QMAX_GYM][3];
+                DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
+                bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
+                if (TERRAIN) near_ground = ngeom > 0;
 #if defined(DQ_KO_GEOM) || defined(OCT_ABL_GEOM)          // (timing experiment only)
-            near_ground = false;
+                near_ground = false;
 #endif
-            if (near_ground) {
-                const QInRec &rc = QM.in[s][j];
-                for (int k = 0; k < ngeom; ++k) {
-                    float F[3], xr[3];
-                    geom_force<TERRAIN>(M.geoms[rc.geom[k]], P, R, x, v, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
-                    if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
-                        float nb[3];
-                        cross3(xr, F, nb);
-                        DQ_UNROLL for (int i = 0; i < 3; ++i) { pA[i] -= nb[i]; pA[3 + i] -= F[i]; }
-                        const int t = (rc.geom_slot >> (2 * k)) & 3;
-                        DQ_UNROLL for (int tt2 = 0; tt2 < QMAX_GYM; ++tt2)
-                            if (tt2 == t) { cf[tt2][0] += F[0]; cf[tt2][1] += F[1]; cf[tt2][2] += F[2]; }
-                    }
-                }
-            }
-            if (sc_any && scm) {
-                float scW[QMAX_OWN][6];
-                DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = park[6 * p + i];
-                const int scGym0 = f2i(park[6 * QMAX_OWN]);
-                DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
-                    if ((scm >> p) & 1) {
-                        DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] -= scW[p][i];
-                        const int gy = (scGym0 >> (8 * p)) & 255;     // (0 where unloaded: adds nothing)
-                        DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
-                            if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
-                    }
-            }
-            if (last) {
-                DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
-                    if (t < ngym) {
-                        const int gy = (gymbits >> (8 * t)) & 255;
-                        if (gy == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
-                        else {
-                            if (over_1n(cf[t])) X.coll = 1;
-                            if (wr) {
-                                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
-                                dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
-                            }
+                if (near_ground) {
+                    const QInRec &rc = QM.in[sm][j];
+                    for (int k = 0; k < ngeom; ++k) {
+                        float F[3], xr[3];
+                        geom_force<TERRAIN>(M.geoms[rc.geom[k]], P, R, x, v, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
+                        if (F[0] != 0.0f || F[1] != 0.0f || F[2] != 0.0f) {
+                            float nb[3];
+                            cross3(xr, F, nb);
+                            DQ_UNROLL for (int i = 0; i < 3; ++i) { Mb.pv[i] -= nb[i]; Mb.pv[3 + i] -= F[i]; }
+                            const int t = (rc.geom_slot >> (2 * k)) & 3;
+                            DQ_UNROLL for (int tt2 = 0; tt2 < QMAX_GYM; ++tt2)
+                                if (tt2 == t) { cf[tt2][0] += F[0]; cf[tt2][1] += F[1]; cf[tt2][2] += F[2]; }
                         }
                     }
+                }
+                if (sc_any && scm) {
+                    float scW[QMAX_OWN][6];
+                    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = park[6 * p + i];
+                    const int scGym0 = f2i(park[6 * QMAX_OWN]);
+                    DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
+                        if ((scm >> p) & 1) {
+                            DQ_UNROLL for (int i = 0; i < 6; ++i) Mb.pv[i] -= scW[p][i];
+                            const int gy = (scGym0 >> (8 * p)) & 255;     // (0 where unloaded: adds nothing)
+                            DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
+                                if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
+                        }
+                }
+                if (last) {
+                    DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
+                        if (t < ngym) {
+                            const int gy = (gymbits >> (8 * t)) & 255;
+                            if (gy == my_sole_gym) { X.footF[0] = cf[t][0]; X.footF[1] = cf[t][1]; X.footF[2] = cf[t][2]; }
+                            else {
+                                if (over_1n(cf[t])) X.coll = 1;
+                                if (X.valid) {
+                                    float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
+                                    dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
+                                }
+                            }
+                        }
+                }
             }
-            // articulated-body step
-            float U[6];
-            DQ_UNROLL for (int r = 0; r < 6; ++r) {
-                float acc = 0.0f;
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * S[c];
-                U[r] = acc;
-            }
-            const float D = dot6(S, U) + dd;
-            const float Dinv = dw::rcp_nr(D);
-            const float u = tt - dot6(S, pA);
-            float m[6], cb[6];
-            DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = S[i] * qd;
-            dw::motion_cross(v, m, cb);
-            DQ_UNROLL for (int r = 0; r < 6; ++r) {
-                const float urd = U[r] * Dinv;
-                DQ_UNROLL for (int c = r; c < 6; ++c) IA[sym6(r, c)] -= urd * U[c];
-            }
-            const float ud = u * Dinv;
-            float pa[6];
-            DQ_UNROLL for (int r = 0; r < 6; ++r) {
-                float acc = pA[r] + U[r] * ud;
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * cb[c];
-                pa[r] = acc;
-            }
-            DQ_UNROLL for (int r = 0; r < 6; ++r) pA[r] = pa[r];
-            OQ_SLOT(b, 0, X.pos) = mk4(S[0], S[1], S[2], Dinv);
-            OQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], u);
-            OQ_SLOT(b, 2, X.pos) = mk4(U[0], U[1], U[2], qd);
-            OQ_SLOT(b, 3, X.pos) = mk4(U[3], U[4], U[5], 0.0f);
         }
+        wave_sync();          // every map has read its slot rows before the recursion overwrites any
+        OQ_TOCK(tq_map); OQ_TICK();
+        // ---- recursion: step s on half 0's map, then step s + 1 on half 1's ----
+        DQ_UNROLL for (int t2 = 0; t2 < 2; ++t2) {
+            const int sr = s + t2;
+            if (sr >= T) break;
+            if (t2 == 1) {        // half 1's map result to half 0 (the high quads keep their own)
+                DQ_UNROLL for (int i = 0; i < 6; ++i) { Mb.Ao[i] = oct_hi(Mb.Ao[i]); Mb.pv[i] = oct_hi(Mb.pv[i]); Mb.S[i] = oct_hi(Mb.S[i]); Mb.cb[i] = oct_hi(Mb.cb[i]); }
+                DQ_UNROLL for (int i = 0; i < 3; ++i) Mb.ho[i] = oct_hi(Mb.ho[i]);
+                Mb.mass = oct_hi(Mb.mass); Mb.tt = oct_hi(Mb.tt); Mb.dd = oct_hi(Mb.dd); Mb.qd = oct_hi(Mb.qd);
+            }
+            const int bits = f2i(H.in[sr][j][0]);
+            const int b = (bits & 255) - 1;
+            const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
+            const int gw = H.gany[sr];
+            if (gw >> 8) {                      // a finished chain joins the finished chain of an idle lane (same parent) before its lane starts afresh
+                const int src = (gw >> 9) & 3, dst = (gw >> 11) & 3;
+                float tI[21], tp[6];
+                quad_bcast_arr(src, IA, tI);
+                quad_bcast_arr(src, pA, tp);
+                if (j == dst) {
+                    DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] += tI[i];
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] += tp[i];
+                }
+            }
+            if (flags & 1) {
+                DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
+            }
+            // gathers (wave-uniform per step): child chains that ended on other lanes
+            if (gw & 1) {
+                const int g0 = f2i(H.in[sr][0][1]), g1 = f2i(H.in[sr][1][1]), g2 = f2i(H.in[sr][2][1]), g3 = f2i(H.in[sr][3][1]);
+                const int mine = f2i(H.in[sr][j][1]);
+                DQ_UNROLL for (int src = 0; src < 4; ++src) {
+                    const int code = src | 8;
+                    bool used = false, want = false;
+                    DQ_UNROLL for (int k = 0; k < 3; ++k) {
+                        used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
+                               (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
+                        want = want || (((mine >> (4 * k)) & 15) == code);
+                    }
+                    if (used) {
+                        DQ_UNROLL for (int i = 0; i < 21; ++i) {
+                            const float t = src == 0 ? quad_bcast<0>(IA[i]) : (src == 1 ? quad_bcast<1>(IA[i]) : (src == 2 ? quad_bcast<2>(IA[i]) : quad_bcast<3>(IA[i])));
+                            if (want) IA[i] += t;
+                        }
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) {
+                            const float t = src == 0 ? quad_bcast<0>(pA[i]) : (src == 1 ? quad_bcast<1>(pA[i]) : (src == 2 ? quad_bcast<2>(pA[i]) : quad_bcast<3>(pA[i])));
+                            if (want) pA[i] += t;
+                        }
+                    }
+                }
+            }
+            if (b >= 0) {
+                add_rigid_inertia(IA, Mb.Ao, Mb.ho, Mb.mass);
+                DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] += Mb.pv[i];
+                const float *S = Mb.S;
+                float U[6];
+                DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                    float acc = 0.0f;
+                    DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * S[c];
+                    U[r] = acc;
+                }
+                const float D = dot6(S, U) + Mb.dd;
+                const float Dinv = dw::rcp_nr(D);
+                const float u = Mb.tt - dot6(S, pA);
+                DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                    const float urd = U[r] * Dinv;
+                    DQ_UNROLL for (int c = r; c < 6; ++c) IA[sym6(r, c)] -= urd * U[c];
+                }
+                const float ud = u * Dinv;
+                float pa[6];
+                DQ_UNROLL for (int r = 0; r < 6; ++r) {
+                    float acc = pA[r] + U[r] * ud;
+                    DQ_UNROLL for (int c = 0; c < 6; ++c) acc += IA[sym6(r, c)] * Mb.cb[c];
+                    pa[r] = acc;
+                }
+                DQ_UNROLL for (int r = 0; r < 6; ++r) pA[r] = pa[r];
+                if (X.h == 0) {
+                    OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(S[0], S[1], S[2], Dinv);
+                    OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(S[3], S[4], S[5], u);
+                    OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(U[0], U[1], U[2], Mb.qd);
+                    OQ_SLOT(T - 1 - sr, 3, X.pos) = mk4(U[3], U[4], U[5], 0.0f);
+                }
+            }
+        }
+        OQ_TOCK(tq_rec);
     }
+    wave_sync();
+#if defined(DQ_STAMPS) && defined(__HIPCC__)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && SB == 1) { B.gate_acc[200 + 32] = tq_map; B.gate_acc[200 + 33] = tq_rec; }
+#endif
+    // (the sole body's non-sole contact force was found by whichever half mapped it)
+    DQ_UNROLL for (int i = 0; i < 3; ++i) X.footF[i] += oct_xor4(X.footF[i]);
 
     DQ_STAMP(B, SB + 4);
     // the warm-start impulses of my foot's corners (previous substep): requested here, used by the contact solve below -- held in
@@ -507,6 +630,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             DQ_OPAQUE(qo4[0]);
             quat_to_mat(qo4, R0);
         }
+        // (the recursion of the inward pass is valid in half 0 only: half 1 takes the gathered inertia over)
+        DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = oct_lo(I0[i]);
+        DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = oct_lo(p0[i]);
         const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
         float Ao[6], ho[3], mass;
         const int base_gym = f2i(H.base[10]), base_ngeom = f2i(H.base[11]);
@@ -580,29 +706,34 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 5);
-    // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot ----
+    // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot (lean / chain-start forms as in
+    //      pass 1) ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {
             const int bits = f2i(H.fk[s][j][3]);
             const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
-            float fa[6], fv[6];
-            bool fetched = false;
-            const int fm = H.fmask[s];
-            if (fm) {
-                for (int xl = 0; xl < 4; ++xl)
-                    if ((fm >> xl) & 1) {
-                        float ta[6], tv[6];
-                        quad_bcast_arr(xl, ar, ta); quad_bcast_arr(xl, vr, tv);
-                        if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) { fa[i] = ta[i]; fv[i] = tv[i]; } }
-                    }
-            }
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
-            if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
+            if (b >= 0) { s0 = OQ_LD(s, 0, X.pos); s1 = OQ_LD(s, 1, X.pos); s2 = OQ_LD(s, 2, X.pos); s3 = OQ_LD(s, 3, X.pos); OQ_KEEP1(s3); }
+            if ((startmask >> s) & 1) {
+                float fa[6], fv[6];
+                bool fetched = false;
+                const int fm = H.fmask[s];
+                if (fm) {
+                    for (int xl = 0; xl < 4; ++xl)
+                        if ((fm >> xl) & 1) {
+                            float ta[6], tv[6];
+                            quad_bcast_arr(xl, ar, ta); quad_bcast_arr(xl, vr, tv);
+                            if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) { fa[i] = ta[i]; fv[i] = tv[i]; } }
+                        }
+                }
+                if (b >= 0) {
+                    if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = a0[i]; ar[3 + i] = a0[3 + i]; vr[i] = ww[i]; vr[3 + i] = vo[i]; } }
+                    else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] = fa[i]; vr[i] = fv[i]; } }
+                }
+            }
             wave_sync();
-            if (b >= 0) {
-                if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = a0[i]; ar[3 + i] = a0[3 + i]; vr[i] = ww[i]; vr[3 + i] = vo[i]; } }
-                else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] = fa[i]; vr[i] = fv[i]; } }
+            {
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 const float Dinv = s0.w, u = s1.w, qd = s2.w;
                 float m[6], c[6];
@@ -611,8 +742,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] += c[i]; vr[i] += m[i]; }
                 const float qdd = (u - dot6(U, ar)) * Dinv;
                 DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * qdd;
-                OQ_SLOT(b, 2, X.pos) = mk4(U[0], U[1], U[2], qd + dt * qdd);      // free velocity
-                OQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], 0.0f);                // u is dead: the word becomes the impulse-sweep d
+                if (b >= 0) {
+                    OQ_SLOT(s, 2, X.pos) = mk4(U[0], U[1], U[2], qd + dt * qdd);      // free velocity
+                    OQ_SLOT(s, 1, X.pos) = mk4(S[3], S[4], S[5], 0.0f);                // u is dead: the word becomes the impulse-sweep d
+                }
             }
         }
     }
@@ -635,7 +768,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         // the pose of foot f lives in lane f: lanes 2, 3 fetch it from their partner (l ^ 2)
         float fR[9], fx[3];
         {
-            const F4 fq4 = ld4(L.slot[2 * f][X.el]), fx4 = ld4(L.slot[2 * f + 1][X.el]);
+            F4 fq4 = ldp(L.slot[2 * f][X.el]), fx4 = ldp(L.slot[2 * f + 1][X.el]);
+            OQ_KEEP1(fx4);
             const float fq[4] = {fq4.x, fq4.y, fq4.z, fq4.w};
             quat_to_mat(fq, fR);
             fx[0] = fx4.x; fx[1] = fx4.y; fx[2] = fx4.z;
@@ -671,10 +805,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         float twf[6];
         {
             float acc[6] = {wwf[0], wwf[1], wwf[2], vowf[0], vowf[1], vowf[2]};
-            const OPos posf = pcode(X.el, f);
+            const OPos posf = pcode(H, X.el, f);
             DQ_UNROLL for (int i = 1; i <= 6; ++i) {
-                const int b = 6 * f + i;
-                const F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf);
+                const int b = T - 7 + i;          // (the legs are right-aligned in the schedule: hip .. sole = steps T - 6 .. T - 1)
+                F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf);
+                OQ_KEEP2(s0, s1);
                 acc[0] += s0.x * s2.w; acc[1] += s0.y * s2.w; acc[2] += s0.z * s2.w;
                 acc[3] += s1.x * s2.w; acc[4] += s1.y * s2.w; acc[5] += s1.z * s2.w;
             }
@@ -689,11 +824,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         {
             float dp[3][6], dc[3][6];
             DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int i = 0; i < 6; ++i) dp[c][i] = (i == 3 * part + c) ? -1.0f : 0.0f;
-            const OPos posf = pcode(X.el, f);
+            const OPos posf = pcode(H, X.el, f);
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
                 DQ_SCHED_FENCE();
-                const int b = 6 * f + i;
-                const F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf), s3 = OQ_LD(b, 3, posf);
+                const int b = T - 7 + i;
+                F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf), s3 = OQ_LD(b, 3, posf);
+                OQ_KEEP3(s1, s2, s3);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 DQ_UNROLL for (int c = 0; c < 3; ++c) {
                     const float d = -dot6(S, dp[c]);
@@ -708,11 +844,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[sym6(r, k)] * dp[c][k];
                     Wg[c][r] = acc;
                 }
-            const OPos posg = pcode(X.el, g);
+            const OPos posg = pcode(H, X.el, g);
             DQ_UNROLL for (int i = 1; i <= 6; ++i) {
                 DQ_SCHED_FENCE();
-                const int b = 6 * g + i;
-                const F4 s0 = OQ_LD(b, 0, posg), s1 = OQ_LD(b, 1, posg), s2 = OQ_LD(b, 2, posg), s3 = OQ_LD(b, 3, posg);
+                const int b = T - 7 + i;
+                F4 s0 = OQ_LD(b, 0, posg), s1 = OQ_LD(b, 1, posg), s2 = OQ_LD(b, 2, posg), s3 = OQ_LD(b, 3, posg);
+                OQ_KEEP3(s1, s2, s3);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 DQ_UNROLL for (int c = 0; c < 3; ++c) {
                     const float ua = dot6(U, Wg[c]);
@@ -866,8 +1003,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
             float dp[6] = {-Nm[0], -Nm[1], -Nm[2], -Fs[0], -Fs[1], -Fs[2]};
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
-                const int b = 6 * f + i;
-                const F4 s0 = OQ_LD(b, 0, X.pos), s1 = OQ_LD(b, 1, X.pos), s2 = OQ_LD(b, 2, X.pos), s3 = OQ_LD(b, 3, X.pos);
+                const int b = T - 7 + i;
+                F4 s0 = OQ_LD(b, 0, X.pos), s1 = OQ_LD(b, 1, X.pos), s2 = OQ_LD(b, 2, X.pos), s3 = OQ_LD(b, 3, X.pos);
+                OQ_KEEP3(s1, s2, s3);
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 const float d = -dot6(S, dp);
                 const float k = d * s0.w;
@@ -911,33 +1049,37 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
-            float fa[6];
-            bool fetched = false;
-            const int fm = H.fmask[s];
-            if (fm) {
-                for (int xl = 0; xl < 4; ++xl)
-                    if ((fm >> xl) & 1) {
-                        float ta[6];
-                        quad_bcast_arr(xl, ar, ta);
-                        if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) fa[i] = ta[i]; }
-                    }
-            }
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
-            if (b >= 0) { s0 = OQ_LD(b, 0, X.pos); s1 = OQ_LD(b, 1, X.pos); s2 = OQ_LD(b, 2, X.pos); s3 = OQ_LD(b, 3, X.pos); }
+            if (b >= 0) { s0 = OQ_LD(s, 0, X.pos); s1 = OQ_LD(s, 1, X.pos); s2 = OQ_LD(s, 2, X.pos); s3 = OQ_LD(s, 3, X.pos); OQ_KEEP1(s3); }
+            if ((startmask >> s) & 1) {
+                float fa[6];
+                bool fetched = false;
+                const int fm = H.fmask[s];
+                if (fm) {
+                    for (int xl = 0; xl < 4; ++xl)
+                        if ((fm >> xl) & 1) {
+                            float ta[6];
+                            quad_bcast_arr(xl, ar, ta);
+                            if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) fa[i] = ta[i]; }
+                        }
+                }
+                if (b >= 0) {
+                    if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = dqb[i]; }
+                    else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fa[i]; }
+                }
+            }
             wave_sync();
-            if (b >= 0) {
-                if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = dqb[i]; }
-                else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fa[i]; }
+            {
                 const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
                 const float dq = (s1.w - dot6(U, ar)) * s0.w;
                 DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * dq;
                 float qd = s2.w + dq;
                 if (qd > rc.vmax) qd = rc.vmax;
                 if (qd < -rc.vmax) qd = -rc.vmax;
-                OQ_SLOT(b, 0, X.pos) = mk4(rc.qlo, qd, rc.qhi, 0.0f);        // joint range and new velocity for integrate_joints
+                if (b >= 0) OQ_SLOT(s, 0, X.pos) = mk4(rc.qlo, qd, rc.qhi, 0.0f);        // joint range and new velocity for integrate_joints
             }
         }
     }
@@ -976,7 +1118,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 }
 
 // Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
-DQ_HD void oct_lane_init(OLane &X, int wave_index, int num_envs, const PhysParams &P, float friction, const DwBuffers &B) {
+DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, const PhysParams &P, float friction, const DwBuffers &B) {
     X.lane = lane_id();
     X.wave = wave_index;
     X.o = X.lane & 7; X.j = X.lane & 3; X.h = (X.lane >> 2) & 1;
@@ -984,7 +1126,7 @@ DQ_HD void oct_lane_init(OLane &X, int wave_index, int num_envs, const PhysParam
     const int eg = wave_index * EPO + X.el;
     X.valid = eg < num_envs;
     X.env = X.valid ? eg : num_envs - 1;
-    X.pos = pcode(X.el, X.j);
+    X.pos = pcode(H, X.el, X.j);
     DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = B.root_states[(size_t)13 * X.env + i];
     X.mu = friction * B.friction_scale[X.env];
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
@@ -1007,12 +1149,13 @@ DQ_HD JointItem joint_item(const QHot &H, int wave_index, int num_envs, int lane
     it.ok = (i < EPO * ND) && (eg < num_envs);
     if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }
     it.env = eg < num_envs ? eg : num_envs - 1;
-    it.pos = pcode(it.el, H.owner[it.b]);
+    it.pos = icode(H, it.el, it.b);
     return it;
 }
 // semi-implicit Euler of one joint from the slot the final pass left: q = q_old + dt qd, joint range (outward rate zeroed)
 DQ_HD void joint_integrate(OSlots &L, const JointItem &it, float dt, float q_old, float *q_out, float *qd_out) {
-    const F4 o = OQ_LD(it.b, 0, it.pos);        // {qlo, qd, qhi, *}
+    F4 o = OQ_LD(0, 0, it.pos);        // {qlo, qd, qhi, *}
+    OQ_KEEP1(o);
     float qd = o.y, q = q_old + dt * qd;
     if (q < o.x) { q = o.x; if (qd < 0) qd = 0; }
     if (q > o.z) { q = o.z; if (qd > 0) qd = 0; }
@@ -1025,7 +1168,7 @@ DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel
                         const DwBuffers &B, const float *tau, const float *push, int wave_index) {
     if (wave_index * EPO >= num_envs) return;        // the second wave of the last workgroup may have no env at all
     OLane X;
-    oct_lane_init(X, wave_index, num_envs, P, friction, B);
+    oct_lane_init(X, QM.hot, wave_index, num_envs, P, friction, B);
     stage_hot(HW, QM);
     const QHot &H = HW;
     const int e = X.env, f = X.j & 1;
@@ -1036,7 +1179,7 @@ DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel
         const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
         const float damp = B.dof_damping[g], arm = B.dof_armature[g];
         qkeep[k] = q;
-        if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau[g] - damp * qd, arm + P.dt * damp);
+        if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, it.pos) = mk4(q, qd, tau[g] - damp * qd, arm + P.dt * damp);
     }
     wave_sync();
     oct_substep<TERRAIN>(L, H, QM, M, P, X, B, push ? push[2 * e] : 0.0f, push ? push[2 * e + 1] : 0.0f, true);

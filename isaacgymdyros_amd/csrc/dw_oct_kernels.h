@@ -45,7 +45,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     //      the hot tables -- in one straight run, so that the wave waits for memory once.  (Each request a lone wave waits
     //      for costs ~4 k cycles, about 1 % of the step: phase_stamps) ====
     OLane X;
-    oct_lane_init(X, wave_index, C.num_envs, C.phys, C.friction, B);
+    oct_lane_init(X, QM.hot, wave_index, C.num_envs, C.phys, C.friction, B);
     const int e = X.env, f = X.j & 1;
     float *es = B.env_state + (size_t)DW_ES_WORDS * e;
     const float r_time = es[DW_ES_TIME], r_epi = es[DW_ES_EPI_LEN], r_mag = es[DW_ES_MAGNITUDE], r_phase = es[DW_ES_PHASE];
@@ -70,11 +70,11 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         it.ok = (i < EPO * ND) && (eg < C.num_envs);
         if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }
         it.env = eg < C.num_envs ? eg : C.num_envs - 1;
-        it.pos = pcode(0, 0);
+        it.pos = pcode_cell(0, 0, 0);
         return it;
     };
     // (an item's slot position: from the owner table in LDS at every use, not held across the physics)
-#define OQ_IPOS(it) pcode((it).el, HW.owner[(it).b])
+#define OQ_IPOS(it) icode(HW, (it).el, (it).b)
     float rq[ONI], rqd[ONI], rdamp[ONI], rarm[ONI], rqpre[ONI], rms[ONI], rah[ONI], rac[ONI], rkp[ONI], rkv[ONI], rcol[ONI][DW_ALOG_SLOTS - 1];
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = item(k);
@@ -235,7 +235,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             // upper body: PD to the mocap target; the second substep forms its own torque from the new state
             const float tau = d < 12 ? t1 : rkp[k] * (target - q) + rkv[k] * (-qd);
             if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_TAU2 + d] = d < 12 ? t2 : target;
-            if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
+            if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
         }
     }
     wave_sync();
@@ -248,7 +248,9 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         //      slot reads and the noise of all items first, then the arithmetic, then the stores ----
         F4 fin[ONI];
         float nzw[ONI];
-        DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); fin[k] = OQ_LD(it.b, 0, OQ_IPOS(it)); }      // {qlo, qd, qhi, *}
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); fin[k] = OQ_LD(0, 0, OQ_IPOS(it)); }      // {qlo, qd, qhi, *}
+        static_assert(ONI == 5, "the grouped touch below names five loads");
+        OQ_KEEP3(fin[0], fin[1], fin[2]); OQ_KEEP2(fin[3], fin[4]);
         // damping, armature and the PD gains of the upper body for the second substep's inputs: requested again here (their
         // latency passes behind the noise generation) rather than held in 20 registers through the first substep
         float rdamp2[ONI], rarm2[ONI], rkp2[ONI], rkv2[ONI], tau2[ONI], nzw1[ONI];
@@ -291,7 +293,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             qvk[k] = qv;
             if (sub == 0 && !C.freeze_physics) {
                 const float tau = d < 12 ? tau2[k] : rkp2[k] * (tau2[k] - q) + rkv2[k] * (-qd);
-                if (X.lane + 64 * k < EPO * ND) OQ_SLOT(it.b, 0, OQ_IPOS(it)) = mk4(q, qd, tau - rdamp2[k] * qd, rarm2[k] + dt * rdamp2[k]);
+                if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, OQ_IPOS(it)) = mk4(q, qd, tau - rdamp2[k] * qd, rarm2[k] + dt * rdamp2[k]);
             }
         }
         wave_sync();

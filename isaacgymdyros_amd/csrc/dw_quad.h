@@ -1242,7 +1242,7 @@ DQ_HD JointItem joint_item(const QLds &L, int wave_index, int num_envs, int lane
     it.ok = (i < EPW * ND) && (eg < num_envs);
     if (!(i < EPW * ND)) { it.el = 0; it.d = 0; it.b = 1; }
     it.env = eg < num_envs ? eg : num_envs - 1;
-    it.pos = (it.el + 4 * L.hot.owner[it.b]) & 15;
+    it.pos = (it.el + 4 * (L.hot.owner[it.b] >> 6)) & 15;
     return it;
 }
 // semi-implicit Euler of one joint from the slot the final pass left: q = q_old + dt qd, joint range (outward rate zeroed)

@@ -88,7 +88,7 @@ DQ_HD void quad_step(QLds &L, const QuadModel &QM, const DevModel &M, const Task
     stage_hot(L, QM);
     quad_lane_second_inertial(X, L, QM, B);
     int ipos[QNI];
-    DQ_UNROLL for (int k = 0; k < QNI; ++k) { const JointItem it = item(k); ipos[k] = (it.el + 4 * L.hot.owner[it.b]) & 15; }
+    DQ_UNROLL for (int k = 0; k < QNI; ++k) { const JointItem it = item(k); ipos[k] = (it.el + 4 * (L.hot.owner[it.b] >> 6)) & 15; }
     float push_x = 0.0f, push_y = 0.0f;
     const float dt = C.phys.dt;
     StepKeep KP;

@@ -57,6 +57,7 @@ int build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel
     if (rc == DW_OK && octet)
         for (int s = 0; s < QS_MAX; ++s) for (int l = 0; l < 4; ++l)
             if (q->in[s][l].body >= 0 && (q->in[s][l].flags & 2)) { rc = DW_EINVAL; *err = "octet kernels: the schedule parks a chain"; }
+    if (rc == DW_OK && octet && q->nsteps != QS_MAX) { rc = DW_EINVAL; *err = "octet kernels: built for a schedule of exactly QS_MAX steps"; }
     if (rc) { free(q); return rc; }
     *out = q;
     return DW_OK;

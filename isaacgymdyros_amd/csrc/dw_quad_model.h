@@ -62,11 +62,13 @@ struct alignas(16) QInRec {      // inward constants of one (step, lane): 11 x 1
 struct alignas(16) QHot {
     float fk[QS_MAX][4][12];
     float in[QS_MAX][4][16];
-    float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound
+    float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound, [13] cell bases, [14] first / last step per lane, [15] steps in which a chain starts
     int   fmask[QS_MAX];         // outward step s: bit X set = some lane fetches lane X's running state
     int   gany[QS_MAX];          // inward step s: bit 0 some lane gathers; bits 8.. accumulation (valid | source lane << 1 | destination lane << 3)
     int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] detection passes | pairs << 8, [4..7] pairs of lane l
-    unsigned char owner[36];     // lane that owns each body (slot position = (env + 4 * owner) & 15)
+    unsigned char owner[36];     // per body: lane that owns it (bits 6..7) | its slot CELL in the octet kernels (bits 0..5):
+                                 // cell = cellbase[lane] + outward step, so that a limb's bodies lie in schedule order and a chain
+                                 // pass addresses them as lane base + compile-time offset (dw_oct.h); base[13] = the four cell bases
     alignas(16) float in1[2][12];   // second (welded) inertial record of the sole bodies, per leg lane: com[3], mass, I[6], [10] its Gym body (int bits), [11] its inward step (int bits)
     // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner lane << 16 | index among the
     // owner's proxies << 18.  Detection: proxy p is evaluated by lane p & 3 (its register set p >> 2), and the pairs are
@@ -441,7 +443,38 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         for (int i = 0; i < 6; ++i) H.base[4 + i] = Q->base_I[i];
         H.base[10] = fi(Q->base_gym); H.base[11] = fi(Q->base_ngeom); H.base[12] = Q->base_bound;
         H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nprox; H.misc[3] = ncombo | (Q->npair << 8);
-        for (int b = 0; b < NB; ++b) H.owner[b] = (unsigned char)(Q->owner[b] < 0 ? 0 : Q->owner[b]);
+        {
+            // slot cells: per lane the bodies in schedule order, one lane after the other (cell 0 = the base's four rows: scratch)
+            int first[4] = {QS_MAX, QS_MAX, QS_MAX, QS_MAX}, last[4] = {-1, -1, -1, -1}, count[4] = {0, 0, 0, 0}, cellbase[4] = {0, 0, 0, 0};
+            for (int b = 1; b < NB; ++b) {
+                const int l = Q->owner[b], st = Q->step_of[b];
+                if (st < first[l]) first[l] = st;
+                if (st > last[l]) last[l] = st;
+                count[l] += 1;
+            }
+            int next = 1;
+            bool contiguous = true;
+            for (int l = 0; l < 4; ++l) {
+                if (count[l] == 0) continue;
+                if (last[l] - first[l] + 1 != count[l]) contiguous = false;
+                cellbase[l] = next - first[l];
+                next += count[l];
+            }
+            if (accumulate && !contiguous) { *err = "octet kernels: a lane's bodies are not contiguous in the schedule"; return DW_EINVAL; }
+            H.owner[0] = 0;
+            for (int b = 1; b < NB; ++b) {
+                const int l = Q->owner[b];
+                const int cell = contiguous ? cellbase[l] + Q->step_of[b] : b;
+                H.owner[b] = (unsigned char)((l << 6) | (cell & 63));
+            }
+            H.base[13] = fi((cellbase[0] & 255) | ((cellbase[1] & 255) << 8) | ((cellbase[2] & 255) << 16) | ((cellbase[3] & 255) << 24));
+            {
+                int startmask = 0;      // outward steps in which some lane starts a chain (parent = the base or another lane's body)
+                for (int s2 = 0; s2 < Q->nsteps; ++s2) for (int l = 0; l < 4; ++l) if (Q->fk[s2][l].body >= 0 && Q->fk[s2][l].psrc != 0) startmask |= 1 << s2;
+                H.base[15] = fi(startmask);
+            }
+            H.base[14] = fi(first[0] | (first[1] << 4) | (first[2] << 8) | (first[3] << 12) | (last[0] << 16) | (last[1] << 20) | (last[2] << 24) | (last[3] << 28));
+        }
         for (int l = 0; l < 2; ++l) {
             int s2k = 0;
             for (int s2 = 0; s2 < Q->nsteps; ++s2) if (Q->in[s2][l].body >= 0 && Q->in[s2][l].nin > 1) s2k = s2;

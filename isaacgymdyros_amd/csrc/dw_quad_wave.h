@@ -11,7 +11,7 @@
 //   quad_bcast<J>(x)       value of x in lane J of the caller's quad            (v_mov_dpp quad_perm:[J,J,J,J])
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   oct_xor4(x)            value of x in lane (l ^ 4)  (octet kernels)           (row_shl:4 / row_shr:4, complementary bank masks)
-//   oct_lo(x)              value of x in lane (l & ~4) (octet kernels)           (row_shr:4 into the high quads)
+//   oct_lo(x) / oct_hi(x)  value of x in lane (l & ~4) / (l | 4) (octet kernels) (row_shr:4 into the high quads / row_shl:4 into the low quads)
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
 //   wave_ballot(p)         64-bit mask of p over the lanes, the same in every lane (v_cmp into an SGPR pair)
 //   wave_sync_global()     as wave_sync, for global memory too (workgroup-scope release / acquire).
@@ -55,6 +55,11 @@ DQ_HD float oct_xor4(float x) {
 DQ_HD float oct_lo(float x) {
     const int xi = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x114, 0xF, 0xA, false));
+}
+// value of x in the half-1 lane of my limb (lane l | 4): one move, the low quads take the value 4 lanes up
+DQ_HD float oct_hi(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x104, 0xF, 0x5, false));
 }
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
@@ -221,6 +226,7 @@ DQ_HD float quad_xor1(float x) { return emu_xchg(x, g_emu->cur ^ 1); }
 DQ_HD float quad_xor2(float x) { return emu_xchg(x, g_emu->cur ^ 2); }
 DQ_HD float oct_xor4(float x) { return emu_xchg(x, g_emu->cur ^ 4); }
 DQ_HD float oct_lo(float x) { return emu_xchg(x, g_emu->cur & ~4); }
+DQ_HD float oct_hi(float x) { return emu_xchg(x, g_emu->cur | 4); }
 DQ_HD bool wave_any(bool p) {
     WaveEmu *e = g_emu;
     const int l = e->cur, par = (int)(e->nsync[l] & 1);

@@ -71,6 +71,7 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     int rc = dw::build_devmodel(model, task, &h->model, &err);
     if (rc == DW_OK) rc = dwq::build_quadmodel(&h->model, model, &h->qmodel, &err, true);
     if (rc == DW_OK) for (int s = 0; s < dwq::QS_MAX; ++s) for (int l = 0; l < 4; ++l) if (h->qmodel.in[s][l].body >= 0 && (h->qmodel.in[s][l].flags & 2)) { rc = DW_EINVAL; err = "octet kernels: the schedule parks a chain"; }
+    if (rc == DW_OK && h->qmodel.nsteps != dwq::QS_MAX) { rc = DW_EINVAL; err = "octet kernels: built for a schedule of exactly QS_MAX steps"; }
     if (rc) { free(h); return fail(rc, err); }
     h->dp.C = dw::make_task_params(cfg);
     h->sc_park = (float *)calloc((size_t)(cfg->num_envs + 15) / 16 * 2 * 64 * dwo::SC_PARK_WORDS, sizeof(float));

@@ -8,7 +8,9 @@ _lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
 from isaacgymdyros_amd.config import default_cfg
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-env = DyrosDynamicWalk(default_cfg(N, "cuda:0"), "cuda:0", 0, True)
+cfg = default_cfg(N, "cuda:0")
+cfg["sim"]["mi355"]["pipeline"] = int(os.environ.get("DW_PIPE", "0"))          # 2 quad, 3 octet
+env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 g = torch.Generator(device="cuda").manual_seed(42)
 acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
 names = {0: "substep entry", 1: "base kin -> FK", 2: "FK", 3: "self-collision", 4: "inward", 5: "base solve", 6: "outward", 7: "corners, free twist",
@@ -33,6 +35,8 @@ for i in range(30 + K):
                 print("   %-22s %7d" % ("encoder epilogue", st[base + 14] - st[base + 13]))
             print("self-collision of substep 1: proxies %d, detection %d, resolution %d (any hit in the wave: %d)" % (st[51] - st[1 + 16 + 2], st[52] - st[51], st[1 + 16 + 3] - st[52], st[53]))
             print("kernel epilogue %d" % (st[40] - st[1 + 16 + 14]))
+            if st[32] > 0:
+                print("inward pass of substep 0 (octet kernels): map %d, recursion + hand-over %d" % (st[32], st[33]))
             if st[41] > st[40]:
                 print("post_physics_step %d" % (st[41] - st[40]))
                 pn = {42: "stage", 43: "Q1 + guard", 44: "Q2 reward", 45: "Q3", 46: "reset", 47: "Q4 obs", 48: "Q5 obs_buf", 49: "Q6", 50: "write back"}

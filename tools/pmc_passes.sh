@@ -10,6 +10,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+  if [ -n "${PMC_MAX_PASS:-}" ] && [ $i -ge $PMC_MAX_PASS ]; then break; fi
   i=$((i+1))
   timeout -k 10 280 rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/pass$i -- python3 $ROOT/tools/prof_step.py $N $STEPS > $ROOT/$OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $ROOT/$OUT/fail.log
 done

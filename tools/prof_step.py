@@ -7,7 +7,9 @@ from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-env = DyrosDynamicWalk(default_cfg(N, "cuda:0"), "cuda:0", 0, True)
+cfg = default_cfg(N, "cuda:0")
+cfg["sim"]["mi355"]["pipeline"] = int(os.environ.get("DW_PIPE", "0"))
+env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 g = torch.Generator(device="cuda").manual_seed(42)
 acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
 for i in range(steps):
