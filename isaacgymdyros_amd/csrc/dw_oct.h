@@ -597,14 +597,6 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_UNROLL for (int i = 0; i < 3; ++i) X.footF[i] += oct_xor4(X.footF[i]);
 
     DQ_STAMP(B, SB + 4);
-    // the warm-start impulses of my foot's corners (previous substep): requested here, used by the contact solve below -- held in
-    // registers from one contact solve to the next they would sit through the inward pass, where the register budget is tightest
-    float warm[12];
-    {
-        wave_sync_global();          // (the previous substep of this launch stored them)
-        const float *wsrc = B.env_state ? B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * (j & 1) : nullptr;
-        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = wsrc ? wsrc[i] : 0.0f;
-    }
     // ---- base: gather the chains below the root, own inertia, external forces, inverse ----
     float Minv[21], a0[6];            // inverse of the base's articulated inertia, symmetric storage (sym6)
     {
@@ -749,7 +741,15 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
         }
     }
-    wave_sync();
+    // the warm-start impulses of my foot's corners (previous substep) from the task record: requested here, at a point where the
+    // wave synchronises anyway, used by the contact solve below
+    float warm[12];
+    DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = 0.0f;
+    wave_sync_global();          // (also: the previous substep of this launch stored the impulses)
+    if (B.env_state) {           // (dw_simulate may run without a task record: the solve then starts from zero)
+        const float *wsrc = B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * (j & 1);
+        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = wsrc[i];
+    }
     DQ_STAMP(B, SB + 6);
     // ---- free base velocity; sole-corner gaps of my foot (foot f = j & 1; lanes f and f + 2 work on it together) ----
     float wwf[3], vowf[3];
@@ -820,6 +820,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         //      to my 3 unit wrenches (components 3 part .. 3 part + 2) on foot f.  Up leg f: d = -S'p, p += U d / D (both
         //      halves); base: dv = -Minv p; down leg g: qdd = (d - U'dv) / D, dv += S qdd ----
         const int g = X.h ^ f;
+        const int mrow_id = X.o < 6 ? X.o : X.o - 6;
+        float mrow[6];
         float Wg[3][6];
         {
             float dp[3][6], dc[3][6];
@@ -844,6 +846,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[sym6(r, k)] * dp[c][k];
                     Wg[c][r] = acc;
                 }
+            DQ_UNROLL for (int c = 0; c < 6; ++c) {
+                float v = Minv[sym6(0, c)];
+                DQ_UNROLL for (int r = 1; r < 6; ++r) v = (mrow_id == r) ? Minv[sym6(r, c)] : v;
+                mrow[c] = v;
+            }
             const OPos posg = pcode(H, X.el, g);
             DQ_UNROLL for (int i = 1; i <= 6; ++i) {
                 DQ_SCHED_FENCE();
@@ -1020,11 +1027,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 const float a = quad_bcast<0>(dpb[i]), b2 = quad_bcast<1>(dpb[i]);
                 tot[i] = a + b2;
             }
-            DQ_UNROLL for (int r = 0; r < 6; ++r) {
-                float acc = 0.0f;
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc -= Minv[sym6(r, c)] * tot[c];
-                dqb[r] = acc;
-            }
+            float y = 0.0f;
+            DQ_UNROLL for (int c = 0; c < 6; ++c) y -= mrow[c] * tot[c];
+            dqb[0] = oct_lo(quad_bcast<0>(y)); dqb[1] = oct_lo(quad_bcast<1>(y)); dqb[2] = oct_lo(quad_bcast<2>(y)); dqb[3] = oct_lo(quad_bcast<3>(y));
+            dqb[4] = oct_hi(quad_bcast<0>(y)); dqb[5] = oct_hi(quad_bcast<1>(y));
         }
         if (last && part == 0) {
             DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i] + Fs[i] * inv_dt;

@@ -261,6 +261,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             if (sub == 0) { rdamp2[k] = B.dof_damping[g]; rarm2[k] = B.dof_armature[g]; rkp2[k] = M.kp[it.d]; rkv2[k] = M.kv[it.d]; tau2[k] = pk[PK_TAU2 + it.d]; }
             else nzw1[k] = noise ? 0.0f : pk[PK_NZ1 + it.d];
         }
+        if (sub == 0) DQ_STAMP(B, 34);
         if (noise) {
             DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); nzw[k] = noise[(size_t)DW_NOISE_WORDS * it.env + DW_NZ_ENC + ND * sub + it.d]; }
         } else if (sub == 0) {          // one generator call per joint gives the draws of both substeps
@@ -275,6 +276,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         } else {
             DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = nzw1[k];
         }
+        if (sub == 0) DQ_STAMP(B, 35);
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             const JointItem it = item(k);
             const size_t g = (size_t)ND * it.env + it.d;

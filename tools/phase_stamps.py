@@ -35,6 +35,8 @@ for i in range(30 + K):
                 print("   %-22s %7d" % ("encoder epilogue", st[base + 14] - st[base + 13]))
             print("self-collision of substep 1: proxies %d, detection %d, resolution %d (any hit in the wave: %d)" % (st[51] - st[1 + 16 + 2], st[52] - st[51], st[1 + 16 + 3] - st[52], st[53]))
             print("kernel epilogue %d" % (st[40] - st[1 + 16 + 14]))
+            if st[34] > 0:
+                print("encoder epilogue of substep 0: loads issued %d, noise %d, arithmetic + stores %d" % (st[34] - st[1 + 13], st[35] - st[34], st[1 + 14] - st[35]))
             if st[32] > 0:
                 print("inward pass of substep 0 (octet kernels): map %d, recursion + hand-over %d" % (st[32], st[33]))
             if st[41] > st[40]:
