@@ -47,11 +47,12 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     OLane X;
     oct_lane_init(X, QM.hot, wave_index, C.num_envs, C.phys, C.friction, B);
     const int e = X.env, f = X.j & 1;
-    float *es = B.env_state + (size_t)DW_ES_WORDS * e;
-    const float r_time = es[DW_ES_TIME], r_epi = es[DW_ES_EPI_LEN], r_mag = es[DW_ES_MAGNITUDE], r_phase = es[DW_ES_PHASE];
-    const float r_init = es[DW_ES_INIT_MOCAP], r_pstart = es[DW_ES_PERT_START], r_pon = es[DW_ES_PERT_ON], r_pcount = es[DW_ES_PERT_COUNT];
-    const float r_imp = es[DW_ES_IMPULSE], r_dur = es[DW_ES_PERT_DURATION], r_ptim = es[DW_ES_PERT_TIMING];
-    const float r_dl = es[DW_ES_DELAY_IDX], r_sl = es[DW_ES_SIMUL_LEN];          // (integer fields travel as bit patterns)
+    // (record fields of my env: B.env_state[ES(field)]; no base pointer is held across the phases)
+#define OQ_ES(f) B.env_state[(size_t)DW_ES_WORDS * e + (f)]
+    const float r_time = OQ_ES(DW_ES_TIME), r_epi = OQ_ES(DW_ES_EPI_LEN), r_mag = OQ_ES(DW_ES_MAGNITUDE), r_phase = OQ_ES(DW_ES_PHASE);
+    const float r_init = OQ_ES(DW_ES_INIT_MOCAP), r_pstart = OQ_ES(DW_ES_PERT_START), r_pon = OQ_ES(DW_ES_PERT_ON), r_pcount = OQ_ES(DW_ES_PERT_COUNT);
+    const float r_imp = OQ_ES(DW_ES_IMPULSE), r_dur = OQ_ES(DW_ES_PERT_DURATION), r_ptim = OQ_ES(DW_ES_PERT_TIMING);
+    const float r_dl = OQ_ES(DW_ES_DELAY_IDX), r_sl = OQ_ES(DW_ES_SIMUL_LEN);          // (integer fields travel as bit patterns)
     constexpr int NAI = (EPO * DW_NUM_ACT + 63) / 64;
     float r_act[NAI], r_head[NAI];
     DQ_UNROLL for (int k = 0; k < NAI; ++k) {
@@ -75,7 +76,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     };
     // (an item's slot position: from the owner table in LDS at every use, not held across the physics)
 #define OQ_IPOS(it) icode(HW, (it).el, (it).b)
-    float rq[ONI], rqd[ONI], rdamp[ONI], rarm[ONI], rqpre[ONI], rms[ONI], rah[ONI], rac[ONI], rkp[ONI], rkv[ONI], rcol[ONI][DW_ALOG_SLOTS - 1];
+    float rq[ONI], rqd[ONI], rdamp[ONI], rarm[ONI], rms[ONI], rah[ONI], rac[ONI], rkp[ONI], rkv[ONI], rcol[ONI][DW_ALOG_SLOTS - 1];
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = item(k);
         const size_t g = (size_t)ND * it.env + it.d;
@@ -83,7 +84,6 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         const int d = it.d, dc = d < 12 ? d : 11;       // (leg-only fields: index clamped rather than a branch)
         rq[k] = B.dof_state[g * 2]; rqd[k] = B.dof_state[g * 2 + 1];
         rdamp[k] = B.dof_damping[g]; rarm[k] = B.dof_armature[g];
-        rqpre[k] = ei[DW_ES_QPOS_PRE + d];
         rms[k] = ei[DW_ES_MOTOR_SCALE + dc]; rah[k] = M.action_high[dc];
         rac[k] = actions[DW_NUM_ACT * it.env + dc];
         rkp[k] = M.kp[d]; rkv[k] = M.kv[d];
@@ -95,11 +95,12 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     const float dt = C.phys.dt;
     // What the pre-physics phase produces for the task record goes to the record in global memory right away (the post phase
     // stages the records after the physics and finds it there): carried in registers across two substeps it is what made the
-    // first form of this kernel spill.  Across the physics a lane keeps, per item: the joint angle and the previous encoder
-    // reading.  The second substep's torque input and encoder draw wait in the env's row of obs_buf, which is scratch until the
-    // post phase writes the new observation into it (words PK_TAU2.., PK_NZ1..).
+    // first form of this kernel spill.  Across the physics a lane keeps NOTHING per item: the joint angle is read back from
+    // dof_state and the previous encoder reading from the record (both written after the first substep), the second substep's
+    // torque input and encoder draw wait in the env's row of obs_buf, which is scratch until the post phase writes the new
+    // observation into it (words PK_TAU2.., PK_NZ1..).  Every epilogue requests all of it in one go.
     StepKeep KP;
-    float qkeep[ONI], qdkeep[ONI], qnprev[ONI];
+    float qkeep[ONI], qdkeep[ONI], qnprev[ONI];          // (filled by the last encoder epilogue: what the post phase takes over)
     float (&qvk)[ONI] = KP.qv;
     const bool wr_env = X.valid && X.h == 0;          // per-env scalars: half 0 writes
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
@@ -123,9 +124,9 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             OQ_ENVW(X.el, EW_DL) = r_dl;
             OQ_ENVW(X.el, EW_SL) = r_sl;
             if (wr_env) {
-                es[DW_ES_MOCAP_IDX] = __builtin_bit_cast(float, midx);
+                OQ_ES(DW_ES_MOCAP_IDX) = __builtin_bit_cast(float, midx);
                 const int sl2 = simul_len0 + 2 > DW_ALOG_SLOTS ? DW_ALOG_SLOTS : simul_len0 + 2;
-                es[DW_ES_SIMUL_LEN] = __builtin_bit_cast(float, sl2);
+                OQ_ES(DW_ES_SIMUL_LEN) = __builtin_bit_cast(float, sl2);
             }
         }
         wave_sync();
@@ -176,10 +177,10 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
                 }
             }
             if (wr_env) {
-                es[DW_ES_PERT_START] = __builtin_bit_cast(float, pert_start); es[DW_ES_PERT_ON] = __builtin_bit_cast(float, pert_on);
-                es[DW_ES_PERT_COUNT] = __builtin_bit_cast(float, pert_count); es[DW_ES_IMPULSE] = __builtin_bit_cast(float, impulse);
-                es[DW_ES_PERT_DURATION] = __builtin_bit_cast(float, duration);
-                es[DW_ES_MAGNITUDE] = magnitude; es[DW_ES_PHASE] = phase;
+                OQ_ES(DW_ES_PERT_START) = __builtin_bit_cast(float, pert_start); OQ_ES(DW_ES_PERT_ON) = __builtin_bit_cast(float, pert_on);
+                OQ_ES(DW_ES_PERT_COUNT) = __builtin_bit_cast(float, pert_count); OQ_ES(DW_ES_IMPULSE) = __builtin_bit_cast(float, impulse);
+                OQ_ES(DW_ES_PERT_DURATION) = __builtin_bit_cast(float, duration);
+                OQ_ES(DW_ES_MAGNITUDE) = magnitude; OQ_ES(DW_ES_PHASE) = phase;
             }
         }
         push_x = quad_bcast<1>(px);
@@ -197,8 +198,8 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             }
         }
         if (X.j == 0 && wr_env) {
-            es[DW_ES_TARGET_FORCE] = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[2], rtf[3]);
-            es[DW_ES_TARGET_FORCE + 1] = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[4], rtf[5]);
+            OQ_ES(DW_ES_TARGET_FORCE) = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[2], rtf[3]);
+            OQ_ES(DW_ES_TARGET_FORCE + 1) = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[4], rtf[5]);
         }
 
         // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps.  Kept per item in
@@ -210,8 +211,6 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             it.pos = OQ_IPOS(it);
             const int d = it.d;
             const float q = rq[k], qd = rqd[k], damp = rdamp[k], arm = rarm[k];
-            qkeep[k] = q; qdkeep[k] = qd;
-            qnprev[k] = rqpre[k];
             // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
             const float target = dw::cubic_t(OQ_ENVW(it.el, EW_LTP), rt0[k], rt1[k], rm0[k], rm1[k]);
             const float atq = d < 12 ? fminf(fmaxf(rac[k], -1.0f), 1.0f) * rms[k] * rah[k] : 0.0f;
@@ -258,6 +257,8 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             const JointItem it = item(k);
             const size_t g = (size_t)ND * it.env + it.d;
             const float *pk = B.obs_buf + (size_t)DW_NUM_OBS * it.env;
+            qkeep[k] = B.dof_state[g * 2]; qdkeep[k] = B.dof_state[g * 2 + 1];
+            qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * it.env + DW_ES_QPOS_PRE + it.d];
             if (sub == 0) { rdamp2[k] = B.dof_damping[g]; rarm2[k] = B.dof_armature[g]; rkp2[k] = M.kp[it.d]; rkv2[k] = M.kv[it.d]; tau2[k] = pk[PK_TAU2 + it.d]; }
             else nzw1[k] = noise ? 0.0f : pk[PK_NZ1 + it.d];
         }
@@ -287,12 +288,13 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
                 if (q < fin[k].x) { q = fin[k].x; if (qd < 0) qd = 0; }
                 if (q > fin[k].z) { q = fin[k].z; if (qd > 0) qd = 0; }
                 qkeep[k] = q; qdkeep[k] = qd;
-                if (it.ok && sub == 1) { B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd; }
+                if (it.ok) { B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd; }
             }
             const float qn = q + fminf(fmaxf(nzw[k], -0.00016f), 0.00016f);
             const float qv = C.gpu_div ? (qn - qnprev[k]) * C.inv_dt_f : (qn - qnprev[k]) / dt;
             qnprev[k] = qn;
             qvk[k] = qv;
+            if (sub == 0 && it.ok) B.env_state[(size_t)DW_ES_WORDS * it.env + DW_ES_QPOS_PRE + d] = qn;
             if (sub == 0 && !C.freeze_physics) {
                 const float tau = d < 12 ? tau2[k] : rkp2[k] * (tau2[k] - q) + rkv2[k] * (-qd);
                 if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, OQ_IPOS(it)) = mk4(q, qd, tau - rdamp2[k] * qd, rarm2[k] + dt * rdamp2[k]);
@@ -301,7 +303,11 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         wave_sync();
         DQ_STAMP(B, 1 + 16 * sub + 14);
     }
-    if (X.valid && !C.freeze_physics && X.o == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
+    if (X.valid && !C.freeze_physics && X.o == 0) {
+        int e2 = e;
+        DQ_OPAQUE(e2);            // (the row's address again from the index: held since the loads at the top it is a register pair through both substeps)
+        DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e2 + i] = X.root[i];
+    }
     DQ_UNROLL for (int k = 0; k < ONI; ++k) KP.qn[k] = qnprev[k];
     DQ_STAMP(B, 40);
     {

@@ -84,7 +84,10 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     //  registers across the two substeps)
     int lane = X.lane;
     DQ_OPAQUE(lane);
-    const int j = lane & 7, el = lane >> 3, e = X.env;      // j: octet lane (0..7); lanes 4..7 idle in the per-env scalar groups
+    const int j = lane & 7, el = lane >> 3;                 // j: octet lane (0..7); lanes 4..7 idle in the per-env scalar groups
+    const int eg_ = wave_index * EPO + el;
+    const bool xvalid = eg_ < C.num_envs;
+    const int e = xvalid ? eg_ : C.num_envs - 1;
     const int N = C.num_envs;
     dw::TaskBuffers TB;
     TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
@@ -186,13 +189,13 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         time = time + C.dt_policy_f;
         time = time + C.clock_gain_f * q1_clock;
         PQ_ES(el, DW_ES_TIME) = time;
-        if (X.valid) {
+        if (xvalid) {
             B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
             B.progress_buf[e] = p + 1;
         }
         PQ_PSI(el, PS_PROGRESS) = (int)(p + 1);
         rb = rb + 1;
-        if (X.valid) B.randomize_buf[e] = rb;
+        if (xvalid) B.randomize_buf[e] = rb;
         PQ_PSI(el, PS_RANDOMIZE) = rb;
         bool bad = false;
         DQ_UNROLL for (int i = 0; i < 13; ++i) bad = bad || !dw::finitef(PQ_ROOT(el, i));
@@ -309,7 +312,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         const bool collision = PQ_PSI(el, PS_COLL) != 0;
         const float aerr = PQ_PS(el, PS_RTERM + 14);
         // stacked_rewards: 15 words per env, the quad writes them (lane j takes 4 j .. 4 j + 3)
-        if (X.valid) {
+        if (xvalid) {
             DQ_UNROLL for (int i = 0; i < 4; ++i) {
                 const int l = 4 * j + i;
                 if (l < 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
@@ -325,7 +328,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             if ((float)PQ_PSI(el, PS_PROGRESS) >= C.max_episode_length - 1.0f) reset = 1;
             if (collision) reset = 1;
             if (PQ_PSI(el, PS_BAD)) reset = 1;
-            if (X.valid) { B.rew_buf[e] = total; B.reset_buf[e] = reset; }
+            if (xvalid) { B.rew_buf[e] = total; B.reset_buf[e] = reset; }
             PQ_PSI(el, PS_RESET) = reset;
             float ret = PQ_ES(el, DW_ES_EPI_RETURN) + total;
             if (reset) {
@@ -359,8 +362,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             long long ty = B.terrain_types[e];
             ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
             const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + ty) * 3;
-            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (X.valid) B.env_origins[3 * e + i] = o; }
-            if (X.valid) B.terrain_levels[e] = lvl;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (xvalid) B.env_origins[3 * e + i] = o; }
+            if (xvalid) B.terrain_levels[e] = lvl;
         }
         wave_sync();
         // one pass per env that ended (a wave-uniform loop over the ballot: resets are rare, and a pass over all 16 x 33
@@ -408,18 +411,18 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         if (j == 0 && mine) {
             const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
             if (do_dr) {
-                if (C.dr_friction && X.valid) {
+                if (C.dr_friction && xvalid) {
                     const float uf = dw::noise_word(K.nz, DW_NZ_DR_FRIC);
                     B.friction_scale[e] = C.dr_fric[0] + uf * (C.dr_fric[1] - C.dr_fric[0]);
                 }
-                if (X.valid) B.randomize_buf[e] = 0;
+                if (xvalid) B.randomize_buf[e] = 0;
             }
             const float vel_mag = dw::noise_word(K.nz, DW_NZ_TARGET_VEL) * 0.8f;
             PQ_ES(el, DW_ES_TARGET_VEL) = vel_mag * 1.0f;
             PQ_ES(el, DW_ES_TARGET_VEL + 1) = vel_mag * 0.0f;
             PQ_ESI(el, DW_ES_INIT_MOCAP) = dw::noise_word(K.nz, DW_NZ_INIT_MOCAP) > 0.5f ? 0 : 1800;
             PQ_ES(el, DW_ES_TIME) = 0.0f;
-            if (X.valid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
+            if (xvalid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
             int k = (int)(dw::noise_word(K.nz, DW_NZ_DELAY) * 4.0f);
             if (k > 3) k = 3;
             PQ_ESI(el, DW_ES_DELAY_IDX) = 2 + k;
@@ -570,7 +573,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     wave_sync();
     if (j == 0) {
         PQ_ESI(el, DW_ES_HIST_HEAD) = (PQ_ESI(el, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
-        if (C.perturb && !C.force_perturb_start && X.valid) {
+        if (C.perturb && !C.force_perturb_start && xvalid) {
             const float eln = PQ_ES(el, DW_ES_EPI_LEN_LOG), cm = PQ_ES(el, DW_ES_CRM);
             const int bk = e % dw::GATE_BUCKETS;
             long long de, dc = 0;
@@ -595,7 +598,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
         const bool changed = PQ_PSI(el, PS_RESET) != 0 || PQ_PSI(el, PS_BAD) != 0;
         if (wave_any(changed)) {
-            if (j == 0 && changed && X.valid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
+            if (j == 0 && changed && xvalid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
             DQ_UNROLL for (int k = 0; k < ONI; ++k) {
                 const int i = lane + 64 * k;
                 if (i < EPO * ND) {
