@@ -243,62 +243,71 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         X.stamp_base = 1 + 16 * sub;
         if (!C.freeze_physics) oct_substep<TERRAIN>(L, H, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
         wave_sync();
-        // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep: the
-        //      slot reads and the noise of all items first, then the arithmetic, then the stores ----
+        // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep.  Four
+        //      straight-line blocks -- every request, the noise, the arithmetic, every store -- with no branch between two requests:
+        //      a store under `if (ok)` between two items' loads had made the compiler wait for memory once per item. ----
+        JointItem its[ONI];
+        OPos ips[ONI];
+        size_t gs[ONI];
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) { its[k] = item(k); ips[k] = OQ_IPOS(its[k]); gs[k] = (size_t)ND * its[k].env + its[k].d; }
         F4 fin[ONI];
-        float nzw[ONI];
-        DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); fin[k] = OQ_LD(0, 0, OQ_IPOS(it)); }      // {qlo, qd, qhi, *}
+        float nzw[ONI], rdamp2[ONI], rarm2[ONI], rkp2[ONI], rkv2[ONI], pkv[ONI];
+        const int pk_off = sub == 0 ? PK_TAU2 : PK_NZ1;          // obs_buf scratch: the second substep's torque input / its encoder draw
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) fin[k] = OQ_LD(0, 0, ips[k]);      // {qlo, qd, qhi, *}
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+            qkeep[k] = B.dof_state[gs[k] * 2]; qdkeep[k] = B.dof_state[gs[k] * 2 + 1];
+            qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d];
+            pkv[k] = B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + pk_off + its[k].d];
+            // damping, armature and the PD gains of the upper body (used after the first substep only; requested in both so that the
+            // block has no branch): again from memory rather than held in 20 registers through the first substep
+            rdamp2[k] = B.dof_damping[gs[k]]; rarm2[k] = B.dof_armature[gs[k]]; rkp2[k] = M.kp[its[k].d]; rkv2[k] = M.kv[its[k].d];
+        }
+        if (noise) { DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = noise[(size_t)DW_NOISE_WORDS * its[k].env + DW_NZ_ENC + ND * sub + its[k].d]; }
         static_assert(ONI == 5, "the grouped touch below names five loads");
         OQ_KEEP3(fin[0], fin[1], fin[2]); OQ_KEEP2(fin[3], fin[4]);
-        // damping, armature and the PD gains of the upper body for the second substep's inputs: requested again here (their
-        // latency passes behind the noise generation) rather than held in 20 registers through the first substep
-        float rdamp2[ONI], rarm2[ONI], rkp2[ONI], rkv2[ONI], tau2[ONI], nzw1[ONI];
-        DQ_UNROLL for (int k = 0; k < ONI; ++k) {
-            const JointItem it = item(k);
-            const size_t g = (size_t)ND * it.env + it.d;
-            const float *pk = B.obs_buf + (size_t)DW_NUM_OBS * it.env;
-            qkeep[k] = B.dof_state[g * 2]; qdkeep[k] = B.dof_state[g * 2 + 1];
-            qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * it.env + DW_ES_QPOS_PRE + it.d];
-            if (sub == 0) { rdamp2[k] = B.dof_damping[g]; rarm2[k] = B.dof_armature[g]; rkp2[k] = M.kp[it.d]; rkv2[k] = M.kv[it.d]; tau2[k] = pk[PK_TAU2 + it.d]; }
-            else nzw1[k] = noise ? 0.0f : pk[PK_NZ1 + it.d];
-        }
         if (sub == 0) DQ_STAMP(B, 34);
-        if (noise) {
-            DQ_UNROLL for (int k = 0; k < ONI; ++k) { const JointItem it = item(k); nzw[k] = noise[(size_t)DW_NOISE_WORDS * it.env + DW_NZ_ENC + ND * sub + it.d]; }
-        } else if (sub == 0) {          // one generator call per joint gives the draws of both substeps
-            DQ_UNROLL for (int k = 0; k < ONI; ++k) {
-                const JointItem it = item(k);
-                dw::NoiseSrc nz;
-                nz.rec = nullptr; nz.seed = C.seed; nz.env = (unsigned int)it.env; nz.step = (unsigned long long)step; nz.stream = 0;
-                float n1;
-                dw::noise_enc_pair(nz, it.d, &nzw[k], &n1);
-                if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_NZ1 + it.d] = n1;
+        float n1[ONI];
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) n1[k] = 0.0f;
+        if (!noise) {
+            if (sub == 0) {          // one generator call per joint gives the draws of both substeps
+                DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+                    dw::NoiseSrc nz;
+                    nz.rec = nullptr; nz.seed = C.seed; nz.env = (unsigned int)its[k].env; nz.step = (unsigned long long)step; nz.stream = 0;
+                    dw::noise_enc_pair(nz, its[k].d, &nzw[k], &n1[k]);
+                }
+            } else {
+                DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = pkv[k];
             }
-        } else {
-            DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = nzw1[k];
         }
         if (sub == 0) DQ_STAMP(B, 35);
+        float qo[ONI], qdo[ONI], qno[ONI];
+        F4 nxt[ONI];
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
-            const JointItem it = item(k);
-            const size_t g = (size_t)ND * it.env + it.d;
-            const int d = it.d;
-            float q = qkeep[k], qd = 0.0f;
+            const int d = its[k].d;
+            float q = qkeep[k], qd = qdkeep[k];
             if (!C.freeze_physics) {
                 qd = fin[k].y; q = qkeep[k] + dt * qd;
                 if (q < fin[k].x) { q = fin[k].x; if (qd < 0) qd = 0; }
                 if (q > fin[k].z) { q = fin[k].z; if (qd > 0) qd = 0; }
-                qkeep[k] = q; qdkeep[k] = qd;
-                if (it.ok) { B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd; }
             }
             const float qn = q + fminf(fmaxf(nzw[k], -0.00016f), 0.00016f);
             const float qv = C.gpu_div ? (qn - qnprev[k]) * C.inv_dt_f : (qn - qnprev[k]) / dt;
-            qnprev[k] = qn;
-            qvk[k] = qv;
-            if (sub == 0 && it.ok) B.env_state[(size_t)DW_ES_WORDS * it.env + DW_ES_QPOS_PRE + d] = qn;
-            if (sub == 0 && !C.freeze_physics) {
-                const float tau = d < 12 ? tau2[k] : rkp2[k] * (tau2[k] - q) + rkv2[k] * (-qd);
-                if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, OQ_IPOS(it)) = mk4(q, qd, tau - rdamp2[k] * qd, rarm2[k] + dt * rdamp2[k]);
+            qo[k] = q; qdo[k] = qd; qno[k] = qn;
+            qkeep[k] = q; qdkeep[k] = qd; qnprev[k] = qn; qvk[k] = qv;
+            const float tau = d < 12 ? pkv[k] : rkp2[k] * (pkv[k] - q) + rkv2[k] * (-qd);
+            nxt[k] = mk4(q, qd, tau - rdamp2[k] * qd, rarm2[k] + dt * rdamp2[k]);
+        }
+        // stores: the state (dof_state always holds the current one), after the first substep also the encoder reading, the second
+        // substep's encoder draw and the slot inputs of the second substep
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+            if (its[k].ok) {
+                if (!C.freeze_physics) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
+                if (sub == 0) {
+                    B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d] = qno[k];
+                    if (!noise) B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + PK_NZ1 + its[k].d] = n1[k];
+                }
             }
+            if (sub == 0 && !C.freeze_physics && X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, ips[k]) = nxt[k];
         }
         wave_sync();
         DQ_STAMP(B, 1 + 16 * sub + 14);
