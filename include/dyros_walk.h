@@ -23,9 +23,9 @@
  *                            (tasks/dyros_dynamic_walk.py:502,520,525-526,547-549): ONE physics substep.
  *   dw_step                  VecTask.step: pre_physics_step + 2x simulate + post_physics_step
  *                            (tasks/base/vec_task.py:293-344; tasks/dyros_dynamic_walk.py:449-563,581-669,
- *                            750-947): three launches on the caller's stream (task logic before the substeps,
- *                            the two substeps with the actuator model, task logic after them) or, with
- *                            DwConfig.pipeline = 1, one fused launch.
+ *                            750-947): ONE launch on the caller's stream, whichever kernel generation
+ *                            DwConfig.pipeline selects.  During the launch the env's row of obs_buf is scratch
+ *                            (it is rewritten with the new observation at the end of the same launch).
  *   dw_reset_idx             DyrosDynamicWalk.reset_idx + set_actor_root_state_tensor_indexed +
  *                            set_dof_state_tensor_indexed (tasks/dyros_dynamic_walk.py:598-669,720-748),
  *                            as reached from VecTask.reset_done (tasks/base/vec_task.py:376-391).
@@ -184,9 +184,11 @@ typedef struct DwConfig {
     float   terrain_env_length;         /* terrain_length [m]: walked more than half of it => level up */
     float   max_episode_length_s;       /* env.episodeLength as the curriculum uses it (:34, :685)    */
     int32_t custom_origins;             /* 1 = reset adds U(-1,1) m of xy jitter to the origin (:729-732) */
-    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate: 0 = default (2), 1 = the wave-per-env
-                                           kernels of round 1 (one wavefront per env), 2 = the quad kernels (4 lanes per
-                                           env, 16 envs per wavefront, one launch per policy step) */
+    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate (one launch per policy step in all):
+                                           0 = default (3), 1 = the wave-per-env kernels of round 1, 2 = the quad kernels
+                                           (4 lanes per env, 16 envs per wavefront, one wave per SIMD), 3 = the octet
+                                           kernels (8 lanes per env, 8 envs per wavefront, two waves per SIMD; DESIGN.md
+                                           section 5) */
 } DwConfig;
 
 /* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of

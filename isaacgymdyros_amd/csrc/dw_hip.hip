@@ -1,11 +1,12 @@
 // dw_hip.hip -- gfx950 kernels and the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so).
 //
-// Two kernel generations sit behind the C-ABI (DwConfig.pipeline).  The default is the quad generation (4 lanes per env,
-// 16 envs per wavefront: dw_quad*.h, entry points in dw_quad_kernels.hip, launched from here).  This file also holds the
-// wave-per-env generation of round 1 (one workgroup = one wavefront = one environment; bodies in dw_task.h / dw_physics.h as
-// wave regions over a 13.5 KB LDS block per env) and dw_k_reset, which both use for reset_idx.  It owns the read-only
-// model / mocap tables in device memory and validates arguments.  Nothing here allocates, synchronises or copies per call
-// (graph-capture safe).
+// Three kernel generations sit behind the C-ABI (DwConfig.pipeline), each a single launch per policy step.  The default is the
+// octet generation (8 lanes per env, 8 envs per wavefront, two wavefronts per SIMD: dw_oct*.h, entry points in
+// dw_oct_kernels.hip); the quad generation (4 lanes per env, 16 envs per wavefront: dw_quad*.h, dw_quad_kernels.hip) and the
+// wave-per-env generation of round 1 (bodies in dw_task.h / dw_physics.h, entry points here) are the second and third
+// implementations every parity test also runs.  This file also holds dw_k_reset, which all three use for reset_idx; it owns
+// the read-only model / mocap tables in device memory and validates arguments.  Nothing here allocates, synchronises or
+// copies per call.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -142,7 +143,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     const char *err = "";
     int rc = dw::build_devmodel(model, task, hm, &err);
     if (rc) { free(hm); free(h); return fail(rc, err); }
-    h->pipeline = cfg->pipeline == 0 ? 2 : cfg->pipeline;
+    h->pipeline = cfg->pipeline == 0 ? 3 : cfg->pipeline;
     dwq::QuadModel *hq = nullptr;
     if (h->pipeline >= 2) {
         rc = dwq::build_quadmodel_host(hm, model, &hq, &err, h->pipeline == 3);

@@ -404,8 +404,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #define OQ_TICK() ((void)0)
 #define OQ_TOCK(acc) ((void)0)
 #endif
-    const OPos posM = {X.pos.e - X.h * 512, X.pos.o - X.h * 512};          // my map's body of a round: outward step T - 1 - s - h
+    const int first_j = (f2i(H.base[14]) >> (4 * j)) & 15, last_j = (f2i(H.base[14]) >> (16 + 4 * j)) & 15;      // my limb's steps
+#if defined(OCT_ABL_INWARD)
+    DQ_ROLLED for (int s = 0; s < 0; s += 2) {
+#else
     DQ_ROLLED for (int s = 0; s < T; s += 2) {
+#endif
         OQ_TICK();
 #if defined(DQ_STAMPS_INWARD)
         if (SB == 1) DQ_STAMP(B, 42 + s);
@@ -421,8 +425,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             const int gymbits = f2i(h0.z);
             const float ms0 = ms_next;
             ms_next = mscale_e[(f2i(H.in[step_clamped(s + 2 + X.h)][j][2]) >> 24) & 255];
-            F4 s0 = mk4(0.0f, 0.0f, 0.0f, 1.0f), s1 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s2 = s1, s3 = s1;
-            if (b >= 0) { s0 = OQ_LD(T - 1 - s, 0, posM); s1 = OQ_LD(T - 1 - s, 1, posM); s2 = OQ_LD(T - 1 - s, 2, posM); s3 = OQ_LD(T - 1 - s, 3, posM); }
+            // (the slot rows are requested together with the table record, not after it: a lane that idles in this step reads the
+            //  nearest body of its own limb instead -- the step index clamped to the limb's range -- and nothing is done with it)
+            int som = T - 1 - s - X.h;
+            som = som < first_j ? first_j : (som > last_j ? last_j : som);
+            const F4 s0 = OQ_LD(som, 0, X.pos), s1 = OQ_LD(som, 1, X.pos), s2 = OQ_LD(som, 2, X.pos), s3 = OQ_LD(som, 3, X.pos);
             F4 ax4 = ldp(reinterpret_cast<const F4 *>(H.fk[T - 1 - sm][j])[1]);
             OQ_KEEP1(ax4);
             const float axis[3] = {ax4.x, ax4.y, ax4.z};
@@ -698,6 +705,15 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 5);
+    // the warm-start impulses of my foot's corners (previous substep) from the task record: requested here, a whole
+    // outward pass before the contact solve uses them
+    float warm[12];
+    DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = 0.0f;
+    wave_sync_global();          // (also: the previous substep of this launch stored the impulses)
+    if (B.env_state) {           // (dw_simulate may run without a task record: the solve then starts from zero)
+        const float *wsrc = B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * (j & 1);
+        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = wsrc[i];
+    }
     // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot (lean / chain-start forms as in
     //      pass 1) ----
     {
@@ -741,15 +757,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
         }
     }
-    // the warm-start impulses of my foot's corners (previous substep) from the task record: requested here, at a point where the
-    // wave synchronises anyway, used by the contact solve below
-    float warm[12];
-    DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = 0.0f;
-    wave_sync_global();          // (also: the previous substep of this launch stored the impulses)
-    if (B.env_state) {           // (dw_simulate may run without a task record: the solve then starts from zero)
-        const float *wsrc = B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * (j & 1);
-        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = wsrc[i];
-    }
+    wave_sync();
     DQ_STAMP(B, SB + 6);
     // ---- free base velocity; sole-corner gaps of my foot (foot f = j & 1; lanes f and f + 2 work on it together) ----
     float wwf[3], vowf[3];

@@ -17,6 +17,9 @@ void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::De
                    const float *actions, const float *noise, long long step) {
     __shared__ dwo::OLds L;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));          // (wave-uniform: keep it in a scalar register)
+#if defined(OCT_STAGGER_SHIFT)      // (timing experiment: hold back every other group of workgroups so that the two waves of a SIMD are in different phases)
+    if ((blockIdx.x >> OCT_STAGGER_SHIFT) & 1) for (int i = 0; i < OCT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     dwo::oct_step<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C, B, actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
 }
 // One physics substep at the Gym boundary, same layout.

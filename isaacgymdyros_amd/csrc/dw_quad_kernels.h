@@ -1,8 +1,7 @@
-// dw_quad_kernels.h -- the policy step of the split pipeline, physics part: for 16 envs per wavefront, the two physics
-// substeps of VecTask.step with the actuator model around them (reference tasks/dyros_dynamic_walk.py:504-530: upper-body
-// PD, 6-slot torque FIFO with per-env delay, simulate, encoder model), on the quad layout of dw_quad.h.  dw_k_pre has
-// already written this step's action torques, mocap target and push into the task record; dw_k_post consumes the state,
-// the net contact forces and the encoder fields this kernel leaves behind.
+// dw_quad_kernels.h -- the whole VecTask.step for the 16 envs of a quad wave (dw_quad.h), in one launch: pre_physics_step, the
+// two physics substeps with the actuator model around them (reference tasks/dyros_dynamic_walk.py:449-541: mocap target,
+// action torques, push, upper-body PD, 6-slot torque FIFO with per-env delay, simulate, encoder model), then
+// post_physics_step (dw_quad_post.h).
 //
 // Every fp32 expression that the reference pins bit for bit (tau per substep, qpos_noise, qvel_noise: SURVEY 8c) is
 // written exactly as in dw_task.h P3 (fp contraction off in this region of the file).

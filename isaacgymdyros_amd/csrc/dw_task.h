@@ -738,7 +738,7 @@ DW_HD int task_post(const W &wave, LT &S, const DevModel &M, const TaskParams &C
     return did_reset | uniform(S.flags[1]);
 }
 
-// The fused wave-per-env step (first-generation kernel; still the one that runs on height fields)
+// The fused wave-per-env step (first-generation kernel, DwConfig.pipeline = 1; flat ground and height fields)
 template <bool TERRAIN, class W>
 DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
     const DwBuffers &B = *T.b;

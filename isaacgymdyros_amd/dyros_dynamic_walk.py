@@ -356,7 +356,7 @@ class DyrosDynamicWalk(VecTask):
     def kernel_info(self) -> dict:
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
         profiles/ carry the same name)."""
-        pl = int(self._ccfg.pipeline) or 2
+        pl = int(self._ccfg.pipeline) or 3
         name = {1: "dw_k_step", 2: "dw_k_step_quad", 3: "dw_k_step_oct"}[pl]
         desc = {1: "wave per env", 2: "quad (4 lanes per env, 16 envs per wave)", 3: "octet (8 lanes per env, 8 envs per wave, 2 waves per SIMD)"}[pl]
         return {"kernels": name, "pipeline": desc, "launches_per_step": 1}

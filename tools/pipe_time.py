@@ -4,6 +4,8 @@ usage: python tools/pipe_time.py [--pipes 3,2] [--envs 4096,16384] [--rounds 3] 
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from isaacgymdyros_amd import _lib
+_lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
 from isaacgymdyros_amd.config import default_cfg
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 
