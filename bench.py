@@ -19,18 +19,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 A_STEP_BYTES = 6816        # algorithmic bytes per env-step, SURVEY.md section 8(d): 1704 words
+A_PHYS_BYTES = 1636        # algorithmic bytes per env-substep at the Gym boundary, SURVEY.md section 8(d): 409 words
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HORIZON = 128              # rollout horizon of the reference's PPO config; logging gather once per horizon
 VALU_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
 FLOPS_PER_ENV_STEP = 1.0e5 # useful flops of one env-step (2 substeps: ABA ~14 k + contact ~30 k each, task logic ~5 k), SURVEY 8(d)
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: the PMC traffic record under profiles/ names the sources it was measured on, and is
+    quoted only for exactly those."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "isaacgymdyros_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/dyros_walk.h"]:
+        p = os.path.join(csrc, f)
+        if os.path.isfile(p) and (f.endswith((".h", ".hip"))):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(seconds_budget: float = 15.0):
-    """The CPU oracle (C restatement, `kind: port`) on the host cores: bounded sample of the same workload."""
+    """The CPU oracle (C restatement, `kind: port`) on the host cores: bounded sample of the same workload (16384 envs, so
+    that every thread of a 256-thread host has 64 envs per step)."""
     import numpy as np
     from isaacgymdyros_amd.task_constants import load_task_constants
     from oracle.oracle import OracleSim
-    N = 4096
+    N = 16384
     threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     sim = OracleSim(N, task_const=load_task_constants(), torch_gpu_div=1)
     sim.buf["dof_state"][:, :, 0] = load_task_constants()["initial_dof_pos"]
@@ -60,6 +75,7 @@ def cpu_baseline(seconds_budget: float = 15.0):
             one.step(a1[k1 % 8], None, 1 + k1)
             k1 += 1
         out["single_core_value"] = 128 * k1 / (time.perf_counter() - t1)
+        out["parallel_efficiency"] = out["value"] / (out["single_core_value"] * threads)
         gomp.omp_set_num_threads(threads)
     except Exception:
         pass
@@ -123,6 +139,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also-4096", action="store_true", help="skip the secondary 4096-env measurement")
+    ap.add_argument("--no-config5", action="store_true", help="skip the friction-DR + forced-pushes leg (BASELINE config 5)")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the PPO-consumer leg (BASELINE config 3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = CPU plumbing rehearsal of the N-rank path (no kernel runs; the line is marked invalid)")
     args = ap.parse_args()
@@ -160,14 +178,21 @@ def main():
         if not plumbing:
             torch.cuda.synchronize()
 
-    def run(envs, steps, warmup):
+    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False):
+        """K steps of VecTask.step on `envs` envs of this rank.  alias_obs = False is the product's default contract (step() returns
+        a fresh observation tensor, as the reference's torch.clamp does); True returns the view of obs_buf, so that the stream
+        holds nothing but the step kernel."""
         if plumbing:
             env = _PlumbingEnv(envs, rank)
             pool = [torch.zeros(envs, 13)]
         else:
             cfg = default_cfg(envs, dev)
             cfg["seed"] = 42 + rank
-            cfg["sim"]["mi355"]["alias_obs"] = True       # zero-copy obs: the bench keeps nothing across steps
+            cfg["sim"]["mi355"]["alias_obs"] = bool(alias_obs)
+            cfg["sim"]["mi355"].update(mi or {})
+            if friction_dr:
+                from isaacgymdyros_amd.config import with_friction_randomization
+                cfg = with_friction_randomization(cfg)
             env = DyrosDynamicWalk(cfg, dev, 0, True)
             g = torch.Generator(device=dev).manual_seed(42 + rank)
             pool = [torch.rand(envs, 13, generator=g, device=dev) * 2 - 1 for _ in range(64)]
@@ -196,13 +221,29 @@ def main():
         if world > 1:
             dist.barrier()
         wall = time.perf_counter() - t0
-        # device time per step on the launch stream (HIP events): the step's kernels, launch gaps included
+        # device time per step on the launch stream (HIP events on torch's current stream, which is the stream step() launches
+        # on): the step's kernels, launch gaps included
         kernel_ms = (e0.elapsed_time(e1) / steps) if not plumbing else wall / steps * 1e3
         stats = dwdist.gather_episode_stats(env._buf["env_state"])
         resets = int(env.episodes_finished.sum())
         kinfo = env.kernel_info() if hasattr(env, "kernel_info") else {}
+        # the Gym-boundary substep (dw_simulate: the ABA + contact step the north star names), same envs, same stream
+        sim_ms = None
+        if not plumbing and alias_obs:
+            tau = (torch.rand(envs, 33, device=dev) * 2 - 1) * 20
+            for _ in range(20):
+                env.simulate(tau)
+            sync()
+            e0.record()
+            for _ in range(200):
+                env.simulate(tau)
+            e1.record()
+            sync()
+            sim_ms = e0.elapsed_time(e1) / 200
+        pert = float(env._buf["stacked_rewards"][:, 14].mean()) if not plumbing else 0.0
         env.close()
-        return wall, kernel_ms, dwdist.summarize(stats), resets, kinfo
+        return {"wall": wall, "kernel_ms": kernel_ms, "episodes": dwdist.summarize(stats), "resets": resets, "kinfo": kinfo,
+                "sim_ms": sim_ms, "perturb_start_fraction": pert}
 
     def reduce_max(x):
         t = torch.tensor([x], device=dev, dtype=torch.float64)
@@ -210,30 +251,39 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    wall, kernel_ms, epi, resets, kinfo = run(args.envs_per_gpu, args.steps, args.warmup)
-    wall_max = reduce_max(wall)
+    head = run(args.envs_per_gpu, args.steps, args.warmup)                 # the headline: the product's default obs contract
+    wall_max = reduce_max(head["wall"])
     total_envs = args.envs_per_gpu * n_joined
     value = total_envs * args.steps / wall_max
     # a short driver run (--steps 20 is 12 ms) says little by itself: time a longer region as well and report both
     long_run = None
     if args.steps < 200 and not plumbing:
-        w_l, k_l, _, _, _ = run(args.envs_per_gpu, 256, 16)
-        w_l = reduce_max(w_l)
-        long_run = {"steps": 256, "value": total_envs * 256 / w_l, "ms_per_step": w_l / 256 * 1e3, "kernel_ms": k_l}
+        r = run(args.envs_per_gpu, 256, 16)
+        w_l = reduce_max(r["wall"])
+        long_run = {"steps": 256, "value": total_envs * 256 / w_l, "ms_per_step": w_l / 256 * 1e3}
+    # the step kernel alone on the stream (zero-copy observation view): its mean launch duration is the roofline's denominator
+    alias = run(args.envs_per_gpu, max(args.steps, 256), args.warmup, alias_obs=True) if not plumbing else head
+    w_a = reduce_max(alias["wall"])
+    kernel_ms = alias["kernel_ms"]
+    n_a = max(args.steps, 256) if not plumbing else args.steps
 
     out = None
     if rank == 0:
+        kinfo = head["kinfo"]
         achieved = A_STEP_BYTES * args.envs_per_gpu / (kernel_ms * 1e-3) / 1e9
-        traffic, lane_slots = None, None
+        traffic, lane_slots, traffic_note = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(str(args.envs_per_gpu), {})
-                if rec.get("kernel", kinfo.get("kernels")) == kinfo.get("kernels"):      # counters of THIS kernel only
+                if rec.get("kernel") == kinfo.get("kernels") and rec.get("kernel_source_hash") == kernel_source_hash():
                     traffic = rec.get("hbm_bytes_per_launch")
                     lane_slots = rec.get("lane_slots_per_env_step")
-            except Exception:
-                traffic, lane_slots = None, None
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was measured on kernel %s at sources %s; this build is %s at %s" % (
+                        rec.get("kernel"), rec.get("kernel_source_hash"), kinfo.get("kernels"), kernel_source_hash())
+            except Exception as e:
+                traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
         useful_flops = FLOPS_PER_ENV_STEP * args.envs_per_gpu
         valu = useful_flops / (kernel_ms * 1e-3) / 1e12
         out = {
@@ -242,29 +292,62 @@ def main():
             "ms_per_step": wall_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not plumbing else "plumbing-test (no kernel ran)",
             "config": {"workload": "DyrosDynamicWalk random-action rollout, flat ground, mu=1, DR (mass/damping/armature) on, "
-                                   "resets on, in-kernel RNG", "num_envs_per_gpu": args.envs_per_gpu,
+                                   "resets on, in-kernel RNG, step() returns a fresh observation tensor (reference contract)",
+                       "num_envs_per_gpu": args.envs_per_gpu,
                        "total_envs": total_envs, "substeps_per_step": 2, "dt": 0.002,
                        "parallelism": "env-sharded x%d, no collective in step; RCCL all-gather of episode stats every %d steps" % (n_joined, HORIZON)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kinfo.get("kernels", "dw_k_step"), "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": A_STEP_BYTES * args.envs_per_gpu},
+                         "algorithmic_bytes_per_launch": A_STEP_BYTES * args.envs_per_gpu,
+                         "kernel_source_hash": kernel_source_hash()},
             # the second roof: useful flops of the step (per-phase count in DESIGN.md section 6) against
             # the fp32 vector peak; lane_slots_per_env_step comes from the SQ_INSTS_VALU PMC pass when one is committed
             "roofline_valu": {"bound": "valu_f32", "achieved": valu, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": valu / VALU_PEAK_TF, "useful_flops_per_env_step": FLOPS_PER_ENV_STEP,
                               "lane_slots_per_env_step": lane_slots},
-            "episodes": dict(epi, finished_total=resets),
+            "alias_obs": {"value": total_envs * n_a / w_a, "ms_per_step": w_a / n_a * 1e3,
+                          "note": "cfg sim.mi355.alias_obs: step() returns the view of obs_buf (no copy kernel on the stream)"},
+            "episodes": dict(head["episodes"], finished_total=head["resets"]),
         }
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
+        if alias.get("sim_ms"):
+            # the roofline the north star names: algorithmic bytes of ONE ABA + contact substep at the Gym boundary over the mean
+            # duration of dw_k_simulate_oct (HIP events around 200 dw_simulate launches)
+            a_p = A_PHYS_BYTES * args.envs_per_gpu / (alias["sim_ms"] * 1e-3) / 1e9
+            out["roofline_phys"] = {"bound": "hbm", "achieved": a_p, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_p / HBM_PEAK_GBS,
+                                    "kernel": kinfo.get("kernels", "dw_k_step").replace("step", "simulate"), "kernel_ms": alias["sim_ms"],
+                                    "algorithmic_bytes_per_launch": A_PHYS_BYTES * args.envs_per_gpu,
+                                    "env_substeps_per_s": args.envs_per_gpu / (alias["sim_ms"] * 1e-3)}
         if plumbing:
             out["valid"] = False
         if long_run:
             out["long_run"] = long_run
-    if not args.no_also_4096 and world == 1 and not plumbing:
-        w2, k2, _, _, _ = run(4096, max(args.steps, 256), args.warmup)
-        if rank == 0:
-            n2 = max(args.steps, 256)
-            out["num_envs_4096"] = {"value": 4096 * n2 / w2, "ms_per_step": w2 / n2 * 1e3, "kernel_ms": k2}
+    if world == 1 and not plumbing:
+        n2 = max(args.steps, 256)
+        if not args.no_also_4096:               # BASELINE config 2
+            r2 = run(4096, n2, args.warmup)
+            a2 = run(4096, n2, args.warmup, alias_obs=True)
+            ach2 = A_STEP_BYTES * 4096 / (a2["kernel_ms"] * 1e-3) / 1e9
+            out["num_envs_4096"] = {"value": 4096 * n2 / r2["wall"], "ms_per_step": r2["wall"] / n2 * 1e3, "kernel_ms": a2["kernel_ms"],
+                                    "roofline_frac": ach2 / HBM_PEAK_GBS}
+        if not args.no_config5:                 # BASELINE config 5: friction DR next to mass / damping / armature, pushes forced on
+            r5 = run(args.envs_per_gpu, n2, args.warmup, mi={"force_perturb_start": True}, friction_dr=True)
+            out["config5_dr_friction_pushes"] = {"value": args.envs_per_gpu * n2 / r5["wall"], "ms_per_step": r5["wall"] / n2 * 1e3,
+                                                 "perturb_start_fraction": r5["perturb_start_fraction"], "episodes_finished": r5["resets"],
+                                                 "note": "friction x U(0.7,1.3) per env at reset, force_perturb_start (tasks/dyros_dynamic_walk.py:491)"}
+        if not args.no_ppo:                     # BASELINE config 3: the DYROS PPO loop attached (examples/ppo_consumer.py), one epoch
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(ROOT, "examples", "ppo_consumer.py"))
+                ppo = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(ppo)
+                st = ppo.train(args.envs_per_gpu, epochs=1, device=dev, log=lambda s_: None)[-1]
+                out["config3_ppo"] = {k: st[k] for k in ("step_fps", "play_fps", "total_fps", "mean_reward")}
+                out["config3_ppo"]["note"] = "one epoch: horizon 128 rollout with the policy in the loop, then the DYROS PPO update"
+            except Exception as e:
+                out["config3_ppo"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not plumbing:
             try:

@@ -309,6 +309,13 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
  * or NULL; step_index = number of dw_step calls made before this one. */
 int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream);
 
+/* The same step with the step counter in DEVICE memory (int64, caller-owned, initialised by the caller): the kernel reads it and
+ * a one-thread launch behind it adds 1.  No argument of the call changes from step to step, so a rollout step -- this call, or
+ * this call with the policy network around it -- can be captured in a hipGraph once and replayed; every replay draws from the
+ * next block of the counter-based generator, exactly as successive dw_step calls do.  (dw_step itself takes step_index by
+ * value: replaying a captured dw_step would replay its noise.) */
+int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream);
+
 /* reset_idx for the env ids listed (int32, device memory). */
 int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise,
                  int64_t step_index, void *stream);

@@ -116,11 +116,12 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     api["bind"] = fn("bind", C.c_int, H, C.POINTER(DwBuffers))
     api["simulate"] = fn("simulate", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p)
     api["step"] = fn("step", C.c_int, H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    api["step_dev"] = fn("step_dev", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
     api["reset_idx"] = fn("reset_idx", C.c_int, H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
     return api
 
 
-EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step",
+EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev",
            "reset_idx"]
 
 

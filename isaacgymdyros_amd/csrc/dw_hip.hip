@@ -41,8 +41,9 @@ static int fail_hip(const char *what, hipError_t e) {
 // 13.5 KB of LDS per env admits 12 envs per CU = 3 waves per SIMD; cap the registers at 168 to match (measured +16 %
 // over 2 waves/SIMD at 256 registers; the kernel fits the cap without scratch)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
+void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dw::Lds S;
+    if (step_dev) step = *step_dev;
     dw::Wave w;
     dw::TaskBuffers T;
     T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
@@ -51,8 +52,9 @@ void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actio
 
 // the same step on a height field (DwConfig.terrain = 1): every contact point samples the terrain
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step) {
+void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dw::Lds S;
+    if (step_dev) step = *step_dev;
     dw::Wave w;
     dw::TaskBuffers T;
     T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
@@ -65,7 +67,7 @@ void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const floa
 namespace dwq {
 struct QuadModel;
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step);
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
 int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err, bool octet);      // malloc'ed
@@ -75,7 +77,7 @@ int  quad_lds_bytes();
 // The octet kernels (DwConfig.pipeline = 3): dw_oct_kernels.hip; they take the quad generation's schedule and tables.
 namespace dwo {
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step);
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
 int  oct_lds_bytes();
@@ -229,7 +231,11 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     return DW_OK;
 }
 
-int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream) {
+// advances the device-resident step counter of dw_step_dev behind the step kernel (same stream)
+__global__ void dw_k_bump(long long *counter) { *counter += 1; }
+
+static int launch_step(DwHandle *h, const float *actions, const float *noise, long long step_index, const long long *step_dev, void *stream,
+                       const char *who) {
     if (!h || !h->bound || !h->has_task) return fail(DW_ESTATE, "dw_step: handle has no task constants or no buffers bound");
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
@@ -237,18 +243,33 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
     DeviceGuard guard(h->device);
     if (h->pipeline == 3) {
         dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
-                         actions, noise, (long long)step_index);
+                         actions, noise, step_index, step_dev);
     } else if (h->pipeline == 2) {
         dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
-                         actions, noise, (long long)step_index);
+                         actions, noise, step_index, step_dev);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
-                           h->d_params, actions, noise, (long long)step_index);
+                           h->d_params, actions, noise, step_index, step_dev);
     else
         hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
-                           actions, noise, (long long)step_index);
+                           actions, noise, step_index, step_dev);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip("dw_step: launch", e);
+    if (e != hipSuccess) return fail_hip(who, e);
+    return DW_OK;
+}
+
+int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream) {
+    return launch_step(h, actions, noise, (long long)step_index, nullptr, stream, "dw_step: launch");
+}
+
+int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream) {
+    if (!step_counter) return fail(DW_EINVAL, "dw_step_dev: step_counter is null");
+    const int rc = launch_step(h, actions, noise, 0, (const long long *)step_counter, stream, "dw_step_dev: launch");
+    if (rc != DW_OK) return rc;
+    DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(dw_k_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)step_counter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip("dw_step_dev: counter launch", e);
     return DW_OK;
 }
 

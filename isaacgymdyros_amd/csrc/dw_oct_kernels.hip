@@ -14,8 +14,9 @@
 template <bool TERRAIN>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
-                   const float *actions, const float *noise, long long step) {
+                   const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dwo::OLds L;
+    if (step_dev) step = *step_dev;          // (dw_step_dev: the counter lives in device memory so that a captured launch can be replayed)
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));          // (wave-uniform: keep it in a scalar register)
 #if defined(OCT_STAGGER_SHIFT)      // (timing experiment: hold back every other group of workgroups so that the two waves of a SIMD are in different phases)
     if ((blockIdx.x >> OCT_STAGGER_SHIFT) & 1) for (int i = 0; i < OCT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
@@ -37,10 +38,10 @@ namespace dwo {
 static int groups(int num_envs) { return (num_envs + EPO * WPG - 1) / (EPO * WPG); }
 
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step) {
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
     const dim3 grid(groups(num_envs));
-    if (terrain) hipLaunchKernelGGL(dw_k_step_oct<true>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, mocap, actions, noise, step);
-    else hipLaunchKernelGGL(dw_k_step_oct<false>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, mocap, actions, noise, step);
+    if (terrain) hipLaunchKernelGGL(dw_k_step_oct<true>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
+    else hipLaunchKernelGGL(dw_k_step_oct<false>, grid, dim3(64 * WPG), 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
 }
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push) {

@@ -15,8 +15,9 @@
 template <bool TERRAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
-                    const float *actions, const float *noise, long long step) {
+                    const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dwq::QLds L;
+    if (step_dev) step = *step_dev;
 #if defined(DQ_STAGGER)
 #ifndef DQ_STAGGER_MULT
 #define DQ_STAGGER_MULT 1
@@ -38,10 +39,10 @@ void dw_k_simulate_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const d
 namespace dwq {
 
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step) {
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
     const dim3 grid((num_envs + EPW - 1) / EPW);
-    if (terrain) hipLaunchKernelGGL(dw_k_step_quad<true>, grid, dim3(64), 0, stream, QM, M, P, B, mocap, actions, noise, step);
-    else hipLaunchKernelGGL(dw_k_step_quad<false>, grid, dim3(64), 0, stream, QM, M, P, B, mocap, actions, noise, step);
+    if (terrain) hipLaunchKernelGGL(dw_k_step_quad<true>, grid, dim3(64), 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
+    else hipLaunchKernelGGL(dw_k_step_quad<false>, grid, dim3(64), 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
 }
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push) {

@@ -88,6 +88,11 @@ class DyrosDynamicWalk(VecTask):
         self._initial_state()
         self._bind()
         self._step_count = 0
+        # cfg sim.mi355.device_step_counter: the step counter lives in device memory (dw_step_dev), so that step() can be captured
+        # in a hipGraph and replayed
+        self._step_dev = None
+        if self.cfg["sim"].get("mi355", {}).get("device_step_counter", False):
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=self._tdev)
         self.extras["reward_names"] = list(REWARD_NAMES)
 
     # ------------------------------------------------------------------ native handle
@@ -329,7 +334,11 @@ class DyrosDynamicWalk(VecTask):
                 raise ValueError("noise must be a contiguous float32 [N, DW_NOISE_WORDS] tensor")
             nz = noise.data_ptr()
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
-        _lib.check(self._api, self._api["step"](self._h, a.data_ptr(), nz, self._step_count, stream))
+        if self._step_dev is not None:
+            # (graph-capturable form: no argument changes from step to step; the kernel reads the counter, a one-thread launch adds 1)
+            _lib.check(self._api, self._api["step_dev"](self._h, a.data_ptr(), nz, self._step_dev.data_ptr(), stream))
+        else:
+            _lib.check(self._api, self._api["step"](self._h, a.data_ptr(), nz, self._step_count, stream))
         self._step_count += 1
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.extras["stacked_rewards"] = self._buf["stacked_rewards"]
@@ -406,6 +415,8 @@ class DyrosDynamicWalk(VecTask):
         for k, v in self._buf.items():
             v.copy_(d[k].to(v.device))
         self._step_count = int(d["_step_count"])
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._step_count)
 
     def close(self):
         if getattr(self, "_h", None) is not None:

@@ -386,21 +386,18 @@ static void reward_env(DwHandle *h, int e, int *reset_out) {
 }
 
 /* gate_acc layout: [slot 0..2][bucket = env % 32][2], latch at DW_GATE_LATCH (include/dyros_walk.h) */
-static void gate_contribution(DwHandle *h, int64_t step, int e, float el, float cm) {
-    int64_t *acc = h->buf.gate_acc;
-    const int cur = (int)(step % 3), nxt = (int)((step + 1) % 3), bk = e % DW_GATE_BUCKETS;
+/* (each thread of dwo_step sums into its own [bucket][2] block, merged once per step: 256 threads adding atomically into 32
+ *  shared buckets of four per cache line was what kept the all-core baseline at 7x one core) */
+static void gate_contribution(int64_t *loc, int e, float el, float cm) {
+    const int bk = e % DW_GATE_BUCKETS;
     int64_t de, dc = 0;
     if (isfinite(el) && isfinite(cm)) { de = (int64_t)el; dc = (int64_t)llrintf(cm * 4294967296.0f); }
     else de = -((int64_t)1 << 62);
-#pragma omp atomic
-    acc[(cur * DW_GATE_BUCKETS + bk) * 2] += de;
-#pragma omp atomic
-    acc[(cur * DW_GATE_BUCKETS + bk) * 2 + 1] += dc;
-    acc[(nxt * DW_GATE_BUCKETS + bk) * 2] = 0;
-    acc[(nxt * DW_GATE_BUCKETS + bk) * 2 + 1] = 0;
+    loc[bk * 2] += de;
+    loc[bk * 2 + 1] += dc;
 }
 
-static void step_env(DwHandle *h, int e, const float *actions, const float *noise, int64_t step, int gate_open) {
+static void step_env(DwHandle *h, int e, const float *actions, const float *noise, int64_t step, int gate_open, int64_t *gate_loc) {
     const DwConfig *cfg = &h->cfg;
     const DwBuffers *b = &h->buf;
     float *es = ES(h, e);
@@ -539,7 +536,7 @@ static void step_env(DwHandle *h, int e, const float *actions, const float *nois
     }
     for (int i = 0; i < DW_NUM_ACT; ++i) es[DW_ES_ACTIONS_PRE + i] = es[DW_ES_ACTIONS + i];
     /* statistics for the next step's perturbation gate */
-    if (cfg->perturb && !cfg->force_perturb_start) gate_contribution(h, step, e, es[DW_ES_EPI_LEN_LOG], es[DW_ES_CRM]);
+    if (cfg->perturb && !cfg->force_perturb_start) gate_contribution(gate_loc, e, es[DW_ES_EPI_LEN_LOG], es[DW_ES_CRM]);
 }
 
 /* perturbation gate (tasks/dyros_dynamic_walk.py:489): population means of the previous step */
@@ -575,9 +572,30 @@ int dwo_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     const int N = h->cfg.num_envs;
     int open = gate_is_open(h, step_index);
     if (open && !h->cfg.force_perturb_start) h->buf.gate_acc[DW_GATE_LATCH] = 1;
-#pragma omp parallel for schedule(static)
-    for (int e = 0; e < N; ++e) step_env(h, e, actions, noise, step_index, open);
+    int64_t *acc = h->buf.gate_acc;
+    const int cur = (int)(step_index % 3), nxt = (int)((step_index + 1) % 3);
+#pragma omp parallel
+    {
+        int64_t loc[DW_GATE_BUCKETS * 2];
+        for (int k = 0; k < DW_GATE_BUCKETS * 2; ++k) loc[k] = 0;
+#pragma omp for schedule(static) nowait
+        for (int e = 0; e < N; ++e) step_env(h, e, actions, noise, step_index, open, loc);
+        if (h->cfg.perturb && !h->cfg.force_perturb_start) {
+#pragma omp critical
+            for (int k = 0; k < DW_GATE_BUCKETS * 2; ++k) acc[cur * DW_GATE_BUCKETS * 2 + k] += loc[k];
+        }
+    }
+    if (h->cfg.perturb && !h->cfg.force_perturb_start)
+        for (int k = 0; k < DW_GATE_BUCKETS * 2 && k < 2 * N; ++k) acc[nxt * DW_GATE_BUCKETS * 2 + k] = 0;
     return DW_OK;
+}
+
+/* the counter of dw_step_dev is a host word here: read, step, add one */
+int dwo_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream) {
+    if (!step_counter) return dwo_fail(DW_EINVAL, "dwo_step_dev: step_counter is null");
+    const int rc = dwo_step(h, actions, noise, *step_counter, stream);
+    if (rc == DW_OK) *step_counter += 1;
+    return rc;
 }
 
 int dwo_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise, int64_t step_index, void *stream) {

@@ -84,6 +84,12 @@ int dwe_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     delete S;
     return DW_OK;
 }
+int dwe_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream) {
+    if (!step_counter) return fail(DW_EINVAL, "step_counter is null");
+    const int rc = dwe_step(h, actions, noise, *step_counter, stream);
+    if (rc == DW_OK) *step_counter += 1;
+    return rc;
+}
 int dwe_reset_idx(DwHandle *h, const int32_t *ids, int32_t n, const float *noise, int64_t step_index, void *) {
     if (!h || !h->bound || !h->model.has_task) return fail(DW_ESTATE, "not ready");
     if (n < 0 || (n > 0 && !ids)) return fail(DW_EINVAL, "bad env id list");

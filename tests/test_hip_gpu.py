@@ -707,3 +707,38 @@ def test_reset_idx_with_terrain_curriculum_vs_oracle_on_gpu(task_const):
     for k in ("terrain_levels", "env_origins", "root_states", "dof_state", "env_state", "reset_buf", "progress_buf",
               "randomize_buf", "dof_damping", "dof_armature"):
         assert np.array_equal(ora.buf[k], env._buf[k].cpu().numpy()), k
+
+
+@pytest.mark.gpu
+def test_captured_step_replays_with_advancing_noise(pipeline):
+    """dw_step_dev keeps the step counter in device memory: one captured launch, replayed 8 times, equals 8 eager dw_step
+    calls bit for bit (in-kernel Philox draws included -- a captured dw_step would have replayed the noise of one step)."""
+    from hip_backend import make_env
+    N = 256
+    a = make_env(N, seed=5, pipeline=pipeline)
+    b = make_env(N, seed=5, pipeline=pipeline, device_step_counter=True)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(11)]
+    for t in range(3):                                      # eager warm-up of both (module loading, allocator)
+        a.step(acts[t]); b.step(acts[t])
+    torch.cuda.synchronize()
+    assert torch.equal(a._buf["env_state"], b._buf["env_state"]) and int(b._step_dev) == 3
+    static_act = acts[3].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = b._api["step_dev"](b._h, static_act.data_ptr(), 0, b._step_dev.data_ptr(), stream)
+            assert rc == 0
+    torch.cuda.synchronize()
+    assert int(b._step_dev) == 3                            # capture does not execute
+    for t in range(3, 11):
+        a.step(acts[t])
+        static_act.copy_(acts[t])
+        graph.replay()
+    torch.cuda.synchronize()
+    assert int(b._step_dev) == 11
+    for k in ("env_state", "root_states", "dof_state", "obs_buf", "rew_buf", "reset_buf", "obs_history", "dof_damping"):
+        assert torch.equal(a._buf[k], b._buf[k]), k

@@ -1,0 +1,69 @@
+"""Register / LDS / scratch budget of the shipped kernels, read from the compiler (hipcc -Rpass-analysis=kernel-resource-usage,
+the flags of isaacgymdyros_amd/build.py; cross-compiles without a GPU).  The octet kernels run two waves per SIMD only if they
+fit 256 registers and 40 KB of LDS per workgroup, and a spill inside a memory phase costs a full round trip per reload (r03:
+nine reloads in the encoder epilogue were 30 % of the step) -- so the budget is an assertion, not a comment: a change that
+spills fails here instead of showing up as a few per cent in a bench line."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from isaacgymdyros_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def resource_usage(src, extra):
+    cmd = [build.hipcc()] + build.FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull, os.path.join(build.CSRC, src)]
+    err = subprocess.run(cmd, cwd=build.CSRC, capture_output=True, text=True, check=True).stderr
+    out, cur = {}, None
+    for line in err.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            k = re.search(r"(dw_k_[a-z_]+?)ILb([01])E", name)
+            cur = ("%s<%s>" % (k.group(1), "true" if k.group(2) == "1" else "false")) if k else name
+            out[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            out[cur][m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+@pytest.fixture(scope="module")
+def usage():
+    u = {}
+    for src, extra in build.SOURCES:
+        if src != "dw_hip.hip":
+            u.update(resource_usage(src, extra))
+    path = os.path.join(ROOT, "profiles", "r03_kernel_resources.json")
+    try:
+        json.dump(u, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return u
+
+
+def test_octet_kernels_fit_two_waves_per_simd_without_scratch(usage):
+    for k in ("dw_k_step_oct<false>", "dw_k_simulate_oct<false>", "dw_k_simulate_oct<true>"):
+        r = usage[k]
+        assert r["ScratchSize"] == 0, (k, r)
+        assert r["Occupancy"] == 2, (k, r)
+        assert r["VGPRs"] + r["AGPRs"] <= 256, (k, r)
+        assert r["LDS Size"] <= 40960, (k, r)
+
+
+def test_terrain_step_kernel_scratch_is_bounded(usage):
+    """The height-field variant of the step kernel carries 36 more words of contact frames through the solve; what it spills is
+    recorded and may not grow (work list: DESIGN.md section 7)."""
+    r = usage["dw_k_step_oct<true>"]
+    assert r["Occupancy"] == 2 and r["ScratchSize"] <= 128, r
+
+
+def test_quad_kernels_keep_one_wave_per_simd_budget(usage):
+    for k in ("dw_k_step_quad<false>", "dw_k_simulate_quad<false>"):
+        r = usage[k]
+        assert r["LDS Size"] <= 40960 and r["VGPRs"] + r["AGPRs"] <= 512, (k, r)

@@ -19,11 +19,14 @@ if not traffic_only:
 summ = json.loads(open(os.path.join(src, "pmc", "summary.txt")).read())
 name = "%s_pmc_summary_step_16384.json" % tag
 json.dump(summ, open(os.path.join(dst, name), "w"), indent=1)
-kname = "dw_k_step_quad" if "dw_k_step_quad" in summ else "dw_k_step"
+kname = next(n for n in ("dw_k_step_oct", "dw_k_step_quad", "dw_k_step") if n in summ)
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash
 k = summ[kname]
 fetch, write = k["FETCH_SIZE"], k["WRITE_SIZE"]
 traffic = {"16384": {
     "kernel": kname,
+    "kernel_source_hash": kernel_source_hash(),          # bench.py quotes this record only for exactly these sources
     "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
     "lane_slots_per_env_step": k["SQ_INSTS_VALU"] * 64.0 / 16384.0,          # VALU instructions x 64 lanes, per env
     "fetch_size_kb": fetch, "write_size_kb": write,
