@@ -39,6 +39,24 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def effective_cpus():
+    """Threads the host really gives this process: the affinity mask capped by the cgroup CPU quota (a 1-GPU slice of a
+    256-thread host is 16 CPUs; 256 OpenMP threads on it were what made r02's all-core figure 7x one core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = "affinity mask: %d" % n
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            c = max(1, int(float(q) / float(p) + 0.5))
+            if c < n:
+                n, why = c, "cgroup cpu.max quota: %d of %d visible" % (c, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    if os.environ.get("OMP_NUM_THREADS"):
+        n, why = int(os.environ["OMP_NUM_THREADS"]), "OMP_NUM_THREADS"
+    return n, why
+
+
 def cpu_baseline(seconds_budget: float = 15.0):
     """The CPU oracle (C restatement, `kind: port`) on the host cores: bounded sample of the same workload (16384 envs, so
     that every thread of a 256-thread host has 64 envs per step)."""
@@ -46,7 +64,12 @@ def cpu_baseline(seconds_budget: float = 15.0):
     from isaacgymdyros_amd.task_constants import load_task_constants
     from oracle.oracle import OracleSim
     N = 16384
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    threads, why = effective_cpus()
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except Exception:
+        pass
     sim = OracleSim(N, task_const=load_task_constants(), torch_gpu_div=1)
     sim.buf["dof_state"][:, :, 0] = load_task_constants()["initial_dof_pos"]
     rng = np.random.default_rng(42)
@@ -59,7 +82,7 @@ def cpu_baseline(seconds_budget: float = 15.0):
         sim.step(acts[k % 8], None, 3 + k)
         k += 1
     dt = time.perf_counter() - t0
-    out = {"value": N * k / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    out = {"value": N * k / dt, "unit": "env-steps/s", "cores": threads, "cores_from": why, "kind": "port",
            "sample": "%d envs x %d steps of the C oracle (oracle/dw_oracle.c, OpenMP over envs), %.1f s" % (N, k, dt)}
     # the same code on ONE core (SURVEY 8d asks for both ends), a 5 s sample of 128 envs
     try:
