@@ -277,6 +277,9 @@ def test_obs_reward_vs_torch_twin_on_gpu(task_const, model):
     mean, var = env.obs_mean, env.obs_var
     nf = env.non_feet_idxs
     exact = total = 0
+    # per output column: bit-identical count (37 observation entries, 14 reward terms, the total), for the attribution below
+    col_exact = {"obs": torch.zeros(37, device="cuda"), "terms": torch.zeros(14, device="cuda"), "total": torch.zeros(1, device="cuda")}
+    col_n = 0
     for t in range(int(g["steps"])):
         be.write_state(g["inj_root"][t], g["inj_dof"][t], g["inj_cf"][t])
         pre = {k: getattr(env, k).clone() for k in ("actions_pre", "pre_joint_velocity_states", "foot_force_pre")}
@@ -296,8 +299,35 @@ def test_obs_reward_vs_torch_twin_on_gpu(task_const, model):
             assert bool((err <= 2e-6 + 4e-6 * a.abs()).all()), (t, float(err.max()))
             exact += int((a == b).sum())
             total += a.numel()
+        col_exact["obs"] += (obs_t == got_obs).float().sum(0)
+        col_exact["terms"] += (st == env._buf["stacked_rewards"][:, :14]).float().sum(0)
+        col_exact["total"] += (tot == env.rew_buf).float().sum()
+        col_n += N
+    frac = {k: (v / col_n).cpu().numpy() for k, v in col_exact.items()}
     print("bit-identical outputs HIP vs torch-GPU twin: %.2f %%" % (100.0 * exact / total))
-    assert exact / total > 0.5
+    names = ["euler x", "euler y", "euler z"] + ["qpos %d" % i for i in range(12)] + ["qvel %d" % i for i in range(12)] + \
+            ["sin phase", "cos phase", "target vx", "target vy"] + ["root vel %d" % i for i in range(6)]
+    low = [(n, round(float(f), 4)) for n, f in zip(names, frac["obs"]) if f < 1.0]
+    print("observation entries below 100 %:", low)
+    print("reward terms:", [(n, round(float(f), 4)) for n, f in zip(env.extras["reward_names"][:14], frac["terms"])], "total", float(frac["total"][0]))
+    # ATTRIBUTION, measured on the MI355X:
+    #  * all 37 observation entries are bit-identical to torch-ROCm's eager result -- Euler angles (atan2), gait phase (sincos),
+    #    normalisation included;
+    #  * exp is not a source of difference: OCML expf as hipcc links it equals torch.exp on 100 % of 3 M arguments
+    #    (tools/probe_exp.py); the reward terms without a norm upstream -- thresholds, the force-reference term, the contact
+    #    penalty, qacc (its exp underflows) -- are bit-identical;
+    #  * what differs, in the last bit, are the terms downstream of torch.norm over 33 / 12 / 3 / 2 elements (qpos 76 %,
+    #    qvel 85 %, torque 77 %, torque-diff 78 %, contact-force-diff 87 %, body velocity 95 %, orientation 96 % identical): the
+    #    GPU reduction sums a row in an order that depends on the row's alignment in memory (tools/probe_gpu_norm*.py), so there
+    #    is no fixed order to reproduce; the kernels keep torch's CPU order, which the reference goldens pin bit for bit.
+    assert float(frac["obs"].min()) == 1.0, low
+    names_r = list(env.extras["reward_names"][:14])
+    exact_terms = ["contact_force_penalty", "qacc_regulation", "foot_contact_reward", "double_support_force_diff_regulation",
+                   "force_thres_penalty", "force_diff_thres_penalty", "force_ref_reward"]
+    for n_, f_ in zip(names_r, frac["terms"]):
+        assert f_ == 1.0 if n_ in exact_terms else f_ > {"mimic_body_orientation_reward": 0.93, "body_vel_reward": 0.92,
+                                                         "contact_force_diff_regulation": 0.82, "qvel_regulation": 0.80}.get(n_, 0.70), (n_, f_)
+    assert exact / total > 0.97
 
 
 def g_target_vel(env, g, t):
