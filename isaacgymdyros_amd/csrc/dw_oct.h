@@ -31,7 +31,10 @@ using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEO
 
 constexpr int LPE = 8;               // lanes per env
 constexpr int EPO = 64 / LPE;        // envs per wavefront
-constexpr int WPG = 2;               // wavefronts per workgroup (they share the hot tables, nothing else)
+#if !defined(OCT_WPG)
+#define OCT_WPG 2
+#endif
+constexpr int WPG = OCT_WPG;         // wavefronts per workgroup (they share the hot tables, nothing else)
 constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 1;      // per lane: PhysParams::sc_park
 
 // One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env as in dw_quad.h.  A row is 8 envs x 16 B
@@ -42,7 +45,7 @@ struct alignas(16) OLds {
     OSlots w[WPG];
     QHot   hot;
 };
-static_assert(sizeof(OLds) <= 40960, "OLds: 4 workgroups (8 waves) per CU must fit 160 KB of LDS");
+static_assert(sizeof(OLds) * (8 / WPG) <= 163840, "OLds: 8 waves per CU must fit 160 KB of LDS");
 // (as byte offsets: even rows of a flipped limb lie one row up, odd rows one row down -- two lane-dependent bases, so that every
 //  access is base + a compile-time offset and the compiler need not keep one address register per body and row)
 // A body's slot is its CELL: cellbase[owner lane] + outward step (dw_quad_model.h), so a limb's bodies lie in schedule order and

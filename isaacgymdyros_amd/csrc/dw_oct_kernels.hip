@@ -12,7 +12,7 @@
 // 8 waves per CU, TWO per SIMD, so a wave may use 256 registers (VGPRs + AGPRs; the register file is unified on gfx950).
 // (DwBuffers travels BY VALUE: see dw_quad_kernels.hip.)
 template <bool TERRAIN>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
                    const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dwo::OLds L;
@@ -25,7 +25,7 @@ void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::De
 }
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dw_k_simulate_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *tau,
                        const float *push) {
     __shared__ dwo::OLds L;

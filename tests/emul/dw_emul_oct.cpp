@@ -30,12 +30,12 @@ void wave_body(void *p, int) {
     DwHandle *h = w->h;
     switch (w->kind) {
     case 0:
-        if (h->cfg.terrain) dwo::oct_simulate<true>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
-        else dwo::oct_simulate<false>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
+        if (h->cfg.terrain) dwo::oct_simulate<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
+        else dwo::oct_simulate<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
         break;
     case 1:
-        if (h->cfg.terrain) dwo::oct_step<true>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else dwo::oct_step<false>(w->lds->w[w->wave & 1], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        if (h->cfg.terrain) dwo::oct_step<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else dwo::oct_step<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
         break;
     }
 }
@@ -46,7 +46,7 @@ int run_waves(DwHandle *h, int kind, const float *a0, const float *a1, long long
     dwo::OLds *lds = (dwo::OLds *)aligned_alloc(64, (sizeof(dwo::OLds) + 63) / 64 * 64);
     int rc = DW_OK;
     for (int w = 0; w < nw && rc == DW_OK; ++w) {
-        if ((w & 1) == 0) memset(lds, 0xff, sizeof(*lds));           // NaN-fill per workgroup: a read of a never-written slot poisons the result
+        if ((w % dwo::WPG) == 0) memset(lds, 0xff, sizeof(*lds));           // NaN-fill per workgroup: a read of a never-written slot poisons the result
         WaveArgs a{h, a0, a1, step, w, kind, lds, nullptr};
         if (!dwq::run_wave(wave_body, &a)) rc = fail(DW_ESTATE, "octet emulation: lanes disagree on the number of cross-lane operations");
     }
