@@ -211,6 +211,7 @@ typedef struct DwConfig {
 #define DW_NZ_TERRAIN_LVL 173 /* [1] randint_like for robots that solved the last level (:689) */
 #define DW_NZ_ROOT_JITTER 174 /* [2] spawn jitter on terrain (:732)                            */
 #define DW_NOISE_WORDS 176
+#define DW_NZ_UBLOCK 0x10000 /* generated (not injected) uniform words: Philox counter word of the block holding words 4b..4b+3 is DW_NZ_UBLOCK + b */
 
 /* Per-env task-state record: DW_ES_WORDS 32-bit words, 16-byte aligned, one contiguous row per env
  * so a wavefront moves it with dwordx4 loads.  Offsets in words; `i:` marks int32 fields. */

@@ -13,7 +13,7 @@
 // (DwBuffers travels BY VALUE: see dw_quad_kernels.hip.)
 template <bool TERRAIN>
 __global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
+void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwBuffers B, const float *mocap,
                    const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dwo::OLds L;
     if (step_dev) step = *step_dev;          // (dw_step_dev: the counter lives in device memory so that a captured launch can be replayed)
@@ -26,7 +26,7 @@ void dw_k_step_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::De
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN>
 __global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void dw_k_simulate_oct(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *tau,
+void dw_k_simulate_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwBuffers B, const float *tau,
                        const float *push) {
     __shared__ dwo::OLds L;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

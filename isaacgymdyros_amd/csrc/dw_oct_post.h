@@ -16,6 +16,15 @@
 
 namespace dwo {
 
+#if defined(DQ_WAVE_TIME) && defined(__HIPCC__)      // (timing experiment, tools/wave_times.py: the post phases of EVERY wave, left in the reward rows of its second env)
+#define DQ_WT_DECL long long dq_wt[14]; int dq_wn = 0
+#define DQ_WT() dq_wt[dq_wn++] = (long long)__builtin_readcyclecounter()
+#define DQ_WT_FLUSH(B, wave_index) do { if (lane == 0) for (int i_ = 1; i_ < dq_wn; ++i_) (B).stacked_rewards[((size_t)(wave_index) * EPO + 1) * DW_NUM_REW + i_] = (float)(dq_wt[i_] - dq_wt[i_ - 1]); } while (0)
+#else
+#define DQ_WT_DECL do { } while (0)
+#define DQ_WT() do { } while (0)
+#define DQ_WT_FLUSH(B, wave_index) do { } while (0)
+#endif
 
 using dw::TaskParams;
 
@@ -28,7 +37,8 @@ constexpr int PL_NORMED = PL_ROOT + EPO * 13 + 16;       // [8][37] normalised o
 constexpr int PL_PS = PL_NORMED + EPO * DW_NUM_OBS1;     // [8][32] per-env scratch
 constexpr int PL_OBN = PL_PS + EPO * 32;                 // [2][37] observation mean, divisor (the hot tables belong to both waves of the workgroup)
 static_assert((PL_Q * 4) % 16 == 0, "post layout: the record block must end on a 16-byte boundary");
-static_assert(PL_OBN + 2 * DW_NUM_OBS1 <= NB * 4 * EPO * 4, "post layout does not fit the slot area");
+constexpr int PL_RC = PL_OBN + 2 * DW_NUM_OBS1;          // [33][2] per-joint constants of the reset: initial angle, the same clamped to the joint range
+static_assert(PL_RC + 2 * ND <= NB * 4 * EPO * 4, "post layout does not fit the slot area");
 // per-env scratch words
 constexpr int PS_RTERM = 0;      // [16] reward terms, [14] = |orientation error|
 constexpr int PS_BAD = 16, PS_COLL = 17, PS_RESET = 18, PS_PROGRESS = 19, PS_RANDOMIZE = 20, PS_MASS = 21;
@@ -80,6 +90,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
                           const float *noise, long long step, int wave_index, OLane &X, const float (&qv)[ONI], const float (&qdv)[ONI],
                           const StepKeep &KP) {
     float *LF = reinterpret_cast<float *>(&L.slot[0][0]);
+    DQ_WT_DECL; DQ_WT();
     // (the lane id again, opaque to the optimiser: index arithmetic shared with the pre-physics phase would otherwise be kept in
     //  registers across the two substeps)
     int lane = X.lane;
@@ -102,7 +113,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const long long q1_progress = B.progress_buf[e], q1_randomize = B.randomize_buf[e];
     const float q1_mass = B.total_mass[e], q1_clock = dw::clamp_action(actions, e, 12);
     const int lj = lane < ND ? lane : 0, lo1 = lane < DW_NUM_OBS1 ? lane : 0;
-    const float c_qinit = M.q_init[lj], c_qhi = M.qhi[lj], c_qlo = M.qlo[lj], c_damp = M.damp_nom[lj], c_arm = M.arm_nom[lj];
+    const float c_qinit = M.q_init[lj], c_qhi = M.qhi[lj], c_qlo = M.qlo[lj];
     const float c_org0 = B.env_origins[3 * e], c_org1 = B.env_origins[3 * e + 1], c_org2 = B.env_origins[3 * e + 2];
     float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
     const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
@@ -140,6 +151,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
     }
     if (lane < DW_NUM_OBS1) { OBN[lane] = c_om; OBN[DW_NUM_OBS1 + lane] = c_od; }
+    if (lane < ND) { LF[PL_RC + 2 * lane] = c_qinit; LF[PL_RC + 2 * lane + 1] = fmaxf(fminf(c_qinit, c_qhi), c_qlo); }
     wave_sync();
     // ---- the record fields this step has produced so far (dw_task.h P1..P3), from the lanes that hold them ----
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
@@ -341,7 +353,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
     wave_sync();
 
-    DQ_STAMP(B, 45);
+    DQ_STAMP(B, 45); DQ_WT();
     // ---- reset_idx for the envs that ended (dw_task.h reset_region) ----
     const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
     if (any_reset) {
@@ -366,50 +378,86 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             if (xvalid) B.terrain_levels[e] = lvl;
         }
         wave_sync();
-        // one pass per env that ended (a wave-uniform loop over the ballot: resets are rare, and a pass over all 16 x 33
-        // items with most lanes idle cost nine times as much): lane = joint
-        for (unsigned long long rbits = wave_ballot(j == 0 && mine); rbits != 0ull; rbits &= rbits - 1ull) {
-            const int ee = __builtin_ctzll(rbits) >> 3, l = lane < ND ? lane : 0;
-            const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
-            if (lane < ND) {
-                dw::NoiseSrc nz = K.nz;
-                nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
-                const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(ee, PS_RANDOMIZE) >= 1;
-                if (do_dr && C.dr_dof) {
-                    const float ud = dw::noise_word(nz, DW_NZ_DR_DAMP + l), ua = dw::noise_word(nz, DW_NZ_DR_ARM + l);
-                    const float sd = C.dr_damp[0] + ud * (C.dr_damp[1] - C.dr_damp[0]);
-                    const float sa = C.dr_arm[0] + ua * (C.dr_arm[1] - C.dr_arm[0]);
-                    if (egr < N) { B.dof_damping[(size_t)ND * eg + l] = c_damp + sd; B.dof_armature[(size_t)ND * eg + l] = c_arm * sa; }
-                }
-                PQ_ES(ee, DW_ES_QPOS_NOISE + l) = c_qinit;
-                PQ_ES(ee, DW_ES_QPOS_PRE + l) = c_qinit;
-                PQ_ES(ee, DW_ES_QVEL_NOISE + l) = 0.0f;
-                PQ_ES(ee, DW_ES_PRE_QVEL + l) = 0.0f;
-                PQ_Q(ee, l) = fmaxf(fminf(c_qinit, c_qhi), c_qlo);
-                PQ_QD(ee, l) = 0.0f;
-                if (l < 12) {
-                    PQ_ES(ee, DW_ES_QPOS_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QPOS_BIAS + l) * 6.28f, 100.0) - (float)(3.14 / 100);
-                    PQ_ES(ee, DW_ES_MOTOR_SCALE + l) = dw::noise_word(nz, DW_NZ_MOTOR + l) * 0.4f + 0.8f;
-                    PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = 0.0f;
-                }
-                if (l < 3) PQ_ES(ee, DW_ES_QUAT_BIAS + l) = dw::divs(C.gpu_div, dw::noise_word(nz, DW_NZ_QUAT_BIAS + l) * 6.28f, 150.0) - (float)(3.14 / 150);
-                if (l < 24) PQ_ES(ee, DW_ES_WARM + l) = 0.0f;
-                if (l < 6) PQ_ES(ee, DW_ES_FOOT_FORCE_PRE + l) = PQ_PS(ee, PS_FOOT + l);
-                if (l >= 16 && l < 29) {
-                    const int ii = l - 16;
-                    float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
-                    if (ii < 3) v += PQ_PS(ee, PS_ORG + ii);          // (the env's origin; the curriculum has put the new one there)
-                    if (ii < 2 && C.custom_origins) v += 2.0f * dw::noise_word(nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
-                    PQ_ROOT(ee, ii) = v;
+        // ALL envs that ended at once, each on its own eight lanes (a pass per ended env made the launch wait for the waves
+        // with several: tools/wave_times.py).  The 32 uniform words DW_NZ_QPOS_BIAS .. DW_NZ_PTIMING of an env are eight
+        // generator blocks: one per lane, each word transformed and stored by the lane that drew it.
+        static_assert(DW_NZ_QPOS_BIAS % 4 == 0 && DW_NZ_PTIMING < DW_NZ_QPOS_BIAS + 32, "reset words: eight blocks per env");
+        const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
+        DQ_WT();
+        if (mine) {
+            float u[4];
+            dw::noise_block(K.nz, DW_NZ_QPOS_BIAS / 4 + j, u);
+            DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                const int w = DW_NZ_QPOS_BIAS + 4 * j + i;
+                if (w < DW_NZ_QUAT_BIAS) PQ_ES(el, DW_ES_QPOS_BIAS + (w - DW_NZ_QPOS_BIAS)) = dw::divs(C.gpu_div, u[i] * 6.28f, 100.0) - (float)(3.14 / 100);
+                else if (w < DW_NZ_TARGET_VEL) PQ_ES(el, DW_ES_QUAT_BIAS + (w - DW_NZ_QUAT_BIAS)) = dw::divs(C.gpu_div, u[i] * 6.28f, 150.0) - (float)(3.14 / 150);
+                else if (w == DW_NZ_TARGET_VEL) {
+                    const float vel_mag = u[i] * 0.8f;
+                    PQ_ES(el, DW_ES_TARGET_VEL) = vel_mag * 1.0f;
+                    PQ_ES(el, DW_ES_TARGET_VEL + 1) = vel_mag * 0.0f;
+                } else if (w == DW_NZ_INIT_MOCAP) PQ_ESI(el, DW_ES_INIT_MOCAP) = u[i] > 0.5f ? 0 : 1800;
+                else if (w < DW_NZ_DELAY) PQ_ES(el, DW_ES_MOTOR_SCALE + (w - DW_NZ_MOTOR)) = u[i] * 0.4f + 0.8f;
+                else if (w == DW_NZ_DELAY) {
+                    int k = (int)(u[i] * 4.0f);
+                    if (k > 3) k = 3;
+                    PQ_ESI(el, DW_ES_DELAY_IDX) = 2 + k;
+                } else if (w == DW_NZ_PTIMING) {
+                    int kt = (int)(u[i] * 2000.0f);
+                    if (kt > 1999) kt = 1999;
+                    PQ_ESI(el, DW_ES_PERT_TIMING) = kt;
                 }
             }
-            // torque FIFO and action ring, zeroed
-            for (int i = lane; i < DW_ALOG_SLOTS * 12; i += 64) PQ_ES(ee, DW_ES_ACTION_LOG + i) = 0.0f;
-            if (egr < N) { for (int i = lane; i < DW_HIST_SLOTS * DW_NUM_ACT; i += 64) B.action_history[(size_t)eg * DW_HIST_SLOTS * DW_NUM_ACT + i] = 0.0f; }
         }
+        DQ_WT();
+        if (wave_any(mine && do_dr && C.dr_dof)) {
+            // dof-property randomisation (vec_task.py:519-733): rare -- the randomisation interval has passed for this env
+            DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+                const int l = j + 8 * k, lc = l < ND ? l : 0;
+                if (mine && do_dr && l < ND) {
+                    const float ud = dw::noise_word(K.nz, DW_NZ_DR_DAMP + lc), ua = dw::noise_word(K.nz, DW_NZ_DR_ARM + lc);
+                    const float sd = C.dr_damp[0] + ud * (C.dr_damp[1] - C.dr_damp[0]);
+                    const float sa = C.dr_arm[0] + ua * (C.dr_arm[1] - C.dr_arm[0]);
+                    if (xvalid) { B.dof_damping[(size_t)ND * e + l] = M.damp_nom[l] + sd; B.dof_armature[(size_t)ND * e + l] = M.arm_nom[l] * sa; }
+                }
+            }
+        }
+        DQ_WT();
+        if (mine) {
+            DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+                const int l = j + 8 * k;
+                if (l < ND) {
+                    const float qi = LF[PL_RC + 2 * l];
+                    PQ_ES(el, DW_ES_QPOS_NOISE + l) = qi;
+                    PQ_ES(el, DW_ES_QPOS_PRE + l) = qi;
+                    PQ_ES(el, DW_ES_QVEL_NOISE + l) = 0.0f;
+                    PQ_ES(el, DW_ES_PRE_QVEL + l) = 0.0f;
+                    PQ_Q(el, l) = LF[PL_RC + 2 * l + 1];
+                    PQ_QD(el, l) = 0.0f;
+                    if (l < 12) PQ_ES(el, DW_ES_ACTION_TORQUE_PRE + l) = 0.0f;
+                    if (l < 24) PQ_ES(el, DW_ES_WARM + l) = 0.0f;
+                    if (l < 6) PQ_ES(el, DW_ES_FOOT_FORCE_PRE + l) = PQ_PS(el, PS_FOOT + l);
+                    if (l >= 16 && l < 29) {
+                        const int ii = l - 16;
+                        float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
+                        if (ii < 3) v += PQ_PS(el, PS_ORG + ii);          // (the env's origin; the curriculum has put the new one there)
+                        if (ii < 2 && C.custom_origins) v += 2.0f * dw::noise_word(K.nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
+                        PQ_ROOT(el, ii) = v;
+                    }
+                }
+            }
+        DQ_WT();
+            // torque FIFO and action ring, zeroed
+            static_assert((DW_HIST_SLOTS * DW_NUM_ACT) % 4 == 0, "action ring of an env: whole 16-byte pieces");
+            constexpr int NAL = DW_ALOG_SLOTS * 12, NAH = DW_HIST_SLOTS * DW_NUM_ACT / 4;
+            DQ_UNROLL for (int i = 0; i < (NAL + 7) / 8; ++i) { if (j + 8 * i < NAL) PQ_ES(el, DW_ES_ACTION_LOG + j + 8 * i) = 0.0f; }
+            if (xvalid) {
+                F4 *ah = reinterpret_cast<F4 *>(B.action_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_ACT);
+                DQ_UNROLL for (int i = 0; i < (NAH + 7) / 8; ++i) { if (j + 8 * i < NAH) ah[j + 8 * i] = mk4(0.0f, 0.0f, 0.0f, 0.0f); }
+            }
+        }
+        DQ_WT();
         // per-env scalars (dw_task.h reset_region, lane 40)
         if (j == 0 && mine) {
-            const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
             if (do_dr) {
                 if (C.dr_friction && xvalid) {
                     const float uf = dw::noise_word(K.nz, DW_NZ_DR_FRIC);
@@ -417,15 +465,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
                 }
                 if (xvalid) B.randomize_buf[e] = 0;
             }
-            const float vel_mag = dw::noise_word(K.nz, DW_NZ_TARGET_VEL) * 0.8f;
-            PQ_ES(el, DW_ES_TARGET_VEL) = vel_mag * 1.0f;
-            PQ_ES(el, DW_ES_TARGET_VEL + 1) = vel_mag * 0.0f;
-            PQ_ESI(el, DW_ES_INIT_MOCAP) = dw::noise_word(K.nz, DW_NZ_INIT_MOCAP) > 0.5f ? 0 : 1800;
             PQ_ES(el, DW_ES_TIME) = 0.0f;
             if (xvalid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
-            int k = (int)(dw::noise_word(K.nz, DW_NZ_DELAY) * 4.0f);
-            if (k > 3) k = 3;
-            PQ_ESI(el, DW_ES_DELAY_IDX) = 2 + k;
             PQ_ES(el, DW_ES_CRM) = PQ_ES(el, DW_ES_CRS) / PQ_ES(el, DW_ES_EPI_LEN);
             PQ_ES(el, DW_ES_CRS) = 0.0f;
             PQ_ESI(el, DW_ES_SIMUL_LEN) = 0;
@@ -433,14 +474,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             PQ_ES(el, DW_ES_EPI_LEN) = 0.0f;
             PQ_ESI(el, DW_ES_PERT_COUNT) = 0;
             PQ_ESI(el, DW_ES_PERT_ON) = 0;
-            int kt = (int)(dw::noise_word(K.nz, DW_NZ_PTIMING) * 2000.0f);
-            if (kt > 1999) kt = 1999;
-            PQ_ESI(el, DW_ES_PERT_TIMING) = kt;
         }
         wave_sync();
     }
 
-    DQ_STAMP(B, 46);
+    DQ_STAMP(B, 46); DQ_WT();
     // ---- Q5, first half: request the history taps now, use them after Q4 (one memory latency, spent computing the new
     //      observation).  A lane takes ROWS (env, tap): 37 observation words and 13 action words, consecutive in the rings and
     //      in obs_buf, so a row is 10 + 4 requests with constant offsets and no per-word index arithmetic.  The newest
@@ -524,7 +562,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
     wave_sync();
 
-    DQ_STAMP(B, 47);
+    DQ_STAMP(B, 47); DQ_WT();
     // ---- Q5, second half: the 487-d observation buffer.  Rows requested above go out as they came (an env that was just
     //      reset shows its first observation in every tap and zeros in the action taps, tasks/dyros_dynamic_walk.py:655-669);
     //      the newest tap is copied from LDS, items (env, word). ----
@@ -558,7 +596,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
     }
 
-    DQ_STAMP(B, 48);
+    DQ_STAMP(B, 48); DQ_WT();
     // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
@@ -587,7 +625,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
     wave_sync();
 
-    DQ_STAMP(B, 49);
+    DQ_STAMP(B, 49); DQ_WT();
     // ---- write back: the records (contiguous), and the Gym state of the envs whose state the task changed ----
     {
         constexpr int NP = EPO * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
@@ -611,7 +649,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             }
         }
     }
-    DQ_STAMP(B, 50);
+    DQ_STAMP(B, 50); DQ_WT();
+    DQ_WT_FLUSH(B, wave_index);
 }
 
 #undef PQ_LF

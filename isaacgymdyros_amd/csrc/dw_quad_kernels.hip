@@ -14,7 +14,7 @@
 //  counted on the LDS counter as well, so that each wait for an LDS read also waited for all global requests in flight.)
 template <bool TERRAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *mocap,
+void dw_k_step_quad(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwBuffers B, const float *mocap,
                     const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dwq::QLds L;
     if (step_dev) step = *step_dev;
@@ -30,7 +30,7 @@ void dw_k_step_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::D
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void dw_k_simulate_quad(const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers B, const float *tau,
+void dw_k_simulate_quad(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwBuffers B, const float *tau,
                         const float *push) {
     __shared__ dwq::QLds L;
     dwq::quad_simulate<TERRAIN>(L, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, B, tau, push, (int)blockIdx.x);

@@ -103,15 +103,27 @@ DW_HD float enc_normal(unsigned int a, unsigned int b) {
 #endif
     return z * (float)(0.00016 / 3.0);
 }
+// Uniform words 4b .. 4b+3 (b >= DW_NZ_VEL / 4) in one generator call: counter word DW_NZ_UBLOCK + b (oracle/dw_task.c noise_word)
+DW_HD void noise_block(const NoiseSrc &nz, int b, float (&u)[4]) {
+    if (nz.rec) { for (int i = 0; i < 4; ++i) u[i] = nz.rec[4 * b + i]; return; }
+    unsigned int c[4] = {(unsigned int)(DW_NZ_UBLOCK + b), nz.env, (unsigned int)nz.step, (unsigned int)(nz.step >> 32) | (nz.stream << 31)};
+    philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));
+    for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * 5.9604644775390625e-08f;
+}
 DW_HD float noise_word(const NoiseSrc &nz, int w) {
     if (nz.rec) return nz.rec[w];
+    if (w >= DW_NZ_VEL) {
+        unsigned int c[4] = {(unsigned int)(DW_NZ_UBLOCK + (w >> 2)), nz.env, (unsigned int)nz.step, (unsigned int)(nz.step >> 32) | (nz.stream << 31)};
+        philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));
+        const unsigned int lo = (w & 1) ? c[1] : c[0], hi = (w & 1) ? c[3] : c[2];
+        return (float)(((w & 2) ? hi : lo) >> 8) * 5.9604644775390625e-08f;
+    }
     // the two encoder draws of a joint (one per substep) share one Philox block: outputs 0,1 and 2,3
-    const int pair = (w < DW_NZ_VEL && w >= DW_NZ_ENC + DW_NUM_DOF) ? 1 : 0;
+    const int pair = w >= DW_NZ_ENC + DW_NUM_DOF ? 1 : 0;
     unsigned int c[4] = {(unsigned int)(pair ? w - DW_NUM_DOF : w), nz.env, (unsigned int)nz.step,
                          (unsigned int)(nz.step >> 32) | (nz.stream << 31)};
     philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));
-    if (w < DW_NZ_VEL) return pair ? enc_normal(c[2], c[3]) : enc_normal(c[0], c[1]);
-    return (float)(c[0] >> 8) * 5.9604644775390625e-08f;
+    return pair ? enc_normal(c[2], c[3]) : enc_normal(c[0], c[1]);
 }
 // both encoder draws of joint d in one generator call (the quad kernels keep the second for the second substep)
 DW_HD void noise_enc_pair(const NoiseSrc &nz, int d, float *z0, float *z1) {

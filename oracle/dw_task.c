@@ -18,7 +18,7 @@
  *
  * All randomness is an INPUT: word w of the env's noise record (layout DW_NZ_* in dyros_walk.h) comes
  * from the `noise` argument or, when that is NULL, from Philox4x32-10 keyed by cfg.seed with counter
- * (w, env, step_lo, step_hi | stream<<31).
+ * (w, env, step_lo, step_hi | stream<<31) for the encoder words and (DW_NZ_UBLOCK + w/4, ...) for the uniform words.
  */
 #include "dw_oracle.h"
 
@@ -52,7 +52,9 @@ static float noise_word(const Noise *nz, int w) {
     /* The two encoder draws of a joint (one per substep) share ONE Philox block: counter word = the joint's word of the
      * first substep, outputs 0,1 for the first substep and 2,3 for the second (half the generator calls of the hot path). */
     const int pair = (w < DW_NZ_VEL && w >= DW_NZ_ENC + DW_NUM_DOF) ? 1 : 0;
-    const int cw = pair ? w - DW_NUM_DOF : w;
+    /* The uniform words (w >= DW_NZ_VEL) come four to a block: counter word = DW_NZ_UBLOCK + w / 4, output w % 4 (a reset
+     * draws its 32 words DW_NZ_QPOS_BIAS .. DW_NZ_PTIMING from eight blocks). */
+    const int cw = w >= DW_NZ_VEL ? DW_NZ_UBLOCK + (w >> 2) : (pair ? w - DW_NUM_DOF : w);
     uint32_t c[4] = {(uint32_t)cw, nz->env, (uint32_t)nz->step, (uint32_t)(nz->step >> 32) | (nz->stream << 31)};
     philox4x32_10(c, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32));
     if (w < DW_NZ_VEL) {   /* encoder noise ~ N(0, 0.00016/3): Box-Muller */
@@ -61,7 +63,7 @@ static float noise_word(const Noise *nz, int w) {
         float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
         return z * (float)(0.00016 / 3.0);
     }
-    return (float)(c[0] >> 8) * 5.9604644775390625e-08f;                  /* U[0,1) */
+    return (float)(c[w & 3] >> 8) * 5.9604644775390625e-08f;              /* U[0,1) */
 }
 
 /* ------------------------------------------------------------------ torch-flavoured scalar helpers */
