@@ -358,7 +358,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
     if (any_reset) {
         const bool mine = PQ_PSI(el, PS_RESET) != 0;
-        if (C.terrain_curriculum && j == 0 && mine) {
+        if (
+#if defined(OCT_X_NO_TERR)
+            false &&
+#endif
+            C.terrain_curriculum && j == 0 && mine) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
             const float distance = dw::norm_t(d, 2);
             const bool move_up = distance > C.terrain_half_length;
@@ -384,68 +388,95 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         static_assert(DW_NZ_QPOS_BIAS % 4 == 0 && DW_NZ_PTIMING < DW_NZ_QPOS_BIAS + 32, "reset words: eight blocks per env");
         const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
         DQ_WT();
+        // (branch-free: a lane-dependent branch per word made a chain of short blocks, each with its own waits; a store that does
+        //  not apply goes to the env's spare scratch word)
+        const int dummy = PL_PS + el * 32 + 31;
+        int *LI = reinterpret_cast<int *>(LF);
         if (mine) {
             float u[4];
             dw::noise_block(K.nz, DW_NZ_QPOS_BIAS / 4 + j, u);
+            const bool gd = C.gpu_div != 0;
+            const int esb = PL_ES + el * PL_ES_STRIDE;
             DQ_UNROLL for (int i = 0; i < 4; ++i) {
                 const int w = DW_NZ_QPOS_BIAS + 4 * j + i;
-                if (w < DW_NZ_QUAT_BIAS) PQ_ES(el, DW_ES_QPOS_BIAS + (w - DW_NZ_QPOS_BIAS)) = dw::divs(C.gpu_div, u[i] * 6.28f, 100.0) - (float)(3.14 / 100);
-                else if (w < DW_NZ_TARGET_VEL) PQ_ES(el, DW_ES_QUAT_BIAS + (w - DW_NZ_QUAT_BIAS)) = dw::divs(C.gpu_div, u[i] * 6.28f, 150.0) - (float)(3.14 / 150);
-                else if (w == DW_NZ_TARGET_VEL) {
-                    const float vel_mag = u[i] * 0.8f;
-                    PQ_ES(el, DW_ES_TARGET_VEL) = vel_mag * 1.0f;
-                    PQ_ES(el, DW_ES_TARGET_VEL + 1) = vel_mag * 0.0f;
-                } else if (w == DW_NZ_INIT_MOCAP) PQ_ESI(el, DW_ES_INIT_MOCAP) = u[i] > 0.5f ? 0 : 1800;
-                else if (w < DW_NZ_DELAY) PQ_ES(el, DW_ES_MOTOR_SCALE + (w - DW_NZ_MOTOR)) = u[i] * 0.4f + 0.8f;
-                else if (w == DW_NZ_DELAY) {
-                    int k = (int)(u[i] * 4.0f);
-                    if (k > 3) k = 3;
-                    PQ_ESI(el, DW_ES_DELAY_IDX) = 2 + k;
-                } else if (w == DW_NZ_PTIMING) {
-                    int kt = (int)(u[i] * 2000.0f);
-                    if (kt > 1999) kt = 1999;
-                    PQ_ESI(el, DW_ES_PERT_TIMING) = kt;
-                }
+                const bool isq = w < DW_NZ_QUAT_BIAS, isb = !isq && w < DW_NZ_TARGET_VEL, ist = w == DW_NZ_TARGET_VEL;
+                const bool ism = w >= DW_NZ_MOTOR && w < DW_NZ_DELAY;
+                const float x = u[i] * (w < DW_NZ_TARGET_VEL ? 6.28f : (ist ? 0.8f : 0.4f));
+                // divs(gpu_div, x, 100.0 | 150.0) - (float)(3.14 / 100 | 150)
+                const float dv = isq ? 100.0f : 150.0f, rv = isq ? (float)(1.0 / 100.0) : (float)(1.0 / 150.0);
+                const float cv = isq ? (float)(3.14 / 100) : (float)(3.14 / 150);
+                const float yd = (gd ? x * rv : x / dv) - cv;
+                const float y = (isq || isb) ? yd : (ist ? x * 1.0f : x + 0.8f);
+                int k4 = (int)(u[i] * 4.0f), kt = (int)(u[i] * 2000.0f);
+                k4 = k4 > 3 ? 3 : k4; kt = kt > 1999 ? 1999 : kt;
+                const int bits = w == DW_NZ_INIT_MOCAP ? (u[i] > 0.5f ? 0 : 1800) : (w == DW_NZ_DELAY ? 2 + k4 : (w == DW_NZ_PTIMING ? kt : f2i(y)));
+                const int dst = isq ? DW_ES_QPOS_BIAS + (w - DW_NZ_QPOS_BIAS) : isb ? DW_ES_QUAT_BIAS + (w - DW_NZ_QUAT_BIAS)
+                              : ist ? DW_ES_TARGET_VEL : w == DW_NZ_INIT_MOCAP ? DW_ES_INIT_MOCAP : ism ? DW_ES_MOTOR_SCALE + (w - DW_NZ_MOTOR)
+                              : w == DW_NZ_DELAY ? DW_ES_DELAY_IDX : w == DW_NZ_PTIMING ? DW_ES_PERT_TIMING : -1;
+                LI[dst >= 0 ? esb + dst : dummy] = bits;
+                if (i == DW_NZ_TARGET_VEL % 4) LF[ist ? esb + DW_ES_TARGET_VEL + 1 : dummy] = x * 0.0f;
             }
         }
         DQ_WT();
-        if (wave_any(mine && do_dr && C.dr_dof)) {
-            // dof-property randomisation (vec_task.py:519-733): rare -- the randomisation interval has passed for this env
-            DQ_UNROLL for (int k = 0; k < ONI; ++k) {
-                const int l = j + 8 * k, lc = l < ND ? l : 0;
-                if (mine && do_dr && l < ND) {
-                    const float ud = dw::noise_word(K.nz, DW_NZ_DR_DAMP + lc), ua = dw::noise_word(K.nz, DW_NZ_DR_ARM + lc);
-                    const float sd = C.dr_damp[0] + ud * (C.dr_damp[1] - C.dr_damp[0]);
-                    const float sa = C.dr_arm[0] + ua * (C.dr_arm[1] - C.dr_arm[0]);
-                    if (xvalid) { B.dof_damping[(size_t)ND * e + l] = M.damp_nom[l] + sd; B.dof_armature[(size_t)ND * e + l] = M.arm_nom[l] * sa; }
+        if (wave_any(mine && do_dr)) {
+            // dof-property and friction randomisation (vec_task.py:519-733; `randomize` is on in the yaml, so every reset passes
+            // here): the 67 uniform words DW_NZ_DR_DAMP .. DW_NZ_DR_FRIC are 18 generator blocks, three per lane at most,
+            // and a word goes from the lane that drew it straight to its place
+            static_assert(DW_NZ_DR_ARM == DW_NZ_DR_DAMP + DW_NUM_DOF && DW_NZ_DR_FRIC == DW_NZ_DR_ARM + DW_NUM_DOF, "DR words are contiguous");
+            constexpr int B0 = DW_NZ_DR_DAMP / 4, NBLK = DW_NZ_DR_FRIC / 4 - B0 + 1, NPASS = (NBLK + 7) / 8;
+            float nom[NPASS][4], u[NPASS][4] = {};
+            const bool go = mine && do_dr;
+            DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) {
+                DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                    const int w = 4 * (B0 + j + 8 * p2) + i;
+                    const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
+                    const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
+                    nom[p2][i] = (isa ? M.arm_nom : M.damp_nom)[l];
+                }
+            }
+            if (go) { DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) dw::noise_block(K.nz, B0 + j + 8 * p2 < B0 + NBLK ? B0 + j + 8 * p2 : B0, u[p2]); }
+            const float d0 = C.dr_damp[0], d1 = C.dr_damp[1] - C.dr_damp[0], a0 = C.dr_arm[0], a1 = C.dr_arm[1] - C.dr_arm[0];
+            const float f0 = C.dr_fric[0], f1 = C.dr_fric[1] - C.dr_fric[0];
+            DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) {
+                DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                    const int w = 4 * (B0 + j + 8 * p2) + i;
+                    const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
+                    const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
+                    const float sd = d0 + u[p2][i] * d1, sa = a0 + u[p2][i] * a1;
+                    if (go && xvalid && C.dr_dof && (isd || isa)) (isa ? B.dof_armature : B.dof_damping)[(size_t)ND * e + l] = isa ? nom[p2][i] * sa : nom[p2][i] + sd;
+                    if (go && xvalid && C.dr_friction && w == DW_NZ_DR_FRIC) B.friction_scale[e] = f0 + u[p2][i] * f1;
                 }
             }
         }
         DQ_WT();
         if (mine) {
+            const int esb = PL_ES + el * PL_ES_STRIDE;
             DQ_UNROLL for (int k = 0; k < ONI; ++k) {
                 const int l = j + 8 * k;
-                if (l < ND) {
-                    const float qi = LF[PL_RC + 2 * l];
-                    PQ_ES(el, DW_ES_QPOS_NOISE + l) = qi;
-                    PQ_ES(el, DW_ES_QPOS_PRE + l) = qi;
-                    PQ_ES(el, DW_ES_QVEL_NOISE + l) = 0.0f;
-                    PQ_ES(el, DW_ES_PRE_QVEL + l) = 0.0f;
-                    PQ_Q(el, l) = LF[PL_RC + 2 * l + 1];
-                    PQ_QD(el, l) = 0.0f;
-                    if (l < 12) PQ_ES(el, DW_ES_ACTION_TORQUE_PRE + l) = 0.0f;
-                    if (l < 24) PQ_ES(el, DW_ES_WARM + l) = 0.0f;
-                    if (l < 6) PQ_ES(el, DW_ES_FOOT_FORCE_PRE + l) = PQ_PS(el, PS_FOOT + l);
-                    if (l >= 16 && l < 29) {
-                        const int ii = l - 16;
-                        float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
-                        if (ii < 3) v += PQ_PS(el, PS_ORG + ii);          // (the env's origin; the curriculum has put the new one there)
-                        if (ii < 2 && C.custom_origins) v += 2.0f * dw::noise_word(K.nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
-                        PQ_ROOT(el, ii) = v;
+                const bool lv = l < ND;
+                const int lc = lv ? l : 0;
+                const float qi = LF[PL_RC + 2 * lc], qc = LF[PL_RC + 2 * lc + 1];
+                LF[lv ? esb + DW_ES_QPOS_NOISE + l : dummy] = qi;
+                LF[lv ? esb + DW_ES_QPOS_PRE + l : dummy] = qi;
+                LF[lv ? esb + DW_ES_QVEL_NOISE + l : dummy] = 0.0f;
+                LF[lv ? esb + DW_ES_PRE_QVEL + l : dummy] = 0.0f;
+                LF[lv ? PL_Q + (el * ND + l) * 2 : dummy] = qc;
+                LF[lv ? PL_Q + (el * ND + l) * 2 + 1 : dummy] = 0.0f;
+                if (8 * k < 12) LF[l < 12 ? esb + DW_ES_ACTION_TORQUE_PRE + l : dummy] = 0.0f;
+                if (8 * k < 24) LF[l < 24 ? esb + DW_ES_WARM + l : dummy] = 0.0f;
+                if (8 * k < 6) { const int lf = l < 6 ? l : 0; const float ff = PQ_PS(el, PS_FOOT + lf); LF[l < 6 ? esb + DW_ES_FOOT_FORCE_PRE + l : dummy] = ff; }
+                if (8 * k + 7 >= 16 && 8 * k < 29) {
+                    const bool rv = l >= 16 && l < 29;
+                    const int ii = rv ? l - 16 : 0;
+                    float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
+                    v += ii < 3 ? PQ_PS(el, PS_ORG + (ii < 3 ? ii : 0)) : 0.0f;          // (the env's origin; the curriculum has put the new one there)
+                    if (8 * k <= 16 && 8 * k + 7 >= 16 && C.custom_origins) {
+                        const float jit = 2.0f * dw::noise_word(K.nz, DW_NZ_ROOT_JITTER + (ii < 2 ? ii : 0)) + (-1.0f);
+                        if (rv && ii < 2) v += jit;
                     }
+                    LF[rv ? PL_ROOT + el * 13 + ii : dummy] = v;
                 }
             }
-        DQ_WT();
             // torque FIFO and action ring, zeroed
             static_assert((DW_HIST_SLOTS * DW_NUM_ACT) % 4 == 0, "action ring of an env: whole 16-byte pieces");
             constexpr int NAL = DW_ALOG_SLOTS * 12, NAH = DW_HIST_SLOTS * DW_NUM_ACT / 4;
@@ -458,13 +489,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         DQ_WT();
         // per-env scalars (dw_task.h reset_region, lane 40)
         if (j == 0 && mine) {
-            if (do_dr) {
-                if (C.dr_friction && xvalid) {
-                    const float uf = dw::noise_word(K.nz, DW_NZ_DR_FRIC);
-                    B.friction_scale[e] = C.dr_fric[0] + uf * (C.dr_fric[1] - C.dr_fric[0]);
-                }
-                if (xvalid) B.randomize_buf[e] = 0;
-            }
+            if (do_dr && xvalid) B.randomize_buf[e] = 0;
             PQ_ES(el, DW_ES_TIME) = 0.0f;
             if (xvalid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
             PQ_ES(el, DW_ES_CRM) = PQ_ES(el, DW_ES_CRS) / PQ_ES(el, DW_ES_EPI_LEN);
