@@ -23,8 +23,9 @@ def resource_usage(src, extra):
         m = re.search(r"remark: Function Name: (\S+)", line)
         if m:
             name = m.group(1)
-            k = re.search(r"(dw_k_[a-z_]+?)ILb([01])E", name)
-            cur = ("%s<%s>" % (k.group(1), "true" if k.group(2) == "1" else "false")) if k else name
+            k = re.search(r"(dw_k_[a-z_]+?)ILb([01])E(?:Li(\d)E)?", name)
+            # (the octet kernels exist in two builds, dw_oct_kernels.hip: "<..>" is the two-waves-per-SIMD one, "<..,1>" the spread one)
+            cur = ("%s<%s%s>" % (k.group(1), "true" if k.group(2) == "1" else "false", ",1" if k.group(3) == "1" else "")) if k else name
             out[cur] = {}
             continue
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
@@ -54,6 +55,15 @@ def test_octet_kernels_fit_two_waves_per_simd_without_scratch(usage):
         assert r["Occupancy"] == 2, (k, r)
         assert r["VGPRs"] + r["AGPRs"] <= 256, (k, r)
         assert r["LDS Size"] <= 40960, (k, r)
+
+
+def test_spread_build_of_the_octet_kernels(usage):
+    """Launches with no more waves than SIMDs use the build declared for one wave per SIMD: the same code and LDS, and with the
+    whole register file to itself nothing may spill (the height-field step kernel takes AGPRs for what its two-wave build spills)."""
+    for k in ("dw_k_step_oct<false%s>", "dw_k_simulate_oct<false%s>", "dw_k_simulate_oct<true%s>", "dw_k_step_oct<true%s>"):
+        a, b = usage[k % ""], usage[k % ",1"]
+        assert b["Occupancy"] == 1 and b["ScratchSize"] == 0, (k, b)
+        assert b["LDS Size"] == a["LDS Size"] and b["VGPRs"] + b["AGPRs"] <= 512, (k, a, b)
 
 
 def test_terrain_step_kernel_scratch_is_bounded(usage):
