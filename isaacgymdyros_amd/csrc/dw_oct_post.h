@@ -117,6 +117,17 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const float c_org0 = B.env_origins[3 * e], c_org1 = B.env_origins[3 * e + 1], c_org2 = B.env_origins[3 * e + 2];
     float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
     const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
+    // (nominal damping / armature of the joints whose randomisation words this lane draws at a reset: requested here, with everything else)
+    constexpr int DR_B0 = DW_NZ_DR_DAMP / 4, DR_NBLK = DW_NZ_DR_FRIC / 4 - DR_B0 + 1, DR_NPASS = (DR_NBLK + 7) / 8;
+    float dr_nom[DR_NPASS][4];
+    DQ_UNROLL for (int p2 = 0; p2 < DR_NPASS; ++p2) {
+        DQ_UNROLL for (int i = 0; i < 4; ++i) {
+            const int w = 4 * (DR_B0 + j + 8 * p2) + i;
+            const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
+            const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
+            dr_nom[p2][i] = (isa ? M.arm_nom : M.damp_nom)[l];
+        }
+    }
     // ---- stage: joint state, base state, contact summary, the 16 task records ----
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
@@ -423,17 +434,9 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             // here): the 67 uniform words DW_NZ_DR_DAMP .. DW_NZ_DR_FRIC are 18 generator blocks, three per lane at most,
             // and a word goes from the lane that drew it straight to its place
             static_assert(DW_NZ_DR_ARM == DW_NZ_DR_DAMP + DW_NUM_DOF && DW_NZ_DR_FRIC == DW_NZ_DR_ARM + DW_NUM_DOF, "DR words are contiguous");
-            constexpr int B0 = DW_NZ_DR_DAMP / 4, NBLK = DW_NZ_DR_FRIC / 4 - B0 + 1, NPASS = (NBLK + 7) / 8;
-            float nom[NPASS][4], u[NPASS][4] = {};
+            constexpr int B0 = DR_B0, NBLK = DR_NBLK, NPASS = DR_NPASS;
+            float u[NPASS][4] = {};
             const bool go = mine && do_dr;
-            DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) {
-                DQ_UNROLL for (int i = 0; i < 4; ++i) {
-                    const int w = 4 * (B0 + j + 8 * p2) + i;
-                    const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
-                    const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
-                    nom[p2][i] = (isa ? M.arm_nom : M.damp_nom)[l];
-                }
-            }
             if (go) { DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) dw::noise_block(K.nz, B0 + j + 8 * p2 < B0 + NBLK ? B0 + j + 8 * p2 : B0, u[p2]); }
             const float d0 = C.dr_damp[0], d1 = C.dr_damp[1] - C.dr_damp[0], a0 = C.dr_arm[0], a1 = C.dr_arm[1] - C.dr_arm[0];
             const float f0 = C.dr_fric[0], f1 = C.dr_fric[1] - C.dr_fric[0];
@@ -443,7 +446,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
                     const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
                     const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
                     const float sd = d0 + u[p2][i] * d1, sa = a0 + u[p2][i] * a1;
-                    if (go && xvalid && C.dr_dof && (isd || isa)) (isa ? B.dof_armature : B.dof_damping)[(size_t)ND * e + l] = isa ? nom[p2][i] * sa : nom[p2][i] + sd;
+                    if (go && xvalid && C.dr_dof && (isd || isa)) (isa ? B.dof_armature : B.dof_damping)[(size_t)ND * e + l] = isa ? dr_nom[p2][i] * sa : dr_nom[p2][i] + sd;
                     if (go && xvalid && C.dr_friction && w == DW_NZ_DR_FRIC) B.friction_scale[e] = f0 + u[p2][i] * f1;
                 }
             }
