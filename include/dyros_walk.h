@@ -59,6 +59,8 @@ extern "C" {
 #define DW_NUM_ACT      13   /* 12 leg torques + 1 gait-clock action                      */
 #define DW_NUM_LOWER    12
 #define DW_NUM_OBS1     37   /* single-step observation                                   */
+#define DW_AMP_NUM_OBS1 36   /* TocabiAMPLower single-step observation (tasks/amp/tocabi_amp_lower_base.py:45) */
+#define DW_AMP_NUM_ACT  12   /* TocabiAMPLower actions: the 12 leg torques (:46)          */
 #define DW_NUM_HIS      10
 #define DW_NUM_SKIP      2
 #define DW_HIST_SLOTS   20   /* NumHis*NumSkip                                            */
@@ -320,6 +322,36 @@ int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *
 /* reset_idx for the env ids listed (int32, device memory). */
 int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise,
                  int64_t step_index, void *stream);
+
+/* ---- Row f-3: env-side functions of the sibling TOCABI tasks on the same physics. -------------------
+ * Stateless, one thread per env, device pointers, asynchronous on `stream`; argument order and meaning are those of the
+ * reference's TorchScript functions so that a maintainer binds them at the reference's own call sites:
+ *   dw_amp_observations  tasks/amp/tocabi_amp_lower_base.py:918-962  compute_humanoid_observations -> obs [N,DW_AMP_NUM_OBS1]
+ *                        (key_pos, which the reference passes and never reads, is omitted)
+ *   dw_amp_reward        :964-1023 compute_humanoid_reward -> reward [N], reward_values [N,9]; actions [N,12], contact_force [N,38,3]
+ *   dw_amp_reset         :1025-1069 compute_humanoid_reset -> reset [N], terminated [N]; contact_body_ids: Gym bodies whose contact
+ *                        does not terminate (the feet), rigid_body_pos [N,38,3] (rows 0, 8, 16 are read), rigid_body_rot [N,38,4] (row 0)
+ *   dw_newwalk_reward    tasks/tocabi_new_walk.py:384-496 compute_humanoid_walk_reward -> total_reward [N], reset [N], reward8 [N,8]
+ *                        (hard-codes contact rows 7 and 14 as the reference does; num_dof <= 64)
+ *   dw_body_positions    world position of the origin of up to DW_MAX_BODY_QUERY MOVING bodies (HOST array of indices) of every env,
+ *                        out [N,nb,3]: the rows of acquire_rigid_body_state_tensor (:108) those functions need, from the bound
+ *                        root_states / dof_state */
+#define DW_MAX_BODY_QUERY 8
+int dw_amp_observations(int n, const float *root_states, const float *rootvel_noise, const float *dof_pos, const float *dof_pos_bias,
+                        const float *quat_bias, const float *dof_vel, const float *commands, float *obs, void *stream);
+int dw_amp_reward(int n, const float *root_states, const float *dof_vel, const float *dof_vel_pre, const float *commands,
+                  const float *actions, const float *actions_pre, const float *motor_efforts, const float *contact_force,
+                  const float *total_mass, float *reward, float *reward_values, void *stream);
+int dw_amp_reset(int n, const int64_t *progress_buf, const float *contact_buf, const int32_t *contact_body_ids, int n_contact_ids,
+                 const float *rigid_body_pos, const float *rigid_body_rot, float max_episode_length, int enable_early_termination,
+                 float termination_height, int64_t *reset, int64_t *terminated, void *stream);
+int dw_newwalk_reward(int n, const int64_t *reset_buf, const int64_t *progress_buf, const float *target_vel, const float *root_pose_states,
+                      const float *joint_position_states, const float *joint_velocity_states, const int32_t *non_feet_idxs, int n_non_feet,
+                      const float *contact_forces, int num_bodies, float termination_height, float death_cost, float max_episode_length,
+                      const float *q_nominal, int num_dof, const float *head_states, const float *lfoot_states, const float *rfoot_states,
+                      const float *phase, float *total_reward, int64_t *reset, float *reward8, void *stream);
+int dw_body_positions(DwHandle *h, const int32_t *moving_bodies, int nb, float *out, void *stream);
+
 
 #ifdef __cplusplus
 }

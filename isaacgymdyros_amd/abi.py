@@ -118,11 +118,21 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     api["step"] = fn("step", C.c_int, H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
     api["step_dev"] = fn("step_dev", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
     api["reset_idx"] = fn("reset_idx", C.c_int, H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
+    if prefix == "dwe_":        # (the host emulation of the step kernels, tests/emul/, does not carry the row f-3 functions)
+        return api
+    # row f-3: env-side functions of the sibling TOCABI tasks (device pointers as c_void_p, trailing stream)
+    P = C.c_void_p
+    api["amp_observations"] = fn("amp_observations", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P)
+    api["amp_reward"] = fn("amp_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P)
+    api["amp_reset"] = fn("amp_reset", C.c_int, C.c_int, P, P, P, C.c_int, P, P, C.c_float, C.c_int, C.c_float, P, P, P)
+    api["newwalk_reward"] = fn("newwalk_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, C.c_int, P, C.c_int, C.c_float, C.c_float,
+                               C.c_float, P, C.c_int, P, P, P, P, P, P, P, P)
+    api["body_positions"] = fn("body_positions", C.c_int, H, C.POINTER(C.c_int32), C.c_int, P, P)
     return api
 
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev",
-           "reset_idx"]
+           "reset_idx", "amp_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions"]
 
 
 # name -> (per-env shape, numpy dtype string); gate_acc is the one buffer without an env dimension

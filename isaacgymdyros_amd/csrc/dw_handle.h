@@ -1,0 +1,22 @@
+// dw_handle.h -- what a DwHandle (include/dyros_walk.h) points to; shared by the translation units that implement C-ABI entry
+// points (dw_hip.hip, dw_amp.hip).
+#pragma once
+
+#include "dw_params.h"
+
+namespace dwq { struct QuadModel; }
+
+struct DwHandle {
+    DwConfig        cfg;
+    dw::TaskParams  params;
+    dw::DevModel   *d_model;
+    dwq::QuadModel *d_qmodel;
+    dw::DevParams  *d_params;
+    int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env); one launch per step in all three
+    float          *d_mocap;
+    float          *d_sc_park;      // octet kernels: PhysParams::sc_park
+    DwBuffers       buf;
+    int             bound;
+    int             has_task;
+    int             device;
+};

@@ -14,25 +14,12 @@
 
 #include "dw_params.h"
 
-namespace dwq { struct QuadModel; }
-
-struct DwHandle {
-    DwConfig        cfg;
-    dw::TaskParams  params;
-    dw::DevModel   *d_model;
-    dwq::QuadModel *d_qmodel;
-    dw::DevParams  *d_params;
-    int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env); one launch per step in all three
-    float          *d_mocap;
-    float          *d_sc_park;      // octet kernels: PhysParams::sc_park
-    DwBuffers       buf;
-    int             bound;
-    int             has_task;
-    int             device;
-};
+#include "dw_handle.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+// (for the other translation unit with C-ABI entry points, dw_amp.hip; not exported)
+extern "C" __attribute__((visibility("hidden"))) void dw_set_error(int code, const char *msg) { (void)code; snprintf(g_err, sizeof(g_err), "%s", msg); }
 static int fail_hip(const char *what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return DW_EHIP;

@@ -1,0 +1,402 @@
+"""TocabiAMPLower's env side on the MI355X physics.
+
+Mirrors `TocabiAMPLowerBase` of the reference (paths relative to python/IsaacGymEnvs/isaacgymenvs):
+  tasks/amp/tocabi_amp_lower_base.py:50-236   constructor state (gains, biases, histories, delay FIFO, command schedule)
+                                    :238-305  reset_idx
+                                    :540-580  _compute_observations (history stacking: NumHis x NumSkip)
+                                    :642-748  pre_physics_step (push perturbation, command ramp, torque / PD actuation with the
+                                              delayed-torque FIFO, controlFrequencyInv substeps, encoder model)
+                                    :750-804  post_physics_step
+                                    :918-1069 the three TorchScript functions -- here the HIP entry points dw_amp_observations,
+                                              dw_amp_reward, dw_amp_reset (include/dyros_walk.h), pinned bit for bit against the
+                                              reference's own functions (tests/golden/amp_lower_ref.npz)
+  cfg/task/TocabiAMPLower.yaml                default_amp_cfg below
+
+What runs where.  `gym.simulate` is dw_simulate of the bound physics handle (one launch per substep, the same octet kernel the
+DyrosDynamicWalk step fuses); observation, reward and termination are one HIP launch each; the rows of the rigid-body state
+tensor they need (base, the two foot links) come from dw_body_positions.  The bookkeeping between them -- history shifts,
+the command ramp, the torque FIFO -- is a few dozen elementwise torch launches per step on [N,12]..[N,480] tensors: this task
+is the reference's sibling, not the north star's hot path, and is NOT fused into one kernel the way VecTask.step of
+DyrosDynamicWalk is.  Random draws are torch's device generator, as in the reference: the class is held
+to the reference statistically, its three pure functions bit for bit.
+
+Not built: the motion-library state initialisation and the discriminator observations of the subclass
+(tasks/tocabi_amp_lower.py: `stateInit` Random / Hybrid, `_compute_amp_observations`), which need the reference's motion
+assets; `stateInit: Default` is what reset_idx implements.  The triangle-mesh terrain of this task is not wired either.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Any, Dict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import default_cfg
+from .dyros_dynamic_walk import DyrosDynamicWalk
+from .task_constants import ACTION_HIGH
+from .vec_task import VecTask
+
+NUM_OBS = 3 + 6 + 3 + 12 + 12          # reference :45 (root euler, root velocities, command, leg dof pos, leg dof vel)
+NUM_ACTIONS = 12                        # :46
+REWARD_NAMES = ["x_vel_tracking", "y_vel_tracking", "yaw_vel_tracking", "contact_force_threshold", "contact_force_penalty",
+                "joint_velocity_regulation", "joint_acceleration_regulation", "torque_regulation", "torque_diff_regulation"]   # :1010-1012
+INIT_ANGLE = [0.0, 0.0, -0.28, 0.6, -0.32, 0.0, 0.0, 0.0, -0.28, 0.6, -0.32, 0.0, 0.0, 0.0, 0.0,
+              0.3, 0.174533, 1.22173, -1.27, -1.57, 0.0, -1.0, 0.0, 0.0, 0.0,
+              -0.3, -0.174533, -1.22173, 1.27, 1.57, 0.0, 1.0, 0.0]                                    # :90-95
+ARMATURE = [0.614, 0.862, 1.09, 1.09, 1.09, 0.360, 0.614, 0.862, 1.09, 1.09, 1.09, 0.360, 0.078, 0.078, 0.078,
+            0.18, 0.18, 0.18, 0.18, 0.0032, 0.0032, 0.0032, 0.0032, 0.0032, 0.0032,
+            0.18, 0.18, 0.18, 0.18, 0.0032, 0.0032, 0.0032, 0.0032]                                   # :443-447
+# reference :1073-1103 (class control), by DoF order; applied as p / 9 and d / 3 (:167-168)
+P_GAINS = [2000, 5000, 4000, 3700, 3200, 3200] * 2 + [6000, 10000, 10000] + [400, 1000, 400, 400, 400, 400, 100, 100] + [100, 100] + \
+          [400, 1000, 400, 400, 400, 400, 100, 100]
+D_GAINS = [15, 50, 20, 25, 24, 24] * 2 + [200, 100, 100] + [10, 28, 10, 10, 10, 10, 3, 3] + [100, 100] + [10, 28, 10, 10, 10, 10, 3, 3]
+
+
+def default_amp_cfg(num_envs: int = 4096, sim_device: str = "cuda:0") -> dict:
+    """cfg/task/TocabiAMPLower.yaml with the Hydra interpolations resolved (plane terrain)."""
+    return {
+        "name": "TocabiAMPLower", "physics_engine": "physx", "rl_device": sim_device, "seed": 42,
+        "env": {"numEnvs": num_envs, "envSpacing": 5, "episodeLength": 8000, "enableDebugVis": False, "pdControl": False,
+                "powerScale": 1.0, "controlFrequencyInv": 2, "stateInit": "Default", "localRootObs": False,
+                "contactBodies": ["L_Foot_Link", "R_Foot_Link"], "terminationHeight": 0.6, "enableEarlyTermination": True,
+                "perturbation": False, "velChange": True, "NumHis": 10, "NumSkip": 2,
+                "command": {"x": [-0.5, 1.0], "y": [-0.0, 0.0], "yaw": [-0.0, 0.0]},
+                "terrain": {"terrainType": "plane", "staticFriction": 1.0, "dynamicFriction": 1.0, "restitution": 0.0, "curriculum": True}},
+        "sim": {"dt": 0.002, "substeps": 1, "up_axis": "z", "use_gpu_pipeline": True, "gravity": [0.0, 0.0, -9.81],
+                "physx": {"num_position_iterations": 4, "num_velocity_iterations": 0, "contact_offset": 0.002, "rest_offset": 0.0,
+                          "bounce_threshold_velocity": 0.04, "max_depenetration_velocity": 10.0}},
+        "task": {"noise": True, "randomize": True,
+                 "randomization_params": {"frequency": 1, "actor_params": {"humanoid": {
+                     "rigid_body_properties": {"mass": {"range": [0.8, 1.2], "operation": "scaling", "distribution": "uniform", "setup_only": True}},
+                     "dof_properties": {"damping": {"range": [0.0, 2.9], "operation": "additive", "distribution": "uniform"},
+                                        "armature": {"range": [0.8, 1.2], "operation": "scaling", "distribution": "uniform"}}}}}},
+    }
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class TocabiAMPLower(VecTask):
+
+    def __init__(self, cfg: Dict[str, Any], sim_device: str, graphics_device_id: int = 0, headless: bool = True):
+        self.cfg = cfg
+        e = cfg["env"]
+        if e["terrain"]["terrainType"] not in ("plane", "none"):
+            raise ValueError("TocabiAMPLower on the MI355X physics: only terrainType 'plane' is wired (module docstring)")
+        if e.get("stateInit", "Default") != "Default":
+            raise ValueError("TocabiAMPLower on the MI355X physics: only stateInit 'Default' (the motion library is not part of this build)")
+        self._pd_control = e["pdControl"]
+        self.randomize = cfg["task"]["randomize"]
+        self.noise = cfg["task"]["noise"]
+        self.randomization_params = cfg["task"]["randomization_params"]
+        self.max_episode_length = e["episodeLength"]
+        self._termination_height = e["terminationHeight"]
+        self._enable_early_termination = e["enableEarlyTermination"]
+        self.perturb = e["perturbation"]
+        self.c_x, self.c_y, self.c_yaw = e["command"]["x"], e["command"]["y"], e["command"]["yaw"]
+        self.num_obs_his, self.num_obs_skip = e["NumHis"], e["NumSkip"]
+        e["numObservations"] = (NUM_OBS + NUM_ACTIONS) * self.num_obs_his - NUM_ACTIONS            # :83
+        e["numActions"] = NUM_ACTIONS
+        super().__init__(config=cfg, sim_device=sim_device, graphics_device_id=graphics_device_id, headless=headless)
+
+        # ---- the physics: a bound DwHandle with the Gym tensors, carried by the DyrosDynamicWalk host class (its task state is unused)
+        pc = default_cfg(self.num_envs, self.device)
+        pc["seed"] = cfg.get("seed", 42)
+        pc["sim"].update({k: copy.deepcopy(v) for k, v in cfg["sim"].items() if k != "mi355"})
+        pc["sim"]["physx"]["num_velocity_iterations"] = max(1, cfg["sim"]["physx"].get("num_velocity_iterations", 0))
+        pc["sim"]["mi355"].update(cfg["sim"].get("mi355", {}))
+        pc["env"]["perturbation"] = False
+        # spawn height: the reference's 0.89 (:394) puts the soles 2.2 cm INTO the plane in the initial pose; PhysX resolves that
+        # positionally, this simulator's contact model through a velocity bias (erp), which launches the robot at 2 m/s.  Default
+        # here: the DyrosDynamicWalk height (soles 1.8 cm above the plane); cfg sim.mi355.amp_initial_height = 0.89 restores the number
+        self._spawn_z = float(cfg["sim"].get("mi355", {}).get("amp_initial_height", 0.93))
+        pc["env"]["initialHieght"] = self._spawn_z
+        pc["task"]["randomize"] = bool(self.randomize)
+        pc["task"]["randomization_params"] = {"frequency": 1, "actor_params": {"humanoid": {
+            "rigid_body_properties": copy.deepcopy(self.randomization_params["actor_params"]["humanoid"].get("rigid_body_properties", {}))}}}
+        self._phys = DyrosDynamicWalk(pc, self.device, graphics_device_id, headless)
+        self._lib, self._api = self._phys._lib, self._phys._api
+        dev = self._tdev = self._phys._tdev
+        N = self.num_envs
+        f = dict(dtype=torch.float, device=dev)
+        self.dt = cfg["sim"]["dt"]                                                             # :98
+        self.num_bodies, self.num_dof = 38, 33
+        self.pelvis_idx, self.left_foot_idx, self.right_foot_idx = 0, 8, 16
+        b = self._phys._buf
+        self._root_states = b["root_states"]
+        self._dof_state = b["dof_state"]
+        self._dof_pos, self._dof_vel = b["dof_state"][..., 0], b["dof_state"][..., 1]
+        self._contact_forces = b["contact_forces"]
+        self.total_mass = b["total_mass"].view(N, 1)
+        self.init_angle = torch.tensor(INIT_ANGLE, **f)
+        self.motor_efforts = torch.tensor(ACTION_HIGH[:12], **f)                              # :357-358 (ctrlrange upper limits)
+        self.max_motor_effort = float(self.motor_efforts.max())
+        self.p_gains = torch.tensor(P_GAINS, **f) / 9.0
+        self.d_gains = torch.tensor(D_GAINS, **f) / 3.0
+        self._nominal_damping = torch.full((33,), 0.1, **f)                                    # :441
+        self._nominal_armature = torch.tensor(ARMATURE, **f)
+        b["dof_damping"][:] = self._nominal_damping
+        b["dof_armature"][:] = self._nominal_armature
+        self._initial_root_states = torch.zeros(N, 13, **f)
+        self._initial_root_states[:, 2] = self._spawn_z
+        self._initial_root_states[:, 6] = 1.0
+        self._root_states[:] = self._initial_root_states
+        self._initial_dof_pos = self.init_angle.repeat(N, 1)
+        self._dof_pos[:] = self._initial_dof_pos
+        self._dof_vel[:] = 0.0
+        self._contact_forces.zero_()
+        self.power_scale = torch.ones(N, 12, **f)
+        self.actions = torch.zeros(N, NUM_ACTIONS, **f)
+        self.actions_pre = self.actions.clone()
+        self._dof_vel_pre = self._dof_vel.clone()
+        # rows 0, 8, 16 of the rigid-body state (what compute_humanoid_reset reads); the other rows stay zero
+        self._rigid_body_pos = torch.zeros(N, 38, 3, **f)
+        self._rigid_body_rot = torch.zeros(N, 38, 4, **f)
+        self._rigid_body_rot[..., 3] = 1.0
+        self._foot_pos = torch.zeros(N, 2, 3, **f)
+        self._foot_mv = (C.c_int32 * 2)(6, 12)                                                  # moving bodies of L_/R_Foot_Link's parent joint
+        self._contact_body_ids = torch.tensor([8, 16], dtype=torch.int32, device=dev)
+        self.commands = torch.zeros(N, 3, **f)
+        self._terminate_buf = torch.ones(N, device=dev, dtype=torch.long)
+        self.reset_buf = torch.ones(N, device=dev, dtype=torch.long)
+        self.progress_buf = torch.zeros(N, device=dev, dtype=torch.long)
+        self.randomize_buf = torch.zeros(N, device=dev, dtype=torch.long)
+        self.timeout_buf = torch.zeros(N, device=dev, dtype=torch.bool)
+        self.obs_buf = torch.zeros(N, self.num_obs, **f)
+        self.rew_buf = torch.zeros(N, **f)
+        self._obs1 = torch.zeros(N, NUM_OBS, **f)
+        self._reward_values = torch.zeros(N, 9, **f)
+        self.qpos_bias, self.quat_bias = torch.zeros(N, 12, **f), torch.zeros(N, 3, **f)
+        self.qpos_noise, self.qvel_noise, self.qpos_pre = (torch.zeros(N, 33, **f) for _ in range(3))
+        self.epi_len, self.epi_len_log = torch.zeros(N, **f), torch.zeros(N, **f)
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(int(cfg.get("seed", 42)))
+        self.perturbation_count = torch.zeros(N, device=dev, dtype=torch.long)
+        self.pert_duration = torch.randint(1, 100, (N,), device=dev, generator=self._gen)
+        self.pert_on = torch.zeros(N, device=dev, dtype=torch.bool)
+        self.impulse = torch.zeros(N, device=dev, dtype=torch.long)
+        self.magnitude, self.phase = torch.zeros(N, **f), torch.zeros(N, **f)
+        self.perturb_timing = torch.ones(N, device=dev, dtype=torch.long)
+        self.perturb_start = False
+        self.vel_change = e["velChange"]
+        self.vel_change_duration = torch.zeros(N, device=dev, dtype=torch.long)
+        self.cur_vel_change_duration = torch.zeros(N, device=dev, dtype=torch.long)
+        self.start_target_vel, self.final_target_vel = torch.zeros(N, 3, **f), torch.zeros(N, 3, **f)
+        self.obs_history = torch.zeros(N, self.num_obs_his * self.num_obs_skip * NUM_OBS, **f)
+        self.action_history = torch.zeros(N, self.num_obs_his * self.num_obs_skip * NUM_ACTIONS, **f)
+        self._log_slots = round(0.01 / self.dt) + 1                                            # :225
+        self.action_log = torch.zeros(N, self._log_slots, 12, **f)
+        self.delay_idx = torch.ones(N, device=dev, dtype=torch.long)                           # delay_idx_tensor[:,1]
+        self.simul_len = torch.zeros(N, device=dev, dtype=torch.long)                          # simul_len_tensor[:,1]
+        self._env_ar = torch.arange(N, device=dev)
+        self._push = torch.zeros(N, 2, **f)
+        self.time_step = 0
+        self.extras["reward_names"] = list(REWARD_NAMES)
+        if self._pd_control:
+            lo, hi = self._phys.model.dof_lower, self._phys.model.dof_upper
+            lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
+            mid, sc = 0.5 * (hi + lo), 1.0 * (hi - lo)                                         # :485-503
+            self._pd_action_offset = torch.tensor(0.5 * ((mid + sc) + (mid - sc)), **f)
+            self._pd_action_scale = torch.tensor(0.5 * ((mid + sc) - (mid - sc)), **f)
+
+    # ------------------------------------------------------------------ helpers
+    def _rand(self, *shape):
+        return torch.rand(*shape, device=self._tdev, generator=self._gen)
+
+    def _rand_float(self, lo, hi, shape):                 # torch_rand_float (python/isaacgym/torch_utils.py:50-52)
+        return (hi - lo) * self._rand(*shape) + lo
+
+    def _chk(self, rc):
+        _lib.check(self._api, rc)
+
+    def _refresh_sim_tensors(self):
+        """refresh_*_tensor of the reference (:527-538): the Gym tensors are the physics' own buffers; the three rigid-body rows
+        the reset needs are recomputed from them."""
+        self._chk(self._api["body_positions"](self._phys._h, self._foot_mv, 2, _p(self._foot_pos), None))
+        self._rigid_body_pos[:, 0] = self._root_states[:, 0:3]
+        self._rigid_body_pos[:, 8] = self._foot_pos[:, 0]
+        self._rigid_body_pos[:, 16] = self._foot_pos[:, 1]
+        self._rigid_body_rot[:, 0] = self._root_states[:, 3:7]
+
+    # ------------------------------------------------------------------ reset (:238-305)
+    def reset_idx(self, env_ids):
+        env_ids = env_ids.to(self._tdev).long()
+        n = len(env_ids)
+        if n == 0:
+            return
+        if self.randomize:
+            self.power_scale[env_ids] = self._rand_float(0.8, 1.2, (n, 12))
+            # apply_randomizations (tasks/base/vec_task.py:519-733) for the dof properties: envs that are resetting and whose
+            # randomize_buf has reached the frequency draw damping (additive) and armature (scaling) from the ORIGINAL values
+            freq = self.randomization_params.get("frequency", 1)
+            dofp = self.randomization_params["actor_params"]["humanoid"].get("dof_properties", {})
+            sel = env_ids[(self.randomize_buf[env_ids] >= freq) & (self.reset_buf[env_ids] != 0)]
+            if len(sel) > 0:
+                b = self._phys._buf
+                if "damping" in dofp:
+                    lo, hi = dofp["damping"]["range"]
+                    b["dof_damping"][sel] = self._nominal_damping + self._rand_float(lo, hi, (len(sel), 33))
+                if "armature" in dofp:
+                    lo, hi = dofp["armature"]["range"]
+                    b["dof_armature"][sel] = self._nominal_armature * self._rand_float(lo, hi, (len(sel), 33))
+                self.randomize_buf[sel] = 0
+        # _reset_actors (:611-626)
+        self._dof_pos[env_ids] = self._initial_dof_pos[env_ids]
+        self._dof_vel[env_ids] = 0.0
+        self._root_states[env_ids] = self._initial_root_states[env_ids]
+        self._contact_forces[env_ids] = 0.0
+        self.progress_buf[env_ids] = 0
+        self.reset_buf[env_ids] = 0
+        self._terminate_buf[env_ids] = 0
+        self._refresh_sim_tensors()
+        # the reference computes the observation of the reset envs HERE (:253), before the new command, encoder state and biases
+        # are drawn (:266-279) and before it zeroes the two histories (:296-297): the reset env's obs_buf rows are made of the
+        # episode's last encoder reading, and its history starts from zeros
+        self._compute_observations(env_ids)
+        self._dof_vel_pre[env_ids] = 0.0
+        self.actions_pre[env_ids] = 0.0
+        self.commands[env_ids, 0] = self._rand_float(self.c_x[0], self.c_x[1], (n,))
+        self.commands[env_ids, 1] = self._rand_float(self.c_y[0], self.c_y[1], (n,))
+        self.commands[env_ids, 2] = self._rand_float(self.c_yaw[0], self.c_yaw[1], (n,))
+        self.qpos_noise[env_ids] = self._initial_dof_pos[env_ids]
+        self.qpos_pre[env_ids] = self._initial_dof_pos[env_ids]
+        self.qvel_noise[env_ids] = 0.0
+        if self.noise:
+            self.qpos_bias[env_ids] = self._rand(n, 12) * 6.28 / 100 - 3.14 / 100
+            self.quat_bias[env_ids] = self._rand(n, 3) * 6.28 / 150 - 3.14 / 150
+        else:
+            self.qpos_bias[env_ids] = 0.0
+            self.quat_bias[env_ids] = 0.0
+        self.time_step = 0
+        self.epi_len_log[env_ids] = self.epi_len[env_ids]
+        self.epi_len[env_ids] = 0
+        self.perturbation_count[env_ids] = 0
+        self.pert_on[env_ids] = False
+        self.perturb_timing[env_ids] = torch.randint(0, int(8 / 0.002), (n,), device=self._tdev, generator=self._gen)
+        self.obs_history[env_ids] = 0
+        self.action_history[env_ids] = 0
+        self.action_log[env_ids] = 0
+        self.delay_idx[env_ids] = torch.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,), device=self._tdev, generator=self._gen)
+        self.simul_len[env_ids] = 0
+
+    # ------------------------------------------------------------------ observations (:540-610)
+    def _compute_humanoid_obs(self):
+        self.time_step += 1
+        N = self.num_envs
+        nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
+        self._chk(self._api["amp_observations"](N, _p(self._root_states), _p(nz), _p(self.qpos_noise), _p(self.qpos_bias), _p(self.quat_bias),
+                                                _p(self.qvel_noise), _p(self.commands), _p(self._obs1), None))
+        return self._obs1
+
+    def _compute_observations(self, env_ids=None):
+        obs = self._compute_humanoid_obs()
+        if env_ids is None:
+            self.obs_history = torch.cat((self.obs_history[:, NUM_OBS:], obs), dim=-1)
+        else:
+            self.obs_history[env_ids] = obs[env_ids].repeat(1, self.num_obs_his * self.num_obs_skip)
+        H, S = self.num_obs_his, self.num_obs_skip
+        oh = self.obs_history.view(self.num_envs, H * S, NUM_OBS)
+        ah = self.action_history.view(self.num_envs, H * S, NUM_ACTIONS)
+        self.obs_buf[:, :NUM_OBS * H] = oh[:, S - 1::S].reshape(self.num_envs, -1)                       # slots S(i+1)-1
+        self.obs_buf[:, NUM_OBS * H:] = ah[:, S::S][:, :H - 1].reshape(self.num_envs, -1)               # slots S(i+1), i < H-1
+
+    # ------------------------------------------------------------------ pre-physics (:642-748)
+    def pre_physics_step(self, actions):
+        N, dev = self.num_envs, self._tdev
+        self.actions = actions.to(dev).clone()
+        self.action_history = torch.cat((self.action_history[:, NUM_ACTIONS:], self.actions), dim=-1)
+        push = None
+        if self.perturb and float(self.epi_len_log.mean()) > self.max_episode_length - 8 / 0.002:
+            self.perturb_start = True
+        if self.perturb_start:
+            start = (self.epi_len % (8 / 0.002)) == self.perturb_timing
+            ns = int(start.sum())
+            if ns:
+                self.pert_on[start] = True
+                self.impulse[start] = torch.randint(50, 250, (ns,), device=dev, generator=self._gen)
+                self.pert_duration[start] = torch.randint(int(0.1 / 0.002), int(1 / 0.002), (ns,), device=dev, generator=self._gen)
+                self.magnitude[start] = self.impulse[start] / (self.pert_duration[start] * 0.002)
+                self.phase[start] = self._rand(ns) * 2 * 3.14159265358979
+            self.perturbation_count = torch.where(self.pert_on, self.perturbation_count + 1, self.perturbation_count)
+            self._push[:, 0] = torch.where(self.pert_on, self.magnitude * torch.cos(self.phase), torch.zeros_like(self.magnitude))
+            self._push[:, 1] = torch.where(self.pert_on, self.magnitude * torch.sin(self.phase), torch.zeros_like(self.magnitude))
+            done = self.perturbation_count == self.pert_duration
+            self.pert_on[done] = False
+            self.perturbation_count[done] = 0
+            push = self._push
+        if self.vel_change:
+            change = (self.epi_len % int(self.max_episode_length / 2)) == int(self.max_episode_length / 4 - 1)
+            nc = int(change.sum())
+            if nc:
+                self.vel_change_duration[change] = torch.randint(1, 250, (nc,), device=dev, generator=self._gen)
+                self.cur_vel_change_duration[change] = 0
+                self.start_target_vel[change] = self.commands[change]
+                self.final_target_vel[change, 0] = self._rand_float(self.c_x[0], self.c_x[1], (nc,))
+                self.final_target_vel[change, 1] = self._rand_float(self.c_y[0], self.c_y[1], (nc,))
+                self.final_target_vel[change, 2] = self._rand_float(self.c_yaw[0], self.c_yaw[1], (nc,))
+            mask = self.cur_vel_change_duration < self.vel_change_duration
+            ramp = self.start_target_vel + (self.final_target_vel - self.start_target_vel) * (self.cur_vel_change_duration / self.vel_change_duration).unsqueeze(-1)
+            self.commands = torch.where(mask.unsqueeze(-1), ramp, self.commands)
+            self.cur_vel_change_duration += mask.long()
+        for _ in range(self.control_freq_inv):
+            upper = self.p_gains[12:] * (self.init_angle[12:] - self._dof_pos[:, 12:]) + self.d_gains[12:] * (-self._dof_vel[:, 12:])
+            if self._pd_control:
+                tar = self._pd_action_offset[:12] + self._pd_action_scale[:12] * self.actions
+                lower = self.p_gains[:12] * (tar - self._dof_pos[:, :12]) + self.d_gains[:12] * (-self._dof_vel[:, :12])
+            else:
+                lower = self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale
+                lower = torch.max(torch.min(lower, self.motor_efforts.unsqueeze(0)), -self.motor_efforts.unsqueeze(0))
+                # delayed-torque FIFO (:712-724): newest at the end, read `delay_idx` back once the FIFO has filled that far
+                self.action_log = torch.cat((self.action_log[:, 1:], lower.unsqueeze(1)), dim=1)
+                self.simul_len = (self.simul_len + 1).clamp(max=self._log_slots, min=0)
+                filled = self.simul_len > self.delay_idx
+                delayed = torch.where(filled.unsqueeze(-1), self.action_log[self._env_ar, self.delay_idx], self.action_log[self._env_ar, -self.simul_len])
+                if self.noise:
+                    lower = delayed
+            self._phys.simulate(torch.cat((lower, upper), dim=1).contiguous(), push)
+            push = None                                  # (applied forces last one simulate())
+            if self.noise:
+                z = torch.randn(N, 33, device=dev, generator=self._gen) * (0.00016 / 3.0)
+                self.qpos_noise = self._dof_pos + torch.clamp(z, min=-0.00016, max=0.00016)
+            else:
+                self.qpos_noise = self._dof_pos.clone()
+            self.qvel_noise = (self.qpos_noise - self.qpos_pre) / self.dt
+            self.qpos_pre = self.qpos_noise.clone()
+        self.epi_len += 1
+
+    # ------------------------------------------------------------------ post-physics (:750-804)
+    def post_physics_step(self):
+        N = self.num_envs
+        self.progress_buf += 1
+        self.randomize_buf += 1
+        self._refresh_sim_tensors()
+        self._compute_observations()
+        dv = self._dof_vel.contiguous()
+        self._chk(self._api["amp_reward"](N, _p(self._root_states), _p(dv), _p(self._dof_vel_pre), _p(self.commands), _p(self.actions),
+                                          _p(self.actions_pre), _p(self.motor_efforts), _p(self._contact_forces), _p(self.total_mass),
+                                          _p(self.rew_buf), _p(self._reward_values), None))
+        self.extras["reward_names"] = list(REWARD_NAMES)
+        self.extras["reward_values"] = self._reward_values
+        self._chk(self._api["amp_reset"](N, _p(self.progress_buf), _p(self._contact_forces), _p(self._contact_body_ids), 2,
+                                         _p(self._rigid_body_pos), _p(self._rigid_body_rot), float(self.max_episode_length),
+                                         int(bool(self._enable_early_termination)), float(self._termination_height),
+                                         _p(self.reset_buf), _p(self._terminate_buf), None))
+        self.extras["terminate"] = self._terminate_buf
+        self._dof_vel_pre = dv.clone()
+        self.actions_pre = self.actions.clone()
+
+    def step(self, actions):                              # :806-845
+        action_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)
+        self.pre_physics_step(action_tensor)
+        self.post_physics_step()
+        self.timeout_buf = (self.progress_buf >= self.max_episode_length - 1) & (self.reset_buf != 0)
+        self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
+        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+
+    def close(self):
+        self._phys.close()

@@ -1,0 +1,145 @@
+"""Row f-3 on the GPU: the HIP entry points dw_amp_* / dw_newwalk_reward / dw_body_positions against the CPU oracle and the
+reference fixture, and the TocabiAMPLower env class stepping on the MI355X physics."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import amp_calls
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "amp_lower_ref.npz")
+_NP2T = {"f4": torch.float32, "i8": torch.int64, "i4": torch.int32}
+
+
+def ulps(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def hip_outputs(g, early=True):
+    from isaacgymdyros_amd import _lib
+    lib, api = _lib.load()
+
+    def chk(rc):
+        assert rc == 0, lib.dw_last_error()
+    out = amp_calls.run_all(api, g, lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(),
+                            lambda s, d: torch.zeros(s, dtype=_NP2T[d], device="cuda"), chk, early)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def oracle_outputs(g, early=True):
+    from oracle import oracle
+    lib, api = oracle.load()
+
+    def chk(rc):
+        assert rc == 0
+    return amp_calls.run_all(api, g, lambda a: np.ascontiguousarray(a), lambda s, d: np.zeros(s, d), chk, early)
+
+
+def test_amp_functions_hip_vs_oracle_and_reference():
+    g = np.load(G)
+    h, o = hip_outputs(g), oracle_outputs(g)
+    # observations: 33 of the 36 entries are the reference's bit patterns; the three Euler angles go through atan2f, where the
+    # device library and torch's SLEEF kernel round differently (measured: <= 2.4e-7 rad, 1 ulp of the largest angles; tools/amp_diag.py)
+    d = ulps(h["obs"], g["ref_obs"])
+    assert d[:, 3:].max() == 0, np.argwhere(d[:, 3:] > 0)[:5]
+    assert np.abs(h["obs"][:, :3] - g["ref_obs"][:, :3]).max() <= 2.4e-7
+    assert np.abs(h["obs"] - o["obs"]).max() <= 2.4e-7
+    # reward: exp of the device library against torch's / glibc's: <= 2 ulp per term
+    assert ulps(h["reward_values"], g["ref_reward_values"]).max() <= 2
+    assert ulps(h["reward_values"], o["reward_values"]).max() <= 2
+    assert np.abs(h["reward"] - g["ref_reward"]).max() <= 1.2e-7
+    # termination: exact
+    for early in (True, False):
+        hh = hip_outputs(g, early)
+        assert np.array_equal(hh["reset"], g["ref_reset_early%d" % early])
+        assert np.array_equal(hh["terminated"], g["ref_terminated_early%d" % early])
+    # TocabiNewWalk's reward
+    assert np.array_equal(h["nw_reset"], g["ref_nw_reset"])
+    assert np.array_equal(h["nw_total"] == -1.0, g["ref_nw_total"] == -1.0)
+    assert np.abs(h["nw_reward8"] - g["ref_nw_reward8"]).max() <= 5e-7
+    assert np.abs(h["nw_total"] - g["ref_nw_total"]).max() <= 2e-7
+
+
+def test_amp_argument_checks():
+    from isaacgymdyros_amd import _lib
+    lib, api = _lib.load()
+    x = torch.zeros(16, 64, device="cuda")
+    p = C.c_void_p(x.data_ptr())
+    assert api["amp_observations"](0, p, p, p, p, p, p, p, p, None) != 0
+    assert api["amp_observations"](4, None, p, p, p, p, p, p, p, None) != 0
+    assert b"dw_amp_observations" in lib.dw_last_error()
+    assert api["newwalk_reward"](4, p, p, p, p, p, p, p, 2, p, 15, 0.6, -1.0, 1000.0, p, 65, p, p, p, p, p, p, p, None) != 0
+
+
+def test_body_positions_hip_vs_oracle():
+    """dw_body_positions (the rows of the rigid-body state tensor the reset reads) against the oracle's double-precision
+    quaternion chain, on random joint angles and base poses."""
+    from isaacgymdyros_amd.config import default_cfg
+    from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+    from oracle.oracle import OracleSim
+    N = 64
+    env = DyrosDynamicWalk(default_cfg(N, "cuda:0"), "cuda:0", 0, True)
+    rng = np.random.default_rng(5)
+    root = np.zeros((N, 13), np.float32)
+    root[:, :3] = rng.normal(size=(N, 3))
+    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    root[:, 3:7] = q
+    dof = np.zeros((N, 33, 2), np.float32)
+    dof[..., 0] = rng.uniform(-1.2, 1.2, size=(N, 33))
+    env._buf["root_states"].copy_(torch.from_numpy(root))
+    env._buf["dof_state"].copy_(torch.from_numpy(dof))
+    bodies = [6, 12, 0, 3, 22, 33, 15, 30]
+    arr = (C.c_int32 * len(bodies))(*bodies)
+    out = torch.zeros(N, len(bodies), 3, device="cuda")
+    assert env._api["body_positions"](env._h, arr, len(bodies), C.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    osim = OracleSim(N)
+    osim.buf["root_states"][:] = root
+    osim.buf["dof_state"][:] = dof
+    ref = np.zeros((N, len(bodies), 3), np.float32)
+    assert osim.api["body_positions"](osim.h, arr, len(bodies), ref.ctypes.data_as(C.c_void_p), None) == 0
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < 5e-6, err                     # fp32 matrix chain of up to 8 links against double: ~1e-6 m
+    assert np.abs(ref[:, 2] - root[:, :3]).max() == 0          # moving body 0 is the base itself
+    # out-of-range body index is refused on the host
+    bad = (C.c_int32 * 1)(34)
+    assert env._api["body_positions"](env._h, bad, 1, C.c_void_p(out.data_ptr()), None) != 0
+    env.close()
+
+
+def test_tocabi_amp_lower_env_steps():
+    """The env class on the MI355X physics: shapes, the reset flow driven by reset_done() as the AMP learner drives it, finite
+    observations, rewards inside the reference's range, terminations from falls, and the robots standing on their feet under
+    zero actions at the start (the physics really is under the class)."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg, NUM_OBS, NUM_ACTIONS
+    N = 256
+    env = TocabiAMPLower(default_amp_cfg(N, "cuda:0"), "cuda:0", 0, True)
+    assert env.num_obs == (NUM_OBS + NUM_ACTIONS) * 10 - NUM_ACTIONS == 468 and env.num_actions == 12
+    obs, ids = env.reset_done()
+    assert len(ids) == N and obs["obs"].shape == (N, 468)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    total_resets, rew_sum = 0, 0.0
+    for t in range(300):
+        a = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * (0.0 if t < 40 else 0.6)
+        obs, rew, reset, extras = env.step(a)
+        assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+        assert float(rew.min()) >= -0.2 - 1e-6 and float(rew.max()) <= 0.8 + 0.6 + 0.1 + 0.05 + 0.05 + 0.08 + 0.6 + 1e-5
+        if t == 39:
+            # 40 steps of zero torque on the legs (upper body under its PD): nobody has terminated yet and both feet carry load
+            z = env._root_states[:, 2]
+            assert int(reset.sum()) == 0 or float((reset != 0).float().mean()) < 0.2, (int(reset.sum()), float(z.min()))
+            fz = env._contact_forces[:, [8, 16], 2].sum(dim=1)
+            assert float((fz > 100.0).float().mean()) > 0.5, float(fz.mean())
+        rew_sum += float(rew.mean())
+        total_resets += int(reset.sum())
+        # the newest observation slot of obs_buf is this step's 36-word observation
+        assert torch.equal(env.obs_buf[:, 36 * 9:36 * 10], env._obs1)
+        _, ids = env.reset_done()
+        assert int(env.reset_buf[ids].sum()) == 0 and int(env.progress_buf[ids].sum()) == 0
+    assert total_resets > 0                       # random torques make robots fall: the termination path ran
+    assert extras["reward_values"].shape == (N, 9) and len(extras["reward_names"]) == 9
+    env.close()
