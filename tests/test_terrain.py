@@ -68,6 +68,36 @@ def test_rough_slope_specification():
     assert full.heightsamples.shape == (2 * 80 + 20, 10 * 80 + 20)
 
 
+@pytest.mark.parametrize("args", [dict(min_height=-0.05, max_height=0.05, step=0.005, downsampled_scale=0.2),    # utils/terrain.py:128-130 (curriculum)
+                                  dict(min_height=-0.1, max_height=0.1, step=0.025, downsampled_scale=0.2),     # tasks/amp/tocabi_amp_lower_base.py:1204
+                                  dict(min_height=-0.1, max_height=0.1, step=0.05, downsampled_scale=0.2)])    # :1151
+def test_random_uniform_against_scipys_replacement_of_interp2d(args):
+    """`random_uniform_terrain` (python/isaacgym/terrain_utils.py:17-51) cannot run on this image: it calls
+    `scipy.interpolate.interp2d`, removed in SciPy 1.14, whose removal notice names `RectBivariateSpline` as the "nearly
+    bug-for-bug compatible" replacement on regular grids.  This restates the reference's lines with that one substitution --
+    same draws (`choice` over `arange(min, max + step, step)`), same argument order f(y, x) with z of shape (len(x), len(y)), same
+    `linspace` nodes, `np.rint`, int16 accumulation -- and holds the package's generator to it sample for sample, for the
+    arguments of all three call sites in the reference."""
+    from scipy.interpolate import RectBivariateSpline
+    for seed in range(6):
+        t = Tile(80, 80, 0.005, 0.1)
+        t.height_field_raw += np.random.RandomState(100 + seed).randint(-3, 4, size=(80, 80)).astype(np.int16)      # (accumulates onto a slope)
+        base = t.height_field_raw.copy()
+        random_uniform(t, np.random.RandomState(seed), **args)
+        # the reference's body
+        rs = np.random.RandomState(seed)
+        lo, hi, st = int(args["min_height"] / 0.005), int(args["max_height"] / 0.005), int(args["step"] / 0.005)
+        heights_range = np.arange(lo, hi + st, st)
+        coarse = rs.choice(heights_range, (int(80 * 0.1 / args["downsampled_scale"]), int(80 * 0.1 / args["downsampled_scale"])))
+        x = np.linspace(0, 80 * 0.1, coarse.shape[0])
+        y = np.linspace(0, 80 * 0.1, coarse.shape[1])
+        f = RectBivariateSpline(y, x, coarse.T.astype(np.float64), kx=1, ky=1, s=0)        # interp2d(y, x, z, kind='linear')
+        xu, yu = np.linspace(0, 80 * 0.1, 80), np.linspace(0, 80 * 0.1, 80)
+        z = np.rint(f(yu, xu).T)                                                              # f(y_upsampled, x_upsampled): rows = x
+        assert np.array_equal(t.height_field_raw, base + z.astype(np.int16)), seed
+        assert np.abs(z).max() > 0
+
+
 def test_height_lookup_is_bilinear():
     t = Terrain(TerrainCfg(mesh_type="heightfield", curriculum=True, num_rows=2, num_cols=2, border_size=1,
                            terrain_proportions=[1.0, 0.0, 0.0, 0.0, 0.0]), 4, seed=0)
