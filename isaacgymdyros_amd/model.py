@@ -295,6 +295,12 @@ def compile_mjcf(xml_path: str) -> Dict:
         sc_pairs.append([idx[side + "Armlink_Link"], idx[SC_TORSO_BODY]])    # upper arm against the torso
     sc_pairs += [[idx["L_Forearm_Link"], idx["R_Forearm_Link"]], [idx["L_Wrist2_Link"], idx["R_Wrist2_Link"]],
                  [idx["L_Wrist2_Link"], idx["R_Forearm_Link"]], [idx["L_Forearm_Link"], idx["R_Wrist2_Link"]]]
+    # third tranche (towards the reference's filter 0, tasks/dyros_dynamic_walk.py:354): each hand against the thigh of the OTHER
+    # side.  With it the pair table of the kernels (32) is full.  A head capsule does not fit the octet kernels' budget of four
+    # proxies per lane (its lane already carries an arm and the torso); what is still absent is listed in DESIGN.md section 2
+    other = {"L_": "R_", "R_": "L_"}
+    for side in ("L_", "R_"):
+        sc_pairs.append([idx[side + "Wrist2_Link"], thigh[other[side]]])
 
     model = dict(
         body_names=names,
