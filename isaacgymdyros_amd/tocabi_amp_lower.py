@@ -17,7 +17,7 @@ DyrosDynamicWalk step fuses); observation, reward and termination are one HIP la
 tensor they need (base, the two foot links) come from dw_body_positions.  The bookkeeping between them -- history shifts,
 the command ramp, the torque FIFO -- is a few dozen elementwise torch launches per step on [N,12]..[N,480] tensors: this task
 is the reference's sibling, not the north star's hot path, and is NOT fused into one kernel the way VecTask.step of
-DyrosDynamicWalk is (DESIGN.md section 8).  Random draws are torch's device generator, as in the reference: the class is held
+DyrosDynamicWalk is (DESIGN.md section 9).  Random draws are torch's device generator, as in the reference: the class is held
 to the reference statistically, its three pure functions bit for bit.
 
 Not built: the motion-library state initialisation and the discriminator observations of the subclass
