@@ -95,8 +95,16 @@ DQ_HD void stage_hot(QHot &HW, const QuadModel &QM) {
     const int l = lane_id();
     const F4 *src = reinterpret_cast<const F4 *>(&QM.hot);
     F4 *dst = reinterpret_cast<F4 *>(&HW);
-    constexpr int NQ = (int)(sizeof(QHot) / 16);
-    for (int i = l; i < NQ; i += 64) dst[i] = src[i];
+    constexpr int NQ = (int)(sizeof(QHot) / 16), IT = (NQ + 63) / 64;
+    // every piece requested before the first one is stored: as a loop this was one memory round trip per 1 KB (the store of
+    // an iteration waits for its load, and the next load is issued after the store)
+    float tx[IT], ty[IT], tz[IT], tw[IT];
+    DQ_UNROLL for (int k = 0; k < IT; ++k) {
+        const int i = l + 64 * k;
+        const F4 v = src[i < NQ ? i : 0];
+        tx[k] = v.x; ty[k] = v.y; tz[k] = v.z; tw[k] = v.w;
+    }
+    DQ_UNROLL for (int k = 0; k < IT; ++k) { const int i = l + 64 * k; if (i < NQ) dst[i] = mk4(tx[k], ty[k], tz[k], tw[k]); }
     wave_sync();
 }
 
