@@ -220,8 +220,11 @@ def _sync(device):
 
 # ------------------------------------------------------------------------------------------------ the loop
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
-          rank=0, world=1, seed=42):
-    """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch."""
+          rank=0, world=1, seed=42, graph_rollout=False):
+    """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch.
+    graph_rollout: one rollout step (policy inference, sampling, env step, bookkeeping) is captured once in a hipGraph and
+    replayed `horizon` times per epoch -- possible because dw_step_dev keeps the step counter in device memory, so a replayed
+    launch draws fresh noise (include/dyros_walk.h).  The eager loop pays ~40 kernel launches and two host syncs per step."""
     from isaacgymdyros_amd.config import default_cfg
     from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
     cfg = cfg or TRAIN_CFG
@@ -232,6 +235,9 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     if own_env:
         ecfg = default_cfg(num_envs, device)
         ecfg["seed"] = seed + rank
+        if graph_rollout:
+            ecfg["sim"]["mi355"]["device_step_counter"] = True
+            ecfg["sim"]["mi355"]["alias_obs"] = True          # (the loop copies what it keeps)
         env = DyrosDynamicWalk(ecfg, device, 0, True)
     N = env.num_envs
     torch.manual_seed(seed)                          # same initial weights on every rank
@@ -260,6 +266,44 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     mbs = min(int(c["minibatch_size"]), batch)
     assert batch % mbs == 0, "horizon * num_envs must be a multiple of minibatch_size (a2c_common_dyros.py:192)"
     stats = []
+    graph = None
+    if graph_rollout:
+        if not str(device).startswith("cuda") or getattr(env, "_step_dev", None) is None:
+            raise ValueError("graph_rollout needs a GPU env with cfg sim.mi355.device_step_counter = True")
+        g_obs, g_dones = obs.clone(), dones.clone()
+        g_n = torch.zeros(1, dtype=torch.long, device=device)
+        g_terms = torch.zeros(len(names) or 15, device=device)
+
+        def rollout_step():
+            mu, logstd, value = net(g_obs)
+            sigma = torch.exp(logstd)
+            a = mu + sigma * torch.randn_like(mu)           # (Normal(mu, sigma).sample() and torch.normal check sigma >= 0 on the host: a sync, not capturable)
+            for k, v in (("obs", g_obs), ("act", a), ("mu", mu), ("neglogp", neglogp(a, mu, sigma, logstd)), ("val", value), ("done", g_dones)):
+                mb[k].index_copy_(0, g_n, v.unsqueeze(0))
+            o, r, d, infos = env.step(torch.clamp(a, -1.0, 1.0))
+            r = r.unsqueeze(1) * c["reward_scale"]
+            if c["value_bootstrap"] and "time_outs" in infos:
+                r = r + c["gamma"] * value * infos["time_outs"].unsqueeze(1).float()
+            mb["rew"].index_copy_(0, g_n, r.unsqueeze(0))
+            if "stacked_rewards" in infos:
+                g_terms.add_(infos["stacked_rewards"][:, :g_terms.numel()].mean(0))
+            g_dones.copy_(d.float())
+            g_obs.copy_(o["obs"])
+            g_n.add_(1)
+
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(3):                                                  # (warm-up on the side stream, as capture requires)
+                g_n.zero_()
+                rollout_step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        g_n.zero_()
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+            rollout_step()
+        obs, dones = g_obs, g_dones
     for ep in range(1, epochs + 1):
         net.update_action_noise((max_epochs - ep) / max_epochs)                 # a2c_common_dyros.py:985
         lr = sched(ep)
@@ -269,7 +313,13 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         step_time = 0.0
         terms = torch.zeros(len(names) or 15, device=device)
         with torch.no_grad():                                                   # a2c_common_dyros.py:842
-            for n in range(H):
+            if graph is not None:
+                g_n.zero_(); g_terms.zero_()
+                for n in range(H):
+                    graph.replay()
+                terms = g_terms.clone()
+                step_time = float("nan")                                        # (the env step is not separable inside the graph)
+            for n in range(H if graph is None else 0):
                 mu, logstd, value = net(obs)
                 sigma = torch.exp(logstd)
                 a = torch.distributions.Normal(mu, sigma).sample()
@@ -289,6 +339,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             last_values = net(obs)[2]
             advs = discount_values(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
             returns = advs + mb["val"]
+        _sync(device)                                                           # (the rollout's device work is part of play_time in both modes)
         play_time = time.perf_counter() - t0
         # swap_and_flatten01: env-major flat batch, minibatches are contiguous slices (no shuffling in rl_games' dataset)
         flat = lambda x: x.transpose(0, 1).reshape(batch, *x.shape[2:])        # noqa: E731

@@ -365,6 +365,21 @@ def test_ppo_consumer_drives_the_env():
     assert stats[0]["lr"] > stats[1]["lr"]
 
 
+def test_ppo_rollout_step_captured_in_a_graph():
+    """The rollout step of the PPO loop (policy inference, sampling, env step through dw_step_dev, bookkeeping) captured once in
+    a hipGraph and replayed: the epoch statistics stay in the range of the eager loop's, every slot of the horizon is filled,
+    and the env's device step counter has advanced once per replayed step (fresh noise per replay)."""
+    mod = _ppo()
+    eager = mod.train(num_envs=1024, epochs=2, horizon=32, log=lambda *_: None)
+    graph = mod.train(num_envs=1024, epochs=2, horizon=32, log=lambda *_: None, graph_rollout=True)
+    for e, g in zip(eager, graph):
+        assert np.isfinite([g["mean_reward"], g["a_loss"], g["c_loss"], g["kl"], g["play_fps"]]).all()
+        assert abs(g["mean_reward"] - e["mean_reward"]) < 0.15, (g["mean_reward"], e["mean_reward"])
+        assert len(g["reward_terms"]) == 15 and abs(sum(list(g["reward_terms"].values())[:14]) - g["mean_reward"]) < 0.05
+        assert g["mean_episode_length"] >= 0
+    assert graph[0]["sigma"] > graph[1]["sigma"]                        # the in-place sigma schedule reaches the captured graph
+
+
 def test_config3_16384_envs_with_the_ppo_loop_attached():
     """BASELINE config 3 at full size: 16384 envs, horizon 128, the DYROS PPO epoch (5 mini-epochs over minibatches of 4096).
     Finite losses, the per-term reward means logged from extras["stacked_rewards"], env stepping at a sane rate with a host
