@@ -36,6 +36,8 @@ template <bool TERRAIN>
 DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     if (wave_index * EPO >= C.num_envs) return;      // the second wave of the last workgroup may have no env at all (wave-uniform exit; no barrier follows)
+    int c_num_envs = C.num_envs, c_freeze = C.freeze_physics;          // (launch-invariant, read by every item of every phase)
+    DQ_SGPR_KEEP(c_num_envs); DQ_SGPR_KEEP(c_freeze);
     DQ_STAMP(B, 54);
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)          // (timing experiment: the life of every wave, tools/wave_times.py)
     const long long dq_t0 = (long long)__builtin_readcyclecounter();
@@ -45,7 +47,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     //      the hot tables -- in one straight run, so that the wave waits for memory once.  (Each request a lone wave waits
     //      for costs ~4 k cycles, about 1 % of the step: phase_stamps) ====
     OLane X;
-    oct_lane_init(X, QM.hot, wave_index, C.num_envs, C.phys, C.friction, B);
+    oct_lane_init(X, QM.hot, wave_index, c_num_envs, C.phys, C.friction, B);
     const int e = X.env, f = X.j & 1;
     // (record fields of my env: B.env_state[ES(field)]; no base pointer is held across the phases)
 #define OQ_ES(f) B.env_state[(size_t)DW_ES_WORDS * e + (f)]
@@ -58,7 +60,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     DQ_UNROLL for (int k = 0; k < NAI; ++k) {
         const int i = X.lane + 64 * k, ic = i < EPO * DW_NUM_ACT ? i : 0;
         const int el = ic / DW_NUM_ACT, a = ic - DW_NUM_ACT * el;
-        const int eg = wave_index * EPO + el, egc = eg < C.num_envs ? eg : C.num_envs - 1;
+        const int eg = wave_index * EPO + el, egc = eg < c_num_envs ? eg : c_num_envs - 1;
         r_act[k] = actions[DW_NUM_ACT * egc + a];
         r_head[k] = B.env_state[(size_t)DW_ES_WORDS * egc + DW_ES_HIST_HEAD];
     }
@@ -68,9 +70,9 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         DQ_OPAQUE(i);                 // (recomputed at every use: five sets of derived indices held across the physics cost 20 registers)
         it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
         const int eg = wave_index * EPO + it.el;
-        it.ok = (i < EPO * ND) && (eg < C.num_envs);
+        it.ok = (i < EPO * ND) && (eg < c_num_envs);
         if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }
-        it.env = eg < C.num_envs ? eg : C.num_envs - 1;
+        it.env = eg < c_num_envs ? eg : c_num_envs - 1;
         it.pos = pcode_cell(0, 0, 0);
         return it;
     };
@@ -192,7 +194,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             const int eg = wave_index * EPO + el;
             float v = fminf(fmaxf(r_act[k], -1.0f), 1.0f);
             if (a == 12) v = (v > 0 ? 1.0f : 0.0f) * v;
-            if (i < EPO * DW_NUM_ACT && eg < C.num_envs) {
+            if (i < EPO * DW_NUM_ACT && eg < c_num_envs) {
                 B.action_history[((size_t)eg * DW_HIST_SLOTS + f2i(r_head[k])) * DW_NUM_ACT + a] = v;
                 B.env_state[(size_t)DW_ES_WORDS * eg + DW_ES_ACTIONS + a] = v;
             }
@@ -247,7 +249,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         // kernel -- no envs -- is not waited for)
         __builtin_amdgcn_s_barrier();
 #endif
-        if (!C.freeze_physics) oct_substep<TERRAIN>(L, H, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
+        if (!c_freeze) oct_substep<TERRAIN>(L, H, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
         wave_sync();
         // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep.  Four
         //      straight-line blocks -- every request, the noise, the arithmetic, every store -- with no branch between two requests:
@@ -291,7 +293,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             const int d = its[k].d;
             float q = qkeep[k], qd = qdkeep[k];
-            if (!C.freeze_physics) {
+            if (!c_freeze) {
                 qd = fin[k].y; q = qkeep[k] + dt * qd;
                 if (q < fin[k].x) { q = fin[k].x; if (qd < 0) qd = 0; }
                 if (q > fin[k].z) { q = fin[k].z; if (qd > 0) qd = 0; }
@@ -307,18 +309,18 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         // substep's encoder draw and the slot inputs of the second substep
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             if (its[k].ok) {
-                if (!C.freeze_physics) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
+                if (!c_freeze) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
                 if (sub == 0) {
                     B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d] = qno[k];
                     if (!noise) B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + PK_NZ1 + its[k].d] = n1[k];
                 }
             }
-            if (sub == 0 && !C.freeze_physics && X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, ips[k]) = nxt[k];
+            if (sub == 0 && !c_freeze && X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, ips[k]) = nxt[k];
         }
         wave_sync();
         DQ_STAMP(B, 1 + 16 * sub + 14);
     }
-    if (X.valid && !C.freeze_physics && X.o == 0) {
+    if (X.valid && !c_freeze && X.o == 0) {
         int e2 = e;
         DQ_OPAQUE(e2);            // (the row's address again from the index: held since the loads at the top it is a register pair through both substeps)
         DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e2 + i] = X.root[i];

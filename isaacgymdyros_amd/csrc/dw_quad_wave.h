@@ -29,6 +29,9 @@
 #include <hip/hip_runtime.h>
 #define DQ_HD __device__ __forceinline__
 #define DQ_OPAQUE(i) asm volatile("" : "+v"(i))
+// a wave-uniform value pinned in a scalar register: the compiler may otherwise re-load a launch-invariant parameter from memory at
+// every use instead of keeping it (a scalar-memory round trip on the critical path of a lone wave)
+#define DQ_SGPR_KEEP(x) asm volatile("" : "+s"(x))
 // the machine scheduler moves nothing across this point: bounds how many iterations of an unrolled loop it overlaps (and with
 // them the registers their loads occupy)
 #define DQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -90,6 +93,7 @@ DQ_HD void atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicA
 #include <string.h>
 #define DQ_HD static inline
 #define DQ_OPAQUE(i) ((void)0)
+#define DQ_SGPR_KEEP(x) ((void)0)
 #define DQ_SCHED_FENCE() ((void)0)
 #if defined(__SANITIZE_ADDRESS__)
 extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
