@@ -41,6 +41,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     DQ_STAMP(B, 54);
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)          // (timing experiment: the life of every wave, tools/wave_times.py)
     const long long dq_t0 = (long long)__builtin_readcyclecounter();
+    const long long dq_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     // ==== round 1 of requests: everything whose address is known at entry -- the base state, the scalars of the record the
     //      pre-physics phase reads, the actions, the inputs of the actuator model for this lane's nine (env, joint) items,
@@ -345,6 +346,12 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     if (X.lane == 0) {
         B.stacked_rewards[(size_t)wave_index * EPO * DW_NUM_REW + 14] = (float)((long long)__builtin_readcyclecounter() - dq_t0);
         B.stacked_rewards[(size_t)wave_index * EPO * DW_NUM_REW + 13] = (float)(dq_t1 - dq_t0);          // physics part
+        // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID, as exact small integers in two floats of env 2's row
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 1] = (float)(hw & 0xffff);
+        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 2] = (float)(xcc & 0xf);
+        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 3] = (float)(dq_r0 & 0xffffff);      // start time, 100 MHz clock common to the chip (low bits)
+        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 4] = (float)((long long)__builtin_amdgcn_s_memrealtime() & 0xffffff);      // end time
     }
 #endif
 }

@@ -7,4 +7,4 @@ F="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fno-strict-aliasing -fno-slp-vect
 hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp -c -o isaacgymdyros_amd/_ab/st_a.o isaacgymdyros_amd/csrc/dw_hip.hip
 hipcc $F -c -o isaacgymdyros_amd/_ab/st_b.o isaacgymdyros_amd/csrc/dw_quad_kernels.hip
 hipcc $F -c -o isaacgymdyros_amd/_ab/st_c.o isaacgymdyros_amd/csrc/dw_oct_kernels.hip
-hipcc --offload-arch=gfx950 -shared -fPIC -o isaacgymdyros_amd/_ab/libdw_stamps.so isaacgymdyros_amd/_ab/st_a.o isaacgymdyros_amd/_ab/st_b.o isaacgymdyros_amd/_ab/st_c.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o isaacgymdyros_amd/_ab/libdw_stamps.so isaacgymdyros_amd/_ab/st_a.o isaacgymdyros_amd/_ab/st_b.o isaacgymdyros_amd/_ab/st_c.o isaacgymdyros_amd/_obj/dw_amp.o
