@@ -896,3 +896,46 @@ def test_sliding_sole_contacts_with_friction_dr_vs_oracle(task_const, pipeline):
     assert keep.sum() > N // 2
     dq = np.abs(env.dof_pos.cpu().numpy()[keep] - ora.buf["dof_state"][keep, :, 0]).max()
     assert dq < 1e-4, dq
+
+
+def test_physics_only_handle_as_the_engine_behind_the_references_own_task(task_const):
+    """INTEGRATION.md section 2 (`Mi355Gym`): dw_create(task = NULL) + a bind of the physics tensors alone is the engine the
+    reference's own task file would drive -- set_dof_actuation_force_tensor + simulate + refresh_* = dw_simulate.  The partial
+    handle tracks the physics of a full one on the same state and torques, and refuses the task entry points."""
+    import ctypes as C
+    from isaacgymdyros_amd import _lib, abi
+    from isaacgymdyros_amd.model import load_model
+    from hip_backend import make_env
+    N = 64
+    full = make_env(N)
+    lib, api = _lib.load()
+    cfg = abi.DwConfig.from_buffer_copy(full._ccfg)             # (the same contact-model knobs as the full handle)
+    cm = load_model().to_c()
+    h = C.c_void_p()
+    assert api["create"](C.byref(cfg), C.byref(cm), None, C.byref(h)) == 0, lib.dw_last_error()
+    names = ("root_states", "dof_state", "contact_forces", "mass_scale", "dof_damping", "dof_armature", "friction_scale")
+    buf = {k: full._buf[k].clone() for k in names}
+    db = abi.DwBuffers()
+    for k in names:
+        setattr(db, k, buf[k].data_ptr())
+    assert api["bind"](h, C.byref(db)) == 0, lib.dw_last_error()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for t in range(20):
+        tau = (torch.rand(N, 33, generator=g, device="cuda") * 2 - 1) * 30
+        assert api["simulate"](h, tau.data_ptr(), None, None) == 0, lib.dw_last_error()
+        full.simulate(tau)
+    torch.cuda.synchronize()
+    # (not bit for bit: the contact solver warm-starts from the impulses it keeps in the task record, env_state, which a
+    #  physics-only handle does not have -- it starts every solve from zero and converges to the same contact within the tolerance)
+    assert float((buf["root_states"][:, :3] - full._buf["root_states"][:, :3]).abs().max()) < 2e-3
+    assert float((buf["dof_state"][..., 0] - full._buf["dof_state"][..., 0]).abs().max()) < 5e-3
+    fz_a, fz_b = buf["contact_forces"][:, [8, 16], 2].sum(1), full._buf["contact_forces"][:, [8, 16], 2].sum(1)
+    assert float((fz_a - fz_b).abs().mean()) < 0.05 * float(fz_b.abs().mean()) + 1.0
+    assert float(buf["contact_forces"].abs().max()) > 10.0            # the feet did touch down in those 20 substeps
+    # no task constants, no task buffers: the task entry points refuse
+    a = torch.zeros(N, 13, device="cuda")
+    assert api["step"](h, a.data_ptr(), None, 0, None) != 0 and b"dw_step" in lib.dw_last_error()
+    ids = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert api["reset_idx"](h, ids.data_ptr(), 1, None, 0, None) != 0
+    assert api["destroy"](h) == 0
+    full.close()
