@@ -17,8 +17,13 @@ DyrosDynamicWalk step fuses); observation, reward and termination are one HIP la
 tensor they need (base, the two foot links) come from dw_body_positions.  The bookkeeping between them -- history shifts,
 the command ramp, the torque FIFO -- is a few dozen elementwise torch launches per step on [N,12]..[N,480] tensors: this task
 is the reference's sibling, not the north star's hot path, and is NOT fused into one kernel the way VecTask.step of
-DyrosDynamicWalk is.  Random draws are torch's device generator, as in the reference: the class is held
-to the reference statistically, its three pure functions bit for bit.
+DyrosDynamicWalk is.  Random draws are torch's device generator, as in the reference; the generator and
+`simulate` are injectable, and tests/test_amp_gpu.py replays the reference CLASS' recorded draws and physics states through this
+class for 60 steps (tests/golden/amp_class_ref.npz): every state field, the torques handed to the engine and the reset flow are
+bit-identical, the observation and reward to the rounding of atan2f / expf.  Four things that replay found and that are now as
+the reference has them: the gains are quotients rounded once from double; the TorchScript observation function adds the
+encoder bias to `qpos_noise` IN PLACE; `x / dt` divides on the CPU and multiplies by a reciprocal on the GPU (cfg
+sim.mi355.torch_gpu_div picks the flavour); the command ramp multiplies before it divides.
 
 Not built: the motion-library state initialisation and the discriminator observations of the subclass
 (tasks/tocabi_amp_lower.py: `stateInit` Random / Hybrid, `_compute_amp_observations`), which need the reference's motion
@@ -80,6 +85,27 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class TorchDraws:
+    """The class' source of random numbers: torch's device generator, one method per kind of draw the reference makes
+    (torch.rand, torch.randint, torch.normal).  A test replaces it with a replay of the reference's recorded draws
+    (tests/test_amp_gpu.py), which is why every draw of the class goes through here and happens in the reference's order --
+    including the draws of size zero the reference makes every step for the command ramp."""
+
+    def __init__(self, device, seed):
+        self.device = device
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
+
+    def rand(self, *shape):
+        return torch.rand(*shape, device=self.device, generator=self.gen)
+
+    def randint(self, lo, hi, shape):
+        return torch.randint(lo, hi, shape, device=self.device, generator=self.gen)
+
+    def normal(self, shape, std):
+        return torch.randn(*shape, device=self.device, generator=self.gen) * std
+
+
 class TocabiAMPLower(VecTask):
 
     def __init__(self, cfg: Dict[str, Any], sim_device: str, graphics_device_id: int = 0, headless: bool = True):
@@ -135,8 +161,9 @@ class TocabiAMPLower(VecTask):
         self.init_angle = torch.tensor(INIT_ANGLE, **f)
         self.motor_efforts = torch.tensor(ACTION_HIGH[:12], **f)                              # :357-358 (ctrlrange upper limits)
         self.max_motor_effort = float(self.motor_efforts.max())
-        self.p_gains = torch.tensor(P_GAINS, **f) / 9.0
-        self.d_gains = torch.tensor(D_GAINS, **f) / 3.0
+        # (the quotients are formed in double and rounded once, as the reference's element-wise assignment does, :167-168)
+        self.p_gains = torch.tensor([p / 9.0 for p in P_GAINS], **f)
+        self.d_gains = torch.tensor([d / 3.0 for d in D_GAINS], **f)
         self._nominal_damping = torch.full((33,), 0.1, **f)                                    # :441
         self._nominal_armature = torch.tensor(ARMATURE, **f)
         b["dof_damping"][:] = self._nominal_damping
@@ -173,10 +200,11 @@ class TocabiAMPLower(VecTask):
         self.qpos_bias, self.quat_bias = torch.zeros(N, 12, **f), torch.zeros(N, 3, **f)
         self.qpos_noise, self.qvel_noise, self.qpos_pre = (torch.zeros(N, 33, **f) for _ in range(3))
         self.epi_len, self.epi_len_log = torch.zeros(N, **f), torch.zeros(N, **f)
-        self._gen = torch.Generator(device=dev)
-        self._gen.manual_seed(int(cfg.get("seed", 42)))
+        self._gpu_div = bool(cfg["sim"].get("mi355", {}).get("torch_gpu_div", True))
+        self._rng = TorchDraws(dev, cfg.get("seed", 42))
+        self._simulate = self._phys.simulate          # (`gym.simulate`; a test injects recorded physics states here)
         self.perturbation_count = torch.zeros(N, device=dev, dtype=torch.long)
-        self.pert_duration = torch.randint(1, 100, (N,), device=dev, generator=self._gen)
+        self.pert_duration = self._rng.randint(1, 100, (N,))
         self.pert_on = torch.zeros(N, device=dev, dtype=torch.bool)
         self.impulse = torch.zeros(N, device=dev, dtype=torch.long)
         self.magnitude, self.phase = torch.zeros(N, **f), torch.zeros(N, **f)
@@ -205,7 +233,13 @@ class TocabiAMPLower(VecTask):
 
     # ------------------------------------------------------------------ helpers
     def _rand(self, *shape):
-        return torch.rand(*shape, device=self._tdev, generator=self._gen)
+        return self._rng.rand(*shape)
+
+    def _div(self, x, s):
+        """`tensor / python_scalar` as torch does it: its GPU kernels multiply by float(1 / s), its CPU kernels divide (the last
+        bit differs).  cfg sim.mi355.torch_gpu_div (default True) = what the reference would compute on a GPU; False = the CPU
+        flavour the fixtures were recorded with (a tensor divisor makes the GPU divide too)."""
+        return x / s if self._gpu_div else x / torch.tensor(float(s), device=x.device, dtype=x.dtype)
 
     def _rand_float(self, lo, hi, shape):                 # torch_rand_float (python/isaacgym/torch_utils.py:50-52)
         return (hi - lo) * self._rand(*shape) + lo
@@ -213,10 +247,13 @@ class TocabiAMPLower(VecTask):
     def _chk(self, rc):
         _lib.check(self._api, rc)
 
+    def _foot_positions(self):
+        self._chk(self._api["body_positions"](self._phys._h, self._foot_mv, 2, _p(self._foot_pos), None))
+
     def _refresh_sim_tensors(self):
         """refresh_*_tensor of the reference (:527-538): the Gym tensors are the physics' own buffers; the three rigid-body rows
         the reset needs are recomputed from them."""
-        self._chk(self._api["body_positions"](self._phys._h, self._foot_mv, 2, _p(self._foot_pos), None))
+        self._foot_positions()
         self._rigid_body_pos[:, 0] = self._root_states[:, 0:3]
         self._rigid_body_pos[:, 8] = self._foot_pos[:, 0]
         self._rigid_body_pos[:, 16] = self._foot_pos[:, 1]
@@ -266,8 +303,8 @@ class TocabiAMPLower(VecTask):
         self.qpos_pre[env_ids] = self._initial_dof_pos[env_ids]
         self.qvel_noise[env_ids] = 0.0
         if self.noise:
-            self.qpos_bias[env_ids] = self._rand(n, 12) * 6.28 / 100 - 3.14 / 100
-            self.quat_bias[env_ids] = self._rand(n, 3) * 6.28 / 150 - 3.14 / 150
+            self.qpos_bias[env_ids] = self._div(self._rand(n, 12) * 6.28, 100) - 3.14 / 100
+            self.quat_bias[env_ids] = self._div(self._rand(n, 3) * 6.28, 150) - 3.14 / 150
         else:
             self.qpos_bias[env_ids] = 0.0
             self.quat_bias[env_ids] = 0.0
@@ -276,11 +313,11 @@ class TocabiAMPLower(VecTask):
         self.epi_len[env_ids] = 0
         self.perturbation_count[env_ids] = 0
         self.pert_on[env_ids] = False
-        self.perturb_timing[env_ids] = torch.randint(0, int(8 / 0.002), (n,), device=self._tdev, generator=self._gen)
+        self.perturb_timing[env_ids] = self._rng.randint(0, int(8 / 0.002), (n,))
         self.obs_history[env_ids] = 0
         self.action_history[env_ids] = 0
         self.action_log[env_ids] = 0
-        self.delay_idx[env_ids] = torch.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,), device=self._tdev, generator=self._gen)
+        self.delay_idx[env_ids] = self._rng.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,))
         self.simul_len[env_ids] = 0
 
     # ------------------------------------------------------------------ observations (:540-610)
@@ -295,6 +332,10 @@ class TocabiAMPLower(VecTask):
     def _compute_observations(self, env_ids=None):
         obs = self._compute_humanoid_obs()
         if env_ids is None:
+            # the reference's TorchScript function adds the bias to the tensor it is handed, IN PLACE (`dof_pos[:, :12] +=
+            # dof_pos_bias`, :945), and on this path that tensor is self.qpos_noise itself: the encoder reading carries the
+            # bias from here to the next substep -- and an env that resets now shows it twice in its reset observation
+            self.qpos_noise[:, :12] += self.qpos_bias
             self.obs_history = torch.cat((self.obs_history[:, NUM_OBS:], obs), dim=-1)
         else:
             self.obs_history[env_ids] = obs[env_ids].repeat(1, self.num_obs_his * self.num_obs_skip)
@@ -317,8 +358,8 @@ class TocabiAMPLower(VecTask):
             ns = int(start.sum())
             if ns:
                 self.pert_on[start] = True
-                self.impulse[start] = torch.randint(50, 250, (ns,), device=dev, generator=self._gen)
-                self.pert_duration[start] = torch.randint(int(0.1 / 0.002), int(1 / 0.002), (ns,), device=dev, generator=self._gen)
+                self.impulse[start] = self._rng.randint(50, 250, (ns,))
+                self.pert_duration[start] = self._rng.randint(int(0.1 / 0.002), int(1 / 0.002), (ns,))
                 self.magnitude[start] = self.impulse[start] / (self.pert_duration[start] * 0.002)
                 self.phase[start] = self._rand(ns) * 2 * 3.14159265358979
             self.perturbation_count = torch.where(self.pert_on, self.perturbation_count + 1, self.perturbation_count)
@@ -331,15 +372,16 @@ class TocabiAMPLower(VecTask):
         if self.vel_change:
             change = (self.epi_len % int(self.max_episode_length / 2)) == int(self.max_episode_length / 4 - 1)
             nc = int(change.sum())
-            if nc:
-                self.vel_change_duration[change] = torch.randint(1, 250, (nc,), device=dev, generator=self._gen)
-                self.cur_vel_change_duration[change] = 0
-                self.start_target_vel[change] = self.commands[change]
-                self.final_target_vel[change, 0] = self._rand_float(self.c_x[0], self.c_x[1], (nc,))
-                self.final_target_vel[change, 1] = self._rand_float(self.c_y[0], self.c_y[1], (nc,))
-                self.final_target_vel[change, 2] = self._rand_float(self.c_yaw[0], self.c_yaw[1], (nc,))
+            # (the four draws happen every step, of size zero when no env changes its command: the reference's generator stream)
+            self.vel_change_duration[change] = self._rng.randint(1, 250, (nc,))
+            self.cur_vel_change_duration[change] = 0
+            self.start_target_vel[change] = self.commands[change]
+            self.final_target_vel[change, 0] = self._rand_float(self.c_x[0], self.c_x[1], (nc,))
+            self.final_target_vel[change, 1] = self._rand_float(self.c_y[0], self.c_y[1], (nc,))
+            self.final_target_vel[change, 2] = self._rand_float(self.c_yaw[0], self.c_yaw[1], (nc,))
             mask = self.cur_vel_change_duration < self.vel_change_duration
-            ramp = self.start_target_vel + (self.final_target_vel - self.start_target_vel) * (self.cur_vel_change_duration / self.vel_change_duration).unsqueeze(-1)
+            # (the reference's order of operations, :690-691: difference times elapsed, then divided by the duration)
+            ramp = self.start_target_vel + (self.final_target_vel - self.start_target_vel) * self.cur_vel_change_duration.unsqueeze(-1) / self.vel_change_duration.unsqueeze(-1)
             self.commands = torch.where(mask.unsqueeze(-1), ramp, self.commands)
             self.cur_vel_change_duration += mask.long()
         for _ in range(self.control_freq_inv):
@@ -357,14 +399,14 @@ class TocabiAMPLower(VecTask):
                 delayed = torch.where(filled.unsqueeze(-1), self.action_log[self._env_ar, self.delay_idx], self.action_log[self._env_ar, -self.simul_len])
                 if self.noise:
                     lower = delayed
-            self._phys.simulate(torch.cat((lower, upper), dim=1).contiguous(), push)
+            self._simulate(torch.cat((lower, upper), dim=1).contiguous(), push)
             push = None                                  # (applied forces last one simulate())
             if self.noise:
-                z = torch.randn(N, 33, device=dev, generator=self._gen) * (0.00016 / 3.0)
+                z = self._rng.normal((N, 33), 0.00016 / 3.0)
                 self.qpos_noise = self._dof_pos + torch.clamp(z, min=-0.00016, max=0.00016)
             else:
                 self.qpos_noise = self._dof_pos.clone()
-            self.qvel_noise = (self.qpos_noise - self.qpos_pre) / self.dt
+            self.qvel_noise = self._div(self.qpos_noise - self.qpos_pre, self.dt)
             self.qpos_pre = self.qpos_noise.clone()
         self.epi_len += 1
 

@@ -143,3 +143,100 @@ def test_tocabi_amp_lower_env_steps():
     assert total_resets > 0                       # random torques make robots fall: the termination path ran
     assert extras["reward_values"].shape == (N, 9) and len(extras["reward_names"]) == 9
     env.close()
+
+
+class _ReplayDraws:
+    """The reference class' recorded torch draws, handed out in order (oracle/make_amp_class_goldens.py).  Kind and element
+    count of every request must match the recording: the class then makes the reference's draws in the reference's order."""
+
+    def __init__(self, g):
+        self.kind, self.off, self.data = [str(k) for k in g["draw_kind"]], g["draw_offset"], g["draw_data"]
+        self.i = 0
+
+    def _next(self, kind, shape):
+        assert self.i < len(self.kind), "the class draws more than the reference did"
+        assert self.kind[self.i] == kind, (self.i, self.kind[self.i], kind)
+        v = self.data[self.off[self.i]:self.off[self.i + 1]]
+        n = int(np.prod(shape)) if len(shape) else 1
+        assert len(v) == n, (self.i, kind, len(v), shape)
+        self.i += 1
+        return torch.from_numpy(np.ascontiguousarray(v)).cuda().reshape(shape)
+
+    def rand(self, *shape):
+        return self._next("rand", shape)
+
+    def randint(self, lo, hi, shape):
+        return self._next("randint", tuple(shape)).long()
+
+    def normal(self, shape, std):
+        return self._next("normal", tuple(shape))
+
+
+def test_tocabi_amp_lower_class_replays_the_reference_class():
+    """The reference's TocabiAMPLowerBase stepped 60 times over the oracle's physics (fixture tests/golden/amp_class_ref.npz:
+    its draws, the physics state after every simulate, its outputs).  The host class here is given the same actions, the same
+    draws and the same physics states (its generator and its simulate are injectable) and must produce the reference's numbers:
+    torques handed to the engine, encoder model, command ramp, delayed-torque FIFO, histories, the 468-word observation,
+    reward, termination, time-outs, and the reset flow in the reference's order."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+    g = np.load(os.path.join(os.path.dirname(G), "amp_class_ref.npz"))
+    N, STEPS = int(g["num_envs"]), int(g["steps"])
+    cfg = default_amp_cfg(N, "cuda:0")
+    cfg["env"]["episodeLength"] = int(g["episode_length"])
+    cfg["task"]["randomize"] = False
+    cfg["sim"]["mi355"] = {"amp_initial_height": 0.89, "torch_gpu_div": False}          # (the fixture is torch-CPU arithmetic)
+    env = TocabiAMPLower(cfg, "cuda:0", 0, True)
+    assert np.array_equal(env.motor_efforts.cpu().numpy(), g["motor_efforts"])
+    assert np.array_equal(env.p_gains.cpu().numpy(), g["p_gains"]) and np.array_equal(env.d_gains.cpu().numpy(), g["d_gains"])
+    env.total_mass[:] = torch.from_numpy(g["total_mass"]).cuda()
+    env._rng = _ReplayDraws(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()          # noqa: E731
+    state = {"k": 0, "fresh": False, "tau_err": 0.0}
+    default_feet = env._foot_positions
+
+    def inject(tau, push=None):
+        k = state["k"]
+        state["tau_err"] = max(state["tau_err"], float((tau - T(g["sim_tau"][k])).abs().max()))
+        env._root_states.copy_(T(g["sim_root"][k]))
+        env._dof_state.copy_(T(g["sim_dof"][k]))
+        env._contact_forces.copy_(T(g["sim_contact"][k]))
+        state["k"], state["fresh"] = k + 1, True
+
+    def feet():
+        if state["fresh"]:
+            env._foot_pos.copy_(T(g["sim_feet"][state["k"] - 1]))
+            state["fresh"] = False
+        else:
+            default_feet()
+    env._simulate, env._foot_positions = inject, feet
+
+    def ulps(a, b):
+        return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    exact = {"reset_buf": "reset_buf", "_terminate_buf": "_terminate_buf", "progress_buf": "progress_buf", "commands": "commands",
+             "qpos_noise": "qpos_noise", "qvel_noise": "qvel_noise", "qpos_pre": "qpos_pre", "action_log": "action_log", "epi_len": "epi_len",
+             "qpos_bias": "qpos_bias", "quat_bias": "quat_bias", "_dof_vel_pre": "_dof_vel_pre", "actions_pre": "actions_pre",
+             "action_history": "action_history", "delay_idx": "delay_idx", "simul_len": "simul_len"}
+    for t in range(STEPS):
+        _, ids = env.reset_done()
+        want = g["ref_reset_ids"][t]
+        assert np.array_equal(ids.cpu().numpy(), want[want >= 0]), t
+        env.step(T(g["actions"][t]))
+        for mine, ref in exact.items():
+            a = getattr(env, mine).cpu().numpy()
+            b = g["ref_" + ref][t]
+            assert np.array_equal(a.reshape(b.shape).astype(b.dtype), b), (t, mine, np.abs(a.reshape(b.shape).astype(np.float64) - b).max())
+        assert np.array_equal(env.timeout_buf.cpu().numpy(), g["ref_timeout_buf"][t]), t
+        # the observation: exact but for the three Euler angles of every history slot (atan2f, see the function test)
+        ob, rob = env.obs_buf.cpu().numpy(), g["ref_obs_buf"][t]
+        eul = np.zeros(468, bool)
+        for i in range(10):
+            eul[36 * i:36 * i + 3] = True
+        assert np.array_equal(ob[:, ~eul], rob[:, ~eul]), (t, np.argwhere(ob[:, ~eul] != rob[:, ~eul])[:4])
+        assert np.abs(ob[:, eul] - rob[:, eul]).max() <= 2.4e-7, t
+        oh, roh = env.obs_history.cpu().numpy(), g["ref_obs_history"][t]
+        assert np.abs(oh - roh).max() <= 2.4e-7, t
+        assert np.abs(env.rew_buf.cpu().numpy() - g["ref_rew_buf"][t]).max() <= 2.4e-7, t
+    assert state["k"] == 2 * STEPS and env._rng.i == len(env._rng.kind)          # every simulate and every draw consumed
+    assert state["tau_err"] == 0.0, state["tau_err"]                               # the torques handed to the engine, bit for bit
+    assert g["ref__terminate_buf"].sum() > 0 and (g["ref_reset_ids"][1:] >= 0).sum() > 0          # the fixture terminates and resets envs
+    env.close()

@@ -9,6 +9,9 @@ from isaacgymdyros_amd.config import default_cfg
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 cfg = default_cfg(N, "cuda:0")
+if os.environ.get("DW_TERRAIN"):          # the height-field variant (10 x 20 curriculum map)
+    from isaacgymdyros_amd.config import with_terrain
+    cfg = with_terrain(cfg, mesh_type="trimesh", curriculum=True)
 cfg["sim"]["mi355"]["pipeline"] = int(os.environ.get("DW_PIPE", "0"))          # 2 quad, 3 octet
 env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 g = torch.Generator(device="cuda").manual_seed(42)
