@@ -102,7 +102,7 @@ def amp_cfg(num_envs):
     cfg["physics_engine"] = "physx"
     cfg["env"]["numEnvs"] = num_envs
     cfg["env"]["stateInit"] = "Default"
-    cfg["env"]["episodeLength"] = 40                       # so that the time-out branch and the command ramp both fire inside 60 steps
+    cfg["env"]["episodeLength"] = 31                       # so that falls, time-outs (the robots that are still up at step 30) and the command ramp all occur inside 60 steps
     cfg["sim"]["use_gpu_pipeline"] = False
     cfg["sim"]["physx"].update(num_threads=4, solver_type=1, use_gpu=False, num_subscenes=4)
     cfg["rl_device"] = "cpu"

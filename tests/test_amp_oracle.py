@@ -74,3 +74,31 @@ def test_newwalk_class_cannot_normalise_its_observation(g):
     """tasks/tocabi_new_walk.py:558-567 subtracts a 37-entry mean from a [N,30] observation: torch refuses the shapes, so the class
     never steps and only its reward function is a meaningful parity target."""
     assert "must match" in str(g["nw_broadcast_error"]) and "30" in str(g["nw_broadcast_error"]) and "37" in str(g["nw_broadcast_error"])
+
+
+def test_oracle_termination_on_the_reference_class_run():
+    """The class-level fixture (tests/golden/amp_class_ref.npz: the reference's TocabiAMPLowerBase stepping over the oracle's
+    physics) seen from the CPU side: the oracle's termination function, fed the recorded physics state of every step, returns
+    the reset and terminate flags the reference class produced."""
+    import ctypes as C
+    c = np.load(os.path.join(os.path.dirname(G), "amp_class_ref.npz"))
+    lib, api = oracle.load()
+    N, steps = int(c["num_envs"]), int(c["steps"])
+    ids = np.array([8, 16], np.int32)
+    seen = 0
+    for t in range(steps):
+        k = 2 * t + 1                                   # the state after the step's second simulate()
+        pos = np.zeros((N, 38, 3), np.float32)
+        rot = np.zeros((N, 38, 4), np.float32)
+        pos[:, 0] = c["sim_root"][k][:, 0:3]
+        pos[:, 8], pos[:, 16] = c["sim_feet"][k][:, 0], c["sim_feet"][k][:, 1]
+        rot[:, 0] = c["sim_root"][k][:, 3:7]
+        prog = np.ascontiguousarray(c["ref_progress_buf"][t])
+        cf = np.ascontiguousarray(c["sim_contact"][k])
+        rs, term = np.zeros(N, np.int64), np.zeros(N, np.int64)
+        p = lambda a: C.c_void_p(a.ctypes.data)          # noqa: E731
+        assert api["amp_reset"](N, p(prog), p(cf), p(ids), 2, p(pos), p(rot), float(c["episode_length"]), 1, 0.6, p(rs), p(term), None) == 0
+        assert np.array_equal(rs, c["ref_reset_buf"][t]), t
+        assert np.array_equal(term, c["ref__terminate_buf"][t]), t
+        seen += int(term.sum())
+    assert seen > 0 and int(c["ref_timeout_buf"].sum()) > 0          # falls and time-outs both occur in the run
