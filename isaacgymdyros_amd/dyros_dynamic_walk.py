@@ -140,7 +140,8 @@ class DyrosDynamicWalk(VecTask):
         c.self_collision = int(bool(mi.get("self_collision", True)))
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
-        # which kernels: 0/2 = quad kernels, 4 lanes per env, one launch per step (default), 1 = wave-per-env kernels of round 1
+        # which kernels: 0/3 = octet kernels, 8 lanes per env, two waves per SIMD (default), 2 = quad kernels (4 lanes per env), 1 = wave-per-env
+        # kernels of round 1; one launch per policy step in all three
         c.pipeline = {"auto": 0, "fused": 1, "quad": 2, "oct": 3}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
         tc = self.terrain_cfg
         c.terrain = int(self.custom_origins)
