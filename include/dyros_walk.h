@@ -319,6 +319,14 @@ int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_
  * value: replaying a captured dw_step would replay its noise.) */
 int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream);
 
+/* dw_step with the 487-word observations written to `obs_out` [N,487] (device memory) instead of DwBuffers.obs_buf, for this call
+ * only.  The reference's step returns a FRESH tensor every call (torch.clamp(self.obs_buf, ...), tasks/base/vec_task.py:338): a host
+ * that hands a newly allocated tensor here keeps that contract without a copy of 1 948 B per env after the kernel.  step_counter:
+ * NULL (step_index is used, as dw_step) or the device counter of dw_step_dev.  Pipelines 2 and 3 (they take DwBuffers by value).
+ * (dw_reset_idx never touches obs_buf: a reset env's observations are rebuilt by the next step, as in the reference.) */
+int dw_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t step_index, int64_t *step_counter, float *obs_out,
+                void *stream);
+
 /* reset_idx for the env ids listed (int32, device memory). */
 int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise,
                  int64_t step_index, void *stream);

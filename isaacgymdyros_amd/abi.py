@@ -120,6 +120,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     api["reset_idx"] = fn("reset_idx", C.c_int, H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
     if prefix == "dwe_":        # (the host emulation of the step kernels, tests/emul/, does not carry the row f-3 functions)
         return api
+    api["step_obs"] = fn("step_obs", C.c_int, H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p)
     # row f-3: env-side functions of the sibling TOCABI tasks (device pointers as c_void_p, trailing stream)
     P = C.c_void_p
     api["amp_observations"] = fn("amp_observations", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P)
@@ -131,7 +132,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     return api
 
 
-EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev",
+EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
            "reset_idx", "amp_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions"]
 
 

@@ -222,17 +222,21 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
 __global__ void dw_k_bump(long long *counter) { *counter += 1; }
 
 static int launch_step(DwHandle *h, const float *actions, const float *noise, long long step_index, const long long *step_dev, void *stream,
-                       const char *who) {
+                       const char *who, float *obs_out = nullptr) {
     if (!h || !h->bound || !h->has_task) return fail(DW_ESTATE, "dw_step: handle has no task constants or no buffers bound");
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
+    if (obs_out && h->pipeline != 2 && h->pipeline != 3) return fail(DW_EINVAL, "dw_step_obs: an observation destination per call needs pipeline 2 or 3");
     DeviceGuard guard(h->device);
+    // (the quad / octet kernels take DwBuffers by value: this launch's copy may name another observation buffer)
+    DwBuffers bufs = h->buf;
+    if (obs_out) bufs.obs_buf = obs_out;
     if (h->pipeline == 3) {
-        dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
+        dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
     } else if (h->pipeline == 2) {
-        dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_mocap,
+        dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
     } else if (h->cfg.terrain)
         hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
@@ -257,6 +261,17 @@ int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *
     hipLaunchKernelGGL(dw_k_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)step_counter);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_step_dev: counter launch", e);
+    return DW_OK;
+}
+
+int dw_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t step_index, int64_t *step_counter, float *obs_out, void *stream) {
+    if (!obs_out) return fail(DW_EINVAL, "dw_step_obs: obs_out is null");
+    const int rc = launch_step(h, actions, noise, step_counter ? 0 : (long long)step_index, (const long long *)step_counter, stream, "dw_step_obs: launch", obs_out);
+    if (rc != DW_OK || !step_counter) return rc;
+    DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(dw_k_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)step_counter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip("dw_step_obs: counter launch", e);
     return DW_OK;
 }
 

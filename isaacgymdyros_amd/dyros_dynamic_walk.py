@@ -93,6 +93,8 @@ class DyrosDynamicWalk(VecTask):
         self._step_dev = None
         if self.cfg["sim"].get("mi355", {}).get("device_step_counter", False):
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=self._tdev)
+        self._bound_obs = self._buf["obs_buf"]
+        self._fresh_obs = (not self.alias_obs) and np.isinf(self.clip_obs) and int(self._ccfg.pipeline or 3) in (2, 3)
         self.extras["reward_names"] = list(REWARD_NAMES)
 
     # ------------------------------------------------------------------ native handle
@@ -335,7 +337,17 @@ class DyrosDynamicWalk(VecTask):
                 raise ValueError("noise must be a contiguous float32 [N, DW_NOISE_WORDS] tensor")
             nz = noise.data_ptr()
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
-        if self._step_dev is not None:
+        # The reference returns a FRESH observation tensor every step (torch.clamp(self.obs_buf, ...), vec_task.py:338).  Here the
+        # kernel itself writes this step's observations into a newly allocated tensor (dw_step_obs: the quad / octet kernels take the
+        # buffer table by value, so the destination is a per-launch argument), which becomes self.obs_buf: the contract without the
+        # 1 948 B-per-env copy after the kernel.  alias_obs, a clipping range, the wave-per-env kernels and a captured graph (whose
+        # pointers must not change) keep the bound buffer.
+        fresh = self._fresh_obs and self._step_dev is None
+        if fresh:
+            out = torch.empty_like(self._bound_obs)
+            _lib.check(self._api, self._api["step_obs"](self._h, a.data_ptr(), nz, self._step_count, None, out.data_ptr(), stream))
+            self.obs_buf = self._buf["obs_buf"] = out          # (the newest observations; self._bound_obs stays the tensor dw_bind named)
+        elif self._step_dev is not None:
             # (graph-capturable form: no argument changes from step to step; the kernel reads the counter, a one-thread launch adds 1)
             _lib.check(self._api, self._api["step_dev"](self._h, a.data_ptr(), nz, self._step_dev.data_ptr(), stream))
         else:
@@ -352,7 +364,7 @@ class DyrosDynamicWalk(VecTask):
                 self.extras["reward_names"] = list(REWARD_NAMES) + ["terrain %d level" % i for i in range(nc)]
             means = torch.zeros(nc, device=self._tdev).index_add_(0, self.terrain_types, self.terrain_levels.to(torch.float)) / self._type_counts
             self.extras["stacked_rewards"] = torch.cat([self._buf["stacked_rewards"], means.unsqueeze(0).expand(self.num_envs, nc)], 1)
-        self.obs_dict["obs"] = self._clip_obs(self.obs_buf).to(self.rl_device)
+        self.obs_dict["obs"] = (self.obs_buf if fresh else self._clip_obs(self.obs_buf)).to(self.rl_device)
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 
     def reset_idx(self, env_ids: torch.Tensor, noise: torch.Tensor = None):
@@ -362,6 +374,7 @@ class DyrosDynamicWalk(VecTask):
         nz = noise.data_ptr() if noise is not None else 0
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
         _lib.check(self._api, self._api["reset_idx"](self._h, ids.data_ptr(), int(ids.numel()), nz, self._step_count, stream))
+        # (reset_idx does not touch the observations: the reference recomputes them in the next step's post-physics, :655-669)
 
     def kernel_info(self) -> dict:
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under

@@ -27,6 +27,7 @@ int dwo_destroy(DwHandle *h);
 int dwo_bind(DwHandle *h, const DwBuffers *buffers);
 int dwo_simulate(DwHandle *h, const float *tau, const float *push_xy, void *stream);
 int dwo_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream);
+int dwo_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t step_index, int64_t *step_counter, float *obs_out, void *stream);
 int dwo_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise, int64_t step_index,
                   void *stream);
 int dwo_forward_dynamics(DwHandle *h, int e, const float *tau33, double *qdd, double *a0);

@@ -593,6 +593,17 @@ int dwo_step(DwHandle *h, const float *actions, const float *noise, int64_t step
 }
 
 /* the counter of dw_step_dev is a host word here: read, step, add one */
+/* dw_step_obs: the step with its observations written to obs_out instead of the bound obs_buf */
+int dwo_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t step_index, int64_t *step_counter, float *obs_out, void *stream) {
+    if (!h || !obs_out) return dwo_fail(DW_EINVAL, "dwo_step_obs: null argument");
+    float *bound = h->buf.obs_buf;
+    h->buf.obs_buf = obs_out;
+    const int rc = dwo_step(h, actions, noise, step_counter ? *step_counter : step_index, stream);
+    h->buf.obs_buf = bound;
+    if (rc == DW_OK && step_counter) *step_counter += 1;
+    return rc;
+}
+
 int dwo_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream) {
     if (!step_counter) return dwo_fail(DW_EINVAL, "dwo_step_dev: step_counter is null");
     const int rc = dwo_step(h, actions, noise, *step_counter, stream);

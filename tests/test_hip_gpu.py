@@ -939,3 +939,40 @@ def test_physics_only_handle_as_the_engine_behind_the_references_own_task(task_c
     assert api["reset_idx"](h, ids.data_ptr(), 1, None, 0, None) != 0
     assert api["destroy"](h) == 0
     full.close()
+
+
+def test_step_returns_a_fresh_observation_tensor_without_a_copy():
+    """The reference's contract (`torch.clamp(self.obs_buf, ...)`, tasks/base/vec_task.py:338: a new tensor every step) met by
+    letting the kernel write each step's observations into a newly allocated tensor (dw_step_obs): tensors returned by earlier
+    steps stay what they were, the numbers equal those of the bound-buffer path (alias_obs), env.obs_buf is the newest
+    observation, and reset_idx leaves it alone (the reference rebuilds a reset env's observations in the next step)."""
+    from hip_backend import make_env
+    N = 200
+    a_env, f_env = make_env(N, alias_obs=True), make_env(N)
+    assert f_env._fresh_obs and not a_env._fresh_obs
+    g = torch.Generator(device="cuda").manual_seed(12)
+    kept = []
+    for t in range(12):
+        a = torch.rand(N, 13, generator=g, device="cuda") * 2 - 1
+        oa = a_env.step(a)[0]["obs"]
+        of = f_env.step(a)[0]["obs"]
+        assert torch.equal(oa, of), t                              # same kernel, same numbers
+        assert of is f_env.obs_buf and of.data_ptr() != f_env._bound_obs.data_ptr()
+        kept.append((of, of.clone()))
+    assert len({o.data_ptr() for o, _ in kept}) == len(kept)      # twelve live tensors, twelve storages
+    for o, c in kept:
+        assert torch.equal(o, c)                                   # later steps did not touch what was returned earlier
+    held = f_env.obs_buf
+    snap = held.clone()
+    ids = torch.tensor([3, 77, 150], device="cuda")
+    f_env.reset_idx(ids)
+    a_env.reset_idx(ids)
+    torch.cuda.synchronize()
+    assert torch.equal(held, snap) and f_env.obs_buf is held              # reset_idx does not write observations ...
+    assert torch.equal(f_env.obs_buf, a_env.obs_buf)                      # ... on either path
+    for t in range(3):                                                    # and the steps after the reset agree again, reset envs included
+        a = torch.rand(N, 13, generator=g, device="cuda") * 2 - 1
+        assert torch.equal(a_env.step(a)[0]["obs"], f_env.step(a)[0]["obs"]), t
+    sd = f_env.state_dict()
+    assert torch.equal(sd["obs_buf"], f_env.obs_buf)
+    a_env.close(); f_env.close()
