@@ -228,7 +228,9 @@ DW_HD void newwalk_reward(const NewWalkArgs &A, int e) {
     const float leg_len = norm_t(dl, 2);
     bool coll = false;
     for (int k = 0; k < A.n_non_feet; ++k) {
-        const float f3[3] = {cf[3 * A.non_feet_idxs[k]], cf[3 * A.non_feet_idxs[k] + 1], cf[3 * A.non_feet_idxs[k] + 2]};
+        int bi = A.non_feet_idxs[k];
+        bi = bi < 0 ? 0 : (bi >= A.num_bodies ? A.num_bodies - 1 : bi);          // (ids come from device memory: never index past the env's rows)
+        const float f3[3] = {cf[3 * bi], cf[3 * bi + 1], cf[3 * bi + 2]};
         coll = coll || norm_t(f3, 3) > 1.0f;
     }
     const bool low = rp[2] < A.termination_height, conv = leg_len < 0.1f;

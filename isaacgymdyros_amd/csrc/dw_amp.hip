@@ -81,6 +81,7 @@ int dw_amp_reset(int n, const int64_t *progress_buf, const float *contact_buf, c
     if (n <= 0 || !progress_buf || !contact_buf || (n_contact_ids > 0 && !contact_body_ids) || n_contact_ids < 0 || !rigid_body_pos ||
         !rigid_body_rot || !reset || !terminated)
         return fail(DW_EINVAL, "dw_amp_reset: null argument or n <= 0");
+    if (n_contact_ids > DW_NUM_BODIES) return fail(DW_EINVAL, "dw_amp_reset: more contact body ids than bodies");
     const dwa::ResetArgs A{n, progress_buf, contact_buf, contact_body_ids, n_contact_ids, rigid_body_pos, rigid_body_rot, max_episode_length,
                            enable_early_termination, termination_height, reset, terminated};
     hipLaunchKernelGGL(dw_k_amp_reset, dim3(blocks(n)), dim3(TPB), 0, (hipStream_t)stream, A);
@@ -97,6 +98,7 @@ int dw_newwalk_reward(int n, const int64_t *reset_buf, const int64_t *progress_b
         !rfoot_states || !phase || !total_reward || !reset || !reward8)
         return fail(DW_EINVAL, "dw_newwalk_reward: null argument or n <= 0");
     if (num_dof <= 0 || num_dof > dwa::NW_MAX_DOF || num_bodies < 15) return fail(DW_EINVAL, "dw_newwalk_reward: num_dof must be 1..64 and num_bodies >= 15");
+    if (n_non_feet > num_bodies) return fail(DW_EINVAL, "dw_newwalk_reward: more non-feet indices than bodies");
     const dwa::NewWalkArgs A{n, reset_buf, progress_buf, target_vel, root_pose_states, joint_position_states, joint_velocity_states,
                              non_feet_idxs, n_non_feet, contact_forces, num_bodies, termination_height, death_cost, max_episode_length,
                              q_nominal, num_dof, head_states, lfoot_states, rfoot_states, phase, total_reward, reset, reward8};
