@@ -369,11 +369,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
     if (any_reset) {
         const bool mine = PQ_PSI(el, PS_RESET) != 0;
-        if (
-#if defined(OCT_X_NO_TERR)
-            false &&
-#endif
-            C.terrain_curriculum && j == 0 && mine) {
+        if (C.terrain_curriculum && j == 0 && mine) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
             const float distance = dw::norm_t(d, 2);
             const bool move_up = distance > C.terrain_half_length;
