@@ -3,7 +3,7 @@ two compiled models, the shipped one and the one given in DW_MODEL_B (a tocabi_m
 usage: DW_MODEL_B=path/to/other_model.json python tools/sc_pairs_effect.py [N] [steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from isaacgymdyros_amd import model as M, dyros_dynamic_walk as D
 from isaacgymdyros_amd.config import default_cfg
 
