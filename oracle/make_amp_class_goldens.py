@@ -13,7 +13,7 @@ tests/test_amp_gpu.py replays the draws and the physics states into `isaacgymdyr
 (its generator and its `simulate` are injectable for exactly this) and compares every output: the class logic -- history
 stacking, command ramp, torque FIFO with delay, encoder model, reset order -- is then pinned, not only the three pure functions.
 Configuration: the reference's TocabiAMPLower.yaml with `randomize: False` (the dof-property randomisation is VecTask code
-pinned by dr_reset.npz; its numpy draws are not torch draws) and 24 envs x 60 steps.
+pinned by dr_reset.npz; its numpy draws are not torch draws), 16 envs x 60 steps, episode length 31.
 """
 from __future__ import annotations
 
@@ -44,7 +44,6 @@ class AmpFakeGym(RH.FakeGym):
         self.rb = torch.zeros(self.N * 38, 13)
         self.rb[:, 6] = 1.0
         self.after_sim = []          # physics state after every simulate(): what the replay injects
-        self._feet = (RH.types.SimpleNamespace(), )
 
     def get_asset_actuator_properties(self, asset):
         return [RH._Bag(upper_control_limit=float(v)) for v in ACTION_HIGH]
