@@ -370,8 +370,9 @@ def main():
                 out["config3_ppo"] = {k: st[k] for k in ("step_fps", "play_fps", "total_fps", "mean_reward")}
                 out["config3_ppo"]["note"] = "one epoch: horizon 128 rollout with the policy in the loop, then the DYROS PPO update"
                 # the same epoch with the rollout step captured in a hipGraph (dw_step_dev: step counter in device memory)
-                sg = ppo.train(args.envs_per_gpu, epochs=1, device=dev, log=lambda s_: None, graph_rollout=True)[-1]
+                sg = ppo.train(args.envs_per_gpu, epochs=1, device=dev, log=lambda s_: None, graph_rollout=True, graph_update=True)[-1]
                 out["config3_ppo"]["graph_rollout"] = {k: sg[k] for k in ("play_fps", "total_fps", "mean_reward")}
+                out["config3_ppo"]["graph_rollout"]["note"] = "rollout step and minibatch update each captured in a hipGraph (fused capturable Adam)"
             except Exception as e:
                 out["config3_ppo"] = {"error": str(e)}
     if rank == 0:

@@ -220,11 +220,14 @@ def _sync(device):
 
 # ------------------------------------------------------------------------------------------------ the loop
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
-          rank=0, world=1, seed=42, graph_rollout=False):
+          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False):
     """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch.
     graph_rollout: one rollout step (policy inference, sampling, env step, bookkeeping) is captured once in a hipGraph and
     replayed `horizon` times per epoch -- possible because dw_step_dev keeps the step counter in device memory, so a replayed
-    launch draws fresh noise (include/dyros_walk.h).  The eager loop pays ~40 kernel launches and two host syncs per step."""
+    launch draws fresh noise (include/dyros_walk.h).  The eager loop pays ~40 kernel launches and two host syncs per step.
+    graph_update: one minibatch update (forward, the four losses, backward, unscale, clip, both optimiser steps, scaler update) is
+    captured once and replayed 5 x 512 times per epoch; needs the fused, capturable Adam (its update is what GradScaler can skip
+    on the device instead of asking the host), one rank."""
     from isaacgymdyros_amd.config import default_cfg
     from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
     cfg = cfg or TRAIN_CFG
@@ -243,8 +246,14 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     torch.manual_seed(seed)                          # same initial weights on every rank
     net = DyrosActorCritic(env.num_obs, env.num_acts, cfg["network"]).to(device)
     torch.manual_seed(seed + 7919 * rank)            # ... but its own exploration noise (Normal.sample draws from the global generator)
-    opt_a = torch.optim.Adam(net.actor_parameters(), lr=c["learning_rate"], eps=1e-8)
-    opt_c = torch.optim.Adam(net.critic_parameters(), lr=c["critic_lr"], eps=1e-8)
+    graph_update = bool(graph_update) and str(device).startswith("cuda") and world == 1
+    if graph_update:        # (learning rates as device tensors: the schedule writes them in place and the captured step reads them)
+        opt_a = torch.optim.Adam(net.actor_parameters(), lr=torch.tensor(float(c["learning_rate"]), device=device), eps=1e-8, fused=True, capturable=True)
+        opt_c = torch.optim.Adam(net.critic_parameters(), lr=torch.tensor(float(c["critic_lr"]), device=device), eps=1e-8, fused=True, capturable=True)
+    else:
+        opt_a = torch.optim.Adam(net.actor_parameters(), lr=c["learning_rate"], eps=1e-8)
+        opt_c = torch.optim.Adam(net.critic_parameters(), lr=c["critic_lr"], eps=1e-8)
+    upd_graph, upd_static, upd_out = None, None, {}
     sched = LinearLR(c["learning_rate"], c["learning_rate_min"], max_epochs)
     amp = bool(c["mixed_precision"]) and str(device).startswith("cuda")
     scaler = torch.amp.GradScaler("cuda", enabled=amp)
@@ -308,7 +317,10 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         net.update_action_noise((max_epochs - ep) / max_epochs)                 # a2c_common_dyros.py:985
         lr = sched(ep)
         for g in opt_a.param_groups:                                           # update_lr touches the actor only (:293-295)
-            g["lr"] = lr
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
         t0 = time.perf_counter()
         step_time = 0.0
         terms = torch.zeros(len(names) or 15, device=device)
@@ -349,32 +361,65 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         if c["normalize_advantage"]:
             adv = (adv - adv.mean()) / (adv.std() + 1e-8)                       # :945
         a_l = c_l = b_l = cf = kl = torch.zeros((), device=device)
+
+        def minibatch_update(obs_, act_, nlp_old, mu_old, adv_, ret_, val_):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                mu, logstd, value = net(obs_)
+                sigma = torch.exp(logstd)
+                nlp = neglogp(act_, mu, sigma, logstd)
+                a_loss, cf_ = actor_loss(nlp_old, nlp, adv_, c["e_clip"])
+                c_loss = critic_loss(val_, value, c["e_clip"], ret_, c["clip_value"])
+                b_loss = bound_loss(mu)
+                # Normal(mu, sigma).entropy() written out (torch/distributions/normal.py): the constructor's argument check is a host sync
+                entropy = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(sigma)).sum(dim=-1)
+                al, cl, bl = a_loss.mean(), c_loss.mean(), b_loss.mean()
+                loss = al + 0.5 * cl * c["critic_coef"] - entropy.mean() * c["entropy_coef"] + bl * c["bounds_loss_coef"]
+            for p in net.parameters():
+                p.grad = None
+            scaler.scale(loss).backward()
+            # synchronise first, unscale after (a2c_continuous_seperate.py:171-175): the still-scaled gradients are averaged
+            # (the loss scale is the same on every rank), so an overflow on one rank reaches every rank through the sum,
+            # every rank's unscale_ finds it, every rank skips the step and backs its scale off alike
+            allreduce_grads(net.actor_parameters() + net.critic_parameters(), world)
+            scaler.unscale_(opt_a); scaler.unscale_(opt_c)
+            if c["truncate_grads"]:
+                nn.utils.clip_grad_norm_(net.actor_parameters(), c["grad_norm"])       # the actor only (:178)
+            scaler.step(opt_a); scaler.step(opt_c); scaler.update()
+            with torch.no_grad():
+                kl_ = policy_kl(mu.detach().float(), sigma.detach().float(), mu_old, torch.exp(net.sigma).expand_as(mu))
+            return al.detach(), cl.detach(), bl.detach(), cf_.detach(), kl_
+
+        srcs = (B["obs"], B["act"], B["neglogp"], B["mu"], adv, ret, val)
+        if graph_update and upd_static is None:
+            upd_static = [torch.empty_like(x[:mbs]) for x in srcs]
+        it = 0
         for _ in range(int(c["mini_epochs"])):
             for i in range(batch // mbs):
-                s = slice(i * mbs, (i + 1) * mbs)
-                with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
-                    mu, logstd, value = net(B["obs"][s])
-                    sigma = torch.exp(logstd)
-                    nlp = neglogp(B["act"][s], mu, sigma, logstd)
-                    a_loss, cf = actor_loss(B["neglogp"][s], nlp, adv[s], c["e_clip"])
-                    c_loss = critic_loss(val[s], value, c["e_clip"], ret[s], c["clip_value"])
-                    b_loss = bound_loss(mu)
-                    entropy = torch.distributions.Normal(mu, sigma).entropy().sum(dim=-1)
-                    a_l, c_l, b_l = a_loss.mean(), c_loss.mean(), b_loss.mean()
-                    loss = a_l + 0.5 * c_l * c["critic_coef"] - entropy.mean() * c["entropy_coef"] + b_l * c["bounds_loss_coef"]
-                for p in net.parameters():
-                    p.grad = None
-                scaler.scale(loss).backward()
-                # synchronise first, unscale after (a2c_continuous_seperate.py:171-175): the still-scaled gradients are averaged
-                # (the loss scale is the same on every rank), so an overflow on one rank reaches every rank through the sum,
-                # every rank's unscale_ finds it, every rank skips the step and backs its scale off alike
-                allreduce_grads(net.actor_parameters() + net.critic_parameters(), world)
-                scaler.unscale_(opt_a); scaler.unscale_(opt_c)
-                if c["truncate_grads"]:
-                    nn.utils.clip_grad_norm_(net.actor_parameters(), c["grad_norm"])       # the actor only (:178)
-                scaler.step(opt_a); scaler.step(opt_c); scaler.update()
-                with torch.no_grad():
-                    kl = policy_kl(mu.detach().float(), sigma.detach().float(), B["mu"][s], torch.exp(net.sigma).expand_as(mu))
+                sl = slice(i * mbs, (i + 1) * mbs)
+                if not graph_update:
+                    a_l, c_l, b_l, cf, kl = minibatch_update(*[x[sl] for x in srcs])
+                    continue
+                for d_, x in zip(upd_static, srcs):
+                    d_.copy_(x[sl])
+                if upd_graph is None and it < 3:
+                    # (the first three minibatches run eagerly on a side stream: the warm-up a capture requires, spent on real work)
+                    side_u = torch.cuda.Stream(device=device)
+                    side_u.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(side_u):
+                        outs = minibatch_update(*upd_static)
+                    torch.cuda.current_stream(device).wait_stream(side_u)
+                    a_l, c_l, b_l, cf, kl = outs
+                else:
+                    if upd_graph is None:
+                        torch.cuda.synchronize()
+                        for p in net.parameters():
+                            p.grad = None
+                        upd_graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(upd_graph):
+                            upd_out["v"] = minibatch_update(*upd_static)
+                    upd_graph.replay()
+                    a_l, c_l, b_l, cf, kl = upd_out["v"]
+                it += 1
         _sync(device)
         total = time.perf_counter() - t0
         fin = env.episodes_finished > 0

@@ -378,6 +378,13 @@ def test_ppo_rollout_step_captured_in_a_graph():
         assert len(g["reward_terms"]) == 15 and abs(sum(list(g["reward_terms"].values())[:14]) - g["mean_reward"]) < 0.05
         assert g["mean_episode_length"] >= 0
     assert graph[0]["sigma"] > graph[1]["sigma"]                        # the in-place sigma schedule reaches the captured graph
+    # ... and with the minibatch update captured as well (fused capturable Adam; learning rate as a device tensor the schedule writes)
+    both = mod.train(num_envs=1024, epochs=2, horizon=32, log=lambda *_: None, graph_rollout=True, graph_update=True)
+    for e, g in zip(eager, both):
+        assert np.isfinite([g["mean_reward"], g["a_loss"], g["c_loss"], g["b_loss"], g["kl"], g["clip_frac"], g["total_fps"]]).all()
+        assert abs(g["mean_reward"] - e["mean_reward"]) < 0.15
+        assert abs(g["c_loss"] - e["c_loss"]) < 0.5 * abs(e["c_loss"]) + 1e-3, (g["c_loss"], e["c_loss"])       # the same optimisation problem, another Adam kernel
+    assert both[0]["lr"] > both[1]["lr"]
 
 
 def test_config3_16384_envs_with_the_ppo_loop_attached():
