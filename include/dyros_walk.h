@@ -60,6 +60,8 @@ extern "C" {
 #define DW_NUM_LOWER    12
 #define DW_NUM_OBS1     37   /* single-step observation                                   */
 #define DW_AMP_NUM_OBS1 36   /* TocabiAMPLower single-step observation (tasks/amp/tocabi_amp_lower_base.py:45) */
+#define DW_AMP_DISC_BASE 28  /* discriminator observation per step without the key bodies: root height 1 + root euler 3 + leg
+                               dof pos 12 + leg dof vel 12 (tasks/tocabi_amp_lower.py:47); + 3 per key body (two feet: 34) */
 #define DW_AMP_NUM_ACT  12   /* TocabiAMPLower actions: the 12 leg torques (:46)          */
 #define DW_NUM_HIS      10
 #define DW_NUM_SKIP      2
@@ -336,6 +338,12 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
  * reference's TorchScript functions so that a maintainer binds them at the reference's own call sites:
  *   dw_amp_observations  tasks/amp/tocabi_amp_lower_base.py:918-962  compute_humanoid_observations -> obs [N,DW_AMP_NUM_OBS1]
  *                        (key_pos, which the reference passes and never reads, is omitted)
+ *   dw_amp_disc_observations  tasks/tocabi_amp_lower.py:310-350 build_amp_observations -> obs [N, DW_AMP_DISC_BASE + 3 n_key]: the
+ *                        discriminator's per-step observation of the AMP subclass (root height, root euler, 12 leg dof positions and
+ *                        velocities, key-body positions relative to the root in the heading frame; local_root_obs != 0: key_pos copied
+ *                        as given).  dof_pos / dof_vel: 12 leading dofs of each row, rows dof_row_stride elements apart, dofs
+ *                        dof_elem_stride apart (33, 1 for a [N,33] tensor; 66, 2 for the two halves of dof_state [N,33,2]; 12, 1 for
+ *                        the motion library's [M,12]); key_pos [N,n_key,3]
  *   dw_amp_reward        :964-1023 compute_humanoid_reward -> reward [N], reward_values [N,9]; actions [N,12], contact_force [N,38,3]
  *   dw_amp_reset         :1025-1069 compute_humanoid_reset -> reset [N], terminated [N]; contact_body_ids: Gym bodies whose contact
  *                        does not terminate (the feet), rigid_body_pos [N,38,3] (rows 0, 8, 16 are read), rigid_body_rot [N,38,4] (row 0)
@@ -347,6 +355,8 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
 #define DW_MAX_BODY_QUERY 8
 int dw_amp_observations(int n, const float *root_states, const float *rootvel_noise, const float *dof_pos, const float *dof_pos_bias,
                         const float *quat_bias, const float *dof_vel, const float *commands, float *obs, void *stream);
+int dw_amp_disc_observations(int n, const float *root_states, const float *dof_pos, const float *dof_vel, int dof_row_stride,
+                             int dof_elem_stride, int local_root_obs, const float *key_pos, int n_key, float *obs, void *stream);
 int dw_amp_reward(int n, const float *root_states, const float *dof_vel, const float *dof_vel_pre, const float *commands,
                   const float *actions, const float *actions_pre, const float *motor_efforts, const float *contact_force,
                   const float *total_mass, float *reward, float *reward_values, void *stream);

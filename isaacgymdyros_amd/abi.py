@@ -124,6 +124,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     # row f-3: env-side functions of the sibling TOCABI tasks (device pointers as c_void_p, trailing stream)
     P = C.c_void_p
     api["amp_observations"] = fn("amp_observations", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P)
+    api["amp_disc_observations"] = fn("amp_disc_observations", C.c_int, C.c_int, P, P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P)
     api["amp_reward"] = fn("amp_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P)
     api["amp_reset"] = fn("amp_reset", C.c_int, C.c_int, P, P, P, C.c_int, P, P, C.c_float, C.c_int, C.c_float, P, P, P)
     api["newwalk_reward"] = fn("newwalk_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, C.c_int, P, C.c_int, C.c_float, C.c_float,
@@ -133,7 +134,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
 
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
-           "reset_idx", "amp_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions"]
+           "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions"]
 
 
 # name -> (per-env shape, numpy dtype string); gate_acc is the one buffer without an env dimension

@@ -4,7 +4,10 @@
 // Reference: tasks/amp/tocabi_amp_lower_base.py:918-962 (compute_humanoid_observations), :964-1023 (compute_humanoid_reward),
 // :1025-1069 (compute_humanoid_reset); tasks/tocabi_new_walk.py:384-496 (compute_humanoid_walk_reward);
 // python/isaacgym/torch_utils.py:72-81 (quat_rotate_inverse), :227-273 (quat2euler); utils/torch_jit_utils.py:80-135
-// (scale_transform, saturate), :141-160 (quat_diff_rad), :406-418 (sync_reward).
+// (scale_transform, saturate), :141-160 (quat_diff_rad), :406-418 (sync_reward); tasks/tocabi_amp_lower.py:310-350
+// (build_amp_observations: the discriminator's per-step observation of the AMP subclass) with utils/torch_jit_utils.py:199-209
+// (my_quat_rotate), :333-368 (calc_heading, calc_heading_quat_inv), python/isaacgym/torch_utils.py:44-46,92-102 (normalize,
+// quat_unit, quat_from_angle_axis).
 #pragma once
 
 #include "dw_task.h"
@@ -66,6 +69,69 @@ DW_HD void observations(const ObsArgs &A, int e) {
     for (int i = 0; i < 3; ++i) o[9 + i] = A.commands[3 * (size_t)e + i];
     for (int i = 0; i < 12; ++i) o[12 + i] = A.dof_pos[DW_NUM_DOF * (size_t)e + i] + A.dof_pos_bias[12 * (size_t)e + i];
     for (int i = 0; i < 12; ++i) o[24 + i] = A.dof_vel[DW_NUM_DOF * (size_t)e + i];
+}
+
+// my_quat_rotate(q, v) = a + b + c (utils/torch_jit_utils.py:199-209; the sign of b is what separates it from quat_rotate_inverse)
+DW_HD void my_quat_rotate(const float *q /* xyzw */, const float *v, float *o) {
+    const float w = q[3];
+    const float s = 2.0f * (w * w) - 1.0f;
+    const float cr[3] = {fmaf(q[1], v[2], -(q[2] * v[1])), fmaf(q[2], v[0], -(q[0] * v[2])), fmaf(q[0], v[1], -(q[1] * v[0]))};
+    const float dot = (q[0] * v[0] + q[1] * v[1]) + q[2] * v[2];
+    for (int i = 0; i < 3; ++i) {
+        const float a = v[i] * s;
+        const float b = cr[i] * w * 2.0f;
+        const float c = q[i] * dot * 2.0f;
+        o[i] = a + b + c;
+    }
+}
+
+// calc_heading_quat_inv(q): the rotation about z that takes the base's heading back to the x axis
+DW_HD void heading_quat_inv(const float *q, float *hq) {
+    const float ref[3] = {1.0f, 0.0f, 0.0f};
+    float rd[3];
+    my_quat_rotate(q, ref, rd);
+    const float heading = atan2f(rd[1], rd[0]);
+    const float theta = (-heading) / 2.0f;
+    const float sn = sinf(theta), cs = cosf(theta);
+    // quat_from_angle_axis: normalize((0, 0, 1)) = (0, 0, 1) / 1 exactly; the zeros keep the sign the product gives them
+    float u[4] = {0.0f * sn, 0.0f * sn, 1.0f * sn, cs};
+    float nn = norm_t(u, 4);
+    nn = nn < 1e-9f ? 1e-9f : nn;
+    for (int i = 0; i < 4; ++i) hq[i] = u[i] / nn;
+}
+
+struct DiscObsArgs {
+    int n;
+    const float *root_states, *dof_pos, *dof_vel;
+    int dof_row_stride, dof_elem_stride;       // elements between two envs' rows / between two dofs of a row
+    int local_root_obs;
+    const float *key_pos;
+    int n_key;
+    float *obs;
+};
+DW_HD void disc_observations(const DiscObsArgs &A, int e) {
+    const float *r = A.root_states + 13 * (size_t)e;
+    float *o = A.obs + (size_t)(DW_AMP_DISC_BASE + 3 * A.n_key) * e;
+    const float q[4] = {r[3], r[4], r[5], r[6]};
+    float hq[4], eu[3];
+    heading_quat_inv(q, hq);
+    quat2euler(q, eu);
+    o[0] = r[2];
+    for (int i = 0; i < 3; ++i) o[1 + i] = eu[i];
+    const float *dp = A.dof_pos + (size_t)A.dof_row_stride * e, *dv = A.dof_vel + (size_t)A.dof_row_stride * e;
+    for (int i = 0; i < 12; ++i) o[4 + i] = dp[(size_t)A.dof_elem_stride * i];
+    for (int i = 0; i < 12; ++i) o[16 + i] = dv[(size_t)A.dof_elem_stride * i];
+    for (int k = 0; k < A.n_key; ++k) {
+        const float *kp = A.key_pos + ((size_t)A.n_key * e + k) * 3;
+        if (A.local_root_obs) {
+            for (int i = 0; i < 3; ++i) o[DW_AMP_DISC_BASE + 3 * k + i] = kp[i];
+        } else {
+            const float lp[3] = {kp[0] - r[0], kp[1] - r[1], kp[2] - r[2]};
+            float le[3];
+            my_quat_rotate(hq, lp, le);
+            for (int i = 0; i < 3; ++i) o[DW_AMP_DISC_BASE + 3 * k + i] = le[i];
+        }
+    }
 }
 
 struct RewardArgs {

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(TPB) void dw_k_amp_observations(const dwa::ObsArgs 
     const int e = (int)(blockIdx.x * TPB + threadIdx.x);
     if (e < A.n) dwa::observations(A, e);
 }
+__global__ __launch_bounds__(TPB) void dw_k_amp_disc_observations(const dwa::DiscObsArgs A) {
+    const int e = (int)(blockIdx.x * TPB + threadIdx.x);
+    if (e < A.n) dwa::disc_observations(A, e);
+}
 __global__ __launch_bounds__(TPB) void dw_k_amp_reward(const dwa::RewardArgs A) {
     const int e = (int)(blockIdx.x * TPB + threadIdx.x);
     if (e < A.n) dwa::reward(A, e);
@@ -61,6 +65,17 @@ int dw_amp_observations(int n, const float *root_states, const float *rootvel_no
     const dwa::ObsArgs A{n, root_states, rootvel_noise, dof_pos, dof_pos_bias, quat_bias, dof_vel, commands, obs};
     hipLaunchKernelGGL(dw_k_amp_observations, dim3(blocks(n)), dim3(TPB), 0, (hipStream_t)stream, A);
     return launched("dw_amp_observations: launch");
+}
+
+int dw_amp_disc_observations(int n, const float *root_states, const float *dof_pos, const float *dof_vel, int dof_row_stride,
+                             int dof_elem_stride, int local_root_obs, const float *key_pos, int n_key, float *obs, void *stream) {
+    if (n <= 0 || !root_states || !dof_pos || !dof_vel || !key_pos || !obs) return fail(DW_EINVAL, "dw_amp_disc_observations: null argument or n <= 0");
+    if (n_key < 1 || n_key > DW_MAX_BODY_QUERY) return fail(DW_EINVAL, "dw_amp_disc_observations: n_key must be 1..DW_MAX_BODY_QUERY");
+    if (dof_elem_stride < 1 || dof_row_stride < 12 * dof_elem_stride - (dof_elem_stride - 1))
+        return fail(DW_EINVAL, "dw_amp_disc_observations: a row must hold 12 dofs at the element stride given");
+    const dwa::DiscObsArgs A{n, root_states, dof_pos, dof_vel, dof_row_stride, dof_elem_stride, local_root_obs, key_pos, n_key, obs};
+    hipLaunchKernelGGL(dw_k_amp_disc_observations, dim3(blocks(n)), dim3(TPB), 0, (hipStream_t)stream, A);
+    return launched("dw_amp_disc_observations: launch");
 }
 
 int dw_amp_reward(int n, const float *root_states, const float *dof_vel, const float *dof_vel_pre, const float *commands,

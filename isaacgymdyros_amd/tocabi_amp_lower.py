@@ -25,9 +25,22 @@ the reference has them: the gains are quotients rounded once from double; the To
 encoder bias to `qpos_noise` IN PLACE; `x / dt` divides on the CPU and multiplies by a reciprocal on the GPU (cfg
 sim.mi355.torch_gpu_div picks the flavour); the command ramp multiplies before it divides.
 
-Not built: the motion-library state initialisation and the discriminator observations of the subclass
-(tasks/tocabi_amp_lower.py: `stateInit` Random / Hybrid, `_compute_amp_observations`), which need the reference's motion
-assets; `stateInit: Default` is what reset_idx implements.  The triangle-mesh terrain of this task is not wired either.
+The AMP subclass' layer (tasks/tocabi_amp_lower.py) is part of this class:
+  :47                NUM_AMP_OBS_PER_STEP = 34; `numAMPObsSteps` of them form the discriminator's observation
+  :88-96             post_physics_step: shift the AMP history, compute the newest step, extras["amp_obs"]
+  :105-131           fetch_amp_obs_demo: demonstration observations from the motion library (isaacgymdyros_amd/motion_lib.py)
+  :144-178,180-256   reset_idx / _reset_actors: stateInit Default | Start | Random | Hybrid (reference state initialisation
+                     from the motion library), then _init_amp_obs (history of a reset env: copies of its current observation for
+                     a default start, the motion's earlier frames for a reference start)
+  :310-350           build_amp_observations -- here the HIP entry point dw_amp_disc_observations, pinned against the reference's
+                     function (tests/golden/amp_disc_ref.npz)
+The reference's motion tables (assets/amp/tocabi_motions/*.txt) are not in its checkout: `cfg.env.motion_file` must name the
+user's own (a .yaml list or one .txt) for every stateInit but Default and for fetch_amp_obs_demo; the motion library is pinned
+against the reference's on synthetic tables (tests/test_amp_motion.py).  The key-body rows of the rigid-body state a reset
+env's observation reads are recomputed from the state just set (dw_body_positions); Isaac Gym's deferred setters would still
+show the pre-reset rows there -- irrelevant for the history, which _init_amp_obs overwrites.
+
+Not built: `stateInit: Custom` (the task's triangle-mesh terrain origins; the terrain of this task is not wired).
 """
 from __future__ import annotations
 
@@ -42,10 +55,12 @@ from . import _lib
 from .config import default_cfg
 from .dyros_dynamic_walk import DyrosDynamicWalk
 from .task_constants import ACTION_HIGH
-from .vec_task import VecTask
+from .vec_task import Box, VecTask
 
 NUM_OBS = 3 + 6 + 3 + 12 + 12          # reference :45 (root euler, root velocities, command, leg dof pos, leg dof vel)
 NUM_ACTIONS = 12                        # :46
+NUM_AMP_OBS_PER_STEP = 1 + 3 + 12 + 12 + 6          # tasks/tocabi_amp_lower.py:47 (root height, root euler, leg dof pos / vel, two foot positions)
+STATE_INITS = ("Default", "Start", "Random", "Hybrid")
 REWARD_NAMES = ["x_vel_tracking", "y_vel_tracking", "yaw_vel_tracking", "contact_force_threshold", "contact_force_penalty",
                 "joint_velocity_regulation", "joint_acceleration_regulation", "torque_regulation", "torque_diff_regulation"]   # :1010-1012
 INIT_ANGLE = [0.0, 0.0, -0.28, 0.6, -0.32, 0.0, 0.0, 0.0, -0.28, 0.6, -0.32, 0.0, 0.0, 0.0, 0.0,
@@ -65,7 +80,8 @@ def default_amp_cfg(num_envs: int = 4096, sim_device: str = "cuda:0") -> dict:
     return {
         "name": "TocabiAMPLower", "physics_engine": "physx", "rl_device": sim_device, "seed": 42,
         "env": {"numEnvs": num_envs, "envSpacing": 5, "episodeLength": 8000, "enableDebugVis": False, "pdControl": False,
-                "powerScale": 1.0, "controlFrequencyInv": 2, "stateInit": "Default", "localRootObs": False,
+                "powerScale": 1.0, "controlFrequencyInv": 2, "stateInit": "Default", "hybridInitProb": 0.5, "numAMPObsSteps": 2,
+                "motion_file": None, "localRootObs": False,
                 "contactBodies": ["L_Foot_Link", "R_Foot_Link"], "terminationHeight": 0.6, "enableEarlyTermination": True,
                 "perturbation": False, "velChange": True, "NumHis": 10, "NumSkip": 2,
                 "command": {"x": [-0.5, 1.0], "y": [-0.0, 0.0], "yaw": [-0.0, 0.0]},
@@ -113,8 +129,17 @@ class TocabiAMPLower(VecTask):
         e = cfg["env"]
         if e["terrain"]["terrainType"] not in ("plane", "none"):
             raise ValueError("TocabiAMPLower on the MI355X physics: only terrainType 'plane' is wired (module docstring)")
-        if e.get("stateInit", "Default") != "Default":
-            raise ValueError("TocabiAMPLower on the MI355X physics: only stateInit 'Default' (the motion library is not part of this build)")
+        self._state_init = e.get("stateInit", "Default")
+        if self._state_init not in STATE_INITS:
+            raise ValueError("TocabiAMPLower on the MI355X physics: stateInit must be one of %s (module docstring)" % (STATE_INITS,))
+        self._hybrid_init_prob = float(e.get("hybridInitProb", 0.5))
+        self._num_amp_obs_steps = int(e.get("numAMPObsSteps", 2))
+        if self._num_amp_obs_steps < 2:
+            raise ValueError("numAMPObsSteps must be at least 2 (tasks/tocabi_amp_lower.py:65)")
+        self._local_root_obs = bool(e.get("localRootObs", False))
+        if self._state_init != "Default" and not e.get("motion_file"):
+            raise ValueError("stateInit %r draws its start states from the motion library: set cfg.env.motion_file (the reference's "
+                             "tables are not in its checkout)" % self._state_init)
         self._pd_control = e["pdControl"]
         self.randomize = cfg["task"]["randomize"]
         self.noise = cfg["task"]["noise"]
@@ -224,6 +249,20 @@ class TocabiAMPLower(VecTask):
         self._push = torch.zeros(N, 2, **f)
         self.time_step = 0
         self.extras["reward_names"] = list(REWARD_NAMES)
+        # ---- the AMP subclass' state (tasks/tocabi_amp_lower.py:58-86)
+        self._motion_lib = None
+        if e.get("motion_file"):
+            from .motion_lib import TocabiLowerMotionLib
+            self._motion_lib = TocabiLowerMotionLib(e["motion_file"], self.num_dof, dev)
+        self.num_amp_obs = self._num_amp_obs_steps * NUM_AMP_OBS_PER_STEP
+        self._amp_obs_space = Box(np.ones(self.num_amp_obs) * -np.inf, np.ones(self.num_amp_obs) * np.inf)
+        self._amp_obs_buf = torch.zeros(N, self._num_amp_obs_steps, NUM_AMP_OBS_PER_STEP, **f)
+        self._curr_amp_obs_buf = self._amp_obs_buf[:, 0]
+        self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
+        self._amp_obs_demo_buf = None
+        self._amp_obs1 = torch.zeros(N, NUM_AMP_OBS_PER_STEP, **f)
+        self._reset_default_env_ids, self._reset_ref_env_ids = [], []
+        self._reset_ref_motion_ids = self._reset_ref_motion_times = None
         if self._pd_control:
             lo, hi = self._phys.model.dof_lower, self._phys.model.dof_upper
             lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
@@ -281,14 +320,8 @@ class TocabiAMPLower(VecTask):
                     lo, hi = dofp["armature"]["range"]
                     b["dof_armature"][sel] = self._nominal_armature * self._rand_float(lo, hi, (len(sel), 33))
                 self.randomize_buf[sel] = 0
-        # _reset_actors (:611-626)
-        self._dof_pos[env_ids] = self._initial_dof_pos[env_ids]
-        self._dof_vel[env_ids] = 0.0
-        self._root_states[env_ids] = self._initial_root_states[env_ids]
+        self._reset_actors(env_ids)
         self._contact_forces[env_ids] = 0.0
-        self.progress_buf[env_ids] = 0
-        self.reset_buf[env_ids] = 0
-        self._terminate_buf[env_ids] = 0
         self._refresh_sim_tensors()
         # the reference computes the observation of the reset envs HERE (:253), before the new command, encoder state and biases
         # are drawn (:266-279) and before it zeroes the two histories (:296-297): the reset env's obs_buf rows are made of the
@@ -319,6 +352,107 @@ class TocabiAMPLower(VecTask):
         self.action_log[env_ids] = 0
         self.delay_idx[env_ids] = self._rng.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,))
         self.simul_len[env_ids] = 0
+        self._init_amp_obs(env_ids)                       # (tasks/tocabi_amp_lower.py:144-147)
+
+    # ------------------------------------------------------------------ state initialisation (tasks/tocabi_amp_lower.py:149-256)
+    def _reset_actors(self, env_ids):
+        self._reset_default_env_ids, self._reset_ref_env_ids = [], []
+        if self._state_init == "Default":
+            self._reset_default(env_ids)
+        elif self._state_init in ("Start", "Random"):
+            self._reset_ref_state_init(env_ids)
+        else:                                             # Hybrid: a reference start with probability hybridInitProb, else the default pose
+            ref = torch.bernoulli(torch.full((len(env_ids),), self._hybrid_init_prob, device=self._tdev), generator=self._rng.gen) == 1.0
+            if bool(ref.any()):
+                self._reset_ref_state_init(env_ids[ref])
+            if bool((~ref).any()):
+                self._reset_default(env_ids[~ref])
+        self.progress_buf[env_ids] = 0
+        self.reset_buf[env_ids] = 0
+        self._terminate_buf[env_ids] = 0
+
+    def _reset_default(self, env_ids):
+        self._dof_pos[env_ids] = self._initial_dof_pos[env_ids]
+        self._dof_vel[env_ids] = 0.0
+        self._root_states[env_ids] = self._initial_root_states[env_ids]
+        self._reset_default_env_ids = env_ids
+
+    def _reset_ref_state_init(self, env_ids):
+        ml, n = self._motion_lib, len(env_ids)
+        motion_ids = ml.sample_motions(n)
+        motion_times = ml.sample_time(motion_ids) if self._state_init in ("Random", "Hybrid") else np.zeros(n)
+        root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, _ = ml.get_motion_state(motion_ids, motion_times)
+        # the legs from the motion, the upper body at its initial pose and at rest (:214-215)
+        self._root_states[env_ids, 0:3] = root_pos
+        self._root_states[env_ids, 3:7] = root_rot
+        self._root_states[env_ids, 7:10] = root_vel
+        self._root_states[env_ids, 10:13] = root_ang_vel
+        self._dof_pos[env_ids] = torch.cat([dof_pos, self._initial_dof_pos[env_ids][:, 12:]], dim=-1)
+        self._dof_vel[env_ids] = torch.cat([dof_vel, torch.zeros(n, 21, device=self._tdev)], dim=-1)
+        self._reset_ref_env_ids = env_ids
+        self._reset_ref_motion_ids, self._reset_ref_motion_times = motion_ids, motion_times
+
+    # ------------------------------------------------------------------ discriminator observations (tasks/tocabi_amp_lower.py:88-131,258-305)
+    def get_num_amp_obs(self):
+        return self.num_amp_obs
+
+    @property
+    def amp_observation_space(self):
+        return self._amp_obs_space
+
+    def _build_amp_obs(self, root_states, dof_pos, dof_vel, key_pos, out):
+        """build_amp_observations (:310-350) on device tensors; dof_pos / dof_vel either the two halves of dof_state or [M,12]."""
+        n = root_states.shape[0]
+        assert root_states.is_contiguous() and key_pos.is_contiguous() and out.is_contiguous()
+        assert dof_pos.stride() == dof_vel.stride()
+        self._chk(self._api["amp_disc_observations"](n, _p(root_states), _p(dof_pos), _p(dof_vel), dof_pos.stride(0), dof_pos.stride(1),
+                                                     int(self._local_root_obs), _p(key_pos), key_pos.shape[1], _p(out), None))
+        return out
+
+    def _compute_amp_observations(self, env_ids=None):
+        # key bodies = the two foot links (:47-48 of the base): rows 8 and 16 of the rigid-body state, kept in _foot_pos
+        obs = self._build_amp_obs(self._root_states, self._dof_pos, self._dof_vel, self._foot_pos, self._amp_obs1)
+        if env_ids is None:
+            self._curr_amp_obs_buf[:] = obs
+        else:
+            self._curr_amp_obs_buf[env_ids] = obs[env_ids]
+
+    def _update_hist_amp_obs(self):
+        # slot i -> slot i + 1, oldest dropped (:283-290); one copy through a temporary instead of the reference's reversed loop
+        self._amp_obs_buf[:, 1:] = self._amp_obs_buf[:, :-1].clone()
+
+    def _init_amp_obs(self, env_ids):
+        self._compute_amp_observations(env_ids)
+        if len(self._reset_default_env_ids) > 0:
+            ids = self._reset_default_env_ids
+            self._hist_amp_obs_buf[ids] = self._curr_amp_obs_buf[ids].unsqueeze(-2)
+        if len(self._reset_ref_env_ids) > 0:
+            ids, steps = self._reset_ref_env_ids, self._num_amp_obs_steps - 1
+            mids = np.tile(np.expand_dims(self._reset_ref_motion_ids, axis=-1), [1, steps]).flatten()
+            times = (np.expand_dims(self._reset_ref_motion_times, axis=-1) + (-self.dt * (np.arange(0, steps) + 1))).flatten()
+            self._hist_amp_obs_buf[ids] = self._motion_amp_obs(mids, times).view(len(ids), steps, NUM_AMP_OBS_PER_STEP)
+
+    def _motion_amp_obs(self, motion_ids, motion_times):
+        root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_pos = self._motion_lib.get_motion_state(motion_ids, motion_times)
+        root_states = torch.cat([root_pos, root_rot, root_vel, root_ang_vel], dim=-1).contiguous()
+        out = torch.empty(root_states.shape[0], NUM_AMP_OBS_PER_STEP, dtype=torch.float, device=self._tdev)
+        return self._build_amp_obs(root_states, dof_pos.contiguous(), dof_vel.contiguous(), key_pos.contiguous(), out)
+
+    def fetch_amp_obs_demo(self, num_samples):
+        """[num_samples, numAMPObsSteps * 34] demonstration observations: a random motion and time per sample and the steps before it."""
+        if self._motion_lib is None:
+            raise RuntimeError("fetch_amp_obs_demo needs the motion library: set cfg.env.motion_file")
+        ml, steps = self._motion_lib, self._num_amp_obs_steps
+        motion_ids = ml.sample_motions(num_samples)
+        if self._amp_obs_demo_buf is None:
+            self._amp_obs_demo_buf = torch.zeros(num_samples, steps, NUM_AMP_OBS_PER_STEP, dtype=torch.float, device=self._tdev)
+        else:
+            assert self._amp_obs_demo_buf.shape[0] == num_samples
+        times0 = ml.sample_time(motion_ids)
+        mids = np.tile(np.expand_dims(motion_ids, axis=-1), [1, steps]).flatten()
+        times = (np.expand_dims(times0, axis=-1) + (-self.dt * np.arange(0, steps))).flatten()
+        self._amp_obs_demo_buf[:] = self._motion_amp_obs(mids, times).view(self._amp_obs_demo_buf.shape)
+        return self._amp_obs_demo_buf.view(-1, self.num_amp_obs)
 
     # ------------------------------------------------------------------ observations (:540-610)
     def _compute_humanoid_obs(self):
@@ -430,6 +564,10 @@ class TocabiAMPLower(VecTask):
         self.extras["terminate"] = self._terminate_buf
         self._dof_vel_pre = dv.clone()
         self.actions_pre = self.actions.clone()
+        # the AMP subclass' part (tasks/tocabi_amp_lower.py:88-96)
+        self._update_hist_amp_obs()
+        self._compute_amp_observations()
+        self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.num_amp_obs)
 
     def step(self, actions):                              # :806-845
         action_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)

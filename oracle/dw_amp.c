@@ -6,6 +6,9 @@
  *
  *   dwo_amp_observations   tasks/amp/tocabi_amp_lower_base.py:918-962  compute_humanoid_observations
  *                          (quat2euler: python/isaacgym/torch_utils.py:227-273, quat_rotate_inverse: :72-81)
+ *   dwo_amp_disc_observations  tasks/tocabi_amp_lower.py:310-350 build_amp_observations (the AMP subclass' discriminator
+ *                          observation; my_quat_rotate / calc_heading_quat_inv: utils/torch_jit_utils.py:199-209,333-368;
+ *                          quat_from_angle_axis / normalize: python/isaacgym/torch_utils.py:44-46,92-102)
  *   dwo_amp_reward         tasks/amp/tocabi_amp_lower_base.py:964-1023 compute_humanoid_reward
  *   dwo_amp_reset          tasks/amp/tocabi_amp_lower_base.py:1025-1069 compute_humanoid_reset
  *                          (quat_diff_rad: utils/torch_jit_utils.py:141-160)
@@ -102,6 +105,66 @@ int dwo_amp_observations(int n, const float *root_states, const float *rootvel_n
         for (int i = 0; i < 3; ++i) o[9 + i] = commands[3 * e + i];
         for (int i = 0; i < 12; ++i) o[12 + i] = dof_pos[33 * e + i] + dof_pos_bias[12 * e + i];
         for (int i = 0; i < 12; ++i) o[24 + i] = dof_vel[33 * e + i];
+    }
+    return DW_OK;
+}
+
+/* my_quat_rotate(q, v) = a + b + c, utils/torch_jit_utils.py:199-209 */
+static void my_quat_rotate(const float *q, const float *v, float *o) {
+    const float w = q[3];
+    const float s = 2.0f * (w * w) - 1.0f;
+    const float cr[3] = {fmaf(q[1], v[2], -(q[2] * v[1])), fmaf(q[2], v[0], -(q[0] * v[2])), fmaf(q[0], v[1], -(q[1] * v[0]))};
+    const float dot = (q[0] * v[0] + q[1] * v[1]) + q[2] * v[2];
+    for (int i = 0; i < 3; ++i) {
+        const float a = v[i] * s;
+        const float b = cr[i] * w * 2.0f;
+        const float c = q[i] * dot * 2.0f;
+        o[i] = a + b + c;
+    }
+}
+
+/* calc_heading_quat_inv(q), utils/torch_jit_utils.py:333-368: heading = atan2 of the rotated x axis, then
+ * quat_unit(quat_from_angle_axis(-heading, z)) */
+static void heading_quat_inv(const float *q, float *hq) {
+    const float ref[3] = {1.0f, 0.0f, 0.0f};
+    float rd[3];
+    my_quat_rotate(q, ref, rd);
+    const float heading = atan2f(rd[1], rd[0]);
+    const float theta = (-heading) / 2.0f;
+    const volatile float zero = 0.0f;                       /* (0 * sin keeps the product's sign) */
+    const float sn = sinf(theta), cs = cosf(theta);
+    float u[4] = {zero * sn, zero * sn, 1.0f * sn, cs};
+    float nn = norm_t(u, 4);
+    nn = nn < 1e-9f ? 1e-9f : nn;
+    for (int i = 0; i < 4; ++i) hq[i] = u[i] / nn;
+}
+
+int dwo_amp_disc_observations(int n, const float *root_states, const float *dof_pos, const float *dof_vel, int dof_row_stride,
+                               int dof_elem_stride, int local_root_obs, const float *key_pos, int n_key, float *obs, void *stream) {
+    (void)stream;
+    if (n <= 0 || n_key < 1 || n_key > DW_MAX_BODY_QUERY || dof_elem_stride < 1) return DW_EINVAL;
+    const int W = DW_AMP_DISC_BASE + 3 * n_key;
+    for (int e = 0; e < n; ++e) {
+        const float *r = root_states + 13 * (size_t)e;
+        float *o = obs + (size_t)W * e;
+        float hq[4], eu[3];
+        heading_quat_inv(r + 3, hq);
+        quat2euler(r + 3, eu);
+        o[0] = r[2];
+        for (int i = 0; i < 3; ++i) o[1 + i] = eu[i];
+        for (int i = 0; i < 12; ++i) o[4 + i] = dof_pos[(size_t)dof_row_stride * e + (size_t)dof_elem_stride * i];
+        for (int i = 0; i < 12; ++i) o[16 + i] = dof_vel[(size_t)dof_row_stride * e + (size_t)dof_elem_stride * i];
+        for (int k = 0; k < n_key; ++k) {
+            const float *kp = key_pos + ((size_t)n_key * e + k) * 3;
+            if (local_root_obs) {
+                for (int i = 0; i < 3; ++i) o[DW_AMP_DISC_BASE + 3 * k + i] = kp[i];
+            } else {
+                const float lp[3] = {kp[0] - r[0], kp[1] - r[1], kp[2] - r[2]};
+                float le[3];
+                my_quat_rotate(hq, lp, le);
+                for (int i = 0; i < 3; ++i) o[DW_AMP_DISC_BASE + 3 * k + i] = le[i];
+            }
+        }
     }
     return DW_OK;
 }

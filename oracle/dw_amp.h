@@ -10,6 +10,8 @@ extern "C" {
 int dwo_amp_observations(int n, const float *root_states, const float *rootvel_noise, const float *dof_pos,
                           const float *dof_pos_bias, const float *quat_bias, const float *dof_vel, const float *commands,
                           float *obs, void *stream);
+int dwo_amp_disc_observations(int n, const float *root_states, const float *dof_pos, const float *dof_vel, int dof_row_stride,
+                               int dof_elem_stride, int local_root_obs, const float *key_pos, int n_key, float *obs, void *stream);
 int dwo_amp_reward(int n, const float *root_states, const float *dof_vel, const float *dof_vel_pre, const float *commands,
                     const float *actions, const float *actions_pre, const float *motor_efforts, const float *contact_force,
                     const float *total_mass, float *reward, float *reward_values, void *stream);

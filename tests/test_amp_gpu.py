@@ -240,3 +240,178 @@ def test_tocabi_amp_lower_class_replays_the_reference_class():
     assert state["tau_err"] == 0.0, state["tau_err"]                               # the torques handed to the engine, bit for bit
     assert g["ref__terminate_buf"].sum() > 0 and (g["ref_reset_ids"][1:] >= 0).sum() > 0          # the fixture terminates and resets envs
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The AMP subclass' layer (reference tasks/tocabi_amp_lower.py): discriminator observations, reference state initialisation
+GD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "amp_disc_ref.npz")
+
+
+def _disc(api, chk, root, dp, dv, row, elem, local, key, cuda):
+    N, nk = root.shape[0], key.shape[1]
+    if cuda:
+        out = torch.zeros(N, 28 + 3 * nk, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+    else:
+        out = np.zeros((N, 28 + 3 * nk), np.float32)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+    chk(api["amp_disc_observations"](N, p(root), p(dp), p(dv), row, elem, int(local), p(key), nk, p(out), None))
+    return out
+
+
+def test_amp_disc_observations_hip_vs_oracle_and_reference():
+    from isaacgymdyros_amd import _lib
+    from oracle import oracle
+    g = np.load(GD)
+    lib, api = _lib.load()
+    olib, oapi = oracle.load()
+
+    def chk(rc):
+        assert rc == 0, lib.dw_last_error()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    root, key, dp, dv = (np.ascontiguousarray(g[k]) for k in ("root_states", "key_pos", "dof_pos", "dof_vel"))
+    for local in (0, 1):
+        h = _disc(api, chk, cu(root), cu(dp), cu(dv), 33, 1, local, cu(key), True)
+        torch.cuda.synchronize()
+        h = h.cpu().numpy()
+        o = _disc(oapi, chk, root, dp, dv, 33, 1, local, key, False)
+        ref = g["ref_obs_local%d" % local]
+        d = ulps(h, ref)
+        copies = [0] + list(range(4, 28))
+        assert d[:, copies].max() == 0                                  # root height and the 24 dof entries: the reference's bits
+        assert np.abs(h[:, 1:4] - ref[:, 1:4]).max() <= 2.4e-7          # Euler angles: atan2f (as dw_amp_observations above)
+        if local:
+            assert d[:, 28:].max() == 0
+        else:
+            # key bodies in the heading frame: downstream of atan2f / sinf / cosf of the heading (positions of order 1 m)
+            assert np.abs(h[:, 28:] - ref[:, 28:]).max() <= 1e-6, np.abs(h[:, 28:] - ref[:, 28:]).max()
+        assert np.abs(h - o).max() <= 1e-6
+    # the two halves of an interleaved dof_state and the motion library's 12-wide tensors
+    ds = cu(np.stack([dp, dv], axis=-1))
+    h_il = _disc(api, chk, cu(root), ds[..., 0], ds[..., 1], 66, 2, 0, cu(key), True)
+    h_33 = _disc(api, chk, cu(root), cu(dp), cu(dv), 33, 1, 0, cu(key), True)
+    h_12 = _disc(api, chk, cu(root), cu(dp[:, :12]), cu(dv[:, :12]), 12, 1, 0, cu(key), True)
+    torch.cuda.synchronize()
+    assert torch.equal(h_il, h_33) and torch.equal(h_12, h_33)
+    # argument checks: key-body count and strides
+    x = torch.zeros(64, 66, device="cuda")
+    assert api["amp_disc_observations"](4, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), 33, 1, 0,
+                                        C.c_void_p(x.data_ptr()), 9, C.c_void_p(x.data_ptr()), None) != 0
+    assert api["amp_disc_observations"](4, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), 12, 2, 0,
+                                        C.c_void_p(x.data_ptr()), 2, C.c_void_p(x.data_ptr()), None) != 0
+    assert b"amp_disc_observations" in lib.dw_last_error()
+
+
+def _oracle_disc_of_env(env):
+    from oracle import oracle
+    olib, oapi = oracle.load()
+    root = env._root_states.cpu().numpy()
+    ds = np.ascontiguousarray(env._dof_state.cpu().numpy()).reshape(-1)
+    key = np.ascontiguousarray(env._foot_pos.cpu().numpy())
+
+    def chk(rc):
+        assert rc == 0
+    return _disc(oapi, chk, np.ascontiguousarray(root), ds, ds[1:], 66, 2, 0, key, False)
+
+
+def test_tocabi_amp_lower_amp_obs_history():
+    """stateInit Default: a reset env's AMP history is copies of its current observation; stepping shifts the history by one slot
+    and the newest slot is build_amp_observations of the current state (checked against the CPU oracle)."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg, NUM_AMP_OBS_PER_STEP
+    N = 128
+    cfg = default_amp_cfg(N, "cuda:0")
+    cfg["env"]["numAMPObsSteps"] = 3
+    env = TocabiAMPLower(cfg, "cuda:0", 0, True)
+    assert env.get_num_amp_obs() == 3 * NUM_AMP_OBS_PER_STEP == 102 and env.amp_observation_space.shape == (102,)
+    env.reset_done()
+    b = env._amp_obs_buf
+    assert torch.equal(b[:, 1], b[:, 0]) and torch.equal(b[:, 2], b[:, 0])
+    assert float(b[:, 0, 0].min()) > 0.9 and torch.equal(b[:, 0, 4:16], env._dof_pos[:, :12])          # root height, leg angles
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(30):
+        prev = env._amp_obs_buf.clone()
+        _, _, reset, extras = env.step((torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * 0.5)
+        cur = env._amp_obs_buf
+        assert extras["amp_obs"].shape == (N, 102) and extras["amp_obs"].data_ptr() == cur.data_ptr()
+        assert torch.equal(cur[:, 1:], prev[:, :-1])
+        assert np.abs(cur[:, 0].cpu().numpy() - _oracle_disc_of_env(env)).max() <= 1e-6
+        _, ids = env.reset_done()
+        if len(ids):
+            assert torch.equal(env._amp_obs_buf[ids, 1], env._amp_obs_buf[ids, 0])
+            keep = torch.ones(N, dtype=torch.bool, device="cuda")
+            keep[ids] = False
+            assert torch.equal(env._amp_obs_buf[keep], cur[keep])
+    env.close()
+
+
+def test_tocabi_amp_lower_reference_state_init(tmp_path):
+    """stateInit Random / Start / Hybrid on synthetic motion tables: reset envs start at the motion library's state for the ids and
+    times it drew (numpy's global generator, re-seeded here to know them), their AMP history holds the motion's earlier frames,
+    and fetch_amp_obs_demo returns the demonstration observations of the same function."""
+    from isaacgymdyros_amd.motion_lib import TocabiLowerMotionLib
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+    from oracle import oracle
+    from tests import amp_motion_synth as SY
+    olib, oapi = oracle.load()
+    yml = SY.write(str(tmp_path))
+    ml = TocabiLowerMotionLib(yml, 33, "cpu")
+    N = 64
+
+    def chk(rc):
+        assert rc == 0
+
+    def motion_obs(ids, times):
+        rp, rr, rv, ra, dp, dv, kp = ml.get_motion_state(ids, times)
+        root = torch.cat([rp, rr, rv, ra], dim=-1).numpy()
+        return _disc(oapi, chk, np.ascontiguousarray(root), np.ascontiguousarray(dp.numpy()), np.ascontiguousarray(dv.numpy()), 12, 1, 0,
+                     np.ascontiguousarray(kp.numpy()), False), (rp, rr, rv, ra, dp, dv)
+    with pytest.raises(ValueError, match="motion_file"):
+        c = default_amp_cfg(N, "cuda:0"); c["env"]["stateInit"] = "Random"
+        TocabiAMPLower(c, "cuda:0", 0, True)
+    for mode in ("Random", "Start", "Hybrid"):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["env"].update({"stateInit": mode, "motion_file": yml, "numAMPObsSteps": 3, "hybridInitProb": 0.5})
+        env = TocabiAMPLower(cfg, "cuda:0", 0, True)
+        np.random.seed(77)
+        _, ids = env.reset_done()
+        assert len(ids) == N
+        ref_ids = env._reset_ref_env_ids
+        n_ref = len(ref_ids)
+        np.random.seed(77)
+        mids = ml.sample_motions(n_ref)
+        mt = ml.sample_time(mids) if mode != "Start" else np.zeros(n_ref)
+        assert np.array_equal(mids, env._reset_ref_motion_ids) and np.array_equal(mt, env._reset_ref_motion_times)
+        if mode == "Hybrid":
+            assert 0 < n_ref < N and len(env._reset_default_env_ids) == N - n_ref
+            dflt = env._reset_default_env_ids
+            assert torch.equal(env._dof_pos[dflt], env._initial_dof_pos[dflt]) and torch.equal(env._amp_obs_buf[dflt, 1], env._amp_obs_buf[dflt, 0])
+        else:
+            assert n_ref == N
+        _, (rp, rr, rv, ra, dp, dv) = motion_obs(mids, mt)
+        rs = env._root_states[ref_ids].cpu()
+        tol = dict(rtol=0, atol=2e-6)           # (slerp's acos / sin on the device against torch's CPU kernels)
+        assert torch.allclose(rs[:, 0:3], rp, **tol) and torch.allclose(rs[:, 3:7], rr, **tol)
+        assert torch.allclose(rs[:, 7:10], rv, **tol) and torch.allclose(rs[:, 10:13], ra, **tol)
+        assert torch.allclose(env._dof_pos[ref_ids, :12].cpu(), dp, **tol) and torch.allclose(env._dof_vel[ref_ids, :12].cpu(), dv, **tol)
+        assert torch.equal(env._dof_pos[ref_ids, 12:], env._initial_dof_pos[ref_ids, 12:]) and float(env._dof_vel[ref_ids, 12:].abs().max()) == 0.0
+        # history slots 1, 2 = the motion 1 and 2 simulation steps earlier
+        for k in (1, 2):
+            exp, _ = motion_obs(mids, mt - env.dt * k)
+            got = env._amp_obs_buf[ref_ids, k].cpu().numpy()
+            assert np.allclose(got, exp, rtol=0, atol=2e-5, equal_nan=True), (mode, k, np.nanmax(np.abs(got - exp)))
+        # demonstrations
+        np.random.seed(5)
+        demo = env.fetch_amp_obs_demo(32)
+        assert demo.shape == (32, 102)
+        np.random.seed(5)
+        di = ml.sample_motions(32)
+        dt0 = ml.sample_time(di)
+        for k in range(3):
+            exp, _ = motion_obs(di, dt0 - env.dt * k)
+            got = demo[:, 34 * k:34 * (k + 1)].cpu().numpy()
+            assert np.allclose(got, exp, rtol=0, atol=2e-5, equal_nan=True), (mode, k, np.nanmax(np.abs(got - exp)))
+        # and the env steps from there
+        for t in range(5):
+            obs, rew, reset, extras = env.step(torch.zeros(N, 12, device="cuda"))
+            assert torch.isfinite(obs["obs"]).all() and extras["amp_obs"].shape == (N, 102)
+        env.close()
