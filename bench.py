@@ -22,7 +22,11 @@ A_STEP_BYTES = 6816        # algorithmic bytes per env-step, SURVEY.md section 8
 A_PHYS_BYTES = 1636        # algorithmic bytes per env-substep at the Gym boundary, SURVEY.md section 8(d): 409 words
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HORIZON = 128              # rollout horizon of the reference's PPO config; logging gather once per horizon
-VALU_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
+VALU_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32 vector peak (packed v_pk_fma_f32: 64 flop / clk / SIMD)
+# Plain (unpacked) fp32 vector instructions issue at one wave64 instruction per ~4.6 cycles per SIMD however many waves share it
+# (tools/valu_issue.hip on the MI355X, profiles/r03g_valu_issue.txt: 2.941 / 4.945 / 9.125 ms for 1.28 M independent v_fma_f32 per
+# wave at 1 / 2 / 4 waves per SIMD) -- half the packed peak.  Seconds per instruction per SIMD at two waves per SIMD:
+VALU_ISSUE_S_2W = 4.945e-3 / (20000 * 64 * 2)
 FLOPS_PER_ENV_STEP = 1.0e5 # useful flops of one env-step (2 substeps: ABA ~14 k + contact ~30 k each, task logic ~5 k), SURVEY 8(d)
 
 
@@ -333,6 +337,15 @@ def main():
                           "note": "cfg sim.mi355.alias_obs: step() returns the view of obs_buf (no copy kernel on the stream)"},
             "episodes": dict(head["episodes"], finished_total=head["resets"]),
         }
+        if lane_slots and torch.cuda.is_available():
+            # what binds the kernel at this size: the SIMD's vector-instruction issue.  Floor = the kernel's own VALU instruction
+            # count (PMC) at the measured issue rate of plain fp32 instructions, spread evenly over the device's SIMDs
+            simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+            floor_ms = lane_slots / 64.0 * args.envs_per_gpu / simds * VALU_ISSUE_S_2W * 1e3
+            out["roofline_valu"]["issue"] = {"valu_instructions_per_simd": lane_slots / 64.0 * args.envs_per_gpu / simds,
+                                             "ns_per_instruction_per_simd": VALU_ISSUE_S_2W * 1e9, "issue_floor_ms": floor_ms,
+                                             "frac_of_issue_floor": floor_ms / kernel_ms,
+                                             "note": "plain v_fma_f32 rate at 2 waves per SIMD, tools/valu_issue.hip"}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
         if alias.get("sim_ms"):

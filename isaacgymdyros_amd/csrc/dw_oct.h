@@ -5,8 +5,8 @@
 //
 // Why octets.  A body-env slot is 64 bytes, so 160 KB of LDS hold 64 envs per CU whatever the lane mapping.  The quad
 // kernels (4 lanes per env, 16 envs per wave) therefore run ONE wave per SIMD -- and one wave alone issues a vector
-// instruction every 4 cycles where the SIMD could take one every 2 (MI355X_MICROARCH.md, constants table), and nothing
-// covers its LDS / memory round trips.  Here the same 64 envs per CU are 8 waves of 8 envs: two waves per SIMD, each with
+// instruction every 5.5 cycles where two waves together get one every 4.6 (tools/valu_issue.hip; plain fp32 instructions do
+// not reach the 2 cycles of MI355X_MICROARCH.md's constants table), and nothing covers its LDS / memory round trips.  Here the same 64 envs per CU are 8 waves of 8 envs: two waves per SIMD, each with
 // half the envs' joint-parallel work per lane and at most 256 registers, and the phases with two-way data parallelism
 // inside an env (self-collision pairs, the 12 unit-wrench responses of the contact phase, the corner blocks) use the
 // second quad of the octet for it.
@@ -71,8 +71,32 @@ DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
 // through the 64 KB instruction cache (measured: +5 % step time)
 #if defined(__HIPCC__) && !defined(OCT_UNROLLED)
 #define DQ_ROLLED _Pragma("clang loop unroll(disable)")
+#if defined(OCT_U_FK)
+#define DQ_ROLLED_FK _Pragma("clang loop unroll_count(OCT_U_FK)")
+#else
+#define DQ_ROLLED_FK DQ_ROLLED
+#endif
+#if defined(OCT_U_IN)
+#define DQ_ROLLED_IN _Pragma("clang loop unroll_count(OCT_U_IN)")
+#else
+#define DQ_ROLLED_IN DQ_ROLLED
+#endif
+#if defined(OCT_U_O2)
+#define DQ_ROLLED_O2 _Pragma("clang loop unroll_count(OCT_U_O2)")
+#else
+#define DQ_ROLLED_O2 DQ_ROLLED
+#endif
+#if defined(OCT_U_O3)
+#define DQ_ROLLED_O3 _Pragma("clang loop unroll_count(OCT_U_O3)")
+#else
+#define DQ_ROLLED_O3 DQ_ROLLED
+#endif
 #else
 #define DQ_ROLLED
+#define DQ_ROLLED_FK
+#define DQ_ROLLED_IN
+#define DQ_ROLLED_O2
+#define DQ_ROLLED_O3
 #endif
 // 16-byte LDS loads that stay 16 bytes wide.  A load whose .w is unused is narrowed to ds_read_b96 (twice the LDS cycles of
 // ds_read_b128, MI355X_MICROARCH.md); dw_quad.h's ld4() prevents that with an opaque touch after EVERY load, which also makes
@@ -240,7 +264,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
             }
         };
-        DQ_ROLLED for (int s = 0; s < T; ++s) {
+        DQ_ROLLED_FK for (int s = 0; s < T; ++s) {
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             // (both halves of a limb walk it: every lane reads its slot row before any lane overwrites it)
@@ -419,7 +443,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #if defined(OCT_ABL_INWARD)
     DQ_ROLLED for (int s = 0; s < 0; s += 2) {
 #else
-    DQ_ROLLED for (int s = 0; s < T; s += 2) {
+    DQ_ROLLED_IN for (int s = 0; s < T; s += 2) {
 #endif
         OQ_TICK();
 #if defined(DQ_STAMPS_INWARD)
@@ -729,7 +753,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     //      pass 1) ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
-        DQ_ROLLED for (int s = 0; s < T; ++s) {
+        DQ_ROLLED_O2 for (int s = 0; s < T; ++s) {
             const int bits = f2i(H.fk[s][j][3]);
             const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
@@ -1074,7 +1098,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0};
-        DQ_ROLLED for (int s = 0; s < T; ++s) {
+        DQ_ROLLED_O3 for (int s = 0; s < T; ++s) {
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
