@@ -71,32 +71,8 @@ DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
 // through the 64 KB instruction cache (measured: +5 % step time)
 #if defined(__HIPCC__) && !defined(OCT_UNROLLED)
 #define DQ_ROLLED _Pragma("clang loop unroll(disable)")
-#if defined(OCT_U_FK)
-#define DQ_ROLLED_FK _Pragma("clang loop unroll_count(OCT_U_FK)")
-#else
-#define DQ_ROLLED_FK DQ_ROLLED
-#endif
-#if defined(OCT_U_IN)
-#define DQ_ROLLED_IN _Pragma("clang loop unroll_count(OCT_U_IN)")
-#else
-#define DQ_ROLLED_IN DQ_ROLLED
-#endif
-#if defined(OCT_U_O2)
-#define DQ_ROLLED_O2 _Pragma("clang loop unroll_count(OCT_U_O2)")
-#else
-#define DQ_ROLLED_O2 DQ_ROLLED
-#endif
-#if defined(OCT_U_O3)
-#define DQ_ROLLED_O3 _Pragma("clang loop unroll_count(OCT_U_O3)")
-#else
-#define DQ_ROLLED_O3 DQ_ROLLED
-#endif
 #else
 #define DQ_ROLLED
-#define DQ_ROLLED_FK
-#define DQ_ROLLED_IN
-#define DQ_ROLLED_O2
-#define DQ_ROLLED_O3
 #endif
 // 16-byte LDS loads that stay 16 bytes wide.  A load whose .w is unused is narrowed to ds_read_b96 (twice the LDS cycles of
 // ds_read_b128, MI355X_MICROARCH.md); dw_quad.h's ld4() prevents that with an opaque touch after EVERY load, which also makes
@@ -264,7 +240,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
             }
         };
-        DQ_ROLLED_FK for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             // (both halves of a limb walk it: every lane reads its slot row before any lane overwrites it)
@@ -443,7 +419,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #if defined(OCT_ABL_INWARD)
     DQ_ROLLED for (int s = 0; s < 0; s += 2) {
 #else
-    DQ_ROLLED_IN for (int s = 0; s < T; s += 2) {
+    DQ_ROLLED for (int s = 0; s < T; s += 2) {
 #endif
         OQ_TICK();
 #if defined(DQ_STAMPS_INWARD)
@@ -753,7 +729,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     //      pass 1) ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
-        DQ_ROLLED_O2 for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {
             const int bits = f2i(H.fk[s][j][3]);
             const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
@@ -1098,7 +1074,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0};
-        DQ_ROLLED_O3 for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
