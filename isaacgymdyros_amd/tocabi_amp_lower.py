@@ -121,6 +121,9 @@ class TorchDraws:
     def normal(self, shape, std):
         return torch.randn(*shape, device=self.device, generator=self.gen) * std
 
+    def bernoulli(self, n, p):
+        return torch.bernoulli(torch.full((n,), float(p), device=self.device), generator=self.gen)
+
 
 class TocabiAMPLower(VecTask):
 
@@ -329,6 +332,11 @@ class TocabiAMPLower(VecTask):
         self._compute_observations(env_ids)
         self._dof_vel_pre[env_ids] = 0.0
         self.actions_pre[env_ids] = 0.0
+        # the reference now writes the INITIAL root state over the reset envs' rows (:262-263, no custom origins) -- also over the root
+        # pose and velocity a reference start has just taken from the motion library: a motion start keeps the motion's joint state and
+        # its reset observation, but stands at the default place (its key-body rows, refreshed above, are still the motion's when
+        # _init_amp_obs reads them)
+        self._root_states[env_ids] = self._initial_root_states[env_ids]
         self.commands[env_ids, 0] = self._rand_float(self.c_x[0], self.c_x[1], (n,))
         self.commands[env_ids, 1] = self._rand_float(self.c_y[0], self.c_y[1], (n,))
         self.commands[env_ids, 2] = self._rand_float(self.c_yaw[0], self.c_yaw[1], (n,))
@@ -356,13 +364,15 @@ class TocabiAMPLower(VecTask):
 
     # ------------------------------------------------------------------ state initialisation (tasks/tocabi_amp_lower.py:149-256)
     def _reset_actors(self, env_ids):
-        self._reset_default_env_ids, self._reset_ref_env_ids = [], []
+        # (as in the reference, _reset_default_env_ids / _reset_ref_env_ids are NOT cleared here: the ids of an earlier reset of the
+        #  other kind stay listed, and _init_amp_obs re-initialises those envs' AMP history too -- tasks/tocabi_amp_lower.py:258-267;
+        #  the class-level fixture tests/golden/amp_subclass_ref.npz holds this class to it)
         if self._state_init == "Default":
             self._reset_default(env_ids)
         elif self._state_init in ("Start", "Random"):
             self._reset_ref_state_init(env_ids)
         else:                                             # Hybrid: a reference start with probability hybridInitProb, else the default pose
-            ref = torch.bernoulli(torch.full((len(env_ids),), self._hybrid_init_prob, device=self._tdev), generator=self._rng.gen) == 1.0
+            ref = self._rng.bernoulli(len(env_ids), self._hybrid_init_prob) == 1.0
             if bool(ref.any()):
                 self._reset_ref_state_init(env_ids[ref])
             if bool((~ref).any()):
