@@ -263,6 +263,7 @@ class TocabiAMPLower(VecTask):
         self._curr_amp_obs_buf = self._amp_obs_buf[:, 0]
         self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
         self._amp_obs_demo_buf = None
+        self._graph, self._capturing, self._g_actions, self._g_out = None, False, None, None
         self._amp_obs1 = torch.zeros(N, NUM_AMP_OBS_PER_STEP, **f)
         self._reset_default_env_ids, self._reset_ref_env_ids = [], []
         self._reset_ref_motion_ids = self._reset_ref_motion_times = None
@@ -289,8 +290,13 @@ class TocabiAMPLower(VecTask):
     def _chk(self, rc):
         _lib.check(self._api, rc)
 
+    def _stream(self):
+        """torch's current stream on the task's device: the entry points launch where torch's own kernels of this step run (the
+        null stream in eager use, the capturing stream while enable_graph_step() records a step)."""
+        return C.c_void_p(torch.cuda.current_stream(self._tdev).cuda_stream)
+
     def _foot_positions(self):
-        self._chk(self._api["body_positions"](self._phys._h, self._foot_mv, 2, _p(self._foot_pos), None))
+        self._chk(self._api["body_positions"](self._phys._h, self._foot_mv, 2, _p(self._foot_pos), self._stream()))
 
     def _refresh_sim_tensors(self):
         """refresh_*_tensor of the reference (:527-538): the Gym tensors are the physics' own buffers; the three rigid-body rows
@@ -416,7 +422,7 @@ class TocabiAMPLower(VecTask):
         assert root_states.is_contiguous() and key_pos.is_contiguous() and out.is_contiguous()
         assert dof_pos.stride() == dof_vel.stride()
         self._chk(self._api["amp_disc_observations"](n, _p(root_states), _p(dof_pos), _p(dof_vel), dof_pos.stride(0), dof_pos.stride(1),
-                                                     int(self._local_root_obs), _p(key_pos), key_pos.shape[1], _p(out), None))
+                                                     int(self._local_root_obs), _p(key_pos), key_pos.shape[1], _p(out), self._stream()))
         return out
 
     def _compute_amp_observations(self, env_ids=None):
@@ -470,7 +476,7 @@ class TocabiAMPLower(VecTask):
         N = self.num_envs
         nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
         self._chk(self._api["amp_observations"](N, _p(self._root_states), _p(nz), _p(self.qpos_noise), _p(self.qpos_bias), _p(self.quat_bias),
-                                                _p(self.qvel_noise), _p(self.commands), _p(self._obs1), None))
+                                                _p(self.qvel_noise), _p(self.commands), _p(self._obs1), self._stream()))
         return self._obs1
 
     def _compute_observations(self, env_ids=None):
@@ -480,7 +486,7 @@ class TocabiAMPLower(VecTask):
             # dof_pos_bias`, :945), and on this path that tensor is self.qpos_noise itself: the encoder reading carries the
             # bias from here to the next substep -- and an env that resets now shows it twice in its reset observation
             self.qpos_noise[:, :12] += self.qpos_bias
-            self.obs_history = torch.cat((self.obs_history[:, NUM_OBS:], obs), dim=-1)
+            self.obs_history.copy_(torch.cat((self.obs_history[:, NUM_OBS:], obs), dim=-1))
         else:
             self.obs_history[env_ids] = obs[env_ids].repeat(1, self.num_obs_his * self.num_obs_skip)
         H, S = self.num_obs_his, self.num_obs_skip
@@ -492,8 +498,10 @@ class TocabiAMPLower(VecTask):
     # ------------------------------------------------------------------ pre-physics (:642-748)
     def pre_physics_step(self, actions):
         N, dev = self.num_envs, self._tdev
-        self.actions = actions.to(dev).clone()
-        self.action_history = torch.cat((self.action_history[:, NUM_ACTIONS:], self.actions), dim=-1)
+        # (every piece of state is updated IN PLACE, in tensors that live as long as the env: a step recorded in a hipGraph,
+        #  enable_graph_step(), then reads and writes the same memory at every replay)
+        self.actions.copy_(actions.to(dev))
+        self.action_history.copy_(torch.cat((self.action_history[:, NUM_ACTIONS:], self.actions), dim=-1))
         push = None
         if self.perturb and float(self.epi_len_log.mean()) > self.max_episode_length - 8 / 0.002:
             self.perturb_start = True
@@ -513,7 +521,23 @@ class TocabiAMPLower(VecTask):
             self.pert_on[done] = False
             self.perturbation_count[done] = 0
             push = self._push
-        if self.vel_change:
+        if self.vel_change and (self._graph is not None or self._capturing):
+            # the same command ramp without a host round trip (a recorded step cannot size its draws by a count): draws for every
+            # env, kept where the env changes its command.  Same distributions, another use of the generator's stream than the
+            # reference's, which draws exactly as many numbers as envs change (the eager branch below, pinned by the replay tests)
+            change = (self.epi_len % int(self.max_episode_length / 2)) == int(self.max_episode_length / 4 - 1)
+            self.vel_change_duration.copy_(torch.where(change, self._rng.randint(1, 250, (N,)), self.vel_change_duration))
+            self.cur_vel_change_duration.copy_(torch.where(change, torch.zeros_like(self.cur_vel_change_duration), self.cur_vel_change_duration))
+            ch = change.unsqueeze(-1)
+            self.start_target_vel.copy_(torch.where(ch, self.commands, self.start_target_vel))
+            fin = torch.stack((self._rand_float(self.c_x[0], self.c_x[1], (N,)), self._rand_float(self.c_y[0], self.c_y[1], (N,)),
+                               self._rand_float(self.c_yaw[0], self.c_yaw[1], (N,))), dim=-1)
+            self.final_target_vel.copy_(torch.where(ch, fin, self.final_target_vel))
+            mask = self.cur_vel_change_duration < self.vel_change_duration
+            ramp = self.start_target_vel + (self.final_target_vel - self.start_target_vel) * self.cur_vel_change_duration.unsqueeze(-1) / self.vel_change_duration.unsqueeze(-1)
+            self.commands.copy_(torch.where(mask.unsqueeze(-1), ramp, self.commands))
+            self.cur_vel_change_duration += mask.long()
+        elif self.vel_change:
             change = (self.epi_len % int(self.max_episode_length / 2)) == int(self.max_episode_length / 4 - 1)
             nc = int(change.sum())
             # (the four draws happen every step, of size zero when no env changes its command: the reference's generator stream)
@@ -526,7 +550,7 @@ class TocabiAMPLower(VecTask):
             mask = self.cur_vel_change_duration < self.vel_change_duration
             # (the reference's order of operations, :690-691: difference times elapsed, then divided by the duration)
             ramp = self.start_target_vel + (self.final_target_vel - self.start_target_vel) * self.cur_vel_change_duration.unsqueeze(-1) / self.vel_change_duration.unsqueeze(-1)
-            self.commands = torch.where(mask.unsqueeze(-1), ramp, self.commands)
+            self.commands.copy_(torch.where(mask.unsqueeze(-1), ramp, self.commands))
             self.cur_vel_change_duration += mask.long()
         for _ in range(self.control_freq_inv):
             upper = self.p_gains[12:] * (self.init_angle[12:] - self._dof_pos[:, 12:]) + self.d_gains[12:] * (-self._dof_vel[:, 12:])
@@ -537,8 +561,8 @@ class TocabiAMPLower(VecTask):
                 lower = self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale
                 lower = torch.max(torch.min(lower, self.motor_efforts.unsqueeze(0)), -self.motor_efforts.unsqueeze(0))
                 # delayed-torque FIFO (:712-724): newest at the end, read `delay_idx` back once the FIFO has filled that far
-                self.action_log = torch.cat((self.action_log[:, 1:], lower.unsqueeze(1)), dim=1)
-                self.simul_len = (self.simul_len + 1).clamp(max=self._log_slots, min=0)
+                self.action_log.copy_(torch.cat((self.action_log[:, 1:], lower.unsqueeze(1)), dim=1))
+                self.simul_len.copy_((self.simul_len + 1).clamp(max=self._log_slots, min=0))
                 filled = self.simul_len > self.delay_idx
                 delayed = torch.where(filled.unsqueeze(-1), self.action_log[self._env_ar, self.delay_idx], self.action_log[self._env_ar, -self.simul_len])
                 if self.noise:
@@ -547,11 +571,11 @@ class TocabiAMPLower(VecTask):
             push = None                                  # (applied forces last one simulate())
             if self.noise:
                 z = self._rng.normal((N, 33), 0.00016 / 3.0)
-                self.qpos_noise = self._dof_pos + torch.clamp(z, min=-0.00016, max=0.00016)
+                self.qpos_noise.copy_(self._dof_pos + torch.clamp(z, min=-0.00016, max=0.00016))
             else:
-                self.qpos_noise = self._dof_pos.clone()
-            self.qvel_noise = self._div(self.qpos_noise - self.qpos_pre, self.dt)
-            self.qpos_pre = self.qpos_noise.clone()
+                self.qpos_noise.copy_(self._dof_pos)
+            self.qvel_noise.copy_(self._div(self.qpos_noise - self.qpos_pre, self.dt))
+            self.qpos_pre.copy_(self.qpos_noise)
         self.epi_len += 1
 
     # ------------------------------------------------------------------ post-physics (:750-804)
@@ -564,29 +588,64 @@ class TocabiAMPLower(VecTask):
         dv = self._dof_vel.contiguous()
         self._chk(self._api["amp_reward"](N, _p(self._root_states), _p(dv), _p(self._dof_vel_pre), _p(self.commands), _p(self.actions),
                                           _p(self.actions_pre), _p(self.motor_efforts), _p(self._contact_forces), _p(self.total_mass),
-                                          _p(self.rew_buf), _p(self._reward_values), None))
+                                          _p(self.rew_buf), _p(self._reward_values), self._stream()))
         self.extras["reward_names"] = list(REWARD_NAMES)
         self.extras["reward_values"] = self._reward_values
         self._chk(self._api["amp_reset"](N, _p(self.progress_buf), _p(self._contact_forces), _p(self._contact_body_ids), 2,
                                          _p(self._rigid_body_pos), _p(self._rigid_body_rot), float(self.max_episode_length),
                                          int(bool(self._enable_early_termination)), float(self._termination_height),
-                                         _p(self.reset_buf), _p(self._terminate_buf), None))
+                                         _p(self.reset_buf), _p(self._terminate_buf), self._stream()))
         self.extras["terminate"] = self._terminate_buf
-        self._dof_vel_pre = dv.clone()
-        self.actions_pre = self.actions.clone()
+        self._dof_vel_pre.copy_(dv)
+        self.actions_pre.copy_(self.actions)
         # the AMP subclass' part (tasks/tocabi_amp_lower.py:88-96)
         self._update_hist_amp_obs()
         self._compute_amp_observations()
         self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.num_amp_obs)
 
-    def step(self, actions):                              # :806-845
+    def _step_body(self, actions):
         action_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)
         self.pre_physics_step(action_tensor)
         self.post_physics_step()
-        self.timeout_buf = (self.progress_buf >= self.max_episode_length - 1) & (self.reset_buf != 0)
+        self.timeout_buf.copy_((self.progress_buf >= self.max_episode_length - 1) & (self.reset_buf != 0))
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+
+    def step(self, actions):                              # :806-845
+        if self._graph is None:
+            return self._step_body(actions)
+        self._g_actions.copy_(actions)
+        self._graph.replay()
+        self.obs_dict["obs"] = self._g_obs               # (reset_done() puts its own tensor there between two steps)
+        return self._g_out
+
+    def enable_graph_step(self, warmup: int = 3):
+        """Records one step() -- the ~100 elementwise torch launches, the two dw_simulate launches and the HIP entry points between
+        them -- in a hipGraph and replays it from then on (reset_done() stays eager: it returns ids to the host).  What changes for
+        the caller: the tensors step() returns are the same objects every time, overwritten by the next step (copy what you keep);
+        the command ramp draws for every env instead of for the envs that change (pre_physics_step).  `warmup` real steps with
+        zero actions run first, as a capture requires.  Needs perturbation off (its schedule reads a mean back to the host)."""
+        if self.perturb:
+            raise ValueError("enable_graph_step: env.perturbation reads a population mean on the host every step; not capturable")
+        if self.rl_device != self.device:
+            raise ValueError("enable_graph_step: rl_device must be the simulation device")
+        dev = self._tdev
+        self._g_actions = torch.zeros(self.num_envs, NUM_ACTIONS, device=dev)
+        self._capturing = True
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                self._step_body(self._g_actions)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        graph.register_generator_state(self._rng.gen)
+        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+            self._g_out = self._step_body(self._g_actions)
+        self._g_obs = self.obs_dict["obs"]
+        self._graph = graph              # (_capturing stays set: pre_physics_step keeps to the recorded branch if it is ever run eagerly again)
 
     def close(self):
         self._phys.close()

@@ -498,3 +498,41 @@ def test_tocabi_amp_lower_subclass_replays_the_reference_subclass(tmp_path):
     assert np.abs(np.stack(demos) - g["ref_demos"]).max() <= tol_amp
     print("AMP observation history vs the reference subclass: max |diff| %.2e over %d steps (%d reference starts, %d default starts)" % (amp_err, STEPS, n_ref, n_default))
     env.close()
+
+
+def test_tocabi_amp_lower_graph_step_equals_eager():
+    """enable_graph_step(): the recorded step replayed 60 times (reset_done() eager between the replays) against a second env that
+    runs the same branch of the step eagerly -- same seeds, same actions: observations, rewards, resets, the AMP history and the
+    physics state agree bit for bit (the generator is registered with the graph, so both draw the same numbers)."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+    N = 256
+    envs = []
+    for k in range(2):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["env"]["episodeLength"] = 40
+        envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
+    a, b = envs
+    for e in envs:
+        e.reset_done()
+    a.enable_graph_step(warmup=3)
+    b._capturing = True                                   # the recorded branch of the command ramp, run eagerly
+    for _ in range(3):
+        b._step_body(torch.zeros(N, 12, device="cuda"))
+    g = torch.Generator(device="cuda").manual_seed(9)
+    resets = 0
+    for t in range(60):
+        for e in envs:
+            e.reset_done()
+        act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * 0.8
+        oa, ra, da, xa = a.step(act)
+        ob, rb, db, xb = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), t
+        assert torch.equal(xa["amp_obs"], xb["amp_obs"]) and torch.equal(xa["time_outs"], xb["time_outs"]), t
+        assert torch.equal(a._root_states, b._root_states) and torch.equal(a._dof_state, b._dof_state) and torch.equal(a.commands, b.commands), t
+        resets += int(da.sum())
+    assert resets > N // 2                               # falls and the 40-step episode limit: the reset path ran between replays
+    with pytest.raises(ValueError, match="perturbation"):
+        c = default_amp_cfg(64, "cuda:0"); c["env"]["perturbation"] = True
+        TocabiAMPLower(c, "cuda:0", 0, True).enable_graph_step()
+    for e in envs:
+        e.close()
