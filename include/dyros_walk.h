@@ -370,6 +370,61 @@ int dw_newwalk_reward(int n, const int64_t *reset_buf, const int64_t *progress_b
                       const float *phase, float *total_reward, int64_t *reset, float *reward8, void *stream);
 int dw_body_positions(DwHandle *h, const int32_t *moving_bodies, int nb, float *out, void *stream);
 
+/* ---- Row f-3, fused: the bookkeeping of one TocabiAMPLower step between the physics launches, as four kernels instead of ~100
+ * elementwise torch launches (tasks/amp/tocabi_amp_lower_base.py:642-804, tasks/tocabi_amp_lower.py:88-96).  The host class
+ * (isaacgymdyros_amd/tocabi_amp_lower.py, cfg sim.mi355.amp_fused) calls, per step:
+ *   dw_amp_step_pre                                   action clamp + history, command ramp
+ *   2 x [ dw_amp_step_tau, dw_simulate, dw_amp_step_encoder ]   torques (PD / delayed-torque FIFO), physics, encoder model
+ *   dw_amp_step_post                                  counters, foot positions, observation + history stacking, reward, termination,
+ *                                                     discriminator observation history, time-outs, clamped observation
+ * Random numbers come in as tensors the caller drew (torch's generator, as in the reference): every expression is the one of the
+ * torch implementation of the same class, so that the fused step is bit-identical to it (tests/test_amp_gpu.py).  All pointers
+ * are device memory, [N, ...] row-major float32 unless noted; int64 where the reference holds torch.long. */
+typedef struct DwAmpBuffers {
+    float   *actions, *actions_pre;                 /* [N,12]                                                        */
+    float   *action_history, *obs_history;          /* [N, his*skip*12], [N, his*skip*36]                            */
+    float   *commands, *start_target_vel, *final_target_vel;       /* [N,3]                                          */
+    int64_t *vel_change_duration, *cur_vel_change_duration;        /* [N]                                            */
+    float   *epi_len;                               /* [N]                                                           */
+    float   *power_scale;                           /* [N,12]                                                        */
+    float   *action_log;                            /* [N, log_slots, 12] delayed-torque FIFO, newest last           */
+    int64_t *delay_idx, *simul_len;                 /* [N]                                                           */
+    float   *qpos_noise, *qvel_noise, *qpos_pre;    /* [N,33]                                                        */
+    float   *qpos_bias, *quat_bias;                 /* [N,12], [N,3]                                                 */
+    float   *dof_vel_pre;                           /* [N,33]                                                        */
+    float   *tau;                                   /* [N,33] what dw_simulate is handed                             */
+    int64_t *progress_buf, *randomize_buf, *reset_buf, *terminate_buf;   /* [N]                                      */
+    uint8_t *timeout_buf;                           /* [N] torch.bool                                                */
+    float   *rigid_body_pos, *rigid_body_rot;       /* [N,38,3], [N,38,4]: rows 0, 8, 16 / row 0 are maintained      */
+    float   *foot_pos;                              /* [N,2,3]                                                       */
+    float   *obs1, *obs_buf, *obs_out;              /* [N,36], [N,num_obs], [N,num_obs] (= clamp(obs_buf, +-clip))   */
+    float   *rew_buf, *reward_values;               /* [N], [N,9]                                                    */
+    float   *total_mass;                            /* [N]                                                           */
+    float   *amp_obs_buf, *amp_obs1;                /* [N, amp_steps, 34], [N,34]                                    */
+    const float *motor_efforts, *p_gains, *d_gains, *init_angle;   /* [12], [33], [33], [33]                         */
+    const float *pd_action_offset, *pd_action_scale;               /* [12] each (pd_control only, else NULL)         */
+} DwAmpBuffers;
+typedef struct DwAmpConfig {
+    int32_t num_envs, num_his, num_skip, log_slots, amp_steps;
+    int32_t pd_control, noise, vel_change, local_root_obs, enable_early_termination;
+    float   clip_actions, clip_obs;                 /* +inf = no clipping                                            */
+    float   max_episode_length, termination_height;
+    float   inv_dt;                                 /* float(1 / dt): torch's GPU kernels multiply by it for `x / dt` */
+    float   dt;
+    int32_t gpu_div;                                /* 1: qvel = d * inv_dt (torch on a GPU), 0: d / dt (torch on a CPU) */
+    float   cmd_lo[3], cmd_scale[3];                /* command ranges x, y, yaw: float(lo), float(hi - lo)            */
+} DwAmpConfig;
+/* ramp_dur [N] int64 in [1,250), ramp_u [N,3] uniform in [0,1): the draws of the command ramp for EVERY env (kept where an env changes
+ * its command); NULL with vel_change = 0 */
+int dw_amp_step_pre(const DwAmpConfig *c, const DwAmpBuffers *b, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u,
+                    void *stream);
+/* dof_state: the bound [N,33,2] */
+int dw_amp_step_tau(const DwAmpConfig *c, const DwAmpBuffers *b, const float *dof_state, void *stream);
+/* z [N,33]: normal draws with sigma 0.00016 / 3 (ignored with noise = 0) */
+int dw_amp_step_encoder(const DwAmpConfig *c, const DwAmpBuffers *b, const float *dof_state, const float *z, void *stream);
+/* rootvel_noise [N,6]: uniform in +-0.025 (zeros with noise = 0); reads the bound root_states / dof_state / contact_forces of h */
+int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *rootvel_noise, void *stream);
+
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,25 @@ class DwBuffers(C.Structure):
 BUFFER_NAMES = [n for n, _ in DwBuffers._fields_]
 
 
+AMP_BUFFER_NAMES = ["actions", "actions_pre", "action_history", "obs_history", "commands", "start_target_vel", "final_target_vel",
+                    "vel_change_duration", "cur_vel_change_duration", "epi_len", "power_scale", "action_log", "delay_idx", "simul_len",
+                    "qpos_noise", "qvel_noise", "qpos_pre", "qpos_bias", "quat_bias", "dof_vel_pre", "tau", "progress_buf", "randomize_buf",
+                    "reset_buf", "terminate_buf", "timeout_buf", "rigid_body_pos", "rigid_body_rot", "foot_pos", "obs1", "obs_buf", "obs_out",
+                    "rew_buf", "reward_values", "total_mass", "amp_obs_buf", "amp_obs1", "motor_efforts", "p_gains", "d_gains", "init_angle",
+                    "pd_action_offset", "pd_action_scale"]
+
+
+class DwAmpBuffers(C.Structure):            # include/dyros_walk.h, the fused TocabiAMPLower step
+    _fields_ = [(n, C.c_void_p) for n in AMP_BUFFER_NAMES]
+
+
+class DwAmpConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_his", "num_skip", "log_slots", "amp_steps", "pd_control", "noise", "vel_change",
+                                         "local_root_obs", "enable_early_termination")] + \
+               [(n, C.c_float) for n in ("clip_actions", "clip_obs", "max_episode_length", "termination_height", "inv_dt", "dt")] + \
+               [("gpu_div", C.c_int32), ("cmd_lo", C.c_float * 3), ("cmd_scale", C.c_float * 3)]
+
+
 def declare(lib: C.CDLL, prefix: str = "dw_"):
     """Attach argtypes/restype for every entry point the header declares; raises AttributeError if the
     shared object lacks one of them."""
@@ -130,11 +149,18 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     api["newwalk_reward"] = fn("newwalk_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, C.c_int, P, C.c_int, C.c_float, C.c_float,
                                C.c_float, P, C.c_int, P, P, P, P, P, P, P, P)
     api["body_positions"] = fn("body_positions", C.c_int, H, C.POINTER(C.c_int32), C.c_int, P, P)
+    if prefix == "dw_":         # (the fused TocabiAMPLower step: HIP library only -- its checker is the torch class, not the C oracle)
+        AB, AC = C.POINTER(DwAmpBuffers), C.POINTER(DwAmpConfig)
+        api["amp_step_pre"] = fn("amp_step_pre", C.c_int, AC, AB, P, P, P, P)
+        api["amp_step_tau"] = fn("amp_step_tau", C.c_int, AC, AB, P, P)
+        api["amp_step_encoder"] = fn("amp_step_encoder", C.c_int, AC, AB, P, P, P)
+        api["amp_step_post"] = fn("amp_step_post", C.c_int, H, AC, AB, P, P)
     return api
 
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
-           "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions"]
+           "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions",
+           "amp_step_pre", "amp_step_tau", "amp_step_encoder", "amp_step_post"]
 
 
 # name -> (per-env shape, numpy dtype string); gate_acc is the one buffer without an env dimension

@@ -56,19 +56,23 @@ struct ObsArgs {
     const float *root_states, *rootvel_noise, *dof_pos, *dof_pos_bias, *quat_bias, *dof_vel, *commands;
     float *obs;
 };
-DW_HD void observations(const ObsArgs &A, int e) {
-    const float *r = A.root_states + 13 * (size_t)e, *nz = A.rootvel_noise + 6 * (size_t)e;
-    float *o = A.obs + DW_AMP_NUM_OBS1 * (size_t)e;
+// one env's 36-word observation from its rows (dof_pos / dof_vel: the env's 33-word rows)
+DW_HD void observations_row(const float *r, const float *nz, const float *dof_pos, const float *dof_pos_bias, const float *quat_bias,
+                            const float *dof_vel, const float *commands, float *o) {
     float q[4] = {r[3], r[4], r[5], r[6]}, eu[3], vel[3], lv[3];
     quat2euler(q, eu);
-    for (int i = 0; i < 3; ++i) o[i] = eu[i] + A.quat_bias[3 * (size_t)e + i];
+    for (int i = 0; i < 3; ++i) o[i] = eu[i] + quat_bias[i];
     for (int i = 0; i < 3; ++i) vel[i] = r[7 + i] + nz[i];
     quat_rotate_inverse(q, vel, lv);
     for (int i = 0; i < 3; ++i) o[3 + i] = lv[i];
     for (int i = 0; i < 3; ++i) o[6 + i] = r[10 + i] + nz[3 + i];
-    for (int i = 0; i < 3; ++i) o[9 + i] = A.commands[3 * (size_t)e + i];
-    for (int i = 0; i < 12; ++i) o[12 + i] = A.dof_pos[DW_NUM_DOF * (size_t)e + i] + A.dof_pos_bias[12 * (size_t)e + i];
-    for (int i = 0; i < 12; ++i) o[24 + i] = A.dof_vel[DW_NUM_DOF * (size_t)e + i];
+    for (int i = 0; i < 3; ++i) o[9 + i] = commands[i];
+    for (int i = 0; i < 12; ++i) o[12 + i] = dof_pos[i] + dof_pos_bias[i];
+    for (int i = 0; i < 12; ++i) o[24 + i] = dof_vel[i];
+}
+DW_HD void observations(const ObsArgs &A, int e) {
+    observations_row(A.root_states + 13 * (size_t)e, A.rootvel_noise + 6 * (size_t)e, A.dof_pos + DW_NUM_DOF * (size_t)e, A.dof_pos_bias + 12 * (size_t)e,
+                     A.quat_bias + 3 * (size_t)e, A.dof_vel + DW_NUM_DOF * (size_t)e, A.commands + 3 * (size_t)e, A.obs + DW_AMP_NUM_OBS1 * (size_t)e);
 }
 
 // my_quat_rotate(q, v) = a + b + c (utils/torch_jit_utils.py:199-209; the sign of b is what separates it from quat_rotate_inverse)
@@ -109,21 +113,19 @@ struct DiscObsArgs {
     int n_key;
     float *obs;
 };
-DW_HD void disc_observations(const DiscObsArgs &A, int e) {
-    const float *r = A.root_states + 13 * (size_t)e;
-    float *o = A.obs + (size_t)(DW_AMP_DISC_BASE + 3 * A.n_key) * e;
+DW_HD void disc_observations_row(const float *r, const float *dp, const float *dv, int dof_elem_stride, int local_root_obs, const float *key_pos,
+                                 int n_key, float *o) {
     const float q[4] = {r[3], r[4], r[5], r[6]};
     float hq[4], eu[3];
     heading_quat_inv(q, hq);
     quat2euler(q, eu);
     o[0] = r[2];
     for (int i = 0; i < 3; ++i) o[1 + i] = eu[i];
-    const float *dp = A.dof_pos + (size_t)A.dof_row_stride * e, *dv = A.dof_vel + (size_t)A.dof_row_stride * e;
-    for (int i = 0; i < 12; ++i) o[4 + i] = dp[(size_t)A.dof_elem_stride * i];
-    for (int i = 0; i < 12; ++i) o[16 + i] = dv[(size_t)A.dof_elem_stride * i];
-    for (int k = 0; k < A.n_key; ++k) {
-        const float *kp = A.key_pos + ((size_t)A.n_key * e + k) * 3;
-        if (A.local_root_obs) {
+    for (int i = 0; i < 12; ++i) o[4 + i] = dp[(size_t)dof_elem_stride * i];
+    for (int i = 0; i < 12; ++i) o[16 + i] = dv[(size_t)dof_elem_stride * i];
+    for (int k = 0; k < n_key; ++k) {
+        const float *kp = key_pos + (size_t)k * 3;
+        if (local_root_obs) {
             for (int i = 0; i < 3; ++i) o[DW_AMP_DISC_BASE + 3 * k + i] = kp[i];
         } else {
             const float lp[3] = {kp[0] - r[0], kp[1] - r[1], kp[2] - r[2]};
@@ -133,14 +135,19 @@ DW_HD void disc_observations(const DiscObsArgs &A, int e) {
         }
     }
 }
+DW_HD void disc_observations(const DiscObsArgs &A, int e) {
+    disc_observations_row(A.root_states + 13 * (size_t)e, A.dof_pos + (size_t)A.dof_row_stride * e, A.dof_vel + (size_t)A.dof_row_stride * e,
+                          A.dof_elem_stride, A.local_root_obs, A.key_pos + (size_t)A.n_key * 3 * e, A.n_key,
+                          A.obs + (size_t)(DW_AMP_DISC_BASE + 3 * A.n_key) * e);
+}
 
 struct RewardArgs {
     int n;
     const float *root_states, *dof_vel, *dof_vel_pre, *commands, *actions, *actions_pre, *motor_efforts, *contact_force, *total_mass;
     float *reward, *reward_values;
 };
-DW_HD void reward(const RewardArgs &A, int e) {
-    const float *r = A.root_states + 13 * (size_t)e, *cmd = A.commands + 3 * (size_t)e;
+DW_HD void reward_row(const float *r, const float *dvp, int dv_stride, const float *dvq, const float *cmd, const float *act, const float *act_pre,
+                      const float *motor_efforts, const float *cf, float total_mass, float *reward, float *rv) {
     const float q[4] = {r[3], r[4], r[5], r[6]}, v[3] = {r[7], r[8], r[9]};
     float lv[3];
     quat_rotate_inverse(q, v, lv);
@@ -150,8 +157,7 @@ DW_HD void reward(const RewardArgs &A, int e) {
     const float ry = 0.8f * expf(-6.0f * (d * d));
     d = cmd[2] - r[12];
     const float ryaw = 0.6f * expf(-7.0f * (d * d));
-    const float thr = (float)(1.4 * 9.81) * A.total_mass[e];
-    const float *cf = A.contact_force + (size_t)DW_NUM_BODIES * 3 * e;
+    const float thr = (float)(1.4 * 9.81) * total_mass;
     const float fl = cf[8 * 3 + 2], fr = cf[16 * 3 + 2];
     const bool thres = (fl > thr) || (fr > thr);
     const float r_thr = -0.2f * (thres ? 1.0f : 0.0f);
@@ -161,14 +167,13 @@ DW_HD void reward(const RewardArgs &A, int e) {
     const float nl = norm_t(&cl, 1), nr = norm_t(&cr, 1);
     const float pen = 0.1f * (1.0f - expf(-0.007f * (nl + nr)));
     const float r_pen = thres ? pen : 0.1f * 1.0f;
-    const float *dvp = A.dof_vel + DW_NUM_DOF * (size_t)e, *dvq = A.dof_vel_pre + DW_NUM_DOF * (size_t)e;
     float dv[DW_NUM_DOF], dd[DW_NUM_DOF], ta[12], td[12];
-    for (int i = 0; i < DW_NUM_DOF; ++i) { dv[i] = dvp[i]; dd[i] = dvp[i] - dvq[i]; }
+    for (int i = 0; i < DW_NUM_DOF; ++i) { dv[i] = dvp[(size_t)dv_stride * i]; dd[i] = dvp[(size_t)dv_stride * i] - dvq[i]; }
     const float nv = norm_t(dv, DW_NUM_DOF), na = norm_t(dd, DW_NUM_DOF);
     const float r_jv = 0.05f * expf(-0.01f * (nv * nv));
     const float r_ja = 0.05f * expf(-20.0f * (na * na));
     for (int i = 0; i < 12; ++i) {
-        const float a = A.actions[12 * (size_t)e + i], ap = A.actions_pre[12 * (size_t)e + i], m = A.motor_efforts[i];
+        const float a = act[i], ap = act_pre[i], m = motor_efforts[i];
         ta[i] = a * m; td[i] = (a - ap) * m;
     }
     const float r_t = 0.08f * expf(-0.05f * norm_t(ta, 12));
@@ -181,9 +186,13 @@ DW_HD void reward(const RewardArgs &A, int e) {
     rew += r_ja;
     rew += r_t;
     rew += r_td;
-    A.reward[e] = rew;
-    float *rv = A.reward_values + 9 * (size_t)e;
+    *reward = rew;
     rv[0] = rx; rv[1] = ry; rv[2] = ryaw; rv[3] = r_thr; rv[4] = r_pen; rv[5] = r_jv; rv[6] = r_ja; rv[7] = r_t; rv[8] = r_td;
+}
+DW_HD void reward(const RewardArgs &A, int e) {
+    reward_row(A.root_states + 13 * (size_t)e, A.dof_vel + DW_NUM_DOF * (size_t)e, 1, A.dof_vel_pre + DW_NUM_DOF * (size_t)e, A.commands + 3 * (size_t)e,
+               A.actions + 12 * (size_t)e, A.actions_pre + 12 * (size_t)e, A.motor_efforts, A.contact_force + (size_t)DW_NUM_BODIES * 3 * e, A.total_mass[e],
+               A.reward + e, A.reward_values + 9 * (size_t)e);
 }
 
 struct ResetArgs {

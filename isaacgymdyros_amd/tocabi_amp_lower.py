@@ -207,7 +207,7 @@ class TocabiAMPLower(VecTask):
         self.power_scale = torch.ones(N, 12, **f)
         self.actions = torch.zeros(N, NUM_ACTIONS, **f)
         self.actions_pre = self.actions.clone()
-        self._dof_vel_pre = self._dof_vel.clone()
+        self._dof_vel_pre = self._dof_vel.clone().contiguous()
         # rows 0, 8, 16 of the rigid-body state (what compute_humanoid_reset reads); the other rows stay zero
         self._rigid_body_pos = torch.zeros(N, 38, 3, **f)
         self._rigid_body_rot = torch.zeros(N, 38, 4, **f)
@@ -264,6 +264,10 @@ class TocabiAMPLower(VecTask):
         self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
         self._amp_obs_demo_buf = None
         self._graph, self._capturing, self._g_actions, self._g_out = None, False, None, None
+        # cfg sim.mi355.amp_fused: the step's bookkeeping as four HIP kernels (dw_amp_step_*) instead of ~100 torch launches
+        self._fused = bool(cfg["sim"].get("mi355", {}).get("amp_fused", False))
+        self._tau = torch.zeros(N, 33, **f)
+        self._obs_out = torch.zeros(N, self.num_obs, **f)
         self._amp_obs1 = torch.zeros(N, NUM_AMP_OBS_PER_STEP, **f)
         self._reset_default_env_ids, self._reset_ref_env_ids = [], []
         self._reset_ref_motion_ids = self._reset_ref_motion_times = None
@@ -603,7 +607,75 @@ class TocabiAMPLower(VecTask):
         self._compute_amp_observations()
         self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.num_amp_obs)
 
+    # ------------------------------------------------------------------ the fused step (include/dyros_walk.h: dw_amp_step_*)
+    def _fused_tables(self):
+        """DwAmpConfig / DwAmpBuffers over the class' own tensors (they are updated in place and never re-bound, so the table is
+        built once)."""
+        from . import abi
+        if getattr(self, "_amp_cfg", None) is not None:
+            return self._amp_cfg, self._amp_buf
+        c = abi.DwAmpConfig()
+        c.num_envs, c.num_his, c.num_skip, c.log_slots, c.amp_steps = self.num_envs, self.num_obs_his, self.num_obs_skip, self._log_slots, self._num_amp_obs_steps
+        c.pd_control, c.noise, c.vel_change = int(bool(self._pd_control)), int(bool(self.noise)), int(bool(self.vel_change))
+        c.local_root_obs, c.enable_early_termination = int(self._local_root_obs), int(bool(self._enable_early_termination))
+        c.clip_actions, c.clip_obs = float(self.clip_actions), float(self.clip_obs)
+        c.max_episode_length, c.termination_height = float(self.max_episode_length), float(self._termination_height)
+        c.inv_dt, c.dt, c.gpu_div = float(np.float32(1.0 / self.dt)), float(self.dt), int(self._gpu_div)
+        for i, (lo, hi) in enumerate((self.c_x, self.c_y, self.c_yaw)):
+            c.cmd_lo[i], c.cmd_scale[i] = float(lo), float(hi - lo)
+        t = {"actions": self.actions, "actions_pre": self.actions_pre, "action_history": self.action_history, "obs_history": self.obs_history,
+             "commands": self.commands, "start_target_vel": self.start_target_vel, "final_target_vel": self.final_target_vel,
+             "vel_change_duration": self.vel_change_duration, "cur_vel_change_duration": self.cur_vel_change_duration, "epi_len": self.epi_len,
+             "power_scale": self.power_scale, "action_log": self.action_log, "delay_idx": self.delay_idx, "simul_len": self.simul_len,
+             "qpos_noise": self.qpos_noise, "qvel_noise": self.qvel_noise, "qpos_pre": self.qpos_pre, "qpos_bias": self.qpos_bias,
+             "quat_bias": self.quat_bias, "dof_vel_pre": self._dof_vel_pre, "tau": self._tau, "progress_buf": self.progress_buf,
+             "randomize_buf": self.randomize_buf, "reset_buf": self.reset_buf, "terminate_buf": self._terminate_buf, "timeout_buf": self.timeout_buf,
+             "rigid_body_pos": self._rigid_body_pos, "rigid_body_rot": self._rigid_body_rot, "foot_pos": self._foot_pos, "obs1": self._obs1,
+             "obs_buf": self.obs_buf, "obs_out": self._obs_out, "rew_buf": self.rew_buf, "reward_values": self._reward_values,
+             "total_mass": self.total_mass, "amp_obs_buf": self._amp_obs_buf, "amp_obs1": self._amp_obs1, "motor_efforts": self.motor_efforts,
+             "p_gains": self.p_gains, "d_gains": self.d_gains, "init_angle": self.init_angle,
+             "pd_action_offset": self._pd_action_offset if self._pd_control else None, "pd_action_scale": self._pd_action_scale if self._pd_control else None}
+        b = abi.DwAmpBuffers()
+        for name in abi.AMP_BUFFER_NAMES:
+            v = t[name]
+            if v is not None:
+                assert v.is_contiguous() and v.device == self.actions.device, name
+            setattr(b, name, v.data_ptr() if v is not None else None)
+        self._amp_cfg, self._amp_buf, self._amp_keep = c, b, t
+        return c, b
+
+    def _step_fused(self, actions):
+        """One step with the bookkeeping in four kernels; the draws are torch's, in the order of the torch implementation's
+        recorded branch (pre_physics_step), so both give the same numbers (tests/test_amp_gpu.py)."""
+        if self.perturb:
+            raise ValueError("amp_fused: env.perturbation is not part of the fused step")
+        N, api, st = self.num_envs, self._api, self._stream()
+        c, b = self._fused_tables()
+        a = actions.to(self._tdev).float().contiguous()
+        rd = ru = None
+        if self.vel_change:
+            rd = self._rng.randint(1, 250, (N,))
+            ru = torch.stack((self._rand(N), self._rand(N), self._rand(N)), dim=-1).contiguous()
+        self._chk(api["amp_step_pre"](C.byref(c), C.byref(b), _p(a), _p(rd), _p(ru), st))
+        for _ in range(self.control_freq_inv):
+            self._chk(api["amp_step_tau"](C.byref(c), C.byref(b), _p(self._dof_state), st))
+            self._simulate(self._tau, None)
+            z = self._rng.normal((N, 33), 0.00016 / 3.0).contiguous() if self.noise else None
+            self._chk(api["amp_step_encoder"](C.byref(c), C.byref(b), _p(self._dof_state), _p(z), st))
+        self.time_step += 1
+        nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
+        self._chk(api["amp_step_post"](self._phys._h, C.byref(c), C.byref(b), _p(nz), st))
+        self.extras["reward_names"] = list(REWARD_NAMES)
+        self.extras["reward_values"] = self._reward_values
+        self.extras["terminate"] = self._terminate_buf
+        self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.num_amp_obs)
+        self.extras["time_outs"] = self.timeout_buf
+        self.obs_dict["obs"] = self._obs_out
+        return self.obs_dict, self.rew_buf, self.reset_buf, self.extras
+
     def _step_body(self, actions):
+        if self._fused:
+            return self._step_fused(actions)
         action_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)
         self.pre_physics_step(action_tensor)
         self.post_physics_step()

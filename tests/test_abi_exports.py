@@ -25,6 +25,16 @@ def test_header_and_python_mirror_agree():
     assert offs[-1][0] + offs[-1][1] <= abi.K["DW_ES_WORDS"]
 
 
+def test_amp_step_structs_mirror_the_header():
+    src = open(os.path.join(ROOT, "include", "dyros_walk.h")).read()
+    strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+    blk = strip(src[src.index("typedef struct DwAmpBuffers {"):src.index("} DwAmpBuffers;")])
+    assert re.findall(r"\*([a-z_0-9]+)", blk) == abi.AMP_BUFFER_NAMES
+    blk = strip(src[src.index("typedef struct DwAmpConfig {"):src.index("} DwAmpConfig;")])
+    assert re.findall(r"([a-z_0-9]+)(?:\[3\])?[,;]", blk) == [f[0] for f in abi.DwAmpConfig._fields_]
+    assert ctypes.sizeof(abi.DwAmpBuffers) == 8 * len(abi.AMP_BUFFER_NAMES)
+
+
 def test_library_builds_and_exports_the_abi():
     lib_path = build.build()
     lib = ctypes.CDLL(lib_path)

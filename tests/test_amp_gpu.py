@@ -536,3 +536,54 @@ def test_tocabi_amp_lower_graph_step_equals_eager():
         TocabiAMPLower(c, "cuda:0", 0, True).enable_graph_step()
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize("pd_control", [False, True])
+def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control):
+    """cfg sim.mi355.amp_fused: the step's bookkeeping in four HIP kernels (dw_amp_step_pre / _tau / _encoder / _post) against the
+    torch implementation of the same class (the branch of the command ramp that draws for every env; itself pinned to the
+    reference class by the replay tests above): same seeds and actions for 80 steps with resets in between -- every output and
+    every piece of state must be bit-identical.  Episode length 40 so that time-outs and the command ramp (episode step 9) occur."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+    N = 201                                              # (not a multiple of the kernels' four envs per workgroup)
+    envs = []
+    for fused in (True, False):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["env"].update({"episodeLength": 40, "pdControl": pd_control, "numAMPObsSteps": 3})
+        cfg["sim"]["mi355"] = {"amp_fused": fused}
+        envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
+    a, b = envs
+    b._capturing = True
+    g = torch.Generator(device="cuda").manual_seed(4)
+    names = ["actions", "actions_pre", "action_history", "obs_history", "commands", "start_target_vel", "final_target_vel", "vel_change_duration",
+             "cur_vel_change_duration", "epi_len", "action_log", "simul_len", "qpos_noise", "qvel_noise", "qpos_pre", "_dof_vel_pre", "progress_buf",
+             "randomize_buf", "reset_buf", "_terminate_buf", "timeout_buf", "_rigid_body_pos", "_rigid_body_rot", "_foot_pos", "obs_buf", "rew_buf",
+             "_reward_values", "_amp_obs_buf", "_root_states", "_dof_state", "_contact_forces"]
+    ramps = resets = 0
+    for t in range(80):
+        for e in envs:
+            e.reset_done()
+        act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * (1.3 if t % 7 == 0 else 0.7)          # (beyond +-1 now and then: the clamp)
+        oa, ra, da, xa = a.step(act)
+        ob, rb, db, xb = b.step(act)
+        for n in names:
+            va, vb = getattr(a, n), getattr(b, n)
+            assert torch.equal(va, vb), (t, n, float((va.double() - vb.double()).abs().max()))
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), t
+        assert torch.equal(xa["amp_obs"], xb["amp_obs"]) and torch.equal(xa["time_outs"], xb["time_outs"]) and torch.equal(xa["terminate"], xb["terminate"]), t
+        ramps += int((a.cur_vel_change_duration > 0).sum())
+        resets += int(da.sum())
+    assert resets > N and ramps > 0
+    # and recorded in a hipGraph: the same numbers again
+    a.enable_graph_step(warmup=2)
+    for _ in range(2):
+        b._step_body(torch.zeros(N, 12, device="cuda"))
+    for t in range(20):
+        for e in envs:
+            e.reset_done()
+        act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * 0.7
+        oa, ra, da, xa = a.step(act)
+        ob, rb, db, xb = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(xa["amp_obs"], xb["amp_obs"]), t
+    for e in envs:
+        e.close()

@@ -1,5 +1,5 @@
 """Where the TocabiAMPLower step goes: step() and reset_done() timed separately (host clock around a device sync each).
-usage: python tools/amp_time2.py [N] [--graph]"""
+usage: python tools/amp_time2.py [N] [--graph] [--fused]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,9 @@ from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
 GRAPH = "--graph" in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]) if args else 16384
-env = TocabiAMPLower(default_amp_cfg(N, "cuda:0"), "cuda:0", 0, True)
+cfg = default_amp_cfg(N, "cuda:0")
+cfg["sim"]["mi355"] = {"amp_fused": "--fused" in sys.argv}
+env = TocabiAMPLower(cfg, "cuda:0", 0, True)
 env.reset_done()
 if GRAPH:
     env.enable_graph_step()
@@ -23,5 +25,5 @@ for i in range(K):
     _, ids = env.reset_done()
     torch.cuda.synchronize(); t2 = time.perf_counter()
     ts += t1 - t0; tr += t2 - t1; nres += len(ids)
-print("N=%d%s: step %.3f ms, reset_done %.3f ms (%.1f resets per call)" % (N, " graph" if GRAPH else "", ts / K * 1e3, tr / K * 1e3, nres / K))
+print("N=%d%s%s: step %.3f ms, reset_done %.3f ms (%.1f resets per call)" % (N, " fused" if "--fused" in sys.argv else "", " graph" if GRAPH else "", ts / K * 1e3, tr / K * 1e3, nres / K))
 env.close()
