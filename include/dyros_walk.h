@@ -403,6 +403,11 @@ typedef struct DwAmpBuffers {
     float   *amp_obs_buf, *amp_obs1;                /* [N, amp_steps, 34], [N,34]                                    */
     const float *motor_efforts, *p_gains, *d_gains, *init_angle;   /* [12], [33], [33], [33]                         */
     const float *pd_action_offset, *pd_action_scale;               /* [12] each (pd_control only, else NULL)         */
+    /* touched by dw_amp_reset_rows only */
+    float   *epi_len_log;                           /* [N]                                                           */
+    int64_t *perturbation_count, *perturb_timing;   /* [N]                                                           */
+    uint8_t *pert_on;                               /* [N] torch.bool                                                */
+    const float *initial_root_states;               /* [N,13]                                                        */
 } DwAmpBuffers;
 typedef struct DwAmpConfig {
     int32_t num_envs, num_his, num_skip, log_slots, amp_steps;
@@ -424,6 +429,15 @@ int dw_amp_step_tau(const DwAmpConfig *c, const DwAmpBuffers *b, const float *do
 int dw_amp_step_encoder(const DwAmpConfig *c, const DwAmpBuffers *b, const float *dof_state, const float *z, void *stream);
 /* rootvel_noise [N,6]: uniform in +-0.025 (zeros with noise = 0); reads the bound root_states / dof_state / contact_forces of h */
 int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *rootvel_noise, void *stream);
+/* reset_idx of the listed envs (tasks/amp/tocabi_amp_lower_base.py:238-305 with the default state initialisation, then
+ * tasks/tocabi_amp_lower.py:144-147,258-272) as ONE launch instead of ~60 indexed assignments: a wavefront per listed env writes its rows
+ * of the Gym tensors (initial pose, zero contact), the reset observation (computed from the episode's last encoder reading, as the
+ * reference does), every piece of task state, and the env's discriminator history (copies of its current observation).  ids [n] int64 in
+ * device memory, distinct; the draws are the caller's, one row per listed env in the order of ids: power_scale [n,12] (NULL: keep),
+ * commands [n,3], qpos_bias [n,12], quat_bias [n,3], perturb_timing [n] int64, delay_idx [n] int64; rootvel_noise [N,6] is indexed by env. */
+int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale,
+                      const float *rootvel_noise, const float *commands, const float *qpos_bias, const float *quat_bias,
+                      const int64_t *perturb_timing, const int64_t *delay_idx, void *stream);
 
 
 #ifdef __cplusplus

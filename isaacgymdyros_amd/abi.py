@@ -102,7 +102,7 @@ AMP_BUFFER_NAMES = ["actions", "actions_pre", "action_history", "obs_history", "
                     "qpos_noise", "qvel_noise", "qpos_pre", "qpos_bias", "quat_bias", "dof_vel_pre", "tau", "progress_buf", "randomize_buf",
                     "reset_buf", "terminate_buf", "timeout_buf", "rigid_body_pos", "rigid_body_rot", "foot_pos", "obs1", "obs_buf", "obs_out",
                     "rew_buf", "reward_values", "total_mass", "amp_obs_buf", "amp_obs1", "motor_efforts", "p_gains", "d_gains", "init_angle",
-                    "pd_action_offset", "pd_action_scale"]
+                    "pd_action_offset", "pd_action_scale", "epi_len_log", "perturbation_count", "perturb_timing", "pert_on", "initial_root_states"]
 
 
 class DwAmpBuffers(C.Structure):            # include/dyros_walk.h, the fused TocabiAMPLower step
@@ -155,12 +155,13 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
         api["amp_step_tau"] = fn("amp_step_tau", C.c_int, AC, AB, P, P)
         api["amp_step_encoder"] = fn("amp_step_encoder", C.c_int, AC, AB, P, P, P)
         api["amp_step_post"] = fn("amp_step_post", C.c_int, H, AC, AB, P, P)
+        api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P)
     return api
 
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
            "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions",
-           "amp_step_pre", "amp_step_tau", "amp_step_encoder", "amp_step_post"]
+           "amp_step_pre", "amp_step_tau", "amp_step_encoder", "amp_step_post", "amp_reset_rows"]
 
 
 # name -> (per-env shape, numpy dtype string); gate_acc is the one buffer without an env dimension

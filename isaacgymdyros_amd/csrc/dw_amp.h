@@ -322,7 +322,9 @@ DW_HD void newwalk_reward(const NewWalkArgs &A, int e) {
 
 // World position of the origin of the listed MOVING bodies (what refresh_rigid_body_state_tensor would return for them):
 // out[e][k] = x(body k).  Thread = (env, k): the chain from the body up to the base is at most MAX_LEVELS long.
-DW_HD void body_position(const dw::DevModel &M, const float *root_states, const float *dof_state, int e, int body, float *out3) {
+// (MM: dw::DevModel, or a copy of its first rows in faster memory with the same member names -- LegModel below)
+template <class MM>
+DW_HD void body_position(const MM &M, const float *root_states, const float *dof_state, int e, int body, float *out3) {
     int chain[dw::MAX_LEVELS], n = 0;
     for (int b = body; b > 0; b = M.parent[b]) chain[n++] = b;
     const float *r = root_states + 13 * (size_t)e;
@@ -353,6 +355,13 @@ DW_HD void body_position(const dw::DevModel &M, const float *root_states, const 
     }
     out3[0] = x[0]; out3[1] = x[1]; out3[2] = x[2];
 }
+
+// the rows of DevModel that the chains of the two foot links run through (moving bodies 0 .. 12: base, left leg, right leg)
+struct LegModel {
+    static constexpr int NBODY = 13;
+    int   parent[NBODY];
+    float pos[NBODY][3], axis[NBODY][3], rot0[NBODY][9];
+};
 
 }  // namespace dwa
 

@@ -75,6 +75,19 @@ __device__ inline void wave_fence() {
 }
 int env_blocks(int n) { return (n + WPB - 1) / WPB; }
 
+// the leg rows of the model into LDS, by the whole workgroup (a chain walk on one lane reads them serially: from global memory
+// that was the longest thing in the kernel)
+__device__ inline void stage_leg_model(dwa::LegModel &L, const dw::DevModel &M) {
+    for (int i = (int)threadIdx.x; i < dwa::LegModel::NBODY * 16; i += 64 * WPB) {
+        const int b = i >> 4, k = i & 15;
+        if (k < 3) L.pos[b][k] = M.pos[b][k];
+        else if (k < 6) L.axis[b][k - 3] = M.axis[b][k - 3];
+        else if (k < 15) L.rot0[b][k - 6] = M.rot0[b][k - 6];
+        else L.parent[b] = M.parent[b];
+    }
+    __syncthreads();
+}
+
 // row[0 .. len - shift) = row[shift .. len), row[len - shift .. len) = tail[0 .. shift): every lane reads its elements before any writes
 template <int MAXPER>
 __device__ inline void shift_append(float *row, int len, int shift, const float *tail, int l) {
@@ -183,6 +196,8 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_step_encoder(const DwAmpCon
 __global__ __launch_bounds__(64 * WPB) void dw_k_amp_step_post(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const float *root_states,
                                                                const float *dof_state, const float *contact_forces, const float *rootvel_noise) {
     const int e = wave_env(), l = wave_lane(), w = (int)(threadIdx.x >> 6);
+    __shared__ dwa::LegModel LM;
+    stage_leg_model(LM, *M);
     if (e >= C.num_envs) return;
     // the env's rows staged in LDS once: the per-env functions below are serial code on one lane each, and a dependent global load
     // per operand is what they must not pay
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_step_post(const dw::DevMode
     // step's observation, the reward
     if (l < 2) {
         float p[3];
-        dwa::body_position(*M, r, ds, 0, l == 0 ? 6 : 12, p);          // (the staged rows are env 0 of their own little tensors)
+        dwa::body_position(LM, r, ds, 0, l == 0 ? 6 : 12, p);          // (the staged rows are env 0 of their own little tensors)
         for (int i = 0; i < 3; ++i) {
             s_foot[w][3 * l + i] = p[i];
             B.foot_pos[((size_t)2 * e + l) * 3 + i] = p[i];
@@ -283,6 +298,90 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_step_post(const dw::DevMode
     wave_fence();
     for (int k = 0; k < 2; ++k) { const int i = l + 64 * k; if (i >= AW && i < C.amp_steps * AW) ab[i] = keep[k]; }
     if (l < AW) { ab[l] = s_amp[w][l]; B.amp_obs1[(size_t)AW * e + l] = s_amp[w][l]; }
+}
+
+
+__global__ __launch_bounds__(64 * WPB) void dw_k_amp_reset_rows(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, float *root_states,
+                                                                float *dof_state, float *contact_forces, const int64_t *ids, int n, const float *ps,
+                                                                const float *rootvel_noise, const float *cmd, const float *qb, const float *quatb,
+                                                                const int64_t *ptime, const int64_t *didx) {
+    const int k = wave_env(), l = wave_lane(), w = (int)(threadIdx.x >> 6);
+    __shared__ dwa::LegModel LM;
+    stage_leg_model(LM, *M);
+    if (k >= n) return;
+    const int e = (int)ids[k];
+    if (e < 0 || e >= C.num_envs) return;          // (ids come from device memory: never write past the tensors)
+    __shared__ float s_obs[WPB][DW_AMP_NUM_OBS1], s_amp[WPB][DW_AMP_DISC_BASE + 6], s_foot[WPB][6], s_root[WPB][13], s_ds[WPB][DW_NUM_DOF * 2],
+        s_old[WPB][64];
+    enum { SO_QN = 0, SO_QV = 12, SO_BIAS = 24, SO_QB = 36, SO_CMD = 39, SO_NZ = 42 };
+    const int NH = C.num_his * C.num_skip, AW = DW_AMP_DISC_BASE + 6;
+    // what the reset observation is made of: the episode's LAST encoder reading, biases and command (the reference computes it before
+    // it draws the new ones, :253 before :266-279)
+    if (l < 12) {
+        s_old[w][SO_QN + l] = B.qpos_noise[(size_t)DW_NUM_DOF * e + l]; s_old[w][SO_QV + l] = B.qvel_noise[(size_t)DW_NUM_DOF * e + l];
+        s_old[w][SO_BIAS + l] = B.qpos_bias[12 * (size_t)e + l];
+    }
+    if (l < 3) { s_old[w][SO_QB + l] = B.quat_bias[3 * (size_t)e + l]; s_old[w][SO_CMD + l] = B.commands[3 * (size_t)e + l]; }
+    if (l < 6) s_old[w][SO_NZ + l] = rootvel_noise[6 * (size_t)e + l];
+    // the Gym tensors' rows: initial root state, initial pose at rest, no contact (_reset_actors, :611-626)
+    if (l < 13) { const float v = B.initial_root_states[13 * (size_t)e + l]; s_root[w][l] = v; root_states[13 * (size_t)e + l] = v; }
+    if (l < DW_NUM_DOF) {
+        const float q0 = B.init_angle[l];
+        s_ds[w][2 * l] = q0; s_ds[w][2 * l + 1] = 0.0f;
+        dof_state[((size_t)DW_NUM_DOF * e + l) * 2] = q0; dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1] = 0.0f;
+    }
+    for (int i = l; i < DW_NUM_BODIES * 3; i += 64) contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i] = 0.0f;
+    if (ps && l < 12) B.power_scale[12 * (size_t)e + l] = ps[12 * (size_t)k + l];
+    wave_fence();
+    const float *r = s_root[w], *ds = s_ds[w];
+    if (l < 2) {          // the rigid-body rows of the new state
+        float p[3];
+        dwa::body_position(LM, r, ds, 0, l == 0 ? 6 : 12, p);
+        for (int i = 0; i < 3; ++i) {
+            s_foot[w][3 * l + i] = p[i];
+            B.foot_pos[((size_t)2 * e + l) * 3 + i] = p[i];
+            B.rigid_body_pos[((size_t)DW_NUM_BODIES * e + (l == 0 ? 8 : 16)) * 3 + i] = p[i];
+        }
+    } else if (l == 2) {
+        dwa::observations_row(r, &s_old[w][SO_NZ], &s_old[w][SO_QN], &s_old[w][SO_BIAS], &s_old[w][SO_QB], &s_old[w][SO_QV], &s_old[w][SO_CMD], s_obs[w]);
+    }
+    if (l >= 4 && l < 7) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (l - 4)] = r[l - 4];
+    if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
+    wave_fence();
+    if (l == 1) dwa::disc_observations_row(r, ds, ds + 1, 2, C.local_root_obs, s_foot[w], 2, s_amp[w]);
+    if (l < DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + l] = s_obs[w][l];
+    // the reset env's observation: every history slot shows the reset observation, the action slots what the action history still
+    // holds; only then are the two histories zeroed (:296-297)
+    const float *ah = B.action_history + (size_t)NH * 12 * e;
+    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
+    float *ob = B.obs_buf + (size_t)num_obs * e;
+    for (int i = l; i < num_obs; i += 64) {
+        float v;
+        if (i < DW_AMP_NUM_OBS1 * C.num_his) v = s_obs[w][i % DW_AMP_NUM_OBS1];
+        else { const int j = i - DW_AMP_NUM_OBS1 * C.num_his, slot = j / 12, kk = j - 12 * slot; v = ah[(size_t)(C.num_skip * (slot + 1)) * 12 + kk]; }
+        ob[i] = v;
+    }
+    wave_fence();
+    for (int i = l; i < NH * DW_AMP_NUM_OBS1; i += 64) B.obs_history[(size_t)NH * DW_AMP_NUM_OBS1 * e + i] = 0.0f;
+    for (int i = l; i < NH * 12; i += 64) B.action_history[(size_t)NH * 12 * e + i] = 0.0f;
+    for (int i = l; i < C.log_slots * 12; i += 64) B.action_log[(size_t)C.log_slots * 12 * e + i] = 0.0f;
+    if (l < DW_NUM_DOF) {
+        const size_t g = (size_t)DW_NUM_DOF * e + l;
+        B.dof_vel_pre[g] = 0.0f; B.qpos_noise[g] = B.init_angle[l]; B.qpos_pre[g] = B.init_angle[l]; B.qvel_noise[g] = 0.0f;
+    }
+    if (l < 12) { B.actions_pre[12 * (size_t)e + l] = 0.0f; B.qpos_bias[12 * (size_t)e + l] = C.noise ? qb[12 * (size_t)k + l] : 0.0f; }
+    if (l < 3) { B.commands[3 * (size_t)e + l] = cmd[3 * (size_t)k + l]; B.quat_bias[3 * (size_t)e + l] = C.noise ? quatb[3 * (size_t)k + l] : 0.0f; }
+    if (l == 0) {
+        B.progress_buf[e] = 0; B.reset_buf[e] = 0; B.terminate_buf[e] = 0;
+        B.epi_len_log[e] = B.epi_len[e]; B.epi_len[e] = 0.0f;
+        B.perturbation_count[e] = 0; B.pert_on[e] = 0; B.perturb_timing[e] = ptime[k];
+        B.delay_idx[e] = didx[k]; B.simul_len[e] = 0;
+    }
+    wave_fence();
+    // discriminator history of a default start: every slot the current observation (tasks/tocabi_amp_lower.py:258-272)
+    float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
+    for (int i = l; i < C.amp_steps * AW; i += 64) ab[i] = s_amp[w][i % AW];
+    if (l < AW) B.amp_obs1[(size_t)AW * e + l] = s_amp[w][l];
 }
 
 bool amp_args_ok(const DwAmpConfig *c, const DwAmpBuffers *b) {
@@ -401,6 +500,23 @@ int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, c
     hipLaunchKernelGGL(dw_k_amp_step_post, dim3(env_blocks(c->num_envs)), dim3(64 * WPB), 0, (hipStream_t)stream, h->d_model, *c, *b, h->buf.root_states,
                        h->buf.dof_state, h->buf.contact_forces, rootvel_noise);
     return launched("dw_amp_step_post: launch");
+}
+
+int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale,
+                      const float *rootvel_noise, const float *commands, const float *qpos_bias, const float *quat_bias,
+                      const int64_t *perturb_timing, const int64_t *delay_idx, void *stream) {
+    if (!h || !amp_args_ok(c, b) || !ids || !rootvel_noise || !commands || !perturb_timing || !delay_idx)
+        return fail(DW_EINVAL, "dw_amp_reset_rows: bad configuration or null argument");
+    if (c->noise && (!qpos_bias || !quat_bias)) return fail(DW_EINVAL, "dw_amp_reset_rows: noise needs the bias draws");
+    if (!b->epi_len_log || !b->perturbation_count || !b->perturb_timing || !b->pert_on || !b->initial_root_states)
+        return fail(DW_EINVAL, "dw_amp_reset_rows: the reset's own buffers are missing from DwAmpBuffers");
+    if (!h->bound) return fail(DW_ESTATE, "dw_amp_reset_rows: dw_bind first");
+    if (n < 0 || n > c->num_envs || c->num_envs != h->cfg.num_envs) return fail(DW_EINVAL, "dw_amp_reset_rows: n out of range or num_envs differs from the handle's");
+    if (n == 0) return DW_OK;
+    hipLaunchKernelGGL(dw_k_amp_reset_rows, dim3(env_blocks(n)), dim3(64 * WPB), 0, (hipStream_t)stream, h->d_model, *c, *b, h->buf.root_states,
+                       h->buf.dof_state, h->buf.contact_forces, ids, n, power_scale, rootvel_noise, commands, qpos_bias, quat_bias, perturb_timing,
+                       delay_idx);
+    return launched("dw_amp_reset_rows: launch");
 }
 
 }  // extern "C"

@@ -15,9 +15,10 @@ Mirrors `TocabiAMPLowerBase` of the reference (paths relative to python/IsaacGym
 What runs where.  `gym.simulate` is dw_simulate of the bound physics handle (one launch per substep, the same octet kernel the
 DyrosDynamicWalk step fuses); observation, reward and termination are one HIP launch each; the rows of the rigid-body state
 tensor they need (base, the two foot links) come from dw_body_positions.  The bookkeeping between them -- history shifts,
-the command ramp, the torque FIFO -- is a few dozen elementwise torch launches per step on [N,12]..[N,480] tensors: this task
-is the reference's sibling, not the north star's hot path, and is NOT fused into one kernel the way VecTask.step of
-DyrosDynamicWalk is.  Random draws are torch's device generator, as in the reference; the generator and
+the command ramp, the torque FIFO -- is either ~100 elementwise torch launches per step on [N,12]..[N,480] tensors (the form the
+replay tests pin to the reference class) or, with cfg sim.mi355.amp_fused, five HIP kernels that give the torch form's bits
+(dw_amp_step_pre / _tau / _encoder / _post, dw_amp_reset_rows); enable_graph_step() records a step of
+either form in a hipGraph.  Random draws are torch's device generator, as in the reference; the generator and
 `simulate` are injectable, and tests/test_amp_gpu.py replays the reference CLASS' recorded draws and physics states through this
 class for 60 steps (tests/golden/amp_class_ref.npz): every state field, the torques handed to the engine and the reset flow are
 bit-identical, the observation and reward to the rounding of atan2f / expf.  Four things that replay found and that are now as
@@ -317,22 +318,11 @@ class TocabiAMPLower(VecTask):
         n = len(env_ids)
         if n == 0:
             return
+        if self._fused and self._state_init == "Default":
+            return self._reset_fused(env_ids)
         if self.randomize:
             self.power_scale[env_ids] = self._rand_float(0.8, 1.2, (n, 12))
-            # apply_randomizations (tasks/base/vec_task.py:519-733) for the dof properties: envs that are resetting and whose
-            # randomize_buf has reached the frequency draw damping (additive) and armature (scaling) from the ORIGINAL values
-            freq = self.randomization_params.get("frequency", 1)
-            dofp = self.randomization_params["actor_params"]["humanoid"].get("dof_properties", {})
-            sel = env_ids[(self.randomize_buf[env_ids] >= freq) & (self.reset_buf[env_ids] != 0)]
-            if len(sel) > 0:
-                b = self._phys._buf
-                if "damping" in dofp:
-                    lo, hi = dofp["damping"]["range"]
-                    b["dof_damping"][sel] = self._nominal_damping + self._rand_float(lo, hi, (len(sel), 33))
-                if "armature" in dofp:
-                    lo, hi = dofp["armature"]["range"]
-                    b["dof_armature"][sel] = self._nominal_armature * self._rand_float(lo, hi, (len(sel), 33))
-                self.randomize_buf[sel] = 0
+            self._randomize_dof_properties(env_ids)
         self._reset_actors(env_ids)
         self._contact_forces[env_ids] = 0.0
         self._refresh_sim_tensors()
@@ -371,6 +361,46 @@ class TocabiAMPLower(VecTask):
         self.delay_idx[env_ids] = self._rng.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,))
         self.simul_len[env_ids] = 0
         self._init_amp_obs(env_ids)                       # (tasks/tocabi_amp_lower.py:144-147)
+
+    def _randomize_dof_properties(self, env_ids):
+        """apply_randomizations (tasks/base/vec_task.py:519-733) for the dof properties: envs that are resetting and whose
+        randomize_buf has reached the frequency draw damping (additive) and armature (scaling) from the ORIGINAL values."""
+        freq = self.randomization_params.get("frequency", 1)
+        dofp = self.randomization_params["actor_params"]["humanoid"].get("dof_properties", {})
+        sel = env_ids[(self.randomize_buf[env_ids] >= freq) & (self.reset_buf[env_ids] != 0)]
+        if len(sel) > 0:
+            b = self._phys._buf
+            if "damping" in dofp:
+                lo, hi = dofp["damping"]["range"]
+                b["dof_damping"][sel] = self._nominal_damping + self._rand_float(lo, hi, (len(sel), 33))
+            if "armature" in dofp:
+                lo, hi = dofp["armature"]["range"]
+                b["dof_armature"][sel] = self._nominal_armature * self._rand_float(lo, hi, (len(sel), 33))
+            self.randomize_buf[sel] = 0
+
+    def _reset_fused(self, env_ids):
+        """reset_idx with one launch for all the row writes (dw_amp_reset_rows): the draws are made here, in reset_idx's order and
+        sizes, so the result is reset_idx's bit for bit (tests/test_amp_gpu.py); default state initialisation only."""
+        n, N = len(env_ids), self.num_envs
+        ps = None
+        if self.randomize:
+            ps = self._rand_float(0.8, 1.2, (n, 12)).contiguous()
+            self._randomize_dof_properties(env_ids)
+        self.time_step += 1
+        nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
+        cmd = torch.stack((self._rand_float(self.c_x[0], self.c_x[1], (n,)), self._rand_float(self.c_y[0], self.c_y[1], (n,)),
+                           self._rand_float(self.c_yaw[0], self.c_yaw[1], (n,))), dim=-1).contiguous()
+        qb = quatb = None
+        if self.noise:
+            qb = (self._div(self._rand(n, 12) * 6.28, 100) - 3.14 / 100).contiguous()
+            quatb = (self._div(self._rand(n, 3) * 6.28, 150) - 3.14 / 150).contiguous()
+        ptime = self._rng.randint(0, int(8 / 0.002), (n,))
+        didx = self._rng.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,))
+        c, b = self._fused_tables()
+        self._chk(self._api["amp_reset_rows"](self._phys._h, C.byref(c), C.byref(b), _p(env_ids.contiguous()), n, _p(ps), _p(nz), _p(cmd), _p(qb), _p(quatb),
+                                              _p(ptime), _p(didx), self._stream()))
+        self.time_step = 0
+        self._reset_default_env_ids = env_ids
 
     # ------------------------------------------------------------------ state initialisation (tasks/tocabi_amp_lower.py:149-256)
     def _reset_actors(self, env_ids):
@@ -634,7 +664,9 @@ class TocabiAMPLower(VecTask):
              "obs_buf": self.obs_buf, "obs_out": self._obs_out, "rew_buf": self.rew_buf, "reward_values": self._reward_values,
              "total_mass": self.total_mass, "amp_obs_buf": self._amp_obs_buf, "amp_obs1": self._amp_obs1, "motor_efforts": self.motor_efforts,
              "p_gains": self.p_gains, "d_gains": self.d_gains, "init_angle": self.init_angle,
-             "pd_action_offset": self._pd_action_offset if self._pd_control else None, "pd_action_scale": self._pd_action_scale if self._pd_control else None}
+             "pd_action_offset": self._pd_action_offset if self._pd_control else None, "pd_action_scale": self._pd_action_scale if self._pd_control else None,
+             "epi_len_log": self.epi_len_log, "perturbation_count": self.perturbation_count, "perturb_timing": self.perturb_timing,
+             "pert_on": self.pert_on, "initial_root_states": self._initial_root_states}
         b = abi.DwAmpBuffers()
         for name in abi.AMP_BUFFER_NAMES:
             v = t[name]

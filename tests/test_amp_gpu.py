@@ -560,9 +560,14 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control):
              "randomize_buf", "reset_buf", "_terminate_buf", "timeout_buf", "_rigid_body_pos", "_rigid_body_rot", "_foot_pos", "obs_buf", "rew_buf",
              "_reward_values", "_amp_obs_buf", "_root_states", "_dof_state", "_contact_forces"]
     ramps = resets = 0
+    after_reset = ["obs_buf", "_amp_obs_buf", "commands", "qpos_bias", "quat_bias", "delay_idx", "perturb_timing", "epi_len_log", "power_scale",
+                   "obs_history", "action_history", "action_log", "qpos_noise", "_root_states", "_dof_state", "_contact_forces", "_foot_pos", "reset_buf"]
     for t in range(80):
-        for e in envs:
-            e.reset_done()
+        ra_, rb_ = a.reset_done(), b.reset_done()          # (a: dw_amp_reset_rows, b: reset_idx's indexed assignments)
+        assert torch.equal(ra_[1], rb_[1]) and torch.equal(ra_[0]["obs"], rb_[0]["obs"]), t
+        for n in after_reset:
+            assert torch.equal(getattr(a, n), getattr(b, n)), (t, "after reset", n)
+        assert torch.equal(a._phys._buf["dof_damping"], b._phys._buf["dof_damping"]) and torch.equal(a._phys._buf["dof_armature"], b._phys._buf["dof_armature"]), t
         act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * (1.3 if t % 7 == 0 else 0.7)          # (beyond +-1 now and then: the clamp)
         oa, ra, da, xa = a.step(act)
         ob, rb, db, xb = b.step(act)
