@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--no-also-4096", action="store_true", help="skip the secondary 4096-env measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the friction-DR + forced-pushes leg (BASELINE config 5)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO-consumer leg (BASELINE config 3)")
+    ap.add_argument("--no-amp", action="store_true", help="skip the sibling-task leg (TocabiAMPLower, SURVEY 8 row f-3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = CPU plumbing rehearsal of the N-rank path (no kernel runs; the line is marked invalid)")
     args = ap.parse_args()
@@ -388,6 +389,30 @@ def main():
                 out["config3_ppo"]["graph_rollout"]["note"] = "rollout step and minibatch update each captured in a hipGraph (fused capturable Adam)"
             except Exception as e:
                 out["config3_ppo"] = {"error": str(e)}
+        if not args.no_amp and not plumbing:    # the sibling task on the same physics, step() + reset_done() as the AMP learner calls them
+            try:
+                from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+                acfg = default_amp_cfg(args.envs_per_gpu, dev)
+                acfg["sim"]["mi355"] = {"amp_fused": True}
+                aenv = TocabiAMPLower(acfg, dev, 0, True)
+                aenv.reset_done()
+                aenv.enable_graph_step()
+                ag = torch.Generator(device=dev).manual_seed(1)
+                aact = [(torch.rand(args.envs_per_gpu, 12, generator=ag, device=dev) * 2 - 1) * 0.3 for _ in range(8)]
+                for i in range(30):
+                    aenv.step(aact[i % 8]); aenv.reset_done()
+                sync(); t0 = time.perf_counter()
+                ka, nres = 200, 0
+                for i in range(ka):
+                    aenv.step(aact[i % 8])
+                    nres += len(aenv.reset_done()[1])
+                sync(); wa = time.perf_counter() - t0
+                aenv.close()
+                out["amp_lower"] = {"value": args.envs_per_gpu * ka / wa, "unit": "env-steps/s", "ms_per_step": wa / ka * 1e3, "resets_per_step": nres / ka,
+                                    "note": "TocabiAMPLower (tasks/amp/tocabi_amp_lower_base.py + tasks/tocabi_amp_lower.py) on dw_simulate: step() with the "
+                                            "bookkeeping in four HIP kernels, recorded in a hipGraph, + reset_done() every step (eager: it returns ids)"}
+            except Exception as e:
+                out["amp_lower"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not plumbing:
             try:
