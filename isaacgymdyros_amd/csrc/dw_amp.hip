@@ -5,6 +5,7 @@
 // that a maintainer binds them where the reference calls its own; dw_body_positions stands in for the rows of
 // acquire_rigid_body_state_tensor those functions read.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdio.h>
 
 #include "dw_handle.h"
@@ -385,7 +386,14 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_reset_rows(const dw::DevMod
 }
 
 bool amp_args_ok(const DwAmpConfig *c, const DwAmpBuffers *b) {
-    return c && b && c->num_envs > 0 && c->num_his >= 1 && c->num_skip >= 1 && c->num_his * c->num_skip * DW_AMP_NUM_OBS1 <= 64 * 12 &&
+    if (!c || !b) return false;
+    // every table entry up to init_angle is mandatory (a null one would be a fault on the device, not an error code); the PD offsets and
+    // the reset's own buffers are checked by the entry points that use them
+    static_assert(sizeof(DwAmpBuffers) % sizeof(void *) == 0, "DwAmpBuffers is a table of pointers");
+    const void *const *tbl = reinterpret_cast<const void *const *>(b);
+    const size_t mandatory = offsetof(DwAmpBuffers, pd_action_offset) / sizeof(void *);
+    for (size_t i = 0; i < mandatory; ++i) if (!tbl[i]) return false;
+    return c->num_envs > 0 && c->num_his >= 1 && c->num_skip >= 1 && c->num_his * c->num_skip * DW_AMP_NUM_OBS1 <= 64 * 12 &&
            c->num_his * c->num_skip * 12 <= 64 * 4 && c->log_slots >= 1 && c->amp_steps >= 1 && c->amp_steps * (DW_AMP_DISC_BASE + 6) <= 128;
 }
 

@@ -592,3 +592,23 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control):
         assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(xa["amp_obs"], xb["amp_obs"]), t
     for e in envs:
         e.close()
+
+
+def test_amp_step_argument_checks():
+    """The fused entry points refuse a table with a missing buffer or sizes beyond what a wave stages, with an error code and a
+    message, before anything is launched."""
+    from isaacgymdyros_amd import _lib, abi
+    lib, api = _lib.load()
+    c, b = abi.DwAmpConfig(), abi.DwAmpBuffers()
+    x = torch.zeros(1024, device="cuda")
+    c.num_envs, c.num_his, c.num_skip, c.log_slots, c.amp_steps = 4, 10, 2, 6, 2
+    for name in abi.AMP_BUFFER_NAMES:
+        setattr(b, name, x.data_ptr())
+    b.obs_history = None
+    assert api["amp_step_pre"](C.byref(c), C.byref(b), C.c_void_p(x.data_ptr()), None, None, None) != 0
+    assert b"dw_amp_step_pre" in lib.dw_last_error()
+    b.obs_history = x.data_ptr()
+    c.num_his = 40                                       # 40 x 2 x 36 words: more than a wave stages
+    assert api["amp_step_tau"](C.byref(c), C.byref(b), C.c_void_p(x.data_ptr()), None) != 0
+    c.num_his, c.vel_change = 10, 1
+    assert api["amp_step_pre"](C.byref(c), C.byref(b), C.c_void_p(x.data_ptr()), None, None, None) != 0          # the ramp draws are missing
