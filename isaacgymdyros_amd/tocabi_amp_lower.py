@@ -734,6 +734,9 @@ class TocabiAMPLower(VecTask):
             raise ValueError("enable_graph_step: env.perturbation reads a population mean on the host every step; not capturable")
         if self.rl_device != self.device:
             raise ValueError("enable_graph_step: rl_device must be the simulation device")
+        if not self._gpu_div and not self._fused:
+            raise ValueError("enable_graph_step: sim.mi355.torch_gpu_div = False makes the torch step build a tensor from a host scalar "
+                             "every substep (the CPU flavour of `x / dt`, for replaying CPU fixtures); not capturable")
         dev = self._tdev
         self._g_actions = torch.zeros(self.num_envs, NUM_ACTIONS, device=dev)
         self._capturing = True
