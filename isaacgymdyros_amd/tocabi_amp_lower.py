@@ -267,6 +267,9 @@ class TocabiAMPLower(VecTask):
         self._graph, self._capturing, self._g_actions, self._g_out = None, False, None, None
         # cfg sim.mi355.amp_fused: the step's bookkeeping as four HIP kernels (dw_amp_step_*) instead of ~100 torch launches
         self._fused = bool(cfg["sim"].get("mi355", {}).get("amp_fused", False))
+        # (the fused reset makes the reference's draws in the reference's order, so it can be switched on by itself and replayed
+        #  against the reference class; the fused step cannot: its command ramp draws for every env)
+        self._fused_reset = bool(cfg["sim"].get("mi355", {}).get("amp_fused_reset", self._fused))
         self._tau = torch.zeros(N, 33, **f)
         self._obs_out = torch.zeros(N, self.num_obs, **f)
         self._amp_obs1 = torch.zeros(N, NUM_AMP_OBS_PER_STEP, **f)
@@ -318,7 +321,7 @@ class TocabiAMPLower(VecTask):
         n = len(env_ids)
         if n == 0:
             return
-        if self._fused and self._state_init == "Default":
+        if self._fused_reset and self._state_init == "Default":
             return self._reset_fused(env_ids)
         if self.randomize:
             self.power_scale[env_ids] = self._rand_float(0.8, 1.2, (n, 12))

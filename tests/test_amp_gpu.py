@@ -175,7 +175,8 @@ class _ReplayDraws:
         return self._next("bernoulli", (n,))
 
 
-def test_tocabi_amp_lower_class_replays_the_reference_class():
+@pytest.mark.parametrize("fused_reset", [False, True])
+def test_tocabi_amp_lower_class_replays_the_reference_class(fused_reset):
     """The reference's TocabiAMPLowerBase stepped 60 times over the oracle's physics (fixture tests/golden/amp_class_ref.npz:
     its draws, the physics state after every simulate, its outputs).  The host class here is given the same actions, the same
     draws and the same physics states (its generator and its simulate are injectable) and must produce the reference's numbers:
@@ -187,7 +188,9 @@ def test_tocabi_amp_lower_class_replays_the_reference_class():
     cfg = default_amp_cfg(N, "cuda:0")
     cfg["env"]["episodeLength"] = int(g["episode_length"])
     cfg["task"]["randomize"] = False
-    cfg["sim"]["mi355"] = {"amp_initial_height": 0.89, "torch_gpu_div": False}          # (the fixture is torch-CPU arithmetic)
+    # (the fixture is torch-CPU arithmetic; fused_reset: reset_idx as the one launch of dw_amp_reset_rows -- it makes the reference's draws in
+    #  the reference's order, so the reference class pins it directly)
+    cfg["sim"]["mi355"] = {"amp_initial_height": 0.89, "torch_gpu_div": False, "amp_fused_reset": fused_reset}
     env = TocabiAMPLower(cfg, "cuda:0", 0, True)
     assert np.array_equal(env.motor_efforts.cpu().numpy(), g["motor_efforts"])
     assert np.array_equal(env.p_gains.cpu().numpy(), g["p_gains"]) and np.array_equal(env.d_gains.cpu().numpy(), g["d_gains"])
