@@ -433,11 +433,13 @@ int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, c
  * tasks/tocabi_amp_lower.py:144-147,258-272) as ONE launch instead of ~60 indexed assignments: a wavefront per listed env writes its rows
  * of the Gym tensors (initial pose, zero contact), the reset observation (computed from the episode's last encoder reading, as the
  * reference does), every piece of task state, and the env's discriminator history (copies of its current observation).  ids [n] int64 in
- * device memory, distinct; the draws are the caller's, one row per listed env in the order of ids: power_scale [n,12] (NULL: keep),
- * commands [n,3], qpos_bias [n,12], quat_bias [n,3], perturb_timing [n] int64, delay_idx [n] int64; rootvel_noise [N,6] is indexed by env. */
-int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale,
-                      const float *rootvel_noise, const float *commands, const float *qpos_bias, const float *quat_bias,
-                      const int64_t *perturb_timing, const int64_t *delay_idx, void *stream);
+ * device memory, distinct.  The draws are the caller's RAW uniforms in [0,1), one row per listed env in the order of ids, turned into
+ * values here with torch's own arithmetic: power_scale_u [n,12] -> 0.8 + 0.4 u (NULL: keep the scales), cmd_x_u / cmd_y_u / cmd_yaw_u [n]
+ * -> DwAmpConfig.cmd_lo + cmd_scale u, qpos_bias_u [n,12] -> u 6.28 / 100 - 3.14 / 100, quat_bias_u [n,3] -> u 6.28 / 150 - 3.14 / 150 (the
+ * division as DwAmpConfig.gpu_div says); perturb_timing [n], delay_idx [n] int64 as drawn; rootvel_noise [N,6] is indexed by env. */
+int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale_u,
+                      const float *rootvel_noise, const float *cmd_x_u, const float *cmd_y_u, const float *cmd_yaw_u, const float *qpos_bias_u,
+                      const float *quat_bias_u, const int64_t *perturb_timing, const int64_t *delay_idx, void *stream);
 
 
 #ifdef __cplusplus

@@ -155,7 +155,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
         api["amp_step_tau"] = fn("amp_step_tau", C.c_int, AC, AB, P, P)
         api["amp_step_encoder"] = fn("amp_step_encoder", C.c_int, AC, AB, P, P, P)
         api["amp_step_post"] = fn("amp_step_post", C.c_int, H, AC, AB, P, P)
-        api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P)
+        api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P, P, P)
     return api
 
 

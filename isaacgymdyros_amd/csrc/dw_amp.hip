@@ -304,8 +304,8 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_step_post(const dw::DevMode
 
 __global__ __launch_bounds__(64 * WPB) void dw_k_amp_reset_rows(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, float *root_states,
                                                                 float *dof_state, float *contact_forces, const int64_t *ids, int n, const float *ps,
-                                                                const float *rootvel_noise, const float *cmd, const float *qb, const float *quatb,
-                                                                const int64_t *ptime, const int64_t *didx) {
+                                                                const float *rootvel_noise, const float *cmdx, const float *cmdy, const float *cmdyaw,
+                                                                const float *qb, const float *quatb, const int64_t *ptime, const int64_t *didx) {
     const int k = wave_env(), l = wave_lane(), w = (int)(threadIdx.x >> 6);
     __shared__ dwa::LegModel LM;
     stage_leg_model(LM, *M);
@@ -332,7 +332,9 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_reset_rows(const dw::DevMod
         dof_state[((size_t)DW_NUM_DOF * e + l) * 2] = q0; dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1] = 0.0f;
     }
     for (int i = l; i < DW_NUM_BODIES * 3; i += 64) contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i] = 0.0f;
-    if (ps && l < 12) B.power_scale[12 * (size_t)e + l] = ps[12 * (size_t)k + l];
+    // (the draws arrive as raw uniforms; the values are formed with torch's arithmetic: `(hi - lo) * u + lo` with the scalars rounded to
+    //  float32 first, `x / s` as a multiplication by 1.0f / s on a GPU and a division on a CPU)
+    if (ps && l < 12) B.power_scale[12 * (size_t)e + l] = (float)(1.2 - 0.8) * ps[12 * (size_t)k + l] + (float)0.8;
     wave_fence();
     const float *r = s_root[w], *ds = s_ds[w];
     if (l < 2) {          // the rigid-body rows of the new state
@@ -370,8 +372,25 @@ __global__ __launch_bounds__(64 * WPB) void dw_k_amp_reset_rows(const dw::DevMod
         const size_t g = (size_t)DW_NUM_DOF * e + l;
         B.dof_vel_pre[g] = 0.0f; B.qpos_noise[g] = B.init_angle[l]; B.qpos_pre[g] = B.init_angle[l]; B.qvel_noise[g] = 0.0f;
     }
-    if (l < 12) { B.actions_pre[12 * (size_t)e + l] = 0.0f; B.qpos_bias[12 * (size_t)e + l] = C.noise ? qb[12 * (size_t)k + l] : 0.0f; }
-    if (l < 3) { B.commands[3 * (size_t)e + l] = cmd[3 * (size_t)k + l]; B.quat_bias[3 * (size_t)e + l] = C.noise ? quatb[3 * (size_t)k + l] : 0.0f; }
+    if (l < 12) {
+        B.actions_pre[12 * (size_t)e + l] = 0.0f;
+        float v = 0.0f;
+        if (C.noise) {
+            const float x = qb[12 * (size_t)k + l] * 6.28f;
+            v = (C.gpu_div ? x * (1.0f / 100.0f) : x / 100.0f) - (float)(3.14 / 100);
+        }
+        B.qpos_bias[12 * (size_t)e + l] = v;
+    }
+    if (l < 3) {
+        const float u = l == 0 ? cmdx[k] : (l == 1 ? cmdy[k] : cmdyaw[k]);
+        B.commands[3 * (size_t)e + l] = C.cmd_scale[l] * u + C.cmd_lo[l];
+        float v = 0.0f;
+        if (C.noise) {
+            const float x = quatb[3 * (size_t)k + l] * 6.28f;
+            v = (C.gpu_div ? x * (1.0f / 150.0f) : x / 150.0f) - (float)(3.14 / 150);
+        }
+        B.quat_bias[3 * (size_t)e + l] = v;
+    }
     if (l == 0) {
         B.progress_buf[e] = 0; B.reset_buf[e] = 0; B.terminate_buf[e] = 0;
         B.epi_len_log[e] = B.epi_len[e]; B.epi_len[e] = 0.0f;
@@ -511,9 +530,9 @@ int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, c
 }
 
 int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale,
-                      const float *rootvel_noise, const float *commands, const float *qpos_bias, const float *quat_bias,
-                      const int64_t *perturb_timing, const int64_t *delay_idx, void *stream) {
-    if (!h || !amp_args_ok(c, b) || !ids || !rootvel_noise || !commands || !perturb_timing || !delay_idx)
+                      const float *rootvel_noise, const float *cmd_x, const float *cmd_y, const float *cmd_yaw, const float *qpos_bias,
+                      const float *quat_bias, const int64_t *perturb_timing, const int64_t *delay_idx, void *stream) {
+    if (!h || !amp_args_ok(c, b) || !ids || !rootvel_noise || !cmd_x || !cmd_y || !cmd_yaw || !perturb_timing || !delay_idx)
         return fail(DW_EINVAL, "dw_amp_reset_rows: bad configuration or null argument");
     if (c->noise && (!qpos_bias || !quat_bias)) return fail(DW_EINVAL, "dw_amp_reset_rows: noise needs the bias draws");
     if (!b->epi_len_log || !b->perturbation_count || !b->perturb_timing || !b->pert_on || !b->initial_root_states)
@@ -522,8 +541,8 @@ int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, 
     if (n < 0 || n > c->num_envs || c->num_envs != h->cfg.num_envs) return fail(DW_EINVAL, "dw_amp_reset_rows: n out of range or num_envs differs from the handle's");
     if (n == 0) return DW_OK;
     hipLaunchKernelGGL(dw_k_amp_reset_rows, dim3(env_blocks(n)), dim3(64 * WPB), 0, (hipStream_t)stream, h->d_model, *c, *b, h->buf.root_states,
-                       h->buf.dof_state, h->buf.contact_forces, ids, n, power_scale, rootvel_noise, commands, qpos_bias, quat_bias, perturb_timing,
-                       delay_idx);
+                       h->buf.dof_state, h->buf.contact_forces, ids, n, power_scale, rootvel_noise, cmd_x, cmd_y, cmd_yaw, qpos_bias, quat_bias,
+                       perturb_timing, delay_idx);
     return launched("dw_amp_reset_rows: launch");
 }
 

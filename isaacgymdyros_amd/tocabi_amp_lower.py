@@ -385,23 +385,22 @@ class TocabiAMPLower(VecTask):
         """reset_idx with one launch for all the row writes (dw_amp_reset_rows): the draws are made here, in reset_idx's order and
         sizes, so the result is reset_idx's bit for bit (tests/test_amp_gpu.py); default state initialisation only."""
         n, N = len(env_ids), self.num_envs
+        # (raw uniforms in reset_idx's order and sizes; the kernel forms the values with the same float32 arithmetic)
         ps = None
         if self.randomize:
-            ps = self._rand_float(0.8, 1.2, (n, 12)).contiguous()
+            ps = self._rand(n, 12)
             self._randomize_dof_properties(env_ids)
         self.time_step += 1
         nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
-        cmd = torch.stack((self._rand_float(self.c_x[0], self.c_x[1], (n,)), self._rand_float(self.c_y[0], self.c_y[1], (n,)),
-                           self._rand_float(self.c_yaw[0], self.c_yaw[1], (n,))), dim=-1).contiguous()
+        cx, cy, cyaw = self._rand(n), self._rand(n), self._rand(n)
         qb = quatb = None
         if self.noise:
-            qb = (self._div(self._rand(n, 12) * 6.28, 100) - 3.14 / 100).contiguous()
-            quatb = (self._div(self._rand(n, 3) * 6.28, 150) - 3.14 / 150).contiguous()
+            qb, quatb = self._rand(n, 12), self._rand(n, 3)
         ptime = self._rng.randint(0, int(8 / 0.002), (n,))
         didx = self._rng.randint(1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt), (n,))
         c, b = self._fused_tables()
-        self._chk(self._api["amp_reset_rows"](self._phys._h, C.byref(c), C.byref(b), _p(env_ids.contiguous()), n, _p(ps), _p(nz), _p(cmd), _p(qb), _p(quatb),
-                                              _p(ptime), _p(didx), self._stream()))
+        self._chk(self._api["amp_reset_rows"](self._phys._h, C.byref(c), C.byref(b), _p(env_ids.contiguous()), n, _p(ps), _p(nz), _p(cx), _p(cy), _p(cyaw),
+                                              _p(qb), _p(quatb), _p(ptime), _p(didx), self._stream()))
         self.time_step = 0
         self._reset_default_env_ids = env_ids
 
