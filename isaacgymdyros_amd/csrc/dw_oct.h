@@ -204,11 +204,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 1);
-    // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist.  A step comes in two forms,
-    //      chosen by a wave-uniform bit of the schedule: in most steps no lane starts a chain, every lane's parent is the body
-    //      of its previous step, and the lean form updates the running state unconditionally (lanes that idle compute on
-    //      zeros and store nothing); the three steps in which some chain starts -- at the base or below another lane's body,
-    //      whose running state is fetched from that lane's registers -- take the general form with its selects. ----
+    // ---- outward pass 1: kinematics.  Running parent state: quaternion, rotation, origin, twist.  In most steps no lane starts
+    //      a chain, every lane's parent is the body of its previous step, and the running state is updated unconditionally
+    //      (lanes that idle compute on zeros and store nothing); in the three steps in which some chain starts -- at the base or
+    //      below another lane's body, whose running state is fetched from that lane's registers -- a wave-uniform bit of the
+    //      schedule puts the fetch in front.  ONE copy of the step's arithmetic follows either way: written as two call sites
+    //      (one per branch) it cost 35 more register copies per step at the join and 1 % of the whole kernel. ----
     const int startmask = f2i(H.base[15]);
     {
         float qr[4] = {0, 0, 0, 1}, Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xr_[3] = {0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
@@ -276,12 +277,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                         DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
                     }
                 }
-                wave_sync();
-                fk_body(s, rc, in);
-            } else {
-                wave_sync();
-                fk_body(s, rc, in);
             }
+            wave_sync();
+            fk_body(s, rc, in);
         }
     }
     wave_sync();
