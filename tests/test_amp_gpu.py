@@ -541,8 +541,8 @@ def test_tocabi_amp_lower_graph_step_equals_eager():
         e.close()
 
 
-@pytest.mark.parametrize("pd_control", [False, True])
-def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control):
+@pytest.mark.parametrize("pd_control,plain", [(False, False), (True, False), (False, True)])
+def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
     """cfg sim.mi355.amp_fused: the step's bookkeeping in four HIP kernels (dw_amp_step_pre / _tau / _encoder / _post) against the
     torch implementation of the same class (the branch of the command ramp that draws for every env; itself pinned to the
     reference class by the replay tests above): same seeds and actions for 80 steps with resets in between -- every output and
@@ -553,6 +553,8 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control):
     for fused in (True, False):
         cfg = default_amp_cfg(N, "cuda:0")
         cfg["env"].update({"episodeLength": 40, "pdControl": pd_control, "numAMPObsSteps": 3})
+        if plain:          # no encoder / observation noise, no command ramp, no randomisation: the entry points then get no draws at all
+            cfg["task"]["noise"], cfg["task"]["randomize"], cfg["env"]["velChange"] = False, False, False
         cfg["sim"]["mi355"] = {"amp_fused": fused}
         envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
     a, b = envs
@@ -581,7 +583,7 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control):
         assert torch.equal(xa["amp_obs"], xb["amp_obs"]) and torch.equal(xa["time_outs"], xb["time_outs"]) and torch.equal(xa["terminate"], xb["terminate"]), t
         ramps += int((a.cur_vel_change_duration > 0).sum())
         resets += int(da.sum())
-    assert resets > N and ramps > 0
+    assert resets > N and (ramps > 0 or plain)
     # and recorded in a hipGraph: the same numbers again
     a.enable_graph_step(warmup=2)
     for _ in range(2):
