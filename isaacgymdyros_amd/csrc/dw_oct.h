@@ -19,6 +19,7 @@
 #pragma once
 
 #include "dw_quad.h"
+#include "dw_bufg.h"
 
 namespace dwo {
 
@@ -172,7 +173,7 @@ DQ_HD int sched_body(const QHot &H, int s, int j) {
 }
 
 template <bool TERRAIN>
-DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevModel &M, const PhysParams &P, OLane &X, const DwBuffers &B,
+DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevModel &M, const PhysParams &P, OLane &X, const OBuf &B,
                         float push_x, float push_y, bool last) {
     const float dt = P.dt, inv_dt = 1.0f / P.dt;
     const int j = X.j;
@@ -342,7 +343,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         sc_any = wave_any(hits != 0);
         DQ_STAMP(B, 52);
 #if defined(DQ_STAMPS) && defined(__HIPCC__)
-        if (blockIdx.x == 0 && threadIdx.x == 0) B.gate_acc[200 + 53] = sc_any;
+        if (blockIdx.x == 0 && threadIdx.x == 0) OQ_COLD(gate_acc)[200 + 53] = sc_any;
 #endif
         if (sc_any) {
             float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
@@ -607,7 +608,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
     wave_sync();
 #if defined(DQ_STAMPS) && defined(__HIPCC__)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && SB == 1) { B.gate_acc[200 + 32] = tq_map; B.gate_acc[200 + 33] = tq_rec; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && SB == 1) { OQ_COLD(gate_acc)[200 + 32] = tq_map; OQ_COLD(gate_acc)[200 + 33] = tq_rec; }
 #endif
     // (the sole body's non-sole contact force was found by whichever half mapped it)
     DQ_UNROLL for (int i = 0; i < 3; ++i) X.footF[i] += oct_xor4(X.footF[i]);
@@ -1141,7 +1142,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 }
 
 // Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
-DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, const PhysParams &P, float friction, const DwBuffers &B) {
+DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, const PhysParams &P, float friction, const OBuf &B) {
     X.lane = lane_id();
     X.wave = wave_index;
     X.o = X.lane & 7; X.j = X.lane & 3; X.h = (X.lane >> 2) & 1;
@@ -1151,7 +1152,7 @@ DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, 
     X.env = X.valid ? eg : num_envs - 1;
     X.pos = pcode(H, X.el, X.j);
     DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = B.root_states[(size_t)13 * X.env + i];
-    X.mu = friction * B.friction_scale[X.env];
+    X.mu = friction * OQ_COLD(friction_scale)[X.env];
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     X.stamp_base = 0;
     X.coll = 0;
@@ -1188,7 +1189,7 @@ DQ_HD void joint_integrate(OSlots &L, const JointItem &it, float dt, float q_old
 // Gym-boundary substep for 8 envs: tau [N,33], push [N,2] or nullptr (replaces dw::simulate_env)
 template <bool TERRAIN>
 DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const PhysParams &P, float friction, int num_envs,
-                        const DwBuffers &B, const float *tau, const float *push, int wave_index) {
+                        const OBuf &B, const float *tau, const float *push, int wave_index) {
     if (wave_index * EPO >= num_envs) return;        // the second wave of the last workgroup may have no env at all
     OLane X;
     oct_lane_init(X, QM.hot, wave_index, num_envs, P, friction, B);

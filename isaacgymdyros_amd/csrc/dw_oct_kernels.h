@@ -33,7 +33,7 @@ constexpr int PK_TAU2 = 0, PK_NZ1 = 64;      // words of the env's obs_buf row u
 // post_physics_step (dw_quad_post.h).  The task record is read where needed and written ONCE, by the post phase, from its
 // LDS image: what the earlier phases produce for it stays in registers (StepKeep) until the image exists.
 template <bool TERRAIN>
-DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const TaskParams &C, const DwBuffers &B,
+DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const TaskParams &C, const OBuf &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     if (wave_index * EPO >= C.num_envs) return;      // the second wave of the last workgroup may have no env at all (wave-uniform exit; no barrier follows)
     int c_num_envs = C.num_envs, c_freeze = C.freeze_physics;          // (launch-invariant, read by every item of every phase)
@@ -113,9 +113,10 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         // ---- pre_physics_step, per-env scalar parts on the quad's lanes (dw_task.h P1): lane 0 the mocap phase, lane 1 the
         //      push schedule; every fp32 expression as there ----
         dw::TaskBuffers TB;
-        TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = mocap; TB.step = step;
+        TB.b = B.all; TB.actions = actions; TB.noise = noise; TB.mocap = mocap; TB.step = step;
         const dw::StepCtx K = dw::make_step_ctx(C, TB, e);
-        if (X.lane == 1) OQ_ENVW(0, WW_GATE) = __builtin_bit_cast(float, dw::gate_open(C, K));
+        long long DW_GPTR *gate = reinterpret_cast<long long DW_GPTR *>(OQ_COLD(gate_acc));          // (K.gate is the same words through a generic pointer)
+        if (X.lane == 1) OQ_ENVW(0, WW_GATE) = __builtin_bit_cast(float, dw::gate_open_at(C, K, gate));
         if (X.j == 0) {
             const float time = r_time;
             const int init_idx = f2i(r_init);
@@ -155,7 +156,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             float magnitude = r_mag, phase = r_phase;
             if (open) {
                 pert_start = 1;
-                if (!C.force_perturb_start && X.valid && X.h == 0) K.gate[dw::GATE_LATCH] = 1;
+                if (!C.force_perturb_start && X.valid && X.h == 0) gate[dw::GATE_LATCH] = 1;
             }
             if (pert_start) {
                 if (dw::remainder_t(r_epi, C.pert_period_f) == (float)f2i(r_ptim)) {
@@ -344,14 +345,14 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     DQ_STAMP(B, 41);
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)
     if (X.lane == 0) {
-        B.stacked_rewards[(size_t)wave_index * EPO * DW_NUM_REW + 14] = (float)((long long)__builtin_readcyclecounter() - dq_t0);
-        B.stacked_rewards[(size_t)wave_index * EPO * DW_NUM_REW + 13] = (float)(dq_t1 - dq_t0);          // physics part
+        OQ_COLD(stacked_rewards)[(size_t)wave_index * EPO * DW_NUM_REW + 14] = (float)((long long)__builtin_readcyclecounter() - dq_t0);
+        OQ_COLD(stacked_rewards)[(size_t)wave_index * EPO * DW_NUM_REW + 13] = (float)(dq_t1 - dq_t0);          // physics part
         // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID, as exact small integers in two floats of env 2's row
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 1] = (float)(hw & 0xffff);
-        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 2] = (float)(xcc & 0xf);
-        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 3] = (float)(dq_r0 & 0xffffff);      // start time, 100 MHz clock common to the chip (low bits)
-        B.stacked_rewards[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 4] = (float)((long long)__builtin_amdgcn_s_memrealtime() & 0xffffff);      // end time
+        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 1] = (float)(hw & 0xffff);
+        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 2] = (float)(xcc & 0xf);
+        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 3] = (float)(dq_r0 & 0xffffff);      // start time, 100 MHz clock common to the chip (low bits)
+        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 4] = (float)((long long)__builtin_amdgcn_s_memrealtime() & 0xffffff);      // end time
     }
 #endif
 }

@@ -10,14 +10,15 @@
 // The whole VecTask.step of 8 envs per wavefront, 8 lanes per env; a workgroup is two wavefronts that share one copy of the
 // hot tables and nothing else (grid = ceil(N / 16) workgroups of 128 threads).  40 KB of LDS per workgroup: 4 workgroups =
 // 8 waves per CU, TWO per SIMD, so a wave may use 256 registers (VGPRs + AGPRs; the register file is unified on gfx950).
-// (DwBuffers travels BY VALUE: see dw_quad_kernels.hip.)
+// (The buffer table travels split: DwHot by value -- the pointers of the physics and the item loops, global not generic as kernel
+// arguments -- and the rest read from the parameter block through DwBuffersG: dw_bufg.h.)
 // Two builds of each kernel from the same source.  WPE = 2: two waves per SIMD (the register budget the code is written for),
 // for launches with more waves than the device has SIMDs.  WPE = 1: declared occupancy one wave per SIMD -- the same 250
 // registers, but the hardware then never puts two of the launch's waves on one SIMD while another SIMD is idle, which it
 // otherwise does as soon as a CU holds two workgroups (measured at 8192 envs: 0.1329 ms against 0.1428 ms).
 template <bool TERRAIN, int WPE>
 __global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwBuffers B, const float *mocap,
+void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwHot HB, const float *mocap,
                    const float *actions, const float *noise, long long step, const long long *step_dev) {
     __shared__ dwo::OLds L;
     if (step_dev) step = *step_dev;          // (dw_step_dev: the counter lives in device memory so that a captured launch can be replayed)
@@ -25,16 +26,16 @@ void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__
 #if defined(OCT_STAGGER_SHIFT)      // (timing experiment: hold back every other group of workgroups so that the two waves of a SIMD are in different phases)
     if ((blockIdx.x >> OCT_STAGGER_SHIFT) & 1) for (int i = 0; i < OCT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-    dwo::oct_step<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C, B, actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
+    dwo::oct_step<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C, make_obuf(HB, &P->B), actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
 }
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN, int WPE>
 __global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void dw_k_simulate_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwBuffers B, const float *tau,
+void dw_k_simulate_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwHot HB, const float *tau,
                        const float *push) {
     __shared__ dwo::OLds L;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    dwo::oct_simulate<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, B, tau, push, (int)blockIdx.x * dwo::WPG + w);
+    dwo::oct_simulate<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, make_obuf(HB, &P->B), tau, push, (int)blockIdx.x * dwo::WPG + w);
 }
 
 namespace dwo {
@@ -55,19 +56,19 @@ void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::Quad
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
     const dim3 grid(groups(num_envs)), block(64 * WPG);
     const bool sp = spread(num_envs);
-    if (terrain && sp) hipLaunchKernelGGL((dw_k_step_oct<true, 1>), grid, block, 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
-    else if (terrain) hipLaunchKernelGGL((dw_k_step_oct<true, 2>), grid, block, 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
-    else if (sp) hipLaunchKernelGGL((dw_k_step_oct<false, 1>), grid, block, 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
-    else hipLaunchKernelGGL((dw_k_step_oct<false, 2>), grid, block, 0, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
+    if (terrain && sp) hipLaunchKernelGGL((dw_k_step_oct<true, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    else if (terrain) hipLaunchKernelGGL((dw_k_step_oct<true, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    else if (sp) hipLaunchKernelGGL((dw_k_step_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    else hipLaunchKernelGGL((dw_k_step_oct<false, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
 }
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push) {
     const dim3 grid(groups(num_envs)), block(64 * WPG);
     const bool sp = spread(num_envs);
-    if (terrain && sp) hipLaunchKernelGGL((dw_k_simulate_oct<true, 1>), grid, block, 0, stream, QM, M, P, B, tau, push);
-    else if (terrain) hipLaunchKernelGGL((dw_k_simulate_oct<true, 2>), grid, block, 0, stream, QM, M, P, B, tau, push);
-    else if (sp) hipLaunchKernelGGL((dw_k_simulate_oct<false, 1>), grid, block, 0, stream, QM, M, P, B, tau, push);
-    else hipLaunchKernelGGL((dw_k_simulate_oct<false, 2>), grid, block, 0, stream, QM, M, P, B, tau, push);
+    if (terrain && sp) hipLaunchKernelGGL((dw_k_simulate_oct<true, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+    else if (terrain) hipLaunchKernelGGL((dw_k_simulate_oct<true, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+    else if (sp) hipLaunchKernelGGL((dw_k_simulate_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+    else hipLaunchKernelGGL((dw_k_simulate_oct<false, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
 }
 int oct_lds_bytes() { return (int)sizeof(OLds); }
 int sc_park_words() { return SC_PARK_WORDS; }

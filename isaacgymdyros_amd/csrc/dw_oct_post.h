@@ -86,7 +86,7 @@ DQ_HD float norm3_t(float x, float y, float z) {
 // X.coll / X.footT (collision flag of my bodies, net force on my sole body).  With physics frozen (tests) the state and
 // the contact forces are the Gym tensors as they are.
 template <bool TERRAIN>
-DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, const DwBuffers &B, const float *actions,
+DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, const OBuf &B, const float *actions,
                           const float *noise, long long step, int wave_index, OLane &X, const float (&qv)[ONI], const float (&qdv)[ONI],
                           const StepKeep &KP) {
     float *LF = reinterpret_cast<float *>(&L.slot[0][0]);
@@ -101,7 +101,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const int e = xvalid ? eg_ : C.num_envs - 1;
     const int N = C.num_envs;
     dw::TaskBuffers TB;
-    TB.b = &B; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
+    TB.b = B.all; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
     const dw::StepCtx K = dw::make_step_ctx(C, TB, e);        // (nz of MY env; items build their own)
     const float period = K.period;
     const double cdt_d = K.cdt_d;
@@ -110,11 +110,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     // (the VecTask counters and the clock action of Q1, the per-joint constants of the reset path and the observation's mean /
     //  scale, requested together with the records: one memory latency for all.  The hot tables of the physics are dead by now:
     //  the observation constants go where they were.)
-    const long long q1_progress = B.progress_buf[e], q1_randomize = B.randomize_buf[e];
-    const float q1_mass = B.total_mass[e], q1_clock = dw::clamp_action(actions, e, 12);
+    const long long q1_progress = OQ_COLD(progress_buf)[e], q1_randomize = OQ_COLD(randomize_buf)[e];
+    const float q1_mass = OQ_COLD(total_mass)[e], q1_clock = dw::clamp_action(actions, e, 12);
     const int lj = lane < ND ? lane : 0, lo1 = lane < DW_NUM_OBS1 ? lane : 0;
     const float c_qinit = M.q_init[lj], c_qhi = M.qhi[lj], c_qlo = M.qlo[lj];
-    const float c_org0 = B.env_origins[3 * e], c_org1 = B.env_origins[3 * e + 1], c_org2 = B.env_origins[3 * e + 2];
+    const float c_org0 = OQ_COLD(env_origins)[3 * e], c_org1 = OQ_COLD(env_origins)[3 * e + 1], c_org2 = OQ_COLD(env_origins)[3 * e + 2];
     float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
     const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
     // (nominal damping / armature of the joints whose randomisation words this lane draws at a reset: requested here, with everything else)
@@ -213,12 +213,12 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         time = time + C.clock_gain_f * q1_clock;
         PQ_ES(el, DW_ES_TIME) = time;
         if (xvalid) {
-            B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
-            B.progress_buf[e] = p + 1;
+            OQ_COLD(timeout_buf)[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
+            OQ_COLD(progress_buf)[e] = p + 1;
         }
         PQ_PSI(el, PS_PROGRESS) = (int)(p + 1);
         rb = rb + 1;
-        if (xvalid) B.randomize_buf[e] = rb;
+        if (xvalid) OQ_COLD(randomize_buf)[e] = rb;
         PQ_PSI(el, PS_RANDOMIZE) = rb;
         bool bad = false;
         DQ_UNROLL for (int i = 0; i < 13; ++i) bad = bad || !dw::finitef(PQ_ROOT(el, i));
@@ -338,8 +338,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         if (xvalid) {
             DQ_UNROLL for (int i = 0; i < 4; ++i) {
                 const int l = 4 * j + i;
-                if (l < 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
-                if (l == 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + 14] = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
+                if (l < 14) OQ_COLD(stacked_rewards)[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
+                if (l == 14) OQ_COLD(stacked_rewards)[(size_t)DW_NUM_REW * e + 14] = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
             }
         }
         if (j == 0) {
@@ -351,7 +351,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             if ((float)PQ_PSI(el, PS_PROGRESS) >= C.max_episode_length - 1.0f) reset = 1;
             if (collision) reset = 1;
             if (PQ_PSI(el, PS_BAD)) reset = 1;
-            if (xvalid) { B.rew_buf[e] = total; B.reset_buf[e] = reset; }
+            if (xvalid) { OQ_COLD(rew_buf)[e] = total; OQ_COLD(reset_buf)[e] = reset; }
             PQ_PSI(el, PS_RESET) = reset;
             float ret = PQ_ES(el, DW_ES_EPI_RETURN) + total;
             if (reset) {
@@ -376,17 +376,17 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
             const float need = dw::norm_t(tv, 2) * C.max_episode_length_s * 0.5f;
             const bool move_down = (distance < need) && !move_up;
-            long long lvl = B.terrain_levels[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
+            long long lvl = OQ_COLD(terrain_levels)[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
             if (lvl >= C.terrain_num_levels) {
                 int k = (int)(dw::noise_word(K.nz, DW_NZ_TERRAIN_LVL) * (float)C.terrain_num_levels);
                 if (k > C.terrain_num_levels - 1) k = C.terrain_num_levels - 1;
                 lvl = k;
             } else if (lvl < 0) lvl = 0;
-            long long ty = B.terrain_types[e];
+            long long ty = OQ_COLD(terrain_types)[e];
             ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
-            const float *org = B.terrain_origins + ((size_t)lvl * C.terrain_num_types + ty) * 3;
-            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (xvalid) B.env_origins[3 * e + i] = o; }
-            if (xvalid) B.terrain_levels[e] = lvl;
+            const float DW_GPTR *org = OQ_COLD(terrain_origins) + ((size_t)lvl * C.terrain_num_types + ty) * 3;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (xvalid) OQ_COLD(env_origins)[3 * e + i] = o; }
+            if (xvalid) OQ_COLD(terrain_levels)[e] = lvl;
         }
         wave_sync();
         // ALL envs that ended at once, each on its own eight lanes (a pass per ended env made the launch wait for the waves
@@ -443,7 +443,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
                     const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
                     const float sd = d0 + u[p2][i] * d1, sa = a0 + u[p2][i] * a1;
                     if (go && xvalid && C.dr_dof && (isd || isa)) (isa ? B.dof_armature : B.dof_damping)[(size_t)ND * e + l] = isa ? dr_nom[p2][i] * sa : dr_nom[p2][i] + sd;
-                    if (go && xvalid && C.dr_friction && w == DW_NZ_DR_FRIC) B.friction_scale[e] = f0 + u[p2][i] * f1;
+                    if (go && xvalid && C.dr_friction && w == DW_NZ_DR_FRIC) OQ_COLD(friction_scale)[e] = f0 + u[p2][i] * f1;
                 }
             }
         }
@@ -488,9 +488,9 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         DQ_WT();
         // per-env scalars (dw_task.h reset_region, lane 40)
         if (j == 0 && mine) {
-            if (do_dr && xvalid) B.randomize_buf[e] = 0;
+            if (do_dr && xvalid) OQ_COLD(randomize_buf)[e] = 0;
             PQ_ES(el, DW_ES_TIME) = 0.0f;
-            if (xvalid) { B.progress_buf[e] = 0; B.reset_buf[e] = 1; }
+            if (xvalid) { OQ_COLD(progress_buf)[e] = 0; OQ_COLD(reset_buf)[e] = 1; }
             PQ_ES(el, DW_ES_CRM) = PQ_ES(el, DW_ES_CRS) / PQ_ES(el, DW_ES_EPI_LEN);
             PQ_ES(el, DW_ES_CRS) = 0.0f;
             PQ_ESI(el, DW_ES_SIMUL_LEN) = 0;
@@ -641,10 +641,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             long long de, dc = 0;
             if (dw::finitef(eln) && dw::finitef(cm)) { de = (long long)eln; dc = (long long)llrintf(cm * 4294967296.0f); }
             else de = -((long long)1 << 62);
-            atomic_add_u64(reinterpret_cast<unsigned long long *>(&K.gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2]), (unsigned long long)de);
-            atomic_add_u64(reinterpret_cast<unsigned long long *>(&K.gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2 + 1]), (unsigned long long)dc);
-            K.gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2] = 0;
-            K.gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2 + 1] = 0;
+            long long DW_GPTR *gate = reinterpret_cast<long long DW_GPTR *>(OQ_COLD(gate_acc));
+            atomic_add_u64(reinterpret_cast<unsigned long long DW_GPTR *>(&gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2]), (unsigned long long)de);
+            atomic_add_u64(reinterpret_cast<unsigned long long DW_GPTR *>(&gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2 + 1]), (unsigned long long)dc);
+            gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2] = 0;
+            gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2 + 1] = 0;
         }
     }
     wave_sync();

@@ -82,6 +82,11 @@ DQ_HD float rsqrt_nr(float x) { const float y = __builtin_amdgcn_rsqf(x); return
 DQ_HD float rcp_nr(float x) { const float y = __builtin_amdgcn_rcpf(x); return y * (2.0f - x * y); }
 DQ_HD float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }          // 1 ulp
 DQ_HD void atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
+#if defined(__HIP_DEVICE_COMPILE__)          // (the same through a global pointer: global_atomic instead of flat_atomic, dw_bufg.h)
+DQ_HD void atomic_add_u64(unsigned long long __attribute__((address_space(1))) *p, unsigned long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 }  // namespace dwq
 #else

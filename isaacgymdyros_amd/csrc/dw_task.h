@@ -382,14 +382,15 @@ DW_HD StepCtx make_step_ctx(const TaskParams &C, const TaskBuffers &T, int e) {
     return K;
 }
 // population statistics of the previous step (tasks/dyros_dynamic_walk.py:489): is the perturbation gate open
-DW_HD int gate_open(const TaskParams &C, const StepCtx &K) {
+template <class GP>
+DW_HD int gate_open_at(const TaskParams &C, const StepCtx &K, GP gate) {          // (gate: the gate words, through whatever pointer type the caller holds)
     int open = C.force_perturb_start;
     if (!open && C.perturb) {
-        const long long latch = K.gate[GATE_LATCH];
+        const long long latch = gate[GATE_LATCH];
         long long se = 0, sc = 0;
         for (int k = 0; k < GATE_BUCKETS; ++k) {
-            se += K.gate[(K.slot_prev * GATE_BUCKETS + k) * 2];
-            sc += K.gate[(K.slot_prev * GATE_BUCKETS + k) * 2 + 1];
+            se += gate[(K.slot_prev * GATE_BUCKETS + k) * 2];
+            sc += gate[(K.slot_prev * GATE_BUCKETS + k) * 2 + 1];
         }
         const double n = (double)C.num_envs;
         const double mean_epi = (double)se / n, mean_crm = (double)sc / 4294967296.0 / n;
@@ -397,6 +398,7 @@ DW_HD int gate_open(const TaskParams &C, const StepCtx &K) {
     }
     return open;
 }
+DW_HD int gate_open(const TaskParams &C, const StepCtx &K) { return gate_open_at(C, K, K.gate); }
 // VecTask counters and the env's mass into the flag / scratch words the post regions read
 template <class LT>
 DW_HD void load_counters(LT &S, const DwBuffers &B, int e) {

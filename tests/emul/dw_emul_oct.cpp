@@ -30,12 +30,12 @@ void wave_body(void *p, int) {
     DwHandle *h = w->h;
     switch (w->kind) {
     case 0:
-        if (h->cfg.terrain) dwo::oct_simulate<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
-        else dwo::oct_simulate<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, h->dp.B, w->a0, w->a1, w->wave);
+        if (h->cfg.terrain) dwo::oct_simulate<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
+        else dwo::oct_simulate<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
         break;
     case 1:
-        if (h->cfg.terrain) dwo::oct_step<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else dwo::oct_step<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C, h->dp.B, w->a0, h->mocap, w->a1, w->step, w->wave);
+        if (h->cfg.terrain) dwo::oct_step<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, h->mocap, w->a1, w->step, w->wave);
+        else dwo::oct_step<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, h->mocap, w->a1, w->step, w->wave);
         break;
     }
 }
