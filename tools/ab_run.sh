@@ -1,3 +1,7 @@
+#!/bin/bash
+# A/B timing of library variants on ONE GPU box: tools/pipe_time.py (octet pipeline, 4096 and 16384 envs, three rounds each) once per
+# library named on the command line (files under isaacgymdyros_amd/_ab/; list the baseline first AND last to see the box's drift).
+# usage (GPU box): bash tools/ab_run.sh base.so variant.so base.so
 mkdir -p gpurun_out
 for lib in "$@"; do
   echo "== $lib"
