@@ -5,16 +5,18 @@
 #include "dw_params.h"
 
 namespace dwq { struct QuadModel; }
+namespace dwl { struct LaneModel; }
 
 struct DwHandle {
     DwConfig        cfg;
     dw::TaskParams  params;
     dw::DevModel   *d_model;
     dwq::QuadModel *d_qmodel;
+    dwl::LaneModel *d_lmodel;
     dw::DevParams  *d_params;
-    int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env); one launch per step in all three
+    int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env), 4 lane (one lane per env, one wave per limb); one launch per step in all
     float          *d_mocap;
-    float          *d_sc_park;      // octet kernels: PhysParams::sc_park
+    float          *d_sc_park;      // octet / lane kernels: PhysParams::sc_park
     DwBuffers       buf;
     int             bound;
     int             has_task;

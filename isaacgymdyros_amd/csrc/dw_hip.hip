@@ -71,6 +71,19 @@ int  oct_lds_bytes();
 int  sc_park_words();
 }  // namespace dwo
 
+// The lane kernels (DwConfig.pipeline = 4): dw_lane_kernels.hip.
+namespace dwl {
+struct LaneModel;
+void launch_step(bool terrain, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
+void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
+                     const DwBuffers &B, const float *tau, const float *push);
+int  build_lanemodel_host(const dw::DevModel *hm, LaneModel **out, const char **err);      // malloc'ed
+size_t lanemodel_bytes();
+int  lane_lds_bytes();
+size_t sc_park_floats(int num_envs);
+}  // namespace dwl
+
 __global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
                                                     const float *tau, const float *push) {
     __shared__ dw::Lds S;
@@ -132,9 +145,14 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     const char *err = "";
     int rc = dw::build_devmodel(model, task, hm, &err);
     if (rc) { free(hm); free(h); return fail(rc, err); }
-    h->pipeline = cfg->pipeline == 0 ? 3 : cfg->pipeline;
+    h->pipeline = cfg->pipeline == 0 ? DW_DEFAULT_PIPELINE : cfg->pipeline;
     dwq::QuadModel *hq = nullptr;
-    if (h->pipeline >= 2) {
+    dwl::LaneModel *hl = nullptr;
+    if (h->pipeline == 4) {
+        rc = dwl::build_lanemodel_host(hm, &hl, &err);
+        if (rc) { free(hm); free(h); return fail(rc, err); }
+    }
+    if (h->pipeline == 2 || h->pipeline == 3) {
         rc = dwq::build_quadmodel_host(hm, model, &hq, &err, h->pipeline == 3);
         if (rc) { free(hm); free(h); return fail(rc, err); }
     }
@@ -147,7 +165,19 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
         if (e == hipSuccess) e = hipMemcpy(h->d_qmodel, hq, dwq::quadmodel_bytes(), hipMemcpyHostToDevice);
     }
     free(hq);
+    if (e == hipSuccess && hl) {
+        e = hipMalloc((void **)&h->d_lmodel, dwl::lanemodel_bytes());
+        if (e == hipSuccess) e = hipMemcpy(h->d_lmodel, hl, dwl::lanemodel_bytes(), hipMemcpyHostToDevice);
+    }
+    free(hl);
     if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
+    if (h->pipeline == 4) {
+        const size_t bytes = dwl::sc_park_floats(cfg->num_envs) * sizeof(float);
+        e = hipMalloc((void **)&h->d_sc_park, bytes);
+        if (e == hipSuccess) e = hipMemset(h->d_sc_park, 0, bytes);
+        if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: self-collision park buffer", e); }
+        h->params.phys.sc_park = h->d_sc_park;
+    }
     if (h->pipeline == 3) {
         const size_t waves = (size_t)(cfg->num_envs + 15) / 16 * 2;
         e = hipMalloc((void **)&h->d_sc_park, waves * 64 * dwo::sc_park_words() * sizeof(float));
@@ -175,6 +205,7 @@ int dw_destroy(DwHandle *h) {
     DeviceGuard guard(h->device);
     if (h->d_model) (void)hipFree(h->d_model);
     if (h->d_qmodel) (void)hipFree(h->d_qmodel);
+    if (h->d_lmodel) (void)hipFree(h->d_lmodel);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_mocap) (void)hipFree(h->d_mocap);
     if (h->d_sc_park) (void)hipFree(h->d_sc_park);
@@ -203,7 +234,9 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
     DeviceGuard guard(h->device);
-    if (h->pipeline == 3) {
+    if (h->pipeline == 4) {
+        dwl::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
+    } else if (h->pipeline == 3) {
         dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
     } else if (h->pipeline == 2) {
         dwq::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
@@ -227,12 +260,15 @@ static int launch_step(DwHandle *h, const float *actions, const float *noise, lo
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
-    if (obs_out && h->pipeline != 2 && h->pipeline != 3) return fail(DW_EINVAL, "dw_step_obs: an observation destination per call needs pipeline 2 or 3");
+    if (obs_out && h->pipeline < 2) return fail(DW_EINVAL, "dw_step_obs: an observation destination per call needs pipeline 2, 3 or 4");
     DeviceGuard guard(h->device);
     // (the quad / octet kernels take DwBuffers by value: this launch's copy may name another observation buffer)
     DwBuffers bufs = h->buf;
     if (obs_out) bufs.obs_buf = obs_out;
-    if (h->pipeline == 3) {
+    if (h->pipeline == 4) {
+        dwl::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, bufs, h->d_mocap,
+                         actions, noise, step_index, step_dev);
+    } else if (h->pipeline == 3) {
         dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
     } else if (h->pipeline == 2) {
@@ -291,5 +327,6 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
 int dw_lds_bytes(void) { return (int)sizeof(dw::Lds); }
 int dw_quad_lds_bytes(void) { return dwq::quad_lds_bytes(); }
 int dw_oct_lds_bytes(void) { return dwo::oct_lds_bytes(); }
+int dw_lane_lds_bytes(void) { return dwl::lane_lds_bytes(); }
 
 }  // extern "C"

@@ -1,0 +1,677 @@
+// dw_lane_post.h -- post_physics_step of DyrosDynamicWalk for the 64 envs of a lane workgroup (dw_lane.h), run at the end of
+// the fused step kernel (dw_lane_kernels.h) when the physics is done and the workgroup's 132 KB of body slots are free.  The
+// same fp32 expressions in the same order as dw_oct_post.h / dw_task.h regions Q1..Q6 and reset_region (fp contraction off),
+// so the reference goldens hold bit for bit; the mapping: per-env scalar work with lane = env on one of the four waves (one
+// group of reward terms each), per-word work over ITEMS (env, index) = thread + 256 k.
+// Reference: tasks/dyros_dynamic_walk.py:543-563 (post_physics_step), :581-596 (check_termination), :802-947 (reward),
+// :598-669,720-748 (reset_idx), :750-796 (observations); vec_task.py:519-733 (dof-property randomisation).
+#pragma once
+
+#include "dw_lane.h"
+#include "dw_task.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace dwl {
+
+using dw::TaskParams;
+
+// flat LDS layout of the post phase (float words over the whole LLds)
+constexpr int PL_ES_STRIDE = DW_ES_WORDS;                // = the global layout: the 64 records move as one 95 KB run of 16-byte pieces
+constexpr int PL_ES = 0;                                 // [64][372] task records
+constexpr int PL_Q = EPW * DW_ES_WORDS;                  // [64][33][2] joint state
+constexpr int PL_ROOT = PL_Q + EPW * ND * 2;             // [64][13]
+constexpr int PL_NORMED = PL_ROOT + EPW * 13;            // [64][37] normalised observation of this step
+constexpr int PL_PS = PL_NORMED + EPW * DW_NUM_OBS1;     // [64][32] per-env scratch
+constexpr int PL_OBN = PL_PS + EPW * 32;                 // [2][37] observation mean, divisor
+constexpr int PL_RC = PL_OBN + 2 * DW_NUM_OBS1 + 2;      // [33][2] per-joint constants of the reset: initial angle, the same clamped to the joint range
+constexpr int PL_END = PL_RC + 2 * ND;
+static_assert((PL_Q * 4) % 16 == 0, "post layout: the record block must end on a 16-byte boundary");
+static_assert(PL_END * 4 <= (int)sizeof(LLds), "post layout does not fit the workgroup's LDS");
+// per-env scratch words
+constexpr int PS_RTERM = 0;      // [16] reward terms, [14] = |orientation error|
+constexpr int PS_BAD = 16, PS_COLL = 17, PS_RESET = 18, PS_PROGRESS = 19, PS_RANDOMIZE = 20, PS_MASS = 21;
+constexpr int PS_FOOT = 22;      // [2][3] net contact force on the two sole bodies
+constexpr int PS_ORG = 28;       // [3] new tile origin (terrain curriculum)
+
+#define PQ_ES(el, off) LF[PL_ES + (el) * PL_ES_STRIDE + (off)]
+#define PQ_ESI(el, off) (*reinterpret_cast<int *>(&LF[PL_ES + (el) * PL_ES_STRIDE + (off)]))
+#define PQ_Q(el, d) LF[PL_Q + ((el) * ND + (d)) * 2]
+#define PQ_QD(el, d) LF[PL_Q + ((el) * ND + (d)) * 2 + 1]
+#define PQ_ROOT(el, i) LF[PL_ROOT + (el) * 13 + (i)]
+#define PQ_NORMED(el, k) LF[PL_NORMED + (el) * DW_NUM_OBS1 + (k)]
+#define PQ_PS(el, w_) LF[PL_PS + (el) * 32 + (w_)]
+#define PQ_PSI(el, w_) (*reinterpret_cast<int *>(&LF[PL_PS + (el) * 32 + (w_)]))
+
+// Rows of NW consecutive floats at any 4-byte alignment, moved in 16-byte pieces (global_load/store_dwordx4 take dword-aligned
+// addresses): a 37-word history row is 10 requests instead of 37.
+struct __attribute__((packed, aligned(4))) U4 { float x, y, z, w; };
+template <int NW> DQ_HD void ld_row(const float *p, float (&v)[NW]) {
+    DQ_UNROLL for (int i = 0; i + 4 <= NW; i += 4) { const U4 t = *reinterpret_cast<const U4 *>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+    DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) v[i] = p[i];
+}
+template <int NW> DQ_HD void st_row(float *p, const float (&v)[NW]) {
+    DQ_UNROLL for (int i = 0; i + 4 <= NW; i += 4) { U4 t; t.x = v[i]; t.y = v[i + 1]; t.z = v[i + 2]; t.w = v[i + 3]; *reinterpret_cast<U4 *>(p + i) = t; }
+    DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) p[i] = v[i];
+}
+
+// torch.norm of 3 elements on the CPU reference (dw_task.h norm_t with n = 3: fused scalar tail)
+DQ_HD float norm3_t(float x, float y, float z) {
+    float b0 = fmaf(x, x, 0.0f);
+    b0 = fmaf(y, y, b0);
+    b0 = fmaf(z, z, b0);
+    return sqrtf(b0);
+}
+
+// Inputs from the physics part of the kernel: KP = the new joint state and the encoder angle / rate after the second substep of
+// the joints my wave owns (lane = env), X.root, X.coll / X.footT (collision flag of my wave's bodies, net force on
+// my sole body).  With physics frozen (tests) the state and the contact forces are the Gym tensors as they are.
+template <bool TERRAIN>
+DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const TaskParams &C, const OBuf &B, const float *actions,
+                          const float *noise, long long step, int group, LState &X, const LaneKeep &KP, unsigned long long dl_t0 = 0) {
+    float *LF = reinterpret_cast<float *>(&L);
+    int t = tid();
+    DQ_OPAQUE(t);
+    const int w = X.w, el = t & 63;             // per-env scalar groups: wave w, env el
+    const int eg_ = group * EPW + el;
+    const bool xvalid = eg_ < C.num_envs;
+    const int e = xvalid ? eg_ : C.num_envs - 1;
+    const int N = C.num_envs;
+    dw::TaskBuffers TB;
+    TB.b = B.all; TB.actions = actions; TB.noise = noise; TB.mocap = nullptr; TB.step = step;
+    const dw::StepCtx K = dw::make_step_ctx(C, TB, e);        // (nz of MY env; items build their own)
+    const float period = K.period;
+    const double cdt_d = K.cdt_d;
+    const int LFG = M.left_foot_gym, RFG = M.right_foot_gym;
+
+    // (the VecTask counters and the clock action of Q1, requested together with the records: one memory latency for all)
+    long long q1_progress = 0, q1_randomize = 0;
+    float q1_mass = 0.0f, q1_clock = 0.0f, c_org0 = 0.0f, c_org1 = 0.0f, c_org2 = 0.0f;
+    if (w == 0) {
+        q1_progress = OQ_COLD(progress_buf)[e]; q1_randomize = OQ_COLD(randomize_buf)[e];
+        q1_mass = OQ_COLD(total_mass)[e]; q1_clock = dw::clamp_action(actions, e, 12);
+        c_org0 = OQ_COLD(env_origins)[3 * e]; c_org1 = OQ_COLD(env_origins)[3 * e + 1]; c_org2 = OQ_COLD(env_origins)[3 * e + 2];
+    }
+    float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
+    DL_STAMP2(15);
+    wg_barrier_global();          // the slots are dead from here; the pre-physics phase wrote fields of the records that are staged below
+    // ---- stage: joint state, base state, contact summary, the 64 task records ----
+    const LCtl &CT = LM.ctl[w];
+    const unsigned own0 = CT.own_b[0], own1 = CT.own_b[1], own2 = CT.own_b[2];
+    const int n_own = CT.n_own;
+    auto own_body = [&](int j) { return (int)(((j < 4 ? own0 : (j < 8 ? own1 : own2)) >> (8 * (j & 3))) & 255u); };
+    DQ_UNROLL for (int j = 0; j < MAXOWN; ++j)
+        if (j < n_own) { const int d = own_body(j) - 1; PQ_Q(el, d) = KP.q[j]; PQ_QD(el, d) = KP.qd[j]; }
+    if (w == 0) {
+        DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = X.root[i];
+        PQ_PSI(el, PS_BAD) = 0; PQ_PSI(el, PS_COLL) = 0; PQ_PSI(el, PS_RESET) = 0;
+        PQ_PS(el, PS_ORG) = c_org0; PQ_PS(el, PS_ORG + 1) = c_org1; PQ_PS(el, PS_ORG + 2) = c_org2;
+    }
+    {
+        // 64 records = 5952 pieces of 16 bytes, contiguous in HBM and in LDS
+        static_assert((EPW * DW_ES_WORDS) % 4 == 0 && (DW_ES_WORDS * 4) % 16 == 0, "record block must be a whole number of 16-byte pieces");
+        constexpr int NP = EPW * DW_ES_WORDS / 4, PER = (NP + NT - 1) / NT;
+        const int nvalid = N - group * EPW;                          // envs of this workgroup that exist (>= 1)
+        const int np_ok = (nvalid >= EPW ? EPW : nvalid) * (DW_ES_WORDS / 4);
+        const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)group * EPW * DW_ES_WORDS);
+        F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
+        constexpr int GRP = 8;
+        DL_ROLLED for (int g8 = 0; g8 < PER; g8 += GRP) {
+            float tx[GRP], ty[GRP], tz[GRP], tw[GRP];
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) {
+                const int pi = t + NT * (g8 + u);
+                // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
+                const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
+                const F4 v = src[pi < NP ? ps : 0];
+                tx[u] = v.x; ty[u] = v.y; tz[u] = v.z; tw[u] = v.w;
+            }
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) { const int pi = t + NT * (g8 + u); if (pi < NP) dst[pi] = mk4(tx[u], ty[u], tz[u], tw[u]); }
+        }
+    }
+    DL_STAMP2(16);
+    if (t < DW_NUM_OBS1) { OBN[t] = M.obs_mean[t]; OBN[DW_NUM_OBS1 + t] = M.obs_inv_std_den[t]; }
+    if (t >= 64 && t < 64 + ND) { const int l = t - 64; const float qi = M.q_init[l]; LF[PL_RC + 2 * l] = qi; LF[PL_RC + 2 * l + 1] = fmaxf(fminf(qi, M.qhi[l]), M.qlo[l]); }
+    wg_barrier();
+    DL_STAMP2(17);
+    // ---- the record fields the substeps produced (dw_task.h P3), from the waves that hold them ----
+    DQ_UNROLL for (int j = 0; j < MAXOWN; ++j) {
+        if (j < n_own) {
+            const int d = own_body(j) - 1;
+            PQ_ES(el, DW_ES_QPOS_NOISE + d) = KP.qn[j];
+            PQ_ES(el, DW_ES_QPOS_PRE + d) = KP.qn[j];
+            PQ_ES(el, DW_ES_QVEL_NOISE + d) = KP.qv[j];
+            if (d < 12) {
+                // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
+                const float at = PQ_ES(el, DW_ES_ACTION_TORQUE + d);
+                float col[DW_ALOG_SLOTS];
+                DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(el, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;
+                DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) PQ_ES(el, DW_ES_ACTION_LOG + 12 * s2 + d) = col[s2];
+            }
+        }
+    }
+    if (w < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * w + i) = X.warm[i]; }      // warm-start impulses of my sole
+    if (C.freeze_physics) {
+        // debug mode: simulate() was the identity, so the net contact forces are an input (dw_task.h step_env)
+        if (w == 0) {
+            const float *cf = B.contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { PQ_PS(el, PS_FOOT + i) = cf[3 * LFG + i]; PQ_PS(el, PS_FOOT + 3 + i) = cf[3 * RFG + i]; }
+        }
+        wg_barrier();
+        for (int i = t; i < EPW * DW_NUM_BODIES; i += NT) {
+            const int ee = i / DW_NUM_BODIES, g = i - DW_NUM_BODIES * ee;
+            const int eg = group * EPW + ee < N ? group * EPW + ee : N - 1;
+            const float *cf = B.contact_forces + ((size_t)DW_NUM_BODIES * eg + g) * 3;
+            if (g != LFG && g != RFG && norm3_t(cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
+        }
+    } else {
+        wg_barrier();
+        if (X.coll) PQ_PSI(el, PS_COLL) = 1;
+        if (w < 2) { DQ_UNROLL for (int i = 0; i < 3; ++i) PQ_PS(el, PS_FOOT + 3 * w + i) = X.footT[i]; }
+    }
+    wg_barrier();
+
+    DL_STAMP2(18);
+    // ---- Q1: clocks, VecTask counters, non-finite guard ----
+    if (w == 0) {
+        const long long p = q1_progress, rbl = q1_randomize;
+        int rb = (int)(rbl > 0x7ffffffe ? 0x7ffffffe : rbl);
+        PQ_PS(el, PS_MASS) = q1_mass;
+        PQ_ES(el, DW_ES_EPI_LEN) += 1.0f;
+        float time = PQ_ES(el, DW_ES_TIME);
+        time = time + C.dt_policy_f;
+        time = time + C.clock_gain_f * q1_clock;
+        PQ_ES(el, DW_ES_TIME) = time;
+        if (xvalid) {
+            OQ_COLD(timeout_buf)[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
+            OQ_COLD(progress_buf)[e] = p + 1;
+        }
+        PQ_PSI(el, PS_PROGRESS) = (int)(p + 1);
+        rb = rb + 1;
+        if (xvalid) OQ_COLD(randomize_buf)[e] = rb;
+        PQ_PSI(el, PS_RANDOMIZE) = rb;
+        bool bad = false;
+        DQ_UNROLL for (int i = 0; i < 13; ++i) bad = bad || !dw::finitef(PQ_ROOT(el, i));
+        if (bad) PQ_PSI(el, PS_BAD) = 1;
+    }
+    DQ_UNROLL for (int k = 0; k < LNI; ++k) {
+        const int i = t + NT * k;
+        if (i < EPW * ND && (!dw::finitef(LF[PL_Q + 2 * i]) || !dw::finitef(LF[PL_Q + 2 * i + 1]))) PQ_PSI(i / ND, PS_BAD) = 1;
+    }
+    wg_barrier();
+    {
+        // (workgroup-uniform: every thread looks at all 64 flags)
+        int anybad = 0;
+        for (int i = 0; i < EPW; ++i) anybad |= PQ_PSI(i, PS_BAD);
+        if (anybad) {
+            wg_barrier();
+            if (w == 0 && PQ_PSI(el, PS_BAD)) {
+                DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = (i == 2) ? C.initial_height : (i == 6 ? 1.0f : 0.0f);
+                PQ_ESI(el, DW_ES_NAN_RESETS) += 1;
+                PQ_PSI(el, PS_COLL) = 0;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) PQ_PS(el, PS_FOOT + i) = 0.0f;
+            }
+            DQ_UNROLL for (int k = 0; k < LNI; ++k) {
+                const int i = t + NT * k;
+                if (i < EPW * ND && PQ_PSI(i / ND, PS_BAD)) { LF[PL_Q + 2 * i] = 0.0f; LF[PL_Q + 2 * i + 1] = 0.0f; }
+            }
+            for (int i = t; i < EPW * DW_NUM_BODIES * 3; i += NT) {
+                const int ee = i / (DW_NUM_BODIES * 3), w3 = i - DW_NUM_BODIES * 3 * ee, eg = group * EPW + ee;
+                if (eg < N && PQ_PSI(ee, PS_BAD)) B.contact_forces[(size_t)DW_NUM_BODIES * 3 * eg + w3] = 0.0f;
+            }
+            wg_barrier();
+        }
+    }
+
+    DL_STAMP2(19);
+    // ---- Q2: reward terms, one group per wave ----
+    {
+        // the three 33-element norms in torch's CPU order: 8 fused accumulators over elements a, a+8, a+16, a+24, added in
+        // order, then the 33rd element fused (dw_task.h Q2 / Q2b)
+        auto norm33 = [&](int which) {
+            float acc[8];
+            DQ_UNROLL for (int a = 0; a < 8; ++a) {
+                float s = 0.0f;
+                DQ_UNROLL for (int d0 = 0; d0 < 32; d0 += 8) {
+                    const int jj = d0 + a;
+                    const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
+                                  : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
+                    s = fmaf(x, x, s);
+                }
+                acc[a] = s;
+            }
+            float b0 = acc[0];
+            DQ_UNROLL for (int a = 1; a < 8; ++a) b0 = b0 + acc[a];
+            const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + 32) - PQ_Q(el, 32)
+                          : (which == 1 ? 0.0f - PQ_QD(el, 32) : PQ_QD(el, 32) - PQ_ES(el, DW_ES_PRE_QVEL + 32));
+            b0 = fmaf(x, x, b0);
+            const float n = sqrtf(b0);
+            const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
+            return coef * expf(rate * (n * n));
+        };
+        if (w == 0) {
+            const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
+            const float aerr = fabsf(dw::quat_err(qq));
+            PQ_PS(el, PS_RTERM + 14) = aerr;
+            PQ_PS(el, PS_RTERM + 0) = 0.3f * expf(-13.2f * aerr);
+            const float dv[2] = {PQ_ES(el, DW_ES_TARGET_VEL) - PQ_ROOT(el, 7), PQ_ES(el, DW_ES_TARGET_VEL + 1) - PQ_ROOT(el, 8)};
+            const float n = dw::norm_t(dv, 2);
+            PQ_PS(el, PS_RTERM + 6) = 0.3f * expf(-3.0f * (n * n));
+        }
+        if (w == 1) {
+            PQ_PS(el, PS_RTERM + 1) = norm33(0);
+            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_fn([&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }, 12));
+        }
+        if (w == 2) {
+            PQ_PS(el, PS_RTERM + 2) = norm33(1);
+            PQ_PS(el, PS_RTERM + 7) = norm33(2);
+        }
+        if (w == 3) {
+            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_fn([&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }, 12));
+            const float lf[3] = {PQ_PS(el, PS_FOOT), PQ_PS(el, PS_FOOT + 1), PQ_PS(el, PS_FOOT + 2)};
+            const float rf[3] = {PQ_PS(el, PS_FOOT + 3), PQ_PS(el, PS_FOOT + 4), PQ_PS(el, PS_FOOT + 5)};
+            const float lfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 1), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 2)};
+            const float rfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 3), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 4), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 5)};
+            float dl[3], dr[3];
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
+            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_t(dl, 3) + dw::norm_t(dr, 3)));
+            const bool lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
+            const int idx = PQ_ESI(el, DW_ES_MOCAP_IDX);
+            const bool DSP = (3300 <= idx && idx < 3600) || (idx < 300) || (1500 <= idx && idx < 2100);
+            const bool RSSP = 300 <= idx && idx < 1500;
+            const bool LSSP = 2100 <= idx && idx < 3300;
+            float fcr = 0.0f;
+            if (DSP && rcon && lcon) fcr = 0.2f;
+            if (RSSP && rcon && !lcon) fcr = 0.2f;
+            if (LSSP && !rcon && lcon) fcr = 0.2f;
+            PQ_PS(el, PS_RTERM + 8) = fcr;
+            PQ_ES(el, DW_ES_CRS) = PQ_ES(el, DW_ES_CRS) + fcr;
+            PQ_PS(el, PS_RTERM + 10) = 0.0f;
+            const float tm = PQ_PS(el, PS_MASS);
+            const float thr = (float)(1.4 * 9.81) * tm;
+            const bool th = (lf[2] > thr) || (rf[2] > thr);
+            PQ_PS(el, PS_RTERM + 11) = th ? -0.2f * 1.0f : 0.0f;
+            const float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
+            const float pen = 0.1f * expf(-0.007f * (dw::norm_t(&cl, 1) + dw::norm_t(&cr, 1)));
+            PQ_PS(el, PS_RTERM + 3) = th ? pen : 0.1f * 1.0f;
+            const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
+            const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
+            PQ_PS(el, PS_RTERM + 12) = dd ? -0.05f * 1.0f : 0.0f;
+            const float ws = dw::divs(C.gpu_div, tm, 104.48);
+            const float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * PQ_ES(el, DW_ES_TARGET_FORCE)));
+            const float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * PQ_ES(el, DW_ES_TARGET_FORCE + 1)));
+            PQ_PS(el, PS_RTERM + 13) = tl + tr;
+        }
+    }
+    wg_barrier();
+
+    DL_STAMP2(20);
+    // ---- Q3: total reward, termination ----
+    {
+        const bool collision = PQ_PSI(el, PS_COLL) != 0;
+        const float aerr = PQ_PS(el, PS_RTERM + 14);
+        // stacked_rewards: 15 words per env, the four waves write them (wave w takes 4 w .. 4 w + 3)
+        if (xvalid) {
+            DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                const int l = 4 * w + i;
+                if (l < 14) OQ_COLD(stacked_rewards)[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
+                if (l == 14) OQ_COLD(stacked_rewards)[(size_t)DW_NUM_REW * e + 14] = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
+            }
+        }
+        if (w == 0) {
+            const float *r = &PQ_PS(el, PS_RTERM);
+            float total = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + r[10] + r[11] + r[12] + r[13];
+            if (collision) total = 1.0f * C.death_cost;
+            if (aerr > 0.5f) total = 1.0f * C.death_cost;
+            int reset = aerr > 0.5f ? 1 : 0;
+            if ((float)PQ_PSI(el, PS_PROGRESS) >= C.max_episode_length - 1.0f) reset = 1;
+            if (collision) reset = 1;
+            if (PQ_PSI(el, PS_BAD)) reset = 1;
+            if (xvalid) { OQ_COLD(rew_buf)[e] = total; OQ_COLD(reset_buf)[e] = reset; }
+            PQ_PSI(el, PS_RESET) = reset;
+            float ret = PQ_ES(el, DW_ES_EPI_RETURN) + total;
+            if (reset) {
+                PQ_ES(el, DW_ES_LAST_RETURN) = ret;
+                PQ_ESI(el, DW_ES_EPISODES) += 1;
+                ret = 0.0f;
+            }
+            PQ_ES(el, DW_ES_EPI_RETURN) = ret;
+        }
+    }
+    wg_barrier();
+
+    DL_STAMP2(21);
+    // ---- reset_idx for the envs that ended (dw_task.h reset_region) ----
+    int any_reset = 0;
+    for (int i = 0; i < EPW; ++i) any_reset |= PQ_PSI(i, PS_RESET);          // (workgroup-uniform)
+    if (any_reset) {
+        if (C.terrain_curriculum && w == 0 && PQ_PSI(el, PS_RESET)) {
+            const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
+            const float distance = dw::norm_t(d, 2);
+            const bool move_up = distance > C.terrain_half_length;
+            const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
+            const float need = dw::norm_t(tv, 2) * C.max_episode_length_s * 0.5f;
+            const bool move_down = (distance < need) && !move_up;
+            long long lvl = OQ_COLD(terrain_levels)[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
+            if (lvl >= C.terrain_num_levels) {
+                int k = (int)(dw::noise_word(K.nz, DW_NZ_TERRAIN_LVL) * (float)C.terrain_num_levels);
+                if (k > C.terrain_num_levels - 1) k = C.terrain_num_levels - 1;
+                lvl = k;
+            } else if (lvl < 0) lvl = 0;
+            long long ty = OQ_COLD(terrain_types)[e];
+            ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
+            const float DW_GPTR *org = OQ_COLD(terrain_origins) + ((size_t)lvl * C.terrain_num_types + ty) * 3;
+            DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (xvalid) OQ_COLD(env_origins)[3 * e + i] = o; }
+            if (xvalid) OQ_COLD(terrain_levels)[e] = lvl;
+        }
+        wg_barrier();
+        // Items (env, j), j = 0..7: thread i of pass p works for env (i + 256 p) / 8 with octet index j -- an env's 32 uniform
+        // words DW_NZ_QPOS_BIAS .. DW_NZ_PTIMING are eight generator blocks, one per j, each word transformed and stored by the
+        // thread that drew it (the layout of the reset in dw_oct_post.h, which shares the draws' definition).
+        static_assert(DW_NZ_QPOS_BIAS % 4 == 0 && DW_NZ_PTIMING < DW_NZ_QPOS_BIAS + 32, "reset words: eight blocks per env");
+        constexpr int DR_B0 = DW_NZ_DR_DAMP / 4, DR_NBLK = DW_NZ_DR_FRIC / 4 - DR_B0 + 1, DR_NPASS = (DR_NBLK + 7) / 8;
+        static_assert(DW_NZ_DR_ARM == DW_NZ_DR_DAMP + DW_NUM_DOF && DW_NZ_DR_FRIC == DW_NZ_DR_ARM + DW_NUM_DOF, "DR words are contiguous");
+        int *LI = reinterpret_cast<int *>(LF);
+        DL_ROLLED for (int pass = 0; pass < EPW * 8 / NT; ++pass) {
+            const int ii = t + NT * pass, re = ii >> 3, j = ii & 7;          // env within the workgroup, octet index
+            const int reg_ = group * EPW + re;
+            const bool rvalid = reg_ < N;
+            const int rg = rvalid ? reg_ : N - 1;
+            const bool mine = PQ_PSI(re, PS_RESET) != 0;
+            if (!wave_any(mine)) continue;
+            dw::NoiseSrc nz = K.nz;
+            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * rg : nullptr; nz.env = (unsigned int)rg;
+            const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(re, PS_RANDOMIZE) >= 1;
+            const int dummy = PL_PS + re * 32 + 31;
+            const int esb = PL_ES + re * PL_ES_STRIDE;
+            if (mine) {
+                float u[4];
+                dw::noise_block(nz, DW_NZ_QPOS_BIAS / 4 + j, u);
+                const bool gd = C.gpu_div != 0;
+                DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                    const int wd = DW_NZ_QPOS_BIAS + 4 * j + i;
+                    const bool isq = wd < DW_NZ_QUAT_BIAS, isb = !isq && wd < DW_NZ_TARGET_VEL, ist = wd == DW_NZ_TARGET_VEL;
+                    const bool ism = wd >= DW_NZ_MOTOR && wd < DW_NZ_DELAY;
+                    const float x = u[i] * (wd < DW_NZ_TARGET_VEL ? 6.28f : (ist ? 0.8f : 0.4f));
+                    // divs(gpu_div, x, 100.0 | 150.0) - (float)(3.14 / 100 | 150)
+                    const float dv = isq ? 100.0f : 150.0f, rv = isq ? (float)(1.0 / 100.0) : (float)(1.0 / 150.0);
+                    const float cv = isq ? (float)(3.14 / 100) : (float)(3.14 / 150);
+                    const float yd = (gd ? x * rv : x / dv) - cv;
+                    const float y = (isq || isb) ? yd : (ist ? x * 1.0f : x + 0.8f);
+                    int k4 = (int)(u[i] * 4.0f), kt = (int)(u[i] * 2000.0f);
+                    k4 = k4 > 3 ? 3 : k4; kt = kt > 1999 ? 1999 : kt;
+                    const int bits = wd == DW_NZ_INIT_MOCAP ? (u[i] > 0.5f ? 0 : 1800) : (wd == DW_NZ_DELAY ? 2 + k4 : (wd == DW_NZ_PTIMING ? kt : f2i(y)));
+                    const int dst = isq ? DW_ES_QPOS_BIAS + (wd - DW_NZ_QPOS_BIAS) : isb ? DW_ES_QUAT_BIAS + (wd - DW_NZ_QUAT_BIAS)
+                                  : ist ? DW_ES_TARGET_VEL : wd == DW_NZ_INIT_MOCAP ? DW_ES_INIT_MOCAP : ism ? DW_ES_MOTOR_SCALE + (wd - DW_NZ_MOTOR)
+                                  : wd == DW_NZ_DELAY ? DW_ES_DELAY_IDX : wd == DW_NZ_PTIMING ? DW_ES_PERT_TIMING : -1;
+                    LI[dst >= 0 ? esb + dst : dummy] = bits;
+                    if (i == DW_NZ_TARGET_VEL % 4) LF[ist ? esb + DW_ES_TARGET_VEL + 1 : dummy] = x * 0.0f;
+                }
+            }
+            if (wave_any(mine && do_dr)) {
+                // dof-property and friction randomisation (vec_task.py:519-733): the 67 uniform words DW_NZ_DR_DAMP .. DW_NZ_DR_FRIC
+                // are 18 generator blocks, three per j at most, and a word goes from the thread that drew it straight to its place
+                float u[DR_NPASS][4] = {};
+                const bool go = mine && do_dr;
+                if (go) { DQ_UNROLL for (int p2 = 0; p2 < DR_NPASS; ++p2) dw::noise_block(nz, DR_B0 + j + 8 * p2 < DR_B0 + DR_NBLK ? DR_B0 + j + 8 * p2 : DR_B0, u[p2]); }
+                const float d0 = C.dr_damp[0], d1 = C.dr_damp[1] - C.dr_damp[0], a0 = C.dr_arm[0], a1 = C.dr_arm[1] - C.dr_arm[0];
+                const float f0 = C.dr_fric[0], f1 = C.dr_fric[1] - C.dr_fric[0];
+                DQ_UNROLL for (int p2 = 0; p2 < DR_NPASS; ++p2) {
+                    DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                        const int wd = 4 * (DR_B0 + j + 8 * p2) + i;
+                        const bool isd = wd >= DW_NZ_DR_DAMP && wd < DW_NZ_DR_ARM, isa = wd >= DW_NZ_DR_ARM && wd < DW_NZ_DR_FRIC;
+                        const int l = isd ? wd - DW_NZ_DR_DAMP : (isa ? wd - DW_NZ_DR_ARM : 0);
+                        const float nom = (isa ? M.arm_nom : M.damp_nom)[l];
+                        const float sd = d0 + u[p2][i] * d1, sa = a0 + u[p2][i] * a1;
+                        if (go && rvalid && C.dr_dof && (isd || isa)) (isa ? B.dof_armature : B.dof_damping)[(size_t)ND * rg + l] = isa ? nom * sa : nom + sd;
+                        if (go && rvalid && C.dr_friction && wd == DW_NZ_DR_FRIC) OQ_COLD(friction_scale)[rg] = f0 + u[p2][i] * f1;
+                    }
+                }
+            }
+            if (mine) {
+                DQ_UNROLL for (int k = 0; k < 5; ++k) {
+                    const int l = j + 8 * k;
+                    const bool lv = l < ND;
+                    const int lc = lv ? l : 0;
+                    const float qi = LF[PL_RC + 2 * lc], qc = LF[PL_RC + 2 * lc + 1];
+                    LF[lv ? esb + DW_ES_QPOS_NOISE + l : dummy] = qi;
+                    LF[lv ? esb + DW_ES_QPOS_PRE + l : dummy] = qi;
+                    LF[lv ? esb + DW_ES_QVEL_NOISE + l : dummy] = 0.0f;
+                    LF[lv ? esb + DW_ES_PRE_QVEL + l : dummy] = 0.0f;
+                    LF[lv ? PL_Q + (re * ND + l) * 2 : dummy] = qc;
+                    LF[lv ? PL_Q + (re * ND + l) * 2 + 1 : dummy] = 0.0f;
+                    if (8 * k < 12) LF[l < 12 ? esb + DW_ES_ACTION_TORQUE_PRE + l : dummy] = 0.0f;
+                    if (8 * k < 24) LF[l < 24 ? esb + DW_ES_WARM + l : dummy] = 0.0f;
+                    if (8 * k < 6) { const int lf = l < 6 ? l : 0; const float ff = PQ_PS(re, PS_FOOT + lf); LF[l < 6 ? esb + DW_ES_FOOT_FORCE_PRE + l : dummy] = ff; }
+                    if (8 * k + 7 >= 16 && 8 * k < 29) {
+                        const bool rv = l >= 16 && l < 29;
+                        const int i2 = rv ? l - 16 : 0;
+                        float v = i2 == 2 ? C.initial_height : (i2 == 6 ? 1.0f : 0.0f);
+                        v += i2 < 3 ? PQ_PS(re, PS_ORG + (i2 < 3 ? i2 : 0)) : 0.0f;          // (the env's origin; the curriculum has put the new one there)
+                        if (8 * k <= 16 && 8 * k + 7 >= 16 && C.custom_origins) {
+                            const float jit = 2.0f * dw::noise_word(nz, DW_NZ_ROOT_JITTER + (i2 < 2 ? i2 : 0)) + (-1.0f);
+                            if (rv && i2 < 2) v += jit;
+                        }
+                        LF[rv ? PL_ROOT + re * 13 + i2 : dummy] = v;
+                    }
+                }
+                // torque FIFO and action ring, zeroed
+                static_assert((DW_HIST_SLOTS * DW_NUM_ACT) % 4 == 0, "action ring of an env: whole 16-byte pieces");
+                constexpr int NAL = DW_ALOG_SLOTS * 12, NAH = DW_HIST_SLOTS * DW_NUM_ACT / 4;
+                DQ_UNROLL for (int i = 0; i < (NAL + 7) / 8; ++i) { if (j + 8 * i < NAL) PQ_ES(re, DW_ES_ACTION_LOG + j + 8 * i) = 0.0f; }
+                if (rvalid) {
+                    F4 *ah = reinterpret_cast<F4 *>(B.action_history + (size_t)rg * DW_HIST_SLOTS * DW_NUM_ACT);
+                    DQ_UNROLL for (int i = 0; i < (NAH + 7) / 8; ++i) { if (j + 8 * i < NAH) ah[j + 8 * i] = mk4(0.0f, 0.0f, 0.0f, 0.0f); }
+                }
+                // per-env scalars (dw_task.h reset_region, lane 40)
+                if (j == 0) {
+                    if (do_dr && rvalid) OQ_COLD(randomize_buf)[rg] = 0;
+                    PQ_ES(re, DW_ES_TIME) = 0.0f;
+                    if (rvalid) { OQ_COLD(progress_buf)[rg] = 0; OQ_COLD(reset_buf)[rg] = 1; }
+                    PQ_ES(re, DW_ES_CRM) = PQ_ES(re, DW_ES_CRS) / PQ_ES(re, DW_ES_EPI_LEN);
+                    PQ_ES(re, DW_ES_CRS) = 0.0f;
+                    PQ_ESI(re, DW_ES_SIMUL_LEN) = 0;
+                    PQ_ES(re, DW_ES_EPI_LEN_LOG) = PQ_ES(re, DW_ES_EPI_LEN);
+                    PQ_ES(re, DW_ES_EPI_LEN) = 0.0f;
+                    PQ_ESI(re, DW_ES_PERT_COUNT) = 0;
+                    PQ_ESI(re, DW_ES_PERT_ON) = 0;
+                }
+            }
+        }
+        wg_barrier_global();
+    }
+
+    DL_STAMP2(22);
+    // ---- Q5, first half: request the history taps now, use them after Q4.  A thread takes ROWS (env, tap): 37 observation
+    //      words and 13 action words, consecutive in the rings and in obs_buf.  The newest observation tap is this step's own
+    //      (Q4, still in LDS) and is not read back. ----
+    constexpr int NTAP = DW_NUM_HIS - 1, NPAIR = EPW * NTAP, RPL = (NPAIR + NT - 1) / NT;
+    static_assert((DW_NUM_SKIP * DW_NUM_HIS) % DW_HIST_SLOTS == 0, "the last observation tap must be the newest slot");
+    float tapo[RPL][DW_NUM_OBS1], tapa[RPL][DW_NUM_ACT];
+    DQ_UNROLL for (int r = 0; r < RPL; ++r) {
+        const int p = t + NT * r, pc = p < NPAIR ? p : 0;
+        const int ee = pc / NTAP, tap = pc - NTAP * ee;
+        const int egr = group * EPW + ee, eg = egr < N ? egr : N - 1;
+        const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+        const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
+        ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, tapo[r]);
+        ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, tapa[r]);
+    }
+    DL_STAMP2(23);
+    // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
+    //      expensive functions (atan2, sincos, the noise draw) is executed by few wave passes ----
+    {
+        auto finish = [&](int ee, int l, float o) {
+            const int egr = group * EPW + ee;
+            const float nrm = (o - OBN[l]) / OBN[DW_NUM_OBS1 + l];
+            PQ_NORMED(ee, l) = nrm;
+            if (egr < N) {
+                float *oh = B.obs_history + (size_t)egr * DW_HIST_SLOTS * DW_NUM_OBS1;
+                if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {
+                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2) oh[s2 * DW_NUM_OBS1 + l] = nrm;
+                } else {
+                    oh[PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l] = nrm;
+                }
+            }
+        };
+        // joint angles / rates of the legs with their biases, target velocity: 26 plain entries per env
+        for (int i = t; i < EPW * 26; i += NT) {
+            const int ee = i / 26, tt = i - 26 * ee;
+            const int l = tt < 24 ? 3 + tt : 29 + (tt - 24);
+            float o;
+            if (l < 15) o = PQ_ES(ee, DW_ES_QPOS_NOISE + (l - 3)) + PQ_ES(ee, DW_ES_QPOS_BIAS + (l - 3));
+            else if (l < 27) o = PQ_ES(ee, DW_ES_QVEL_NOISE + (l - 15));
+            else o = PQ_ES(ee, DW_ES_TARGET_VEL + (l - 29));
+            finish(ee, l, o);
+        }
+        // Euler angles of the base (quat2euler / mat2euler, python/isaacgym/torch_utils.py:227-273): 3 per env
+        if (t < EPW * 3) {
+            const int ee = t / 3, l = t - 3 * ee;
+            const float x = PQ_ROOT(ee, 3), y = PQ_ROOT(ee, 4), z = PQ_ROOT(ee, 5), wq = PQ_ROOT(ee, 6);
+            const float m00 = wq * wq + x * x - y * y - z * z;
+            const float m01 = 2 * x * y - 2 * wq * z;
+            const float m10 = 2 * x * y + 2 * wq * z;
+            const float m11 = wq * wq - x * x + y * y - z * z;
+            const float m20 = 2 * x * z - 2 * wq * y;
+            const float m21 = 2 * y * z + 2 * wq * x;
+            const float m22 = wq * wq - x * x - y * y + z * z;
+            const float cy = sqrtf(m00 * m00 + m10 * m10);
+            const bool cond = cy > (float)(2.220446049250313e-16 * 4);
+            const float num = l == 0 ? m21 : (l == 1 ? -m20 : (cond ? m10 : -m01));
+            const float den = l == 0 ? m22 : (l == 1 ? cy : (cond ? m00 : m11));
+            float o = atan2f(num, den);
+            if (l == 0 && !cond) o = 0.0f;
+            o = o + PQ_ES(ee, DW_ES_QUAT_BIAS + l);
+            finish(ee, l, o);
+        }
+        // gait phase as sin / cos: 2 per env
+        if (t < EPW * 2) {
+            const int ee = t >> 1, l = 27 + (t & 1);
+            const float time2idx = dw::divs(C.gpu_div, dw::remainder_t(PQ_ES(ee, DW_ES_TIME), period), cdt_d);
+            const float phase = dw::divs(C.gpu_div, dw::remainder_t((float)PQ_ESI(ee, DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
+            const float ang = (float)(2 * 3.14159265358979) * phase;
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            finish(ee, l, l == 27 ? sn : cs);
+        }
+        // base velocity with its noise draw: 6 per env
+        for (int i = t; i < EPW * 6; i += NT) {
+            const int ee = i / 6, l = 31 + (i - 6 * ee);
+            const int egr = group * EPW + ee, eg = egr < N ? egr : N - 1;
+            dw::NoiseSrc nz = K.nz;
+            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+            finish(ee, l, PQ_ROOT(ee, 7 + (l - 31)) + (dw::noise_word(nz, DW_NZ_VEL + (l - 31)) * 0.05f - 0.025f));
+        }
+    }
+    wg_barrier();
+
+    DL_STAMP2(24);
+    // ---- Q5, second half: the 487-d observation buffer.  Rows requested above go out as they came (an env that was just
+    //      reset shows its first observation in every tap and zeros in the action taps, tasks/dyros_dynamic_walk.py:655-669);
+    //      the newest tap is copied from LDS, items (env, word). ----
+    {
+        float *ob = B.obs_buf + (size_t)group * EPW * DW_NUM_OBS;
+        DQ_UNROLL for (int r = 0; r < RPL; ++r) {
+            const int p = t + NT * r, pc = p < NPAIR ? p : 0;
+            const int ee = pc / NTAP, tap = pc - NTAP * ee;
+            const bool ok = p < NPAIR && group * EPW + ee < N;
+            const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
+            if (wave_any(fill)) {
+                if (fill) { DQ_UNROLL for (int k = 0; k < DW_NUM_OBS1; ++k) tapo[r][k] = PQ_NORMED(ee, k); }
+            }
+            const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD);
+            const bool own = ((newest + 1) % DW_HIST_SLOTS + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS == newest;    // (never, with 2 x 10 slots)
+            if (wave_any(rs || own)) {
+                if (rs) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = 0.0f; }
+                else if (own) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = PQ_ES(ee, DW_ES_ACTIONS + k); }
+            }
+            if (ok) {
+                st_row(ob + ee * DW_NUM_OBS + tap * DW_NUM_OBS1, tapo[r]);
+                st_row(ob + ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + tap * DW_NUM_ACT, tapa[r]);
+            }
+        }
+        for (int i = t; i < EPW * DW_NUM_OBS1; i += NT) {
+            const int ee = i / DW_NUM_OBS1, k = i - DW_NUM_OBS1 * ee;
+            if (group * EPW + ee < N) ob[ee * DW_NUM_OBS + NTAP * DW_NUM_OBS1 + k] = PQ_NORMED(ee, k);
+        }
+    }
+
+    DL_STAMP2(25);
+    // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
+    DQ_UNROLL for (int k = 0; k < LNI; ++k) {
+        const int i = t + NT * k;
+        if (i < EPW * ND) {
+            const int ee = i / ND, l = i - ND * ee;
+            PQ_ES(ee, DW_ES_PRE_QVEL + l) = PQ_QD(ee, l);
+            if (l < 12) PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = PQ_ES(ee, DW_ES_ACTION_TORQUE + l);
+            if (l < DW_NUM_ACT) PQ_ES(ee, DW_ES_ACTIONS_PRE + l) = PQ_ES(ee, DW_ES_ACTIONS + l);
+            if (l >= 20 && l < 26) PQ_ES(ee, DW_ES_FOOT_FORCE_PRE + (l - 20)) = PQ_PS(ee, PS_FOOT + (l - 20));
+        }
+    }
+    wg_barrier();
+    if (w == 0) {
+        PQ_ESI(el, DW_ES_HIST_HEAD) = (PQ_ESI(el, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+        if (C.perturb && !C.force_perturb_start && xvalid) {
+            const float eln = PQ_ES(el, DW_ES_EPI_LEN_LOG), cm = PQ_ES(el, DW_ES_CRM);
+            const int bk = e % dw::GATE_BUCKETS;
+            long long de, dc = 0;
+            if (dw::finitef(eln) && dw::finitef(cm)) { de = (long long)eln; dc = (long long)llrintf(cm * 4294967296.0f); }
+            else de = -((long long)1 << 62);
+            long long DW_GPTR *gate = reinterpret_cast<long long DW_GPTR *>(OQ_COLD(gate_acc));
+            dwq::atomic_add_u64(reinterpret_cast<unsigned long long DW_GPTR *>(&gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2]), (unsigned long long)de);
+            dwq::atomic_add_u64(reinterpret_cast<unsigned long long DW_GPTR *>(&gate[(K.slot_cur * dw::GATE_BUCKETS + bk) * 2 + 1]), (unsigned long long)dc);
+            gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2] = 0;
+            gate[(K.slot_next * dw::GATE_BUCKETS + bk) * 2 + 1] = 0;
+        }
+    }
+    wg_barrier();
+
+    DL_STAMP2(26);
+    // ---- write back: the records (contiguous), and the Gym state of the envs whose state the task changed ----
+    {
+        constexpr int NP = EPW * DW_ES_WORDS / 4, PER = (NP + NT - 1) / NT;
+        const int nvalid = N - group * EPW;
+        const int np_ok = (nvalid >= EPW ? EPW : nvalid) * (DW_ES_WORDS / 4);
+        F4 *dstg = reinterpret_cast<F4 *>(B.env_state + (size_t)group * EPW * DW_ES_WORDS);
+        const F4 *srcl = reinterpret_cast<const F4 *>(LF + PL_ES);
+        DL_ROLLED for (int u = 0; u < PER; ++u) { const int pi = t + NT * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
+        if (!C.freeze_physics) {
+            // the Gym state of every env (the physics kept it on chip), as contiguous runs
+            const int nv = nvalid >= EPW ? EPW : nvalid;
+            stage_out(LF, PL_Q, B.dof_state + (size_t)group * EPW * ND * 2, ND * 2, nv);
+            stage_out(LF, PL_ROOT, B.root_states + (size_t)group * EPW * 13, 13, nv);
+        } else {
+            // (debug mode: only the envs whose state the task changed)
+            if (w == 0) {
+                const bool changed = PQ_PSI(el, PS_RESET) != 0 || PQ_PSI(el, PS_BAD) != 0;
+                if (changed && xvalid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
+            }
+            DQ_UNROLL for (int k = 0; k < LNI; ++k) {
+                const int i = t + NT * k;
+                if (i < EPW * ND) {
+                    const int ee = i / ND, eg = group * EPW + ee;
+                    if (eg < N && (PQ_PSI(ee, PS_RESET) || PQ_PSI(ee, PS_BAD))) {
+                        B.dof_state[((size_t)ND * group * EPW) * 2 + 2 * i] = LF[PL_Q + 2 * i];
+                        B.dof_state[((size_t)ND * group * EPW) * 2 + 2 * i + 1] = LF[PL_Q + 2 * i + 1];
+                    }
+                }
+            }
+        }
+    }
+}
+
+#undef PQ_ES
+#undef PQ_ESI
+#undef PQ_Q
+#undef PQ_QD
+#undef PQ_ROOT
+#undef PQ_NORMED
+#undef PQ_PS
+#undef PQ_PSI
+
+}  // namespace dwl
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

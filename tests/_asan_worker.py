@@ -7,8 +7,8 @@ import emul_backend, replay as R
 from isaacgymdyros_amd import abi
 from isaacgymdyros_amd.task_constants import load_task_constants
 KIND = sys.argv[1] if len(sys.argv) > 1 else ''
-QUAD = {'': False, 'quad': True, 'oct': 'oct'}[KIND]
-stem = {'': 'libdw_emul', 'quad': 'libdw_emul_quad', 'oct': 'libdw_emul_oct'}[KIND]
+QUAD = {'': False, 'quad': True, 'oct': 'oct', 'lane': 'lane'}[KIND]
+stem = {'': 'libdw_emul', 'quad': 'libdw_emul_quad', 'oct': 'libdw_emul_oct', 'lane': 'libdw_emul_lane'}[KIND]
 lib = C.CDLL(os.path.join(HERE, 'emul', '_build', stem + '_asan.so'))
 emul_backend._cache[stem + '.so'] = (lib, abi.declare(lib, 'dwe_'))
 tc = load_task_constants()

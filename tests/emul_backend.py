@@ -11,8 +11,8 @@ _cache = {}
 
 
 def load(asan=False, quad=False):
-    # quad: False = wave-per-env kernels, True = quad kernels, "oct" = octet kernels
-    name = {False: "libdw_emul", True: "libdw_emul_quad", "oct": "libdw_emul_oct"}[quad] + ("_asan.so" if asan else ".so")
+    # quad: False = wave-per-env kernels, True = quad kernels, "oct" = octet kernels, "lane" = lane kernels
+    name = {False: "libdw_emul", True: "libdw_emul_quad", "oct": "libdw_emul_oct", "lane": "libdw_emul_lane"}[quad] + ("_asan.so" if asan else ".so")
     if name not in _cache:
         subprocess.check_call(["make", "-C", HERE, "-s", "_build/" + name])
         lib = C.CDLL(os.path.join(HERE, "_build", name))

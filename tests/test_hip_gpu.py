@@ -9,7 +9,7 @@ from oracle import parity as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[3, 2, 1], ids=["oct", "quad", "wave-per-env"])
+@pytest.fixture(params=[4, 3, 2, 1], ids=["lane", "oct", "quad", "wave-per-env"])
 def pipeline(request):
     """The three kernel generations behind the same C-ABI (one launch per policy step each): 3 = octet kernels (8 lanes per
     env, two waves per SIMD), 2 = quad kernels (4 lanes per env), 1 = the wave-per-env kernels of round 1."""

@@ -10,7 +10,7 @@ from oracle import parity as P
 from oracle.oracle import OracleSim
 
 
-@pytest.fixture(params=[False, True, "oct"], ids=["wave-per-env", "quad", "oct"])
+@pytest.fixture(params=[False, True, "oct", "lane"], ids=["wave-per-env", "quad", "oct", "lane"])
 def quad(request):
     """Both kernel generations run the same checks: the fused wave-per-env kernel (dw_task.h + dw_physics.h) and the split
     pipeline around the quad physics kernel (dw_quad*.h, 4 lanes per env, one fiber per lane on the host)."""
@@ -164,13 +164,13 @@ def test_self_collision_vs_oracle(quad):
     assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 0].max() < 1e-5
 
 
-@pytest.mark.parametrize("which", ["oracle", "wave-per-env", "quad", "oct"])
+@pytest.mark.parametrize("which", ["oracle", "wave-per-env", "quad", "oct", "lane"])
 def test_mirrored_legs_get_a_mirrored_response(which):
     """Exactly parallel capsules (mirror-symmetric legs): contact in the middle of the overlap, so the response is mirrored
     -- joint rates of the two legs are mirror images, the base neither yaws nor drifts sideways (the textbook closest-point
     rule put the contact at whichever end rounding chose).  Envs whose shank axes intersect are left out."""
     N = 40
-    sim = OracleSim(N) if which == "oracle" else EmulSim(N, quad={"wave-per-env": False, "quad": True, "oct": "oct"}[which])
+    sim = OracleSim(N) if which == "oracle" else EmulSim(N, quad={"wave-per-env": False, "quad": True, "oct": "oct", "lane": "lane"}[which])
     sim.buf["root_states"][:, 0:2] = 0
     sim.buf["root_states"][:, 2] = 3.0
     sim.buf["dof_state"][:, :, 0] = _crossed(N, True)

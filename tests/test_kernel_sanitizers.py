@@ -21,7 +21,7 @@ def _lib(name):
         return None
 
 
-@pytest.mark.parametrize("quad", ["", "quad", "oct"], ids=["wave-per-env", "quad", "oct"])
+@pytest.mark.parametrize("quad", ["", "quad", "oct", "lane"], ids=["wave-per-env", "quad", "oct", "lane"])
 def test_kernel_body_under_asan_ubsan(quad):
     asan, ubsan = _lib("libasan.so"), _lib("libubsan.so")
     if not asan or not ubsan:

@@ -17,5 +17,9 @@ g = torch.Generator(device="cuda").manual_seed(42)
 acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
 for i in range(steps):
     env.step(acts[i % 8])
+if os.environ.get("DW_SIM"):
+    tau = (torch.rand(N, 33, generator=g, device="cuda") * 2 - 1) * 20
+    for i in range(steps):
+        env.simulate(tau)
 torch.cuda.synchronize()
 env.close()
