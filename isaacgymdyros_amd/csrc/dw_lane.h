@@ -34,7 +34,7 @@ namespace dwl {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::f2i; using dwq::sincos_fast; using dwq::qmul; using dwq::over_1n;
-using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_dist2_fast; using dwq::capsule_pair;
+using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_dist2_fast;
 using dwq::rcp_fast;
 
 constexpr int EPW = 64;                      // envs per workgroup = lanes per wave
@@ -48,14 +48,20 @@ struct alignas(16) LLds {
     F4   xch[3][XCH_ROWS][EPW];              // exchange records; between their uses also: per-env scratch of the task phases (B), the
                                              // trunk joints' inputs (A, during the kinematics pass), self-collision hit masks (C)
     LHot hot;                                // the model's per-body constants (dw_lane_model.h), staged once per kernel
-    int  wflag[NWAVE][4];                    // per wave: some env has a touching pair
+    int  wflag[NWAVE][4];                    // per wave: [0] some env has a touching pair, [1] the wave's hand-off counter (contact phase)
 };
 static_assert(sizeof(LLds) <= 163840, "LLds must fit the 160 KB of LDS of one CU");
 
 #define DL_SL(b, r) L.slot[(b) - 1][(r)][X.ln]
 // Profiling builds (-DDL_STAMPS, tools/lane_stamps.py) record the clock at phase boundaries of every wave of workgroup 0 into the
 // first rows of stacked_rewards (dw_simulate leaves that buffer alone).  Never defined in the shipped library.
-#if defined(DL_STAMPS) && defined(__HIPCC__)
+#if defined(DL_STAMPS) && defined(__HIPCC__) && defined(DL_SUB_BASE)
+// (substep stamps of the fused step kernel: window DL_SUB_BASE .. +13 into the tail of gate_acc, as DL_STAMP2 below)
+#define DL_STAMP(n) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (n) >= DL_SUB_BASE && (n) < DL_SUB_BASE + 14) B.cold->gate_acc[200 + (threadIdx.x >> 6) * 14 + (n) - DL_SUB_BASE] = (long long)(__builtin_readcyclecounter() - dl_t0); } while (0)
+#define DL_STAMP_T0() const unsigned long long dl_t0 = __builtin_readcyclecounter()
+#define DL_STAMP2(n) do { } while (0)
+#define DL_T0 dl_t0
+#elif defined(DL_STAMPS) && defined(__HIPCC__)
 #define DL_STAMP(n) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) B.cold->stacked_rewards[X.w * 32 + (n)] = (float)(long long)(__builtin_readcyclecounter() - dl_t0); } while (0)
 #define DL_STAMP_T0() const unsigned long long dl_t0 = __builtin_readcyclecounter()
 // step-level stamps (tools/lane_stamps.py --step): 14 per wave in the free tail of gate_acc (words 200 ..), the window of stamp
@@ -89,6 +95,7 @@ struct LState {
     int   act[4];
     int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
     float footT[3];                          // last substep: net contact force on my sole's Gym body (leg waves)
+    int   seq;                               // leg waves: hand-offs made so far (flag_post / flag_wait, dw_lane_wave.h)
     float warm[12];                          // leg waves: impulses of my sole's corners, carried from substep to substep (the caller
                                              // loads them from the task record, DW_ES_WARM, and stores them back)
 };
@@ -113,6 +120,62 @@ DQ_HD void rigid_bias(const float *Ao, const float *ho, float mass, const float 
     pv[0] = t1[0] + t2[0]; pv[1] = t1[1] + t2[1]; pv[2] = t1[2] + t2[2];
     cross3(om, f, t1);
     pv[3] = t1[0]; pv[4] = t1[1]; pv[5] = t1[2];
+}
+
+// Closest points of two segments and the penalty force of two capsules as dw_quad.h's seg_seg / capsule_pair (written decision:
+// oracle/dw_physics.c seg_seg), with the quotients as Newton-refined reciprocals (~1 ulp) instead of IEEE divisions: ten
+// divisions are a third of the evaluation, and with 64 envs per wave some env has a touching pair in most substeps.
+DQ_HD void seg_seg_l(const float *da, const float *db, const float *r, float *so, float *to) {
+    const float aa = dot3(da, da), ee = dot3(db, db), ff = dot3(db, r), eps = 1e-12f;
+    float sa, sb;
+    auto c01 = [](float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); };
+    if (aa <= eps && ee <= eps) { sa = 0.0f; sb = 0.0f; }
+    else if (aa <= eps) { sa = 0.0f; sb = c01(ff * dw::rcp_nr(ee)); }
+    else {
+        const float cc = dot3(da, r), ia = dw::rcp_nr(aa);
+        if (ee <= eps) { sb = 0.0f; sa = c01(-cc * ia); }
+        else {
+            const float ie = dw::rcp_nr(ee);
+            const float bbv = dot3(da, db), den = aa * ee - bbv * bbv;
+            float se = den > eps ? c01((bbv * ff - cc * ee) * dw::rcp_nr(den)) : 0.0f;
+            float te = (bbv * se + ff) * ie;
+            if (te < 0.0f) { te = 0.0f; se = c01(-cc * ia); }
+            else if (te > 1.0f) { te = 1.0f; se = c01((bbv - cc) * ia); }
+            const float t0 = -cc * ia, t1 = t0 + bbv * ia;
+            float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+            if (lo < 0.0f) lo = 0.0f;
+            if (hi > 1.0f) hi = 1.0f;
+            const float sp = c01(0.5f * (lo + hi)), tp = c01((bbv * sp + ff) * ie), reg = 1e-3f * aa * ee;
+            const float w = den > eps ? den * den * dw::rcp_nr(den * den + reg * reg) : 0.0f;
+            sa = w * se + (1.0f - w) * sp;
+            sb = w * te + (1.0f - w) * tp;
+        }
+    }
+    *so = sa; *to = sb;
+}
+DQ_HD bool capsule_pair_l(const float *a0, const float *a1, float ra, const float *b0, const float *b1, float rb, const float *va,
+                          const float *vb, const PhysParams &P, float *F, float *pa, float *pb) {
+    const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
+    const float r[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
+    float sa, sb;
+    seg_seg_l(da, db, r, &sa, &sb);
+    float n[3];
+    DQ_UNROLL for (int i = 0; i < 3; ++i) { pa[i] = a0[i] + sa * da[i]; pb[i] = b0[i] + sb * db[i]; n[i] = pa[i] - pb[i]; }
+    const float d2 = dot3(n, n);
+    const float dist = sqrtf(d2);
+    const float depth = ra + rb - dist;
+    if (!(depth > 0.0f && dist > 1e-6f)) return false;
+    const float idist = dw::rcp_nr(dist);
+    DQ_UNROLL for (int i = 0; i < 3; ++i) n[i] *= idist;
+    float ta[3], tb[3];
+    cross3(va, pa, ta);
+    cross3(vb, pb, tb);
+    float vn = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) vn += ((va[3 + i] + ta[i]) - (vb[3 + i] + tb[i])) * n[i];
+    float fn = P.pen_k * depth - P.pen_c * vn;
+    if (fn < 0.0f) fn = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) F[i] = fn * n[i];
+    return true;
 }
 
 // a 27-word record (symmetric 6x6 + 6-vector) to / from an exchange buffer
@@ -258,11 +321,17 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
     unsigned sc_hits = 0;
     bool sc_wg = false;
     float *park = P.sc_park + (size_t)e * DW_MAX_SC_PAIRS * SC_PARK_WORDS;
-    if (c_selfcoll && CT.pair_n > 0) {
+    // every wave's FIRST touching pair of an env crosses in LDS (12 words + the pair and the two proxies' body / Gym-slot bits: rows
+    // 3 (w & 1) .. of exchange record A (waves 0, 1) or B (waves 2, 3), free at this point); a second one of the same wave and env
+    // (rare) goes through the global park.  fh: what every wave has read of the four slots after the barrier.
+    F4 fh[NWAVE][3];
+    DQ_UNROLL for (int sw = 0; sw < NWAVE; ++sw) { fh[sw][0] = fh[sw][1] = mk4(0.0f, 0.0f, 0.0f, 0.0f); fh[sw][2] = mk4(0.0f, __builtin_bit_cast(float, -1), 0.0f, 0.0f); }
+    if (c_selfcoll && LM.npair > 0) {
         unsigned hits = 0;
+        F4 my0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), my1 = my0, my2 = mk4(0.0f, __builtin_bit_cast(float, -1), 0.0f, 0.0f);
         const unsigned pba0 = CT.pair_ba[0], pba1 = CT.pair_ba[1], pbb0 = CT.pair_bb[0], pbb1 = CT.pair_bb[1];
         const unsigned ppa0 = CT.pair_pa[0], ppa1 = CT.pair_pa[1], ppb0 = CT.pair_pb[0], ppb1 = CT.pair_pb[1];
-        const int k_lo = CT.pair_lo, k_n = CT.pair_n;
+        const int k_n = CT.pair_n;
         // (the two proxies' records and both bodies' pose rows are requested a pair ahead)
         auto pair_fetch = [&](int i, F4 (&pr)[4], F4 &qa, F4 &xa, F4 &qb, F4 &xb) {
             const int pa = (int)(((i < 4 ? ppa0 : ppa1) >> (8 * (i & 3))) & 255u), pb = (int)(((i < 4 ? ppb0 : ppb1) >> (8 * (i & 3))) & 255u);
@@ -282,12 +351,12 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
             p1w[0] = x4.x + t1[0]; p1w[1] = x4.y + t1[1]; p1w[2] = x4.z + t1[2];
         };
         F4 npr[4], nqa, nxa, nqb, nxb;
-        pair_fetch(0, npr, nqa, nxa, nqb, nxb);
+        if (k_n > 0) pair_fetch(0, npr, nqa, nxa, nqb, nxb);
         DL_ROLLED for (int i = 0; i < k_n; ++i) {
             const F4 p0 = npr[0], p1 = npr[1], p2 = npr[2], p3 = npr[3], qa = nqa, qb = nqb; F4 xa = nxa, xb = nxb;
             DL_KEEP2(xa, xb);
             pair_fetch(i + 1 < k_n ? i + 1 : i, npr, nqa, nxa, nqb, nxb);
-            const int k = k_lo + i;
+            const int k = w + NWAVE * i;
             // proxy record words: p0.xyz radius | p1.xyz bits
             const float la0[3] = {p0.x, p0.y, p0.z}, la1[3] = {p1.x, p1.y, p1.z}, lb0[3] = {p2.x, p2.y, p2.z}, lb1[3] = {p3.x, p3.y, p3.z};
             float a0[3], a1[3], b0[3], b1[3];
@@ -305,32 +374,41 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
                     DL_KEEP2(va2, va3); DL_KEEP2(vb2, vb3);
                     const float va[6] = {va2.x, va2.y, va2.z, va3.x, va3.y, va3.z}, vb[6] = {vb2.x, vb2.y, vb2.z, vb3.x, vb3.y, vb3.z};
                     float F[3], ca[3], cb[3];
-                    if (capsule_pair(a0, a1, p0.w, b0, b1, p2.w, va, vb, P, F, ca, cb)) {
-                        hits |= 1u << k;
+                    if (capsule_pair_l(a0, a1, p0.w, b0, b1, p2.w, va, vb, P, F, ca, cb)) {
                         float na[3], nb[3];
                         const float Fm[3] = {-F[0], -F[1], -F[2]};
                         cross3(ca, F, na);
                         cross3(cb, Fm, nb);
-                        F4 *pk = reinterpret_cast<F4 *>(park + SC_PARK_WORDS * k);
-                        pk[0] = mk4(na[0], na[1], na[2], F[0]);
-                        pk[1] = mk4(F[1], F[2], nb[0], nb[1]);
-                        pk[2] = mk4(nb[2], 0.0f, 0.0f, 0.0f);
+                        if (hits == 0) {
+                            my0 = mk4(na[0], na[1], na[2], F[0]); my1 = mk4(F[1], F[2], nb[0], nb[1]);
+                            my2 = mk4(nb[2], __builtin_bit_cast(float, k), p1.w, p3.w);
+                        } else {
+                            F4 *pk = reinterpret_cast<F4 *>(park + SC_PARK_WORDS * k);
+                            pk[0] = mk4(na[0], na[1], na[2], F[0]);
+                            pk[1] = mk4(F[1], F[2], nb[0], nb[1]);
+                            pk[2] = mk4(nb[2], 0.0f, 0.0f, 0.0f);
+                        }
+                        hits |= 1u << k;
                     }
                 }
             }
+        }
+        {
+            const int xb_ = w < 2 ? XA : XB, r0_ = 3 * (w & 1);
+            L.xch[xb_][r0_][ln] = my0; L.xch[xb_][r0_ + 1][ln] = my1; L.xch[xb_][r0_ + 2][ln] = my2;
         }
         reinterpret_cast<int *>(&L.xch[XC][0][ln])[w] = (int)hits;
         const bool any = wave_any(hits != 0);
         if (ln == 0) L.wflag[w][0] = any ? 1 : 0;
         wg_barrier_global();
         sc_wg = (L.wflag[0][0] | L.wflag[1][0] | L.wflag[2][0] | L.wflag[3][0]) != 0;
-        if (sc_wg) { const F4 hv = L.xch[XC][0][ln]; sc_hits = (unsigned)(f2i(hv.x) | f2i(hv.y) | f2i(hv.z) | f2i(hv.w)); }
-    } else if (c_selfcoll && LM.npair > 0) {
-        reinterpret_cast<int *>(&L.xch[XC][0][ln])[w] = 0;
-        if (ln == 0) L.wflag[w][0] = 0;
-        wg_barrier_global();
-        sc_wg = (L.wflag[0][0] | L.wflag[1][0] | L.wflag[2][0] | L.wflag[3][0]) != 0;
-        if (sc_wg) { const F4 hv = L.xch[XC][0][ln]; sc_hits = (unsigned)(f2i(hv.x) | f2i(hv.y) | f2i(hv.z) | f2i(hv.w)); }
+        if (sc_wg) {
+            const F4 hv = L.xch[XC][0][ln];
+            sc_hits = (unsigned)(f2i(hv.x) | f2i(hv.y) | f2i(hv.z) | f2i(hv.w));
+            DQ_UNROLL for (int sw = 0; sw < NWAVE; ++sw)
+                DQ_UNROLL for (int r = 0; r < 3; ++r) fh[sw][r] = L.xch[sw < 2 ? XA : XB][3 * (sw & 1) + r][ln];
+            wg_barrier();          // (every wave holds the slots: the exchange records may be written again)
+        }
     }
     DL_STAMP(3);
 
@@ -461,23 +539,33 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
                         }
                     }
                     if (scb) {
-                        // my side of every touching pair that involves a proxy of this body, in pair order
-                        const unsigned bm = bpairs;
-                        DL_ROLLED for (int kp = 0; kp < LM.npair; ++kp) {
-                            if (!((bm >> kp) & 1u)) continue;
-                            const bool hit = ((sc_hits >> kp) & 1u) != 0;
-                            if (!wave_any(hit)) continue;
-                            const int rba = L.hot.prox[LM.pair_a[kp]].bits, rbb = L.hot.prox[LM.pair_b[kp]].bits;
-                            const bool side_a = (rba & 255) == b;
-                            const int t = ((side_a ? rba : rbb) >> 8) & 255;
-                            if (hit) {
-                                const F4 *pk = reinterpret_cast<const F4 *>(park + SC_PARK_WORDS * kp);
-                                const F4 k0 = pk[0], k1 = pk[1], k2 = pk[2];
-                                const float W6[6] = {side_a ? k0.x : k1.z, side_a ? k0.y : k1.w, side_a ? k0.z : k2.x,
-                                                     side_a ? k0.w : -k0.w, side_a ? k1.x : -k1.x, side_a ? k1.y : -k1.y};
-                                DQ_UNROLL for (int i = 0; i < 6; ++i) pv[i] -= W6[i];
-                                DQ_UNROLL for (int t2 = 0; t2 < LMAX_GYM; ++t2)
-                                    if (t2 == t) { cf[t2][0] += W6[3]; cf[t2][1] += W6[4]; cf[t2][2] += W6[5]; }
+                        // my side of every touching pair that involves a proxy of this body: the waves' first hits (registers), then
+                        // what went through the park, in pair order
+                        auto apply = [&](bool side_a, int t, const F4 &k0, const F4 &k1, const F4 &k2) {
+                            const float W6[6] = {side_a ? k0.x : k1.z, side_a ? k0.y : k1.w, side_a ? k0.z : k2.x,
+                                                 side_a ? k0.w : -k0.w, side_a ? k1.x : -k1.x, side_a ? k1.y : -k1.y};
+                            DQ_UNROLL for (int i = 0; i < 6; ++i) pv[i] -= W6[i];
+                            DQ_UNROLL for (int t2 = 0; t2 < LMAX_GYM; ++t2)
+                                if (t2 == t) { cf[t2][0] += W6[3]; cf[t2][1] += W6[4]; cf[t2][2] += W6[5]; }
+                        };
+                        DQ_UNROLL for (int sw = 0; sw < NWAVE; ++sw) {
+                            const int pid = f2i(fh[sw][2].y), ba_ = f2i(fh[sw][2].z), bb_ = f2i(fh[sw][2].w);
+                            const bool ona = pid >= 0 && (ba_ & 255) == b, onb = pid >= 0 && (bb_ & 255) == b;
+                            if (ona || onb) apply(ona, ((ona ? ba_ : bb_) >> 8) & 255, fh[sw][0], fh[sw][1], fh[sw][2]);
+                        }
+                        unsigned rest = sc_hits & bpairs;
+                        DQ_UNROLL for (int sw = 0; sw < NWAVE; ++sw) { const int pid = f2i(fh[sw][2].y); if (pid >= 0) rest &= ~(1u << pid); }
+                        if (wave_any(rest != 0)) {
+                            DL_ROLLED for (int kp = 0; kp < LM.npair; ++kp) {
+                                if (!((bpairs >> kp) & 1u)) continue;
+                                const bool hit = ((rest >> kp) & 1u) != 0;
+                                if (!wave_any(hit)) continue;
+                                const int rba = L.hot.prox[LM.pair_a[kp]].bits, rbb = L.hot.prox[LM.pair_b[kp]].bits;
+                                const bool side_a = (rba & 255) == b;
+                                if (hit) {
+                                    const F4 *pk = reinterpret_cast<const F4 *>(park + SC_PARK_WORDS * kp);
+                                    apply(side_a, ((side_a ? rba : rbb) >> 8) & 255, pk[0], pk[1], pk[2]);
+                                }
                             }
                         }
                     }
@@ -683,7 +771,6 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
     //      waves exchange the twist change they cause on the other foot (6 words through LDS, one barrier; waves 2 and 3 only
     //      keep the barrier count).  Block-Jacobi across the feet, Gauss-Seidel over the four corners of a sole, as everywhere. ----
     float dqb[6] = {0, 0, 0, 0, 0, 0};              // base velocity jump
-    const int nupd = P.iters * 4;
     if (legwave) {
         const int f = w, g = 1 - w;
         // free twist of my foot: base + sum over my leg of S qdf
@@ -783,7 +870,9 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
                 }
             L.xch[XB][2 * f][ln] = mk4(xo[0], xo[1], xo[2], 0.0f);
             L.xch[XB][2 * f + 1][ln] = mk4(xo[3], xo[4], xo[5], 0.0f);
-            wg_barrier();
+            X.seq += 1;
+            flag_post(&L.wflag[f][1], X.seq);
+            flag_wait(&L.wflag[g][1], X.seq);
             const F4 o0 = L.xch[XB][2 * g][ln], o1 = L.xch[XB][2 * g + 1][ln];
             tw[0] += o0.x; tw[1] += o0.y; tw[2] += o0.z; tw[3] += o1.x; tw[4] += o1.y; tw[5] += o1.z;
         }
@@ -826,7 +915,9 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
                 const int buf = par ? XC : XB;
                 L.xch[buf][2 * f][ln] = mk4(xo[0], xo[1], xo[2], 0.0f);
                 L.xch[buf][2 * f + 1][ln] = mk4(xo[3], xo[4], xo[5], 0.0f);
-                wg_barrier();
+                X.seq += 1;
+                flag_post(&L.wflag[f][1], X.seq);
+                flag_wait(&L.wflag[g][1], X.seq);
                 const F4 o0 = L.xch[buf][2 * g][ln], o1 = L.xch[buf][2 * g + 1][ln];
                 tw[0] += o0.x; tw[1] += o0.y; tw[2] += o0.z; tw[3] += o1.x; tw[4] += o1.y; tw[5] += o1.z;
             }
@@ -867,12 +958,11 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
         }
     } else {
         idle.work();
-        for (int i = 0; i < nupd + 1; ++i) wg_barrier();
-        idle.publish();
     }
     DL_STAMP(15);
     wg_barrier();
     DL_STAMP(16);
+    if (!legwave) idle.publish();          // (the leg waves' hand-offs are over: exchange record C is free)
     {
         const F4 a0v = L.xch[XA][0][ln], a1v = L.xch[XA][1][ln], b0v = L.xch[XA][2][ln], b1v = L.xch[XA][3][ln];
         const float tot[6] = {a0v.x + b0v.x, a0v.y + b0v.y, a0v.z + b0v.z, a1v.x + b1v.x, a1v.y + b1v.y, a1v.z + b1v.z};
@@ -952,6 +1042,7 @@ DQ_HD void stage_hot(LLds &L, const LaneModel &LM) {
     F4 *dst = reinterpret_cast<F4 *>(&L.hot);
     constexpr int NQ = (int)(sizeof(LHot) / 16);
     for (int i = tid(); i < NQ; i += NT) dst[i] = src[i];
+    if (tid() < NWAVE) { L.wflag[tid()][0] = 0; L.wflag[tid()][1] = 0; }
 }
 
 // Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
@@ -965,6 +1056,7 @@ DQ_HD void lane_init(LState &X, int group, int num_envs, float friction, const O
     X.mu = friction * OQ_COLD(friction_scale)[X.e];
     X.coll = 0;
     X.footT[0] = X.footT[1] = X.footT[2] = 0.0f;
+    X.seq = 0;
     DQ_UNROLL for (int i = 0; i < 12; ++i) X.warm[i] = 0.0f;
     DQ_UNROLL for (int c = 0; c < 4; ++c) {
         X.act[c] = 0; X.vmin[c] = 0.0f;
@@ -982,7 +1074,14 @@ DQ_HD void stage_in(float *LF, int dst, const float *src, int wpe, int nvalid) {
     if (nvalid == EPW) {
         const F4 *s4 = reinterpret_cast<const F4 *>(src);
         F4 *d4 = reinterpret_cast<F4 *>(LF + dst);
-        for (int p = t; p < nw / 4; p += NT) d4[p] = s4[p];
+        const int np = nw / 4;
+        // eight requests in flight per thread before the first store (as a plain loop this was one memory round trip per piece)
+        constexpr int GRP = 8;
+        for (int p0 = 0; p0 < np; p0 += GRP * NT) {
+            F4 v[GRP];
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) { const int p = p0 + t + NT * u; v[u] = s4[p < np ? p : np - 1]; }
+            DQ_UNROLL for (int u = 0; u < GRP; ++u) { const int p = p0 + t + NT * u; if (p < np) d4[p] = v[u]; }
+        }
     } else {
         for (int i = t; i < nw; i += NT) LF[dst + i] = i < nv ? src[i] : 0.0f;
     }

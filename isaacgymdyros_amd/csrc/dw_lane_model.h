@@ -318,10 +318,13 @@ inline int build_lanemodel(const dw::DevModel *d, LaneModel *Q, const char **err
                 c.own_ts |= (unsigned)(Q->trunk_slot[b] + 1) << (2 * c.n_own);
                 ++c.n_own;
             }
-        c.pair_lo = Q->pair_lo[w]; c.pair_n = Q->pair_lo[w + 1] - Q->pair_lo[w];
+        // detection: wave w tests the pairs w, w + 4, w + 8, ... (the model lists a proxy's pairs together, and touching pairs cluster
+        // on the legs: interleaved, every wave gets its share of them)
+        c.pair_lo = w; c.pair_n = (Q->npair - w + NWAVE - 1) / NWAVE;
+        if (c.pair_n < 0) c.pair_n = 0;
         if (c.pair_n > 8) { *err = "lane kernels: more than 8 detection pairs per wave"; return DW_EINVAL; }
         for (int i = 0; i < c.pair_n; ++i) {
-            const int k = c.pair_lo + i;
+            const int k = w + NWAVE * i;
             c.pair_ba[i >> 2] |= (unsigned)d->scp[k].ba << (8 * (i & 3));
             c.pair_bb[i >> 2] |= (unsigned)d->scp[k].bb << (8 * (i & 3));
             c.pair_pa[i >> 2] |= (unsigned)d->sc_pair[k][0] << (8 * (i & 3));

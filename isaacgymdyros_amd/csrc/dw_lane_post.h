@@ -482,22 +482,8 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
         wg_barrier_global();
     }
 
-    DL_STAMP2(22);
-    // ---- Q5, first half: request the history taps now, use them after Q4.  A thread takes ROWS (env, tap): 37 observation
-    //      words and 13 action words, consecutive in the rings and in obs_buf.  The newest observation tap is this step's own
-    //      (Q4, still in LDS) and is not read back. ----
     constexpr int NTAP = DW_NUM_HIS - 1, NPAIR = EPW * NTAP, RPL = (NPAIR + NT - 1) / NT;
     static_assert((DW_NUM_SKIP * DW_NUM_HIS) % DW_HIST_SLOTS == 0, "the last observation tap must be the newest slot");
-    float tapo[RPL][DW_NUM_OBS1], tapa[RPL][DW_NUM_ACT];
-    DQ_UNROLL for (int r = 0; r < RPL; ++r) {
-        const int p = t + NT * r, pc = p < NPAIR ? p : 0;
-        const int ee = pc / NTAP, tap = pc - NTAP * ee;
-        const int egr = group * EPW + ee, eg = egr < N ? egr : N - 1;
-        const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
-        const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
-        ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, tapo[r]);
-        ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, tapa[r]);
-    }
     DL_STAMP2(23);
     // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
     //      expensive functions (atan2, sincos, the noise draw) is executed by few wave passes ----
@@ -572,23 +558,37 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
     //      the newest tap is copied from LDS, items (env, word). ----
     {
         float *ob = B.obs_buf + (size_t)group * EPW * DW_NUM_OBS;
+        // (the nine history taps of every env were copied from the rings during the second substep, dw_lane_kernels.h; with physics
+        //  frozen -- tests -- they are copied here)
         DQ_UNROLL for (int r = 0; r < RPL; ++r) {
             const int p = t + NT * r, pc = p < NPAIR ? p : 0;
             const int ee = pc / NTAP, tap = pc - NTAP * ee;
-            const bool ok = p < NPAIR && group * EPW + ee < N;
+            const int egr = group * EPW + ee, eg = egr < N ? egr : N - 1;
+            const bool ok = p < NPAIR && egr < N;
             const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
-            if (wave_any(fill)) {
-                if (fill) { DQ_UNROLL for (int k = 0; k < DW_NUM_OBS1; ++k) tapo[r][k] = PQ_NORMED(ee, k); }
+            if (C.freeze_physics) {
+                const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
+                const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
+                float ro[DW_NUM_OBS1], ra[DW_NUM_ACT];
+                ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, ro);
+                ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, ra);
+                if (ok && !fill) st_row(ob + ee * DW_NUM_OBS + tap * DW_NUM_OBS1, ro);
+                if (ok && !rs) st_row(ob + ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + tap * DW_NUM_ACT, ra);
             }
-            const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD);
-            const bool own = ((newest + 1) % DW_HIST_SLOTS + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS == newest;    // (never, with 2 x 10 slots)
-            if (wave_any(rs || own)) {
-                if (rs) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = 0.0f; }
-                else if (own) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = PQ_ES(ee, DW_ES_ACTIONS + k); }
+            // an env that was just reset shows its first observation in every tap and zeros in the action taps
+            if (wave_any(ok && fill)) {
+                if (ok && fill) {
+                    float ro[DW_NUM_OBS1];
+                    DQ_UNROLL for (int k = 0; k < DW_NUM_OBS1; ++k) ro[k] = PQ_NORMED(ee, k);
+                    st_row(ob + ee * DW_NUM_OBS + tap * DW_NUM_OBS1, ro);
+                }
             }
-            if (ok) {
-                st_row(ob + ee * DW_NUM_OBS + tap * DW_NUM_OBS1, tapo[r]);
-                st_row(ob + ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + tap * DW_NUM_ACT, tapa[r]);
+            if (wave_any(ok && rs)) {
+                if (ok && rs) {
+                    float ra[DW_NUM_ACT];
+                    DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) ra[k] = 0.0f;
+                    st_row(ob + ee * DW_NUM_OBS + DW_NUM_OBS1 * DW_NUM_HIS + tap * DW_NUM_ACT, ra);
+                }
             }
         }
         for (int i = t; i < EPW * DW_NUM_OBS1; i += NT) {

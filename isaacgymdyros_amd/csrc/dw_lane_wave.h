@@ -41,6 +41,20 @@ DQ_HD void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 DQ_HD void wg_barrier_global() { __syncthreads(); }
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }          // a value every lane of the wave holds, into a scalar register
+// Hand-off between TWO waves of the workgroup without stopping the others at a barrier: the producer's LDS stores, then
+// flag_post(mine, n); the consumer's flag_wait(theirs, n), then its LDS loads.  A wave's LDS operations execute in order, so
+// whoever sees the flag sees the data; n counts up for the life of the kernel (the flags are zeroed before its first barrier).
+DQ_HD void flag_post(int *flag, int n) {
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63u) == 0) *reinterpret_cast<volatile int *>(flag) = n;
+}
+DQ_HD void flag_wait(const int *flag, int n) {
+    for (;;) {
+        const int v = *reinterpret_cast<const volatile int *>(flag);
+        if (__builtin_amdgcn_readfirstlane(v) >= n) break;
+    }
+    asm volatile("" ::: "memory");
+}
 
 }  // namespace dwl
 #else
@@ -164,6 +178,13 @@ static inline void wg_barrier() {
 }
 static inline void wg_barrier_global() { wg_barrier(); }
 static inline int uniform(int x) { return x; }
+static inline bool wave_any(bool p);
+// (host lanes do not run in lock step: the wave's lanes meet before lane 0 posts, as the device's do by construction)
+static inline void flag_post(int *flag, int n) { (void)wave_any(true); if ((g_wg->cur & 63) == 0) *flag = n; }
+static inline void flag_wait(const int *flag, int n) {
+    g_wg->idle_switches = 0;
+    while (*reinterpret_cast<const volatile int *>(flag) < n) wg_yield_public();
+}
 static inline bool wave_any(bool p) {
     WgEmu *e = g_wg;
     const int l = e->cur, w0 = l & ~63;

@@ -8,7 +8,9 @@ _lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
 from isaacgymdyros_amd.config import default_cfg
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+import json
 cfg = default_cfg(N, "cuda:0"); cfg["sim"]["mi355"]["pipeline"] = 4
+cfg["sim"]["mi355"].update(json.loads(os.environ.get("DW_MI355", "{}")))
 env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 g = torch.Generator(device="cuda").manual_seed(42)
 acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
@@ -44,6 +46,8 @@ if "--step" in sys.argv:
         env.step(acts[i % 8]); torch.cuda.synchronize()
         rows.append(env._buf["gate_acc"][200:256].cpu().numpy().reshape(4, 14).astype(np.float64).copy())
     med = np.median(np.stack(rows[10:]), axis=0)
+    if "--sub" in sys.argv:
+        names2 = dict(enumerate(names))
     print("step-level stamps (window %d..%d)" % (base, base + 13))
     for n in range(14):
         cells = []
