@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 5
+#define DW_ABI_VERSION 6
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -370,16 +370,24 @@ int dw_newwalk_reward(int n, const int64_t *reset_buf, const int64_t *progress_b
                       const float *phase, float *total_reward, int64_t *reset, float *reward8, void *stream);
 int dw_body_positions(DwHandle *h, const int32_t *moving_bodies, int nb, float *out, void *stream);
 
-/* ---- Row f-3, fused: the bookkeeping of one TocabiAMPLower step between the physics launches, as four kernels instead of ~100
+/* ---- Row f-3, fused: the bookkeeping of one TocabiAMPLower step between the physics launches, as three kernels instead of ~100
  * elementwise torch launches (tasks/amp/tocabi_amp_lower_base.py:642-804, tasks/tocabi_amp_lower.py:88-96).  The host class
- * (isaacgymdyros_amd/tocabi_amp_lower.py, cfg sim.mi355.amp_fused) calls, per step:
- *   dw_amp_step_pre                                   action clamp + history, command ramp
- *   2 x [ dw_amp_step_tau, dw_simulate, dw_amp_step_encoder ]   torques (PD / delayed-torque FIFO), physics, encoder model
- *   dw_amp_step_post                                  counters, foot positions, observation + history stacking, reward, termination,
- *                                                     discriminator observation history, time-outs, clamped observation
- * Random numbers come in as tensors the caller drew (torch's generator, as in the reference): every expression is the one of the
- * torch implementation of the same class, so that the fused step is bit-identical to it (tests/test_amp_gpu.py).  All pointers
- * are device memory, [N, ...] row-major float32 unless noted; int64 where the reference holds torch.long. */
+ * (isaacgymdyros_amd/tocabi_amp_lower.py, cfg sim.mi355.amp_fused) calls, per step of controlFrequencyInv = K substeps:
+ *   dw_amp_step_begin                 action clamp + action history, command ramp, torques of substep 0 (PD / delayed-torque FIFO)
+ *   dw_simulate
+ *   (K - 1) x [ dw_amp_step_mid(k), dw_simulate ]   encoder model of substep k - 1, torques of substep k
+ *   dw_amp_step_end(K - 1)            encoder model of the last substep, counters, foot positions, observation + history stacking,
+ *                                     reward, termination, discriminator observation history, time-outs, clamped observation
+ * and dw_amp_reset_done between two steps.  One wavefront per env (csrc/dw_amp_step.h; the same source runs under g++ in
+ * tests/emul/ and under ASan / UBSan).
+ * Random numbers: tensors the caller drew (torch's generator, in the torch implementation's order: every expression is the one
+ * of the torch implementation of the same class, so the fused step is bit-identical to it, tests/test_amp_gpu.py) -- or, with
+ * DwAmpConfig.device_draws = 1 and NULL draw arguments, drawn inside the kernels (Philox4x32-10 keyed by DwAmpConfig.seed, the env
+ * and the env's counter DwAmpBuffers.draw_ctr, which the kernels advance: a step recorded in a hipGraph draws fresh numbers at
+ * every replay).  Histories: DwAmpConfig.hist_ring = 0 is the reference's layout (newest slot last, the whole row shifts every
+ * step); 1 keeps action_history / obs_history as rings, DwAmpBuffers.hist_head [N,2] = physical slot of the oldest entry of the
+ * two (logical slot i = physical slot (head + i) mod num_his * num_skip).  All pointers are device memory, [N, ...] row-major
+ * float32 unless noted; int64 where the reference holds torch.long. */
 typedef struct DwAmpBuffers {
     float   *actions, *actions_pre;                 /* [N,12]                                                        */
     float   *action_history, *obs_history;          /* [N, his*skip*12], [N, his*skip*36]                            */
@@ -408,6 +416,11 @@ typedef struct DwAmpBuffers {
     int64_t *perturbation_count, *perturb_timing;   /* [N]                                                           */
     uint8_t *pert_on;                               /* [N] torch.bool                                                */
     const float *initial_root_states;               /* [N,13]                                                        */
+    /* rings and device draws (NULL unless DwAmpConfig.hist_ring / device_draws) */
+    int32_t *hist_head;                             /* [N,2] action / observation history: slot of the oldest entry  */
+    int64_t *draw_ctr;                              /* [N] the env's draw counter                                    */
+    /* dw_amp_reset_done with DwAmpConfig.dr_damping / dr_armature */
+    const float *nominal_damping, *nominal_armature;               /* [33] each                                      */
 } DwAmpBuffers;
 typedef struct DwAmpConfig {
     int32_t num_envs, num_his, num_skip, log_slots, amp_steps;
@@ -418,17 +431,27 @@ typedef struct DwAmpConfig {
     float   dt;
     int32_t gpu_div;                                /* 1: qvel = d * inv_dt (torch on a GPU), 0: d / dt (torch on a CPU) */
     float   cmd_lo[3], cmd_scale[3];                /* command ranges x, y, yaw: float(lo), float(hi - lo)            */
+    int32_t hist_ring;                              /* 1: action_history / obs_history are rings (hist_head)         */
+    int32_t device_draws;                           /* 1: NULL draw arguments are drawn in the kernels (draw_ctr)    */
+    int32_t randomize;                              /* task.randomize: power_scale (and the dof properties) at reset */
+    int32_t dr_damping, dr_armature, dr_frequency;  /* dw_amp_reset_done: dof-property randomisation of a resetting env whose
+                                                       randomize_buf has reached dr_frequency (tasks/base/vec_task.py:519-733) */
+    float   dr_damping_range[2], dr_armature_range[2];             /* additive / scaling, uniform                    */
+    int32_t delay_idx_range[2];                     /* device draws: delay_idx in [lo, hi) = [1 + int(0.002 / dt), 1 + round(0.01 / dt)) (:302) */
+    uint64_t seed;                                  /* key of the device draws                                       */
 } DwAmpConfig;
-/* ramp_dur [N] int64 in [1,250), ramp_u [N,3] uniform in [0,1): the draws of the command ramp for EVERY env (kept where an env changes
- * its command); NULL with vel_change = 0 */
-int dw_amp_step_pre(const DwAmpConfig *c, const DwAmpBuffers *b, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u,
+/* actions_in [N,12] (clamped to +-clip_actions inside).  ramp_dur [N] int64 in [1,250), ramp_u [N,3] uniform in [0,1): the draws of
+ * the command ramp for EVERY env (kept where an env changes its command); NULL with vel_change = 0 or device_draws = 1.  Reads the
+ * bound dof_state of h. */
+int dw_amp_step_begin(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *actions_in, const int64_t *ramp_dur,
+                      const float *ramp_u, void *stream);
+/* between substep `substep` - 1 and substep `substep` (1 <= substep < 8).  z [N,33]: normal draws with sigma 0.00016 / 3 for the
+ * encoder model of the substep that ended (NULL with noise = 0 or device_draws = 1) */
+int dw_amp_step_mid(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *z, int substep, void *stream);
+/* after the last substep (index `substep`).  z as above; rootvel_noise [N,6]: uniform in +-0.025 (NULL: zeros with noise = 0, drawn
+ * with device_draws = 1); reads the bound root_states / dof_state / contact_forces of h */
+int dw_amp_step_end(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *z, int substep, const float *rootvel_noise,
                     void *stream);
-/* dof_state: the bound [N,33,2] */
-int dw_amp_step_tau(const DwAmpConfig *c, const DwAmpBuffers *b, const float *dof_state, void *stream);
-/* z [N,33]: normal draws with sigma 0.00016 / 3 (ignored with noise = 0) */
-int dw_amp_step_encoder(const DwAmpConfig *c, const DwAmpBuffers *b, const float *dof_state, const float *z, void *stream);
-/* rootvel_noise [N,6]: uniform in +-0.025 (zeros with noise = 0); reads the bound root_states / dof_state / contact_forces of h */
-int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *rootvel_noise, void *stream);
 /* reset_idx of the listed envs (tasks/amp/tocabi_amp_lower_base.py:238-305 with the default state initialisation, then
  * tasks/tocabi_amp_lower.py:144-147,258-272) as ONE launch instead of ~60 indexed assignments: a wavefront per listed env writes its rows
  * of the Gym tensors (initial pose, zero contact), the reset observation (computed from the episode's last encoder reading, as the
@@ -440,6 +463,16 @@ int dw_amp_step_post(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, c
 int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale_u,
                       const float *rootvel_noise, const float *cmd_x_u, const float *cmd_y_u, const float *cmd_yaw_u, const float *qpos_bias_u,
                       const float *quat_bias_u, const int64_t *perturb_timing, const int64_t *delay_idx, void *stream);
+/* VecTask.reset_done's reset_idx (tasks/base/vec_task.py:376-391 -> tasks/amp/tocabi_amp_lower_base.py:238-305) for EVERY env whose
+ * reset_buf is non-zero, in one launch and without an id list (no host round trip before the launch): what dw_amp_reset_rows does for a
+ * listed env, plus the dof-property randomisation (DwAmpConfig.dr_*: damping = nominal + U, armature = nominal * U into the bound
+ * dof_damping / dof_armature of h) and the clamped observation row (obs_out).  Draws: rows of the caller's arrays indexed BY ENV
+ * ([N, ...]: raw uniforms as for dw_amp_reset_rows; damping_u / armature_u [N,33]) or, with device_draws = 1, NULL = drawn here. */
+typedef struct DwAmpResetDraws {
+    const float *power_scale_u, *rootvel_noise, *cmd_x_u, *cmd_y_u, *cmd_yaw_u, *qpos_bias_u, *quat_bias_u, *damping_u, *armature_u;
+    const int64_t *perturb_timing, *delay_idx;
+} DwAmpResetDraws;
+int dw_amp_reset_done(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const DwAmpResetDraws *draws, void *stream);
 
 
 #ifdef __cplusplus

@@ -102,7 +102,8 @@ AMP_BUFFER_NAMES = ["actions", "actions_pre", "action_history", "obs_history", "
                     "qpos_noise", "qvel_noise", "qpos_pre", "qpos_bias", "quat_bias", "dof_vel_pre", "tau", "progress_buf", "randomize_buf",
                     "reset_buf", "terminate_buf", "timeout_buf", "rigid_body_pos", "rigid_body_rot", "foot_pos", "obs1", "obs_buf", "obs_out",
                     "rew_buf", "reward_values", "total_mass", "amp_obs_buf", "amp_obs1", "motor_efforts", "p_gains", "d_gains", "init_angle",
-                    "pd_action_offset", "pd_action_scale", "epi_len_log", "perturbation_count", "perturb_timing", "pert_on", "initial_root_states"]
+                    "pd_action_offset", "pd_action_scale", "epi_len_log", "perturbation_count", "perturb_timing", "pert_on", "initial_root_states",
+                    "hist_head", "draw_ctr", "nominal_damping", "nominal_armature"]
 
 
 class DwAmpBuffers(C.Structure):            # include/dyros_walk.h, the fused TocabiAMPLower step
@@ -113,7 +114,17 @@ class DwAmpConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_his", "num_skip", "log_slots", "amp_steps", "pd_control", "noise", "vel_change",
                                          "local_root_obs", "enable_early_termination")] + \
                [(n, C.c_float) for n in ("clip_actions", "clip_obs", "max_episode_length", "termination_height", "inv_dt", "dt")] + \
-               [("gpu_div", C.c_int32), ("cmd_lo", C.c_float * 3), ("cmd_scale", C.c_float * 3)]
+               [("gpu_div", C.c_int32), ("cmd_lo", C.c_float * 3), ("cmd_scale", C.c_float * 3)] + \
+               [(n, C.c_int32) for n in ("hist_ring", "device_draws", "randomize", "dr_damping", "dr_armature", "dr_frequency")] + \
+               [("dr_damping_range", C.c_float * 2), ("dr_armature_range", C.c_float * 2), ("delay_idx_range", C.c_int32 * 2), ("seed", C.c_uint64)]
+
+
+AMP_RESET_DRAW_NAMES = ["power_scale_u", "rootvel_noise", "cmd_x_u", "cmd_y_u", "cmd_yaw_u", "qpos_bias_u", "quat_bias_u", "damping_u", "armature_u",
+                        "perturb_timing", "delay_idx"]
+
+
+class DwAmpResetDraws(C.Structure):         # include/dyros_walk.h: the caller's draws of dw_amp_reset_done, rows indexed by env
+    _fields_ = [(n, C.c_void_p) for n in AMP_RESET_DRAW_NAMES]
 
 
 def declare(lib: C.CDLL, prefix: str = "dw_"):
@@ -137,11 +148,23 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     api["step"] = fn("step", C.c_int, H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
     api["step_dev"] = fn("step_dev", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
     api["reset_idx"] = fn("reset_idx", C.c_int, H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
-    if prefix == "dwe_":        # (the host emulation of the step kernels, tests/emul/, does not carry the row f-3 functions)
+    P = C.c_void_p
+
+    def fused_amp():
+        # the fused TocabiAMPLower step and reset (csrc/dw_amp_step.h)
+        AB, AC = C.POINTER(DwAmpBuffers), C.POINTER(DwAmpConfig)
+        api["amp_step_begin"] = fn("amp_step_begin", C.c_int, H, AC, AB, P, P, P, P)
+        api["amp_step_mid"] = fn("amp_step_mid", C.c_int, H, AC, AB, P, C.c_int, P)
+        api["amp_step_end"] = fn("amp_step_end", C.c_int, H, AC, AB, P, C.c_int, P, P)
+        api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P, P, P)
+        api["amp_reset_done"] = fn("amp_reset_done", C.c_int, H, AC, AB, C.POINTER(DwAmpResetDraws), P)
+
+    if prefix == "dwe_":        # (the host emulation of the kernels, tests/emul/: the octet library also carries the fused AMP step)
+        if hasattr(lib, "dwe_amp_step_begin"):
+            fused_amp()
         return api
     api["step_obs"] = fn("step_obs", C.c_int, H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p)
     # row f-3: env-side functions of the sibling TOCABI tasks (device pointers as c_void_p, trailing stream)
-    P = C.c_void_p
     api["amp_observations"] = fn("amp_observations", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P)
     api["amp_disc_observations"] = fn("amp_disc_observations", C.c_int, C.c_int, P, P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P)
     api["amp_reward"] = fn("amp_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P)
@@ -149,19 +172,14 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
     api["newwalk_reward"] = fn("newwalk_reward", C.c_int, C.c_int, P, P, P, P, P, P, P, C.c_int, P, C.c_int, C.c_float, C.c_float,
                                C.c_float, P, C.c_int, P, P, P, P, P, P, P, P)
     api["body_positions"] = fn("body_positions", C.c_int, H, C.POINTER(C.c_int32), C.c_int, P, P)
-    if prefix == "dw_":         # (the fused TocabiAMPLower step: HIP library only -- its checker is the torch class, not the C oracle)
-        AB, AC = C.POINTER(DwAmpBuffers), C.POINTER(DwAmpConfig)
-        api["amp_step_pre"] = fn("amp_step_pre", C.c_int, AC, AB, P, P, P, P)
-        api["amp_step_tau"] = fn("amp_step_tau", C.c_int, AC, AB, P, P)
-        api["amp_step_encoder"] = fn("amp_step_encoder", C.c_int, AC, AB, P, P, P)
-        api["amp_step_post"] = fn("amp_step_post", C.c_int, H, AC, AB, P, P)
-        api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P, P, P)
+    if prefix == "dw_":         # (HIP library; the C oracle does not carry the fused step -- its checkers are the torch class and the emulation)
+        fused_amp()
     return api
 
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
            "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions",
-           "amp_step_pre", "amp_step_tau", "amp_step_encoder", "amp_step_post", "amp_reset_rows"]
+           "amp_step_begin", "amp_step_mid", "amp_step_end", "amp_reset_rows", "amp_reset_done"]
 
 
 # name -> (per-env shape, numpy dtype string); gate_acc is the one buffer without an env dimension

@@ -14,7 +14,7 @@ LIB = os.path.join(PKG, "libdyroswalk_hip.so")
 SOURCES = [("dw_hip.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_quad_kernels.hip", []),
            ("dw_oct_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_lane_kernels.hip", []), ("dw_amp.hip", [])]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
-           "dw_quad.h", "dw_quad_kernels.h", "dw_quad_post.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h",
+           "dw_quad.h", "dw_quad_kernels.h", "dw_quad_post.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h",
            "dw_lane_wave.h", "dw_lane_model.h", "dw_lane.h", "dw_lane_kernels.h", "dw_lane_post.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_* pairs, which costs more
 # v_mov operand shuffling than it saves here (static v_mov count halves without it)

@@ -1,0 +1,505 @@
+// dw_amp_step.h -- the fused TocabiAMPLower step and reset (include/dyros_walk.h: dw_amp_step_begin / _mid / _end, dw_amp_reset_rows,
+// dw_amp_reset_done): ONE WAVEFRONT PER ENV, lanes over the env's rows, the rows it computes on staged in LDS.  Written as REGIONS
+// (EnvWave::par): every lane runs a region to its end before any lane starts the next one, regions exchange data through LDS and
+// through the env's rows in global memory only.  On the device a region boundary is a workgroup-scope fence (the workgroup IS the
+// wave); the host emulation (tests/emul/, g++) runs a region as a loop over the 64 lanes -- which is why no value crosses a
+// region boundary in a local variable and why a word that several lanes read is only written in a LATER region.
+//
+// Every expression is the torch class' (isaacgymdyros_amd/tocabi_amp_lower.py, itself pinned to the reference class by replay:
+// tasks/amp/tocabi_amp_lower_base.py:238-305 reset_idx, :540-580 history stacking, :642-748 pre-physics, :750-804 post-physics;
+// tasks/tocabi_amp_lower.py:88-96,144-147,258-272), in its operation order, with fp contraction off: with the caller's draws the
+// fused step gives the torch implementation's bits (tests/test_amp_gpu.py).
+//
+// Random numbers: the caller's (torch's, in the torch implementation's order -- the pinned form) or, with DwAmpConfig.device_draws,
+// drawn here: Philox4x32-10 keyed by DwAmpConfig.seed, counter = (word, env, the env's draw counter DwAmpBuffers.draw_ctr, stream).
+// The draw counter lives in device memory and is advanced by the kernels, so a step recorded in a hipGraph draws fresh numbers at
+// every replay.
+//
+// Histories: DwAmpConfig.hist_ring = 0 keeps the reference's layout (newest slot last, every step shifts the whole row: 960 words
+// read and written per env and step); = 1 keeps both histories as rings (DwAmpBuffers.hist_head: the physical slot of the OLDEST
+// entry), a step writes 48 words and the stacked observation gathers through the head.  Logical slot i is physical slot
+// (head + i) mod (num_his * num_skip) in both (head = 0 without the ring).
+#pragma once
+
+#include "dw_amp.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace dwa {
+
+#if defined(__HIPCC__)
+struct EnvWave {
+    template <class F> DW_HD void par(F &&f) const {
+        f((int)(threadIdx.x & 63u));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+#else
+struct EnvWave {
+    template <class F> void par(F &&f) const { for (int l = 0; l < 64; ++l) f(l); }
+};
+#endif
+
+constexpr int AW = DW_AMP_DISC_BASE + 6;          // discriminator observation of one step (two key bodies)
+constexpr int HIST_STAGE = 64 * 12;               // words of a history row a wave stages (amp_args_ok holds the configuration to it)
+
+struct StepLds {
+    LegModel LM;
+    float root[13], ds[DW_NUM_DOF * 2], cf[DW_NUM_BODIES * 3], obs[DW_AMP_NUM_OBS1], amp[AW], foot[6], qn[12], qv[12], small[64], dvp[DW_NUM_DOF];
+    float acts[12];
+    float hist[HIST_STAGE];                       // a row on its way (linear histories, the discriminator history)
+    long long i64[4];
+    int   touch, head[2];
+};
+enum { SM_NZ = 0, SM_BIAS = 6, SM_QB = 18, SM_CMD = 21, SM_ACT = 24, SM_ACTP = 36, SM_EFF = 48 };          // words of StepLds::small
+
+// the Gym tensors of the bound handle (what dw_simulate reads and writes)
+struct GymRows { float *root_states, *dof_state, *contact_forces, *dof_damping, *dof_armature; };
+
+// ---------------------------------------------------------------------------------------------------------------------- draws
+struct DrawKey { unsigned long long seed; unsigned int env; unsigned long long ctr; };
+enum { DS_RAMP = 1, DS_ENC = 2 /* + substep, < 8 */, DS_ROOTVEL = 12, DS_RESET = 13, DS_DR = 14 };
+DW_HD void draw_block(const DrawKey &k, unsigned int stream, unsigned int idx, unsigned int *c) {
+    c[0] = idx; c[1] = k.env; c[2] = (unsigned int)k.ctr; c[3] = ((unsigned int)(k.ctr >> 32) & 0x0fffffffu) | (stream << 28);
+    dw::philox4x32_10(c, (unsigned int)k.seed, (unsigned int)(k.seed >> 32));
+}
+DW_HD unsigned int draw_u32(const DrawKey &k, unsigned int stream, int w) {
+    unsigned int c[4];
+    draw_block(k, stream, (unsigned int)(w >> 2), c);
+    return c[w & 3];
+}
+// uniform in [0, 1) with 24 bits, as torch.rand makes its floats
+DW_HD float draw_uniform(const DrawKey &k, unsigned int stream, int w) { return (float)(draw_u32(k, stream, w) >> 8) * 5.9604644775390625e-08f; }
+// normal with sigma 0.00016 / 3 (the encoder model's): two per block
+DW_HD float draw_enc_normal(const DrawKey &k, unsigned int stream, int w) {
+    unsigned int c[4];
+    draw_block(k, stream, (unsigned int)(w >> 1), c);
+    return (w & 1) ? dw::enc_normal(c[2], c[3]) : dw::enc_normal(c[0], c[1]);
+}
+// integer in [lo, hi) (torch.randint: a 32-bit word modulo the range)
+DW_HD long long draw_int(const DrawKey &k, unsigned int stream, int w, long long lo, long long hi) {
+    return lo + (long long)(draw_u32(k, stream, w) % (unsigned int)(hi - lo));
+}
+DW_HD DrawKey draw_key(const DwAmpConfig &C, const DwAmpBuffers &B, int e) {
+    DrawKey k;
+    k.seed = C.seed; k.env = (unsigned int)e; k.ctr = C.device_draws ? (unsigned long long)B.draw_ctr[e] : 0ull;
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- pieces
+DW_HD void stage_leg_model(const EnvWave &W, StepLds &S, const dw::DevModel &M) {
+    W.par([&](int l) {
+        for (int i = l; i < LegModel::NBODY * 16; i += 64) {
+            const int b = i >> 4, k = i & 15;
+            if (k < 3) S.LM.pos[b][k] = M.pos[b][k];
+            else if (k < 6) S.LM.axis[b][k - 3] = M.axis[b][k - 3];
+            else if (k < 15) S.LM.rot0[b][k - 6] = M.rot0[b][k - 6];
+            else S.LM.parent[b] = M.parent[b];
+        }
+    });
+}
+
+// One entry appended to a history row of `nh` slots of `w` words (w <= 36): the ring writes the new entry over the oldest slot
+// and moves the head; the linear layout moves every slot one down (every lane reads its words in one region and writes them in
+// the next).  `head_slot`: 0 = action history, 1 = observation history.
+DW_HD void history_append(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, float *row, int nh, int w, const float *entry,
+                          int head_slot, int e) {
+    if (C.hist_ring) {
+        W.par([&](int l) {
+            const int head = B.hist_head[2 * (size_t)e + head_slot];
+            if (l < w) row[(size_t)head * w + l] = entry[l];
+            if (l == 0) S.head[head_slot] = head + 1 >= nh ? 0 : head + 1;
+        });
+        W.par([&](int l) { if (l == 0) B.hist_head[2 * (size_t)e + head_slot] = S.head[head_slot]; });
+    } else {
+        const int len = nh * w;
+        W.par([&](int l) {
+            for (int i = l; i < len; i += 64) S.hist[i] = i < len - w ? row[i + w] : entry[i - (len - w)];
+        });
+        W.par([&](int l) {
+            for (int i = l; i < len; i += 64) row[i] = S.hist[i];
+            if (l == 0) S.head[head_slot] = 0;
+        });
+    }
+}
+DW_HD int hist_phys(int head, int logical, int nh) { const int p = head + logical; return p >= nh ? p - nh : p; }
+
+// the torques of one substep into DwAmpBuffers.tau (:696-724).  Region 1 computes, region 2 moves the FIFO counter (every lane of
+// region 1 read it).
+DW_HD void torques(const EnvWave &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, int e) {
+    W.par([&](int l) {
+        if (l >= DW_NUM_DOF) return;
+        const float q = dof_state[((size_t)DW_NUM_DOF * e + l) * 2], qd = dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1];
+        float tau;
+        if (l >= 12) {
+            tau = B.p_gains[l] * (B.init_angle[l] - q) + B.d_gains[l] * (-qd);          // upper body: PD to the initial pose (:696)
+        } else if (C.pd_control) {
+            const float tar = B.pd_action_offset[l] + B.pd_action_scale[l] * B.actions[12 * (size_t)e + l];
+            tau = B.p_gains[l] * (tar - q) + B.d_gains[l] * (-qd);
+        } else {
+            const int64_t sl0 = B.simul_len[e], dl = B.delay_idx[e];
+            const float m = B.motor_efforts[l];
+            float lower = B.actions[12 * (size_t)e + l] * m * B.power_scale[12 * (size_t)e + l];
+            lower = fmaxf(fminf(lower, m), -m);
+            // delayed-torque FIFO (:712-724), column l: shift, append, read `delay_idx` back once the FIFO has filled that far
+            float *col = B.action_log + (size_t)C.log_slots * 12 * e + l;
+            int64_t sl = sl0 + 1;
+            sl = sl > C.log_slots ? C.log_slots : (sl < 0 ? 0 : sl);
+            float delayed = 0.0f;
+            for (int s = 0; s < C.log_slots; ++s) {
+                const float v = s + 1 < C.log_slots ? col[(size_t)12 * (s + 1)] : lower;
+                col[(size_t)12 * s] = v;
+                const int64_t want = sl > dl ? dl : (int64_t)C.log_slots - sl;
+                if (s == want) delayed = v;
+            }
+            tau = C.noise ? delayed : lower;
+        }
+        B.tau[(size_t)DW_NUM_DOF * e + l] = tau;
+    });
+    if (!C.pd_control) {
+        W.par([&](int l) {
+            if (l != 0) return;
+            const int64_t sl = B.simul_len[e] + 1;
+            B.simul_len[e] = sl > C.log_slots ? C.log_slots : (sl < 0 ? 0 : sl);
+        });
+    }
+}
+
+// the encoder model after one substep (:728-736): z = the caller's normal draws [N,33] or nullptr (device draws / no noise).
+// `keep`: also leave the leg joints' reading in S.qn / S.qv (the post-physics half of dw_amp_step_end reads them from there).
+DW_HD void encoder(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep,
+                   bool keep, int e) {
+    W.par([&](int l) {
+        if (l >= DW_NUM_DOF) return;
+        const size_t g = (size_t)DW_NUM_DOF * e + l;
+        const float q = dof_state[g * 2];
+        float qn = q;
+        if (C.noise) {
+            const float zz = z ? z[g] : draw_enc_normal(draw_key(C, B, e), DS_ENC + (unsigned int)substep, l);
+            qn = q + fminf(fmaxf(zz, -0.00016f), 0.00016f);
+        }
+        const float d = qn - B.qpos_pre[g];
+        const float qv = C.gpu_div ? d * C.inv_dt : d / C.dt;
+        B.qpos_noise[g] = qn;
+        B.qvel_noise[g] = qv;
+        B.qpos_pre[g] = qn;
+        if (keep && l < 12) { S.qn[l] = qn; S.qv[l] = qv; }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- step
+// dw_amp_step_begin: action clamp + record + action history, command ramp (:642-693), then the torques of the first substep.
+DW_HD void step_begin(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *actions_in,
+                      const int64_t *ramp_dur, const float *ramp_u, int e) {
+    W.par([&](int l) {
+        if (l < 12) {
+            float a = actions_in[12 * (size_t)e + l];
+            a = fminf(fmaxf(a, -C.clip_actions), C.clip_actions);
+            S.acts[l] = a;
+            B.actions[12 * (size_t)e + l] = a;
+        }
+        // command ramp (:676-693), the branch of the host class that draws for every env
+        if (C.vel_change && l < 3) {
+            const int half = (int)(C.max_episode_length / 2), when = (int)(C.max_episode_length / 4 - 1);
+            const bool change = fmodf(B.epi_len[e], (float)half) == (float)when;
+            int64_t dur = B.vel_change_duration[e], cur = B.cur_vel_change_duration[e];
+            float start = B.start_target_vel[3 * (size_t)e + l], fin = B.final_target_vel[3 * (size_t)e + l], cmd = B.commands[3 * (size_t)e + l];
+            if (change) {
+                const DrawKey k = draw_key(C, B, e);
+                dur = ramp_dur ? ramp_dur[e] : draw_int(k, DS_RAMP, 0, 1, 250);
+                cur = 0;
+                start = cmd;
+                const float u = ramp_u ? ramp_u[3 * (size_t)e + l] : draw_uniform(k, DS_RAMP, 1 + l);
+                fin = C.cmd_scale[l] * u + C.cmd_lo[l];
+            }
+            const bool mask = cur < dur;
+            const float ramp = start + (fin - start) * (float)cur / (float)dur;
+            if (mask) cmd = ramp;
+            B.start_target_vel[3 * (size_t)e + l] = start;
+            B.final_target_vel[3 * (size_t)e + l] = fin;
+            B.commands[3 * (size_t)e + l] = cmd;
+            if (l == 0) { S.i64[0] = dur; S.i64[1] = cur + (mask ? 1 : 0); }
+        }
+    });
+    if (C.vel_change) {
+        W.par([&](int l) {
+            if (l == 0) { B.vel_change_duration[e] = S.i64[0]; B.cur_vel_change_duration[e] = S.i64[1]; }
+        });
+    }
+    history_append(W, S, C, B, B.action_history + (size_t)C.num_his * C.num_skip * 12 * e, C.num_his * C.num_skip, 12, S.acts, 0, e);
+    torques(W, C, B, dof_state, e);
+}
+
+// dw_amp_step_mid: between two substeps -- the encoder model of the one that ended, the torques of the one that starts
+DW_HD void step_mid(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int e) {
+    encoder(W, S, C, B, dof_state, z, substep, false, e);
+    torques(W, C, B, dof_state, e);
+}
+
+// dw_amp_step_end: the encoder model of the last substep, then post-physics (:750-804 + the subclass' :88-96): counters, foot
+// positions, observation + history stacking, reward, termination, time-outs, the discriminator observation and its history.
+DW_HD void step_end(const EnvWave &W, StepLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G, const float *z,
+                    int substep, const float *rootvel_noise, int e) {
+    stage_leg_model(W, S, M);
+    encoder(W, S, C, B, G.dof_state, z, substep, true, e);
+    const int NH = C.num_his * C.num_skip;
+    // the env's rows staged in LDS once: the per-env functions below are serial code on one lane each, and a dependent global load
+    // per operand is what they must not pay
+    W.par([&](int l) {
+        if (l < 13) S.root[l] = G.root_states[13 * (size_t)e + l];
+        for (int i = l; i < DW_NUM_DOF * 2; i += 64) S.ds[i] = G.dof_state[(size_t)DW_NUM_DOF * 2 * e + i];
+        for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.cf[i] = G.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
+        if (l < 12) {
+            S.small[SM_BIAS + l] = B.qpos_bias[12 * (size_t)e + l];
+            S.small[SM_ACT + l] = B.actions[12 * (size_t)e + l]; S.small[SM_ACTP + l] = B.actions_pre[12 * (size_t)e + l];
+            S.small[SM_EFF + l] = B.motor_efforts[l];
+        }
+        if (l < 6) {
+            float nz = 0.0f;
+            if (rootvel_noise) nz = rootvel_noise[6 * (size_t)e + l];
+            else if (C.noise && C.device_draws) nz = draw_uniform(draw_key(C, B, e), DS_ROOTVEL, l) * 0.05f - 0.025f;
+            S.small[SM_NZ + l] = nz;
+        }
+        if (l < 3) { S.small[SM_QB + l] = B.quat_bias[3 * (size_t)e + l]; S.small[SM_CMD + l] = B.commands[3 * (size_t)e + l]; }
+        if (l < DW_NUM_DOF) S.dvp[l] = B.dof_vel_pre[(size_t)DW_NUM_DOF * e + l];
+        if (l == 0) S.touch = 0;
+    });
+    // counters (:751-752; epi_len: the last line of pre_physics_step); four independent pieces of serial arithmetic on four lanes:
+    // the two foot positions (the rigid-body rows the task reads), this step's observation, the reward; non-foot bodies in contact
+    W.par([&](int l) {
+        const float *r = S.root, *ds = S.ds, *cf = S.cf;
+        if (l < 2) {
+            float p[3];
+            body_position(S.LM, r, ds, 0, l == 0 ? 6 : 12, p);          // (the staged rows are env 0 of their own little tensors)
+            for (int i = 0; i < 3; ++i) {
+                S.foot[3 * l + i] = p[i];
+                B.foot_pos[((size_t)2 * e + l) * 3 + i] = p[i];
+                B.rigid_body_pos[((size_t)DW_NUM_BODIES * e + (l == 0 ? 8 : 16)) * 3 + i] = p[i];
+            }
+        } else if (l == 2) {
+            observations_row(r, &S.small[SM_NZ], S.qn, &S.small[SM_BIAS], &S.small[SM_QB], S.qv, &S.small[SM_CMD], S.obs);
+        } else if (l == 3) {
+            reward_row(r, ds + 1, 2, S.dvp, &S.small[SM_CMD], &S.small[SM_ACT], &S.small[SM_ACTP], &S.small[SM_EFF], cf, B.total_mass[e],
+                       B.rew_buf + e, B.reward_values + 9 * (size_t)e);
+        }
+        if (l >= 4 && l < 7) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (l - 4)] = r[l - 4];
+        if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
+        if (l < DW_NUM_BODIES && l != 8 && l != 16 && (cf[3 * l] > 1.0f || cf[3 * l + 1] > 1.0f || cf[3 * l + 2] > 1.0f)) S.touch = 1;
+        if (l == 63) { B.progress_buf[e] += 1; B.randomize_buf[e] += 1; B.epi_len[e] += 1.0f; }
+    });
+    W.par([&](int l) {
+        const float *r = S.root, *ds = S.ds;
+        // the encoder reading takes the bias (the reference's observation function adds it in place, :945)
+        if (l >= 2 && l < 14) B.qpos_noise[(size_t)DW_NUM_DOF * e + (l - 2)] = S.qn[l - 2] + S.small[SM_BIAS + (l - 2)];
+        if (l >= 14 && l < 14 + DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + (l - 14)] = S.obs[l - 14];
+        // termination (:1025-1069) on lane 0, the discriminator observation (tasks/tocabi_amp_lower.py:310-350) on lane 1
+        if (l == 0) {
+            const int64_t prog = B.progress_buf[e];
+            int64_t term = 0;
+            if (C.enable_early_termination) {
+                bool fall_height = r[2] < C.termination_height;
+                fall_height = fall_height || S.foot[2] > 0.5f || S.foot[5] > 0.5f;
+                bool fallen = (S.touch != 0) || fall_height;
+                const float q0[4] = {r[3], r[4], r[5], r[6]};
+                fallen = fallen || fabsf(dw::quat_err(q0)) > (float)(3.141592 / 4.0);
+                fallen = fallen && (prog > 1);
+                term = fallen ? 1 : 0;
+            }
+            const int64_t rs = ((float)prog >= C.max_episode_length - 1.0f) ? 1 : term;
+            B.terminate_buf[e] = term;
+            B.reset_buf[e] = rs;
+            B.timeout_buf[e] = (uint8_t)(((float)prog >= C.max_episode_length - 1.0f) && rs != 0);
+        } else if (l == 1) {
+            disc_observations_row(r, ds, ds + 1, 2, C.local_root_obs, S.foot, 2, S.amp);
+        }
+    });
+    // observation history and the stacked observation (:540-580): obs slots S (i + 1) - 1, action slots S (i + 1), i < H - 1
+    float *oh = B.obs_history + (size_t)NH * DW_AMP_NUM_OBS1 * e;
+    history_append(W, S, C, B, oh, NH, DW_AMP_NUM_OBS1, S.obs, 1, e);
+    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
+    W.par([&](int l) {
+        const float *ah = B.action_history + (size_t)NH * 12 * e;
+        const int oh_head = S.head[1], ah_head = C.hist_ring ? B.hist_head[2 * (size_t)e] : 0;
+        float *ob = B.obs_buf + (size_t)num_obs * e, *oo = B.obs_out + (size_t)num_obs * e;
+        for (int i = l; i < num_obs; i += 64) {
+            float v;
+            if (i < DW_AMP_NUM_OBS1 * C.num_his) {
+                const int slot = i / DW_AMP_NUM_OBS1, k = i - DW_AMP_NUM_OBS1 * slot;
+                v = oh[(size_t)hist_phys(oh_head, C.num_skip * (slot + 1) - 1, NH) * DW_AMP_NUM_OBS1 + k];
+            } else {
+                const int j = i - DW_AMP_NUM_OBS1 * C.num_his, slot = j / 12, k = j - 12 * slot;
+                v = ah[(size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + k];
+            }
+            ob[i] = v;
+            oo[i] = fminf(fmaxf(v, -C.clip_obs), C.clip_obs);
+        }
+        // what the next step compares against
+        if (l < DW_NUM_DOF) B.dof_vel_pre[(size_t)DW_NUM_DOF * e + l] = S.ds[2 * l + 1];
+        if (l < 12) B.actions_pre[12 * (size_t)e + l] = S.small[SM_ACT + l];
+        // discriminator observation history (tasks/tocabi_amp_lower.py:88-96): slot k -> k + 1, the newest into slot 0
+        const float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
+        for (int i = l; i < C.amp_steps * AW; i += 64) S.hist[i] = i >= AW ? ab[i - AW] : S.amp[i];
+    });
+    W.par([&](int l) {
+        float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
+        for (int i = l; i < C.amp_steps * AW; i += 64) ab[i] = S.hist[i];
+        if (l < AW) B.amp_obs1[(size_t)AW * e + l] = S.amp[l];
+        if (l == 63 && C.device_draws) B.draw_ctr[e] += 1;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- reset
+// Where a reset env's draws come from: the caller's RAW uniforms (rows of the arrays at `row`: position in an id list for
+// dw_amp_reset_rows, the env for dw_amp_reset_done) or the generator.
+struct ResetSrc {
+    const float *ps, *cx, *cy, *cyaw, *qb, *quatb, *damp, *arm;
+    const int64_t *ptime, *didx;
+    const float *rootvel_noise;          // [N,6], by env
+    size_t row;
+    bool dr;                             // dof-property randomisation inside the kernel (dw_amp_reset_done)
+    bool power;                          // draw power_scale
+};
+
+// reset_idx of env e (tasks/amp/tocabi_amp_lower_base.py:238-305 with the default state initialisation, then
+// tasks/tocabi_amp_lower.py:144-147,258-272)
+DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G,
+                     const ResetSrc &R, int e) {
+    enum { SO_QN = 0, SO_QV = 12, SO_BIAS = 24, SO_QB = 36, SO_CMD = 39, SO_NZ = 42 };
+    const int NH = C.num_his * C.num_skip;
+    const bool dev = C.device_draws != 0;
+    stage_leg_model(W, S, M);
+    W.par([&](int l) {
+        const DrawKey k = draw_key(C, B, e);
+        // what the reset observation is made of: the episode's LAST encoder reading, biases and command (the reference computes it
+        // before it draws the new ones, :253 before :266-279)
+        if (l < 12) {
+            S.small[SO_QN + l] = B.qpos_noise[(size_t)DW_NUM_DOF * e + l]; S.small[SO_QV + l] = B.qvel_noise[(size_t)DW_NUM_DOF * e + l];
+            S.small[SO_BIAS + l] = B.qpos_bias[12 * (size_t)e + l];
+        }
+        if (l < 3) { S.small[SO_QB + l] = B.quat_bias[3 * (size_t)e + l]; S.small[SO_CMD + l] = B.commands[3 * (size_t)e + l]; }
+        if (l < 6) {
+            float nz = 0.0f;
+            if (R.rootvel_noise) nz = R.rootvel_noise[6 * (size_t)e + l];
+            else if (C.noise && dev) nz = draw_uniform(k, DS_RESET, 40 + l) * 0.05f - 0.025f;
+            S.small[SO_NZ + l] = nz;
+        }
+        // the Gym tensors' rows: initial root state, initial pose at rest, no contact (_reset_actors, :611-626)
+        if (l < 13) { const float v = B.initial_root_states[13 * (size_t)e + l]; S.root[l] = v; G.root_states[13 * (size_t)e + l] = v; }
+        if (l < DW_NUM_DOF) {
+            const float q0 = B.init_angle[l];
+            S.ds[2 * l] = q0; S.ds[2 * l + 1] = 0.0f;
+            G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2] = q0; G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1] = 0.0f;
+        }
+        for (int i = l; i < DW_NUM_BODIES * 3; i += 64) G.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i] = 0.0f;
+        // (the draws arrive as raw uniforms; the values are formed with torch's arithmetic: `(hi - lo) * u + lo` with the scalars
+        //  rounded to float32 first, `x / s` as a multiplication by 1.0f / s on a GPU and a division on a CPU)
+        if (R.power && l < 12) {
+            const float u = R.ps ? R.ps[12 * R.row + l] : draw_uniform(k, DS_RESET, l);
+            B.power_scale[12 * (size_t)e + l] = (float)(1.2 - 0.8) * u + (float)0.8;
+        }
+        // dof properties (apply_randomizations, tasks/base/vec_task.py:519-733): additive damping, scaled armature, from the
+        // nominal values, for a resetting env whose randomize_buf has reached the frequency
+        if (R.dr && l < DW_NUM_DOF && B.randomize_buf[e] >= (int64_t)C.dr_frequency) {
+            if (C.dr_damping) {
+                const float u = R.damp ? R.damp[(size_t)DW_NUM_DOF * R.row + l] : draw_uniform(k, DS_DR, l);
+                G.dof_damping[(size_t)DW_NUM_DOF * e + l] = B.nominal_damping[l] + ((C.dr_damping_range[1] - C.dr_damping_range[0]) * u + C.dr_damping_range[0]);
+            }
+            if (C.dr_armature) {
+                const float u = R.arm ? R.arm[(size_t)DW_NUM_DOF * R.row + l] : draw_uniform(k, DS_DR, DW_NUM_DOF + l);
+                G.dof_armature[(size_t)DW_NUM_DOF * e + l] = B.nominal_armature[l] * ((C.dr_armature_range[1] - C.dr_armature_range[0]) * u + C.dr_armature_range[0]);
+            }
+        }
+    });
+    W.par([&](int l) {
+        const float *r = S.root, *ds = S.ds;
+        if (l < 2) {          // the rigid-body rows of the new state
+            float p[3];
+            body_position(S.LM, r, ds, 0, l == 0 ? 6 : 12, p);
+            for (int i = 0; i < 3; ++i) {
+                S.foot[3 * l + i] = p[i];
+                B.foot_pos[((size_t)2 * e + l) * 3 + i] = p[i];
+                B.rigid_body_pos[((size_t)DW_NUM_BODIES * e + (l == 0 ? 8 : 16)) * 3 + i] = p[i];
+            }
+        } else if (l == 2) {
+            observations_row(r, &S.small[SO_NZ], &S.small[SO_QN], &S.small[SO_BIAS], &S.small[SO_QB], &S.small[SO_QV], &S.small[SO_CMD], S.obs);
+        }
+        if (l >= 4 && l < 7) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (l - 4)] = r[l - 4];
+        if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
+        if (R.dr && l == 63 && B.randomize_buf[e] >= (int64_t)C.dr_frequency) B.randomize_buf[e] = 0;
+    });
+    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
+    W.par([&](int l) {
+        if (l == 1) disc_observations_row(S.root, S.ds, S.ds + 1, 2, C.local_root_obs, S.foot, 2, S.amp);
+        if (l >= 2 && l < 2 + DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + (l - 2)] = S.obs[l - 2];
+        // the reset env's observation: every history slot shows the reset observation, the action slots what the action history
+        // still holds; only then are the two histories zeroed (:296-297)
+        const float *ah = B.action_history + (size_t)NH * 12 * e;
+        const int ah_head = C.hist_ring ? B.hist_head[2 * (size_t)e] : 0;
+        float *ob = B.obs_buf + (size_t)num_obs * e;
+        for (int i = l; i < num_obs; i += 64) {
+            float v;
+            if (i < DW_AMP_NUM_OBS1 * C.num_his) v = S.obs[i % DW_AMP_NUM_OBS1];
+            else { const int j = i - DW_AMP_NUM_OBS1 * C.num_his, slot = j / 12, kk = j - 12 * slot; v = ah[(size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + kk]; }
+            ob[i] = v;
+            if (B.obs_out && R.dr) B.obs_out[(size_t)num_obs * e + i] = fminf(fmaxf(v, -C.clip_obs), C.clip_obs);
+        }
+    });
+    W.par([&](int l) {
+        const DrawKey k = draw_key(C, B, e);
+        for (int i = l; i < NH * DW_AMP_NUM_OBS1; i += 64) B.obs_history[(size_t)NH * DW_AMP_NUM_OBS1 * e + i] = 0.0f;
+        for (int i = l; i < NH * 12; i += 64) B.action_history[(size_t)NH * 12 * e + i] = 0.0f;
+        for (int i = l; i < C.log_slots * 12; i += 64) B.action_log[(size_t)C.log_slots * 12 * e + i] = 0.0f;
+        if (l < DW_NUM_DOF) {
+            const size_t g = (size_t)DW_NUM_DOF * e + l;
+            B.dof_vel_pre[g] = 0.0f; B.qpos_noise[g] = B.init_angle[l]; B.qpos_pre[g] = B.init_angle[l]; B.qvel_noise[g] = 0.0f;
+        }
+        if (l < 12) {
+            B.actions_pre[12 * (size_t)e + l] = 0.0f;
+            float v = 0.0f;
+            if (C.noise) {
+                const float u = R.qb ? R.qb[12 * R.row + l] : draw_uniform(k, DS_RESET, 12 + l);
+                const float x = u * 6.28f;
+                v = (C.gpu_div ? x * (1.0f / 100.0f) : x / 100.0f) - (float)(3.14 / 100);
+            }
+            B.qpos_bias[12 * (size_t)e + l] = v;
+        }
+        if (l < 3) {
+            float u;
+            if (l == 0) u = R.cx ? R.cx[R.row] : draw_uniform(k, DS_RESET, 24);
+            else if (l == 1) u = R.cy ? R.cy[R.row] : draw_uniform(k, DS_RESET, 25);
+            else u = R.cyaw ? R.cyaw[R.row] : draw_uniform(k, DS_RESET, 26);
+            B.commands[3 * (size_t)e + l] = C.cmd_scale[l] * u + C.cmd_lo[l];
+            float v = 0.0f;
+            if (C.noise) {
+                const float uq = R.quatb ? R.quatb[3 * R.row + l] : draw_uniform(k, DS_RESET, 28 + l);
+                const float x = uq * 6.28f;
+                v = (C.gpu_div ? x * (1.0f / 150.0f) : x / 150.0f) - (float)(3.14 / 150);
+            }
+            B.quat_bias[3 * (size_t)e + l] = v;
+        }
+        if (l == 63) {
+            B.progress_buf[e] = 0; B.reset_buf[e] = 0; B.terminate_buf[e] = 0;
+            B.epi_len_log[e] = B.epi_len[e]; B.epi_len[e] = 0.0f;
+            B.perturbation_count[e] = 0; B.pert_on[e] = 0;
+            B.perturb_timing[e] = R.ptime ? R.ptime[R.row] : draw_int(k, DS_RESET, 32, 0, (long long)(8 / 0.002));
+            B.delay_idx[e] = R.didx ? R.didx[R.row] : draw_int(k, DS_RESET, 33, C.delay_idx_range[0], C.delay_idx_range[1]);
+            B.simul_len[e] = 0;
+            if (C.hist_ring) { B.hist_head[2 * (size_t)e] = 0; B.hist_head[2 * (size_t)e + 1] = 0; }
+        }
+        // discriminator history of a default start: every slot the current observation (tasks/tocabi_amp_lower.py:258-272)
+        float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
+        for (int i = l; i < C.amp_steps * AW; i += 64) ab[i] = S.amp[i % AW];
+        if (l < AW) B.amp_obs1[(size_t)AW * e + l] = S.amp[l];
+    });
+    if (dev) W.par([&](int l) { if (l == 0) B.draw_ctr[e] += 1; });
+}
+
+}  // namespace dwa
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

@@ -373,8 +373,16 @@ class DyrosDynamicWalk(VecTask):
             return
         nz = noise.data_ptr() if noise is not None else 0
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
-        _lib.check(self._api, self._api["reset_idx"](self._h, ids.data_ptr(), int(ids.numel()), nz, self._step_count, stream))
+        _lib.check(self._api, self._api["reset_idx"](self._h, ids.data_ptr(), int(ids.numel()), nz, self._current_step(), stream))
         # (reset_idx does not touch the observations: the reference recomputes them in the next step's post-physics, :655-669)
+
+    def _current_step(self) -> int:
+        """The step index that keys the in-kernel RNG.  With cfg sim.mi355.device_step_counter the truth is the device word:
+        a replayed hipGraph advances it without running any Python, so the host's count is stale (one host sync here; do not
+        call while a capture is open)."""
+        if self._step_dev is not None:
+            self._step_count = int(self._step_dev.item())
+        return self._step_count
 
     def kernel_info(self) -> dict:
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
@@ -404,7 +412,7 @@ class DyrosDynamicWalk(VecTask):
         RNG.  The reference never checkpoints simulation state (rl_games only saves the policy); here it is free."""
         torch.cuda.synchronize(self._tdev)
         d = {k: v.detach().clone() for k, v in self._buf.items()}
-        d["_step_count"] = self._step_count
+        d["_step_count"] = self._current_step()
         return d
 
     def load_state_dict(self, d):

@@ -16,9 +16,11 @@ What runs where.  `gym.simulate` is dw_simulate of the bound physics handle (one
 DyrosDynamicWalk step fuses); observation, reward and termination are one HIP launch each; the rows of the rigid-body state
 tensor they need (base, the two foot links) come from dw_body_positions.  The bookkeeping between them -- history shifts,
 the command ramp, the torque FIFO -- is either ~100 elementwise torch launches per step on [N,12]..[N,480] tensors (the form the
-replay tests pin to the reference class) or, with cfg sim.mi355.amp_fused, five HIP kernels that give the torch form's bits
-(dw_amp_step_pre / _tau / _encoder / _post, dw_amp_reset_rows); enable_graph_step() records a step of
-either form in a hipGraph.  Random draws are torch's device generator, as in the reference; the generator and
+replay tests pin to the reference class) or, with cfg sim.mi355.amp_fused, HIP kernels that give the torch form's bits
+(dw_amp_step_begin / _mid / _end around the physics launches, dw_amp_reset_rows / _done; csrc/dw_amp_step.h, DESIGN.md section 9;
+histories as rings, sim.mi355.amp_hist_ring); enable_graph_step() records a step of either form in a hipGraph.  Random draws are
+torch's device generator, as in the reference -- or, with cfg sim.mi355.amp_device_draws, made inside the fused kernels (no draw
+launches, reset_done() one launch; same distributions, another stream).  The generator and
 `simulate` are injectable, and tests/test_amp_gpu.py replays the reference CLASS' recorded draws and physics states through this
 class for 60 steps (tests/golden/amp_class_ref.npz): every state field, the torques handed to the engine and the reset flow are
 bit-identical, the observation and reward to the rounding of atan2f / expf.  Four things that replay found and that are now as
@@ -270,6 +272,20 @@ class TocabiAMPLower(VecTask):
         # (the fused reset makes the reference's draws in the reference's order, so it can be switched on by itself and replayed
         #  against the reference class; the fused step cannot: its command ramp draws for every env)
         self._fused_reset = bool(cfg["sim"].get("mi355", {}).get("amp_fused_reset", self._fused))
+        # cfg sim.mi355.amp_hist_ring (fused step only, default on with it): action_history / obs_history are rings in memory
+        # (include/dyros_walk.h DwAmpConfig.hist_ring); history_linear() gives the reference's layout.
+        # cfg sim.mi355.amp_device_draws (fused step only): every draw of step() and reset_done() is made inside the kernels
+        # (Philox keyed by the seed, the env and the env's draw counter) instead of by torch's generator: no draw kernels, no host
+        # round trip; same distributions, another stream -- the form bench.py measures.
+        mi = cfg["sim"].get("mi355", {})
+        self._hist_ring = bool(mi.get("amp_hist_ring", self._fused)) and self._fused
+        self._device_draws = bool(mi.get("amp_device_draws", False))
+        if self._device_draws and not (self._fused and self._fused_reset):
+            raise ValueError("sim.mi355.amp_device_draws needs amp_fused (step and reset)")
+        if self._device_draws and self._state_init != "Default":
+            raise ValueError("sim.mi355.amp_device_draws: the fused reset covers stateInit 'Default' only")
+        self._hist_head = torch.zeros(N, 2, dtype=torch.int32, device=dev)
+        self._draw_ctr = torch.zeros(N, dtype=torch.int64, device=dev)
         self._tau = torch.zeros(N, 33, **f)
         self._obs_out = torch.zeros(N, self.num_obs, **f)
         self._amp_obs1 = torch.zeros(N, NUM_AMP_OBS_PER_STEP, **f)
@@ -655,6 +671,16 @@ class TocabiAMPLower(VecTask):
         c.inv_dt, c.dt, c.gpu_div = float(np.float32(1.0 / self.dt)), float(self.dt), int(self._gpu_div)
         for i, (lo, hi) in enumerate((self.c_x, self.c_y, self.c_yaw)):
             c.cmd_lo[i], c.cmd_scale[i] = float(lo), float(hi - lo)
+        c.hist_ring, c.device_draws, c.randomize = int(self._hist_ring), int(self._device_draws), int(bool(self.randomize))
+        c.seed = int(self.cfg.get("seed", 42)) & (2 ** 64 - 1)
+        c.delay_idx_range[0], c.delay_idx_range[1] = 1 + int(0.002 / self.dt), 1 + round(0.01 / self.dt)
+        dofp = self.randomization_params["actor_params"]["humanoid"].get("dof_properties", {}) if self.randomize else {}
+        c.dr_frequency = int(self.randomization_params.get("frequency", 1))
+        c.dr_damping, c.dr_armature = int("damping" in dofp), int("armature" in dofp)
+        if "damping" in dofp:
+            c.dr_damping_range[0], c.dr_damping_range[1] = (float(v) for v in dofp["damping"]["range"])
+        if "armature" in dofp:
+            c.dr_armature_range[0], c.dr_armature_range[1] = (float(v) for v in dofp["armature"]["range"])
         t = {"actions": self.actions, "actions_pre": self.actions_pre, "action_history": self.action_history, "obs_history": self.obs_history,
              "commands": self.commands, "start_target_vel": self.start_target_vel, "final_target_vel": self.final_target_vel,
              "vel_change_duration": self.vel_change_duration, "cur_vel_change_duration": self.cur_vel_change_duration, "epi_len": self.epi_len,
@@ -668,7 +694,8 @@ class TocabiAMPLower(VecTask):
              "p_gains": self.p_gains, "d_gains": self.d_gains, "init_angle": self.init_angle,
              "pd_action_offset": self._pd_action_offset if self._pd_control else None, "pd_action_scale": self._pd_action_scale if self._pd_control else None,
              "epi_len_log": self.epi_len_log, "perturbation_count": self.perturbation_count, "perturb_timing": self.perturb_timing,
-             "pert_on": self.pert_on, "initial_root_states": self._initial_root_states}
+             "pert_on": self.pert_on, "initial_root_states": self._initial_root_states, "hist_head": self._hist_head, "draw_ctr": self._draw_ctr,
+             "nominal_damping": self._nominal_damping, "nominal_armature": self._nominal_armature}
         b = abi.DwAmpBuffers()
         for name in abi.AMP_BUFFER_NAMES:
             v = t[name]
@@ -679,26 +706,32 @@ class TocabiAMPLower(VecTask):
         return c, b
 
     def _step_fused(self, actions):
-        """One step with the bookkeeping in four kernels; the draws are torch's, in the order of the torch implementation's
-        recorded branch (pre_physics_step), so both give the same numbers (tests/test_amp_gpu.py)."""
+        """One step with the bookkeeping in three kernels (dw_amp_step_begin / _mid / _end) around the physics launches.  The draws
+        are torch's, in the order of the torch implementation's recorded branch (pre_physics_step), so both give the same numbers
+        (tests/test_amp_gpu.py) -- or, with sim.mi355.amp_device_draws, the kernels' own."""
         if self.perturb:
             raise ValueError("amp_fused: env.perturbation is not part of the fused step")
-        N, api, st = self.num_envs, self._api, self._stream()
+        N, api, st, h = self.num_envs, self._api, self._stream(), self._phys._h
         c, b = self._fused_tables()
         a = actions.to(self._tdev).float().contiguous()
+        dd = self._device_draws
         rd = ru = None
-        if self.vel_change:
+        if self.vel_change and not dd:
             rd = self._rng.randint(1, 250, (N,))
             ru = torch.stack((self._rand(N), self._rand(N), self._rand(N)), dim=-1).contiguous()
-        self._chk(api["amp_step_pre"](C.byref(c), C.byref(b), _p(a), _p(rd), _p(ru), st))
-        for _ in range(self.control_freq_inv):
-            self._chk(api["amp_step_tau"](C.byref(c), C.byref(b), _p(self._dof_state), st))
+        self._chk(api["amp_step_begin"](h, C.byref(c), C.byref(b), _p(a), _p(rd), _p(ru), st))
+        K = self.control_freq_inv
+        z = None
+        for k in range(K):
             self._simulate(self._tau, None)
-            z = self._rng.normal((N, 33), 0.00016 / 3.0).contiguous() if self.noise else None
-            self._chk(api["amp_step_encoder"](C.byref(c), C.byref(b), _p(self._dof_state), _p(z), st))
+            z = self._rng.normal((N, 33), 0.00016 / 3.0).contiguous() if self.noise and not dd else None
+            if k + 1 < K:
+                self._chk(api["amp_step_mid"](h, C.byref(c), C.byref(b), _p(z), k + 1, st))
         self.time_step += 1
-        nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
-        self._chk(api["amp_step_post"](self._phys._h, C.byref(c), C.byref(b), _p(nz), st))
+        nz = None
+        if not dd:
+            nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
+        self._chk(api["amp_step_end"](h, C.byref(c), C.byref(b), _p(z), K - 1, _p(nz), st))
         self.extras["reward_names"] = list(REWARD_NAMES)
         self.extras["reward_values"] = self._reward_values
         self.extras["terminate"] = self._terminate_buf
@@ -706,6 +739,34 @@ class TocabiAMPLower(VecTask):
         self.extras["time_outs"] = self.timeout_buf
         self.obs_dict["obs"] = self._obs_out
         return self.obs_dict, self.rew_buf, self.reset_buf, self.extras
+
+    def history_linear(self):
+        """(action_history, obs_history) in the reference's layout (newest slot last), whatever the layout in memory: with
+        sim.mi355.amp_hist_ring the two tensors are rings and this gathers through the heads."""
+        if not self._hist_ring:
+            return self.action_history, self.obs_history
+        NH = self.num_obs_his * self.num_obs_skip
+        ar = torch.arange(NH, device=self._tdev).unsqueeze(0)
+        out = []
+        for k, (t, w) in enumerate(((self.action_history, NUM_ACTIONS), (self.obs_history, NUM_OBS))):
+            idx = (self._hist_head[:, k].long().unsqueeze(1) + ar) % NH
+            out.append(torch.gather(t.view(self.num_envs, NH, w), 1, idx.unsqueeze(-1).expand(-1, -1, w)).reshape(self.num_envs, NH * w))
+        return tuple(out)
+
+    def reset_done(self):
+        """VecTask.reset_done (tasks/base/vec_task.py:376-391).  With the fused reset and device draws: ONE launch over all envs
+        (dw_amp_reset_done acts on the envs whose reset_buf is set), queued before the host asks which envs those were."""
+        if not (self._device_draws and self._state_init == "Default"):
+            return super().reset_done()
+        done = self.reset_buf.clone()
+        c, b = self._fused_tables()
+        self._chk(self._api["amp_reset_done"](self._phys._h, C.byref(c), C.byref(b), None, self._stream()))
+        self.time_step = 0
+        self.obs_dict["obs"] = self._obs_out
+        ids = done.nonzero(as_tuple=False).flatten()
+        if len(ids) > 0:
+            self._reset_default_env_ids = ids
+        return self.obs_dict, ids
 
     def _step_body(self, actions):
         if self._fused:

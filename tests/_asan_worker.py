@@ -36,3 +36,15 @@ sim.buf['dof_state'][:, :, 0] = q
 sim.simulate(np.zeros((17,33),np.float32))
 assert (np.linalg.norm(sim.buf['contact_forces'], axis=2) > 1).any(axis=1).sum() >= 8
 print('simulate / reset_idx / step(noise=None) ok')
+# the fused TocabiAMPLower step and reset (csrc/dw_amp_step.h; exported by the octet emulation): rings and the shifting layout,
+# device draws and the caller's, a ragged env count, episodes short enough that every env resets
+if KIND == 'oct':
+    from amp_emul import AmpEmul
+    for ring in (True, False):
+        env = AmpEmul(emul_backend.EmulSim(5, quad='oct', self_collision=0), 5, hist_ring=ring, episode_length=6.0, pd_control=not ring)
+        rng = np.random.default_rng(0)
+        for t in range(14):
+            env.reset_done()
+            env.step((rng.random((5, 12), dtype=np.float32) * 2 - 1) * 1.2)
+        assert np.isfinite(env.a['obs_buf']).all()
+    print('fused amp step / reset ok')

@@ -149,3 +149,5 @@ int dwe_quad_schedule(DwHandle *h, int32_t *out, int32_t cap) {
 }
 
 }  // extern "C"
+
+#include "dw_emul_amp.inc"          // dwe_amp_step_begin / _mid / _end, dwe_amp_reset_rows / _done on this library's handle

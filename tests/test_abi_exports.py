@@ -31,7 +31,9 @@ def test_amp_step_structs_mirror_the_header():
     blk = strip(src[src.index("typedef struct DwAmpBuffers {"):src.index("} DwAmpBuffers;")])
     assert re.findall(r"\*([a-z_0-9]+)", blk) == abi.AMP_BUFFER_NAMES
     blk = strip(src[src.index("typedef struct DwAmpConfig {"):src.index("} DwAmpConfig;")])
-    assert re.findall(r"([a-z_0-9]+)(?:\[3\])?[,;]", blk) == [f[0] for f in abi.DwAmpConfig._fields_]
+    assert re.findall(r"([a-z_0-9]+)(?:\[\d\])?[,;]", blk) == [f[0] for f in abi.DwAmpConfig._fields_]
+    blk = strip(src[src.index("typedef struct DwAmpResetDraws {"):src.index("} DwAmpResetDraws;")])
+    assert re.findall(r"\*([a-z_0-9]+)", blk) == abi.AMP_RESET_DRAW_NAMES
     assert ctypes.sizeof(abi.DwAmpBuffers) == 8 * len(abi.AMP_BUFFER_NAMES)
 
 

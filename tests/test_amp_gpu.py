@@ -543,8 +543,8 @@ def test_tocabi_amp_lower_graph_step_equals_eager():
 
 @pytest.mark.parametrize("pd_control,plain", [(False, False), (True, False), (False, True)])
 def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
-    """cfg sim.mi355.amp_fused: the step's bookkeeping in four HIP kernels (dw_amp_step_pre / _tau / _encoder / _post) against the
-    torch implementation of the same class (the branch of the command ramp that draws for every env; itself pinned to the
+    """cfg sim.mi355.amp_fused: the step's bookkeeping in three HIP kernels (dw_amp_step_begin / _mid / _end; histories as rings, in the
+    `plain` case in the reference's shifting layout) against the torch implementation of the same class (the branch of the command ramp that draws for every env; itself pinned to the
     reference class by the replay tests above): same seeds and actions for 80 steps with resets in between -- every output and
     every piece of state must be bit-identical.  Episode length 40 so that time-outs and the command ramp (episode step 9) occur."""
     from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
@@ -555,11 +555,17 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
         cfg["env"].update({"episodeLength": 40, "pdControl": pd_control, "numAMPObsSteps": 3})
         if plain:          # no encoder / observation noise, no command ramp, no randomisation: the entry points then get no draws at all
             cfg["task"]["noise"], cfg["task"]["randomize"], cfg["env"]["velChange"] = False, False, False
-        cfg["sim"]["mi355"] = {"amp_fused": fused}
+        cfg["sim"]["mi355"] = {"amp_fused": fused, "amp_hist_ring": not plain}
         envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
     a, b = envs
+    assert a._hist_ring == (not plain) and not b._hist_ring
     b._capturing = True
     g = torch.Generator(device="cuda").manual_seed(4)
+
+    def state(env, n):          # (the two histories in the reference's layout, whatever the layout in memory)
+        if n in ("action_history", "obs_history"):
+            return env.history_linear()[0 if n == "action_history" else 1]
+        return getattr(env, n)
     names = ["actions", "actions_pre", "action_history", "obs_history", "commands", "start_target_vel", "final_target_vel", "vel_change_duration",
              "cur_vel_change_duration", "epi_len", "action_log", "simul_len", "qpos_noise", "qvel_noise", "qpos_pre", "_dof_vel_pre", "progress_buf",
              "randomize_buf", "reset_buf", "_terminate_buf", "timeout_buf", "_rigid_body_pos", "_rigid_body_rot", "_foot_pos", "obs_buf", "rew_buf",
@@ -571,13 +577,13 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
         ra_, rb_ = a.reset_done(), b.reset_done()          # (a: dw_amp_reset_rows, b: reset_idx's indexed assignments)
         assert torch.equal(ra_[1], rb_[1]) and torch.equal(ra_[0]["obs"], rb_[0]["obs"]), t
         for n in after_reset:
-            assert torch.equal(getattr(a, n), getattr(b, n)), (t, "after reset", n)
+            assert torch.equal(state(a, n), state(b, n)), (t, "after reset", n)
         assert torch.equal(a._phys._buf["dof_damping"], b._phys._buf["dof_damping"]) and torch.equal(a._phys._buf["dof_armature"], b._phys._buf["dof_armature"]), t
         act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * (1.3 if t % 7 == 0 else 0.7)          # (beyond +-1 now and then: the clamp)
         oa, ra, da, xa = a.step(act)
         ob, rb, db, xb = b.step(act)
         for n in names:
-            va, vb = getattr(a, n), getattr(b, n)
+            va, vb = state(a, n), state(b, n)
             assert torch.equal(va, vb), (t, n, float((va.double() - vb.double()).abs().max()))
         assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), t
         assert torch.equal(xa["amp_obs"], xb["amp_obs"]) and torch.equal(xa["time_outs"], xb["time_outs"]) and torch.equal(xa["terminate"], xb["terminate"]), t
@@ -600,20 +606,204 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
 
 
 def test_amp_step_argument_checks():
-    """The fused entry points refuse a table with a missing buffer or sizes beyond what a wave stages, with an error code and a
-    message, before anything is launched."""
+    """The fused entry points refuse a table with a missing buffer, sizes beyond what a wave stages, missing draws or a handle of
+    another size, with an error code and a message, before anything is launched."""
     from isaacgymdyros_amd import _lib, abi
+    from hip_backend import make_env
     lib, api = _lib.load()
+    env = make_env(4)
+    h = env._h
     c, b = abi.DwAmpConfig(), abi.DwAmpBuffers()
-    x = torch.zeros(1024, device="cuda")
+    x = torch.zeros(4096, device="cuda")
     c.num_envs, c.num_his, c.num_skip, c.log_slots, c.amp_steps = 4, 10, 2, 6, 2
     for name in abi.AMP_BUFFER_NAMES:
         setattr(b, name, x.data_ptr())
+    P = lambda t: C.c_void_p(t.data_ptr())
     b.obs_history = None
-    assert api["amp_step_pre"](C.byref(c), C.byref(b), C.c_void_p(x.data_ptr()), None, None, None) != 0
-    assert b"dw_amp_step_pre" in lib.dw_last_error()
+    assert api["amp_step_begin"](h, C.byref(c), C.byref(b), P(x), None, None, None) != 0
+    assert b"dw_amp_step_begin" in lib.dw_last_error()
     b.obs_history = x.data_ptr()
     c.num_his = 40                                       # 40 x 2 x 36 words: more than a wave stages
-    assert api["amp_step_tau"](C.byref(c), C.byref(b), C.c_void_p(x.data_ptr()), None) != 0
+    assert api["amp_step_mid"](h, C.byref(c), C.byref(b), None, 1, None) != 0
     c.num_his, c.vel_change = 10, 1
-    assert api["amp_step_pre"](C.byref(c), C.byref(b), C.c_void_p(x.data_ptr()), None, None, None) != 0          # the ramp draws are missing
+    assert api["amp_step_begin"](h, C.byref(c), C.byref(b), P(x), None, None, None) != 0          # the ramp draws are missing
+    c.vel_change, c.noise = 0, 1
+    assert api["amp_step_mid"](h, C.byref(c), C.byref(b), None, 1, None) != 0                     # the encoder draws are missing
+    assert api["amp_step_mid"](h, C.byref(c), C.byref(b), P(x), 0, None) != 0                     # substep 0 has no "between"
+    assert api["amp_step_end"](h, C.byref(c), C.byref(b), P(x), 1, None, None) != 0              # the root-velocity draws are missing
+    assert api["amp_reset_done"](h, C.byref(c), C.byref(b), None, None) != 0                      # no draws and no device_draws
+    c.device_draws = 1
+    b.draw_ctr = None
+    assert api["amp_reset_done"](h, C.byref(c), C.byref(b), None, None) != 0                      # the draw counters are missing
+    b.draw_ctr = x.data_ptr()
+    assert api["amp_reset_done"](h, C.byref(c), C.byref(b), None, None) != 0 and b"delay_idx_range" in lib.dw_last_error()
+    c.hist_ring, b.hist_head = 1, None
+    assert api["amp_step_begin"](h, C.byref(c), C.byref(b), P(x), None, None, None) != 0          # the ring heads are missing
+    c.num_envs = 8
+    b.hist_head = x.data_ptr()
+    assert api["amp_step_end"](h, C.byref(c), C.byref(b), None, 1, None, None) != 0 and b"num_envs" in lib.dw_last_error()
+    env.close()
+
+
+class _HipAmp:
+    """tests/amp_emul.py::AmpEmul with the tables in device memory and the HIP library behind them."""
+
+    def __init__(self, N, **kw):
+        from amp_emul import AmpEmul
+        from hip_backend import make_env
+        from isaacgymdyros_amd import abi
+
+        class _Shim:          # what AmpEmul's constructor touches of a backend
+            pass
+        self.env = make_env(N, self_collision=0)
+        shim = _Shim()
+        shim.buf = {k: v.cpu().numpy() for k, v in self.env._buf.items()}
+        self.host = AmpEmul(shim, N, **kw)          # builds the config and the initial tables (numpy)
+        for k in ("root_states", "dof_state", "dof_damping", "dof_armature"):
+            self.env._buf[k].copy_(torch.from_numpy(shim.buf[k]).cuda())
+        self.c, self.N, self.K = self.host.c, N, self.host.K
+        self.t = {n: torch.from_numpy(v).cuda() for n, v in self.host.a.items()}
+        self.b = abi.DwAmpBuffers()
+        for n in abi.AMP_BUFFER_NAMES:
+            setattr(self.b, n, self.t[n].data_ptr())
+        self.api, self.h = self.env._api, self.env._h
+
+    def _chk(self, rc):
+        from isaacgymdyros_amd import _lib
+        _lib.check(self.api, rc)
+
+    def reset_done(self):
+        self._chk(self.api["amp_reset_done"](self.h, C.byref(self.c), C.byref(self.b), None, None))
+
+    def begin(self, actions):
+        self._act = torch.from_numpy(actions).cuda()
+        self._chk(self.api["amp_step_begin"](self.h, C.byref(self.c), C.byref(self.b), C.c_void_p(self._act.data_ptr()), None, None, None))
+
+    def mid(self, k):
+        self._chk(self.api["amp_step_mid"](self.h, C.byref(self.c), C.byref(self.b), None, k, None))
+
+    def end(self):
+        self._chk(self.api["amp_step_end"](self.h, C.byref(self.c), C.byref(self.b), None, self.K - 1, None, None))
+
+    def arrays(self):
+        torch.cuda.synchronize()
+        return {n: v.cpu().numpy() for n, v in self.t.items()}
+
+
+def test_fused_amp_kernels_with_device_draws_equal_their_host_emulation():
+    """sim.mi355.amp_device_draws: the draws are made inside the kernels, so torch has nothing to compare with -- the checker is the
+    host emulation of the same kernel source (tests/emul, g++, fp contraction off like the kernels).  Both run reset_done / begin /
+    mid / end on the same inputs for 24 steps (the physics state after every dw_simulate is copied from the GPU to the emulation):
+    integer state, uniform-derived state (commands, biases, power scale, dof properties), histories, torques and the encoder state
+    without noise terms must be bit-identical; what passes through the device's fast log / cos (encoder noise) or through
+    atan2f / expf / sinf / cosf (observation, reward, discriminator observation) agrees to the rounding of those functions."""
+    from amp_emul import AmpEmul
+    from emul_backend import EmulSim
+    N = 7
+    kw = dict(seed=19, episode_length=10.0, hist_ring=True, device_draws=True)
+    g = _HipAmp(N, **kw)
+    e = AmpEmul(EmulSim(N, quad="oct", self_collision=0), N, **kw)
+    e.a["total_mass"][:] = g.t["total_mass"].cpu().numpy()          # (the GPU env randomised its link masses at setup)
+    exact = ["actions", "actions_pre", "commands", "start_target_vel", "final_target_vel", "vel_change_duration", "cur_vel_change_duration",
+             "epi_len", "power_scale", "delay_idx", "simul_len", "qpos_bias", "quat_bias", "progress_buf", "randomize_buf", "reset_buf", "terminate_buf",
+             "timeout_buf", "epi_len_log", "perturbation_count", "perturb_timing", "pert_on", "hist_head", "draw_ctr", "action_history", "action_log", "tau",
+             "dof_vel_pre", "rigid_body_rot"]
+    close = {"qpos_noise": 2e-9, "qvel_noise": 2e-6, "qpos_pre": 2e-9, "obs1": 2e-5, "obs_buf": 2e-5, "obs_out": 2e-5, "obs_history": 2e-5, "reward_values": 2e-6, "rew_buf": 2e-6, "amp_obs_buf": 2e-6, "amp_obs1": 2e-6, "foot_pos": 2e-6, "rigid_body_pos": 2e-6}
+    rng = np.random.default_rng(5)
+    resets = 0
+
+    def sync_physics():
+        torch.cuda.synchronize()
+        for k in ("root_states", "dof_state", "contact_forces", "dof_damping", "dof_armature"):
+            e.sim.buf[k][...] = g.env._buf[k].cpu().numpy()
+
+    def compare(tag):
+        ga = g.arrays()
+        for n in exact:
+            assert np.array_equal(ga[n], e.a[n]), (tag, n)
+        for n, tol in close.items():
+            d = np.abs(ga[n].astype(np.float64) - e.a[n])
+            assert d.max() <= tol, (tag, n, float(d.max()), np.argwhere(d > tol)[:4].tolist(), ga["reward_values"][:2].tolist(), e.a["reward_values"][:2].tolist())
+        for k in ("dof_damping", "dof_armature"):
+            assert np.array_equal(g.env._buf[k].cpu().numpy(), e.sim.buf[k]), (tag, k)
+
+    for t in range(24):
+        resets += int(e.a["reset_buf"].sum())
+        g.reset_done(); e.reset_done()
+        # (the reset wrote the Gym rows on both sides from the same tables: they must already agree)
+        torch.cuda.synchronize()
+        for k in ("root_states", "dof_state", "contact_forces"):
+            assert np.array_equal(g.env._buf[k].cpu().numpy(), e.sim.buf[k]), (t, k)
+        compare((t, "reset"))
+        act = ((rng.random((N, 12), dtype=np.float32) * 2 - 1) * 0.9).astype(np.float32)
+        api, h, c, b = e.sim.api, e.sim.h, C.byref(e.c), C.byref(e.b)
+        g.begin(act)
+        e._chk(api["amp_step_begin"](h, c, b, act.ctypes.data, None, None, None))
+        compare((t, "begin"))
+        for k in range(g.K):
+            g.env.simulate(g.t["tau"])
+            sync_physics()
+            if k + 1 < g.K:
+                g.mid(k + 1)
+                e._chk(api["amp_step_mid"](h, c, b, None, k + 1, None))
+                compare((t, "mid"))
+        g.end()
+        e._chk(api["amp_step_end"](h, c, b, None, g.K - 1, None, None))
+        compare((t, "end"))
+    assert resets >= 2 * N
+    g.env.close()
+
+
+def test_tocabi_amp_lower_device_draws_class_level():
+    """The host class with sim.mi355.amp_device_draws: step() recorded in a hipGraph + reset_done() as one launch, no torch draw.  The
+    run is reproducible from the seed, differs with another seed, keeps drawing fresh noise at every replay (the draw counters live
+    in device memory), resets what has to be reset, and its draws have the reference's distributions."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+    N = 512
+
+    def make(seed, graph):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["seed"] = seed
+        cfg["env"]["episodeLength"] = 30
+        cfg["sim"]["mi355"] = {"amp_fused": True, "amp_device_draws": True}
+        env = TocabiAMPLower(cfg, "cuda:0", 0, True)
+        env.reset_done()
+        if graph:
+            env.enable_graph_step(warmup=2)
+        else:
+            for _ in range(2):
+                env._step_body(torch.zeros(N, 12, device="cuda"))
+        return env
+    a, b, c = make(3, True), make(3, False), make(4, True)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    enc, nres = [], 0
+    for t in range(45):
+        ids = [e.reset_done()[1] for e in (a, b, c)]
+        assert torch.equal(ids[0], ids[1]), t
+        nres += len(ids[0])
+        for e in (a, b, c):
+            assert int(e.reset_buf.sum()) == 0 and int(e.progress_buf[ids[0]].sum()) == 0 if e is not c else True
+        act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * 0.6
+        oa, ra, da, xa = a.step(act)
+        ob, rb, db, xb = b.step(act)
+        c.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(xa["amp_obs"], xb["amp_obs"]), t
+        assert torch.equal(a.commands, b.commands) and torch.equal(a.qpos_noise, b.qpos_noise), t
+        enc.append((a.qpos_noise[:, 12:] - a._dof_pos[:, 12:]).clone())
+    assert nres >= N                                            # the 30-step limit (and falls)
+    assert not torch.equal(a.commands, c.commands) and not torch.equal(a.qpos_bias, c.qpos_bias)
+    assert not torch.equal(enc[-1], enc[-2])                    # fresh draws at every replay
+    z = torch.stack(enc).flatten()
+    assert float(z.abs().max()) <= 0.00016 + 1e-7
+    assert abs(float(z.mean())) < 2e-7 and abs(float(z.std()) / (0.00016 / 3.0) - 1.0) < 0.02           # sigma 0.00016 / 3, clamped at 3 sigma
+    for e in (a, b):
+        assert float(e.power_scale.min()) >= 0.8 and float(e.power_scale.max()) <= 1.2 and abs(float(e.power_scale.mean()) - 1.0) < 0.01
+        assert float(e.qpos_bias.abs().max()) <= 0.0314 + 1e-6 and abs(float(e.qpos_bias.std()) / (0.0628 / 12 ** 0.5) - 1.0) < 0.05
+        d = e._phys._buf["dof_damping"]
+        assert float(d.min()) >= 0.1 and float(d.max()) <= 3.0 + 1e-5 and abs(float(d.mean()) - 1.55) < 0.02
+        assert int(e.delay_idx.min()) >= 2 and int(e.delay_idx.max()) <= 5
+        assert torch.equal(e.obs_dict["obs"], torch.clamp(e.obs_buf, -e.clip_obs, e.clip_obs))
+    lin_a, lin_b = a.history_linear(), b.history_linear()
+    assert torch.equal(lin_a[0], lin_b[0]) and torch.equal(lin_a[1], lin_b[1])
+    for e in (a, b, c):
+        e.close()

@@ -794,6 +794,22 @@ def test_captured_step_replays_with_advancing_noise(pipeline):
     assert int(b._step_dev) == 11
     for k in ("env_state", "root_states", "dof_state", "obs_buf", "rew_buf", "reset_buf", "obs_history", "dof_damping"):
         assert torch.equal(a._buf[k], b._buf[k]), k
+    # A checkpoint taken after replays carries the DEVICE counter (the host's count saw only the 3 eager steps): restored
+    # into a fresh env, the next step draws the noise of step 11, not of step 3 again -- and equals the uninterrupted run.
+    sd = b.state_dict()
+    assert sd["_step_count"] == 11
+    c = make_env(N, seed=5, pipeline=pipeline)
+    c.load_state_dict(sd)
+    ids = torch.tensor([1, 7, 200], device="cuda")
+    for e in (a, b, c):
+        e.reset_idx(ids)                                    # keyed with the same step index on all three
+    extra = torch.rand(N, 13, generator=g, device="cuda") * 2 - 1
+    a.step(extra); c.step(extra); b.step(extra)
+    torch.cuda.synchronize()
+    assert int(b._step_dev) == 12
+    for k in ("env_state", "root_states", "dof_state", "obs_buf", "rew_buf", "reset_buf", "obs_history"):
+        assert torch.equal(a._buf[k], c._buf[k]), k
+        assert torch.equal(a._buf[k], b._buf[k]), k
 
 
 @pytest.mark.gpu

@@ -33,3 +33,5 @@ def test_kernel_body_under_asan_ubsan(quad):
     assert out.returncode == 0, out.stderr[-3000:]
     assert "replayed 40 steps" in out.stdout and "simulate / reset_idx / step(noise=None) ok" in out.stdout
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+    if quad == "oct":          # (the octet emulation also carries the fused TocabiAMPLower kernels, csrc/dw_amp_step.h)
+        assert "fused amp step / reset ok" in out.stdout

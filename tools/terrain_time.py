@@ -3,8 +3,11 @@ sys.path.insert(0, os.getcwd())
 import torch
 from isaacgymdyros_amd.config import default_cfg, with_terrain
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
+PIPE = int(os.environ.get("DW_PIPE", "0"))
 for N in (4096, 16384):
     cfg = with_terrain(default_cfg(N, "cuda:0"), mesh_type="trimesh", curriculum=True)
+    cfg["sim"]["mi355"]["pipeline"] = PIPE
+    cfg["sim"]["mi355"]["alias_obs"] = True
     env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
     g = torch.Generator(device="cuda").manual_seed(42)
     acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
@@ -15,4 +18,4 @@ for N in (4096, 16384):
     for i in range(200): env.step(acts[i % 8])
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 200
-    print("terrain N=%d %.3f ms/step %.2f M env-steps/s levels mean %.2f" % (N, ms, N / ms / 1e3, float(env.terrain_levels.float().mean())))
+    print("pipeline %d " % PIPE + "terrain N=%d %.3f ms/step %.2f M env-steps/s levels mean %.2f" % (N, ms, N / ms / 1e3, float(env.terrain_levels.float().mean())))
