@@ -146,8 +146,9 @@ struct RewardArgs {
     const float *root_states, *dof_vel, *dof_vel_pre, *commands, *actions, *actions_pre, *motor_efforts, *contact_force, *total_mass;
     float *reward, *reward_values;
 };
+// (fl, fr: the vertical contact force on the two foot links, contact_force[8][2] and [16][2])
 DW_HD void reward_row(const float *r, const float *dvp, int dv_stride, const float *dvq, const float *cmd, const float *act, const float *act_pre,
-                      const float *motor_efforts, const float *cf, float total_mass, float *reward, float *rv) {
+                      const float *motor_efforts, float fl, float fr, float total_mass, float *reward, float *rv) {
     const float q[4] = {r[3], r[4], r[5], r[6]}, v[3] = {r[7], r[8], r[9]};
     float lv[3];
     quat_rotate_inverse(q, v, lv);
@@ -158,7 +159,6 @@ DW_HD void reward_row(const float *r, const float *dvp, int dv_stride, const flo
     d = cmd[2] - r[12];
     const float ryaw = 0.6f * expf(-7.0f * (d * d));
     const float thr = (float)(1.4 * 9.81) * total_mass;
-    const float fl = cf[8 * 3 + 2], fr = cf[16 * 3 + 2];
     const bool thres = (fl > thr) || (fr > thr);
     const float r_thr = -0.2f * (thres ? 1.0f : 0.0f);
     float cl = fl - thr, cr = fr - thr;
@@ -191,7 +191,8 @@ DW_HD void reward_row(const float *r, const float *dvp, int dv_stride, const flo
 }
 DW_HD void reward(const RewardArgs &A, int e) {
     reward_row(A.root_states + 13 * (size_t)e, A.dof_vel + DW_NUM_DOF * (size_t)e, 1, A.dof_vel_pre + DW_NUM_DOF * (size_t)e, A.commands + 3 * (size_t)e,
-               A.actions + 12 * (size_t)e, A.actions_pre + 12 * (size_t)e, A.motor_efforts, A.contact_force + (size_t)DW_NUM_BODIES * 3 * e, A.total_mass[e],
+               A.actions + 12 * (size_t)e, A.actions_pre + 12 * (size_t)e, A.motor_efforts, A.contact_force[((size_t)DW_NUM_BODIES * e + 8) * 3 + 2],
+               A.contact_force[((size_t)DW_NUM_BODIES * e + 16) * 3 + 2], A.total_mass[e],
                A.reward + e, A.reward_values + 9 * (size_t)e);
 }
 

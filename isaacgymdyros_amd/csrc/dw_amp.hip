@@ -72,10 +72,11 @@ __global__ __launch_bounds__(64) void dw_k_amp_step_mid(const DwAmpConfig C, con
     __shared__ dwa::StepLds S;
     dwa::step_mid(dwa::EnvWave(), S, C, B, dof_state, z, substep, (int)blockIdx.x);
 }
-__global__ __launch_bounds__(64) void dw_k_amp_step_end(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
-                                                       const float *z, int substep, const float *rootvel_noise) {
-    __shared__ dwa::StepLds S;
-    dwa::step_end(dwa::EnvWave(), S, *M, C, B, G, z, substep, rootvel_noise, (int)blockIdx.x);
+// (four waves per 64 envs: dw_amp_step.h EnvGroup)
+__global__ __launch_bounds__(dwa::GT) void dw_k_amp_step_end(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
+                                                             const float *z, int substep, const float *rootvel_noise) {
+    __shared__ dwa::GroupLds S;
+    dwa::step_end(dwa::EnvGroup(), S, *M, C, B, G, z, substep, rootvel_noise, (int)blockIdx.x);
 }
 // reset_idx of the listed envs: the draws are rows of the caller's arrays in the order of the list
 __global__ __launch_bounds__(64) void dw_k_amp_reset_rows(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
@@ -224,7 +225,7 @@ int dw_amp_step_end(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, co
     if (!amp_args_ok(c, b) || substep < 0 || substep >= 8) return fail(DW_EINVAL, "dw_amp_step_end: bad configuration or substep not in 0..7");
     if (const char *m = handle_ok(h, c)) { char t[160]; snprintf(t, sizeof t, "dw_amp_step_end: %s", m); return fail(h && !h->bound ? DW_ESTATE : DW_EINVAL, t); }
     if (!c->device_draws && ((c->noise && !z) || !rootvel_noise)) return fail(DW_EINVAL, "dw_amp_step_end: the encoder / root-velocity draws are missing (or device_draws)");
-    hipLaunchKernelGGL(dw_k_amp_step_end, dim3(c->num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, *c, *b, gym_rows(h), z, substep, rootvel_noise);
+    hipLaunchKernelGGL(dw_k_amp_step_end, dim3((c->num_envs + dwa::GE - 1) / dwa::GE), dim3(dwa::GT), 0, (hipStream_t)stream, h->d_model, *c, *b, gym_rows(h), z, substep, rootvel_noise);
     return launched("dw_amp_step_end: launch");
 }
 

@@ -242,69 +242,141 @@ DW_HD void step_mid(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const Dw
 
 // dw_amp_step_end: the encoder model of the last substep, then post-physics (:750-804 + the subclass' :88-96): counters, foot
 // positions, observation + history stacking, reward, termination, time-outs, the discriminator observation and its history.
-DW_HD void step_end(const EnvWave &W, StepLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G, const float *z,
-                    int substep, const float *rootvel_noise, int e) {
-    stage_leg_model(W, S, M);
-    encoder(W, S, C, B, G.dof_state, z, substep, true, e);
+//
+// A WORKGROUP OF FOUR WAVES PER 16 ENVS (EnvGroup): the serial per-env functions -- two chains of six joint rotations for the foot
+// positions, the observation's three atan2f, the reward's eight expf and four norms, the discriminator observation -- are ~3 000
+// instructions; on one lane of a wave per env (the first form of this kernel) they cost 3 000 wave-instructions PER ENV and the
+// launch was bound by instruction issue at 1/64 lane occupancy (83 us at 16384 envs).  Here the rows those functions read are
+// staged in LDS for the group's envs by all 256 threads (items = (env, word), coalesced), the functions then run with LANE = ENV, one
+// function per wave (left foot + termination | observation | reward | right foot + discriminator observation), and the bulk
+// writes are items over all threads again.  The env's row in LDS has an odd stride, so lane = env access is free of bank conflicts.
+// 16 envs per group, not 64: with 64 the serial functions cost nothing (1.5 us) but a launch of 16384 envs is 256 workgroups, four
+// waves per CU, and the item loops -- a dependent global load per iteration -- ran at the latency of one wave (127 us measured);
+// 1024 workgroups keep 16 waves per CU in flight.
+constexpr int GT = 256, GE = 16;
+#if defined(__HIPCC__)
+struct EnvGroup {
+    template <class F> DW_HD void par(F &&f) const { f((int)threadIdx.x); __syncthreads(); }
+};
+#else
+struct EnvGroup {
+    template <class F> void par(F &&f) const { for (int t = 0; t < GT; ++t) f(t); }
+};
+#endif
+enum { GR_ROOT = 0, GR_DS = 13, GR_FZ = 79, GR_QN = 81, GR_QV = 93, GR_NZ = 105, GR_BIAS = 111, GR_QB = 123, GR_CMD = 126, GR_ACT = 129, GR_ACTP = 141,
+       GR_DVP = 153, GR_OBS = 186, GR_AMP = 222, GR_FOOT = 256, GR_WORDS = 262, GR_STRIDE = 263 };
+struct GroupLds {
+    LegModel LM;
+    float eff[12];
+    float row[GE][GR_STRIDE];
+    int   touch[GE], head[GE][2];
+};
+
+DW_HD void step_end(const EnvGroup &W, GroupLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G, const float *z,
+                    int substep, const float *rootvel_noise, int group) {
+    const int N = C.num_envs, e0 = group * GE;
     const int NH = C.num_his * C.num_skip;
-    // the env's rows staged in LDS once: the per-env functions below are serial code on one lane each, and a dependent global load
-    // per operand is what they must not pay
-    W.par([&](int l) {
-        if (l < 13) S.root[l] = G.root_states[13 * (size_t)e + l];
-        for (int i = l; i < DW_NUM_DOF * 2; i += 64) S.ds[i] = G.dof_state[(size_t)DW_NUM_DOF * 2 * e + i];
-        for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.cf[i] = G.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
-        if (l < 12) {
-            S.small[SM_BIAS + l] = B.qpos_bias[12 * (size_t)e + l];
-            S.small[SM_ACT + l] = B.actions[12 * (size_t)e + l]; S.small[SM_ACTP + l] = B.actions_pre[12 * (size_t)e + l];
-            S.small[SM_EFF + l] = B.motor_efforts[l];
+    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
+    W.par([&](int t) {
+        for (int i = t; i < LegModel::NBODY * 16; i += GT) {
+            const int b = i >> 4, k = i & 15;
+            if (k < 3) S.LM.pos[b][k] = M.pos[b][k];
+            else if (k < 6) S.LM.axis[b][k - 3] = M.axis[b][k - 3];
+            else if (k < 15) S.LM.rot0[b][k - 6] = M.rot0[b][k - 6];
+            else S.LM.parent[b] = M.parent[b];
         }
-        if (l < 6) {
-            float nz = 0.0f;
-            if (rootvel_noise) nz = rootvel_noise[6 * (size_t)e + l];
-            else if (C.noise && C.device_draws) nz = draw_uniform(draw_key(C, B, e), DS_ROOTVEL, l) * 0.05f - 0.025f;
-            S.small[SM_NZ + l] = nz;
+        if (t < 12) S.eff[t] = B.motor_efforts[t];
+        if (t < GE) {
+            S.touch[t] = 0;
+            S.head[t][0] = S.head[t][1] = 0;
+            if (C.hist_ring && e0 + t < N) { S.head[t][0] = B.hist_head[2 * (size_t)(e0 + t)]; S.head[t][1] = B.hist_head[2 * (size_t)(e0 + t) + 1]; }
         }
-        if (l < 3) { S.small[SM_QB + l] = B.quat_bias[3 * (size_t)e + l]; S.small[SM_CMD + l] = B.commands[3 * (size_t)e + l]; }
-        if (l < DW_NUM_DOF) S.dvp[l] = B.dof_vel_pre[(size_t)DW_NUM_DOF * e + l];
-        if (l == 0) S.touch = 0;
     });
-    // counters (:751-752; epi_len: the last line of pre_physics_step); four independent pieces of serial arithmetic on four lanes:
-    // the two foot positions (the rigid-body rows the task reads), this step's observation, the reward; non-foot bodies in contact
-    W.par([&](int l) {
-        const float *r = S.root, *ds = S.ds, *cf = S.cf;
-        if (l < 2) {
-            float p[3];
-            body_position(S.LM, r, ds, 0, l == 0 ? 6 : 12, p);          // (the staged rows are env 0 of their own little tensors)
-            for (int i = 0; i < 3; ++i) {
-                S.foot[3 * l + i] = p[i];
-                B.foot_pos[((size_t)2 * e + l) * 3 + i] = p[i];
-                B.rigid_body_pos[((size_t)DW_NUM_BODIES * e + (l == 0 ? 8 : 16)) * 3 + i] = p[i];
+    // ---- the encoder model of the substep that ended (:728-736) and the rows the functions below read, items over all threads
+    W.par([&](int t) {
+        for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
+            const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
+            if (e >= N) continue;
+            const size_t g = (size_t)DW_NUM_DOF * e + l;
+            const float q = G.dof_state[g * 2], qd = G.dof_state[g * 2 + 1];
+            float qn = q;
+            if (C.noise) {
+                const float zz = z ? z[g] : draw_enc_normal(draw_key(C, B, e), DS_ENC + (unsigned int)substep, l);
+                qn = q + fminf(fmaxf(zz, -0.00016f), 0.00016f);
             }
-        } else if (l == 2) {
-            observations_row(r, &S.small[SM_NZ], S.qn, &S.small[SM_BIAS], &S.small[SM_QB], S.qv, &S.small[SM_CMD], S.obs);
-        } else if (l == 3) {
-            reward_row(r, ds + 1, 2, S.dvp, &S.small[SM_CMD], &S.small[SM_ACT], &S.small[SM_ACTP], &S.small[SM_EFF], cf, B.total_mass[e],
+            const float d = qn - B.qpos_pre[g];
+            const float qv = C.gpu_div ? d * C.inv_dt : d / C.dt;
+            B.qpos_noise[g] = qn;
+            B.qvel_noise[g] = qv;
+            B.qpos_pre[g] = qn;
+            float *r = S.row[el];
+            if (l < 12) { r[GR_QN + l] = qn; r[GR_QV + l] = qv; }
+            r[GR_DS + 2 * l] = q; r[GR_DS + 2 * l + 1] = qd;
+            r[GR_DVP + l] = B.dof_vel_pre[g];
+        }
+        for (int i = t; i < GE * 16; i += GT) {                 // root state (13) + the three words of quat_bias
+            const int el = i >> 4, k = i & 15, e = e0 + el;
+            if (e >= N) continue;
+            if (k < 13) S.row[el][GR_ROOT + k] = G.root_states[13 * (size_t)e + k];
+            else S.row[el][GR_QB + (k - 13)] = B.quat_bias[3 * (size_t)e + (k - 13)];
+        }
+        for (int i = t; i < GE * 48; i += GT) {                 // qpos_bias, actions, actions_pre (12 each), root-velocity noise (6), command (3), foot forces (2)
+            const int el = i / 48, k = i - 48 * el, e = e0 + el;
+            if (e >= N) continue;
+            float *r = S.row[el];
+            if (k < 12) r[GR_BIAS + k] = B.qpos_bias[12 * (size_t)e + k];
+            else if (k < 24) r[GR_ACT + (k - 12)] = B.actions[12 * (size_t)e + (k - 12)];
+            else if (k < 36) r[GR_ACTP + (k - 24)] = B.actions_pre[12 * (size_t)e + (k - 24)];
+            else if (k < 42) {
+                const int l = k - 36;
+                float nz = 0.0f;
+                if (rootvel_noise) nz = rootvel_noise[6 * (size_t)e + l];
+                else if (C.noise && C.device_draws) nz = draw_uniform(draw_key(C, B, e), DS_ROOTVEL, l) * 0.05f - 0.025f;
+                r[GR_NZ + l] = nz;
+            } else if (k < 45) r[GR_CMD + (k - 42)] = B.commands[3 * (size_t)e + (k - 42)];
+            else if (k < 47) r[GR_FZ + (k - 45)] = G.contact_forces[((size_t)DW_NUM_BODIES * e + (k == 45 ? 8 : 16)) * 3 + 2];
+        }
+        for (int i = t; i < GE * DW_NUM_BODIES; i += GT) {      // non-foot bodies in contact
+            const int el = i / DW_NUM_BODIES, l = i - DW_NUM_BODIES * el, e = e0 + el;
+            if (e >= N || l == 8 || l == 16) continue;
+            const float *cf = G.contact_forces + ((size_t)DW_NUM_BODIES * e + l) * 3;
+            if (cf[0] > 1.0f || cf[1] > 1.0f || cf[2] > 1.0f) S.touch[el] = 1;
+        }
+    });
+    // ---- the serial functions, lane = env, one function per wave; counters (:751-752; epi_len: the last line of pre_physics_step)
+    W.par([&](int t) {
+        const int el = t & 63, role = t >> 6, e = e0 + el;
+        if (el >= GE || e >= N) return;
+        float *r = S.row[el];
+        if (role == 0 || role == 3) {
+            const int f = role == 0 ? 0 : 1;
+            float p[3];
+            body_position(S.LM, r + GR_ROOT, r + GR_DS, 0, f == 0 ? 6 : 12, p);          // (the staged rows are env 0 of their own little tensors)
+            for (int i = 0; i < 3; ++i) {
+                r[GR_FOOT + 3 * f + i] = p[i];
+                B.foot_pos[((size_t)2 * e + f) * 3 + i] = p[i];
+                B.rigid_body_pos[((size_t)DW_NUM_BODIES * e + (f == 0 ? 8 : 16)) * 3 + i] = p[i];
+            }
+        } else if (role == 1) {
+            observations_row(r + GR_ROOT, r + GR_NZ, r + GR_QN, r + GR_BIAS, r + GR_QB, r + GR_QV, r + GR_CMD, r + GR_OBS);
+            B.progress_buf[e] += 1; B.randomize_buf[e] += 1; B.epi_len[e] += 1.0f;
+        } else {
+            reward_row(r + GR_ROOT, r + GR_DS + 1, 2, r + GR_DVP, r + GR_CMD, r + GR_ACT, r + GR_ACTP, S.eff, r[GR_FZ], r[GR_FZ + 1], B.total_mass[e],
                        B.rew_buf + e, B.reward_values + 9 * (size_t)e);
         }
-        if (l >= 4 && l < 7) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (l - 4)] = r[l - 4];
-        if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
-        if (l < DW_NUM_BODIES && l != 8 && l != 16 && (cf[3 * l] > 1.0f || cf[3 * l + 1] > 1.0f || cf[3 * l + 2] > 1.0f)) S.touch = 1;
-        if (l == 63) { B.progress_buf[e] += 1; B.randomize_buf[e] += 1; B.epi_len[e] += 1.0f; }
     });
-    W.par([&](int l) {
-        const float *r = S.root, *ds = S.ds;
-        // the encoder reading takes the bias (the reference's observation function adds it in place, :945)
-        if (l >= 2 && l < 14) B.qpos_noise[(size_t)DW_NUM_DOF * e + (l - 2)] = S.qn[l - 2] + S.small[SM_BIAS + (l - 2)];
-        if (l >= 14 && l < 14 + DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + (l - 14)] = S.obs[l - 14];
-        // termination (:1025-1069) on lane 0, the discriminator observation (tasks/tocabi_amp_lower.py:310-350) on lane 1
-        if (l == 0) {
+    W.par([&](int t) {
+        const int el = t & 63, role = t >> 6, e = e0 + el;
+        if (el >= GE || e >= N) return;
+        const float *r = S.row[el];
+        if (role == 0) {          // termination (:1025-1069)
             const int64_t prog = B.progress_buf[e];
             int64_t term = 0;
             if (C.enable_early_termination) {
-                bool fall_height = r[2] < C.termination_height;
-                fall_height = fall_height || S.foot[2] > 0.5f || S.foot[5] > 0.5f;
-                bool fallen = (S.touch != 0) || fall_height;
-                const float q0[4] = {r[3], r[4], r[5], r[6]};
+                bool fall_height = r[GR_ROOT + 2] < C.termination_height;
+                fall_height = fall_height || r[GR_FOOT + 2] > 0.5f || r[GR_FOOT + 5] > 0.5f;
+                bool fallen = (S.touch[el] != 0) || fall_height;
+                const float q0[4] = {r[GR_ROOT + 3], r[GR_ROOT + 4], r[GR_ROOT + 5], r[GR_ROOT + 6]};
                 fallen = fallen || fabsf(dw::quat_err(q0)) > (float)(3.141592 / 4.0);
                 fallen = fallen && (prog > 1);
                 term = fallen ? 1 : 0;
@@ -313,42 +385,79 @@ DW_HD void step_end(const EnvWave &W, StepLds &S, const dw::DevModel &M, const D
             B.terminate_buf[e] = term;
             B.reset_buf[e] = rs;
             B.timeout_buf[e] = (uint8_t)(((float)prog >= C.max_episode_length - 1.0f) && rs != 0);
-        } else if (l == 1) {
-            disc_observations_row(r, ds, ds + 1, 2, C.local_root_obs, S.foot, 2, S.amp);
+        } else if (role == 3) {   // the discriminator observation (tasks/tocabi_amp_lower.py:310-350)
+            disc_observations_row(r + GR_ROOT, r + GR_DS, r + GR_DS + 1, 2, C.local_root_obs, r + GR_FOOT, 2, S.row[el] + GR_AMP);
         }
     });
-    // observation history and the stacked observation (:540-580): obs slots S (i + 1) - 1, action slots S (i + 1), i < H - 1
-    float *oh = B.obs_history + (size_t)NH * DW_AMP_NUM_OBS1 * e;
-    history_append(W, S, C, B, oh, NH, DW_AMP_NUM_OBS1, S.obs, 1, e);
-    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
-    W.par([&](int l) {
-        const float *ah = B.action_history + (size_t)NH * 12 * e;
-        const int oh_head = S.head[1], ah_head = C.hist_ring ? B.hist_head[2 * (size_t)e] : 0;
-        float *ob = B.obs_buf + (size_t)num_obs * e, *oo = B.obs_out + (size_t)num_obs * e;
-        for (int i = l; i < num_obs; i += 64) {
-            float v;
-            if (i < DW_AMP_NUM_OBS1 * C.num_his) {
-                const int slot = i / DW_AMP_NUM_OBS1, k = i - DW_AMP_NUM_OBS1 * slot;
-                v = oh[(size_t)hist_phys(oh_head, C.num_skip * (slot + 1) - 1, NH) * DW_AMP_NUM_OBS1 + k];
-            } else {
-                const int j = i - DW_AMP_NUM_OBS1 * C.num_his, slot = j / 12, k = j - 12 * slot;
-                v = ah[(size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + k];
+    // ---- what goes back to memory, items over all threads.  Histories: a thread owns a COLUMN of an env's history (slot s, word k
+    //      for all s), so the shifting layout moves in place without a hazard between threads; the ring writes one slot.
+    W.par([&](int t) {
+        for (int i = t; i < GE * 64; i += GT) {
+            const int el = i >> 6, k = i & 63, e = e0 + el;
+            if (e >= N) continue;
+            const float *r = S.row[el];
+            // the encoder reading takes the bias (the reference's observation function adds it in place, :945)
+            if (k < 12) B.qpos_noise[(size_t)DW_NUM_DOF * e + k] = r[GR_QN + k] + r[GR_BIAS + k];
+            else if (k < 24) B.actions_pre[12 * (size_t)e + (k - 12)] = r[GR_ACT + (k - 12)];
+            else if (k < 27) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (k - 24)] = r[GR_ROOT + (k - 24)];
+            else if (k < 31) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (k - 27)] = r[GR_ROOT + 3 + (k - 27)];
+            if (k < DW_NUM_DOF) B.dof_vel_pre[(size_t)DW_NUM_DOF * e + k] = r[GR_DS + 2 * k + 1];          // what the next step compares against
+            if (k < DW_AMP_NUM_OBS1) {
+                B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + k] = r[GR_OBS + k];
+                float *oh = B.obs_history + (size_t)NH * DW_AMP_NUM_OBS1 * e;
+                if (C.hist_ring) {
+                    oh[(size_t)S.head[el][1] * DW_AMP_NUM_OBS1 + k] = r[GR_OBS + k];
+                } else {
+                    for (int s = 0; s + 1 < NH; ++s) oh[(size_t)s * DW_AMP_NUM_OBS1 + k] = oh[(size_t)(s + 1) * DW_AMP_NUM_OBS1 + k];
+                    oh[(size_t)(NH - 1) * DW_AMP_NUM_OBS1 + k] = r[GR_OBS + k];
+                }
             }
-            ob[i] = v;
-            oo[i] = fminf(fmaxf(v, -C.clip_obs), C.clip_obs);
+            if (k < AW) {
+                // discriminator observation history (tasks/tocabi_amp_lower.py:88-96): slot s -> s + 1, the newest into slot 0
+                float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
+                for (int s = C.amp_steps - 1; s >= 1; --s) ab[(size_t)s * AW + k] = ab[(size_t)(s - 1) * AW + k];
+                ab[k] = r[GR_AMP + k];
+                B.amp_obs1[(size_t)AW * e + k] = r[GR_AMP + k];
+            }
         }
-        // what the next step compares against
-        if (l < DW_NUM_DOF) B.dof_vel_pre[(size_t)DW_NUM_DOF * e + l] = S.ds[2 * l + 1];
-        if (l < 12) B.actions_pre[12 * (size_t)e + l] = S.small[SM_ACT + l];
-        // discriminator observation history (tasks/tocabi_amp_lower.py:88-96): slot k -> k + 1, the newest into slot 0
-        const float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
-        for (int i = l; i < C.amp_steps * AW; i += 64) S.hist[i] = i >= AW ? ab[i - AW] : S.amp[i];
     });
-    W.par([&](int l) {
-        float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
-        for (int i = l; i < C.amp_steps * AW; i += 64) ab[i] = S.hist[i];
-        if (l < AW) B.amp_obs1[(size_t)AW * e + l] = S.amp[l];
-        if (l == 63 && C.device_draws) B.draw_ctr[e] += 1;
+    // the stacked observation (:540-580): obs slots S (i + 1) - 1, action slots S (i + 1), i < H - 1.  Four items per thread at a
+    // time, every load before the first store (the compiler may not move a load over a store into the same table)
+    W.par([&](int t) {
+        for (int i0 = t; i0 < GE * num_obs; i0 += 4 * GT) {
+            float v[4];
+            size_t dst[4];
+            bool ok[4];
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * GT;
+                const int el = i / num_obs, w = i - num_obs * el, e = e0 + el;
+                ok[u] = i < GE * num_obs && e < N;
+                v[u] = 0.0f; dst[u] = 0;
+                if (!ok[u]) continue;
+                int oh_head = S.head[el][1] + (C.hist_ring ? 1 : 0);          // (the head as it will be once this step's entry counts)
+                oh_head = oh_head >= NH ? 0 : oh_head;
+                const int ah_head = S.head[el][0];
+                if (w < DW_AMP_NUM_OBS1 * C.num_his) {
+                    const int slot = w / DW_AMP_NUM_OBS1, k = w - DW_AMP_NUM_OBS1 * slot;
+                    v[u] = B.obs_history[(size_t)NH * DW_AMP_NUM_OBS1 * e + (size_t)hist_phys(oh_head, C.num_skip * (slot + 1) - 1, NH) * DW_AMP_NUM_OBS1 + k];
+                } else {
+                    const int j = w - DW_AMP_NUM_OBS1 * C.num_his, slot = j / 12, k = j - 12 * slot;
+                    v[u] = B.action_history[(size_t)NH * 12 * e + (size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + k];
+                }
+                dst[u] = (size_t)num_obs * e + w;
+            }
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                B.obs_buf[dst[u]] = v[u];
+                B.obs_out[dst[u]] = fminf(fmaxf(v[u], -C.clip_obs), C.clip_obs);
+            }
+        }
+    });
+    W.par([&](int t) {
+        const int e = e0 + t;
+        if (t >= GE || e >= N) return;
+        if (C.hist_ring) { const int h = S.head[t][1] + 1; B.hist_head[2 * (size_t)e + 1] = h >= NH ? 0 : h; }
+        if (C.device_draws) B.draw_ctr[e] += 1;
     });
 }
 
