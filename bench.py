@@ -32,10 +32,12 @@ FLOPS_PER_ENV_STEP = 1.0e5 # useful flops of one env-step (2 substeps: ABA ~14 k
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the kernel sources: the PMC traffic record under profiles/ names the sources it was measured on, and is
-    quoted only for exactly those."""
+    """sha256 over the kernel sources and the flags they are built with (isaacgymdyros_amd/build.py): the PMC traffic record under
+    profiles/ names the build it was measured on, and is quoted only for exactly that one."""
     import hashlib
+    from isaacgymdyros_amd import build
     h = hashlib.sha256()
+    h.update(repr((build.FLAGS, build.SOURCES)).encode())
     csrc = os.path.join(ROOT, "isaacgymdyros_amd", "csrc")
     for f in sorted(os.listdir(csrc)) + ["../../include/dyros_walk.h"]:
         p = os.path.join(csrc, f)

@@ -23,7 +23,7 @@
  *                            (tasks/dyros_dynamic_walk.py:502,520,525-526,547-549): ONE physics substep.
  *   dw_step                  VecTask.step: pre_physics_step + 2x simulate + post_physics_step
  *                            (tasks/base/vec_task.py:293-344; tasks/dyros_dynamic_walk.py:449-563,581-669,
- *                            750-947): ONE launch on the caller's stream, whichever kernel generation
+ *                            750-947): ONE launch on the caller's stream, whichever kernels
  *                            DwConfig.pipeline selects.  During the launch the env's row of obs_buf is scratch
  *                            (it is rewritten with the new observation at the end of the same launch).
  *   dw_reset_idx             DyrosDynamicWalk.reset_idx + set_actor_root_state_tensor_indexed +
@@ -95,7 +95,8 @@ typedef struct DwGeom {
 /* Capsule proxy of a link for self-collision (the reference collides every primitive with every other one:
  * create_actor(..., group=i, filter=0), tasks/dyros_dynamic_walk.py:354).  Segment end points in the moving body's
  * frame.  Shipped model: 4 proxies per leg (all 16 left x right pairs), upper arm / forearm / hand per arm and the torso
- * (forearm and hand against torso and same-side thigh, upper arm against torso, arm against arm): 15 proxies, 30 pairs. */
+ * (forearm and hand against torso and same-side thigh, hand against the other thigh, upper arm against torso, arm against
+ * arm): 15 proxies, 32 pairs (DW_MAX_SC_PAIRS, the table is full). */
 typedef struct DwCapsule {
     int32_t moving, gym;
     float   p0[3], p1[3];
@@ -172,7 +173,7 @@ typedef struct DwConfig {
     int32_t root_vel_at_com;            /* 1 = root linear velocity is the COM's (PhysX convention)   */
     int32_t torch_gpu_div;              /* 1 = `tensor / python_scalar` is tensor * (1/scalar), as torch's GPU
                                            kernels compute it; 0 = true division, as torch's CPU kernels do */
-    int32_t self_collision;             /* 1 = leg-vs-leg capsule self-collision; 0 = ground contacts only */
+    int32_t self_collision;             /* 1 = capsule self-collision of legs, arms and torso (DwCapsule); 0 = ground contacts only */
     int32_t debug_freeze_physics;       /* 1 = simulate() leaves the state untouched (task-logic parity tests) */
     uint64_t seed;                      /* key of the counter-based in-kernel RNG                     */
     /* Terrain (reference cfg/terrain/terrain_cfg.py:1-22, tasks/dyros_dynamic_walk.py:203-270 create,
@@ -188,11 +189,12 @@ typedef struct DwConfig {
     float   terrain_env_length;         /* terrain_length [m]: walked more than half of it => level up */
     float   max_episode_length_s;       /* env.episodeLength as the curriculum uses it (:34, :685)    */
     int32_t custom_origins;             /* 1 = reset adds U(-1,1) m of xy jitter to the origin (:729-732) */
-    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate (one launch per policy step in all):
-                                           0 = default (3), 1 = the wave-per-env kernels of round 1, 2 = the quad kernels
-                                           (4 lanes per env, 16 envs per wavefront, one wave per SIMD), 3 = the octet
-                                           kernels (8 lanes per env, 8 envs per wavefront, two waves per SIMD; DESIGN.md
-                                           section 5) */
+    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate (one launch per policy step in both):
+                                           0 = default (3); 3 = the octet kernels (8 lanes per env, 8 envs per wavefront,
+                                           two waves per SIMD); 4 = the lane kernels (one lane per env, one wavefront per
+                                           limb, 64 envs per workgroup; slower, kept as the second implementation every
+                                           parity test also runs).  1 and 2 (the wave-per-env and quad
+                                           kernels of rounds 1 and 2) are retired: DW_EINVAL */
 } DwConfig;
 
 /* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of

@@ -8,19 +8,20 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdyroswalk_hip.so")
-# (source, extra flags): the wave-per-env kernels want the ILP machine scheduler, the quad kernels the default one
-# (the octet kernels: iterative-ilp as well since the second session of round 3 -- 0.1477 -> 0.1444 ms at 16384 envs, 0.1188 -> 0.1176 at 4096,
-#  no scratch in the flat kernels; before the buffer-table split and the restructured kinematics pass the ILP strategies lost there)
-SOURCES = [("dw_hip.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_quad_kernels.hip", []),
+# (source, its own flags).  The octet kernels are built with the iterative-ilp machine scheduler: the substep is a chain of short
+# dependent regions at two waves per SIMD, and a scheduler that lengthens the distance between an LDS load and its first use
+# pays directly (0.1477 -> 0.1444 ms at 16384 envs, 0.1188 -> 0.1176 at 4096, no scratch in the flat kernels; max-ilp,
+# iterative-minreg and the default max-occupancy scheduler lose; A/Bs of round 3).  The lane kernels and
+# the small kernels keep the compiler's default.
+SOURCES = [("dw_hip.hip", []),
            ("dw_oct_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_lane_kernels.hip", []), ("dw_amp.hip", [])]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
-           "dw_quad.h", "dw_quad_kernels.h", "dw_quad_post.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h",
+           "dw_limb.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h",
            "dw_lane_wave.h", "dw_lane_model.h", "dw_lane.h", "dw_lane_kernels.h", "dw_lane_post.h"]
-# -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_* pairs, which costs more
-# v_mov operand shuffling than it saves here (static v_mov count halves without it)
-# -amdgpu-sched-strategy=iterative-ilp: the kernel is a chain of short dependent regions at 3 waves/SIMD, so a machine
-# scheduler that lengthens the distance between an LDS load and its first use pays directly (measured -4.5 % step time,
-# -7 % lone-wave latency against the default max-occupancy scheduler; max-ilp, max-memory-clause and iterative-minreg lose)
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_*_f32 pairs: in the octet step kernel 1 920
+# packed instructions replace 4 079 scalar ones, but 775 v_mov are added to form the pairs and the two-waves-per-SIMD build (256
+# registers) goes from 0 to 612 B of scratch: 0.149 -> 0.199 ms (round 3), re-measured in round 4 with -slp-threshold 2..16 (DESIGN.md
+# section 7)
 # -O2 rather than -O3: 1 % faster with this scheduler (less aggressive unrolling, same zero scratch)
 FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-fno-slp-vectorize"]
 

@@ -289,14 +289,11 @@ DW_HD void newwalk_reward(const NewWalkArgs &A, int e) {
     const float du[2] = {rp[0] - A.head_states[13 * (size_t)e], rp[1] - A.head_states[13 * (size_t)e + 1]};
     nn = norm_t(du, 2);
     const float rup = expf(-10 * (nn * nn));
-    float dq[NW_MAX_DOF], qv[NW_MAX_DOF];
-    for (int i = 0; i < A.num_dof; ++i) {
-        dq[i] = A.joint_position_states[(size_t)A.num_dof * e + i] - A.q_nominal[i];
-        qv[i] = A.joint_velocity_states[(size_t)A.num_dof * e + i];
-    }
-    nn = norm_t(dq, A.num_dof);
+    // (the two num_dof-long operands are produced element by element, in norm_t's summation order: as local arrays with a run-time
+    //  length they lived in scratch memory, 528 B per lane)
+    nn = dw::norm_fn([&](int i) { return A.joint_position_states[(size_t)A.num_dof * e + i] - A.q_nominal[i]; }, A.num_dof);
     const float rpost = expf(-(nn * nn));
-    nn = norm_t(qv, A.num_dof);
+    nn = dw::norm_fn([&](int i) { return A.joint_velocity_states[(size_t)A.num_dof * e + i]; }, A.num_dof);
     const float rjv = expf(-5e-6f * (nn * nn));
     float r8[8] = {grf, spd, rvel, rang, rh, rup, rpost, rjv};
     float tot = 0.225f * grf + 0.225f * spd + 0.1f * rvel + 0.1f * rang + 0.05f * rh + 0.1f * rup + 0.1f * rpost + 0.1f * rjv;

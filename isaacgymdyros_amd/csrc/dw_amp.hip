@@ -63,38 +63,40 @@ __global__ __launch_bounds__(TPB) void dw_k_body_positions(const dw::DevModel *_
 // wavefront = one workgroup = one env; bodies in dw_amp_step.h (the same source the host emulation compiles).
 namespace {
 
-__global__ __launch_bounds__(64) void dw_k_amp_step_begin(const DwAmpConfig C, const DwAmpBuffers B, const float *dof_state, const float *actions_in,
-                                                         const int64_t *ramp_dur, const float *ramp_u) {
-    __shared__ dwa::StepLds S;
-    dwa::step_begin(dwa::EnvWave(), S, C, B, dof_state, actions_in, ramp_dur, ramp_u, (int)blockIdx.x);
+// (workgroups of four waves per 16 envs: dw_amp_step.h EnvGroup)
+__global__ __launch_bounds__(dwa::GT) void dw_k_amp_step_begin(const DwAmpConfig C, const DwAmpBuffers B, const float *dof_state, const float *actions_in,
+                                                               const int64_t *ramp_dur, const float *ramp_u) {
+    __shared__ dwa::BeginLds S;
+    dwa::step_begin(dwa::EnvGroup(), S, C, B, dof_state, actions_in, ramp_dur, ramp_u, (int)blockIdx.x);
 }
-__global__ __launch_bounds__(64) void dw_k_amp_step_mid(const DwAmpConfig C, const DwAmpBuffers B, const float *dof_state, const float *z, int substep) {
-    __shared__ dwa::StepLds S;
-    dwa::step_mid(dwa::EnvWave(), S, C, B, dof_state, z, substep, (int)blockIdx.x);
+__global__ __launch_bounds__(dwa::GT) void dw_k_amp_step_mid(const DwAmpConfig C, const DwAmpBuffers B, const float *dof_state, const float *z, int substep) {
+    dwa::step_mid(dwa::EnvGroup(), C, B, dof_state, z, substep, (int)blockIdx.x);
 }
-// (four waves per 64 envs: dw_amp_step.h EnvGroup)
 __global__ __launch_bounds__(dwa::GT) void dw_k_amp_step_end(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
                                                              const float *z, int substep, const float *rootvel_noise) {
     __shared__ dwa::GroupLds S;
     dwa::step_end(dwa::EnvGroup(), S, *M, C, B, G, z, substep, rootvel_noise, (int)blockIdx.x);
 }
-// reset_idx of the listed envs: the draws are rows of the caller's arrays in the order of the list
-__global__ __launch_bounds__(64) void dw_k_amp_reset_rows(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
-                                                         const int64_t *ids, dwa::ResetSrc R) {
-    __shared__ dwa::StepLds S;
-    const int e = (int)ids[blockIdx.x];
+// reset_idx of the listed envs: one wavefront per env, four per workgroup; the draws are rows of the caller's arrays in the order of the list
+constexpr int RW = 4;
+__global__ __launch_bounds__(64 * RW) void dw_k_amp_reset_rows(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
+                                                              const int64_t *ids, int n, dwa::ResetSrc R) {
+    __shared__ dwa::StepLds S[RW];
+    const int w = (int)(threadIdx.x >> 6), k = (int)blockIdx.x * RW + w;
+    if (k >= n) return;                            // (wave-uniform: the whole wave leaves; no workgroup barrier below)
+    const int e = (int)ids[k];
     if (e < 0 || e >= C.num_envs) return;          // (ids come from device memory: never write past the tensors)
-    R.row = blockIdx.x;
-    dwa::reset_env(dwa::EnvWave(), S, *M, C, B, G, R, e);
+    R.row = (size_t)k;
+    dwa::reset_env(dwa::EnvWave(), S[w], *M, C, B, G, R, e);
 }
 // reset_done: every env whose reset_buf is set; the draws are indexed by env (or made here)
-__global__ __launch_bounds__(64) void dw_k_amp_reset_done(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
-                                                         dwa::ResetSrc R) {
-    __shared__ dwa::StepLds S;
-    const int e = (int)blockIdx.x;
-    if (B.reset_buf[e] == 0) return;               // (wave-uniform: the whole workgroup leaves)
+__global__ __launch_bounds__(64 * RW) void dw_k_amp_reset_done(const dw::DevModel *__restrict__ M, const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G,
+                                                              dwa::ResetSrc R) {
+    __shared__ dwa::StepLds S[RW];
+    const int w = (int)(threadIdx.x >> 6), e = (int)blockIdx.x * RW + w;
+    if (e >= C.num_envs || B.reset_buf[e] == 0) return;          // (wave-uniform)
     R.row = (size_t)e;
-    dwa::reset_env(dwa::EnvWave(), S, *M, C, B, G, R, e);
+    dwa::reset_env(dwa::EnvWave(), S[w], *M, C, B, G, R, e);
 }
 
 bool amp_args_ok(const DwAmpConfig *c, const DwAmpBuffers *b) {
@@ -210,7 +212,7 @@ int dw_amp_step_begin(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, 
     if (const char *m = handle_ok(h, c)) { char t[160]; snprintf(t, sizeof t, "dw_amp_step_begin: %s", m); return fail(h && !h->bound ? DW_ESTATE : DW_EINVAL, t); }
     if (c->vel_change && !c->device_draws && (!ramp_dur || !ramp_u)) return fail(DW_EINVAL, "dw_amp_step_begin: vel_change needs the ramp draws (or device_draws)");
     if (c->pd_control && (!b->pd_action_offset || !b->pd_action_scale)) return fail(DW_EINVAL, "dw_amp_step_begin: pd_control needs the action offset / scale");
-    hipLaunchKernelGGL(dw_k_amp_step_begin, dim3(c->num_envs), dim3(64), 0, (hipStream_t)stream, *c, *b, h->buf.dof_state, actions_in, ramp_dur, ramp_u);
+    hipLaunchKernelGGL(dw_k_amp_step_begin, dim3((c->num_envs + dwa::GE - 1) / dwa::GE), dim3(dwa::GT), 0, (hipStream_t)stream, *c, *b, h->buf.dof_state, actions_in, ramp_dur, ramp_u);
     return launched("dw_amp_step_begin: launch");
 }
 int dw_amp_step_mid(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *z, int substep, void *stream) {
@@ -218,7 +220,7 @@ int dw_amp_step_mid(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, co
     if (const char *m = handle_ok(h, c)) { char t[160]; snprintf(t, sizeof t, "dw_amp_step_mid: %s", m); return fail(h && !h->bound ? DW_ESTATE : DW_EINVAL, t); }
     if (c->noise && !c->device_draws && !z) return fail(DW_EINVAL, "dw_amp_step_mid: noise needs the encoder draws (or device_draws)");
     if (c->pd_control && (!b->pd_action_offset || !b->pd_action_scale)) return fail(DW_EINVAL, "dw_amp_step_mid: pd_control needs the action offset / scale");
-    hipLaunchKernelGGL(dw_k_amp_step_mid, dim3(c->num_envs), dim3(64), 0, (hipStream_t)stream, *c, *b, h->buf.dof_state, z, substep - 1);
+    hipLaunchKernelGGL(dw_k_amp_step_mid, dim3((c->num_envs + dwa::GE - 1) / dwa::GE), dim3(dwa::GT), 0, (hipStream_t)stream, *c, *b, h->buf.dof_state, z, substep - 1);
     return launched("dw_amp_step_mid: launch");
 }
 int dw_amp_step_end(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *z, int substep, const float *rootvel_noise, void *stream) {
@@ -244,7 +246,7 @@ int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, 
     cc.device_draws = 0;                           // (every draw of this entry point is the caller's)
     dwa::ResetSrc R{power_scale, cmd_x, cmd_y, cmd_yaw, qpos_bias, quat_bias, nullptr, nullptr, perturb_timing, delay_idx, rootvel_noise, 0, false,
                     power_scale != nullptr};
-    hipLaunchKernelGGL(dw_k_amp_reset_rows, dim3(n), dim3(64), 0, (hipStream_t)stream, h->d_model, cc, *b, gym_rows(h), ids, R);
+    hipLaunchKernelGGL(dw_k_amp_reset_rows, dim3((n + RW - 1) / RW), dim3(64 * RW), 0, (hipStream_t)stream, h->d_model, cc, *b, gym_rows(h), ids, n, R);
     return launched("dw_amp_reset_rows: launch");
 }
 
@@ -267,7 +269,7 @@ int dw_amp_reset_done(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, 
     }
     dwa::ResetSrc R{d->power_scale_u, d->cmd_x_u, d->cmd_y_u, d->cmd_yaw_u, d->qpos_bias_u, d->quat_bias_u, d->damping_u, d->armature_u, d->perturb_timing,
                     d->delay_idx, d->rootvel_noise, 0, true, c->randomize != 0};
-    hipLaunchKernelGGL(dw_k_amp_reset_done, dim3(c->num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, *c, *b, gym_rows(h), R);
+    hipLaunchKernelGGL(dw_k_amp_reset_done, dim3((c->num_envs + RW - 1) / RW), dim3(64 * RW), 0, (hipStream_t)stream, h->d_model, *c, *b, gym_rows(h), R);
     return launched("dw_amp_reset_done: launch");
 }
 

@@ -1,9 +1,12 @@
 // dw_amp_step.h -- the fused TocabiAMPLower step and reset (include/dyros_walk.h: dw_amp_step_begin / _mid / _end, dw_amp_reset_rows,
-// dw_amp_reset_done): ONE WAVEFRONT PER ENV, lanes over the env's rows, the rows it computes on staged in LDS.  Written as REGIONS
-// (EnvWave::par): every lane runs a region to its end before any lane starts the next one, regions exchange data through LDS and
-// through the env's rows in global memory only.  On the device a region boundary is a workgroup-scope fence (the workgroup IS the
-// wave); the host emulation (tests/emul/, g++) runs a region as a loop over the 64 lanes -- which is why no value crosses a
-// region boundary in a local variable and why a word that several lanes read is only written in a LATER region.
+// dw_amp_reset_done).  Written as REGIONS: every thread runs a region to its end before any thread starts the next one; regions
+// exchange data through LDS and through the envs' rows in global memory only.  Two shapes:
+//   * the step kernels: a workgroup of 256 threads per 16 envs (EnvGroup), work as items over all threads, the serial per-env
+//     functions with lane = env; a region ends with a workgroup barrier;
+//   * the reset kernels: one wavefront per env (EnvWave), lanes over the env's rows; a region ends with a fence (a wave's memory
+//     operations are ordered; four such waves share a workgroup and never meet).
+// The host emulation (tests/emul/, g++) runs a region as a loop over its threads -- which is why no value crosses a region
+// boundary in a local variable and why a word that several threads read is only written in a LATER region.
 //
 // Every expression is the torch class' (isaacgymdyros_amd/tocabi_amp_lower.py, itself pinned to the reference class by replay:
 // tasks/amp/tocabi_amp_lower_base.py:238-305 reset_idx, :540-580 history stacking, :642-748 pre-physics, :750-804 post-physics;
@@ -103,141 +106,158 @@ DW_HD void stage_leg_model(const EnvWave &W, StepLds &S, const dw::DevModel &M) 
     });
 }
 
-// One entry appended to a history row of `nh` slots of `w` words (w <= 36): the ring writes the new entry over the oldest slot
-// and moves the head; the linear layout moves every slot one down (every lane reads its words in one region and writes them in
-// the next).  `head_slot`: 0 = action history, 1 = observation history.
-DW_HD void history_append(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, float *row, int nh, int w, const float *entry,
-                          int head_slot, int e) {
-    if (C.hist_ring) {
-        W.par([&](int l) {
-            const int head = B.hist_head[2 * (size_t)e + head_slot];
-            if (l < w) row[(size_t)head * w + l] = entry[l];
-            if (l == 0) S.head[head_slot] = head + 1 >= nh ? 0 : head + 1;
-        });
-        W.par([&](int l) { if (l == 0) B.hist_head[2 * (size_t)e + head_slot] = S.head[head_slot]; });
-    } else {
-        const int len = nh * w;
-        W.par([&](int l) {
-            for (int i = l; i < len; i += 64) S.hist[i] = i < len - w ? row[i + w] : entry[i - (len - w)];
-        });
-        W.par([&](int l) {
-            for (int i = l; i < len; i += 64) row[i] = S.hist[i];
-            if (l == 0) S.head[head_slot] = 0;
-        });
-    }
-}
 DW_HD int hist_phys(int head, int logical, int nh) { const int p = head + logical; return p >= nh ? p - nh : p; }
 
-// the torques of one substep into DwAmpBuffers.tau (:696-724).  Region 1 computes, region 2 moves the FIFO counter (every lane of
-// region 1 read it).
-DW_HD void torques(const EnvWave &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, int e) {
-    W.par([&](int l) {
-        if (l >= DW_NUM_DOF) return;
-        const float q = dof_state[((size_t)DW_NUM_DOF * e + l) * 2], qd = dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1];
-        float tau;
-        if (l >= 12) {
-            tau = B.p_gains[l] * (B.init_angle[l] - q) + B.d_gains[l] * (-qd);          // upper body: PD to the initial pose (:696)
-        } else if (C.pd_control) {
-            const float tar = B.pd_action_offset[l] + B.pd_action_scale[l] * B.actions[12 * (size_t)e + l];
-            tau = B.p_gains[l] * (tar - q) + B.d_gains[l] * (-qd);
-        } else {
-            const int64_t sl0 = B.simul_len[e], dl = B.delay_idx[e];
-            const float m = B.motor_efforts[l];
-            float lower = B.actions[12 * (size_t)e + l] * m * B.power_scale[12 * (size_t)e + l];
-            lower = fmaxf(fminf(lower, m), -m);
-            // delayed-torque FIFO (:712-724), column l: shift, append, read `delay_idx` back once the FIFO has filled that far
-            float *col = B.action_log + (size_t)C.log_slots * 12 * e + l;
-            int64_t sl = sl0 + 1;
-            sl = sl > C.log_slots ? C.log_slots : (sl < 0 ? 0 : sl);
-            float delayed = 0.0f;
-            for (int s = 0; s < C.log_slots; ++s) {
-                const float v = s + 1 < C.log_slots ? col[(size_t)12 * (s + 1)] : lower;
-                col[(size_t)12 * s] = v;
-                const int64_t want = sl > dl ? dl : (int64_t)C.log_slots - sl;
-                if (s == want) delayed = v;
+// ---------------------------------------------------------------------------------------------------------------------- step
+// The three step kernels run as workgroups of GT = 256 threads for GE = 16 envs (EnvGroup): their work is ITEMS -- (env, joint),
+// (env, history column), (env, word) -- spread over all threads, so a launch of 16384 envs is 1024 workgroups of four full waves
+// instead of 16384 workgroups of one wave with half its lanes idle (20 us -> for dw_amp_step_begin at 16384 envs).  A region
+// (EnvGroup::par) ends with a workgroup barrier; the same discipline as above holds for what may be read and written where.
+constexpr int GT = 256, GE = 16;
+#if defined(__HIPCC__)
+struct EnvGroup {
+    template <class F> DW_HD void par(F &&f) const { f((int)threadIdx.x); __syncthreads(); }
+};
+#else
+struct EnvGroup {
+    template <class F> void par(F &&f) const { for (int t = 0; t < GT; ++t) f(t); }
+};
+#endif
+
+static_assert(GE * 12 + GE * 3 <= GT, "dw_amp_step_begin: one thread per (env, action) and per (env, command component)");
+struct BeginLds {
+    long long i64[GE][2];
+};
+
+// the torques of one substep into DwAmpBuffers.tau (:696-724), items (env, joint).  A later region moves the FIFO counter
+// (every leg item of the env read it).
+DW_HD void torques(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, int e0) {
+    const int N = C.num_envs;
+    W.par([&](int t) {
+        for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
+            const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
+            if (e >= N) continue;
+            const float q = dof_state[((size_t)DW_NUM_DOF * e + l) * 2], qd = dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1];
+            float tau;
+            if (l >= 12) {
+                tau = B.p_gains[l] * (B.init_angle[l] - q) + B.d_gains[l] * (-qd);          // upper body: PD to the initial pose (:696)
+            } else if (C.pd_control) {
+                const float tar = B.pd_action_offset[l] + B.pd_action_scale[l] * B.actions[12 * (size_t)e + l];
+                tau = B.p_gains[l] * (tar - q) + B.d_gains[l] * (-qd);
+            } else {
+                const int64_t sl0 = B.simul_len[e], dl = B.delay_idx[e];
+                const float m = B.motor_efforts[l];
+                float lower = B.actions[12 * (size_t)e + l] * m * B.power_scale[12 * (size_t)e + l];
+                lower = fmaxf(fminf(lower, m), -m);
+                // delayed-torque FIFO (:712-724), column l: shift, append, read `delay_idx` back once the FIFO has filled that far
+                float *col = B.action_log + (size_t)C.log_slots * 12 * e + l;
+                int64_t sl = sl0 + 1;
+                sl = sl > C.log_slots ? C.log_slots : (sl < 0 ? 0 : sl);
+                float delayed = 0.0f;
+                for (int s = 0; s < C.log_slots; ++s) {
+                    const float v = s + 1 < C.log_slots ? col[(size_t)12 * (s + 1)] : lower;
+                    col[(size_t)12 * s] = v;
+                    const int64_t want = sl > dl ? dl : (int64_t)C.log_slots - sl;
+                    if (s == want) delayed = v;
+                }
+                tau = C.noise ? delayed : lower;
             }
-            tau = C.noise ? delayed : lower;
+            B.tau[(size_t)DW_NUM_DOF * e + l] = tau;
         }
-        B.tau[(size_t)DW_NUM_DOF * e + l] = tau;
     });
     if (!C.pd_control) {
-        W.par([&](int l) {
-            if (l != 0) return;
+        W.par([&](int t) {
+            const int e = e0 + t;
+            if (t >= GE || e >= N) return;
             const int64_t sl = B.simul_len[e] + 1;
             B.simul_len[e] = sl > C.log_slots ? C.log_slots : (sl < 0 ? 0 : sl);
         });
     }
 }
 
-// the encoder model after one substep (:728-736): z = the caller's normal draws [N,33] or nullptr (device draws / no noise).
-// `keep`: also leave the leg joints' reading in S.qn / S.qv (the post-physics half of dw_amp_step_end reads them from there).
-DW_HD void encoder(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep,
-                   bool keep, int e) {
-    W.par([&](int l) {
-        if (l >= DW_NUM_DOF) return;
-        const size_t g = (size_t)DW_NUM_DOF * e + l;
-        const float q = dof_state[g * 2];
-        float qn = q;
-        if (C.noise) {
-            const float zz = z ? z[g] : draw_enc_normal(draw_key(C, B, e), DS_ENC + (unsigned int)substep, l);
-            qn = q + fminf(fmaxf(zz, -0.00016f), 0.00016f);
+// the encoder model after one substep (:728-736), items (env, joint): z = the caller's normal draws [N,33] or nullptr (device
+// draws / no noise)
+DW_HD void encoder(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int e0) {
+    const int N = C.num_envs;
+    W.par([&](int t) {
+        for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
+            const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
+            if (e >= N) continue;
+            const size_t g = (size_t)DW_NUM_DOF * e + l;
+            const float q = dof_state[g * 2];
+            float qn = q;
+            if (C.noise) {
+                const float zz = z ? z[g] : draw_enc_normal(draw_key(C, B, e), DS_ENC + (unsigned int)substep, l);
+                qn = q + fminf(fmaxf(zz, -0.00016f), 0.00016f);
+            }
+            const float d = qn - B.qpos_pre[g];
+            B.qpos_noise[g] = qn;
+            B.qvel_noise[g] = C.gpu_div ? d * C.inv_dt : d / C.dt;
+            B.qpos_pre[g] = qn;
         }
-        const float d = qn - B.qpos_pre[g];
-        const float qv = C.gpu_div ? d * C.inv_dt : d / C.dt;
-        B.qpos_noise[g] = qn;
-        B.qvel_noise[g] = qv;
-        B.qpos_pre[g] = qn;
-        if (keep && l < 12) { S.qn[l] = qn; S.qv[l] = qv; }
     });
 }
 
-// ---------------------------------------------------------------------------------------------------------------------- step
 // dw_amp_step_begin: action clamp + record + action history, command ramp (:642-693), then the torques of the first substep.
-DW_HD void step_begin(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *actions_in,
-                      const int64_t *ramp_dur, const float *ramp_u, int e) {
-    W.par([&](int l) {
-        if (l < 12) {
-            float a = actions_in[12 * (size_t)e + l];
-            a = fminf(fmaxf(a, -C.clip_actions), C.clip_actions);
-            S.acts[l] = a;
-            B.actions[12 * (size_t)e + l] = a;
-        }
-        // command ramp (:676-693), the branch of the host class that draws for every env
-        if (C.vel_change && l < 3) {
-            const int half = (int)(C.max_episode_length / 2), when = (int)(C.max_episode_length / 4 - 1);
-            const bool change = fmodf(B.epi_len[e], (float)half) == (float)when;
-            int64_t dur = B.vel_change_duration[e], cur = B.cur_vel_change_duration[e];
-            float start = B.start_target_vel[3 * (size_t)e + l], fin = B.final_target_vel[3 * (size_t)e + l], cmd = B.commands[3 * (size_t)e + l];
-            if (change) {
-                const DrawKey k = draw_key(C, B, e);
-                dur = ramp_dur ? ramp_dur[e] : draw_int(k, DS_RAMP, 0, 1, 250);
-                cur = 0;
-                start = cmd;
-                const float u = ramp_u ? ramp_u[3 * (size_t)e + l] : draw_uniform(k, DS_RAMP, 1 + l);
-                fin = C.cmd_scale[l] * u + C.cmd_lo[l];
+DW_HD void step_begin(const EnvGroup &W, BeginLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *actions_in,
+                      const int64_t *ramp_dur, const float *ramp_u, int group) {
+    const int N = C.num_envs, e0 = group * GE, NH = C.num_his * C.num_skip;
+    W.par([&](int t) {
+        // items (env, action): clamp, record, history.  A thread owns column k of the env's action history, so the shifting layout
+        // moves in place without a hazard between threads; the ring writes one slot (its head moves in the next region).
+        if (t < GE * 12) {
+            const int el = t / 12, k = t - 12 * el, e = e0 + el;
+            if (e < N) {
+                float a = actions_in[12 * (size_t)e + k];
+                a = fminf(fmaxf(a, -C.clip_actions), C.clip_actions);
+                B.actions[12 * (size_t)e + k] = a;
+                float *ah = B.action_history + (size_t)NH * 12 * e;
+                if (C.hist_ring) {
+                    ah[(size_t)B.hist_head[2 * (size_t)e] * 12 + k] = a;
+                } else {
+                    for (int s = 0; s + 1 < NH; ++s) ah[(size_t)s * 12 + k] = ah[(size_t)(s + 1) * 12 + k];
+                    ah[(size_t)(NH - 1) * 12 + k] = a;
+                }
             }
-            const bool mask = cur < dur;
-            const float ramp = start + (fin - start) * (float)cur / (float)dur;
-            if (mask) cmd = ramp;
-            B.start_target_vel[3 * (size_t)e + l] = start;
-            B.final_target_vel[3 * (size_t)e + l] = fin;
-            B.commands[3 * (size_t)e + l] = cmd;
-            if (l == 0) { S.i64[0] = dur; S.i64[1] = cur + (mask ? 1 : 0); }
+        } else if (C.vel_change && t < GE * 12 + GE * 3) {
+            // command ramp (:676-693), the branch of the host class that draws for every env: items (env, component)
+            const int i = t - GE * 12, el = i / 3, l = i - 3 * el, e = e0 + el;
+            if (e < N) {
+                const int half = (int)(C.max_episode_length / 2), when = (int)(C.max_episode_length / 4 - 1);
+                const bool change = fmodf(B.epi_len[e], (float)half) == (float)when;
+                int64_t dur = B.vel_change_duration[e], cur = B.cur_vel_change_duration[e];
+                float start = B.start_target_vel[3 * (size_t)e + l], fin = B.final_target_vel[3 * (size_t)e + l], cmd = B.commands[3 * (size_t)e + l];
+                if (change) {
+                    const DrawKey k = draw_key(C, B, e);
+                    dur = ramp_dur ? ramp_dur[e] : draw_int(k, DS_RAMP, 0, 1, 250);
+                    cur = 0;
+                    start = cmd;
+                    const float u = ramp_u ? ramp_u[3 * (size_t)e + l] : draw_uniform(k, DS_RAMP, 1 + l);
+                    fin = C.cmd_scale[l] * u + C.cmd_lo[l];
+                }
+                const bool mask = cur < dur;
+                const float ramp = start + (fin - start) * (float)cur / (float)dur;
+                if (mask) cmd = ramp;
+                B.start_target_vel[3 * (size_t)e + l] = start;
+                B.final_target_vel[3 * (size_t)e + l] = fin;
+                B.commands[3 * (size_t)e + l] = cmd;
+                if (l == 0) { S.i64[el][0] = dur; S.i64[el][1] = cur + (mask ? 1 : 0); }
+            }
         }
     });
-    if (C.vel_change) {
-        W.par([&](int l) {
-            if (l == 0) { B.vel_change_duration[e] = S.i64[0]; B.cur_vel_change_duration[e] = S.i64[1]; }
-        });
-    }
-    history_append(W, S, C, B, B.action_history + (size_t)C.num_his * C.num_skip * 12 * e, C.num_his * C.num_skip, 12, S.acts, 0, e);
-    torques(W, C, B, dof_state, e);
+    W.par([&](int t) {
+        const int e = e0 + t;
+        if (t >= GE || e >= N) return;
+        if (C.vel_change) { B.vel_change_duration[e] = S.i64[t][0]; B.cur_vel_change_duration[e] = S.i64[t][1]; }
+        if (C.hist_ring) { const int h = B.hist_head[2 * (size_t)e] + 1; B.hist_head[2 * (size_t)e] = h >= NH ? 0 : h; }
+    });
+    torques(W, C, B, dof_state, e0);
 }
 
 // dw_amp_step_mid: between two substeps -- the encoder model of the one that ended, the torques of the one that starts
-DW_HD void step_mid(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int e) {
-    encoder(W, S, C, B, dof_state, z, substep, false, e);
-    torques(W, C, B, dof_state, e);
+DW_HD void step_mid(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int group) {
+    encoder(W, C, B, dof_state, z, substep, group * GE);
+    torques(W, C, B, dof_state, group * GE);
 }
 
 // dw_amp_step_end: the encoder model of the last substep, then post-physics (:750-804 + the subclass' :88-96): counters, foot
@@ -253,16 +273,6 @@ DW_HD void step_mid(const EnvWave &W, StepLds &S, const DwAmpConfig &C, const Dw
 // 16 envs per group, not 64: with 64 the serial functions cost nothing (1.5 us) but a launch of 16384 envs is 256 workgroups, four
 // waves per CU, and the item loops -- a dependent global load per iteration -- ran at the latency of one wave (127 us measured);
 // 1024 workgroups keep 16 waves per CU in flight.
-constexpr int GT = 256, GE = 16;
-#if defined(__HIPCC__)
-struct EnvGroup {
-    template <class F> DW_HD void par(F &&f) const { f((int)threadIdx.x); __syncthreads(); }
-};
-#else
-struct EnvGroup {
-    template <class F> void par(F &&f) const { for (int t = 0; t < GT; ++t) f(t); }
-};
-#endif
 enum { GR_ROOT = 0, GR_DS = 13, GR_FZ = 79, GR_QN = 81, GR_QV = 93, GR_NZ = 105, GR_BIAS = 111, GR_QB = 123, GR_CMD = 126, GR_ACT = 129, GR_ACTP = 141,
        GR_DVP = 153, GR_OBS = 186, GR_AMP = 222, GR_FOOT = 256, GR_WORDS = 262, GR_STRIDE = 263 };
 struct GroupLds {

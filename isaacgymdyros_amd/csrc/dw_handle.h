@@ -14,7 +14,7 @@ struct DwHandle {
     dwq::QuadModel *d_qmodel;
     dwl::LaneModel *d_lmodel;
     dw::DevParams  *d_params;
-    int             pipeline;       // 1 wave per env, 2 quad (4 lanes per env), 3 octet (8 lanes per env), 4 lane (one lane per env, one wave per limb); one launch per step in all
+    int             pipeline;       // 3 octet (8 lanes per env), 4 lane (one lane per env, one wave per limb); one launch per step in both
     float          *d_mocap;
     float          *d_sc_park;      // octet / lane kernels: PhysParams::sc_park
     DwBuffers       buf;

@@ -1,12 +1,9 @@
-// dw_hip.hip -- gfx950 kernels and the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so).
-//
-// Three kernel generations sit behind the C-ABI (DwConfig.pipeline), each a single launch per policy step.  The default is the
-// octet generation (8 lanes per env, 8 envs per wavefront, two wavefronts per SIMD: dw_oct*.h, entry points in
-// dw_oct_kernels.hip); the quad generation (4 lanes per env, 16 envs per wavefront: dw_quad*.h, dw_quad_kernels.hip) and the
-// wave-per-env generation of round 1 (bodies in dw_task.h / dw_physics.h, entry points here) are the second and third
-// implementations every parity test also runs.  This file also holds dw_k_reset, which all three use for reset_idx; it owns
-// the read-only model / mocap tables in device memory and validates arguments.  Nothing here allocates, synchronises or
-// copies per call.
+// dw_hip.hip -- the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so): argument validation, the read-only model / mocap tables
+// in device memory, dispatch.  One launch per policy step.  The step and substep kernels live in their own translation units:
+// the octet kernels (DwConfig.pipeline 3, the default: 8 lanes per env, 8 envs per wavefront, two wavefronts per SIMD; dw_oct*.h,
+// dw_oct_kernels.hip) and the lane kernels (pipeline 4: one lane per env, one wavefront per limb; dw_lane*.h,
+// dw_lane_kernels.hip).  This file holds dw_k_reset, the kernel behind dw_reset_idx (one wavefront per listed env; the resets
+// inside a step are the step kernels' own).  Nothing here allocates, synchronises or copies per call.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,43 +22,13 @@ static int fail_hip(const char *what, hipError_t e) {
     return DW_EHIP;
 }
 
-// 13.5 KB of LDS per env admits 12 envs per CU = 3 waves per SIMD; cap the registers at 168 to match (measured +16 %
-// over 2 waves/SIMD at 256 registers; the kernel fits the cap without scratch)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void dw_k_step(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step, const long long *step_dev) {
-    __shared__ dw::Lds S;
-    if (step_dev) step = *step_dev;
-    dw::Wave w;
-    dw::TaskBuffers T;
-    T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
-    dw::step_env<false>(w, S, *M, P->C, T, (int)blockIdx.x);
-}
-
-// the same step on a height field (DwConfig.terrain = 1): every contact point samples the terrain
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void dw_k_step_terrain(const dw::DevModel *M, const dw::DevParams *P, const float *actions, const float *noise, long long step, const long long *step_dev) {
-    __shared__ dw::Lds S;
-    if (step_dev) step = *step_dev;
-    dw::Wave w;
-    dw::TaskBuffers T;
-    T.b = &P->B; T.actions = actions; T.noise = noise; T.mocap = P->mocap; T.step = step;
-    dw::step_env<true>(w, S, *M, P->C, T, (int)blockIdx.x);
-}
-
-// The quad kernels (DwConfig.pipeline = 2, the default) are compiled in their own translation unit, dw_quad_kernels.hip,
-// with the compiler's default machine scheduler: the ILP scheduler that pays for the wave-per-env kernels below costs the
-// quad step 7 % (its long unrolled joint loops then keep every iteration's temporaries alive at once and spill).
+// The limb schedule and its tables (dw_quad_model.h), built by the octet unit.
 namespace dwq {
 struct QuadModel;
-void launch_step(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
-void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                     const DwBuffers &B, const float *tau, const float *push);
-int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err, bool octet);      // malloc'ed
+int  build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err);      // malloc'ed
 size_t quadmodel_bytes();
-int  quad_lds_bytes();
 }  // namespace dwq
-// The octet kernels (DwConfig.pipeline = 3): dw_oct_kernels.hip; they take the quad generation's schedule and tables.
+// The octet kernels (DwConfig.pipeline = 3): dw_oct_kernels.hip.
 namespace dwo {
 void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
@@ -83,20 +50,6 @@ size_t lanemodel_bytes();
 int  lane_lds_bytes();
 size_t sc_park_floats(int num_envs);
 }  // namespace dwl
-
-__global__ __launch_bounds__(64) void dw_k_simulate(const dw::DevModel *M, const dw::DevParams *P,
-                                                    const float *tau, const float *push) {
-    __shared__ dw::Lds S;
-    dw::Wave w;
-    dw::simulate_env<false>(w, S, *M, P->C, P->B, tau, push, (int)blockIdx.x);
-}
-
-__global__ __launch_bounds__(64) void dw_k_simulate_terrain(const dw::DevModel *M, const dw::DevParams *P,
-                                                            const float *tau, const float *push) {
-    __shared__ dw::Lds S;
-    dw::Wave w;
-    dw::simulate_env<true>(w, S, *M, P->C, P->B, tau, push, (int)blockIdx.x);
-}
 
 __global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, const dw::DevParams *P, const float *noise,
                                                  long long step, const int32_t *ids, int n) {
@@ -152,8 +105,8 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
         rc = dwl::build_lanemodel_host(hm, &hl, &err);
         if (rc) { free(hm); free(h); return fail(rc, err); }
     }
-    if (h->pipeline == 2 || h->pipeline == 3) {
-        rc = dwq::build_quadmodel_host(hm, model, &hq, &err, h->pipeline == 3);
+    if (h->pipeline == 3) {
+        rc = dwq::build_quadmodel_host(hm, model, &hq, &err);
         if (rc) { free(hm); free(h); return fail(rc, err); }
     }
     (void)hipGetDevice(&h->device);
@@ -236,16 +189,9 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     DeviceGuard guard(h->device);
     if (h->pipeline == 4) {
         dwl::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
-    } else if (h->pipeline == 3) {
+    } else {
         dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
-    } else if (h->pipeline == 2) {
-        dwq::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
-    } else if (h->cfg.terrain)
-        hipLaunchKernelGGL(dw_k_simulate_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
-                           h->d_params, tau, push_xy);
-    else
-        hipLaunchKernelGGL(dw_k_simulate, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
-                           tau, push_xy);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_simulate: launch", e);
     return DW_OK;
@@ -260,26 +206,17 @@ static int launch_step(DwHandle *h, const float *actions, const float *noise, lo
     if (const char *m = dw::check_buffers(&h->buf, true)) return fail(DW_ESTATE, m);
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
-    if (obs_out && h->pipeline < 2) return fail(DW_EINVAL, "dw_step_obs: an observation destination per call needs pipeline 2, 3 or 4");
     DeviceGuard guard(h->device);
-    // (the quad / octet kernels take DwBuffers by value: this launch's copy may name another observation buffer)
+    // (the kernels take the buffer table by value: this launch's copy may name another observation buffer)
     DwBuffers bufs = h->buf;
     if (obs_out) bufs.obs_buf = obs_out;
     if (h->pipeline == 4) {
         dwl::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
-    } else if (h->pipeline == 3) {
+    } else {
         dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
-    } else if (h->pipeline == 2) {
-        dwq::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
-                         actions, noise, step_index, step_dev);
-    } else if (h->cfg.terrain)
-        hipLaunchKernelGGL(dw_k_step_terrain, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model,
-                           h->d_params, actions, noise, step_index, step_dev);
-    else
-        hipLaunchKernelGGL(dw_k_step, dim3(h->cfg.num_envs), dim3(64), 0, (hipStream_t)stream, h->d_model, h->d_params,
-                           actions, noise, step_index, step_dev);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(who, e);
     return DW_OK;
@@ -324,8 +261,6 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
     return DW_OK;
 }
 
-int dw_lds_bytes(void) { return (int)sizeof(dw::Lds); }
-int dw_quad_lds_bytes(void) { return dwq::quad_lds_bytes(); }
 int dw_oct_lds_bytes(void) { return dwo::oct_lds_bytes(); }
 int dw_lane_lds_bytes(void) { return dwl::lane_lds_bytes(); }
 

@@ -19,7 +19,7 @@
 // packed per-body records (6 KB).
 #pragma once
 
-#include "dw_quad.h"
+#include "dw_limb.h"
 #include "dw_bufg.h"
 #include "dw_lane_wave.h"
 #include "dw_lane_model.h"

@@ -57,12 +57,10 @@ template <int NW> DQ_HD void st_row(float *p, const float (&v)[NW]) {
     DQ_UNROLL for (int i = NW - NW % 4; i < NW; ++i) p[i] = v[i];
 }
 
-// torch.norm of 3 elements on the CPU reference (dw_task.h norm_t with n = 3: fused scalar tail)
-DQ_HD float norm3_t(float x, float y, float z) {
-    float b0 = fmaf(x, x, 0.0f);
-    b0 = fmaf(y, y, b0);
-    b0 = fmaf(z, z, b0);
-    return sqrtf(b0);
+// torch.norm of 3 elements in torch's CPU or GPU summation order (dw_task.h norm_sel)
+DQ_HD float norm3_t(int gpu, float x, float y, float z) {
+    const float v[3] = {x, y, z};
+    return dw::norm_sel_v<3>(gpu, v);
 }
 
 // Inputs from the physics part of the kernel: KP = the new joint state and the encoder angle / rate after the second substep of
@@ -163,7 +161,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             const int ee = i / DW_NUM_BODIES, g = i - DW_NUM_BODIES * ee;
             const int eg = group * EPW + ee < N ? group * EPW + ee : N - 1;
             const float *cf = B.contact_forces + ((size_t)DW_NUM_BODIES * eg + g) * 3;
-            if (g != LFG && g != RFG && norm3_t(cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
+            if (g != LFG && g != RFG && norm3_t(C.gpu_div, cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
         }
     } else {
         wg_barrier();
@@ -227,55 +225,42 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
     DL_STAMP2(19);
     // ---- Q2: reward terms, one group per wave ----
     {
-        // the three 33-element norms in torch's CPU order: 8 fused accumulators over elements a, a+8, a+16, a+24, added in
-        // order, then the 33rd element fused (dw_task.h Q2 / Q2b)
+        // the three 33-element norms, in torch's CPU order (8 fused accumulators over elements a, a+8, a+16, a+24, added in order,
+        // then the 33rd element fused) or in its GPU order (dw_task.h norm_sel), elements produced on the fly
         auto norm33 = [&](int which) {
-            float acc[8];
-            DQ_UNROLL for (int a = 0; a < 8; ++a) {
-                float s = 0.0f;
-                DQ_UNROLL for (int d0 = 0; d0 < 32; d0 += 8) {
-                    const int jj = d0 + a;
-                    const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
-                                  : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
-                    s = fmaf(x, x, s);
-                }
-                acc[a] = s;
-            }
-            float b0 = acc[0];
-            DQ_UNROLL for (int a = 1; a < 8; ++a) b0 = b0 + acc[a];
-            const float x = which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + 32) - PQ_Q(el, 32)
-                          : (which == 1 ? 0.0f - PQ_QD(el, 32) : PQ_QD(el, 32) - PQ_ES(el, DW_ES_PRE_QVEL + 32));
-            b0 = fmaf(x, x, b0);
-            const float n = sqrtf(b0);
+            const float n = dw::norm_sel<33>(C.gpu_div, [&](int jj) {
+                return which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
+                     : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
+            });
             const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
             return coef * expf(rate * (n * n));
         };
         if (w == 0) {
             const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
-            const float aerr = fabsf(dw::quat_err(qq));
+            const float aerr = fabsf(dw::quat_err(qq, C.gpu_div));
             PQ_PS(el, PS_RTERM + 14) = aerr;
             PQ_PS(el, PS_RTERM + 0) = 0.3f * expf(-13.2f * aerr);
             const float dv[2] = {PQ_ES(el, DW_ES_TARGET_VEL) - PQ_ROOT(el, 7), PQ_ES(el, DW_ES_TARGET_VEL + 1) - PQ_ROOT(el, 8)};
-            const float n = dw::norm_t(dv, 2);
+            const float n = dw::norm_sel_v<2>(C.gpu_div, dv);
             PQ_PS(el, PS_RTERM + 6) = 0.3f * expf(-3.0f * (n * n));
         }
         if (w == 1) {
             PQ_PS(el, PS_RTERM + 1) = norm33(0);
-            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_fn([&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }, 12));
+            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_sel<12>(C.gpu_div, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }));
         }
         if (w == 2) {
             PQ_PS(el, PS_RTERM + 2) = norm33(1);
             PQ_PS(el, PS_RTERM + 7) = norm33(2);
         }
         if (w == 3) {
-            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_fn([&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }, 12));
+            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_sel<12>(C.gpu_div, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }));
             const float lf[3] = {PQ_PS(el, PS_FOOT), PQ_PS(el, PS_FOOT + 1), PQ_PS(el, PS_FOOT + 2)};
             const float rf[3] = {PQ_PS(el, PS_FOOT + 3), PQ_PS(el, PS_FOOT + 4), PQ_PS(el, PS_FOOT + 5)};
             const float lfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 1), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 2)};
             const float rfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 3), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 4), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 5)};
             float dl[3], dr[3];
             DQ_UNROLL for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
-            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_t(dl, 3) + dw::norm_t(dr, 3)));
+            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_sel_v<3>(C.gpu_div, dl) + dw::norm_sel_v<3>(C.gpu_div, dr)));
             const bool lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
             const int idx = PQ_ESI(el, DW_ES_MOCAP_IDX);
             const bool DSP = (3300 <= idx && idx < 3600) || (idx < 300) || (1500 <= idx && idx < 2100);
@@ -293,7 +278,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             const bool th = (lf[2] > thr) || (rf[2] > thr);
             PQ_PS(el, PS_RTERM + 11) = th ? -0.2f * 1.0f : 0.0f;
             const float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
-            const float pen = 0.1f * expf(-0.007f * (dw::norm_t(&cl, 1) + dw::norm_t(&cr, 1)));
+            const float pen = 0.1f * expf(-0.007f * (dw::norm_sel_v<1>(C.gpu_div, &cl) + dw::norm_sel_v<1>(C.gpu_div, &cr)));
             PQ_PS(el, PS_RTERM + 3) = th ? pen : 0.1f * 1.0f;
             const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
             const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
@@ -348,10 +333,10 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
     if (any_reset) {
         if (C.terrain_curriculum && w == 0 && PQ_PSI(el, PS_RESET)) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
-            const float distance = dw::norm_t(d, 2);
+            const float distance = dw::norm_sel_v<2>(C.gpu_div, d);
             const bool move_up = distance > C.terrain_half_length;
             const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
-            const float need = dw::norm_t(tv, 2) * C.max_episode_length_s * 0.5f;
+            const float need = dw::norm_sel_v<2>(C.gpu_div, tv) * C.max_episode_length_s * 0.5f;
             const bool move_down = (distance < need) && !move_up;
             long long lvl = OQ_COLD(terrain_levels)[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
             if (lvl >= C.terrain_num_levels) {

@@ -18,7 +18,7 @@
 // side effects in global memory.
 #pragma once
 
-#include "dw_quad.h"
+#include "dw_limb.h"
 #include "dw_bufg.h"
 
 namespace dwo {

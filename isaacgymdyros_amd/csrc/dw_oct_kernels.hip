@@ -38,6 +38,24 @@ void dw_k_simulate_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel
     dwo::oct_simulate<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, make_obuf(HB, &P->B), tau, push, (int)blockIdx.x * dwo::WPG + w);
 }
 
+namespace dwq {
+// the limb schedule and its tables (dw_quad_model.h) for the octet kernels, built on the host at dw_create
+int build_quadmodel_host(const dw::DevModel *hm, const DwModel *model, QuadModel **out, const char **err) {
+    QuadModel *q = (QuadModel *)malloc(sizeof(QuadModel));
+    if (!q) { *err = "out of host memory"; return DW_ENOMEM; }
+    int rc = build_quadmodel(hm, model, q, err, true);
+    // (the octet kernels carry no parking registers: build_quadmodel(accumulate) must have scheduled every hand-over)
+    if (rc == DW_OK)
+        for (int s = 0; s < QS_MAX; ++s) for (int l = 0; l < 4; ++l)
+            if (q->in[s][l].body >= 0 && (q->in[s][l].flags & 2)) { rc = DW_EINVAL; *err = "octet kernels: the schedule parks a chain"; }
+    if (rc == DW_OK && q->nsteps != QS_MAX) { rc = DW_EINVAL; *err = "octet kernels: built for a schedule of exactly QS_MAX steps"; }
+    if (rc) { free(q); return rc; }
+    *out = q;
+    return DW_OK;
+}
+size_t quadmodel_bytes() { return sizeof(QuadModel); }
+}  // namespace dwq
+
 namespace dwo {
 
 static int groups(int num_envs) { return (num_envs + EPO * WPG - 1) / (EPO * WPG); }

@@ -3,7 +3,7 @@
 
 #include "dw_task.h"
 
-// which kernel generation DwConfig.pipeline = 0 selects
+// which kernels DwConfig.pipeline = 0 selects
 #define DW_DEFAULT_PIPELINE 3
 
 namespace dw {
@@ -18,7 +18,8 @@ inline const char *check_config(const DwConfig *c) {
         return "terrain: rows/cols >= 2 and positive scales required";
     if (c->terrain_curriculum && (c->terrain_num_levels < 1 || c->terrain_num_types < 1))
         return "terrain curriculum: num_levels and num_types must be positive";
-    if (c->pipeline < 0 || c->pipeline > 4) return "pipeline must be 0 (default), 1 (wave per env), 2 (quad: 4 lanes per env), 3 (octet: 8 lanes per env) or 4 (lane: one lane per env, one wave per limb)";
+    if (c->pipeline == 1 || c->pipeline == 2) return "pipeline 1 (wave per env) and 2 (quad) are retired: use 0 (default), 3 (octet: 8 lanes per env) or 4 (lane: one lane per env, one wave per limb)";
+    if (c->pipeline != 0 && c->pipeline != 3 && c->pipeline != 4) return "pipeline must be 0 (default), 3 (octet: 8 lanes per env) or 4 (lane: one lane per env, one wave per limb)";
     return nullptr;
 }
 

@@ -1,18 +1,14 @@
-// dw_task.h -- the whole VecTask.step of DyrosDynamicWalk for one env, as wave regions.
+// dw_task.h -- what the step kernels of every layout share of the DyrosDynamicWalk task logic, and reset_idx for one env.
 //
-// Mirrors, with every fp32 operation in the reference's order (fp contraction OFF in this file):
-//   VecTask.step                        tasks/base/vec_task.py:293-344
-//   pre_physics_step                    tasks/dyros_dynamic_walk.py:449-541 (cubic: utils/torch_jit_utils.py:373-395)
-//   post_physics_step                   tasks/dyros_dynamic_walk.py:543-563
+// The parameter block (TaskParams, DevParams), the counter-based generator (Philox4x32-10 and the draws built on it), the
+// torch-flavoured scalar helpers (division, remainder, norm in torch's summation orders, the cubic, the quaternion error), the
+// early-termination gate, and reset_idx of ONE env as wave regions (reset_region / reset_only_env: the kernel behind
+// dw_reset_idx, one wavefront per listed env -- a rare, host-driven call; the resets inside a step are the step kernels' own,
+// dw_oct_post.h / dw_lane_post.h).  fp contraction is OFF in this file: every fp32 operation is in the reference's order:
 //   check_termination                   tasks/dyros_dynamic_walk.py:581-596 (quat_diff_rad: utils/torch_jit_utils.py:141-160)
-//   compute_humanoid_walk_reward        tasks/dyros_dynamic_walk.py:802-947
 //   reset_idx + dof-property DR         tasks/dyros_dynamic_walk.py:598-669,720-748; tasks/base/vec_task.py:519-733
-//   compute_humanoid_walk_observations  tasks/dyros_dynamic_walk.py:750-796 (quat2euler: python/isaacgym/torch_utils.py:227-273)
+//   cubic                               utils/torch_jit_utils.py:373-395
 // (paths relative to python/IsaacGymEnvs/isaacgymenvs unless they start with python/).
-//
-// Data flow: the env's task-state record (DW_ES_WORDS words) and its Gym state are staged into LDS once,
-// both physics substeps run on LDS, and only the record, the Gym tensors, the new history slot and the
-// 487-word observation go back to HBM.  Histories are rings: nothing is shifted.
 #pragma once
 
 #include "dw_physics.h"
@@ -170,6 +166,41 @@ DW_HD float norm_fn(F f, int n) {
     for (; d < n; ++d) { const float x = f(d); b0 = fmaf(x, x, b0); }
     return sqrtf(b0);
 }
+// torch.norm over a contiguous fp32 row as torch's GPU reduce kernel sums it on ROCm (ATen/native/cuda/Reduce.cuh, reduction over
+// the fastest dimension with fewer than 128 inputs per output; probed on the MI355X against torch 2.10, tools/probe_gpu_norm3.py:
+// 100 % of 1 M rows for every row length the task uses (33, 12, 3, 2; also 6 and 13), for any base alignment and any number of
+// rows): T = the largest power of two <= n (at most 32) threads share a row; thread t squares x[t], x[t + T], ... into separate
+// accumulators and adds them in that order; the threads combine by shuffle-down with offsets 1, 2, 4, ... -- a balanced tree over
+// t in index order; sqrt is correctly rounded.  (The CPU kernel's order is norm_t / norm_fn above; which one a build reproduces
+// is DwConfig.torch_gpu_div, like the flavour of `tensor / python_scalar`.)
+template <int LO, int LEN, class P>
+DW_HD float norm_g_tree(P &p) {
+    if constexpr (LEN == 1) {
+        return p(LO);
+    } else {
+        const float a = norm_g_tree<LO, LEN / 2>(p);
+        const float b = norm_g_tree<LO + LEN / 2, LEN / 2>(p);
+        return a + b;
+    }
+}
+template <int N, class F>
+DW_HD float norm_g(F f) {
+    constexpr int T = N >= 32 ? 32 : (N >= 16 ? 16 : (N >= 8 ? 8 : (N >= 4 ? 4 : (N >= 2 ? 2 : 1))));
+    static_assert(N >= 1 && N <= 4 * T, "a thread holds at most four accumulators (vt0 = 4)");
+    auto part = [&](int t) {
+        const float x = f(t);
+        float v = x * x;
+        for (int k = t + T; k < N; k += T) { const float y = f(k); const float yy = y * y; v = v + yy; }
+        return v;
+    };
+    return sqrtf(norm_g_tree<0, T>(part));
+}
+// the norm of N elements f(0) .. f(N - 1) in the order of torch's GPU kernel (gpu != 0) or of its CPU kernel
+template <int N, class F>
+DW_HD float norm_sel(int gpu, F f) { return gpu ? norm_g<N>(f) : norm_fn(f, N); }
+template <int N>
+DW_HD float norm_sel_v(int gpu, const float *x) { return norm_sel<N>(gpu, [&](int i) { return x[i]; }); }
+
 DW_HD float cubic_t(float time, float t0, float tf, float x0, float xf) {
     const float elapsed = time - t0;
     const float total = tf - t0;
@@ -184,7 +215,7 @@ DW_HD float cubic_t(float time, float t0, float tf, float x0, float xf) {
     if (t0 <= time && time <= tf) xt = cub;
     return xt;
 }
-DW_HD float quat_err(const float *q) {
+DW_HD float quat_err(const float *q, int gpu_norm = 0) {
     const float x1 = 0, y1 = 0, z1 = 0, w1 = 1;
     const float x2 = -q[0], y2 = -q[1], z2 = -q[2], w2 = q[3];
     const float ww = (z1 + x1) * (x2 + y2);
@@ -196,7 +227,7 @@ DW_HD float quat_err(const float *q) {
     const float y = qq - yy + (w1 - x1) * (y2 + z2);
     const float z = qq - zz + (z1 + y1) * (w2 - x2);
     const float v[3] = {x, y, z};
-    float n = norm_t(v, 3);
+    float n = norm_sel_v<3>(gpu_norm, v);
     if (n > 1.0f) n = 1.0f;
     return 2.0f * asinf(n);
 }
@@ -204,8 +235,7 @@ DW_HD bool finitef(float x) { return fabsf(x) <= 3.4028234663852886e38f; }   // 
 
 #define ESI(off) (*reinterpret_cast<int *>(&S.es[(off)]))
 
-// LDS block of dw_k_reset (reset_idx of listed envs, one wave per env, both pipelines): the task record and the Gym state
-// of one env, 3.6 KB.
+// LDS block of dw_k_reset (reset_idx of listed envs, one wave per env): the task record and the Gym state of one env, 3.6 KB.
 struct alignas(16) TaskLds {
     float root[13];
     float q[ND], qd[ND];
@@ -220,27 +250,6 @@ struct alignas(16) TaskLds {
 };
 
 // ---------------------------------------------------------------------------------------------- load / store
-DW_HD void load_env_lane(int l, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {   // fused kernels
-    {
-        if (with_task)
-            for (int i = l; i < DW_ES_WORDS; i += 64) S.es[i] = B.env_state[(size_t)DW_ES_WORDS * e + i];
-        if (l < 13) S.root[l] = B.root_states[13 * e + l];
-        if (l < ND) {
-            S.q[l] = B.dof_state[(ND * e + l) * 2];
-            S.qd[l] = B.dof_state[(ND * e + l) * 2 + 1];
-            S.arm[l] = B.dof_armature[ND * e + l];
-            S.damp[l] = B.dof_damping[ND * e + l];
-        }
-        if (l < DW_NUM_BODIES) S.mscale[l] = B.mass_scale[DW_NUM_BODIES * e + l];
-        if (l == 40) S.mu = C.friction * B.friction_scale[e];
-        if (l < 4) S.flags[l] = 0;
-    }
-}
-template <class W>
-DW_HD void load_env(const W &wave, Lds &S, const TaskParams &C, const DwBuffers &B, int e, bool with_task) {
-    wave.par([&](int l) { load_env_lane(l, S, C, B, e, with_task); });
-}
-
 template <class W, class LT>
 DW_HD void store_env(const W &wave, LT &S, const DwBuffers &B, int e, bool with_task, bool with_state) {
     wave.par([&](int l) {
@@ -269,9 +278,9 @@ DW_HD void reset_region(const W &wave, LT &S, const DevModel &M, const TaskParam
         wave.par([&](int l) {
             if (l == 0) {
                 const float d[2] = {S.root[0] - B.env_origins[3 * e], S.root[1] - B.env_origins[3 * e + 1]};
-                const float distance = norm_t(d, 2);
+                const float distance = norm_sel_v<2>(C.gpu_div, d);
                 const bool move_up = distance > C.terrain_half_length;
-                const float need = norm_t(&S.es[DW_ES_TARGET_VEL], 2) * C.max_episode_length_s * 0.5f;
+                const float need = norm_sel_v<2>(C.gpu_div, &S.es[DW_ES_TARGET_VEL]) * C.max_episode_length_s * 0.5f;
                 const bool move_down = (distance < need) && !move_up;
                 long long lvl = B.terrain_levels[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
                 if (lvl >= C.terrain_num_levels) {
@@ -413,420 +422,6 @@ DW_HD float clamp_action(const float *actions, int e, int l) {
     return a;
 }
 
-// Regions P1, P2 (pre_physics_step up to the substep loop).  Expects S.es, S.act, S.flags[6] (gate).  FUSED: the warm-start
-// impulses are copied into the physics block (the split pipeline's physics kernel reads them from the record itself).
-template <bool FUSED, class W, class LT>
-DW_HD void task_p1p2(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e, const StepCtx &K) {
-    const DwBuffers &B = *T.b;
-    const NoiseSrc &nz = K.nz;
-    const float period = K.period, cdt = K.cdt;
-    const double cdt_d = K.cdt_d;
-    long long *gate = K.gate;
-    // ---- P1: clamp actions, mocap phase, perturbation gate and schedule (scalar work on single lanes) ----
-    wave.par([&](int l) {
-        if (l < DW_NUM_ACT) {
-            const float a = S.act[l];
-            S.es[DW_ES_ACTIONS + l] = a;
-            B.action_history[((size_t)e * DW_HIST_SLOTS + ESI(DW_ES_HIST_HEAD)) * DW_NUM_ACT + l] = a;
-        }
-        if (l == 32) {
-            const float time = S.es[DW_ES_TIME];
-            const int init_idx = ESI(DW_ES_INIT_MOCAP);
-            const float local_time = remainder_t(time, period);
-            S.scratch[0] = remainder_t(local_time + (float)init_idx * cdt, period);
-            const int midx = (int)(((long long)init_idx + (long long)divs(C.gpu_div, local_time, cdt_d)) % 3599);
-            ESI(DW_ES_MOCAP_IDX) = midx;
-        }
-        if (l == 33) {
-            const int open = S.flags[6];
-            if (open) {
-                ESI(DW_ES_PERT_START) = 1;
-                if (!C.force_perturb_start) gate[GATE_LATCH] = 1;
-            }
-            float px = 0.0f, py = 0.0f;
-            if (ESI(DW_ES_PERT_START)) {
-                if (remainder_t(S.es[DW_ES_EPI_LEN], C.pert_period_f) == (float)ESI(DW_ES_PERT_TIMING)) {
-                    ESI(DW_ES_PERT_ON) = 1;
-                    int imp = 50 + (int)(noise_word(nz, DW_NZ_PERT + 0) * 200.0f);
-                    if (imp > 249) imp = 249;
-                    int dur = C.pert_dur_lo + (int)(noise_word(nz, DW_NZ_PERT + 1) * (float)(C.pert_dur_hi - C.pert_dur_lo));
-                    if (dur > C.pert_dur_hi - 1) dur = C.pert_dur_hi - 1;
-                    ESI(DW_ES_IMPULSE) = imp;
-                    ESI(DW_ES_PERT_DURATION) = dur;
-                    S.es[DW_ES_MAGNITUDE] = (float)imp / ((float)dur * C.dt_policy_f);
-                    S.es[DW_ES_PHASE] = noise_word(nz, DW_NZ_PERT + 2) * 2.0f * (float)3.14159265358979;
-                }
-                if (ESI(DW_ES_PERT_ON)) {
-                    ESI(DW_ES_PERT_COUNT) += 1;
-                    px = S.es[DW_ES_MAGNITUDE] * cosf(S.es[DW_ES_PHASE]);
-                    py = S.es[DW_ES_MAGNITUDE] * sinf(S.es[DW_ES_PHASE]);
-                }
-                if (ESI(DW_ES_PERT_COUNT) == ESI(DW_ES_PERT_DURATION)) {
-                    ESI(DW_ES_PERT_ON) = 0;
-                    ESI(DW_ES_PERT_COUNT) = 0;
-                }
-            }
-            S.scratch[1] = px;
-            S.scratch[2] = py;
-        }
-        if (FUSED) { if (l >= 40 && l < 40 + 24) S.warm[l - 40] = S.es[DW_ES_WARM + (l - 40)]; }
-    });
-    // ---- P2: mocap target (cubic between two table rows), leg torques from the actions ----
-    wave.par([&](int l) {
-        const int midx = ESI(DW_ES_MOCAP_IDX);
-        const float *row0 = T.mocap + (size_t)midx * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
-        const float ltp = S.scratch[0];
-        if (l < 35) {
-            const float v = cubic_t(ltp, row0[0], row1[0], row0[1 + l], row1[1 + l]);
-            if (l < 33) S.es[DW_ES_TARGET_QPOS + l] = v;
-            else S.es[DW_ES_TARGET_FORCE + (l - 33)] = v;
-        }
-        if (l >= 40 && l < 52) {
-            const int i = l - 40;
-            S.es[DW_ES_ACTION_TORQUE + i] = S.act[i] * S.es[DW_ES_MOTOR_SCALE + i] * M.action_high[i];
-        }
-    });
-}
-
-// Regions Q1..Q6 (post_physics_step).  Expects S.es, S.root, S.q, S.qd, S.contact, S.act, S.flags[4], S.flags[5], S.scratch[3],
-// S.flags[0..3] = 0.  Returns whether the env was reset or hit the non-finite guard (its Gym state changed).
-template <bool FUSED, class W, class LT>
-DW_HD int task_post(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e, const StepCtx &K) {
-    const DwBuffers &B = *T.b;
-    const NoiseSrc &nz = K.nz;
-    const float period = K.period;
-    const double cdt_d = K.cdt_d;
-    long long *gate = K.gate;
-    const int slot_cur = K.slot_cur, slot_next = K.slot_next;
-    // ---- Q1: clocks, VecTask counters, non-finite guard ----
-    wave.par([&](int l) {
-        if (l == 40) {
-            S.es[DW_ES_EPI_LEN] += 1.0f;
-            float time = S.es[DW_ES_TIME];
-            time = time + C.dt_policy_f;
-            time = time + C.clock_gain_f * S.act[12];
-            S.es[DW_ES_TIME] = time;
-            const long long p = S.flags[5];
-            B.timeout_buf[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
-            B.progress_buf[e] = p + 1;
-            S.flags[5] = (int)(p + 1);
-            const int rb = S.flags[4] + 1;           // steps since the last parameter randomisation, saturating
-            B.randomize_buf[e] = rb;
-            S.flags[4] = rb;
-        }
-        if (FUSED) { if (l < 24) S.es[DW_ES_WARM + l] = S.warm[l]; }
-        bool bad = false;
-        if (l < 13) bad |= !finitef(S.root[l]);
-        if (l < ND) bad |= !finitef(S.q[l]) || !finitef(S.qd[l]);
-        if (bad) S.flags[1] = 1;
-    });
-    if (uniform(S.flags[1])) {
-        wave.par([&](int l) {
-            if (l < 13) S.root[l] = (l == 2) ? C.initial_height : (l == 6 ? 1.0f : 0.0f);
-            if (l < ND) { S.q[l] = 0.0f; S.qd[l] = 0.0f; }
-            for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = 0.0f;
-            if (l == 40) ESI(DW_ES_NAN_RESETS) += 1;
-        });
-    }
-
-    // ---- Q2: reward terms, one term (or one reduction) per lane ----
-    wave.par([&](int l) {
-        const int LF = M.left_foot_gym, RF = M.right_foot_gym;
-        if (l < DW_NUM_BODIES) {
-            if (l != LF && l != RF && norm_t(&S.contact[3 * l], 3) > 1.0f) S.flags[2] = 1;
-        }
-        if (l == 40) {
-            const float aerr = fabsf(quat_err(&S.root[3]));
-            S.rterm[14] = aerr;
-            S.rterm[0] = 0.3f * expf(-13.2f * aerr);
-        }
-        if (l >= 8 && l < 32) {
-            // three 33-element norms at once: lanes 8..15 / 16..23 / 24..31 hold the 8 fused accumulators of
-            // torch's CPU reduction for qpos error / qvel / qacc; the combine happens in Q3
-            const int which = (l - 8) >> 3, a = (l - 8) & 7;
-            float acc = 0.0f;
-            for (int d = 0; d < 32; d += 8) {
-                const int j = d + a;
-                const float x = which == 0 ? S.es[DW_ES_TARGET_QPOS + j] - S.q[j]
-                              : (which == 1 ? 0.0f - S.qd[j] : S.qd[j] - S.es[DW_ES_PRE_QVEL + j]);
-                acc = fmaf(x, x, acc);
-            }
-            S.normed[(which << 3) + a] = acc; // normed[] is free until Q4
-        }
-        if (l == 44) {
-            S.rterm[4] = 0.05f * expf(-0.01f * norm_fn([&](int i) { return S.es[DW_ES_ACTIONS + i] * 333.0f; }, 12));
-        }
-        if (l == 45) {
-            S.rterm[5] = 0.6f * expf((-0.01f * 1.0f) * norm_fn([&](int i) { return (S.es[DW_ES_ACTIONS + i] - S.es[DW_ES_ACTIONS_PRE + i]) * 333.0f; }, 12));
-        }
-        if (l == 46) {
-            const float dv[2] = {S.es[DW_ES_TARGET_VEL] - S.root[7], S.es[DW_ES_TARGET_VEL + 1] - S.root[8]};
-            const float n = norm_t(dv, 2);
-            S.rterm[6] = 0.3f * expf(-3.0f * (n * n));
-        }
-        if (l == 47) {
-            const float *lf = &S.contact[3 * LF], *rf = &S.contact[3 * RF];
-            const float *lfp = &S.es[DW_ES_FOOT_FORCE_PRE], *rfp = &S.es[DW_ES_FOOT_FORCE_PRE + 3];
-            float dl[3], dr[3];
-            for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
-            S.rterm[9] = 0.2f * expf((-0.01f * 1.0f) * (norm_t(dl, 3) + norm_t(dr, 3)));
-            const bool lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
-            const int idx = ESI(DW_ES_MOCAP_IDX);
-            const bool DSP = (3300 <= idx && idx < 3600) || (idx < 300) || (1500 <= idx && idx < 2100);
-            const bool RSSP = 300 <= idx && idx < 1500;
-            const bool LSSP = 2100 <= idx && idx < 3300;
-            float fcr = 0.0f;
-            if (DSP && rcon && lcon) fcr = 0.2f;
-            if (RSSP && rcon && !lcon) fcr = 0.2f;
-            if (LSSP && !rcon && lcon) fcr = 0.2f;
-            S.rterm[8] = fcr;
-            S.es[DW_ES_CRS] = S.es[DW_ES_CRS] + fcr;
-            S.rterm[10] = 0.0f;
-            const float tm = S.scratch[3];
-            const float thr = (float)(1.4 * 9.81) * tm;
-            const bool th = (lf[2] > thr) || (rf[2] > thr);
-            S.rterm[11] = th ? -0.2f * 1.0f : 0.0f;
-            const float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
-            const float pen = 0.1f * expf(-0.007f * (norm_t(&cl, 1) + norm_t(&cr, 1)));
-            S.rterm[3] = th ? pen : 0.1f * 1.0f;
-            const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
-            const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
-            S.rterm[12] = dd ? -0.05f * 1.0f : 0.0f;
-            const float ws = divs(C.gpu_div, tm, 104.48);
-            const float tl = 0.1f * expf(-0.001f * fabsf(lf[2] + ws * S.es[DW_ES_TARGET_FORCE]));
-            const float tr = 0.1f * expf(-0.001f * fabsf(rf[2] + ws * S.es[DW_ES_TARGET_FORCE + 1]));
-            S.rterm[13] = tl + tr;
-        }
-    });
-    // ---- Q2b: combine the partial sums (lanes in order, then the 33rd element fused), exp ----
-    wave.par([&](int l) {
-        if (l >= 41 && l < 44) {
-            const int which = l - 41;
-            float b0 = S.normed[which << 3];
-            for (int a = 1; a < 8; ++a) b0 = b0 + S.normed[(which << 3) + a];
-            const float x = which == 0 ? S.es[DW_ES_TARGET_QPOS + 32] - S.q[32]
-                          : (which == 1 ? 0.0f - S.qd[32] : S.qd[32] - S.es[DW_ES_PRE_QVEL + 32]);
-            b0 = fmaf(x, x, b0);
-            const float n = sqrtf(b0);
-            const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
-            S.rterm[which == 0 ? 1 : (which == 1 ? 2 : 7)] = coef * expf(rate * (n * n));
-        }
-    });
-    // ---- Q3: total reward, termination ----
-    wave.par([&](int l) {
-        const bool collision = S.flags[2] != 0;
-        const float aerr = S.rterm[14];
-        if (l < 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : S.rterm[l];
-        if (l == 14) B.stacked_rewards[(size_t)DW_NUM_REW * e + 14] = ESI(DW_ES_PERT_START) ? 1.0f : 0.0f;
-        if (l == 40) {
-            const float *r = S.rterm;
-            float total = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + r[10] + r[11] + r[12] + r[13];
-            if (collision) total = 1.0f * C.death_cost;
-            if (aerr > 0.5f) total = 1.0f * C.death_cost;
-            B.rew_buf[e] = total;
-            int reset = aerr > 0.5f ? 1 : 0;
-            if ((float)S.flags[5] >= C.max_episode_length - 1.0f) reset = 1;
-            if (collision) reset = 1;
-            if (S.flags[1]) reset = 1;
-            B.reset_buf[e] = reset;
-            S.flags[3] = reset;
-            float ret = S.es[DW_ES_EPI_RETURN] + total;
-            if (reset) {
-                S.es[DW_ES_LAST_RETURN] = ret;
-                ESI(DW_ES_EPISODES) += 1;
-                ret = 0.0f;
-            }
-            S.es[DW_ES_EPI_RETURN] = ret;
-        }
-    });
-    const int did_reset = uniform(S.flags[3]);
-    if (did_reset) reset_region(wave, S, M, C, B, nz, e);
-
-    // ---- Q4: 37-d observation, normalisation, newest history slot ----
-    wave.par([&](int l) {
-        if (l < DW_NUM_OBS1) {
-            float o;
-            if (l < 3) {
-                const float x = S.root[3], y = S.root[4], z = S.root[5], w = S.root[6];
-                const float m00 = w * w + x * x - y * y - z * z;
-                const float m01 = 2 * x * y - 2 * w * z;
-                const float m10 = 2 * x * y + 2 * w * z;
-                const float m11 = w * w - x * x + y * y - z * z;
-                const float m20 = 2 * x * z - 2 * w * y;
-                const float m21 = 2 * y * z + 2 * w * x;
-                const float m22 = w * w - x * x - y * y + z * z;
-                const float cy = sqrtf(m00 * m00 + m10 * m10);
-                const bool cond = cy > (float)(2.220446049250313e-16 * 4);
-                // one atan2 call for the three lanes: (num, den) per Euler angle (mat2euler, torch_utils.py:248-269)
-                const float num = l == 0 ? m21 : (l == 1 ? -m20 : (cond ? m10 : -m01));
-                const float den = l == 0 ? m22 : (l == 1 ? cy : (cond ? m00 : m11));
-                o = atan2f(num, den);
-                if (l == 0 && !cond) o = 0.0f;
-                o = o + S.es[DW_ES_QUAT_BIAS + l];
-            } else if (l < 15) {
-                o = S.es[DW_ES_QPOS_NOISE + (l - 3)] + S.es[DW_ES_QPOS_BIAS + (l - 3)];
-            } else if (l < 27) {
-                o = S.es[DW_ES_QVEL_NOISE + (l - 15)];
-            } else if (l < 29) {
-                const float time2idx = divs(C.gpu_div, remainder_t(S.es[DW_ES_TIME], period), cdt_d);
-                const float phase = divs(C.gpu_div, remainder_t((float)ESI(DW_ES_INIT_MOCAP) + time2idx, 3599.0f), 3599.0);
-                const float ang = (float)(2 * 3.14159265358979) * phase;
-                float sn, cs;
-                sincosf(ang, &sn, &cs);
-                o = l == 27 ? sn : cs;
-            } else if (l < 31) {
-                o = S.es[DW_ES_TARGET_VEL + (l - 29)];
-            } else {
-                o = S.root[7 + (l - 31)] + (noise_word(nz, DW_NZ_VEL + (l - 31)) * 0.05f - 0.025f);
-            }
-            const float nrm = (o - M.obs_mean[l]) / M.obs_inv_std_den[l];
-            S.normed[l] = nrm;
-            float *oh = B.obs_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_OBS1;
-            if (S.es[DW_ES_EPI_LEN] == 0.0f) {
-                for (int s = 0; s < DW_HIST_SLOTS; ++s) oh[s * DW_NUM_OBS1 + l] = nrm;
-            } else {
-                oh[ESI(DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l] = nrm;
-            }
-        }
-    });
-    // ---- Q5: 487-d observation buffer from the ring taps ----
-    wave.par([&](int l) {
-        const int head = (ESI(DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;       // position of the oldest slot after this step's push
-        const int newest = ESI(DW_ES_HIST_HEAD);
-        const bool fill = S.es[DW_ES_EPI_LEN] == 0.0f;
-        const float *oh = B.obs_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_OBS1;
-        const float *ah = B.action_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_ACT;
-        float *ob = B.obs_buf + (size_t)DW_NUM_OBS * e;
-        // all tap loads are issued before the first store (the two buffers may alias as far as the compiler knows, so a
-        // load-store-load-store loop would pay one memory round trip per tap)
-        constexpr int NO = (DW_NUM_OBS1 * DW_NUM_HIS + 63) / 64, NA = (DW_NUM_ACT * (DW_NUM_HIS - 1) + 63) / 64;
-        float vo[NO], va[NA];
-        for (int j = 0; j < NO; ++j) {
-            const int f = l + 64 * j;
-            vo[j] = 0.0f;
-            if (f < DW_NUM_OBS1 * DW_NUM_HIS) {
-                const int i = f / DW_NUM_OBS1, k = f - i * DW_NUM_OBS1;
-                const int slot = (head + DW_NUM_SKIP * (i + 1) - 1) % DW_HIST_SLOTS;
-                vo[j] = (fill || slot == newest) ? S.normed[k] : oh[slot * DW_NUM_OBS1 + k];
-            }
-        }
-        for (int j = 0; j < NA; ++j) {
-            const int f = l + 64 * j;
-            va[j] = 0.0f;
-            if (f < DW_NUM_ACT * (DW_NUM_HIS - 1)) {
-                const int i = f / DW_NUM_ACT, k = f - i * DW_NUM_ACT;
-                const int slot = (head + DW_NUM_SKIP * (i + 1)) % DW_HIST_SLOTS;
-                va[j] = did_reset ? 0.0f : (slot == newest ? S.act[k] : ah[slot * DW_NUM_ACT + k]);
-            }
-        }
-        for (int j = 0; j < NO; ++j) { const int f = l + 64 * j; if (f < DW_NUM_OBS1 * DW_NUM_HIS) ob[f] = vo[j]; }
-        for (int j = 0; j < NA; ++j) { const int f = l + 64 * j; if (f < DW_NUM_ACT * (DW_NUM_HIS - 1)) ob[DW_NUM_OBS1 * DW_NUM_HIS + f] = va[j]; }
-    });
-    // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
-    wave.par([&](int l) {
-        if (l < ND) S.es[DW_ES_PRE_QVEL + l] = S.qd[l];
-        if (l < 12) S.es[DW_ES_ACTION_TORQUE_PRE + l] = S.es[DW_ES_ACTION_TORQUE + l];
-        if (l < DW_NUM_ACT) S.es[DW_ES_ACTIONS_PRE + l] = S.es[DW_ES_ACTIONS + l];
-        if (l >= 56 && l < 62) {
-            const int i = l - 56, gy = i < 3 ? M.left_foot_gym : M.right_foot_gym;
-            S.es[DW_ES_FOOT_FORCE_PRE + i] = S.contact[3 * gy + (i % 3)];
-        }
-        if (l == 40) ESI(DW_ES_HIST_HEAD) = (ESI(DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
-        if (l == 41 && C.perturb && !C.force_perturb_start) {
-            const float el = S.es[DW_ES_EPI_LEN_LOG], cm = S.es[DW_ES_CRM];
-            const int bk = e % GATE_BUCKETS;
-            long long de, dc = 0;
-            if (finitef(el) && finitef(cm)) { de = (long long)el; dc = (long long)llrintf(cm * 4294967296.0f); }
-            else de = -((long long)1 << 62);
-#if defined(__HIPCC__)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&gate[(slot_cur * GATE_BUCKETS + bk) * 2]), (unsigned long long)de);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&gate[(slot_cur * GATE_BUCKETS + bk) * 2 + 1]), (unsigned long long)dc);
-#else
-            gate[(slot_cur * GATE_BUCKETS + bk) * 2] += de;
-            gate[(slot_cur * GATE_BUCKETS + bk) * 2 + 1] += dc;
-#endif
-            gate[(slot_next * GATE_BUCKETS + bk) * 2] = 0;
-            gate[(slot_next * GATE_BUCKETS + bk) * 2 + 1] = 0;
-        }
-    });
-    return did_reset | uniform(S.flags[1]);
-}
-
-// The fused wave-per-env step (first-generation kernel, DwConfig.pipeline = 1; flat ground and height fields)
-template <bool TERRAIN, class W>
-DW_HD void step_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
-    const DwBuffers &B = *T.b;
-    const StepCtx K = make_step_ctx(C, T, e);
-    const NoiseSrc &nz = K.nz;
-    const float dt = K.dt;
-    const TreeUniform TU = make_tree_uniform(M);
-
-    // One region issues every global load whose address does not depend on this step's arithmetic -- tree tables,
-    // the env's record and state, its actions, counters, mass and the gate sums -- so the wave waits for HBM/L2 once
-    // here instead of once per phase that needs a scalar.
-    wave.par([&](int l) {
-        stage_tree_lane(l, S, M);
-        load_env_lane(l, S, C, B, e, true);
-        if (l < DW_NUM_ACT) S.act[l] = clamp_action(T.actions, e, l);
-        if (l == 33) S.flags[6] = gate_open(C, K);
-        if (l == 34) load_counters(S, B, e);
-    });
-    if (C.freeze_physics) {      // debug mode: simulate() is the identity, so the net contact forces are an input too
-        wave.par([&](int l) {
-            for (int i = l; i < DW_NUM_BODIES * 3; i += 64) S.contact[i] = B.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i];
-        });
-    }
-    task_p1p2<true>(wave, S, M, C, T, e, K);
-
-    // ---- P3: two physics substeps with the actuator model around them ----
-    // unrolled on purpose: as a loop, ~45 lane-constant model loads were hoisted out of it and kept live across the
-    // whole substep body, which at the 168-register cap meant spilling them (188 B/lane of scratch)
-#if !defined(DW_ROLL_SUBSTEPS)
-#pragma unroll
-#else
-#pragma clang loop unroll(disable)
-#endif
-    for (int sub = 0; sub < 2; ++sub) {
-        wave.par([&](int l) {
-            if (l < 12) {
-                // torque FIFO, column l (tasks/dyros_dynamic_walk.py:511-519)
-                float col[DW_ALOG_SLOTS];
-                for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) col[s] = S.es[DW_ES_ACTION_LOG + 12 * (s + 1) + l];
-                col[DW_ALOG_SLOTS - 1] = S.es[DW_ES_ACTION_TORQUE + l];
-                for (int s = 0; s < DW_ALOG_SLOTS; ++s) S.es[DW_ES_ACTION_LOG + 12 * s + l] = col[s];
-                int sl = ESI(DW_ES_SIMUL_LEN) + 1;
-                if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
-                const int dl = ESI(DW_ES_DELAY_IDX);
-                const int src = sl > dl ? dl : DW_ALOG_SLOTS - sl;
-                float t = col[0];
-                for (int s = 1; s < DW_ALOG_SLOTS; ++s) t = (s == src) ? col[s] : t;
-                S.tau[l] = t;
-            } else if (l < ND) {
-                S.tau[l] = M.kp[l] * (S.es[DW_ES_TARGET_QPOS + l] - S.q[l]) + M.kv[l] * (-S.qd[l]);
-            }
-            if (l == 40) { S.push[0] = sub == 0 ? S.scratch[1] : 0.0f; S.push[1] = sub == 0 ? S.scratch[2] : 0.0f; }
-        });
-        if (!C.freeze_physics) physics_substep<TERRAIN>(wave, S, M, C.phys, TU);
-        wave.par([&](int l) {
-            if (l < ND) {
-                const float n = noise_word(nz, DW_NZ_ENC + ND * sub + l);
-                const float qn = S.q[l] + fminf(fmaxf(n, -0.00016f), 0.00016f);
-                S.es[DW_ES_QVEL_NOISE + l] = C.gpu_div ? (qn - S.es[DW_ES_QPOS_PRE + l]) * C.inv_dt_f : (qn - S.es[DW_ES_QPOS_PRE + l]) / dt;
-                S.es[DW_ES_QPOS_NOISE + l] = qn;
-                S.es[DW_ES_QPOS_PRE + l] = qn;
-            }
-            if (l == 40) {
-                int sl = ESI(DW_ES_SIMUL_LEN) + 1;
-                if (sl > DW_ALOG_SLOTS) sl = DW_ALOG_SLOTS;
-                ESI(DW_ES_SIMUL_LEN) = sl;
-            }
-        });
-    }
-
-    task_post<true>(wave, S, M, C, T, e, K);
-    store_env(wave, S, B, e, true, true);
-}
-
 // reset_done path (tasks/base/vec_task.py:376-391 -> reset_idx): one env
 template <class W, class LT>
 DW_HD void reset_only_env(const W &wave, LT &S, const DevModel &M, const TaskParams &C, const TaskBuffers &T, int e) {
@@ -849,23 +444,6 @@ DW_HD void reset_only_env(const W &wave, LT &S, const DevModel &M, const TaskPar
     store_env(wave, S, B, e, true, true);
 }
 
-// Gym-boundary substep: tau [N,33], push [N,2] or nullptr
-template <bool TERRAIN, class W>
-DW_HD void simulate_env(const W &wave, Lds &S, const DevModel &M, const TaskParams &C, const DwBuffers &B,
-                        const float *tau, const float *push, int e) {
-    stage_tree(wave, S, M);
-    load_env(wave, S, C, B, e, false);
-    wave.par([&](int l) {
-        if (l < ND) S.tau[l] = tau[ND * e + l];
-        if (l == 40) { S.push[0] = push ? push[2 * e] : 0.0f; S.push[1] = push ? push[2 * e + 1] : 0.0f; }
-        if (l < 24) S.warm[l] = B.env_state ? B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + l] : 0.0f;
-    });
-    physics_substep<TERRAIN>(wave, S, M, C.phys, make_tree_uniform(M));
-    wave.par([&](int l) {
-        if (l < 24 && B.env_state) B.env_state[(size_t)DW_ES_WORDS * e + DW_ES_WARM + l] = S.warm[l];
-    });
-    store_env(wave, S, B, e, false, true);
-}
 
 #undef ESI
 

@@ -94,7 +94,7 @@ class DyrosDynamicWalk(VecTask):
         if self.cfg["sim"].get("mi355", {}).get("device_step_counter", False):
             self._step_dev = torch.zeros(1, dtype=torch.int64, device=self._tdev)
         self._bound_obs = self._buf["obs_buf"]
-        self._fresh_obs = (not self.alias_obs) and np.isinf(self.clip_obs) and int(self._ccfg.pipeline or 3) in (2, 3, 4)
+        self._fresh_obs = (not self.alias_obs) and np.isinf(self.clip_obs)
         self.extras["reward_names"] = list(REWARD_NAMES)
 
     # ------------------------------------------------------------------ native handle
@@ -144,7 +144,7 @@ class DyrosDynamicWalk(VecTask):
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
         # which kernels: 0/3 = octet kernels, 8 lanes per env, two waves per SIMD (default), 2 = quad kernels (4 lanes per env), 1 = wave-per-env
         # kernels of round 1; one launch per policy step in all three
-        c.pipeline = {"auto": 0, "fused": 1, "quad": 2, "oct": 3, "lane": 4}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
+        c.pipeline = {"auto": 0, "oct": 3, "lane": 4}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
         tc = self.terrain_cfg
         c.terrain = int(self.custom_origins)
         c.custom_origins = int(self.custom_origins)
@@ -388,9 +388,8 @@ class DyrosDynamicWalk(VecTask):
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
         profiles/ carry the same name)."""
         pl = int(self._ccfg.pipeline) or 3
-        name = {1: "dw_k_step", 2: "dw_k_step_quad", 3: "dw_k_step_oct", 4: "dw_k_step_lane"}[pl]
-        desc = {1: "wave per env", 2: "quad (4 lanes per env, 16 envs per wave)", 3: "octet (8 lanes per env, 8 envs per wave, 2 waves per SIMD)",
-                4: "lane (one lane per env, one wave per limb, 64 envs per workgroup)"}[pl]
+        name = {3: "dw_k_step_oct", 4: "dw_k_step_lane"}[pl]
+        desc = {3: "octet (8 lanes per env, 8 envs per wave, 2 waves per SIMD)", 4: "lane (one lane per env, one wave per limb, 64 envs per workgroup)"}[pl]
         return {"kernels": name, "pipeline": desc, "launches_per_step": 1}
 
     def simulate(self, tau: torch.Tensor, push_xy: torch.Tensor = None):

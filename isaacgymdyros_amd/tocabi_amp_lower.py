@@ -44,6 +44,11 @@ env's observation reads are recomputed from the state just set (dw_body_position
 show the pre-reset rows there -- irrelevant for the history, which _init_amp_obs overwrites.
 
 Not built: `stateInit: Custom` (the task's triangle-mesh terrain origins; the terrain of this task is not wired).
+
+Where this class departs from the task yaml, all of it on purpose: the spawn height is 0.93 m, not the reference's 0.89 (which
+starts the soles 2.2 cm inside the plane; cfg sim.mi355.amp_initial_height restores the number); env.contactBodies must be the two
+foot links (the kernels test Gym rows 8 and 16; anything else is refused); terrainType other than 'plane' and stateInit 'Custom'
+are refused.  physx.num_position_iterations + num_velocity_iterations is taken as given (4 + 0 for this task).
 """
 from __future__ import annotations
 
@@ -146,6 +151,10 @@ class TocabiAMPLower(VecTask):
         if self._state_init != "Default" and not e.get("motion_file"):
             raise ValueError("stateInit %r draws its start states from the motion library: set cfg.env.motion_file (the reference's "
                              "tables are not in its checkout)" % self._state_init)
+        # the bodies allowed to touch the ground are the two foot links in the kernels (Gym rows 8 and 16: dw_amp_step_end's
+        # termination, dw_amp_reset's caller); a cfg that names others is refused rather than silently given the feet
+        if list(e.get("contactBodies", ["L_Foot_Link", "R_Foot_Link"])) != ["L_Foot_Link", "R_Foot_Link"]:
+            raise ValueError("TocabiAMPLower on the MI355X physics: env.contactBodies must be ['L_Foot_Link', 'R_Foot_Link'] (module docstring)")
         self._pd_control = e["pdControl"]
         self.randomize = cfg["task"]["randomize"]
         self.noise = cfg["task"]["noise"]
@@ -164,7 +173,8 @@ class TocabiAMPLower(VecTask):
         pc = default_cfg(self.num_envs, self.device)
         pc["seed"] = cfg.get("seed", 42)
         pc["sim"].update({k: copy.deepcopy(v) for k, v in cfg["sim"].items() if k != "mi355"})
-        pc["sim"]["physx"]["num_velocity_iterations"] = max(1, cfg["sim"]["physx"].get("num_velocity_iterations", 0))
+        # (physx.num_position_iterations + num_velocity_iterations = the contact solver's iteration count, as the task yaml gives them:
+        #  4 + 0 for this task, cfg/task/TocabiAMPLower.yaml)
         pc["sim"]["mi355"].update(cfg["sim"].get("mi355", {}))
         pc["env"]["perturbation"] = False
         # spawn height: the reference's 0.89 (:394) puts the soles 2.2 cm INTO the plane in the initial pose; PhysX resolves that

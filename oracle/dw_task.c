@@ -94,6 +94,27 @@ static float norm_t(const float *x, int n) {
     return sqrtf(b0);
 }
 
+/* the same row as torch's GPU reduce kernel sums it on ROCm (ATen/native/cuda/Reduce.cuh, reduction over the fastest dimension, fewer
+ * than 128 inputs per output; probed on an MI355X against torch 2.10, tools/probe_gpu_norm3.py: every bit of 1 M rows for n = 33, 12,
+ * 6, 13, 3, 2, any base alignment, any number of rows): T = the largest power of two <= n (at most 32) threads share the row, thread
+ * t squares x[t], x[t + T], ... into separate accumulators and adds them in order, the threads combine by shuffle-down with offsets
+ * 1, 2, 4, ...; sqrt is correctly rounded */
+static float norm_g(const float *x, int n) {
+    int T = 1;
+    while (T * 2 <= n && T < 32) T *= 2;
+    float part[32];
+    for (int t = 0; t < T; ++t) {
+        float v = x[t] * x[t];
+        for (int k = t + T; k < n; k += T) { float yy = x[k] * x[k]; v = v + yy; }
+        part[t] = v;
+    }
+    for (int off = 1; off < T; off *= 2)
+        for (int t = 0; t + off < T; t += 2 * off) part[t] = part[t] + part[t + off];
+    return sqrtf(part[0]);
+}
+/* which of the two a build reproduces is DwConfig.torch_gpu_div, like the flavour of `tensor / python_scalar` */
+#define norm_s(x, n) (h->cfg.torch_gpu_div ? norm_g((x), (n)) : norm_t((x), (n)))
+
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 /* utils/torch_jit_utils.py:373-395 with x_dot_0 = x_dot_f = 0.0 */
@@ -113,7 +134,7 @@ static float cubic_t(float time, float t0, float tf, float x0, float xf) {
 }
 
 /* quat_diff_rad(identity, q) */
-static float quat_err(const float *q /* xyzw */) {
+static float quat_err(const float *q /* xyzw */, int gpu_norm) {
     const float x1 = 0, y1 = 0, z1 = 0, w1 = 1;
     const float x2 = -q[0], y2 = -q[1], z2 = -q[2], w2 = q[3];
     float ww = (z1 + x1) * (x2 + y2);
@@ -125,7 +146,7 @@ static float quat_err(const float *q /* xyzw */) {
     float y = qq - yy + (w1 - x1) * (y2 + z2);
     float z = qq - zz + (z1 + y1) * (w2 - x2);
     float v[3] = {x, y, z};
-    float n = norm_t(v, 3);
+    float n = gpu_norm ? norm_g(v, 3) : norm_t(v, 3);
     if (n > 1.0f) n = 1.0f;            /* torch.clamp(max=1.0); NaN propagates through fminf differently, see below */
     return 2.0f * asinf(n);
 }
@@ -171,9 +192,9 @@ static void reset_env(DwHandle *h, int e, const Noise *nz) {
     if (cfg->terrain_curriculum) {
         const float *root_old = b->root_states + 13 * e;
         float d[2] = {root_old[0] - b->env_origins[3 * e], root_old[1] - b->env_origins[3 * e + 1]};
-        const float distance = norm_t(d, 2);
+        const float distance = norm_s(d, 2);
         const int move_up = distance > (float)(cfg->terrain_env_length / 2.0);
-        const float need = norm_t(&es[DW_ES_TARGET_VEL], 2) * cfg->max_episode_length_s * 0.5f;
+        const float need = norm_s(&es[DW_ES_TARGET_VEL], 2) * cfg->max_episode_length_s * 0.5f;
         const int move_down = (distance < need) && !move_up;
         int64_t lvl = b->terrain_levels[e] + (1 * move_up - 1 * move_down);
         if (lvl >= cfg->terrain_num_levels) {
@@ -308,37 +329,37 @@ static void reward_env(DwHandle *h, int e, int *reset_out) {
     const float *root = b->root_states + 13 * e;
     const float *cf = b->contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
     const int LF = h->model.left_foot_gym, RF = h->model.right_foot_gym;
-    float qerr = quat_err(root + 3);
+    float qerr = quat_err(root + 3, h->cfg.torch_gpu_div);
     float aerr = fabsf(qerr);
     int collision = 0;
     for (int k = 0; k < DW_NUM_BODIES; ++k) {
         if (k == LF || k == RF) continue;
-        if (norm_t(cf + 3 * k, 3) > 1.0f) collision = 1;
+        if (norm_s(cf + 3 * k, 3) > 1.0f) collision = 1;
     }
     float r[14];
     r[0] = 0.3f * expf(-13.2f * aerr);
     float d33[33];
     for (int j = 0; j < 33; ++j) d33[j] = es[DW_ES_TARGET_QPOS + j] - b->dof_state[(DW_NUM_DOF * e + j) * 2];
-    float n = norm_t(d33, 33);
+    float n = norm_s(d33, 33);
     r[1] = 0.35f * expf(-2.0f * (n * n));
     for (int j = 0; j < 33; ++j) d33[j] = 0.0f - b->dof_state[(DW_NUM_DOF * e + j) * 2 + 1];
-    n = norm_t(d33, 33);
+    n = norm_s(d33, 33);
     r[2] = 0.05f * expf(-0.01f * (n * n));
     const float *lf = cf + 3 * LF, *rf = cf + 3 * RF;
     const float *lfp = es + DW_ES_FOOT_FORCE_PRE, *rfp = es + DW_ES_FOOT_FORCE_PRE + 3;
     float dl[3], dr[3];
     for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
-    r[9] = 0.2f * expf((-0.01f * 1.0f) * (norm_t(dl, 3) + norm_t(dr, 3)));
+    r[9] = 0.2f * expf((-0.01f * 1.0f) * (norm_s(dl, 3) + norm_s(dr, 3)));
     float a12[12];
     for (int i = 0; i < 12; ++i) a12[i] = es[DW_ES_ACTIONS + i] * 333.0f;
-    r[4] = 0.05f * expf(-0.01f * norm_t(a12, 12));
+    r[4] = 0.05f * expf(-0.01f * norm_s(a12, 12));
     for (int i = 0; i < 12; ++i) a12[i] = (es[DW_ES_ACTIONS + i] - es[DW_ES_ACTIONS_PRE + i]) * 333.0f;
-    r[5] = 0.6f * expf((-0.01f * 1.0f) * norm_t(a12, 12));
+    r[5] = 0.6f * expf((-0.01f * 1.0f) * norm_s(a12, 12));
     for (int j = 0; j < 33; ++j) d33[j] = b->dof_state[(DW_NUM_DOF * e + j) * 2 + 1] - es[DW_ES_PRE_QVEL + j];
-    n = norm_t(d33, 33);
+    n = norm_s(d33, 33);
     r[7] = 0.05f * expf(-20.0f * (n * n));
     float dv[2] = {es[DW_ES_TARGET_VEL] - root[7], es[DW_ES_TARGET_VEL + 1] - root[8]};
-    n = norm_t(dv, 2);
+    n = norm_s(dv, 2);
     r[6] = 0.3f * expf(-3.0f * (n * n));
     int lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
     int idx = *esi(es, DW_ES_MOCAP_IDX);
@@ -359,7 +380,7 @@ static void reward_env(DwHandle *h, int e, int *reset_out) {
     r[11] = th ? -0.2f * 1.0f : 0.0f;
     {
         float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
-        float pen = 0.1f * expf(-0.007f * (norm_t(&cl, 1) + norm_t(&cr, 1)));
+        float pen = 0.1f * expf(-0.007f * (norm_s(&cl, 1) + norm_s(&cr, 1)));
         r[3] = th ? pen : 0.1f * 1.0f;
     }
     {

@@ -1,4 +1,4 @@
-"""Loads the host lane-loop emulation of the kernel body (tests/emul) behind the same driver as the oracle."""
+"""Loads the host emulation of the kernel bodies (tests/emul: the kernel source under g++, one fiber per lane) behind the same driver as the oracle."""
 import ctypes as C
 import os
 import subprocess
@@ -10,9 +10,9 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
 _cache = {}
 
 
-def load(asan=False, quad=False):
-    # quad: False = wave-per-env kernels, True = quad kernels, "oct" = octet kernels, "lane" = lane kernels
-    name = {False: "libdw_emul", True: "libdw_emul_quad", "oct": "libdw_emul_oct", "lane": "libdw_emul_lane"}[quad] + ("_asan.so" if asan else ".so")
+def load(asan=False, layout="oct"):
+    # layout: "oct" = octet kernels (also carries the fused TocabiAMPLower kernels), "lane" = lane kernels
+    name = {"oct": "libdw_emul_oct", "lane": "libdw_emul_lane"}[layout] + ("_asan.so" if asan else ".so")
     if name not in _cache:
         subprocess.check_call(["make", "-C", HERE, "-s", "_build/" + name])
         lib = C.CDLL(os.path.join(HERE, "_build", name))
@@ -21,13 +21,13 @@ def load(asan=False, quad=False):
 
 
 class EmulSim(OracleSim):
-    def __init__(self, num_envs, task_const=None, quad=False, **cfg_over):
-        super().__init__(num_envs, task_const=task_const, lib_api=load(quad=quad), **cfg_over)
+    def __init__(self, num_envs, task_const=None, layout="oct", **cfg_over):
+        super().__init__(num_envs, task_const=task_const, lib_api=load(layout=layout), **cfg_over)
 
 
 class EmulBackend:
-    def __init__(self, N, task_const, quad=False, **cfg):
-        self.sim = EmulSim(N, task_const=task_const, quad=quad, **cfg)
+    def __init__(self, N, task_const, layout="oct", **cfg):
+        self.sim = EmulSim(N, task_const=task_const, layout=layout, **cfg)
 
     def load_buffers(self, bufs):
         for k, v in bufs.items():

@@ -11,7 +11,7 @@ from emul_backend import EmulSim
 
 
 def make(N, **kw):
-    sim = EmulSim(N, quad="oct", self_collision=0)
+    sim = EmulSim(N, layout="oct", self_collision=0)
     return AmpEmul(sim, N, **kw)
 
 

@@ -702,7 +702,7 @@ def test_fused_amp_kernels_with_device_draws_equal_their_host_emulation():
     N = 7
     kw = dict(seed=19, episode_length=10.0, hist_ring=True, device_draws=True)
     g = _HipAmp(N, **kw)
-    e = AmpEmul(EmulSim(N, quad="oct", self_collision=0), N, **kw)
+    e = AmpEmul(EmulSim(N, layout="oct", self_collision=0), N, **kw)
     e.a["total_mass"][:] = g.t["total_mass"].cpu().numpy()          # (the GPU env randomised its link masses at setup)
     exact = ["actions", "actions_pre", "commands", "start_target_vel", "final_target_vel", "vel_change_duration", "cur_vel_change_duration",
              "epi_len", "power_scale", "delay_idx", "simul_len", "qpos_bias", "quat_bias", "progress_buf", "randomize_buf", "reset_buf", "terminate_buf",

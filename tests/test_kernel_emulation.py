@@ -10,16 +10,16 @@ from oracle import parity as P
 from oracle.oracle import OracleSim
 
 
-@pytest.fixture(params=[False, True, "oct", "lane"], ids=["wave-per-env", "quad", "oct", "lane"])
-def quad(request):
-    """Both kernel generations run the same checks: the fused wave-per-env kernel (dw_task.h + dw_physics.h) and the split
-    pipeline around the quad physics kernel (dw_quad*.h, 4 lanes per env, one fiber per lane on the host)."""
+@pytest.fixture(params=["oct", "lane"])
+def layout(request):
+    """Both lane layouts run the same checks: the octet kernels (dw_oct*.h: 8 lanes per env, one fiber per lane on the host) and
+    the lane kernels (dw_lane*.h: one lane per env, one wavefront per limb, one fiber per thread of the workgroup)."""
     return request.param
 
 
-def test_task_logic_bitwise_vs_reference_goldens(task_const, quad):
+def test_task_logic_bitwise_vs_reference_goldens(task_const, layout):
     g = R.load("task_logic_frozen.npz")
-    be = EmulBackend(int(g["N"]), task_const, quad=quad, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
+    be = EmulBackend(int(g["N"]), task_const, layout=layout, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
     for t, ref, got in R.replay(g, be):
         exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
         if "obs_history" in ref:
@@ -30,10 +30,10 @@ def test_task_logic_bitwise_vs_reference_goldens(task_const, quad):
     assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
 
 
-def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, quad):
+def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, layout):
     """Row f-4 through the kernel source: level changes, tile origins and spawn jitter of the reference's curriculum."""
     g = R.load("terrain_logic_frozen.npz")
-    be = EmulBackend(int(g["N"]), task_const, quad=quad, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
+    be = EmulBackend(int(g["N"]), task_const, layout=layout, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
                      terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]))
     for t, ref, got in R.replay(g, be):
         ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
@@ -44,14 +44,14 @@ def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, quad):
         assert np.array_equal(g["step_env_origins"][t], got["env_origins"]), t
 
 
-def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, quad):
+def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, layout):
     """Same libm on both sides here, so with physics frozen the kernel body and the oracle agree on every bit,
     in-kernel Philox noise included (noise = None)."""
     g = R.load("task_logic_frozen.npz")
     N = int(g["N"])
     from replay import OracleBackend
     a = OracleBackend(N, task_const, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
-    b = EmulBackend(N, task_const, quad=quad, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
+    b = EmulBackend(N, task_const, layout=layout, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
     init = {k[5:]: v for k, v in g.items() if k.startswith("init_")}
     a.load_buffers(init)
     b.load_buffers(init)
@@ -66,13 +66,13 @@ def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, quad)
             assert np.array_equal(a.read_buffers()[k], b.read_buffers()[k]), k
 
 
-def test_whole_step_tracks_oracle_goldens(task_const, quad):
+def test_whole_step_tracks_oracle_goldens(task_const, layout):
     """Physics differs from the oracle only in summation order (Cholesky solve vs explicit inverse, fused
     Gauss-Seidel update).  Stated tolerance, contacts active, random torques: after 10 policy steps (20 substeps)
     |dq| <= 1e-4 rad, |dqd| <= 2e-2 rad/s (0.5 % of the 4.03 rad/s joint-speed limit), root pose <= 1e-4; the trajectories then separate chaotically, so
     beyond that only a sanity bound and the reset pattern are held."""
     g = R.load("whole_step_oracle.npz")
-    be = EmulBackend(int(g["N"]), task_const, quad=quad, randomize_dof_on_reset=0, torch_gpu_div=0)
+    be = EmulBackend(int(g["N"]), task_const, layout=layout, randomize_dof_on_reset=0, torch_gpu_div=0)
     for t, ref, got in R.replay(g, be):
         dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
         dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
@@ -84,10 +84,10 @@ def test_whole_step_tracks_oracle_goldens(task_const, quad):
         assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
 
 
-def test_physics_substep_vs_oracle_random_flight(quad):
+def test_physics_substep_vs_oracle_random_flight(layout):
     rng = np.random.default_rng(1)
     N = 16
-    A, B = OracleSim(N), EmulSim(N, quad=quad)
+    A, B = OracleSim(N), EmulSim(N, layout=layout)
     A.buf["root_states"][:, 0:3] = rng.normal(size=(N, 3)) + np.array([0, 0, 3])
     q = rng.normal(size=(N, 4))
     A.buf["root_states"][:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
@@ -130,9 +130,9 @@ def _gate_roundtrip(make, N=40):
     return sim.buf["gate_acc"].copy()
 
 
-def test_perturbation_gate_latches_identically(task_const, quad):
+def test_perturbation_gate_latches_identically(task_const, layout):
     a = _gate_roundtrip(lambda N: OracleSim(N, task_const=task_const, debug_freeze_physics=1))
-    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, quad=quad, debug_freeze_physics=1))
+    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, layout=layout, debug_freeze_physics=1))
     assert np.array_equal(a, b)
 
 
@@ -148,10 +148,10 @@ def _crossed(N, symmetric):
     return q
 
 
-def test_self_collision_vs_oracle(quad):
+def test_self_collision_vs_oracle(layout):
     """Row f-1 through the kernel source: skew capsule axes (well-conditioned), one substep: forces 1e-3 relative, state 1e-5."""
     N = 48
-    A, B = OracleSim(N), EmulSim(N, quad=quad)
+    A, B = OracleSim(N), EmulSim(N, layout=layout)
     for s in (A, B):
         s.buf["root_states"][:, 0:2] = 0
         s.buf["root_states"][:, 2] = 3.0
@@ -164,13 +164,13 @@ def test_self_collision_vs_oracle(quad):
     assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 0].max() < 1e-5
 
 
-@pytest.mark.parametrize("which", ["oracle", "wave-per-env", "quad", "oct", "lane"])
+@pytest.mark.parametrize("which", ["oracle", "oct", "lane"])
 def test_mirrored_legs_get_a_mirrored_response(which):
     """Exactly parallel capsules (mirror-symmetric legs): contact in the middle of the overlap, so the response is mirrored
     -- joint rates of the two legs are mirror images, the base neither yaws nor drifts sideways (the textbook closest-point
     rule put the contact at whichever end rounding chose).  Envs whose shank axes intersect are left out."""
     N = 40
-    sim = OracleSim(N) if which == "oracle" else EmulSim(N, quad={"wave-per-env": False, "quad": True, "oct": "oct", "lane": "lane"}[which])
+    sim = OracleSim(N) if which == "oracle" else EmulSim(N, layout=which)
     sim.buf["root_states"][:, 0:2] = 0
     sim.buf["root_states"][:, 2] = 3.0
     sim.buf["dof_state"][:, :, 0] = _crossed(N, True)
@@ -184,12 +184,12 @@ def test_mirrored_legs_get_a_mirrored_response(which):
     assert np.abs(sim.buf["root_states"][keep][:, 8]).max() < 2e-2
 
 
-def test_arms_into_torso_vs_oracle(quad):
+def test_arms_into_torso_vs_oracle(layout):
     """Row f-1, second tranche (forearm / hand against torso and thigh, arm against arm) through the kernel source: the
     arm poses of tests/test_oracle_physics.py (inside the joint limits), one substep: forces 1e-3 relative, state 1e-5."""
     from test_oracle_physics import _arms_in
     N = 48
-    A, B = OracleSim(N), EmulSim(N, quad=quad)
+    A, B = OracleSim(N), EmulSim(N, layout=layout)
     for s in (A, B):
         s.buf["root_states"][:, 0:2] = 0
         s.buf["root_states"][:, 2] = 3.0
@@ -227,7 +227,7 @@ def _terrain_reset_case(sim, g):
     return {k: np.array(v, copy=True) for k, v in sim.buf.items()}
 
 
-def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, quad):
+def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, layout):
     """the reset_done path read the base position from uninitialised LDS when the curriculum decided the
     level change.  A moved env, a stationary env and an untouched env, several ids in one call, against the oracle; the
     emulation NaN-fills its LDS block per id, so stale contents cannot pass."""
@@ -235,7 +235,7 @@ def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, quad):
     N = int(g["N"])
     kw = dict(terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]), torch_gpu_div=1)
     ora = _terrain_reset_case(OracleSim(N, task_const=task_const, **kw), g)
-    emu = _terrain_reset_case(EmulSim(N, task_const=task_const, quad=quad, **kw), g)
+    emu = _terrain_reset_case(EmulSim(N, task_const=task_const, layout=layout, **kw), g)
     assert int(ora["terrain_levels"][3]) == 2 and int(ora["terrain_levels"][5]) == 0 and int(ora["terrain_levels"][6]) == 1
     for k in ("terrain_levels", "env_origins", "root_states", "dof_state", "env_state", "reset_buf", "progress_buf",
               "randomize_buf", "dof_damping", "dof_armature"):

@@ -40,11 +40,9 @@ def usage():
     for src, extra in build.SOURCES:
         if src != "dw_hip.hip":
             u.update(resource_usage(src, extra))
-    path = os.path.join(ROOT, "profiles", "r03_kernel_resources.json")
-    try:
-        json.dump(u, open(path, "w"), indent=1, sort_keys=True)
-    except OSError:
-        pass
+    # (the tracked record under profiles/ is refreshed on request only: DW_WRITE_PROFILES=1 python -m pytest tests/test_kernel_resources.py)
+    if os.environ.get("DW_WRITE_PROFILES") == "1":
+        json.dump(u, open(os.path.join(ROOT, "profiles", "r04_kernel_resources.json"), "w"), indent=1, sort_keys=True)
     return u
 
 
@@ -75,7 +73,23 @@ def test_terrain_step_kernel_scratch_is_bounded(usage):
     assert r["Occupancy"] == 2 and r["ScratchSize"] <= 160, r
 
 
-def test_quad_kernels_keep_one_wave_per_simd_budget(usage):
-    for k in ("dw_k_step_quad<false>", "dw_k_simulate_quad<false>"):
+def test_lane_kernels_budget(usage):
+    """The lane kernels (pipeline 4, the second implementation): one workgroup of four waves per CU, the whole register file per
+    wave.  What they spill beyond the AGPRs is recorded and may not grow (the generation is not the default
+    and lost its A/B; the guard keeps a regression from hiding in it)."""
+    for k, scratch in (("dw_k_step_lane<false>", 800), ("dw_k_simulate_lane<false>", 256), ("dw_k_step_lane<true>", 1200), ("dw_k_simulate_lane<true>", 512)):
         r = usage[k]
-        assert r["LDS Size"] <= 40960 and r["VGPRs"] + r["AGPRs"] <= 512, (k, r)
+        assert r["LDS Size"] <= 163840 and r["VGPRs"] + r["AGPRs"] <= 512 and r["ScratchSize"] <= scratch, (k, r)
+
+
+def test_small_kernels_do_not_spill(usage):
+    """The fused TocabiAMPLower kernels, the stateless row f-3 functions and dw_k_reset's siblings: no scratch, and the LDS of the
+    four-wave step-end kernel leaves room for eight workgroups per CU."""
+    seen = 0
+    for k, r in usage.items():
+        if "dw_k_amp" in k or "dw_k_newwalk" in k or "dw_k_body_positions" in k:
+            seen += 1
+            assert r["ScratchSize"] == 0, (k, r)
+    assert seen >= 10
+    end = [r for k, r in usage.items() if "dw_k_amp_step_end" in k][0]
+    assert end["LDS Size"] <= 20480, end

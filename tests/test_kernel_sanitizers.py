@@ -21,17 +21,17 @@ def _lib(name):
         return None
 
 
-@pytest.mark.parametrize("quad", ["", "quad", "oct", "lane"], ids=["wave-per-env", "quad", "oct", "lane"])
-def test_kernel_body_under_asan_ubsan(quad):
+@pytest.mark.parametrize("layout", ["oct", "lane"])
+def test_kernel_body_under_asan_ubsan(layout):
     asan, ubsan = _lib("libasan.so"), _lib("libubsan.so")
     if not asan or not ubsan:
         pytest.skip("libasan/libubsan not found")
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "emul"), "-s", "_build/libdw_emul%s_asan.so" % ("_" + quad if quad else "")])
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emul"), "-s", "_build/libdw_emul_%s_asan.so" % layout])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
                LD_PRELOAD=asan + ":" + ubsan, OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, os.path.join(HERE, "_asan_worker.py")] + ([quad] if quad else []), env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_asan_worker.py")] + [layout], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "replayed 40 steps" in out.stdout and "simulate / reset_idx / step(noise=None) ok" in out.stdout
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
-    if quad == "oct":          # (the octet emulation also carries the fused TocabiAMPLower kernels, csrc/dw_amp_step.h)
+    if layout == "oct":          # (the octet emulation also carries the fused TocabiAMPLower kernels, csrc/dw_amp_step.h)
         assert "fused amp step / reset ok" in out.stdout

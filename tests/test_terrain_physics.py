@@ -88,15 +88,15 @@ def test_forces_follow_the_slope_normal(model):
     assert -0.05 < sim.buf["root_states"][0, 4] < 0.0            # still pitched back by about the slope angle
 
 
-@pytest.mark.parametrize("quad", [False, True, "oct"], ids=["wave-per-env", "quad", "oct"])
-def test_kernel_body_matches_oracle_on_generated_terrain(quad):
+@pytest.mark.parametrize("layout", ["oct", "lane"])
+def test_kernel_body_matches_oracle_on_generated_terrain(layout):
     """Same inputs through the oracle and through the kernel source (host emulation of either kernel generation) on a
     generated map: random poses near the ground so that sole corners and primitives touch rough terrain."""
     t = Terrain(TerrainCfg(mesh_type="heightfield", curriculum=True, num_rows=2, num_cols=4, border_size=2,
                            terrain_proportions=[0.2, 0.2, 0.3, 0.3, 0.0]), 8, seed=3)
     rng = np.random.default_rng(5)
     N = 12
-    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t, quad=quad)
+    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t, layout=layout)
     org = t.env_origins.reshape(-1, 3)[rng.integers(0, 8, size=N)]
     A.buf["root_states"][:, 0:2] = org[:, 0:2] + rng.uniform(-3, 3, size=(N, 2))
     ground = t.height_at(A.buf["root_states"][:, 0], A.buf["root_states"][:, 1])

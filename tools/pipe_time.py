@@ -1,6 +1,6 @@
 """A/B timing of the kernel generations (DwConfig.pipeline) in ONE process on one GPU box, interleaved so that clock drift
 does not masquerade as a kernel difference: whole policy step (dw_step) and the Gym-boundary substep (dw_simulate).
-usage: python tools/pipe_time.py [--pipes 3,2] [--envs 4096,16384] [--rounds 3] [--steps 200] [--sim]"""
+usage: python tools/pipe_time.py [--pipes 3,4] [--envs 4096,16384] [--rounds 3] [--steps 200] [--sim]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ from isaacgymdyros_amd.config import default_cfg
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--pipes", default="3,2")
+ap.add_argument("--pipes", default="3,4")
 ap.add_argument("--envs", default="4096,16384")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=200)
