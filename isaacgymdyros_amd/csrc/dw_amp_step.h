@@ -111,7 +111,7 @@ DW_HD int hist_phys(int head, int logical, int nh) { const int p = head + logica
 // ---------------------------------------------------------------------------------------------------------------------- step
 // The three step kernels run as workgroups of GT = 256 threads for GE = 16 envs (EnvGroup): their work is ITEMS -- (env, joint),
 // (env, history column), (env, word) -- spread over all threads, so a launch of 16384 envs is 1024 workgroups of four full waves
-// instead of 16384 workgroups of one wave with half its lanes idle (20 us -> for dw_amp_step_begin at 16384 envs).  A region
+// instead of 16384 workgroups of one wave with half its lanes idle (dw_amp_step_begin 20 -> 11 us at 16384 envs).  A region
 // (EnvGroup::par) ends with a workgroup barrier; the same discipline as above holds for what may be read and written where.
 constexpr int GT = 256, GE = 16;
 #if defined(__HIPCC__)
