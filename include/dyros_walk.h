@@ -292,7 +292,8 @@ typedef struct DwBuffers {
      * order-independent, so the gate is deterministic), latch word at [DW_GATE_LATCH] */
     int64_t *gate_acc;        /* [DW_GATE_WORDS]                                        */
     /* terrain (may be NULL when DwConfig.terrain == 0) */
-    int16_t *height_samples;  /* [terrain_rows, terrain_cols] Terrain.heightsamples      */
+    int16_t *height_samples;  /* [terrain_rows, terrain_cols] Terrain.heightsamples; READ AT dw_bind as well (a coarse bound table of
+                                 the field is built from it there): bind again after changing the terrain */
     float   *terrain_origins; /* [terrain_num_levels, terrain_num_types, 3] tile spawn origins */
     int64_t *terrain_levels;  /* [N] current difficulty level of each env                */
     int64_t *terrain_types;   /* [N] terrain type (column) of each env, fixed            */

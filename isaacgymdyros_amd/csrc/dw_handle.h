@@ -17,6 +17,7 @@ struct DwHandle {
     int             pipeline;       // 3 octet (8 lanes per env), 4 lane (one lane per env, one wave per limb); one launch per step in both
     float          *d_mocap;
     float          *d_sc_park;      // octet / lane kernels: PhysParams::sc_park
+    int16_t        *d_hmax;         // height field: the coarse bound table built at dw_bind (PhysParams::hmax)
     DwBuffers       buf;
     int             bound;
     int             has_task;

@@ -51,6 +51,13 @@ int  lane_lds_bytes();
 size_t sc_park_floats(int num_envs);
 }  // namespace dwl
 
+// the coarse bound table of the height field (dw_physics.h terrain_bound), one thread per cell; runs once, at dw_bind
+__global__ __launch_bounds__(256) void dw_k_terrain_bound(const int16_t *hs, int rows, int cols, int cell, int reach, int hm_rows, int hm_cols, int16_t *out) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= hm_rows * hm_cols) return;
+    out[i] = dw::terrain_bound_cell(hs, rows, cols, cell, reach, i / hm_cols, i % hm_cols);
+}
+
 __global__ __launch_bounds__(64) void dw_k_reset(const dw::DevModel *M, const dw::DevParams *P, const float *noise,
                                                  long long step, const int32_t *ids, int n) {
     __shared__ dw::TaskLds S;
@@ -162,6 +169,7 @@ int dw_destroy(DwHandle *h) {
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_mocap) (void)hipFree(h->d_mocap);
     if (h->d_sc_park) (void)hipFree(h->d_sc_park);
+    if (h->d_hmax) (void)hipFree(h->d_hmax);
     free(h);
     return DW_OK;
 }
@@ -175,9 +183,24 @@ int dw_bind(DwHandle *h, const DwBuffers *b) {
     // bind time, not step time: one small synchronous copy of the pointer table into the parameter block
     hipError_t e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip("dw_bind: pointer table upload", e);
-    const int16_t *hs = h->cfg.terrain ? b->height_samples : nullptr;
-    e = hipMemcpy(&h->d_params->C.phys.hs, &hs, sizeof(hs), hipMemcpyHostToDevice);      // (C.phys.sc_park was uploaded with the block at dw_create)
-    if (e != hipSuccess) return fail_hip("dw_bind: terrain pointer upload", e);
+    // height field: the samples' pointer and the coarse bound table built from them HERE (height_samples is read at bind: bind again
+    // after changing the terrain), both patched into the device-resident parameter block
+    h->params.phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
+    if (h->d_hmax) { (void)hipFree(h->d_hmax); h->d_hmax = nullptr; }
+    h->params.phys.hmax = nullptr;
+    if (h->cfg.terrain) {
+        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale);
+        const int hr = (h->cfg.terrain_rows + cell - 1) / cell, hc = (h->cfg.terrain_cols + cell - 1) / cell;
+        e = hipMalloc((void **)&h->d_hmax, sizeof(int16_t) * (size_t)hr * hc);
+        if (e != hipSuccess) return fail_hip("dw_bind: terrain bound table", e);
+        hipLaunchKernelGGL(dw_k_terrain_bound, dim3((hr * hc + 255) / 256), dim3(256), 0, 0, b->height_samples, h->cfg.terrain_rows, h->cfg.terrain_cols,
+                           cell, reach, hr, hc, h->d_hmax);
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail_hip("dw_bind: terrain bound kernel", e);
+        h->params.phys.hmax = h->d_hmax; h->params.phys.hm_cell = cell; h->params.phys.hm_rows = hr; h->params.phys.hm_cols = hc;
+    }
+    e = hipMemcpy(&h->d_params->C.phys, &h->params.phys, sizeof(dw::PhysParams), hipMemcpyHostToDevice);      // (sc_park: set at dw_create)
+    if (e != hipSuccess) return fail_hip("dw_bind: terrain parameters upload", e);
     h->bound = 1;
     return DW_OK;
 }

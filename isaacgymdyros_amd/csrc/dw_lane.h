@@ -91,6 +91,7 @@ struct LState {
     int   ln, w, e, valid;
     float root[13];
     float mu;
+    float zbound;                            // height field: dw_physics.h terrain_bound of my env's base position
     float rk[4][3], vmin[4], frame[4][9];    // leg waves: corners of my sole relative to O, velocity bounds, contact frames (terrain)
     int   act[4];
     int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
@@ -214,6 +215,7 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
     DQ_SGPR_KEEP(c_offset); DQ_SGPR_KEEP(c_erp); DQ_SGPR_KEEP(c_maxdep); DQ_SGPR_KEEP(c_selfcoll);
     DL_STAMP_T0();
     DL_STAMP(0);
+    if (TERRAIN) X.zbound = dw::terrain_bound(P, X.root[0], X.root[1]);          // (requested here, first used in the inward pass)
 
     // ---- base kinematics (every wave, redundantly) ----
     float qn[4], R0[9], ww[3], vo[3], bcom[3];
@@ -491,7 +493,7 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
                 // external forces: ground penalty of the non-sole primitives, self-collision; per Gym body for the report
                 const bool has_geom = ((m_geom >> k) & 1u) != 0;
                 bool near_ground = has_geom && (X.root[2] + x[2] < rc2.z);
-                if (TERRAIN) near_ground = has_geom;
+                if (TERRAIN) near_ground = has_geom && (X.root[2] + x[2] - X.zbound < rc2.z);
                 const bool geo = has_geom && wave_any(near_ground);
                 const unsigned bpairs = (unsigned)f2i(rc3.w);
                 const bool scb = sc_wg && ((m_prox >> k) & 1u) && wave_any((sc_hits & bpairs) != 0);
@@ -623,7 +625,7 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
         add_rigid(IA, pA, Ao, ho, mass, v0);
         const int base_ngeom = M.body_ngeom[0];
         bool near_ground = base_ngeom > 0 && (X.root[2] < LM.bound[0]);
-        if (TERRAIN) near_ground = base_ngeom > 0;
+        if (TERRAIN) near_ground = base_ngeom > 0 && (X.root[2] - X.zbound < LM.bound[0]);
         if (wave_any(near_ground)) {
             float cf[LMAX_GYM][3];
             DQ_UNROLL for (int t = 0; t < LMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;

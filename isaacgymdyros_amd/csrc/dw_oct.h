@@ -116,6 +116,7 @@ struct OLane {
     int   wave;                              // wave index in the launch (wave-uniform)
     float root[13];
     float mu;
+    float zbound;                            // height field: no point of the field within the robot's reach is higher (dw_physics.h terrain_bound)
     float footF[3];                          // non-sole contact force on my foot's sole Gym body (lanes 0, 1)
     int   coll;                              // last substep: one of my non-sole Gym bodies reports more than 1 N (termination)
     float footT[3];                          // last substep: net contact force on my sole body (lanes 0, 1)
@@ -187,6 +188,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     // the mass scale of the second (welded) inertial record of my sole body: requested here, consumed by the inward pass (the
     // record itself sits in the hot tables)
     const float ms1 = mscale_e[f2i(H.in1[j & 1][10])];
+    if (TERRAIN) X.zbound = dw::terrain_bound(P, X.root[0], X.root[1]);          // (requested here, first used in the inward pass)
     // ---- base kinematics (every lane of the quad, redundantly) ----
     float qn[4], R0k[9], ww[3], vo[3], bcom[3];
     {
@@ -471,7 +473,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 float cf[QMAX_GYM][3];
                 DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t) cf[t][0] = cf[t][1] = cf[t][2] = 0.0f;
                 bool near_ground = ngeom > 0 && (X.root[2] + x[2] < h0.w);
-                if (TERRAIN) near_ground = ngeom > 0;
+                if (TERRAIN) near_ground = ngeom > 0 && (X.root[2] + x[2] - X.zbound < h0.w);
 #if defined(DQ_KO_GEOM) || defined(OCT_ABL_GEOM)          // (timing experiment only)
                 near_ground = false;
 #endif
@@ -653,7 +655,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         add_rigid(I0, p0, Ao, ho, mass, v0);
         float cfb[3] = {0, 0, 0};
         bool near_ground = base_ngeom > 0 && (X.root[2] < H.base[12]);
-        if (TERRAIN) near_ground = base_ngeom > 0;
+        if (TERRAIN) near_ground = base_ngeom > 0 && (X.root[2] - X.zbound < H.base[12]);
         if (near_ground) {
             for (int k = 0; k < base_ngeom; ++k) {
                 float F[3], xr[3];

@@ -64,6 +64,7 @@ inline TaskParams make_task_params(const DwConfig *c) {
     t.freeze_physics = c->debug_freeze_physics;
     t.seed = c->seed;
     t.phys.hs = nullptr;                                      // set at bind
+    t.phys.hmax = nullptr; t.phys.hm_cell = 1; t.phys.hm_rows = t.phys.hm_cols = 0;          // built at bind
     t.phys.t_rows = c->terrain_rows; t.phys.t_cols = c->terrain_cols;
     t.phys.t_inv_h = c->terrain ? 1.0f / c->terrain_hscale : 0.0f;
     t.phys.t_vs = c->terrain_vscale; t.phys.t_border = c->terrain_border;

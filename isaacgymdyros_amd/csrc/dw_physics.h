@@ -35,6 +35,9 @@ struct PhysParams {          // wave-uniform scalars (kernel arguments)
     float *sc_park;
     int   t_rows, t_cols;
     float t_inv_h, t_vs, t_border;
+    // coarse upper bound of the height field around a base position (terrain_bound below); built at bind, nullptr = no bound
+    const int16_t *hmax;
+    int   hm_cell, hm_rows, hm_cols;
 };
 
 // Packed index of entry (r,c) of a symmetric 6x6 (upper triangle, row-major): 21 words instead of 36.
@@ -126,5 +129,34 @@ DW_HD void terrain_sample(const PhysParams &P, float x, float y, float *h, float
     cross3(n, t1, t2);
 }
 
+
+// The coarse bound table.  hmax[ci][cj] = the largest height sample within HM_REACH metres (plus the bilinear patch's extra
+// sample) of ANY point of cell (ci, cj), a cell being hm_cell x hm_cell samples.  A robot whose base origin lies in the cell has
+// every point of every body within that window (its links reach < 1.3 m from the base origin, a primitive < 0.25 m from its
+// link's origin: HM_REACH = 1.75 m), so a body whose origin is higher above terrain_bound() than its bounding radius cannot touch
+// the height field, exactly as `z > radius` says so over the plane -- the kernels skip its primitives' height-field fetches and
+// contact frames with no change in any result (the oracle, which samples every primitive, is the checker).
+constexpr float HM_REACH = 1.75f, HM_CELL = 0.5f;
+inline int hm_cell_samples(float hscale) { int c = (int)(HM_CELL / hscale); return c < 1 ? 1 : c; }
+inline int hm_reach_samples(float hscale) { return (int)(HM_REACH / hscale) + 2; }
+DW_HD int16_t terrain_bound_cell(const int16_t *hs, int rows, int cols, int cell, int reach, int ci, int cj) {
+    int i0 = ci * cell - reach, i1 = ci * cell + cell - 1 + reach, j0 = cj * cell - reach, j1 = cj * cell + cell - 1 + reach;
+    i0 = i0 < 0 ? 0 : i0; j0 = j0 < 0 ? 0 : j0;
+    i1 = i1 > rows - 1 ? rows - 1 : i1; j1 = j1 > cols - 1 ? cols - 1 : j1;
+    int16_t m = hs[(size_t)i0 * cols + j0];
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) { const int16_t v = hs[(size_t)i * cols + j]; m = v > m ? v : m; }
+    return m;
+}
+// the height no point of the field within reach of a robot based at world (x, y) exceeds (same index arithmetic as terrain_sample)
+DW_HD float terrain_bound(const PhysParams &P, float x, float y) {
+    if (!P.hmax) return 3.0e38f;
+    float u = (x + P.t_border) * P.t_inv_h, v = (y + P.t_border) * P.t_inv_h;
+    const float umax = (float)(P.t_rows - 1) - 1e-3f, vmax = (float)(P.t_cols - 1) - 1e-3f;
+    u = u < 0.0f ? 0.0f : (u > umax ? umax : u);
+    v = v < 0.0f ? 0.0f : (v > vmax ? vmax : v);
+    const int ci = (int)u / P.hm_cell, cj = (int)v / P.hm_cell;
+    return P.t_vs * (float)P.hmax[(size_t)ci * P.hm_cols + cj];
+}
 
 }  // namespace dw

@@ -17,6 +17,7 @@ struct DwHandle {
     dw::DevParams dp;
     float *mocap;
     float *sc_park;
+    int16_t *hmax;
     int bound;
 };
 
@@ -84,13 +85,21 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     *out = h;
     return DW_OK;
 }
-int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h->sc_park); free(h); return DW_OK; }
+int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h->sc_park); free(h->hmax); free(h); return DW_OK; }
 int dwe_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dwe_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
     if (const char *m = dw::check_terrain_buffers(&h->cfg, b)) return fail(DW_EINVAL, m);
     h->dp.B = *b; h->bound = 1;
     h->dp.C.phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
+    free(h->hmax); h->hmax = nullptr; h->dp.C.phys.hmax = nullptr;
+    if (h->cfg.terrain) {          // the coarse bound table, as dw_bind builds it
+        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale);
+        const int hr = (h->cfg.terrain_rows + cell - 1) / cell, hc = (h->cfg.terrain_cols + cell - 1) / cell;
+        h->hmax = (int16_t *)malloc(sizeof(int16_t) * (size_t)hr * hc);
+        for (int i = 0; i < hr * hc; ++i) h->hmax[i] = dw::terrain_bound_cell(b->height_samples, h->cfg.terrain_rows, h->cfg.terrain_cols, cell, reach, i / hc, i % hc);
+        h->dp.C.phys.hmax = h->hmax; h->dp.C.phys.hm_cell = cell; h->dp.C.phys.hm_rows = hr; h->dp.C.phys.hm_cols = hc;
+    }
     return DW_OK;
 }
 int dwe_simulate(DwHandle *h, const float *tau, const float *push_xy, void *) {

@@ -637,6 +637,50 @@ def test_terrain_physics_vs_oracle_on_gpu(task_const, pipeline):
 
 
 @pytest.mark.gpu
+def test_fallen_robots_on_high_rough_terrain_vs_oracle_on_gpu(pipeline):
+    """The coarse bound of the height field (dw_physics.h terrain_bound, built at dw_bind) lets the kernels skip the fetches of bodies
+    that cannot touch; the oracle samples under every primitive.  512 robots lying, kneeling and tumbling on the highest tiles of a
+    generated map: the same bodies must be loaded, with the same forces (tests/test_terrain_physics.py runs the same scenario on the
+    host emulation, where a bound lowered by 0.4 m was checked to fail)."""
+    from hip_backend import make_env
+    from isaacgymdyros_amd.terrain import Terrain, TerrainCfg
+    from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
+    from oracle.oracle import OracleSim
+    tdict = dict(mesh_type="heightfield", curriculum=True, num_rows=3, num_cols=5, border_size=2, max_init_terrain_level=2,
+                 terrain_proportions=[0.1, 0.2, 0.35, 0.25, 0.1])
+    N = 512
+    env = make_env(N, randomize=False, terrain=tdict, seed=11, pipeline=pipeline)
+    t = Terrain(TerrainCfg(**tdict), N, seed=11)
+    assert np.array_equal(env.height_samples.cpu().numpy(), t.heightsamples)
+    A = OracleSim(N, terrain=t)
+    rng = np.random.default_rng(2)
+    org = t.env_origins.reshape(-1, 3)
+    org = org[np.argsort(-org[:, 2])][:8]
+    pick = org[rng.integers(0, len(org), size=N)]
+    A.buf["root_states"][:, 0:2] = pick[:, 0:2] + rng.uniform(-3.5, 3.5, size=(N, 2))
+    ground = t.height_at(A.buf["root_states"][:, 0], A.buf["root_states"][:, 1])
+    A.buf["root_states"][:, 2] = ground + rng.uniform(0.12, 0.45, size=N)
+    ax = rng.normal(size=(N, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(0.6, 3.0, size=N)
+    A.buf["root_states"][:, 3:6] = ax * np.sin(ang / 2)[:, None]
+    A.buf["root_states"][:, 6] = np.cos(ang / 2)
+    A.buf["root_states"][:, 7:13] = rng.normal(size=(N, 6)) * 0.2
+    A.buf["dof_state"][:, :, 0] = np.asarray(INITIAL_DOF_POS) + rng.normal(size=(N, 33)) * 0.3
+    A.buf["dof_state"][:, :, 1] = rng.normal(size=(N, 33)) * 0.5
+    env.root_states.copy_(torch.from_numpy(A.buf["root_states"]).cuda())
+    env._buf["dof_state"].copy_(torch.from_numpy(A.buf["dof_state"]).cuda())
+    tau = np.zeros((N, 33), np.float32)
+    A.simulate(tau); env.simulate(torch.from_numpy(tau).cuda()); torch.cuda.synchronize()
+    cfa, cfb = A.buf["contact_forces"], env.contact_forces.cpu().numpy()
+    ta, tb = np.linalg.norm(cfa, axis=2) > 1.0, np.linalg.norm(cfb, axis=2) > 1.0
+    feet = np.zeros(38, bool); feet[[8, 16]] = True
+    assert ta[:, ~feet].sum() >= 2 * N and float(ground.max()) > 0.3
+    assert (ta != tb).sum() <= N // 100, int((ta != tb).sum())            # (a body within rounding of 1 N may flip)
+    assert np.abs(cfa - cfb).max() <= 2e-3 * np.abs(cfa).max() + 0.05
+    env.close()
+
+
+@pytest.mark.gpu
 def test_terrain_full_size_rollout_properties():
     """4096 envs on the default 10 x 20 curriculum map: finite, deterministic, robots spawn on their tiles, levels move."""
     from hip_backend import make_env

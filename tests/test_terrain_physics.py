@@ -118,3 +118,46 @@ def test_kernel_body_matches_oracle_on_generated_terrain(layout):
         A.simulate(tau); B.simulate(tau)
     assert np.abs(A.buf["dof_state"][:, :, 0] - B.buf["dof_state"][:, :, 0]).max() < 2e-2
     assert np.isfinite(B.buf["root_states"]).all()
+
+
+@pytest.mark.parametrize("layout", ["oct", "lane"])
+def test_fallen_robots_on_high_rough_terrain_touch_like_the_oracle(layout):
+    """The kernels skip the height-field fetches of a body that is higher above the coarse bound of the field around its robot
+    (dw_physics.h terrain_bound, a table built at bind) than its bounding radius; the oracle samples under every primitive.  Robots
+    lying, kneeling and tumbling on the highest and roughest tiles of a generated map -- torso, arms, knees and head on the ground,
+    at heights far from zero and next to steps and slopes -- must report the same contact forces body by body: a bound that is too
+    low, or indexed wrongly, would lose contacts here."""
+    t = Terrain(TerrainCfg(mesh_type="heightfield", curriculum=True, num_rows=3, num_cols=5, border_size=2,
+                           terrain_proportions=[0.1, 0.2, 0.35, 0.25, 0.1]), 15, seed=11)
+    rng = np.random.default_rng(2)
+    N = 16
+    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t, layout=layout)
+    org = t.env_origins.reshape(-1, 3)
+    org = org[np.argsort(-org[:, 2])][:8]                                 # the highest tile origins (top rows of the curriculum)
+    pick = org[rng.integers(0, len(org), size=N)]
+    A.buf["root_states"][:, 0:2] = pick[:, 0:2] + rng.uniform(-3.5, 3.5, size=(N, 2))
+    ground = t.height_at(A.buf["root_states"][:, 0], A.buf["root_states"][:, 1])
+    A.buf["root_states"][:, 2] = ground + rng.uniform(0.12, 0.45, size=N)      # base a hand's width to knee height above the field
+    ax = rng.normal(size=(N, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(0.6, 3.0, size=N)                                    # far from upright
+    A.buf["root_states"][:, 3:6] = ax * np.sin(ang / 2)[:, None]
+    A.buf["root_states"][:, 6] = np.cos(ang / 2)
+    A.buf["root_states"][:, 7:13] = rng.normal(size=(N, 6)) * 0.2
+    A.buf["dof_state"][:, :, 0] = np.asarray(INITIAL_DOF_POS) + rng.normal(size=(N, 33)) * 0.3
+    A.buf["dof_state"][:, :, 1] = rng.normal(size=(N, 33)) * 0.5
+    for k in ("root_states", "dof_state"):
+        B.buf[k][:] = A.buf[k]
+    assert float(ground.max()) > 0.3 and float(np.abs(ground).max()) > 0.3           # not the plane
+    tau = np.zeros((N, 33), np.float32)
+    A.simulate(tau); B.simulate(tau)
+    cfa, cfb = A.buf["contact_forces"], B.buf["contact_forces"]
+    touching = np.linalg.norm(cfa, axis=2) > 1.0
+    feet = np.zeros(38, bool); feet[[8, 16]] = True
+    assert touching[:, ~feet].sum() >= 2 * N                               # non-sole bodies are on the ground, many of them
+    assert np.array_equal(touching, np.linalg.norm(cfb, axis=2) > 1.0) or (touching != (np.linalg.norm(cfb, axis=2) > 1.0)).sum() <= 1
+    assert np.abs(cfa - cfb).max() <= 2e-3 * np.abs(cfa).max() + 0.05
+    for _ in range(5):
+        A.simulate(tau); B.simulate(tau)
+    ta, tb = np.linalg.norm(A.buf["contact_forces"], axis=2) > 1.0, np.linalg.norm(B.buf["contact_forces"], axis=2) > 1.0
+    assert (ta != tb).sum() <= 3 and ta[:, ~feet].sum() >= N
+    assert np.abs(A.buf["root_states"][:, :3] - B.buf["root_states"][:, :3]).max() < 5e-3
