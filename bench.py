@@ -209,7 +209,7 @@ def main():
         if not plumbing:
             torch.cuda.synchronize()
 
-    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False):
+    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False):
         """K steps of VecTask.step on `envs` envs of this rank.  alias_obs = False is the product's default contract (step() returns
         a fresh observation tensor, as the reference's torch.clamp does); True returns the view of obs_buf, so that the stream
         holds nothing but the step kernel."""
@@ -224,6 +224,9 @@ def main():
             if friction_dr:
                 from isaacgymdyros_amd.config import with_friction_randomization
                 cfg = with_friction_randomization(cfg)
+            if terrain:
+                from isaacgymdyros_amd.config import with_terrain
+                cfg = with_terrain(cfg, mesh_type="trimesh", curriculum=True)
             env = DyrosDynamicWalk(cfg, dev, 0, True)
             g = torch.Generator(device=dev).manual_seed(42 + rank)
             pool = [torch.rand(envs, 13, generator=g, device=dev) * 2 - 1 for _ in range(64)]
@@ -382,6 +385,11 @@ def main():
             out["config5_dr_friction_pushes"] = {"value": args.envs_per_gpu * n2 / r5["wall"], "ms_per_step": r5["wall"] / n2 * 1e3,
                                                  "perturb_start_fraction": r5["perturb_start_fraction"], "episodes_finished": r5["resets"],
                                                  "note": "friction x U(0.7,1.3) per env at reset, force_perturb_start (tasks/dyros_dynamic_walk.py:491)"}
+        if not args.no_config5:                 # the same step on the reference's default 10 x 20 curriculum map (height-field kernels)
+            rt = run(args.envs_per_gpu, n2, args.warmup, alias_obs=True, terrain=True)
+            out["terrain_curriculum"] = {"value": args.envs_per_gpu * n2 / rt["wall"], "ms_per_step": rt["wall"] / n2 * 1e3, "kernel_ms": rt["kernel_ms"],
+                                         "ratio_to_flat_kernel": rt["kernel_ms"] / kernel_ms,
+                                         "note": "cfg/terrain/terrain_cfg.py defaults (trimesh, curriculum), alias_obs; dw_k_step_oct<true, 2>"}
         if not args.no_ppo:                     # BASELINE config 3: the DYROS PPO loop attached (examples/ppo_consumer.py)
             try:
                 import importlib.util
