@@ -1,4 +1,4 @@
-"""Per-phase latency of the quad physics kernel for wave 0 (profiling build: tools/phase_stamps.sh builds the library with
+"""Per-phase latency of the octet step kernel for wave 0 (profiling build: tools/phase_stamps.sh builds the library with
 -DDQ_STAMPS into isaacgymdyros_amd/_ab/ and runs this).  Prints cycles between the stamps."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ cfg = default_cfg(N, "cuda:0")
 if os.environ.get("DW_TERRAIN"):          # the height-field variant (10 x 20 curriculum map)
     from isaacgymdyros_amd.config import with_terrain
     cfg = with_terrain(cfg, mesh_type="trimesh", curriculum=True)
-cfg["sim"]["mi355"]["pipeline"] = int(os.environ.get("DW_PIPE", "0"))          # 2 quad, 3 octet
+cfg["sim"]["mi355"]["pipeline"] = int(os.environ.get("DW_PIPE", "0"))          # 3 octet (the -DDQ_STAMPS build of tools/phase_stamps.sh stamps the octet unit)
 env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 g = torch.Generator(device="cuda").manual_seed(42)
 acts = [torch.rand(N, 13, generator=g, device="cuda") * 2 - 1 for _ in range(8)]
