@@ -247,8 +247,14 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         X.stamp_base = 1 + 16 * sub;
 #if !defined(OCT_NO_WG_ALIGN) && defined(__HIPCC__)
         // the two waves of the workgroup meet before every substep: they share nothing but the instruction stream, and in step
-        // one instruction fetch serves both (measured: -2 % step time at 16384 envs, nothing at 4096; a wave that has left the
-        // kernel -- no envs -- is not waited for)
+        // one instruction fetch serves both (measured: -2 % step time at 16384 envs, nothing at 4096).
+        // HARDWARE RULE RELIED UPON: the second wave of the LAST workgroup may have no envs (N mod 16 in 1..8) and returns at the top
+        // of the kernel, before this barrier.  That is outside HIP's programming rules (every thread of a block must reach a
+        // __syncthreads) and legal on gfx9 / CDNA only because s_barrier counts the waves of the workgroup that have not terminated:
+        // an ended wave is not waited for (CDNA ISA guide, S_BARRIER).  Both waves also write the same bytes into the shared hot
+        // tables without a barrier between them (stage_hot: identical values, so either order is the same memory).  The host
+        // emulation does not see any of this; the GPU test that guards it is tests/test_hip_gpu.py::test_small_and_odd_env_counts
+        // (N = 1, 3, 17, 100: N mod 16 in 1..8, the last workgroup's second wave has no envs).
         __builtin_amdgcn_s_barrier();
 #endif
         if (!c_freeze) oct_substep<TERRAIN>(L, H, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);

@@ -1,6 +1,6 @@
 // dw_oct_kernels.hip -- the gfx950 entry points of the octet kernels (bodies: dw_oct_kernels.h, dw_oct.h, dw_oct_post.h) and
-// their launchers.  A translation unit of its own (default machine scheduler, like dw_quad_kernels.hip); linked into
-// libdyroswalk_hip.so next to dw_hip.hip, which owns the C-ABI.
+// their launchers.  A translation unit of its own (built with -mllvm -amdgpu-sched-strategy=iterative-ilp, isaacgymdyros_amd/build.py);
+// linked into libdyroswalk_hip.so next to dw_hip.hip, which owns the C-ABI.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 

@@ -406,7 +406,9 @@ def test_config3_16384_envs_with_the_ppo_loop_attached():
 
 @pytest.mark.parametrize("N", [1, 3, 17, 100])
 def test_small_and_odd_env_counts(N, task_const, pipeline):
-    """Ragged sizes (the quad kernel's last wave is partly empty: 16 envs per wave); compare with the oracle after a few steps."""
+    """Ragged sizes; compare with the oracle after a few steps.  All four sizes have N mod 16 in 1..8: the last octet workgroup's second
+    wave has no envs and leaves the kernel before the per-substep s_barrier -- this test is the guard of the hardware rule that
+    makes that legal (csrc/dw_oct_kernels.h, at the barrier); the lane kernels' last workgroup is partly empty as well."""
     from hip_backend import make_env
     env = make_env(N, pipeline=pipeline)
     ora = _oracle_like(env, task_const)
