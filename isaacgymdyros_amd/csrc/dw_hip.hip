@@ -30,7 +30,7 @@ size_t quadmodel_bytes();
 }  // namespace dwq
 // The octet kernels (DwConfig.pipeline = 3): dw_oct_kernels.hip.
 namespace dwo {
-void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
@@ -41,7 +41,7 @@ int  sc_park_words();
 // The lane kernels (DwConfig.pipeline = 4): dw_lane_kernels.hip.
 namespace dwl {
 struct LaneModel;
-void launch_step(bool terrain, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
+void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
@@ -233,11 +233,15 @@ static int launch_step(DwHandle *h, const float *actions, const float *noise, lo
     // (the kernels take the buffer table by value: this launch's copy may name another observation buffer)
     DwBuffers bufs = h->buf;
     if (obs_out) bufs.obs_buf = obs_out;
+    // the torch flavour of the post phase's norms is compiled into the step kernels; the lane kernels also have a build without the
+    // code only tests use (an injected noise record, frozen physics) and one that reads every switch at run time (flavour -1)
+    const int flavour = h->cfg.torch_gpu_div != 0 ? 1 : 0;
+    const int lane_flavour = (noise || h->cfg.debug_freeze_physics) ? -1 : flavour;
     if (h->pipeline == 4) {
-        dwl::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, bufs, h->d_mocap,
+        dwl::launch_step(h->cfg.terrain != 0, lane_flavour, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
     } else {
-        dwo::launch_step(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
+        dwo::launch_step(h->cfg.terrain != 0, flavour, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
                          actions, noise, step_index, step_dev);
     }
     hipError_t e = hipGetLastError();

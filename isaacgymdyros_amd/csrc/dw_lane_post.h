@@ -66,9 +66,13 @@ DQ_HD float norm3_t(int gpu, float x, float y, float z) {
 // Inputs from the physics part of the kernel: KP = the new joint state and the encoder angle / rate after the second substep of
 // the joints my wave owns (lane = env), X.root, X.coll / X.footT (collision flag of my wave's bodies, net force on
 // my sole body).  With physics frozen (tests) the state and the contact forces are the Gym tensors as they are.
-template <bool TERRAIN>
+// (GPUF: dw_oct_post.h)
+template <bool TERRAIN, int GPUF = -1>
 DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const TaskParams &C, const OBuf &B, const float *actions,
                           const float *noise, long long step, int group, LState &X, const LaneKeep &KP, unsigned long long dl_t0 = 0) {
+    const int gnorm = GPUF < 0 ? C.gpu_div : GPUF;
+    if (GPUF >= 0) noise = nullptr;          // (product build: dw_oct_kernels.h)
+    const bool frozen = GPUF < 0 && C.freeze_physics;
     float *LF = reinterpret_cast<float *>(&L);
     int t = tid();
     DQ_OPAQUE(t);
@@ -149,8 +153,8 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             }
         }
     }
-    if (w < 2 && !C.freeze_physics) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * w + i) = X.warm[i]; }      // warm-start impulses of my sole
-    if (C.freeze_physics) {
+    if (w < 2 && !frozen) { DQ_UNROLL for (int i = 0; i < 12; ++i) PQ_ES(el, DW_ES_WARM + 12 * w + i) = X.warm[i]; }      // warm-start impulses of my sole
+    if (frozen) {
         // debug mode: simulate() was the identity, so the net contact forces are an input (dw_task.h step_env)
         if (w == 0) {
             const float *cf = B.contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
@@ -161,7 +165,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             const int ee = i / DW_NUM_BODIES, g = i - DW_NUM_BODIES * ee;
             const int eg = group * EPW + ee < N ? group * EPW + ee : N - 1;
             const float *cf = B.contact_forces + ((size_t)DW_NUM_BODIES * eg + g) * 3;
-            if (g != LFG && g != RFG && norm3_t(C.gpu_div, cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
+            if (g != LFG && g != RFG && norm3_t(gnorm, cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
         }
     } else {
         wg_barrier();
@@ -228,7 +232,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
         // the three 33-element norms, in torch's CPU order (8 fused accumulators over elements a, a+8, a+16, a+24, added in order,
         // then the 33rd element fused) or in its GPU order (dw_task.h norm_sel), elements produced on the fly
         auto norm33 = [&](int which) {
-            const float n = dw::norm_sel<33>(C.gpu_div, [&](int jj) {
+            const float n = dw::norm_sel<33>(gnorm, [&](int jj) {
                 return which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
                      : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
             });
@@ -237,30 +241,30 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
         };
         if (w == 0) {
             const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
-            const float aerr = fabsf(dw::quat_err(qq, C.gpu_div));
+            const float aerr = fabsf(dw::quat_err(qq, gnorm));
             PQ_PS(el, PS_RTERM + 14) = aerr;
             PQ_PS(el, PS_RTERM + 0) = 0.3f * expf(-13.2f * aerr);
             const float dv[2] = {PQ_ES(el, DW_ES_TARGET_VEL) - PQ_ROOT(el, 7), PQ_ES(el, DW_ES_TARGET_VEL + 1) - PQ_ROOT(el, 8)};
-            const float n = dw::norm_sel_v<2>(C.gpu_div, dv);
+            const float n = dw::norm_sel_v<2>(gnorm, dv);
             PQ_PS(el, PS_RTERM + 6) = 0.3f * expf(-3.0f * (n * n));
         }
         if (w == 1) {
             PQ_PS(el, PS_RTERM + 1) = norm33(0);
-            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_sel<12>(C.gpu_div, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }));
+            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_sel<12>(gnorm, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }));
         }
         if (w == 2) {
             PQ_PS(el, PS_RTERM + 2) = norm33(1);
             PQ_PS(el, PS_RTERM + 7) = norm33(2);
         }
         if (w == 3) {
-            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_sel<12>(C.gpu_div, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }));
+            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_sel<12>(gnorm, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }));
             const float lf[3] = {PQ_PS(el, PS_FOOT), PQ_PS(el, PS_FOOT + 1), PQ_PS(el, PS_FOOT + 2)};
             const float rf[3] = {PQ_PS(el, PS_FOOT + 3), PQ_PS(el, PS_FOOT + 4), PQ_PS(el, PS_FOOT + 5)};
             const float lfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 1), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 2)};
             const float rfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 3), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 4), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 5)};
             float dl[3], dr[3];
             DQ_UNROLL for (int i = 0; i < 3; ++i) { dl[i] = lf[i] - lfp[i]; dr[i] = rf[i] - rfp[i]; }
-            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_sel_v<3>(C.gpu_div, dl) + dw::norm_sel_v<3>(C.gpu_div, dr)));
+            PQ_PS(el, PS_RTERM + 9) = 0.2f * expf((-0.01f * 1.0f) * (dw::norm_sel_v<3>(gnorm, dl) + dw::norm_sel_v<3>(gnorm, dr)));
             const bool lcon = lf[2] > 1.0f, rcon = rf[2] > 1.0f;
             const int idx = PQ_ESI(el, DW_ES_MOCAP_IDX);
             const bool DSP = (3300 <= idx && idx < 3600) || (idx < 300) || (1500 <= idx && idx < 2100);
@@ -278,7 +282,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             const bool th = (lf[2] > thr) || (rf[2] > thr);
             PQ_PS(el, PS_RTERM + 11) = th ? -0.2f * 1.0f : 0.0f;
             const float cl = fmaxf(lf[2] - thr, 0.0f), cr = fmaxf(rf[2] - thr, 0.0f);
-            const float pen = 0.1f * expf(-0.007f * (dw::norm_sel_v<1>(C.gpu_div, &cl) + dw::norm_sel_v<1>(C.gpu_div, &cr)));
+            const float pen = 0.1f * expf(-0.007f * (dw::norm_sel_v<1>(gnorm, &cl) + dw::norm_sel_v<1>(gnorm, &cr)));
             PQ_PS(el, PS_RTERM + 3) = th ? pen : 0.1f * 1.0f;
             const float thd = ((float)(0.2 * 9.81) * tm) / 1.0f;
             const bool dd = (fabsf(lf[2] - lfp[2]) > thd) || (fabsf(rf[2] - rfp[2]) > thd);
@@ -333,10 +337,10 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
     if (any_reset) {
         if (C.terrain_curriculum && w == 0 && PQ_PSI(el, PS_RESET)) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
-            const float distance = dw::norm_sel_v<2>(C.gpu_div, d);
+            const float distance = dw::norm_sel_v<2>(gnorm, d);
             const bool move_up = distance > C.terrain_half_length;
             const float tv[2] = {PQ_ES(el, DW_ES_TARGET_VEL), PQ_ES(el, DW_ES_TARGET_VEL + 1)};
-            const float need = dw::norm_sel_v<2>(C.gpu_div, tv) * C.max_episode_length_s * 0.5f;
+            const float need = dw::norm_sel_v<2>(gnorm, tv) * C.max_episode_length_s * 0.5f;
             const bool move_down = (distance < need) && !move_up;
             long long lvl = OQ_COLD(terrain_levels)[e] + ((move_up ? 1 : 0) - (move_down ? 1 : 0));
             if (lvl >= C.terrain_num_levels) {
@@ -551,7 +555,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             const int egr = group * EPW + ee, eg = egr < N ? egr : N - 1;
             const bool ok = p < NPAIR && egr < N;
             const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
-            if (C.freeze_physics) {
+            if (frozen) {
                 const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
                 const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
                 float ro[DW_NUM_OBS1], ra[DW_NUM_ACT];
@@ -621,7 +625,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
         F4 *dstg = reinterpret_cast<F4 *>(B.env_state + (size_t)group * EPW * DW_ES_WORDS);
         const F4 *srcl = reinterpret_cast<const F4 *>(LF + PL_ES);
         DL_ROLLED for (int u = 0; u < PER; ++u) { const int pi = t + NT * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
-        if (!C.freeze_physics) {
+        if (!frozen) {
             // the Gym state of every env (the physics kept it on chip), as contiguous runs
             const int nv = nvalid >= EPW ? EPW : nvalid;
             stage_out(LF, PL_Q, B.dof_state + (size_t)group * EPW * ND * 2, ND * 2, nv);

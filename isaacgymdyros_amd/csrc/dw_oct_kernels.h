@@ -32,10 +32,14 @@ constexpr int PK_TAU2 = 0, PK_NZ1 = 64;      // words of the env's obs_buf row u
 // mocap phase and target, perturbation gate and schedule), the two substeps with the actuator and encoder models, and
 // post_physics_step (dw_quad_post.h).  The task record is read where needed and written ONCE, by the post phase, from its
 // LDS image: what the earlier phases produce for it stays in registers (StepKeep) until the image exists.
-template <bool TERRAIN>
+template <bool TERRAIN, int GPUF = -1>
 DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const TaskParams &C, const OBuf &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
-    if (wave_index * EPO >= C.num_envs) return;      // the second wave of the last workgroup may have no env at all (wave-uniform exit; no barrier follows)
+    if (wave_index * EPO >= C.num_envs) return;      // the second wave of the last workgroup may have no env at all (wave-uniform exit BEFORE the per-substep s_barrier: see there)
+    // GPUF: the torch flavour of the post phase's norms, compiled in (dw_oct_post.h: both flavours in one kernel cost 2.1 % of the step
+    // at 16384 envs -- the kernel is larger than the instruction cache it shares with a second CU).  The same was tried for the two
+    // paths only tests use, an injected noise record and frozen physics: WITHOUT them the kernel is 1.6 % slower (0.1475 against
+    // 0.1452 ms, A/B on one box, twice): fewer instructions, another schedule.  They stay in.
     int c_num_envs = C.num_envs, c_freeze = C.freeze_physics;          // (launch-invariant, read by every item of every phase)
     DQ_SGPR_KEEP(c_num_envs); DQ_SGPR_KEEP(c_freeze);
     DQ_STAMP(B, 54);
@@ -347,7 +351,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)
     const long long dq_t1 = (long long)__builtin_readcyclecounter();
 #endif
-    oct_task_post<TERRAIN>(L, M, C, B, actions, noise, step, wave_index, X, qkeep, qdkeep, KP);
+    oct_task_post<TERRAIN, GPUF>(L, M, C, B, actions, noise, step, wave_index, X, qkeep, qdkeep, KP);
     DQ_STAMP(B, 41);
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)
     if (X.lane == 0) {

@@ -16,7 +16,8 @@
 // for launches with more waves than the device has SIMDs.  WPE = 1: declared occupancy one wave per SIMD -- the same 250
 // registers, but the hardware then never puts two of the launch's waves on one SIMD while another SIMD is idle, which it
 // otherwise does as soon as a CU holds two workgroups (measured at 8192 envs: 0.1329 ms against 0.1428 ms).
-template <bool TERRAIN, int WPE>
+// GPUF: the torch flavour (DwConfig.torch_gpu_div) the post phase sums its norms in, compiled in (dw_oct_post.h).
+template <bool TERRAIN, int WPE, int GPUF>
 __global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwHot HB, const float *mocap,
                    const float *actions, const float *noise, long long step, const long long *step_dev) {
@@ -26,7 +27,7 @@ void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__
 #if defined(OCT_STAGGER_SHIFT)      // (timing experiment: hold back every other group of workgroups so that the two waves of a SIMD are in different phases)
     if ((blockIdx.x >> OCT_STAGGER_SHIFT) & 1) for (int i = 0; i < OCT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-    dwo::oct_step<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C, make_obuf(HB, &P->B), actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
+    dwo::oct_step<TERRAIN, GPUF>(L.w[w], L.hot, *QM, *M, P->C, make_obuf(HB, &P->B), actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
 }
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN, int WPE>
@@ -70,14 +71,20 @@ static bool spread(int num_envs) {
     }
     return groups(num_envs) * WPG <= simds;
 }
-void launch_step(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
+template <int GPUF>
+static void launch_step_f(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                          const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
     const dim3 grid(groups(num_envs)), block(64 * WPG);
     const bool sp = spread(num_envs);
-    if (terrain && sp) hipLaunchKernelGGL((dw_k_step_oct<true, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
-    else if (terrain) hipLaunchKernelGGL((dw_k_step_oct<true, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
-    else if (sp) hipLaunchKernelGGL((dw_k_step_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
-    else hipLaunchKernelGGL((dw_k_step_oct<false, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    if (terrain && sp) hipLaunchKernelGGL((dw_k_step_oct<true, 1, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    else if (terrain) hipLaunchKernelGGL((dw_k_step_oct<true, 2, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    else if (sp) hipLaunchKernelGGL((dw_k_step_oct<false, 1, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+    else hipLaunchKernelGGL((dw_k_step_oct<false, 2, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
+}
+void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
+    if (gpu_flavour) launch_step_f<1>(terrain, num_envs, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
+    else launch_step_f<0>(terrain, num_envs, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
 }
 void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push) {

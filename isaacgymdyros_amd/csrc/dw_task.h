@@ -197,7 +197,17 @@ DW_HD float norm_g(F f) {
 }
 // the norm of N elements f(0) .. f(N - 1) in the order of torch's GPU kernel (gpu != 0) or of its CPU kernel
 template <int N, class F>
-DW_HD float norm_sel(int gpu, F f) { return gpu ? norm_g<N>(f) : norm_fn(f, N); }
+DW_HD float norm_sel(int gpu, F f) {
+#if defined(DW_NORM_GPU_ONLY)          // (A/B builds only: what the second flavour costs in code size, tools/tu_lib.sh)
+    (void)gpu;
+    return norm_g<N>(f);
+#elif defined(DW_NORM_CPU_ONLY)
+    (void)gpu;
+    return norm_fn(f, N);
+#else
+    return gpu ? norm_g<N>(f) : norm_fn(f, N);
+#endif
+}
 template <int N>
 DW_HD float norm_sel_v(int gpu, const float *x) { return norm_sel<N>(gpu, [&](int i) { return x[i]; }); }
 

@@ -23,9 +23,21 @@ def resource_usage(src, extra):
         m = re.search(r"remark: Function Name: (\S+)", line)
         if m:
             name = m.group(1)
-            k = re.search(r"(dw_k_[a-z_]+?)ILb([01])E(?:Li(\d)E)?", name)
-            # (the octet kernels exist in two builds, dw_oct_kernels.hip: "<..>" is the two-waves-per-SIMD one, "<..,1>" the spread one)
-            cur = ("%s<%s%s>" % (k.group(1), "true" if k.group(2) == "1" else "false", ",1" if k.group(3) == "1" else "")) if k else name
+            k = re.search(r"(dw_k_[a-z_]+?)ILb([01])E(?:Li(n?\d)E)?(?:Li(n?\d)E)?", name)
+            # (the octet kernels exist in two builds, dw_oct_kernels.hip: "<..>" is the two-waves-per-SIMD one, "<..,1>" the spread one; the
+            #  step kernels also per torch flavour of the post phase's norms -- the GPU flavour, the default, is the one named plainly -- and as
+            #  the build that reads every switch at run time, which tests with an injected noise record or frozen physics get)
+            cur = name
+            if k:
+                g = [x for x in k.groups()[2:] if x is not None]
+                is_step = "_step_" in k.group(1)
+                flav = g[-1] if is_step and g else None
+                wpe = g[0] if ("_oct" in k.group(1) and g) else None
+                cur = "%s<%s%s>" % (k.group(1), "true" if k.group(2) == "1" else "false", ",1" if wpe == "1" else "")
+                if flav == "0":
+                    cur += "[cpu flavour]"
+                elif flav == "n1":
+                    cur += "[test build]"
             out[cur] = {}
             continue
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
