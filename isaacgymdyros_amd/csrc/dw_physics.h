@@ -150,6 +150,9 @@ DW_HD int16_t terrain_bound_cell(const int16_t *hs, int rows, int cols, int cell
 }
 // the height no point of the field within reach of a robot based at world (x, y) exceeds (same index arithmetic as terrain_sample)
 DW_HD float terrain_bound(const PhysParams &P, float x, float y) {
+#if defined(DW_NO_TERRAIN_BOUND)          // (A/B builds only: every body with primitives samples the field, as before round 4)
+    return 3.0e38f;
+#endif
     if (!P.hmax) return 3.0e38f;
     float u = (x + P.t_border) * P.t_inv_h, v = (y + P.t_border) * P.t_inv_h;
     const float umax = (float)(P.t_rows - 1) - 1e-3f, vmax = (float)(P.t_cols - 1) - 1e-3f;
