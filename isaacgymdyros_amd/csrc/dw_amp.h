@@ -333,7 +333,7 @@ DW_HD void body_position(const MM &M, const float *root_states, const float *dof
         R[3] = 2 * (X * Y + W * Z); R[4] = 1 - 2 * (X * X + Z * Z); R[5] = 2 * (Y * Z - W * X);
         R[6] = 2 * (X * Z - W * Y); R[7] = 2 * (Y * Z + W * X); R[8] = 1 - 2 * (X * X + Y * Y);
     }
-    // as the physics (dw_physics.h K1/K2): x_b = x_p + R_p pos_b,  R_b = R_p rot0_b Rot(axis_b, q_b)
+    // as the physics (oracle/dw_physics.c): x_b = x_p + R_p pos_b,  R_b = R_p rot0_b Rot(axis_b, q_b)
     for (int k = n - 1; k >= 0; --k) {
         const int b = chain[k];
         for (int i = 0; i < 3; ++i) x[i] += R[3 * i] * M.pos[b][0] + R[3 * i + 1] * M.pos[b][1] + R[3 * i + 2] * M.pos[b][2];

@@ -123,7 +123,7 @@ DQ_HD void rigid_bias(const float *Ao, const float *ho, float mass, const float 
     pv[3] = t1[0]; pv[4] = t1[1]; pv[5] = t1[2];
 }
 
-// Closest points of two segments and the penalty force of two capsules as dw_quad.h's seg_seg / capsule_pair (written decision:
+// Closest points of two segments and the penalty force of two capsules as dw_limb.h's seg_seg / capsule_pair (written decision:
 // oracle/dw_physics.c seg_seg), with the quotients as Newton-refined reciprocals (~1 ulp) instead of IEEE divisions: ten
 // divisions are a third of the evaluation, and with 64 envs per wave some env has a touching pair in most substeps.
 DQ_HD void seg_seg_l(const float *da, const float *db, const float *r, float *so, float *to) {
@@ -316,7 +316,7 @@ DQ_HD void lane_substep(LLds &L, const LaneModel &LM, const DevModel &M, const P
     DL_STAMP(2);
 
     // ---- self-collision: capsule proxies, pairs from the model.  Wave w tests a quarter of the pairs for its 64 envs (both
-    //      proxies' axes from their bodies' slots, the division-free conservative distance of dw_quad.h).  The common case is
+    //      proxies' axes from their bodies' slots, the division-free conservative distance of dw_limb.h).  The common case is
     //      "nothing touches": then that is all.  A pair that touches in some env of the wave is resolved on the spot, by the
     //      lanes it touches in -- the exact closest points, the penalty force, the wrench on either body -- and parked in
     //      global memory, one 16-word record per (env, pair); the wave that owns a body picks its side up in the inward pass. ----

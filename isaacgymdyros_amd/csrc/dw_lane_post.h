@@ -137,7 +137,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
     if (t >= 64 && t < 64 + ND) { const int l = t - 64; const float qi = M.q_init[l]; LF[PL_RC + 2 * l] = qi; LF[PL_RC + 2 * l + 1] = fmaxf(fminf(qi, M.qhi[l]), M.qlo[l]); }
     wg_barrier();
     DL_STAMP2(17);
-    // ---- the record fields the substeps produced (dw_task.h P3), from the waves that hold them ----
+    // ---- the record fields the substeps produced (oracle/dw_task.c step_env), from the waves that hold them ----
     DQ_UNROLL for (int j = 0; j < MAXOWN; ++j) {
         if (j < n_own) {
             const int d = own_body(j) - 1;
@@ -145,7 +145,7 @@ DQ_HD void lane_task_post(LLds &L, const LaneModel &LM, const DevModel &M, const
             PQ_ES(el, DW_ES_QPOS_PRE + d) = KP.qn[j];
             PQ_ES(el, DW_ES_QVEL_NOISE + d) = KP.qv[j];
             if (d < 12) {
-                // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
+                // action torque of the step, appended to the torque FIFO by both substeps (oracle/dw_task.c step_env)
                 const float at = PQ_ES(el, DW_ES_ACTION_TORQUE + d);
                 float col[DW_ALOG_SLOTS];
                 DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(el, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;

@@ -90,7 +90,7 @@ DQ_HD bool over_1n(const float *F) {
     return sqrtf(b0) > 1.0f;
 }
 
-// Ground penalty force of one primitive of body b (dw_physics.h K4).  R, x: body rotation / origin relative to O; v: body
+// Ground penalty force of one primitive of body b (oracle/dw_physics.c).  R, x: body rotation / origin relative to O; v: body
 // twist about O.  Returns the force in F and the contact point relative to O in xr.
 template <bool TERRAIN>
 DQ_HD void geom_force(const DwGeom &ge, const PhysParams &P, const float *R, const float *x, const float *v, float rootx, float rooty,
@@ -163,7 +163,7 @@ DQ_HD void geom_force(const DwGeom &ge, const PhysParams &P, const float *R, con
     }
 }
 
-// Rigid-body inertia of a body about O in world axes from its (<= 2) inertial records (dw_physics.h K3):
+// Rigid-body inertia of a body about O in world axes from its (<= 2) inertial records (oracle/dw_physics.c):
 // Ao (symmetric 3x3, 6 words: 00 01 02 11 12 22), ho = first moment, mass.
 DQ_HD void rigid_inertia(int nin, const float *com0, float m0, const float *I0, float ms0, const float *com1, float m1, const float *I1,
                          float ms1, const float *R, const float *x, float *Ao, float *ho, float *mass_out) {
@@ -267,7 +267,7 @@ DQ_HD float seg_dist2_fast(const float *da, const float *db, const float *r) {
     return d2;
 }
 
-// Penalty force of two capsules (dw_physics.h K4b).  Returns true and fills F (force on A), pa, pb when they overlap.
+// Penalty force of two capsules (oracle/dw_physics.c).  Returns true and fills F (force on A), pa, pb when they overlap.
 DQ_HD bool capsule_pair(const float *a0, const float *a1, float ra, const float *b0, const float *b1, float rb, const float *va,
                         const float *vb, const PhysParams &P, float *F, float *pa, float *pb) {
     const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};

@@ -1,7 +1,7 @@
 // dw_oct.h -- one physics substep (stand-in for the reference's closed `gym.simulate`, call site
 // tasks/dyros_dynamic_walk.py:525) in the OCTET layout: 8 lanes per env, 8 envs per wavefront, two wavefronts per
 // workgroup that share one copy of the hot tables.  Same physics, same order of the contact iterations and the same
-// written decisions as dw_quad.h / dw_physics.h / oracle/dw_physics.c (DESIGN.md "Physics model").
+// written decisions as oracle/dw_physics.c (DESIGN.md "Physics model").
 //
 // Why octets.  A body-env slot is 64 bytes, so 160 KB of LDS hold 64 envs per CU whatever the lane mapping.  The quad
 // kernels (4 lanes per env, 16 envs per wave) therefore run ONE wave per SIMD -- and one wave alone issues a vector
@@ -13,7 +13,7 @@
 //
 // Lane l of a wave: env el = l >> 3, octet lane o = l & 7 = 4 h + j: limb j (as in dw_quad_model.h: 0 neck + left leg,
 // 1 right leg, 2 waist + left arm, 3 right arm) and half h.  The DPP quads of a wave are the (env, half) groups, so every
-// quad_perm exchange of dw_quad.h means the same thing here; the two halves of a limb exchange with oct_xor4().  Where a
+// quad_perm exchange of the retired quad kernels means the same thing here; the two halves of a limb exchange with oct_xor4().  Where a
 // phase has nothing to split, both halves run it redundantly (in a SIMD machine that costs nothing) and only half 0 has
 // side effects in global memory.
 #pragma once
@@ -38,7 +38,7 @@ constexpr int EPO = 64 / LPE;        // envs per wavefront
 constexpr int WPG = OCT_WPG;         // wavefronts per workgroup (they share the hot tables, nothing else)
 constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 1;      // per lane: PhysParams::sc_park
 
-// One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env as in dw_quad.h.  A row is 8 envs x 16 B
+// One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env.  A row is 8 envs x 16 B
 // = 128 B, half the width of the LDS (64 banks x 4 B), so a limb's position code p = pos | flip << 3 also swaps the rows of
 // odd-numbered owner lanes pairwise: the four limbs of a 16-lane group (2 envs) then read 8 different 16-byte columns.
 struct alignas(16) OSlots { F4 slot[NB * 4][EPO]; };
@@ -76,7 +76,7 @@ DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
 #define DQ_ROLLED
 #endif
 // 16-byte LDS loads that stay 16 bytes wide.  A load whose .w is unused is narrowed to ds_read_b96 (twice the LDS cycles of
-// ds_read_b128, MI355X_MICROARCH.md); dw_quad.h's ld4() prevents that with an opaque touch after EVERY load, which also makes
+// ds_read_b128, MI355X_MICROARCH.md); dw_limb.h's ld4() prevents that with an opaque touch after EVERY load, which also makes
 // the wave wait for every load by itself.  Here loads are plain and ONE touch of the unused .w components follows a group of
 // them: the group is in flight together and waited for once.
 #if defined(__HIPCC__)
@@ -123,7 +123,7 @@ struct OLane {
     int   stamp_base;                        // profiling builds only
 };
 
-// add_rigid of dw_quad.h in two parts: IA += rigid inertia [[Ao, H], [H', m 1]], H = skew(ho) ...
+// add_rigid of dw_limb.h in two parts: IA += rigid inertia [[Ao, H], [H', m 1]], H = skew(ho) ...
 DQ_HD void add_rigid_inertia(float *IA, const float *Ao, const float *ho, float mass) {
     DQ_UNROLL for (int r = 0; r < 3; ++r)
         DQ_UNROLL for (int c = r; c < 3; ++c) IA[sym6(r, c)] += dwq::ao(Ao, r, c);
@@ -290,7 +290,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_STAMP(B, SB + 2);
     // ---- self-collision: capsule proxies (legs, arms, torso), pairs from the model.  Detection is pair-parallel: octet
     //      lane o tests pairs o, o + 8, o + 16, o + 24 -- both proxies' axes from their bodies' slots, the division-free
-    //      conservative distance of dw_quad.h -- and the touching pairs of the env are ORed into a mask over the octet.  The
+    //      conservative distance of dw_limb.h -- and the touching pairs of the env are ORed into a mask over the octet.  The
     //      common case is "nothing touches": then that is all.  Resolution, if any env of the wave has a touching pair: the
     //      lane that owns a proxy's body recomputes the proxy's touching pairs exactly and keeps the wrench (both sides of a
     //      pair compute the same force from the same data: no hand-over between lanes; the two halves of a limb do the same). ----
@@ -681,7 +681,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             cross3(xc, Fw, nb);
             DQ_UNROLL for (int i = 0; i < 3; ++i) { p0[i] -= nb[i]; p0[3 + i] -= Fw[i]; }
         }
-        // Cholesky I0 = L L', Minv by six pairs of triangular solves (dw_physics.h A3)
+        // Cholesky I0 = L L', Minv by six pairs of triangular solves (oracle/dw_physics.c)
         float Lc[36], dinv[6];
         DQ_UNROLL for (int i = 0; i < 36; ++i) Lc[i] = 0.0f;
         DQ_UNROLL for (int c = 0; c < 6; ++c) {

@@ -1,10 +1,10 @@
 // dw_oct_kernels.h -- the whole VecTask.step for the 8 envs of an octet wave (dw_oct.h): pre_physics_step, the two physics
 // substeps with the actuator and encoder models around them (reference tasks/dyros_dynamic_walk.py:449-541), then
-// post_physics_step (dw_oct_post.h), in ONE launch.  Same structure, same fp32 expressions and the same request discipline
-// as dw_quad_kernels.h; what changes is the lane mapping (8 lanes per env, 5 (env, joint) items per lane instead of 9).
+// post_physics_step (dw_oct_post.h), in ONE launch: 8 lanes per env, 5 (env, joint) items per lane in the joint-parallel phases.
 //
 // Every fp32 expression that the reference pins bit for bit (tau per substep, qpos_noise, qvel_noise: SURVEY 8c) is
-// written exactly as in dw_task.h P3 (fp contraction off in this region of the file).
+// written in the reference's operation order (fp contraction off in this region of the file); oracle/dw_task.c is the restatement the
+// CPU tests compare with.
 #pragma once
 
 #include "dw_oct.h"
@@ -28,9 +28,9 @@ constexpr int EW_DL = 4, EW_SL = 5;          // torque FIFO: delay index, fill (
 constexpr int WW_GATE = 15;                  // wave-wide word: perturbation gate open (env 0's scratch)
 constexpr int PK_TAU2 = 0, PK_NZ1 = 64;      // words of the env's obs_buf row used as scratch during the step
 
-// The whole VecTask.step for 16 envs: pre_physics_step up to the substep loop (dw_task.h P1, P2: action clamp and history,
+// The whole VecTask.step for the wave's 8 envs: pre_physics_step up to the substep loop (action clamp and history,
 // mocap phase and target, perturbation gate and schedule), the two substeps with the actuator and encoder models, and
-// post_physics_step (dw_quad_post.h).  The task record is read where needed and written ONCE, by the post phase, from its
+// post_physics_step (dw_oct_post.h).  The task record is read where needed and written ONCE, by the post phase, from its
 // LDS image: what the earlier phases produce for it stays in registers (StepKeep) until the image exists.
 template <bool TERRAIN, int GPUF = -1>
 DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const TaskParams &C, const OBuf &B,
@@ -114,7 +114,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     const int simul_len0 = f2i(r_sl);
     (void)f;
     {
-        // ---- pre_physics_step, per-env scalar parts on the quad's lanes (dw_task.h P1): lane 0 the mocap phase, lane 1 the
+        // ---- pre_physics_step, per-env scalar parts on the quad's lanes (oracle/dw_task.c step_env): lane 0 the mocap phase, lane 1 the
         //      push schedule; every fp32 expression as there ----
         dw::TaskBuffers TB;
         TB.b = B.all; TB.actions = actions; TB.noise = noise; TB.mocap = mocap; TB.step = step;
@@ -210,7 +210,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             OQ_ES(DW_ES_TARGET_FORCE + 1) = dw::cubic_t(OQ_ENVW(X.el, EW_LTP), rtf[0], rtf[1], rtf[4], rtf[5]);
         }
 
-        // ---- actuator model, joint-parallel (items (env, dof), dw_quad.h): inputs of both substeps.  Kept per item in
+        // ---- actuator model, joint-parallel (items (env, dof)): inputs of both substeps.  Kept per item in
         //      registers: the joint angle (integrated after each substep), the delayed leg torque of the second substep, the
         //      encoder reading of the first, damping and gains. ----
         DQ_STAMP(B, 0);
@@ -219,7 +219,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             it.pos = OQ_IPOS(it);
             const int d = it.d;
             const float q = rq[k], qd = rqd[k], damp = rdamp[k], arm = rarm[k];
-            // mocap target of this joint (cubic between two table rows, dw_task.h P2) and, for the legs, the action torque
+            // mocap target of this joint (cubic between two table rows, oracle/dw_task.c step_env) and, for the legs, the action torque
             const float target = dw::cubic_t(OQ_ENVW(it.el, EW_LTP), rt0[k], rt1[k], rm0[k], rm1[k]);
             const float atq = d < 12 ? fminf(fmaxf(rac[k], -1.0f), 1.0f) * rms[k] * rah[k] : 0.0f;
             if (it.ok) {

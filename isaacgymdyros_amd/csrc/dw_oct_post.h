@@ -1,6 +1,6 @@
 // dw_oct_post.h -- post_physics_step of DyrosDynamicWalk for the 8 envs of an octet wave (dw_oct.h), run at the end of the
 // fused step kernel (dw_oct_kernels.h) when the physics is done and the wave's 17 KB of body slots are free.  The same
-// fp32 expressions in the same order as dw_quad_post.h / dw_task.h regions Q1..Q6 and reset_region (fp contraction off), so
+// fp32 expressions in the reference's order -- regions Q1..Q6 and the reset block, as oracle/dw_task.c states them (fp contraction off) -- so
 // the reference goldens hold bit for bit; the lanes are mapped for 8 envs per wave: per-env scalar work on octet lanes
 // 0..3 (one group of reward terms each), per-word work over ITEMS (env, index) = lane + 64 k.
 // Reference: tasks/dyros_dynamic_walk.py:543-563 (post_physics_step), :581-596 (check_termination), :802-947 (reward),
@@ -165,7 +165,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     if (lane < DW_NUM_OBS1) { OBN[lane] = c_om; OBN[DW_NUM_OBS1 + lane] = c_od; }
     if (lane < ND) { LF[PL_RC + 2 * lane] = c_qinit; LF[PL_RC + 2 * lane + 1] = fmaxf(fminf(c_qinit, c_qhi), c_qlo); }
     wave_sync();
-    // ---- the record fields this step has produced so far (dw_task.h P1..P3), from the lanes that hold them ----
+    // ---- the record fields this step has produced so far (oracle/dw_task.c step_env..P3), from the lanes that hold them ----
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
         if (i < EPO * ND) {
@@ -175,7 +175,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             PQ_ES(ee, DW_ES_QPOS_PRE + d) = KP.qn[k];
             PQ_ES(ee, DW_ES_QVEL_NOISE + d) = KP.qv[k];
             if (d < 12) {
-                // action torque of the step, appended to the torque FIFO by both substeps (dw_task.h P2, P3)
+                // action torque of the step, appended to the torque FIFO by both substeps (oracle/dw_task.c step_env)
                 const float at = PQ_ES(ee, DW_ES_ACTION_TORQUE + d);
                 float col[DW_ALOG_SLOTS];
                 DQ_UNROLL for (int s2 = 0; s2 < DW_ALOG_SLOTS; ++s2) col[s2] = s2 + 2 < DW_ALOG_SLOTS ? PQ_ES(ee, DW_ES_ACTION_LOG + 12 * (s2 + 2) + d) : at;

@@ -1,4 +1,5 @@
-// dw_quad_model.h -- limb schedule and per-(step, lane) constant tables of the quad kernels (dw_quad.h), and the host
+// dw_quad_model.h -- limb schedule and per-(step, lane) constant tables of the octet kernels (dw_oct.h; the name is that of the
+// retired quad kernels, which introduced the schedule), and the host
 // routine that derives them from the traversal tables of dw_devmodel.h.
 //
 // A quad = the 4 lanes of one env.  Every lane owns a list of unbranched chains of the kinematic tree and walks them body

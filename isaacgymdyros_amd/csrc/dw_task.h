@@ -121,7 +121,7 @@ DW_HD float noise_word(const NoiseSrc &nz, int w) {
     philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));
     return pair ? enc_normal(c[2], c[3]) : enc_normal(c[0], c[1]);
 }
-// both encoder draws of joint d in one generator call (the quad kernels keep the second for the second substep)
+// both encoder draws of joint d in one generator call (the step kernels keep the second for the second substep)
 DW_HD void noise_enc_pair(const NoiseSrc &nz, int d, float *z0, float *z1) {
     unsigned int c[4] = {(unsigned int)(DW_NZ_ENC + d), nz.env, (unsigned int)nz.step, (unsigned int)(nz.step >> 32) | (nz.stream << 31)};
     philox4x32_10(c, (unsigned int)nz.seed, (unsigned int)(nz.seed >> 32));

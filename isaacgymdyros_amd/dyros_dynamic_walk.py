@@ -142,7 +142,7 @@ class DyrosDynamicWalk(VecTask):
         c.self_collision = int(bool(mi.get("self_collision", True)))
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
-        # which kernels: 0/3 = octet kernels, 8 lanes per env, two waves per SIMD (default), 2 = quad kernels (4 lanes per env), 1 = wave-per-env
+        # which kernels: 0/3 = octet kernels, 8 lanes per env, two waves per SIMD (default); 4 = lane kernels (one lane per env, one wave per limb)
         # kernels of round 1; one launch per policy step in all three
         c.pipeline = {"auto": 0, "oct": 3, "lane": 4}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
         tc = self.terrain_cfg
@@ -338,9 +338,9 @@ class DyrosDynamicWalk(VecTask):
             nz = noise.data_ptr()
         stream = torch.cuda.current_stream(self._tdev).cuda_stream
         # The reference returns a FRESH observation tensor every step (torch.clamp(self.obs_buf, ...), vec_task.py:338).  Here the
-        # kernel itself writes this step's observations into a newly allocated tensor (dw_step_obs: the quad / octet kernels take the
+        # kernel itself writes this step's observations into a newly allocated tensor (dw_step_obs: the kernels take the
         # buffer table by value, so the destination is a per-launch argument), which becomes self.obs_buf: the contract without the
-        # 1 948 B-per-env copy after the kernel.  alias_obs, a clipping range, the wave-per-env kernels and a captured graph (whose
+        # 1 948 B-per-env copy after the kernel.  alias_obs, a clipping range and a captured graph (whose
         # pointers must not change) keep the bound buffer.
         fresh = self._fresh_obs and self._step_dev is None
         if fresh:

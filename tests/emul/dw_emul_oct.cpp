@@ -1,7 +1,7 @@
 // dw_emul_oct.cpp -- host emulation of the OCTET kernels (isaacgymdyros_amd/csrc/dw_oct.h, dw_oct_kernels.h, dw_oct_post.h): the exact
 // kernel source, one fiber per lane, 64 fibers per wave, switching at every cross-lane operation (dw_quad_wave.h).
 // TEST INFRASTRUCTURE ONLY: nothing in isaacgymdyros_amd/ can load it.  Exports the C-ABI with the prefix dwe_ and HOST
-// pointers, like dw_emul.cpp does for the wave-per-env kernels.
+// pointers, so that one driver (oracle/oracle.py) runs the oracle, this library and the lane emulation.
 #define DWQ_EMUL_IMPLEMENTATION
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,9 +1,8 @@
-"""GPU AddressSanitizer is not available on the pool, so the kernel body is sanitised on the CPU: the lane-loop
-emulation (tests/emul) is built with -fsanitize=address,undefined and replays both golden fixtures plus the
-simulate / reset_idx / in-kernel-RNG / self-collision paths -- for both kernel generations: the wave-per-env kernels (lane
-loop; the register-resident Gauss-Seidel runs with one fiber per lane) and the quad kernels (one fiber per lane throughout,
-the fibers' stacks announced to ASan).  Any out-of-bounds LDS or buffer index in the shared kernel source
-aborts the worker."""
+"""GPU AddressSanitizer is not available on the pool, so the kernel bodies are sanitised on the CPU: the host emulations
+(tests/emul) are built with -fsanitize=address,undefined and replay both golden fixtures plus the simulate / reset_idx /
+in-kernel-RNG / self-collision paths -- for both lane layouts: the octet kernels (one fiber per lane) and the lane kernels
+(one fiber per thread of the workgroup; the fibers' stacks announced to ASan) -- and, in the octet library, the fused
+TocabiAMPLower kernels.  Any out-of-bounds LDS or buffer index in the shared kernel source aborts the worker."""
 import os
 import subprocess
 import sys
