@@ -18,6 +18,7 @@ struct DwHandle {
     float          *d_mocap;
     float          *d_sc_park;      // octet / lane kernels: PhysParams::sc_park
     int16_t        *d_hmax;         // height field: the coarse bound table built at dw_bind (PhysParams::hmax)
+    float           reach;          // dw_physics.h model_reach() of the model, computed at dw_create
     DwBuffers       buf;
     int             bound;
     int             has_task;

@@ -106,6 +106,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     int rc = dw::build_devmodel(model, task, hm, &err);
     if (rc) { free(hm); free(h); return fail(rc, err); }
     h->pipeline = cfg->pipeline == 0 ? DW_DEFAULT_PIPELINE : cfg->pipeline;
+    h->reach = dw::model_reach(*hm);
     dwq::QuadModel *hq = nullptr;
     dwl::LaneModel *hl = nullptr;
     if (h->pipeline == 4) {
@@ -189,7 +190,7 @@ int dw_bind(DwHandle *h, const DwBuffers *b) {
     if (h->d_hmax) { (void)hipFree(h->d_hmax); h->d_hmax = nullptr; }
     h->params.phys.hmax = nullptr;
     if (h->cfg.terrain) {
-        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale);
+        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale, h->reach);
         const int hr = (h->cfg.terrain_rows + cell - 1) / cell, hc = (h->cfg.terrain_cols + cell - 1) / cell;
         e = hipMalloc((void **)&h->d_hmax, sizeof(int16_t) * (size_t)hr * hc);
         if (e != hipSuccess) return fail_hip("dw_bind: terrain bound table", e);

@@ -130,15 +130,31 @@ DW_HD void terrain_sample(const PhysParams &P, float x, float y, float *h, float
 }
 
 
-// The coarse bound table.  hmax[ci][cj] = the largest height sample within HM_REACH metres (plus the bilinear patch's extra
-// sample) of ANY point of cell (ci, cj), a cell being hm_cell x hm_cell samples.  A robot whose base origin lies in the cell has
-// every point of every body within that window (its links reach < 1.3 m from the base origin, a primitive < 0.25 m from its
-// link's origin: HM_REACH = 1.75 m), so a body whose origin is higher above terrain_bound() than its bounding radius cannot touch
-// the height field, exactly as `z > radius` says so over the plane -- the kernels skip its primitives' height-field fetches and
-// contact frames with no change in any result (the oracle, which samples every primitive, is the checker).
-constexpr float HM_REACH = 1.75f, HM_CELL = 0.5f;
+// The coarse bound table.  hmax[ci][cj] = the largest height sample within `reach` metres (plus the bilinear patch's extra
+// sample) of ANY point of cell (ci, cj), a cell being hm_cell x hm_cell samples.  `reach` = model_reach(): no point of any
+// collision primitive of the robot is farther from the base origin than that, whatever the joint angles (the sum of the link
+// offsets along the chain to the primitive's body plus the primitive's farthest point from that body's origin -- TOCABI: 1.43 m).
+// A robot whose base origin lies in the cell therefore has every point of every body within the window, so a body whose origin is
+// higher above terrain_bound() than its bounding radius cannot touch the height field, exactly as `z > radius` says so over the
+// plane -- the kernels skip its primitives' height-field fetches and contact frames with no change in any result (the oracle,
+// which samples under every primitive, is the checker).
+constexpr float HM_CELL = 0.5f, HM_MARGIN = 0.05f;
+inline float model_reach(const DevModel &M) {
+    float chain[NB], best = 0.0f;
+    chain[0] = 0.0f;
+    for (int b = 1; b < NB; ++b) chain[b] = chain[M.parent[b]] + sqrtf(M.pos[b][0] * M.pos[b][0] + M.pos[b][1] * M.pos[b][1] + M.pos[b][2] * M.pos[b][2]);
+    for (int g = 0; g < M.ngeom; ++g) {
+        const DwGeom &ge = M.geoms[g];
+        const float off = sqrtf(ge.pos[0] * ge.pos[0] + ge.pos[1] * ge.pos[1] + ge.pos[2] * ge.pos[2]);
+        const float ext = ge.type == 0 ? sqrtf(ge.size[0] * ge.size[0] + ge.size[1] * ge.size[1] + ge.size[2] * ge.size[2])
+                                       : sqrtf(ge.size[0] * ge.size[0] + ge.size[1] * ge.size[1]);
+        const float r = chain[ge.moving] + off + ext;
+        best = r > best ? r : best;
+    }
+    return best + HM_MARGIN;
+}
 inline int hm_cell_samples(float hscale) { int c = (int)(HM_CELL / hscale); return c < 1 ? 1 : c; }
-inline int hm_reach_samples(float hscale) { return (int)(HM_REACH / hscale) + 2; }
+inline int hm_reach_samples(float hscale, float reach) { return (int)(reach / hscale) + 2; }
 DW_HD int16_t terrain_bound_cell(const int16_t *hs, int rows, int cols, int cell, int reach, int ci, int cj) {
     int i0 = ci * cell - reach, i1 = ci * cell + cell - 1 + reach, j0 = cj * cell - reach, j1 = cj * cell + cell - 1 + reach;
     i0 = i0 < 0 ? 0 : i0; j0 = j0 < 0 ? 0 : j0;

@@ -91,7 +91,7 @@ int dwe_bind(DwHandle *h, const DwBuffers *b) {
     h->dp.C.phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
     free(h->hmax); h->hmax = nullptr; h->dp.C.phys.hmax = nullptr;
     if (h->cfg.terrain) {          // the coarse bound table, as dw_bind builds it
-        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale);
+        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale, dw::model_reach(h->model));
         const int hr = (h->cfg.terrain_rows + cell - 1) / cell, hc = (h->cfg.terrain_cols + cell - 1) / cell;
         h->hmax = (int16_t *)malloc(sizeof(int16_t) * (size_t)hr * hc);
         for (int i = 0; i < hr * hc; ++i) h->hmax[i] = dw::terrain_bound_cell(b->height_samples, h->cfg.terrain_rows, h->cfg.terrain_cols, cell, reach, i / hc, i % hc);
