@@ -49,9 +49,11 @@ def resource_usage(src, extra):
 @pytest.fixture(scope="module")
 def usage():
     u = {}
-    for src, extra in build.SOURCES:
-        if src != "dw_hip.hip":
-            u.update(resource_usage(src, extra))
+    from concurrent.futures import ThreadPoolExecutor
+    todo = [(src, extra) for src, extra in build.SOURCES if src != "dw_hip.hip"]
+    with ThreadPoolExecutor(max_workers=len(todo)) as pool:          # (one hipcc per translation unit, side by side)
+        for r in pool.map(lambda a: resource_usage(*a), todo):
+            u.update(r)
     # (the tracked record under profiles/ is refreshed on request only: DW_WRITE_PROFILES=1 python -m pytest tests/test_kernel_resources.py)
     if os.environ.get("DW_WRITE_PROFILES") == "1":
         json.dump(u, open(os.path.join(ROOT, "profiles", "r04_kernel_resources.json"), "w"), indent=1, sort_keys=True)
