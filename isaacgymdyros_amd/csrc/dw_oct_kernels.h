@@ -32,7 +32,10 @@ constexpr int PK_TAU2 = 0, PK_NZ1 = 64;      // words of the env's obs_buf row u
 // mocap phase and target, perturbation gate and schedule), the two substeps with the actuator and encoder models, and
 // post_physics_step (dw_oct_post.h).  The task record is read where needed and written ONCE, by the post phase, from its
 // LDS image: what the earlier phases produce for it stays in registers (StepKeep) until the image exists.
-template <bool TERRAIN, int GPUF = -1>
+// KEEP: the one-wave-per-SIMD build (launches of at most one wave per SIMD, N <= 8192) has the whole register file: what the
+// two-waves build parks in global memory between the phases of a step -- the joint state, the previous encoder reading, the second
+// substep's torque input and encoder draw, damping / armature / gains -- stays in registers there (no round trip in the second epilogue).
+template <bool TERRAIN, int GPUF = -1, bool KEEP = false>
 DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M, const TaskParams &C, const OBuf &B,
                              const float *actions, const float *mocap, const float *noise, long long step, int wave_index) {
     if (wave_index * EPO >= C.num_envs) return;      // the second wave of the last workgroup may have no env at all (wave-uniform exit BEFORE the per-substep s_barrier: see there)
@@ -108,6 +111,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     // observation into it (words PK_TAU2.., PK_NZ1..).  Every epilogue requests all of it in one go.
     StepKeep KP;
     float qkeep[ONI], qdkeep[ONI], qnprev[ONI];          // (filled by the last encoder epilogue: what the post phase takes over)
+    float tau2k[ONI], n1k[ONI], dampk[ONI], armk[ONI], kpk[ONI], kvk[ONI];          // (KEEP builds only)
     float (&qvk)[ONI] = KP.qv;
     const bool wr_env = X.valid && X.h == 0;          // per-env scalars: half 0 writes
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
@@ -241,7 +245,8 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             DQ_UNROLL for (int s = 1; s < DW_ALOG_SLOTS; ++s) { t1 = (s == src1) ? col[s] : t1; t2 = (s == src2) ? col[s + 1] : t2; }
             // upper body: PD to the mocap target; the second substep forms its own torque from the new state
             const float tau = d < 12 ? t1 : rkp[k] * (target - q) + rkv[k] * (-qd);
-            if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_TAU2 + d] = d < 12 ? t2 : target;
+            if (KEEP) { tau2k[k] = d < 12 ? t2 : target; dampk[k] = damp; armk[k] = arm; kpk[k] = rkp[k]; kvk[k] = rkv[k]; }
+            else if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_TAU2 + d] = d < 12 ? t2 : target;
             if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
         }
     }
@@ -274,6 +279,17 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         float nzw[ONI], rdamp2[ONI], rarm2[ONI], rkp2[ONI], rkv2[ONI], pkv[ONI];
         const int pk_off = sub == 0 ? PK_TAU2 : PK_NZ1;          // obs_buf scratch: the second substep's torque input / its encoder draw
         DQ_UNROLL for (int k = 0; k < ONI; ++k) fin[k] = OQ_LD(0, 0, ips[k]);      // {qlo, qd, qhi, *}
+        if (KEEP) {
+            // (the joint state of the first epilogue is still in qkeep / qdkeep / qnprev; the first epilogue itself reads the state the
+            //  step started from and the previous step's encoder reading)
+            if (sub == 0) {
+                DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+                    qkeep[k] = B.dof_state[gs[k] * 2]; qdkeep[k] = B.dof_state[gs[k] * 2 + 1];
+                    qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d];
+                }
+            }
+            DQ_UNROLL for (int k = 0; k < ONI; ++k) { pkv[k] = sub == 0 ? tau2k[k] : n1k[k]; rdamp2[k] = dampk[k]; rarm2[k] = armk[k]; rkp2[k] = kpk[k]; rkv2[k] = kvk[k]; }
+        } else {
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             qkeep[k] = B.dof_state[gs[k] * 2]; qdkeep[k] = B.dof_state[gs[k] * 2 + 1];
             qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d];
@@ -281,6 +297,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             // damping, armature and the PD gains of the upper body (used after the first substep only; requested in both so that the
             // block has no branch): again from memory rather than held in 20 registers through the first substep
             rdamp2[k] = B.dof_damping[gs[k]]; rarm2[k] = B.dof_armature[gs[k]]; rkp2[k] = M.kp[its[k].d]; rkv2[k] = M.kv[its[k].d];
+        }
         }
         if (noise) { DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = noise[(size_t)DW_NOISE_WORDS * its[k].env + DW_NZ_ENC + ND * sub + its[k].d]; }
         static_assert(ONI == 5, "the grouped touch below names five loads");
@@ -321,12 +338,17 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         // substep's encoder draw and the slot inputs of the second substep
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             if (its[k].ok) {
-                if (!c_freeze) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
-                if (sub == 0) {
-                    B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d] = qno[k];
-                    if (!noise) B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + PK_NZ1 + its[k].d] = n1[k];
+                if (KEEP) {          // (dof_state is written once, with the final state; nothing is parked)
+                    if (!c_freeze && sub == 1) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
+                } else {
+                    if (!c_freeze) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
+                    if (sub == 0) {
+                        B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d] = qno[k];
+                        if (!noise) B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + PK_NZ1 + its[k].d] = n1[k];
+                    }
                 }
             }
+            if (KEEP && sub == 0) n1k[k] = n1[k];
             if (sub == 0 && !c_freeze && X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, ips[k]) = nxt[k];
         }
         wave_sync();

@@ -27,7 +27,7 @@ void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__
 #if defined(OCT_STAGGER_SHIFT)      // (timing experiment: hold back every other group of workgroups so that the two waves of a SIMD are in different phases)
     if ((blockIdx.x >> OCT_STAGGER_SHIFT) & 1) for (int i = 0; i < OCT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-    dwo::oct_step<TERRAIN, GPUF>(L.w[w], L.hot, *QM, *M, P->C, make_obuf(HB, &P->B), actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
+    dwo::oct_step<TERRAIN, GPUF, WPE == 1>(L.w[w], L.hot, *QM, *M, P->C, make_obuf(HB, &P->B), actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
 }
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN, int WPE>

@@ -241,3 +241,17 @@ def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, layout):
               "randomize_buf", "dof_damping", "dof_armature"):
         assert np.array_equal(ora[k], emu[k]), k
     assert np.isfinite(emu["root_states"]).all() and np.isfinite(emu["env_state"]).all()
+
+
+def test_octet_register_resident_build_replays_the_goldens():
+    """The HIP library runs launches of at most one wave per SIMD (N <= 8192) with the form of the octet step that keeps its
+    per-joint state in registers instead of parking it in global memory (dw_oct_kernels.h KEEP).  The emulation selects that form
+    with DWE_OCT_KEEP=1 (read once per process): the octet cases of this file again, in a process of their own."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DWE_OCT_KEEP="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "oct and not register_resident",
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert " passed" in out.stdout
