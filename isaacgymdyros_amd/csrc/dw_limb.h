@@ -77,7 +77,8 @@ template <int N> DQ_HD void quad_bcast_arr(int xl, const float (&s)[N], float (&
 // Profiling builds (-DDQ_STAMPS) record the clock at phase boundaries of wave 0 into the free tail of gate_acc (words
 // 200..): tools/phase_stamps.py.  Never defined in the shipped library.
 #if defined(DQ_STAMPS) && defined(__HIPCC__)
-#define DQ_STAMP(B, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) (B).gate_acc[200 + (n)] = (int64_t)__builtin_readcyclecounter(); } while (0)
+// (profiling builds, -DDQ_STAMPS: wave 0 leaves its cycle counter in the spare words of gate_acc; (B) is an OBuf, dw_bufg.h)
+#define DQ_STAMP(B, n) do { if (blockIdx.x == 0 && threadIdx.x == 0) (B).cold->gate_acc[200 + (n)] = (int64_t)__builtin_readcyclecounter(); } while (0)
 #else
 #define DQ_STAMP(B, n) do { } while (0)
 #endif
