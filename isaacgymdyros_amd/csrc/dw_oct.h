@@ -55,7 +55,15 @@ static_assert(sizeof(OLds) * (8 / WPG) <= 163840, "OLds: 8 waves per CU must fit
 // and cross-limb reads reach a body through icode() (cell from the owner table) with st = 0.
 struct OPos { int e, o; };
 DQ_HD OPos pcode_cell(int el, int owner, int cell) {
+#if defined(OCT_PCODE_NAIVE)          // (A/B builds only, profiles/r04_lds_position_code_ab.txt: every limb of env el in column el)
+    const int pos = el & 7, flip = 0;
+#elif defined(OCT_PCODE_ROT2)         // (A/B builds only: columns rotated by two per limb, no row swap)
+    const int pos = (el + 2 * owner) & 7, flip = 0;
+#elif defined(OCT_PCODE_ROT1F)        // (A/B builds only: columns rotated by one per limb, rows of odd limbs swapped)
+    const int pos = (el + owner) & 7, flip = owner & 1;
+#else
     const int pos = (el + 4 * (owner >> 1)) & 7, flip = owner & 1;
+#endif
     OPos p; p.e = cell * 512 + pos * 16 + flip * 128; p.o = cell * 512 + pos * 16 - flip * 128;
     return p;
 }
