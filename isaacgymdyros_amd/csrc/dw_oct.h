@@ -39,8 +39,9 @@ constexpr int WPG = OCT_WPG;         // wavefronts per workgroup (they share the
 constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 1;      // per lane: PhysParams::sc_park
 
 // One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env.  A row is 8 envs x 16 B
-// = 128 B, half the width of the LDS (64 banks x 4 B), so a limb's position code p = pos | flip << 3 also swaps the rows of
-// odd-numbered owner lanes pairwise: the four limbs of a 16-lane group (2 envs) then read 8 different 16-byte columns.
+// = 128 B, half the width of the LDS (64 banks x 4 B); the position code (pcode_cell below) rotates a limb's column by two per limb,
+// so the four limbs of a 16-lane group (2 envs) read 8 different 16-byte columns (`flip`, a pairwise swap of the rows of odd limbs, is
+// what round 3's code did instead and survives for the A/B builds).
 struct alignas(16) OSlots { F4 slot[NB * 4][EPO]; };
 struct alignas(16) OLds {
     OSlots w[WPG];
@@ -55,14 +56,18 @@ static_assert(sizeof(OLds) * (8 / WPG) <= 163840, "OLds: 8 waves per CU must fit
 // and cross-limb reads reach a body through icode() (cell from the owner table) with st = 0.
 struct OPos { int e, o; };
 DQ_HD OPos pcode_cell(int el, int owner, int cell) {
-#if defined(OCT_PCODE_NAIVE)          // (A/B builds only, profiles/r04_lds_position_code_ab.txt: every limb of env el in column el)
+    // Which column (and, with `flip`, which row of a pair) a limb of env `el` uses.  A/B of four codes on one box with the LDS counters
+    // (profiles/r04_lds_position_code_ab.txt): every limb in column el ("naive") has 2.6 x the bank-conflict cycles and costs 1.5 % of
+    // the step; the three rotations below differ by at most 21 % in conflict cycles and the shipped one is the fastest by 0.5 % (16384
+    // envs) and 0.9 % (4096 envs) -- it needs no row swap, so both row bases of a limb are one register.
+#if defined(OCT_PCODE_NAIVE)          // (A/B builds only)
     const int pos = el & 7, flip = 0;
-#elif defined(OCT_PCODE_ROT2)         // (A/B builds only: columns rotated by two per limb, no row swap)
-    const int pos = (el + 2 * owner) & 7, flip = 0;
+#elif defined(OCT_PCODE_R3)           // (A/B builds only: the code of round 3 -- arms four columns from the legs, rows of odd limbs swapped pairwise)
+    const int pos = (el + 4 * (owner >> 1)) & 7, flip = owner & 1;
 #elif defined(OCT_PCODE_ROT1F)        // (A/B builds only: columns rotated by one per limb, rows of odd limbs swapped)
     const int pos = (el + owner) & 7, flip = owner & 1;
-#else
-    const int pos = (el + 4 * (owner >> 1)) & 7, flip = owner & 1;
+#else                                 // columns rotated by two per limb, no row swap
+    const int pos = (el + 2 * owner) & 7, flip = 0;
 #endif
     OPos p; p.e = cell * 512 + pos * 16 + flip * 128; p.o = cell * 512 + pos * 16 - flip * 128;
     return p;
