@@ -23,6 +23,7 @@ A_PHYS_BYTES = 1636        # algorithmic bytes per env-substep at the Gym bounda
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PPO_EPOCHS = 3            # timed epochs of the config-3 leg (after one untimed epoch)
 HORIZON = 128              # rollout horizon of the reference's PPO config; logging gather once per horizon
+WARM_SECONDS = 0.75        # untimed stepping (wall time) on the env that is about to be timed, before the W warm-up steps
 VALU_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32 vector peak (packed v_pk_fma_f32: 64 flop / clk / SIMD)
 # Plain (unpacked) fp32 vector instructions issue at one wave64 instruction per ~4.6 cycles per SIMD however many waves share it
 # (tools/valu_issue.hip on the MI355X, profiles/r03g_valu_issue.txt: 2.941 / 4.945 / 9.125 ms for 1.28 M independent v_fma_f32 per
@@ -170,6 +171,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also-4096", action="store_true", help="skip the secondary 4096-env measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the friction-DR + forced-pushes leg (BASELINE config 5)")
+    ap.add_argument("--no-terrain", action="store_true", help="skip the height-field leg (SURVEY 8 row f-4, default curriculum map)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO-consumer leg (BASELINE config 3)")
     ap.add_argument("--no-amp", action="store_true", help="skip the sibling-task leg (TocabiAMPLower, SURVEY 8 row f-3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -209,7 +211,7 @@ def main():
         if not plumbing:
             torch.cuda.synchronize()
 
-    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False):
+    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False, warm_seconds=WARM_SECONDS):
         """K steps of VecTask.step on `envs` envs of this rank.  alias_obs = False is the product's default contract (step() returns
         a fresh observation tensor, as the reference's torch.clamp does); True returns the view of obs_buf, so that the stream
         holds nothing but the step kernel."""
@@ -231,22 +233,31 @@ def main():
             g = torch.Generator(device=dev).manual_seed(42 + rank)
             pool = [torch.rand(envs, 13, generator=g, device=dev) * 2 - 1 for _ in range(64)]
         env.reset()
-        # The W warm-up steps the caller asked for, preceded by whatever it takes to make one whole logging horizon of untimed
-        # steps (a driver run with --warmup 5 --steps 20 read 8 % low in round 3: the first steps of a fresh process run at the
-        # clock the GPU idles at, and a 12 ms timed region sees it).  Never fewer than W; the timed region is exactly K steps.
-        for i in range(max(0, HORIZON - warmup)):
-            env.step(pool[i % len(pool)])
+        # Warm by WALL TIME, then the W warm-up steps the caller asked for; the timed region is exactly K steps.  A driver run with
+        # --warmup 5 --steps 20 is a 3 ms timed region that is the first GPU work of a fresh process: rounds 3 and 4 read it 8 % and
+        # 12 % under the same run's 256-step leg, and a warm-up counted in steps (one logging horizon = 20 ms of GPU work) did not
+        # cure it -- the clocks of an idle GPU take longer than that to come up.  So: at least WARM_SECONDS of back-to-back stepping
+        # on THIS env (synchronised in chunks, so that the host-side queue is as short when the timer starts as in steady state),
+        # never less than one logging horizon.
+        t_w, n_w = time.perf_counter(), 0
+        while n_w < HORIZON or time.perf_counter() - t_w < warm_seconds:
+            for i in range(32):
+                env.step(pool[(n_w + i) % len(pool)])
+            n_w += 32
+            sync()
         for i in range(warmup):
             env.step(pool[i % len(pool)])
         # everything the timed loop calls must have run once before it: the logging gather's torch kernels are loaded on
         # first use, which on a fresh box costs ~15 ms of host time (measured r02: 0.285 instead of 0.257 ms/step over 512
         # steps whenever --warmup was shorter than one logging horizon)
         dwdist.gather_episode_stats(env._buf["env_state"])
+        if not plumbing:
+            # (both events exist and have been recorded once before the timer starts: creating / first recording one loads code)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
         if world > 1:
             dist.barrier()
         sync()
-        if not plumbing:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         if not plumbing:
             e0.record()
@@ -296,7 +307,7 @@ def main():
     value = total_envs * args.steps / wall_max
     # a short driver run (--steps 20 is 12 ms) says little by itself: time a longer region as well and report both
     long_run = None
-    if args.steps < 200 and not plumbing:
+    if args.steps < 200:
         r = run(args.envs_per_gpu, 256, 16)
         w_l = reduce_max(r["wall"])
         long_run = {"steps": 256, "value": total_envs * 256 / w_l, "ms_per_step": w_l / 256 * 1e3}
@@ -385,10 +396,10 @@ def main():
             out["config5_dr_friction_pushes"] = {"value": args.envs_per_gpu * n2 / r5["wall"], "ms_per_step": r5["wall"] / n2 * 1e3,
                                                  "perturb_start_fraction": r5["perturb_start_fraction"], "episodes_finished": r5["resets"],
                                                  "note": "friction x U(0.7,1.3) per env at reset, force_perturb_start (tasks/dyros_dynamic_walk.py:491)"}
-        if not args.no_config5:                 # the same step on the reference's default 10 x 20 curriculum map (height-field kernels)
+        if not args.no_terrain:                 # the same step on the reference's default 10 x 20 curriculum map (height-field kernels)
             rt = run(args.envs_per_gpu, n2, args.warmup, alias_obs=True, terrain=True)
             out["terrain_curriculum"] = {"value": args.envs_per_gpu * n2 / rt["wall"], "ms_per_step": rt["wall"] / n2 * 1e3, "kernel_ms": rt["kernel_ms"],
-                                         "ratio_to_flat_kernel": rt["kernel_ms"] / kernel_ms,
+                                         "ratio_to_flat_kernel": (rt["kernel_ms"] / kernel_ms) if kernel_ms and kernel_ms > 0 else None,
                                          "note": "cfg/terrain/terrain_cfg.py defaults (trimesh, curriculum), alias_obs; dw_k_step_oct<true, 2>"}
         if not args.no_ppo:                     # BASELINE config 3: the DYROS PPO loop attached (examples/ppo_consumer.py)
             try:

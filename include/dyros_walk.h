@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 6
+#define DW_ABI_VERSION 7
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -189,12 +189,15 @@ typedef struct DwConfig {
     float   terrain_env_length;         /* terrain_length [m]: walked more than half of it => level up */
     float   max_episode_length_s;       /* env.episodeLength as the curriculum uses it (:34, :685)    */
     int32_t custom_origins;             /* 1 = reset adds U(-1,1) m of xy jitter to the origin (:729-732) */
-    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate (one launch per policy step in both):
+    int32_t pipeline;                   /* which kernels run dw_step / dw_simulate (one launch per policy step):
                                            0 = default (3); 3 = the octet kernels (8 lanes per env, 8 envs per wavefront,
-                                           two waves per SIMD); 4 = the lane kernels (one lane per env, one wavefront per
-                                           limb, 64 envs per workgroup; slower, kept as the second implementation every
-                                           parity test also runs).  1 and 2 (the wave-per-env and quad
-                                           kernels of rounds 1 and 2) are retired: DW_EINVAL */
+                                           two waves per SIMD).  1, 2 and 4 (the wave-per-env, quad and lane kernels of
+                                           rounds 1, 2 and 4) are retired: DW_EINVAL */
+    int32_t debug_wave_build;           /* tests only.  The step / substep kernels exist in two builds of one source: one declared for
+                                           one wavefront per SIMD (keeps its per-joint state in registers; chosen when the launch
+                                           has no more wavefronts than the device has SIMDs, N <= 8192 on MI355X) and one for two
+                                           (parks that state in HBM; the 16384-env path).  0 = choose by launch size; 1 / 2 = force
+                                           that build, so that parity tests at small N can run the production-size code */
 } DwConfig;
 
 /* Layout of the injected-noise record, one per env per step (floats).  When the `noise` argument of
@@ -327,7 +330,7 @@ int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *
 /* dw_step with the 487-word observations written to `obs_out` [N,487] (device memory) instead of DwBuffers.obs_buf, for this call
  * only.  The reference's step returns a FRESH tensor every call (torch.clamp(self.obs_buf, ...), tasks/base/vec_task.py:338): a host
  * that hands a newly allocated tensor here keeps that contract without a copy of 1 948 B per env after the kernel.  step_counter:
- * NULL (step_index is used, as dw_step) or the device counter of dw_step_dev.  Pipelines 2 and 3 (they take DwBuffers by value).
+ * NULL (step_index is used, as dw_step) or the device counter of dw_step_dev.
  * (dw_reset_idx never touches obs_buf: a reset env's observations are rebuilt by the next step, as in the reference.) */
 int dw_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t step_index, int64_t *step_counter, float *obs_out,
                 void *stream);

@@ -79,6 +79,7 @@ class DwConfig(C.Structure):
         ("max_episode_length_s", C.c_float),
         ("custom_origins", C.c_int32),
         ("pipeline", C.c_int32),
+        ("debug_wave_build", C.c_int32),
     ]
 
 

@@ -11,13 +11,12 @@ LIB = os.path.join(PKG, "libdyroswalk_hip.so")
 # (source, its own flags).  The octet kernels are built with the iterative-ilp machine scheduler: the substep is a chain of short
 # dependent regions at two waves per SIMD, and a scheduler that lengthens the distance between an LDS load and its first use
 # pays directly (0.1477 -> 0.1444 ms at 16384 envs, 0.1188 -> 0.1176 at 4096, no scratch in the flat kernels; max-ilp,
-# iterative-minreg and the default max-occupancy scheduler lose; A/Bs of round 3).  The lane kernels and
-# the small kernels keep the compiler's default.
+# iterative-minreg and the default max-occupancy scheduler lose; A/Bs of round 3).  The small kernels keep
+# the compiler's default.
 SOURCES = [("dw_hip.hip", []),
-           ("dw_oct_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_lane_kernels.hip", []), ("dw_amp.hip", [])]
+           ("dw_oct_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_amp.hip", [])]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
-           "dw_limb.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h",
-           "dw_lane_wave.h", "dw_lane_model.h", "dw_lane.h", "dw_lane_kernels.h", "dw_lane_post.h"]
+           "dw_limb.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_*_f32 pairs: in the octet step kernel 1 920
 # packed instructions replace 4 079 scalar ones, but 775 v_mov are added to form the pairs and the two-waves-per-SIMD build (256
 # registers) goes from 0 to 612 B of scratch: 0.149 -> 0.199 ms (round 3), re-measured in round 4 with -slp-threshold 2..16 (DESIGN.md

@@ -95,8 +95,8 @@ def validate_cfg(cfg: dict) -> None:
     if len(sim.get("gravity", [0, 0, -9.81])) != 3:
         raise ValueError("sim.gravity must have three components")
     px = sim.get("physx", {})
-    if sim.get("mi355", {}).get("pipeline", 0) not in (0, 3, 4, "auto", "oct", "lane"):
-        raise ValueError("sim.mi355.pipeline must be 0/'auto', 3/'oct' or 4/'lane' (1/'fused' and 2/'quad', the kernels of rounds 1 and 2, are retired)")
+    if sim.get("mi355", {}).get("pipeline", 0) not in (0, 3, "auto", "oct"):
+        raise ValueError("sim.mi355.pipeline must be 0/'auto' or 3/'oct' (1/'fused', 2/'quad' and 4/'lane', the kernels of rounds 1, 2 and 4, are retired)")
     iters = int(px.get("num_position_iterations", 4)) + int(px.get("num_velocity_iterations", 1))
     if not 1 <= iters <= 64:
         raise ValueError("physx.num_position_iterations + num_velocity_iterations must be in 1..64")

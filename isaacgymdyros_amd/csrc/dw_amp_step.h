@@ -479,7 +479,7 @@ struct ResetSrc {
     const int64_t *ptime, *didx;
     const float *rootvel_noise;          // [N,6], by env
     size_t row;
-    bool dr;                             // dof-property randomisation inside the kernel (dw_amp_reset_done)
+    bool dr;                             // dw_amp_reset_done: the kernel also does the dof-property randomisation (under DwAmpConfig.randomize) and writes obs_out
     bool power;                          // draw power_scale
 };
 
@@ -522,7 +522,8 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         }
         // dof properties (apply_randomizations, tasks/base/vec_task.py:519-733): additive damping, scaled armature, from the
         // nominal values, for a resetting env whose randomize_buf has reached the frequency
-        if (R.dr && l < DW_NUM_DOF && B.randomize_buf[e] >= (int64_t)C.dr_frequency) {
+        // (only under task.randomize, as the torch class and the reference: apply_randomizations is what resets randomize_buf)
+        if (R.dr && C.randomize && l < DW_NUM_DOF && B.randomize_buf[e] >= (int64_t)C.dr_frequency) {
             if (C.dr_damping) {
                 const float u = R.damp ? R.damp[(size_t)DW_NUM_DOF * R.row + l] : draw_uniform(k, DS_DR, l);
                 G.dof_damping[(size_t)DW_NUM_DOF * e + l] = B.nominal_damping[l] + ((C.dr_damping_range[1] - C.dr_damping_range[0]) * u + C.dr_damping_range[0]);
@@ -548,7 +549,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         }
         if (l >= 4 && l < 7) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (l - 4)] = r[l - 4];
         if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
-        if (R.dr && l == 63 && B.randomize_buf[e] >= (int64_t)C.dr_frequency) B.randomize_buf[e] = 0;
+        if (R.dr && C.randomize && l == 63 && B.randomize_buf[e] >= (int64_t)C.dr_frequency) B.randomize_buf[e] = 0;
     });
     const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
     W.par([&](int l) {

@@ -5,18 +5,16 @@
 #include "dw_params.h"
 
 namespace dwq { struct QuadModel; }
-namespace dwl { struct LaneModel; }
 
 struct DwHandle {
     DwConfig        cfg;
     dw::TaskParams  params;
     dw::DevModel   *d_model;
     dwq::QuadModel *d_qmodel;
-    dwl::LaneModel *d_lmodel;
     dw::DevParams  *d_params;
-    int             pipeline;       // 3 octet (8 lanes per env), 4 lane (one lane per env, one wave per limb); one launch per step in both
+    int             pipeline;       // 3 = the octet kernels (8 lanes per env), one launch per policy step
     float          *d_mocap;
-    float          *d_sc_park;      // octet / lane kernels: PhysParams::sc_park
+    float          *d_sc_park;      // PhysParams::sc_park
     int16_t        *d_hmax;         // height field: the coarse bound table built at dw_bind (PhysParams::hmax)
     float           reach;          // dw_physics.h model_reach() of the model, computed at dw_create
     DwBuffers       buf;

@@ -1,8 +1,7 @@
 // dw_hip.hip -- the C-ABI of include/dyros_walk.h (libdyroswalk_hip.so): argument validation, the read-only model / mocap tables
 // in device memory, dispatch.  One launch per policy step.  The step and substep kernels live in their own translation units:
-// the octet kernels (DwConfig.pipeline 3, the default: 8 lanes per env, 8 envs per wavefront, two wavefronts per SIMD; dw_oct*.h,
-// dw_oct_kernels.hip) and the lane kernels (pipeline 4: one lane per env, one wavefront per limb; dw_lane*.h,
-// dw_lane_kernels.hip).  This file holds dw_k_reset, the kernel behind dw_reset_idx (one wavefront per listed env; the resets
+// the octet kernels (DwConfig.pipeline 0 / 3: 8 lanes per env, 8 envs per wavefront, two wavefronts per SIMD; dw_oct*.h,
+// dw_oct_kernels.hip).  This file holds dw_k_reset, the kernel behind dw_reset_idx (one wavefront per listed env; the resets
 // inside a step are the step kernels' own).  Nothing here allocates, synchronises or copies per call.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -30,26 +29,13 @@ size_t quadmodel_bytes();
 }  // namespace dwq
 // The octet kernels (DwConfig.pipeline = 3): dw_oct_kernels.hip.
 namespace dwo {
-void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+void launch_step(bool terrain, int gpu_flavour, int wave_build, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
-void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+void launch_simulate(bool terrain, int wave_build, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push);
 int  oct_lds_bytes();
 int  sc_park_words();
 }  // namespace dwo
-
-// The lane kernels (DwConfig.pipeline = 4): dw_lane_kernels.hip.
-namespace dwl {
-struct LaneModel;
-void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
-                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
-void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const LaneModel *LM, const dw::DevModel *M, const dw::DevParams *P,
-                     const DwBuffers &B, const float *tau, const float *push);
-int  build_lanemodel_host(const dw::DevModel *hm, LaneModel **out, const char **err);      // malloc'ed
-size_t lanemodel_bytes();
-int  lane_lds_bytes();
-size_t sc_park_floats(int num_envs);
-}  // namespace dwl
 
 // the coarse bound table of the height field (dw_physics.h terrain_bound), one thread per cell; runs once, at dw_bind
 __global__ __launch_bounds__(256) void dw_k_terrain_bound(const int16_t *hs, int rows, int cols, int cell, int reach, int hm_rows, int hm_cols, int16_t *out) {
@@ -108,15 +94,8 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     h->pipeline = cfg->pipeline == 0 ? DW_DEFAULT_PIPELINE : cfg->pipeline;
     h->reach = dw::model_reach(*hm);
     dwq::QuadModel *hq = nullptr;
-    dwl::LaneModel *hl = nullptr;
-    if (h->pipeline == 4) {
-        rc = dwl::build_lanemodel_host(hm, &hl, &err);
-        if (rc) { free(hm); free(h); return fail(rc, err); }
-    }
-    if (h->pipeline == 3) {
-        rc = dwq::build_quadmodel_host(hm, model, &hq, &err);
-        if (rc) { free(hm); free(h); return fail(rc, err); }
-    }
+    rc = dwq::build_quadmodel_host(hm, model, &hq, &err);
+    if (rc) { free(hm); free(h); return fail(rc, err); }
     (void)hipGetDevice(&h->device);
     e = hipMalloc((void **)&h->d_model, sizeof(dw::DevModel));
     if (e == hipSuccess) e = hipMemcpy(h->d_model, hm, sizeof(dw::DevModel), hipMemcpyHostToDevice);
@@ -126,20 +105,8 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
         if (e == hipSuccess) e = hipMemcpy(h->d_qmodel, hq, dwq::quadmodel_bytes(), hipMemcpyHostToDevice);
     }
     free(hq);
-    if (e == hipSuccess && hl) {
-        e = hipMalloc((void **)&h->d_lmodel, dwl::lanemodel_bytes());
-        if (e == hipSuccess) e = hipMemcpy(h->d_lmodel, hl, dwl::lanemodel_bytes(), hipMemcpyHostToDevice);
-    }
-    free(hl);
     if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
-    if (h->pipeline == 4) {
-        const size_t bytes = dwl::sc_park_floats(cfg->num_envs) * sizeof(float);
-        e = hipMalloc((void **)&h->d_sc_park, bytes);
-        if (e == hipSuccess) e = hipMemset(h->d_sc_park, 0, bytes);
-        if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: self-collision park buffer", e); }
-        h->params.phys.sc_park = h->d_sc_park;
-    }
-    if (h->pipeline == 3) {
+    {
         const size_t waves = (size_t)(cfg->num_envs + 15) / 16 * 2;
         e = hipMalloc((void **)&h->d_sc_park, waves * 64 * dwo::sc_park_words() * sizeof(float));
         if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: self-collision park buffer", e); }
@@ -166,7 +133,6 @@ int dw_destroy(DwHandle *h) {
     DeviceGuard guard(h->device);
     if (h->d_model) (void)hipFree(h->d_model);
     if (h->d_qmodel) (void)hipFree(h->d_qmodel);
-    if (h->d_lmodel) (void)hipFree(h->d_lmodel);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_mocap) (void)hipFree(h->d_mocap);
     if (h->d_sc_park) (void)hipFree(h->d_sc_park);
@@ -180,28 +146,41 @@ int dw_bind(DwHandle *h, const DwBuffers *b) {
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
     if (const char *m = dw::check_terrain_buffers(&h->cfg, b)) return fail(DW_EINVAL, m);
     DeviceGuard guard(h->device);
-    h->buf = *b;
-    // bind time, not step time: one small synchronous copy of the pointer table into the parameter block
-    hipError_t e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return fail_hip("dw_bind: pointer table upload", e);
-    // height field: the samples' pointer and the coarse bound table built from them HERE (height_samples is read at bind: bind again
-    // after changing the terrain), both patched into the device-resident parameter block
-    h->params.phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
-    if (h->d_hmax) { (void)hipFree(h->d_hmax); h->d_hmax = nullptr; }
-    h->params.phys.hmax = nullptr;
+    // height field: the coarse bound table is built from the NEW samples first (height_samples is read at bind: bind again after
+    // changing the terrain); only when that has succeeded are the old table freed and the handle / parameter block switched over, so
+    // a failed rebind leaves the handle as it was (bound to the old buffers and the old, still allocated table)
+    int16_t *new_hmax = nullptr;
+    int cell = 0, hr = 0, hc = 0;
+    hipError_t e;
     if (h->cfg.terrain) {
-        const int cell = dw::hm_cell_samples(h->cfg.terrain_hscale), reach = dw::hm_reach_samples(h->cfg.terrain_hscale, h->reach);
-        const int hr = (h->cfg.terrain_rows + cell - 1) / cell, hc = (h->cfg.terrain_cols + cell - 1) / cell;
-        e = hipMalloc((void **)&h->d_hmax, sizeof(int16_t) * (size_t)hr * hc);
+        cell = dw::hm_cell_samples(h->cfg.terrain_hscale);
+        const int reach = dw::hm_reach_samples(h->cfg.terrain_hscale, h->reach);
+        hr = (h->cfg.terrain_rows + cell - 1) / cell; hc = (h->cfg.terrain_cols + cell - 1) / cell;
+        e = hipMalloc((void **)&new_hmax, sizeof(int16_t) * (size_t)hr * hc);
         if (e != hipSuccess) return fail_hip("dw_bind: terrain bound table", e);
         hipLaunchKernelGGL(dw_k_terrain_bound, dim3((hr * hc + 255) / 256), dim3(256), 0, 0, b->height_samples, h->cfg.terrain_rows, h->cfg.terrain_cols,
-                           cell, reach, hr, hc, h->d_hmax);
-        e = hipDeviceSynchronize();
-        if (e != hipSuccess) return fail_hip("dw_bind: terrain bound kernel", e);
-        h->params.phys.hmax = h->d_hmax; h->params.phys.hm_cell = cell; h->params.phys.hm_rows = hr; h->params.phys.hm_cols = hc;
+                           cell, reach, hr, hc, new_hmax);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(new_hmax); return fail_hip("dw_bind: terrain bound kernel", e); }
     }
-    e = hipMemcpy(&h->d_params->C.phys, &h->params.phys, sizeof(dw::PhysParams), hipMemcpyHostToDevice);      // (sc_park: set at dw_create)
-    if (e != hipSuccess) return fail_hip("dw_bind: terrain parameters upload", e);
+    dw::PhysParams phys = h->params.phys;          // (sc_park: set at dw_create)
+    phys.hs = h->cfg.terrain ? b->height_samples : nullptr;
+    phys.hmax = new_hmax;
+    if (new_hmax) { phys.hm_cell = cell; phys.hm_rows = hr; phys.hm_cols = hc; }
+    // bind time, not step time: two small synchronous copies into the parameter block (the pointer table, the physics parameters)
+    e = hipMemcpy(&h->d_params->C.phys, &phys, sizeof(dw::PhysParams), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(&h->d_params->B, b, sizeof(DwBuffers), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        // the device block may now be half new: nothing may be launched against it until a bind succeeds
+        h->bound = 0;
+        if (new_hmax) (void)hipFree(new_hmax);
+        return fail_hip("dw_bind: parameter block upload", e);
+    }
+    if (h->d_hmax) (void)hipFree(h->d_hmax);
+    h->d_hmax = new_hmax;
+    h->params.phys = phys;
+    h->buf = *b;
     h->bound = 1;
     return DW_OK;
 }
@@ -211,11 +190,7 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
     DeviceGuard guard(h->device);
-    if (h->pipeline == 4) {
-        dwl::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
-    } else {
-        dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
-    }
+    dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.debug_wave_build, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_simulate: launch", e);
     return DW_OK;
@@ -234,17 +209,10 @@ static int launch_step(DwHandle *h, const float *actions, const float *noise, lo
     // (the kernels take the buffer table by value: this launch's copy may name another observation buffer)
     DwBuffers bufs = h->buf;
     if (obs_out) bufs.obs_buf = obs_out;
-    // the torch flavour of the post phase's norms is compiled into the step kernels; the lane kernels also have a build without the
-    // code only tests use (an injected noise record, frozen physics) and one that reads every switch at run time (flavour -1)
+    // the torch flavour of the post phase's norms is compiled into the step kernels
     const int flavour = h->cfg.torch_gpu_div != 0 ? 1 : 0;
-    const int lane_flavour = (noise || h->cfg.debug_freeze_physics) ? -1 : flavour;
-    if (h->pipeline == 4) {
-        dwl::launch_step(h->cfg.terrain != 0, lane_flavour, h->cfg.num_envs, (hipStream_t)stream, h->d_lmodel, h->d_model, h->d_params, bufs, h->d_mocap,
-                         actions, noise, step_index, step_dev);
-    } else {
-        dwo::launch_step(h->cfg.terrain != 0, flavour, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
-                         actions, noise, step_index, step_dev);
-    }
+    dwo::launch_step(h->cfg.terrain != 0, flavour, h->cfg.debug_wave_build, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
+                     actions, noise, step_index, step_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(who, e);
     return DW_OK;
@@ -290,6 +258,5 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
 }
 
 int dw_oct_lds_bytes(void) { return dwo::oct_lds_bytes(); }
-int dw_lane_lds_bytes(void) { return dwl::lane_lds_bytes(); }
 
 }  // extern "C"

@@ -202,6 +202,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     // record itself sits in the hot tables)
     const float ms1 = mscale_e[f2i(H.in1[j & 1][10])];
     if (TERRAIN) X.zbound = dw::terrain_bound(P, X.root[0], X.root[1]);          // (requested here, first used in the inward pass)
+    // @phase fk
     // ---- base kinematics (every lane of the quad, redundantly) ----
     float qn[4], R0k[9], ww[3], vo[3], bcom[3];
     {
@@ -257,19 +258,19 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
             }
         };
-        DQ_ROLLED for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {          /*@trip:11*/
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             // (both halves of a limb walk it: every lane reads its slot row before any lane overwrites it)
             F4 in = mk4(0.0f, 0.0f, 0.0f, 0.0f);
             if (b >= 0) in = OQ_LD(s, 0, X.pos);            // {q, qd, tt, dd}
-            if ((startmask >> s) & 1) {
+            if ((startmask >> s) & 1) {          /*@prob:0.27*/
                 // limbs that start below another lane's body fetch that lane's running state (still in its registers)
                 float fq[4], fx[3], fv[6];
                 bool fetched = false;
                 const int fm = H.fmask[s];
-                if (fm) {
-                    for (int xl = 0; xl < 4; ++xl)
+                if (fm) {          /*@prob:0.33*/
+                    for (int xl = 0; xl < 4; ++xl)          /*@trip:1*/
                         if ((fm >> xl) & 1) {
                             float tq[4], tx[3], tv[6];
                             quad_bcast_arr(xl, qr, tq); quad_bcast_arr(xl, xr_, tx); quad_bcast_arr(xl, vr, tv);
@@ -301,6 +302,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     wave_sync();
 
     DQ_STAMP(B, SB + 2);
+    // @phase self_collision
     // ---- self-collision: capsule proxies (legs, arms, torso), pairs from the model.  Detection is pair-parallel: octet
     //      lane o tests pairs o, o + 8, o + 16, o + 24 -- both proxies' axes from their bodies' slots, the division-free
     //      conservative distance of dw_limb.h -- and the touching pairs of the env are ORed into a mask over the octet.  The
@@ -336,7 +338,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #endif
         DQ_STAMP(B, 51);
         int hits = 0;
-        for (int k0 = 0; k0 < npair; k0 += LPE) {           // (wave-uniform trip count; a lane past the last pair tests pair 0 again)
+        for (int k0 = 0; k0 < npair; k0 += LPE) {  /*@trip:4*/ // (wave-uniform trip count; a lane past the last pair tests pair 0 again)
             const int pid = k0 + X.o, pidc = pid < npair ? pid : 0;
             const int pr = (H.pairs[pidc >> 2] >> (8 * (pidc & 3))) & 255, pa = pr & 15, pbx = pr >> 4;
             float a0[3], a1[3], b0[3], b1[3];
@@ -360,7 +362,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #if defined(DQ_STAMPS) && defined(__HIPCC__)
         if (blockIdx.x == 0 && threadIdx.x == 0) OQ_COLD(gate_acc)[200 + 53] = sc_any;
 #endif
-        if (sc_any) {
+        if (sc_any) {          /*@prob:0*/
             float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
             int scGym0 = 0;                      // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
             DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
@@ -405,6 +407,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     wave_sync();      // the leg lanes read each other's slots above; the inward pass below overwrites them
 
     DQ_STAMP(B, SB + 3);
+    // @phase inward
     // ---- inward pass: articulated inertias and bias forces, in reverse schedule order, TWO steps per round.  What a body
     //      contributes by itself -- joint subspace, rigid inertia about O, gyroscopic bias, external forces, velocity-product
     //      acceleration: more than half of a step's arithmetic, and no recursion in it -- is a MAP over bodies: half 0 of a limb
@@ -433,7 +436,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #if defined(OCT_ABL_INWARD)
     DQ_ROLLED for (int s = 0; s < 0; s += 2) {
 #else
-    DQ_ROLLED for (int s = 0; s < T; s += 2) {
+    DQ_ROLLED for (int s = 0; s < T; s += 2) {          /*@trip:6*/
 #endif
         OQ_TICK();
 #if defined(DQ_STAMPS_INWARD)
@@ -490,7 +493,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #if defined(DQ_KO_GEOM) || defined(OCT_ABL_GEOM)          // (timing experiment only)
                 near_ground = false;
 #endif
-                if (near_ground) {
+                if (near_ground) {          /*@prob:0.17*/
                     const QInRec &rc = QM.in[sm][j];
                     for (int k = 0; k < ngeom; ++k) {
                         float F[3], xr[3];
@@ -505,7 +508,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                         }
                     }
                 }
-                if (sc_any && scm) {
+                if (sc_any && scm) {          /*@prob:0*/
                     float scW[QMAX_OWN][6];
                     DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = park[6 * p + i];
                     const int scGym0 = f2i(park[6 * QMAX_OWN]);
@@ -548,7 +551,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             const int b = (bits & 255) - 1;
             const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
             const int gw = H.gany[sr];
-            if (gw >> 8) {                      // a finished chain joins the finished chain of an idle lane (same parent) before its lane starts afresh
+            if (gw >> 8) {  /*@prob:0.09*/      // a finished chain joins the finished chain of an idle lane (same parent) before its lane starts afresh
                 const int src = (gw >> 9) & 3, dst = (gw >> 11) & 3;
                 float tI[21], tp[6];
                 quad_bcast_arr(src, IA, tI);
@@ -563,7 +566,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
             }
             // gathers (wave-uniform per step): child chains that ended on other lanes
-            if (gw & 1) {
+            if (gw & 1) {          /*@prob:0.09*/
                 const int g0 = f2i(H.in[sr][0][1]), g1 = f2i(H.in[sr][1][1]), g2 = f2i(H.in[sr][2][1]), g3 = f2i(H.in[sr][3][1]);
                 const int mine = f2i(H.in[sr][j][1]);
                 DQ_UNROLL for (int src = 0; src < 4; ++src) {
@@ -629,6 +632,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_UNROLL for (int i = 0; i < 3; ++i) X.footF[i] += oct_xor4(X.footF[i]);
 
     DQ_STAMP(B, SB + 4);
+    // @phase base_solve
     // ---- base: gather the chains below the root, own inertia, external forces, inverse ----
     float Minv[21], a0[6];            // inverse of the base's articulated inertia, symmetric storage (sym6)
     {
@@ -669,7 +673,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         float cfb[3] = {0, 0, 0};
         bool near_ground = base_ngeom > 0 && (X.root[2] < H.base[12]);
         if (TERRAIN) near_ground = base_ngeom > 0 && (X.root[2] - X.zbound < H.base[12]);
-        if (near_ground) {
+        if (near_ground) {          /*@prob:0*/
             for (int k = 0; k < base_ngeom; ++k) {
                 float F[3], xr[3];
                 geom_force<TERRAIN>(M.geoms[QM.base_geom[k]], P, R0, x0, v0, X.root[0], X.root[1], X.root[2], X.mu, F, xr);
@@ -730,6 +734,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 5);
+    // @phase outward2
     // the warm-start impulses of my foot's corners (previous substep) from the task record: requested here, a whole
     // outward pass before the contact solve uses them
     float warm[12];
@@ -743,17 +748,17 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     //      pass 1) ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
-        DQ_ROLLED for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {          /*@trip:11*/
             const int bits = f2i(H.fk[s][j][3]);
             const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
             if (b >= 0) { s0 = OQ_LD(s, 0, X.pos); s1 = OQ_LD(s, 1, X.pos); s2 = OQ_LD(s, 2, X.pos); s3 = OQ_LD(s, 3, X.pos); OQ_KEEP1(s3); }
-            if ((startmask >> s) & 1) {
+            if ((startmask >> s) & 1) {          /*@prob:0.27*/
                 float fa[6], fv[6];
                 bool fetched = false;
                 const int fm = H.fmask[s];
-                if (fm) {
-                    for (int xl = 0; xl < 4; ++xl)
+                if (fm) {          /*@prob:0.33*/
+                    for (int xl = 0; xl < 4; ++xl)          /*@trip:1*/
                         if ((fm >> xl) & 1) {
                             float ta[6], tv[6];
                             quad_bcast_arr(xl, ar, ta); quad_bcast_arr(xl, vr, tv);
@@ -784,6 +789,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
     wave_sync();
     DQ_STAMP(B, SB + 6);
+    // @phase contact_setup
     // ---- free base velocity; sole-corner gaps of my foot (foot f = j & 1; lanes f and f + 2 work on it together) ----
     float wwf[3], vowf[3];
     {
@@ -849,6 +855,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             DQ_UNROLL for (int i = 0; i < 6; ++i) twf[i] = acc[i];
         }
         DQ_STAMP(B, SB + 7);
+        // @phase contact_W
         // ---- my block of W: the response of ONE foot (leg g: half 0 of the octet takes its own foot f, half 1 the other foot)
         //      to my 3 unit wrenches (components 3 part .. 3 part + 2) on foot f.  Up leg f: d = -S'p, p += U d / D (both
         //      halves); base: dv = -Minv p; down leg g: qdd = (d - U'dv) / D, dv += S qdd ----
@@ -899,6 +906,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
         }
         DQ_STAMP(B, SB + 8);
+        // @phase contact_Akk
         // ---- 3x3 diagonal blocks of the Delassus matrix of my foot's corners: A_kk = J_k W_ff J_k' (frame-projected on
         //      terrain); what the solver needs of them: the three diagonal inverses and the couplings zx, zy, xy.  W_ff is
         //      spread over the half-0 lanes of the foot (rows 3 part ..): they compute, half 1 takes the results over ----
@@ -971,11 +979,12 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
         }
         DQ_STAMP(B, SB + 9);
+        // @phase contact_gs
         // ---- projected Gauss-Seidel, block-Jacobi across the feet: corner kk of the left sole and corner kk of the right
         //      sole are updated together from the same snapshot, the four corners of a sole one after the other ----
         bool pair_on[4];
         DQ_UNROLL for (int kk = 0; kk < 4; ++kk) pair_on[kk] = wave_any(act[kk] != 0);
-        for (int it = 0; it < P.iters; ++it) {
+        for (int it = 0; it < P.iters; ++it) {          /*@trip:5*/
             DQ_UNROLL for (int kk = 0; kk < 4; ++kk) {
                 if (pair_on[kk]) {
                     float o3[3];
@@ -1026,6 +1035,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
         }
         DQ_STAMP(B, SB + 10);
+        // @phase contact_up
         // ---- impulses -> wrench on my foot -> up my leg (leg lanes), base jump ----
         float dpb[6] = {0, 0, 0, 0, 0, 0};
         float Fs[3] = {0, 0, 0};
@@ -1085,20 +1095,21 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     }
 
     DQ_STAMP(B, SB + 11);
+    // @phase outward3
     // ---- outward pass 3: velocity jumps down the tree, final joint velocities (speed limit); the caller integrates ----
     {
         float ar[6] = {0, 0, 0, 0, 0, 0};
-        DQ_ROLLED for (int s = 0; s < T; ++s) {
+        DQ_ROLLED for (int s = 0; s < T; ++s) {          /*@trip:11*/
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
             if (b >= 0) { s0 = OQ_LD(s, 0, X.pos); s1 = OQ_LD(s, 1, X.pos); s2 = OQ_LD(s, 2, X.pos); s3 = OQ_LD(s, 3, X.pos); OQ_KEEP1(s3); }
-            if ((startmask >> s) & 1) {
+            if ((startmask >> s) & 1) {          /*@prob:0.27*/
                 float fa[6];
                 bool fetched = false;
                 const int fm = H.fmask[s];
-                if (fm) {
-                    for (int xl = 0; xl < 4; ++xl)
+                if (fm) {          /*@prob:0.33*/
+                    for (int xl = 0; xl < 4; ++xl)          /*@trip:1*/
                         if ((fm >> xl) & 1) {
                             float ta[6];
                             quad_bcast_arr(xl, ar, ta);
@@ -1123,6 +1134,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         }
     }
     DQ_STAMP(B, SB + 12);
+    // @phase base_final
     // ---- base: final velocity, clamps, pose update (dw_physics.h V2) ----
     {
         float wwn[3], von[3];
@@ -1156,6 +1168,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_STAMP(B, SB + 13);
 }
 
+// @phase lane_init
 // Lane set-up shared by the entry points: which env this lane works for, its base state and parameters.
 DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, const PhysParams &P, float friction, const OBuf &B) {
     X.lane = lane_id();

@@ -50,6 +50,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     const long long dq_t0 = (long long)__builtin_readcyclecounter();
     const long long dq_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    // @phase pre_physics
     // ==== round 1 of requests: everything whose address is known at entry -- the base state, the scalars of the record the
     //      pre-physics phase reads, the actions, the inputs of the actuator model for this lane's nine (env, joint) items,
     //      the hot tables -- in one straight run, so that the wave waits for memory once.  (Each request a lone wave waits
@@ -252,7 +253,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     }
     wave_sync();
 
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < 2; ++sub) {          /*@trip:2*/
         X.stamp_base = 1 + 16 * sub;
 #if !defined(OCT_NO_WG_ALIGN) && defined(__HIPCC__)
         // the two waves of the workgroup meet before every substep: they share nothing but the instruction stream, and in step
@@ -268,6 +269,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
 #endif
         if (!c_freeze) oct_substep<TERRAIN>(L, H, QM, M, C.phys, X, B, sub == 0 ? push_x : 0.0f, sub == 0 ? push_y : 0.0f, sub == 1);
         wave_sync();
+        // @phase encoder_epilogue
         // ---- integrate the joints, encoder model (tasks/dyros_dynamic_walk.py:527-530), inputs of the next substep.  Four
         //      straight-line blocks -- every request, the noise, the arithmetic, every store -- with no branch between two requests:
         //      a store under `if (ok)` between two items' loads had made the compiler wait for memory once per item. ----
@@ -354,6 +356,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         wave_sync();
         DQ_STAMP(B, 1 + 16 * sub + 14);
     }
+    // @phase post_entry
     if (X.valid && !c_freeze && X.o == 0) {
         int e2 = e;
         DQ_OPAQUE(e2);            // (the row's address again from the index: held since the loads at the top it is a register pair through both substeps)

@@ -61,8 +61,10 @@ namespace dwo {
 
 static int groups(int num_envs) { return (num_envs + EPO * WPG - 1) / (EPO * WPG); }
 
-// waves of the launch <= SIMDs of the device: the one-wave-per-SIMD build
-static bool spread(int num_envs) {
+// waves of the launch <= SIMDs of the device: the one-wave-per-SIMD build (wave_build: DwConfig.debug_wave_build, 1 / 2 force a build)
+static bool spread(int num_envs, int wave_build) {
+    if (wave_build == 1) return true;
+    if (wave_build == 2) return false;
     static int simds = 0;
     if (!simds) {
         int dev = 0, cus = 0;
@@ -72,24 +74,24 @@ static bool spread(int num_envs) {
     return groups(num_envs) * WPG <= simds;
 }
 template <int GPUF>
-static void launch_step_f(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+static void launch_step_f(bool terrain, int wave_build, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                           const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
     const dim3 grid(groups(num_envs)), block(64 * WPG);
-    const bool sp = spread(num_envs);
+    const bool sp = spread(num_envs, wave_build);
     if (terrain && sp) hipLaunchKernelGGL((dw_k_step_oct<true, 1, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
     else if (terrain) hipLaunchKernelGGL((dw_k_step_oct<true, 2, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
     else if (sp) hipLaunchKernelGGL((dw_k_step_oct<false, 1, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
     else hipLaunchKernelGGL((dw_k_step_oct<false, 2, GPUF>), grid, block, 0, stream, QM, M, P, make_hot(B), mocap, actions, noise, step, step_dev);
 }
-void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+void launch_step(bool terrain, int gpu_flavour, int wave_build, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                  const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev) {
-    if (gpu_flavour) launch_step_f<1>(terrain, num_envs, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
-    else launch_step_f<0>(terrain, num_envs, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
+    if (gpu_flavour) launch_step_f<1>(terrain, wave_build, num_envs, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
+    else launch_step_f<0>(terrain, wave_build, num_envs, stream, QM, M, P, B, mocap, actions, noise, step, step_dev);
 }
-void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+void launch_simulate(bool terrain, int wave_build, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
                      const DwBuffers &B, const float *tau, const float *push) {
     const dim3 grid(groups(num_envs)), block(64 * WPG);
-    const bool sp = spread(num_envs);
+    const bool sp = spread(num_envs, wave_build);
     if (terrain && sp) hipLaunchKernelGGL((dw_k_simulate_oct<true, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
     else if (terrain) hipLaunchKernelGGL((dw_k_simulate_oct<true, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
     else if (sp) hipLaunchKernelGGL((dw_k_simulate_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);

@@ -108,6 +108,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const double cdt_d = K.cdt_d;
     const int LFG = M.left_foot_gym, RFG = M.right_foot_gym;
 
+    // @phase post_stage
     // (the VecTask counters and the clock action of Q1, the per-joint constants of the reset path and the observation's mean /
     //  scale, requested together with the records: one memory latency for all.  The hot tables of the physics are dead by now:
     //  the observation constants go where they were.)
@@ -184,7 +185,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
     }
     wave_sync();
-    if (C.freeze_physics) {
+    if (C.freeze_physics) {          /*@prob:0*/
         // debug mode: simulate() was the identity, so the net contact forces are an input (dw_task.h step_env)
         if (j == 0) {
             const float *cf = B.contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
@@ -203,6 +204,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     wave_sync();
 
     DQ_STAMP(B, 42);
+    // @phase post_q1
     // ---- Q1: clocks, VecTask counters, non-finite guard ----
     if (j == 0) {
         const long long p = q1_progress, rbl = q1_randomize;
@@ -230,7 +232,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         if (i < EPO * ND && (!dw::finitef(LF[PL_Q + 2 * i]) || !dw::finitef(LF[PL_Q + 2 * i + 1]))) PQ_PSI(i / ND, PS_BAD) = 1;
     }
     wave_sync();
-    if (wave_any(PQ_PSI(el, PS_BAD) != 0)) {
+    if (wave_any(PQ_PSI(el, PS_BAD) != 0)) {          /*@prob:0*/
         if (j == 0 && PQ_PSI(el, PS_BAD)) {
             DQ_UNROLL for (int i = 0; i < 13; ++i) PQ_ROOT(el, i) = (i == 2) ? C.initial_height : (i == 6 ? 1.0f : 0.0f);
             PQ_ESI(el, DW_ES_NAN_RESETS) += 1;
@@ -249,6 +251,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
 
     DQ_STAMP(B, 43);
+    // @phase post_reward
     // ---- Q2: reward terms, one group per lane of the quad ----
     {
         // the three 33-element norms, in torch's CPU order (8 fused accumulators over elements a, a+8, a+16, a+24, added in order,
@@ -318,6 +321,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     wave_sync();
 
     DQ_STAMP(B, 44);
+    // @phase post_q3
     // ---- Q3: total reward, termination ----
     {
         const bool collision = PQ_PSI(el, PS_COLL) != 0;
@@ -353,9 +357,10 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     wave_sync();
 
     DQ_STAMP(B, 45); DQ_WT();
+    // @phase post_reset
     // ---- reset_idx for the envs that ended (dw_task.h reset_region) ----
     const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
-    if (any_reset) {
+    if (any_reset) {          /*@prob:0.18*/
         const bool mine = PQ_PSI(el, PS_RESET) != 0;
         if (C.terrain_curriculum && j == 0 && mine) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
@@ -491,6 +496,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
 
     DQ_STAMP(B, 46); DQ_WT();
+    // @phase post_taps
     // ---- Q5, first half: request the history taps now, use them after Q4 (one memory latency, spent computing the new
     //      observation).  A lane takes ROWS (env, tap): 37 observation words and 13 action words, consecutive in the rings and
     //      in obs_buf, so a row is 10 + 4 requests with constant offsets and no per-word index arithmetic.  The newest
@@ -507,6 +513,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, tapo[r]);
         ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, tapa[r]);
     }
+    // @phase post_obs
     // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
     //      expensive functions (atan2, sincos, the noise draw) is executed by one or two wave passes, not by all ten ----
     {
@@ -516,8 +523,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             PQ_NORMED(ee, l) = nrm;
             if (egr < N) {
                 float *oh = B.obs_history + (size_t)egr * DW_HIST_SLOTS * DW_NUM_OBS1;
-                if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {
-                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2) oh[s2 * DW_NUM_OBS1 + l] = nrm;
+                if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {          /*@prob:0.18*/
+                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2)          /*@trip:20*/ oh[s2 * DW_NUM_OBS1 + l] = nrm;
                 } else {
                     oh[PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l] = nrm;
                 }
@@ -575,6 +582,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     wave_sync();
 
     DQ_STAMP(B, 47); DQ_WT();
+    // @phase post_obsbuf
     // ---- Q5, second half: the 487-d observation buffer.  Rows requested above go out as they came (an env that was just
     //      reset shows its first observation in every tap and zeros in the action taps, tasks/dyros_dynamic_walk.py:655-669);
     //      the newest tap is copied from LDS, items (env, word). ----
@@ -585,12 +593,12 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             const int ee = pc / NTAP, tap = pc - NTAP * ee;
             const bool ok = p < NPAIR && wave_index * EPO + ee < N;
             const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
-            if (wave_any(fill)) {
+            if (wave_any(fill)) {          /*@prob:0.18*/
                 if (fill) { DQ_UNROLL for (int k = 0; k < DW_NUM_OBS1; ++k) tapo[r][k] = PQ_NORMED(ee, k); }
             }
             const int newest = PQ_ESI(ee, DW_ES_HIST_HEAD);
             const bool own = ((newest + 1) % DW_HIST_SLOTS + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS == newest;    // (never, with 2 x 10 slots)
-            if (wave_any(rs || own)) {
+            if (wave_any(rs || own)) {          /*@prob:0.18*/
                 if (rs) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = 0.0f; }
                 else if (own) { DQ_UNROLL for (int k = 0; k < DW_NUM_ACT; ++k) tapa[r][k] = PQ_ES(ee, DW_ES_ACTIONS + k); }
             }
@@ -609,6 +617,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
 
     DQ_STAMP(B, 48); DQ_WT();
+    // @phase post_q6
     // ---- Q6: late updates (tasks/dyros_dynamic_walk.py:560-563), ring head, gate statistics ----
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
@@ -639,6 +648,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     wave_sync();
 
     DQ_STAMP(B, 49); DQ_WT();
+    // @phase post_writeback
     // ---- write back: the records (contiguous), and the Gym state of the envs whose state the task changed ----
     {
         constexpr int NP = EPO * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
@@ -648,7 +658,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         const F4 *srcl = reinterpret_cast<const F4 *>(LF + PL_ES);
         DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
         const bool changed = PQ_PSI(el, PS_RESET) != 0 || PQ_PSI(el, PS_BAD) != 0;
-        if (wave_any(changed)) {
+        if (wave_any(changed)) {          /*@prob:0.18*/
             if (j == 0 && changed && xvalid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
             DQ_UNROLL for (int k = 0; k < ONI; ++k) {
                 const int i = lane + 64 * k;

@@ -18,8 +18,10 @@ inline const char *check_config(const DwConfig *c) {
         return "terrain: rows/cols >= 2 and positive scales required";
     if (c->terrain_curriculum && (c->terrain_num_levels < 1 || c->terrain_num_types < 1))
         return "terrain curriculum: num_levels and num_types must be positive";
-    if (c->pipeline == 1 || c->pipeline == 2) return "pipeline 1 (wave per env) and 2 (quad) are retired: use 0 (default), 3 (octet: 8 lanes per env) or 4 (lane: one lane per env, one wave per limb)";
-    if (c->pipeline != 0 && c->pipeline != 3 && c->pipeline != 4) return "pipeline must be 0 (default), 3 (octet: 8 lanes per env) or 4 (lane: one lane per env, one wave per limb)";
+    if (c->pipeline == 1 || c->pipeline == 2 || c->pipeline == 4)
+        return "pipeline 1 (wave per env), 2 (quad) and 4 (lane per env, wave per limb) are retired: use 0 (default) or 3 (octet: 8 lanes per env)";
+    if (c->pipeline != 0 && c->pipeline != 3) return "pipeline must be 0 (default) or 3 (octet: 8 lanes per env)";
+    if (c->debug_wave_build < 0 || c->debug_wave_build > 2) return "debug_wave_build must be 0 (by launch size), 1 or 2";
     return nullptr;
 }
 

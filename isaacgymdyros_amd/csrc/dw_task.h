@@ -66,7 +66,7 @@ constexpr int GATE_LATCH = 192;
 
 // ---------------------------------------------------------------------------------------------- RNG
 DW_HD void philox4x32_10(unsigned int *c, unsigned int k0, unsigned int k1) {
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < 10; ++r) {          /*@trip:10*/
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
         const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;

@@ -142,9 +142,10 @@ class DyrosDynamicWalk(VecTask):
         c.self_collision = int(bool(mi.get("self_collision", True)))
         c.debug_freeze_physics = int(bool(mi.get("debug_freeze_physics", False)))
         c.seed = int(self.cfg.get("seed", 42)) & 0xFFFFFFFFFFFFFFFF
-        # which kernels: 0/3 = octet kernels, 8 lanes per env, two waves per SIMD (default); 4 = lane kernels (one lane per env, one wave per limb)
+        # which kernels: 0/3 = octet kernels, 8 lanes per env, two waves per SIMD (the only generation shipped)
         # kernels of round 1; one launch per policy step in all three
-        c.pipeline = {"auto": 0, "oct": 3, "lane": 4}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
+        c.pipeline = {"auto": 0, "oct": 3}.get(mi.get("pipeline", 0), mi.get("pipeline", 0))
+        c.debug_wave_build = int(mi.get("debug_wave_build", 0))          # tests: force the one- / two-waves-per-SIMD build of the kernels
         tc = self.terrain_cfg
         c.terrain = int(self.custom_origins)
         c.custom_origins = int(self.custom_origins)
@@ -387,10 +388,7 @@ class DyrosDynamicWalk(VecTask):
     def kernel_info(self) -> dict:
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
         profiles/ carry the same name)."""
-        pl = int(self._ccfg.pipeline) or 3
-        name = {3: "dw_k_step_oct", 4: "dw_k_step_lane"}[pl]
-        desc = {3: "octet (8 lanes per env, 8 envs per wave, 2 waves per SIMD)", 4: "lane (one lane per env, one wave per limb, 64 envs per workgroup)"}[pl]
-        return {"kernels": name, "pipeline": desc, "launches_per_step": 1}
+        return {"kernels": "dw_k_step_oct", "pipeline": "octet (8 lanes per env, 8 envs per wave, 2 waves per SIMD)", "launches_per_step": 1}
 
     def simulate(self, tau: torch.Tensor, push_xy: torch.Tensor = None):
         """One physics substep at the Gym boundary: set_dof_actuation_force_tensor + apply_rigid_body_force_tensors

@@ -288,7 +288,15 @@ class TocabiAMPLower(VecTask):
         # (Philox keyed by the seed, the env and the env's draw counter) instead of by torch's generator: no draw kernels, no host
         # round trip; same distributions, another stream -- the form bench.py measures.
         mi = cfg["sim"].get("mi355", {})
-        self._hist_ring = bool(mi.get("amp_hist_ring", self._fused)) and self._fused
+        # The ring layout is understood by the fused kernels only (dw_amp_step_*, dw_amp_reset_rows / _done).  A reset that takes the
+        # torch path -- stateInit Start / Random / Hybrid, or amp_fused_reset off -- reads the histories in the reference's shifting
+        # layout (_compute_observations(env_ids)), so the rings default to ON only where every reset is the fused one, and asking
+        # for them elsewhere is an error rather than a silently rotated observation.
+        ring_ok = self._fused and self._fused_reset and self._state_init == "Default"
+        if "amp_hist_ring" in mi and bool(mi["amp_hist_ring"]) and not ring_ok:
+            raise ValueError("sim.mi355.amp_hist_ring needs amp_fused with the fused reset (amp_fused_reset, stateInit 'Default'): "
+                             "the torch reset path reads the histories in the reference's shifting layout")
+        self._hist_ring = bool(mi.get("amp_hist_ring", ring_ok)) and ring_ok
         self._device_draws = bool(mi.get("amp_device_draws", False))
         if self._device_draws and not (self._fused and self._fused_reset):
             raise ValueError("sim.mi355.amp_device_draws needs amp_fused (step and reset)")
@@ -771,10 +779,10 @@ class TocabiAMPLower(VecTask):
         done = self.reset_buf.clone()
         c, b = self._fused_tables()
         self._chk(self._api["amp_reset_done"](self._phys._h, C.byref(c), C.byref(b), None, self._stream()))
-        self.time_step = 0
         self.obs_dict["obs"] = self._obs_out
         ids = done.nonzero(as_tuple=False).flatten()
         if len(ids) > 0:
+            self.time_step = 0          # (as reset_idx: only when some env was reset)
             self._reset_default_env_ids = ids
         return self.obs_dict, ids
 

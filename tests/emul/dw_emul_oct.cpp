@@ -35,9 +35,9 @@ void wave_body(void *p, int) {
         else dwo::oct_simulate<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
         break;
     case 1: {
-        // DWE_OCT_KEEP=1: the register-resident form of the one-wave-per-SIMD build (dw_oct_kernels.h KEEP), which the HIP library
-        // uses for launches of at most one wave per SIMD
-        static const bool keep = getenv("DWE_OCT_KEEP") && getenv("DWE_OCT_KEEP")[0] == '1';
+        // DwConfig.debug_wave_build = 1: the register-resident form of the one-wave-per-SIMD build (dw_oct_kernels.h KEEP), which the
+        // HIP library uses for launches of at most one wave per SIMD; otherwise the two-waves form (what 16384 envs run)
+        const bool keep = h->cfg.debug_wave_build == 1;
         dwo::OSlots &sl = w->lds->w[w->wave % dwo::WPG];
         const OBuf ob = make_obuf(make_hot(h->dp.B), &h->dp.B);
         if (h->cfg.terrain && keep) dwo::oct_step<true, -1, true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);

@@ -10,9 +10,9 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
 _cache = {}
 
 
-def load(asan=False, layout="oct"):
-    # layout: "oct" = octet kernels (also carries the fused TocabiAMPLower kernels), "lane" = lane kernels
-    name = {"oct": "libdw_emul_oct", "lane": "libdw_emul_lane"}[layout] + ("_asan.so" if asan else ".so")
+def load(asan=False):
+    # the octet kernels (also carries the fused TocabiAMPLower kernels)
+    name = "libdw_emul_oct" + ("_asan.so" if asan else ".so")
     if name not in _cache:
         subprocess.check_call(["make", "-C", HERE, "-s", "_build/" + name])
         lib = C.CDLL(os.path.join(HERE, "_build", name))
@@ -21,13 +21,14 @@ def load(asan=False, layout="oct"):
 
 
 class EmulSim(OracleSim):
-    def __init__(self, num_envs, task_const=None, layout="oct", **cfg_over):
-        super().__init__(num_envs, task_const=task_const, lib_api=load(layout=layout), **cfg_over)
+    def __init__(self, num_envs, task_const=None, **cfg_over):
+        # cfg_over debug_wave_build = 1: the register-resident (KEEP) form of the step, 0 / 2: the two-waves form
+        super().__init__(num_envs, task_const=task_const, lib_api=load(), **cfg_over)
 
 
 class EmulBackend:
-    def __init__(self, N, task_const, layout="oct", **cfg):
-        self.sim = EmulSim(N, task_const=task_const, layout=layout, **cfg)
+    def __init__(self, N, task_const, **cfg):
+        self.sim = EmulSim(N, task_const=task_const, **cfg)
 
     def load_buffers(self, bufs):
         for k, v in bufs.items():

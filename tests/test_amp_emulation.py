@@ -11,7 +11,7 @@ from emul_backend import EmulSim
 
 
 def make(N, **kw):
-    sim = EmulSim(N, layout="oct", self_collision=0)
+    sim = EmulSim(N, self_collision=0)
     return AmpEmul(sim, N, **kw)
 
 
@@ -121,3 +121,16 @@ def test_caller_draws_are_used_verbatim():
     want = q + np.clip(z1, -0.00016, 0.00016).astype(np.float32)
     want[:, :12] += env.a["qpos_bias"]                          # (the observation function adds the bias in place)
     assert np.array_equal(env.a["qpos_noise"], want)
+
+
+def test_reset_done_leaves_dof_properties_alone_without_task_randomize():
+    """DwAmpConfig.randomize = 0: dw_amp_reset_done neither redraws damping / armature nor clears randomize_buf (the torch class and
+    the reference run apply_randomizations, which is what resets the counter, under task.randomize only)."""
+    N = 3
+    env = make(N, randomize=False, episode_length=50.0)
+    env.a["randomize_buf"][:] = 7
+    damp, arm = env.sim.buf["dof_damping"].copy(), env.sim.buf["dof_armature"].copy()
+    ids = env.reset_done()
+    assert len(ids) == N and (env.a["reset_buf"] == 0).all()
+    assert (env.a["randomize_buf"] == 7).all()
+    assert np.array_equal(env.sim.buf["dof_damping"], damp) and np.array_equal(env.sim.buf["dof_armature"], arm)

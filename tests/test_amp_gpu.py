@@ -605,6 +605,55 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
         e.close()
 
 
+def test_fused_step_with_a_motion_start_keeps_the_shifting_histories(tmp_path):
+    """amp_fused with a stateInit other than 'Default' takes the torch reset path, which reads the histories in the
+    reference's shifting layout -- so the rings must be OFF there (they default to on only where every reset is the fused one), and
+    asking for them is an error.  Checked as behaviour: the fused step with stateInit 'Hybrid' against the non-fused class, same
+    seeds and actions, resets in between -- the observation returned by reset_done(), obs_buf and both histories bit-identical."""
+    from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
+    from tests import amp_motion_synth as SY
+    N = 67
+    yml = SY.write(str(tmp_path))
+    envs = []
+    for fused in (True, False):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["env"].update({"episodeLength": 30, "stateInit": "Hybrid", "hybridInitProb": 0.5, "numAMPObsSteps": 3, "motion_file": yml})
+        cfg["sim"]["mi355"] = {"amp_fused": fused}
+        envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
+    a, b = envs
+    assert a._fused and not a._hist_ring and not b._hist_ring
+    b._capturing = True          # (the torch step's branch of the command ramp that draws for every env, as the fused step does)
+    with pytest.raises(ValueError, match="amp_hist_ring"):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["env"].update({"stateInit": "Hybrid", "motion_file": yml})
+        cfg["sim"]["mi355"] = {"amp_fused": True, "amp_hist_ring": True}
+        TocabiAMPLower(cfg, "cuda:0", 0, True)
+    with pytest.raises(ValueError, match="amp_hist_ring"):
+        cfg = default_amp_cfg(N, "cuda:0")
+        cfg["sim"]["mi355"] = {"amp_fused": True, "amp_fused_reset": False, "amp_hist_ring": True}
+        TocabiAMPLower(cfg, "cuda:0", 0, True)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    resets = 0
+    for t in range(70):
+        np.random.seed(100 + t)
+        ra_ = a.reset_done()
+        np.random.seed(100 + t)
+        rb_ = b.reset_done()
+        assert torch.equal(ra_[1], rb_[1]) and torch.equal(ra_[0]["obs"], rb_[0]["obs"]), t
+        for n in ("obs_buf", "obs_history", "action_history", "_amp_obs_buf", "_dof_state", "_root_states"):
+            assert torch.equal(getattr(a, n), getattr(b, n)), (t, "after reset", n)
+        act = (torch.rand(N, 12, generator=g, device="cuda") * 2 - 1) * 0.7
+        oa, ra, da, xa = a.step(act)
+        ob, rb, db, xb = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(xa["amp_obs"], xb["amp_obs"]), t
+        for n in ("obs_buf", "obs_history", "action_history"):
+            assert torch.equal(getattr(a, n), getattr(b, n)), (t, n)
+        resets += int(da.sum())
+    assert resets > N
+    for e in envs:
+        e.close()
+
+
 def test_amp_step_argument_checks():
     """The fused entry points refuse a table with a missing buffer, sizes beyond what a wave stages, missing draws or a handle of
     another size, with an error code and a message, before anything is launched."""
@@ -702,7 +751,7 @@ def test_fused_amp_kernels_with_device_draws_equal_their_host_emulation():
     N = 7
     kw = dict(seed=19, episode_length=10.0, hist_ring=True, device_draws=True)
     g = _HipAmp(N, **kw)
-    e = AmpEmul(EmulSim(N, layout="oct", self_collision=0), N, **kw)
+    e = AmpEmul(EmulSim(N, self_collision=0), N, **kw)
     e.a["total_mass"][:] = g.t["total_mass"].cpu().numpy()          # (the GPU env randomised its link masses at setup)
     exact = ["actions", "actions_pre", "commands", "start_target_vel", "final_target_vel", "vel_change_duration", "cur_vel_change_duration",
              "epi_len", "power_scale", "delay_idx", "simul_len", "qpos_bias", "quat_bias", "progress_buf", "randomize_buf", "reset_buf", "terminate_buf",

@@ -10,11 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=300):
+def _run(extra, env_extra=None, timeout=300, steps=6):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(env_extra or {})
     env["OMP_NUM_THREADS"] = "1"
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--steps", "6", "--warmup", "2",
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--steps", str(steps), "--warmup", "2",
                            "--envs-per-gpu", "16", "--no-cpu-baseline", "--no-also-4096"] + extra,
                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
 
@@ -49,3 +49,15 @@ def test_single_rank_needs_no_launcher():
 def test_contradicting_world_size_is_an_error():
     p = _run(["--gpus", "4"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "contradicts WORLD_SIZE" in p.stderr
+
+
+def test_short_head_leg_reads_like_the_long_leg():
+    """A driver-style short run (--steps well under 200) times a second, 256-step region in the same process; the two must
+    tell the same ms/step (the 20-step headline read 12 % under its own long leg because the warm-up was
+    counted in steps).  On the plumbing env a step is a 1 ms sleep, so this checks the SHAPE of run(): warm by wall time,
+    events / gather exercised before the timer, exactly K steps inside it."""
+    p = _run(["--gpus", "1"], steps=100)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["steps"] == 100 and out["long_run"]["steps"] == 256
+    assert abs(out["ms_per_step"] - out["long_run"]["ms_per_step"]) / out["long_run"]["ms_per_step"] < 0.03, (out["ms_per_step"], out["long_run"])

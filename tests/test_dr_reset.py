@@ -40,7 +40,7 @@ def check_dr_replay(backend, steps=None):
     assert (prev_a >= 0.8 * np.asarray(ARMATURE, np.float32) - 1e-6).all() and (prev_a <= 1.2 * np.asarray(ARMATURE, np.float32) + 1e-5).all()
 
 
-@pytest.mark.parametrize("which", ["oracle", "oct", "lane"])
+@pytest.mark.parametrize("which", ["oracle", "oct"])
 def test_reset_time_dr_matches_the_reference(which, task_const):
     g = R.load("dr_reset.npz")
     N = int(g["N"])
@@ -49,5 +49,5 @@ def test_reset_time_dr_matches_the_reference(which, task_const):
         be = R.OracleBackend(N, task_const, **kw)
     else:
         from emul_backend import EmulBackend
-        be = EmulBackend(N, task_const, layout=which, **kw)
+        be = EmulBackend(N, task_const, **kw)
     check_dr_replay(be)

@@ -10,16 +10,17 @@ from oracle import parity as P
 from oracle.oracle import OracleSim
 
 
-@pytest.fixture(params=["oct", "lane"])
-def layout(request):
-    """Both lane layouts run the same checks: the octet kernels (dw_oct*.h: 8 lanes per env, one fiber per lane on the host) and
-    the lane kernels (dw_lane*.h: one lane per env, one wavefront per limb, one fiber per thread of the workgroup)."""
+@pytest.fixture(params=[2, 1], ids=["two_waves", "keep"])
+def wave_build(request):
+    """Both forms of the octet step (dw_oct_kernels.h) run the same checks: 2 = the two-waves-per-SIMD form, which parks its
+    per-joint state in global memory across the physics (what 16384 envs run on the GPU), 1 = the register-resident form of the
+    one-wave-per-SIMD build (KEEP; launches of N <= 8192).  DwConfig.debug_wave_build selects; dw_simulate has one form."""
     return request.param
 
 
-def test_task_logic_bitwise_vs_reference_goldens(task_const, layout):
+def test_task_logic_bitwise_vs_reference_goldens(task_const, wave_build):
     g = R.load("task_logic_frozen.npz")
-    be = EmulBackend(int(g["N"]), task_const, layout=layout, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
+    be = EmulBackend(int(g["N"]), task_const, debug_wave_build=wave_build, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0)
     for t, ref, got in R.replay(g, be):
         exact = R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"]
         if "obs_history" in ref:
@@ -30,10 +31,10 @@ def test_task_logic_bitwise_vs_reference_goldens(task_const, layout):
     assert P.compare(ref, got, atol={"obs_history": (2e-6, 4e-6)}) == []
 
 
-def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, layout):
+def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, wave_build):
     """Row f-4 through the kernel source: level changes, tile origins and spawn jitter of the reference's curriculum."""
     g = R.load("terrain_logic_frozen.npz")
-    be = EmulBackend(int(g["N"]), task_const, layout=layout, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
+    be = EmulBackend(int(g["N"]), task_const, debug_wave_build=wave_build, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
                      terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]))
     for t, ref, got in R.replay(g, be):
         ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
@@ -44,14 +45,14 @@ def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, layout):
         assert np.array_equal(g["step_env_origins"][t], got["env_origins"]), t
 
 
-def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, layout):
+def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, wave_build):
     """Same libm on both sides here, so with physics frozen the kernel body and the oracle agree on every bit,
     in-kernel Philox noise included (noise = None)."""
     g = R.load("task_logic_frozen.npz")
     N = int(g["N"])
     from replay import OracleBackend
     a = OracleBackend(N, task_const, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
-    b = EmulBackend(N, task_const, layout=layout, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
+    b = EmulBackend(N, task_const, debug_wave_build=wave_build, debug_freeze_physics=1, torch_gpu_div=1, randomize_friction_on_reset=1)
     init = {k[5:]: v for k, v in g.items() if k.startswith("init_")}
     a.load_buffers(init)
     b.load_buffers(init)
@@ -66,13 +67,13 @@ def test_kernel_body_equals_oracle_bitwise_when_physics_frozen(task_const, layou
             assert np.array_equal(a.read_buffers()[k], b.read_buffers()[k]), k
 
 
-def test_whole_step_tracks_oracle_goldens(task_const, layout):
+def test_whole_step_tracks_oracle_goldens(task_const, wave_build):
     """Physics differs from the oracle only in summation order (Cholesky solve vs explicit inverse, fused
     Gauss-Seidel update).  Stated tolerance, contacts active, random torques: after 10 policy steps (20 substeps)
     |dq| <= 1e-4 rad, |dqd| <= 2e-2 rad/s (0.5 % of the 4.03 rad/s joint-speed limit), root pose <= 1e-4; the trajectories then separate chaotically, so
     beyond that only a sanity bound and the reset pattern are held."""
     g = R.load("whole_step_oracle.npz")
-    be = EmulBackend(int(g["N"]), task_const, layout=layout, randomize_dof_on_reset=0, torch_gpu_div=0)
+    be = EmulBackend(int(g["N"]), task_const, debug_wave_build=wave_build, randomize_dof_on_reset=0, torch_gpu_div=0)
     for t, ref, got in R.replay(g, be):
         dq = np.abs(ref["dof_state"][:, :, 0] - got["dof_state"][:, :, 0]).max()
         dqd = np.abs(ref["dof_state"][:, :, 1] - got["dof_state"][:, :, 1]).max()
@@ -84,10 +85,10 @@ def test_whole_step_tracks_oracle_goldens(task_const, layout):
         assert np.array_equal(ref["reset_buf"], got["reset_buf"]), t
 
 
-def test_physics_substep_vs_oracle_random_flight(layout):
+def test_physics_substep_vs_oracle_random_flight(wave_build):
     rng = np.random.default_rng(1)
     N = 16
-    A, B = OracleSim(N), EmulSim(N, layout=layout)
+    A, B = OracleSim(N), EmulSim(N, debug_wave_build=wave_build)
     A.buf["root_states"][:, 0:3] = rng.normal(size=(N, 3)) + np.array([0, 0, 3])
     q = rng.normal(size=(N, 4))
     A.buf["root_states"][:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
@@ -130,9 +131,9 @@ def _gate_roundtrip(make, N=40):
     return sim.buf["gate_acc"].copy()
 
 
-def test_perturbation_gate_latches_identically(task_const, layout):
+def test_perturbation_gate_latches_identically(task_const, wave_build):
     a = _gate_roundtrip(lambda N: OracleSim(N, task_const=task_const, debug_freeze_physics=1))
-    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, layout=layout, debug_freeze_physics=1))
+    b = _gate_roundtrip(lambda N: EmulSim(N, task_const=task_const, debug_wave_build=wave_build, debug_freeze_physics=1))
     assert np.array_equal(a, b)
 
 
@@ -148,10 +149,10 @@ def _crossed(N, symmetric):
     return q
 
 
-def test_self_collision_vs_oracle(layout):
+def test_self_collision_vs_oracle(wave_build):
     """Row f-1 through the kernel source: skew capsule axes (well-conditioned), one substep: forces 1e-3 relative, state 1e-5."""
     N = 48
-    A, B = OracleSim(N), EmulSim(N, layout=layout)
+    A, B = OracleSim(N), EmulSim(N, debug_wave_build=wave_build)
     for s in (A, B):
         s.buf["root_states"][:, 0:2] = 0
         s.buf["root_states"][:, 2] = 3.0
@@ -164,13 +165,13 @@ def test_self_collision_vs_oracle(layout):
     assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 0].max() < 1e-5
 
 
-@pytest.mark.parametrize("which", ["oracle", "oct", "lane"])
+@pytest.mark.parametrize("which", ["oracle", "oct"])
 def test_mirrored_legs_get_a_mirrored_response(which):
     """Exactly parallel capsules (mirror-symmetric legs): contact in the middle of the overlap, so the response is mirrored
     -- joint rates of the two legs are mirror images, the base neither yaws nor drifts sideways (the textbook closest-point
     rule put the contact at whichever end rounding chose).  Envs whose shank axes intersect are left out."""
     N = 40
-    sim = OracleSim(N) if which == "oracle" else EmulSim(N, layout=which)
+    sim = OracleSim(N) if which == "oracle" else EmulSim(N)
     sim.buf["root_states"][:, 0:2] = 0
     sim.buf["root_states"][:, 2] = 3.0
     sim.buf["dof_state"][:, :, 0] = _crossed(N, True)
@@ -184,12 +185,12 @@ def test_mirrored_legs_get_a_mirrored_response(which):
     assert np.abs(sim.buf["root_states"][keep][:, 8]).max() < 2e-2
 
 
-def test_arms_into_torso_vs_oracle(layout):
+def test_arms_into_torso_vs_oracle(wave_build):
     """Row f-1, second tranche (forearm / hand against torso and thigh, arm against arm) through the kernel source: the
     arm poses of tests/test_oracle_physics.py (inside the joint limits), one substep: forces 1e-3 relative, state 1e-5."""
     from test_oracle_physics import _arms_in
     N = 48
-    A, B = OracleSim(N), EmulSim(N, layout=layout)
+    A, B = OracleSim(N), EmulSim(N, debug_wave_build=wave_build)
     for s in (A, B):
         s.buf["root_states"][:, 0:2] = 0
         s.buf["root_states"][:, 2] = 3.0
@@ -227,7 +228,7 @@ def _terrain_reset_case(sim, g):
     return {k: np.array(v, copy=True) for k, v in sim.buf.items()}
 
 
-def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, layout):
+def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, wave_build):
     """the reset_done path read the base position from uninitialised LDS when the curriculum decided the
     level change.  A moved env, a stationary env and an untouched env, several ids in one call, against the oracle; the
     emulation NaN-fills its LDS block per id, so stale contents cannot pass."""
@@ -235,23 +236,9 @@ def test_reset_idx_with_terrain_curriculum_vs_oracle(task_const, layout):
     N = int(g["N"])
     kw = dict(terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]), torch_gpu_div=1)
     ora = _terrain_reset_case(OracleSim(N, task_const=task_const, **kw), g)
-    emu = _terrain_reset_case(EmulSim(N, task_const=task_const, layout=layout, **kw), g)
+    emu = _terrain_reset_case(EmulSim(N, task_const=task_const, debug_wave_build=wave_build, **kw), g)
     assert int(ora["terrain_levels"][3]) == 2 and int(ora["terrain_levels"][5]) == 0 and int(ora["terrain_levels"][6]) == 1
     for k in ("terrain_levels", "env_origins", "root_states", "dof_state", "env_state", "reset_buf", "progress_buf",
               "randomize_buf", "dof_damping", "dof_armature"):
         assert np.array_equal(ora[k], emu[k]), k
     assert np.isfinite(emu["root_states"]).all() and np.isfinite(emu["env_state"]).all()
-
-
-def test_octet_register_resident_build_replays_the_goldens():
-    """The HIP library runs launches of at most one wave per SIMD (N <= 8192) with the form of the octet step that keeps its
-    per-joint state in registers instead of parking it in global memory (dw_oct_kernels.h KEEP).  The emulation selects that form
-    with DWE_OCT_KEEP=1 (read once per process): the octet cases of this file again, in a process of their own."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, DWE_OCT_KEEP="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "oct and not register_resident",
-                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-3000:]
-    assert " passed" in out.stdout

@@ -88,15 +88,14 @@ def test_forces_follow_the_slope_normal(model):
     assert -0.05 < sim.buf["root_states"][0, 4] < 0.0            # still pitched back by about the slope angle
 
 
-@pytest.mark.parametrize("layout", ["oct", "lane"])
-def test_kernel_body_matches_oracle_on_generated_terrain(layout):
+def test_kernel_body_matches_oracle_on_generated_terrain():
     """Same inputs through the oracle and through the kernel source (host emulation of either kernel generation) on a
     generated map: random poses near the ground so that sole corners and primitives touch rough terrain."""
     t = Terrain(TerrainCfg(mesh_type="heightfield", curriculum=True, num_rows=2, num_cols=4, border_size=2,
                            terrain_proportions=[0.2, 0.2, 0.3, 0.3, 0.0]), 8, seed=3)
     rng = np.random.default_rng(5)
     N = 12
-    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t, layout=layout)
+    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t)
     org = t.env_origins.reshape(-1, 3)[rng.integers(0, 8, size=N)]
     A.buf["root_states"][:, 0:2] = org[:, 0:2] + rng.uniform(-3, 3, size=(N, 2))
     ground = t.height_at(A.buf["root_states"][:, 0], A.buf["root_states"][:, 1])
@@ -120,8 +119,7 @@ def test_kernel_body_matches_oracle_on_generated_terrain(layout):
     assert np.isfinite(B.buf["root_states"]).all()
 
 
-@pytest.mark.parametrize("layout", ["oct", "lane"])
-def test_fallen_robots_on_high_rough_terrain_touch_like_the_oracle(layout):
+def test_fallen_robots_on_high_rough_terrain_touch_like_the_oracle():
     """The kernels skip the height-field fetches of a body that is higher above the coarse bound of the field around its robot
     (dw_physics.h terrain_bound, a table built at bind) than its bounding radius; the oracle samples under every primitive.  Robots
     lying, kneeling and tumbling on the highest and roughest tiles of a generated map -- torso, arms, knees and head on the ground,
@@ -131,7 +129,7 @@ def test_fallen_robots_on_high_rough_terrain_touch_like_the_oracle(layout):
                            terrain_proportions=[0.1, 0.2, 0.35, 0.25, 0.1]), 15, seed=11)
     rng = np.random.default_rng(2)
     N = 16
-    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t, layout=layout)
+    A, B = OracleSim(N, terrain=t), EmulSim(N, terrain=t)
     org = t.env_origins.reshape(-1, 3)
     org = org[np.argsort(-org[:, 2])][:8]                                 # the highest tile origins (top rows of the curriculum)
     pick = org[rng.integers(0, len(org), size=N)]
