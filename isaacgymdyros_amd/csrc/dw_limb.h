@@ -74,6 +74,19 @@ template <int N> DQ_HD void quad_bcast_arr(int xl, const float (&s)[N], float (&
     else { DQ_UNROLL for (int i = 0; i < N; ++i) d[i] = quad_bcast<3>(s[i]); }
 }
 
+// chain starts of the outward passes: a[i] = take ? (a[i] of quad lane xl) : a[i], in place (wave-uniform xl, per-lane take) -- one
+// DPP move and one select per word, no control flow (written as branches, the register copies at the joins of those branches were
+// 6 moves per word: tools/isa_dyn.py, round 5)
+template <int XL, int N> DQ_HD void quad_take_arr_x(bool take, float (&a)[N]) {
+    DQ_UNROLL for (int i = 0; i < N; ++i) { const float t = quad_bcast<XL>(a[i]); a[i] = take ? t : a[i]; }
+}
+template <int N> DQ_HD void quad_take_arr(int xl, bool take, float (&a)[N]) {
+    if (xl == 0) quad_take_arr_x<0>(take, a);
+    else if (xl == 1) quad_take_arr_x<1>(take, a);
+    else if (xl == 2) quad_take_arr_x<2>(take, a);
+    else quad_take_arr_x<3>(take, a);
+}
+
 // Profiling builds (-DDQ_STAMPS) record the clock at phase boundaries of wave 0 into the free tail of gate_acc (words
 // 200..): tools/phase_stamps.py.  Never defined in the shipped library.
 #if defined(DQ_STAMPS) && defined(__HIPCC__)

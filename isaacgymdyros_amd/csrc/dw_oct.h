@@ -26,7 +26,7 @@ namespace dwo {
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
 using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
-using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::over_1n;
+using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
 
@@ -197,6 +197,14 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     const int e = X.env;
     const bool wr = X.valid && X.h == 0;          // global side effects: half 0 only (half 1 mirrors it)
     const float *mscale_e = B.mass_scale + (size_t)DW_NUM_BODIES * e;
+    const int first_j = (f2i(H.base[14]) >> (4 * j)) & 15, last_j = (f2i(H.base[14]) >> (16 + 4 * j)) & 15;      // my limb's steps
+    // The three outward passes read their slot rows in EVERY step, also where a lane's limb has no body (its chain starts later or
+    // has ended): such a lane reads the nearest body of its own limb -- the step clamped to the limb's range -- computes on it and
+    // stores nothing.  Its running state is garbage then, which nobody sees: a limb's own chains are contiguous in the schedule, the
+    // running state is rewritten where a chain starts, and another lane fetches a running state only in the step right after its
+    // owner worked on the parent body (dw_quad_model.h).  (The loads were conditional before, onto registers zeroed in every step: 16
+    // moves per step and pass.)
+    auto own_step = [&](int s) { return s < first_j ? first_j : (s > last_j ? last_j : s); };
 
     // the mass scale of the second (welded) inertial record of my sole body: requested here, consumed by the inward pass (the
     // record itself sits in the hot tables)
@@ -262,38 +270,22 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
             // (both halves of a limb walk it: every lane reads its slot row before any lane overwrites it)
-            F4 in = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (b >= 0) in = OQ_LD(s, 0, X.pos);            // {q, qd, tt, dd}
+            const F4 in = OQ_LD(own_step(s), 0, X.pos);            // {q, qd, tt, dd}
             if ((startmask >> s) & 1) {          /*@prob:0.27*/
-                // limbs that start below another lane's body fetch that lane's running state (still in its registers)
-                float fq[4], fx[3], fv[6];
-                bool fetched = false;
+                // limbs that start below another lane's body take that lane's running state (still in its registers), limbs that
+                // start at the base the base's: selects, no branches
                 const int fm = H.fmask[s];
                 if (fm) {          /*@prob:0.33*/
                     for (int xl = 0; xl < 4; ++xl)          /*@trip:1*/
                         if ((fm >> xl) & 1) {
-                            float tq[4], tx[3], tv[6];
-                            quad_bcast_arr(xl, qr, tq); quad_bcast_arr(xl, xr_, tx); quad_bcast_arr(xl, vr, tv);
-                            if (b >= 0 && psrc == 2 + xl) {
-                                fetched = true;
-                                DQ_UNROLL for (int i = 0; i < 4; ++i) fq[i] = tq[i];
-                                DQ_UNROLL for (int i = 0; i < 3; ++i) fx[i] = tx[i];
-                                DQ_UNROLL for (int i = 0; i < 6; ++i) fv[i] = tv[i];
-                            }
+                            const bool take = b >= 0 && psrc == 2 + xl;
+                            quad_take_arr(xl, take, qr); quad_take_arr(xl, take, Rr); quad_take_arr(xl, take, xr_); quad_take_arr(xl, take, vr);
                         }
                 }
-                if (b >= 0) {
-                    if (psrc == 1) {
-                        DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = qn[i];
-                        DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = R0k[i];
-                        DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = 0.0f; vr[i] = ww[i]; vr[3 + i] = vo[i]; }
-                    } else if (fetched) {
-                        DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fq[i];
-                        quat_to_mat(qr, Rr);
-                        DQ_UNROLL for (int i = 0; i < 3; ++i) xr_[i] = fx[i];
-                        DQ_UNROLL for (int i = 0; i < 6; ++i) vr[i] = fv[i];
-                    }
-                }
+                const bool fb = b >= 0 && psrc == 1;
+                DQ_UNROLL for (int i = 0; i < 4; ++i) qr[i] = fb ? qn[i] : qr[i];
+                DQ_UNROLL for (int i = 0; i < 9; ++i) Rr[i] = fb ? R0k[i] : Rr[i];
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { xr_[i] = fb ? 0.0f : xr_[i]; vr[i] = fb ? ww[i] : vr[i]; vr[3 + i] = fb ? vo[i] : vr[3 + i]; }
             }
             wave_sync();
             fk_body(s, rc, in);
@@ -432,7 +424,6 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #define OQ_TICK() ((void)0)
 #define OQ_TOCK(acc) ((void)0)
 #endif
-    const int first_j = (f2i(H.base[14]) >> (4 * j)) & 15, last_j = (f2i(H.base[14]) >> (16 + 4 * j)) & 15;      // my limb's steps
 #if defined(OCT_ABL_INWARD)
     DQ_ROLLED for (int s = 0; s < 0; s += 2) {
 #else
@@ -751,24 +742,20 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         DQ_ROLLED for (int s = 0; s < T; ++s) {          /*@trip:11*/
             const int bits = f2i(H.fk[s][j][3]);
             const int b = (bits & 255) == 255 ? -1 : (bits & 255), psrc = (bits >> 8) & 15;
-            F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
-            if (b >= 0) { s0 = OQ_LD(s, 0, X.pos); s1 = OQ_LD(s, 1, X.pos); s2 = OQ_LD(s, 2, X.pos); s3 = OQ_LD(s, 3, X.pos); OQ_KEEP1(s3); }
+            const int so = own_step(s);
+            F4 s0 = OQ_LD(so, 0, X.pos), s1 = OQ_LD(so, 1, X.pos), s2 = OQ_LD(so, 2, X.pos), s3 = OQ_LD(so, 3, X.pos);
+            OQ_KEEP1(s3);
             if ((startmask >> s) & 1) {          /*@prob:0.27*/
-                float fa[6], fv[6];
-                bool fetched = false;
                 const int fm = H.fmask[s];
                 if (fm) {          /*@prob:0.33*/
                     for (int xl = 0; xl < 4; ++xl)          /*@trip:1*/
                         if ((fm >> xl) & 1) {
-                            float ta[6], tv[6];
-                            quad_bcast_arr(xl, ar, ta); quad_bcast_arr(xl, vr, tv);
-                            if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) { fa[i] = ta[i]; fv[i] = tv[i]; } }
+                            const bool take = b >= 0 && psrc == 2 + xl;
+                            quad_take_arr(xl, take, ar); quad_take_arr(xl, take, vr);
                         }
                 }
-                if (b >= 0) {
-                    if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = a0[i]; ar[3 + i] = a0[3 + i]; vr[i] = ww[i]; vr[3 + i] = vo[i]; } }
-                    else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] = fa[i]; vr[i] = fv[i]; } }
-                }
+                const bool fb = b >= 0 && psrc == 1;
+                DQ_UNROLL for (int i = 0; i < 3; ++i) { ar[i] = fb ? a0[i] : ar[i]; ar[3 + i] = fb ? a0[3 + i] : ar[3 + i]; vr[i] = fb ? ww[i] : vr[i]; vr[3 + i] = fb ? vo[i] : vr[3 + i]; }
             }
             wave_sync();
             {
@@ -1102,24 +1089,17 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         DQ_ROLLED for (int s = 0; s < T; ++s) {          /*@trip:11*/
             const FkHot rc = fk_hot(H, s, j);
             const int b = rc.body, psrc = rc.psrc;
-            F4 s0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
-            if (b >= 0) { s0 = OQ_LD(s, 0, X.pos); s1 = OQ_LD(s, 1, X.pos); s2 = OQ_LD(s, 2, X.pos); s3 = OQ_LD(s, 3, X.pos); OQ_KEEP1(s3); }
+            const int so = own_step(s);
+            F4 s0 = OQ_LD(so, 0, X.pos), s1 = OQ_LD(so, 1, X.pos), s2 = OQ_LD(so, 2, X.pos), s3 = OQ_LD(so, 3, X.pos);
+            OQ_KEEP1(s3);
             if ((startmask >> s) & 1) {          /*@prob:0.27*/
-                float fa[6];
-                bool fetched = false;
                 const int fm = H.fmask[s];
                 if (fm) {          /*@prob:0.33*/
                     for (int xl = 0; xl < 4; ++xl)          /*@trip:1*/
-                        if ((fm >> xl) & 1) {
-                            float ta[6];
-                            quad_bcast_arr(xl, ar, ta);
-                            if (b >= 0 && psrc == 2 + xl) { fetched = true; DQ_UNROLL for (int i = 0; i < 6; ++i) fa[i] = ta[i]; }
-                        }
+                        if ((fm >> xl) & 1) quad_take_arr(xl, b >= 0 && psrc == 2 + xl, ar);
                 }
-                if (b >= 0) {
-                    if (psrc == 1) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = dqb[i]; }
-                    else if (fetched) { DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fa[i]; }
-                }
+                const bool fb = b >= 0 && psrc == 1;
+                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] = fb ? dqb[i] : ar[i];
             }
             wave_sync();
             {

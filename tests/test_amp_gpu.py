@@ -555,7 +555,7 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
         cfg["env"].update({"episodeLength": 40, "pdControl": pd_control, "numAMPObsSteps": 3})
         if plain:          # no encoder / observation noise, no command ramp, no randomisation: the entry points then get no draws at all
             cfg["task"]["noise"], cfg["task"]["randomize"], cfg["env"]["velChange"] = False, False, False
-        cfg["sim"]["mi355"] = {"amp_fused": fused, "amp_hist_ring": not plain}
+        cfg["sim"]["mi355"] = dict({"amp_fused": fused}, **({"amp_hist_ring": not plain} if fused else {}))          # (the rings exist with the fused step only)
         envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
     a, b = envs
     assert a._hist_ring == (not plain) and not b._hist_ring

@@ -165,11 +165,13 @@ def main():
         for j in range(a, b + 1):
             w[j] *= t
     # forward conditional branches
+    big = []
     for k, (op, loc, text) in enumerate(ins):
         if op.startswith('s_cbranch'):
             tgt = text.split()[-1]
             if tgt in labels and labels[tgt] > k:
                 p = probs.get(key(loc))
+                big.append((k, labels[tgt], loc, p, op))
                 if p is not None:
                     used_probs[key(loc)] += 1
                     for j in range(k + 1, labels[tgt]):
@@ -206,6 +208,12 @@ def main():
             c = per_phase[name]
             print('  %-28s %8.0f  %s' % (name, sum(c[x] for x in vk), ' '.join('%7.0f' % c[x] for x in vk)) +
                   ' %7.0f %7.0f %7.0f' % (c['lds'], c['vmem'], sum(c[x] for x in c if x.startswith('s'))))
+    if '--branches' in sys.argv:
+        print('  forward branches over >= 25 VALU (untagged = assumed taken):')
+        for k, t, loc, p, op in big:
+            nv = sum(1 for j in range(k + 1, t) if ins[j][0].startswith('v_'))
+            if nv >= 25:
+                print('    %5d..%5d  %-18s static VALU %4d  weight %.2f  at %s  prob %s' % (k, t, op, nv, w[k], loc, p))
     if unknown_loops:
         print('  loops without a trip count (counted once):')
         for h, k, loc in unknown_loops:
