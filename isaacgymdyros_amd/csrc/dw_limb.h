@@ -210,6 +210,34 @@ DQ_HD void rigid_inertia(int nin, const float *com0, float m0, const float *I0, 
     DQ_UNROLL for (int i = 0; i < 3; ++i) ho[i] = hy[i] + mass * x[i];
     *mass_out = mass;
 }
+// The same from records PREPARED on the host (dw_quad_model.h, the hot tables' in / in1 records): hm = mass * com and
+// A6 = I + mass (|com|^2 1 - com com') (xx yy zz xy xz yz), the body-frame inertia about the body origin at mass scale 1.  Both are
+// linear in the mass scale, so a record costs 10 multiplications here instead of the 34 operations of forming them per env and substep.
+DQ_HD void rigid_inertia_pre(int nin, const float *hm0, float m0, const float *A60, float ms0, const float *hm1, float m1, const float *A61,
+                             float ms1, const float *R, const float *x, float *Ao, float *ho, float *mass_out) {
+    float A6[6], h[3], mass = ms0 * m0;
+    DQ_UNROLL for (int i = 0; i < 6; ++i) A6[i] = ms0 * A60[i];
+    DQ_UNROLL for (int i = 0; i < 3; ++i) h[i] = ms0 * hm0[i];
+    if (nin > 1) {
+        DQ_UNROLL for (int i = 0; i < 6; ++i) A6[i] += ms1 * A61[i];
+        DQ_UNROLL for (int i = 0; i < 3; ++i) h[i] += ms1 * hm1[i];
+        mass += ms1 * m1;
+    }
+    const float A[9] = {A6[0], A6[3], A6[4], A6[3], A6[1], A6[5], A6[4], A6[5], A6[2]};
+    float T[9], hy[3];
+    dw::m3m(R, A, T);
+    m3v(R, h, hy);
+    const float xx = dot3(x, x), xh = dot3(x, hy);
+    int o = 0;
+    DQ_UNROLL for (int r3 = 0; r3 < 3; ++r3)
+        DQ_UNROLL for (int c3 = r3; c3 < 3; ++c3) {
+            float v = T[3 * r3] * R[3 * c3] + T[3 * r3 + 1] * R[3 * c3 + 1] + T[3 * r3 + 2] * R[3 * c3 + 2];
+            v += (r3 == c3 ? mass * xx + 2.0f * xh : 0.0f) - mass * x[r3] * x[c3] - (x[r3] * hy[c3] + hy[r3] * x[c3]);
+            Ao[o++] = v;
+        }
+    DQ_UNROLL for (int i = 0; i < 3; ++i) ho[i] = hy[i] + mass * x[i];
+    *mass_out = mass;
+}
 DQ_HD float ao(const float *Ao, int r, int c) {      // symmetric 3x3 from 6 words
     return Ao[r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : (c == 0 ? r : (c == 1 ? 2 + r : 5))];
 }

@@ -27,9 +27,36 @@ using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
 using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
-using dwq::geom_force; using dwq::rigid_inertia; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
+using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
 
+// Index type of the per-env streams.  Every buffer of the table is addressed as uniform base + 32-bit element index, which the
+// compiler turns into the scalar-base + 32-bit vector-offset form of the global instructions (no 64-bit address arithmetic in the
+// vector pipe: 522 such instructions in the listing of round 4).  The largest stream is obs_buf, 1 948 B per env: the byte offset fits
+// 32 bits up to 2.2 M envs per GPU; config.validate_cfg / dw_create refuse more than 2^20.
+#if defined(OQ_IX64)
+using OQ_IX = size_t;
+#else
+using OQ_IX = unsigned int;
+#endif
+// element i of a stream: the BYTE offset is formed in 32 bits and added to the (wave-uniform) base, which is what selects the
+// scalar-base form `global_load v, v_offset, s[base:base+1]`; indexing a pointer with a 32-bit integer does not (the scaling by the
+// element size is done after the extension to 64 bits: v_lshl_add_u64 / v_mad_u64_u32, the latter at a quarter of the issue rate)
+// oq_at(base, i, k): element i + k with k a compile-time constant: the constant goes into the instruction's immediate offset (added to
+// i in 32 bits it would not: unsigned addition may wrap, so the compiler has to keep a separate offset register per element).
+template <class T> DQ_HD T *oq_ptr(T *base, OQ_IX i) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (OQ_IX)(i * (OQ_IX)sizeof(T))); }
+template <class T> DQ_HD const T *oq_ptr(const T *base, OQ_IX i) { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (OQ_IX)(i * (OQ_IX)sizeof(T))); }
+template <class T> DQ_HD T &oq_at(T *base, OQ_IX i, int k = 0) { return oq_ptr(base, i)[k]; }
+template <class T> DQ_HD const T &oq_at(const T *base, OQ_IX i, int k = 0) { return oq_ptr(base, i)[k]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> DQ_HD T DW_GPTR *oq_ptr(T DW_GPTR *base, OQ_IX i) { return (T DW_GPTR *)((char DW_GPTR *)base + (OQ_IX)(i * (OQ_IX)sizeof(T))); }
+template <class T> DQ_HD const T DW_GPTR *oq_ptr(const T DW_GPTR *base, OQ_IX i) { return (const T DW_GPTR *)((const char DW_GPTR *)base + (OQ_IX)(i * (OQ_IX)sizeof(T))); }
+template <class T> DQ_HD T DW_GPTR &oq_at(T DW_GPTR *base, OQ_IX i, int k = 0) { return oq_ptr(base, i)[k]; }
+template <class T> DQ_HD const T DW_GPTR &oq_at(const T DW_GPTR *base, OQ_IX i, int k = 0) { return oq_ptr(base, i)[k]; }
+#endif
+// env index x row stride: both below 2^24 (num_envs <= 2^20), so the product is ONE full-rate v_mul_u32_u24 / v_mad_u32_u24 (a
+// 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+DQ_HD OQ_IX oq_row(int stride, int env) { return ((OQ_IX)stride & 0xffffffu) * ((OQ_IX)env & 0xffffffu); }
 constexpr int LPE = 8;               // lanes per env
 constexpr int EPO = 64 / LPE;        // envs per wavefront
 #if !defined(OCT_WPG)
@@ -196,7 +223,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_STAMP(B, SB + 0);
     const int e = X.env;
     const bool wr = X.valid && X.h == 0;          // global side effects: half 0 only (half 1 mirrors it)
-    const float *mscale_e = B.mass_scale + (size_t)DW_NUM_BODIES * e;
+    const OQ_IX ms_row = oq_row(DW_NUM_BODIES, e);          // my env's row of mass_scale
     const int first_j = (f2i(H.base[14]) >> (4 * j)) & 15, last_j = (f2i(H.base[14]) >> (16 + 4 * j)) & 15;      // my limb's steps
     // The three outward passes read their slot rows in EVERY step, also where a lane's limb has no body (its chain starts later or
     // has ended): such a lane reads the nearest body of its own limb -- the step clamped to the limb's range -- computes on it and
@@ -208,7 +235,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 
     // the mass scale of the second (welded) inertial record of my sole body: requested here, consumed by the inward pass (the
     // record itself sits in the hot tables)
-    const float ms1 = mscale_e[f2i(H.in1[j & 1][10])];
+    const float ms1 = oq_at(B.mass_scale, ms_row + f2i(H.in1[j & 1][10]));
     if (TERRAIN) X.zbound = dw::terrain_bound(P, X.root[0], X.root[1]);          // (requested here, first used in the inward pass)
     // @phase fk
     // ---- base kinematics (every lane of the quad, redundantly) ----
@@ -304,7 +331,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     bool sc_any = false;
     // (the wrenches of my own proxies, found by the resolution, wait for the inward pass in global memory: touching pairs are
     //  rare, and 25 registers held through the inward pass for them are what the two-waves-per-SIMD budget cannot afford)
-    float *park = P.sc_park + ((size_t)X.wave * 64 + X.lane) * SC_PARK_WORDS;
+    float *park = P.sc_park + ((size_t)X.wave * 64 + X.lane) * SC_PARK_WORDS;          // (touched only when some env of the wave has a touching pair)
     const int npair = (H.misc[3] >> 8) & 255;
     auto proxy_bits = [&](int p) { return f2i(H.prox[p][7]); };
     auto proxy_ends = [&](int p, float *p0w, float *p1w) {       // end points of proxy p in the common frame, from its body's slot
@@ -415,7 +442,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     struct BodyMap { float Ao[6], ho[3], mass, pv[6], S[6], cb[6], tt, dd, qd; };       // 31 words
     auto step_clamped = [&](int s) { return s < T ? s : T - 1; };
     // the one per-env global value a map needs (the mass scale of the body's Gym body) is requested a round ahead
-    float ms_next = mscale_e[(f2i(H.in[step_clamped(X.h)][j][2]) >> 24) & 255];
+    float ms_next = oq_at(B.mass_scale, ms_row + ((f2i(H.in[step_clamped(X.h)][j][2]) >> 24) & 255));
 #if defined(DQ_STAMPS) && defined(__HIPCC__)
     long long tq_map = 0, tq_rec = 0, tq_t0 = 0;
 #define OQ_TICK() (tq_t0 = (long long)__builtin_readcyclecounter())
@@ -443,7 +470,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             const int nin = (bits >> 12) & 3, ngym = (bits >> 14) & 3, ngeom = (bits >> 16) & 15, scm = (bits >> 24) & 255;
             const int gymbits = f2i(h0.z);
             const float ms0 = ms_next;
-            ms_next = mscale_e[(f2i(H.in[step_clamped(s + 2 + X.h)][j][2]) >> 24) & 255];
+            ms_next = oq_at(B.mass_scale, ms_row + ((f2i(H.in[step_clamped(s + 2 + X.h)][j][2]) >> 24) & 255));
             // (the slot rows are requested together with the table record, not after it: a lane that idles in this step reads the
             //  nearest body of its own limb instead -- the step index clamped to the limb's range -- and nothing is done with it)
             int som = T - 1 - s - X.h;
@@ -459,15 +486,14 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             m3v(R, axis, Mb.S);
             cross3(x, Mb.S, Mb.S + 3);
             {
-                const float com0[3] = {h1.x, h1.y, h1.z}, I0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
-                if (nin > 1) {          // the two sole bodies carry a second (welded) inertial record
-                    const F4 *ir = reinterpret_cast<const F4 *>(H.in1[j & 1]);
-                    const F4 i0 = ldp(ir[0]), i1 = ldp(ir[1]), i2 = ldp(ir[2]);
-                    const float com1[3] = {i0.x, i0.y, i0.z}, I1[6] = {i1.x, i1.y, i1.z, i1.w, i2.x, i2.y};
-                    rigid_inertia(2, com0, h1.w, I0, ms0, com1, i0.w, I1, ms1, R, x, Mb.Ao, Mb.ho, &Mb.mass);
-                } else {
-                    rigid_inertia(1, com0, h1.w, I0, ms0, com0, 0.0f, I0, 0.0f, R, x, Mb.Ao, Mb.ho, &Mb.mass);
-                }
+                // (the records arrive prepared: mass * com, mass, inertia about the body origin -- dw_quad_model.h prepared_inertia.
+                //  The two sole bodies carry a second, welded record; it is read by every lane -- three LDS reads -- so that there is ONE
+                //  copy of the rotation code below, and added by the lanes that have it)
+                const float hm0[3] = {h1.x, h1.y, h1.z}, A0[6] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y};
+                const F4 *ir = reinterpret_cast<const F4 *>(H.in1[j & 1]);
+                const F4 i0 = ldp(ir[0]), i1 = ldp(ir[1]), i2 = ldp(ir[2]);
+                const float hm1[3] = {i0.x, i0.y, i0.z}, A1[6] = {i1.x, i1.y, i1.z, i1.w, i2.x, i2.y};
+                rigid_inertia_pre(nin, hm0, h1.w, A0, ms0, hm1, i0.w, A1, ms1, R, x, Mb.Ao, Mb.ho, &Mb.mass);
             }
             rigid_bias(Mb.Ao, Mb.ho, Mb.mass, v, Mb.pv);
             {
@@ -519,8 +545,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                             else {
                                 if (over_1n(cf[t])) X.coll = 1;
                                 if (X.valid) {
-                                    float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + gy) * 3;
-                                    dst[0] = cf[t][0]; dst[1] = cf[t][1]; dst[2] = cf[t][2];
+                                    const OQ_IX dst = (oq_row(DW_NUM_BODIES, e) + gy) * 3;
+                                    oq_at(B.contact_forces, dst, 0) = cf[t][0]; oq_at(B.contact_forces, dst, 1) = cf[t][1]; oq_at(B.contact_forces, dst, 2) = cf[t][2];
                                 }
                             }
                         }
@@ -655,7 +681,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
         float Ao[6], ho[3], mass;
         const int base_gym = f2i(H.base[10]), base_ngeom = f2i(H.base[11]);
-        const float ms = mscale_e[base_gym];
+        const float ms = oq_at(B.mass_scale, ms_row + base_gym);
         {
             const float bI[6] = {H.base[4], H.base[5], H.base[6], H.base[7], H.base[8], H.base[9]};
             rigid_inertia(1, bcom, H.base[3], bI, ms, bcom, 0.0f, bI, 0.0f, R0, x0, Ao, ho, &mass);
@@ -678,8 +704,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         if (last && j == 3) {
             if (over_1n(cfb)) X.coll = 1;
             if (wr) {
-                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + base_gym) * 3;
-                dst[0] = cfb[0]; dst[1] = cfb[1]; dst[2] = cfb[2];
+                const OQ_IX dst = (oq_row(DW_NUM_BODIES, e) + base_gym) * 3;
+                oq_at(B.contact_forces, dst, 0) = cfb[0]; oq_at(B.contact_forces, dst, 1) = cfb[1]; oq_at(B.contact_forces, dst, 2) = cfb[2];
             }
         }
         {   // push on the base COM
@@ -732,8 +758,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = 0.0f;
     wave_sync_global();          // (also: the previous substep of this launch stored the impulses)
     if (B.env_state) {           // (dw_simulate may run without a task record: the solve then starts from zero)
-        const float *wsrc = B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * (j & 1);
-        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = wsrc[i];
+        const OQ_IX wsrc = oq_row(DW_ES_WORDS, e) + DW_ES_WARM + 12 * (j & 1);
+        DQ_UNROLL for (int i = 0; i < 12; ++i) warm[i] = oq_at(B.env_state, wsrc, i);
     }
     // ---- outward pass 2: accelerations; free joint velocities qdf = qd + dt qdd into the slot (lean / chain-start forms as in
     //      pass 1) ----
@@ -1065,20 +1091,20 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         if (last && part == 0) {
             DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i] + Fs[i] * inv_dt;
             if (wr) {
-                float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
-                dst[0] = X.footT[0]; dst[1] = X.footT[1]; dst[2] = X.footT[2];
+                const OQ_IX dst = (oq_row(DW_NUM_BODIES, e) + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+                oq_at(B.contact_forces, dst, 0) = X.footT[0]; oq_at(B.contact_forces, dst, 1) = X.footT[1]; oq_at(B.contact_forces, dst, 2) = X.footT[2];
             }
         }
     } else if (last && part == 0) {
         DQ_UNROLL for (int i = 0; i < 3; ++i) X.footT[i] = X.footF[i];
         if (wr) {
-            float *dst = B.contact_forces + ((size_t)DW_NUM_BODIES * e + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
-            dst[0] = X.footF[0]; dst[1] = X.footF[1]; dst[2] = X.footF[2];
+            const OQ_IX dst = (oq_row(DW_NUM_BODIES, e) + (f == 0 ? M.left_foot_gym : M.right_foot_gym)) * 3;
+            oq_at(B.contact_forces, dst, 0) = X.footF[0]; oq_at(B.contact_forces, dst, 1) = X.footF[1]; oq_at(B.contact_forces, dst, 2) = X.footF[2];
         }
     }
     if (wr && j < 2 && B.env_state) {
-        float *wdst = B.env_state + (size_t)DW_ES_WORDS * e + DW_ES_WARM + 12 * j;
-        DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) wdst[3 * k + i] = Pk[k][i];
+        const OQ_IX wdst = oq_row(DW_ES_WORDS, e) + DW_ES_WARM + 12 * j;
+        DQ_UNROLL for (int k = 0; k < 4; ++k) DQ_UNROLL for (int i = 0; i < 3; ++i) oq_at(B.env_state, wdst, 3 * k + i) = Pk[k][i];
     }
 
     DQ_STAMP(B, SB + 11);
@@ -1159,7 +1185,7 @@ DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, 
     X.valid = eg < num_envs;
     X.env = X.valid ? eg : num_envs - 1;
     X.pos = pcode(H, X.el, X.j);
-    DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = B.root_states[(size_t)13 * X.env + i];
+    DQ_UNROLL for (int i = 0; i < 13; ++i) X.root[i] = oq_at(B.root_states, oq_row(13, X.env), i);
     X.mu = friction * OQ_COLD(friction_scale)[X.env];
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     X.stamp_base = 0;
@@ -1207,26 +1233,26 @@ DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel
     float qkeep[ONI];
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = joint_item(H, wave_index, num_envs, X.lane, k);
-        const size_t g = (size_t)ND * it.env + it.d;
-        const float q = B.dof_state[g * 2], qd = B.dof_state[g * 2 + 1];
-        const float damp = B.dof_damping[g], arm = B.dof_armature[g];
+        const OQ_IX g = oq_row(ND, it.env) + it.d;
+        const float q = oq_at(B.dof_state, g * 2, 0), qd = oq_at(B.dof_state, g * 2, 1);
+        const float damp = oq_at(B.dof_damping, g), arm = oq_at(B.dof_armature, g);
         qkeep[k] = q;
-        if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, it.pos) = mk4(q, qd, tau[g] - damp * qd, arm + P.dt * damp);
+        if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, it.pos) = mk4(q, qd, oq_at(tau, g) - damp * qd, arm + P.dt * damp);
     }
     wave_sync();
-    oct_substep<TERRAIN>(L, H, QM, M, P, X, B, push ? push[2 * e] : 0.0f, push ? push[2 * e + 1] : 0.0f, true);
+    oct_substep<TERRAIN>(L, H, QM, M, P, X, B, push ? oq_at(push, 2 * (OQ_IX)e, 0) : 0.0f, push ? oq_at(push, 2 * (OQ_IX)e, 1) : 0.0f, true);
     wave_sync();
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = joint_item(H, wave_index, num_envs, X.lane, k);
         float q, qd;
         joint_integrate(L, it, P.dt, qkeep[k], &q, &qd);
         if (it.ok) {
-            const size_t g = (size_t)ND * it.env + it.d;
-            B.dof_state[g * 2] = q; B.dof_state[g * 2 + 1] = qd;
+            const OQ_IX g = oq_row(ND, it.env) + it.d;
+            oq_at(B.dof_state, g * 2, 0) = q; oq_at(B.dof_state, g * 2, 1) = qd;
         }
     }
     if (X.valid && X.h == 0) {
-        if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = X.root[i]; }
+        if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) oq_at(B.root_states, oq_row(13, e), i) = X.root[i]; }
     }
 }
 

@@ -59,7 +59,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     oct_lane_init(X, QM.hot, wave_index, c_num_envs, C.phys, C.friction, B);
     const int e = X.env, f = X.j & 1;
     // (record fields of my env: B.env_state[ES(field)]; no base pointer is held across the phases)
-#define OQ_ES(f) B.env_state[(size_t)DW_ES_WORDS * e + (f)]
+#define OQ_ES(f) oq_at(B.env_state, oq_row(DW_ES_WORDS, e), (f))
     const float r_time = OQ_ES(DW_ES_TIME), r_epi = OQ_ES(DW_ES_EPI_LEN), r_mag = OQ_ES(DW_ES_MAGNITUDE), r_phase = OQ_ES(DW_ES_PHASE);
     const float r_init = OQ_ES(DW_ES_INIT_MOCAP), r_pstart = OQ_ES(DW_ES_PERT_START), r_pon = OQ_ES(DW_ES_PERT_ON), r_pcount = OQ_ES(DW_ES_PERT_COUNT);
     const float r_imp = OQ_ES(DW_ES_IMPULSE), r_dur = OQ_ES(DW_ES_PERT_DURATION), r_ptim = OQ_ES(DW_ES_PERT_TIMING);
@@ -70,8 +70,8 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         const int i = X.lane + 64 * k, ic = i < EPO * DW_NUM_ACT ? i : 0;
         const int el = ic / DW_NUM_ACT, a = ic - DW_NUM_ACT * el;
         const int eg = wave_index * EPO + el, egc = eg < c_num_envs ? eg : c_num_envs - 1;
-        r_act[k] = actions[DW_NUM_ACT * egc + a];
-        r_head[k] = B.env_state[(size_t)DW_ES_WORDS * egc + DW_ES_HIST_HEAD];
+        r_act[k] = oq_at(actions, oq_row(DW_NUM_ACT, egc) + a);
+        r_head[k] = oq_at(B.env_state, oq_row(DW_ES_WORDS, egc), DW_ES_HIST_HEAD);
     }
     auto item = [&](int k) {          // this lane's k-th (env, joint) item; pos is filled in below
         JointItem it;
@@ -90,15 +90,15 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     float rq[ONI], rqd[ONI], rdamp[ONI], rarm[ONI], rms[ONI], rah[ONI], rac[ONI], rkp[ONI], rkv[ONI], rcol[ONI][DW_ALOG_SLOTS - 1];
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const JointItem it = item(k);
-        const size_t g = (size_t)ND * it.env + it.d;
-        const float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
+        const OQ_IX g = oq_row(ND, it.env) + it.d;
+        const OQ_IX ei = oq_row(DW_ES_WORDS, it.env);          // the item's task record
         const int d = it.d, dc = d < 12 ? d : 11;       // (leg-only fields: index clamped rather than a branch)
-        rq[k] = B.dof_state[g * 2]; rqd[k] = B.dof_state[g * 2 + 1];
-        rdamp[k] = B.dof_damping[g]; rarm[k] = B.dof_armature[g];
-        rms[k] = ei[DW_ES_MOTOR_SCALE + dc]; rah[k] = M.action_high[dc];
-        rac[k] = actions[DW_NUM_ACT * it.env + dc];
+        rq[k] = oq_at(B.dof_state, g * 2, 0); rqd[k] = oq_at(B.dof_state, g * 2, 1);
+        rdamp[k] = oq_at(B.dof_damping, g); rarm[k] = oq_at(B.dof_armature, g);
+        rms[k] = oq_at(B.env_state, ei + dc, DW_ES_MOTOR_SCALE); rah[k] = M.action_high[dc];
+        rac[k] = oq_at(actions, oq_row(DW_NUM_ACT, it.env) + dc);
         rkp[k] = M.kp[d]; rkv[k] = M.kv[d];
-        DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) rcol[k][s] = ei[DW_ES_ACTION_LOG + 12 * (s + 1) + dc];
+        DQ_UNROLL for (int s = 0; s < DW_ALOG_SLOTS - 1; ++s) rcol[k][s] = oq_at(B.env_state, ei + dc, DW_ES_ACTION_LOG + 12 * (s + 1));
     }
     stage_hot(HW, QM);
     const QHot &H = HW;
@@ -148,14 +148,16 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         float rt0[ONI], rt1[ONI], rm0[ONI], rm1[ONI];
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             const JointItem it = item(k);
-            const float *row0 = mocap + (size_t)f2i(OQ_ENVW(it.el, EW_MIDX)) * DW_MOCAP_COLS;
-            rt0[k] = row0[0]; rt1[k] = row0[DW_MOCAP_COLS];
-            rm0[k] = row0[1 + it.d]; rm1[k] = row0[DW_MOCAP_COLS + 1 + it.d];
+            const OQ_IX row0 = oq_row(DW_MOCAP_COLS, f2i(OQ_ENVW(it.el, EW_MIDX)));
+            rt0[k] = oq_at(mocap, row0, 0); rt1[k] = oq_at(mocap, row0, DW_MOCAP_COLS);
+            rm0[k] = oq_at(mocap, row0 + it.d, 1); rm1[k] = oq_at(mocap, row0 + it.d, DW_MOCAP_COLS + 1);
         }
         float rtf[6];
         {
-            const float *row0 = mocap + (size_t)f2i(OQ_ENVW(X.el, EW_MIDX)) * DW_MOCAP_COLS, *row1 = row0 + DW_MOCAP_COLS;
-            rtf[0] = row0[0]; rtf[1] = row1[0]; rtf[2] = row0[1 + 33]; rtf[3] = row1[1 + 33]; rtf[4] = row0[1 + 34]; rtf[5] = row1[1 + 34];
+            const OQ_IX row0 = oq_row(DW_MOCAP_COLS, f2i(OQ_ENVW(X.el, EW_MIDX)));
+            constexpr int R1 = DW_MOCAP_COLS;
+            rtf[0] = oq_at(mocap, row0, 0); rtf[1] = oq_at(mocap, row0, R1); rtf[2] = oq_at(mocap, row0, 1 + 33); rtf[3] = oq_at(mocap, row0, R1 + 1 + 33);
+            rtf[4] = oq_at(mocap, row0, 1 + 34); rtf[5] = oq_at(mocap, row0, R1 + 1 + 34);
         }
         float px = 0.0f, py = 0.0f;
         if (X.j == 1) {
@@ -206,8 +208,8 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             float v = fminf(fmaxf(r_act[k], -1.0f), 1.0f);
             if (a == 12) v = (v > 0 ? 1.0f : 0.0f) * v;
             if (i < EPO * DW_NUM_ACT && eg < c_num_envs) {
-                B.action_history[((size_t)eg * DW_HIST_SLOTS + f2i(r_head[k])) * DW_NUM_ACT + a] = v;
-                B.env_state[(size_t)DW_ES_WORDS * eg + DW_ES_ACTIONS + a] = v;
+                oq_at(B.action_history, (oq_row(DW_HIST_SLOTS, eg) + f2i(r_head[k])) * DW_NUM_ACT + a) = v;
+                oq_at(B.env_state, oq_row(DW_ES_WORDS, eg) + a, DW_ES_ACTIONS) = v;
             }
         }
         if (X.j == 0 && wr_env) {
@@ -228,9 +230,9 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             const float target = dw::cubic_t(OQ_ENVW(it.el, EW_LTP), rt0[k], rt1[k], rm0[k], rm1[k]);
             const float atq = d < 12 ? fminf(fmaxf(rac[k], -1.0f), 1.0f) * rms[k] * rah[k] : 0.0f;
             if (it.ok) {
-                float *ei = B.env_state + (size_t)DW_ES_WORDS * it.env;
-                ei[DW_ES_TARGET_QPOS + d] = target;
-                if (d < 12) ei[DW_ES_ACTION_TORQUE + d] = atq;
+                const OQ_IX ei = oq_row(DW_ES_WORDS, it.env);
+                oq_at(B.env_state, ei + d, DW_ES_TARGET_QPOS) = target;
+                if (d < 12) oq_at(B.env_state, ei + d, DW_ES_ACTION_TORQUE) = atq;
             }
             // torque FIFO, column d (tasks/dyros_dynamic_walk.py:511-519): shift, append, pick the delayed slot -- twice, for
             // the two substeps (the action torque of the step is appended both times); the record gets the final column
@@ -247,7 +249,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             // upper body: PD to the mocap target; the second substep forms its own torque from the new state
             const float tau = d < 12 ? t1 : rkp[k] * (target - q) + rkv[k] * (-qd);
             if (KEEP) { tau2k[k] = d < 12 ? t2 : target; dampk[k] = damp; armk[k] = arm; kpk[k] = rkp[k]; kvk[k] = rkv[k]; }
-            else if (it.ok) B.obs_buf[(size_t)DW_NUM_OBS * it.env + PK_TAU2 + d] = d < 12 ? t2 : target;
+            else if (it.ok) oq_at(B.obs_buf, oq_row(DW_NUM_OBS, it.env) + d, PK_TAU2) = d < 12 ? t2 : target;
             if (X.lane + 64 * k < EPO * ND) OQ_SLOT(0, 0, it.pos) = mk4(q, qd, tau - damp * qd, arm + dt * damp);
         }
     }
@@ -275,8 +277,8 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         //      a store under `if (ok)` between two items' loads had made the compiler wait for memory once per item. ----
         JointItem its[ONI];
         OPos ips[ONI];
-        size_t gs[ONI];
-        DQ_UNROLL for (int k = 0; k < ONI; ++k) { its[k] = item(k); ips[k] = OQ_IPOS(its[k]); gs[k] = (size_t)ND * its[k].env + its[k].d; }
+        OQ_IX gs[ONI];
+        DQ_UNROLL for (int k = 0; k < ONI; ++k) { its[k] = item(k); ips[k] = OQ_IPOS(its[k]); gs[k] = oq_row(ND, its[k].env) + its[k].d; }
         F4 fin[ONI];
         float nzw[ONI], rdamp2[ONI], rarm2[ONI], rkp2[ONI], rkv2[ONI], pkv[ONI];
         const int pk_off = sub == 0 ? PK_TAU2 : PK_NZ1;          // obs_buf scratch: the second substep's torque input / its encoder draw
@@ -286,22 +288,22 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             //  step started from and the previous step's encoder reading)
             if (sub == 0) {
                 DQ_UNROLL for (int k = 0; k < ONI; ++k) {
-                    qkeep[k] = B.dof_state[gs[k] * 2]; qdkeep[k] = B.dof_state[gs[k] * 2 + 1];
-                    qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d];
+                    qkeep[k] = oq_at(B.dof_state, gs[k] * 2, 0); qdkeep[k] = oq_at(B.dof_state, gs[k] * 2, 1);
+                    qnprev[k] = oq_at(B.env_state, oq_row(DW_ES_WORDS, its[k].env) + its[k].d, DW_ES_QPOS_PRE);
                 }
             }
             DQ_UNROLL for (int k = 0; k < ONI; ++k) { pkv[k] = sub == 0 ? tau2k[k] : n1k[k]; rdamp2[k] = dampk[k]; rarm2[k] = armk[k]; rkp2[k] = kpk[k]; rkv2[k] = kvk[k]; }
         } else {
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
-            qkeep[k] = B.dof_state[gs[k] * 2]; qdkeep[k] = B.dof_state[gs[k] * 2 + 1];
-            qnprev[k] = B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d];
-            pkv[k] = B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + pk_off + its[k].d];
+            qkeep[k] = oq_at(B.dof_state, gs[k] * 2, 0); qdkeep[k] = oq_at(B.dof_state, gs[k] * 2, 1);
+            qnprev[k] = oq_at(B.env_state, oq_row(DW_ES_WORDS, its[k].env) + its[k].d, DW_ES_QPOS_PRE);
+            pkv[k] = oq_at(B.obs_buf, oq_row(DW_NUM_OBS, its[k].env) + its[k].d + pk_off);
             // damping, armature and the PD gains of the upper body (used after the first substep only; requested in both so that the
             // block has no branch): again from memory rather than held in 20 registers through the first substep
-            rdamp2[k] = B.dof_damping[gs[k]]; rarm2[k] = B.dof_armature[gs[k]]; rkp2[k] = M.kp[its[k].d]; rkv2[k] = M.kv[its[k].d];
+            rdamp2[k] = oq_at(B.dof_damping, gs[k]); rarm2[k] = oq_at(B.dof_armature, gs[k]); rkp2[k] = M.kp[its[k].d]; rkv2[k] = M.kv[its[k].d];
         }
         }
-        if (noise) { DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = noise[(size_t)DW_NOISE_WORDS * its[k].env + DW_NZ_ENC + ND * sub + its[k].d]; }
+        if (noise) { DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = oq_at(noise, oq_row(DW_NOISE_WORDS, its[k].env) + ND * sub + its[k].d, DW_NZ_ENC); }
         static_assert(ONI == 5, "the grouped touch below names five loads");
         OQ_KEEP3(fin[0], fin[1], fin[2]); OQ_KEEP2(fin[3], fin[4]);
         if (sub == 0) DQ_STAMP(B, 34);
@@ -341,12 +343,12 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         DQ_UNROLL for (int k = 0; k < ONI; ++k) {
             if (its[k].ok) {
                 if (KEEP) {          // (dof_state is written once, with the final state; nothing is parked)
-                    if (!c_freeze && sub == 1) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
+                    if (!c_freeze && sub == 1) { oq_at(B.dof_state, gs[k] * 2, 0) = qo[k]; oq_at(B.dof_state, gs[k] * 2, 1) = qdo[k]; }
                 } else {
-                    if (!c_freeze) { B.dof_state[gs[k] * 2] = qo[k]; B.dof_state[gs[k] * 2 + 1] = qdo[k]; }
+                    if (!c_freeze) { oq_at(B.dof_state, gs[k] * 2, 0) = qo[k]; oq_at(B.dof_state, gs[k] * 2, 1) = qdo[k]; }
                     if (sub == 0) {
-                        B.env_state[(size_t)DW_ES_WORDS * its[k].env + DW_ES_QPOS_PRE + its[k].d] = qno[k];
-                        if (!noise) B.obs_buf[(size_t)DW_NUM_OBS * its[k].env + PK_NZ1 + its[k].d] = n1[k];
+                        oq_at(B.env_state, oq_row(DW_ES_WORDS, its[k].env) + its[k].d, DW_ES_QPOS_PRE) = qno[k];
+                        if (!noise) oq_at(B.obs_buf, oq_row(DW_NUM_OBS, its[k].env) + its[k].d, PK_NZ1) = n1[k];
                     }
                 }
             }
@@ -360,7 +362,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     if (X.valid && !c_freeze && X.o == 0) {
         int e2 = e;
         DQ_OPAQUE(e2);            // (the row's address again from the index: held since the loads at the top it is a register pair through both substeps)
-        DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e2 + i] = X.root[i];
+        DQ_UNROLL for (int i = 0; i < 13; ++i) oq_at(B.root_states, oq_row(13, e2), i) = X.root[i];
     }
     DQ_UNROLL for (int k = 0; k < ONI; ++k) KP.qn[k] = qnprev[k];
     DQ_STAMP(B, 40);
@@ -380,14 +382,14 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     DQ_STAMP(B, 41);
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)
     if (X.lane == 0) {
-        OQ_COLD(stacked_rewards)[(size_t)wave_index * EPO * DW_NUM_REW + 14] = (float)((long long)__builtin_readcyclecounter() - dq_t0);
-        OQ_COLD(stacked_rewards)[(size_t)wave_index * EPO * DW_NUM_REW + 13] = (float)(dq_t1 - dq_t0);          // physics part
+        OQ_COLD(stacked_rewards)[(OQ_IX)wave_index * EPO * DW_NUM_REW + 14] = (float)((long long)__builtin_readcyclecounter() - dq_t0);
+        OQ_COLD(stacked_rewards)[(OQ_IX)wave_index * EPO * DW_NUM_REW + 13] = (float)(dq_t1 - dq_t0);          // physics part
         // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID, as exact small integers in two floats of env 2's row
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 1] = (float)(hw & 0xffff);
-        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 2] = (float)(xcc & 0xf);
-        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 3] = (float)(dq_r0 & 0xffffff);      // start time, 100 MHz clock common to the chip (low bits)
-        OQ_COLD(stacked_rewards)[((size_t)wave_index * EPO + 2) * DW_NUM_REW + 4] = (float)((long long)__builtin_amdgcn_s_memrealtime() & 0xffffff);      // end time
+        OQ_COLD(stacked_rewards)[((OQ_IX)wave_index * EPO + 2) * DW_NUM_REW + 1] = (float)(hw & 0xffff);
+        OQ_COLD(stacked_rewards)[((OQ_IX)wave_index * EPO + 2) * DW_NUM_REW + 2] = (float)(xcc & 0xf);
+        OQ_COLD(stacked_rewards)[((OQ_IX)wave_index * EPO + 2) * DW_NUM_REW + 3] = (float)(dq_r0 & 0xffffff);      // start time, 100 MHz clock common to the chip (low bits)
+        OQ_COLD(stacked_rewards)[((OQ_IX)wave_index * EPO + 2) * DW_NUM_REW + 4] = (float)((long long)__builtin_amdgcn_s_memrealtime() & 0xffffff);      // end time
     }
 #endif
 }

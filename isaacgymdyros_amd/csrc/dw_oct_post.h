@@ -19,7 +19,7 @@ namespace dwo {
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)      // (timing experiment, tools/wave_times.py: the post phases of EVERY wave, left in the reward rows of its second env)
 #define DQ_WT_DECL long long dq_wt[14]; int dq_wn = 0
 #define DQ_WT() dq_wt[dq_wn++] = (long long)__builtin_readcyclecounter()
-#define DQ_WT_FLUSH(B, wave_index) do { if (lane == 0) for (int i_ = 1; i_ < dq_wn; ++i_) (B).stacked_rewards[((size_t)(wave_index) * EPO + 1) * DW_NUM_REW + i_] = (float)(dq_wt[i_] - dq_wt[i_ - 1]); } while (0)
+#define DQ_WT_FLUSH(B, wave_index) do { if (lane == 0) for (int i_ = 1; i_ < dq_wn; ++i_) (B).stacked_rewards[((OQ_IX)(wave_index) * EPO + 1) * DW_NUM_REW + i_] = (float)(dq_wt[i_] - dq_wt[i_ - 1]); } while (0)
 #else
 #define DQ_WT_DECL do { } while (0)
 #define DQ_WT() do { } while (0)
@@ -112,11 +112,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     // (the VecTask counters and the clock action of Q1, the per-joint constants of the reset path and the observation's mean /
     //  scale, requested together with the records: one memory latency for all.  The hot tables of the physics are dead by now:
     //  the observation constants go where they were.)
-    const long long q1_progress = OQ_COLD(progress_buf)[e], q1_randomize = OQ_COLD(randomize_buf)[e];
-    const float q1_mass = OQ_COLD(total_mass)[e], q1_clock = dw::clamp_action(actions, e, 12);
+    const long long q1_progress = oq_at(OQ_COLD(progress_buf), (OQ_IX)e), q1_randomize = oq_at(OQ_COLD(randomize_buf), (OQ_IX)e);
+    const float q1_mass = oq_at(OQ_COLD(total_mass), (OQ_IX)e), q1_clock = dw::clamp_action(actions, e, 12);
     const int lj = lane < ND ? lane : 0, lo1 = lane < DW_NUM_OBS1 ? lane : 0;
     const float c_qinit = M.q_init[lj], c_qhi = M.qhi[lj], c_qlo = M.qlo[lj];
-    const float c_org0 = OQ_COLD(env_origins)[3 * e], c_org1 = OQ_COLD(env_origins)[3 * e + 1], c_org2 = OQ_COLD(env_origins)[3 * e + 2];
+    const float c_org0 = oq_at(OQ_COLD(env_origins), 3 * (OQ_IX)e, 0), c_org1 = oq_at(OQ_COLD(env_origins), 3 * (OQ_IX)e, 1), c_org2 = oq_at(OQ_COLD(env_origins), 3 * (OQ_IX)e, 2);
     float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
     const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
     // (nominal damping / armature of the joints whose randomisation words this lane draws at a reset: requested here, with everything else)
@@ -148,7 +148,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         const int nvalid = N - wave_index * EPO;                          // envs of this wave that exist (>= 1)
         const int np_ok = (nvalid >= EPO ? EPO : nvalid) * (DW_ES_WORDS / 4);
         wave_sync_global();           // (the pre-physics phase of this wave wrote fields of these records)
-        const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (size_t)wave_index * EPO * DW_ES_WORDS);
+        const F4 *src = reinterpret_cast<const F4 *>(B.env_state + (OQ_IX)wave_index * EPO * DW_ES_WORDS);
         F4 *dst = reinterpret_cast<F4 *>(LF + PL_ES);
         constexpr int GRP = PER;
         DQ_UNROLL for (int g8 = 0; g8 < PER; g8 += GRP) {
@@ -188,13 +188,13 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     if (C.freeze_physics) {          /*@prob:0*/
         // debug mode: simulate() was the identity, so the net contact forces are an input (dw_task.h step_env)
         if (j == 0) {
-            const float *cf = B.contact_forces + (size_t)DW_NUM_BODIES * 3 * e;
+            const float *cf = B.contact_forces + (OQ_IX)DW_NUM_BODIES * 3 * e;
             DQ_UNROLL for (int i = 0; i < 3; ++i) { PQ_PS(el, PS_FOOT + i) = cf[3 * LFG + i]; PQ_PS(el, PS_FOOT + 3 + i) = cf[3 * RFG + i]; }
         }
         for (int i = lane; i < EPO * DW_NUM_BODIES; i += 64) {
             const int ee = i / DW_NUM_BODIES, g = i - DW_NUM_BODIES * ee;
             const int eg = wave_index * EPO + ee < N ? wave_index * EPO + ee : N - 1;
-            const float *cf = B.contact_forces + ((size_t)DW_NUM_BODIES * eg + g) * 3;
+            const float *cf = B.contact_forces + ((OQ_IX)DW_NUM_BODIES * eg + g) * 3;
             if (g != LFG && g != RFG && norm3_t(gnorm, cf[0], cf[1], cf[2]) > 1.0f) PQ_PSI(ee, PS_COLL) = 1;
         }
     } else {
@@ -216,12 +216,12 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         time = time + C.clock_gain_f * q1_clock;
         PQ_ES(el, DW_ES_TIME) = time;
         if (xvalid) {
-            OQ_COLD(timeout_buf)[e] = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
-            OQ_COLD(progress_buf)[e] = p + 1;
+            oq_at(OQ_COLD(timeout_buf), (OQ_IX)e) = ((float)(p + (C.timeout_fix ? 1 : 0)) >= C.max_episode_length - 1.0f) ? 1 : 0;
+            oq_at(OQ_COLD(progress_buf), (OQ_IX)e) = p + 1;
         }
         PQ_PSI(el, PS_PROGRESS) = (int)(p + 1);
         rb = rb + 1;
-        if (xvalid) OQ_COLD(randomize_buf)[e] = rb;
+        if (xvalid) oq_at(OQ_COLD(randomize_buf), (OQ_IX)e) = rb;
         PQ_PSI(el, PS_RANDOMIZE) = rb;
         bool bad = false;
         DQ_UNROLL for (int i = 0; i < 13; ++i) bad = bad || !dw::finitef(PQ_ROOT(el, i));
@@ -245,7 +245,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
         for (int i = lane; i < EPO * DW_NUM_BODIES * 3; i += 64) {
             const int ee = i / (DW_NUM_BODIES * 3), w = i - DW_NUM_BODIES * 3 * ee, eg = wave_index * EPO + ee;
-            if (eg < N && PQ_PSI(ee, PS_BAD)) B.contact_forces[(size_t)DW_NUM_BODIES * 3 * eg + w] = 0.0f;
+            if (eg < N && PQ_PSI(ee, PS_BAD)) B.contact_forces[(OQ_IX)DW_NUM_BODIES * 3 * eg + w] = 0.0f;
         }
         wave_sync();
     }
@@ -330,8 +330,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         if (xvalid) {
             DQ_UNROLL for (int i = 0; i < 4; ++i) {
                 const int l = 4 * j + i;
-                if (l < 14) OQ_COLD(stacked_rewards)[(size_t)DW_NUM_REW * e + l] = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
-                if (l == 14) OQ_COLD(stacked_rewards)[(size_t)DW_NUM_REW * e + 14] = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
+                if (l < 14) oq_at(OQ_COLD(stacked_rewards), oq_row(DW_NUM_REW, e) + l) = collision ? 1.0f * C.death_cost : PQ_PS(el, PS_RTERM + l);
+                if (l == 14) oq_at(OQ_COLD(stacked_rewards), oq_row(DW_NUM_REW, e), 14) = PQ_ESI(el, DW_ES_PERT_START) ? 1.0f : 0.0f;
             }
         }
         if (j == 0) {
@@ -343,7 +343,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             if ((float)PQ_PSI(el, PS_PROGRESS) >= C.max_episode_length - 1.0f) reset = 1;
             if (collision) reset = 1;
             if (PQ_PSI(el, PS_BAD)) reset = 1;
-            if (xvalid) { OQ_COLD(rew_buf)[e] = total; OQ_COLD(reset_buf)[e] = reset; }
+            if (xvalid) { oq_at(OQ_COLD(rew_buf), (OQ_IX)e) = total; oq_at(OQ_COLD(reset_buf), (OQ_IX)e) = reset; }
             PQ_PSI(el, PS_RESET) = reset;
             float ret = PQ_ES(el, DW_ES_EPI_RETURN) + total;
             if (reset) {
@@ -377,7 +377,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             } else if (lvl < 0) lvl = 0;
             long long ty = OQ_COLD(terrain_types)[e];
             ty = ty < 0 ? 0 : (ty > C.terrain_num_types - 1 ? C.terrain_num_types - 1 : ty);
-            const float DW_GPTR *org = OQ_COLD(terrain_origins) + ((size_t)lvl * C.terrain_num_types + ty) * 3;
+            const float DW_GPTR *org = OQ_COLD(terrain_origins) + ((OQ_IX)lvl * C.terrain_num_types + ty) * 3;
             DQ_UNROLL for (int i = 0; i < 3; ++i) { const float o = org[i]; PQ_PS(el, PS_ORG + i) = o; if (xvalid) OQ_COLD(env_origins)[3 * e + i] = o; }
             if (xvalid) OQ_COLD(terrain_levels)[e] = lvl;
         }
@@ -435,7 +435,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
                     const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
                     const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
                     const float sd = d0 + u[p2][i] * d1, sa = a0 + u[p2][i] * a1;
-                    if (go && xvalid && C.dr_dof && (isd || isa)) (isa ? B.dof_armature : B.dof_damping)[(size_t)ND * e + l] = isa ? dr_nom[p2][i] * sa : dr_nom[p2][i] + sd;
+                    if (go && xvalid && C.dr_dof && (isd || isa)) oq_at(isa ? B.dof_armature : B.dof_damping, oq_row(ND, e) + l) = isa ? dr_nom[p2][i] * sa : dr_nom[p2][i] + sd;
                     if (go && xvalid && C.dr_friction && w == DW_NZ_DR_FRIC) OQ_COLD(friction_scale)[e] = f0 + u[p2][i] * f1;
                 }
             }
@@ -474,7 +474,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             constexpr int NAL = DW_ALOG_SLOTS * 12, NAH = DW_HIST_SLOTS * DW_NUM_ACT / 4;
             DQ_UNROLL for (int i = 0; i < (NAL + 7) / 8; ++i) { if (j + 8 * i < NAL) PQ_ES(el, DW_ES_ACTION_LOG + j + 8 * i) = 0.0f; }
             if (xvalid) {
-                F4 *ah = reinterpret_cast<F4 *>(B.action_history + (size_t)e * DW_HIST_SLOTS * DW_NUM_ACT);
+                F4 *ah = reinterpret_cast<F4 *>(&oq_at(B.action_history, oq_row(DW_HIST_SLOTS * DW_NUM_ACT, e)));
                 DQ_UNROLL for (int i = 0; i < (NAH + 7) / 8; ++i) { if (j + 8 * i < NAH) ah[j + 8 * i] = mk4(0.0f, 0.0f, 0.0f, 0.0f); }
             }
         }
@@ -510,8 +510,8 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
         const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
         const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
-        ld_row(B.obs_history + ((size_t)eg * DW_HIST_SLOTS + so) * DW_NUM_OBS1, tapo[r]);
-        ld_row(B.action_history + ((size_t)eg * DW_HIST_SLOTS + sa) * DW_NUM_ACT, tapa[r]);
+        ld_row(&oq_at(B.obs_history, (oq_row(DW_HIST_SLOTS, eg) + so) * DW_NUM_OBS1), tapo[r]);
+        ld_row(&oq_at(B.action_history, (oq_row(DW_HIST_SLOTS, eg) + sa) * DW_NUM_ACT), tapa[r]);
     }
     // @phase post_obs
     // ---- Q4: 37-d observation, normalisation, newest history slot.  Items (env, entry), grouped by kind so that each of the
@@ -522,11 +522,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             const float nrm = (o - OBN[l]) / OBN[DW_NUM_OBS1 + l];
             PQ_NORMED(ee, l) = nrm;
             if (egr < N) {
-                float *oh = B.obs_history + (size_t)egr * DW_HIST_SLOTS * DW_NUM_OBS1;
+                const OQ_IX oh = oq_row(DW_HIST_SLOTS * DW_NUM_OBS1, egr);
                 if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {          /*@prob:0.18*/
-                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2)          /*@trip:20*/ oh[s2 * DW_NUM_OBS1 + l] = nrm;
+                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2)          /*@trip:20*/ oq_at(B.obs_history, oh + l, s2 * DW_NUM_OBS1) = nrm;
                 } else {
-                    oh[PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l] = nrm;
+                    oq_at(B.obs_history, oh + PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l) = nrm;
                 }
             }
         };
@@ -575,7 +575,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             const int ee = i / 6, l = 31 + (i - 6 * ee);
             const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
             dw::NoiseSrc nz = K.nz;
-            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+            nz.rec = noise ? noise + (OQ_IX)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
             finish(ee, l, PQ_ROOT(ee, 7 + (l - 31)) + (dw::noise_word(nz, DW_NZ_VEL + (l - 31)) * 0.05f - 0.025f));
         }
     }
@@ -587,7 +587,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     //      reset shows its first observation in every tap and zeros in the action taps, tasks/dyros_dynamic_walk.py:655-669);
     //      the newest tap is copied from LDS, items (env, word). ----
     {
-        float *ob = B.obs_buf + (size_t)wave_index * EPO * DW_NUM_OBS;
+        float *ob = B.obs_buf + (OQ_IX)wave_index * EPO * DW_NUM_OBS;
         DQ_UNROLL for (int r = 0; r < RPL; ++r) {
             const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
             const int ee = pc / NTAP, tap = pc - NTAP * ee;
@@ -654,19 +654,19 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         constexpr int NP = EPO * DW_ES_WORDS / 4, PER = (NP + 63) / 64;
         const int nvalid = N - wave_index * EPO;
         const int np_ok = (nvalid >= EPO ? EPO : nvalid) * (DW_ES_WORDS / 4);
-        F4 *dstg = reinterpret_cast<F4 *>(B.env_state + (size_t)wave_index * EPO * DW_ES_WORDS);
+        F4 *dstg = reinterpret_cast<F4 *>(B.env_state + (OQ_IX)wave_index * EPO * DW_ES_WORDS);
         const F4 *srcl = reinterpret_cast<const F4 *>(LF + PL_ES);
         DQ_UNROLL for (int u = 0; u < PER; ++u) { const int pi = lane + 64 * u; if (pi < np_ok) dstg[pi] = srcl[pi]; }
         const bool changed = PQ_PSI(el, PS_RESET) != 0 || PQ_PSI(el, PS_BAD) != 0;
         if (wave_any(changed)) {          /*@prob:0.18*/
-            if (j == 0 && changed && xvalid) { DQ_UNROLL for (int i = 0; i < 13; ++i) B.root_states[(size_t)13 * e + i] = PQ_ROOT(el, i); }
+            if (j == 0 && changed && xvalid) { DQ_UNROLL for (int i = 0; i < 13; ++i) oq_at(B.root_states, oq_row(13, e), i) = PQ_ROOT(el, i); }
             DQ_UNROLL for (int k = 0; k < ONI; ++k) {
                 const int i = lane + 64 * k;
                 if (i < EPO * ND) {
                     const int ee = i / ND, eg = wave_index * EPO + ee;
                     if (eg < N && (PQ_PSI(ee, PS_RESET) || PQ_PSI(ee, PS_BAD))) {
-                        B.dof_state[((size_t)ND * wave_index * EPO) * 2 + 2 * i] = LF[PL_Q + 2 * i];
-                        B.dof_state[((size_t)ND * wave_index * EPO) * 2 + 2 * i + 1] = LF[PL_Q + 2 * i + 1];
+                        B.dof_state[((OQ_IX)ND * wave_index * EPO) * 2 + 2 * i] = LF[PL_Q + 2 * i];
+                        B.dof_state[((OQ_IX)ND * wave_index * EPO) * 2 + 2 * i + 1] = LF[PL_Q + 2 * i + 1];
                     }
                 }
             }

@@ -59,7 +59,8 @@ struct alignas(16) QInRec {      // inward constants of one (step, lane): 11 x 1
 // per-(step, lane) records and the wave-uniform masks.  Integer fields travel as bit patterns in float words.
 //   fk[s][l]: [0..2] pos, [3] body | psrc << 8 | flags << 12 | proxies << 16, [4..6] axis, [7] vmax, [8] qlo, [9] qhi
 //   in[s][l]: [0] body + 1 | flags << 8 | nin << 12 | ngym << 14 | ngeom << 16 | proxies << 24, [1] gather,
-//             [2] gyms[0] | gyms[1] << 8 | gyms[2] << 16 | in0_gym << 24, [3] bound, [4..6] in0_com, [7] in0_mass, [8..13] in0_I
+//             [2] gyms[0] | gyms[1] << 8 | gyms[2] << 16 | in0_gym << 24, [3] bound, [4..13] the first inertial record PREPARED
+//             (prepared_inertia below: mass * com, mass, inertia about the body origin)
 struct alignas(16) QHot {
     float fk[QS_MAX][4][12];
     float in[QS_MAX][4][16];
@@ -70,7 +71,7 @@ struct alignas(16) QHot {
     unsigned char owner[36];     // per body: lane that owns it (bits 6..7) | its slot CELL in the octet kernels (bits 0..5):
                                  // cell = cellbase[lane] + outward step, so that a limb's bodies lie in schedule order and a chain
                                  // pass addresses them as lane base + compile-time offset (dw_oct.h); base[13] = the four cell bases
-    alignas(16) float in1[2][12];   // second (welded) inertial record of the sole bodies, per leg lane: com[3], mass, I[6], [10] its Gym body (int bits), [11] its inward step (int bits)
+    alignas(16) float in1[2][12];   // second (welded) inertial record of the sole bodies, per leg lane, prepared as in[][4..13]; [10] its Gym body (int bits), [11] its inward step (int bits)
     // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner lane << 16 | index among the
     // owner's proxies << 18.  Detection: proxy p is evaluated by lane p & 3 (its register set p >> 2), and the pairs are
     // tested in PASSES: pass c broadcasts proxy b = combo[c][0] & 255 to the quad and every lane whose bit is set in
@@ -106,6 +107,16 @@ static inline void quat_of_rot(const float *R, float *q) {     // row-major rota
     else if (m11 > m22) { double s = __builtin_sqrt(1.0 + m11 - m00 - m22) * 2; w = (m02 - m20) / s; x = (m01 + m10) / s; y = 0.25 * s; z = (m12 + m21) / s; }
     else { double s = __builtin_sqrt(1.0 + m22 - m00 - m11) * 2; w = (m10 - m01) / s; x = (m02 + m20) / s; y = (m12 + m21) / s; z = 0.25 * s; }
     q[0] = (float)x; q[1] = (float)y; q[2] = (float)z; q[3] = (float)w;
+}
+
+// An inertial record as the inward pass wants it (dw_limb.h rigid_inertia_pre): out[0..2] = mass * com, [3] = mass, [4..9] = the inertia
+// about the BODY ORIGIN in body axes, I + mass (|com|^2 1 - com com'), in the order xx yy zz xy xz yz -- formed once here, in double.
+static inline void prepared_inertia(const float *com, float mass, const float *I6, float *out) {
+    const double c[3] = {com[0], com[1], com[2]}, m = mass, cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    for (int i = 0; i < 3; ++i) out[i] = (float)(m * c[i]);
+    out[3] = mass;
+    out[4] = (float)(I6[0] + m * (cc - c[0] * c[0])); out[5] = (float)(I6[1] + m * (cc - c[1] * c[1])); out[6] = (float)(I6[2] + m * (cc - c[2] * c[2]));
+    out[7] = (float)(I6[3] - m * c[0] * c[1]); out[8] = (float)(I6[4] - m * c[0] * c[2]); out[9] = (float)(I6[5] - m * c[1] * c[2]);
 }
 
 // Builds the schedule and the constant tables.  Returns 0 or DW_EINVAL with a message.
@@ -433,9 +444,7 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
                 p[1] = fi(n.body >= 0 ? n.gather : 0);
                 p[2] = fi((n.gyms[0] & 255) | ((n.gyms[1] & 255) << 8) | ((n.gyms[2] & 255) << 16) | ((n.in0_gym & 255) << 24));
                 p[3] = n.bound;
-                for (int i = 0; i < 3; ++i) p[4 + i] = n.in0_com[i];
-                p[7] = n.in0_mass;
-                for (int i = 0; i < 6; ++i) p[8 + i] = n.in0_I[i];
+                prepared_inertia(n.in0_com, n.in0_mass, n.in0_I, p + 4);
                 if (n.body >= 0 && n.gather) H.gany[s2] |= 1;
             }
         for (int s2 = 0; s2 < QS_MAX; ++s2) H.gany[s2] |= acc_step[s2] << 8;
@@ -480,9 +489,7 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
             int s2k = 0;
             for (int s2 = 0; s2 < Q->nsteps; ++s2) if (Q->in[s2][l].body >= 0 && Q->in[s2][l].nin > 1) s2k = s2;
             const QInRec &n = Q->in[s2k][l];
-            for (int i = 0; i < 3; ++i) H.in1[l][i] = n.in1_com[i];
-            H.in1[l][3] = n.in1_mass;
-            for (int i = 0; i < 6; ++i) H.in1[l][4 + i] = n.in1_I[i];
+            prepared_inertia(n.in1_com, n.in1_mass, n.in1_I, H.in1[l]);
             H.in1[l][10] = fi(n.in1_gym >= 0 && n.in1_gym < DW_NUM_BODIES ? n.in1_gym : 0);
             H.in1[l][11] = fi(s2k);
         }
