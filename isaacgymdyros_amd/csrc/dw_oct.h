@@ -25,7 +25,7 @@ namespace dwo {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
@@ -54,6 +54,14 @@ template <class T> DQ_HD const T DW_GPTR *oq_ptr(const T DW_GPTR *base, OQ_IX i)
 template <class T> DQ_HD T DW_GPTR &oq_at(T DW_GPTR *base, OQ_IX i, int k = 0) { return oq_ptr(base, i)[k]; }
 template <class T> DQ_HD const T DW_GPTR &oq_at(const T DW_GPTR *base, OQ_IX i, int k = 0) { return oq_ptr(base, i)[k]; }
 #endif
+// i / D for a small non-negative item index (0 <= i < LIMIT): one full-rate 24-bit multiply and a shift instead of the compiler's
+// v_mul_hi (quarter rate) sequence for a signed division by a constant.  M = ceil(2^16 / D); exact while i * (M D - 2^16) < 2^16
+// (checked at compile time for LIMIT).
+template <int D, int LIMIT = 1024> DQ_HD int oq_div(int i) {
+    constexpr unsigned M = (65536u + D - 1) / D;
+    static_assert((unsigned long long)(LIMIT - 1) * (M * D - 65536u) < 65536ull && (unsigned long long)(LIMIT - 1) * M < (1ull << 32), "oq_div: LIMIT too large for this divisor");
+    return (int)((((unsigned)i & 0xffffffu) * M) >> 16);
+}
 // env index x row stride: both below 2^24 (num_envs <= 2^20), so the product is ONE full-rate v_mul_u32_u24 / v_mad_u32_u24 (a
 // 32-bit v_mul_lo_u32 issues at a quarter of the rate)
 DQ_HD OQ_IX oq_row(int stride, int env) { return ((OQ_IX)stride & 0xffffffu) * ((OQ_IX)env & 0xffffffu); }
@@ -984,7 +992,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 DQ_UNROLL for (int i = 0; i < 3; ++i) { lam[i] += t[i]; lam[3 + i] += pw[i]; }
             }
             float lv[6];
-            DQ_UNROLL for (int i = 0; i < 6; ++i) { const float lo = quad_xor1(lam[i]); lv[i] = X.h ? lo : lam[i]; }
+            DQ_UNROLL for (int i = 0; i < 6; ++i) lv[i] = quad_xor1_hi(lam[i]);          // (half 1: the other foot's wrench)
             DQ_UNROLL for (int r = 0; r < 3; ++r) {
                 float acc = 0.0f;
                 DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wg[r][c] * lv[c];
@@ -1000,10 +1008,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         for (int it = 0; it < P.iters; ++it) {          /*@trip:5*/
             DQ_UNROLL for (int kk = 0; kk < 4; ++kk) {
                 if (pair_on[kk]) {
-                    float o3[3];
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) o3[i] = quad_xor2(tw3[i]);
+                    // (the foot's twist: angular rows in the part-0 lane of the pair, linear rows in the part-1 lane)
                     float wv[3], lv[3];
-                    DQ_UNROLL for (int i = 0; i < 3; ++i) { wv[i] = part ? o3[i] : tw3[i]; lv[i] = part ? tw3[i] : o3[i]; }
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) { wv[i] = quad_pair_lo(tw3[i]); lv[i] = quad_pair_hi(tw3[i]); }
                     const float *r = rk[kk];
                     float vwld[3] = {lv[0] + wv[1] * r[2] - wv[2] * r[1], lv[1] + wv[2] * r[0] - wv[0] * r[2], lv[2] + wv[0] * r[1] - wv[1] * r[0]};
                     float vx0 = vwld[0], vy0 = vwld[1], vz = vwld[2];
@@ -1038,7 +1045,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     float lam[6], lmv[6];
                     cross3(r, d, lam);
                     lam[3] = d[0]; lam[4] = d[1]; lam[5] = d[2];
-                    DQ_UNROLL for (int i = 0; i < 6; ++i) { const float lo = quad_xor1(lam[i]); lmv[i] = X.h ? lo : lam[i]; }
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) lmv[i] = quad_xor1_hi(lam[i]);
                     DQ_UNROLL for (int rr = 0; rr < 3; ++rr) {
                         float acc = 0.0f;
                         DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wg[rr][c] * lmv[c];
@@ -1202,7 +1209,7 @@ struct JointItem { int ok, el, d, b, env; OPos pos; };
 DQ_HD JointItem joint_item(const QHot &H, int wave_index, int num_envs, int lane, int k) {
     JointItem it;
     const int i = lane + 64 * k;
-    it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
+    it.el = oq_div<ND>(i); it.d = i - ND * it.el; it.b = it.d + 1;
     const int eg = wave_index * EPO + it.el;
     it.ok = (i < EPO * ND) && (eg < num_envs);
     if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }

@@ -68,7 +68,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     float r_act[NAI], r_head[NAI];
     DQ_UNROLL for (int k = 0; k < NAI; ++k) {
         const int i = X.lane + 64 * k, ic = i < EPO * DW_NUM_ACT ? i : 0;
-        const int el = ic / DW_NUM_ACT, a = ic - DW_NUM_ACT * el;
+        const int el = oq_div<DW_NUM_ACT>(ic), a = ic - DW_NUM_ACT * el;
         const int eg = wave_index * EPO + el, egc = eg < c_num_envs ? eg : c_num_envs - 1;
         r_act[k] = oq_at(actions, oq_row(DW_NUM_ACT, egc) + a);
         r_head[k] = oq_at(B.env_state, oq_row(DW_ES_WORDS, egc), DW_ES_HIST_HEAD);
@@ -77,7 +77,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         JointItem it;
         int i = X.lane + 64 * k;
         DQ_OPAQUE(i);                 // (recomputed at every use: five sets of derived indices held across the physics cost 20 registers)
-        it.el = i / ND; it.d = i - ND * it.el; it.b = it.d + 1;
+        it.el = oq_div<ND>(i); it.d = i - ND * it.el; it.b = it.d + 1;
         const int eg = wave_index * EPO + it.el;
         it.ok = (i < EPO * ND) && (eg < c_num_envs);
         if (!(i < EPO * ND)) { it.el = 0; it.d = 0; it.b = 1; }
@@ -203,7 +203,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         // ---- actions: clamp, the record, the newest slot of the action ring; items (env, action) ----
         DQ_UNROLL for (int k = 0; k < NAI; ++k) {
             const int i = X.lane + 64 * k;
-            const int el = i / DW_NUM_ACT, a = i - DW_NUM_ACT * el;
+            const int el = oq_div<DW_NUM_ACT>(i), a = i - DW_NUM_ACT * el;
             const int eg = wave_index * EPO + el;
             float v = fminf(fmaxf(r_act[k], -1.0f), 1.0f);
             if (a == 12) v = (v > 0 ? 1.0f : 0.0f) * v;

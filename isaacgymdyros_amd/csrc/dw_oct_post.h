@@ -156,7 +156,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             DQ_UNROLL for (int u = 0; u < GRP; ++u) {
                 const int pi = lane + 64 * (g8 + u);
                 // (pieces of envs past the end mirror the last env's record; nothing of theirs is stored)
-                const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + pi % (DW_ES_WORDS / 4);
+                const int ps = pi < np_ok ? pi : (np_ok - (DW_ES_WORDS / 4)) + (pi - (DW_ES_WORDS / 4) * oq_div<DW_ES_WORDS / 4>(pi));
                 const F4 v = src[pi < NP ? ps : 0];
                 tx[u] = v.x; ty[u] = v.y; tz[u] = v.z; tw[u] = v.w;
             }
@@ -170,7 +170,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
         if (i < EPO * ND) {
-            const int ee = i / ND, d = i - ND * ee;
+            const int ee = oq_div<ND>(i), d = i - ND * ee;
             const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
             PQ_ES(ee, DW_ES_QPOS_NOISE + d) = KP.qn[k];
             PQ_ES(ee, DW_ES_QPOS_PRE + d) = KP.qn[k];
@@ -229,7 +229,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     }
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
-        if (i < EPO * ND && (!dw::finitef(LF[PL_Q + 2 * i]) || !dw::finitef(LF[PL_Q + 2 * i + 1]))) PQ_PSI(i / ND, PS_BAD) = 1;
+        if (i < EPO * ND && (!dw::finitef(LF[PL_Q + 2 * i]) || !dw::finitef(LF[PL_Q + 2 * i + 1]))) PQ_PSI(oq_div<ND>(i), PS_BAD) = 1;
     }
     wave_sync();
     if (wave_any(PQ_PSI(el, PS_BAD) != 0)) {          /*@prob:0*/
@@ -506,10 +506,12 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     float tapo[RPL][DW_NUM_OBS1], tapa[RPL][DW_NUM_ACT];
     DQ_UNROLL for (int r = 0; r < RPL; ++r) {
         const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
-        const int ee = pc / NTAP, tap = pc - NTAP * ee;
+        const int ee = oq_div<NTAP>(pc), tap = pc - NTAP * ee;
         const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
-        const int head = (PQ_ESI(ee, DW_ES_HIST_HEAD) + 1) % DW_HIST_SLOTS;
-        const int so = (head + DW_NUM_SKIP * (tap + 1) - 1) % DW_HIST_SLOTS, sa = (head + DW_NUM_SKIP * (tap + 1)) % DW_HIST_SLOTS;
+        // (ring slots: the head lies in [0, DW_HIST_SLOTS), the sums below in [0, 2 DW_HIST_SLOTS]: a compare and subtract, not a division)
+        auto wrap = [](int x) { return x >= 2 * DW_HIST_SLOTS ? x - 2 * DW_HIST_SLOTS : (x >= DW_HIST_SLOTS ? x - DW_HIST_SLOTS : x); };
+        const int head = wrap(PQ_ESI(ee, DW_ES_HIST_HEAD) + 1);
+        const int so = wrap(head + DW_NUM_SKIP * (tap + 1) - 1), sa = wrap(head + DW_NUM_SKIP * (tap + 1));
         ld_row(&oq_at(B.obs_history, (oq_row(DW_HIST_SLOTS, eg) + so) * DW_NUM_OBS1), tapo[r]);
         ld_row(&oq_at(B.action_history, (oq_row(DW_HIST_SLOTS, eg) + sa) * DW_NUM_ACT), tapa[r]);
     }
@@ -532,7 +534,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         };
         // joint angles / rates of the legs with their biases, target velocity: 26 plain entries per env
         for (int i = lane; i < EPO * 26; i += 64) {
-            const int ee = i / 26, t = i - 26 * ee;
+            const int ee = oq_div<26>(i), t = i - 26 * ee;
             const int l = t < 24 ? 3 + t : 29 + (t - 24);
             float o;
             if (l < 15) o = PQ_ES(ee, DW_ES_QPOS_NOISE + (l - 3)) + PQ_ES(ee, DW_ES_QPOS_BIAS + (l - 3));
@@ -542,7 +544,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
         // Euler angles of the base (quat2euler / mat2euler, python/isaacgym/torch_utils.py:227-273): 3 per env
         if (lane < EPO * 3) {
-            const int ee = lane / 3, l = lane - 3 * ee;
+            const int ee = oq_div<3>(lane), l = lane - 3 * ee;
             const float x = PQ_ROOT(ee, 3), y = PQ_ROOT(ee, 4), z = PQ_ROOT(ee, 5), w = PQ_ROOT(ee, 6);
             const float m00 = w * w + x * x - y * y - z * z;
             const float m01 = 2 * x * y - 2 * w * z;
@@ -572,7 +574,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
         // base velocity with its noise draw: 6 per env
         for (int i = lane; i < EPO * 6; i += 64) {
-            const int ee = i / 6, l = 31 + (i - 6 * ee);
+            const int ee = oq_div<6>(i), l = 31 + (i - 6 * ee);
             const int egr = wave_index * EPO + ee, eg = egr < N ? egr : N - 1;
             dw::NoiseSrc nz = K.nz;
             nz.rec = noise ? noise + (OQ_IX)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
@@ -590,7 +592,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         float *ob = B.obs_buf + (OQ_IX)wave_index * EPO * DW_NUM_OBS;
         DQ_UNROLL for (int r = 0; r < RPL; ++r) {
             const int p = lane + 64 * r, pc = p < NPAIR ? p : 0;
-            const int ee = pc / NTAP, tap = pc - NTAP * ee;
+            const int ee = oq_div<NTAP>(pc), tap = pc - NTAP * ee;
             const bool ok = p < NPAIR && wave_index * EPO + ee < N;
             const bool fill = PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f, rs = PQ_PSI(ee, PS_RESET) != 0;
             if (wave_any(fill)) {          /*@prob:0.18*/
@@ -610,7 +612,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         DQ_UNROLL for (int u = 0; u < (EPO * DW_NUM_OBS1 + 63) / 64; ++u) {
             const int i = lane + 64 * u;
             if (i < EPO * DW_NUM_OBS1) {
-                const int ee = i / DW_NUM_OBS1, k = i - DW_NUM_OBS1 * ee;
+                const int ee = oq_div<DW_NUM_OBS1>(i), k = i - DW_NUM_OBS1 * ee;
                 if (wave_index * EPO + ee < N) ob[ee * DW_NUM_OBS + NTAP * DW_NUM_OBS1 + k] = PQ_NORMED(ee, k);
             }
         }
@@ -622,7 +624,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
         const int i = lane + 64 * k;
         if (i < EPO * ND) {
-            const int ee = i / ND, l = i - ND * ee;
+            const int ee = oq_div<ND>(i), l = i - ND * ee;
             PQ_ES(ee, DW_ES_PRE_QVEL + l) = PQ_QD(ee, l);
             if (l < 12) PQ_ES(ee, DW_ES_ACTION_TORQUE_PRE + l) = PQ_ES(ee, DW_ES_ACTION_TORQUE + l);
             if (l < DW_NUM_ACT) PQ_ES(ee, DW_ES_ACTIONS_PRE + l) = PQ_ES(ee, DW_ES_ACTIONS + l);
@@ -663,7 +665,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             DQ_UNROLL for (int k = 0; k < ONI; ++k) {
                 const int i = lane + 64 * k;
                 if (i < EPO * ND) {
-                    const int ee = i / ND, eg = wave_index * EPO + ee;
+                    const int ee = oq_div<ND>(i), eg = wave_index * EPO + ee;
                     if (eg < N && (PQ_PSI(ee, PS_RESET) || PQ_PSI(ee, PS_BAD))) {
                         B.dof_state[((OQ_IX)ND * wave_index * EPO) * 2 + 2 * i] = LF[PL_Q + 2 * i];
                         B.dof_state[((OQ_IX)ND * wave_index * EPO) * 2 + 2 * i + 1] = LF[PL_Q + 2 * i + 1];

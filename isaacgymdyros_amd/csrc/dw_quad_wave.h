@@ -12,6 +12,7 @@
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   oct_xor4(x)            value of x in lane (l ^ 4)  (octet kernels)           (row_shl:4 / row_shr:4, complementary bank masks)
 //   oct_lo(x) / oct_hi(x)  value of x in lane (l & ~4) / (l | 4) (octet kernels) (row_shr:4 into the high quads / row_shl:4 into the low quads)
+//   quad_xor1_hi / quad_pair_lo / quad_pair_hi: one-move forms of `cond ? exchanged : own` (below)
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
 //   wave_ballot(p)         64-bit mask of p over the lanes, the same in every lane (v_cmp into an SGPR pair)
 //   wave_sync_global()     as wave_sync, for global memory too (workgroup-scope release / acquire).
@@ -64,6 +65,15 @@ DQ_HD float oct_hi(float x) {
     const int xi = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x104, 0xF, 0x5, false));
 }
+// selections that a lane-dependent `cond ? exchanged : own` would spend a move AND a select on, as ONE move:
+//   quad_xor1_hi(x)   half-1 lanes (l & 4) take x of lane l ^ 1, half-0 lanes keep their own (bank mask: the high quads of a row)
+//   quad_pair_lo(x)   x of the lane (l & ~2) of my pair {l, l ^ 2};  quad_pair_hi(x): of the lane (l | 2)
+DQ_HD float quad_xor1_hi(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 1 | (0 << 2) | (3 << 4) | (2 << 6), 0xF, 0xA, false));
+}
+DQ_HD float quad_pair_lo(float x) { return dpp_quad<0 | (1 << 2) | (0 << 4) | (1 << 6)>(x); }
+DQ_HD float quad_pair_hi(float x) { return dpp_quad<2 | (3 << 2) | (2 << 4) | (3 << 6)>(x); }
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
 DQ_HD void wave_sync() {
@@ -236,6 +246,9 @@ DQ_HD float quad_xor2(float x) { return emu_xchg(x, g_emu->cur ^ 2); }
 DQ_HD float oct_xor4(float x) { return emu_xchg(x, g_emu->cur ^ 4); }
 DQ_HD float oct_lo(float x) { return emu_xchg(x, g_emu->cur & ~4); }
 DQ_HD float oct_hi(float x) { return emu_xchg(x, g_emu->cur | 4); }
+DQ_HD float quad_xor1_hi(float x) { return emu_xchg(x, (g_emu->cur & 4) ? (g_emu->cur ^ 1) : g_emu->cur); }
+DQ_HD float quad_pair_lo(float x) { return emu_xchg(x, g_emu->cur & ~2); }
+DQ_HD float quad_pair_hi(float x) { return emu_xchg(x, g_emu->cur | 2); }
 DQ_HD bool wave_any(bool p) {
     WaveEmu *e = g_emu;
     const int l = e->cur, par = (int)(e->nsync[l] & 1);
