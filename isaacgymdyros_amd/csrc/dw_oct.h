@@ -25,7 +25,7 @@ namespace dwo {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
@@ -365,17 +365,40 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #endif
         DQ_STAMP(B, 51);
         int hits = 0;
-        for (int k0 = 0; k0 < npair; k0 += LPE) {  /*@trip:4*/ // (wave-uniform trip count; a lane past the last pair tests pair 0 again)
-            const int pid = k0 + X.o, pidc = pid < npair ? pid : 0;
-            const int pr = (H.pairs[pidc >> 2] >> (8 * (pidc & 3))) & 255, pa = pr & 15, pbx = pr >> 4;
-            float a0[3], a1[3], b0[3], b1[3];
-            proxy_ends(pa, a0, a1);
-            proxy_ends(pbx, b0, b1);
-            const float da[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]}, db[3] = {b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2]};
-            const float rv[3] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2]};
-            const float rr = H.prox[pa][3] + H.prox[pbx][3];
-            // conservative: the least distance of the axes (the force uses the blended points, never closer), 0.2 % slack
-            if (pid < npair && seg_dist2_fast(da, db, rv) < 1.004f * rr * rr) hits |= 1 << pid;
+        {
+            // the axes, built ONCE per proxy: octet lane o has proxy o (class 0) and proxy o + 8 (class 1) -- origin point and direction in
+            // the common frame, from the proxy's body slot.  (Until round 5 every pair test rebuilt both of its proxies: 64 builds for 15.)
+            const int nprox = H.misc[2] & 255;
+            float E[2][6];
+            DQ_UNROLL for (int c = 0; c < 2; ++c) {
+                const int pp = X.o + 8 * c, p = pp < nprox ? pp : nprox - 1;          // (a lane past the last proxy builds the last one again; nobody fetches it)
+                const F4 *pr = reinterpret_cast<const F4 *>(H.prox[p]);
+                F4 c0 = ldp(pr[0]), c1 = ldp(pr[1]);
+                const OPos posp = icode(H, X.el, f2i(c1.w) & 255);
+                F4 q4 = OQ_LD(0, 0, posp), x4 = OQ_LD(0, 1, posp);
+                OQ_KEEP2(c0, x4);
+                const float qb[4] = {q4.x, q4.y, q4.z, q4.w}, l0[3] = {c0.x, c0.y, c0.z}, dl[3] = {c1.x - c0.x, c1.y - c0.y, c1.z - c0.z};
+                float Rb[9], t0[3];
+                quat_to_mat(qb, Rb);
+                m3v(Rb, l0, t0);
+                m3v(Rb, dl, &E[c][3]);
+                E[c][0] = x4.x + t0[0]; E[c][1] = x4.y + t0[1]; E[c][2] = x4.z + t0[2];
+            }
+            // the rounds: lane o tests pair scround[r][o], the axes fetched from the lanes that built them (conservative: the least
+            // distance of the axes against a threshold rounded up; the force uses the blended points, never closer)
+            const int nr0 = (H.misc[2] >> 8) & 15, nr1 = (H.misc[2] >> 12) & 15, nr2 = (H.misc[2] >> 16) & 15;
+            auto round = [&](int r, const float (&Ea)[6], const float (&Eb)[6]) {
+                const int w = H.scround[r][X.o];
+                const int la = w & 7, lb = (w >> 3) & 7, pid = (w >> 6) & 127;
+                float a[6], b[6];
+                DQ_UNROLL for (int i = 0; i < 6; ++i) { a[i] = oct_fetch(Ea[i], la); b[i] = oct_fetch(Eb[i], lb); }
+                const float rv[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+                if (pid != 127 && seg_dist2_fast(&a[3], &b[3], rv) < half_bits_to_float((w >> 16) & 0xffff)) hits |= 1 << pid;
+            };
+            int r = 0;
+            for (int k = 0; k < nr0; ++k, ++r) round(r, E[0], E[0]);          /*@trip:2*/
+            for (int k = 0; k < nr1; ++k, ++r) round(r, E[1], E[1]);          /*@trip:2*/
+            for (int k = 0; k < nr2; ++k, ++r) round(r, E[1], E[0]);          /*@trip:1*/
         }
         {   // the env's mask: OR over the octet (bit patterns through the DPP moves)
             int m = hits;

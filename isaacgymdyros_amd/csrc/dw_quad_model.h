@@ -28,7 +28,7 @@ namespace dwq {
 constexpr int EPW = 16;          // environments per wavefront
 constexpr int QS_MAX = 11;       // schedule length bound (TOCABI needs 11; every step costs 448 B of LDS)
 constexpr int QMAX_PROX = 16;    // self-collision proxies
-constexpr int QMAX_COMBO = 16;   // detection passes (see QHot::combo)
+constexpr int QMAX_ROUNDS = 8;   // detection rounds of the octet kernels (see QHot::scround): 8 pairs each
 constexpr int QMAX_OWN = 4;      // proxies on the bodies of one lane (TOCABI: 4 per leg, torso + 3 on the left arm's lane, 3 on the right arm's)
 constexpr int QMAX_GEOM = 6;     // ground primitives per moving body the inward step handles
 constexpr int QMAX_GYM = 3;      // Gym bodies welded into one moving body
@@ -67,19 +67,21 @@ struct alignas(16) QHot {
     float base[16];              // [0..2] com, [3] mass, [4..9] I, [10] gym, [11] ngeom, [12] bound, [13] cell bases, [14] first / last step per lane, [15] steps in which a chain starts
     int   fmask[QS_MAX];         // outward step s: bit X set = some lane fetches lane X's running state
     int   gany[QS_MAX];          // inward step s: bit 0 some lane gathers; bits 8.. accumulation (valid | source lane << 1 | destination lane << 3)
-    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies, [3] detection passes | pairs << 8, [4..7] pairs of lane l
+    int   misc[8];               // [0] nsteps, [1] base_gather, [2] number of proxies | detection rounds per class << 8 (scround), [3] pairs << 8, [4..7] pairs of lane l
     unsigned char owner[36];     // per body: lane that owns it (bits 6..7) | its slot CELL in the octet kernels (bits 0..5):
                                  // cell = cellbase[lane] + outward step, so that a limb's bodies lie in schedule order and a chain
                                  // pass addresses them as lane base + compile-time offset (dw_oct.h); base[13] = the four cell bases
     alignas(16) float in1[2][12];   // second (welded) inertial record of the sole bodies, per leg lane, prepared as in[][4..13]; [10] its Gym body (int bits), [11] its inward step (int bits)
     // self-collision proxies: [0..2] p0, [3] radius, [4..6] p1, [7] body | gym << 8 | owner lane << 16 | index among the
-    // owner's proxies << 18.  Detection: proxy p is evaluated by lane p & 3 (its register set p >> 2), and the pairs are
-    // tested in PASSES: pass c broadcasts proxy b = combo[c][0] & 255 to the quad and every lane whose bit is set in
-    // (combo[c][0] >> (8 + 4 r)) & 15 tests its proxy of register set r against it; combo[c][1 + r] holds the four lanes'
-    // pair ids (one byte each) for the hit mask.  pairs: byte k = proxies of pair k (a | b << 4); misc[4 + l]: the pairs lane
-    // l resolves (one of the two proxies sits on one of its bodies).
+    // owner's proxies << 18.  pairs: byte k = proxies of pair k (a | b << 4); misc[4 + l]: the pairs lane l resolves (one of the
+    // two proxies sits on one of its bodies).
+    // Detection (dw_oct.h): octet lane o builds the axes of proxies o (class 0) and o + 8 (class 1) once; the pairs are then tested
+    // in ROUNDS of eight, one pair per octet lane, the two axes fetched from the lanes that built them.  A round's pairs all have
+    // the same classes (a, b) -- (0,0), then (1,1), then (1,0); misc[2] = nprox | n00 << 8 | n11 << 12 | n10 << 16 -- so that the
+    // fetches name fixed registers.  scround[r][o] = lane of a | lane of b << 3 | pair id << 6 (127: none) | threshold << 16, the
+    // threshold 1.004 (ra + rb)^2 as a half-precision number rounded UP (detection is conservative; the force is exact).
     alignas(16) float prox[QMAX_PROX][8];
-    int   combo[QMAX_COMBO][5];
+    int   scround[QMAX_ROUNDS][8];
     int   pairs[8];
 };
 
@@ -396,24 +398,38 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         Q->in[T - 1 - step_of[pb]][l].sc_mask |= 1 << k;
         if (add_gym(pb, d->sc_proxy[p2].gym) < 0) { *err = "quad model: proxy Gym body does not fit"; return DW_EINVAL; }
     }
-    // detection passes: one per broadcast proxy b; word 0 = b | lanes of register set r << (8 + 4 r), words 1 + r = the four
-    // lanes' pair ids of register set r (one byte each)
-    int ncombo = 0;
-    int combo[QMAX_COMBO][5];
-    for (int k = 0; k < d->num_sc_pairs; ++k) {
-        const int a = d->sc_pair[k][0], b2 = d->sc_pair[k][1];
-        const int lane = a & 3, reg = a >> 2;
-        int c = -1;
-        for (int i = 0; i < ncombo; ++i) if ((combo[i][0] & 255) == b2) c = i;
-        if (c < 0) {
-            if (ncombo >= QMAX_COMBO) { *err = "quad model: self-collision pairs need more detection passes than QMAX_COMBO"; return DW_EINVAL; }
-            c = ncombo++;
-            combo[c][0] = b2;
-            for (int i = 1; i < 5; ++i) combo[c][i] = 0;
+    // detection rounds of the octet kernels (QHot::scround)
+    int scround[QMAX_ROUNDS][8];
+    int nround_class[3] = {0, 0, 0};
+    {
+        auto half_up = [](float v) -> int {      // smallest half-precision number >= v (v positive and in half's normal range), as its 16 bits
+            unsigned int u; memcpy(&u, &v, 4);
+            const int e = (int)((u >> 23) & 255) - 127 + 15;
+            unsigned int m = (u & 0x7fffffu);
+            unsigned int h = ((unsigned int)e << 10) | (m >> 13);
+            if (m & 0x1fffu) h += 1;            // (a carry into the exponent is the next binade: still the smallest half above v)
+            return (int)(h & 0xffffu);
+        };
+        for (int r = 0; r < QMAX_ROUNDS; ++r) for (int o = 0; o < 8; ++o) scround[r][o] = 127 << 6;
+        int r0 = 0;
+        for (int cls = 0; cls < 3; ++cls) {      // (class of a, class of b) = (0,0), (1,1), (1,0)
+            int n = 0;
+            for (int k = 0; k < d->num_sc_pairs; ++k) {
+                int a = d->sc_pair[k][0], b2 = d->sc_pair[k][1];
+                if ((a >> 3) < (b2 >> 3)) { const int t = a; a = b2; b2 = t; }
+                const int c = (a >> 3) == (b2 >> 3) ? (a >> 3) : 2;
+                if (c != cls) continue;
+                const int r = r0 + n / 8, o = n % 8;
+                if (r >= QMAX_ROUNDS) { *err = "quad model: self-collision pairs need more detection rounds than QMAX_ROUNDS"; return DW_EINVAL; }
+                const float rr = d->sc_proxy[a].radius + d->sc_proxy[b2].radius, thr = 1.004f * rr * rr;
+                if (!(thr > 1e-4f && thr < 6.0e4f)) { *err = "quad model: self-collision radii outside the range of the detection threshold"; return DW_EINVAL; }
+                scround[r][o] = (a & 7) | ((b2 & 7) << 3) | (k << 6) | (half_up(thr) << 16);
+                n += 1;
+            }
+            nround_class[cls] = (n + 7) / 8;
+            r0 += nround_class[cls];
         }
-        if ((combo[c][0] >> (8 + 4 * reg + lane)) & 1) { *err = "quad model: two pairs of one detection pass on the same lane"; return DW_EINVAL; }
-        combo[c][0] |= 1 << (8 + 4 * reg + lane);
-        combo[c][1 + reg] |= k << (8 * lane);
+        if (d->num_sc_pairs > 64 || Q->nprox > 16) { *err = "quad model: more than 64 self-collision pairs or 16 proxies"; return DW_EINVAL; }
     }
     // every Gym body must be reported by exactly one moving body (the kernels write, never accumulate, contact forces)
     for (int b = 1; b < NB; ++b) if (add_gym(b, dm->mv_gym[b]) < 0) { *err = "quad model: Gym body of a moving body does not fit"; return DW_EINVAL; }
@@ -452,7 +468,8 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
         H.base[3] = Q->base_mass;
         for (int i = 0; i < 6; ++i) H.base[4 + i] = Q->base_I[i];
         H.base[10] = fi(Q->base_gym); H.base[11] = fi(Q->base_ngeom); H.base[12] = Q->base_bound;
-        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather; H.misc[2] = Q->nprox; H.misc[3] = ncombo | (Q->npair << 8);
+        H.misc[0] = Q->nsteps; H.misc[1] = Q->base_gather;
+        H.misc[2] = Q->nprox | (nround_class[0] << 8) | (nround_class[1] << 12) | (nround_class[2] << 16); H.misc[3] = Q->npair << 8;
         {
             // slot cells: per lane the bodies in schedule order, one lane after the other (cell 0 = the base's four rows: scratch)
             int first[4] = {QS_MAX, QS_MAX, QS_MAX, QS_MAX}, last[4] = {-1, -1, -1, -1}, count[4] = {0, 0, 0, 0}, cellbase[4] = {0, 0, 0, 0};
@@ -499,7 +516,7 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
             H.prox[p2][3] = cp.radius;
             H.prox[p2][7] = fi((cp.moving & 255) | ((cp.gym & 255) << 8) | ((Q->owner[cp.moving] & 3) << 16) | ((local_of[p2] & 7) << 18));
         }
-        for (int c = 0; c < ncombo; ++c) for (int i = 0; i < 5; ++i) H.combo[c][i] = combo[c][i];
+        for (int r = 0; r < QMAX_ROUNDS; ++r) for (int o = 0; o < 8; ++o) H.scround[r][o] = scround[r][o];
         for (int i = 0; i < 8; ++i) H.pairs[i] = 0;
         for (int i = 4; i < 8; ++i) H.misc[i] = 0;
         for (int k = 0; k < d->num_sc_pairs; ++k) {

@@ -12,6 +12,7 @@
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   oct_xor4(x)            value of x in lane (l ^ 4)  (octet kernels)           (row_shl:4 / row_shr:4, complementary bank masks)
 //   oct_lo(x) / oct_hi(x)  value of x in lane (l & ~4) / (l | 4) (octet kernels) (row_shr:4 into the high quads / row_shl:4 into the low quads)
+//   oct_fetch(x, src)      x of lane (l & ~7) | src of the caller's octet, src per lane (ds_bpermute)
 //   quad_xor1_hi / quad_pair_lo / quad_pair_hi: one-move forms of `cond ? exchanged : own` (below)
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
 //   wave_ballot(p)         64-bit mask of p over the lanes, the same in every lane (v_cmp into an SGPR pair)
@@ -72,6 +73,11 @@ DQ_HD float quad_xor1_hi(float x) {
     const int xi = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 1 | (0 << 2) | (3 << 4) | (2 << 6), 0xF, 0xA, false));
 }
+// x of lane (l & ~7) | src of my octet, src per lane (ds_bpermute: through the LDS crossbar, no memory touched)
+DQ_HD float oct_fetch(float x, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 56u) | (unsigned)src) << 2), __builtin_bit_cast(int, x)));
+}
+DQ_HD float half_bits_to_float(int h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
 DQ_HD float quad_pair_lo(float x) { return dpp_quad<0 | (1 << 2) | (0 << 4) | (1 << 6)>(x); }
 DQ_HD float quad_pair_hi(float x) { return dpp_quad<2 | (3 << 2) | (2 << 4) | (3 << 6)>(x); }
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -247,6 +253,13 @@ DQ_HD float oct_xor4(float x) { return emu_xchg(x, g_emu->cur ^ 4); }
 DQ_HD float oct_lo(float x) { return emu_xchg(x, g_emu->cur & ~4); }
 DQ_HD float oct_hi(float x) { return emu_xchg(x, g_emu->cur | 4); }
 DQ_HD float quad_xor1_hi(float x) { return emu_xchg(x, (g_emu->cur & 4) ? (g_emu->cur ^ 1) : g_emu->cur); }
+DQ_HD float oct_fetch(float x, int src) { return emu_xchg(x, (g_emu->cur & ~7) | src); }
+DQ_HD float half_bits_to_float(int h) {          // (positive normal numbers and zero: all the tables hold)
+    const unsigned int e = ((unsigned int)h >> 10) & 31u, m = (unsigned int)h & 1023u;
+    if (e == 0) return 0.0f;
+    const unsigned int u = ((e - 15u + 127u) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
 DQ_HD float quad_pair_lo(float x) { return emu_xchg(x, g_emu->cur & ~2); }
 DQ_HD float quad_pair_hi(float x) { return emu_xchg(x, g_emu->cur | 2); }
 DQ_HD bool wave_any(bool p) {

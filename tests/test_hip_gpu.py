@@ -507,6 +507,31 @@ def test_self_collision_vs_oracle(task_const, model, wave_build):
     assert np.abs(env.dof_pos.cpu().numpy() - ora.buf["dof_state"][:, :, 0]).max() < 2e-2
 
 
+def test_self_collision_random_poses_vs_oracle(task_const, model, wave_build):
+    """Row f-1 detection on the device (axes built once per proxy, exchanged inside the octet by ds_bpermute, pairs tested in rounds
+    by class against a half-precision threshold rounded up): random poses wide enough that pairs of every class touch; the set of
+    loaded Gym bodies equals the oracle's exhaustive test and the forces agree to 1e-3 relative after one substep."""
+    from hip_backend import make_env
+    from test_kernel_emulation import _random_poses
+    N = 200
+    env = make_env(N, randomize=False, debug_wave_build=wave_build)
+    b = env._buf
+    b["root_states"][:, 0:2] = 0
+    b["root_states"][:, 2] = 3.0
+    b["dof_state"][..., 0] = torch.from_numpy(_random_poses(N, seed=5)).cuda()
+    b["dof_state"][..., 1] = 0
+    ora = _oracle_like(env, task_const)
+    tau = torch.zeros(N, 33)
+    env.simulate(tau.cuda())
+    ora.simulate(tau.numpy())
+    torch.cuda.synchronize()
+    cg, co = env.contact_forces.cpu().numpy(), ora.buf["contact_forces"]
+    lo = np.linalg.norm(co, axis=2) > 1.0
+    assert lo.any(axis=1).sum() > N // 4 and lo.sum() > N // 2
+    assert np.array_equal(np.linalg.norm(cg, axis=2) > 1.0, lo)
+    assert np.abs(cg - co).max() <= 1e-3 * np.abs(co).max()
+
+
 def test_arms_into_torso_vs_oracle(task_const, model, wave_build):
     """Row f-1, second tranche, on the device: arm poses inside the joint limits that press upper arms, forearms and hands
     into the torso, a thigh or the other arm.  Same bars as the leg sweep: forces 1e-3 relative and the same set of loaded

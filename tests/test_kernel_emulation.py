@@ -206,6 +206,45 @@ def test_arms_into_torso_vs_oracle(wave_build):
     assert np.abs(A.buf["dof_state"] - B.buf["dof_state"])[:, :, 1].max() < 2e-2
 
 
+def _random_poses(N, seed=3):
+    """Joint angles drawn wide inside the joint limits: legs, arms and torso interpenetrate somewhere in most envs."""
+    from isaacgymdyros_amd.model import load_model
+    from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
+    m = load_model()
+    lo, hi = np.minimum(m.dof_lower, m.dof_upper), np.maximum(m.dof_lower, m.dof_upper)
+    rng = np.random.default_rng(seed)
+    q0 = np.asarray(INITIAL_DOF_POS, np.float32)
+    q = q0 + rng.uniform(-0.9, 0.9, size=(N, 33)).astype(np.float32)
+    return np.clip(q, lo + 1e-3, hi - 1e-3).astype(np.float32)
+
+
+def test_self_collision_random_poses_touch_every_pair_class(wave_build, model):
+    """Row f-1 detection (dw_oct.h: axes built once per proxy, pairs tested in rounds by class, a half-precision threshold rounded
+    up) must flag every pair the oracle's exhaustive test finds touching: random poses wide enough that leg x leg, arm x torso /
+    arm x arm and arm x thigh pairs all occur; every Gym body the oracle loads is loaded by the kernel body too, forces 1e-3."""
+    N = 96
+    A, B = OracleSim(N), EmulSim(N, debug_wave_build=wave_build)
+    q = _random_poses(N)
+    for s in (A, B):
+        s.buf["root_states"][:, 0:2] = 0
+        s.buf["root_states"][:, 2] = 3.0          # (far above the ground: every contact force is a self-collision)
+        s.buf["dof_state"][:, :, 0] = q
+    tau = np.zeros((N, 33), np.float32)
+    A.simulate(tau); B.simulate(tau)
+    ca, cb = A.buf["contact_forces"], B.buf["contact_forces"]
+    la, lb = np.linalg.norm(ca, axis=2) > 1.0, np.linalg.norm(cb, axis=2) > 1.0
+    names = list(model.body_names)
+    leg = [i for i, n in enumerate(names) if any(k in n for k in ("Thigh", "Knee", "Ankle", "Foot"))]
+    arm = [i for i, n in enumerate(names) if any(k in n for k in ("Armlink", "Forearm", "Wrist2"))]
+    torso = names.index("Upperbody_Link")
+    assert la[:, leg].any(axis=1).sum() > N // 4 and la[:, arm].any(axis=1).sum() > N // 4 and la[:, torso].sum() > N // 8
+    # an arm and a thigh loaded in the same env with no torso / other-arm load: the mixed class (arm x thigh) at work
+    thigh = [names.index("L_Thigh_Link"), names.index("R_Thigh_Link")]
+    assert (la[:, arm].any(axis=1) & la[:, thigh].any(axis=1)).sum() >= 3
+    assert np.array_equal(la, lb)
+    assert np.abs(ca - cb).max() <= 1e-3 * np.abs(ca).max()
+
+
 def _terrain_reset_case(sim, g):
     """All envs at level 1 of the golden's curriculum map; env 3 has walked 6 m from its tile origin (level up), env 5 has
     not moved (level down), env 6 is not in the id list.  Returns the buffers after reset_idx([3, 5])."""
