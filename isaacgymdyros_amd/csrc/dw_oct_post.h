@@ -19,7 +19,7 @@ namespace dwo {
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)      // (timing experiment, tools/wave_times.py: the post phases of EVERY wave, left in the reward rows of its second env)
 #define DQ_WT_DECL long long dq_wt[14]; int dq_wn = 0
 #define DQ_WT() dq_wt[dq_wn++] = (long long)__builtin_readcyclecounter()
-#define DQ_WT_FLUSH(B, wave_index) do { if (lane == 0) for (int i_ = 1; i_ < dq_wn; ++i_) (B).stacked_rewards[((OQ_IX)(wave_index) * EPO + 1) * DW_NUM_REW + i_] = (float)(dq_wt[i_] - dq_wt[i_ - 1]); } while (0)
+#define DQ_WT_FLUSH(B, wave_index) do { if (lane == 0) for (int i_ = 1; i_ < dq_wn; ++i_) (B).cold->stacked_rewards[((OQ_IX)(wave_index) * EPO + 1) * DW_NUM_REW + i_] = (float)(dq_wt[i_] - dq_wt[i_ - 1]); } while (0)
 #else
 #define DQ_WT_DECL do { } while (0)
 #define DQ_WT() do { } while (0)
@@ -78,6 +78,41 @@ template <int NW> DQ_HD void st_row(float *p, const float (&v)[NW]) {
 DQ_HD float norm3_t(int gpu, float x, float y, float z) {
     const float v[3] = {x, y, z};
     return dw::norm_sel_v<3>(gpu, v);
+}
+
+// torch.norm of N = 33 or 12 elements f(0..N-1), summed by the EIGHT lanes of an octet together in exactly torch's order (dw_task.h
+// norm_g / norm_fn): every lane of the octet calls it (o = its octet lane) and gets the result.  One lane alone walks 33 dependent
+// additions per norm -- three such norms and two of 12 elements were 600 of the post phase's instructions and its longest chains.
+//   GPU order: T = 32 (8) threads square x[t] (+ x[t + T]) and combine in a balanced tree over t: lane o takes the leaves 4 o .. 4 o + 3
+//   (N = 33) or leaf o (N = 12), the upper tree levels are the exchanges l ^ 1, l ^ 2, l ^ 4 (a + b == b + a bit for bit).
+//   CPU order: eight fused accumulators over x[l], x[l + 8], ... -- lane l's -- added in lane order, then the tail as the scalar code.
+template <int N, class F>
+DQ_HD float oct_norm(int gpu, int o, F f) {
+    static_assert(N == 33 || N == 12, "oct_norm: the row lengths of the reward's long norms");
+    if (gpu) {
+        float r;
+        if constexpr (N == 33) {
+            float v[4];
+            DQ_UNROLL for (int i = 0; i < 4; ++i) { const float x = f(4 * o + i); v[i] = x * x; }
+            { const float y = f(32), yy = y * y; v[0] = o == 0 ? v[0] + yy : v[0]; }
+            r = (v[0] + v[1]) + (v[2] + v[3]);
+        } else {
+            const float x = f(o), y = f(o < 4 ? o + 8 : o), yy = y * y;
+            r = x * x;
+            r = o < 4 ? r + yy : r;
+        }
+        r = r + quad_xor1(r);
+        r = r + quad_xor2(r);
+        r = r + oct_xor4(r);
+        return sqrtf(r);
+    }
+    float acc = 0.0f;
+    DQ_UNROLL for (int d = 0; d + 8 <= N; d += 8) { const float x = f(d + o); acc = fmaf(x, x, acc); }
+    float b0 = oct_fetch(acc, 0);
+    DQ_UNROLL for (int l = 1; l < 8; ++l) b0 = b0 + oct_fetch(acc, l);
+    if constexpr (N == 12) { DQ_UNROLL for (int l = 0; l < 4; ++l) { const float x = f(8 + l); const float p2 = x * x; b0 = b0 + p2; } }
+    else { const float x = f(32); b0 = fmaf(x, x, b0); }
+    return sqrtf(b0);
 }
 
 // Inputs from the physics part of the kernel: qv/qdv = the item lanes' new joint state (items as joint_item()), X.root,
@@ -254,16 +289,13 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     // @phase post_reward
     // ---- Q2: reward terms, one group per lane of the quad ----
     {
-        // the three 33-element norms, in torch's CPU order (8 fused accumulators over elements a, a+8, a+16, a+24, added in order,
-        // then the 33rd element fused) or in its GPU order (dw_task.h norm_sel), elements produced on the fly
-        auto norm33 = [&](int which) {
-            const float n = dw::norm_sel<33>(gnorm, [&](int jj) {
-                return which == 0 ? PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj)
-                     : (which == 1 ? 0.0f - PQ_QD(el, jj) : PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj));
-            });
-            const float coef = which == 0 ? 0.35f : 0.05f, rate = which == 0 ? -2.0f : (which == 1 ? -0.01f : -20.0f);
-            return coef * expf(rate * (n * n));
-        };
+        // the three 33-element norms and the two 12-element ones: the octet's eight lanes together (oct_norm above), in torch's CPU or
+        // GPU order (dw_task.h norm_sel)
+        const float n_q = oct_norm<33>(gnorm, j, [&](int jj) { return PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj); });
+        const float n_qd = oct_norm<33>(gnorm, j, [&](int jj) { return 0.0f - PQ_QD(el, jj); });
+        const float n_qa = oct_norm<33>(gnorm, j, [&](int jj) { return PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj); });
+        const float n_a = oct_norm<12>(gnorm, j, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; });
+        const float n_da = oct_norm<12>(gnorm, j, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; });
         if (j == 0) {
             const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
             const float aerr = fabsf(dw::quat_err(qq, gnorm));
@@ -274,15 +306,15 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             PQ_PS(el, PS_RTERM + 6) = 0.3f * expf(-3.0f * (n * n));
         }
         if (j == 1) {
-            PQ_PS(el, PS_RTERM + 1) = norm33(0);
-            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * dw::norm_sel<12>(gnorm, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; }));
+            PQ_PS(el, PS_RTERM + 1) = 0.35f * expf(-2.0f * (n_q * n_q));
+            PQ_PS(el, PS_RTERM + 4) = 0.05f * expf(-0.01f * n_a);
         }
         if (j == 2) {
-            PQ_PS(el, PS_RTERM + 2) = norm33(1);
-            PQ_PS(el, PS_RTERM + 7) = norm33(2);
+            PQ_PS(el, PS_RTERM + 2) = 0.05f * expf(-0.01f * (n_qd * n_qd));
+            PQ_PS(el, PS_RTERM + 7) = 0.05f * expf(-20.0f * (n_qa * n_qa));
         }
         if (j == 3) {
-            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * dw::norm_sel<12>(gnorm, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; }));
+            PQ_PS(el, PS_RTERM + 5) = 0.6f * expf((-0.01f * 1.0f) * n_da);
             const float lf[3] = {PQ_PS(el, PS_FOOT), PQ_PS(el, PS_FOOT + 1), PQ_PS(el, PS_FOOT + 2)};
             const float rf[3] = {PQ_PS(el, PS_FOOT + 3), PQ_PS(el, PS_FOOT + 4), PQ_PS(el, PS_FOOT + 5)};
             const float lfp[3] = {PQ_ES(el, DW_ES_FOOT_FORCE_PRE), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 1), PQ_ES(el, DW_ES_FOOT_FORCE_PRE + 2)};
