@@ -13,6 +13,7 @@ struct DwHandle {
     dwq::QuadModel *d_qmodel;
     dw::DevParams  *d_params;
     int             pipeline;       // 3 = the octet kernels (8 lanes per env), one launch per policy step
+    int             hex;            // this handle's launches use the hex instantiation (16 lanes per env): N <= 4096, or DwConfig.debug_wave_build = 3
     float          *d_mocap;
     float          *d_sc_park;      // PhysParams::sc_park
     int16_t        *d_hmax;         // height field: the coarse bound table built at dw_bind (PhysParams::hmax)

@@ -35,7 +35,18 @@ void launch_simulate(bool terrain, int wave_build, int num_envs, hipStream_t str
                      const DwBuffers &B, const float *tau, const float *push);
 int  oct_lds_bytes();
 int  sc_park_words();
+int  device_simds();
+int  waves(int num_envs);
 }  // namespace dwo
+// The hex instantiation of the same source (16 lanes per env; launches of at most one wavefront per SIMD, N <= 4096): dw_hex_kernels.hip.
+namespace dwx {
+void launch_step(bool terrain, int gpu_flavour, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                 const DwBuffers &B, const float *mocap, const float *actions, const float *noise, long long step, const long long *step_dev);
+void launch_simulate(bool terrain, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,
+                     const DwBuffers &B, const float *tau, const float *push);
+int  hex_lds_bytes();
+int  waves(int num_envs);
+}  // namespace dwx
 
 // the coarse bound table of the height field (dw_physics.h terrain_bound), one thread per cell; runs once, at dw_bind
 __global__ __launch_bounds__(256) void dw_k_terrain_bound(const int16_t *hs, int rows, int cols, int cell, int reach, int hm_rows, int hm_cols, int16_t *out) {
@@ -106,8 +117,11 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     }
     free(hq);
     if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: model upload", e); }
+    // which lane layout runs this handle's launches: the hex instantiation (16 lanes per env) when all its wavefronts find a SIMD of
+    // their own -- N <= 4096 on an MI355X -- or when a test asks for it (debug_wave_build = 3); the octet kernels otherwise
+    h->hex = cfg->debug_wave_build == 3 || (cfg->debug_wave_build == 0 && dwx::waves(cfg->num_envs) <= dwo::device_simds());
     {
-        const size_t waves = (size_t)(cfg->num_envs + 15) / 16 * 2;
+        const size_t waves = (size_t)(h->hex ? dwx::waves(cfg->num_envs) : dwo::waves(cfg->num_envs));
         e = hipMalloc((void **)&h->d_sc_park, waves * 64 * dwo::sc_park_words() * sizeof(float));
         if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: self-collision park buffer", e); }
         h->params.phys.sc_park = h->d_sc_park;
@@ -190,7 +204,8 @@ int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *strea
     if (!tau) return fail(DW_EINVAL, "dw_simulate: tau is null");
     if (h->cfg.debug_freeze_physics) return DW_OK;
     DeviceGuard guard(h->device);
-    dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.debug_wave_build, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
+    if (h->hex) dwx::launch_simulate(h->cfg.terrain != 0, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
+    else dwo::launch_simulate(h->cfg.terrain != 0, h->cfg.debug_wave_build, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, tau, push_xy);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_simulate: launch", e);
     return DW_OK;
@@ -211,8 +226,10 @@ static int launch_step(DwHandle *h, const float *actions, const float *noise, lo
     if (obs_out) bufs.obs_buf = obs_out;
     // the torch flavour of the post phase's norms is compiled into the step kernels
     const int flavour = h->cfg.torch_gpu_div != 0 ? 1 : 0;
-    dwo::launch_step(h->cfg.terrain != 0, flavour, h->cfg.debug_wave_build, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
-                     actions, noise, step_index, step_dev);
+    if (h->hex) dwx::launch_step(h->cfg.terrain != 0, flavour, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
+                                 actions, noise, step_index, step_dev);
+    else dwo::launch_step(h->cfg.terrain != 0, flavour, h->cfg.debug_wave_build, h->cfg.num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, bufs, h->d_mocap,
+                          actions, noise, step_index, step_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(who, e);
     return DW_OK;
@@ -258,5 +275,6 @@ int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *no
 }
 
 int dw_oct_lds_bytes(void) { return dwo::oct_lds_bytes(); }
+int dw_hex_lds_bytes(void) { return dwx::hex_lds_bytes(); }
 
 }  // extern "C"

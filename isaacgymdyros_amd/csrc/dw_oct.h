@@ -21,11 +21,22 @@
 #include "dw_limb.h"
 #include "dw_bufg.h"
 
-namespace dwo {
+#if !defined(OCT_LPE)
+#define OCT_LPE 8
+#endif
+#if OCT_LPE == 8
+#define OCT_NS dwo
+#elif OCT_LPE == 16
+#define OCT_NS dwx
+#else
+#error "OCT_LPE must be 8 (octet layout) or 16 (hex layout)"
+#endif
+
+namespace OCT_NS {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::hex_xor8; using dwq::quarter_take; using dwq::quarter0_all; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
@@ -65,8 +76,15 @@ template <int D, int LIMIT = 1024> DQ_HD int oq_div(int i) {
 // env index x row stride: both below 2^24 (num_envs <= 2^20), so the product is ONE full-rate v_mul_u32_u24 / v_mad_u32_u24 (a
 // 32-bit v_mul_lo_u32 issues at a quarter of the rate)
 DQ_HD OQ_IX oq_row(int stride, int env) { return ((OQ_IX)stride & 0xffffffu) * ((OQ_IX)env & 0xffffffu); }
-constexpr int LPE = 8;               // lanes per env
+// LPE = 8 is the layout this file describes.  OCT_LPE = 16 compiles the SAME source as the "hex" instantiation (namespace dwx, entry
+// points dw_k_*_hex, dw_hex_kernels.hip) for launches of at most 4096 envs, where the octet layout leaves half of the SIMDs idle: 16
+// lanes = one DPP row per env, four QUARTERS q of four limb lanes, 4 envs per wave, 1024 waves at 4096 envs = one on every SIMD.
+// What is a map over bodies is split four ways instead of two (the inward pass maps steps s .. s + 3 per round; item loops have 3
+// items per lane instead of 5; 16 proxies are one per lane), the chain recursions run mirrored in all quarters, and the contact
+// phase runs as two mirrored octets (quarter pairs (0,1) and (2,3): h = q & 1), so its lane arithmetic is the octet's.
+constexpr int LPE = OCT_LPE;         // lanes per env
 constexpr int EPO = 64 / LPE;        // envs per wavefront
+constexpr int NQ = LPE / 4;          // quads ("halves" / quarters) of an env
 #if !defined(OCT_WPG)
 #define OCT_WPG 2
 #endif
@@ -77,7 +95,9 @@ constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 1;      // per lane: PhysParams::sc
 // = 128 B, half the width of the LDS (64 banks x 4 B); the position code (pcode_cell below) rotates a limb's column by two per limb,
 // so the four limbs of a 16-lane group (2 envs) read 8 different 16-byte columns (`flip`, a pairwise swap of the rows of odd limbs, is
 // what round 3's code did instead and survives for the A/B builds).
-struct alignas(16) OSlots { F4 slot[NB * 4][EPO]; };
+constexpr int XROWS = LPE == 16 ? 12 : 0;          // (hex: the post phase's LDS image needs 124 words more than 33 bodies x 4 envs give)
+constexpr int ROWB = EPO * 16;                      // bytes of a slot row
+struct alignas(16) OSlots { F4 slot[NB * 4 + XROWS][EPO]; };
 struct alignas(16) OLds {
     OSlots w[WPG];
     QHot   hot;
@@ -102,9 +122,9 @@ DQ_HD OPos pcode_cell(int el, int owner, int cell) {
 #elif defined(OCT_PCODE_ROT1F)        // (A/B builds only: columns rotated by one per limb, rows of odd limbs swapped)
     const int pos = (el + owner) & 7, flip = owner & 1;
 #else                                 // columns rotated by two per limb, no row swap
-    const int pos = (el + 2 * owner) & 7, flip = 0;
+    const int pos = LPE == 8 ? ((el + 2 * owner) & 7) : ((el + owner) & 3), flip = 0;
 #endif
-    OPos p; p.e = cell * 512 + pos * 16 + flip * 128; p.o = cell * 512 + pos * 16 - flip * 128;
+    OPos p; p.e = cell * (4 * ROWB) + pos * 16 + flip * ROWB; p.o = cell * (4 * ROWB) + pos * 16 - flip * ROWB;
     return p;
 }
 DQ_HD OPos pcode(const QHot &H, int el, int owner) {          // a limb: cell = cellbase + step
@@ -114,7 +134,7 @@ DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
     const int co = H.owner[b];
     return pcode_cell(el, co >> 6, co & 63);
 }
-#define OQ_SLOT(st, q, p) (*reinterpret_cast<F4 *>(reinterpret_cast<char *>(&L.slot[0][0]) + (((q) & 1) ? (p).o : (p).e) + ((st) * 4 + (q)) * 128))
+#define OQ_SLOT(st, q, p) (*reinterpret_cast<F4 *>(reinterpret_cast<char *>(&L.slot[0][0]) + (((q) & 1) ? (p).o : (p).e) + ((st) * 4 + (q)) * ROWB))
 #define OQ_LD(b, q, p) ldp(OQ_SLOT(b, q, p))
 // the loops over the schedule steps stay loops: unrolled, one substep is 100 KB of straight-line code that every wave streams
 // through the 64 KB instruction cache (measured: +5 % step time)
@@ -159,7 +179,7 @@ DQ_HD void stage_hot(QHot &HW, const QuadModel &QM) {
 
 // What a lane keeps in registers across the phases of a step.
 struct OLane {
-    int   lane, o, j, h, el, env, valid;     // octet lane, limb, half, env within the wave, global env (clamped)
+    int   lane, o, j, h, q, prim, el, env, valid;     // octet lane (l & 7), limb, half (q & 1), quad of the env (0 .. NQ - 1), q == 0, env within the wave, global env (clamped)
     OPos  pos;                               // position code of my limb's slots
     int   wave;                              // wave index in the launch (wave-uniform)
     float root[13];
@@ -230,7 +250,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     const int SB = X.stamp_base; (void)SB;
     DQ_STAMP(B, SB + 0);
     const int e = X.env;
-    const bool wr = X.valid && X.h == 0;          // global side effects: half 0 only (half 1 mirrors it)
+    const bool wr = X.valid && X.prim;          // global side effects: quad 0 of the env only (the others mirror it)
     const OQ_IX ms_row = oq_row(DW_NUM_BODIES, e);          // my env's row of mass_scale
     const int first_j = (f2i(H.base[14]) >> (4 * j)) & 15, last_j = (f2i(H.base[14]) >> (16 + 4 * j)) & 15;      // my limb's steps
     // The three outward passes read their slot rows in EVERY step, also where a lane's limb has no body (its chain starts later or
@@ -387,24 +407,29 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             // the rounds: lane o tests pair scround[r][o], the axes fetched from the lanes that built them (conservative: the least
             // distance of the axes against a threshold rounded up; the force uses the blended points, never closer)
             const int nr0 = (H.misc[2] >> 8) & 15, nr1 = (H.misc[2] >> 12) & 15, nr2 = (H.misc[2] >> 16) & 15;
-            auto round = [&](int r, const float (&Ea)[6], const float (&Eb)[6]) {
-                const int w = H.scround[r][X.o];
+            // (hex layout: the env's two octets both hold all the axes and take alternate rounds of a class)
+            constexpr int NOCT = LPE / 8;
+            const int oc = (X.lane >> 3) & (NOCT - 1);
+            auto round = [&](int r0, int k, int nr, const float (&Ea)[6], const float (&Eb)[6]) {
+                const int kk = k * NOCT + oc;
+                const bool live = kk < nr;
+                const int w = H.scround[live ? r0 + kk : r0][X.o];
                 const int la = w & 7, lb = (w >> 3) & 7, pid = (w >> 6) & 127;
                 float a[6], b[6];
                 DQ_UNROLL for (int i = 0; i < 6; ++i) { a[i] = oct_fetch(Ea[i], la); b[i] = oct_fetch(Eb[i], lb); }
                 const float rv[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
-                if (pid != 127 && seg_dist2_fast(&a[3], &b[3], rv) < half_bits_to_float((w >> 16) & 0xffff)) hits |= 1 << pid;
+                if (live && pid != 127 && seg_dist2_fast(&a[3], &b[3], rv) < half_bits_to_float((w >> 16) & 0xffff)) hits |= 1 << pid;
             };
-            int r = 0;
-            for (int k = 0; k < nr0; ++k, ++r) round(r, E[0], E[0]);          /*@trip:2*/
-            for (int k = 0; k < nr1; ++k, ++r) round(r, E[1], E[1]);          /*@trip:2*/
-            for (int k = 0; k < nr2; ++k, ++r) round(r, E[1], E[0]);          /*@trip:1*/
+            for (int k = 0; k * NOCT < nr0; ++k) round(0, k, nr0, E[0], E[0]);          /*@trip:2*/
+            for (int k = 0; k * NOCT < nr1; ++k) round(nr0, k, nr1, E[1], E[1]);          /*@trip:2*/
+            for (int k = 0; k * NOCT < nr2; ++k) round(nr0 + nr1, k, nr2, E[1], E[0]);          /*@trip:1*/
         }
         {   // the env's mask: OR over the octet (bit patterns through the DPP moves)
             int m = hits;
             m |= f2i(quad_xor1(__builtin_bit_cast(float, m)));
             m |= f2i(quad_xor2(__builtin_bit_cast(float, m)));
             m |= f2i(oct_xor4(__builtin_bit_cast(float, m)));
+            if (LPE == 16) m |= f2i(hex_xor8(__builtin_bit_cast(float, m)));
             hits = m;
         }
         sc_any = wave_any(hits != 0);
@@ -473,7 +498,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     struct BodyMap { float Ao[6], ho[3], mass, pv[6], S[6], cb[6], tt, dd, qd; };       // 31 words
     auto step_clamped = [&](int s) { return s < T ? s : T - 1; };
     // the one per-env global value a map needs (the mass scale of the body's Gym body) is requested a round ahead
-    float ms_next = oq_at(B.mass_scale, ms_row + ((f2i(H.in[step_clamped(X.h)][j][2]) >> 24) & 255));
+    float ms_next = oq_at(B.mass_scale, ms_row + ((f2i(H.in[step_clamped(X.q)][j][2]) >> 24) & 255));
 #if defined(DQ_STAMPS) && defined(__HIPCC__)
     long long tq_map = 0, tq_rec = 0, tq_t0 = 0;
 #define OQ_TICK() (tq_t0 = (long long)__builtin_readcyclecounter())
@@ -485,7 +510,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #if defined(OCT_ABL_INWARD)
     DQ_ROLLED for (int s = 0; s < 0; s += 2) {
 #else
-    DQ_ROLLED for (int s = 0; s < T; s += 2) {          /*@trip:6*/
+    DQ_ROLLED for (int s = 0; s < T; s += NQ) {          /*@trip:6*/
 #endif
         OQ_TICK();
 #if defined(DQ_STAMPS_INWARD)
@@ -493,18 +518,18 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #endif
         BodyMap Mb;
         {   // ---- map: my body of this round (step s + h) ----
-            const int sm = step_clamped(s + X.h);
+            const int sm = step_clamped(s + X.q);
             const F4 *hr = reinterpret_cast<const F4 *>(H.in[sm][j]);
             const F4 h0 = ldp(hr[0]), h1 = ldp(hr[1]), h2 = ldp(hr[2]), h3 = ldp(hr[3]);
             const int bits = f2i(h0.x);
-            const int b = (s + X.h < T) ? (bits & 255) - 1 : -1;
+            const int b = (s + X.q < T) ? (bits & 255) - 1 : -1;
             const int nin = (bits >> 12) & 3, ngym = (bits >> 14) & 3, ngeom = (bits >> 16) & 15, scm = (bits >> 24) & 255;
             const int gymbits = f2i(h0.z);
             const float ms0 = ms_next;
-            ms_next = oq_at(B.mass_scale, ms_row + ((f2i(H.in[step_clamped(s + 2 + X.h)][j][2]) >> 24) & 255));
+            ms_next = oq_at(B.mass_scale, ms_row + ((f2i(H.in[step_clamped(s + NQ + X.q)][j][2]) >> 24) & 255));
             // (the slot rows are requested together with the table record, not after it: a lane that idles in this step reads the
             //  nearest body of its own limb instead -- the step index clamped to the limb's range -- and nothing is done with it)
-            int som = T - 1 - s - X.h;
+            int som = T - 1 - s - X.q;
             som = som < first_j ? first_j : (som > last_j ? last_j : som);
             const F4 s0 = OQ_LD(som, 0, X.pos), s1 = OQ_LD(som, 1, X.pos), s2 = OQ_LD(som, 2, X.pos), s3 = OQ_LD(som, 3, X.pos);
             F4 ax4 = ldp(reinterpret_cast<const F4 *>(H.fk[T - 1 - sm][j])[1]);
@@ -587,13 +612,20 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         wave_sync();          // every map has read its slot rows before the recursion overwrites any
         OQ_TOCK(tq_map); OQ_TICK();
         // ---- recursion: step s on half 0's map, then step s + 1 on half 1's ----
-        DQ_UNROLL for (int t2 = 0; t2 < 2; ++t2) {
+        BodyMap Mq = Mb;          // (hex layout: quad 0 takes the maps of quads 1, 2, 3 in turn from the lanes that made them)
+        DQ_UNROLL for (int t2 = 0; t2 < NQ; ++t2) {
             const int sr = s + t2;
             if (sr >= T) break;
-            if (t2 == 1) {        // half 1's map result to half 0 (the high quads keep their own)
+            if (LPE == 8 && t2 == 1) {        // half 1's map result to half 0 (the high quads keep their own)
                 DQ_UNROLL for (int i = 0; i < 6; ++i) { Mb.Ao[i] = oct_hi(Mb.Ao[i]); Mb.pv[i] = oct_hi(Mb.pv[i]); Mb.S[i] = oct_hi(Mb.S[i]); Mb.cb[i] = oct_hi(Mb.cb[i]); }
                 DQ_UNROLL for (int i = 0; i < 3; ++i) Mb.ho[i] = oct_hi(Mb.ho[i]);
                 Mb.mass = oct_hi(Mb.mass); Mb.tt = oct_hi(Mb.tt); Mb.dd = oct_hi(Mb.dd); Mb.qd = oct_hi(Mb.qd);
+            }
+            if (LPE == 16 && t2 >= 1) {
+                auto take = [&](float x) { return t2 == 1 ? quarter_take<1>(x) : (t2 == 2 ? quarter_take<2>(x) : quarter_take<3>(x)); };
+                DQ_UNROLL for (int i = 0; i < 6; ++i) { Mb.Ao[i] = take(Mq.Ao[i]); Mb.pv[i] = take(Mq.pv[i]); Mb.S[i] = take(Mq.S[i]); Mb.cb[i] = take(Mq.cb[i]); }
+                DQ_UNROLL for (int i = 0; i < 3; ++i) Mb.ho[i] = take(Mq.ho[i]);
+                Mb.mass = take(Mq.mass); Mb.tt = take(Mq.tt); Mb.dd = take(Mq.dd); Mb.qd = take(Mq.qd);
             }
             const int bits = f2i(H.in[sr][j][0]);
             const int b = (bits & 255) - 1;
@@ -662,7 +694,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     pa[r] = acc;
                 }
                 DQ_UNROLL for (int r = 0; r < 6; ++r) pA[r] = pa[r];
-                if (X.h == 0) {
+                if (X.prim) {
                     OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(S[0], S[1], S[2], Dinv);
                     OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(S[3], S[4], S[5], u);
                     OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(U[0], U[1], U[2], Mb.qd);
@@ -677,7 +709,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     if (blockIdx.x == 0 && threadIdx.x == 0 && SB == 1) { OQ_COLD(gate_acc)[200 + 32] = tq_map; OQ_COLD(gate_acc)[200 + 33] = tq_rec; }
 #endif
     // (the sole body's non-sole contact force was found by whichever half mapped it)
-    DQ_UNROLL for (int i = 0; i < 3; ++i) X.footF[i] += oct_xor4(X.footF[i]);
+    DQ_UNROLL for (int i = 0; i < 3; ++i) { X.footF[i] += oct_xor4(X.footF[i]); if (LPE == 16) X.footF[i] += hex_xor8(X.footF[i]); }
 
     DQ_STAMP(B, SB + 4);
     // @phase base_solve
@@ -707,8 +739,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             quat_to_mat(qo4, R0);
         }
         // (the recursion of the inward pass is valid in half 0 only: half 1 takes the gathered inertia over)
-        DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = oct_lo(I0[i]);
-        DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = oct_lo(p0[i]);
+        DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = LPE == 8 ? oct_lo(I0[i]) : quarter0_all(I0[i]);
+        DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = LPE == 8 ? oct_lo(p0[i]) : quarter0_all(p0[i]);
         const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
         float Ao[6], ho[3], mass;
         const int base_gym = f2i(H.base[10]), base_ngeom = f2i(H.base[11]);
@@ -1209,8 +1241,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 DQ_HD void oct_lane_init(OLane &X, const QHot &H, int wave_index, int num_envs, const PhysParams &P, float friction, const OBuf &B) {
     X.lane = lane_id();
     X.wave = wave_index;
-    X.o = X.lane & 7; X.j = X.lane & 3; X.h = (X.lane >> 2) & 1;
-    X.el = X.lane >> 3;
+    X.o = X.lane & 7; X.j = X.lane & 3; X.h = (X.lane >> 2) & 1; X.q = (X.lane >> 2) & (NQ - 1); X.prim = X.q == 0;
+    X.el = X.lane / LPE;
     const int eg = wave_index * EPO + X.el;
     X.valid = eg < num_envs;
     X.env = X.valid ? eg : num_envs - 1;
@@ -1281,9 +1313,9 @@ DQ_HD void oct_simulate(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel
             oq_at(B.dof_state, g * 2, 0) = q; oq_at(B.dof_state, g * 2, 1) = qd;
         }
     }
-    if (X.valid && X.h == 0) {
+    if (X.valid && X.prim) {
         if (X.j == 0) { DQ_UNROLL for (int i = 0; i < 13; ++i) oq_at(B.root_states, oq_row(13, e), i) = X.root[i]; }
     }
 }
 
-}  // namespace dwo
+}  // namespace OCT_NS

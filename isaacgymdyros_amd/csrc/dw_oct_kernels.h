@@ -15,7 +15,7 @@
 #pragma clang fp contract(off)
 #endif
 
-namespace dwo {
+namespace OCT_NS {
 
 
 using dw::TaskParams;
@@ -114,7 +114,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
     float qkeep[ONI], qdkeep[ONI], qnprev[ONI];          // (filled by the last encoder epilogue: what the post phase takes over)
     float tau2k[ONI], n1k[ONI], dampk[ONI], armk[ONI], kpk[ONI], kvk[ONI];          // (KEEP builds only)
     float (&qvk)[ONI] = KP.qv;
-    const bool wr_env = X.valid && X.h == 0;          // per-env scalars: half 0 writes
+    const bool wr_env = X.valid && X.prim;          // per-env scalars: quad 0 of the env writes
     // (simul_len is read by every leg item of an env: it is advanced once, at the end, by the env's lane 0)
     const int simul_len0 = f2i(r_sl);
     (void)f;
@@ -167,7 +167,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
             float magnitude = r_mag, phase = r_phase;
             if (open) {
                 pert_start = 1;
-                if (!C.force_perturb_start && X.valid && X.h == 0) gate[dw::GATE_LATCH] = 1;
+                if (!C.force_perturb_start && X.valid && X.prim) gate[dw::GATE_LATCH] = 1;
             }
             if (pert_start) {
                 if (dw::remainder_t(r_epi, C.pert_period_f) == (float)f2i(r_ptim)) {
@@ -304,8 +304,9 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         }
         }
         if (noise) { DQ_UNROLL for (int k = 0; k < ONI; ++k) nzw[k] = oq_at(noise, oq_row(DW_NOISE_WORDS, its[k].env) + ND * sub + its[k].d, DW_NZ_ENC); }
-        static_assert(ONI == 5, "the grouped touch below names five loads");
-        OQ_KEEP3(fin[0], fin[1], fin[2]); OQ_KEEP2(fin[3], fin[4]);
+        static_assert(ONI == 5 || ONI == 3, "the grouped touch below names the loads");
+        OQ_KEEP3(fin[0], fin[1], fin[2]);
+        if constexpr (ONI == 5) OQ_KEEP2(fin[3], fin[4]);
         if (sub == 0) DQ_STAMP(B, 34);
         float n1[ONI];
         DQ_UNROLL for (int k = 0; k < ONI; ++k) n1[k] = 0.0f;
@@ -359,7 +360,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         DQ_STAMP(B, 1 + 16 * sub + 14);
     }
     // @phase post_entry
-    if (X.valid && !c_freeze && X.o == 0) {
+    if (X.valid && !c_freeze && X.o == 0 && X.prim) {
         int e2 = e;
         DQ_OPAQUE(e2);            // (the row's address again from the index: held since the loads at the top it is a register pair through both substeps)
         DQ_UNROLL for (int i = 0; i < 13; ++i) oq_at(B.root_states, oq_row(13, e2), i) = X.root[i];
@@ -372,6 +373,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
         c += quad_xor1(c);
         c += quad_xor2(c);
         c += oct_xor4(c);
+        if (LPE == 16) c += hex_xor8(c);
         X.coll = c > 0.0f;
     }
     wave_sync();
@@ -394,7 +396,7 @@ DQ_HD void oct_step(OSlots &L, QHot &HW, const QuadModel &QM, const DevModel &M,
 #endif
 }
 
-}  // namespace dwo
+}  // namespace OCT_NS
 
 #if defined(__clang__)
 #pragma clang fp contract(fast)

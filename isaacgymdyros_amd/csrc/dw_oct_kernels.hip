@@ -62,16 +62,20 @@ namespace dwo {
 static int groups(int num_envs) { return (num_envs + EPO * WPG - 1) / (EPO * WPG); }
 
 // waves of the launch <= SIMDs of the device: the one-wave-per-SIMD build (wave_build: DwConfig.debug_wave_build, 1 / 2 force a build)
-static bool spread(int num_envs, int wave_build) {
-    if (wave_build == 1) return true;
-    if (wave_build == 2) return false;
+int device_simds() {
     static int simds = 0;
     if (!simds) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         simds = 4 * cus;
     }
-    return groups(num_envs) * WPG <= simds;
+    return simds;
+}
+int waves(int num_envs) { return groups(num_envs) * WPG; }
+static bool spread(int num_envs, int wave_build) {
+    if (wave_build == 1) return true;
+    if (wave_build == 2) return false;
+    return groups(num_envs) * WPG <= device_simds();
 }
 template <int GPUF>
 static void launch_step_f(bool terrain, int wave_build, int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P,

@@ -14,7 +14,7 @@
 #pragma clang fp contract(off)
 #endif
 
-namespace dwo {
+namespace OCT_NS {
 
 #if defined(DQ_WAVE_TIME) && defined(__HIPCC__)      // (timing experiment, tools/wave_times.py: the post phases of EVERY wave, left in the reward rows of its second env)
 #define DQ_WT_DECL long long dq_wt[14]; int dq_wn = 0
@@ -38,7 +38,7 @@ constexpr int PL_PS = PL_NORMED + EPO * DW_NUM_OBS1;     // [8][32] per-env scra
 constexpr int PL_OBN = PL_PS + EPO * 32;                 // [2][37] observation mean, divisor (the hot tables belong to both waves of the workgroup)
 static_assert((PL_Q * 4) % 16 == 0, "post layout: the record block must end on a 16-byte boundary");
 constexpr int PL_RC = PL_OBN + 2 * DW_NUM_OBS1;          // [33][2] per-joint constants of the reset: initial angle, the same clamped to the joint range
-static_assert(PL_RC + 2 * ND <= NB * 4 * EPO * 4, "post layout does not fit the slot area");
+static_assert(PL_RC + 2 * ND <= (NB * 4 + XROWS) * EPO * 4, "post layout does not fit the slot area");
 // per-env scratch words
 constexpr int PS_RTERM = 0;      // [16] reward terms, [14] = |orientation error|
 constexpr int PS_BAD = 16, PS_COLL = 17, PS_RESET = 18, PS_PROGRESS = 19, PS_RANDOMIZE = 20, PS_MASS = 21;
@@ -131,7 +131,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     //  registers across the two substeps)
     int lane = X.lane;
     DQ_OPAQUE(lane);
-    const int j = lane & 7, el = lane >> 3;                 // j: octet lane (0..7); lanes 4..7 idle in the per-env scalar groups
+    const int j = lane & (LPE - 1), el = lane / LPE;        // j: lane of the env (0 .. LPE - 1); lanes 4.. idle in the per-env scalar groups
     const int eg_ = wave_index * EPO + el;
     const bool xvalid = eg_ < C.num_envs;
     const int e = xvalid ? eg_ : C.num_envs - 1;
@@ -291,11 +291,11 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     {
         // the three 33-element norms and the two 12-element ones: the octet's eight lanes together (oct_norm above), in torch's CPU or
         // GPU order (dw_task.h norm_sel)
-        const float n_q = oct_norm<33>(gnorm, j, [&](int jj) { return PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj); });
-        const float n_qd = oct_norm<33>(gnorm, j, [&](int jj) { return 0.0f - PQ_QD(el, jj); });
-        const float n_qa = oct_norm<33>(gnorm, j, [&](int jj) { return PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj); });
-        const float n_a = oct_norm<12>(gnorm, j, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; });
-        const float n_da = oct_norm<12>(gnorm, j, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; });
+        const float n_q = oct_norm<33>(gnorm, j & 7, [&](int jj) { return PQ_ES(el, DW_ES_TARGET_QPOS + jj) - PQ_Q(el, jj); });
+        const float n_qd = oct_norm<33>(gnorm, j & 7, [&](int jj) { return 0.0f - PQ_QD(el, jj); });
+        const float n_qa = oct_norm<33>(gnorm, j & 7, [&](int jj) { return PQ_QD(el, jj) - PQ_ES(el, DW_ES_PRE_QVEL + jj); });
+        const float n_a = oct_norm<12>(gnorm, j & 7, [&](int i) { return PQ_ES(el, DW_ES_ACTIONS + i) * 333.0f; });
+        const float n_da = oct_norm<12>(gnorm, j & 7, [&](int i) { return (PQ_ES(el, DW_ES_ACTIONS + i) - PQ_ES(el, DW_ES_ACTIONS_PRE + i)) * 333.0f; });
         if (j == 0) {
             const float qq[4] = {PQ_ROOT(el, 3), PQ_ROOT(el, 4), PQ_ROOT(el, 5), PQ_ROOT(el, 6)};
             const float aerr = fabsf(dw::quat_err(qq, gnorm));
@@ -394,6 +394,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
     if (any_reset) {          /*@prob:0.18*/
         const bool mine = PQ_PSI(el, PS_RESET) != 0;
+        const bool mine8 = mine && j < 8;          // (the draws and the joint loops below are laid out for eight lanes per env; the hex layout's lanes 8 .. 15 stand by)
         if (C.terrain_curriculum && j == 0 && mine) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
             const float distance = dw::norm_sel_v<2>(gnorm, d);
@@ -424,7 +425,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         //  not apply goes to the env's spare scratch word)
         const int dummy = PL_PS + el * 32 + 31;
         int *LI = reinterpret_cast<int *>(LF);
-        if (mine) {
+        if (mine8) {
             float u[4];
             dw::noise_block(K.nz, DW_NZ_QPOS_BIAS / 4 + j, u);
             const bool gd = C.gpu_div != 0;
@@ -457,7 +458,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             static_assert(DW_NZ_DR_ARM == DW_NZ_DR_DAMP + DW_NUM_DOF && DW_NZ_DR_FRIC == DW_NZ_DR_ARM + DW_NUM_DOF, "DR words are contiguous");
             constexpr int B0 = DR_B0, NBLK = DR_NBLK, NPASS = DR_NPASS;
             float u[NPASS][4] = {};
-            const bool go = mine && do_dr;
+            const bool go = mine8 && do_dr;
             if (go) { DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) dw::noise_block(K.nz, B0 + j + 8 * p2 < B0 + NBLK ? B0 + j + 8 * p2 : B0, u[p2]); }
             const float d0 = C.dr_damp[0], d1 = C.dr_damp[1] - C.dr_damp[0], a0 = C.dr_arm[0], a1 = C.dr_arm[1] - C.dr_arm[0];
             const float f0 = C.dr_fric[0], f1 = C.dr_fric[1] - C.dr_fric[0];
@@ -473,9 +474,9 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             }
         }
         DQ_WT();
-        if (mine) {
+        if (mine8) {
             const int esb = PL_ES + el * PL_ES_STRIDE;
-            DQ_UNROLL for (int k = 0; k < ONI; ++k) {
+            DQ_UNROLL for (int k = 0; k < (ND + 7) / 8; ++k) {
                 const int l = j + 8 * k;
                 const bool lv = l < ND;
                 const int lc = lv ? l : 0;
@@ -720,7 +721,7 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
 #undef PQ_PS
 #undef PQ_PSI
 
-}  // namespace dwo
+}  // namespace OCT_NS
 
 #if defined(__clang__)
 #pragma clang fp contract(fast)

@@ -21,7 +21,8 @@ inline const char *check_config(const DwConfig *c) {
     if (c->pipeline == 1 || c->pipeline == 2 || c->pipeline == 4)
         return "pipeline 1 (wave per env), 2 (quad) and 4 (lane per env, wave per limb) are retired: use 0 (default) or 3 (octet: 8 lanes per env)";
     if (c->pipeline != 0 && c->pipeline != 3) return "pipeline must be 0 (default) or 3 (octet: 8 lanes per env)";
-    if (c->debug_wave_build < 0 || c->debug_wave_build > 2) return "debug_wave_build must be 0 (by launch size), 1 or 2";
+    if (c->debug_wave_build < 0 || c->debug_wave_build > 3) return "debug_wave_build must be 0 (by launch size), 1, 2 (octet kernels: one / two waves per SIMD) or 3 (hex instantiation)";
+    if (c->num_envs > (1 << 20)) return "num_envs above 2^20 per GPU (the kernels address the per-env streams with 32-bit byte offsets)";
     return nullptr;
 }
 

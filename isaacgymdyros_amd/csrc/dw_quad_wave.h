@@ -80,6 +80,27 @@ DQ_HD float oct_fetch(float x, int src) {
 DQ_HD float half_bits_to_float(int h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
 DQ_HD float quad_pair_lo(float x) { return dpp_quad<0 | (1 << 2) | (0 << 4) | (1 << 6)>(x); }
 DQ_HD float quad_pair_hi(float x) { return dpp_quad<2 | (3 << 2) | (2 << 4) | (3 << 6)>(x); }
+// The 16-lanes-per-env ("hex") instantiation of the octet kernels (dw_oct.h, OCT_LPE = 16): an env is one DPP row, four QUARTERS
+// q = (l >> 2) & 3 of four limb lanes each.
+//   hex_xor8(x)          x of lane l ^ 8 (the other octet of the row)                      (row_ror:8)
+//   quarter_take<K>(x)   quarter-0 lanes take x of lane l + 4 K (quarter K, same limb); other lanes keep theirs  (row_shl:4K, bank 0)
+//   quarter0_all(x)      every lane takes x of lane l & ~12 (quarter 0, same limb)          (three bank-masked row_shr moves)
+DQ_HD float hex_xor8(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x128, 0xF, 0xF, false));
+}
+template <int K> DQ_HD float quarter_take(float x) {
+    static_assert(K >= 1 && K <= 3, "quarter_take: K = 1..3");
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x100 + 4 * K, 0xF, 0x1, false));
+}
+DQ_HD float quarter0_all(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    int r = __builtin_amdgcn_update_dpp(xi, xi, 0x114, 0xF, 0x2, false);          // row_shr:4  into bank 1
+    r = __builtin_amdgcn_update_dpp(r, xi, 0x118, 0xF, 0x4, false);               // row_shr:8  into bank 2
+    r = __builtin_amdgcn_update_dpp(r, xi, 0x11C, 0xF, 0x8, false);               // row_shr:12 into bank 3
+    return __builtin_bit_cast(float, r);
+}
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
 DQ_HD void wave_sync() {
@@ -262,6 +283,9 @@ DQ_HD float half_bits_to_float(int h) {          // (positive normal numbers and
 }
 DQ_HD float quad_pair_lo(float x) { return emu_xchg(x, g_emu->cur & ~2); }
 DQ_HD float quad_pair_hi(float x) { return emu_xchg(x, g_emu->cur | 2); }
+DQ_HD float hex_xor8(float x) { return emu_xchg(x, g_emu->cur ^ 8); }
+template <int K> DQ_HD float quarter_take(float x) { return emu_xchg(x, (g_emu->cur & 12) == 0 ? g_emu->cur + 4 * K : g_emu->cur); }
+DQ_HD float quarter0_all(float x) { return emu_xchg(x, g_emu->cur & ~12); }
 DQ_HD bool wave_any(bool p) {
     WaveEmu *e = g_emu;
     const int l = e->cur, par = (int)(e->nsync[l] & 1);

@@ -7,7 +7,7 @@ import emul_backend, replay as R
 from isaacgymdyros_amd import abi
 from isaacgymdyros_amd.task_constants import load_task_constants
 WB = int(sys.argv[1]) if len(sys.argv) > 1 else 2          # DwConfig.debug_wave_build: 2 = two-waves form, 1 = register-resident form
-stem = 'libdw_emul_oct'
+stem = 'libdw_emul_hex' if WB == 3 else 'libdw_emul_oct'
 lib = C.CDLL(os.path.join(HERE, 'emul', '_build', stem + '_asan.so'))
 emul_backend._cache[stem + '.so'] = (lib, abi.declare(lib, 'dwe_'))
 tc = load_task_constants()

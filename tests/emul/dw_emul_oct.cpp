@@ -25,25 +25,25 @@ static char g_err[256] = "";
 static int fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
 
 namespace {
-struct WaveArgs { DwHandle *h; const float *a0; const float *a1; long long step; int wave; int kind; dwo::OLds *lds; dw::TaskLds *tlds; };
+struct WaveArgs { DwHandle *h; const float *a0; const float *a1; long long step; int wave; int kind; OCT_NS::OLds *lds; dw::TaskLds *tlds; };
 void wave_body(void *p, int) {
     WaveArgs *w = (WaveArgs *)p;
     DwHandle *h = w->h;
     switch (w->kind) {
     case 0:
-        if (h->cfg.terrain) dwo::oct_simulate<true>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
-        else dwo::oct_simulate<false>(w->lds->w[w->wave % dwo::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
+        if (h->cfg.terrain) OCT_NS::oct_simulate<true>(w->lds->w[w->wave % OCT_NS::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
+        else OCT_NS::oct_simulate<false>(w->lds->w[w->wave % OCT_NS::WPG], w->lds->hot, h->qmodel, h->model, h->dp.C.phys, h->dp.C.friction, h->cfg.num_envs, make_obuf(make_hot(h->dp.B), &h->dp.B), w->a0, w->a1, w->wave);
         break;
     case 1: {
         // DwConfig.debug_wave_build = 1: the register-resident form of the one-wave-per-SIMD build (dw_oct_kernels.h KEEP), which the
         // HIP library uses for launches of at most one wave per SIMD; otherwise the two-waves form (what 16384 envs run)
-        const bool keep = h->cfg.debug_wave_build == 1;
-        dwo::OSlots &sl = w->lds->w[w->wave % dwo::WPG];
+        const bool keep = h->cfg.debug_wave_build == 1 || OCT_NS::LPE == 16;          // (the hex instantiation has the one-wave-per-SIMD form only)
+        OCT_NS::OSlots &sl = w->lds->w[w->wave % OCT_NS::WPG];
         const OBuf ob = make_obuf(make_hot(h->dp.B), &h->dp.B);
-        if (h->cfg.terrain && keep) dwo::oct_step<true, -1, true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else if (h->cfg.terrain) dwo::oct_step<true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else if (keep) dwo::oct_step<false, -1, true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
-        else dwo::oct_step<false>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
+        if (h->cfg.terrain && keep) OCT_NS::oct_step<true, -1, true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else if (h->cfg.terrain) OCT_NS::oct_step<true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else if (keep) OCT_NS::oct_step<false, -1, true>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
+        else OCT_NS::oct_step<false>(sl, w->lds->hot, h->qmodel, h->model, h->dp.C, ob, w->a0, h->mocap, w->a1, w->step, w->wave);
     }
         break;
     }
@@ -51,11 +51,11 @@ void wave_body(void *p, int) {
 int run_waves(DwHandle *h, int kind, const float *a0, const float *a1, long long step) {
     // a workgroup = two waves with one copy of the hot tables; the waves are independent (each stages the tables itself), so
     // they run one after the other here.  Odd env counts leave the last workgroup's second wave without envs: it still runs.
-    const int nw = (h->cfg.num_envs + dwo::EPO * dwo::WPG - 1) / (dwo::EPO * dwo::WPG) * dwo::WPG;
-    dwo::OLds *lds = (dwo::OLds *)aligned_alloc(64, (sizeof(dwo::OLds) + 63) / 64 * 64);
+    const int nw = (h->cfg.num_envs + OCT_NS::EPO * OCT_NS::WPG - 1) / (OCT_NS::EPO * OCT_NS::WPG) * OCT_NS::WPG;
+    OCT_NS::OLds *lds = (OCT_NS::OLds *)aligned_alloc(64, (sizeof(OCT_NS::OLds) + 63) / 64 * 64);
     int rc = DW_OK;
     for (int w = 0; w < nw && rc == DW_OK; ++w) {
-        if ((w % dwo::WPG) == 0) memset(lds, 0xff, sizeof(*lds));           // NaN-fill per workgroup: a read of a never-written slot poisons the result
+        if ((w % OCT_NS::WPG) == 0) memset(lds, 0xff, sizeof(*lds));           // NaN-fill per workgroup: a read of a never-written slot poisons the result
         WaveArgs a{h, a0, a1, step, w, kind, lds, nullptr};
         if (!dwq::run_wave(wave_body, &a)) rc = fail(DW_ESTATE, "octet emulation: lanes disagree on the number of cross-lane operations");
     }
@@ -83,7 +83,7 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     if (rc == DW_OK && h->qmodel.nsteps != dwq::QS_MAX) { rc = DW_EINVAL; err = "octet kernels: built for a schedule of exactly QS_MAX steps"; }
     if (rc) { free(h); return fail(rc, err); }
     h->dp.C = dw::make_task_params(cfg);
-    h->sc_park = (float *)calloc((size_t)(cfg->num_envs + 15) / 16 * 2 * 64 * dwo::SC_PARK_WORDS, sizeof(float));
+    h->sc_park = (float *)calloc((size_t)((cfg->num_envs + OCT_NS::EPO * OCT_NS::WPG - 1) / (OCT_NS::EPO * OCT_NS::WPG)) * OCT_NS::WPG * 64 * OCT_NS::SC_PARK_WORDS, sizeof(float));
     h->dp.C.phys.sc_park = h->sc_park;
     if (task) {
         h->mocap = (float *)malloc(sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
@@ -151,7 +151,7 @@ int dwe_reset_idx(DwHandle *h, const int32_t *ids, int32_t n, const float *noise
     delete S;
     return DW_OK;
 }
-int dwe_lds_bytes(void) { return (int)sizeof(dwo::OLds); }
+int dwe_lds_bytes(void) { return (int)sizeof(OCT_NS::OLds); }
 
 // the derived schedule, for tests/test_quad_schedule.py: out[0] = nsteps, then [step][lane] bodies (outward order)
 int dwe_quad_schedule(DwHandle *h, int32_t *out, int32_t cap) {

@@ -10,9 +10,9 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
 _cache = {}
 
 
-def load(asan=False):
-    # the octet kernels (also carries the fused TocabiAMPLower kernels)
-    name = "libdw_emul_oct" + ("_asan.so" if asan else ".so")
+def load(asan=False, hex=False):
+    # the octet kernels (also carries the fused TocabiAMPLower kernels), or the same source as the 16-lanes-per-env instantiation
+    name = ("libdw_emul_hex" if hex else "libdw_emul_oct") + ("_asan.so" if asan else ".so")
     if name not in _cache:
         subprocess.check_call(["make", "-C", HERE, "-s", "_build/" + name])
         lib = C.CDLL(os.path.join(HERE, "_build", name))
@@ -22,8 +22,9 @@ def load(asan=False):
 
 class EmulSim(OracleSim):
     def __init__(self, num_envs, task_const=None, **cfg_over):
-        # cfg_over debug_wave_build = 1: the register-resident (KEEP) form of the step, 0 / 2: the two-waves form
-        super().__init__(num_envs, task_const=task_const, lib_api=load(), **cfg_over)
+        # cfg_over debug_wave_build = 1: the register-resident (KEEP) form of the step, 0 / 2: the two-waves form, 3: the hex
+        # instantiation (16 lanes per env; its own library, the same source compiled with OCT_LPE = 16)
+        super().__init__(num_envs, task_const=task_const, lib_api=load(hex=cfg_over.get("debug_wave_build", 0) == 3), **cfg_over)
 
 
 class EmulBackend:

@@ -9,12 +9,13 @@ from oracle import parity as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 2], ids=["by_size", "two_waves"])
+@pytest.fixture(params=[0, 2, 3], ids=["by_size", "two_waves", "hex"])
 def wave_build(request):
     """The step / substep kernels are two builds of one source (dw_oct_kernels.hip): the one-wave-per-SIMD build keeps its per-joint
     state in registers and is what launches of N <= 8192 get; the two-waves build parks that state in HBM and is what the 16384-env
-    headline runs.  0 = chosen by launch size (what a user gets), 2 = the two-waves build forced (DwConfig.debug_wave_build), so that
-    every small-N parity test below also checks the production-size code path bit for bit."""
+    headline runs.  0 = chosen by launch size (what a user gets: the hex instantiation up to 4096 envs), 2 = the two-waves build of
+    the octet kernels forced (DwConfig.debug_wave_build), so that every small-N parity test below also checks the production-size
+    code path bit for bit, 3 = the hex instantiation forced (16 lanes per env; the same source compiled with OCT_LPE = 16)."""
     return request.param
 
 

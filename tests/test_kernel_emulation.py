@@ -10,11 +10,12 @@ from oracle import parity as P
 from oracle.oracle import OracleSim
 
 
-@pytest.fixture(params=[2, 1], ids=["two_waves", "keep"])
+@pytest.fixture(params=[2, 1, 3], ids=["two_waves", "keep", "hex"])
 def wave_build(request):
     """Both forms of the octet step (dw_oct_kernels.h) run the same checks: 2 = the two-waves-per-SIMD form, which parks its
     per-joint state in global memory across the physics (what 16384 envs run on the GPU), 1 = the register-resident form of the
-    one-wave-per-SIMD build (KEEP; launches of N <= 8192).  DwConfig.debug_wave_build selects; dw_simulate has one form."""
+    one-wave-per-SIMD build (KEEP; launches of N <= 8192), 3 = the hex instantiation (the same source with 16 lanes per env, what
+    launches of N <= 4096 run).  DwConfig.debug_wave_build selects; dw_simulate has one form per lane layout."""
     return request.param
 
 

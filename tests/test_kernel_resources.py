@@ -56,7 +56,7 @@ def usage():
             u.update(r)
     # (the tracked record under profiles/ is refreshed on request only: DW_WRITE_PROFILES=1 python -m pytest tests/test_kernel_resources.py)
     if os.environ.get("DW_WRITE_PROFILES") == "1":
-        json.dump(u, open(os.path.join(ROOT, "profiles", "r04_kernel_resources.json"), "w"), indent=1, sort_keys=True)
+        json.dump(u, open(os.path.join(ROOT, "profiles", "r05_kernel_resources.json"), "w"), indent=1, sort_keys=True)
     return u
 
 
@@ -76,6 +76,15 @@ def test_spread_build_of_the_octet_kernels(usage):
         a, b = usage[k % ""], usage[k % ",1"]
         assert b["Occupancy"] == 1 and b["ScratchSize"] == 0, (k, b)
         assert b["LDS Size"] == a["LDS Size"] and b["VGPRs"] + b["AGPRs"] <= 512, (k, a, b)
+
+
+def test_hex_instantiation_budget(usage):
+    """The 16-lanes-per-env instantiation (dw_hex_kernels.hip; launches of at most 4096 envs): one wave per SIMD by construction, so
+    the whole register file and no scratch, and LDS small enough that a CU could hold more than the four workgroups it gets."""
+    for k in ("dw_k_step_hex<false>", "dw_k_step_hex<true>", "dw_k_simulate_hex<false>", "dw_k_simulate_hex<true>", "dw_k_step_hex<false>[cpu flavour]"):
+        r = usage[k]
+        assert r["ScratchSize"] == 0 and r["Occupancy"] == 1, (k, r)
+        assert r["VGPRs"] + r["AGPRs"] <= 512 and r["LDS Size"] <= 40960, (k, r)
 
 
 def test_terrain_step_kernel_scratch_is_bounded(usage):
