@@ -83,10 +83,15 @@ class AmpEmul:
 
     def reset_done(self, draws=None):
         ids = np.nonzero(self.a["reset_buf"])[0]
+        if isinstance(draws, dict):          # numpy arrays by name -> the C struct (kept alive until the call returns)
+            d = abi.DwAmpResetDraws()
+            for n in abi.AMP_RESET_DRAW_NAMES:
+                setattr(d, n, draws[n].ctypes.data)
+            draws = C.byref(d)
         self._chk(self.sim.api["amp_reset_done"](self.sim.h, C.byref(self.c), C.byref(self.b), draws, None))
         return ids
 
-    def step(self, actions, z=(None, None), rootvel_noise=None, ramp=(None, None)):
+    def step(self, actions, z=(None, None), rootvel_noise=None, ramp=(None, None), sync_physics=None):
         api, h, c, b = self.sim.api, self.sim.h, C.byref(self.c), C.byref(self.b)
         p = lambda t: None if t is None else t.ctypes.data
         actions = np.ascontiguousarray(actions, dtype=np.float32)

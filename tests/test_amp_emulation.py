@@ -134,3 +134,70 @@ def test_reset_done_leaves_dof_properties_alone_without_task_randomize():
     assert len(ids) == N and (env.a["reset_buf"] == 0).all()
     assert (env.a["randomize_buf"] == 7).all()
     assert np.array_equal(env.sim.buf["dof_damping"], damp) and np.array_equal(env.sim.buf["dof_armature"], arm)
+
+
+def test_philox_restatement_known_answers():
+    """oracle/amp_draws.py's Philox4x32-10 against the known-answer vectors of Random123 (kat_vectors: zero counter / key, and the
+    digits-of-pi counter with key a4093822 299f31d0)."""
+    from oracle.amp_draws import philox4x32_10
+    c = np.array([[0, 0, 0, 0], [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xffffffff] * 4], dtype=np.uint32)
+    assert philox4x32_10(c[0:1], 0, 0)[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox4x32_10(c[1:2], 0xa4093822, 0x299f31d0)[0].tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert philox4x32_10(c[2:3], 0xffffffff, 0xffffffff)[0].tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+def device_vs_caller_draws(dev, cal, steps, sync_physics=None, after=None):
+    """Drives `dev` (device_draws = 1) and `cal` (device_draws = 0, every draw handed over from oracle/amp_draws.py, the numpy
+    restatement of the kernels' generator) side by side.  Both are AmpEmul-like: .a tables, .c config, reset_done(draws), step(...).
+    Returns the number of resets seen; `after(tag)` compares."""
+    import ctypes as C
+    from isaacgymdyros_amd import abi
+    from oracle.amp_draws import AmpDraws
+    N = dev.N
+    gen = AmpDraws(dev.c.seed, N)
+    ctr = np.zeros(N, dtype=np.uint64)          # the test's own count of the envs' draw counters
+    rng = np.random.default_rng(11)
+    resets = 0
+    for t in range(steps):
+        rmask = dev.arrays()["reset_buf"] != 0 if hasattr(dev, "arrays") else dev.a["reset_buf"] != 0
+        resets += int(rmask.sum())
+        u = gen.reset(ctr, int(dev.c.delay_idx_range[0]), int(dev.c.delay_idx_range[1]))
+        dev.reset_done()
+        cal.reset_done(u)
+        ctr = ctr + rmask.astype(np.uint64)
+        after((t, "reset"))
+        act = ((rng.random((N, 12), dtype=np.float32) * 2 - 1) * 0.9).astype(np.float32)
+        rd, ru = gen.ramp(ctr)
+        z = [gen.encoder(ctr, k) for k in range(dev.K)]
+        nz = gen.rootvel(ctr)
+        dev.step(act, sync_physics=sync_physics)
+        cal.step(act, z=tuple(z), rootvel_noise=nz, ramp=(rd, ru), sync_physics=sync_physics)
+        ctr = ctr + np.uint64(1)
+        after((t, "step"))
+    return resets, ctr
+
+
+def test_device_draws_equal_caller_draws_from_the_numpy_restatement():
+    """The device-draws form of the fused kernels (what bench.py's amp_lower leg times) against the caller-draws form fed from an
+    independent restatement of the generator (oracle/amp_draws.py): every integer and uniform-derived piece of state bit-identical, what
+    passes through the encoder's Box-Muller to the rounding of log / cos.  On the host emulation here; tests/test_amp_gpu.py repeats it on
+    the device."""
+    N = 6
+    kw = dict(seed=23, episode_length=9.0, hist_ring=True)
+    dev, cal = make(N, device_draws=True, **kw), make(N, device_draws=False, **kw)
+    exact = ["actions", "commands", "start_target_vel", "final_target_vel", "vel_change_duration", "cur_vel_change_duration", "epi_len", "power_scale",
+             "delay_idx", "simul_len", "qpos_bias", "quat_bias", "progress_buf", "randomize_buf", "reset_buf", "terminate_buf", "perturb_timing", "hist_head",
+             "action_history", "action_log", "tau"]
+    close = {"qpos_noise": 3e-9, "qvel_noise": 3e-6, "obs_buf": 3e-5, "rew_buf": 3e-6}
+
+    def after(tag):
+        for n in exact:
+            assert np.array_equal(dev.a[n], cal.a[n]), (tag, n)
+        for n, tol in close.items():
+            assert np.abs(dev.a[n].astype(np.float64) - cal.a[n]).max() <= tol, (tag, n)
+        for k in ("dof_damping", "dof_armature", "root_states", "dof_state"):
+            assert np.allclose(dev.sim.buf[k], cal.sim.buf[k], rtol=0, atol=1e-5), (tag, k)
+        assert np.array_equal(dev.sim.buf["dof_damping"], cal.sim.buf["dof_damping"]), tag
+    resets, ctr = device_vs_caller_draws(dev, cal, 30, after=after)
+    assert resets >= 2 * N
+    assert np.array_equal(dev.a["draw_ctr"].astype(np.uint64), ctr)          # one per step and one per reset, counted here independently

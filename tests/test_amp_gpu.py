@@ -738,6 +738,41 @@ class _HipAmp:
         torch.cuda.synchronize()
         return {n: v.cpu().numpy() for n, v in self.t.items()}
 
+    # ---- the AmpEmul-like driver interface of tests/test_amp_emulation.py::device_vs_caller_draws
+    @property
+    def a(self):
+        return self.arrays()
+
+    def _dev(self, x):
+        if x is None:
+            return None
+        t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr())
+
+    def reset_done_with(self, draws):
+        from isaacgymdyros_amd import abi
+        self._keep = []
+        d = None
+        if draws is not None:
+            d = abi.DwAmpResetDraws()
+            for n in abi.AMP_RESET_DRAW_NAMES:
+                setattr(d, n, self._dev(draws[n]).value)
+            d = C.byref(d)
+        self._chk(self.api["amp_reset_done"](self.h, C.byref(self.c), C.byref(self.b), d, None))
+        torch.cuda.synchronize()
+
+    def step(self, actions, z=(None, None), rootvel_noise=None, ramp=(None, None), sync_physics=None):
+        self._keep = []
+        c, b = C.byref(self.c), C.byref(self.b)
+        self._chk(self.api["amp_step_begin"](self.h, c, b, self._dev(actions), self._dev(ramp[0]), self._dev(ramp[1]), None))
+        for k in range(self.K):
+            self.env.simulate(self.t["tau"])
+            if k + 1 < self.K:
+                self._chk(self.api["amp_step_mid"](self.h, c, b, self._dev(z[k]), k + 1, None))
+        self._chk(self.api["amp_step_end"](self.h, c, b, self._dev(z[self.K - 1]), self.K - 1, self._dev(rootvel_noise), None))
+        torch.cuda.synchronize()
+
 
 def test_fused_amp_kernels_with_device_draws_equal_their_host_emulation():
     """sim.mi355.amp_device_draws: the draws are made inside the kernels, so torch has nothing to compare with -- the checker is the
@@ -801,6 +836,44 @@ def test_fused_amp_kernels_with_device_draws_equal_their_host_emulation():
         compare((t, "end"))
     assert resets >= 2 * N
     g.env.close()
+
+
+def test_device_draws_equal_caller_draws_from_the_numpy_restatement():
+    """the device-draws form of the fused kernels -- what bench.py's amp_lower leg times -- had no checker but the
+    host emulation of its own source.  Here it runs next to the caller-draws form of the same entry points, every draw handed over from
+    oracle/amp_draws.py, an independent numpy restatement of the generator (Philox4x32-10 pinned by Random123's known-answer vectors,
+    the key / stream / word scheme restated from the reference's draw sites); the caller-draws form in turn equals the torch
+    implementation of the class bit for bit (test_tocabi_amp_lower_fused_step_equals_torch_step), which replays the reference class.
+    Bars: integer and uniform-derived state bit-identical; what passes through the device's fast log / cos (the encoder's Box-Muller)
+    to their rounding; the draw counters equal the test's own count (one per step, one per reset)."""
+    from test_amp_emulation import device_vs_caller_draws
+    N = 37
+    kw = dict(seed=29, episode_length=9.0, hist_ring=True)
+    dev, cal = _HipAmp(N, device_draws=True, **kw), _HipAmp(N, device_draws=False, **kw)
+    cal.t["total_mass"].copy_(dev.t["total_mass"])
+    for k in ("mass_scale", "total_mass"):          # (each env randomised its link masses at setup from its own generator state)
+        cal.env._buf[k].copy_(dev.env._buf[k])
+    dev.reset_done = lambda: dev.reset_done_with(None)
+    cal.reset_done = lambda u=None: cal.reset_done_with(u)
+    exact = ["actions", "commands", "start_target_vel", "final_target_vel", "vel_change_duration", "cur_vel_change_duration", "epi_len", "power_scale",
+             "delay_idx", "simul_len", "qpos_bias", "quat_bias", "progress_buf", "randomize_buf", "reset_buf", "terminate_buf", "perturb_timing", "hist_head",
+             "action_history", "action_log"]
+    # (the device's fast log / cos against numpy's: 1e-6 of a 5e-5 rad draw, which can move the sum q + draw by one ulp of q -- 1.2e-7
+    #  below 2 rad -- and the encoder's rate (difference of two such sums / 2 ms) by 1.2e-4; the observation divides by its scales)
+    close = {"qpos_noise": 1.3e-7, "qvel_noise": 2e-4, "tau": 1e-3, "obs_buf": 5e-3, "rew_buf": 1e-3}
+
+    def after(tag):
+        da, ca = dev.arrays(), cal.arrays()
+        for n in exact:
+            assert np.array_equal(da[n], ca[n]), (tag, n)
+        for n, tol in close.items():
+            assert np.abs(da[n].astype(np.float64) - ca[n]).max() <= tol, (tag, n, float(np.abs(da[n].astype(np.float64) - ca[n]).max()))
+        for k in ("dof_damping", "dof_armature"):
+            assert torch.equal(dev.env._buf[k], cal.env._buf[k]), (tag, k)
+    resets, ctr = device_vs_caller_draws(dev, cal, 30, after=after)
+    assert resets >= 2 * N
+    assert np.array_equal(dev.arrays()["draw_ctr"].astype(np.uint64), ctr)
+    dev.env.close(); cal.env.close()
 
 
 def test_tocabi_amp_lower_device_draws_class_level():
