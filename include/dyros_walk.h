@@ -55,7 +55,7 @@ extern "C" {
 #define DW_MAX_GEOMS    64
 #define DW_NUM_FOOT_PTS  8   /* 4 sole corners per foot                                   */
 #define DW_MAX_SC_PROXIES 16  /* capsule proxies for self-collision                        */
-#define DW_MAX_SC_PAIRS   32  /* proxy pairs tested each substep                           */
+#define DW_MAX_SC_PAIRS   64  /* proxy pairs tested each substep                           */
 #define DW_NUM_ACT      13   /* 12 leg torques + 1 gait-clock action                      */
 #define DW_NUM_LOWER    12
 #define DW_NUM_OBS1     37   /* single-step observation                                   */
@@ -94,9 +94,10 @@ typedef struct DwGeom {
 
 /* Capsule proxy of a link for self-collision (the reference collides every primitive with every other one:
  * create_actor(..., group=i, filter=0), tasks/dyros_dynamic_walk.py:354).  Segment end points in the moving body's
- * frame.  Shipped model: 4 proxies per leg (all 16 left x right pairs), upper arm / forearm / hand per arm and the torso
- * (forearm and hand against torso and same-side thigh, hand against the other thigh, upper arm against torso, arm against
- * arm): 15 proxies, 32 pairs (DW_MAX_SC_PAIRS, the table is full). */
+ * frame.  Shipped model: 4 proxies per leg (all 16 left x right pairs), upper arm / forearm / hand per arm, the torso and
+ * the head (forearm and hand against torso, head and same-side thigh; hand against the other thigh and the same-side shank;
+ * forearm against the other thigh; upper arm against torso, same-side thigh and the other arm; arm against arm):
+ * 16 proxies (DW_MAX_SC_PROXIES, the table is full), 47 pairs of at most DW_MAX_SC_PAIRS = 64. */
 typedef struct DwCapsule {
     int32_t moving, gym;
     float   p0[3], p1[3];

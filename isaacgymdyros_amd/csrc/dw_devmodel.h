@@ -17,7 +17,7 @@ constexpr int MAX_PER_LEVEL = 5;    // widest level (legs + arms + neck)
 constexpr int MAX_CHILD = 3;
 constexpr int MAX_BODY_GEOMS = 8;
 constexpr int MAX_BODY_INERT = 2;
-constexpr int MAX_BODY_PAIRS = 8;
+constexpr int MAX_BODY_PAIRS = 12;
 constexpr int MAX_CHAINS = 8;        // unbranched runs of the tree (legs, torso, arms, neck)
 constexpr int MAX_CHAIN_LEN = 8;
 constexpr int MAX_PHASES = 3;        // chains hanging off chains: base -> torso -> arms    // self-collision pairs one body takes part in

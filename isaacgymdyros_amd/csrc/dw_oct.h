@@ -89,7 +89,8 @@ constexpr int NQ = LPE / 4;          // quads ("halves" / quarters) of an env
 #define OCT_WPG 2
 #endif
 constexpr int WPG = OCT_WPG;         // wavefronts per workgroup (they share the hot tables, nothing else)
-constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 1;      // per lane: PhysParams::sc_park
+constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 2;      // per lane: PhysParams::sc_park (the wrenches of up to QMAX_OWN own proxies, their Gym bodies one byte each)
+static_assert(QMAX_OWN <= 8, "the Gym bodies of a lane's own proxies travel in two words, one byte each");
 
 // One wave's body slots: slot[body * 4 + row][position], 64 bytes per body and env.  A row is 8 envs x 16 B
 // = 128 B, half the width of the LDS (64 banks x 4 B); the position code (pcode_cell below) rotates a limb's column by two per limb,
@@ -384,7 +385,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     if (P.self_collision && npair > 0) {
 #endif
         DQ_STAMP(B, 51);
-        int hits = 0;
+        unsigned long long hits = 0ull;          // bit k: pair k may touch (up to DW_MAX_SC_PAIRS = 64 pairs)
         {
             // the axes, built ONCE per proxy: octet lane o has proxy o (class 0) and proxy o + 8 (class 1) -- origin point and direction in
             // the common frame, from the proxy's body slot.  (Until round 5 every pair test rebuilt both of its proxies: 64 builds for 15.)
@@ -418,19 +419,21 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 float a[6], b[6];
                 DQ_UNROLL for (int i = 0; i < 6; ++i) { a[i] = oct_fetch(Ea[i], la); b[i] = oct_fetch(Eb[i], lb); }
                 const float rv[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
-                if (live && pid != 127 && seg_dist2_fast(&a[3], &b[3], rv) < half_bits_to_float((w >> 16) & 0xffff)) hits |= 1 << pid;
+                if (live && pid != 127 && seg_dist2_fast(&a[3], &b[3], rv) < half_bits_to_float((w >> 16) & 0xffff)) hits |= 1ull << pid;
             };
             for (int k = 0; k * NOCT < nr0; ++k) round(0, k, nr0, E[0], E[0]);          /*@trip:2*/
             for (int k = 0; k * NOCT < nr1; ++k) round(nr0, k, nr1, E[1], E[1]);          /*@trip:2*/
             for (int k = 0; k * NOCT < nr2; ++k) round(nr0 + nr1, k, nr2, E[1], E[0]);          /*@trip:1*/
         }
         {   // the env's mask: OR over the octet (bit patterns through the DPP moves)
-            int m = hits;
-            m |= f2i(quad_xor1(__builtin_bit_cast(float, m)));
-            m |= f2i(quad_xor2(__builtin_bit_cast(float, m)));
-            m |= f2i(oct_xor4(__builtin_bit_cast(float, m)));
-            if (LPE == 16) m |= f2i(hex_xor8(__builtin_bit_cast(float, m)));
-            hits = m;
+            int m[2] = {(int)(unsigned int)hits, (int)(unsigned int)(hits >> 32)};
+            DQ_UNROLL for (int w = 0; w < 2; ++w) {
+                m[w] |= f2i(quad_xor1(__builtin_bit_cast(float, m[w])));
+                m[w] |= f2i(quad_xor2(__builtin_bit_cast(float, m[w])));
+                m[w] |= f2i(oct_xor4(__builtin_bit_cast(float, m[w])));
+                if (LPE == 16) m[w] |= f2i(hex_xor8(__builtin_bit_cast(float, m[w])));
+            }
+            hits = (unsigned long long)(unsigned int)m[0] | ((unsigned long long)(unsigned int)m[1] << 32);
         }
         sc_any = wave_any(hits != 0);
         DQ_STAMP(B, 52);
@@ -439,13 +442,13 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
 #endif
         if (sc_any) {          /*@prob:0*/
             float scW[QMAX_OWN][6];              // wrench (common frame) on my k-th own proxy: [0..2] moment, [3..5] force
-            int scGym0 = 0;                      // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
+            unsigned long long scGym = 0ull;     // Gym body of my k-th own proxy, one byte each (filled for the loaded ones)
             DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) { DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = 0.0f; }
             // every lane works through the touching pairs that involve one of its bodies
-            int mine = hits & (j == 0 ? H.misc[4] : (j == 1 ? H.misc[5] : (j == 2 ? H.misc[6] : H.misc[7])));
+            unsigned long long mine = hits & ((unsigned long long)(unsigned int)H.misc[4 + j] | ((unsigned long long)(unsigned int)H.pairmask_hi[j] << 32));
             while (wave_any(mine != 0)) {
                 if (mine != 0) {
-                    const int pid = __builtin_ctz(mine);
+                    const int pid = __builtin_ctzll(mine);
                     mine &= mine - 1;
                     const int pr = (H.pairs[pid >> 2] >> (8 * (pid & 3))) & 255, pa = pr & 15, pbx = pr >> 4;
                     const int bita = proxy_bits(pa), bitb = proxy_bits(pbx);
@@ -469,13 +472,14 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                             cross3(side ? cb : ca, Fs, nb);
                             DQ_UNROLL for (int kk = 0; kk < QMAX_OWN; ++kk)
                                 if (kk == k) { DQ_UNROLL for (int i = 0; i < 3; ++i) { scW[kk][i] += nb[i]; scW[kk][3 + i] += Fs[i]; } }
-                            scGym0 |= gy << (8 * k);
+                            scGym |= (unsigned long long)gy << (8 * k);
                         }
                     }
                 }
             }
             DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) park[6 * p + i] = scW[p][i];
-            park[6 * QMAX_OWN] = __builtin_bit_cast(float, scGym0);
+            park[6 * QMAX_OWN] = __builtin_bit_cast(float, (int)(unsigned int)scGym);
+            park[6 * QMAX_OWN + 1] = __builtin_bit_cast(float, (int)(unsigned int)(scGym >> 32));
             wave_sync_global();
         }
     }
@@ -584,11 +588,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 if (sc_any && scm) {          /*@prob:0*/
                     float scW[QMAX_OWN][6];
                     DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p) DQ_UNROLL for (int i = 0; i < 6; ++i) scW[p][i] = park[6 * p + i];
-                    const int scGym0 = f2i(park[6 * QMAX_OWN]);
+                    const unsigned long long scGym = (unsigned long long)(unsigned int)f2i(park[6 * QMAX_OWN]) | ((unsigned long long)(unsigned int)f2i(park[6 * QMAX_OWN + 1]) << 32);
                     DQ_UNROLL for (int p = 0; p < QMAX_OWN; ++p)
                         if ((scm >> p) & 1) {
                             DQ_UNROLL for (int i = 0; i < 6; ++i) Mb.pv[i] -= scW[p][i];
-                            const int gy = (scGym0 >> (8 * p)) & 255;     // (0 where unloaded: adds nothing)
+                            const int gy = (int)((scGym >> (8 * p)) & 255ull);     // (0 where unloaded: adds nothing)
                             DQ_UNROLL for (int t = 0; t < QMAX_GYM; ++t)
                                 if (t < ngym && ((gymbits >> (8 * t)) & 255) == gy) { cf[t][0] += scW[p][3]; cf[t][1] += scW[p][4]; cf[t][2] += scW[p][5]; }
                         }

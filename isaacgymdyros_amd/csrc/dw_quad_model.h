@@ -29,7 +29,7 @@ constexpr int EPW = 16;          // environments per wavefront
 constexpr int QS_MAX = 11;       // schedule length bound (TOCABI needs 11; every step costs 448 B of LDS)
 constexpr int QMAX_PROX = 16;    // self-collision proxies
 constexpr int QMAX_ROUNDS = 8;   // detection rounds of the octet kernels (see QHot::scround): 8 pairs each
-constexpr int QMAX_OWN = 4;      // proxies on the bodies of one lane (TOCABI: 4 per leg, torso + 3 on the left arm's lane, 3 on the right arm's)
+constexpr int QMAX_OWN = 5;      // proxies on the bodies of one lane (TOCABI: head + 4 of the left leg, 4 right leg, torso + 3 on the left arm's lane, 3 on the right arm's)
 constexpr int QMAX_GEOM = 6;     // ground primitives per moving body the inward step handles
 constexpr int QMAX_GYM = 3;      // Gym bodies welded into one moving body
 
@@ -82,7 +82,8 @@ struct alignas(16) QHot {
     // threshold 1.004 (ra + rb)^2 as a half-precision number rounded UP (detection is conservative; the force is exact).
     alignas(16) float prox[QMAX_PROX][8];
     int   scround[QMAX_ROUNDS][8];
-    int   pairs[8];
+    int   pairs[16];             // byte k: the proxies of pair k (a | b << 4)
+    int   pairmask_hi[4];        // pairs 32 .. 63 of lane l (misc[4 + l]: pairs 0 .. 31)
 };
 
 struct QuadModel {
@@ -380,7 +381,7 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
     Q->base_bound = geom_bound(0, Q->base_ngeom, Q->base_geom);
     // self-collision: proxies keep the model's order (the model compiler lists a pair as [tested proxy, broadcast proxy] and
     // orders the proxies so that the tested proxies of the pairs sharing a partner sit on different lanes, model.py)
-    if (d->num_sc_pairs > 0 && (d->num_sc_pairs > 32 || DW_MAX_SC_PROXIES > QMAX_PROX)) { *err = "quad model: too many self-collision pairs or proxies"; return DW_EINVAL; }
+    if (d->num_sc_pairs > 0 && (d->num_sc_pairs > 64 || DW_MAX_SC_PROXIES > QMAX_PROX)) { *err = "quad model: too many self-collision pairs or proxies"; return DW_EINVAL; }
     Q->npair = d->num_sc_pairs;
     Q->nprox = 0;
     for (int k = 0; k < d->num_sc_pairs; ++k) for (int side = 0; side < 2; ++side) if (d->sc_pair[k][side] + 1 > Q->nprox) Q->nprox = d->sc_pair[k][side] + 1;
@@ -517,13 +518,15 @@ inline int build_quadmodel(const dw::DevModel *d, const DwModel *dm, QuadModel *
             H.prox[p2][7] = fi((cp.moving & 255) | ((cp.gym & 255) << 8) | ((Q->owner[cp.moving] & 3) << 16) | ((local_of[p2] & 7) << 18));
         }
         for (int r = 0; r < QMAX_ROUNDS; ++r) for (int o = 0; o < 8; ++o) H.scround[r][o] = scround[r][o];
-        for (int i = 0; i < 8; ++i) H.pairs[i] = 0;
-        for (int i = 4; i < 8; ++i) H.misc[i] = 0;
+        for (int i = 0; i < 16; ++i) H.pairs[i] = 0;
+        for (int i = 4; i < 8; ++i) { H.misc[i] = 0; H.pairmask_hi[i - 4] = 0; }
         for (int k = 0; k < d->num_sc_pairs; ++k) {
             const int a = d->sc_pair[k][0], b2 = d->sc_pair[k][1];
             H.pairs[k >> 2] |= (a | (b2 << 4)) << (8 * (k & 3));
-            H.misc[4 + Q->owner[d->sc_proxy[a].moving]] |= 1 << k;
-            H.misc[4 + Q->owner[d->sc_proxy[b2].moving]] |= 1 << k;
+            for (int side = 0; side < 2; ++side) {
+                const int l = Q->owner[d->sc_proxy[side ? b2 : a].moving];
+                if (k < 32) H.misc[4 + l] |= (int)(1u << k); else H.pairmask_hi[l] |= (int)(1u << (k - 32));
+            }
         }
     }
     return DW_OK;

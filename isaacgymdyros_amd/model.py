@@ -41,12 +41,13 @@ NUM_INERT = 36
 MAX_GEOMS = 64
 NUM_FOOT_PTS = 8
 MAX_SC_PROXIES = 16
-MAX_SC_PAIRS = 32
+MAX_SC_PAIRS = 64
 # links that get a self-collision capsule: (left, right) chains thigh / shank / ankle / foot assembly ...
 SC_LEG_BODIES = ("Thigh_Link", "Knee_Link", "AnkleCenter_Link", "Foot_Redundant_Link")
 # ... and, second tranche ("leg<->leg, arm<->torso/leg"): upper arm, forearm, hand of each arm and the torso
 SC_ARM_BODIES = ("Armlink_Link", "Forearm_Link", "Wrist2_Link")
 SC_TORSO_BODY = "Upperbody_Link"
+SC_HEAD_BODY = "Head_Link"
 
 # Per-DoF constants the reference hard-codes in the task (not in the MJCF).
 # reference: tasks/dyros_dynamic_walk.py:366-372 (armature, damping, velocity)
@@ -301,6 +302,25 @@ def compile_mjcf(xml_path: str) -> Dict:
     other = {"L_": "R_", "R_": "L_"}
     for side in ("L_", "R_"):
         sc_pairs.append([idx[side + "Wrist2_Link"], thigh[other[side]]])
+    # fourth tranche (round 5; the kernels' pair table holds 64 since the detection tests pairs in rounds of eight, dw_oct.h): a head
+    # capsule -- the 16th proxy, the table of proxies is full with it -- against forearms and hands; upper arm against the thigh of its
+    # side, forearm against the thigh of the other side, hand against the shank of its side; upper arm against the other arm's upper
+    # arm, forearm and hand.  Still absent from the reference's filter 0: the waist links and the neck (no proxy left), the foot
+    # boxes as boxes.
+    knee = {"L_": 1, "R_": nl + 1}
+    idx[SC_HEAD_BODY] = len(sc_proxies)
+    sc_proxies.append(span_capsule(names.index(SC_HEAD_BODY)))
+    for side in ("L_", "R_"):
+        for part in ("Forearm_Link", "Wrist2_Link"):
+            sc_pairs.append([idx[SC_HEAD_BODY], idx[side + part]])
+    for side in ("L_", "R_"):
+        sc_pairs.append([idx[side + "Armlink_Link"], thigh[side]])
+        sc_pairs.append([idx[side + "Forearm_Link"], thigh[other[side]]])
+        sc_pairs.append([idx[side + "Wrist2_Link"], knee[side]])
+    sc_pairs.append([idx["L_Armlink_Link"], idx["R_Armlink_Link"]])
+    for side in ("L_", "R_"):
+        sc_pairs.append([idx[side + "Armlink_Link"], idx[other[side] + "Forearm_Link"]])
+        sc_pairs.append([idx[side + "Wrist2_Link"], idx[other[side] + "Armlink_Link"]])
 
     model = dict(
         body_names=names,

@@ -533,6 +533,32 @@ def test_self_collision_random_poses_vs_oracle(task_const, model, wave_build):
     assert np.abs(cg - co).max() <= 1e-3 * np.abs(co).max()
 
 
+def test_self_collision_head_and_upper_arm_pairs_vs_oracle(task_const, model, wave_build):
+    """The fourth tranche of pairs on the device (head against forearms / hands, upper arm against thigh and the other arm: pairs 32 ..
+    46, the upper word of the 64-bit hit mask): arm poses over the whole joint range, the loaded Gym bodies equal the oracle's, the head
+    among them, forces 1e-3 relative after one substep."""
+    from hip_backend import make_env
+    from test_kernel_emulation import _random_arm_poses
+    N = 1024
+    env = make_env(N, randomize=False, debug_wave_build=wave_build)
+    b = env._buf
+    b["root_states"][:, 0:2] = 0
+    b["root_states"][:, 2] = 3.0
+    b["dof_state"][..., 0] = torch.from_numpy(_random_arm_poses(N, seed=8)).cuda()
+    b["dof_state"][..., 1] = 0
+    ora = _oracle_like(env, task_const)
+    tau = torch.zeros(N, 33)
+    env.simulate(tau.cuda())
+    ora.simulate(tau.numpy())
+    torch.cuda.synchronize()
+    cg, co = env.contact_forces.cpu().numpy(), ora.buf["contact_forces"]
+    lo = np.linalg.norm(co, axis=2) > 1.0
+    names = list(model.body_names)
+    assert lo[:, names.index("Head_Link")].sum() >= 2
+    assert np.array_equal(np.linalg.norm(cg, axis=2) > 1.0, lo)
+    assert np.abs(cg - co).max() <= 1e-3 * np.abs(co).max()
+
+
 def test_arms_into_torso_vs_oracle(task_const, model, wave_build):
     """Row f-1, second tranche, on the device: arm poses inside the joint limits that press upper arms, forearms and hands
     into the torso, a thigh or the other arm.  Same bars as the leg sweep: forces 1e-3 relative and the same set of loaded

@@ -219,6 +219,44 @@ def _random_poses(N, seed=3):
     return np.clip(q, lo + 1e-3, hi - 1e-3).astype(np.float32)
 
 
+def _random_arm_poses(N, seed=7):
+    """The arms over 90 % of their whole joint range, everything else at the initial pose: a few envs in a hundred put a hand or a
+    forearm on the head (the 16th proxy, round 5) or an upper arm on a thigh."""
+    import json
+    import os
+    from isaacgymdyros_amd.model import load_model, MODEL_JSON
+    from isaacgymdyros_amd.task_constants import INITIAL_DOF_POS
+    m = load_model()
+    dn = json.load(open(MODEL_JSON))["dof_names"]
+    lo, hi = np.minimum(m.dof_lower, m.dof_upper), np.maximum(m.dof_lower, m.dof_upper)
+    arm = [i for i, n in enumerate(dn) if any(k in n for k in ("Shoulder", "Armlink", "Elbow", "Forearm", "Wrist"))]
+    rng = np.random.default_rng(seed)
+    q = np.tile(np.asarray(INITIAL_DOF_POS, np.float32), (N, 1))
+    q[:, arm] = rng.uniform(lo[arm] * 0.9, hi[arm] * 0.9, size=(N, len(arm))).astype(np.float32)
+    return q
+
+
+def test_self_collision_head_and_upper_arm_pairs(model):
+    """The fourth tranche of pairs (head against forearms / hands, upper arm against thigh and against the other arm): arm poses over the
+    whole joint range; the kernel body loads exactly the Gym bodies the oracle loads, the head among them, forces 1e-3."""
+    N = 512
+    A, B = OracleSim(N), EmulSim(N)
+    q = _random_arm_poses(N)
+    for s in (A, B):
+        s.buf["root_states"][:, 0:2] = 0
+        s.buf["root_states"][:, 2] = 3.0
+        s.buf["dof_state"][:, :, 0] = q
+    tau = np.zeros((N, 33), np.float32)
+    A.simulate(tau); B.simulate(tau)
+    ca, cb = A.buf["contact_forces"], B.buf["contact_forces"]
+    la, lb = np.linalg.norm(ca, axis=2) > 1.0, np.linalg.norm(cb, axis=2) > 1.0
+    names = list(model.body_names)
+    assert la[:, names.index("Head_Link")].sum() >= 2
+    assert la[:, [names.index("L_Armlink_Link"), names.index("R_Armlink_Link")]].any(axis=1).sum() >= 8
+    assert np.array_equal(la, lb)
+    assert np.abs(ca - cb).max() <= 1e-3 * np.abs(ca).max()
+
+
 def test_self_collision_random_poses_touch_every_pair_class(wave_build, model):
     """Row f-1 detection (dw_oct.h: axes built once per proxy, pairs tested in rounds by class, a half-precision threshold rounded
     up) must flag every pair the oracle's exhaustive test finds touching: random poses wide enough that leg x leg, arm x torso /
