@@ -155,15 +155,14 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     float *OBN = LF + PL_OBN;                                   // [2][37] mean, divisor
     const float c_om = M.obs_mean[lo1], c_od = M.obs_inv_std_den[lo1];            // (stored below, after the records' requests)
     // (nominal damping / armature of the joints whose randomisation words this lane draws at a reset: requested here, with everything else)
-    constexpr int DR_B0 = DW_NZ_DR_DAMP / 4, DR_NBLK = DW_NZ_DR_FRIC / 4 - DR_B0 + 1, DR_NPASS = (DR_NBLK + 7) / 8;
-    float dr_nom[DR_NPASS][4];
-    DQ_UNROLL for (int p2 = 0; p2 < DR_NPASS; ++p2) {
-        DQ_UNROLL for (int i = 0; i < 4; ++i) {
-            const int w = 4 * (DR_B0 + j + 8 * p2) + i;
-            const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
-            const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
-            dr_nom[p2][i] = (isa ? M.arm_nom : M.damp_nom)[l];
-        }
+    constexpr int DR_B0 = DW_NZ_DR_DAMP / 4, DR_NBLK = DW_NZ_DR_FRIC / 4 - DR_B0 + 1;
+    float dr_nom[4];          // (lane 8 + b draws block DR_B0 + b at a reset)
+    DQ_UNROLL for (int i = 0; i < 4; ++i) {
+        const int bl = lane >= 8 && lane < 8 + DR_NBLK ? lane - 8 : 0;
+        const int w = 4 * (DR_B0 + bl) + i;
+        const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
+        const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
+        dr_nom[i] = (isa ? M.arm_nom : M.damp_nom)[l];
     }
     // ---- stage: joint state, base state, contact summary, the 16 task records ----
     DQ_UNROLL for (int k = 0; k < ONI; ++k) {
@@ -394,7 +393,6 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
     const bool any_reset = wave_any(PQ_PSI(el, PS_RESET) != 0);
     if (any_reset) {          /*@prob:0.18*/
         const bool mine = PQ_PSI(el, PS_RESET) != 0;
-        const bool mine8 = mine && j < 8;          // (the draws and the joint loops below are laid out for eight lanes per env; the hex layout's lanes 8 .. 15 stand by)
         if (C.terrain_curriculum && j == 0 && mine) {
             const float d[2] = {PQ_ROOT(el, 0) - c_org0, PQ_ROOT(el, 1) - c_org1};
             const float distance = dw::norm_sel_v<2>(gnorm, d);
@@ -415,115 +413,111 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             if (xvalid) OQ_COLD(terrain_levels)[e] = lvl;
         }
         wave_sync();
-        // ALL envs that ended at once, each on its own eight lanes (a pass per ended env made the launch wait for the waves
-        // with several: tools/wave_times.py).  The 32 uniform words DW_NZ_QPOS_BIAS .. DW_NZ_PTIMING of an env are eight
-        // generator blocks: one per lane, each word transformed and stored by the lane that drew it.
+        // ONE ended env at a time, on all 64 lanes (round 5).  Until then every ended env worked on its own eight lanes: 4 generator
+        // blocks per lane in a row (the 32 reset words = 8 blocks, the 67 randomisation words = 18), five passes over the joints, nine
+        // over the torque FIFO and the action ring -- and since a wave nearly always has ONE ended env (tools/wave_times.py: 6 555 of
+        // 7 156 resetting waves), 56 lanes watched 8 work: 13 k cycles that the whole launch then waits for, because some SIMD holds two
+        // such waves in every step.  Now lane L draws block L of the env (0 .. 7 the reset words, 8 .. 25 the randomisation words): one
+        // generator call deep, one pass over the joints, two over the FIFO and the ring; k ended envs take k turns.
         static_assert(DW_NZ_QPOS_BIAS % 4 == 0 && DW_NZ_PTIMING < DW_NZ_QPOS_BIAS + 32, "reset words: eight blocks per env");
-        const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(el, PS_RANDOMIZE) >= 1;
+        static_assert(DW_NZ_DR_ARM == DW_NZ_DR_DAMP + DW_NUM_DOF && DW_NZ_DR_FRIC == DW_NZ_DR_ARM + DW_NUM_DOF, "DR words are contiguous");
+        static_assert(8 + DR_NBLK <= 64 && ND <= 64, "one generator block and one joint per lane");
         DQ_WT();
-        // (branch-free: a lane-dependent branch per word made a chain of short blocks, each with its own waits; a store that does
-        //  not apply goes to the env's spare scratch word)
-        const int dummy = PL_PS + el * 32 + 31;
         int *LI = reinterpret_cast<int *>(LF);
-        if (mine8) {
-            float u[4];
-            dw::noise_block(K.nz, DW_NZ_QPOS_BIAS / 4 + j, u);
-            const bool gd = C.gpu_div != 0;
-            const int esb = PL_ES + el * PL_ES_STRIDE;
-            DQ_UNROLL for (int i = 0; i < 4; ++i) {
-                const int w = DW_NZ_QPOS_BIAS + 4 * j + i;
-                const bool isq = w < DW_NZ_QUAT_BIAS, isb = !isq && w < DW_NZ_TARGET_VEL, ist = w == DW_NZ_TARGET_VEL;
-                const bool ism = w >= DW_NZ_MOTOR && w < DW_NZ_DELAY;
-                const float x = u[i] * (w < DW_NZ_TARGET_VEL ? 6.28f : (ist ? 0.8f : 0.4f));
-                // divs(gpu_div, x, 100.0 | 150.0) - (float)(3.14 / 100 | 150)
-                const float dv = isq ? 100.0f : 150.0f, rv = isq ? (float)(1.0 / 100.0) : (float)(1.0 / 150.0);
-                const float cv = isq ? (float)(3.14 / 100) : (float)(3.14 / 150);
-                const float yd = (gd ? x * rv : x / dv) - cv;
-                const float y = (isq || isb) ? yd : (ist ? x * 1.0f : x + 0.8f);
-                int k4 = (int)(u[i] * 4.0f), kt = (int)(u[i] * 2000.0f);
-                k4 = k4 > 3 ? 3 : k4; kt = kt > 1999 ? 1999 : kt;
-                const int bits = w == DW_NZ_INIT_MOCAP ? (u[i] > 0.5f ? 0 : 1800) : (w == DW_NZ_DELAY ? 2 + k4 : (w == DW_NZ_PTIMING ? kt : f2i(y)));
-                const int dst = isq ? DW_ES_QPOS_BIAS + (w - DW_NZ_QPOS_BIAS) : isb ? DW_ES_QUAT_BIAS + (w - DW_NZ_QUAT_BIAS)
-                              : ist ? DW_ES_TARGET_VEL : w == DW_NZ_INIT_MOCAP ? DW_ES_INIT_MOCAP : ism ? DW_ES_MOTOR_SCALE + (w - DW_NZ_MOTOR)
-                              : w == DW_NZ_DELAY ? DW_ES_DELAY_IDX : w == DW_NZ_PTIMING ? DW_ES_PERT_TIMING : -1;
-                LI[dst >= 0 ? esb + dst : dummy] = bits;
-                if (i == DW_NZ_TARGET_VEL % 4) LF[ist ? esb + DW_ES_TARGET_VEL + 1 : dummy] = x * 0.0f;
-            }
-        }
-        DQ_WT();
-        if (wave_any(mine && do_dr)) {
-            // dof-property and friction randomisation (vec_task.py:519-733; `randomize` is on in the yaml, so every reset passes
-            // here): the 67 uniform words DW_NZ_DR_DAMP .. DW_NZ_DR_FRIC are 18 generator blocks, three per lane at most,
-            // and a word goes from the lane that drew it straight to its place
-            static_assert(DW_NZ_DR_ARM == DW_NZ_DR_DAMP + DW_NUM_DOF && DW_NZ_DR_FRIC == DW_NZ_DR_ARM + DW_NUM_DOF, "DR words are contiguous");
-            constexpr int B0 = DR_B0, NBLK = DR_NBLK, NPASS = DR_NPASS;
-            float u[NPASS][4] = {};
-            const bool go = mine8 && do_dr;
-            if (go) { DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) dw::noise_block(K.nz, B0 + j + 8 * p2 < B0 + NBLK ? B0 + j + 8 * p2 : B0, u[p2]); }
-            const float d0 = C.dr_damp[0], d1 = C.dr_damp[1] - C.dr_damp[0], a0 = C.dr_arm[0], a1 = C.dr_arm[1] - C.dr_arm[0];
-            const float f0 = C.dr_fric[0], f1 = C.dr_fric[1] - C.dr_fric[0];
-            DQ_UNROLL for (int p2 = 0; p2 < NPASS; ++p2) {
+        unsigned long long todo = wave_ballot(mine && j == 0);          // bit LPE * el: env el of this wave ended
+        while (todo != 0ull) {
+            const int er = (int)(__builtin_ctzll(todo) / LPE);          // (wave-uniform)
+            todo &= todo - 1ull;
+            const int egr = wave_index * EPO + er, eg = egr < N ? egr : N - 1;
+            const bool rvalid = egr < N;
+            dw::NoiseSrc nz = K.nz;
+            nz.rec = noise ? noise + (size_t)DW_NOISE_WORDS * eg : nullptr; nz.env = (unsigned int)eg;
+            const bool do_dr = (C.dr_dof || C.dr_friction) && PQ_PSI(er, PS_RANDOMIZE) >= 1;
+            const int esb = PL_ES + er * PL_ES_STRIDE;
+            const int dummy = PL_PS + er * 32 + 31;          // (a store that does not apply goes to the env's spare scratch word: branch-free)
+            // ---- the draws: lanes 0 .. 7 the reset words, lanes 8 .. 8 + DR_NBLK - 1 the dof-property / friction words (vec_task.py:519-733;
+            //      `randomize` is on in the yaml, so every reset passes there) ----
+            const bool l_reset = lane < 8, l_dr = lane >= 8 && lane < 8 + DR_NBLK && do_dr;
+            float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (l_reset || l_dr) dw::noise_block(nz, l_reset ? DW_NZ_QPOS_BIAS / 4 + lane : DR_B0 + (lane - 8), u);
+            if (l_reset) {
+                const bool gd = C.gpu_div != 0;
                 DQ_UNROLL for (int i = 0; i < 4; ++i) {
-                    const int w = 4 * (B0 + j + 8 * p2) + i;
-                    const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
-                    const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
-                    const float sd = d0 + u[p2][i] * d1, sa = a0 + u[p2][i] * a1;
-                    if (go && xvalid && C.dr_dof && (isd || isa)) oq_at(isa ? B.dof_armature : B.dof_damping, oq_row(ND, e) + l) = isa ? dr_nom[p2][i] * sa : dr_nom[p2][i] + sd;
-                    if (go && xvalid && C.dr_friction && w == DW_NZ_DR_FRIC) OQ_COLD(friction_scale)[e] = f0 + u[p2][i] * f1;
+                    const int w = DW_NZ_QPOS_BIAS + 4 * lane + i;
+                    const bool isq = w < DW_NZ_QUAT_BIAS, isb = !isq && w < DW_NZ_TARGET_VEL, ist = w == DW_NZ_TARGET_VEL;
+                    const bool ism = w >= DW_NZ_MOTOR && w < DW_NZ_DELAY;
+                    const float x = u[i] * (w < DW_NZ_TARGET_VEL ? 6.28f : (ist ? 0.8f : 0.4f));
+                    // divs(gpu_div, x, 100.0 | 150.0) - (float)(3.14 / 100 | 150)
+                    const float dv = isq ? 100.0f : 150.0f, rv = isq ? (float)(1.0 / 100.0) : (float)(1.0 / 150.0);
+                    const float cv = isq ? (float)(3.14 / 100) : (float)(3.14 / 150);
+                    const float yd = (gd ? x * rv : x / dv) - cv;
+                    const float y = (isq || isb) ? yd : (ist ? x * 1.0f : x + 0.8f);
+                    int k4 = (int)(u[i] * 4.0f), kt = (int)(u[i] * 2000.0f);
+                    k4 = k4 > 3 ? 3 : k4; kt = kt > 1999 ? 1999 : kt;
+                    const int bits = w == DW_NZ_INIT_MOCAP ? (u[i] > 0.5f ? 0 : 1800) : (w == DW_NZ_DELAY ? 2 + k4 : (w == DW_NZ_PTIMING ? kt : f2i(y)));
+                    const int dst = isq ? DW_ES_QPOS_BIAS + (w - DW_NZ_QPOS_BIAS) : isb ? DW_ES_QUAT_BIAS + (w - DW_NZ_QUAT_BIAS)
+                                  : ist ? DW_ES_TARGET_VEL : w == DW_NZ_INIT_MOCAP ? DW_ES_INIT_MOCAP : ism ? DW_ES_MOTOR_SCALE + (w - DW_NZ_MOTOR)
+                                  : w == DW_NZ_DELAY ? DW_ES_DELAY_IDX : w == DW_NZ_PTIMING ? DW_ES_PERT_TIMING : -1;
+                    LI[dst >= 0 ? esb + dst : dummy] = bits;
+                    if (ist) LF[esb + DW_ES_TARGET_VEL + 1] = x * 0.0f;
                 }
             }
-        }
-        DQ_WT();
-        if (mine8) {
-            const int esb = PL_ES + el * PL_ES_STRIDE;
-            DQ_UNROLL for (int k = 0; k < (ND + 7) / 8; ++k) {
-                const int l = j + 8 * k;
-                const bool lv = l < ND;
-                const int lc = lv ? l : 0;
-                const float qi = LF[PL_RC + 2 * lc], qc = LF[PL_RC + 2 * lc + 1];
-                LF[lv ? esb + DW_ES_QPOS_NOISE + l : dummy] = qi;
-                LF[lv ? esb + DW_ES_QPOS_PRE + l : dummy] = qi;
-                LF[lv ? esb + DW_ES_QVEL_NOISE + l : dummy] = 0.0f;
-                LF[lv ? esb + DW_ES_PRE_QVEL + l : dummy] = 0.0f;
-                LF[lv ? PL_Q + (el * ND + l) * 2 : dummy] = qc;
-                LF[lv ? PL_Q + (el * ND + l) * 2 + 1 : dummy] = 0.0f;
-                if (8 * k < 12) LF[l < 12 ? esb + DW_ES_ACTION_TORQUE_PRE + l : dummy] = 0.0f;
-                if (8 * k < 24) LF[l < 24 ? esb + DW_ES_WARM + l : dummy] = 0.0f;
-                if (8 * k < 6) { const int lf = l < 6 ? l : 0; const float ff = PQ_PS(el, PS_FOOT + lf); LF[l < 6 ? esb + DW_ES_FOOT_FORCE_PRE + l : dummy] = ff; }
-                if (8 * k + 7 >= 16 && 8 * k < 29) {
-                    const bool rv = l >= 16 && l < 29;
-                    const int ii = rv ? l - 16 : 0;
+            if (l_dr) {
+                const float d0 = C.dr_damp[0], d1 = C.dr_damp[1] - C.dr_damp[0], a0 = C.dr_arm[0], a1 = C.dr_arm[1] - C.dr_arm[0];
+                const float f0 = C.dr_fric[0], f1 = C.dr_fric[1] - C.dr_fric[0];
+                DQ_UNROLL for (int i = 0; i < 4; ++i) {
+                    const int w = 4 * (DR_B0 + (lane - 8)) + i;
+                    const bool isd = w >= DW_NZ_DR_DAMP && w < DW_NZ_DR_ARM, isa = w >= DW_NZ_DR_ARM && w < DW_NZ_DR_FRIC;
+                    const int l = isd ? w - DW_NZ_DR_DAMP : (isa ? w - DW_NZ_DR_ARM : 0);
+                    const float sd = d0 + u[i] * d1, sa = a0 + u[i] * a1;
+                    if (rvalid && C.dr_dof && (isd || isa)) oq_at(isa ? B.dof_armature : B.dof_damping, oq_row(ND, eg) + l) = isa ? dr_nom[i] * sa : dr_nom[i] + sd;
+                    if (rvalid && C.dr_friction && w == DW_NZ_DR_FRIC) oq_at(OQ_COLD(friction_scale), (OQ_IX)eg) = f0 + u[i] * f1;
+                }
+            }
+            DQ_WT();
+            // ---- the joints (lane = joint), the sole forces, the root state (lanes 16 .. 28) ----
+            if (lane < ND) {
+                const int l = lane;
+                const float qi = LF[PL_RC + 2 * l], qc = LF[PL_RC + 2 * l + 1];
+                LF[esb + DW_ES_QPOS_NOISE + l] = qi;
+                LF[esb + DW_ES_QPOS_PRE + l] = qi;
+                LF[esb + DW_ES_QVEL_NOISE + l] = 0.0f;
+                LF[esb + DW_ES_PRE_QVEL + l] = 0.0f;
+                LF[PL_Q + (er * ND + l) * 2] = qc;
+                LF[PL_Q + (er * ND + l) * 2 + 1] = 0.0f;
+                if (l < 12) LF[esb + DW_ES_ACTION_TORQUE_PRE + l] = 0.0f;
+                if (l < 24) LF[esb + DW_ES_WARM + l] = 0.0f;
+                if (l < 6) LF[esb + DW_ES_FOOT_FORCE_PRE + l] = PQ_PS(er, PS_FOOT + l);
+                if (l >= 16 && l < 29) {
+                    const int ii = l - 16;
                     float v = ii == 2 ? C.initial_height : (ii == 6 ? 1.0f : 0.0f);
-                    v += ii < 3 ? PQ_PS(el, PS_ORG + (ii < 3 ? ii : 0)) : 0.0f;          // (the env's origin; the curriculum has put the new one there)
-                    if (8 * k <= 16 && 8 * k + 7 >= 16 && C.custom_origins) {
-                        const float jit = 2.0f * dw::noise_word(K.nz, DW_NZ_ROOT_JITTER + (ii < 2 ? ii : 0)) + (-1.0f);
-                        if (rv && ii < 2) v += jit;
-                    }
-                    LF[rv ? PL_ROOT + el * 13 + ii : dummy] = v;
+                    v += ii < 3 ? PQ_PS(er, PS_ORG + (ii < 3 ? ii : 0)) : 0.0f;          // (the env's origin; the curriculum has put the new one there)
+                    if (C.custom_origins && ii < 2) v += 2.0f * dw::noise_word(nz, DW_NZ_ROOT_JITTER + ii) + (-1.0f);
+                    LF[PL_ROOT + er * 13 + ii] = v;
                 }
             }
             // torque FIFO and action ring, zeroed
             static_assert((DW_HIST_SLOTS * DW_NUM_ACT) % 4 == 0, "action ring of an env: whole 16-byte pieces");
             constexpr int NAL = DW_ALOG_SLOTS * 12, NAH = DW_HIST_SLOTS * DW_NUM_ACT / 4;
-            DQ_UNROLL for (int i = 0; i < (NAL + 7) / 8; ++i) { if (j + 8 * i < NAL) PQ_ES(el, DW_ES_ACTION_LOG + j + 8 * i) = 0.0f; }
-            if (xvalid) {
-                F4 *ah = reinterpret_cast<F4 *>(&oq_at(B.action_history, oq_row(DW_HIST_SLOTS * DW_NUM_ACT, e)));
-                DQ_UNROLL for (int i = 0; i < (NAH + 7) / 8; ++i) { if (j + 8 * i < NAH) ah[j + 8 * i] = mk4(0.0f, 0.0f, 0.0f, 0.0f); }
+            DQ_UNROLL for (int i = 0; i < (NAL + 63) / 64; ++i) { if (lane + 64 * i < NAL) PQ_ES(er, DW_ES_ACTION_LOG + lane + 64 * i) = 0.0f; }
+            if (rvalid) {
+                F4 *ah = reinterpret_cast<F4 *>(&oq_at(B.action_history, oq_row(DW_HIST_SLOTS * DW_NUM_ACT, eg)));
+                DQ_UNROLL for (int i = 0; i < (NAH + 63) / 64; ++i) { if (lane + 64 * i < NAH) ah[lane + 64 * i] = mk4(0.0f, 0.0f, 0.0f, 0.0f); }
             }
-        }
-        DQ_WT();
-        // per-env scalars (dw_task.h reset_region, lane 40)
-        if (j == 0 && mine) {
-            if (do_dr && xvalid) OQ_COLD(randomize_buf)[e] = 0;
-            PQ_ES(el, DW_ES_TIME) = 0.0f;
-            if (xvalid) { OQ_COLD(progress_buf)[e] = 0; OQ_COLD(reset_buf)[e] = 1; }
-            PQ_ES(el, DW_ES_CRM) = PQ_ES(el, DW_ES_CRS) / PQ_ES(el, DW_ES_EPI_LEN);
-            PQ_ES(el, DW_ES_CRS) = 0.0f;
-            PQ_ESI(el, DW_ES_SIMUL_LEN) = 0;
-            PQ_ES(el, DW_ES_EPI_LEN_LOG) = PQ_ES(el, DW_ES_EPI_LEN);
-            PQ_ES(el, DW_ES_EPI_LEN) = 0.0f;
-            PQ_ESI(el, DW_ES_PERT_COUNT) = 0;
-            PQ_ESI(el, DW_ES_PERT_ON) = 0;
+            DQ_WT();
+            // per-env scalars (dw_task.h reset_region, lane 40)
+            if (lane == 40) {
+                if (do_dr && rvalid) oq_at(OQ_COLD(randomize_buf), (OQ_IX)eg) = 0;
+                PQ_ES(er, DW_ES_TIME) = 0.0f;
+                if (rvalid) { oq_at(OQ_COLD(progress_buf), (OQ_IX)eg) = 0; oq_at(OQ_COLD(reset_buf), (OQ_IX)eg) = 1; }
+                PQ_ES(er, DW_ES_CRM) = PQ_ES(er, DW_ES_CRS) / PQ_ES(er, DW_ES_EPI_LEN);
+                PQ_ES(er, DW_ES_CRS) = 0.0f;
+                PQ_ESI(er, DW_ES_SIMUL_LEN) = 0;
+                PQ_ES(er, DW_ES_EPI_LEN_LOG) = PQ_ES(er, DW_ES_EPI_LEN);
+                PQ_ES(er, DW_ES_EPI_LEN) = 0.0f;
+                PQ_ESI(er, DW_ES_PERT_COUNT) = 0;
+                PQ_ESI(er, DW_ES_PERT_ON) = 0;
+            }
         }
         wave_sync();
     }
