@@ -550,14 +550,9 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
             const int egr = wave_index * EPO + ee;
             const float nrm = (o - OBN[l]) / OBN[DW_NUM_OBS1 + l];
             PQ_NORMED(ee, l) = nrm;
-            if (egr < N) {
-                const OQ_IX oh = oq_row(DW_HIST_SLOTS * DW_NUM_OBS1, egr);
-                if (PQ_ES(ee, DW_ES_EPI_LEN) == 0.0f) {          /*@prob:0.18*/
-                    for (int s2 = 0; s2 < DW_HIST_SLOTS; ++s2)          /*@trip:20*/ oq_at(B.obs_history, oh + l, s2 * DW_NUM_OBS1) = nrm;
-                } else {
-                    oq_at(B.obs_history, oh + PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l) = nrm;
-                }
-            }
+            // (the newest slot; an env that was just reset shows this observation in EVERY slot, tasks/dyros_dynamic_walk.py:655-669: its
+            //  ring is filled below, by the whole wave)
+            if (egr < N && PQ_ES(ee, DW_ES_EPI_LEN) != 0.0f) oq_at(B.obs_history, oq_row(DW_HIST_SLOTS * DW_NUM_OBS1, egr) + PQ_ESI(ee, DW_ES_HIST_HEAD) * DW_NUM_OBS1 + l) = nrm;
         };
         // joint angles / rates of the legs with their biases, target velocity: 26 plain entries per env
         for (int i = lane; i < EPO * 26; i += 64) {
@@ -609,6 +604,29 @@ DQ_HD void oct_task_post(OSlots &L, const DevModel &M, const TaskParams &C, cons
         }
     }
     wave_sync();
+    {
+        // the observation ring of the envs that were reset: 20 slots x 37 words = 185 sixteen-byte pieces per env, every word the new
+        // normalised observation's -- one env at a time on all 64 lanes (three stores per lane; as per-item stores this was 20 stores in
+        // each of the seven item groups of Q4 for the whole wave)
+        static_assert((DW_HIST_SLOTS * DW_NUM_OBS1) % 4 == 0, "observation ring of an env: whole 16-byte pieces");
+        constexpr int NOH = DW_HIST_SLOTS * DW_NUM_OBS1 / 4;
+        unsigned long long todo = wave_ballot(j == 0 && PQ_ES(el, DW_ES_EPI_LEN) == 0.0f);
+        while (todo != 0ull) {
+            const int er = (int)(__builtin_ctzll(todo) / LPE);
+            todo &= todo - 1ull;
+            const int egr = wave_index * EPO + er;
+            if (egr < N) {
+                F4 *oh = reinterpret_cast<F4 *>(&oq_at(B.obs_history, oq_row(DW_HIST_SLOTS * DW_NUM_OBS1, egr)));
+                DQ_UNROLL for (int i = 0; i < (NOH + 63) / 64; ++i) {
+                    const int pc = lane + 64 * i;
+                    if (pc < NOH) {
+                        const int w0 = 4 * pc;
+                        oh[pc] = mk4(PQ_NORMED(er, w0 % DW_NUM_OBS1), PQ_NORMED(er, (w0 + 1) % DW_NUM_OBS1), PQ_NORMED(er, (w0 + 2) % DW_NUM_OBS1), PQ_NORMED(er, (w0 + 3) % DW_NUM_OBS1));
+                    }
+                }
+            }
+        }
+    }
 
     DQ_STAMP(B, 47); DQ_WT();
     // @phase post_obsbuf
