@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--no-also-4096", action="store_true", help="skip the secondary 4096-env measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the friction-DR + forced-pushes leg (BASELINE config 5)")
     ap.add_argument("--no-terrain", action="store_true", help="skip the height-field leg (SURVEY 8 row f-4, default curriculum map)")
+    ap.add_argument("--warm-seconds", type=float, default=WARM_SECONDS, help="wall time of untimed stepping before each timed leg")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO-consumer leg (BASELINE config 3)")
     ap.add_argument("--no-amp", action="store_true", help="skip the sibling-task leg (TocabiAMPLower, SURVEY 8 row f-3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -211,7 +212,7 @@ def main():
         if not plumbing:
             torch.cuda.synchronize()
 
-    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False, warm_seconds=WARM_SECONDS):
+    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False, warm_seconds=None):
         """K steps of VecTask.step on `envs` envs of this rank.  alias_obs = False is the product's default contract (step() returns
         a fresh observation tensor, as the reference's torch.clamp does); True returns the view of obs_buf, so that the stream
         holds nothing but the step kernel."""
@@ -239,24 +240,29 @@ def main():
         # cure it -- the clocks of an idle GPU take longer than that to come up.  So: at least WARM_SECONDS of back-to-back stepping
         # on THIS env (synchronised in chunks, so that the host-side queue is as short when the timer starts as in steady state),
         # never less than one logging horizon.
+        warm_seconds = args.warm_seconds if warm_seconds is None else warm_seconds
+        # everything the timed loop calls must have run once before it: the logging gather's torch kernels are loaded on first use,
+        # which on a fresh box costs ~15 ms of host time.  It runs BEFORE the warm-up stepping, not between it and the timer: the gather's
+        # temporaries stir torch's caching allocator, and the fresh 32 MB observation tensor of each of the next steps (the reference's
+        # contract) then comes from memory the device has not touched yet -- 20 steps right after a gather take 0.151 / 0.148 / 0.145 ms each
+        # in three consecutive regions against 0.140 otherwise (tools/first_steps.py; the zero-copy contract does not show it).  This,
+        # not clocks or the synchronize, was what made the driver's --steps 20 line of rounds 3 and 4 read 8 - 12 % under its long leg.
+        dwdist.gather_episode_stats(env._buf["env_state"])
         t_w, n_w = time.perf_counter(), 0
         while n_w < HORIZON or time.perf_counter() - t_w < warm_seconds:
             for i in range(32):
                 env.step(pool[(n_w + i) % len(pool)])
             n_w += 32
             sync()
-        for i in range(warmup):
-            env.step(pool[i % len(pool)])
-        # everything the timed loop calls must have run once before it: the logging gather's torch kernels are loaded on
-        # first use, which on a fresh box costs ~15 ms of host time (measured r02: 0.285 instead of 0.257 ms/step over 512
-        # steps whenever --warmup was shorter than one logging horizon)
-        dwdist.gather_episode_stats(env._buf["env_state"])
         if not plumbing:
             # (both events exist and have been recorded once before the timer starts: creating / first recording one loads code)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); e1.record()
         if world > 1:
             dist.barrier()
+        # The W warm-up steps come last, right before the synchronize that opens the timed region.
+        for i in range(max(warmup, 8)):
+            env.step(pool[i % len(pool)])
         sync()
         t0 = time.perf_counter()
         if not plumbing:
@@ -359,6 +365,7 @@ def main():
             "alias_obs": {"value": total_envs * n_a / w_a, "ms_per_step": w_a / n_a * 1e3,
                           "note": "cfg sim.mi355.alias_obs: step() returns the view of obs_buf (no copy kernel on the stream)"},
             "episodes": dict(head["episodes"], finished_total=head["resets"]),
+            "head_leg_device_ms_per_step": head["kernel_ms"],          # HIP events around the same K steps (no host latency at either end)
         }
         if lane_slots and torch.cuda.is_available():
             # what binds the kernel at this size: the SIMD's vector-instruction issue.  Floor = the kernel's own VALU instruction
@@ -427,6 +434,15 @@ def main():
                 # the same epochs with the rollout step captured in a hipGraph (dw_step_dev: step counter in device memory)
                 out["config3_ppo"]["graph_rollout"] = epochs_summary(keys=("play_fps", "total_fps"), graph_rollout=True, graph_update=True)          # (a replayed step has no host-side env-step clock)
                 out["config3_ppo"]["graph_rollout"]["note"] = "rollout step and minibatch update each captured in a hipGraph (fused capturable Adam)"
+                # the reference's yaml sizes its minibatch for 4096 envs (cfg/train/DyrosDynamicWalkPPO.yaml:86, "u may play with this"): 128
+                # minibatches x 5 mini-epochs = 640 updates per epoch.  With 16384 envs the same 4096-sample minibatch is 2 560 updates of a
+                # launch-bound size; scaled with the env count (the same 640 updates per epoch) the update is not the epoch any more
+                import copy
+                scaled = copy.deepcopy(ppo.TRAIN_CFG)
+                scaled["config"]["minibatch_size"] = int(scaled["config"]["minibatch_size"]) * max(1, args.envs_per_gpu // 4096)
+                out["config3_ppo"]["graph_rollout_minibatch_scaled"] = epochs_summary(keys=("play_fps", "total_fps"), graph_rollout=True, graph_update=True, cfg=scaled)
+                out["config3_ppo"]["graph_rollout_minibatch_scaled"]["note"] = ("as graph_rollout with minibatch_size x (envs / 4096) = %d: the reference's 640 updates per epoch"
+                                                                                  % scaled["config"]["minibatch_size"])
             except Exception as e:
                 out["config3_ppo"] = {"error": str(e)}
         if not args.no_amp and not plumbing:    # the sibling task on the same physics, step() + reset_done() as the AMP learner calls them
