@@ -86,6 +86,9 @@ def validate_cfg(cfg: dict) -> None:
     n = env["numEnvs"]
     if not isinstance(n, int) or n < 1:
         raise ValueError("env.numEnvs must be a positive integer, got %r" % (n,))
+    if n > (1 << 20):
+        raise ValueError("env.numEnvs = %d: at most 2^20 envs per GPU (the kernels address the per-env streams with 32-bit byte offsets; shard over "
+                         "more GPUs, isaacgymdyros_amd.dist)" % n)
     if (env.get("NumHis"), env.get("NumSkip"), env.get("NumSingleStepObs"), env.get("NumAction")) != (10, 2, 37, 13):
         raise ValueError("the MI355X step kernel is specialised for NumHis=10, NumSkip=2, NumSingleStepObs=37, NumAction=13")
     if env.get("controlFrequencyInv", 2) != 2:
@@ -95,6 +98,8 @@ def validate_cfg(cfg: dict) -> None:
     if len(sim.get("gravity", [0, 0, -9.81])) != 3:
         raise ValueError("sim.gravity must have three components")
     px = sim.get("physx", {})
+    if int(sim.get("mi355", {}).get("debug_wave_build", 0)) not in (0, 1, 2, 3):
+        raise ValueError("sim.mi355.debug_wave_build must be 0 (by launch size), 1 / 2 (octet kernels: one / two waves per SIMD) or 3 (hex instantiation)")
     if sim.get("mi355", {}).get("pipeline", 0) not in (0, 3, "auto", "oct"):
         raise ValueError("sim.mi355.pipeline must be 0/'auto' or 3/'oct' (1/'fused', 2/'quad' and 4/'lane', the kernels of rounds 1, 2 and 4, are retired)")
     iters = int(px.get("num_position_iterations", 4)) + int(px.get("num_velocity_iterations", 1))

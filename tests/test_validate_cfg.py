@@ -33,7 +33,7 @@ def test_bad_terrain_cfg_raises_before_any_device_work(terrain, msg):
 
 
 def test_bad_env_and_sim_values_raise():
-    for path, val, msg in [(("env", "numEnvs"), 0, "numEnvs"), (("env", "NumHis"), 5, "specialised"),
+    for path, val, msg in [(("env", "numEnvs"), 0, "numEnvs"), (("env", "numEnvs"), (1 << 20) + 1, "2\\^20"), (("env", "NumHis"), 5, "specialised"),
                            (("env", "controlFrequencyInv"), 4, "controlFrequencyInv"), (("sim", "dt"), 0.0, "dt")]:
         cfg = copy.deepcopy(default_cfg(64))
         cfg[path[0]][path[1]] = val
