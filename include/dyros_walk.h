@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 7
+#define DW_ABI_VERSION 8
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -335,6 +335,15 @@ int dw_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *
  * (dw_reset_idx never touches obs_buf: a reset env's observations are rebuilt by the next step, as in the reference.) */
 int dw_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t step_index, int64_t *step_counter, float *obs_out,
                 void *stream);
+
+/* The logging columns of the terrain curriculum (tasks/dyros_dynamic_walk.py:415-421: the reference loops over the terrain types with a
+ * nonzero() + sum + cat each): out [N, DW_NUM_REW + terrain_num_types] (device memory) = every env's row of DwBuffers.stacked_rewards
+ * followed, for each terrain type, by the mean terrain level of the envs of that type as the NEWEST step found DwBuffers.terrain_levels
+ * (the reference forms the columns in compute_reward, before the step's reset_idx moves any level; float(sum) / float(count), or float(sum) * (1 / float(count)) with
+ * DwConfig.torch_gpu_div as torch-ROCm divides by a host scalar; count = 0 reads as 1).  The step kernels sum levels and counts per type while they run, from the bound tables -- a caller's edits of
+ * terrain_levels / terrain_types between steps are seen by the next step; call this after a dw_step /
+ * dw_step_dev / dw_step_obs on the same stream.  One launch.  DW_ESTATE unless DwConfig.terrain and terrain_curriculum are set. */
+int dw_terrain_log(DwHandle *h, float *out, void *stream);
 
 /* reset_idx for the env ids listed (int32, device memory). */
 int dw_reset_idx(DwHandle *h, const int32_t *env_ids, int32_t n, const float *noise,

@@ -160,6 +160,8 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
         api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P, P, P)
         api["amp_reset_done"] = fn("amp_reset_done", C.c_int, H, AC, AB, C.POINTER(DwAmpResetDraws), P)
 
+    if prefix in ("dw_", "dwe_"):
+        api["terrain_log"] = fn("terrain_log", C.c_int, H, C.c_void_p, C.c_void_p)
     if prefix == "dwe_":        # (the host emulation of the kernels, tests/emul/: the octet library also carries the fused AMP step)
         if hasattr(lib, "dwe_amp_step_begin"):
             fused_amp()
@@ -179,7 +181,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
 
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
-           "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions",
+           "terrain_log", "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions",
            "amp_step_begin", "amp_step_mid", "amp_step_end", "amp_reset_rows", "amp_reset_done"]
 
 

@@ -17,6 +17,7 @@ struct DwHandle {
     float          *d_mocap;
     float          *d_sc_park;      // PhysParams::sc_park
     int16_t        *d_hmax;         // height field: the coarse bound table built at dw_bind (PhysParams::hmax)
+    unsigned long long *d_lvl_acc;  // TaskParams::terrain_lvl_acc (terrain curriculum only)
     float           reach;          // dw_physics.h model_reach() of the model, computed at dw_create
     DwBuffers       buf;
     int             bound;

@@ -126,6 +126,13 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
         if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: self-collision park buffer", e); }
         h->params.phys.sc_park = h->d_sc_park;
     }
+    if (cfg->terrain && cfg->terrain_curriculum) {
+        const size_t bytes = sizeof(unsigned long long) * dw::lvl_acc_words(cfg->terrain_num_types);
+        e = hipMalloc((void **)&h->d_lvl_acc, bytes);
+        if (e == hipSuccess) e = hipMemset(h->d_lvl_acc, 0, bytes);
+        if (e != hipSuccess) { dw_destroy(h); return fail_hip("dw_create: curriculum level sums", e); }
+        h->params.terrain_lvl_acc = h->d_lvl_acc;
+    }
     e = hipMalloc((void **)&h->d_params, sizeof(dw::DevParams));
     if (e == hipSuccess) e = hipMemset(h->d_params, 0, sizeof(dw::DevParams));
     if (e == hipSuccess) e = hipMemcpy(&h->d_params->C, &h->params, sizeof(dw::TaskParams), hipMemcpyHostToDevice);
@@ -151,6 +158,7 @@ int dw_destroy(DwHandle *h) {
     if (h->d_mocap) (void)hipFree(h->d_mocap);
     if (h->d_sc_park) (void)hipFree(h->d_sc_park);
     if (h->d_hmax) (void)hipFree(h->d_hmax);
+    if (h->d_lvl_acc) (void)hipFree(h->d_lvl_acc);
     free(h);
     return DW_OK;
 }
@@ -258,6 +266,42 @@ int dw_step_obs(DwHandle *h, const float *actions, const float *noise, int64_t s
     hipLaunchKernelGGL(dw_k_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)step_counter);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip("dw_step_obs: counter launch", e);
+    return DW_OK;
+}
+
+// The curriculum's logging columns: out[e] = the env's DW_NUM_REW reward columns, then for every terrain type the mean level
+// of its envs as the newest step left them (sum and count from the step kernel's accumulators; float(sum) / float(max(count, 1))).
+__global__ __launch_bounds__(256) void dw_k_terrain_log(const float *__restrict__ stacked, const unsigned long long *__restrict__ acc, int types, int n, int gpu_div, float *__restrict__ out) {
+    extern __shared__ float mean[];          // [types]
+    const int row = types * dw::LVL_BUCKETS;
+    for (int t = threadIdx.x; t < types; t += 256) {
+        const unsigned long long *slot = acc + acc[3 * row] * row;
+        unsigned long long w = 0;
+        for (int b = 0; b < dw::LVL_BUCKETS; ++b) w += slot[b * types + t];
+        const unsigned int cnt = (unsigned int)(w >> 32), sum = (unsigned int)w;
+        // (torch-ROCm divides a tensor by a host scalar as a * (1 / b), BinaryDivTrueKernel; torch on the CPU divides: DwConfig.torch_gpu_div)
+        const float fc = (float)(cnt ? cnt : 1u);
+        mean[t] = gpu_div ? (float)sum * (1.0f / fc) : (float)sum / fc;
+    }
+    __syncthreads();
+    const int width = DW_NUM_REW + types;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n * width) return;
+    const int e = (int)(i / width), c = (int)(i - (long long)e * width);
+    out[i] = c < DW_NUM_REW ? stacked[(size_t)e * DW_NUM_REW + c] : mean[c - DW_NUM_REW];
+}
+
+int dw_terrain_log(DwHandle *h, float *out, void *stream) {
+    if (!h || !h->bound || !h->has_task) return fail(DW_ESTATE, "dw_terrain_log: handle has no task constants or no buffers bound");
+    if (!h->d_lvl_acc) return fail(DW_ESTATE, "dw_terrain_log: the handle was created without a terrain curriculum");
+    if (!out) return fail(DW_EINVAL, "dw_terrain_log: out is null");
+    DeviceGuard guard(h->device);
+    const int types = h->cfg.terrain_num_types;
+    const long long total = (long long)h->cfg.num_envs * (DW_NUM_REW + types);
+    hipLaunchKernelGGL(dw_k_terrain_log, dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(float) * types, (hipStream_t)stream, h->buf.stacked_rewards, h->d_lvl_acc, types,
+                       h->cfg.num_envs, h->cfg.torch_gpu_div != 0 ? 1 : 0, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip("dw_terrain_log: launch", e);
     return DW_OK;
 }
 

@@ -27,7 +27,14 @@ void dw_k_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__
 #if defined(OCT_STAGGER_SHIFT)      // (timing experiment: hold back every other group of workgroups so that the two waves of a SIMD are in different phases)
     if ((blockIdx.x >> OCT_STAGGER_SHIFT) & 1) for (int i = 0; i < OCT_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
+#if defined(OCT_FORCE_SCRATCH)      // (timing experiment: what a launch pays for HAVING private memory, with none of it on a hot path)
+    volatile int pad[4];
+    pad[threadIdx.x & 3] = (int)step;
+#endif
     dwo::oct_step<TERRAIN, GPUF, WPE == 1>(L.w[w], L.hot, *QM, *M, P->C, make_obuf(HB, &P->B), actions, mocap, noise, step, (int)blockIdx.x * dwo::WPG + w);
+#if defined(OCT_FORCE_SCRATCH)
+    if (pad[(threadIdx.x + 1) & 3] == 0x7fffffff) __builtin_trap();
+#endif
 }
 // One physics substep at the Gym boundary, same layout.
 template <bool TERRAIN, int WPE>

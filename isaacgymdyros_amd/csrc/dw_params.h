@@ -18,6 +18,8 @@ inline const char *check_config(const DwConfig *c) {
         return "terrain: rows/cols >= 2 and positive scales required";
     if (c->terrain_curriculum && (c->terrain_num_levels < 1 || c->terrain_num_types < 1))
         return "terrain curriculum: num_levels and num_types must be positive";
+    if (c->terrain_curriculum && c->terrain_num_levels > (1 << LVL_BITS))
+        return "terrain_num_levels: at most 256 levels (the step kernel sums the levels of a wave's envs over 8 bit planes)";
     if (c->pipeline == 1 || c->pipeline == 2 || c->pipeline == 4)
         return "pipeline 1 (wave per env), 2 (quad) and 4 (lane per env, wave per limb) are retired: use 0 (default) or 3 (octet: 8 lanes per env)";
     if (c->pipeline != 0 && c->pipeline != 3) return "pipeline must be 0 (default) or 3 (octet: 8 lanes per env)";

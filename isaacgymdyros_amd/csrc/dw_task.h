@@ -43,7 +43,14 @@ struct TaskParams {                  // wave-uniform scalars (kernel arguments)
     int     terrain_num_levels, terrain_num_types;
     float   terrain_half_length;       // (float)(terrain_length / 2)
     float   max_episode_length_s;
+    // the curriculum's logging columns (tasks/dyros_dynamic_walk.py:417-421: mean level of the envs of each terrain type): the step
+    // kernel adds (envs << 32 | sum of their levels) to word [step % 3][bucket][type] and clears slot (step + 1) % 3, the last word
+    // names the slot of the newest step; dw_terrain_log reads them.  Library-owned (dw_create), nullptr without a curriculum.
+    unsigned long long *terrain_lvl_acc;
 };
+constexpr int LVL_BUCKETS = 16;      // terrain_lvl_acc: [3][LVL_BUCKETS][types] + 1 words
+constexpr int LVL_BITS = 8;          // levels < 256 (check_config)
+inline size_t lvl_acc_words(int types) { return 3 * (size_t)LVL_BUCKETS * types + 1; }
 
 struct TaskBuffers {                 // device pointers (DwBuffers, read through memory) + per-call pointers
     const DwBuffers *b;

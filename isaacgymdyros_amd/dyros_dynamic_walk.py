@@ -357,14 +357,15 @@ class DyrosDynamicWalk(VecTask):
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.extras["stacked_rewards"] = self._buf["stacked_rewards"]
         if self.custom_origins and self.terrain_cfg.curriculum:
-            # logging columns of the curriculum (reference :417-426): mean level of the envs of each terrain type, as
-            # three device ops and no host sync (the reference loops over the types with a nonzero() each)
+            # logging columns of the curriculum (reference :417-426): mean level of the envs of each terrain type.  The step kernel has
+            # summed levels and counts per type while it ran; one small launch writes the [N, 15 + types] tensor (the reference loops
+            # over the types with a nonzero() + sum + cat each)
             nc = self.terrain_cfg.num_cols
-            if not hasattr(self, "_type_counts"):
-                self._type_counts = torch.bincount(self.terrain_types, minlength=nc).clamp(min=1).to(torch.float)
+            if len(self.extras["reward_names"]) == len(REWARD_NAMES):
                 self.extras["reward_names"] = list(REWARD_NAMES) + ["terrain %d level" % i for i in range(nc)]
-            means = torch.zeros(nc, device=self._tdev).index_add_(0, self.terrain_types, self.terrain_levels.to(torch.float)) / self._type_counts
-            self.extras["stacked_rewards"] = torch.cat([self._buf["stacked_rewards"], means.unsqueeze(0).expand(self.num_envs, nc)], 1)
+            log = torch.empty(self.num_envs, self._buf["stacked_rewards"].shape[1] + nc, device=self._tdev, dtype=torch.float)
+            _lib.check(self._api, self._api["terrain_log"](self._h, log.data_ptr(), stream))
+            self.extras["stacked_rewards"] = log
         self.obs_dict["obs"] = (self.obs_buf if fresh else self._clip_obs(self.obs_buf)).to(self.rl_device)
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 

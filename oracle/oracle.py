@@ -151,6 +151,12 @@ class OracleSim:
             nz = noise.ctypes.data
         self._chk(self.api["step"](self.h, actions.ctypes.data, nz, step_index, None))
 
+    def terrain_log(self):
+        """[N, 15 + terrain types]: the reward columns followed by the curriculum's logging columns (dw_terrain_log; libraries that carry it)."""
+        out = np.zeros((self.N, abi.K["DW_NUM_REW"] + int(self.cfg.terrain_num_types)), dtype=np.float32)
+        self._chk(self.api["terrain_log"](self.h, out.ctypes.data, None))
+        return out
+
     def reset_idx(self, env_ids, noise=None, step_index=0):
         ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         nz = None

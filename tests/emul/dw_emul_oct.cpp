@@ -18,6 +18,7 @@ struct DwHandle {
     float *mocap;
     float *sc_park;
     int16_t *hmax;
+    unsigned long long *lvl_acc;
     int bound;
 };
 
@@ -85,6 +86,10 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     h->dp.C = dw::make_task_params(cfg);
     h->sc_park = (float *)calloc((size_t)((cfg->num_envs + OCT_NS::EPO * OCT_NS::WPG - 1) / (OCT_NS::EPO * OCT_NS::WPG)) * OCT_NS::WPG * 64 * OCT_NS::SC_PARK_WORDS, sizeof(float));
     h->dp.C.phys.sc_park = h->sc_park;
+    if (cfg->terrain && cfg->terrain_curriculum) {
+        h->lvl_acc = (unsigned long long *)calloc(dw::lvl_acc_words(cfg->terrain_num_types), sizeof(unsigned long long));
+        h->dp.C.terrain_lvl_acc = h->lvl_acc;
+    }
     if (task) {
         h->mocap = (float *)malloc(sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
         memcpy(h->mocap, task->mocap, sizeof(float) * DW_MOCAP_ROWS * DW_MOCAP_COLS);
@@ -93,7 +98,7 @@ int dwe_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *tas
     *out = h;
     return DW_OK;
 }
-int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h->sc_park); free(h->hmax); free(h); return DW_OK; }
+int dwe_destroy(DwHandle *h) { if (!h) return fail(DW_EINVAL, "null handle"); free(h->mocap); free(h->sc_park); free(h->hmax); free(h->lvl_acc); free(h); return DW_OK; }
 int dwe_bind(DwHandle *h, const DwBuffers *b) {
     if (!h || !b) return fail(DW_EINVAL, "dwe_bind: null argument");
     if (const char *m = dw::check_buffers(b, false)) return fail(DW_EINVAL, m);
@@ -129,6 +134,23 @@ int dwe_step(DwHandle *h, const float *actions, const float *noise, int64_t step
     // (post_physics_step runs inside the quad kernel too: quad_physics_step<.., POST = true>)
     delete S;
     return rc;
+}
+int dwe_terrain_log(DwHandle *h, float *out, void *) {          // (the arithmetic of dw_k_terrain_log, dw_hip.hip)
+    if (!h || !h->bound || !h->model.has_task) return fail(DW_ESTATE, "not ready");
+    if (!h->lvl_acc) return fail(DW_ESTATE, "dwe_terrain_log: no terrain curriculum");
+    if (!out) return fail(DW_EINVAL, "out is null");
+    const int types = h->cfg.terrain_num_types, width = DW_NUM_REW + types, row = types * dw::LVL_BUCKETS;
+    const unsigned long long *slot = h->lvl_acc + h->lvl_acc[3 * row] * row;
+    for (int e = 0; e < h->cfg.num_envs; ++e)
+        for (int c = 0; c < width; ++c) {
+            if (c < DW_NUM_REW) { out[(size_t)e * width + c] = h->dp.B.stacked_rewards[(size_t)e * DW_NUM_REW + c]; continue; }
+            unsigned long long w = 0;
+            for (int b = 0; b < dw::LVL_BUCKETS; ++b) w += slot[b * types + (c - DW_NUM_REW)];
+            const unsigned int cnt = (unsigned int)(w >> 32), sum = (unsigned int)w;
+            const float fc = (float)(cnt ? cnt : 1u);
+            out[(size_t)e * width + c] = h->cfg.torch_gpu_div ? (float)sum * (1.0f / fc) : (float)sum / fc;
+        }
+    return DW_OK;
 }
 int dwe_step_dev(DwHandle *h, const float *actions, const float *noise, int64_t *step_counter, void *stream) {
     if (!step_counter) return fail(DW_EINVAL, "step_counter is null");

@@ -747,7 +747,20 @@ def test_terrain_full_size_rollout_properties():
         g = torch.Generator(device="cuda").manual_seed(7)
         lv0 = env.terrain_levels.clone()
         for t in range(80):
+            before = env.terrain_levels.clone()
+            if t == 60:          # (a caller's edit of the table between steps is seen by the next step's logging columns)
+                env.terrain_levels[::7] = (env.terrain_levels[::7] + 3) % 10
+                before = env.terrain_levels.clone()
             obs, rew, done, extras = env.step(torch.rand(4096, 13, generator=g, device="cuda") * 2 - 1)
+            if t % 10 == 0 or t > 76:
+                # the curriculum's logging columns as the reference forms them (tasks/dyros_dynamic_walk.py:417-421), from the levels the
+                # step found (compute_reward runs before reset_idx)
+                cols = []
+                for i in range(20):
+                    idx = (env.terrain_types == i).nonzero(as_tuple=False).squeeze(-1)
+                    cols.append(torch.sum(before[idx]) / len(idx) * torch.ones_like(before).unsqueeze(-1))
+                assert torch.equal(extras["stacked_rewards"][:, 15:], torch.cat(cols, 1)), t
+                assert torch.equal(extras["stacked_rewards"][:, :15], env._buf["stacked_rewards"])
         torch.cuda.synchronize()
         outs.append((obs["obs"].clone(), env.root_states.clone(), env.terrain_levels.clone()))
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))

@@ -38,7 +38,13 @@ def test_terrain_curriculum_bitwise_vs_reference_golden(task_const, wave_build):
     be = EmulBackend(int(g["N"]), task_const, debug_wave_build=wave_build, randomize_dof_on_reset=0, debug_freeze_physics=1, torch_gpu_div=0,
                      terrain=R.GoldenTerrain(g), max_episode_length_s=float(g["cfg_max_episode_length_s"]))
     for t, ref, got in R.replay(g, be):
-        ref["stacked_rewards"] = ref["stacked_rewards"][:, :15]
+        # the reference's stacked_rewards carries the curriculum's logging columns (mean level per terrain type, :417-421) behind the
+        # 15 reward columns: here they come out of dw_terrain_log, from the sums the step kernel formed
+        wide = ref["stacked_rewards"]
+        log = be.sim.terrain_log()
+        assert log.shape == wide.shape and np.array_equal(log[:, 15:], wide[:, 15:]), t
+        assert np.array_equal(log[:, :15], got["stacked_rewards"]), t
+        ref["stacked_rewards"] = wide[:, :15]
         bad = P.compare(ref, got, exact=R.EXACT_LOGIC + ["qpos_noise", "qvel_noise", "root_states", "dof_state"],
                         atol=R.TRANSCENDENTAL)
         assert not bad, (t, bad)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from isaacgymdyros_amd import _lib
 _lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
-from isaacgymdyros_amd.config import default_cfg
+from isaacgymdyros_amd.config import default_cfg, with_terrain
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 
 ap = argparse.ArgumentParser()
@@ -15,6 +15,7 @@ ap.add_argument("--envs", default="4096,16384")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--sim", action="store_true", help="also time dw_simulate (one physics substep at the Gym boundary)")
+ap.add_argument("--terrain", action="store_true", help="cfg/terrain/terrain_cfg.py defaults (trimesh, curriculum) instead of the plane")
 ap.add_argument("--mi355", default="{}", help='extra sim.mi355 settings as JSON, e.g. {"self_collision": 0}')
 a = ap.parse_args()
 pipes = [int(x) for x in a.pipes.split(",")]
@@ -23,6 +24,8 @@ for N in [int(x) for x in a.envs.split(",")]:
     envs = {}
     for p in pipes:
         cfg = default_cfg(N, "cuda:0")
+        if a.terrain:
+            cfg = with_terrain(cfg, mesh_type="trimesh", curriculum=True)
         cfg["sim"]["mi355"].update(extra)
         cfg["sim"]["mi355"]["pipeline"] = p
         cfg["sim"]["mi355"]["alias_obs"] = True

@@ -4,13 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from isaacgymdyros_amd import _lib
 _lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
-from isaacgymdyros_amd.config import default_cfg
+from isaacgymdyros_amd.config import default_cfg, with_terrain
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = default_cfg(N, "cuda:0")
 cfg["sim"]["mi355"]["pipeline"] = int(os.environ.get("DW_PIPE", "0"))
+if os.environ.get("DW_TERRAIN"): cfg = with_terrain(cfg, mesh_type="trimesh", curriculum=True)
 if os.environ.get("DW_FREEZE"): cfg["sim"]["mi355"]["debug_freeze_physics"] = True
 env = DyrosDynamicWalk(cfg, "cuda:0", 0, True)
 g = torch.Generator(device="cuda").manual_seed(42)

@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from isaacgymdyros_amd import _lib
 _lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)
-from isaacgymdyros_amd.config import default_cfg
+from isaacgymdyros_amd.config import default_cfg, with_terrain
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 cfg = default_cfg(N, "cuda:0")
+if os.environ.get("DW_TERRAIN"): cfg = with_terrain(cfg, mesh_type="trimesh", curriculum=True)
 PIPE = int(os.environ.get("DW_PIPE", "3"))
 cfg["sim"]["mi355"]["pipeline"] = PIPE
 EPW = 8 if PIPE == 3 else 16          # envs per wave
