@@ -8,6 +8,11 @@
 #include <stdlib.h>
 
 #define OCT_LPE 16
+// The rolled chain loops (kinematics and the two velocity / acceleration passes: 11 steps each) two steps per iteration: the lone wave
+// of a SIMD is bound by the latency of its dependent chains, and with two steps in one block the scheduler starts a step's table and
+// slot reads under the previous step's arithmetic (A/B at 4096 envs: -1.7 %; 3 steps per iteration: +2.6 %, 4: as 2; the octet build
+// for two waves per SIMD loses 2 % to it -- a second wave hides that latency already and the longer code costs instruction fetch).
+#define OCT_CHAIN_UNROLL 2
 #include "dw_params.h"
 #include "dw_oct_kernels.h"
 

@@ -139,7 +139,11 @@ DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
 #define OQ_LD(b, q, p) ldp(OQ_SLOT(b, q, p))
 // the loops over the schedule steps stay loops: unrolled, one substep is 100 KB of straight-line code that every wave streams
 // through the 64 KB instruction cache (measured: +5 % step time)
-#if defined(__HIPCC__) && !defined(OCT_UNROLLED)
+#if defined(__HIPCC__) && defined(OCT_CHAIN_UNROLL)
+#define DQ_PRAGMA_(x) _Pragma(#x)
+#define DQ_PRAGMA(x) DQ_PRAGMA_(x)
+#define DQ_ROLLED DQ_PRAGMA(clang loop unroll_count(OCT_CHAIN_UNROLL))
+#elif defined(__HIPCC__) && !defined(OCT_UNROLLED)
 #define DQ_ROLLED _Pragma("clang loop unroll(disable)")
 #else
 #define DQ_ROLLED
