@@ -220,14 +220,16 @@ def _sync(device):
 
 # ------------------------------------------------------------------------------------------------ the loop
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
-          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False):
+          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False, fused_update=False):
     """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch.
     graph_rollout: one rollout step (policy inference, sampling, env step, bookkeeping) is captured once in a hipGraph and
     replayed `horizon` times per epoch -- possible because dw_step_dev keeps the step counter in device memory, so a replayed
     launch draws fresh noise (include/dyros_walk.h).  The eager loop pays ~40 kernel launches and two host syncs per step.
     graph_update: one minibatch update (forward, the four losses, backward, unscale, clip, both optimiser steps, scaler update) is
     captured once and replayed 5 x 512 times per epoch; needs the fused, capturable Adam (its update is what GradScaler can skip
-    on the device instead of asking the host), one rank."""
+    on the device instead of asking the host), one rank.
+    fused_update: the same update as 17 launches -- batched fp16 GEMMs for actor and critic together, the HIP kernels of
+    include/dyros_ppo.h between them (isaacgymdyros_amd/ppo_update.py) -- captured once and replayed; one rank, GPU only."""
     from isaacgymdyros_amd.config import default_cfg
     from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
     cfg = cfg or TRAIN_CFG
@@ -247,6 +249,15 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     net = DyrosActorCritic(env.num_obs, env.num_acts, cfg["network"]).to(device)
     torch.manual_seed(seed + 7919 * rank)            # ... but its own exploration noise (Normal.sample draws from the global generator)
     graph_update = bool(graph_update) and str(device).startswith("cuda") and world == 1
+    fused = None
+    if fused_update:
+        if not str(device).startswith("cuda") or world != 1:
+            raise ValueError("fused_update needs one GPU rank")
+        from isaacgymdyros_amd.ppo_update import FusedPpoUpdate
+        _b = int(horizon or c["horizon_length"]) * env.num_envs
+        _m = min(int(c["minibatch_size"]), _b)
+        fused = FusedPpoUpdate(net, c, _m, _b // _m, device)          # (re-points the module's parameters at its master buffer: before any capture)
+        graph_update = False
     if graph_update:        # (learning rates as device tensors: the schedule writes them in place and the captured step reads them)
         opt_a = torch.optim.Adam(net.actor_parameters(), lr=torch.tensor(float(c["learning_rate"]), device=device), eps=1e-8, fused=True, capturable=True)
         opt_c = torch.optim.Adam(net.critic_parameters(), lr=torch.tensor(float(c["critic_lr"]), device=device), eps=1e-8, fused=True, capturable=True)
@@ -316,6 +327,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     for ep in range(1, epochs + 1):
         net.update_action_noise((max_epochs - ep) / max_epochs)                 # a2c_common_dyros.py:985
         lr = sched(ep)
+        if fused is not None:
+            fused.set_learning_rates(lr, float(c["critic_lr"]))
         for g in opt_a.param_groups:                                           # update_lr touches the actor only (:293-295)
             if torch.is_tensor(g["lr"]):
                 g["lr"].fill_(lr)
@@ -389,11 +402,37 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 kl_ = policy_kl(mu.detach().float(), sigma.detach().float(), mu_old, torch.exp(net.sigma).expand_as(mu))
             return al.detach(), cl.detach(), bl.detach(), cf_.detach(), kl_
 
+        if fused is not None:
+            if fused.src is None:          # (static homes of the epoch's flat arrays: a captured update replays their addresses)
+                fused.bind_batch(*[torch.empty(batch, *sh, device=device) for sh in ((env.num_obs,), (env.num_acts,), (), (env.num_acts,), (), ())])
+            for d_, x in zip(fused.src, (B["obs"], B["act"], B["neglogp"], B["mu"], adv, ret)):
+                d_.copy_(x.reshape(d_.shape))
+            fused.rewind()
+            n_upd = int(c["mini_epochs"]) * (batch // mbs)
+            done_upd = 0
+            if upd_graph is None:
+                # (two updates run eagerly on a side stream: the warm-up a capture requires -- GEMM workspaces --, spent on real work)
+                side_u = torch.cuda.Stream(device=device)
+                side_u.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side_u), torch.no_grad():
+                    for _ in range(min(2, n_upd)):
+                        fused.update()
+                        done_upd += 1
+                torch.cuda.current_stream(device).wait_stream(side_u)
+                torch.cuda.synchronize()
+                if done_upd < n_upd:
+                    upd_graph = torch.cuda.CUDAGraph()
+                    with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
+                        fused.update()
+            for _ in range(n_upd - done_upd):
+                upd_graph.replay()
+            lg = fused.logged()
+            a_l, c_l, b_l, cf, kl = lg[0], lg[1], lg[2], lg[3], lg[4]
         srcs = (B["obs"], B["act"], B["neglogp"], B["mu"], adv, ret, val)
         if graph_update and upd_static is None:
             upd_static = [torch.empty_like(x[:mbs]) for x in srcs]
         it = 0
-        for _ in range(int(c["mini_epochs"])):
+        for _ in range(int(c["mini_epochs"]) if fused is None else 0):
             for i in range(batch // mbs):
                 sl = slice(i * mbs, (i + 1) * mbs)
                 if not graph_update:

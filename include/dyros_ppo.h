@@ -1,0 +1,91 @@
+/* dyros_ppo.h -- C-ABI of the fused minibatch update of the on-GPU PPO consumer.
+ *
+ * What it replaces: the body of `calc_gradients` of the reference's learner for this task,
+ *   learning/rl_games_custom/a2c_continuous_seperate.py:108-193 -- forward of the two separate MLPs under autocast, the losses of
+ *   learning/rl_games_custom/common_losses.py:4-26 and models_dyros.py:59-62 (neglogp), `scaler.scale(loss).backward()`,
+ *   `scaler.unscale_` of both optimisers, `clip_grad_norm_` of the actor's parameters, both `scaler.step`s and `scaler.update()`
+ *   (cfg/train/DyrosDynamicWalkPPO.yaml: mlp units [256, 256], relu, mixed_precision, separate_opt, grad_norm 0.5, e_clip 0.2).
+ * With torch's autograd that is ~190 kernel launches for a 4096 x 487 minibatch whose arithmetic is 10 GFLOP: launch-bound
+ * (0.98 ms per update inside a hipGraph on an MI355X).  Here the GEMMs stay library calls (torch.baddbmm / bmm on fp16 operands:
+ * hipBLASLt / rocBLAS; actor and critic have the same shapes and run as ONE batched GEMM per layer and direction) and everything
+ * between them is five kernels:
+ *   dwp_stage_obs   fp32 observations of minibatch i -> the fp16 input matrix (autocast's cast of the Linear input)
+ *   dwp_loss        from the two heads' outputs: neglogp, PPO ratio, the clipped surrogate, the value loss, the logged bound loss,
+ *                   clip fraction and KL; d loss / d outputs times the loss scale as fp16; the heads' bias gradients
+ *   dwp_relu_bwd    d relu in place on a hidden layer's gradient + that layer's bias gradient
+ *   dwp_grad_stats  sum of squares of the actor's unscaled gradients (clip_grad_norm_) and inf / nan flags of both nets (unscale_)
+ *   dwp_adam        unscale, clip (actor), Adam step on the fp32 master parameters unless the net's flag is set, fp16 copy for the
+ *                   next forward (what autocast's weight cast produces); the last launch of an update, dwp_finish, moves the loss
+ *                   scale as GradScaler.update does, counts the steps, publishes the logged means and clears the accumulators
+ * All pointers are device pointers; every function enqueues on `stream` and returns 0, or -1 with dwp_last_error() set.
+ *
+ * Parameter layout (fp32 masters `p`, fp16 copies `p16`, Adam moments `m`, `v`: the same layout; IN = 487, HID = 256, OUTP = 16):
+ *   W1 [2][HID][IN] | W2 [2][HID][HID] | W3 [2][OUTP][HID] | b1 [2][HID] | b2 [2][HID] | b3 [2][OUTP]
+ * index 0 of the leading dimension is the actor, 1 the critic; the heads are padded to OUTP = 16 rows (actor: 13 action means,
+ * critic: 1 value; the other rows are zero and stay zero: their gradients are zero).  Weight gradients arrive as fp16 in `g16`
+ * (the weight part of the layout: what a backward under autocast produces), bias gradients as fp32 sums in `gb`
+ * (b1 | b2 | b3), both still multiplied by the loss scale. */
+#ifndef DYROS_PPO_H
+#define DYROS_PPO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWP_ABI_VERSION 1
+#define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
+#define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
+#define DWP_OUTP  16    /* rows of the padded heads                                          */
+#define DWP_ACT   13    /* action means (the actor's head)                                   */
+
+/* accumulators and state of one update, float words of `state` (device memory, zero-initialised by the caller once) */
+#define DWP_S_ALOSS      0   /* sums over the minibatch: surrogate loss                      */
+#define DWP_S_CLOSS      1   /*   value loss                                                 */
+#define DWP_S_BLOSS      2   /*   bound loss                                                 */
+#define DWP_S_CLIPPED    3   /*   samples with |ratio - 1| > e_clip                          */
+#define DWP_S_KL         4   /*   policy KL                                                  */
+#define DWP_S_NORM2      5   /* sum of squares of the actor's unscaled gradients             */
+#define DWP_S_FOUND_INF  6   /* [2] unscale_'s found_inf of the actor / the critic           */
+#define DWP_S_SCALE      8   /* GradScaler: the loss scale (initialise: 65536)               */
+#define DWP_S_GROWTH     9   /*   growth tracker                                             */
+#define DWP_S_STEP       10  /* [2] Adam step counts of the actor / the critic               */
+#define DWP_S_LR         12  /* [2] learning rates (the caller's schedule writes them)       */
+#define DWP_S_MB         14  /* index of the minibatch the next update takes (as a float)    */
+#define DWP_S_OUT        16  /* [8] published by dwp_finish: a_loss, c_loss, b_loss, clip fraction, kl, grad norm, scale, skipped */
+#define DWP_S_WORDS      32
+
+int dwp_abi_version(void);
+const char *dwp_last_error(void);
+
+/* x16 [B][IN] (fp16) = obs[(mb * B + i)][k], mb = (int)state[DWP_S_MB] */
+int dwp_stage_obs(const float *obs, const float *state, int32_t B, uint16_t *x16, void *stream);
+
+/* out16 [2][B][OUTP] fp16 (row i of [0]: the action means, word 0 of row i of [1]: the value).  The per-sample inputs are the
+ * epoch's flat arrays (row mb * B + i is used): act [.][ACT], old_nlp [.], old_mu [.][ACT], adv [.], ret [.].  logstd [ACT]: the
+ * fixed log sigma.  dout16 [2][B][OUTP] = scale * d loss / d out16, loss = mean(surrogate) + 0.5 * critic_coef * mean((ret - v)^2)
+ * (entropy and bound loss have coefficient 0 in this configuration and are only logged).  Adds the heads' bias gradients to
+ * gb[2 * HID * 2 ..] and the logged sums to state. */
+int dwp_loss(const uint16_t *out16, const float *act, const float *old_nlp, const float *old_mu, const float *adv, const float *ret,
+             const float *logstd, float *state, float *gb, int32_t B, float e_clip, float critic_coef, uint16_t *dout16, void *stream);
+
+/* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */
+int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
+
+/* state[NORM2] += sum over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient is not finite */
+int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, void *stream);
+
+/* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
+ * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first */
+int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, const float *state, float max_norm,
+             void *stream);
+
+/* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
+ * accumulators and gb cleared, minibatch index advanced modulo num_minibatches */
+int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,169 @@
+"""The fused minibatch update of the on-GPU PPO consumer (include/dyros_ppo.h).
+
+Reference: `calc_gradients` of learning/rl_games_custom/a2c_continuous_seperate.py:108-193 for the DyrosDynamicWalk configuration
+(cfg/train/DyrosDynamicWalkPPO.yaml: two separate [256, 256] relu MLPs, mixed_precision, separate_opt, truncate_grads with
+grad_norm 0.5 on the actor, e_clip 0.2, clip_value False, entropy_coef 0, bounds_loss_coef 0).  One update is
+
+    stage (1 launch) | 3 batched GEMMs + 2 relu forward | loss (1) | 5 batched GEMMs + 2 relu-backward | grad stats, Adam, finish (3)
+
+= 17 launches instead of the ~190 of torch's autograd under autocast, with the same arithmetic types: fp16 operands and outputs
+with fp32 accumulation in the GEMMs (what autocast gives nn.Linear), fp32 in the losses, fp16 weight gradients, fp32 master
+parameters and Adam moments, dynamic loss scaling as torch.amp.GradScaler does it.  Actor and critic have the same shapes, so
+each layer is ONE batched GEMM (batch index 0 = actor, 1 = critic).  The GEMMs are torch.baddbmm / torch.bmm (hipBLASLt / rocBLAS);
+the kernels between them are csrc/dw_ppo.hip.  Nothing here has a CPU form: the class raises without the HIP library.
+
+The network's own parameters (`DyrosActorCritic` of examples/ppo_consumer.py, any module with actor_mlp / critic_mlp / mu / value)
+are re-pointed at views of the flat fp32 master buffer, so the module used for the rollout sees every update."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+import os
+
+import torch
+
+from . import _lib
+
+
+def _constants() -> dict:
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dyros_ppo.h")).read()
+    return {k: int(v) for k, v in re.findall(r"#define\s+(DWP_[A-Z0-9_]+)\s+(\d+)", src)}
+
+
+K = _constants()
+EXPORTS = ["abi_version", "last_error", "stage_obs", "loss", "relu_bwd", "grad_stats", "adam", "finish"]
+IN, HID, OUTP, ACT = K["DWP_IN"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
+NW1, NW2, NW3 = 2 * HID * IN, 2 * HID * HID, 2 * OUTP * HID
+NWT = NW1 + NW2 + NW3
+NB1, NB2, NB3 = 2 * HID, 2 * HID, 2 * OUTP
+NP = NWT + NB1 + NB2 + NB3
+
+
+def declare(lib: C.CDLL) -> dict:
+    P = C.c_void_p
+
+    def fn(name, restype, *argtypes):
+        f = getattr(lib, "dwp_" + name)
+        f.restype, f.argtypes = restype, list(argtypes)
+        return f
+    api = {"abi_version": fn("abi_version", C.c_int), "last_error": fn("last_error", C.c_char_p)}
+    api["stage_obs"] = fn("stage_obs", C.c_int, P, P, C.c_int32, P, P)
+    api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
+    api["relu_bwd"] = fn("relu_bwd", C.c_int, P, P, P, C.c_int32, P)
+    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P)
+    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, C.c_float, P)
+    api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P)
+    if api["abi_version"]() != K["DWP_ABI_VERSION"]:
+        raise RuntimeError("libdyroswalk_hip.so: dwp ABI %d, header %d" % (api["abi_version"](), K["DWP_ABI_VERSION"]))
+    return api
+
+
+class FusedPpoUpdate:
+    """Owns the flat parameter / moment / gradient buffers and the activations of one minibatch size; `update()` enqueues one update
+    of the minibatch whose index lives in the device state (it advances by itself: the call has no argument that changes, so it can
+    be captured in a hipGraph once and replayed)."""
+
+    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device):
+        c = cfg
+        if bool(c.get("clip_value")) or float(c.get("entropy_coef", 0.0)) != 0.0 or float(c.get("bounds_loss_coef", 0.0)) != 0.0:
+            raise ValueError("the fused update is written for clip_value False, entropy_coef 0, bounds_loss_coef 0 (DyrosDynamicWalkPPO.yaml)")
+        if not bool(c.get("truncate_grads", True)) or not bool(c.get("mixed_precision", True)):
+            raise ValueError("the fused update is written for truncate_grads and mixed_precision (DyrosDynamicWalkPPO.yaml)")
+        lins = [[m for m in trunk if isinstance(m, torch.nn.Linear)] for trunk in (net.actor_mlp, net.critic_mlp)]
+        shapes = [tuple(l.weight.shape) for l in lins[0]] + [tuple(net.mu.weight.shape), tuple(net.value.weight.shape)]
+        if shapes != [(HID, IN), (HID, HID), (ACT, HID), (1, HID)] or [tuple(l.weight.shape) for l in lins[1]] != shapes[:2]:
+            raise ValueError("the fused update is built for %d -> [%d, %d] -> %d / 1 networks, got %r" % (IN, HID, HID, ACT, shapes))
+        self.lib = _lib.load()[0]
+        self.api = declare(self.lib)
+        self.dev = torch.device(device)
+        self.B, self.nmb = int(minibatch), int(num_minibatches)
+        self.e_clip, self.critic_coef, self.max_norm = float(c["e_clip"]), float(c["critic_coef"]), float(c["grad_norm"])
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        f16 = dict(device=self.dev, dtype=torch.float16)
+        self.p = torch.zeros(NP, **f32)
+        self.m, self.v = torch.zeros(NP, **f32), torch.zeros(NP, **f32)
+        self.p16 = torch.zeros(NP, **f16)
+        self.g16 = torch.zeros(NWT, **f16)
+        self.gb = torch.zeros(NB1 + NB2 + NB3, **f32)
+        self.state = torch.zeros(K["DWP_S_WORDS"], **f32)
+        self.state[K["DWP_S_SCALE"]] = 65536.0
+        o = 0
+        self.views, self.views16, self.gviews = {}, {}, {}
+        for name, shape in (("W1", (2, HID, IN)), ("W2", (2, HID, HID)), ("W3", (2, OUTP, HID)), ("b1", (2, HID)), ("b2", (2, HID)), ("b3", (2, OUTP))):
+            n = 1
+            for s in shape:
+                n *= s
+            self.views[name] = self.p[o:o + n].view(shape)
+            self.views16[name] = self.p16[o:o + n].view(shape)
+            if name.startswith("W"):
+                self.gviews[name] = self.g16[o:o + n].view(shape)
+            o += n
+        # adopt the module's initial values, then make the module's parameters views of the master buffer
+        with torch.no_grad():
+            for k, (trunk, head, rows) in enumerate(((lins[0], net.mu, ACT), (lins[1], net.value, 1))):
+                for name, lin in (("1", trunk[0]), ("2", trunk[1])):
+                    self.views["W" + name][k].copy_(lin.weight)
+                    self.views["b" + name][k].copy_(lin.bias)
+                    lin.weight.data, lin.bias.data = self.views["W" + name][k], self.views["b" + name][k]
+                self.views["W3"][k, :rows].copy_(head.weight)
+                self.views["b3"][k, :rows].copy_(head.bias)
+                head.weight.data, head.bias.data = self.views["W3"][k, :rows], self.views["b3"][k, :rows]
+            self.p16.copy_(self.p)
+        B = self.B
+        self.x16 = torch.zeros(B, IN, **f16)
+        self.h1, self.h2 = torch.zeros(2, B, HID, **f16), torch.zeros(2, B, HID, **f16)
+        self.out = torch.zeros(2, B, OUTP, **f16)
+        self.dout = torch.zeros(2, B, OUTP, **f16)
+        self.dh2, self.dh1 = torch.zeros(2, B, HID, **f16), torch.zeros(2, B, HID, **f16)
+        self.logstd = net.sigma
+        self.src = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.api["last_error"]().decode())
+
+    def set_learning_rates(self, lr_actor: float, lr_critic: float):
+        self.state[K["DWP_S_LR"]:K["DWP_S_LR"] + 2] = torch.tensor([lr_actor, lr_critic], device=self.dev)
+
+    def bind_batch(self, obs, act, neglogp, mu, adv, ret):
+        """The epoch's flat arrays (env-major, `batch` rows; fp32, contiguous).  Their ADDRESSES are what a captured update replays:
+        keep the tensors and copy_ each epoch's data into them."""
+        for t in (obs, act, neglogp, mu, adv, ret):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == self.B * self.nmb
+        self.src = (obs, act, neglogp, mu, adv, ret)
+
+    def rewind(self):
+        """Start the next pass at minibatch 0 (a new epoch)."""
+        self.state[K["DWP_S_MB"]] = 0.0
+
+    def update(self):
+        """Enqueue one minibatch update on the current stream."""
+        api, st, B = self.api, self.state.data_ptr(), self.B
+        obs, act, nlp, mu_old, adv, ret = self.src
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        W, W16, G = self.views, self.views16, self.gviews
+        self._chk(api["stage_obs"](obs.data_ptr(), st, B, self.x16.data_ptr(), s))
+        # forward: Linear + relu twice, the two heads (fp16 in, fp32 accumulate, fp16 out: nn.Linear under autocast)
+        torch.baddbmm(W16["b1"].unsqueeze(1), self.x16.unsqueeze(0).expand(2, B, IN), W16["W1"].transpose(1, 2), out=self.h1)
+        torch.relu_(self.h1)
+        torch.baddbmm(W16["b2"].unsqueeze(1), self.h1, W16["W2"].transpose(1, 2), out=self.h2)
+        torch.relu_(self.h2)
+        torch.baddbmm(W16["b3"].unsqueeze(1), self.h2, W16["W3"].transpose(1, 2), out=self.out)
+        self._chk(api["loss"](self.out.data_ptr(), act.data_ptr(), nlp.data_ptr(), mu_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.logstd.data_ptr(), st,
+                              self.gb.data_ptr(), B, self.e_clip, self.critic_coef, self.dout.data_ptr(), s))
+        # backward: weight gradients dY' X, input gradients dY W, relu masks (with the bias gradients) in between
+        torch.bmm(self.dout.transpose(1, 2), self.h2, out=G["W3"])
+        torch.bmm(self.dout, W16["W3"], out=self.dh2)
+        self._chk(api["relu_bwd"](self.h2.data_ptr(), self.dh2.data_ptr(), self.gb.data_ptr() + 4 * NB1, B, s))
+        torch.bmm(self.dh2.transpose(1, 2), self.h1, out=G["W2"])
+        torch.bmm(self.dh2, W16["W2"], out=self.dh1)
+        self._chk(api["relu_bwd"](self.h1.data_ptr(), self.dh1.data_ptr(), self.gb.data_ptr(), B, s))
+        torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, IN), out=G["W1"])
+        # unscale + clip + Adam + scaler
+        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, s))
+        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.max_norm, s))
+        self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, s))
+
+    def logged(self):
+        """(a_loss, c_loss, b_loss, clip fraction, kl, actor grad norm, loss scale, skipped) of the last update: a device tensor view."""
+        return self.state[K["DWP_S_OUT"]:K["DWP_S_OUT"] + 8]

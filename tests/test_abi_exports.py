@@ -43,6 +43,14 @@ def test_library_builds_and_exports_the_abi():
     for fn in declared_functions():
         assert hasattr(lib, fn), fn
     assert lib.dw_abi_version() == abi.K["DW_ABI_VERSION"]
+    # include/dyros_ppo.h: the kernels of the PPO consumer's fused update
+    from isaacgymdyros_amd import ppo_update
+    src = open(os.path.join(ROOT, "include", "dyros_ppo.h")).read()
+    declared = sorted(set(re.findall(r"\b(dwp_[a-z_]+)\s*\(", src)))
+    assert declared == sorted("dwp_" + n for n in ppo_update.EXPORTS)
+    for fn in declared:
+        assert hasattr(lib, fn), fn
+    assert lib.dwp_abi_version() == ppo_update.K["DWP_ABI_VERSION"]
 
 
 def test_product_refuses_cpu_device():

@@ -1,0 +1,267 @@
+"""The fused PPO minibatch update (include/dyros_ppo.h, isaacgymdyros_amd/ppo_update.py) against torch's autograd running the same
+update under autocast with GradScaler and two Adam optimisers -- the form of the reference's calc_gradients
+(learning/rl_games_custom/a2c_continuous_seperate.py:108-193), which examples/ppo_consumer.py keeps as its other path."""
+import copy
+import importlib.util
+import math
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ppo():
+    spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(ROOT, "examples", "ppo_consumer.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _autograd_update(ppo, net, opt_a, opt_c, scaler, c, obs, act, nlp_old, mu_old, adv, ret):
+    """One minibatch update as examples/ppo_consumer.py::minibatch_update does it; returns (a_loss, c_loss, clip fraction, kl,
+    unscaled gradients before clipping by parameter name)."""
+    with torch.autocast("cuda", dtype=torch.float16):
+        mu, logstd, value = net(obs)
+        sigma = torch.exp(logstd)
+        nlp = ppo.neglogp(act, mu, sigma, logstd)
+        a_loss, cf = ppo.actor_loss(nlp_old, nlp, adv, c["e_clip"])
+        c_loss = ppo.critic_loss(None, value, c["e_clip"], ret, False)
+        al, cl = a_loss.mean(), c_loss.mean()
+        loss = al + 0.5 * cl * c["critic_coef"]
+    for p in net.parameters():
+        p.grad = None
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt_a); scaler.unscale_(opt_c)
+    grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    torch.nn.utils.clip_grad_norm_(net.actor_parameters(), c["grad_norm"])
+    scaler.step(opt_a); scaler.step(opt_c); scaler.update()
+    with torch.no_grad():
+        kl = ppo.policy_kl(mu.detach().float(), sigma.detach().float(), mu_old, torch.exp(net.sigma).expand_as(mu))
+    return float(al.detach()), float(cl.detach()), float(cf), float(kl), grads
+
+
+def _lively(net):
+    with torch.no_grad():          # (the yaml's gain 0.01 makes every activation tiny: a livelier network is the harder test)
+        for p in net.parameters():
+            if p.requires_grad and p.dim() == 2:
+                torch.nn.init.orthogonal_(p, gain=1.0)
+            elif p.requires_grad:
+                p.uniform_(-0.1, 0.1)
+
+
+def _batch(ppo, ref, U, n, dev, seed=11):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    obs = torch.randn(n, U.IN, generator=g, device=dev)
+    with torch.no_grad():
+        mu0, logstd, _ = ref(obs)
+        sigma = torch.exp(logstd)
+        act = mu0 + sigma * torch.randn(n, U.ACT, generator=g, device=dev)
+        mu_old = mu0 + 0.1 * sigma * torch.randn(n, U.ACT, generator=g, device=dev)          # (an older policy: ratios on both sides of the clip range)
+        nlp_old = ppo.neglogp(act, mu_old, sigma, logstd)
+    adv = torch.randn(n, generator=g, device=dev)
+    ret = torch.randn(n, generator=g, device=dev)
+    return obs, act, nlp_old, mu_old, adv, ret
+
+
+def _close16(a, b, ulps=3.0):
+    """fp16 results of the same sums in another order: a few fp16 ulps of the entry, or of 1e-3 of the tensor's largest entry"""
+    a, b = a.float(), b.float()
+    tol = ulps * 2.0 ** -10 * torch.maximum(b.abs(), 1e-3 * b.abs().max())
+    return bool(((a - b).abs() <= tol).all()), float(((a - b).abs() / tol).max())
+
+
+@pytest.mark.gpu
+def test_fused_update_piece_by_piece_against_torch():
+    """Every stage of the fused update against torch arithmetic on the SAME inputs (no chaos from samples that sit on the clip boundary):
+    staging, the three layers, the loss kernel's output gradient against autograd on the heads' outputs, the five backward GEMMs and
+    masks, gradient statistics, the Adam step."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    ref = copy.deepcopy(net)
+    B, nmb = 4096, 2
+    fused = U.FusedPpoUpdate(net, c, B, nmb, dev)
+    lr_a, lr_c = 3e-5, 5e-5
+    fused.set_learning_rates(lr_a, lr_c)
+    obs, act, nlp_old, mu_old, adv, ret = _batch(ppo, ref, U, B * nmb, dev)
+    fused.bind_batch(obs, act, nlp_old, mu_old, adv, ret)
+    for i in range(nmb):
+        sl = slice(i * B, (i + 1) * B)
+        p16, p, m0, v0 = fused.p16.clone(), fused.p.clone(), fused.m.clone(), fused.v.clone()
+        W = {k: t.clone().float() for k, t in fused.views16.items()}
+        scale = float(fused.state[U.K["DWP_S_SCALE"]])
+        fused.update()
+        torch.cuda.synchronize()
+        lg = fused.logged().cpu().tolist()
+        assert lg[7] == 0.0 and lg[6] == scale
+        # forward
+        assert torch.equal(fused.x16, obs[sl].half())
+        x = fused.x16.float()
+        h1 = torch.relu(torch.matmul(x, W["W1"].transpose(1, 2)) + W["b1"].unsqueeze(1))
+        ok, worst = _close16(fused.h1, h1); assert ok, ("h1", worst)
+        h2 = torch.relu(torch.matmul(fused.h1.float(), W["W2"].transpose(1, 2)) + W["b2"].unsqueeze(1))
+        ok, worst = _close16(fused.h2, h2); assert ok, ("h2", worst)
+        out = torch.matmul(fused.h2.float(), W["W3"].transpose(1, 2)) + W["b3"].unsqueeze(1)
+        ok, worst = _close16(fused.out, out); assert ok, ("out", worst)
+        # the loss kernel against autograd on the heads' outputs as they are in the fused buffers
+        mu = fused.out[0, :, :U.ACT].float().requires_grad_()
+        val = fused.out[1, :, :1].float().requires_grad_()
+        logstd = net.sigma.expand_as(mu)
+        sigma = torch.exp(logstd)
+        nlp = ppo.neglogp(act[sl], mu, sigma, logstd)
+        a_loss, cf = ppo.actor_loss(nlp_old[sl], nlp, adv[sl], c["e_clip"])
+        c_loss = ppo.critic_loss(None, val, c["e_clip"], ret[sl].unsqueeze(1), False)
+        al, cl = a_loss.mean(), c_loss.mean()
+        (scale * (al + 0.5 * cl * c["critic_coef"])).backward()
+        assert lg[0] == pytest.approx(float(al.detach()), rel=1e-5, abs=1e-6) and lg[1] == pytest.approx(float(cl.detach()), rel=1e-5)
+        assert lg[2] == pytest.approx(float(ppo.bound_loss(mu.detach()).mean()), rel=1e-5) and lg[3] == pytest.approx(float(cf), abs=0.5 / B) and 0.05 < float(cf) < 0.95
+        assert lg[4] == pytest.approx(float(ppo.policy_kl(mu.detach(), sigma, mu_old[sl], sigma)), rel=1e-4)
+        ok, worst = _close16(fused.dout[0, :, :U.ACT], mu.grad, ulps=1.5); assert ok, ("dmu", worst)
+        ok, worst = _close16(fused.dout[1, :, :1], val.grad, ulps=1.5); assert ok, ("dvalue", worst)
+        assert float(fused.dout[0, :, U.ACT:].abs().max()) == 0.0 and float(fused.dout[1, :, 1:].abs().max()) == 0.0
+        # backward: from the fused output gradient
+        d3 = fused.dout.float()
+        ok, worst = _close16(fused.gviews["W3"], torch.matmul(d3.transpose(1, 2), fused.h2.float())); assert ok, ("gW3", worst)
+        dz2 = (torch.matmul(d3, W["W3"]).half().float()) * (fused.h2 > 0)
+        ok, worst = _close16(fused.dh2, dz2); assert ok, ("dz2", worst)
+        ok, worst = _close16(fused.gviews["W2"], torch.matmul(fused.dh2.float().transpose(1, 2), fused.h1.float())); assert ok, ("gW2", worst)
+        dz1 = (torch.matmul(fused.dh2.float(), W["W2"]).half().float()) * (fused.h1 > 0)
+        ok, worst = _close16(fused.dh1, dz1); assert ok, ("dz1", worst)
+        ok, worst = _close16(fused.gviews["W1"], torch.matmul(fused.dh1.float().transpose(1, 2), x)); assert ok, ("gW1", worst)
+        # the optimiser: unscale, actor clip, Adam -- from the gradients in the fused buffers and bias gradients = column sums
+        gb = torch.cat([fused.dh1.float().sum(1).reshape(-1), fused.dh2.float().sum(1).reshape(-1), d3.sum(1).reshape(-1)])
+        gfull = torch.cat([fused.g16.float(), gb]) / scale
+        actor = torch.zeros(U.NP, dtype=torch.bool, device=dev)
+        o = 0
+        for nelem in (U.NW1, U.NW2, U.NW3, U.NB1, U.NB2, U.NB3):
+            actor[o:o + nelem // 2] = True
+            o += nelem
+        norm = float(gfull[actor].norm())
+        assert lg[5] == pytest.approx(norm, rel=1e-4)
+        gfull = torch.where(actor, gfull * min(1.0, c["grad_norm"] / (norm + 1e-6)), gfull)
+        step = float(i + 1)
+        m1 = m0 + (gfull - m0) * 0.1
+        v1 = 0.999 * v0 + 0.001 * gfull * gfull
+        lr = torch.where(actor, torch.tensor(lr_a, device=dev), torch.tensor(lr_c, device=dev))
+        pn = p - (lr / (1 - 0.9 ** step)) * (m1 / (v1.sqrt() / math.sqrt(1 - 0.999 ** step) + 1e-8))
+        assert float((fused.m - m1).abs().max()) <= 1e-5 * float(m1.abs().max()) + 1e-12
+        assert float((fused.v - v1).abs().max()) <= 1e-4 * float(v1.abs().max()) + 1e-20
+        assert float((fused.p - pn).abs().max()) <= 0.02 * lr_a          # (bias sums are fp32 atomics in another order: a moment within rounding of zero)
+        # the fp16 copy the next forward reads: the master rounded to nearest (the compiler rounds the fused multiply-add of the step once,
+        # to fp16 -- v_fma_mixlo_f16 --, so an entry whose fp32 value is a tie may round the other way than fp32 -> fp16 does)
+        assert bool(((fused.p16.float() - fused.p).abs() <= 2.0 ** -11 * fused.p.abs() + 1e-7).all())
+        assert int((fused.p16 != fused.p.half()).sum()) < 1e-3 * U.NP
+    assert float(fused.views["W3"][0, U.ACT:].abs().max()) == 0.0 and float(fused.views["b3"][1, 1:].abs().max()) == 0.0          # (padding rows stay zero)
+    assert float(fused.state[U.K["DWP_S_MB"]]) == 0.0 and fused.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() == [2.0, 2.0]
+
+
+@pytest.mark.gpu
+def test_fused_update_tracks_the_autograd_update():
+    """End to end against the autograd path under autocast (other GEMM tilings, so a handful of the 4096 samples land on the other side
+    of the clip boundary: gradients agree in the norm, not entry by entry), and the loss scale moves alike."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    ref = copy.deepcopy(net)
+    B, nmb = 4096, 3
+    fused = U.FusedPpoUpdate(net, c, B, nmb, dev)
+    lr_a, lr_c = 3e-5, 5e-5
+    fused.set_learning_rates(lr_a, lr_c)
+    opt_a = torch.optim.Adam(ref.actor_parameters(), lr=lr_a, eps=1e-8)
+    opt_c = torch.optim.Adam(ref.critic_parameters(), lr=lr_c, eps=1e-8)
+    scaler = torch.amp.GradScaler("cuda")
+    obs, act, nlp_old, mu_old, adv, ret = _batch(ppo, ref, U, B * nmb, dev)
+    fused.bind_batch(obs, act, nlp_old, mu_old, adv, ret)
+    names = {"W1": ("actor_mlp.0.weight", "critic_mlp.0.weight"), "W2": ("actor_mlp.2.weight", "critic_mlp.2.weight"), "W3": ("mu.weight", "value.weight")}
+    clean = 0
+    for i in range(nmb):
+        sl = slice(i * B, (i + 1) * B)
+        with torch.no_grad():          # (every step starts from the same parameters)
+            for pr, pf in zip(ref.parameters(), net.parameters()):
+                pr.copy_(pf)
+        al, cl, cf, kl, grads = _autograd_update(ppo, ref, opt_a, opt_c, scaler, c, obs[sl], act[sl], nlp_old[sl], mu_old[sl], adv[sl], ret[sl].unsqueeze(1))
+        scale = float(fused.state[U.K["DWP_S_SCALE"]])
+        fused.update()
+        torch.cuda.synchronize()
+        lg = fused.logged().cpu().tolist()
+        # the two paths overflow fp16 together or not at all (the gradient at the heads' outputs is the same number in both), and then
+        # skip, back off and count alike
+        assert lg[6] == scale and float(fused.state[U.K["DWP_S_SCALE"]]) == scaler.get_scale()
+        assert lg[7] == (1.0 if scaler.get_scale() < scale else 0.0)
+        clean += lg[7] == 0.0
+        if lg[7] != 0.0:
+            continue
+        assert lg[0] == pytest.approx(al, rel=5e-3, abs=5e-4) and lg[1] == pytest.approx(cl, rel=2e-3)
+        assert lg[3] == pytest.approx(cf, abs=16.0 / B) and lg[4] == pytest.approx(kl, rel=5e-3)
+        for w, (na, nc) in names.items():
+            for k, nm in enumerate((na, nc)):
+                gr = grads[nm]
+                gf = fused.gviews[w][k, :gr.shape[0]].float() / scale
+                assert float((gf - gr).norm()) <= 0.1 * float(gr.norm()), (i, nm, float((gf - gr).norm()), float(gr.norm()))
+        assert lg[5] == pytest.approx(math.sqrt(sum(float((grads[n_] ** 2).sum()) for n_ in grads if n_.startswith(("actor_mlp", "mu.")))), rel=3e-2)
+    assert clean == nmb          # (this data does not overflow: every comparison above ran)
+
+
+@pytest.mark.gpu
+def test_fused_update_skips_and_backs_off_on_overflow():
+    """GradScaler's contract: a non-finite gradient in one net skips THAT optimiser's step, halves the scale, leaves the other net's
+    step alone (separate unscale_ / step per optimiser, a2c_continuous_seperate.py:184-189)."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    torch.manual_seed(5)
+    dev = "cuda:0"
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    B = 256
+    fused = U.FusedPpoUpdate(net, c, B, 2, dev)
+    fused.set_learning_rates(1e-3, 1e-3)
+    g = torch.Generator(device=dev).manual_seed(1)
+    obs = torch.randn(2 * B, U.IN, generator=g, device=dev)
+    act = torch.randn(2 * B, U.ACT, generator=g, device=dev) * 0.1
+    mu_old = torch.zeros(2 * B, U.ACT, device=dev)
+    with torch.no_grad():
+        nlp_old = ppo.neglogp(act, mu_old, torch.exp(net.sigma), net.sigma.expand_as(act))
+    adv = torch.randn(2 * B, generator=g, device=dev)
+    ret = torch.randn(2 * B, generator=g, device=dev)
+    ret[:B] = 3.0e4          # value error x scale 65536 / B overflows fp16 in the critic's output gradient: inf in the critic only
+    fused.bind_batch(obs, act, nlp_old, mu_old, adv, ret)
+    p0 = fused.p.clone()
+    fused.update()
+    torch.cuda.synchronize()
+    lg = fused.logged().cpu().tolist()
+    assert lg[7] == 1.0 and float(fused.state[U.K["DWP_S_SCALE"]]) == 32768.0
+    assert fused.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() == [1.0, 0.0]
+    moved = (fused.p != p0)
+    crit = torch.zeros_like(moved)
+    o = 0
+    for nelem in (U.NW1, U.NW2, U.NW3, U.NB1, U.NB2, U.NB3):
+        crit[o + nelem // 2:o + nelem] = True
+        o += nelem
+    assert not bool((moved & crit).any()) and bool((moved & ~crit).any())
+    fused.update()          # minibatch 1 is clean: both step
+    torch.cuda.synchronize()
+    assert fused.logged()[7].item() == 0.0 and fused.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() == [2.0, 1.0]
+
+
+@pytest.mark.gpu
+def test_consumer_trains_with_the_fused_update():
+    """Two short epochs of the PPO consumer with the rollout and the fused update each replayed from a hipGraph: finite, and the losses
+    are those of the autograd path on the same seed to within what fp16 GEMM tilings differ by (the first epoch's rollout is identical:
+    same seed, same initial weights)."""
+    ppo = _ppo()
+    a = ppo.train(256, epochs=2, horizon=16, device="cuda:0", log=lambda *_: None, graph_rollout=True, graph_update=True)
+    b = ppo.train(256, epochs=2, horizon=16, device="cuda:0", log=lambda *_: None, graph_rollout=True, fused_update=True)
+    for sa, sb in zip(a, b):
+        assert all(math.isfinite(sb[k]) for k in ("a_loss", "c_loss", "kl", "mean_reward"))
+    assert b[0]["mean_reward"] == pytest.approx(a[0]["mean_reward"], rel=1e-6)
+    assert b[0]["c_loss"] == pytest.approx(a[0]["c_loss"], rel=2e-2) and b[0]["a_loss"] == pytest.approx(a[0]["a_loss"], rel=5e-2, abs=2e-3)
