@@ -443,8 +443,14 @@ def main():
                 out["config3_ppo"]["graph_rollout_minibatch_scaled"] = epochs_summary(keys=("play_fps", "total_fps"), graph_rollout=True, graph_update=True, cfg=scaled)
                 out["config3_ppo"]["graph_rollout_minibatch_scaled"]["note"] = ("as graph_rollout with minibatch_size x (envs / 4096) = %d: the reference's 640 updates per epoch"
                                                                                   % scaled["config"]["minibatch_size"])
+                # the update as 17 launches: batched fp16 GEMMs for both nets, the HIP kernels of include/dyros_ppo.h between them
+                # (isaacgymdyros_amd/ppo_update.py); the yaml's own minibatch of 4096
+                rec = epochs_summary(keys=("play_fps", "total_fps"), graph_rollout=True, fused_update=True)
+                rec["note"] = ("rollout step and the FUSED minibatch update (include/dyros_ppo.h: 17 launches instead of ~190) each captured in a hipGraph; "
+                               "minibatch_size as in the yaml")
+                out["config3_ppo"]["fused_update"] = rec
             except Exception as e:
-                out["config3_ppo"] = {"error": str(e)}
+                out["config3_ppo"] = dict(out.get("config3_ppo") or {}, error=str(e))
         if not args.no_amp and not plumbing:    # the sibling task on the same physics, step() + reset_done() as the AMP learner calls them
             try:
                 from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg

@@ -8,9 +8,10 @@
  * With torch's autograd that is ~190 kernel launches for a 4096 x 487 minibatch whose arithmetic is 10 GFLOP: launch-bound
  * (0.98 ms per update inside a hipGraph on an MI355X).  Here the GEMMs stay library calls (torch.baddbmm / bmm on fp16 operands:
  * hipBLASLt / rocBLAS; actor and critic have the same shapes and run as ONE batched GEMM per layer and direction) and everything
- * between them is five kernels:
+ * between them is six kernels:
  *   dwp_stage_obs   fp32 observations of minibatch i -> the fp16 input matrix (autocast's cast of the Linear input)
- *   dwp_loss        from the two heads' outputs: neglogp, PPO ratio, the clipped surrogate, the value loss, the logged bound loss,
+ *   dwp_bias_relu   bias + relu of a hidden layer, in place on the batched product
+ *   dwp_loss        the heads' biases, then from the two heads' outputs: neglogp, PPO ratio, the clipped surrogate, the value loss, the logged bound loss,
  *                   clip fraction and KL; d loss / d outputs times the loss scale as fp16; the heads' bias gradients
  *   dwp_relu_bwd    d relu in place on a hidden layer's gradient + that layer's bias gradient
  *   dwp_grad_stats  sum of squares of the actor's unscaled gradients (clip_grad_norm_) and inf / nan flags of both nets (unscale_)
@@ -19,8 +20,9 @@
  *                   scale as GradScaler.update does, counts the steps, publishes the logged means and clears the accumulators
  * All pointers are device pointers; every function enqueues on `stream` and returns 0, or -1 with dwp_last_error() set.
  *
- * Parameter layout (fp32 masters `p`, fp16 copies `p16`, Adam moments `m`, `v`: the same layout; IN = 487, HID = 256, OUTP = 16):
- *   W1 [2][HID][IN] | W2 [2][HID][HID] | W3 [2][OUTP][HID] | b1 [2][HID] | b2 [2][HID] | b3 [2][OUTP]
+ * Parameter layout (fp32 masters `p`, fp16 copies `p16`, Adam moments `m`, `v`: the same layout; IN = 487 padded to INP = 512 -- a 974-byte row
+ * is not even word aligned and costs the first layer's GEMMs half their speed --, HID = 256, OUTP = 16):
+ *   W1 [2][HID][INP] | W2 [2][HID][HID] | W3 [2][OUTP][HID] | b1 [2][HID] | b2 [2][HID] | b3 [2][OUTP]
  * index 0 of the leading dimension is the actor, 1 the critic; the heads are padded to OUTP = 16 rows (actor: 13 action means,
  * critic: 1 value; the other rows are zero and stay zero: their gradients are zero).  Weight gradients arrive as fp16 in `g16`
  * (the weight part of the layout: what a backward under autocast produces), bias gradients as fp32 sums in `gb`
@@ -36,6 +38,7 @@ extern "C" {
 
 #define DWP_ABI_VERSION 1
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
+#define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
 #define DWP_OUTP  16    /* rows of the padded heads                                          */
 #define DWP_ACT   13    /* action means (the actor's head)                                   */
@@ -59,15 +62,20 @@ extern "C" {
 int dwp_abi_version(void);
 const char *dwp_last_error(void);
 
-/* x16 [B][IN] (fp16) = obs[(mb * B + i)][k], mb = (int)state[DWP_S_MB] */
+/* x16 [B][INP] (fp16) = obs[(mb * B + i)][k] for k < IN, 0 in the padding; mb = (int)state[DWP_S_MB] */
 int dwp_stage_obs(const float *obs, const float *state, int32_t B, uint16_t *x16, void *stream);
 
-/* out16 [2][B][OUTP] fp16 (row i of [0]: the action means, word 0 of row i of [1]: the value).  The per-sample inputs are the
+/* h16 [2][B][HID] = relu(h16 + b16[net][.]) in place: bias and activation of a hidden Linear behind the bare batched product (the GEMM's
+ * fp16 output, then the bias in fp32 and one more rounding: at most one fp16 ulp from a fused epilogue) */
+int dwp_bias_relu(uint16_t *h16, const uint16_t *b16, int32_t B, void *stream);
+
+/* out16 [2][B][OUTP] fp16: the heads' bare products on entry, their outputs on exit (b3_16 [2][OUTP] added: row i of [0] the action
+ * means, word 0 of row i of [1] the value).  The per-sample inputs are the
  * epoch's flat arrays (row mb * B + i is used): act [.][ACT], old_nlp [.], old_mu [.][ACT], adv [.], ret [.].  logstd [ACT]: the
  * fixed log sigma.  dout16 [2][B][OUTP] = scale * d loss / d out16, loss = mean(surrogate) + 0.5 * critic_coef * mean((ret - v)^2)
  * (entropy and bound loss have coefficient 0 in this configuration and are only logged).  Adds the heads' bias gradients to
  * gb[2 * HID * 2 ..] and the logged sums to state. */
-int dwp_loss(const uint16_t *out16, const float *act, const float *old_nlp, const float *old_mu, const float *adv, const float *ret,
+int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const float *old_nlp, const float *old_mu, const float *adv, const float *ret,
              const float *logstd, float *state, float *gb, int32_t B, float e_clip, float critic_coef, uint16_t *dout16, void *stream);
 
 /* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */

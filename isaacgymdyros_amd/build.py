@@ -15,7 +15,7 @@ LIB = os.path.join(PKG, "libdyroswalk_hip.so")
 # the compiler's default.
 SOURCES = [("dw_hip.hip", []),
            ("dw_oct_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
-           ("dw_hex_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_amp.hip", []), ("dw_ppo.hip", [])]
+           ("dw_hex_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_amp.hip", []), ("dw_ppo.hip", ["-munsafe-fp-atomics"])]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
            "dw_limb.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_*_f32 pairs: in the octet step kernel 1 920

@@ -4,7 +4,7 @@ Reference: `calc_gradients` of learning/rl_games_custom/a2c_continuous_seperate.
 (cfg/train/DyrosDynamicWalkPPO.yaml: two separate [256, 256] relu MLPs, mixed_precision, separate_opt, truncate_grads with
 grad_norm 0.5 on the actor, e_clip 0.2, clip_value False, entropy_coef 0, bounds_loss_coef 0).  One update is
 
-    stage (1 launch) | 3 batched GEMMs + 2 relu forward | loss (1) | 5 batched GEMMs + 2 relu-backward | grad stats, Adam, finish (3)
+    stage (1 launch) | 3 batched GEMMs + 2 bias-relu | loss (1) | 5 batched GEMMs + 2 relu-backward | grad stats, Adam, finish (3)
 
 = 17 launches instead of the ~190 of torch's autograd under autocast, with the same arithmetic types: fp16 operands and outputs
 with fp32 accumulation in the GEMMs (what autocast gives nn.Linear), fp32 in the losses, fp16 weight gradients, fp32 master
@@ -31,9 +31,9 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "loss", "relu_bwd", "grad_stats", "adam", "finish"]
-IN, HID, OUTP, ACT = K["DWP_IN"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
-NW1, NW2, NW3 = 2 * HID * IN, 2 * HID * HID, 2 * OUTP * HID
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish"]
+IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
+NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
 NB1, NB2, NB3 = 2 * HID, 2 * HID, 2 * OUTP
 NP = NWT + NB1 + NB2 + NB3
@@ -48,7 +48,8 @@ def declare(lib: C.CDLL) -> dict:
         return f
     api = {"abi_version": fn("abi_version", C.c_int), "last_error": fn("last_error", C.c_char_p)}
     api["stage_obs"] = fn("stage_obs", C.c_int, P, P, C.c_int32, P, P)
-    api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
+    api["bias_relu"] = fn("bias_relu", C.c_int, P, P, C.c_int32, P)
+    api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
     api["relu_bwd"] = fn("relu_bwd", C.c_int, P, P, P, C.c_int32, P)
     api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P)
     api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, C.c_float, P)
@@ -89,7 +90,7 @@ class FusedPpoUpdate:
         self.state[K["DWP_S_SCALE"]] = 65536.0
         o = 0
         self.views, self.views16, self.gviews = {}, {}, {}
-        for name, shape in (("W1", (2, HID, IN)), ("W2", (2, HID, HID)), ("W3", (2, OUTP, HID)), ("b1", (2, HID)), ("b2", (2, HID)), ("b3", (2, OUTP))):
+        for name, shape in (("W1", (2, HID, INP)), ("W2", (2, HID, HID)), ("W3", (2, OUTP, HID)), ("b1", (2, HID)), ("b2", (2, HID)), ("b3", (2, OUTP))):
             n = 1
             for s in shape:
                 n *= s
@@ -102,15 +103,16 @@ class FusedPpoUpdate:
         with torch.no_grad():
             for k, (trunk, head, rows) in enumerate(((lins[0], net.mu, ACT), (lins[1], net.value, 1))):
                 for name, lin in (("1", trunk[0]), ("2", trunk[1])):
-                    self.views["W" + name][k].copy_(lin.weight)
+                    cols = lin.weight.shape[1]          # (W1: 487 of its 512 padded columns; the padding stays zero -- its gradient is zero)
+                    self.views["W" + name][k, :, :cols].copy_(lin.weight)
                     self.views["b" + name][k].copy_(lin.bias)
-                    lin.weight.data, lin.bias.data = self.views["W" + name][k], self.views["b" + name][k]
+                    lin.weight.data, lin.bias.data = self.views["W" + name][k, :, :cols], self.views["b" + name][k]
                 self.views["W3"][k, :rows].copy_(head.weight)
                 self.views["b3"][k, :rows].copy_(head.bias)
                 head.weight.data, head.bias.data = self.views["W3"][k, :rows], self.views["b3"][k, :rows]
             self.p16.copy_(self.p)
         B = self.B
-        self.x16 = torch.zeros(B, IN, **f16)
+        self.x16 = torch.zeros(B, INP, **f16)
         self.h1, self.h2 = torch.zeros(2, B, HID, **f16), torch.zeros(2, B, HID, **f16)
         self.out = torch.zeros(2, B, OUTP, **f16)
         self.dout = torch.zeros(2, B, OUTP, **f16)
@@ -144,13 +146,13 @@ class FusedPpoUpdate:
         W, W16, G = self.views, self.views16, self.gviews
         self._chk(api["stage_obs"](obs.data_ptr(), st, B, self.x16.data_ptr(), s))
         # forward: Linear + relu twice, the two heads (fp16 in, fp32 accumulate, fp16 out: nn.Linear under autocast)
-        torch.baddbmm(W16["b1"].unsqueeze(1), self.x16.unsqueeze(0).expand(2, B, IN), W16["W1"].transpose(1, 2), out=self.h1)
-        torch.relu_(self.h1)
-        torch.baddbmm(W16["b2"].unsqueeze(1), self.h1, W16["W2"].transpose(1, 2), out=self.h2)
-        torch.relu_(self.h2)
-        torch.baddbmm(W16["b3"].unsqueeze(1), self.h2, W16["W3"].transpose(1, 2), out=self.out)
-        self._chk(api["loss"](self.out.data_ptr(), act.data_ptr(), nlp.data_ptr(), mu_old.data_ptr(), adv.data_ptr(), ret.data_ptr(), self.logstd.data_ptr(), st,
-                              self.gb.data_ptr(), B, self.e_clip, self.critic_coef, self.dout.data_ptr(), s))
+        torch.bmm(self.x16.unsqueeze(0).expand(2, B, INP), W16["W1"].transpose(1, 2), out=self.h1)
+        self._chk(api["bias_relu"](self.h1.data_ptr(), W16["b1"].data_ptr(), B, s))
+        torch.bmm(self.h1, W16["W2"].transpose(1, 2), out=self.h2)
+        self._chk(api["bias_relu"](self.h2.data_ptr(), W16["b2"].data_ptr(), B, s))
+        torch.bmm(self.h2, W16["W3"].transpose(1, 2), out=self.out)
+        self._chk(api["loss"](self.out.data_ptr(), W16["b3"].data_ptr(), act.data_ptr(), nlp.data_ptr(), mu_old.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                              self.logstd.data_ptr(), st, self.gb.data_ptr(), B, self.e_clip, self.critic_coef, self.dout.data_ptr(), s))
         # backward: weight gradients dY' X, input gradients dY W, relu masks (with the bias gradients) in between
         torch.bmm(self.dout.transpose(1, 2), self.h2, out=G["W3"])
         torch.bmm(self.dout, W16["W3"], out=self.dh2)
@@ -158,7 +160,7 @@ class FusedPpoUpdate:
         torch.bmm(self.dh2.transpose(1, 2), self.h1, out=G["W2"])
         torch.bmm(self.dh2, W16["W2"], out=self.dh1)
         self._chk(api["relu_bwd"](self.h1.data_ptr(), self.dh1.data_ptr(), self.gb.data_ptr(), B, s))
-        torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, IN), out=G["W1"])
+        torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
         # unscale + clip + Adam + scaler
         self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, s))
         self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.max_norm, s))
