@@ -81,12 +81,15 @@ int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const flo
 /* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */
 int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
 
-/* state[NORM2] += sum over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient is not finite */
-int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, void *stream);
+#define DWP_PARTS 256   /* words of `part` */
+/* part[0 .. DWP_PARTS) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
+ * that net is not finite */
+int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, float *part, void *stream);
 
 /* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
- * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first */
-int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, const float *state, float max_norm,
+ * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first (norm^2 = the sum of `part`, published in
+ * state[NORM2]) */
+int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
              void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),

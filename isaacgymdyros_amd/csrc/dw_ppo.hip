@@ -38,15 +38,17 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 __global__ __launch_bounds__(256) void k_stage_obs(const float *__restrict__ obs, const float *__restrict__ state, int B, _Float16 *__restrict__ x16) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    // one thread per pair of output words: consecutive lanes read consecutive floats of a row (rows are 487 words: no wider aligned load exists)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const size_t base = (size_t)(int)state[DWP_S_MB] * B * IN;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;          // one thread per 8 output words
-    if (t >= (size_t)B * (INP / 8)) return;
-    const size_t row = t / (INP / 8);
-    const int c0 = (int)(t % (INP / 8)) * 8;
-    h8 v;
-    for (int q = 0; q < 8; ++q) v[q] = c0 + q < IN ? (_Float16)obs[base + row * IN + c0 + q] : (_Float16)0.0f;
-    *reinterpret_cast<h8 *>(x16 + row * INP + c0) = v;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)B * (INP / 2)) return;
+    const size_t row = t / (INP / 2);
+    const int c0 = (int)(t % (INP / 2)) * 2;
+    h2 v;
+    v[0] = c0 < IN ? (_Float16)obs[base + row * IN + c0] : (_Float16)0.0f;
+    v[1] = c0 + 1 < IN ? (_Float16)obs[base + row * IN + c0 + 1] : (_Float16)0.0f;
+    *reinterpret_cast<h2 *>(x16 + row * INP + c0) = v;
 }
 
 // 16 lanes per sample (lane k < 13: action k; lane 0 also the value), 64 samples per block (few blocks: every block ends in 19 atomic adds
@@ -154,8 +156,9 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const _Float16 *__restrict__ h
 
 __device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *gb, int i) { return i < NWT ? (float)g16[i] : gb[i - NWT]; }
 
-constexpr int GS_BLOCKS = 64;          // (every block ends in one atomic add on the same word)
-__global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state) {
+constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per block, in `part`; dwp_adam's blocks add them up (no atomics: 256
+                                        // adds on one word are served one after the other and were most of this kernel's 12 us)
+__global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part) {
     __shared__ float red[4];
     const float inv = 1.0f / state[DWP_S_SCALE];
     float sq = 0.0f;
@@ -170,20 +173,30 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
     sq = wave_sum(sq);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&state[DWP_S_NORM2], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     if (bad0) state[DWP_S_FOUND_INF] = 1.0f;
     if (bad1) state[DWP_S_FOUND_INF + 1] = 1.0f;
 }
 
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
-                                              const _Float16 *__restrict__ g16, const float *__restrict__ gb, const float *__restrict__ state, float max_norm) {
+                                              const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
+                                              float max_norm) {
+    __shared__ float red[4];
+    static_assert(GS_BLOCKS == 256, "one partial per thread");
+    {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
+        const float s = wave_sum(part[threadIdx.x]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+    }
+    const float norm2 = red[0] + red[1] + red[2] + red[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NP) return;
     const int net = net_of(i);
     if (state[DWP_S_FOUND_INF + net] != 0.0f) return;          // GradScaler.step: this optimiser's step is skipped
     float g = scaled_grad(g16, gb, i) * (1.0f / state[DWP_S_SCALE]);
     if (net == 0) {
-        const float coef = max_norm / (sqrtf(state[DWP_S_NORM2]) + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+        const float coef = max_norm / (sqrtf(norm2) + 1e-6f);          // torch.nn.utils.clip_grad_norm_
         g *= fminf(coef, 1.0f);
     }
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
@@ -234,7 +247,7 @@ const char *dwp_last_error(void) { return g_err; }
 
 int dwp_stage_obs(const float *obs, const float *state, int32_t B, uint16_t *x16, void *stream) {
     if (!obs || !state || !x16 || B < 1) return fail("dwp_stage_obs: bad argument");
-    const size_t n = (size_t)B * (INP / 8);
+    const size_t n = (size_t)B * (INP / 2);
     hipLaunchKernelGGL(k_stage_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, state, B, (_Float16 *)x16);
     return done("dwp_stage_obs");
 }
@@ -260,15 +273,15 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
     return done("dwp_relu_bwd");
 }
 
-int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, void *stream) {
-    if (!g16 || !gb || !state) return fail("dwp_grad_stats: bad argument");
-    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state);
+int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, float *part, void *stream) {
+    if (!g16 || !gb || !state || !part) return fail("dwp_grad_stats: bad argument");
+    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part);
     return done("dwp_grad_stats");
 }
 
-int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, const float *state, float max_norm, void *stream) {
-    if (!p || !p16 || !m || !v || !g16 || !gb || !state) return fail("dwp_adam: bad argument");
-    hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, max_norm);
+int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, void *stream) {
+    if (!p || !p16 || !m || !v || !g16 || !gb || !state || !part) return fail("dwp_adam: bad argument");
+    hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm);
     return done("dwp_adam");
 }
 

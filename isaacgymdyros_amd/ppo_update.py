@@ -51,8 +51,8 @@ def declare(lib: C.CDLL) -> dict:
     api["bias_relu"] = fn("bias_relu", C.c_int, P, P, C.c_int32, P)
     api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
     api["relu_bwd"] = fn("relu_bwd", C.c_int, P, P, P, C.c_int32, P)
-    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P)
-    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, C.c_float, P)
+    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P, P)
+    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P)
     if api["abi_version"]() != K["DWP_ABI_VERSION"]:
         raise RuntimeError("libdyroswalk_hip.so: dwp ABI %d, header %d" % (api["abi_version"](), K["DWP_ABI_VERSION"]))
@@ -87,6 +87,7 @@ class FusedPpoUpdate:
         self.g16 = torch.zeros(NWT, **f16)
         self.gb = torch.zeros(NB1 + NB2 + NB3, **f32)
         self.state = torch.zeros(K["DWP_S_WORDS"], **f32)
+        self.part = torch.zeros(K["DWP_PARTS"], **f32)
         self.state[K["DWP_S_SCALE"]] = 65536.0
         o = 0
         self.views, self.views16, self.gviews = {}, {}, {}
@@ -162,8 +163,8 @@ class FusedPpoUpdate:
         self._chk(api["relu_bwd"](self.h1.data_ptr(), self.dh1.data_ptr(), self.gb.data_ptr(), B, s))
         torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
         # unscale + clip + Adam + scaler
-        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, s))
-        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.max_norm, s))
+        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), s))
+        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, s))
         self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, s))
 
     def logged(self):
