@@ -186,3 +186,21 @@ dist.barrier(); dist.destroy_process_group()
         o = json.load(open(tmp_path / ("t%d.json" % k)))
         assert o["same_weights"] and o["finite"] and o["epochs"] == 2, o
         assert not o["same_noise"], "every rank drew the same exploration noise"
+
+
+def test_fused_update_refuses_what_it_was_not_written_for():
+    """isaacgymdyros_amd/ppo_update.py: configurations and network shapes other than DyrosDynamicWalkPPO.yaml's are a ValueError on the
+    host before the library is touched; the layout constants mirror include/dyros_ppo.h."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _mod()
+    c = dict(ppo.TRAIN_CFG["config"])
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"])
+    for bad in ({"clip_value": True}, {"entropy_coef": 0.01}, {"bounds_loss_coef": 0.1}, {"truncate_grads": False}, {"mixed_precision": False}):
+        with pytest.raises(ValueError):
+            U.FusedPpoUpdate(net, dict(c, **bad), 4096, 4, "cpu")
+    wide = ppo.DyrosActorCritic(U.IN, U.ACT, dict(ppo.TRAIN_CFG["network"], mlp_units=[512, 256]))
+    with pytest.raises(ValueError):
+        U.FusedPpoUpdate(wide, c, 4096, 4, "cpu")
+    assert (U.IN, U.INP, U.HID, U.OUTP, U.ACT) == (487, 512, 256, 16, 13) and U.NP == 2 * (256 * 512 + 256 * 256 + 16 * 256 + 256 + 256 + 16)
+    with pytest.raises(ValueError):
+        ppo.train(8, epochs=1, horizon=4, device="cpu", fused_update=True, env=type("E", (), {"num_envs": 8, "num_obs": U.IN, "num_acts": U.ACT})())
