@@ -898,19 +898,33 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             fx[0] = fx4.x; fx[1] = fx4.y; fx[2] = fx4.z;
         }
         DQ_UNROLL for (int k = 0; k < 4; ++k) {
-            float r[3];
-            m3v(fR, M.foot_pos[4 * f + k], r);
-            DQ_UNROLL for (int i = 0; i < 3; ++i) r[i] += fx[i];
-            float phi = X.root[2] + r[2];
-            if (TERRAIN) {
-                float hh;
-                dw::terrain_sample(P, X.root[0] + r[0], X.root[1] + r[1], &hh, frame[k]);
-                phi = (phi - hh) * frame[k][8];
-            } else {
-                DQ_UNROLL for (int i = 0; i < 9; ++i) frame[k][i] = (i % 4 == 0) ? 1.0f : 0.0f;
+            m3v(fR, M.foot_pos[4 * f + k], rk[k]);
+            DQ_UNROLL for (int i = 0; i < 3; ++i) rk[k][i] += fx[i];
+        }
+        float hh4[4];
+        if (TERRAIN) {
+#if defined(OCT_SAMPLE_ALL)          // (A/B builds only: every lane of the foot samples all four corners, as before round 5)
+            DQ_UNROLL for (int k = 0; k < 4; ++k) dw::terrain_sample(P, X.root[0] + rk[k][0], X.root[1] + rk[k][1], &hh4[k], frame[k]);
+#else
+            // The four lanes that work on a foot (2 parts x 2 halves) each sample the height field under ONE corner -- corner part + 2 h --
+            // and hand height and frame round: 4 fetches of 2 bytes and one interpolation per lane instead of 16 and four, for two DPP moves
+            // per word (the values are the ones every lane computed for itself before: same arithmetic on the same corner)
+            const int ko = part + 2 * X.h;
+            float ro[2], ho, fo[9];
+            DQ_UNROLL for (int i = 0; i < 2; ++i) ro[i] = ko == 0 ? rk[0][i] : (ko == 1 ? rk[1][i] : (ko == 2 ? rk[2][i] : rk[3][i]));
+            dw::terrain_sample(P, X.root[0] + ro[0], X.root[1] + ro[1], &ho, fo);
+            DQ_UNROLL for (int k = 0; k < 4; ++k) {
+                auto from = [&](float x) { const float t = (k & 1) ? quad_pair_hi(x) : quad_pair_lo(x); return (k >> 1) ? oct_hi(t) : oct_lo(t); };
+                hh4[k] = from(ho);
+                DQ_UNROLL for (int i = 0; i < 9; ++i) frame[k][i] = from(fo[i]);
             }
+#endif
+        }
+        DQ_UNROLL for (int k = 0; k < 4; ++k) {
+            float phi = X.root[2] + rk[k][2];
+            if (TERRAIN) phi = (phi - hh4[k]) * frame[k][8];
+            else { DQ_UNROLL for (int i = 0; i < 9; ++i) frame[k][i] = (i % 4 == 0) ? 1.0f : 0.0f; }
             act[k] = phi < P.contact_offset;
-            DQ_UNROLL for (int i = 0; i < 3; ++i) rk[k][i] = r[i];
             vminr[k] = phi >= 0 ? -phi * inv_dt : fminf(P.erp * (-phi) * inv_dt, P.max_depen);
         }
     }
