@@ -5,7 +5,8 @@ import torch
 from isaacgymdyros_amd.config import default_cfg, with_terrain, with_friction_randomization
 from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
 
-N, STEPS = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096          # (4096: the hex instantiation; 16384: the two-waves octet build)
 for name, cfg in (("flat", with_friction_randomization(default_cfg(N, "cuda:0"))),
                   ("terrain", with_terrain(default_cfg(N, "cuda:0"), mesh_type="trimesh", curriculum=True))):
     cfg["sim"]["mi355"]["force_perturb_start"] = True
