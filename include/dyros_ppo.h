@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 1
+#define DWP_ABI_VERSION 2
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -82,19 +82,45 @@ int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const flo
 int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
 
 #define DWP_PARTS 256   /* words of `part` */
+#define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
+#define DWP_PBUF_WORDS 544   /* words of a row of dwp_mlp's accumulators */
+#define DWP_PBUF_BUCKETS 32  /* rows per net: pbuf is [DWP_PBUF_BUCKETS][2][DWP_PBUF_WORDS] floats, zero-initialised by the caller once */
 /* part[0 .. DWP_PARTS) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
- * that net is not finite */
-int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, float *part, void *stream);
+ * that net is not finite.  pbuf (or NULL): dwp_mlp's accumulators: the bias gradients are their sums over the buckets (cleared here)
+ * and are left in gb for dwp_adam (without it gb holds them already: dwp_loss / dwp_relu_bwd) */
+int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, void *stream);
 
 /* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
  * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first (norm^2 = the sum of `part`, published in
- * state[NORM2]) */
+ * state[NORM2]).  p16f (or NULL): the fragment-order fp16 copy of the weights that dwp_mlp reads (DWP_P16F_WORDS halves, zero-initialised
+ * by the caller and filled once with dwp_retile) */
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
-             void *stream);
+             uint16_t *p16f, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
- * accumulators and gb cleared, minibatch index advanced modulo num_minibatches */
-int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, void *stream);
+ * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum
+ * words are added to the logged sums first (and cleared) */
+int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream);
+
+/* dwp_stage_obs + the three layers of both nets + dwp_loss + the two input-gradient products with their relu masks and all bias
+ * gradients, in ONE launch on the matrix cores (v_mfma_f32_16x16x32_f16): a workgroup of four wavefronts takes 32 samples through one net
+ * (every product split four ways by columns), activations
+ * in LDS, weights from the fragment-order fp16 copy (resident in L2; every request of a wave is one contiguous KB).  What is left of an update after it: the three weight-gradient GEMMs
+ * (dout' h2, dz2' h1, dz1' x16: library calls), dwp_grad_stats, dwp_adam, dwp_finish.  Buffers as the other entry points name them;
+ * pbuf: the accumulators of the bias gradients and the logged sums (DWP_PBUF_*: a wave adds into the row of its bucket), read and cleared
+ * by dwp_grad_stats and dwp_finish.  B: a multiple of 32. */
+/* p16f from p16 (all weights; after construction or after loading parameters) */
+int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream);
+
+typedef struct DwpMlp {
+    const float *obs, *state, *act, *old_nlp, *old_mu, *adv, *ret, *logstd;
+    const uint16_t *p16, *p16t;          /* p16t: the fragment-order copy (p16f of dwp_adam / dwp_retile) */
+    float *pbuf;
+    uint16_t *x16, *h1, *h2, *out16, *dout16, *dz2, *dz1;
+    int32_t B;
+    float e_clip, critic_coef;
+} DwpMlp;
+int dwp_mlp(const DwpMlp *a, void *stream);
 
 #ifdef __cplusplus
 }

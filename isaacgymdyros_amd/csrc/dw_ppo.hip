@@ -17,6 +17,8 @@ int fail(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return -1
 constexpr int IN = DWP_IN, INP = DWP_INP, HID = DWP_HID, OUTP = DWP_OUTP, ACT = DWP_ACT;
 constexpr int NW1 = 2 * HID * INP, NW2 = 2 * HID * HID, NW3 = 2 * OUTP * HID, NWT = NW1 + NW2 + NW3;
 constexpr int NB1 = 2 * HID, NB2 = 2 * HID, NB3 = 2 * OUTP, NBT = NB1 + NB2 + NB3, NP = NWT + NBT;
+constexpr int PBK = DWP_PBUF_BUCKETS, PBW = DWP_PBUF_WORDS, PB_B1 = 0, PB_B2 = HID, PB_B3 = 2 * HID, PB_ST = 2 * HID + OUTP;          // a row of dwp_mlp's partial sums (k_mlp)
+static_assert(PB_ST + 5 <= PBW, "row of partial sums");
 
 // which net (0 actor, 1 critic) owns element i of the parameter layout
 __device__ __forceinline__ int net_of(int i) {
@@ -32,6 +34,34 @@ __device__ __forceinline__ int net_of(int i) {
     i -= NB2;
     return i >= NB3 / 2;
 }
+// dwp_mlp reads its weights in FRAGMENT order: the eight halves lane l of a wave feeds to v_mfma_f32_16x16x32_f16 as B for k-step kk and
+// column tile nt -- W[row 16 nt + (l & 15)][k = 32 kk + 8 (l >> 4) + j] -- are 16 consecutive bytes at ((kk * NT + nt) * 64 + l) * 16, so a
+// wave's request is ONE contiguous KB and successive requests walk through memory.  (Read from the row-major copy a request touched 16
+// rows a KB apart -- 16 half-used cache lines on 4 of a die's 16 channels -- and the kernel waited for L2 70 % of its time.)
+// Layout of p16f (halves): W1 | W2 | W3 as forward operands (row = output, k = input), then W2 | W3 as input-gradient operands (row = input,
+// k = output; the head's k padded 16 -> 32 with zeros).  dwp_adam writes every weight to its one or two places; dwp_retile fills the lot.
+constexpr int F_W1 = 0, F_W2 = F_W1 + NW1, F_W3 = F_W2 + NW2, F_W2T = F_W3 + NW3, F_W3T = F_W2T + NW2, F_END = F_W3T + 2 * HID * 32;
+static_assert(F_END == DWP_P16F_WORDS, "include/dyros_ppo.h");
+__device__ __forceinline__ int frag_pos(int nt_count, int row, int k) { return ((((k >> 5) * nt_count + (row >> 4)) * 64 + ((k & 31) >> 3) * 16 + (row & 15)) << 3) + (k & 7); }
+__device__ __forceinline__ void write_frags(_Float16 *__restrict__ p16f, int i, _Float16 v) {          // i: index of a WEIGHT in the parameter layout
+    if (i < NW1) { const int net = i / (HID * INP), o = (i / INP) % HID, k = i % INP; p16f[F_W1 + net * HID * INP + frag_pos(HID / 16, o, k)] = v; return; }
+    i -= NW1;
+    if (i < NW2) {
+        const int net = i / (HID * HID), o = (i / HID) % HID, k = i % HID;
+        p16f[F_W2 + net * HID * HID + frag_pos(HID / 16, o, k)] = v;
+        p16f[F_W2T + net * HID * HID + frag_pos(HID / 16, k, o)] = v;
+        return;
+    }
+    i -= NW2;
+    const int net = i / (OUTP * HID), o = (i / HID) % OUTP, k = i % HID;
+    p16f[F_W3 + net * OUTP * HID + frag_pos(1, o, k)] = v;
+    p16f[F_W3T + net * HID * 32 + frag_pos(HID / 16, k, o)] = v;
+}
+__global__ __launch_bounds__(256) void k_retile(const _Float16 *__restrict__ p16, _Float16 *__restrict__ p16f) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NWT) write_frags(p16f, i, p16[i]);
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
     for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
@@ -158,14 +188,28 @@ __device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *g
 
 constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per block, in `part`; dwp_adam's blocks add them up (no atomics: 256
                                         // adds on one word are served one after the other and were most of this kernel's 12 us)
-__global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part) {
+__global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part,
+                                                    float *__restrict__ pbuf) {
     __shared__ float red[4];
     const float inv = 1.0f / state[DWP_S_SCALE];
     float sq = 0.0f;
     int bad0 = 0, bad1 = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < NP; i += GS_BLOCKS * 256) {
-        const float g = scaled_grad(g16, gb, i);
         const int net = net_of(i);
+        float g;
+        if (i >= NWT && pbuf) {
+            // a bias gradient of the dwp_mlp path: the column's sum over the buckets (cleared for the next update), left in gb for dwp_adam
+            const int q = i - NWT;
+            const int col = q < NB1 ? PB_B1 + q % HID : (q < NB1 + NB2 ? PB_B2 + (q - NB1) % HID : PB_B3 + (q - NB1 - NB2) % OUTP);
+            float *pc = pbuf + (size_t)net * PBW + col;
+            float s0 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < PBK; ++w) { s0 += pc[(size_t)w * 2 * PBW]; }
+#pragma unroll
+            for (int w = 0; w < PBK; ++w) pc[(size_t)w * 2 * PBW] = 0.0f;
+            g = s0;
+            gb[q] = g;
+        } else g = scaled_grad(g16, gb, i);
         if (!isfinite(g)) { if (net) bad1 = 1; else bad0 = 1; }
         const float u = g * inv;
         if (net == 0) sq += u * u;
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
 
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
-                                              float max_norm) {
+                                              float max_norm, _Float16 *__restrict__ p16f) {
     __shared__ float red[4];
     static_assert(GS_BLOCKS == 256, "one partial per thread");
     {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
@@ -209,10 +253,19 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     const float pi = p[i] - (lr / bc1) * (mi / denom);
     p[i] = pi;
     p16[i] = (_Float16)pi;
+    if (p16f && i < NWT) write_frags(p16f, i, (_Float16)pi);
 }
 
-__global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float *__restrict__ gb, int B, int nmb, int growth_interval) {
+__global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float *__restrict__ gb, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
     for (int i = threadIdx.x; i < NBT; i += 256) gb[i] = 0.0f;
+    if (pbuf) {          // dwp_mlp's logged sums: over the buckets and the two nets, cleared for the next update
+        if (threadIdx.x < 5) {
+            float t = 0.0f;
+            for (int r = 0; r < 2 * PBK; ++r) { t += pbuf[(size_t)r * PBW + PB_ST + threadIdx.x]; pbuf[(size_t)r * PBW + PB_ST + threadIdx.x] = 0.0f; }
+            state[threadIdx.x] += t;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
     const float invB = 1.0f / (float)B;
     const bool f0 = state[DWP_S_FOUND_INF] != 0.0f, f1 = state[DWP_S_FOUND_INF + 1] != 0.0f;
@@ -231,6 +284,237 @@ __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float
     for (int k = 0; k < 8; ++k) state[k] = 0.0f;
     const int mb = (int)state[DWP_S_MB] + 1;
     state[DWP_S_MB] = (float)(mb >= nmb ? 0 : mb);
+}
+
+// ------------------------------------------------------------------------------------------------ dwp_mlp: forward, loss, input gradients
+// One wavefront = one workgroup takes 16 samples through ONE net (blockIdx.y: 0 actor, 1 critic): three layers on
+// v_mfma_f32_16x16x32_f16 (A = the wave's 16 activation rows from LDS, B = eight consecutive input weights of one output row per lane,
+// straight from the fp16 parameter copy in L2 -- the 1 MB of weights is resident there), bias + relu in the epilogue, the loss on the
+// head's accumulator tile (its 16 columns are the 16 lanes of a DPP row: per-sample sums are row reductions), then the two
+// input-gradient products against the k-outermost weight copies with the relu masks and the bias gradients in their epilogues.  Nothing
+// is shared between waves, so there is no barrier wider than the wave.  Writes every buffer the weight-gradient GEMMs read (x16, h1, h2,
+// dout, dz2, dz1) in 16-byte rows.
+// Lane maps (cdna_hip_programming.md section 3; checked by tests/test_ppo_gpu.py against torch matmul on the same operands):
+//   A[row l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][col l & 15], j = 0..7;  C/D[row 4 (l >> 4) + r][col l & 15], r = 0..3.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+// A workgroup = 4 waves takes MT = 32 samples (MR = 2 row tiles of 16) through ONE net.  The waves share the activation images in LDS and
+// split every product by COLUMNS: wave w owns column tiles 4 w .. 4 w + 3 of the 16 (so a weight fragment is fetched by one wave of the
+// workgroup and used for MR products), writes its columns of the layer's output image, and a workgroup barrier separates the layers.
+// (One wave doing all 16 column tiles of 16 or 32 rows took 43-47 us whatever the tiling: a lone wave per SIMD runs its GEMM steps,
+// epilogues and copies one after the other; split four ways each SIMD of the CU has a wave and a quarter of the work.)
+constexpr int MR = 2, MT = 16 * MR, WPB = 4, XS = INP + 8, HS = HID + 8, NTL = HID / 16, NTW = NTL / WPB;          // LDS row strides in halves (+16 B)
+
+// acc[mr][t] = As[16 mr .. +15][K] . W[16 (nt0 + t) .. +15][K]' for NT column tiles from nt0 (NTA = column tiles of the whole matrix); W in
+// fragment order.  A lone wave per SIMD has nothing to hide an L2 round trip behind but its own products: the B fragments are requested
+// RD - 1 k-steps ahead into a ring of RD register sets (the loop is unrolled: every index is static), and scheduling barriers keep the
+// requests where they are written -- the machine scheduler otherwise sinks every request to just before its product (fewer live
+// registers, and the ring is gone: measured 71 % of the wave's cycles waiting at vmcnt(1) / vmcnt(2)).
+template <int K, int AS, int NTA, int NT, int RD>
+__device__ __forceinline__ void mfma_rows(const _Float16 *As, const _Float16 *__restrict__ W, int nt0, f4 (&acc)[MR][NT], int lane) {
+    constexpr int KS = K / 32;
+    const int ar = lane & 15, ak = 8 * (lane >> 4);
+    const h8 *wl = reinterpret_cast<const h8 *>(W) + nt0 * 64 + lane;          // (W: the matrix in fragment order, frag_pos)
+    h8 b[RD][NT];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mr][t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int pk = 0; pk < RD - 1 && pk < KS; ++pk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[pk][t] = wl[(pk * NTA + t) * 64];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        if (kk + RD - 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[(kk + RD - 1) % RD][t] = wl[((kk + RD - 1) * NTA + t) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h8 a[MR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a[mr] = *reinterpret_cast<const h8 *>(As + (16 * mr + ar) * AS + 32 * kk + ak);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mr], b[kk % RD][t], acc[mr][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the workgroup's MT rows of an LDS image [MT][stride] to global rows of `cols` halves, 16 bytes per thread and request
+template <int COLS, int STRIDE>
+__device__ __forceinline__ void rows_out(const _Float16 *Ls, _Float16 *__restrict__ g, int tid) {
+#pragma unroll
+    for (int t = tid; t < MT * (COLS / 8); t += 64 * WPB) {
+        const int r = t / (COLS / 8), c = (t % (COLS / 8)) * 8;
+        *reinterpret_cast<h8 *>(g + (size_t)r * COLS + c) = *reinterpret_cast<const h8 *>(Ls + r * STRIDE + c);
+    }
+}
+// bias + relu of my column tiles of a hidden layer from the accumulator tiles into the layer's LDS image
+__device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][NTW], const float (&bia)[NTW], _Float16 *Hs, int nt0, int cr, int g) {
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const _Float16 h = (_Float16)(acc[mr][t][r] + bia[t]);
+                Hs[(16 * mr + 4 * g + r) * HS + 16 * (nt0 + t) + cr] = (float)h > 0.0f ? h : (_Float16)0.0f;
+            }
+}
+// relu mask of my column tiles of a hidden layer's gradient (Hs: that layer's activations) into Zs, their bias gradient into the accumulators
+__device__ __forceinline__ void masked_out(const f4 (&acc)[MR][NTW], const _Float16 *Hs, _Float16 *Zs, float *pcol, int nt0, int cr, int g, int lane) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        float cs = 0.0f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = (16 * mr + 4 * g + r) * HS + 16 * (nt0 + t) + cr;
+                const _Float16 z = (float)Hs[idx] > 0.0f ? (_Float16)acc[mr][t][r] : (_Float16)0.0f;
+                Zs[idx] = z;
+                cs += (float)z;
+            }
+        cs += __shfl_xor(cs, 16, 64); cs += __shfl_xor(cs, 32, 64);
+        if (lane < 16) atomicAdd(&pcol[16 * (nt0 + t) + lane], cs);
+    }
+}
+
+// Bias gradients and logged sums of dwp_mlp: every workgroup adds its samples' column sums into ONE OF 32 rows of accumulators (its
+// bucket: workgroup index mod 32) -- [0, 256) the first hidden layer's bias gradient, [256, 512) the second's, [512, 528) the head's,
+// [528, 533) the logged sums -- so that an accumulator word sees 4 adds per update instead of 128.  dwp_grad_stats adds the buckets up
+// into gb and clears them, dwp_finish does the same for the logged sums.
+struct MlpArgs {
+    const float *obs, *state, *act, *old_nlp, *old_mu, *adv, *ret, *logstd;
+    const _Float16 *p16, *p16t;
+    float *pbuf;
+    _Float16 *x16, *h1, *h2, *out16, *dout16, *dz2, *dz1;
+    int B;
+    float e_clip, critic_coef;
+};
+
+__global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
+    __shared__ _Float16 Xs[MT * XS];          // the input rows; after the first layer: the masked gradient of the second hidden layer
+    __shared__ _Float16 H1s[MT * HS], H2s[MT * HS], Ds[MT * HS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, net = blockIdx.y, r0 = blockIdx.x * MT, B = A.B;
+    const int nt0 = NTW * wv;          // my column tiles: nt0 .. nt0 + NTW - 1
+    const int mb = (int)A.state[DWP_S_MB];
+    const int cr = lane & 15, g = lane >> 4;          // my column in a C tile, my group of four rows
+    float *prow = A.pbuf + ((size_t)(blockIdx.x & (PBK - 1)) * 2 + net) * PBW;          // (my bucket's row of accumulators)
+    const _Float16 *W1 = A.p16t + F_W1 + (size_t)net * HID * INP, *W2 = A.p16t + F_W2 + (size_t)net * HID * HID, *W3 = A.p16t + F_W3 + (size_t)net * OUTP * HID;
+    const _Float16 *b1 = A.p16 + NWT + net * HID, *b2 = A.p16 + NWT + NB1 + net * HID, *b3 = A.p16 + NWT + NB1 + NB2 + net * OUTP;
+    const _Float16 *W2T = A.p16t + F_W2T + (size_t)net * HID * HID, *W3T = A.p16t + F_W3T + (size_t)net * HID * 32;
+    // ---- the input rows: fp32 observations -> fp16, zero padding (autocast's cast of the Linear input) ----
+    {
+        const float *src = A.obs + ((size_t)mb * B + r0) * IN;
+        // the rows are MT x 487 consecutive floats: every thread requests its share before it converts the first word -- one memory
+        // latency for the block instead of one per turn of a loop
+        constexpr int NF = MT * IN, PER = (NF + 64 * WPB - 1) / (64 * WPB);
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int i = tid + 64 * WPB * u; v[u] = src[i < NF ? i : NF - 1]; }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + 64 * WPB * u;
+            if (i < NF) { const int r = i / IN, c = i - r * IN; Xs[r * XS + c] = (_Float16)v[u]; }
+        }
+        for (int t = tid; t < MT * (INP - IN); t += 64 * WPB) { const int r = t / (INP - IN), c = IN + t % (INP - IN); Xs[r * XS + c] = (_Float16)0.0f; }
+        __syncthreads();
+        if (net == 0) rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid);
+    }
+    f4 acc[MR][NTW];
+    float bia[NTW];          // (a layer's biases, requested before its products: their latency passes under the GEMM)
+    // ---- hidden layer 1 ----
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bia[t] = (float)b1[16 * (nt0 + t) + cr];
+    mfma_rows<INP, XS, NTL, NTW, 4>(Xs, W1, nt0, acc, lane);
+    hidden_out(acc, bia, H1s, nt0, cr, g);
+    __syncthreads();
+    rows_out<HID, HS>(H1s, A.h1 + ((size_t)net * B + r0) * HID, tid);
+    // ---- hidden layer 2 ----
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bia[t] = (float)b2[16 * (nt0 + t) + cr];
+    mfma_rows<HID, HS, NTL, NTW, 4>(H1s, W2, nt0, acc, lane);
+    hidden_out(acc, bia, H2s, nt0, cr, g);
+    __syncthreads();
+    rows_out<HID, HS>(H2s, A.h2 + ((size_t)net * B + r0) * HID, tid);
+    // ---- the head (16 padded outputs = one column tile; every wave forms it -- 16 products) and the loss on its accumulator tiles: column =
+    //      lane of a DPP row; wave w takes accumulator row w of every lane group, i.e. samples 4 g + w of each row tile ----
+    // (what the loss needs from memory is requested before the head's products; so are my head weights of the product after it)
+    const bool ak = cr < ACT;
+    const float scale = A.state[DWP_S_SCALE], invB = 1.0f / (float)B;
+    const float bias = (float)b3[cr], ls = ak ? A.logstd[cr] : 0.0f;
+    float in_a[MR], in_om[MR], in_adv[MR], in_nlp[MR], in_ret[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const size_t srow = (size_t)mb * B + r0 + 16 * mr + 4 * g + wv;
+        in_a[mr] = net == 0 && ak ? A.act[srow * ACT + cr] : 0.0f; in_om[mr] = net == 0 && ak ? A.old_mu[srow * ACT + cr] : 0.0f;
+        in_adv[mr] = A.adv[srow]; in_nlp[mr] = A.old_nlp[srow]; in_ret[mr] = A.ret[srow];
+    }
+    h8 w3t[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) w3t[t] = reinterpret_cast<const h8 *>(W3T)[(nt0 + t) * 64 + lane];          // (k 16 .. 31: the zero padding)
+    f4 o4[MR][1];
+    mfma_rows<HID, HS, 1, 1, 8>(H2s, W3, 0, o4, lane);
+    {
+        float st[5] = {0, 0, 0, 0, 0}, gsum = 0.0f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int row = 16 * mr + 4 * g + wv;
+            const float oacc = wv == 0 ? o4[mr][0][0] : (wv == 1 ? o4[mr][0][1] : (wv == 2 ? o4[mr][0][2] : o4[mr][0][3]));
+            const _Float16 o16 = (net == 0 ? ak : cr == 0) ? (_Float16)(oacc + bias) : (_Float16)0.0f;
+            A.out16[((size_t)net * B + r0 + row) * OUTP + cr] = o16;
+            _Float16 d16 = (_Float16)0.0f;
+            if (net == 0) {
+                const float mu = (float)o16, a = in_a[mr], om = in_om[mr];
+                const float sg = expf(ls), z = (a - mu) / sg, s2 = sg * sg;
+                const float hi = fminf(mu - 1.1f, 0.0f), lo = fminf(-mu + 1.1f, 0.0f);
+                const float sq = sum16(ak ? z * z : 0.0f), lsum = sum16(ls), bl = sum16(ak ? lo * lo + hi * hi : 0.0f);
+                const float kl = sum16(ak ? logf(sg / sg + 1e-5f) + (s2 + (om - mu) * (om - mu)) / (2.0f * (s2 + 1e-5f)) - 0.5f : 0.0f);
+                const float nlp = 0.5f * sq + 0.5f * 1.8378770664093453f * (float)ACT + lsum;
+                const float Ad = in_adv[mr], ratio = expf(in_nlp[mr] - nlp);
+                const float rc = fminf(fmaxf(ratio, 1.0f - A.e_clip), 1.0f + A.e_clip);
+                const float s1 = -Ad * ratio, sc = -Ad * rc;
+                const bool inside = ratio >= 1.0f - A.e_clip && ratio <= 1.0f + A.e_clip;
+                float w = s1 > sc ? 1.0f : (s1 == sc ? 0.5f : 0.0f);
+                if (inside) w += sc > s1 ? 1.0f : (s1 == sc ? 0.5f : 0.0f);
+                d16 = (_Float16)(ak ? scale * invB * (Ad * ratio * w) * (-(a - mu) / s2) : 0.0f);
+                if (cr == 0) { st[0] += fmaxf(s1, sc); st[2] += bl; st[3] += fabsf(ratio - 1.0f) > A.e_clip ? 1.0f : 0.0f; st[4] += kl; }
+            } else {
+                const float v = (float)o16, rt = in_ret[mr];
+                d16 = (_Float16)(cr == 0 ? scale * invB * A.critic_coef * (v - rt) : 0.0f);
+                if (cr == 0) st[1] += (rt - v) * (rt - v);
+            }
+            A.dout16[((size_t)net * B + r0 + row) * OUTP + cr] = d16;
+            Ds[row * HS + cr] = d16;
+            Ds[row * HS + 16 + cr] = (_Float16)0.0f;          // (k 16 .. 31 of the head's input-gradient product: zero)
+            gsum += (float)d16;
+        }
+        // the head's bias gradient (column sums over my rows) and the logged sums, into the workgroup's row of accumulators
+        gsum += __shfl_xor(gsum, 16, 64); gsum += __shfl_xor(gsum, 32, 64);
+        if (lane < OUTP && gsum != 0.0f) atomicAdd(&prow[PB_B3 + lane], gsum);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const float t = wave_sum(st[q]); if (lane == 0 && t != 0.0f) atomicAdd(&prow[PB_ST + q], t); }
+    }
+    __syncthreads();
+    // ---- gradient of the second hidden layer: dOut [rows x 16 (+16 zeros)] . W3 [16 x 256], relu mask, bias gradient ----
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const h8 a = *reinterpret_cast<const h8 *>(Ds + (16 * mr + cr) * HS + 8 * g);          // (lanes with k = 16 .. 31: A is zero there)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3t[t], (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+    }
+    _Float16 *Z2 = Xs;          // [MT][HS]
+    masked_out(acc, H2s, Z2, prow + PB_B2, nt0, cr, g, lane);
+    __syncthreads();
+    rows_out<HID, HS>(Z2, A.dz2 + ((size_t)net * B + r0) * HID, tid);
+    // ---- gradient of the first hidden layer: dz2 [rows x 256] . W2 [256 x 256], relu mask, bias gradient ----
+    mfma_rows<HID, HS, NTL, NTW, 4>(Z2, W2T, nt0, acc, lane);
+    _Float16 *Z1 = Ds;          // (every wave has read its rows of dOut from it: the barrier above)
+    masked_out(acc, H1s, Z1, prow + PB_B1, nt0, cr, g, lane);
+    __syncthreads();
+    rows_out<HID, HS>(Z1, A.dz1 + ((size_t)net * B + r0) * HID, tid);
 }
 
 int done(const char *who) {
@@ -273,22 +557,45 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
     return done("dwp_relu_bwd");
 }
 
-int dwp_grad_stats(const uint16_t *g16, const float *gb, float *state, float *part, void *stream) {
+int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, void *stream) {
     if (!g16 || !gb || !state || !part) return fail("dwp_grad_stats: bad argument");
-    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part);
+    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part, pbuf);
     return done("dwp_grad_stats");
 }
 
-int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, void *stream) {
+int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
+             void *stream) {
     if (!p || !p16 || !m || !v || !g16 || !gb || !state || !part) return fail("dwp_adam: bad argument");
-    hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm);
+    hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
+                       (_Float16 *)p16t);
     return done("dwp_adam");
 }
 
-int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, void *stream) {
+int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream) {
     if (!state || !gb || B < 1 || num_minibatches < 1 || growth_interval < 1) return fail("dwp_finish: bad argument");
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, state, gb, B, num_minibatches, growth_interval);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, state, gb, B, num_minibatches, growth_interval, pbuf);
     return done("dwp_finish");
+}
+
+int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream) {
+    if (!p16 || !p16f) return fail("dwp_retile: bad argument");
+    hipLaunchKernelGGL(k_retile, dim3((NWT + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)p16, (_Float16 *)p16f);
+    return done("dwp_retile");
+}
+
+int dwp_mlp(const DwpMlp *a, void *stream) {
+    if (!a) return fail("dwp_mlp: null argument");
+    const void *need[] = {a->obs, a->state, a->act, a->old_nlp, a->old_mu, a->adv, a->ret, a->logstd, a->p16, a->p16t, a->pbuf, a->x16, a->h1, a->h2, a->out16,
+                          a->dout16, a->dz2, a->dz1};
+    for (const void *q : need) if (!q) return fail("dwp_mlp: null pointer in the argument block");
+    if (a->B < MT || a->B % MT) return fail("dwp_mlp: the minibatch must be a multiple of 32 samples");
+    MlpArgs A;
+    A.obs = a->obs; A.state = a->state; A.act = a->act; A.old_nlp = a->old_nlp; A.old_mu = a->old_mu; A.adv = a->adv; A.ret = a->ret; A.logstd = a->logstd;
+    A.p16 = (const _Float16 *)a->p16; A.p16t = (const _Float16 *)a->p16t; A.pbuf = a->pbuf;
+    A.x16 = (_Float16 *)a->x16; A.h1 = (_Float16 *)a->h1; A.h2 = (_Float16 *)a->h2; A.out16 = (_Float16 *)a->out16; A.dout16 = (_Float16 *)a->dout16;
+    A.dz2 = (_Float16 *)a->dz2; A.dz1 = (_Float16 *)a->dz1; A.B = a->B; A.e_clip = a->e_clip; A.critic_coef = a->critic_coef;
+    hipLaunchKernelGGL(k_mlp, dim3(a->B / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, A);
+    return done("dwp_mlp");
 }
 
 }  // extern "C"

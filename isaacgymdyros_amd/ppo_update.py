@@ -31,12 +31,17 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish"]
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
 NB1, NB2, NB3 = 2 * HID, 2 * HID, 2 * OUTP
 NP = NWT + NB1 + NB2 + NB3
+
+
+class DwpMlp(C.Structure):          # include/dyros_ppo.h
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "state", "act", "old_nlp", "old_mu", "adv", "ret", "logstd", "p16", "p16t", "pbuf",
+                                          "x16", "h1", "h2", "out16", "dout16", "dz2", "dz1")] + [("B", C.c_int32), ("e_clip", C.c_float), ("critic_coef", C.c_float)]
 
 
 def declare(lib: C.CDLL) -> dict:
@@ -51,9 +56,11 @@ def declare(lib: C.CDLL) -> dict:
     api["bias_relu"] = fn("bias_relu", C.c_int, P, P, C.c_int32, P)
     api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
     api["relu_bwd"] = fn("relu_bwd", C.c_int, P, P, P, C.c_int32, P)
-    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P, P)
-    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P)
-    api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P)
+    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P, P, P)
+    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P)
+    api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
+    api["retile"] = fn("retile", C.c_int, P, P, P)
+    api["mlp"] = fn("mlp", C.c_int, C.POINTER(DwpMlp), P)
     if api["abi_version"]() != K["DWP_ABI_VERSION"]:
         raise RuntimeError("libdyroswalk_hip.so: dwp ABI %d, header %d" % (api["abi_version"](), K["DWP_ABI_VERSION"]))
     return api
@@ -64,7 +71,9 @@ class FusedPpoUpdate:
     of the minibatch whose index lives in the device state (it advances by itself: the call has no argument that changes, so it can
     be captured in a hipGraph once and replayed)."""
 
-    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device):
+    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True):
+        """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp; the minibatch must be a multiple of 16) instead
+        of eight library GEMM launches with six kernels between them; the weight-gradient GEMMs and the optimiser kernels are the same."""
         c = cfg
         if bool(c.get("clip_value")) or float(c.get("entropy_coef", 0.0)) != 0.0 or float(c.get("bounds_loss_coef", 0.0)) != 0.0:
             raise ValueError("the fused update is written for clip_value False, entropy_coef 0, bounds_loss_coef 0 (DyrosDynamicWalkPPO.yaml)")
@@ -120,6 +129,11 @@ class FusedPpoUpdate:
         self.dh2, self.dh1 = torch.zeros(2, B, HID, **f16), torch.zeros(2, B, HID, **f16)
         self.logstd = net.sigma
         self.src = None
+        self.mfma = bool(mfma) and B % 32 == 0
+        self.p16t = torch.zeros(K["DWP_P16F_WORDS"], **f16)          # the weights once more, in the order dwp_mlp's matrix instructions take them
+        self._chk(self.api["retile"](self.p16.data_ptr(), self.p16t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
+        self.pbuf = torch.zeros(K["DWP_PBUF_BUCKETS"], 2, K["DWP_PBUF_WORDS"], **f32)          # dwp_mlp: accumulators of bias gradients and logged sums
+        self._mlp_args = None
 
     def _chk(self, rc):
         if rc != 0:
@@ -129,6 +143,7 @@ class FusedPpoUpdate:
         self.state[K["DWP_S_LR"]:K["DWP_S_LR"] + 2] = torch.tensor([lr_actor, lr_critic], device=self.dev)
 
     def bind_batch(self, obs, act, neglogp, mu, adv, ret):
+        self._mlp_args = None
         """The epoch's flat arrays (env-major, `batch` rows; fp32, contiguous).  Their ADDRESSES are what a captured update replays:
         keep the tensors and copy_ each epoch's data into them."""
         for t in (obs, act, neglogp, mu, adv, ret):
@@ -145,6 +160,24 @@ class FusedPpoUpdate:
         obs, act, nlp, mu_old, adv, ret = self.src
         s = torch.cuda.current_stream(self.dev).cuda_stream
         W, W16, G = self.views, self.views16, self.gviews
+        if self.mfma:
+            if self._mlp_args is None:
+                a = DwpMlp()
+                for k_, t_ in (("obs", obs), ("state", self.state), ("act", act), ("old_nlp", nlp), ("old_mu", mu_old), ("adv", adv), ("ret", ret), ("logstd", self.logstd),
+                               ("p16", self.p16), ("p16t", self.p16t), ("pbuf", self.pbuf), ("x16", self.x16), ("h1", self.h1), ("h2", self.h2),
+                               ("out16", self.out), ("dout16", self.dout), ("dz2", self.dh2), ("dz1", self.dh1)):
+                    setattr(a, k_, t_.data_ptr())
+                a.B, a.e_clip, a.critic_coef = B, self.e_clip, self.critic_coef
+                self._mlp_args = a
+            self._chk(api["mlp"](C.byref(self._mlp_args), s))
+            torch.bmm(self.dout.transpose(1, 2), self.h2, out=G["W3"])
+            torch.bmm(self.dh2.transpose(1, 2), self.h1, out=G["W2"])
+            torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
+            self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), s))
+            self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st,
+                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), s))
+            self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
+            return
         self._chk(api["stage_obs"](obs.data_ptr(), st, B, self.x16.data_ptr(), s))
         # forward: Linear + relu twice, the two heads (fp16 in, fp32 accumulate, fp16 out: nn.Linear under autocast)
         torch.bmm(self.x16.unsqueeze(0).expand(2, B, INP), W16["W1"].transpose(1, 2), out=self.h1)
@@ -163,9 +196,9 @@ class FusedPpoUpdate:
         self._chk(api["relu_bwd"](self.h1.data_ptr(), self.dh1.data_ptr(), self.gb.data_ptr(), B, s))
         torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
         # unscale + clip + Adam + scaler
-        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), s))
-        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, s))
-        self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, s))
+        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), None, s))
+        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), s))
+        self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, None, s))
 
     def logged(self):
         """(a_loss, c_loss, b_loss, clip fraction, kl, actor grad norm, loss scale, skipped) of the last update: a device tensor view."""

@@ -75,7 +75,8 @@ def _close16(a, b, ulps=3.0, floor=0.0):
 
 
 @pytest.mark.gpu
-def test_fused_update_piece_by_piece_against_torch():
+@pytest.mark.parametrize("mfma", [True, False], ids=["mfma", "gemm"])
+def test_fused_update_piece_by_piece_against_torch(mfma):
     """Every stage of the fused update against torch arithmetic on the SAME inputs (no chaos from samples that sit on the clip boundary):
     staging, the three layers, the loss kernel's output gradient against autograd on the heads' outputs, the five backward GEMMs and
     masks, gradient statistics, the Adam step."""
@@ -88,7 +89,7 @@ def test_fused_update_piece_by_piece_against_torch():
     _lively(net)
     ref = copy.deepcopy(net)
     B, nmb = 4096, 2
-    fused = U.FusedPpoUpdate(net, c, B, nmb, dev)
+    fused = U.FusedPpoUpdate(net, c, B, nmb, dev, mfma=mfma)
     lr_a, lr_c = 3e-5, 5e-5
     fused.set_learning_rates(lr_a, lr_c)
     obs, act, nlp_old, mu_old, adv, ret = _batch(ppo, ref, U, B * nmb, dev)
@@ -165,7 +166,8 @@ def test_fused_update_piece_by_piece_against_torch():
 
 
 @pytest.mark.gpu
-def test_fused_update_tracks_the_autograd_update():
+@pytest.mark.parametrize("mfma", [True, False], ids=["mfma", "gemm"])
+def test_fused_update_tracks_the_autograd_update(mfma):
     """End to end against the autograd path under autocast (other GEMM tilings, so a handful of the 4096 samples land on the other side
     of the clip boundary: gradients agree in the norm, not entry by entry), and the loss scale moves alike."""
     from isaacgymdyros_amd import ppo_update as U
@@ -177,7 +179,7 @@ def test_fused_update_tracks_the_autograd_update():
     _lively(net)
     ref = copy.deepcopy(net)
     B, nmb = 4096, 3
-    fused = U.FusedPpoUpdate(net, c, B, nmb, dev)
+    fused = U.FusedPpoUpdate(net, c, B, nmb, dev, mfma=mfma)
     lr_a, lr_c = 3e-5, 5e-5
     fused.set_learning_rates(lr_a, lr_c)
     opt_a = torch.optim.Adam(ref.actor_parameters(), lr=lr_a, eps=1e-8)
@@ -216,7 +218,8 @@ def test_fused_update_tracks_the_autograd_update():
 
 
 @pytest.mark.gpu
-def test_fused_update_skips_and_backs_off_on_overflow():
+@pytest.mark.parametrize("mfma", [True, False], ids=["mfma", "gemm"])
+def test_fused_update_skips_and_backs_off_on_overflow(mfma):
     """GradScaler's contract: a non-finite gradient in one net skips THAT optimiser's step, halves the scale, leaves the other net's
     step alone (separate unscale_ / step per optimiser, a2c_continuous_seperate.py:184-189)."""
     from isaacgymdyros_amd import ppo_update as U
@@ -226,7 +229,7 @@ def test_fused_update_skips_and_backs_off_on_overflow():
     dev = "cuda:0"
     net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
     B = 256
-    fused = U.FusedPpoUpdate(net, c, B, 2, dev)
+    fused = U.FusedPpoUpdate(net, c, B, 2, dev, mfma=mfma)
     fused.set_learning_rates(1e-3, 1e-3)
     g = torch.Generator(device=dev).manual_seed(1)
     obs = torch.randn(2 * B, U.IN, generator=g, device=dev)
