@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 2
+#define DWP_ABI_VERSION 3
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -56,6 +56,7 @@ extern "C" {
 #define DWP_S_STEP       10  /* [2] Adam step counts of the actor / the critic               */
 #define DWP_S_LR         12  /* [2] learning rates (the caller's schedule writes them)       */
 #define DWP_S_MB         14  /* index of the minibatch the next update takes (as a float)    */
+#define DWP_S_GPAR       15  /* which of dwp_wgrad's two sets of accumulators this update fills (0 / 1) */
 #define DWP_S_OUT        16  /* [8] published by dwp_finish: a_loss, c_loss, b_loss, clip fraction, kl, grad norm, scale, skipped */
 #define DWP_S_WORDS      32
 
@@ -87,15 +88,16 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
 #define DWP_PBUF_BUCKETS 32  /* rows per net: pbuf is [DWP_PBUF_BUCKETS][2][DWP_PBUF_WORDS] floats, zero-initialised by the caller once */
 /* part[0 .. DWP_PARTS) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
  * that net is not finite.  pbuf (or NULL): dwp_mlp's accumulators: the bias gradients are their sums over the buckets (cleared here)
- * and are left in gb for dwp_adam (without it gb holds them already: dwp_loss / dwp_relu_bwd) */
-int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, void *stream);
+ * and are left in gb for dwp_adam (without it gb holds them already: dwp_loss / dwp_relu_bwd).
+ * g32 (or NULL): the weight gradients are dwp_wgrad's fp32 accumulators [2][weights] instead of g16 */
+int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, void *stream);
 
 /* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
  * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first (norm^2 = the sum of `part`, published in
  * state[NORM2]).  p16f (or NULL): the fragment-order fp16 copy of the weights that dwp_mlp reads (DWP_P16F_WORDS halves, zero-initialised
- * by the caller and filled once with dwp_retile) */
+ * by the caller and filled once with dwp_retile).  g32 (or NULL): as dwp_grad_stats; the set the NEXT update fills is cleared here */
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
-             uint16_t *p16f, void *stream);
+             uint16_t *p16f, float *g32, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
  * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum
@@ -117,10 +119,16 @@ typedef struct DwpMlp {
     const uint16_t *p16, *p16t;          /* p16t: the fragment-order copy (p16f of dwp_adam / dwp_retile) */
     float *pbuf;
     uint16_t *x16, *h1, *h2, *out16, *dout16, *dz2, *dz1;
+    uint16_t *xf, *h1f, *h2f, *doutf, *dz2f, *dz1f;          /* (or all NULL) the same once more as operands of dwp_wgrad: xf [B * INP], h1f .. dz1f [2][B * HID], doutf [2][B * OUTP] */
     int32_t B;
     float e_clip, critic_coef;
 } DwpMlp;
 int dwp_mlp(const DwpMlp *a, void *stream);
+
+/* the three weight gradients of both nets from dwp_mlp's operand-order copies, on the matrix cores: g32 [2][weights] fp32 accumulators in the
+ * parameter layout's weight part (the set state[DWP_S_GPAR] names is added into; zero-initialised by the caller once, then kept by dwp_adam) */
+int dwp_wgrad(const uint16_t *xf, const uint16_t *h1f, const uint16_t *h2f, const uint16_t *doutf, const uint16_t *dz2f, const uint16_t *dz1f, const float *state,
+              float *g32, int32_t B, void *stream);
 
 #ifdef __cplusplus
 }

@@ -184,13 +184,18 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const _Float16 *__restrict__ h
     atomicAdd(&gb_layer[net * HID + col], s_);
 }
 
-__device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *gb, int i) { return i < NWT ? (float)g16[i] : gb[i - NWT]; }
+// a (still scaled) gradient: weights from the fp16 buffer of the library GEMMs, or -- g32 given -- from the fp32 accumulators of dwp_wgrad
+// (two sets: state[DWP_S_GPAR] names the one this update filled; dwp_adam clears the other for the next update); biases from gb
+__device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *g32, const float *gb, int i) {
+    return i < NWT ? (g32 ? g32[i] : (float)g16[i]) : gb[i - NWT];
+}
 
 constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per block, in `part`; dwp_adam's blocks add them up (no atomics: 256
                                         // adds on one word are served one after the other and were most of this kernel's 12 us)
 __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part,
-                                                    float *__restrict__ pbuf) {
+                                                    float *__restrict__ pbuf, const float *__restrict__ g32) {
     __shared__ float red[4];
+    if (g32) g32 += (int)state[DWP_S_GPAR] * NWT;
     const float inv = 1.0f / state[DWP_S_SCALE];
     float sq = 0.0f;
     int bad0 = 0, bad1 = 0;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
             for (int w = 0; w < PBK; ++w) pc[(size_t)w * 2 * PBW] = 0.0f;
             g = s0;
             gb[q] = g;
-        } else g = scaled_grad(g16, gb, i);
+        } else g = scaled_grad(g16, g32, gb, i);
         if (!isfinite(g)) { if (net) bad1 = 1; else bad0 = 1; }
         const float u = g * inv;
         if (net == 0) sq += u * u;
@@ -224,8 +229,9 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
 
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
-                                              float max_norm, _Float16 *__restrict__ p16f) {
+                                              float max_norm, _Float16 *__restrict__ p16f, float *__restrict__ g32) {
     __shared__ float red[4];
+    float *gcur = g32 ? g32 + (int)state[DWP_S_GPAR] * NWT : nullptr, *gnext = g32 ? g32 + (1 - (int)state[DWP_S_GPAR]) * NWT : nullptr;
     static_assert(GS_BLOCKS == 256, "one partial per thread");
     {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
         const float s = wave_sum(part[threadIdx.x]);
@@ -236,9 +242,10 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NP) return;
+    if (gnext && i < NWT) gnext[i] = 0.0f;          // (the accumulators the next update adds into)
     const int net = net_of(i);
     if (state[DWP_S_FOUND_INF + net] != 0.0f) return;          // GradScaler.step: this optimiser's step is skipped
-    float g = scaled_grad(g16, gb, i) * (1.0f / state[DWP_S_SCALE]);
+    float g = scaled_grad(g16, gcur, gb, i) * (1.0f / state[DWP_S_SCALE]);
     if (net == 0) {
         const float coef = max_norm / (sqrtf(norm2) + 1e-6f);          // torch.nn.utils.clip_grad_norm_
         g *= fminf(coef, 1.0f);
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float
     for (int k = 0; k < 8; ++k) state[k] = 0.0f;
     const int mb = (int)state[DWP_S_MB] + 1;
     state[DWP_S_MB] = (float)(mb >= nmb ? 0 : mb);
+    state[DWP_S_GPAR] = 1.0f - state[DWP_S_GPAR];          // (dwp_wgrad's other set of accumulators: cleared by this update's dwp_adam)
 }
 
 // ------------------------------------------------------------------------------------------------ dwp_mlp: forward, loss, input gradients
@@ -350,6 +358,21 @@ __device__ __forceinline__ void rows_out(const _Float16 *Ls, _Float16 *__restric
         *reinterpret_cast<h8 *>(g + (size_t)r * COLS + c) = *reinterpret_cast<const h8 *>(Ls + r * STRIDE + c);
     }
 }
+// The workgroup's MT = 32 rows of an LDS image as operands of the weight-gradient products, whose k index is the SAMPLE: 32 samples are
+// one k-step, and for feature tile t lane l of the consuming wave wants samples 8 (l >> 4) .. + 7 of feature 16 t + (l & 15) as its eight
+// halves (A operand if the features are the product's rows, B if its columns: the same packing).  Block (k-step) kb of a buffer with
+// FEAT features: (kb * FEAT / 16 + t) * 64 + l, 16 bytes each -- a consumer's request is one contiguous KB.
+template <int FEAT, int STRIDE>
+__device__ __forceinline__ void frags_out(const _Float16 *Ls, _Float16 *__restrict__ dstblock, int tid) {
+    for (int it = tid; it < (FEAT / 16) * 64; it += 64 * WPB) {
+        const int t = it >> 6, l = it & 63;
+        const _Float16 *src = Ls + (8 * (l >> 4)) * STRIDE + 16 * t + (l & 15);
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j * STRIDE];
+        reinterpret_cast<h8 *>(dstblock)[it] = v;
+    }
+}
 // bias + relu of my column tiles of a hidden layer from the accumulator tiles into the layer's LDS image
 __device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][NTW], const float (&bia)[NTW], _Float16 *Hs, int nt0, int cr, int g) {
 #pragma unroll
@@ -390,6 +413,7 @@ struct MlpArgs {
     const _Float16 *p16, *p16t;
     float *pbuf;
     _Float16 *x16, *h1, *h2, *out16, *dout16, *dz2, *dz1;
+    _Float16 *xf, *h1f, *h2f, *doutf, *dz2f, *dz1f;          // (or all null) the same once more in dwp_wgrad's operand order
     int B;
     float e_clip, critic_coef;
 };
@@ -421,7 +445,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
         }
         for (int t = tid; t < MT * (INP - IN); t += 64 * WPB) { const int r = t / (INP - IN), c = IN + t % (INP - IN); Xs[r * XS + c] = (_Float16)0.0f; }
         __syncthreads();
-        if (net == 0) rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid);
+        if (net == 0) { rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid); if (A.xf) frags_out<INP, XS>(Xs, A.xf + (size_t)blockIdx.x * INP * 32, tid); }
     }
     f4 acc[MR][NTW];
     float bia[NTW];          // (a layer's biases, requested before its products: their latency passes under the GEMM)
@@ -432,6 +456,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     hidden_out(acc, bia, H1s, nt0, cr, g);
     __syncthreads();
     rows_out<HID, HS>(H1s, A.h1 + ((size_t)net * B + r0) * HID, tid);
+    if (A.h1f) frags_out<HID, HS>(H1s, A.h1f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
     // ---- hidden layer 2 ----
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bia[t] = (float)b2[16 * (nt0 + t) + cr];
@@ -439,6 +464,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     hidden_out(acc, bia, H2s, nt0, cr, g);
     __syncthreads();
     rows_out<HID, HS>(H2s, A.h2 + ((size_t)net * B + r0) * HID, tid);
+    if (A.h2f) frags_out<HID, HS>(H2s, A.h2f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
     // ---- the head (16 padded outputs = one column tile; every wave forms it -- 16 products) and the loss on its accumulator tiles: column =
     //      lane of a DPP row; wave w takes accumulator row w of every lane group, i.e. samples 4 g + w of each row tile ----
     // (what the loss needs from memory is requested before the head's products; so are my head weights of the product after it)
@@ -498,6 +524,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
         for (int q = 0; q < 5; ++q) { const float t = wave_sum(st[q]); if (lane == 0 && t != 0.0f) atomicAdd(&prow[PB_ST + q], t); }
     }
     __syncthreads();
+    if (A.doutf) frags_out<OUTP, HS>(Ds, A.doutf + ((size_t)net * gridDim.x + blockIdx.x) * OUTP * 32, tid);
     // ---- gradient of the second hidden layer: dOut [rows x 16 (+16 zeros)] . W3 [16 x 256], relu mask, bias gradient ----
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
@@ -509,12 +536,85 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     masked_out(acc, H2s, Z2, prow + PB_B2, nt0, cr, g, lane);
     __syncthreads();
     rows_out<HID, HS>(Z2, A.dz2 + ((size_t)net * B + r0) * HID, tid);
+    if (A.dz2f) frags_out<HID, HS>(Z2, A.dz2f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
     // ---- gradient of the first hidden layer: dz2 [rows x 256] . W2 [256 x 256], relu mask, bias gradient ----
     mfma_rows<HID, HS, NTL, NTW, 4>(Z2, W2T, nt0, acc, lane);
     _Float16 *Z1 = Ds;          // (every wave has read its rows of dOut from it: the barrier above)
     masked_out(acc, H1s, Z1, prow + PB_B1, nt0, cr, g, lane);
     __syncthreads();
     rows_out<HID, HS>(Z1, A.dz1 + ((size_t)net * B + r0) * HID, tid);
+    if (A.dz1f) frags_out<HID, HS>(Z1, A.dz1f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
+}
+
+// ------------------------------------------------------------------------------------------------ dwp_wgrad: the three weight gradients
+// G[o][i] = sum over the samples of dz[s][o] act[s][i], per net, for the three layers, from dwp_mlp's operand-order copies (frags_out): a
+// wave takes a block of MTB x NTB output tiles and a slab of the samples (the k index: one k-step = 32 samples = one workgroup of
+// dwp_mlp), and adds its partial tiles to fp32 accumulators (float atomics on distinct words: SLABS adds per word).  Ring of requests and
+// scheduling barriers as in mfma_rows.
+constexpr int WG_SLABS = 4;
+template <int MTB, int NTB, int FA, int FB>          // FA / FB: features of the A / B operand buffers
+__device__ __forceinline__ void wgrad_block(const _Float16 *__restrict__ Af, const _Float16 *__restrict__ Bf, int mt0, int nt0, int kb0, int kb1, float *__restrict__ G,
+                                            int ld, int lane) {
+    constexpr int RD = 3;
+    f4 acc[MTB][NTB];
+    h8 fa[RD][MTB], fb[RD][NTB];
+    const h8 *pa = reinterpret_cast<const h8 *>(Af) + mt0 * 64 + lane, *pb = reinterpret_cast<const h8 *>(Bf) + nt0 * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) acc[m][n] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    auto request = [&](int slot, int kb) {
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) fa[slot][m] = pa[((size_t)kb * (FA / 16) + m) * 64];
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) fb[slot][n] = pb[((size_t)kb * (FB / 16) + n) * 64];
+    };
+    // (the slab has a multiple of RD k-steps or not: the ring is indexed by a counter that is static inside an unrolled group of RD)
+    const int nk = kb1 - kb0;
+    request(0, kb0);
+    if (nk > 1) request(1, kb0 + 1);
+    for (int k0 = 0; k0 < nk; k0 += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            const int k = k0 + u;
+            if (k < nk) {
+                if (k + RD - 1 < nk) request((u + RD - 1) % RD, kb0 + k + RD - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u][m], fb[u][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const int cr = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&G[(size_t)(16 * (mt0 + m) + 4 * g + r) * ld + 16 * (nt0 + n) + cr], acc[m][n][r]);
+}
+struct WgradArgs { const _Float16 *xf, *h1f, *h2f, *doutf, *dz2f, *dz1f; const float *state; float *g32; int nkb; };
+// tasks per net and slab: layer 1: 4 x 4 blocks of 4 x 8 tiles (256 x 512); layer 2: 4 x 4 blocks of 4 x 4 tiles (256 x 256); the heads: 4 blocks
+// of 1 x 4 tiles (16 x 256)
+constexpr int WG_T1 = 16, WG_T2 = 16, WG_T3 = 4, WG_TASKS = WG_T1 + WG_T2 + WG_T3;
+__global__ __launch_bounds__(64) void k_wgrad(const WgradArgs A) {
+    const int lane = threadIdx.x, task = blockIdx.x, net = blockIdx.y, slab = blockIdx.z;
+    const int per = (A.nkb + WG_SLABS - 1) / WG_SLABS, kb0 = slab * per, kb1 = kb0 + per < A.nkb ? kb0 + per : A.nkb;
+    if (kb0 >= kb1) return;
+    float *G = A.g32 + (size_t)(int)A.state[DWP_S_GPAR] * NWT;
+    const size_t nb = (size_t)net * A.nkb;          // (net's first block in the per-net operand buffers)
+    if (task < WG_T1) {
+        wgrad_block<4, 8, HID, INP>(A.dz1f + nb * HID * 32, A.xf, 4 * (task >> 2), 8 * (task & 3), kb0, kb1, G + (size_t)net * HID * INP, INP, lane);
+    } else if (task < WG_T1 + WG_T2) {
+        const int t = task - WG_T1;
+        wgrad_block<4, 4, HID, HID>(A.dz2f + nb * HID * 32, A.h1f + nb * HID * 32, 4 * (t >> 2), 4 * (t & 3), kb0, kb1, G + NW1 + (size_t)net * HID * HID, HID, lane);
+    } else {
+        const int t = task - WG_T1 - WG_T2;
+        wgrad_block<1, 4, OUTP, HID>(A.doutf + nb * OUTP * 32, A.h2f + nb * HID * 32, 0, 4 * t, kb0, kb1, G + NW1 + NW2 + (size_t)net * OUTP * HID, HID, lane);
+    }
 }
 
 int done(const char *who) {
@@ -557,18 +657,26 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
     return done("dwp_relu_bwd");
 }
 
-int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, void *stream) {
-    if (!g16 || !gb || !state || !part) return fail("dwp_grad_stats: bad argument");
-    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part, pbuf);
+int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, void *stream) {
+    if ((!g16 && !g32) || !gb || !state || !part) return fail("dwp_grad_stats: bad argument");
+    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part, pbuf, g32);
     return done("dwp_grad_stats");
 }
 
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
-             void *stream) {
-    if (!p || !p16 || !m || !v || !g16 || !gb || !state || !part) return fail("dwp_adam: bad argument");
+             float *g32, void *stream) {
+    if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part) return fail("dwp_adam: bad argument");
     hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
-                       (_Float16 *)p16t);
+                       (_Float16 *)p16t, g32);
     return done("dwp_adam");
+}
+
+int dwp_wgrad(const uint16_t *xf, const uint16_t *h1f, const uint16_t *h2f, const uint16_t *doutf, const uint16_t *dz2f, const uint16_t *dz1f, const float *state,
+              float *g32, int32_t B, void *stream) {
+    if (!xf || !h1f || !h2f || !doutf || !dz2f || !dz1f || !state || !g32 || B < 32 || B % 32) return fail("dwp_wgrad: bad argument");
+    WgradArgs A{(const _Float16 *)xf, (const _Float16 *)h1f, (const _Float16 *)h2f, (const _Float16 *)doutf, (const _Float16 *)dz2f, (const _Float16 *)dz1f, state, g32, B / 32};
+    hipLaunchKernelGGL(k_wgrad, dim3(WG_TASKS, 2, WG_SLABS), dim3(64), 0, (hipStream_t)stream, A);
+    return done("dwp_wgrad");
 }
 
 int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream) {
@@ -593,7 +701,8 @@ int dwp_mlp(const DwpMlp *a, void *stream) {
     A.obs = a->obs; A.state = a->state; A.act = a->act; A.old_nlp = a->old_nlp; A.old_mu = a->old_mu; A.adv = a->adv; A.ret = a->ret; A.logstd = a->logstd;
     A.p16 = (const _Float16 *)a->p16; A.p16t = (const _Float16 *)a->p16t; A.pbuf = a->pbuf;
     A.x16 = (_Float16 *)a->x16; A.h1 = (_Float16 *)a->h1; A.h2 = (_Float16 *)a->h2; A.out16 = (_Float16 *)a->out16; A.dout16 = (_Float16 *)a->dout16;
-    A.dz2 = (_Float16 *)a->dz2; A.dz1 = (_Float16 *)a->dz1; A.B = a->B; A.e_clip = a->e_clip; A.critic_coef = a->critic_coef;
+    A.dz2 = (_Float16 *)a->dz2; A.dz1 = (_Float16 *)a->dz1; A.B = a->B;
+    A.xf = (_Float16 *)a->xf; A.h1f = (_Float16 *)a->h1f; A.h2f = (_Float16 *)a->h2f; A.doutf = (_Float16 *)a->doutf; A.dz2f = (_Float16 *)a->dz2f; A.dz1f = (_Float16 *)a->dz1f; A.e_clip = a->e_clip; A.critic_coef = a->critic_coef;
     hipLaunchKernelGGL(k_mlp, dim3(a->B / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, A);
     return done("dwp_mlp");
 }

@@ -31,7 +31,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp"]
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -41,7 +41,7 @@ NP = NWT + NB1 + NB2 + NB3
 
 class DwpMlp(C.Structure):          # include/dyros_ppo.h
     _fields_ = [(n, C.c_void_p) for n in ("obs", "state", "act", "old_nlp", "old_mu", "adv", "ret", "logstd", "p16", "p16t", "pbuf",
-                                          "x16", "h1", "h2", "out16", "dout16", "dz2", "dz1")] + [("B", C.c_int32), ("e_clip", C.c_float), ("critic_coef", C.c_float)]
+                                          "x16", "h1", "h2", "out16", "dout16", "dz2", "dz1", "xf", "h1f", "h2f", "doutf", "dz2f", "dz1f")] + [("B", C.c_int32), ("e_clip", C.c_float), ("critic_coef", C.c_float)]
 
 
 def declare(lib: C.CDLL) -> dict:
@@ -56,11 +56,12 @@ def declare(lib: C.CDLL) -> dict:
     api["bias_relu"] = fn("bias_relu", C.c_int, P, P, C.c_int32, P)
     api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
     api["relu_bwd"] = fn("relu_bwd", C.c_int, P, P, P, C.c_int32, P)
-    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P, P, P)
-    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P)
+    api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P, P, P, P)
+    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
     api["mlp"] = fn("mlp", C.c_int, C.POINTER(DwpMlp), P)
+    api["wgrad"] = fn("wgrad", C.c_int, P, P, P, P, P, P, P, P, C.c_int32, P)
     if api["abi_version"]() != K["DWP_ABI_VERSION"]:
         raise RuntimeError("libdyroswalk_hip.so: dwp ABI %d, header %d" % (api["abi_version"](), K["DWP_ABI_VERSION"]))
     return api
@@ -99,7 +100,7 @@ class FusedPpoUpdate:
         self.part = torch.zeros(K["DWP_PARTS"], **f32)
         self.state[K["DWP_S_SCALE"]] = 65536.0
         o = 0
-        self.views, self.views16, self.gviews = {}, {}, {}
+        self.views, self.views16, self._gviews16, self._gshape = {}, {}, {}, {}
         for name, shape in (("W1", (2, HID, INP)), ("W2", (2, HID, HID)), ("W3", (2, OUTP, HID)), ("b1", (2, HID)), ("b2", (2, HID)), ("b3", (2, OUTP))):
             n = 1
             for s in shape:
@@ -107,7 +108,8 @@ class FusedPpoUpdate:
             self.views[name] = self.p[o:o + n].view(shape)
             self.views16[name] = self.p16[o:o + n].view(shape)
             if name.startswith("W"):
-                self.gviews[name] = self.g16[o:o + n].view(shape)
+                self._gviews16[name] = self.g16[o:o + n].view(shape)
+                self._gshape[name] = (o, n, shape)
             o += n
         # adopt the module's initial values, then make the module's parameters views of the master buffer
         with torch.no_grad():
@@ -134,6 +136,20 @@ class FusedPpoUpdate:
         self._chk(self.api["retile"](self.p16.data_ptr(), self.p16t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
         self.pbuf = torch.zeros(K["DWP_PBUF_BUCKETS"], 2, K["DWP_PBUF_WORDS"], **f32)          # dwp_mlp: accumulators of bias gradients and logged sums
         self._mlp_args = None
+        if self.mfma:          # dwp_mlp's outputs once more as operands of dwp_wgrad, and its two sets of fp32 accumulators
+            self.xf = torch.zeros(B * INP, **f16)
+            self.h1f, self.h2f, self.dz2f, self.dz1f = (torch.zeros(2 * B * HID, **f16) for _ in range(4))
+            self.doutf = torch.zeros(2 * B * OUTP, **f16)
+            self.g32 = torch.zeros(2, NWT, **f32)
+
+    @property
+    def gviews(self):
+        """The weight gradients of the last update (still multiplied by its loss scale), by layer: fp16 [2, out, in] from the library GEMMs,
+        or fp32 from dwp_wgrad's accumulators (the set the last update filled: one host read of the state)."""
+        if not self.mfma:
+            return self._gviews16
+        par = 1 - int(self.state[K["DWP_S_GPAR"]].item())          # (dwp_finish has flipped it)
+        return {name: self.g32[par, o:o + n].view(shape) for name, (o, n, shape) in self._gshape.items()}
 
     def _chk(self, rc):
         if rc != 0:
@@ -159,23 +175,23 @@ class FusedPpoUpdate:
         api, st, B = self.api, self.state.data_ptr(), self.B
         obs, act, nlp, mu_old, adv, ret = self.src
         s = torch.cuda.current_stream(self.dev).cuda_stream
-        W, W16, G = self.views, self.views16, self.gviews
+        W, W16, G = self.views, self.views16, self._gviews16
         if self.mfma:
             if self._mlp_args is None:
                 a = DwpMlp()
                 for k_, t_ in (("obs", obs), ("state", self.state), ("act", act), ("old_nlp", nlp), ("old_mu", mu_old), ("adv", adv), ("ret", ret), ("logstd", self.logstd),
                                ("p16", self.p16), ("p16t", self.p16t), ("pbuf", self.pbuf), ("x16", self.x16), ("h1", self.h1), ("h2", self.h2),
-                               ("out16", self.out), ("dout16", self.dout), ("dz2", self.dh2), ("dz1", self.dh1)):
+                               ("out16", self.out), ("dout16", self.dout), ("dz2", self.dh2), ("dz1", self.dh1), ("xf", self.xf), ("h1f", self.h1f), ("h2f", self.h2f),
+                               ("doutf", self.doutf), ("dz2f", self.dz2f), ("dz1f", self.dz1f)):
                     setattr(a, k_, t_.data_ptr())
                 a.B, a.e_clip, a.critic_coef = B, self.e_clip, self.critic_coef
                 self._mlp_args = a
             self._chk(api["mlp"](C.byref(self._mlp_args), s))
-            torch.bmm(self.dout.transpose(1, 2), self.h2, out=G["W3"])
-            torch.bmm(self.dh2.transpose(1, 2), self.h1, out=G["W2"])
-            torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
-            self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), s))
-            self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st,
-                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), s))
+            self._chk(api["wgrad"](self.xf.data_ptr(), self.h1f.data_ptr(), self.h2f.data_ptr(), self.doutf.data_ptr(), self.dz2f.data_ptr(), self.dz1f.data_ptr(), st,
+                                   self.g32.data_ptr(), B, s))
+            self._chk(api["grad_stats"](None, self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), self.g32.data_ptr(), s))
+            self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), None, self.gb.data_ptr(), st,
+                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), s))
             self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
             return
         self._chk(api["stage_obs"](obs.data_ptr(), st, B, self.x16.data_ptr(), s))
@@ -196,8 +212,8 @@ class FusedPpoUpdate:
         self._chk(api["relu_bwd"](self.h1.data_ptr(), self.dh1.data_ptr(), self.gb.data_ptr(), B, s))
         torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
         # unscale + clip + Adam + scaler
-        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), None, s))
-        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), s))
+        self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), None, None, s))
+        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), None, s))
         self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, None, s))
 
     def logged(self):

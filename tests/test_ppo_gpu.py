@@ -139,7 +139,8 @@ def test_fused_update_piece_by_piece_against_torch(mfma):
         ok, worst = _close16(fused.gviews["W1"], torch.matmul(fused.dh1.float().transpose(1, 2), x)); assert ok, ("gW1", worst)
         # the optimiser: unscale, actor clip, Adam -- from the gradients in the fused buffers and bias gradients = column sums
         gb = torch.cat([fused.dh1.float().sum(1).reshape(-1), fused.dh2.float().sum(1).reshape(-1), d3.sum(1).reshape(-1)])
-        gfull = torch.cat([fused.g16.float(), gb]) / scale
+        gv = fused.gviews          # (fp16 from the library GEMMs, fp32 from dwp_wgrad)
+        gfull = torch.cat([gv[n_].reshape(-1).float() for n_ in ("W1", "W2", "W3")] + [gb]) / scale
         actor = torch.zeros(U.NP, dtype=torch.bool, device=dev)
         o = 0
         for nelem in (U.NW1, U.NW2, U.NW3, U.NB1, U.NB2, U.NB3):
