@@ -6,18 +6,25 @@
  *   `scaler.unscale_` of both optimisers, `clip_grad_norm_` of the actor's parameters, both `scaler.step`s and `scaler.update()`
  *   (cfg/train/DyrosDynamicWalkPPO.yaml: mlp units [256, 256], relu, mixed_precision, separate_opt, grad_norm 0.5, e_clip 0.2).
  * With torch's autograd that is ~190 kernel launches for a 4096 x 487 minibatch whose arithmetic is 10 GFLOP: launch-bound
- * (0.98 ms per update inside a hipGraph on an MI355X).  Here the GEMMs stay library calls (torch.baddbmm / bmm on fp16 operands:
- * hipBLASLt / rocBLAS; actor and critic have the same shapes and run as ONE batched GEMM per layer and direction) and everything
- * between them is six kernels:
- *   dwp_stage_obs   fp32 observations of minibatch i -> the fp16 input matrix (autocast's cast of the Linear input)
- *   dwp_bias_relu   bias + relu of a hidden layer, in place on the batched product
- *   dwp_loss        the heads' biases, then from the two heads' outputs: neglogp, PPO ratio, the clipped surrogate, the value loss, the logged bound loss,
- *                   clip fraction and KL; d loss / d outputs times the loss scale as fp16; the heads' bias gradients
- *   dwp_relu_bwd    d relu in place on a hidden layer's gradient + that layer's bias gradient
- *   dwp_grad_stats  sum of squares of the actor's unscaled gradients (clip_grad_norm_) and inf / nan flags of both nets (unscale_)
- *   dwp_adam        unscale, clip (actor), Adam step on the fp32 master parameters unless the net's flag is set, fp16 copy for the
- *                   next forward (what autocast's weight cast produces); the last launch of an update, dwp_finish, moves the loss
- *                   scale as GradScaler.update does, counts the steps, publishes the logged means and clears the accumulators
+ * (0.98 ms per update inside a hipGraph on an MI355X).  Two forms here, same arithmetic types (fp16 operands, fp32 accumulation; fp32 losses,
+ * masters and moments; dynamic loss scale):
+ *   five launches, the products on the matrix cores (0.059 ms per update):
+ *     dwp_mlp         observations -> fp16, the three layers of both nets, loss and output gradient, the two input-gradient products, relu
+ *                     masks, all bias gradients (v_mfma_f32_16x16x32_f16; weights read in fragment order: dwp_retile, kept by dwp_adam)
+ *     dwp_wgrad       the three weight gradients of both nets (fp32 accumulators)
+ *     dwp_grad_stats  bias gradients from their buckets, sum of squares of the actor's unscaled gradients (clip_grad_norm_), inf / nan flags
+ *                     of both nets (unscale_)
+ *     dwp_adam        unscale, clip (actor), Adam step on the fp32 master parameters unless the net's flag is set, fp16 copies for the
+ *                     next forward (what autocast's weight cast produces)
+ *     dwp_finish      moves the loss scale as GradScaler.update does, counts the steps, publishes the logged means, clears accumulators
+ *   seventeen launches, the eight products as library calls (torch.bmm: hipBLASLt / rocBLAS; actor and critic as one batched GEMM per layer
+ *   and direction), with between them:
+ *     dwp_stage_obs   fp32 observations of minibatch i -> the fp16 input matrix (autocast's cast of the Linear input)
+ *     dwp_bias_relu   bias + relu of a hidden layer, in place on the batched product
+ *     dwp_loss        the heads' biases, then from the two heads' outputs: neglogp, PPO ratio, the clipped surrogate, the value loss, the logged
+ *                     bound loss, clip fraction and KL; d loss / d outputs times the loss scale as fp16; the heads' bias gradients
+ *     dwp_relu_bwd    d relu in place on a hidden layer's gradient + that layer's bias gradient
+ *   and the same dwp_grad_stats / dwp_adam / dwp_finish.
  * All pointers are device pointers; every function enqueues on `stream` and returns 0, or -1 with dwp_last_error() set.
  *
  * Parameter layout (fp32 masters `p`, fp16 copies `p16`, Adam moments `m`, `v`: the same layout; IN = 487 padded to INP = 512 -- a 974-byte row
