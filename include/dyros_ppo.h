@@ -63,7 +63,6 @@ extern "C" {
 #define DWP_S_STEP       10  /* [2] Adam step counts of the actor / the critic               */
 #define DWP_S_LR         12  /* [2] learning rates (the caller's schedule writes them)       */
 #define DWP_S_MB         14  /* index of the minibatch the next update takes (as a float)    */
-#define DWP_S_GPAR       15  /* which of dwp_wgrad's two sets of accumulators this update fills (0 / 1) */
 #define DWP_S_OUT        16  /* [8] published by dwp_finish: a_loss, c_loss, b_loss, clip fraction, kl, grad norm, scale, skipped */
 #define DWP_S_WORDS      32
 
@@ -91,20 +90,21 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
 
 #define DWP_PARTS 256   /* words of `part` */
 #define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
+#define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */
 #define DWP_PBUF_WORDS 544   /* words of a row of dwp_mlp's accumulators */
 #define DWP_PBUF_BUCKETS 32  /* rows per net: pbuf is [DWP_PBUF_BUCKETS][2][DWP_PBUF_WORDS] floats, zero-initialised by the caller once */
 /* part[0 .. DWP_PARTS) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
  * that net is not finite.  pbuf (or NULL): dwp_mlp's accumulators: the bias gradients are their sums over the buckets (cleared here)
  * and are left in gb for dwp_adam (without it gb holds them already: dwp_loss / dwp_relu_bwd).
- * g32 (or NULL): the weight gradients are dwp_wgrad's fp32 accumulators [2][weights] instead of g16 */
+ * g32 (or NULL): the weight gradients are the sums over dwp_wgrad's partial gradients [DWP_WGRAD_SLABS][weights] instead of g16 */
 int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, void *stream);
 
 /* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
  * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first (norm^2 = the sum of `part`, published in
  * state[NORM2]).  p16f (or NULL): the fragment-order fp16 copy of the weights that dwp_mlp reads (DWP_P16F_WORDS halves, zero-initialised
- * by the caller and filled once with dwp_retile).  g32 (or NULL): as dwp_grad_stats; the set the NEXT update fills is cleared here */
+ * by the caller and filled once with dwp_retile).  g32 (or NULL): as dwp_grad_stats */
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
-             uint16_t *p16f, float *g32, void *stream);
+             uint16_t *p16f, const float *g32, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
  * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum
@@ -132,8 +132,9 @@ typedef struct DwpMlp {
 } DwpMlp;
 int dwp_mlp(const DwpMlp *a, void *stream);
 
-/* the three weight gradients of both nets from dwp_mlp's operand-order copies, on the matrix cores: g32 [2][weights] fp32 accumulators in the
- * parameter layout's weight part (the set state[DWP_S_GPAR] names is added into; zero-initialised by the caller once, then kept by dwp_adam) */
+/* the three weight gradients of both nets from dwp_mlp's operand-order copies, on the matrix cores: g32 [DWP_WGRAD_SLABS][weights], fp32, the
+ * parameter layout's weight part once per slab of samples -- every word is written by exactly one wave (no atomics, nothing to clear); the
+ * gradient is the sum over the slabs, formed by dwp_grad_stats / dwp_adam as they read */
 int dwp_wgrad(const uint16_t *xf, const uint16_t *h1f, const uint16_t *h2f, const uint16_t *doutf, const uint16_t *dz2f, const uint16_t *dz1f, const float *state,
               float *g32, int32_t B, void *stream);
 

@@ -186,10 +186,17 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const _Float16 *__restrict__ h
     atomicAdd(&gb_layer[net * HID + col], s_);
 }
 
-// a (still scaled) gradient: weights from the fp16 buffer of the library GEMMs, or -- g32 given -- from the fp32 accumulators of dwp_wgrad
-// (two sets: state[DWP_S_GPAR] names the one this update filled; dwp_adam clears the other for the next update); biases from gb
+// a (still scaled) gradient: weights from the fp16 buffer of the library GEMMs, or -- g32 given -- the sum of dwp_wgrad's partial products
+// over its slabs of samples (g32 [DWP_WGRAD_SLABS][weights], every word written by exactly one wave per update: no atomics, nothing to
+// clear); biases from gb
+constexpr int WG_SLABS = DWP_WGRAD_SLABS;
 __device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *g32, const float *gb, int i) {
-    return i < NWT ? (g32 ? g32[i] : (float)g16[i]) : gb[i - NWT];
+    if (i >= NWT) return gb[i - NWT];
+    if (!g32) return (float)g16[i];
+    float s = g32[i];
+#pragma unroll
+    for (int k = 1; k < WG_SLABS; ++k) s += g32[(size_t)k * NWT + i];
+    return s;
 }
 
 constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per block, in `part`; dwp_adam's blocks add them up (no atomics: 256
@@ -197,7 +204,6 @@ constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per bloc
 __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part,
                                                     float *__restrict__ pbuf, const float *__restrict__ g32) {
     __shared__ float red[4];
-    if (g32) g32 += (int)state[DWP_S_GPAR] * NWT;
     const float inv = 1.0f / state[DWP_S_SCALE];
     float sq = 0.0f;
     int bad0 = 0, bad1 = 0;
@@ -231,9 +237,8 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
 
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
-                                              float max_norm, _Float16 *__restrict__ p16f, float *__restrict__ g32) {
+                                              float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32) {
     __shared__ float red[4];
-    float *gcur = g32 ? g32 + (int)state[DWP_S_GPAR] * NWT : nullptr, *gnext = g32 ? g32 + (1 - (int)state[DWP_S_GPAR]) * NWT : nullptr;
     static_assert(GS_BLOCKS == 256, "one partial per thread");
     {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
         const float s = wave_sum(part[threadIdx.x]);
@@ -244,10 +249,9 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NP) return;
-    if (gnext && i < NWT) gnext[i] = 0.0f;          // (the accumulators the next update adds into)
     const int net = net_of(i);
     if (state[DWP_S_FOUND_INF + net] != 0.0f) return;          // GradScaler.step: this optimiser's step is skipped
-    float g = scaled_grad(g16, gcur, gb, i) * (1.0f / state[DWP_S_SCALE]);
+    float g = scaled_grad(g16, g32, gb, i) * (1.0f / state[DWP_S_SCALE]);
     if (net == 0) {
         const float coef = max_norm / (sqrtf(norm2) + 1e-6f);          // torch.nn.utils.clip_grad_norm_
         g *= fminf(coef, 1.0f);
@@ -293,7 +297,6 @@ __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float
     for (int k = 0; k < 8; ++k) state[k] = 0.0f;
     const int mb = (int)state[DWP_S_MB] + 1;
     state[DWP_S_MB] = (float)(mb >= nmb ? 0 : mb);
-    state[DWP_S_GPAR] = 1.0f - state[DWP_S_GPAR];          // (dwp_wgrad's other set of accumulators: cleared by this update's dwp_adam)
 }
 
 // ------------------------------------------------------------------------------------------------ dwp_mlp: forward, loss, input gradients
@@ -551,9 +554,8 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
 // ------------------------------------------------------------------------------------------------ dwp_wgrad: the three weight gradients
 // G[o][i] = sum over the samples of dz[s][o] act[s][i], per net, for the three layers, from dwp_mlp's operand-order copies (frags_out): a
 // wave takes a block of MTB x NTB output tiles and a slab of the samples (the k index: one k-step = 32 samples = one workgroup of
-// dwp_mlp), and adds its partial tiles to fp32 accumulators (float atomics on distinct words: SLABS adds per word).  Ring of requests and
+// dwp_mlp), and stores its partial tiles in ITS SLAB's copy of the gradient (the readers add the slabs up).  Ring of requests and
 // scheduling barriers as in mfma_rows.
-constexpr int WG_SLABS = 4;
 template <int MTB, int NTB, int FA, int FB>          // FA / FB: features of the A / B operand buffers
 __device__ __forceinline__ void wgrad_block(const _Float16 *__restrict__ Af, const _Float16 *__restrict__ Bf, int mt0, int nt0, int kb0, int kb1, float *__restrict__ G,
                                             int ld, int lane) {
@@ -573,7 +575,7 @@ __device__ __forceinline__ void wgrad_block(const _Float16 *__restrict__ Af, con
     };
     // (the slab has a multiple of RD k-steps or not: the ring is indexed by a counter that is static inside an unrolled group of RD)
     const int nk = kb1 - kb0;
-    request(0, kb0);
+    if (nk > 0) request(0, kb0);
     if (nk > 1) request(1, kb0 + 1);
     for (int k0 = 0; k0 < nk; k0 += RD) {
 #pragma unroll
@@ -596,20 +598,19 @@ __device__ __forceinline__ void wgrad_block(const _Float16 *__restrict__ Af, con
 #pragma unroll
         for (int n = 0; n < NTB; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&G[(size_t)(16 * (mt0 + m) + 4 * g + r) * ld + 16 * (nt0 + n) + cr], acc[m][n][r]);
+            for (int r = 0; r < 4; ++r) G[(size_t)(16 * (mt0 + m) + 4 * g + r) * ld + 16 * (nt0 + n) + cr] = acc[m][n][r];
 }
 struct WgradArgs { const _Float16 *xf, *h1f, *h2f, *doutf, *dz2f, *dz1f; const float *state; float *g32; int nkb; };
-// tasks per net and slab: layer 1: 4 x 4 blocks of 4 x 8 tiles (256 x 512); layer 2: 4 x 4 blocks of 4 x 4 tiles (256 x 256); the heads: 4 blocks
+// tasks per net and slab: layer 1: 4 x 8 blocks of 4 x 4 tiles (256 x 512); layer 2: 4 x 4 blocks of 4 x 4 tiles (256 x 256); the heads: 4 blocks
 // of 1 x 4 tiles (16 x 256)
-constexpr int WG_T1 = 16, WG_T2 = 16, WG_T3 = 4, WG_TASKS = WG_T1 + WG_T2 + WG_T3;
+constexpr int WG_T1 = 32, WG_T2 = 16, WG_T3 = 4, WG_TASKS = WG_T1 + WG_T2 + WG_T3;
 __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs A) {
     const int lane = threadIdx.x, task = blockIdx.x, net = blockIdx.y, slab = blockIdx.z;
-    const int per = (A.nkb + WG_SLABS - 1) / WG_SLABS, kb0 = slab * per, kb1 = kb0 + per < A.nkb ? kb0 + per : A.nkb;
-    if (kb0 >= kb1) return;
-    float *G = A.g32 + (size_t)(int)A.state[DWP_S_GPAR] * NWT;
+    const int per = (A.nkb + WG_SLABS - 1) / WG_SLABS, kb0 = slab * per < A.nkb ? slab * per : A.nkb, kb1 = kb0 + per < A.nkb ? kb0 + per : A.nkb;
+    float *G = A.g32 + (size_t)slab * NWT;          // (a slab without samples -- tiny minibatches -- stores zeros)
     const size_t nb = (size_t)net * A.nkb;          // (net's first block in the per-net operand buffers)
     if (task < WG_T1) {
-        wgrad_block<4, 8, HID, INP>(A.dz1f + nb * HID * 32, A.xf, 4 * (task >> 2), 8 * (task & 3), kb0, kb1, G + (size_t)net * HID * INP, INP, lane);
+        wgrad_block<4, 4, HID, INP>(A.dz1f + nb * HID * 32, A.xf, 4 * (task >> 3), 4 * (task & 7), kb0, kb1, G + (size_t)net * HID * INP, INP, lane);
     } else if (task < WG_T1 + WG_T2) {
         const int t = task - WG_T1;
         wgrad_block<4, 4, HID, HID>(A.dz2f + nb * HID * 32, A.h1f + nb * HID * 32, 4 * (t >> 2), 4 * (t & 3), kb0, kb1, G + NW1 + (size_t)net * HID * HID, HID, lane);
@@ -666,7 +667,7 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
 }
 
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
-             float *g32, void *stream) {
+             const float *g32, void *stream) {
     if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part) return fail("dwp_adam: bad argument");
     hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
                        (_Float16 *)p16t, g32);

@@ -140,16 +140,16 @@ class FusedPpoUpdate:
             self.xf = torch.zeros(B * INP, **f16)
             self.h1f, self.h2f, self.dz2f, self.dz1f = (torch.zeros(2 * B * HID, **f16) for _ in range(4))
             self.doutf = torch.zeros(2 * B * OUTP, **f16)
-            self.g32 = torch.zeros(2, NWT, **f32)
+            self.g32 = torch.zeros(K["DWP_WGRAD_SLABS"], NWT, **f32)          # dwp_wgrad's partial gradients, one copy per slab of samples
 
     @property
     def gviews(self):
         """The weight gradients of the last update (still multiplied by its loss scale), by layer: fp16 [2, out, in] from the library GEMMs,
-        or fp32 from dwp_wgrad's accumulators (the set the last update filled: one host read of the state)."""
+        or fp32 (the sum of dwp_wgrad's partial gradients)."""
         if not self.mfma:
             return self._gviews16
-        par = 1 - int(self.state[K["DWP_S_GPAR"]].item())          # (dwp_finish has flipped it)
-        return {name: self.g32[par, o:o + n].view(shape) for name, (o, n, shape) in self._gshape.items()}
+        g = self.g32.sum(0)
+        return {name: g[o:o + n].view(shape) for name, (o, n, shape) in self._gshape.items()}
 
     def _chk(self, rc):
         if rc != 0:
