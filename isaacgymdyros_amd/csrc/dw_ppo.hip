@@ -300,13 +300,11 @@ __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float
 }
 
 // ------------------------------------------------------------------------------------------------ dwp_mlp: forward, loss, input gradients
-// One wavefront = one workgroup takes 16 samples through ONE net (blockIdx.y: 0 actor, 1 critic): three layers on
-// v_mfma_f32_16x16x32_f16 (A = the wave's 16 activation rows from LDS, B = eight consecutive input weights of one output row per lane,
-// straight from the fp16 parameter copy in L2 -- the 1 MB of weights is resident there), bias + relu in the epilogue, the loss on the
-// head's accumulator tile (its 16 columns are the 16 lanes of a DPP row: per-sample sums are row reductions), then the two
-// input-gradient products against the k-outermost weight copies with the relu masks and the bias gradients in their epilogues.  Nothing
-// is shared between waves, so there is no barrier wider than the wave.  Writes every buffer the weight-gradient GEMMs read (x16, h1, h2,
-// dout, dz2, dz1) in 16-byte rows.
+// Three layers on v_mfma_f32_16x16x32_f16 per net (blockIdx.y: 0 actor, 1 critic): A = activation rows from LDS, B = weight fragments
+// straight from the fragment-order fp16 copy in L2 (the 1 MB of weights is resident there), bias + relu in the epilogue, the loss on the
+// head's accumulator tiles (their 16 columns are the 16 lanes of a DPP row: per-sample sums are row reductions), then the two
+// input-gradient products with the relu masks and the bias gradients in their epilogues.  Writes every buffer the weight gradients read
+// (x16, h1, h2, dout, dz2, dz1), row-major and in dwp_wgrad's operand order.
 // Lane maps (cdna_hip_programming.md section 3; checked by tests/test_ppo_gpu.py against torch matmul on the same operands):
 //   A[row l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][col l & 15], j = 0..7;  C/D[row 4 (l >> 4) + r][col l & 15], r = 0..3.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
