@@ -263,8 +263,11 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     m[i] = mi; v[i] = vi;
     const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
     const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    const float pi = p[i] - (lr / bc1) * (mi / denom);
+    float pi = p[i] - (lr / bc1) * (mi / denom);
     p[i] = pi;
+    // the fp16 copies are the STORED fp32 value rounded (what a cast of the master gives, e.g. after a checkpoint is loaded): without the
+    // opaque touch the compiler rounds the multiply-add once, straight to fp16 (v_fma_mixlo_f16), and ties fall the other way
+    asm volatile("" : "+v"(pi));
     p16[i] = (_Float16)pi;
     if (p16f && i < NWT) write_frags(p16f, i, (_Float16)pi);
 }

@@ -155,6 +155,29 @@ class FusedPpoUpdate:
         if rc != 0:
             raise RuntimeError(self.api["last_error"]().decode())
 
+    def refresh_copies(self):
+        """After the module's parameters were written from outside (a checkpoint loaded into the network: they are views of the master buffer):
+        the fp16 copies the next forward reads, row-major and in fragment order."""
+        with torch.no_grad():
+            self.p16.copy_(self.p)
+        self._chk(self.api["retile"](self.p16.data_ptr(), self.p16t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
+
+    def state_dict(self) -> dict:
+        """Optimiser side of a checkpoint (the parameters themselves are the network's): Adam moments, step counts, loss scale and its growth
+        tracker (torch.optim.Adam.state_dict + GradScaler.state_dict in one)."""
+        st = self.state
+        return {"m": self.m.clone(), "v": self.v.clone(), "scale": float(st[K["DWP_S_SCALE"]]), "growth": float(st[K["DWP_S_GROWTH"]]),
+                "steps": st[K["DWP_S_STEP"]:K["DWP_S_STEP"] + 2].tolist()}
+
+    def load_state_dict(self, d: dict):
+        if tuple(d["m"].shape) != (NP,) or tuple(d["v"].shape) != (NP,):
+            raise ValueError("fused PPO update: moments of %r / %r, expected (%d,)" % (tuple(d["m"].shape), tuple(d["v"].shape), NP))
+        with torch.no_grad():
+            self.m.copy_(d["m"]); self.v.copy_(d["v"])
+            self.state[K["DWP_S_SCALE"]] = float(d["scale"]); self.state[K["DWP_S_GROWTH"]] = float(d["growth"])
+            self.state[K["DWP_S_STEP"]:K["DWP_S_STEP"] + 2] = torch.tensor([float(x) for x in d["steps"]], device=self.dev)
+        self.refresh_copies()
+
     def set_learning_rates(self, lr_actor: float, lr_critic: float):
         self.state[K["DWP_S_LR"]:K["DWP_S_LR"] + 2] = torch.tensor([lr_actor, lr_critic], device=self.dev)
 
