@@ -256,7 +256,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         from isaacgymdyros_amd.ppo_update import FusedPpoUpdate
         _b = int(horizon or c["horizon_length"]) * env.num_envs
         _m = min(int(c["minibatch_size"]), _b)
-        fused = FusedPpoUpdate(net, c, _m, _b // _m, device)          # (re-points the module's parameters at its master buffer: before any capture)
+        fused = FusedPpoUpdate(net, c, _m, _b // _m, device, rowmajor=False)          # (re-points the module's parameters at its master buffer: before any capture)
         graph_update = False
     if graph_update:        # (learning rates as device tensors: the schedule writes them in place and the captured step reads them)
         opt_a = torch.optim.Adam(net.actor_parameters(), lr=torch.tensor(float(c["learning_rate"]), device=device), eps=1e-8, fused=True, capturable=True)

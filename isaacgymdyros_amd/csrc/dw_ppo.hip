@@ -324,20 +324,24 @@ constexpr int MR = 2, MT = 16 * MR, WPB = 4, XS = INP + 8, HS = HID + 8, NTL = H
 // RD - 1 k-steps ahead into a ring of RD register sets (the loop is unrolled: every index is static), and scheduling barriers keep the
 // requests where they are written -- the machine scheduler otherwise sinks every request to just before its product (fewer live
 // registers, and the ring is gone: measured 71 % of the wave's cycles waiting at vmcnt(1) / vmcnt(2)).
+template <int K, int NTA, int NT, int RD>
+__device__ __forceinline__ void ring_fill(const _Float16 *__restrict__ W, int nt0, h8 (&b)[RD][NT], int lane) {          // the first RD - 1 k-steps' requests
+    const h8 *wl = reinterpret_cast<const h8 *>(W) + nt0 * 64 + lane;          // (W: the matrix in fragment order, frag_pos)
+#pragma unroll
+    for (int pk = 0; pk < RD - 1 && pk < K / 32; ++pk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[pk][t] = wl[(pk * NTA + t) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+}
 template <int K, int AS, int NTA, int NT, int RD>
-__device__ __forceinline__ void mfma_rows(const _Float16 *As, const _Float16 *__restrict__ W, int nt0, f4 (&acc)[MR][NT], int lane) {
+__device__ __forceinline__ void mfma_go(const _Float16 *As, const _Float16 *__restrict__ W, int nt0, f4 (&acc)[MR][NT], h8 (&b)[RD][NT], int lane) {
     constexpr int KS = K / 32;
     const int ar = lane & 15, ak = 8 * (lane >> 4);
-    const h8 *wl = reinterpret_cast<const h8 *>(W) + nt0 * 64 + lane;          // (W: the matrix in fragment order, frag_pos)
-    h8 b[RD][NT];
+    const h8 *wl = reinterpret_cast<const h8 *>(W) + nt0 * 64 + lane;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[mr][t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int pk = 0; pk < RD - 1 && pk < KS; ++pk)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[pk][t] = wl[(pk * NTA + t) * 64];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         if (kk + RD - 1 < KS) {
@@ -354,6 +358,12 @@ __device__ __forceinline__ void mfma_rows(const _Float16 *As, const _Float16 *__
             for (int t = 0; t < NT; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mr], b[kk % RD][t], acc[mr][t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <int K, int AS, int NTA, int NT, int RD>
+__device__ __forceinline__ void mfma_rows(const _Float16 *As, const _Float16 *__restrict__ W, int nt0, f4 (&acc)[MR][NT], int lane) {
+    h8 b[RD][NT];
+    ring_fill<K, NTA, NT, RD>(W, nt0, b, lane);
+    mfma_go<K, AS, NTA, NT, RD>(As, W, nt0, acc, b, lane);
 }
 // the workgroup's MT rows of an LDS image [MT][stride] to global rows of `cols` halves, 16 bytes per thread and request
 template <int COLS, int STRIDE>
@@ -379,32 +389,56 @@ __device__ __forceinline__ void frags_out(const _Float16 *Ls, _Float16 *__restri
         reinterpret_cast<h8 *>(dstblock)[it] = v;
     }
 }
+// The same operand-order rows straight from a wave's C tiles (no LDS round trip): the lane of group g holds samples 16 mr + 4 g + r (r = 0 .. 3)
+// of its column; the operand lane for those samples is group 2 mr + (g >> 1) of the same column and wants eight -- the four of group g
+// (even) followed by the four of group g + 1.  One exchange with the lane 16 up, then the even groups store 16 bytes per row tile.
+__device__ __forceinline__ void frag_store_tile(const _Float16 (&z)[MR][4], _Float16 *__restrict__ dstblock, int feat_tiles, int nt, int cr, int g) {
+    (void)feat_tiles;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 lo = {z[mr][0], z[mr][1]}, hi = {z[mr][2], z[mr][3]};
+        const int plo = __shfl_down(__builtin_bit_cast(int, lo), 16, 64), phi = __shfl_down(__builtin_bit_cast(int, hi), 16, 64);
+        if ((g & 1) == 0) {
+            const h2 qlo = __builtin_bit_cast(h2, plo), qhi = __builtin_bit_cast(h2, phi);
+            const h8 v = {z[mr][0], z[mr][1], z[mr][2], z[mr][3], qlo[0], qlo[1], qhi[0], qhi[1]};
+            reinterpret_cast<h8 *>(dstblock)[nt * 64 + (2 * mr + (g >> 1)) * 16 + cr] = v;
+        }
+    }
+}
 // bias + relu of my column tiles of a hidden layer from the accumulator tiles into the layer's LDS image
-__device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][NTW], const float (&bia)[NTW], _Float16 *Hs, int nt0, int cr, int g) {
+__device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][NTW], const float (&bia)[NTW], _Float16 *Hs, _Float16 *__restrict__ fdst, int nt0, int cr, int g) {
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
+    for (int t = 0; t < NTW; ++t) {
+        _Float16 z[MR][4];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const _Float16 h = (_Float16)(acc[mr][t][r] + bia[t]);
-                Hs[(16 * mr + 4 * g + r) * HS + 16 * (nt0 + t) + cr] = (float)h > 0.0f ? h : (_Float16)0.0f;
+                z[mr][r] = (float)h > 0.0f ? h : (_Float16)0.0f;
+                Hs[(16 * mr + 4 * g + r) * HS + 16 * (nt0 + t) + cr] = z[mr][r];
             }
+        if (fdst) frag_store_tile(z, fdst, NTL, nt0 + t, cr, g);
+    }
 }
 // relu mask of my column tiles of a hidden layer's gradient (Hs: that layer's activations) into Zs, their bias gradient into the accumulators
-__device__ __forceinline__ void masked_out(const f4 (&acc)[MR][NTW], const _Float16 *Hs, _Float16 *Zs, float *pcol, int nt0, int cr, int g, int lane) {
+__device__ __forceinline__ void masked_out(const f4 (&acc)[MR][NTW], const _Float16 *Hs, _Float16 *Zs, _Float16 *__restrict__ fdst, float *pcol, int nt0, int cr,
+                                           int g, int lane) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         float cs = 0.0f;
+        _Float16 z[MR][4];
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int idx = (16 * mr + 4 * g + r) * HS + 16 * (nt0 + t) + cr;
-                const _Float16 z = (float)Hs[idx] > 0.0f ? (_Float16)acc[mr][t][r] : (_Float16)0.0f;
-                Zs[idx] = z;
-                cs += (float)z;
+                z[mr][r] = (float)Hs[idx] > 0.0f ? (_Float16)acc[mr][t][r] : (_Float16)0.0f;
+                Zs[idx] = z[mr][r];
+                cs += (float)z[mr][r];
             }
+        if (fdst) frag_store_tile(z, fdst, NTL, nt0 + t, cr, g);
         cs += __shfl_xor(cs, 16, 64); cs += __shfl_xor(cs, 32, 64);
         if (lane < 16) atomicAdd(&pcol[16 * (nt0 + t) + lane], cs);
     }
@@ -424,6 +458,11 @@ struct MlpArgs {
     float e_clip, critic_coef;
 };
 
+#if defined(DWP_STAMPS)          // (profiling builds only: cycle stamps of workgroup 0's wave 0 into the tail of pbuf's first row)
+#define MLP_STAMP(n) do { if ((n) <= 10 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) A.pbuf[PB_ST + 5 + (n)] = (float)(unsigned)(__builtin_readcyclecounter() & 0xffffff); } while (0)
+#else
+#define MLP_STAMP(n) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     __shared__ _Float16 Xs[MT * XS];          // the input rows; after the first layer: the masked gradient of the second hidden layer
     __shared__ _Float16 H1s[MT * HS], H2s[MT * HS], Ds[MT * HS];
@@ -435,42 +474,49 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     const _Float16 *W1 = A.p16t + F_W1 + (size_t)net * HID * INP, *W2 = A.p16t + F_W2 + (size_t)net * HID * HID, *W3 = A.p16t + F_W3 + (size_t)net * OUTP * HID;
     const _Float16 *b1 = A.p16 + NWT + net * HID, *b2 = A.p16 + NWT + NB1 + net * HID, *b3 = A.p16 + NWT + NB1 + NB2 + net * OUTP;
     const _Float16 *W2T = A.p16t + F_W2T + (size_t)net * HID * HID, *W3T = A.p16t + F_W3T + (size_t)net * HID * 32;
+    // (a product's first weight fragments are requested before the work that precedes it -- the staging, the previous layer's epilogue --
+    //  so that their L2 round trip passes under it: the weights do not depend on anything computed here)
+    MLP_STAMP(0);
+    h8 ring[4][NTW];
+    ring_fill<INP, NTL, NTW, 4>(W1, nt0, ring, lane);
     // ---- the input rows: fp32 observations -> fp16, zero padding (autocast's cast of the Linear input) ----
     {
         const float *src = A.obs + ((size_t)mb * B + r0) * IN;
-        // the rows are MT x 487 consecutive floats: every thread requests its share before it converts the first word -- one memory
-        // latency for the block instead of one per turn of a loop
-        constexpr int NF = MT * IN, PER = (NF + 64 * WPB - 1) / (64 * WPB);
-        float v[PER];
+        // thread t takes columns t and t + 256 of every row (consecutive threads: consecutive floats of a row; no index arithmetic per word):
+        // all of a thread's requests go out before it converts the first word -- one memory latency for the block
+        static_assert(64 * WPB == 256 && INP == 512, "two column slots per thread");
+        const int c0 = tid, c1 = tid + 256, c1l = c1 < IN ? c1 : c0;          // (the second slot's padding columns re-read the first: no branch per request)
+        float v0[MT], v1[MT];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { const int i = tid + 64 * WPB * u; v[u] = src[i < NF ? i : NF - 1]; }
+        for (int r = 0; r < MT; ++r) { v0[r] = src[(size_t)r * IN + c0]; v1[r] = src[(size_t)r * IN + c1l]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = tid + 64 * WPB * u;
-            if (i < NF) { const int r = i / IN, c = i - r * IN; Xs[r * XS + c] = (_Float16)v[u]; }
-        }
-        for (int t = tid; t < MT * (INP - IN); t += 64 * WPB) { const int r = t / (INP - IN), c = IN + t % (INP - IN); Xs[r * XS + c] = (_Float16)0.0f; }
+        for (int r = 0; r < MT; ++r) { Xs[r * XS + c0] = (_Float16)v0[r]; Xs[r * XS + c1] = c1 < IN ? (_Float16)v1[r] : (_Float16)0.0f; }
         __syncthreads();
-        if (net == 0) { rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid); if (A.xf) frags_out<INP, XS>(Xs, A.xf + (size_t)blockIdx.x * INP * 32, tid); }
+        if (net == 0) { if (A.x16) rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid); if (A.xf) frags_out<INP, XS>(Xs, A.xf + (size_t)blockIdx.x * INP * 32, tid); }
     }
+    MLP_STAMP(1);
     f4 acc[MR][NTW];
     float bia[NTW];          // (a layer's biases, requested before its products: their latency passes under the GEMM)
     // ---- hidden layer 1 ----
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bia[t] = (float)b1[16 * (nt0 + t) + cr];
-    mfma_rows<INP, XS, NTL, NTW, 4>(Xs, W1, nt0, acc, lane);
-    hidden_out(acc, bia, H1s, nt0, cr, g);
+    mfma_go<INP, XS, NTL, NTW, 4>(Xs, W1, nt0, acc, ring, lane);
+    MLP_STAMP(2);
+    ring_fill<HID, NTL, NTW, 4>(W2, nt0, ring, lane);
+    const size_t fblk = ((size_t)net * gridDim.x + blockIdx.x) * HID * 32;          // (my block of the per-net operand-order buffers)
+    hidden_out(acc, bia, H1s, A.h1f ? A.h1f + fblk : nullptr, nt0, cr, g);
     __syncthreads();
-    rows_out<HID, HS>(H1s, A.h1 + ((size_t)net * B + r0) * HID, tid);
-    if (A.h1f) frags_out<HID, HS>(H1s, A.h1f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
+    if (A.h1) rows_out<HID, HS>(H1s, A.h1 + ((size_t)net * B + r0) * HID, tid);
     // ---- hidden layer 2 ----
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bia[t] = (float)b2[16 * (nt0 + t) + cr];
-    mfma_rows<HID, HS, NTL, NTW, 4>(H1s, W2, nt0, acc, lane);
-    hidden_out(acc, bia, H2s, nt0, cr, g);
+    MLP_STAMP(3);
+    mfma_go<HID, HS, NTL, NTW, 4>(H1s, W2, nt0, acc, ring, lane);
+    MLP_STAMP(4);
+    hidden_out(acc, bia, H2s, A.h2f ? A.h2f + fblk : nullptr, nt0, cr, g);
     __syncthreads();
-    rows_out<HID, HS>(H2s, A.h2 + ((size_t)net * B + r0) * HID, tid);
-    if (A.h2f) frags_out<HID, HS>(H2s, A.h2f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
+    if (A.h2) rows_out<HID, HS>(H2s, A.h2 + ((size_t)net * B + r0) * HID, tid);
     // ---- the head (16 padded outputs = one column tile; every wave forms it -- 16 products) and the loss on its accumulator tiles: column =
     //      lane of a DPP row; wave w takes accumulator row w of every lane group, i.e. samples 4 g + w of each row tile ----
     // (what the loss needs from memory is requested before the head's products; so are my head weights of the product after it)
@@ -488,22 +534,41 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) w3t[t] = reinterpret_cast<const h8 *>(W3T)[(nt0 + t) * 64 + lane];          // (k 16 .. 31: the zero padding)
     f4 o4[MR][1];
+    MLP_STAMP(5);
     mfma_rows<HID, HS, 1, 1, 8>(H2s, W3, 0, o4, lane);
+    MLP_STAMP(6);
     {
         float st[5] = {0, 0, 0, 0, 0}, gsum = 0.0f;
+        // (the per-sample sums of both row tiles are reduced TOGETHER over the 16 lanes of a DPP row -- eight independent chains of four
+        //  exchanges instead of one after the other: a lone wave waits out every exchange)
+        _Float16 o16[MR];
+        float red[MR][4];
+        const float sg = expf(ls), s2 = sg * sg;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const float oacc = wv == 0 ? o4[mr][0][0] : (wv == 1 ? o4[mr][0][1] : (wv == 2 ? o4[mr][0][2] : o4[mr][0][3]));
+            o16[mr] = (net == 0 ? ak : cr == 0) ? (_Float16)(oacc + bias) : (_Float16)0.0f;
+            const float mu = (float)o16[mr], z = (in_a[mr] - mu) / sg, om = in_om[mr];
+            const float hi = fminf(mu - 1.1f, 0.0f), lo = fminf(-mu + 1.1f, 0.0f);
+            red[mr][0] = ak ? z * z : 0.0f; red[mr][1] = ls; red[mr][2] = ak ? lo * lo + hi * hi : 0.0f;
+            red[mr][3] = ak ? logf(sg / sg + 1e-5f) + (s2 + (om - mu) * (om - mu)) / (2.0f * (s2 + 1e-5f)) - 0.5f : 0.0f;
+        }
+        if (net == 0) {
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[mr][q] += __shfl_xor(red[mr][q], o, 16);
+        }
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             const int row = 16 * mr + 4 * g + wv;
-            const float oacc = wv == 0 ? o4[mr][0][0] : (wv == 1 ? o4[mr][0][1] : (wv == 2 ? o4[mr][0][2] : o4[mr][0][3]));
-            const _Float16 o16 = (net == 0 ? ak : cr == 0) ? (_Float16)(oacc + bias) : (_Float16)0.0f;
-            A.out16[((size_t)net * B + r0 + row) * OUTP + cr] = o16;
+            A.out16[((size_t)net * B + r0 + row) * OUTP + cr] = o16[mr];
             _Float16 d16 = (_Float16)0.0f;
             if (net == 0) {
-                const float mu = (float)o16, a = in_a[mr], om = in_om[mr];
-                const float sg = expf(ls), z = (a - mu) / sg, s2 = sg * sg;
-                const float hi = fminf(mu - 1.1f, 0.0f), lo = fminf(-mu + 1.1f, 0.0f);
-                const float sq = sum16(ak ? z * z : 0.0f), lsum = sum16(ls), bl = sum16(ak ? lo * lo + hi * hi : 0.0f);
-                const float kl = sum16(ak ? logf(sg / sg + 1e-5f) + (s2 + (om - mu) * (om - mu)) / (2.0f * (s2 + 1e-5f)) - 0.5f : 0.0f);
+                const float mu = (float)o16[mr], a = in_a[mr];
+                const float sq = red[mr][0], lsum = red[mr][1], bl = red[mr][2], kl = red[mr][3];
                 const float nlp = 0.5f * sq + 0.5f * 1.8378770664093453f * (float)ACT + lsum;
                 const float Ad = in_adv[mr], ratio = expf(in_nlp[mr] - nlp);
                 const float rc = fminf(fmaxf(ratio, 1.0f - A.e_clip), 1.0f + A.e_clip);
@@ -514,7 +579,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
                 d16 = (_Float16)(ak ? scale * invB * (Ad * ratio * w) * (-(a - mu) / s2) : 0.0f);
                 if (cr == 0) { st[0] += fmaxf(s1, sc); st[2] += bl; st[3] += fabsf(ratio - 1.0f) > A.e_clip ? 1.0f : 0.0f; st[4] += kl; }
             } else {
-                const float v = (float)o16, rt = in_ret[mr];
+                const float v = (float)o16[mr], rt = in_ret[mr];
                 d16 = (_Float16)(cr == 0 ? scale * invB * A.critic_coef * (v - rt) : 0.0f);
                 if (cr == 0) st[1] += (rt - v) * (rt - v);
             }
@@ -523,14 +588,23 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
             Ds[row * HS + 16 + cr] = (_Float16)0.0f;          // (k 16 .. 31 of the head's input-gradient product: zero)
             gsum += (float)d16;
         }
-        // the head's bias gradient (column sums over my rows) and the logged sums, into the workgroup's row of accumulators
+        // the head's bias gradient (column sums over my rows) and the logged sums, into the workgroup's row of accumulators: six values
+        // reduced over the wave together
+        float w6[6] = {st[0], st[1], st[2], st[3], st[4], 0.0f};
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) w6[q] += __shfl_xor(w6[q], o, 64);
         gsum += __shfl_xor(gsum, 16, 64); gsum += __shfl_xor(gsum, 32, 64);
         if (lane < OUTP && gsum != 0.0f) atomicAdd(&prow[PB_B3 + lane], gsum);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { const float t = wave_sum(st[q]); if (lane == 0 && t != 0.0f) atomicAdd(&prow[PB_ST + q], t); }
+        if (lane < 5 && w6[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : (lane == 3 ? 3 : 4)))] != 0.0f) {
+            const float t = lane == 0 ? w6[0] : (lane == 1 ? w6[1] : (lane == 2 ? w6[2] : (lane == 3 ? w6[3] : w6[4])));
+            atomicAdd(&prow[PB_ST + lane], t);
+        }
     }
     __syncthreads();
     if (A.doutf) frags_out<OUTP, HS>(Ds, A.doutf + ((size_t)net * gridDim.x + blockIdx.x) * OUTP * 32, tid);
+    MLP_STAMP(7);
     // ---- gradient of the second hidden layer: dOut [rows x 16 (+16 zeros)] . W3 [16 x 256], relu mask, bias gradient ----
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
@@ -538,18 +612,23 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3t[t], (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
     }
+    MLP_STAMP(8);
+    ring_fill<HID, NTL, NTW, 4>(W2T, nt0, ring, lane);
     _Float16 *Z2 = Xs;          // [MT][HS]
-    masked_out(acc, H2s, Z2, prow + PB_B2, nt0, cr, g, lane);
+    masked_out(acc, H2s, Z2, A.dz2f ? A.dz2f + fblk : nullptr, prow + PB_B2, nt0, cr, g, lane);
     __syncthreads();
-    rows_out<HID, HS>(Z2, A.dz2 + ((size_t)net * B + r0) * HID, tid);
-    if (A.dz2f) frags_out<HID, HS>(Z2, A.dz2f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
+    if (A.dz2) rows_out<HID, HS>(Z2, A.dz2 + ((size_t)net * B + r0) * HID, tid);
     // ---- gradient of the first hidden layer: dz2 [rows x 256] . W2 [256 x 256], relu mask, bias gradient ----
-    mfma_rows<HID, HS, NTL, NTW, 4>(Z2, W2T, nt0, acc, lane);
+    MLP_STAMP(9);
+    mfma_go<HID, HS, NTL, NTW, 4>(Z2, W2T, nt0, acc, ring, lane);
+    MLP_STAMP(10);
     _Float16 *Z1 = Ds;          // (every wave has read its rows of dOut from it: the barrier above)
-    masked_out(acc, H1s, Z1, prow + PB_B1, nt0, cr, g, lane);
-    __syncthreads();
-    rows_out<HID, HS>(Z1, A.dz1 + ((size_t)net * B + r0) * HID, tid);
-    if (A.dz1f) frags_out<HID, HS>(Z1, A.dz1f + ((size_t)net * gridDim.x + blockIdx.x) * HID * 32, tid);
+    if (A.dz1) {          // (the row-major copy: tests and the library-GEMM weight gradients; the operand-order copy needs no LDS image)
+        masked_out(acc, H1s, Z1, A.dz1f ? A.dz1f + fblk : nullptr, prow + PB_B1, nt0, cr, g, lane);
+        __syncthreads();
+        rows_out<HID, HS>(Z1, A.dz1 + ((size_t)net * B + r0) * HID, tid);
+    } else masked_out(acc, H1s, Z1, A.dz1f ? A.dz1f + fblk : nullptr, prow + PB_B1, nt0, cr, g, lane);
+    MLP_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------ dwp_wgrad: the three weight gradients
@@ -697,8 +776,8 @@ int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream) {
 
 int dwp_mlp(const DwpMlp *a, void *stream) {
     if (!a) return fail("dwp_mlp: null argument");
-    const void *need[] = {a->obs, a->state, a->act, a->old_nlp, a->old_mu, a->adv, a->ret, a->logstd, a->p16, a->p16t, a->pbuf, a->x16, a->h1, a->h2, a->out16,
-                          a->dout16, a->dz2, a->dz1};
+    const void *need[] = {a->obs, a->state, a->act, a->old_nlp, a->old_mu, a->adv, a->ret, a->logstd, a->p16, a->p16t, a->pbuf, a->out16, a->dout16};
+    if (!a->xf && !a->x16) return fail("dwp_mlp: neither row-major nor operand-order outputs");
     for (const void *q : need) if (!q) return fail("dwp_mlp: null pointer in the argument block");
     if (a->B < MT || a->B % MT) return fail("dwp_mlp: the minibatch must be a multiple of 32 samples");
     MlpArgs A;

@@ -72,9 +72,10 @@ class FusedPpoUpdate:
     of the minibatch whose index lives in the device state (it advances by itself: the call has no argument that changes, so it can
     be captured in a hipGraph once and replayed)."""
 
-    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True):
+    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True, rowmajor: bool = True):
         """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp; the minibatch must be a multiple of 16) instead
-        of eight library GEMM launches with six kernels between them; the weight-gradient GEMMs and the optimiser kernels are the same."""
+        of eight library GEMM launches with six kernels between them.  rowmajor (mfma only): dwp_mlp also writes its activations and their
+        gradients as plain [2, B, 256] / [B, 512] matrices (x16, h1, h2, dh2, dh1: what the tests read); a trainer passes False."""
         c = cfg
         if bool(c.get("clip_value")) or float(c.get("entropy_coef", 0.0)) != 0.0 or float(c.get("bounds_loss_coef", 0.0)) != 0.0:
             raise ValueError("the fused update is written for clip_value False, entropy_coef 0, bounds_loss_coef 0 (DyrosDynamicWalkPPO.yaml)")
@@ -132,6 +133,7 @@ class FusedPpoUpdate:
         self.logstd = net.sigma
         self.src = None
         self.mfma = bool(mfma) and B % 32 == 0
+        self.rowmajor = bool(rowmajor) or not self.mfma
         self.p16t = torch.zeros(K["DWP_P16F_WORDS"], **f16)          # the weights once more, in the order dwp_mlp's matrix instructions take them
         self._chk(self.api["retile"](self.p16.data_ptr(), self.p16t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
         self.pbuf = torch.zeros(K["DWP_PBUF_BUCKETS"], 2, K["DWP_PBUF_WORDS"], **f32)          # dwp_mlp: accumulators of bias gradients and logged sums
@@ -206,7 +208,7 @@ class FusedPpoUpdate:
                                ("p16", self.p16), ("p16t", self.p16t), ("pbuf", self.pbuf), ("x16", self.x16), ("h1", self.h1), ("h2", self.h2),
                                ("out16", self.out), ("dout16", self.dout), ("dz2", self.dh2), ("dz1", self.dh1), ("xf", self.xf), ("h1f", self.h1f), ("h2f", self.h2f),
                                ("doutf", self.doutf), ("dz2f", self.dz2f), ("dz1f", self.dz1f)):
-                    setattr(a, k_, t_.data_ptr())
+                    setattr(a, k_, t_.data_ptr() if self.rowmajor or k_ not in ("x16", "h1", "h2", "dz2", "dz1") else None)
                 a.B, a.e_clip, a.critic_coef = B, self.e_clip, self.critic_coef
                 self._mlp_args = a
             self._chk(api["mlp"](C.byref(self._mlp_args), s))
