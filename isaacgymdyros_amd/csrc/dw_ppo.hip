@@ -16,6 +16,8 @@ char g_err[256] = "";
 int fail_hip(const char *who, hipError_t e) { snprintf(g_err, sizeof(g_err), "%s: %s", who, hipGetErrorString(e)); return -1; }
 int fail(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return -1; }
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int IN = DWP_IN, INP = DWP_INP, HID = DWP_HID, OUTP = DWP_OUTP, ACT = DWP_ACT;
 constexpr int NW1 = 2 * HID * INP, NW2 = 2 * HID * HID, NW3 = 2 * OUTP * HID, NWT = NW1 + NW2 + NW3;
 constexpr int NB1 = 2 * HID, NB2 = 2 * HID, NB3 = 2 * OUTP, NBT = NB1 + NB2 + NB3, NP = NWT + NBT;
@@ -157,7 +159,6 @@ __global__ __launch_bounds__(256) void k_bias_relu(_Float16 *__restrict__ h16, c
     const size_t n = (size_t)2 * B * HID, i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= n) return;
     const int net = i >= (size_t)B * HID, col = (int)(i % HID);
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 x = *reinterpret_cast<const h8 *>(h16 + i);
     const h8 b = *reinterpret_cast<const h8 *>(b16 + net * HID + col);
     for (int q = 0; q < 8; ++q) { const _Float16 y = (_Float16)((float)x[q] + (float)b[q]); x[q] = (float)y > 0.0f ? y : (_Float16)0.0f; }
@@ -167,7 +168,6 @@ __global__ __launch_bounds__(256) void k_bias_relu(_Float16 *__restrict__ h16, c
 // block = 32 column groups of 8 (one 16-byte load each) x 8 row lanes; RB_ROWS rows per block; column sums over the row lanes in LDS
 constexpr int RB_ROWS = 64;
 __global__ __launch_bounds__(256) void k_relu_bwd(const _Float16 *__restrict__ h16, _Float16 *__restrict__ dh16, float *__restrict__ gb_layer, int B) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     __shared__ float red[8][HID];
     const int net = blockIdx.y, cg = threadIdx.x & 31, rl = threadIdx.x >> 5, r0 = blockIdx.x * RB_ROWS;
     float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -235,6 +235,10 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
     if (bad1) state[DWP_S_FOUND_INF + 1] = 1.0f;
 }
 
+// Eight consecutive parameters per thread: a run of eight never crosses a row, a net or a tensor (every row length is a multiple of
+// 8), and it is exactly one fragment of the forward operand order -- so the master, the moments, the row-major fp16 copy and the forward
+// fragment copy move as 16- / 32-byte pieces; only the input-gradient copies of W2 / W3 (k = the OUTPUT index) are eight scattered halves.
+static_assert(NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0 && NB1 % 8 == 0 && NB2 % 8 == 0 && NB3 % 8 == 0 && INP % 8 == 0 && HID % 8 == 0, "runs of eight");
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
                                               float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32) {
@@ -247,29 +251,72 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     }
     const float norm2 = red[0] + red[1] + red[2] + red[3];
     if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NP) return;
-    const int net = net_of(i);
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= NP) return;
+    const int net = net_of(i0);
     if (state[DWP_S_FOUND_INF + net] != 0.0f) return;          // GradScaler.step: this optimiser's step is skipped
-    float g = scaled_grad(g16, g32, gb, i) * (1.0f / state[DWP_S_SCALE]);
-    if (net == 0) {
-        const float coef = max_norm / (sqrtf(norm2) + 1e-6f);          // torch.nn.utils.clip_grad_norm_
-        g *= fminf(coef, 1.0f);
-    }
+    const float inv = 1.0f / state[DWP_S_SCALE];
+    const float coef = net == 0 ? fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f) : 1.0f;          // torch.nn.utils.clip_grad_norm_ (the actor only)
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const float step = state[DWP_S_STEP + net] + 1.0f, lr = state[DWP_S_LR + net];
-    const float mi = m[i] + (g - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
-    m[i] = mi; v[i] = vi;
-    const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    float pi = p[i] - (lr / bc1) * (mi / denom);
-    p[i] = pi;
-    // the fp16 copies are the STORED fp32 value rounded (what a cast of the master gives, e.g. after a checkpoint is loaded): without the
-    // opaque touch the compiler rounds the multiply-add once, straight to fp16 (v_fma_mixlo_f16), and ties fall the other way
-    asm volatile("" : "+v"(pi));
-    p16[i] = (_Float16)pi;
-    if (p16f && i < NWT) write_frags(p16f, i, (_Float16)pi);
+    const float bc1 = 1.0f - powf(b1, step), sq2 = sqrtf(1.0f - powf(b2, step)), ss = lr / bc1;
+    f4 pv[2] = {reinterpret_cast<const f4 *>(p + i0)[0], reinterpret_cast<const f4 *>(p + i0)[1]};
+    f4 mv[2] = {reinterpret_cast<const f4 *>(m + i0)[0], reinterpret_cast<const f4 *>(m + i0)[1]};
+    f4 vv[2] = {reinterpret_cast<const f4 *>(v + i0)[0], reinterpret_cast<const f4 *>(v + i0)[1]};
+    float gs[8];
+    if (i0 >= NWT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = gb[i0 - NWT + q];
+    } else if (g32) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WG_SLABS; ++k) {
+            const f4 a = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + i0)[0], c = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + i0)[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { gs[q] += a[q]; gs[4 + q] += c[q]; }
+        }
+    } else {
+        const h8 gh = *reinterpret_cast<const h8 *>(g16 + i0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = (float)gh[q];
+    }
+    h8 ph;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float g = gs[q] * inv * coef;
+        const float mq = mv[q >> 2][q & 3], vq = vv[q >> 2][q & 3];
+        const float mi = mq + (g - mq) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = b2 * vq + (1.0f - b2) * g * g;
+        const float denom = sqrtf(vi) / sq2 + eps;
+        float pi = pv[q >> 2][q & 3] - ss * (mi / denom);
+        mv[q >> 2][q & 3] = mi; vv[q >> 2][q & 3] = vi; pv[q >> 2][q & 3] = pi;
+        // the fp16 copies are the STORED fp32 value rounded (what a cast of the master gives, e.g. after a checkpoint is loaded): without the
+        // opaque touch the compiler rounds the multiply-add once, straight to fp16 (v_fma_mixlo_f16), and ties fall the other way
+        asm volatile("" : "+v"(pi));
+        ph[q] = (_Float16)pi;
+    }
+    reinterpret_cast<f4 *>(p + i0)[0] = pv[0]; reinterpret_cast<f4 *>(p + i0)[1] = pv[1];
+    reinterpret_cast<f4 *>(m + i0)[0] = mv[0]; reinterpret_cast<f4 *>(m + i0)[1] = mv[1];
+    reinterpret_cast<f4 *>(v + i0)[0] = vv[0]; reinterpret_cast<f4 *>(v + i0)[1] = vv[1];
+    *reinterpret_cast<h8 *>(p16 + i0) = ph;
+    if (p16f && i0 < NWT) {
+        // forward operand order: my eight are one fragment (frag_pos of the first, k & 7 = 0); input-gradient order: one half each
+        int i = i0;
+        if (i < NW1) { const int nn = i / (HID * INP), o = (i / INP) % HID, k = i % INP; *reinterpret_cast<h8 *>(p16f + F_W1 + nn * HID * INP + frag_pos(HID / 16, o, k)) = ph; }
+        else if ((i -= NW1) < NW2) {
+            const int nn = i / (HID * HID), o = (i / HID) % HID, k = i % HID;
+            *reinterpret_cast<h8 *>(p16f + F_W2 + nn * HID * HID + frag_pos(HID / 16, o, k)) = ph;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p16f[F_W2T + nn * HID * HID + frag_pos(HID / 16, k + q, o)] = ph[q];
+        } else {
+            i -= NW2;
+            const int nn = i / (OUTP * HID), o = (i / HID) % OUTP, k = i % HID;
+            *reinterpret_cast<h8 *>(p16f + F_W3 + nn * OUTP * HID + frag_pos(1, o, k)) = ph;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p16f[F_W3T + nn * HID * 32 + frag_pos(HID / 16, k + q, o)] = ph[q];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float *__restrict__ gb, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
@@ -310,8 +357,6 @@ __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float
 // (x16, h1, h2, dout, dz2, dz1), row-major and in dwp_wgrad's operand order.
 // Lane maps (cdna_hip_programming.md section 3; checked by tests/test_ppo_gpu.py against torch matmul on the same operands):
 //   A[row l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][col l & 15], j = 0..7;  C/D[row 4 (l >> 4) + r][col l & 15], r = 0..3.
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 // A workgroup = 4 waves takes MT = 32 samples (MR = 2 row tiles of 16) through ONE net.  The waves share the activation images in LDS and
 // split every product by COLUMNS: wave w owns column tiles 4 w .. 4 w + 3 of the 16 (so a weight fragment is fetched by one wave of the
 // workgroup and used for MR products), writes its columns of the layer's output image, and a workgroup barrier separates the layers.
@@ -749,7 +794,7 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
              const float *g32, void *stream) {
     if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part) return fail("dwp_adam: bad argument");
-    hipLaunchKernelGGL(k_adam, dim3((NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
+    hipLaunchKernelGGL(k_adam, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
                        (_Float16 *)p16t, g32);
     return done("dwp_adam");
 }
