@@ -362,13 +362,22 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 dones = d.float()
                 obs = o["obs"].clone()
             last_values = net(obs)[2]
-            advs = discount_values(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
+            if fused is not None:          # (the same recursion in one launch instead of 128 x 8: isaacgymdyros_amd/ppo_update.py::gae)
+                from isaacgymdyros_amd.ppo_update import gae as _gae
+                advs = _gae(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
+            else:
+                advs = discount_values(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
             returns = advs + mb["val"]
         _sync(device)                                                           # (the rollout's device work is part of play_time in both modes)
         play_time = time.perf_counter() - t0
         # swap_and_flatten01: env-major flat batch, minibatches are contiguous slices (no shuffling in rl_games' dataset)
         flat = lambda x: x.transpose(0, 1).reshape(batch, *x.shape[2:])        # noqa: E731
-        B = {k: flat(v) for k, v in mb.items()}
+        if fused is not None and fused.src is not None:
+            # (the observations go straight into their static home, env-major: one strided copy of 4 GB instead of two)
+            fused.src[0].view(N, H, -1).copy_(mb["obs"].transpose(0, 1))
+            B = {k: (fused.src[0] if k == "obs" else flat(v)) for k, v in mb.items()}
+        else:
+            B = {k: flat(v) for k, v in mb.items()}
         ret, val = flat(returns), B["val"]
         adv = (ret - val).sum(dim=1)
         if c["normalize_advantage"]:
@@ -406,7 +415,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             if fused.src is None:          # (static homes of the epoch's flat arrays: a captured update replays their addresses)
                 fused.bind_batch(*[torch.empty(batch, *sh, device=device) for sh in ((env.num_obs,), (env.num_acts,), (), (env.num_acts,), (), ())])
             for d_, x in zip(fused.src, (B["obs"], B["act"], B["neglogp"], B["mu"], adv, ret)):
-                d_.copy_(x.reshape(d_.shape))
+                if d_.data_ptr() != x.data_ptr():
+                    d_.copy_(x.reshape(d_.shape))
             fused.rewind()
             n_upd = int(c["mini_epochs"]) * (batch // mbs)
             done_upd = 0

@@ -118,6 +118,13 @@ int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int3
  * (dout' h2, dz2' h1, dz1' x16: library calls), dwp_grad_stats, dwp_adam, dwp_finish.  Buffers as the other entry points name them;
  * pbuf: the accumulators of the bias gradients and the logged sums (DWP_PBUF_*: a wave adds into the row of its bucket), read and cleared
  * by dwp_grad_stats and dwp_finish.  B: a multiple of 32. */
+/* GAE of one rollout, `discount_values` of learning/rl_games_custom/a2c_common_dyros.py:485-500 (a Python loop of H steps there): advs [H][N] from
+ * fdones [N] (the dones after the last step), last_values [N], mb_fdones [H][N], mb_values [H][N], mb_rewards [H][N]; per element the same fp32
+ * operations in the same order.  (Note the reference's indexing: step t uses mb_fdones[t + 1] and mb_values[t + 1], the last step fdones and
+ * last_values.) */
+int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdones, const float *mb_values, const float *mb_rewards, float gamma, float tau, int32_t H,
+            int32_t N, float *advs, void *stream);
+
 /* p16f from p16 (all weights; after construction or after loading parameters) */
 int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream);
 

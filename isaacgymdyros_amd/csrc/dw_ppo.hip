@@ -745,6 +745,27 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dwp_gae
+// Generalised advantage estimation of one rollout (learning/rl_games_custom/a2c_common_dyros.py:485-500 `discount_values`): one thread per
+// env walks its H steps backwards; tensors are [H][N] (step-major), so a wave's 64 envs read 256 consecutive bytes per step.  The reference
+// is a Python loop of H iterations with eight torch kernels each.  Same arithmetic, same order per element (fp32).
+__global__ __launch_bounds__(256) void k_gae(const float *__restrict__ fdones, const float *__restrict__ last_values, const float *__restrict__ mb_fdones,
+                                             const float *__restrict__ mb_values, const float *__restrict__ mb_rewards, float gamma, float gamma_tau, int H, int N,
+                                             float *__restrict__ advs) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    float lastgaelam = 0.0f, nextnonterminal = 1.0f - fdones[e], nextvalues = last_values[e];
+    for (int t = H - 1; t >= 0; --t) {
+        const size_t i = (size_t)t * N + e;
+        const float val = mb_values[i];
+        const float delta = mb_rewards[i] + gamma * nextvalues * nextnonterminal - val;
+        lastgaelam = delta + gamma_tau * nextnonterminal * lastgaelam;          // (gamma * tau: a Python float product in the reference, formed on the host)
+        advs[i] = lastgaelam;
+        nextnonterminal = 1.0f - mb_fdones[i];
+        nextvalues = val;
+    }
+}
+
 int done(const char *who) {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(who, e);
@@ -811,6 +832,14 @@ int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int3
     if (!state || !gb || B < 1 || num_minibatches < 1 || growth_interval < 1) return fail("dwp_finish: bad argument");
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, state, gb, B, num_minibatches, growth_interval, pbuf);
     return done("dwp_finish");
+}
+
+int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdones, const float *mb_values, const float *mb_rewards, float gamma, float tau, int32_t H,
+            int32_t N, float *advs, void *stream) {
+    if (!fdones || !last_values || !mb_fdones || !mb_values || !mb_rewards || !advs || H < 1 || N < 1) return fail("dwp_gae: bad argument");
+    hipLaunchKernelGGL(k_gae, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma,
+                       (float)((double)gamma * (double)tau), H, N, advs);
+    return done("dwp_gae");
 }
 
 int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream) {

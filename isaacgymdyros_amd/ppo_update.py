@@ -31,7 +31,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad"]
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad", "gae"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -60,11 +60,28 @@ def declare(lib: C.CDLL) -> dict:
     api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
+    api["gae"] = fn("gae", C.c_int, P, P, P, P, P, C.c_float, C.c_float, C.c_int32, C.c_int32, P, P)
     api["mlp"] = fn("mlp", C.c_int, C.POINTER(DwpMlp), P)
     api["wgrad"] = fn("wgrad", C.c_int, P, P, P, P, P, P, P, P, C.c_int32, P)
     if api["abi_version"]() != K["DWP_ABI_VERSION"]:
         raise RuntimeError("libdyroswalk_hip.so: dwp ABI %d, header %d" % (api["abi_version"](), K["DWP_ABI_VERSION"]))
     return api
+
+
+def gae(fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma: float, tau: float):
+    """`discount_values` of the reference (a2c_common_dyros.py:485-500) in one launch (dwp_gae).  fp32 CUDA tensors: fdones [N], last_values [N, 1],
+    mb_fdones [H, N], mb_values / mb_rewards [H, N, 1]; returns advs [H, N, 1]."""
+    api = declare(_lib.load()[0])
+    H, N = int(mb_rewards.shape[0]), int(mb_rewards.shape[1])
+    ts = [t.contiguous() for t in (fdones, last_values, mb_fdones, mb_values, mb_rewards)]
+    for t, n in zip(ts, (N, N, H * N, H * N, H * N)):
+        if t.dtype != torch.float32 or t.numel() != n or not t.is_cuda:
+            raise ValueError("gae: expected fp32 GPU tensors of [N] / [N, 1] / [H, N] / [H, N, 1]")
+    advs = torch.empty_like(ts[4])
+    rc = api["gae"](*[t.data_ptr() for t in ts], float(gamma), float(tau), H, N, advs.data_ptr(), torch.cuda.current_stream(advs.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(api["last_error"]().decode())
+    return advs
 
 
 class FusedPpoUpdate:

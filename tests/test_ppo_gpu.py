@@ -303,3 +303,21 @@ def test_fused_update_resumes_from_its_state_dict():
     torch.cuda.synchronize()
     assert torch.equal(fa.out, fb.out) and torch.equal(fa.dout, fb.dout) and torch.equal(fa.g32, fb.g32)
     assert float((fa.p - fb.p).abs().max()) <= 1e-7 and fa.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() == fb.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist()
+
+
+@pytest.mark.gpu
+def test_gae_kernel_equals_the_reference_loop():
+    """dwp_gae against `discount_values` (examples/ppo_consumer.py, restating a2c_common_dyros.py:485-500) on random rollouts with dones."""
+    from isaacgymdyros_amd.ppo_update import gae
+    ppo = _ppo()
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(4)
+    for H, N in ((128, 1000), (7, 3), (1, 64)):
+        rew, val = torch.randn(H, N, 1, generator=g, device=dev), torch.randn(H, N, 1, generator=g, device=dev)
+        done = (torch.rand(H, N, generator=g, device=dev) < 0.05).float()
+        fd = (torch.rand(N, generator=g, device=dev) < 0.05).float()
+        lv = torch.randn(N, 1, generator=g, device=dev)
+        ref = ppo.discount_values(fd, lv, done, val, rew, 0.99, 0.95)
+        got = gae(fd, lv, done, val, rew, 0.99, 0.95)
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6, (H, N)
