@@ -294,8 +294,20 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         g_n = torch.zeros(1, dtype=torch.long, device=device)
         g_terms = torch.zeros(len(names) or 15, device=device)
 
+        recorder = None
+        if fused is not None:          # (the step's bookkeeping in two launches instead of ~30: isaacgymdyros_amd/ppo_update.py::RolloutRecorder)
+            from isaacgymdyros_amd.ppo_update import RolloutRecorder
+            recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"])
+
         def rollout_step():
             mu, logstd, value = net(g_obs)
+            if recorder is not None:
+                act = recorder.pre(mu, value, torch.randn_like(mu), g_obs, g_dones)
+                o, r, d, infos = env.step(act)
+                st = infos.get("stacked_rewards")
+                recorder.post(r, value, infos.get("time_outs"), st if st is not None and st.is_contiguous() else None, d, o["obs"], g_terms, g_dones, g_obs)
+                g_n.add_(1)
+                return
             sigma = torch.exp(logstd)
             a = mu + sigma * torch.randn_like(mu)           # (Normal(mu, sigma).sample() and torch.normal check sigma >= 0 on the host: a sync, not capturable)
             for k, v in (("obs", g_obs), ("act", a), ("mu", mu), ("neglogp", neglogp(a, mu, sigma, logstd)), ("val", value), ("done", g_dones)):

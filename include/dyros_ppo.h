@@ -125,6 +125,18 @@ int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int3
 int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdones, const float *mb_values, const float *mb_rewards, float gamma, float tau, int32_t H,
             int32_t N, float *advs, void *stream);
 
+/* The rollout's bookkeeping around the env step, `play_steps` of learning/rl_games_custom/a2c_common_dyros.py:629-703, in two launches (the torch
+ * form is ~30 small kernels per step).  n: device int64, the step's row of the rollout buffers (the caller advances it).
+ * dwp_rollout_pre: a = mu + exp(logstd) * noise (noise: the caller's standard-normal draws [N][ACT]); row n of mb_obs [H][N][num_obs], mb_act, mb_mu
+ *   [H][N][ACT], mb_nlp (neglogp of a, models_dyros.py:59-62), mb_val, mb_done [H][N]; act [N][ACT] = clamp(a, -1, 1) for the env.
+ * dwp_rollout_post: mb_rew[n] = rew * reward_scale (+ gamma * value * time_outs: the bootstrap of :656-659; time_outs NULL = off); terms[c] += mean over
+ *   the envs of stacked[.][c], c < num_terms (terms NULL = off); g_dones = float(done_buf); g_obs = new_obs (skipped when they are one buffer). */
+int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
+                    int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, void *stream);
+int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
+                     const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
+                     float *g_obs, void *stream);
+
 /* p16f from p16 (all weights; after construction or after loading parameters) */
 int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream);
 

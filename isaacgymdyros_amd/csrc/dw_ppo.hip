@@ -766,6 +766,56 @@ __global__ __launch_bounds__(256) void k_gae(const float *__restrict__ fdones, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the rollout's bookkeeping around env.step
+// What play_steps does between the policy's forward and the env step, and after it (learning/rl_games_custom/a2c_common_dyros.py:629-703):
+// sample the action, its neglogp, the step's row of every rollout buffer; then the shaped reward with the time-out bootstrap, the logged
+// reward terms, the new dones and observations.  ~30 torch kernels per step otherwise, for a few KB of arithmetic and two 32 MB copies.
+struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs; };
+__global__ __launch_bounds__(256) void k_roll_pre(const RollPre A) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)*A.n, N = A.N;
+    const size_t nf4 = N * A.nobs / 4;          // (N * nobs is a multiple of 4: checked by the launcher)
+    if (i < nf4) reinterpret_cast<f4 *>(A.mb_obs + n * N * A.nobs)[i] = reinterpret_cast<const f4 *>(A.obs)[i];
+    if (i < N * ACT) {
+        const int k = (int)(i % ACT);
+        const float m_ = A.mu[i], a = m_ + expf(A.logstd[k]) * A.noise[i];          // mu + sigma * randn
+        A.mb_act[n * N * ACT + i] = a; A.mb_mu[n * N * ACT + i] = m_;
+        A.act[i] = fminf(fmaxf(a, -1.0f), 1.0f);          // clip_actions
+    }
+    if (i < N) {
+        float sq = 0.0f, lsum = 0.0f;
+        for (int k = 0; k < ACT; ++k) {
+            const float ls = A.logstd[k], sg = expf(ls), m_ = A.mu[i * ACT + k], a = m_ + sg * A.noise[i * ACT + k];
+            const float z = (a - m_) / sg;
+            sq += z * z; lsum += ls;
+        }
+        A.mb_nlp[n * N + i] = 0.5f * sq + 0.5f * 1.8378770664093453f * (float)ACT + lsum;          // models_dyros.py:59-62
+        A.mb_val[n * N + i] = A.value[i];
+        A.mb_done[n * N + i] = A.dones[i];
+    }
+}
+struct RollPost { const float *rew, *value, *stacked, *new_obs; const long long *time_outs, *done, *n; float *mb_rew, *terms, *g_dones, *g_obs; int N, nobs, nterms, ncols; float scale, gamma; };
+__global__ __launch_bounds__(256) void k_roll_post(const RollPost A) {
+    __shared__ float red[4][16];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)*A.n, N = A.N;
+    const size_t nf4 = N * A.nobs / 4;
+    if (A.g_obs != A.new_obs && i < nf4) reinterpret_cast<f4 *>(A.g_obs)[i] = reinterpret_cast<const f4 *>(A.new_obs)[i];
+    if (i < N) {
+        float r = A.rew[i] * A.scale;
+        if (A.time_outs) r = r + A.gamma * A.value[i] * (float)A.time_outs[i];          // value_bootstrap (:656-659)
+        A.mb_rew[n * N + i] = r;
+        A.g_dones[i] = (float)A.done[i];
+    }
+    // the logged reward terms: mean over the envs of the first nterms columns, added to the epoch's sums (blocks that hold envs only)
+    if ((size_t)blockIdx.x * 256 < N && A.terms) {
+        for (int c = 0; c < A.nterms && c < 16; ++c) {
+            const float t = wave_sum(i < N ? A.stacked[i * A.ncols + c] : 0.0f);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < A.nterms && threadIdx.x < 16) atomicAdd(&A.terms[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)N);
+    }
+}
+
 int done(const char *who) {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(who, e);
@@ -840,6 +890,28 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
     hipLaunchKernelGGL(k_gae, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma,
                        (float)((double)gamma * (double)tau), H, N, advs);
     return done("dwp_gae");
+}
+
+int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
+                    int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, void *stream) {
+    if (!mu || !value || !noise || !obs || !dones || !logstd || !n || !mb_obs || !mb_act || !mb_mu || !mb_nlp || !mb_val || !mb_done || !act || N < 1 || num_obs < ACT)
+        return fail("dwp_rollout_pre: bad argument");
+    if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_pre: N * num_obs must be a multiple of 4");
+    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs};
+    hipLaunchKernelGGL(k_roll_pre, dim3((unsigned)(((size_t)N * num_obs / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    return done("dwp_rollout_pre");
+}
+
+int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
+                     const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
+                     float *g_obs, void *stream) {
+    if (!rew || !value || !done_buf || !new_obs || !n || !mb_rew || !g_dones || !g_obs || N < 1 || (terms && (!stacked || num_terms < 1 || num_terms > 16 || stacked_cols < num_terms)))
+        return fail("dwp_rollout_post: bad argument");
+    if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_post: N * num_obs must be a multiple of 4");
+    RollPost A{rew, value, stacked, new_obs, (const long long *)time_outs, (const long long *)done_buf, (const long long *)n, mb_rew, terms, g_dones, g_obs, N, num_obs,
+               num_terms, stacked_cols, reward_scale, gamma};
+    hipLaunchKernelGGL(k_roll_post, dim3((unsigned)(((size_t)N * num_obs / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    return done("dwp_rollout_post");
 }
 
 int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream) {

@@ -31,7 +31,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad", "gae"]
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -60,6 +60,8 @@ def declare(lib: C.CDLL) -> dict:
     api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
+    api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P)
+    api["rollout_post"] = fn("rollout_post", C.c_int, P, P, P, P, C.c_int32, P, P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, C.c_int32, P, P, P)
     api["gae"] = fn("gae", C.c_int, P, P, P, P, P, C.c_float, C.c_float, C.c_int32, C.c_int32, P, P)
     api["mlp"] = fn("mlp", C.c_int, C.POINTER(DwpMlp), P)
     api["wgrad"] = fn("wgrad", C.c_int, P, P, P, P, P, P, P, P, C.c_int32, P)
@@ -82,6 +84,40 @@ def gae(fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma: float, tau
     if rc != 0:
         raise RuntimeError(api["last_error"]().decode())
     return advs
+
+
+class RolloutRecorder:
+    """The bookkeeping of one rollout step around env.step in two launches (dwp_rollout_pre / _post): `mb` is the consumer's dict of rollout
+    buffers (obs [H, N, num_obs], act, mu [H, N, 13], neglogp, done [H, N], val, rew [H, N, 1]), n a device int64 [1] the caller advances."""
+
+    def __init__(self, mb: dict, n: torch.Tensor, logstd: torch.Tensor, reward_scale: float, gamma: float, bootstrap: bool):
+        self.api = declare(_lib.load()[0])
+        self.mb, self.n, self.logstd = mb, n, logstd
+        self.scale, self.gamma, self.bootstrap = float(reward_scale), float(gamma), bool(bootstrap)
+        self.H, self.N, self.nobs = (int(x) for x in mb["obs"].shape)
+        for k in ("obs", "act", "mu", "neglogp", "val", "rew", "done"):
+            assert mb[k].is_contiguous() and mb[k].dtype == torch.float32 and mb[k].is_cuda, k
+        self.act = torch.empty(self.N, ACT, device=mb["obs"].device)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.api["last_error"]().decode())
+
+    def pre(self, mu, value, noise, obs, dones):
+        """Returns the clipped action for env.step."""
+        mb, s = self.mb, torch.cuda.current_stream(obs.device).cuda_stream
+        self._chk(self.api["rollout_pre"](mu.data_ptr(), value.data_ptr(), noise.data_ptr(), obs.data_ptr(), dones.data_ptr(), self.logstd.data_ptr(), self.n.data_ptr(),
+                                          self.N, self.nobs, mb["obs"].data_ptr(), mb["act"].data_ptr(), mb["mu"].data_ptr(), mb["neglogp"].data_ptr(),
+                                          mb["val"].data_ptr(), mb["done"].data_ptr(), self.act.data_ptr(), s))
+        return self.act
+
+    def post(self, rew, value, time_outs, stacked, done_buf, new_obs, terms, g_dones, g_obs):
+        s = torch.cuda.current_stream(rew.device).cuda_stream
+        to = time_outs.data_ptr() if (self.bootstrap and time_outs is not None) else None
+        self._chk(self.api["rollout_post"](rew.data_ptr(), value.data_ptr(), to, stacked.data_ptr() if stacked is not None else None,
+                                           int(stacked.shape[1]) if stacked is not None else 0, done_buf.data_ptr(), new_obs.data_ptr(), self.n.data_ptr(), self.N, self.nobs,
+                                           self.scale, self.gamma, self.mb["rew"].data_ptr(), terms.data_ptr() if stacked is not None else None,
+                                           int(terms.numel()) if stacked is not None else 0, g_dones.data_ptr(), g_obs.data_ptr(), s))
 
 
 class FusedPpoUpdate:
