@@ -299,8 +299,13 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             from isaacgymdyros_amd.ppo_update import RolloutRecorder
             recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"])
 
+        pol = (torch.empty(N, env.num_acts, device=device), torch.empty(N, 1, device=device)) if fused is not None and N % 32 == 0 else None
+
         def rollout_step():
-            mu, logstd, value = net(g_obs)
+            if pol is not None:          # (the fp32 forward of both nets in one launch on the matrix cores: FusedPpoUpdate.policy)
+                mu, value = fused.policy(g_obs, *pol)
+            else:
+                mu, logstd, value = net(g_obs)
             if recorder is not None:
                 act = recorder.pre(mu, value, torch.randn_like(mu), g_obs, g_dones)
                 o, r, d, infos = env.step(act)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 3
+#define DWP_ABI_VERSION 4
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -90,6 +90,7 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
 
 #define DWP_PARTS 256   /* words of `part` */
 #define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
+#define DWP_P32F_WORDS 401408   /* floats of p32f, the fp32 weights in the order dwp_policy's matrix instructions take them (csrc/dw_ppo.hip frag32_pos) */
 #define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */
 #define DWP_PBUF_WORDS 544   /* words of a row of dwp_mlp's accumulators */
 #define DWP_PBUF_BUCKETS 32  /* rows per net: pbuf is [DWP_PBUF_BUCKETS][2][DWP_PBUF_WORDS] floats, zero-initialised by the caller once */
@@ -102,9 +103,10 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
 /* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
  * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first (norm^2 = the sum of `part`, published in
  * state[NORM2]).  p16f (or NULL): the fragment-order fp16 copy of the weights that dwp_mlp reads (DWP_P16F_WORDS halves, zero-initialised
- * by the caller and filled once with dwp_retile).  g32 (or NULL): as dwp_grad_stats */
+ * by the caller and filled once with dwp_retile).  g32 (or NULL): as dwp_grad_stats.
+ * p32f (or NULL): the fp32 fragment-order copy of the weights that dwp_policy reads (DWP_P32F_WORDS floats; filled once with dwp_retile32) */
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
-             uint16_t *p16f, const float *g32, void *stream);
+             uint16_t *p16f, const float *g32, float *p32f, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
  * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum
@@ -136,6 +138,12 @@ int dwp_rollout_pre(const float *mu, const float *value, const float *noise, con
 int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
                      const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
                      float *g_obs, void *stream);
+
+/* The rollout's policy forward, get_action_values of the reference (fp32: no autocast there): mu [N][ACT] and value [N] of both nets for obs [N][IN], on
+ * v_mfma_f32_16x16x4_f32 (the library's fp32 GEMMs take 0.25 ms of a 0.39 ms rollout step at 16384 envs).  p: the fp32 masters (biases), p32f: the weights
+ * in operand order (dwp_retile32 once, then kept by dwp_adam).  N: a multiple of 32. */
+int dwp_policy(const float *obs, const float *p, const float *p32f, int32_t N, float *mu, float *value, void *stream);
+int dwp_retile32(const float *p, float *p32f, void *stream);
 
 /* p16f from p16 (all weights; after construction or after loading parameters) */
 int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream);

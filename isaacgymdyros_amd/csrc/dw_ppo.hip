@@ -66,6 +66,25 @@ __global__ __launch_bounds__(256) void k_retile(const _Float16 *__restrict__ p16
     if (i < NWT) write_frags(p16f, i, p16[i]);
 }
 
+// The same for the rollout's fp32 policy forward (dwp_policy, v_mfma_f32_16x16x4_f32: one A and one B word per lane and instruction, lane l:
+// A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15]).  Four k-steps are one 16-byte request: the words of k = 16 kg + 4 j + (l >> 4),
+// j = 0 .. 3, of row 16 nt + (l & 15) sit at ((kg * NT + nt) * 64 + l) * 4 + j.  p32f (floats): W1 | W2 | W3 as forward operands.
+constexpr int G_W1 = 0, G_W2 = G_W1 + NW1, G_W3 = G_W2 + NW2, G_END = G_W3 + NW3;
+static_assert(G_END == DWP_P32F_WORDS, "include/dyros_ppo.h");
+__device__ __forceinline__ int frag32_pos(int nt_count, int row, int k) { return ((((k >> 4) * nt_count + (row >> 4)) * 64 + (k & 3) * 16 + (row & 15)) << 2) + ((k >> 2) & 3); }
+__device__ __forceinline__ void write_frag32(float *__restrict__ p32f, int i, float v) {          // i: index of a WEIGHT in the parameter layout
+    if (i < NW1) { const int net = i / (HID * INP), o = (i / INP) % HID, k = i % INP; p32f[G_W1 + net * HID * INP + frag32_pos(HID / 16, o, k)] = v; return; }
+    i -= NW1;
+    if (i < NW2) { const int net = i / (HID * HID), o = (i / HID) % HID, k = i % HID; p32f[G_W2 + net * HID * HID + frag32_pos(HID / 16, o, k)] = v; return; }
+    i -= NW2;
+    const int net = i / (OUTP * HID), o = (i / HID) % OUTP, k = i % HID;
+    p32f[G_W3 + net * OUTP * HID + frag32_pos(1, o, k)] = v;
+}
+__global__ __launch_bounds__(256) void k_retile32(const float *__restrict__ p, float *__restrict__ p32f) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NWT) write_frag32(p32f, i, p[i]);
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
     for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
 static_assert(NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0 && NB1 % 8 == 0 && NB2 % 8 == 0 && NB3 % 8 == 0 && INP % 8 == 0 && HID % 8 == 0, "runs of eight");
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
-                                              float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32) {
+                                              float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32, float *__restrict__ p32f) {
     __shared__ float red[4];
     static_assert(GS_BLOCKS == 256, "one partial per thread");
     {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
@@ -300,6 +319,10 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     reinterpret_cast<f4 *>(m + i0)[0] = mv[0]; reinterpret_cast<f4 *>(m + i0)[1] = mv[1];
     reinterpret_cast<f4 *>(v + i0)[0] = vv[0]; reinterpret_cast<f4 *>(v + i0)[1] = vv[1];
     *reinterpret_cast<h8 *>(p16 + i0) = ph;
+    if (p32f && i0 < NWT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) write_frag32(p32f, i0 + q, pv[q >> 2][q & 3]);          // (the rollout's fp32 policy reads the masters in ITS operand order)
+    }
     if (p16f && i0 < NWT) {
         // forward operand order: my eight are one fragment (frag_pos of the first, k & 7 = 0); input-gradient order: one half each
         int i = i0;
@@ -816,6 +839,111 @@ __global__ __launch_bounds__(256) void k_roll_post(const RollPost A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dwp_policy: the rollout's forward in fp32
+// mu [N][13] and value [N] of both nets for N observations, fp32 throughout as the reference's get_action_values (no autocast there), on
+// v_mfma_f32_16x16x4_f32: workgroup of four waves = 32 samples through one net, activations in LDS with the k index permuted so that a
+// lane's four k-steps are 16 consecutive bytes, weights from the fp32 fragment-order copy, products split by columns, ring of requests.
+constexpr int XS32 = INP + 4, HS32 = HID + 4;          // LDS row strides in floats
+__device__ __forceinline__ int perm16(int k) { return (k & ~15) + 4 * (k & 3) + ((k >> 2) & 3); }          // position of k inside its group of 16
+template <int KG, int AS, int NTA, int NT, int RD>
+__device__ __forceinline__ void mfma32_rows(const float *As, const float *__restrict__ W, int nt0, f4 (&acc)[MR][NT], int lane) {
+    const int ar = lane & 15, g = lane >> 4;
+    const f4 *wl = reinterpret_cast<const f4 *>(W) + nt0 * 64 + lane;
+    f4 b[RD][NT];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mr][t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int pk = 0; pk < RD - 1 && pk < KG; ++pk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[pk][t] = wl[(pk * NTA + t) * 64];
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+        if (kg + RD - 1 < KG) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[(kg + RD - 1) % RD][t] = wl[((kg + RD - 1) * NTA + t) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f4 a[MR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a[mr] = *reinterpret_cast<const f4 *>(As + (16 * mr + ar) * AS + 16 * kg + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mr][j], b[kg % RD][t][j], acc[mr][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__global__ __launch_bounds__(64 * WPB) void k_policy(const float *__restrict__ obs, const float *__restrict__ p, const float *__restrict__ p32f, int N,
+                                                     float *__restrict__ mu, float *__restrict__ value) {
+    __shared__ float Xs[MT * XS32];          // the input rows; after the first layer: the second hidden layer
+    __shared__ float H1s[MT * HS32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, net = blockIdx.y, r0 = blockIdx.x * MT;
+    const int nt0 = NTW * wv, cr = lane & 15, g = lane >> 4;
+    const float *W1 = p32f + G_W1 + (size_t)net * HID * INP, *W2 = p32f + G_W2 + (size_t)net * HID * HID, *W3 = p32f + G_W3 + (size_t)net * OUTP * HID;
+    const float *b1 = p + NWT + net * HID, *b2 = p + NWT + NB1 + net * HID, *b3 = p + NWT + NB1 + NB2 + net * OUTP;
+    {
+        const float *src = obs + (size_t)r0 * IN;
+        const int c0 = tid, c1 = tid + 256, c1l = c1 < IN ? c1 : c0;
+        float v0[MT], v1[MT];
+#pragma unroll
+        for (int r = 0; r < MT; ++r) { v0[r] = src[(size_t)r * IN + c0]; v1[r] = src[(size_t)r * IN + c1l]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q0 = perm16(c0), q1 = perm16(c1);
+#pragma unroll
+        for (int r = 0; r < MT; ++r) { Xs[r * XS32 + q0] = v0[r]; Xs[r * XS32 + q1] = c1 < IN ? v1[r] : 0.0f; }
+        __syncthreads();
+    }
+    f4 acc[MR][NTW];
+    float bia[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bia[t] = b1[16 * (nt0 + t) + cr];
+    mfma32_rows<INP / 16, XS32, NTL, NTW, 3>(Xs, W1, nt0, acc, lane);
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H1s[(16 * mr + 4 * g + r) * HS32 + perm16(16 * (nt0 + t) + cr)] = fmaxf(acc[mr][t][r] + bia[t], 0.0f);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bia[t] = b2[16 * (nt0 + t) + cr];
+    mfma32_rows<HID / 16, HS32, NTL, NTW, 3>(H1s, W2, nt0, acc, lane);
+    float *H2s = Xs;          // [MT][HS32]
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H2s[(16 * mr + 4 * g + r) * HS32 + perm16(16 * (nt0 + t) + cr)] = fmaxf(acc[mr][t][r] + bia[t], 0.0f);
+    __syncthreads();
+    // the head: one column tile (16 padded outputs); waves 0 and 1 take one row tile each
+    if (wv < MR) {
+        const int ar = lane & 15;
+        const f4 *wl = reinterpret_cast<const f4 *>(W3) + lane;
+        f4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kg = 0; kg < HID / 16; ++kg) {
+            const f4 bq = wl[kg * 64];
+            const f4 aq = *reinterpret_cast<const f4 *>(H2s + (16 * wv + ar) * HS32 + 16 * kg + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j], bq[j], o, 0, 0, 0);
+        }
+        const float bias = b3[cr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 16 * wv + 4 * g + r;
+            if (row < N) {
+                if (net == 0) { if (cr < ACT) mu[(size_t)row * ACT + cr] = o[r] + bias; }
+                else if (cr == 0) value[row] = o[r] + bias;
+            }
+        }
+    }
+}
+
 int done(const char *who) {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail_hip(who, e);
@@ -863,10 +991,10 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
 }
 
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
-             const float *g32, void *stream) {
+             const float *g32, float *p32f, void *stream) {
     if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part) return fail("dwp_adam: bad argument");
     hipLaunchKernelGGL(k_adam, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
-                       (_Float16 *)p16t, g32);
+                       (_Float16 *)p16t, g32, p32f);
     return done("dwp_adam");
 }
 
@@ -918,6 +1046,18 @@ int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream) {
     if (!p16 || !p16f) return fail("dwp_retile: bad argument");
     hipLaunchKernelGGL(k_retile, dim3((NWT + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)p16, (_Float16 *)p16f);
     return done("dwp_retile");
+}
+
+int dwp_retile32(const float *p, float *p32f, void *stream) {
+    if (!p || !p32f) return fail("dwp_retile32: bad argument");
+    hipLaunchKernelGGL(k_retile32, dim3((NWT + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, p32f);
+    return done("dwp_retile32");
+}
+
+int dwp_policy(const float *obs, const float *p, const float *p32f, int32_t N, float *mu, float *value, void *stream) {
+    if (!obs || !p || !p32f || !mu || !value || N < MT || N % MT) return fail("dwp_policy: bad argument (N: a multiple of 32)");
+    hipLaunchKernelGGL(k_policy, dim3(N / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, obs, p, p32f, N, mu, value);
+    return done("dwp_policy");
 }
 
 int dwp_mlp(const DwpMlp *a, void *stream) {

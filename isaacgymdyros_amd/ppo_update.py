@@ -31,7 +31,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post"]
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -57,7 +57,9 @@ def declare(lib: C.CDLL) -> dict:
     api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
     api["relu_bwd"] = fn("relu_bwd", C.c_int, P, P, P, C.c_int32, P)
     api["grad_stats"] = fn("grad_stats", C.c_int, P, P, P, P, P, P, P)
-    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, P)
+    api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, P, P)
+    api["policy"] = fn("policy", C.c_int, P, P, P, C.c_int32, P, P, P)
+    api["retile32"] = fn("retile32", C.c_int, P, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
     api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P)
@@ -189,6 +191,8 @@ class FusedPpoUpdate:
         self.rowmajor = bool(rowmajor) or not self.mfma
         self.p16t = torch.zeros(K["DWP_P16F_WORDS"], **f16)          # the weights once more, in the order dwp_mlp's matrix instructions take them
         self._chk(self.api["retile"](self.p16.data_ptr(), self.p16t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
+        self.p32f = torch.zeros(K["DWP_P32F_WORDS"], **f32)          # the fp32 weights in dwp_policy's operand order
+        self._chk(self.api["retile32"](self.p.data_ptr(), self.p32f.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
         self.pbuf = torch.zeros(K["DWP_PBUF_BUCKETS"], 2, K["DWP_PBUF_WORDS"], **f32)          # dwp_mlp: accumulators of bias gradients and logged sums
         self._mlp_args = None
         if self.mfma:          # dwp_mlp's outputs once more as operands of dwp_wgrad, and its two sets of fp32 accumulators
@@ -210,12 +214,22 @@ class FusedPpoUpdate:
         if rc != 0:
             raise RuntimeError(self.api["last_error"]().decode())
 
+    def policy(self, obs: torch.Tensor, mu: torch.Tensor = None, value: torch.Tensor = None):
+        """The rollout's forward in fp32 (dwp_policy): (mu [N, 13], value [N, 1]) for obs [N, 487], N a multiple of 32.  mu / value: output
+        tensors to reuse (a captured rollout step passes the same ones every time)."""
+        N = int(obs.shape[0])
+        if mu is None:
+            mu, value = torch.empty(N, ACT, device=self.dev), torch.empty(N, 1, device=self.dev)
+        self._chk(self.api["policy"](obs.data_ptr(), self.p.data_ptr(), self.p32f.data_ptr(), N, mu.data_ptr(), value.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
+        return mu, value
+
     def refresh_copies(self):
         """After the module's parameters were written from outside (a checkpoint loaded into the network: they are views of the master buffer):
         the fp16 copies the next forward reads, row-major and in fragment order."""
         with torch.no_grad():
             self.p16.copy_(self.p)
         self._chk(self.api["retile"](self.p16.data_ptr(), self.p16t.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
+        self._chk(self.api["retile32"](self.p.data_ptr(), self.p32f.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
 
     def state_dict(self) -> dict:
         """Optimiser side of a checkpoint (the parameters themselves are the network's): Adam moments, step counts, loss scale and its growth
@@ -269,7 +283,7 @@ class FusedPpoUpdate:
                                    self.g32.data_ptr(), B, s))
             self._chk(api["grad_stats"](None, self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), self.g32.data_ptr(), s))
             self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), None, self.gb.data_ptr(), st,
-                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), s))
+                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), self.p32f.data_ptr(), s))
             self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
             return
         self._chk(api["stage_obs"](obs.data_ptr(), st, B, self.x16.data_ptr(), s))
@@ -291,7 +305,7 @@ class FusedPpoUpdate:
         torch.bmm(self.dh1.transpose(1, 2), self.x16.unsqueeze(0).expand(2, B, INP), out=G["W1"])
         # unscale + clip + Adam + scaler
         self._chk(api["grad_stats"](self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), None, None, s))
-        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), None, s))
+        self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.g16.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), None, self.p32f.data_ptr(), s))
         self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, None, s))
 
     def logged(self):

@@ -46,7 +46,7 @@ def test_library_builds_and_exports_the_abi():
     # include/dyros_ppo.h: the kernels of the PPO consumer's fused update
     from isaacgymdyros_amd import ppo_update
     src = open(os.path.join(ROOT, "include", "dyros_ppo.h")).read()
-    declared = sorted(set(re.findall(r"\b(dwp_[a-z_]+)\s*\(", src)))
+    declared = sorted(set(re.findall(r"\b(dwp_[a-z_0-9]+)\s*\(", src)))
     assert declared == sorted("dwp_" + n for n in ppo_update.EXPORTS)
     for fn in declared:
         assert hasattr(lib, fn), fn

@@ -365,3 +365,39 @@ def test_rollout_recorder_equals_the_torch_bookkeeping():
     assert float((mb["neglogp"] - ref["neglogp"]).abs().max()) <= 2e-5 * float(ref["neglogp"].abs().max())
     assert float((mb["rew"] - ref["rew"]).abs().max()) <= 1e-6 * float(ref["rew"].abs().max()) + 1e-7
     assert float((terms - terms_ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_policy_forward_equals_the_module_in_fp32():
+    """dwp_policy (v_mfma_f32_16x16x4_f32, fp32 weights in operand order) against the torch module's fp32 forward; also after an update (dwp_adam keeps
+    the operand-order copy) and after refresh_copies()."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(12)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 1024, 2
+    f = U.FusedPpoUpdate(net, c, B, nmb, dev)
+    f.set_learning_rates(1e-3, 1e-3)
+    g = torch.Generator(device=dev).manual_seed(3)
+    obs = torch.randn(4096, U.IN, generator=g, device=dev)
+
+    def check():
+        with torch.no_grad():
+            mu_t, _, v_t = net(obs)
+        mu, v = f.policy(obs)
+        torch.cuda.synchronize()
+        assert float((mu - mu_t).abs().max()) <= 2e-5 * float(mu_t.abs().max()) + 1e-6, float((mu - mu_t).abs().max())
+        assert float((v - v_t).abs().max()) <= 2e-5 * float(v_t.abs().max()) + 1e-6
+    check()
+    f.bind_batch(*_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
+    f.update(); f.update()
+    check()          # (the parameters moved by 2 x lr; the module sees the masters, dwp_policy the copy dwp_adam kept)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.requires_grad:
+                p_.mul_(1.01)
+    f.refresh_copies()
+    check()
