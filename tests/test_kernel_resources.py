@@ -107,3 +107,18 @@ def test_small_kernels_do_not_spill(usage):
     assert seen >= 10
     end = [r for k, r in usage.items() if "dw_k_amp_step_end" in k][0]
     assert end["LDS Size"] <= 20480, end
+
+
+def test_ppo_kernels_budget(usage):
+    """csrc/dw_ppo.hip: no scratch anywhere; the matrix-core kernels' LDS leaves one workgroup of four waves per CU (dwp_mlp: the input rows and three
+    fp16 images, dwp_policy: the fp32 input rows and one image) and dwp_wgrad keeps at least two waves per SIMD for its latency."""
+    ppo = {k: r for k, r in usage.items() if any(x in k for x in ("k_mlp", "k_wgrad", "k_policy", "k_adam", "k_grad_stats", "k_finish", "k_gae", "k_roll_pre", "k_roll_post",
+                                                                   "k_loss", "k_relu_bwd", "k_bias_relu", "k_stage_obs", "k_retile"))}
+    assert len(ppo) >= 14, sorted(ppo)
+    for k, r in ppo.items():
+        assert r["ScratchSize"] == 0, (k, r)
+    mlp = [r for k, r in ppo.items() if "k_mlp" in k][0]
+    pol = [r for k, r in ppo.items() if "k_policy" in k][0]
+    wg = [r for k, r in ppo.items() if "k_wgrad" in k][0]
+    assert 80 * 1024 <= mlp["LDS Size"] <= 96 * 1024 and pol["LDS Size"] <= 104 * 1024
+    assert wg["LDS Size"] == 0 and wg["Occupancy"] >= 2
