@@ -204,3 +204,28 @@ def test_fused_update_refuses_what_it_was_not_written_for():
     assert (U.IN, U.INP, U.HID, U.OUTP, U.ACT) == (487, 512, 256, 16, 13) and U.NP == 2 * (256 * 512 + 256 * 256 + 16 * 256 + 256 + 256 + 16)
     with pytest.raises(ValueError):
         ppo.train(8, epochs=1, horizon=4, device="cpu", fused_update=True, env=type("E", (), {"num_envs": 8, "num_obs": U.IN, "num_acts": U.ACT})())
+
+
+def test_operand_order_layouts_are_bijections():
+    """include/dyros_ppo.h / csrc/dw_ppo.hip frag_pos, frag32_pos: the positions of a weight matrix's elements in the order the matrix instructions take
+    them are a permutation of its row-major positions (restated here: a changed formula on one side shows as a size mismatch or a collision), and the
+    copies' sizes are the header's."""
+    import numpy as np
+    from isaacgymdyros_amd import ppo_update as U
+
+    def frag_pos(nt, row, k):          # v_mfma_f32_16x16x32_f16: eight halves of k = 32 kk + 8 g + j per lane (g * 16 + row % 16)
+        return ((((k >> 5) * nt + (row >> 4)) * 64 + ((k & 31) >> 3) * 16 + (row & 15)) << 3) + (k & 7)
+
+    def frag32_pos(nt, row, k):        # v_mfma_f32_16x16x4_f32: four words of k = 16 kg + 4 j + g per lane
+        return ((((k >> 4) * nt + (row >> 4)) * 64 + (k & 3) * 16 + (row & 15)) << 2) + ((k >> 2) & 3)
+    for fn in (frag_pos, frag32_pos):
+        for rows, K in ((U.HID, U.INP), (U.HID, U.HID), (U.OUTP, U.HID)):
+            r, k = np.meshgrid(np.arange(rows), np.arange(K), indexing="ij")
+            pos = fn(rows // 16, r, k).ravel()
+            assert pos.min() == 0 and pos.max() == rows * K - 1 and len(np.unique(pos)) == rows * K, (fn.__name__, rows, K)
+    # the heads' input-gradient operand: rows = the 256 inputs, k = the 16 outputs padded to 32 (the upper half of every fragment stays zero)
+    r, k = np.meshgrid(np.arange(U.HID), np.arange(U.OUTP), indexing="ij")
+    pos = frag_pos(U.HID // 16, r, k).ravel()
+    assert len(np.unique(pos)) == U.HID * U.OUTP and pos.max() < U.HID * 32
+    nw = 2 * (U.HID * U.INP + U.HID * U.HID + U.OUTP * U.HID)
+    assert U.K["DWP_P32F_WORDS"] == nw and U.K["DWP_P16F_WORDS"] == nw + 2 * U.HID * U.HID + 2 * U.HID * 32
