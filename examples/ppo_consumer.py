@@ -299,7 +299,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             from isaacgymdyros_amd.ppo_update import RolloutRecorder
             recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"])
 
-        pol = (torch.empty(N, env.num_acts, device=device), torch.empty(N, 1, device=device)) if fused is not None and N % 32 == 0 else None
+        pol = (torch.empty(N, env.num_acts, device=device), torch.empty(N, 1, device=device)) if fused is not None else None
 
         def rollout_step():
             if pol is not None:          # (the fp32 forward of both nets in one launch on the matrix cores: FusedPpoUpdate.policy)

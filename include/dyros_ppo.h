@@ -141,7 +141,7 @@ int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_o
 
 /* The rollout's policy forward, get_action_values of the reference (fp32: no autocast there): mu [N][ACT] and value [N] of both nets for obs [N][IN], on
  * v_mfma_f32_16x16x4_f32 (the library's fp32 GEMMs take 0.25 ms of a 0.39 ms rollout step at 16384 envs).  p: the fp32 masters (biases), p32f: the weights
- * in operand order (dwp_retile32 once, then kept by dwp_adam).  N: a multiple of 32. */
+ * in operand order (dwp_retile32 once, then kept by dwp_adam).  Any N >= 1. */
 int dwp_policy(const float *obs, const float *p, const float *p32f, int32_t N, float *mu, float *value, void *stream);
 int dwp_retile32(const float *p, float *p32f, void *stream);
 

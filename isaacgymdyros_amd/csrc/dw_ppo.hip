@@ -888,9 +888,10 @@ __global__ __launch_bounds__(64 * WPB) void k_policy(const float *__restrict__ o
     {
         const float *src = obs + (size_t)r0 * IN;
         const int c0 = tid, c1 = tid + 256, c1l = c1 < IN ? c1 : c0;
+        const int rmax = N - 1 - r0;          // (rows past the end -- N is not a multiple of 32 -- read the last row again; nothing of theirs is stored)
         float v0[MT], v1[MT];
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { v0[r] = src[(size_t)r * IN + c0]; v1[r] = src[(size_t)r * IN + c1l]; }
+        for (int r = 0; r < MT; ++r) { const int rr = r < rmax ? r : rmax; v0[r] = src[(size_t)rr * IN + c0]; v1[r] = src[(size_t)rr * IN + c1l]; }
         __builtin_amdgcn_sched_barrier(0);
         const int q0 = perm16(c0), q1 = perm16(c1);
 #pragma unroll
@@ -1055,8 +1056,8 @@ int dwp_retile32(const float *p, float *p32f, void *stream) {
 }
 
 int dwp_policy(const float *obs, const float *p, const float *p32f, int32_t N, float *mu, float *value, void *stream) {
-    if (!obs || !p || !p32f || !mu || !value || N < MT || N % MT) return fail("dwp_policy: bad argument (N: a multiple of 32)");
-    hipLaunchKernelGGL(k_policy, dim3(N / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, obs, p, p32f, N, mu, value);
+    if (!obs || !p || !p32f || !mu || !value || N < 1) return fail("dwp_policy: bad argument");
+    hipLaunchKernelGGL(k_policy, dim3((N + MT - 1) / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, obs, p, p32f, N, mu, value);
     return done("dwp_policy");
 }
 

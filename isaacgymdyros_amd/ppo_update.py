@@ -215,7 +215,7 @@ class FusedPpoUpdate:
             raise RuntimeError(self.api["last_error"]().decode())
 
     def policy(self, obs: torch.Tensor, mu: torch.Tensor = None, value: torch.Tensor = None):
-        """The rollout's forward in fp32 (dwp_policy): (mu [N, 13], value [N, 1]) for obs [N, 487], N a multiple of 32.  mu / value: output
+        """The rollout's forward in fp32 (dwp_policy): (mu [N, 13], value [N, 1]) for obs [N, 487].  mu / value: output
         tensors to reuse (a captured rollout step passes the same ones every time)."""
         N = int(obs.shape[0])
         if mu is None:

@@ -384,7 +384,7 @@ def test_policy_forward_equals_the_module_in_fp32():
     g = torch.Generator(device=dev).manual_seed(3)
     obs = torch.randn(4096, U.IN, generator=g, device=dev)
 
-    def check():
+    def check(obs=obs):
         with torch.no_grad():
             mu_t, _, v_t = net(obs)
         mu, v = f.policy(obs)
@@ -392,6 +392,7 @@ def test_policy_forward_equals_the_module_in_fp32():
         assert float((mu - mu_t).abs().max()) <= 2e-5 * float(mu_t.abs().max()) + 1e-6, float((mu - mu_t).abs().max())
         assert float((v - v_t).abs().max()) <= 2e-5 * float(v_t.abs().max()) + 1e-6
     check()
+    check(obs[:1000]); check(obs[:3]); check(obs[:33])          # (env counts that are not a multiple of the workgroup's 32 rows)
     f.bind_batch(*_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
     f.update(); f.update()
     check()          # (the parameters moved by 2 x lr; the module sees the masters, dwp_policy the copy dwp_adam kept)
