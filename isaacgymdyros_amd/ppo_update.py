@@ -128,7 +128,7 @@ class FusedPpoUpdate:
     be captured in a hipGraph once and replayed)."""
 
     def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True, rowmajor: bool = True):
-        """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp; the minibatch must be a multiple of 16) instead
+        """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp + dwp_wgrad; the minibatch must be a multiple of 32, else the library-GEMM form runs) instead
         of eight library GEMM launches with six kernels between them.  rowmajor (mfma only): dwp_mlp also writes its activations and their
         gradients as plain [2, B, 256] / [B, 512] matrices (x16, h1, h2, dh2, dh1: what the tests read); a trainer passes False."""
         c = cfg
@@ -195,7 +195,7 @@ class FusedPpoUpdate:
         self._chk(self.api["retile32"](self.p.data_ptr(), self.p32f.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
         self.pbuf = torch.zeros(K["DWP_PBUF_BUCKETS"], 2, K["DWP_PBUF_WORDS"], **f32)          # dwp_mlp: accumulators of bias gradients and logged sums
         self._mlp_args = None
-        if self.mfma:          # dwp_mlp's outputs once more as operands of dwp_wgrad, and its two sets of fp32 accumulators
+        if self.mfma:          # dwp_mlp's outputs once more as operands of dwp_wgrad, and dwp_wgrad's partial gradients
             self.xf = torch.zeros(B * INP, **f16)
             self.h1f, self.h2f, self.dz2f, self.dz1f = (torch.zeros(2 * B * HID, **f16) for _ in range(4))
             self.doutf = torch.zeros(2 * B * OUTP, **f16)
