@@ -8,7 +8,7 @@
  * With torch's autograd that is ~190 kernel launches for a 4096 x 487 minibatch whose arithmetic is 10 GFLOP: launch-bound
  * (0.98 ms per update inside a hipGraph on an MI355X).  Two forms here, same arithmetic types (fp16 operands, fp32 accumulation; fp32 losses,
  * masters and moments; dynamic loss scale):
- *   five launches, the products on the matrix cores (0.059 ms per update):
+ *   four launches, the products on the matrix cores (0.05 ms per update):
  *     dwp_mlp         observations -> fp16, the three layers of both nets, loss and output gradient, the two input-gradient products, relu
  *                     masks, all bias gradients (v_mfma_f32_16x16x32_f16; weights read in fragment order: dwp_retile, kept by dwp_adam)
  *     dwp_wgrad       the three weight gradients of both nets (fp32 accumulators)
@@ -17,6 +17,7 @@
  *     dwp_adam        unscale, clip (actor), Adam step on the fp32 master parameters unless the net's flag is set, fp16 copies for the
  *                     next forward (what autocast's weight cast produces)
  *     dwp_finish      moves the loss scale as GradScaler.update does, counts the steps, publishes the logged means, clears accumulators
+ *                     (dwp_adam_finish: the last two in one launch -- what the four-launch form calls)
  *   seventeen launches, the eight products as library calls (torch.bmm: hipBLASLt / rocBLAS; actor and critic as one batched GEMM per layer
  *   and direction), with between them:
  *     dwp_stage_obs   fp32 observations of minibatch i -> the fp16 input matrix (autocast's cast of the Linear input)
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 4
+#define DWP_ABI_VERSION 5
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -88,14 +89,15 @@ int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const flo
 /* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */
 int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
 
-#define DWP_PARTS 256   /* words of `part` */
+#define DWP_PARTS 768   /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates */
 #define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
 #define DWP_P32F_WORDS 401408   /* floats of p32f, the fp32 weights in the order dwp_policy's matrix instructions take them (csrc/dw_ppo.hip frag32_pos) */
 #define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */
 #define DWP_PBUF_WORDS 544   /* words of a row of dwp_mlp's accumulators */
 #define DWP_PBUF_BUCKETS 32  /* rows per net: pbuf is [DWP_PBUF_BUCKETS][2][DWP_PBUF_WORDS] floats, zero-initialised by the caller once */
-/* part[0 .. DWP_PARTS) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
- * that net is not finite.  pbuf (or NULL): dwp_mlp's accumulators: the bias gradients are their sums over the buckets (cleared here)
+/* part[0 .. 256) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
+ * that net is not finite (also per block in part[256 .. 512): bit `net`); part[512 ..] = state's SCALE, STEP[2], LR[2] as they are now
+ * (what dwp_adam_finish's blocks read instead of `state`).  pbuf (or NULL): dwp_mlp's accumulators: the bias gradients are their sums over the buckets (cleared here)
  * and are left in gb for dwp_adam (without it gb holds them already: dwp_loss / dwp_relu_bwd).
  * g32 (or NULL): the weight gradients are the sums over dwp_wgrad's partial gradients [DWP_WGRAD_SLABS][weights] instead of g16 */
 int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, void *stream);
@@ -107,6 +109,12 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
  * p32f (or NULL): the fp32 fragment-order copy of the weights that dwp_policy reads (DWP_P32F_WORDS floats; filled once with dwp_retile32) */
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
              uint16_t *p16f, const float *g32, float *p32f, void *stream);
+
+/* dwp_adam (weight gradients from g32) and dwp_finish in one launch: every block takes the loss scale, step counts, learning rates and
+ * flags from `part` as dwp_grad_stats left them, block 0 does dwp_finish's work on `state` meanwhile.  gb is not cleared (with pbuf
+ * dwp_grad_stats overwrites it) */
+int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16f,
+                    const float *g32, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
  * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum

@@ -218,11 +218,14 @@ __device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *g
     return s;
 }
 
+constexpr int PART_FLAGS = 256, PART_SNAP = 512;          // `part` [DWP_PARTS]: sums of squares | inf / nan flags (bit per net) per block | scale, steps, learning rates
+static_assert(DWP_PARTS >= PART_SNAP + 8, "part buffer");
 constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per block, in `part`; dwp_adam's blocks add them up (no atomics: 256
                                         // adds on one word are served one after the other and were most of this kernel's 12 us)
 __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part,
                                                     float *__restrict__ pbuf, const float *__restrict__ g32) {
     __shared__ float red[4];
+    __shared__ int redf[4];
     const float inv = 1.0f / state[DWP_S_SCALE];
     float sq = 0.0f;
     int bad0 = 0, bad1 = 0;
@@ -249,35 +252,103 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
     sq = wave_sum(sq);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    // per block, for the Adam kernel that also finishes the update (k_adam<true>: its blocks read nothing of `state`, which its block 0
+    // rewrites): the flags next to the partial sum, and -- block 0 -- the words of `state` an Adam block needs
+    const unsigned long long w0 = __ballot(bad0), w1 = __ballot(bad1);
+    if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = (w0 ? 1 : 0) | (w1 ? 2 : 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        part[PART_FLAGS + blockIdx.x] = (float)(redf[0] | redf[1] | redf[2] | redf[3]);
+        if (blockIdx.x == 0) {
+            part[PART_SNAP + 0] = state[DWP_S_SCALE];
+            part[PART_SNAP + 1] = state[DWP_S_STEP]; part[PART_SNAP + 2] = state[DWP_S_STEP + 1];
+            part[PART_SNAP + 3] = state[DWP_S_LR]; part[PART_SNAP + 4] = state[DWP_S_LR + 1];
+        }
+    }
     if (bad0) state[DWP_S_FOUND_INF] = 1.0f;
     if (bad1) state[DWP_S_FOUND_INF + 1] = 1.0f;
+}
+
+// the end of an update, by ONE block of 256 threads (all of them arrive): logged means, GradScaler.update, step counts, minibatch index
+__device__ __forceinline__ void finish_update(float *__restrict__ state, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
+    if (pbuf) {          // dwp_mlp's logged sums: over the buckets and the two nets, cleared for the next update
+        if (threadIdx.x < 5) {
+            float t = 0.0f;
+            for (int r = 0; r < 2 * PBK; ++r) { t += pbuf[(size_t)r * PBW + PB_ST + threadIdx.x]; pbuf[(size_t)r * PBW + PB_ST + threadIdx.x] = 0.0f; }
+            state[threadIdx.x] += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const float invB = 1.0f / (float)B;
+    const bool f0 = state[DWP_S_FOUND_INF] != 0.0f, f1 = state[DWP_S_FOUND_INF + 1] != 0.0f;
+    float *o = state + DWP_S_OUT;
+    o[0] = state[DWP_S_ALOSS] * invB; o[1] = state[DWP_S_CLOSS] * invB; o[2] = state[DWP_S_BLOSS] * invB; o[3] = state[DWP_S_CLIPPED] * invB;
+    o[4] = state[DWP_S_KL] * invB; o[5] = sqrtf(state[DWP_S_NORM2]); o[6] = state[DWP_S_SCALE]; o[7] = (f0 || f1) ? 1.0f : 0.0f;
+    // torch.amp.GradScaler.update (_amp_update_scale_): backoff 0.5 on any inf, growth 2.0 after growth_interval clean updates
+    if (f0 || f1) { state[DWP_S_SCALE] *= 0.5f; state[DWP_S_GROWTH] = 0.0f; }
+    else {
+        const float t = state[DWP_S_GROWTH] + 1.0f;
+        if ((int)t == growth_interval) { state[DWP_S_SCALE] *= 2.0f; state[DWP_S_GROWTH] = 0.0f; }
+        else state[DWP_S_GROWTH] = t;
+    }
+    if (!f0) state[DWP_S_STEP] += 1.0f;
+    if (!f1) state[DWP_S_STEP + 1] += 1.0f;
+    for (int k = 0; k < 8; ++k) state[k] = 0.0f;
+    const int mb = (int)state[DWP_S_MB] + 1;
+    state[DWP_S_MB] = (float)(mb >= nmb ? 0 : mb);
+}
+__global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float *__restrict__ gb, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
+    for (int i = threadIdx.x; i < NBT; i += 256) gb[i] = 0.0f;
+    finish_update(state, B, nmb, growth_interval, pbuf);
 }
 
 // Eight consecutive parameters per thread: a run of eight never crosses a row, a net or a tensor (every row length is a multiple of
 // 8), and it is exactly one fragment of the forward operand order -- so the master, the moments, the row-major fp16 copy and the forward
 // fragment copy move as 16- / 32-byte pieces; only the input-gradient copies of W2 / W3 (k = the OUTPUT index) are eight scattered halves.
 static_assert(NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0 && NB1 % 8 == 0 && NB2 % 8 == 0 && NB3 % 8 == 0 && INP % 8 == 0 && HID % 8 == 0, "runs of eight");
+// FIN: the launch also finishes the update (dwp_adam_finish: one graph node less).  Its blocks then read the loss scale, step counts,
+// learning rates and inf / nan flags from `part`, where dwp_grad_stats left them, because block 0 rewrites `state` while the others run.
+struct FinArgs { int B, nmb, growth_interval; float *pbuf; };
+template <bool FIN>
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
-                                              float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32, float *__restrict__ p32f) {
+                                              float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32, float *__restrict__ p32f, FinArgs fin) {
     __shared__ float red[4];
+    __shared__ int redf[4];
     static_assert(GS_BLOCKS == 256, "one partial per thread");
     {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
         const float s = wave_sum(part[threadIdx.x]);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        if (FIN) {
+            const int fl = (int)part[PART_FLAGS + threadIdx.x];
+            const unsigned long long w0 = __ballot(fl & 1), w1 = __ballot(fl & 2);
+            if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = (w0 ? 1 : 0) | (w1 ? 2 : 0);
+        }
         __syncthreads();
     }
     const float norm2 = red[0] + red[1] + red[2] + red[3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    const int net = net_of(i0 < NP ? i0 : 0);
+    bool skip;
+    float scale, step, lr;
+    if (FIN) {
+        skip = (((redf[0] | redf[1] | redf[2] | redf[3]) >> net) & 1) != 0;
+        scale = part[PART_SNAP]; step = part[PART_SNAP + 1 + net] + 1.0f; lr = part[PART_SNAP + 3 + net];
+    } else {
+        skip = state[DWP_S_FOUND_INF + net] != 0.0f;
+        scale = state[DWP_S_SCALE]; step = state[DWP_S_STEP + net] + 1.0f; lr = state[DWP_S_LR + net];
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
+        if (FIN) finish_update(state, fin.B, fin.nmb, fin.growth_interval, fin.pbuf);
+    }
     if (i0 >= NP) return;
-    const int net = net_of(i0);
-    if (state[DWP_S_FOUND_INF + net] != 0.0f) return;          // GradScaler.step: this optimiser's step is skipped
-    const float inv = 1.0f / state[DWP_S_SCALE];
+    if (skip) return;          // GradScaler.step: this optimiser's step is skipped
+    const float inv = 1.0f / scale;
     const float coef = net == 0 ? fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f) : 1.0f;          // torch.nn.utils.clip_grad_norm_ (the actor only)
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    const float step = state[DWP_S_STEP + net] + 1.0f, lr = state[DWP_S_LR + net];
     const float bc1 = 1.0f - powf(b1, step), sq2 = sqrtf(1.0f - powf(b2, step)), ss = lr / bc1;
     f4 pv[2] = {reinterpret_cast<const f4 *>(p + i0)[0], reinterpret_cast<const f4 *>(p + i0)[1]};
     f4 mv[2] = {reinterpret_cast<const f4 *>(m + i0)[0], reinterpret_cast<const f4 *>(m + i0)[1]};
@@ -340,36 +411,6 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
             for (int q = 0; q < 8; ++q) p16f[F_W3T + nn * HID * 32 + frag_pos(HID / 16, k + q, o)] = ph[q];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float *__restrict__ gb, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
-    for (int i = threadIdx.x; i < NBT; i += 256) gb[i] = 0.0f;
-    if (pbuf) {          // dwp_mlp's logged sums: over the buckets and the two nets, cleared for the next update
-        if (threadIdx.x < 5) {
-            float t = 0.0f;
-            for (int r = 0; r < 2 * PBK; ++r) { t += pbuf[(size_t)r * PBW + PB_ST + threadIdx.x]; pbuf[(size_t)r * PBW + PB_ST + threadIdx.x] = 0.0f; }
-            state[threadIdx.x] += t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const float invB = 1.0f / (float)B;
-    const bool f0 = state[DWP_S_FOUND_INF] != 0.0f, f1 = state[DWP_S_FOUND_INF + 1] != 0.0f;
-    float *o = state + DWP_S_OUT;
-    o[0] = state[DWP_S_ALOSS] * invB; o[1] = state[DWP_S_CLOSS] * invB; o[2] = state[DWP_S_BLOSS] * invB; o[3] = state[DWP_S_CLIPPED] * invB;
-    o[4] = state[DWP_S_KL] * invB; o[5] = sqrtf(state[DWP_S_NORM2]); o[6] = state[DWP_S_SCALE]; o[7] = (f0 || f1) ? 1.0f : 0.0f;
-    // torch.amp.GradScaler.update (_amp_update_scale_): backoff 0.5 on any inf, growth 2.0 after growth_interval clean updates
-    if (f0 || f1) { state[DWP_S_SCALE] *= 0.5f; state[DWP_S_GROWTH] = 0.0f; }
-    else {
-        const float t = state[DWP_S_GROWTH] + 1.0f;
-        if ((int)t == growth_interval) { state[DWP_S_SCALE] *= 2.0f; state[DWP_S_GROWTH] = 0.0f; }
-        else state[DWP_S_GROWTH] = t;
-    }
-    if (!f0) state[DWP_S_STEP] += 1.0f;
-    if (!f1) state[DWP_S_STEP + 1] += 1.0f;
-    for (int k = 0; k < 8; ++k) state[k] = 0.0f;
-    const int mb = (int)state[DWP_S_MB] + 1;
-    state[DWP_S_MB] = (float)(mb >= nmb ? 0 : mb);
 }
 
 // ------------------------------------------------------------------------------------------------ dwp_mlp: forward, loss, input gradients
@@ -994,9 +1035,17 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
              const float *g32, float *p32f, void *stream) {
     if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part) return fail("dwp_adam: bad argument");
-    hipLaunchKernelGGL(k_adam, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
-                       (_Float16 *)p16t, g32, p32f);
+    hipLaunchKernelGGL(k_adam<false>, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
+                       (_Float16 *)p16t, g32, p32f, FinArgs{0, 0, 0, nullptr});
     return done("dwp_adam");
+}
+
+int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t, const float *g32,
+                    float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream) {
+    if (!p || !p16 || !m || !v || !g32 || !gb || !state || !part || !pbuf || B < 1 || num_minibatches < 1 || growth_interval < 1) return fail("dwp_adam_finish: bad argument");
+    hipLaunchKernelGGL(k_adam<true>, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
+                       (_Float16 *)p16t, g32, p32f, FinArgs{B, num_minibatches, growth_interval, pbuf});
+    return done("dwp_adam_finish");
 }
 
 int dwp_wgrad(const uint16_t *xf, const uint16_t *h1f, const uint16_t *h2f, const uint16_t *doutf, const uint16_t *dz2f, const uint16_t *dz1f, const float *state,

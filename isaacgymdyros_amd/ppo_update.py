@@ -31,7 +31,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
+EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "adam_finish", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -60,6 +60,7 @@ def declare(lib: C.CDLL) -> dict:
     api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, P, P)
     api["policy"] = fn("policy", C.c_int, P, P, P, C.c_int32, P, P, P)
     api["retile32"] = fn("retile32", C.c_int, P, P, P)
+    api["adam_finish"] = fn("adam_finish", C.c_int, P, P, P, P, P, P, P, C.c_float, P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
     api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P)
@@ -282,9 +283,8 @@ class FusedPpoUpdate:
             self._chk(api["wgrad"](self.xf.data_ptr(), self.h1f.data_ptr(), self.h2f.data_ptr(), self.doutf.data_ptr(), self.dz2f.data_ptr(), self.dz1f.data_ptr(), st,
                                    self.g32.data_ptr(), B, s))
             self._chk(api["grad_stats"](None, self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), self.g32.data_ptr(), s))
-            self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), None, self.gb.data_ptr(), st,
-                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), self.p32f.data_ptr(), s))
-            self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
+            self._chk(api["adam_finish"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(),
+                                         self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), self.p32f.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
             return
         self._chk(api["stage_obs"](obs.data_ptr(), st, B, self.x16.data_ptr(), s))
         # forward: Linear + relu twice, the two heads (fp16 in, fp32 accumulate, fp16 out: nn.Linear under autocast)
