@@ -219,6 +219,10 @@ def _sync(device):
 
 
 # ------------------------------------------------------------------------------------------------ the loop
+ROLL_CHAIN = int(os.environ.get("DW_PPO_ROLL_CHAIN", "8"))          # rollout steps per replayed graph
+UPD_CHAIN = int(os.environ.get("DW_PPO_CHAIN", "16"))          # fused updates per replayed graph
+
+
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
           rank=0, world=1, seed=42, graph_rollout=False, graph_update=False, fused_update=False):
     """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch.
@@ -249,7 +253,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     net = DyrosActorCritic(env.num_obs, env.num_acts, cfg["network"]).to(device)
     torch.manual_seed(seed + 7919 * rank)            # ... but its own exploration noise (Normal.sample draws from the global generator)
     graph_update = bool(graph_update) and str(device).startswith("cuda") and world == 1
-    fused = None
+    fused, upd_chain = None, None
     if fused_update:
         if not str(device).startswith("cuda") or world != 1:
             raise ValueError("fused_update needs one GPU rank")
@@ -279,7 +283,9 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             a = torch.distributions.Normal(mu, torch.exp(logstd)).sample()
             obs = env.step(torch.clamp(a, -1.0, 1.0))[0]["obs"].clone()
         torch.cuda.synchronize()
-    mb = dict(obs=torch.zeros(H, N, env.num_obs, device=device), act=torch.zeros(H, N, env.num_acts, device=device),
+    # (fused update behind a captured rollout: the observations are recorded straight into the update's env-major flat batch, below)
+    direct_obs = fused is not None and graph_rollout
+    mb = dict(obs=None if direct_obs else torch.zeros(H, N, env.num_obs, device=device), act=torch.zeros(H, N, env.num_acts, device=device),
               neglogp=torch.zeros(H, N, device=device), val=torch.zeros(H, N, 1, device=device), rew=torch.zeros(H, N, 1, device=device),
               done=torch.zeros(H, N, device=device), mu=torch.zeros(H, N, env.num_acts, device=device))
     batch = H * N
@@ -297,7 +303,13 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         recorder = None
         if fused is not None:          # (the step's bookkeeping in two launches instead of ~30: isaacgymdyros_amd/ppo_update.py::RolloutRecorder)
             from isaacgymdyros_amd.ppo_update import RolloutRecorder
-            recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"])
+            # (static homes of the epoch's flat arrays: a captured update replays their addresses)
+            fused.bind_batch(*[torch.empty(batch, *sh, device=device) for sh in ((env.num_obs,), (env.num_acts,), (), (env.num_acts,), (), ())])
+            recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"], obs_env_major=fused.src[0])
+            if env.obs_dict["obs"].data_ptr() == env.obs_buf.data_ptr():
+                # (alias_obs: the env's own buffer is the policy's input -- the recorder has copied it into the batch before env.step
+                #  overwrites it, so the step's 32 MB copy into a second home falls away)
+                g_obs = env.obs_buf
 
         pol = (torch.empty(N, env.num_acts, device=device), torch.empty(N, 1, device=device)) if fused is not None else None
 
@@ -338,8 +350,10 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         g_n.zero_()
+        roll_chain = ROLL_CHAIN if H % ROLL_CHAIN == 0 else 1          # (steps per replayed graph: the step counter and the buffers' row index live on the device)
         with torch.no_grad(), torch.cuda.graph(graph, stream=side):
-            rollout_step()
+            for _ in range(roll_chain):
+                rollout_step()
         obs, dones = g_obs, g_dones
     for ep in range(1, epochs + 1):
         net.update_action_noise((max_epochs - ep) / max_epochs)                 # a2c_common_dyros.py:985
@@ -357,7 +371,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         with torch.no_grad():                                                   # a2c_common_dyros.py:842
             if graph is not None:
                 g_n.zero_(); g_terms.zero_()
-                for n in range(H):
+                for n in range(H // roll_chain):
                     graph.replay()
                 terms = g_terms.clone()
                 step_time = float("nan")                                        # (the env step is not separable inside the graph)
@@ -390,8 +404,9 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         # swap_and_flatten01: env-major flat batch, minibatches are contiguous slices (no shuffling in rl_games' dataset)
         flat = lambda x: x.transpose(0, 1).reshape(batch, *x.shape[2:])        # noqa: E731
         if fused is not None and fused.src is not None:
-            # (the observations go straight into their static home, env-major: one strided copy of 4 GB instead of two)
-            fused.src[0].view(N, H, -1).copy_(mb["obs"].transpose(0, 1))
+            # (the observations are in their static home, env-major, already -- or get there in one strided copy of 4 GB instead of two)
+            if not direct_obs:
+                fused.src[0].view(N, H, -1).copy_(mb["obs"].transpose(0, 1))
             B = {k: (fused.src[0] if k == "obs" else flat(v)) for k, v in mb.items()}
         else:
             B = {k: flat(v) for k, v in mb.items()}
@@ -435,6 +450,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 if d_.data_ptr() != x.data_ptr():
                     d_.copy_(x.reshape(d_.shape))
             fused.rewind()
+            if os.environ.get("DW_PPO_TIMES"):
+                _sync(device); t_prep = time.perf_counter() - t0 - play_time
             n_upd = int(c["mini_epochs"]) * (batch // mbs)
             done_upd = 0
             if upd_graph is None:
@@ -451,7 +468,18 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                     upd_graph = torch.cuda.CUDAGraph()
                     with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
                         fused.update()
-            for _ in range(n_upd - done_upd):
+                    # (the minibatch index lives on the device, so a graph may hold any number of updates: UPD_CHAIN of them back to back
+                    #  have no gap between graph launches inside)
+                    if n_upd >= 2 * UPD_CHAIN:
+                        upd_chain = torch.cuda.CUDAGraph()
+                        with torch.no_grad(), torch.cuda.graph(upd_chain, stream=side_u):
+                            for _ in range(UPD_CHAIN):
+                                fused.update()
+            left = n_upd - done_upd
+            while upd_chain is not None and left >= UPD_CHAIN:
+                upd_chain.replay()
+                left -= UPD_CHAIN
+            for _ in range(left):
                 upd_graph.replay()
             lg = fused.logged()
             a_l, c_l, b_l, cf, kl = lg[0], lg[1], lg[2], lg[3], lg[4]
@@ -494,6 +522,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                  kl=float(kl), lr=lr, sigma=float(net.sigma[0]),
                  reward_terms={(names[i] if i < len(names) else "term%d" % i): float(terms[i] / H) for i in range(terms.numel())},
                  mean_episode_length=float(env.epi_len_log[fin].mean()) if int(fin.sum()) else 0.0)
+        if os.environ.get("DW_PPO_TIMES") and fused is not None:
+            s.update(play_ms=1e3 * play_time, prep_ms=1e3 * t_prep, update_ms=1e3 * (total - play_time - t_prep))
         stats.append(s)
         if rank == 0:
             log("epoch %(epoch)d: fps step %(step_fps).3g  step+inference %(play_fps).3g  total %(total_fps).3g  mean reward %(mean_reward).3f  "

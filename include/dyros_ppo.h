@@ -139,10 +139,13 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
  * form is ~30 small kernels per step).  n: device int64, the step's row of the rollout buffers (the caller advances it).
  * dwp_rollout_pre: a = mu + exp(logstd) * noise (noise: the caller's standard-normal draws [N][ACT]); row n of mb_obs [H][N][num_obs], mb_act, mb_mu
  *   [H][N][ACT], mb_nlp (neglogp of a, models_dyros.py:59-62), mb_val, mb_done [H][N]; act [N][ACT] = clamp(a, -1, 1) for the env.
+ *   env_major_steps = H > 0: mb_obs is [N][H][num_obs] instead -- the env-major flat batch the update reads (swap_and_flatten01,
+ *   a2c_common_dyros.py:1080, done while the rollout runs: no 4 GB transpose per epoch at 16384 envs).
  * dwp_rollout_post: mb_rew[n] = rew * reward_scale (+ gamma * value * time_outs: the bootstrap of :656-659; time_outs NULL = off); terms[c] += mean over
  *   the envs of stacked[.][c], c < num_terms (terms NULL = off); g_dones = float(done_buf); g_obs = new_obs (skipped when they are one buffer). */
 int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
-                    int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, void *stream);
+                    int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, int32_t env_major_steps,
+                    void *stream);
 int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
                      const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
                      float *g_obs, void *stream);

@@ -834,11 +834,22 @@ __global__ __launch_bounds__(256) void k_gae(const float *__restrict__ fdones, c
 // What play_steps does between the policy's forward and the env step, and after it (learning/rl_games_custom/a2c_common_dyros.py:629-703):
 // sample the action, its neglogp, the step's row of every rollout buffer; then the shaped reward with the time-out bootstrap, the logged
 // reward terms, the new dones and observations.  ~30 torch kernels per step otherwise, for a few KB of arithmetic and two 32 MB copies.
-struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs; };
+struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs, env_major_steps; };
 __global__ __launch_bounds__(256) void k_roll_pre(const RollPre A) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)*A.n, N = A.N;
     const size_t nf4 = N * A.nobs / 4;          // (N * nobs is a multiple of 4: checked by the launcher)
-    if (i < nf4) reinterpret_cast<f4 *>(A.mb_obs + n * N * A.nobs)[i] = reinterpret_cast<const f4 *>(A.obs)[i];
+    if (A.env_major_steps) {
+        // mb_obs [N][H][nobs], the flat batch of the update (swap_and_flatten01 done as the rollout goes): four words of one row per thread
+        // (a row of 487 words starts on a 4-byte boundary only)
+        if (i < nf4) {
+            const f4 v = reinterpret_cast<const f4 *>(A.obs)[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t w = 4 * i + q, e = w / (size_t)A.nobs, k = w - e * A.nobs;
+                A.mb_obs[(e * (size_t)A.env_major_steps + n) * A.nobs + k] = v[q];
+            }
+        }
+    } else if (i < nf4) reinterpret_cast<f4 *>(A.mb_obs + n * N * A.nobs)[i] = reinterpret_cast<const f4 *>(A.obs)[i];
     if (i < N * ACT) {
         const int k = (int)(i % ACT);
         const float m_ = A.mu[i], a = m_ + expf(A.logstd[k]) * A.noise[i];          // mu + sigma * randn
@@ -1071,11 +1082,13 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
 }
 
 int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
-                    int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, void *stream) {
-    if (!mu || !value || !noise || !obs || !dones || !logstd || !n || !mb_obs || !mb_act || !mb_mu || !mb_nlp || !mb_val || !mb_done || !act || N < 1 || num_obs < ACT)
+                    int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, int32_t env_major_steps,
+                    void *stream) {
+    if (!mu || !value || !noise || !obs || !dones || !logstd || !n || !mb_obs || !mb_act || !mb_mu || !mb_nlp || !mb_val || !mb_done || !act || N < 1 || num_obs < ACT ||
+        env_major_steps < 0)
         return fail("dwp_rollout_pre: bad argument");
     if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_pre: N * num_obs must be a multiple of 4");
-    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs};
+    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs, env_major_steps};
     hipLaunchKernelGGL(k_roll_pre, dim3((unsigned)(((size_t)N * num_obs / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return done("dwp_rollout_pre");
 }

@@ -63,7 +63,7 @@ def declare(lib: C.CDLL) -> dict:
     api["adam_finish"] = fn("adam_finish", C.c_int, P, P, P, P, P, P, P, C.c_float, P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
-    api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P)
+    api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, C.c_int32, P)
     api["rollout_post"] = fn("rollout_post", C.c_int, P, P, P, P, C.c_int32, P, P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, C.c_int32, P, P, P)
     api["gae"] = fn("gae", C.c_int, P, P, P, P, P, C.c_float, C.c_float, C.c_int32, C.c_int32, P, P)
     api["mlp"] = fn("mlp", C.c_int, C.POINTER(DwpMlp), P)
@@ -93,14 +93,19 @@ class RolloutRecorder:
     """The bookkeeping of one rollout step around env.step in two launches (dwp_rollout_pre / _post): `mb` is the consumer's dict of rollout
     buffers (obs [H, N, num_obs], act, mu [H, N, 13], neglogp, done [H, N], val, rew [H, N, 1]), n a device int64 [1] the caller advances."""
 
-    def __init__(self, mb: dict, n: torch.Tensor, logstd: torch.Tensor, reward_scale: float, gamma: float, bootstrap: bool):
+    def __init__(self, mb: dict, n: torch.Tensor, logstd: torch.Tensor, reward_scale: float, gamma: float, bootstrap: bool, obs_env_major=None):
+        """obs_env_major: a [N * H, num_obs] (or [N, H, num_obs]) tensor that takes the observations instead of mb["obs"], env-major: the flat batch of
+        the update, written as the rollout goes (mb["obs"] is then not touched and may be absent)."""
         self.api = declare(_lib.load()[0])
         self.mb, self.n, self.logstd = mb, n, logstd
         self.scale, self.gamma, self.bootstrap = float(reward_scale), float(gamma), bool(bootstrap)
-        self.H, self.N, self.nobs = (int(x) for x in mb["obs"].shape)
-        for k in ("obs", "act", "mu", "neglogp", "val", "rew", "done"):
+        self.H, self.N = (int(x) for x in mb["act"].shape[:2])
+        self.obs_dst, self.env_major = (obs_env_major, self.H) if obs_env_major is not None else (mb["obs"], 0)
+        self.nobs = int(self.obs_dst.shape[-1])
+        assert self.obs_dst.numel() == self.H * self.N * self.nobs and self.obs_dst.is_contiguous() and self.obs_dst.dtype == torch.float32 and self.obs_dst.is_cuda
+        for k in ("act", "mu", "neglogp", "val", "rew", "done"):
             assert mb[k].is_contiguous() and mb[k].dtype == torch.float32 and mb[k].is_cuda, k
-        self.act = torch.empty(self.N, ACT, device=mb["obs"].device)
+        self.act = torch.empty(self.N, ACT, device=mb["act"].device)
 
     def _chk(self, rc):
         if rc != 0:
@@ -110,8 +115,8 @@ class RolloutRecorder:
         """Returns the clipped action for env.step."""
         mb, s = self.mb, torch.cuda.current_stream(obs.device).cuda_stream
         self._chk(self.api["rollout_pre"](mu.data_ptr(), value.data_ptr(), noise.data_ptr(), obs.data_ptr(), dones.data_ptr(), self.logstd.data_ptr(), self.n.data_ptr(),
-                                          self.N, self.nobs, mb["obs"].data_ptr(), mb["act"].data_ptr(), mb["mu"].data_ptr(), mb["neglogp"].data_ptr(),
-                                          mb["val"].data_ptr(), mb["done"].data_ptr(), self.act.data_ptr(), s))
+                                          self.N, self.nobs, self.obs_dst.data_ptr(), mb["act"].data_ptr(), mb["mu"].data_ptr(), mb["neglogp"].data_ptr(),
+                                          mb["val"].data_ptr(), mb["done"].data_ptr(), self.act.data_ptr(), self.env_major, s))
         return self.act
 
     def post(self, rew, value, time_outs, stacked, done_buf, new_obs, terms, g_dones, g_obs):

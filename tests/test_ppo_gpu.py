@@ -326,8 +326,10 @@ def test_gae_kernel_equals_the_reference_loop():
 
 
 @pytest.mark.gpu
-def test_rollout_recorder_equals_the_torch_bookkeeping():
-    """dwp_rollout_pre / _post against the torch lines of examples/ppo_consumer.py::rollout_step (a2c_common_dyros.py:629-703) on the same draws."""
+@pytest.mark.parametrize("env_major", [False, True], ids=["step_major", "env_major_obs"])
+def test_rollout_recorder_equals_the_torch_bookkeeping(env_major):
+    """dwp_rollout_pre / _post against the torch lines of examples/ppo_consumer.py::rollout_step (a2c_common_dyros.py:629-703) on the same draws;
+    env_major: the observations recorded straight into the env-major flat batch (swap_and_flatten01 of :1080 as the rollout goes)."""
     from isaacgymdyros_amd.ppo_update import RolloutRecorder, ACT
     ppo = _ppo()
     dev = "cuda:0"
@@ -338,7 +340,10 @@ def test_rollout_recorder_equals_the_torch_bookkeeping():
     ref = {k: v.clone() for k, v in mb.items()}
     n = torch.zeros(1, dtype=torch.long, device=dev)
     logstd = torch.full((ACT,), -2.3, device=dev) + 0.1 * torch.randn(ACT, generator=g, device=dev)
-    rec = RolloutRecorder(mb, n, logstd, 0.5, 0.99, True)
+    flat_obs = torch.zeros(N * H, NOBS, device=dev) if env_major else None
+    if env_major:
+        mb["obs"] = None
+    rec = RolloutRecorder(mb, n, logstd, 0.5, 0.99, True, obs_env_major=flat_obs)
     terms, terms_ref = torch.zeros(15, device=dev), torch.zeros(15, device=dev)
     g_dones, g_obs = torch.zeros(N, device=dev), torch.randn(N, NOBS, generator=g, device=dev)
     for step in range(H):
@@ -359,7 +364,9 @@ def test_rollout_recorder_equals_the_torch_bookkeeping():
         torch.cuda.synchronize()
         assert torch.equal(g_dones, d.float()) and torch.equal(g_obs, new_obs)
         n += 1
-    for k in ("obs", "mu", "val", "done"):
+    if env_major:
+        assert torch.equal(flat_obs, ref["obs"].transpose(0, 1).reshape(N * H, NOBS))
+    for k in ("mu", "val", "done") if env_major else ("obs", "mu", "val", "done"):
         assert torch.equal(mb[k], ref[k]), k
     assert float((mb["act"] - ref["act"]).abs().max()) <= 5e-7
     assert float((mb["neglogp"] - ref["neglogp"]).abs().max()) <= 2e-5 * float(ref["neglogp"].abs().max())
