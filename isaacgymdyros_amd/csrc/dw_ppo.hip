@@ -229,7 +229,37 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
     const float inv = 1.0f / state[DWP_S_SCALE];
     float sq = 0.0f;
     int bad0 = 0, bad1 = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < NP; i += GS_BLOCKS * 256) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (g32) {
+        // weights: 16-byte pieces of dwp_wgrad's slabs, a thread's pieces all requested before the first is used (the kernel is one memory
+        // latency long, not one per piece: 6.5 -> 4 us)
+        constexpr int NQ = NWT / 4, PER = (NQ + GS_BLOCKS * 256 - 1) / (GS_BLOCKS * 256);
+        static_assert(NWT % 4 == 0 && NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0, "a piece of four never crosses a net or a tensor");
+        f4 a[PER][WG_SLABS];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = t + u * GS_BLOCKS * 256, qc = q < NQ ? q : 0;
+#pragma unroll
+            for (int k = 0; k < WG_SLABS; ++k) a[u][k] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT)[qc];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = t + u * GS_BLOCKS * 256;
+            if (q < NQ) {
+                f4 s4 = a[u][0];
+#pragma unroll
+                for (int k = 1; k < WG_SLABS; ++k) s4 += a[u][k];          // (the same order as scaled_grad / dwp_adam: the sums are the same numbers)
+                const int net = net_of(4 * q);
+                float s2 = 0.0f;
+                int bad = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float g = s4[c]; bad |= !isfinite(g); const float w = g * inv; s2 += w * w; }
+                if (net == 0) sq += s2;
+                if (bad) { if (net) bad1 = 1; else bad0 = 1; }
+            }
+        }
+    }
+    for (int i = g32 ? NWT + t : t; i < NP; i += GS_BLOCKS * 256) {
         const int net = net_of(i);
         float g;
         if (i >= NWT && pbuf) {
@@ -318,19 +348,44 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     __shared__ float red[4];
     __shared__ int redf[4];
     static_assert(GS_BLOCKS == 256, "one partial per thread");
+    // this thread's parameters, moments and gradients are requested first, the partial sums behind them: one memory latency for both
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8, ic = i0 < NP ? i0 : 0;
+    f4 pv[2] = {reinterpret_cast<const f4 *>(p + ic)[0], reinterpret_cast<const f4 *>(p + ic)[1]};
+    f4 mv[2] = {reinterpret_cast<const f4 *>(m + ic)[0], reinterpret_cast<const f4 *>(m + ic)[1]};
+    f4 vv[2] = {reinterpret_cast<const f4 *>(v + ic)[0], reinterpret_cast<const f4 *>(v + ic)[1]};
+    float gs[8];
+    if (ic >= NWT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = gb[ic - NWT + q];
+    } else if (g32) {
+        f4 a[WG_SLABS][2];
+#pragma unroll
+        for (int k = 0; k < WG_SLABS; ++k) { a[k][0] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[0]; a[k][1] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[1]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WG_SLABS; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { gs[q] += a[k][0][q]; gs[4 + q] += a[k][1][q]; }
+        }
+    } else {
+        const h8 gh = *reinterpret_cast<const h8 *>(g16 + ic);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = (float)gh[q];
+    }
+    const float my_part = part[threadIdx.x];
+    const int fl = FIN ? (int)part[PART_FLAGS + threadIdx.x] : 0;
     {   // the actor's gradient norm from dwp_grad_stats' partial sums (every block adds them up the same way; block 0 publishes it)
-        const float s = wave_sum(part[threadIdx.x]);
+        const float s = wave_sum(my_part);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         if (FIN) {
-            const int fl = (int)part[PART_FLAGS + threadIdx.x];
             const unsigned long long w0 = __ballot(fl & 1), w1 = __ballot(fl & 2);
             if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = (w0 ? 1 : 0) | (w1 ? 2 : 0);
         }
         __syncthreads();
     }
     const float norm2 = red[0] + red[1] + red[2] + red[3];
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-    const int net = net_of(i0 < NP ? i0 : 0);
+    const int net = net_of(ic);
     bool skip;
     float scale, step, lr;
     if (FIN) {
@@ -350,27 +405,6 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     const float coef = net == 0 ? fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f) : 1.0f;          // torch.nn.utils.clip_grad_norm_ (the actor only)
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const float bc1 = 1.0f - powf(b1, step), sq2 = sqrtf(1.0f - powf(b2, step)), ss = lr / bc1;
-    f4 pv[2] = {reinterpret_cast<const f4 *>(p + i0)[0], reinterpret_cast<const f4 *>(p + i0)[1]};
-    f4 mv[2] = {reinterpret_cast<const f4 *>(m + i0)[0], reinterpret_cast<const f4 *>(m + i0)[1]};
-    f4 vv[2] = {reinterpret_cast<const f4 *>(v + i0)[0], reinterpret_cast<const f4 *>(v + i0)[1]};
-    float gs[8];
-    if (i0 >= NWT) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gs[q] = gb[i0 - NWT + q];
-    } else if (g32) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gs[q] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < WG_SLABS; ++k) {
-            const f4 a = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + i0)[0], c = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + i0)[1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { gs[q] += a[q]; gs[4 + q] += c[q]; }
-        }
-    } else {
-        const h8 gh = *reinterpret_cast<const h8 *>(g16 + i0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gs[q] = (float)gh[q];
-    }
     h8 ph;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
