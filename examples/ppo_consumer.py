@@ -304,8 +304,11 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         if fused is not None:          # (the step's bookkeeping in two launches instead of ~30: isaacgymdyros_amd/ppo_update.py::RolloutRecorder)
             from isaacgymdyros_amd.ppo_update import RolloutRecorder
             # (static homes of the epoch's flat arrays: a captured update replays their addresses)
-            fused.bind_batch(*[torch.empty(batch, *sh, device=device) for sh in ((env.num_obs,), (env.num_acts,), (), (env.num_acts,), (), ())])
-            recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"], obs_env_major=fused.src[0])
+            # (the observations as fp16 rows of 512: what the update's first layer reads -- the cast is done once, by the recorder)
+            from isaacgymdyros_amd.ppo_update import INP as _INP
+            fused.bind_batch(torch.zeros(batch, _INP, device=device, dtype=torch.float16),
+                             *[torch.empty(batch, *sh, device=device) for sh in ((env.num_acts,), (), (env.num_acts,), (), ())])
+            recorder = RolloutRecorder(mb, g_n, net.sigma, c["reward_scale"], c["gamma"], c["value_bootstrap"], obs_env_major=fused.src[0], num_obs=env.num_obs)
             if env.obs_dict["obs"].data_ptr() == env.obs_buf.data_ptr():
                 # (alias_obs: the env's own buffer is the policy's input -- the recorder has copied it into the batch before env.step
                 #  overwrites it, so the step's 32 MB copy into a second home falls away)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 5
+#define DWP_ABI_VERSION 6
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -140,12 +140,14 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
  * dwp_rollout_pre: a = mu + exp(logstd) * noise (noise: the caller's standard-normal draws [N][ACT]); row n of mb_obs [H][N][num_obs], mb_act, mb_mu
  *   [H][N][ACT], mb_nlp (neglogp of a, models_dyros.py:59-62), mb_val, mb_done [H][N]; act [N][ACT] = clamp(a, -1, 1) for the env.
  *   env_major_steps = H > 0: mb_obs is [N][H][num_obs] instead -- the env-major flat batch the update reads (swap_and_flatten01,
- *   a2c_common_dyros.py:1080, done while the rollout runs: no 4 GB transpose per epoch at 16384 envs).
+ *   a2c_common_dyros.py:1080, done while the rollout runs: no 4 GB transpose per epoch at 16384 envs).  obs_half != 0 (with env_major_steps):
+ *   mb_obs points to HALVES [N][H][DWP_INP], zero-initialised by the caller once: the observations as the update's first layer takes them
+ *   (autocast's cast of the Linear input), for DwpMlp.obs16.
  * dwp_rollout_post: mb_rew[n] = rew * reward_scale (+ gamma * value * time_outs: the bootstrap of :656-659; time_outs NULL = off); terms[c] += mean over
  *   the envs of stacked[.][c], c < num_terms (terms NULL = off); g_dones = float(done_buf); g_obs = new_obs (skipped when they are one buffer). */
 int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
                     int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, int32_t env_major_steps,
-                    void *stream);
+                    int32_t obs_half, void *stream);
 int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
                      const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
                      float *g_obs, void *stream);
@@ -161,6 +163,7 @@ int dwp_retile(const uint16_t *p16, uint16_t *p16f, void *stream);
 
 typedef struct DwpMlp {
     const float *obs, *state, *act, *old_nlp, *old_mu, *adv, *ret, *logstd;
+    const uint16_t *obs16;               /* used when obs is NULL: the batch's observations as fp16 rows [batch][DWP_INP], columns 487.. zero */
     const uint16_t *p16, *p16t;          /* p16t: the fragment-order copy (p16f of dwp_adam / dwp_retile) */
     float *pbuf;
     uint16_t *x16, *h1, *h2, *out16, *dout16, *dz2, *dz1;
@@ -169,6 +172,7 @@ typedef struct DwpMlp {
     float e_clip, critic_coef;
 } DwpMlp;
 int dwp_mlp(const DwpMlp *a, void *stream);
+int dwp_sizeof_mlp(void);          /* sizeof(DwpMlp) as the library was built: a binding checks its own mirror of the struct against it */
 
 /* the three weight gradients of both nets from dwp_mlp's operand-order copies, on the matrix cores: g32 [DWP_WGRAD_SLABS][weights], fp32, the
  * parameter layout's weight part once per slab of samples -- every word is written by exactly one wave (no atomics, nothing to clear); the

@@ -593,6 +593,7 @@ __device__ __forceinline__ void masked_out(const f4 (&acc)[MR][NTW], const _Floa
 // into gb and clears them, dwp_finish does the same for the logged sums.
 struct MlpArgs {
     const float *obs, *state, *act, *old_nlp, *old_mu, *adv, *ret, *logstd;
+    const _Float16 *obs16;          // (or null) the batch's observations as fp16 rows of INP (zero padding), instead of obs
     const _Float16 *p16, *p16t;
     float *pbuf;
     _Float16 *x16, *h1, *h2, *out16, *dout16, *dz2, *dz1;
@@ -623,7 +624,19 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     h8 ring[4][NTW];
     ring_fill<INP, NTL, NTW, 4>(W1, nt0, ring, lane);
     // ---- the input rows: fp32 observations -> fp16, zero padding (autocast's cast of the Linear input) ----
-    {
+    if (A.obs16) {
+        // the batch holds them as fp16 rows already (dwp_rollout_pre wrote them so): 16-byte pieces, eight per thread
+        static_assert(MT * INP / 8 == 8 * 64 * WPB, "eight pieces per thread");
+        const h8 *src = reinterpret_cast<const h8 *>(A.obs16 + ((size_t)mb * B + r0) * INP);
+        h8 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[tid + 256 * u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int pc = tid + 256 * u, r = pc >> 6, c = pc & 63; *reinterpret_cast<h8 *>(&Xs[r * XS + 8 * c]) = v[u]; }
+        __syncthreads();
+        if (net == 0) { if (A.x16) rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid); if (A.xf) frags_out<INP, XS>(Xs, A.xf + (size_t)blockIdx.x * INP * 32, tid); }
+    } else {
         const float *src = A.obs + ((size_t)mb * B + r0) * IN;
         // thread t takes columns t and t + 256 of every row (consecutive threads: consecutive floats of a row; no index arithmetic per word):
         // all of a thread's requests go out before it converts the first word -- one memory latency for the block
@@ -868,11 +881,24 @@ __global__ __launch_bounds__(256) void k_gae(const float *__restrict__ fdones, c
 // What play_steps does between the policy's forward and the env step, and after it (learning/rl_games_custom/a2c_common_dyros.py:629-703):
 // sample the action, its neglogp, the step's row of every rollout buffer; then the shaped reward with the time-out bootstrap, the logged
 // reward terms, the new dones and observations.  ~30 torch kernels per step otherwise, for a few KB of arithmetic and two 32 MB copies.
-struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs, env_major_steps; };
+struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs, env_major_steps, obs_half; };
 __global__ __launch_bounds__(256) void k_roll_pre(const RollPre A) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)*A.n, N = A.N;
     const size_t nf4 = N * A.nobs / 4;          // (N * nobs is a multiple of 4: checked by the launcher)
-    if (A.env_major_steps) {
+    if (A.obs_half) {
+        // mb_obs: halves [N][H][INP] -- what the update's first layer reads (autocast's cast of the Linear input, done here once instead of in
+        // every one of the five passes over the batch); a thread = eight consecutive words of a row -> one 16-byte piece (the row's last
+        // piece ends in the zero padding, which nobody else writes)
+        const size_t ppr = (size_t)(A.nobs + 7) / 8;          // pieces per row
+        if (i < N * ppr) {
+            const size_t e = i / ppr, c = i - e * ppr;
+            const float *src = A.obs + e * A.nobs + 8 * c;
+            h8 v;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = 8 * c + q < (size_t)A.nobs ? (_Float16)src[q] : (_Float16)0.0f;
+            *reinterpret_cast<h8 *>(reinterpret_cast<_Float16 *>(A.mb_obs) + (e * (size_t)A.env_major_steps + n) * INP + 8 * c) = v;
+        }
+    } else if (A.env_major_steps) {
         // mb_obs [N][H][nobs], the flat batch of the update (swap_and_flatten01 done as the rollout goes): four words of one row per thread
         // (a row of 487 words starts on a 4-byte boundary only)
         if (i < nf4) {
@@ -1117,12 +1143,12 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
 
 int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
                     int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, int32_t env_major_steps,
-                    void *stream) {
+                    int32_t obs_half, void *stream) {
     if (!mu || !value || !noise || !obs || !dones || !logstd || !n || !mb_obs || !mb_act || !mb_mu || !mb_nlp || !mb_val || !mb_done || !act || N < 1 || num_obs < ACT ||
-        env_major_steps < 0)
+        env_major_steps < 0 || (obs_half && (env_major_steps < 1 || num_obs > INP)))
         return fail("dwp_rollout_pre: bad argument");
     if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_pre: N * num_obs must be a multiple of 4");
-    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs, env_major_steps};
+    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs, env_major_steps, obs_half};
     hipLaunchKernelGGL(k_roll_pre, dim3((unsigned)(((size_t)N * num_obs / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return done("dwp_rollout_pre");
 }
@@ -1157,14 +1183,16 @@ int dwp_policy(const float *obs, const float *p, const float *p32f, int32_t N, f
     return done("dwp_policy");
 }
 
+int dwp_sizeof_mlp(void) { return (int)sizeof(DwpMlp); }
+
 int dwp_mlp(const DwpMlp *a, void *stream) {
     if (!a) return fail("dwp_mlp: null argument");
-    const void *need[] = {a->obs, a->state, a->act, a->old_nlp, a->old_mu, a->adv, a->ret, a->logstd, a->p16, a->p16t, a->pbuf, a->out16, a->dout16};
+    const void *need[] = {a->obs ? (const void *)a->obs : (const void *)a->obs16, a->state, a->act, a->old_nlp, a->old_mu, a->adv, a->ret, a->logstd, a->p16, a->p16t, a->pbuf, a->out16, a->dout16};
     if (!a->xf && !a->x16) return fail("dwp_mlp: neither row-major nor operand-order outputs");
     for (const void *q : need) if (!q) return fail("dwp_mlp: null pointer in the argument block");
     if (a->B < MT || a->B % MT) return fail("dwp_mlp: the minibatch must be a multiple of 32 samples");
     MlpArgs A;
-    A.obs = a->obs; A.state = a->state; A.act = a->act; A.old_nlp = a->old_nlp; A.old_mu = a->old_mu; A.adv = a->adv; A.ret = a->ret; A.logstd = a->logstd;
+    A.obs = a->obs; A.obs16 = a->obs ? nullptr : (const _Float16 *)a->obs16; A.state = a->state; A.act = a->act; A.old_nlp = a->old_nlp; A.old_mu = a->old_mu; A.adv = a->adv; A.ret = a->ret; A.logstd = a->logstd;
     A.p16 = (const _Float16 *)a->p16; A.p16t = (const _Float16 *)a->p16t; A.pbuf = a->pbuf;
     A.x16 = (_Float16 *)a->x16; A.h1 = (_Float16 *)a->h1; A.h2 = (_Float16 *)a->h2; A.out16 = (_Float16 *)a->out16; A.dout16 = (_Float16 *)a->dout16;
     A.dz2 = (_Float16 *)a->dz2; A.dz1 = (_Float16 *)a->dz1; A.B = a->B;

@@ -31,7 +31,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "adam_finish", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
+EXPORTS = ["abi_version", "last_error", "sizeof_mlp", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "adam", "adam_finish", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -40,7 +40,7 @@ NP = NWT + NB1 + NB2 + NB3
 
 
 class DwpMlp(C.Structure):          # include/dyros_ppo.h
-    _fields_ = [(n, C.c_void_p) for n in ("obs", "state", "act", "old_nlp", "old_mu", "adv", "ret", "logstd", "p16", "p16t", "pbuf",
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "state", "act", "old_nlp", "old_mu", "adv", "ret", "logstd", "obs16", "p16", "p16t", "pbuf",
                                           "x16", "h1", "h2", "out16", "dout16", "dz2", "dz1", "xf", "h1f", "h2f", "doutf", "dz2f", "dz1f")] + [("B", C.c_int32), ("e_clip", C.c_float), ("critic_coef", C.c_float)]
 
 
@@ -52,6 +52,9 @@ def declare(lib: C.CDLL) -> dict:
         f.restype, f.argtypes = restype, list(argtypes)
         return f
     api = {"abi_version": fn("abi_version", C.c_int), "last_error": fn("last_error", C.c_char_p)}
+    if fn("sizeof_mlp", C.c_int)() != C.sizeof(DwpMlp) or api["abi_version"]() != K["DWP_ABI_VERSION"]:
+        raise RuntimeError("libdyroswalk_hip.so and isaacgymdyros_amd/ppo_update.py disagree about include/dyros_ppo.h (DwpMlp is %d bytes here, ABI %d): rebuild"
+                           % (C.sizeof(DwpMlp), K["DWP_ABI_VERSION"]))
     api["stage_obs"] = fn("stage_obs", C.c_int, P, P, C.c_int32, P, P)
     api["bias_relu"] = fn("bias_relu", C.c_int, P, P, C.c_int32, P)
     api["loss"] = fn("loss", C.c_int, P, P, P, P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P)
@@ -63,7 +66,7 @@ def declare(lib: C.CDLL) -> dict:
     api["adam_finish"] = fn("adam_finish", C.c_int, P, P, P, P, P, P, P, C.c_float, P, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
-    api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, C.c_int32, P)
+    api["rollout_pre"] = fn("rollout_pre", C.c_int, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P, P, P, C.c_int32, C.c_int32, P)
     api["rollout_post"] = fn("rollout_post", C.c_int, P, P, P, P, C.c_int32, P, P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, C.c_int32, P, P, P)
     api["gae"] = fn("gae", C.c_int, P, P, P, P, P, C.c_float, C.c_float, C.c_int32, C.c_int32, P, P)
     api["mlp"] = fn("mlp", C.c_int, C.POINTER(DwpMlp), P)
@@ -93,16 +96,22 @@ class RolloutRecorder:
     """The bookkeeping of one rollout step around env.step in two launches (dwp_rollout_pre / _post): `mb` is the consumer's dict of rollout
     buffers (obs [H, N, num_obs], act, mu [H, N, 13], neglogp, done [H, N], val, rew [H, N, 1]), n a device int64 [1] the caller advances."""
 
-    def __init__(self, mb: dict, n: torch.Tensor, logstd: torch.Tensor, reward_scale: float, gamma: float, bootstrap: bool, obs_env_major=None):
+    def __init__(self, mb: dict, n: torch.Tensor, logstd: torch.Tensor, reward_scale: float, gamma: float, bootstrap: bool, obs_env_major=None, num_obs=None):
         """obs_env_major: a [N * H, num_obs] (or [N, H, num_obs]) tensor that takes the observations instead of mb["obs"], env-major: the flat batch of
-        the update, written as the rollout goes (mb["obs"] is then not touched and may be absent)."""
+        the update, written as the rollout goes (mb["obs"] is then not touched and may be absent).  A float16 [N * H, 512] tensor (zeros) takes them as
+        fp16 rows, the form the update's first layer reads (num_obs = the row length of the env's observations must be given then)."""
         self.api = declare(_lib.load()[0])
         self.mb, self.n, self.logstd = mb, n, logstd
         self.scale, self.gamma, self.bootstrap = float(reward_scale), float(gamma), bool(bootstrap)
         self.H, self.N = (int(x) for x in mb["act"].shape[:2])
         self.obs_dst, self.env_major = (obs_env_major, self.H) if obs_env_major is not None else (mb["obs"], 0)
-        self.nobs = int(self.obs_dst.shape[-1])
-        assert self.obs_dst.numel() == self.H * self.N * self.nobs and self.obs_dst.is_contiguous() and self.obs_dst.dtype == torch.float32 and self.obs_dst.is_cuda
+        self.half = self.obs_dst.dtype == torch.float16          # (fp16 rows of INP: the update's own input format, FusedPpoUpdate.bind_batch)
+        self.nobs = int(num_obs if num_obs is not None else self.obs_dst.shape[-1])
+        assert self.obs_dst.is_contiguous() and self.obs_dst.is_cuda
+        if self.half:
+            assert self.env_major and num_obs is not None and self.obs_dst.numel() == self.H * self.N * INP
+        else:
+            assert self.obs_dst.numel() == self.H * self.N * self.nobs and self.obs_dst.dtype == torch.float32
         for k in ("act", "mu", "neglogp", "val", "rew", "done"):
             assert mb[k].is_contiguous() and mb[k].dtype == torch.float32 and mb[k].is_cuda, k
         self.act = torch.empty(self.N, ACT, device=mb["act"].device)
@@ -116,7 +125,7 @@ class RolloutRecorder:
         mb, s = self.mb, torch.cuda.current_stream(obs.device).cuda_stream
         self._chk(self.api["rollout_pre"](mu.data_ptr(), value.data_ptr(), noise.data_ptr(), obs.data_ptr(), dones.data_ptr(), self.logstd.data_ptr(), self.n.data_ptr(),
                                           self.N, self.nobs, self.obs_dst.data_ptr(), mb["act"].data_ptr(), mb["mu"].data_ptr(), mb["neglogp"].data_ptr(),
-                                          mb["val"].data_ptr(), mb["done"].data_ptr(), self.act.data_ptr(), self.env_major, s))
+                                          mb["val"].data_ptr(), mb["done"].data_ptr(), self.act.data_ptr(), self.env_major, int(self.half), s))
         return self.act
 
     def post(self, rew, value, time_outs, stacked, done_buf, new_obs, terms, g_dones, g_obs):
@@ -260,8 +269,11 @@ class FusedPpoUpdate:
         self._mlp_args = None
         """The epoch's flat arrays (env-major, `batch` rows; fp32, contiguous).  Their ADDRESSES are what a captured update replays:
         keep the tensors and copy_ each epoch's data into them."""
-        for t in (obs, act, neglogp, mu, adv, ret):
+        for t in (act, neglogp, mu, adv, ret):
             assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == self.B * self.nmb
+        # obs: fp32 [batch, 487], or (dwp_mlp form only) fp16 [batch, 512] with zero padding -- what RolloutRecorder(obs_env_major=...) fills
+        assert obs.is_contiguous() and obs.shape[0] == self.B * self.nmb
+        assert (obs.dtype == torch.float32 and obs.shape[1] == IN) or (self.mfma and obs.dtype == torch.float16 and obs.shape[1] == INP)
         self.src = (obs, act, neglogp, mu, adv, ret)
 
     def rewind(self):
@@ -277,7 +289,7 @@ class FusedPpoUpdate:
         if self.mfma:
             if self._mlp_args is None:
                 a = DwpMlp()
-                for k_, t_ in (("obs", obs), ("state", self.state), ("act", act), ("old_nlp", nlp), ("old_mu", mu_old), ("adv", adv), ("ret", ret), ("logstd", self.logstd),
+                for k_, t_ in (("obs16" if obs.dtype == torch.float16 else "obs", obs), ("state", self.state), ("act", act), ("old_nlp", nlp), ("old_mu", mu_old), ("adv", adv), ("ret", ret), ("logstd", self.logstd),
                                ("p16", self.p16), ("p16t", self.p16t), ("pbuf", self.pbuf), ("x16", self.x16), ("h1", self.h1), ("h2", self.h2),
                                ("out16", self.out), ("dout16", self.dout), ("dz2", self.dh2), ("dz1", self.dh1), ("xf", self.xf), ("h1f", self.h1f), ("h2f", self.h2f),
                                ("doutf", self.doutf), ("dz2f", self.dz2f), ("dz1f", self.dz1f)):

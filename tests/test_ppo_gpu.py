@@ -326,7 +326,7 @@ def test_gae_kernel_equals_the_reference_loop():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_major", [False, True], ids=["step_major", "env_major_obs"])
+@pytest.mark.parametrize("env_major", [False, True, "half"], ids=["step_major", "env_major_obs", "env_major_fp16_obs"])
 def test_rollout_recorder_equals_the_torch_bookkeeping(env_major):
     """dwp_rollout_pre / _post against the torch lines of examples/ppo_consumer.py::rollout_step (a2c_common_dyros.py:629-703) on the same draws;
     env_major: the observations recorded straight into the env-major flat batch (swap_and_flatten01 of :1080 as the rollout goes)."""
@@ -340,10 +340,10 @@ def test_rollout_recorder_equals_the_torch_bookkeeping(env_major):
     ref = {k: v.clone() for k, v in mb.items()}
     n = torch.zeros(1, dtype=torch.long, device=dev)
     logstd = torch.full((ACT,), -2.3, device=dev) + 0.1 * torch.randn(ACT, generator=g, device=dev)
-    flat_obs = torch.zeros(N * H, NOBS, device=dev) if env_major else None
+    flat_obs = (torch.zeros(N * H, 512, device=dev, dtype=torch.float16) if env_major == "half" else torch.zeros(N * H, NOBS, device=dev)) if env_major else None
     if env_major:
         mb["obs"] = None
-    rec = RolloutRecorder(mb, n, logstd, 0.5, 0.99, True, obs_env_major=flat_obs)
+    rec = RolloutRecorder(mb, n, logstd, 0.5, 0.99, True, obs_env_major=flat_obs, num_obs=NOBS)
     terms, terms_ref = torch.zeros(15, device=dev), torch.zeros(15, device=dev)
     g_dones, g_obs = torch.zeros(N, device=dev), torch.randn(N, NOBS, generator=g, device=dev)
     for step in range(H):
@@ -364,7 +364,9 @@ def test_rollout_recorder_equals_the_torch_bookkeeping(env_major):
         torch.cuda.synchronize()
         assert torch.equal(g_dones, d.float()) and torch.equal(g_obs, new_obs)
         n += 1
-    if env_major:
+    if env_major == "half":          # (fp16 rows of 512: the cast autocast gives the first Linear's input, zero padding)
+        assert torch.equal(flat_obs[:, :NOBS], ref["obs"].transpose(0, 1).reshape(N * H, NOBS).half()) and float(flat_obs[:, NOBS:].abs().max()) == 0.0
+    elif env_major:
         assert torch.equal(flat_obs, ref["obs"].transpose(0, 1).reshape(N * H, NOBS))
     for k in ("mu", "val", "done") if env_major else ("obs", "mu", "val", "done"):
         assert torch.equal(mb[k], ref[k]), k
@@ -372,6 +374,34 @@ def test_rollout_recorder_equals_the_torch_bookkeeping(env_major):
     assert float((mb["neglogp"] - ref["neglogp"]).abs().max()) <= 2e-5 * float(ref["neglogp"].abs().max())
     assert float((mb["rew"] - ref["rew"]).abs().max()) <= 1e-6 * float(ref["rew"].abs().max()) + 1e-7
     assert float((terms - terms_ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_fp16_observation_batch_gives_the_same_update():
+    """bind_batch with the observations as fp16 rows of 512 (what RolloutRecorder writes for the trainer) against the fp32 batch: the staged
+    input, every activation, the output gradient and the weight-gradient partials are the same bits."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 2048, 2
+    obs, act, nlp_old, mu_old, adv, ret = _batch(ppo, copy.deepcopy(net), U, B * nmb, dev)
+    obs16 = torch.zeros(B * nmb, U.INP, device=dev, dtype=torch.float16)
+    obs16[:, :U.IN] = obs.half()
+    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev)
+    fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev)
+    fa.bind_batch(obs, act, nlp_old, mu_old, adv, ret)
+    fb.bind_batch(obs16, act, nlp_old, mu_old, adv, ret)
+    for _ in range(nmb):
+        fa.update(); fb.update()
+        torch.cuda.synchronize()
+        for name in ("x16", "h1", "h2", "out", "dout", "dh2", "dh1", "g32"):
+            assert torch.equal(getattr(fa, name), getattr(fb, name)), name
+    with pytest.raises(AssertionError):
+        U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, mfma=False).bind_batch(obs16, act, nlp_old, mu_old, adv, ret)          # (the library-GEMM form stages fp32)
 
 
 @pytest.mark.gpu
