@@ -841,7 +841,10 @@ struct WgradArgs { const _Float16 *xf, *h1f, *h2f, *doutf, *dz2f, *dz1f; const f
 // of 1 x 4 tiles (16 x 256)
 constexpr int WG_T1 = 32, WG_T2 = 16, WG_T3 = 4, WG_TASKS = WG_T1 + WG_T2 + WG_T3;
 __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs A) {
-    const int lane = threadIdx.x, task = blockIdx.x, net = blockIdx.y, slab = blockIdx.z;
+    // blocks b and b + 8 land on one XCD (round-robin placement: for speed only): block b works on (net, slab) = b % 8, so that an XCD's waves
+    // all read ONE net's fragments of ONE slab of samples -- 3 MB, which its 4 MB L2 then serves -- instead of every XCD pulling all 16 MB
+    static_assert(2 * WG_SLABS == 8, "one (net, slab) pair per XCD");
+    const int lane = threadIdx.x, task = blockIdx.x >> 3, net = blockIdx.x & 1, slab = (blockIdx.x >> 1) & (WG_SLABS - 1);
     const int per = (A.nkb + WG_SLABS - 1) / WG_SLABS, kb0 = slab * per < A.nkb ? slab * per : A.nkb, kb1 = kb0 + per < A.nkb ? kb0 + per : A.nkb;
     float *G = A.g32 + (size_t)slab * NWT;          // (a slab without samples -- tiny minibatches -- stores zeros)
     const size_t nb = (size_t)net * A.nkb;          // (net's first block in the per-net operand buffers)
@@ -1123,7 +1126,7 @@ int dwp_wgrad(const uint16_t *xf, const uint16_t *h1f, const uint16_t *h2f, cons
               float *g32, int32_t B, void *stream) {
     if (!xf || !h1f || !h2f || !doutf || !dz2f || !dz1f || !state || !g32 || B < 32 || B % 32) return fail("dwp_wgrad: bad argument");
     WgradArgs A{(const _Float16 *)xf, (const _Float16 *)h1f, (const _Float16 *)h2f, (const _Float16 *)doutf, (const _Float16 *)dz2f, (const _Float16 *)dz1f, state, g32, B / 32};
-    hipLaunchKernelGGL(k_wgrad, dim3(WG_TASKS, 2, WG_SLABS), dim3(64), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_wgrad, dim3(WG_TASKS * 2 * WG_SLABS), dim3(64), 0, (hipStream_t)stream, A);
     return done("dwp_wgrad");
 }
 
