@@ -443,10 +443,10 @@ def main():
                 out["config3_ppo"]["graph_rollout_minibatch_scaled"] = epochs_summary(keys=("play_fps", "total_fps"), graph_rollout=True, graph_update=True, cfg=scaled)
                 out["config3_ppo"]["graph_rollout_minibatch_scaled"]["note"] = ("as graph_rollout with minibatch_size x (envs / 4096) = %d: the reference's 640 updates per epoch"
                                                                                   % scaled["config"]["minibatch_size"])
-                # the update as 5 launches: forward + loss + input gradients and the weight gradients on the matrix cores, then gradient
+                # the update as 4 launches: forward + loss + input gradients and the weight gradients on the matrix cores, then gradient
                 # statistics, Adam and the scaler (include/dyros_ppo.h, isaacgymdyros_amd/ppo_update.py); the yaml's own minibatch of 4096
                 rec = epochs_summary(keys=("play_fps", "total_fps"), graph_rollout=True, fused_update=True)
-                rec["note"] = ("rollout step and the FUSED minibatch update (include/dyros_ppo.h: 5 launches on the matrix cores instead of ~190) each captured "
+                rec["note"] = ("rollout step and the FUSED minibatch update (include/dyros_ppo.h: 4 launches on the matrix cores instead of ~190), 16 updates and 8 rollout steps per graph, each captured "
                                "in a hipGraph; minibatch_size as in the yaml")
                 out["config3_ppo"]["fused_update"] = rec
                 # (the legs above are kept for the comparison; this is the path a user of config 3 runs)

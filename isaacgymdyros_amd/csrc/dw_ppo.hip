@@ -2,7 +2,7 @@
 // learning/rl_games_custom/a2c_continuous_seperate.py:108-193, common_losses.py:4-26, models_dyros.py:59-62).  gfx950; fp16 storage as
 // _Float16, products on v_mfma_f32_16x16x32_f16 with fp32 accumulation, everything else in fp32.  Two forms: k_mlp + k_wgrad (the whole
 // forward / backward in two launches on the matrix cores) or the small kernels that sit between library GEMMs; both end in k_grad_stats,
-// k_adam, k_finish.  The update is launch- and latency-bound, not bandwidth-bound (10 GFLOP, 30 MB): a replayed hipGraph node costs 4-5 us
+// k_adam, k_finish (the first form: k_adam<true>, which finishes the update too).  The update is launch- and latency-bound, not bandwidth-bound (10 GFLOP, 30 MB): a replayed hipGraph node costs 4-5 us
 // on an MI355X whatever it does, and torch's autograd needs ~190 of them.
 #include <hip/hip_runtime.h>
 #include <math.h>

@@ -15,7 +15,10 @@ f = U.FusedPpoUpdate(net, c, B, nmb, dev, rowmajor=False)
 f.set_learning_rates(1e-5, 1e-5)
 g = torch.Generator(device=dev).manual_seed(1)
 n = B * nmb
-f.bind_batch(torch.randn(n, U.IN, generator=g, device=dev), torch.randn(n, U.ACT, generator=g, device=dev) * 0.1, torch.zeros(n, device=dev), torch.zeros(n, U.ACT, device=dev),
+obs = torch.randn(n, U.IN, generator=g, device=dev)
+if os.environ.get("OBS16", "1") != "0":          # (the trainer's form: fp16 rows of 512)
+    o16 = torch.zeros(n, U.INP, device=dev, dtype=torch.float16); o16[:, :U.IN] = obs.half(); obs = o16
+f.bind_batch(obs, torch.randn(n, U.ACT, generator=g, device=dev) * 0.1, torch.zeros(n, device=dev), torch.zeros(n, U.ACT, device=dev),
              torch.randn(n, generator=g, device=dev), torch.randn(n, generator=g, device=dev))
 names = ["ring W1", "staging", "layer 1 products", "epilogue 1 (+ring W2)", "layer 2 products", "epilogue 2, loss inputs", "head products", "loss", "second-layer gradient product", "mask 2", "first-layer gradient products", "mask 1 + end"]
 acc = None
