@@ -42,7 +42,7 @@ def kernel_source_hash() -> str:
     csrc = os.path.join(ROOT, "isaacgymdyros_amd", "csrc")
     for f in sorted(os.listdir(csrc)) + ["../../include/dyros_walk.h"]:
         p = os.path.join(csrc, f)
-        if os.path.isfile(p) and f.endswith((".h", ".hip")) and not f.startswith("dw_amp"):          # (dw_amp.*: row f-3's entry points, not part of the step kernels)
+        if os.path.isfile(p) and f.endswith((".h", ".hip")) and not f.startswith(("dw_amp", "dw_ppo")):          # (dw_amp.*, dw_ppo.*: rows f-3 / f-2, not part of the step kernels)
             h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
