@@ -274,6 +274,27 @@ def test_consumer_trains_with_the_fused_update():
 
 
 @pytest.mark.gpu
+def test_consumer_graph_chains_do_not_change_the_epoch():
+    """Several updates / rollout steps per replayed graph (UPD_CHAIN, ROLL_CHAIN of examples/ppo_consumer.py: the minibatch index, the env's step
+    counter and the rollout buffers' row index live on the device) against one per graph: the same epoch (the rollout to the bit; the update
+    up to the order of the bias gradients' fp32 atomics)."""
+    ppo = _ppo()
+    keep = ppo.UPD_CHAIN, ppo.ROLL_CHAIN
+    try:
+        ppo.UPD_CHAIN, ppo.ROLL_CHAIN = 10 ** 6, 1
+        a = ppo.train(256, epochs=2, horizon=16, device="cuda:0", log=lambda *_: None, graph_rollout=True, fused_update=True)
+        ppo.UPD_CHAIN, ppo.ROLL_CHAIN = 2, 4          # (5 updates per epoch: 2 eager, one chain of 2, one single)
+        b = ppo.train(256, epochs=2, horizon=16, device="cuda:0", log=lambda *_: None, graph_rollout=True, fused_update=True)
+    finally:
+        ppo.UPD_CHAIN, ppo.ROLL_CHAIN = keep
+    assert b[0]["mean_reward"] == a[0]["mean_reward"] and b[0]["mean_episode_length"] == a[0]["mean_episode_length"]
+    for sa, sb in zip(a, b):
+        assert sb["mean_reward"] == pytest.approx(sa["mean_reward"], rel=1e-3)
+        assert sb["c_loss"] == pytest.approx(sa["c_loss"], rel=1e-2) and sb["a_loss"] == pytest.approx(sa["a_loss"], rel=2e-2, abs=1e-3)
+        assert sb["kl"] == pytest.approx(sa["kl"], rel=2e-2, abs=1e-5)
+
+
+@pytest.mark.gpu
 def test_fused_update_resumes_from_its_state_dict():
     """Parameters written from outside + refresh_copies(), and the optimiser state through state_dict() / load_state_dict(): a second updater
     built from them continues bit for bit (the matrix-core form is deterministic: no float atomics on anything the parameters depend on
