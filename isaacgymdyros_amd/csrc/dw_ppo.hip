@@ -461,6 +461,8 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
 // (One wave doing all 16 column tiles of 16 or 32 rows took 43-47 us whatever the tiling: a lone wave per SIMD runs its GEMM steps,
 // epilogues and copies one after the other; split four ways each SIMD of the CU has a wave and a quarter of the work.)
 constexpr int MR = 2, MT = 16 * MR, WPB = 4, XS = INP + 8, HS = HID + 8, NTL = HID / 16, NTW = NTL / WPB;          // LDS row strides in halves (+16 B)
+// dwp_mlp's workgroup: MWPB waves, two per SIMD -- one hides the other's LDS, L2 and transcendental latencies (four waves, one per SIMD: 19 -> ? us)
+constexpr int MWPB = 8, MNTW = NTL / MWPB;
 
 // acc[mr][t] = As[16 mr .. +15][K] . W[16 (nt0 + t) .. +15][K]' for NT column tiles from nt0 (NTA = column tiles of the whole matrix); W in
 // fragment order.  A lone wave per SIMD has nothing to hide an L2 round trip behind but its own products: the B fragments are requested
@@ -512,7 +514,7 @@ __device__ __forceinline__ void mfma_rows(const _Float16 *As, const _Float16 *__
 template <int COLS, int STRIDE>
 __device__ __forceinline__ void rows_out(const _Float16 *Ls, _Float16 *__restrict__ g, int tid) {
 #pragma unroll
-    for (int t = tid; t < MT * (COLS / 8); t += 64 * WPB) {
+    for (int t = tid; t < MT * (COLS / 8); t += 64 * MWPB) {
         const int r = t / (COLS / 8), c = (t % (COLS / 8)) * 8;
         *reinterpret_cast<h8 *>(g + (size_t)r * COLS + c) = *reinterpret_cast<const h8 *>(Ls + r * STRIDE + c);
     }
@@ -523,7 +525,7 @@ __device__ __forceinline__ void rows_out(const _Float16 *Ls, _Float16 *__restric
 // FEAT features: (kb * FEAT / 16 + t) * 64 + l, 16 bytes each -- a consumer's request is one contiguous KB.
 template <int FEAT, int STRIDE>
 __device__ __forceinline__ void frags_out(const _Float16 *Ls, _Float16 *__restrict__ dstblock, int tid) {
-    for (int it = tid; it < (FEAT / 16) * 64; it += 64 * WPB) {
+    for (int it = tid; it < (FEAT / 16) * 64; it += 64 * MWPB) {
         const int t = it >> 6, l = it & 63;
         const _Float16 *src = Ls + (8 * (l >> 4)) * STRIDE + 16 * t + (l & 15);
         h8 v;
@@ -550,9 +552,9 @@ __device__ __forceinline__ void frag_store_tile(const _Float16 (&z)[MR][4], _Flo
     }
 }
 // bias + relu of my column tiles of a hidden layer from the accumulator tiles into the layer's LDS image
-__device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][NTW], const float (&bia)[NTW], _Float16 *Hs, _Float16 *__restrict__ fdst, int nt0, int cr, int g) {
+__device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][MNTW], const float (&bia)[MNTW], _Float16 *Hs, _Float16 *__restrict__ fdst, int nt0, int cr, int g) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
+    for (int t = 0; t < MNTW; ++t) {
         _Float16 z[MR][4];
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
@@ -566,10 +568,10 @@ __device__ __forceinline__ void hidden_out(const f4 (&acc)[MR][NTW], const float
     }
 }
 // relu mask of my column tiles of a hidden layer's gradient (Hs: that layer's activations) into Zs, their bias gradient into the accumulators
-__device__ __forceinline__ void masked_out(const f4 (&acc)[MR][NTW], const _Float16 *Hs, _Float16 *Zs, _Float16 *__restrict__ fdst, float *pcol, int nt0, int cr,
+__device__ __forceinline__ void masked_out(const f4 (&acc)[MR][MNTW], const _Float16 *Hs, _Float16 *Zs, _Float16 *__restrict__ fdst, float *pcol, int nt0, int cr,
                                            int g, int lane) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
+    for (int t = 0; t < MNTW; ++t) {
         float cs = 0.0f;
         _Float16 z[MR][4];
 #pragma unroll
@@ -607,11 +609,11 @@ struct MlpArgs {
 #else
 #define MLP_STAMP(n) do { } while (0)
 #endif
-__global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
+__global__ __launch_bounds__(64 * MWPB) void k_mlp(const MlpArgs A) {
     __shared__ _Float16 Xs[MT * XS];          // the input rows; after the first layer: the masked gradient of the second hidden layer
     __shared__ _Float16 H1s[MT * HS], H2s[MT * HS], Ds[MT * HS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, net = blockIdx.y, r0 = blockIdx.x * MT, B = A.B;
-    const int nt0 = NTW * wv;          // my column tiles: nt0 .. nt0 + NTW - 1
+    const int nt0 = MNTW * wv;          // my column tiles: nt0 .. nt0 + MNTW - 1
     const int mb = (int)A.state[DWP_S_MB];
     const int cr = lane & 15, g = lane >> 4;          // my column in a C tile, my group of four rows
     float *prow = A.pbuf + ((size_t)(blockIdx.x & (PBK - 1)) * 2 + net) * PBW;          // (my bucket's row of accumulators)
@@ -621,54 +623,63 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     // (a product's first weight fragments are requested before the work that precedes it -- the staging, the previous layer's epilogue --
     //  so that their L2 round trip passes under it: the weights do not depend on anything computed here)
     MLP_STAMP(0);
-    h8 ring[4][NTW];
-    ring_fill<INP, NTL, NTW, 4>(W1, nt0, ring, lane);
+    h8 ring[4][MNTW];
+    ring_fill<INP, NTL, MNTW, 4>(W1, nt0, ring, lane);
     // ---- the input rows: fp32 observations -> fp16, zero padding (autocast's cast of the Linear input) ----
     if (A.obs16) {
         // the batch holds them as fp16 rows already (dwp_rollout_pre wrote them so): 16-byte pieces, eight per thread
-        static_assert(MT * INP / 8 == 8 * 64 * WPB, "eight pieces per thread");
+        constexpr int PPT = MT * INP / 8 / (64 * MWPB);
+        static_assert(MT * INP / 8 == PPT * 64 * MWPB, "whole pieces per thread");
         const h8 *src = reinterpret_cast<const h8 *>(A.obs16 + ((size_t)mb * B + r0) * INP);
-        h8 v[8];
+        h8 v[PPT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[tid + 256 * u];
+        for (int u = 0; u < PPT; ++u) v[u] = src[tid + 64 * MWPB * u];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int pc = tid + 256 * u, r = pc >> 6, c = pc & 63; *reinterpret_cast<h8 *>(&Xs[r * XS + 8 * c]) = v[u]; }
+        for (int u = 0; u < PPT; ++u) { const int pc = tid + 64 * MWPB * u, r = pc >> 6, c = pc & 63; *reinterpret_cast<h8 *>(&Xs[r * XS + 8 * c]) = v[u]; }
         __syncthreads();
         if (net == 0) { if (A.x16) rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid); if (A.xf) frags_out<INP, XS>(Xs, A.xf + (size_t)blockIdx.x * INP * 32, tid); }
     } else {
         const float *src = A.obs + ((size_t)mb * B + r0) * IN;
-        // thread t takes columns t and t + 256 of every row (consecutive threads: consecutive floats of a row; no index arithmetic per word):
-        // all of a thread's requests go out before it converts the first word -- one memory latency for the block
-        static_assert(64 * WPB == 256 && INP == 512, "two column slots per thread");
-        const int c0 = tid, c1 = tid + 256, c1l = c1 < IN ? c1 : c0;          // (the second slot's padding columns re-read the first: no branch per request)
-        float v0[MT], v1[MT];
+        // thread t takes column t (+ a multiple of the workgroup's size) of every row (consecutive threads: consecutive floats of a row; no index
+        // arithmetic per word): all of a thread's requests go out before it converts the first word -- one memory latency for the block
+        constexpr int CPT = INP / (64 * MWPB);
+        static_assert(INP == CPT * 64 * MWPB, "whole column slots per thread");
+        float v[CPT][MT];
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { v0[r] = src[(size_t)r * IN + c0]; v1[r] = src[(size_t)r * IN + c1l]; }
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + 64 * MWPB * u, cl = c < IN ? c : 0;          // (the padding columns re-read column 0: no branch per request)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) v[u][r] = src[(size_t)r * IN + cl];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { Xs[r * XS + c0] = (_Float16)v0[r]; Xs[r * XS + c1] = c1 < IN ? (_Float16)v1[r] : (_Float16)0.0f; }
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + 64 * MWPB * u;
+#pragma unroll
+            for (int r = 0; r < MT; ++r) Xs[r * XS + c] = c < IN ? (_Float16)v[u][r] : (_Float16)0.0f;
+        }
         __syncthreads();
         if (net == 0) { if (A.x16) rows_out<INP, XS>(Xs, A.x16 + (size_t)r0 * INP, tid); if (A.xf) frags_out<INP, XS>(Xs, A.xf + (size_t)blockIdx.x * INP * 32, tid); }
     }
     MLP_STAMP(1);
-    f4 acc[MR][NTW];
-    float bia[NTW];          // (a layer's biases, requested before its products: their latency passes under the GEMM)
+    f4 acc[MR][MNTW];
+    float bia[MNTW];          // (a layer's biases, requested before its products: their latency passes under the GEMM)
     // ---- hidden layer 1 ----
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) bia[t] = (float)b1[16 * (nt0 + t) + cr];
-    mfma_go<INP, XS, NTL, NTW, 4>(Xs, W1, nt0, acc, ring, lane);
+    for (int t = 0; t < MNTW; ++t) bia[t] = (float)b1[16 * (nt0 + t) + cr];
+    mfma_go<INP, XS, NTL, MNTW, 4>(Xs, W1, nt0, acc, ring, lane);
     MLP_STAMP(2);
-    ring_fill<HID, NTL, NTW, 4>(W2, nt0, ring, lane);
+    ring_fill<HID, NTL, MNTW, 4>(W2, nt0, ring, lane);
     const size_t fblk = ((size_t)net * gridDim.x + blockIdx.x) * HID * 32;          // (my block of the per-net operand-order buffers)
     hidden_out(acc, bia, H1s, A.h1f ? A.h1f + fblk : nullptr, nt0, cr, g);
     __syncthreads();
     if (A.h1) rows_out<HID, HS>(H1s, A.h1 + ((size_t)net * B + r0) * HID, tid);
     // ---- hidden layer 2 ----
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) bia[t] = (float)b2[16 * (nt0 + t) + cr];
+    for (int t = 0; t < MNTW; ++t) bia[t] = (float)b2[16 * (nt0 + t) + cr];
     MLP_STAMP(3);
-    mfma_go<HID, HS, NTL, NTW, 4>(H1s, W2, nt0, acc, ring, lane);
+    mfma_go<HID, HS, NTL, MNTW, 4>(H1s, W2, nt0, acc, ring, lane);
     MLP_STAMP(4);
     hidden_out(acc, bia, H2s, A.h2f ? A.h2f + fblk : nullptr, nt0, cr, g);
     __syncthreads();
@@ -679,16 +690,20 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     const bool ak = cr < ACT;
     const float scale = A.state[DWP_S_SCALE], invB = 1.0f / (float)B;
     const float bias = (float)b3[cr], ls = ak ? A.logstd[cr] : 0.0f;
-    float in_a[MR], in_om[MR], in_adv[MR], in_nlp[MR], in_ret[MR];
+    // the loss's rows: the MR * 4 accumulator rows of a lane group go round the MWPB waves -- wave w takes row w & 3 of LM row tiles from mr0
+    constexpr int LM = MR * 4 / MWPB;
+    static_assert(LM >= 1 && LM * MWPB == MR * 4, "the head's rows split evenly over the waves");
+    const int wr = wv & 3, mr0 = (wv >> 2) * LM;
+    float in_a[LM], in_om[LM], in_adv[LM], in_nlp[LM], in_ret[LM];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) {
-        const size_t srow = (size_t)mb * B + r0 + 16 * mr + 4 * g + wv;
-        in_a[mr] = net == 0 && ak ? A.act[srow * ACT + cr] : 0.0f; in_om[mr] = net == 0 && ak ? A.old_mu[srow * ACT + cr] : 0.0f;
-        in_adv[mr] = A.adv[srow]; in_nlp[mr] = A.old_nlp[srow]; in_ret[mr] = A.ret[srow];
+    for (int i = 0; i < LM; ++i) {
+        const size_t srow = (size_t)mb * B + r0 + 16 * (mr0 + i) + 4 * g + wr;
+        in_a[i] = net == 0 && ak ? A.act[srow * ACT + cr] : 0.0f; in_om[i] = net == 0 && ak ? A.old_mu[srow * ACT + cr] : 0.0f;
+        in_adv[i] = A.adv[srow]; in_nlp[i] = A.old_nlp[srow]; in_ret[i] = A.ret[srow];
     }
-    h8 w3t[NTW];
+    h8 w3t[MNTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) w3t[t] = reinterpret_cast<const h8 *>(W3T)[(nt0 + t) * 64 + lane];          // (k 16 .. 31: the zero padding)
+    for (int t = 0; t < MNTW; ++t) w3t[t] = reinterpret_cast<const h8 *>(W3T)[(nt0 + t) * 64 + lane];          // (k 16 .. 31: the zero padding)
     f4 o4[MR][1];
     MLP_STAMP(5);
     mfma_rows<HID, HS, 1, 1, 8>(H2s, W3, 0, o4, lane);
@@ -697,12 +712,15 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
         float st[5] = {0, 0, 0, 0, 0}, gsum = 0.0f;
         // (the per-sample sums of both row tiles are reduced TOGETHER over the 16 lanes of a DPP row -- eight independent chains of four
         //  exchanges instead of one after the other: a lone wave waits out every exchange)
-        _Float16 o16[MR];
-        float red[MR][4];
+        _Float16 o16[LM];
+        float red[LM][4];
         const float sg = expf(ls), s2 = sg * sg;
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            const float oacc = wv == 0 ? o4[mr][0][0] : (wv == 1 ? o4[mr][0][1] : (wv == 2 ? o4[mr][0][2] : o4[mr][0][3]));
+        for (int mr = 0; mr < LM; ++mr) {
+            f4 ot = o4[0][0];
+#pragma unroll
+            for (int m = 1; m < MR; ++m) if (mr0 + mr == m) ot = o4[m][0];
+            const float oacc = wr == 0 ? ot[0] : (wr == 1 ? ot[1] : (wr == 2 ? ot[2] : ot[3]));
             o16[mr] = (net == 0 ? ak : cr == 0) ? (_Float16)(oacc + bias) : (_Float16)0.0f;
             const float mu = (float)o16[mr], z = (in_a[mr] - mu) / sg, om = in_om[mr];
             const float hi = fminf(mu - 1.1f, 0.0f), lo = fminf(-mu + 1.1f, 0.0f);
@@ -713,13 +731,13 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
 #pragma unroll
             for (int o = 8; o >= 1; o >>= 1)
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
+                for (int mr = 0; mr < LM; ++mr)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[mr][q] += __shfl_xor(red[mr][q], o, 16);
         }
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            const int row = 16 * mr + 4 * g + wv;
+        for (int mr = 0; mr < LM; ++mr) {
+            const int row = 16 * (mr0 + mr) + 4 * g + wr;
             A.out16[((size_t)net * B + r0 + row) * OUTP + cr] = o16[mr];
             _Float16 d16 = (_Float16)0.0f;
             if (net == 0) {
@@ -766,17 +784,17 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp(const MlpArgs A) {
     for (int mr = 0; mr < MR; ++mr) {
         const h8 a = *reinterpret_cast<const h8 *>(Ds + (16 * mr + cr) * HS + 8 * g);          // (lanes with k = 16 .. 31: A is zero there)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3t[t], (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        for (int t = 0; t < MNTW; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3t[t], (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
     }
     MLP_STAMP(8);
-    ring_fill<HID, NTL, NTW, 4>(W2T, nt0, ring, lane);
+    ring_fill<HID, NTL, MNTW, 4>(W2T, nt0, ring, lane);
     _Float16 *Z2 = Xs;          // [MT][HS]
     masked_out(acc, H2s, Z2, A.dz2f ? A.dz2f + fblk : nullptr, prow + PB_B2, nt0, cr, g, lane);
     __syncthreads();
     if (A.dz2) rows_out<HID, HS>(Z2, A.dz2 + ((size_t)net * B + r0) * HID, tid);
     // ---- gradient of the first hidden layer: dz2 [rows x 256] . W2 [256 x 256], relu mask, bias gradient ----
     MLP_STAMP(9);
-    mfma_go<HID, HS, NTL, NTW, 4>(Z2, W2T, nt0, acc, ring, lane);
+    mfma_go<HID, HS, NTL, MNTW, 4>(Z2, W2T, nt0, acc, ring, lane);
     MLP_STAMP(10);
     _Float16 *Z1 = Ds;          // (every wave has read its rows of dOut from it: the barrier above)
     if (A.dz1) {          // (the row-major copy: tests and the library-GEMM weight gradients; the operand-order copy needs no LDS image)
@@ -1200,7 +1218,7 @@ int dwp_mlp(const DwpMlp *a, void *stream) {
     A.x16 = (_Float16 *)a->x16; A.h1 = (_Float16 *)a->h1; A.h2 = (_Float16 *)a->h2; A.out16 = (_Float16 *)a->out16; A.dout16 = (_Float16 *)a->dout16;
     A.dz2 = (_Float16 *)a->dz2; A.dz1 = (_Float16 *)a->dz1; A.B = a->B;
     A.xf = (_Float16 *)a->xf; A.h1f = (_Float16 *)a->h1f; A.h2f = (_Float16 *)a->h2f; A.doutf = (_Float16 *)a->doutf; A.dz2f = (_Float16 *)a->dz2f; A.dz1f = (_Float16 *)a->dz1f; A.e_clip = a->e_clip; A.critic_coef = a->critic_coef;
-    hipLaunchKernelGGL(k_mlp, dim3(a->B / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_mlp, dim3(a->B / MT, 2), dim3(64 * MWPB), 0, (hipStream_t)stream, A);
     return done("dwp_mlp");
 }
 
