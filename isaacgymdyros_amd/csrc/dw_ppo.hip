@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
 // workgroup and used for MR products), writes its columns of the layer's output image, and a workgroup barrier separates the layers.
 // (One wave doing all 16 column tiles of 16 or 32 rows took 43-47 us whatever the tiling: a lone wave per SIMD runs its GEMM steps,
 // epilogues and copies one after the other; split four ways each SIMD of the CU has a wave and a quarter of the work.)
-constexpr int MR = 2, MT = 16 * MR, WPB = 4, XS = INP + 8, HS = HID + 8, NTL = HID / 16, NTW = NTL / WPB;          // LDS row strides in halves (+16 B)
+constexpr int MR = 2, MT = 16 * MR, XS = INP + 8, HS = HID + 8, NTL = HID / 16;          // LDS row strides in halves (+16 B)
 // dwp_mlp's workgroup: MWPB waves, two per SIMD -- one hides the other's LDS, L2 and transcendental latencies (four waves, one per SIMD: 19 -> ? us)
 constexpr int MWPB = 8, MNTW = NTL / MWPB;
 
@@ -915,8 +915,16 @@ __global__ __launch_bounds__(256) void k_roll_pre(const RollPre A) {
             const size_t e = i / ppr, c = i - e * ppr;
             const float *src = A.obs + e * A.nobs + 8 * c;
             h8 v;
+            if (8 * c + 8 <= (size_t)A.nobs) {
+                // (two 16-byte requests on a 4-byte boundary: a wave reads 2 KB in one piece instead of eight strided words per lane)
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const f4u lo = *reinterpret_cast<const f4u *>(src), hi = *reinterpret_cast<const f4u *>(src + 4);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = 8 * c + q < (size_t)A.nobs ? (_Float16)src[q] : (_Float16)0.0f;
+                for (int q = 0; q < 4; ++q) { v[q] = (_Float16)lo[q]; v[4 + q] = (_Float16)hi[q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 8 * c + q < (size_t)A.nobs ? (_Float16)src[q] : (_Float16)0.0f;
+            }
             *reinterpret_cast<h8 *>(reinterpret_cast<_Float16 *>(A.mb_obs) + (e * (size_t)A.env_major_steps + n) * INP + 8 * c) = v;
         }
     } else if (A.env_major_steps) {
@@ -1010,47 +1018,57 @@ __device__ __forceinline__ void mfma32_rows(const float *As, const float *__rest
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-__global__ __launch_bounds__(64 * WPB) void k_policy(const float *__restrict__ obs, const float *__restrict__ p, const float *__restrict__ p32f, int N,
+// dwp_policy's workgroup: PWPB waves, two per SIMD
+constexpr int PWPB = 8, PNTW = NTL / PWPB;
+__global__ __launch_bounds__(64 * PWPB) void k_policy(const float *__restrict__ obs, const float *__restrict__ p, const float *__restrict__ p32f, int N,
                                                      float *__restrict__ mu, float *__restrict__ value) {
     __shared__ float Xs[MT * XS32];          // the input rows; after the first layer: the second hidden layer
     __shared__ float H1s[MT * HS32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, net = blockIdx.y, r0 = blockIdx.x * MT;
-    const int nt0 = NTW * wv, cr = lane & 15, g = lane >> 4;
+    const int nt0 = PNTW * wv, cr = lane & 15, g = lane >> 4;
     const float *W1 = p32f + G_W1 + (size_t)net * HID * INP, *W2 = p32f + G_W2 + (size_t)net * HID * HID, *W3 = p32f + G_W3 + (size_t)net * OUTP * HID;
     const float *b1 = p + NWT + net * HID, *b2 = p + NWT + NB1 + net * HID, *b3 = p + NWT + NB1 + NB2 + net * OUTP;
     {
         const float *src = obs + (size_t)r0 * IN;
-        const int c0 = tid, c1 = tid + 256, c1l = c1 < IN ? c1 : c0;
+        constexpr int CPT = INP / (64 * PWPB);
+        static_assert(INP == CPT * 64 * PWPB, "whole column slots per thread");
         const int rmax = N - 1 - r0;          // (rows past the end -- N is not a multiple of 32 -- read the last row again; nothing of theirs is stored)
-        float v0[MT], v1[MT];
+        float v[CPT][MT];
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { const int rr = r < rmax ? r : rmax; v0[r] = src[(size_t)rr * IN + c0]; v1[r] = src[(size_t)rr * IN + c1l]; }
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + 64 * PWPB * u, cl = c < IN ? c : 0;
+#pragma unroll
+            for (int r = 0; r < MT; ++r) { const int rr = r < rmax ? r : rmax; v[u][r] = src[(size_t)rr * IN + cl]; }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        const int q0 = perm16(c0), q1 = perm16(c1);
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { Xs[r * XS32 + q0] = v0[r]; Xs[r * XS32 + q1] = c1 < IN ? v1[r] : 0.0f; }
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + 64 * PWPB * u, q = perm16(c);
+#pragma unroll
+            for (int r = 0; r < MT; ++r) Xs[r * XS32 + q] = c < IN ? v[u][r] : 0.0f;
+        }
         __syncthreads();
     }
-    f4 acc[MR][NTW];
-    float bia[NTW];
+    f4 acc[MR][PNTW];
+    float bia[PNTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) bia[t] = b1[16 * (nt0 + t) + cr];
-    mfma32_rows<INP / 16, XS32, NTL, NTW, 3>(Xs, W1, nt0, acc, lane);
+    for (int t = 0; t < PNTW; ++t) bia[t] = b1[16 * (nt0 + t) + cr];
+    mfma32_rows<INP / 16, XS32, NTL, PNTW, 3>(Xs, W1, nt0, acc, lane);
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < PNTW; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) H1s[(16 * mr + 4 * g + r) * HS32 + perm16(16 * (nt0 + t) + cr)] = fmaxf(acc[mr][t][r] + bia[t], 0.0f);
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) bia[t] = b2[16 * (nt0 + t) + cr];
-    mfma32_rows<HID / 16, HS32, NTL, NTW, 3>(H1s, W2, nt0, acc, lane);
+    for (int t = 0; t < PNTW; ++t) bia[t] = b2[16 * (nt0 + t) + cr];
+    mfma32_rows<HID / 16, HS32, NTL, PNTW, 3>(H1s, W2, nt0, acc, lane);
     float *H2s = Xs;          // [MT][HS32]
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < PNTW; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) H2s[(16 * mr + 4 * g + r) * HS32 + perm16(16 * (nt0 + t) + cr)] = fmaxf(acc[mr][t][r] + bia[t], 0.0f);
     __syncthreads();
@@ -1200,7 +1218,7 @@ int dwp_retile32(const float *p, float *p32f, void *stream) {
 
 int dwp_policy(const float *obs, const float *p, const float *p32f, int32_t N, float *mu, float *value, void *stream) {
     if (!obs || !p || !p32f || !mu || !value || N < 1) return fail("dwp_policy: bad argument");
-    hipLaunchKernelGGL(k_policy, dim3((N + MT - 1) / MT, 2), dim3(64 * WPB), 0, (hipStream_t)stream, obs, p, p32f, N, mu, value);
+    hipLaunchKernelGGL(k_policy, dim3((N + MT - 1) / MT, 2), dim3(64 * PWPB), 0, (hipStream_t)stream, obs, p, p32f, N, mu, value);
     return done("dwp_policy");
 }
 
