@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
 // epilogues and copies one after the other; split four ways each SIMD of the CU has a wave and a quarter of the work.)
 constexpr int MR = 2, MT = 16 * MR, XS = INP + 8, HS = HID + 8, NTL = HID / 16;          // LDS row strides in halves (+16 B)
 // dwp_mlp's workgroup: MWPB waves, two per SIMD -- one hides the other's LDS, L2 and transcendental latencies (four waves, one per SIMD: 19 -> ? us)
-constexpr int MWPB = 8, MNTW = NTL / MWPB;
+constexpr int MWPB = 8, MNTW = NTL / MWPB, MRD = 6;          // MRD: depth of the ring of weight-fragment requests
 
 // acc[mr][t] = As[16 mr .. +15][K] . W[16 (nt0 + t) .. +15][K]' for NT column tiles from nt0 (NTA = column tiles of the whole matrix); W in
 // fragment order.  A lone wave per SIMD has nothing to hide an L2 round trip behind but its own products: the B fragments are requested
@@ -623,8 +623,8 @@ __global__ __launch_bounds__(64 * MWPB) void k_mlp(const MlpArgs A) {
     // (a product's first weight fragments are requested before the work that precedes it -- the staging, the previous layer's epilogue --
     //  so that their L2 round trip passes under it: the weights do not depend on anything computed here)
     MLP_STAMP(0);
-    h8 ring[4][MNTW];
-    ring_fill<INP, NTL, MNTW, 4>(W1, nt0, ring, lane);
+    h8 ring[MRD][MNTW];
+    ring_fill<INP, NTL, MNTW, MRD>(W1, nt0, ring, lane);
     // ---- the input rows: fp32 observations -> fp16, zero padding (autocast's cast of the Linear input) ----
     if (A.obs16) {
         // the batch holds them as fp16 rows already (dwp_rollout_pre wrote them so): 16-byte pieces, eight per thread
@@ -668,9 +668,9 @@ __global__ __launch_bounds__(64 * MWPB) void k_mlp(const MlpArgs A) {
     // ---- hidden layer 1 ----
 #pragma unroll
     for (int t = 0; t < MNTW; ++t) bia[t] = (float)b1[16 * (nt0 + t) + cr];
-    mfma_go<INP, XS, NTL, MNTW, 4>(Xs, W1, nt0, acc, ring, lane);
+    mfma_go<INP, XS, NTL, MNTW, MRD>(Xs, W1, nt0, acc, ring, lane);
     MLP_STAMP(2);
-    ring_fill<HID, NTL, MNTW, 4>(W2, nt0, ring, lane);
+    ring_fill<HID, NTL, MNTW, MRD>(W2, nt0, ring, lane);
     const size_t fblk = ((size_t)net * gridDim.x + blockIdx.x) * HID * 32;          // (my block of the per-net operand-order buffers)
     hidden_out(acc, bia, H1s, A.h1f ? A.h1f + fblk : nullptr, nt0, cr, g);
     __syncthreads();
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64 * MWPB) void k_mlp(const MlpArgs A) {
 #pragma unroll
     for (int t = 0; t < MNTW; ++t) bia[t] = (float)b2[16 * (nt0 + t) + cr];
     MLP_STAMP(3);
-    mfma_go<HID, HS, NTL, MNTW, 4>(H1s, W2, nt0, acc, ring, lane);
+    mfma_go<HID, HS, NTL, MNTW, MRD>(H1s, W2, nt0, acc, ring, lane);
     MLP_STAMP(4);
     hidden_out(acc, bia, H2s, A.h2f ? A.h2f + fblk : nullptr, nt0, cr, g);
     __syncthreads();
@@ -787,14 +787,14 @@ __global__ __launch_bounds__(64 * MWPB) void k_mlp(const MlpArgs A) {
         for (int t = 0; t < MNTW; ++t) acc[mr][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3t[t], (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
     }
     MLP_STAMP(8);
-    ring_fill<HID, NTL, MNTW, 4>(W2T, nt0, ring, lane);
+    ring_fill<HID, NTL, MNTW, MRD>(W2T, nt0, ring, lane);
     _Float16 *Z2 = Xs;          // [MT][HS]
     masked_out(acc, H2s, Z2, A.dz2f ? A.dz2f + fblk : nullptr, prow + PB_B2, nt0, cr, g, lane);
     __syncthreads();
     if (A.dz2) rows_out<HID, HS>(Z2, A.dz2 + ((size_t)net * B + r0) * HID, tid);
     // ---- gradient of the first hidden layer: dz2 [rows x 256] . W2 [256 x 256], relu mask, bias gradient ----
     MLP_STAMP(9);
-    mfma_go<HID, HS, NTL, MNTW, 4>(Z2, W2T, nt0, acc, ring, lane);
+    mfma_go<HID, HS, NTL, MNTW, MRD>(Z2, W2T, nt0, acc, ring, lane);
     MLP_STAMP(10);
     _Float16 *Z1 = Ds;          // (every wave has read its rows of dOut from it: the barrier above)
     if (A.dz1) {          // (the row-major copy: tests and the library-GEMM weight gradients; the operand-order copy needs no LDS image)
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64 * MWPB) void k_mlp(const MlpArgs A) {
 template <int MTB, int NTB, int FA, int FB>          // FA / FB: features of the A / B operand buffers
 __device__ __forceinline__ void wgrad_block(const _Float16 *__restrict__ Af, const _Float16 *__restrict__ Bf, int mt0, int nt0, int kb0, int kb1, float *__restrict__ G,
                                             int ld, int lane) {
-    constexpr int RD = 3;
+    constexpr int RD = 5;
     f4 acc[MTB][NTB];
     h8 fa[RD][MTB], fb[RD][NTB];
     const h8 *pa = reinterpret_cast<const h8 *>(Af) + mt0 * 64 + lane, *pb = reinterpret_cast<const h8 *>(Bf) + nt0 * 64 + lane;
@@ -829,8 +829,8 @@ __device__ __forceinline__ void wgrad_block(const _Float16 *__restrict__ Af, con
     };
     // (the slab has a multiple of RD k-steps or not: the ring is indexed by a counter that is static inside an unrolled group of RD)
     const int nk = kb1 - kb0;
-    if (nk > 0) request(0, kb0);
-    if (nk > 1) request(1, kb0 + 1);
+#pragma unroll
+    for (int i = 0; i < RD - 1; ++i) if (nk > i) request(i, kb0 + i);
     for (int k0 = 0; k0 < nk; k0 += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
