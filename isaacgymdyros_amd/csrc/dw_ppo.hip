@@ -395,10 +395,15 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
         skip = state[DWP_S_FOUND_INF + net] != 0.0f;
         scale = state[DWP_S_SCALE]; step = state[DWP_S_STEP + net] + 1.0f; lr = state[DWP_S_LR + net];
     }
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
-        if (FIN) finish_update(state, fin.B, fin.nmb, fin.growth_interval, fin.pbuf);
-    }
+    if (FIN) {
+        // the finishing block is an EXTRA one (the last): three dependent round trips to memory (partials, logged sums, state) that run beside
+        // the Adam blocks' own instead of behind block 0's (10 -> ? us)
+        if (blockIdx.x == gridDim.x - 1) {
+            if (threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
+            finish_update(state, fin.B, fin.nmb, fin.growth_interval, fin.pbuf);
+            return;
+        }
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
     if (i0 >= NP) return;
     if (skip) return;          // GradScaler.step: this optimiser's step is skipped
     const float inv = 1.0f / scale;
@@ -1153,7 +1158,7 @@ int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, c
 int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t, const float *g32,
                     float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream) {
     if (!p || !p16 || !m || !v || !g32 || !gb || !state || !part || !pbuf || B < 1 || num_minibatches < 1 || growth_interval < 1) return fail("dwp_adam_finish: bad argument");
-    hipLaunchKernelGGL(k_adam<true>, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
+    hipLaunchKernelGGL(k_adam<true>, dim3((NP / 8 + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
                        (_Float16 *)p16t, g32, p32f, FinArgs{B, num_minibatches, growth_interval, pbuf});
     return done("dwp_adam_finish");
 }
