@@ -302,31 +302,47 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
 
 // the end of an update, by ONE block of 256 threads (all of them arrive): logged means, GradScaler.update, step counts, minibatch index
 __device__ __forceinline__ void finish_update(float *__restrict__ state, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
-    if (pbuf) {          // dwp_mlp's logged sums: over the buckets and the two nets, cleared for the next update
-        if (threadIdx.x < 5) {
-            float t = 0.0f;
-            for (int r = 0; r < 2 * PBK; ++r) { t += pbuf[(size_t)r * PBW + PB_ST + threadIdx.x]; pbuf[(size_t)r * PBW + PB_ST + threadIdx.x] = 0.0f; }
-            state[threadIdx.x] += t;
-        }
-        __syncthreads();
+    // Two round trips to memory in all: every word is requested before the first is used (a thread that walks the 64 bucket rows, or reads a
+    // word of `state` behind a store to `state`, pays one round trip per word: that was 4 of dwp_adam_finish's 10 us).
+    float t5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (threadIdx.x >= 64) return;          // (wave 0 does it)
+    if (pbuf) {          // dwp_mlp's logged sums: over the buckets and the two nets (lane = bucket row), cleared for the next update
+        static_assert(2 * PBK == 64, "one bucket row per lane of wave 0");
+        float *row = pbuf + (size_t)threadIdx.x * PBW + PB_ST;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) t5[q] = row[q];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) row[q] = 0.0f;
     }
+    float sv[5], s_f0 = 0.0f, s_f1 = 0.0f, s_norm2 = 0.0f, s_scale = 0.0f, s_growth = 0.0f, s_st0 = 0.0f, s_st1 = 0.0f, s_mb = 0.0f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) sv[q] = state[q];
+        s_f0 = state[DWP_S_FOUND_INF]; s_f1 = state[DWP_S_FOUND_INF + 1]; s_norm2 = state[DWP_S_NORM2]; s_scale = state[DWP_S_SCALE];
+        s_growth = state[DWP_S_GROWTH]; s_st0 = state[DWP_S_STEP]; s_st1 = state[DWP_S_STEP + 1]; s_mb = state[DWP_S_MB];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) t5[q] = wave_sum(t5[q]);
     if (threadIdx.x != 0) return;
+    static_assert(DWP_S_ALOSS == 0 && DWP_S_CLOSS == 1 && DWP_S_BLOSS == 2 && DWP_S_CLIPPED == 3 && DWP_S_KL == 4, "the logged sums are state[0 .. 4]");
     const float invB = 1.0f / (float)B;
-    const bool f0 = state[DWP_S_FOUND_INF] != 0.0f, f1 = state[DWP_S_FOUND_INF + 1] != 0.0f;
+    const bool f0 = s_f0 != 0.0f, f1 = s_f1 != 0.0f;
     float *o = state + DWP_S_OUT;
-    o[0] = state[DWP_S_ALOSS] * invB; o[1] = state[DWP_S_CLOSS] * invB; o[2] = state[DWP_S_BLOSS] * invB; o[3] = state[DWP_S_CLIPPED] * invB;
-    o[4] = state[DWP_S_KL] * invB; o[5] = sqrtf(state[DWP_S_NORM2]); o[6] = state[DWP_S_SCALE]; o[7] = (f0 || f1) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) o[q] = (sv[q] + t5[q]) * invB;
+    o[5] = sqrtf(s_norm2); o[6] = s_scale; o[7] = (f0 || f1) ? 1.0f : 0.0f;
     // torch.amp.GradScaler.update (_amp_update_scale_): backoff 0.5 on any inf, growth 2.0 after growth_interval clean updates
-    if (f0 || f1) { state[DWP_S_SCALE] *= 0.5f; state[DWP_S_GROWTH] = 0.0f; }
+    if (f0 || f1) { state[DWP_S_SCALE] = s_scale * 0.5f; state[DWP_S_GROWTH] = 0.0f; }
     else {
-        const float t = state[DWP_S_GROWTH] + 1.0f;
-        if ((int)t == growth_interval) { state[DWP_S_SCALE] *= 2.0f; state[DWP_S_GROWTH] = 0.0f; }
+        const float t = s_growth + 1.0f;
+        if ((int)t == growth_interval) { state[DWP_S_SCALE] = s_scale * 2.0f; state[DWP_S_GROWTH] = 0.0f; }
         else state[DWP_S_GROWTH] = t;
     }
-    if (!f0) state[DWP_S_STEP] += 1.0f;
-    if (!f1) state[DWP_S_STEP + 1] += 1.0f;
+    if (!f0) state[DWP_S_STEP] = s_st0 + 1.0f;
+    if (!f1) state[DWP_S_STEP + 1] = s_st1 + 1.0f;
+#pragma unroll
     for (int k = 0; k < 8; ++k) state[k] = 0.0f;
-    const int mb = (int)state[DWP_S_MB] + 1;
+    const int mb = (int)s_mb + 1;
     state[DWP_S_MB] = (float)(mb >= nmb ? 0 : mb);
 }
 __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float *__restrict__ gb, int B, int nmb, int growth_interval, float *__restrict__ pbuf) {
