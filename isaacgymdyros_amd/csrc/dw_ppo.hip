@@ -1221,7 +1221,9 @@ int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_o
     if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_post: N * num_obs must be a multiple of 4");
     RollPost A{rew, value, stacked, new_obs, (const long long *)time_outs, (const long long *)done_buf, (const long long *)n, mb_rew, terms, g_dones, g_obs, N, num_obs,
                num_terms, stacked_cols, reward_scale, gamma};
-    hipLaunchKernelGGL(k_roll_post, dim3((unsigned)(((size_t)N * num_obs / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    // (without the observation copy -- the caller's policy reads the env's own buffer -- the launch covers the envs only)
+    const size_t work = g_obs != new_obs ? (size_t)N * num_obs / 4 : (size_t)N;
+    hipLaunchKernelGGL(k_roll_post, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return done("dwp_rollout_post");
 }
 
