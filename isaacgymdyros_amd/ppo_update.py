@@ -107,13 +107,15 @@ class RolloutRecorder:
         self.obs_dst, self.env_major = (obs_env_major, self.H) if obs_env_major is not None else (mb["obs"], 0)
         self.half = self.obs_dst.dtype == torch.float16          # (fp16 rows of INP: the update's own input format, FusedPpoUpdate.bind_batch)
         self.nobs = int(num_obs if num_obs is not None else self.obs_dst.shape[-1])
-        assert self.obs_dst.is_contiguous() and self.obs_dst.is_cuda
-        if self.half:
-            assert self.env_major and num_obs is not None and self.obs_dst.numel() == self.H * self.N * INP
-        else:
-            assert self.obs_dst.numel() == self.H * self.N * self.nobs and self.obs_dst.dtype == torch.float32
+        if not (self.obs_dst.is_contiguous() and self.obs_dst.is_cuda):
+            raise ValueError("RolloutRecorder: the observation buffer must be a contiguous device tensor")
+        if self.half and not (self.env_major and num_obs is not None and self.obs_dst.numel() == self.H * self.N * INP):
+            raise ValueError("RolloutRecorder: a float16 observation buffer is the env-major [N * H, %d] batch and needs num_obs" % INP)
+        if not self.half and not (self.obs_dst.numel() == self.H * self.N * self.nobs and self.obs_dst.dtype == torch.float32):
+            raise ValueError("RolloutRecorder: the observation buffer must hold H * N rows of num_obs float32")
         for k in ("act", "mu", "neglogp", "val", "rew", "done"):
-            assert mb[k].is_contiguous() and mb[k].dtype == torch.float32 and mb[k].is_cuda, k
+            if not (mb[k].is_contiguous() and mb[k].dtype == torch.float32 and mb[k].is_cuda):
+                raise ValueError("RolloutRecorder: mb[%r] must be a contiguous float32 device tensor" % k)
         self.act = torch.empty(self.N, ACT, device=mb["act"].device)
 
     def _chk(self, rc):
@@ -266,14 +268,18 @@ class FusedPpoUpdate:
         self.state[K["DWP_S_LR"]:K["DWP_S_LR"] + 2] = torch.tensor([lr_actor, lr_critic], device=self.dev)
 
     def bind_batch(self, obs, act, neglogp, mu, adv, ret):
-        self._mlp_args = None
         """The epoch's flat arrays (env-major, `batch` rows; fp32, contiguous).  Their ADDRESSES are what a captured update replays:
-        keep the tensors and copy_ each epoch's data into them."""
-        for t in (act, neglogp, mu, adv, ret):
-            assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == self.B * self.nmb
-        # obs: fp32 [batch, 487], or (dwp_mlp form only) fp16 [batch, 512] with zero padding -- what RolloutRecorder(obs_env_major=...) fills
-        assert obs.is_contiguous() and obs.shape[0] == self.B * self.nmb
-        assert (obs.dtype == torch.float32 and obs.shape[1] == IN) or (self.mfma and obs.dtype == torch.float16 and obs.shape[1] == INP)
+        keep the tensors and copy_ each epoch's data into them.  obs: fp32 [batch, 487], or (dwp_mlp form only) fp16 [batch, 512] with
+        zero padding -- what RolloutRecorder(obs_env_major=...) fills."""
+        rows = self.B * self.nmb
+        for name, t in (("act", act), ("neglogp", neglogp), ("mu", mu), ("adv", adv), ("ret", ret)):
+            if not (t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == rows):
+                raise ValueError("bind_batch: %s must be a contiguous float32 tensor of %d rows" % (name, rows))
+        ok32 = obs.dtype == torch.float32 and tuple(obs.shape) == (rows, IN)
+        ok16 = self.mfma and obs.dtype == torch.float16 and tuple(obs.shape) == (rows, INP)
+        if not (obs.is_contiguous() and (ok32 or ok16)):
+            raise ValueError("bind_batch: obs must be contiguous float32 [%d, %d]%s" % (rows, IN, " or float16 [%d, %d]" % (rows, INP) if self.mfma else ""))
+        self._mlp_args = None
         self.src = (obs, act, neglogp, mu, adv, ret)
 
     def rewind(self):
