@@ -144,10 +144,11 @@ class FusedPpoUpdate:
     of the minibatch whose index lives in the device state (it advances by itself: the call has no argument that changes, so it can
     be captured in a hipGraph once and replayed)."""
 
-    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True, rowmajor: bool = True):
+    def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True, rowmajor: bool = True, split_tail: bool = False):
         """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp + dwp_wgrad; the minibatch must be a multiple of 32, else the library-GEMM form runs) instead
         of eight library GEMM launches with six kernels between them.  rowmajor (mfma only): dwp_mlp also writes its activations and their
-        gradients as plain [2, B, 256] / [B, 512] matrices (x16, h1, h2, dh2, dh1: what the tests read); a trainer passes False."""
+        gradients as plain [2, B, 256] / [B, 512] matrices (x16, h1, h2, dh2, dh1: what the tests read); a trainer passes False.
+        split_tail (mfma only): the last launch, dwp_adam_finish, as dwp_adam + dwp_finish (five launches: what a test compares the merged one with)."""
         c = cfg
         if bool(c.get("clip_value")) or float(c.get("entropy_coef", 0.0)) != 0.0 or float(c.get("bounds_loss_coef", 0.0)) != 0.0:
             raise ValueError("the fused update is written for clip_value False, entropy_coef 0, bounds_loss_coef 0 (DyrosDynamicWalkPPO.yaml)")
@@ -161,6 +162,7 @@ class FusedPpoUpdate:
         self.api = declare(self.lib)
         self.dev = torch.device(device)
         self.B, self.nmb = int(minibatch), int(num_minibatches)
+        self.split_tail = bool(split_tail)
         self.e_clip, self.critic_coef, self.max_norm = float(c["e_clip"]), float(c["critic_coef"]), float(c["grad_norm"])
         f32 = dict(device=self.dev, dtype=torch.float32)
         f16 = dict(device=self.dev, dtype=torch.float16)
@@ -306,6 +308,11 @@ class FusedPpoUpdate:
             self._chk(api["wgrad"](self.xf.data_ptr(), self.h1f.data_ptr(), self.h2f.data_ptr(), self.doutf.data_ptr(), self.dz2f.data_ptr(), self.dz1f.data_ptr(), st,
                                    self.g32.data_ptr(), B, s))
             self._chk(api["grad_stats"](None, self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), self.g32.data_ptr(), s))
+            if self.split_tail:
+                self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), None, self.gb.data_ptr(), st,
+                                      self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), self.p32f.data_ptr(), s))
+                self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
+                return
             self._chk(api["adam_finish"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(),
                                          self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), self.p32f.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
             return

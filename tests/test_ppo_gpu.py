@@ -329,6 +329,45 @@ def test_fused_update_resumes_from_its_state_dict():
 
 
 @pytest.mark.gpu
+def test_adam_finish_equals_adam_then_finish():
+    """The merged last launch (dwp_adam_finish: Adam blocks that read loss scale / steps / flags from the partials buffer, an extra block that
+    finishes the update meanwhile) against dwp_adam followed by dwp_finish, over clean updates and one that overflows the critic only: weights,
+    moments, every copy of the weights and the whole state word for word; biases to the rounding of their buckets' atomic adds."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 1024, 4
+    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev)
+    fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, split_tail=True)
+    batch = list(_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
+    batch[5] = batch[5].clone()
+    batch[5][2 * B:3 * B] = 3.0e4          # (returns of the third minibatch: value error x scale / B overflows fp16 in the critic only)
+    for f in (fa, fb):
+        f.set_learning_rates(3e-5, 5e-5)
+        f.bind_batch(*batch)
+    skipped = []
+    for _ in range(nmb + 1):
+        fa.update(); fb.update()
+        torch.cuda.synchronize()
+        skipped.append(fa.logged()[7].item())
+        nw = U.NWT
+        assert torch.equal(fa.p[:nw], fb.p[:nw]) and torch.equal(fa.m[:nw], fb.m[:nw]) and torch.equal(fa.v[:nw], fb.v[:nw])
+        assert torch.equal(fa.p16[:nw], fb.p16[:nw]) and torch.equal(fa.p16t, fb.p16t) and torch.equal(fa.p32f, fb.p32f)
+        assert float((fa.p[nw:] - fb.p[nw:]).abs().max()) <= 1e-7 and float((fa.m[nw:] - fb.m[nw:]).abs().max()) <= 1e-6 * float(fa.m[nw:].abs().max()) + 1e-12
+        sa, sb = fa.state.cpu(), fb.state.cpu()
+        o = U.K["DWP_S_OUT"]
+        keep = [i for i in range(U.K["DWP_S_WORDS"]) if not (o <= i < o + 6)]          # (the logged means and the norm: sums in another order)
+        assert torch.equal(sa[keep], sb[keep]), (sa.tolist(), sb.tolist())
+        assert torch.allclose(sa[o:o + 6], sb[o:o + 6], rtol=1e-5, atol=1e-7)
+    assert skipped == [0.0, 0.0, 1.0, 0.0, 0.0]
+    assert fa.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() == [5.0, 4.0] and float(fa.state[U.K["DWP_S_SCALE"]]) == 32768.0
+
+
+@pytest.mark.gpu
 def test_gae_kernel_equals_the_reference_loop():
     """dwp_gae against `discount_values` (examples/ppo_consumer.py, restating a2c_common_dyros.py:485-500) on random rollouts with dones."""
     from isaacgymdyros_amd.ppo_update import gae
