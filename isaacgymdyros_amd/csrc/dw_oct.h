@@ -36,7 +36,7 @@ namespace OCT_NS {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::hex_xor8; using dwq::quarter_take; using dwq::quarter0_all; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::oct_take_lo; using dwq::oct_take_hi; using dwq::hex_xor8; using dwq::quarter_take; using dwq::quarter0_all; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
@@ -89,6 +89,13 @@ constexpr int NQ = LPE / 4;          // quads ("halves" / quarters) of an env
 #define OCT_WPG 2
 #endif
 constexpr int WPG = OCT_WPG;         // wavefronts per workgroup (they share the hot tables, nothing else)
+// The articulated recursion of the inward pass with its spatial ROWS split between the two halves of a limb (octet layout; round 6):
+// half 0 keeps the angular rows of IA / pA, half 1 the linear rows (dw_oct.h "inward pass").  The hex instantiation keeps the mirrored form.
+#if OCT_LPE == 8 && !defined(OCT_NO_ROWSPLIT)
+#define OQ_ROWSPLIT 1
+#else
+#define OQ_ROWSPLIT 0
+#endif
 constexpr int SC_PARK_WORDS = QMAX_OWN * 6 + 2;      // per lane: PhysParams::sc_park (the wrenches of up to QMAX_OWN own proxies, their Gym bodies one byte each)
 static_assert(QMAX_OWN <= 8, "the Gym bodies of a lane's own proxies travel in two words, one byte each");
 
@@ -498,9 +505,25 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     //      running inertia, U = IA S, rank-1 downdate, bias) then runs for step 2 r on half 0's result, takes half 1's result
     //      over (31 words, one DPP move each) and runs for step 2 r + 1.  Half 1 executes the recursion's instructions on
     //      values nobody reads (its stores are masked); it gets the base's inertia back before the base solve. ----
+#if OQ_ROWSPLIT
+    //      ROW SPLIT (octet layout, round 6).  The recursion itself is sequential along the limb, so until round 5 half 1 repeated half
+    //      0's instructions on dead values.  Now the two halves of a limb hold different ROWS of every spatial quantity: half 0 the
+    //      angular rows of IA = [[A, H], [H', M]] and of pA, half 1 the linear rows.  Stored alike in both: Dm = the symmetric diagonal
+    //      block of my rows (A | M, 6 words), Om = their off-diagonal block (H | H', 9 words), pO = my three rows of pA; of a
+    //      6-vector x a lane uses own(x) = its three rows and oth(x) = the other three.  Then U_own = Dm own(S) + Om oth(S) is 18
+    //      products per lane instead of 36, the rank-1 downdate 15 instead of 21, IA c 18 instead of 36; D = S'U and u = tt - S'pA are
+    //      sums over the pair (oct_xor4), and U's other three rows come across the same way.  The map of a step is made by one half
+    //      and handed to BOTH in own / oth form (oct_take_lo / _hi: one bank-masked move per word, the making half keeps its own).
+    float Dm[6], Om[9], pO[3];
+    DQ_UNROLL for (int i = 0; i < 6; ++i) Dm[i] = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 9; ++i) Om[i] = 0.0f;
+    DQ_UNROLL for (int i = 0; i < 3; ++i) pO[i] = 0.0f;
+    const float hsgn = X.h ? -1.0f : 1.0f;          // my off-diagonal block of a rigid inertia is skew(ho) (half 0) or its transpose (half 1)
+#else
     float IA[21], pA[6];          // running reflected inertia / bias (no lane parks a second one: build_quadmodel(accumulate))
     DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
     DQ_UNROLL for (int i = 0; i < 6; ++i) pA[i] = 0.0f;
+#endif
     X.footF[0] = X.footF[1] = X.footF[2] = 0.0f;
     const int my_sole_gym = (j == 0) ? M.left_foot_gym : (j == 1 ? M.right_foot_gym : -1);
     struct BodyMap { float Ao[6], ho[3], mass, pv[6], S[6], cb[6], tt, dd, qd; };       // 31 words
@@ -619,6 +642,123 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         }
         wave_sync();          // every map has read its slot rows before the recursion overwrites any
         OQ_TOCK(tq_map); OQ_TICK();
+#if OQ_ROWSPLIT
+        // ---- recursion: step s on half 0's map, then step s + 1 on half 1's, rows split over the halves ----
+        DQ_UNROLL for (int t2 = 0; t2 < 2; ++t2) {
+            const int sr = s + t2;
+            if (sr >= T) break;
+            // the step's map in own / oth form: made by half t2, taken by the other half
+            float So[3], St[3], co[3], ct[3], pvo[3], Da[6], hs[3], tt_, dd_, qd_;
+            if (t2 == 0) {
+                DQ_UNROLL for (int i = 0; i < 3; ++i) {
+                    So[i] = oct_take_lo(Mb.S[i], Mb.S[3 + i]);   St[i] = oct_take_lo(Mb.S[3 + i], Mb.S[i]);
+                    co[i] = oct_take_lo(Mb.cb[i], Mb.cb[3 + i]); ct[i] = oct_take_lo(Mb.cb[3 + i], Mb.cb[i]);
+                    pvo[i] = oct_take_lo(Mb.pv[i], Mb.pv[3 + i]);
+                    hs[i] = hsgn * oct_lo(Mb.ho[i]);
+                }
+                // (my diagonal block of the rigid inertia: Ao in half 0, mass * 1 in half 1)
+                Da[0] = oct_take_lo(Mb.Ao[0], Mb.mass); Da[3] = oct_take_lo(Mb.Ao[3], Mb.mass); Da[5] = oct_take_lo(Mb.Ao[5], Mb.mass);
+                Da[1] = X.h ? 0.0f : Mb.Ao[1]; Da[2] = X.h ? 0.0f : Mb.Ao[2]; Da[4] = X.h ? 0.0f : Mb.Ao[4];
+                tt_ = oct_lo(Mb.tt); dd_ = oct_lo(Mb.dd); qd_ = Mb.qd;
+            } else {
+                DQ_UNROLL for (int i = 0; i < 3; ++i) {
+                    So[i] = oct_take_hi(Mb.S[3 + i], Mb.S[i]);   St[i] = oct_take_hi(Mb.S[i], Mb.S[3 + i]);
+                    co[i] = oct_take_hi(Mb.cb[3 + i], Mb.cb[i]); ct[i] = oct_take_hi(Mb.cb[i], Mb.cb[3 + i]);
+                    pvo[i] = oct_take_hi(Mb.pv[3 + i], Mb.pv[i]);
+                    hs[i] = hsgn * oct_hi(Mb.ho[i]);
+                }
+                Da[0] = oct_take_hi(Mb.mass, Mb.Ao[0]); Da[3] = oct_take_hi(Mb.mass, Mb.Ao[3]); Da[5] = oct_take_hi(Mb.mass, Mb.Ao[5]);
+                Da[1] = oct_take_hi(0.0f, Mb.Ao[1]); Da[2] = oct_take_hi(0.0f, Mb.Ao[2]); Da[4] = oct_take_hi(0.0f, Mb.Ao[4]);
+                tt_ = oct_hi(Mb.tt); dd_ = oct_hi(Mb.dd); qd_ = oct_hi(Mb.qd);
+            }
+            const int bits = f2i(H.in[sr][j][0]);
+            const int b = (bits & 255) - 1;
+            const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
+            const int gw = H.gany[sr];
+            if (gw >> 8) {  /*@prob:0.09*/      // a finished chain joins the finished chain of an idle lane (same parent) before its lane starts afresh
+                const int src = (gw >> 9) & 3, dst = (gw >> 11) & 3;
+                float tD[6], tO[9], tp[3];
+                quad_bcast_arr(src, Dm, tD);
+                quad_bcast_arr(src, Om, tO);
+                quad_bcast_arr(src, pO, tp);
+                if (j == dst) {
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) Dm[i] += tD[i];
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) Om[i] += tO[i];
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) pO[i] += tp[i];
+                }
+            }
+            if (flags & 1) {
+                DQ_UNROLL for (int i = 0; i < 6; ++i) Dm[i] = 0.0f;
+                DQ_UNROLL for (int i = 0; i < 9; ++i) Om[i] = 0.0f;
+                DQ_UNROLL for (int i = 0; i < 3; ++i) pO[i] = 0.0f;
+            }
+            // gathers (wave-uniform per step): child chains that ended on other lanes
+            if (gw & 1) {          /*@prob:0.09*/
+                const int g0 = f2i(H.in[sr][0][1]), g1 = f2i(H.in[sr][1][1]), g2 = f2i(H.in[sr][2][1]), g3 = f2i(H.in[sr][3][1]);
+                const int mine = f2i(H.in[sr][j][1]);
+                DQ_UNROLL for (int src = 0; src < 4; ++src) {
+                    const int code = src | 8;
+                    bool used = false, want = false;
+                    DQ_UNROLL for (int k = 0; k < 3; ++k) {
+                        used = used || (((g0 >> (4 * k)) & 15) == code) || (((g1 >> (4 * k)) & 15) == code) ||
+                               (((g2 >> (4 * k)) & 15) == code) || (((g3 >> (4 * k)) & 15) == code);
+                        want = want || (((mine >> (4 * k)) & 15) == code);
+                    }
+                    if (used) {
+                        auto from = [&](float x) { return src == 0 ? quad_bcast<0>(x) : (src == 1 ? quad_bcast<1>(x) : (src == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x))); };
+                        DQ_UNROLL for (int i = 0; i < 6; ++i) { const float t = from(Dm[i]); if (want) Dm[i] += t; }
+                        DQ_UNROLL for (int i = 0; i < 9; ++i) { const float t = from(Om[i]); if (want) Om[i] += t; }
+                        DQ_UNROLL for (int i = 0; i < 3; ++i) { const float t = from(pO[i]); if (want) pO[i] += t; }
+                    }
+                }
+            }
+            // my rows of U = IA S, my shares of D = S'U and of S'pA
+            float Uo[3] = {0.0f, 0.0f, 0.0f}, dpart = 0.0f, upart = 0.0f;
+            if (b >= 0) {
+                DQ_UNROLL for (int i = 0; i < 6; ++i) Dm[i] += Da[i];
+                Om[1] -= hs[2]; Om[2] += hs[1];
+                Om[3] += hs[2]; Om[5] -= hs[0];
+                Om[6] -= hs[1]; Om[7] += hs[0];
+                DQ_UNROLL for (int i = 0; i < 3; ++i) pO[i] += pvo[i];
+                DQ_UNROLL for (int r = 0; r < 3; ++r) {
+                    float acc = 0.0f;
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) acc += dwq::ao(Dm, r, c) * So[c];
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) acc += Om[3 * r + c] * St[c];
+                    Uo[r] = acc;
+                }
+                dpart = So[0] * Uo[0] + So[1] * Uo[1] + So[2] * Uo[2];
+                upart = So[0] * pO[0] + So[1] * pO[1] + So[2] * pO[2];
+            }
+            // (lanes l and l ^ 4 are the two halves of one limb: both work or both idle)
+            const float dsum = dpart + oct_xor4(dpart), usum = upart + oct_xor4(upart);
+            const float Ut[3] = {oct_xor4(Uo[0]), oct_xor4(Uo[1]), oct_xor4(Uo[2])};
+            if (b >= 0) {
+                const float D = dsum + dd_;
+                const float Dinv = dw::rcp_nr(D);
+                const float u = tt_ - usum;
+                DQ_UNROLL for (int r = 0; r < 3; ++r) {
+                    const float urd = Uo[r] * Dinv;
+                    DQ_UNROLL for (int c = r; c < 3; ++c) Dm[r == 0 ? c : (r == 1 ? 2 + c : 5)] -= urd * Uo[c];
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) Om[3 * r + c] -= urd * Ut[c];
+                }
+                const float ud = u * Dinv;
+                float pa[3];
+                DQ_UNROLL for (int r = 0; r < 3; ++r) {
+                    float acc = pO[r] + Uo[r] * ud;
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) acc += dwq::ao(Dm, r, c) * co[c];
+                    DQ_UNROLL for (int c = 0; c < 3; ++c) acc += Om[3 * r + c] * ct[c];
+                    pa[r] = acc;
+                }
+                DQ_UNROLL for (int r = 0; r < 3; ++r) pO[r] = pa[r];
+                if (X.prim) {          // (half 0: own = angular, oth = linear)
+                    OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(So[0], So[1], So[2], Dinv);
+                    OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(St[0], St[1], St[2], u);
+                    OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(Uo[0], Uo[1], Uo[2], qd_);
+                    OQ_SLOT(T - 1 - sr, 3, X.pos) = mk4(Ut[0], Ut[1], Ut[2], 0.0f);
+                }
+            }
+        }
+#else
         // ---- recursion: step s on half 0's map, then step s + 1 on half 1's ----
         BodyMap Mq = Mb;          // (hex layout: quad 0 takes the maps of quads 1, 2, 3 in turn from the lanes that made them)
         DQ_UNROLL for (int t2 = 0; t2 < NQ; ++t2) {
@@ -710,6 +850,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
             }
         }
+#endif
         OQ_TOCK(tq_rec);
     }
     wave_sync();
@@ -725,9 +866,33 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     float Minv[21], a0[6];            // inverse of the base's articulated inertia, symmetric storage (sym6)
     {
         float I0[21], p0[6];
+        const int g = H.misc[1];
+#if OQ_ROWSPLIT
+        {   // every half gathers its rows of the chains below the root; the two halves then put the whole matrix together
+            float Dg[6] = {0, 0, 0, 0, 0, 0}, Og[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pg[3] = {0, 0, 0};
+            DQ_UNROLL for (int src = 0; src < 4; ++src) {
+                const int code = src | 8;
+                const bool used = ((g & 15) == code) || (((g >> 4) & 15) == code) || (((g >> 8) & 15) == code) || (((g >> 12) & 15) == code);
+                if (used) {
+                    auto from = [&](float x) { return src == 0 ? quad_bcast<0>(x) : (src == 1 ? quad_bcast<1>(x) : (src == 2 ? quad_bcast<2>(x) : quad_bcast<3>(x))); };
+                    DQ_UNROLL for (int i = 0; i < 6; ++i) Dg[i] += from(Dm[i]);
+                    DQ_UNROLL for (int i = 0; i < 9; ++i) Og[i] += from(Om[i]);
+                    DQ_UNROLL for (int i = 0; i < 3; ++i) pg[i] += from(pO[i]);
+                }
+            }
+            DQ_UNROLL for (int r = 0; r < 3; ++r) {
+                DQ_UNROLL for (int c = r; c < 3; ++c) {
+                    const int k = r == 0 ? c : (r == 1 ? 2 + c : 5);
+                    I0[sym6(r, c)] = oct_lo(Dg[k]);
+                    I0[sym6(3 + r, 3 + c)] = oct_hi(Dg[k]);
+                }
+                DQ_UNROLL for (int c = 0; c < 3; ++c) I0[sym6(r, 3 + c)] = oct_lo(Og[3 * r + c]);
+                p0[r] = oct_lo(pg[r]); p0[3 + r] = oct_hi(pg[r]);
+            }
+        }
+#else
         DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = 0.0f;
         DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = 0.0f;
-        const int g = H.misc[1];
         DQ_UNROLL for (int src = 0; src < 4; ++src) {
             const int code = src | 8;
             const bool used = ((g & 15) == code) || (((g >> 4) & 15) == code) || (((g >> 8) & 15) == code) || (((g >> 12) & 15) == code);
@@ -738,6 +903,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     p0[i] += src == 0 ? quad_bcast<0>(pA[i]) : (src == 1 ? quad_bcast<1>(pA[i]) : (src == 2 ? quad_bcast<2>(pA[i]) : quad_bcast<3>(pA[i])));
             }
         }
+#endif
         // (the base's rotation matrix again from its quaternion: kept from the top of the substep it would cost 9 registers
         //  through the inward pass)
         float R0[9];
@@ -746,9 +912,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             DQ_OPAQUE(qo4[0]);
             quat_to_mat(qo4, R0);
         }
+#if !OQ_ROWSPLIT
         // (the recursion of the inward pass is valid in half 0 only: half 1 takes the gathered inertia over)
         DQ_UNROLL for (int i = 0; i < 21; ++i) I0[i] = LPE == 8 ? oct_lo(I0[i]) : quarter0_all(I0[i]);
         DQ_UNROLL for (int i = 0; i < 6; ++i) p0[i] = LPE == 8 ? oct_lo(p0[i]) : quarter0_all(p0[i]);
+#endif
         const float v0[6] = {ww[0], ww[1], ww[2], vo[0], vo[1], vo[2]}, x0[3] = {0, 0, 0};
         float Ao[6], ho[3], mass;
         const int base_gym = f2i(H.base[10]), base_ngeom = f2i(H.base[11]);

@@ -12,6 +12,7 @@
 //   quad_xor1(x)/quad_xor2 value of x in lane (l ^ 1) / (l ^ 2)                 (quad_perm:[1,0,3,2] / [2,3,0,1])
 //   oct_xor4(x)            value of x in lane (l ^ 4)  (octet kernels)           (row_shl:4 / row_shr:4, complementary bank masks)
 //   oct_lo(x) / oct_hi(x)  value of x in lane (l & ~4) / (l | 4) (octet kernels) (row_shr:4 into the high quads / row_shl:4 into the low quads)
+//   oct_take_lo / _hi(own, src): one half of a limb takes ANOTHER register of the other half's lane, the other half keeps `own`
 //   oct_fetch(x, src)      x of lane (l & ~7) | src of the caller's octet, src per lane (ds_bpermute)
 //   quad_xor1_hi / quad_pair_lo / quad_pair_hi: one-move forms of `cond ? exchanged : own` (below)
 //   wave_any(p)            true in every lane iff p holds in some lane           (v_cmp + s_cmp on the ballot)
@@ -65,6 +66,15 @@ DQ_HD float oct_lo(float x) {
 DQ_HD float oct_hi(float x) {
     const int xi = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x104, 0xF, 0x5, false));
+}
+// selections across the halves of a limb with DIFFERENT registers on the two sides (the row-split recursion of dw_oct.h):
+//   oct_take_lo(own, src)   half-1 lanes take src of lane l - 4, half-0 lanes keep `own`   (row_shr:4 into the high quads)
+//   oct_take_hi(own, src)   half-0 lanes take src of lane l + 4, half-1 lanes keep `own`   (row_shl:4 into the low quads)
+DQ_HD float oct_take_lo(float own, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, src), 0x114, 0xF, 0xA, false));
+}
+DQ_HD float oct_take_hi(float own, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, src), 0x104, 0xF, 0x5, false));
 }
 // selections that a lane-dependent `cond ? exchanged : own` would spend a move AND a select on, as ONE move:
 //   quad_xor1_hi(x)   half-1 lanes (l & 4) take x of lane l ^ 1, half-0 lanes keep their own (bank mask: the high quads of a row)
@@ -273,6 +283,8 @@ DQ_HD float quad_xor2(float x) { return emu_xchg(x, g_emu->cur ^ 2); }
 DQ_HD float oct_xor4(float x) { return emu_xchg(x, g_emu->cur ^ 4); }
 DQ_HD float oct_lo(float x) { return emu_xchg(x, g_emu->cur & ~4); }
 DQ_HD float oct_hi(float x) { return emu_xchg(x, g_emu->cur | 4); }
+DQ_HD float oct_take_lo(float own, float src) { const float t = emu_xchg(src, g_emu->cur & ~4); return (g_emu->cur & 4) ? t : own; }
+DQ_HD float oct_take_hi(float own, float src) { const float t = emu_xchg(src, g_emu->cur | 4); return (g_emu->cur & 4) ? own : t; }
 DQ_HD float quad_xor1_hi(float x) { return emu_xchg(x, (g_emu->cur & 4) ? (g_emu->cur ^ 1) : g_emu->cur); }
 DQ_HD float oct_fetch(float x, int src) { return emu_xchg(x, (g_emu->cur & ~7) | src); }
 DQ_HD float half_bits_to_float(int h) {          // (positive normal numbers and zero: all the tables hold)

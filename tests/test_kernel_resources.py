@@ -92,8 +92,10 @@ def test_terrain_step_kernel_scratch_is_bounded(usage):
     recorded and may not grow (work list: DESIGN.md section 7)."""
     # (100 B with the default machine scheduler, 152 B with the iterative-ilp strategy the octet unit is built with since the end of
     #  round 3: the strategy is worth 2.2 % on the flat step kernel and leaves this kernel's time where it was, 0.216 ms at 16384 envs)
+    # (round 6, row-split recursion of the inward pass: 160 -> 168 B; same-box A/B of the height-field step 0.1612 -> 0.1614 ms,
+    #  gpurun_out/r6a_abt.txt -- within the noise of the pool)
     r = usage["dw_k_step_oct<true>"]
-    assert r["Occupancy"] == 2 and r["ScratchSize"] <= 160, r
+    assert r["Occupancy"] == 2 and r["ScratchSize"] <= 168, r
 
 
 def test_small_kernels_do_not_spill(usage):
