@@ -221,10 +221,11 @@ def _sync(device):
 # ------------------------------------------------------------------------------------------------ the loop
 ROLL_CHAIN = int(os.environ.get("DW_PPO_ROLL_CHAIN", "8"))          # rollout steps per replayed graph
 UPD_CHAIN = int(os.environ.get("DW_PPO_CHAIN", "16"))          # fused updates per replayed graph
+GRAPH_COLLECTIVE = os.environ.get("DW_PPO_GRAPH_COLLECTIVE", "0") == "1"          # sharded fused update: the all-reduce captured inside the graph of updates
 
 
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
-          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False, fused_update=False):
+          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False, fused_update=False, fused_collective=None):
     """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch.
     graph_rollout: one rollout step (policy inference, sampling, env step, bookkeeping) is captured once in a hipGraph and
     replayed `horizon` times per epoch -- possible because dw_step_dev keeps the step counter in device memory, so a replayed
@@ -232,8 +233,12 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     graph_update: one minibatch update (forward, the four losses, backward, unscale, clip, both optimiser steps, scaler update) is
     captured once and replayed 5 x 512 times per epoch; needs the fused, capturable Adam (its update is what GradScaler can skip
     on the device instead of asking the host), one rank.
-    fused_update: the same update as 17 launches -- batched fp16 GEMMs for actor and critic together, the HIP kernels of
-    include/dyros_ppo.h between them (isaacgymdyros_amd/ppo_update.py) -- captured once and replayed; one rank, GPU only."""
+    fused_update: the same update as FOUR launches on the matrix cores (include/dyros_ppo.h, isaacgymdyros_amd/ppo_update.py), captured once
+    and replayed; GPU only.  Sharded (world > 1) every update carries ONE all-reduce of the ranks' 1.61 MB gradient bucket between the
+    weight-gradient launch and the statistics (FusedPpoUpdate.allreduce: where the reference's Horovod optimizer.synchronize() stands,
+    a2c_continuous_seperate.py:171-180): by default the update is then two replayed graphs with the collective enqueued between them;
+    DW_PPO_GRAPH_COLLECTIVE=1 captures the collective inside the chain of updates instead (one replay per UPD_CHAIN updates).
+    fused_collective=True runs that sharded form of the update on ONE rank too (tests: same bits as the plain four launches)."""
     from isaacgymdyros_amd.config import default_cfg
     from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
     cfg = cfg or TRAIN_CFG
@@ -253,14 +258,16 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     net = DyrosActorCritic(env.num_obs, env.num_acts, cfg["network"]).to(device)
     torch.manual_seed(seed + 7919 * rank)            # ... but its own exploration noise (Normal.sample draws from the global generator)
     graph_update = bool(graph_update) and str(device).startswith("cuda") and world == 1
-    fused, upd_chain = None, None
+    fused, upd_chain, upd_tail = None, None, None
     if fused_update:
-        if not str(device).startswith("cuda") or world != 1:
-            raise ValueError("fused_update needs one GPU rank")
+        if not str(device).startswith("cuda"):
+            raise ValueError("fused_update needs a GPU")
         from isaacgymdyros_amd.ppo_update import FusedPpoUpdate
         _b = int(horizon or c["horizon_length"]) * env.num_envs
         _m = min(int(c["minibatch_size"]), _b)
-        fused = FusedPpoUpdate(net, c, _m, _b // _m, device, rowmajor=False)          # (re-points the module's parameters at its master buffer: before any capture)
+        # (re-points the module's parameters at its master buffer: before any capture.  Sharded: every rank starts from the same weights --
+        #  the seed above -- and applies the same averaged gradient, so the ranks stay in step without a broadcast)
+        fused = FusedPpoUpdate(net, c, _m, _b // _m, device, rowmajor=False, world=world, collective=fused_collective)
         graph_update = False
     if graph_update:        # (learning rates as device tensors: the schedule writes them in place and the captured step reads them)
         opt_a = torch.optim.Adam(net.actor_parameters(), lr=torch.tensor(float(c["learning_rate"]), device=device), eps=1e-8, fused=True, capturable=True)
@@ -292,7 +299,7 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     mbs = min(int(c["minibatch_size"]), batch)
     assert batch % mbs == 0, "horizon * num_envs must be a multiple of minibatch_size (a2c_common_dyros.py:192)"
     stats = []
-    graph = None
+    graph, recorder = None, None
     if graph_rollout:
         if not str(device).startswith("cuda") or getattr(env, "_step_dev", None) is None:
             raise ValueError("graph_rollout needs a GPU env with cfg sim.mi355.device_step_counter = True")
@@ -300,7 +307,6 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         g_n = torch.zeros(1, dtype=torch.long, device=device)
         g_terms = torch.zeros(len(names) or 15, device=device)
 
-        recorder = None
         if fused is not None:          # (the step's bookkeeping in two launches instead of ~30: isaacgymdyros_amd/ppo_update.py::RolloutRecorder)
             from isaacgymdyros_amd.ppo_update import RolloutRecorder
             # (static homes of the epoch's flat arrays: a captured update replays their addresses)
@@ -402,6 +408,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             else:
                 advs = discount_values(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
             returns = advs + mb["val"]
+        if graph is not None and recorder is not None:
+            recorder.rows()                                                     # (the device row counter must stand at H: a host read, next to the sync below)
         _sync(device)                                                           # (the rollout's device work is part of play_time in both modes)
         play_time = time.perf_counter() - t0
         # swap_and_flatten01: env-major flat batch, minibatches are contiguous slices (no shuffling in rl_games' dataset)
@@ -467,7 +475,14 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                         done_upd += 1
                 torch.cuda.current_stream(device).wait_stream(side_u)
                 torch.cuda.synchronize()
-                if done_upd < n_upd:
+                if done_upd < n_upd and fused.collective and not GRAPH_COLLECTIVE:
+                    # sharded, the collective outside the graphs: head (dwp_mlp, dwp_wgrad, dwp_grad_bucket) | all-reduce | tail (statistics, Adam)
+                    upd_graph, upd_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
+                        fused.update_head()
+                    with torch.no_grad(), torch.cuda.graph(upd_tail, stream=side_u):
+                        fused.update_tail()
+                elif done_upd < n_upd:
                     upd_graph = torch.cuda.CUDAGraph()
                     with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
                         fused.update()
@@ -484,6 +499,9 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 left -= UPD_CHAIN
             for _ in range(left):
                 upd_graph.replay()
+                if upd_tail is not None:
+                    fused.allreduce()
+                    upd_tail.replay()
             lg = fused.logged()
             a_l, c_l, b_l, cf, kl = lg[0], lg[1], lg[2], lg[3], lg[4]
         srcs = (B["obs"], B["act"], B["neglogp"], B["mu"], adv, ret, val)
@@ -541,15 +559,14 @@ def main():
     ap.add_argument("--num-envs", type=int, default=16384, help="envs per GPU")
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--horizon", type=int, default=None)
-    ap.add_argument("--fused", action="store_true", help="one rank: rollout step and minibatch update replayed from hipGraphs, the update, the rollout's "
-                    "forward, its bookkeeping and GAE as the HIP kernels of include/dyros_ppo.h (10.9 M frames/s at 16384 envs instead of 0.35 M eager)")
+    ap.add_argument("--fused", action="store_true", help="rollout step and minibatch update replayed from hipGraphs, the update, the rollout's "
+                    "forward, its bookkeeping and GAE as the HIP kernels of include/dyros_ppo.h (14.7 M frames/s at 16384 envs on one GPU instead of 0.35 M "
+                    "eager); under torchrun every update carries one RCCL all-reduce of the gradient bucket")
     a = ap.parse_args()
     from isaacgymdyros_amd import dist as dwdist
     rank, local_rank, world = dwdist.init_from_env("nccl")
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
-    if a.fused and world != 1:
-        raise SystemExit("--fused: one rank only (the multi-GPU consumer keeps the autograd update and its bucketed all-reduce)")
     train(a.num_envs, a.epochs, a.horizon, device=dev, rank=rank, world=world, graph_rollout=a.fused, fused_update=a.fused)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -11,7 +11,11 @@
  *   four launches, the products on the matrix cores (0.05 ms per update):
  *     dwp_mlp         observations -> fp16, the three layers of both nets, loss and output gradient, the two input-gradient products, relu
  *                     masks, all bias gradients (v_mfma_f32_16x16x32_f16; weights read in fragment order: dwp_retile, kept by dwp_adam)
- *     dwp_wgrad       the three weight gradients of both nets (fp32 accumulators)
+ *     dwp_wgrad       the three weight gradients of both nets (fp32 accumulators).  DEVIATION from autocast, towards more bits: the weight
+ *                     gradients stay fp32 sums of fp16 products, where a backward under autocast (and the seventeen-launch form) rounds them to
+ *                     fp16 once more and overflows at 65 504.  Consequences: found_inf fires on an overflow of the fp16 output / activation
+ *                     gradients only, so with gradients near the fp16 range GradScaler backs off later than the reference would, and the
+ *                     actor's clip norm is taken from unrounded gradients (differences of relative size 2^-11 per entry).
  *     dwp_grad_stats  bias gradients from their buckets, sum of squares of the actor's unscaled gradients (clip_grad_norm_), inf / nan flags
  *                     of both nets (unscale_)
  *     dwp_adam        unscale, clip (actor), Adam step on the fp32 master parameters unless the net's flag is set, fp16 copies for the
@@ -26,6 +30,9 @@
  *                     bound loss, clip fraction and KL; d loss / d outputs times the loss scale as fp16; the heads' bias gradients
  *     dwp_relu_bwd    d relu in place on a hidden layer's gradient + that layer's bias gradient
  *   and the same dwp_grad_stats / dwp_adam / dwp_finish.
+ * Sharded over the GPUs of a node (one process each) the four-launch form is mlp | wgrad | dwp_grad_bucket | ONE all-reduce of 1.61 MB (RCCL) |
+ * grad_stats | adam_finish: the gradients are averaged while still scaled, before unscale_ / clip / step, as the reference's Horovod
+ * optimizer.synchronize() does (a2c_continuous_seperate.py:171-180).
  * All pointers are device pointers; every function enqueues on `stream` and returns 0, or -1 with dwp_last_error() set.
  *
  * Parameter layout (fp32 masters `p`, fp16 copies `p16`, Adam moments `m`, `v`: the same layout; IN = 487 padded to INP = 512 -- a 974-byte row
@@ -44,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 6
+#define DWP_ABI_VERSION 7
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -95,12 +102,24 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
 #define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */
 #define DWP_PBUF_WORDS 544   /* words of a row of dwp_mlp's accumulators */
 #define DWP_PBUF_BUCKETS 32  /* rows per net: pbuf is [DWP_PBUF_BUCKETS][2][DWP_PBUF_WORDS] floats, zero-initialised by the caller once */
+#define DWP_ROLL_TERMS_MAX 64  /* logged reward columns dwp_rollout_post can reduce (15 on the plane, 15 + terrain types with a curriculum) */
 /* part[0 .. 256) = partial sums over the actor's parameters of (g / scale)^2; state[FOUND_INF + net] = 1 where a gradient of
  * that net is not finite (also per block in part[256 .. 512): bit `net`); part[512 ..] = state's SCALE, STEP[2], LR[2] as they are now
  * (what dwp_adam_finish's blocks read instead of `state`).  pbuf (or NULL): dwp_mlp's accumulators: the bias gradients are their sums over the buckets (cleared here)
  * and are left in gb for dwp_adam (without it gb holds them already: dwp_loss / dwp_relu_bwd).
- * g32 (or NULL): the weight gradients are the sums over dwp_wgrad's partial gradients [DWP_WGRAD_SLABS][weights] instead of g16 */
-int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, void *stream);
+ * g32 (or NULL): the weight gradients are the sums over dwp_wgrad's partial gradients [DWP_WGRAD_SLABS][weights] instead of g16;
+ * g32_slabs: DWP_WGRAD_SLABS for that, or 1: g32 is ONE array of weight gradients (dwp_grad_bucket's bucket after the ranks' all-reduce;
+ * gb then points at its bias part and pbuf is NULL) */
+int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, int32_t g32_slabs, void *stream);
+
+/* Sharded training, one process per GPU: this rank's still-scaled gradient as ONE contiguous bucket [weights | biases] (the parameter order
+ * of p: 401 408 + 1 056 floats = 1.61 MB) times inv_world = 1 / world, so that ONE all-reduce (sum) of the bucket over the ranks leaves the
+ * average in it -- Horovod's optimizer.synchronize() of the reference, which runs before unscale_ / clip_grad_norm_ / step
+ * (learning/rl_games_custom/a2c_continuous_seperate.py:171-180, a2c_common_dyros.py:980-981).  Weights: the sum of dwp_wgrad's slabs in
+ * dwp_grad_stats' order; biases: the sums over pbuf's buckets, which are cleared as dwp_grad_stats would.  The update then goes on with
+ * dwp_grad_stats(NULL, bucket + weights, state, part, NULL, bucket, 1) and dwp_adam_finish(..., gb = bucket + weights, g32 = bucket, 1, ...).
+ * With world a power of two the scaling is exact, so a rank alone (world 1) computes the bits of the unsharded update. */
+int dwp_grad_bucket(const float *g32, float *pbuf, float *bucket, float inv_world, void *stream);
 
 /* the Adam step of torch.optim.Adam(fused, capturable; betas (0.9, 0.999), eps 1e-8, no weight decay) behind GradScaler.step, with
  * clip_grad_norm_(actor, max_norm) applied to the actor's unscaled gradients first (norm^2 = the sum of `part`, published in
@@ -108,13 +127,13 @@ int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, fl
  * by the caller and filled once with dwp_retile).  g32 (or NULL): as dwp_grad_stats.
  * p32f (or NULL): the fp32 fragment-order copy of the weights that dwp_policy reads (DWP_P32F_WORDS floats; filled once with dwp_retile32) */
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm,
-             uint16_t *p16f, const float *g32, float *p32f, void *stream);
+             uint16_t *p16f, const float *g32, int32_t g32_slabs, float *p32f, void *stream);
 
 /* dwp_adam (weight gradients from g32) and dwp_finish in one launch: every block takes the loss scale, step counts, learning rates and
  * flags from `part` as dwp_grad_stats left them, block 0 does dwp_finish's work on `state` meanwhile.  gb is not cleared (with pbuf
  * dwp_grad_stats overwrites it) */
 int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16f,
-                    const float *g32, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream);
+                    const float *g32, int32_t g32_slabs, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
  * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum
@@ -122,8 +141,8 @@ int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb
 int dwp_finish(float *state, float *gb, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream);
 
 /* dwp_stage_obs + the three layers of both nets + dwp_loss + the two input-gradient products with their relu masks and all bias
- * gradients, in ONE launch on the matrix cores (v_mfma_f32_16x16x32_f16): a workgroup of four wavefronts takes 32 samples through one net
- * (every product split four ways by columns), activations
+ * gradients, in ONE launch on the matrix cores (v_mfma_f32_16x16x32_f16): a workgroup of EIGHT wavefronts takes 32 samples through one net
+ * (every product split eight ways by columns: two waves on every SIMD of the CU), activations
  * in LDS, weights from the fragment-order fp16 copy (resident in L2; every request of a wave is one contiguous KB).  What is left of an update after it: the three weight-gradient GEMMs
  * (dout' h2, dz2' h1, dz1' x16: library calls), dwp_grad_stats, dwp_adam, dwp_finish.  Buffers as the other entry points name them;
  * pbuf: the accumulators of the bias gradients and the logged sums (DWP_PBUF_*: a wave adds into the row of its bucket), read and cleared
@@ -144,13 +163,16 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
  *   mb_obs points to HALVES [N][H][DWP_INP], zero-initialised by the caller once: the observations as the update's first layer takes them
  *   (autocast's cast of the Linear input), for DwpMlp.obs16.
  * dwp_rollout_post: mb_rew[n] = rew * reward_scale (+ gamma * value * time_outs: the bootstrap of :656-659; time_outs NULL = off); terms[c] += mean over
- *   the envs of stacked[.][c], c < num_terms (terms NULL = off); g_dones = float(done_buf); g_obs = new_obs (skipped when they are one buffer). */
+ *   the envs of stacked[.][c], c < num_terms <= DWP_ROLL_TERMS_MAX (terms NULL = off); g_dones = float(done_buf); g_obs = new_obs (skipped when they are one buffer).
+ * H: the rows of the rollout buffers.  The row counter n is device memory that a replayed graph advances; a step whose n is outside [0, H)
+ *   -- a caller that did not rewind it -- writes NO row of any buffer (the env still gets its clipped action, g_dones / g_obs are still kept),
+ *   so a forgotten rewind costs recorded samples, never memory outside the buffers. */
 int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
                     int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, int32_t env_major_steps,
-                    int32_t obs_half, void *stream);
+                    int32_t obs_half, int32_t H, void *stream);
 int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
                      const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
-                     float *g_obs, void *stream);
+                     float *g_obs, int32_t H, void *stream);
 
 /* The rollout's policy forward, get_action_values of the reference (fp32: no autocast there): mu [N][ACT] and value [N] of both nets for obs [N][IN], on
  * v_mfma_f32_16x16x4_f32 (the library's fp32 GEMMs take 0.25 ms of a 0.39 ms rollout step at 16384 envs).  p: the fp32 masters (biases), p32f: the weights

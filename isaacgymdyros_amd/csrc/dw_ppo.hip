@@ -209,12 +209,13 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const _Float16 *__restrict__ h
 // over its slabs of samples (g32 [DWP_WGRAD_SLABS][weights], every word written by exactly one wave per update: no atomics, nothing to
 // clear); biases from gb
 constexpr int WG_SLABS = DWP_WGRAD_SLABS;
+template <int SLABS>
 __device__ __forceinline__ float scaled_grad(const _Float16 *g16, const float *g32, const float *gb, int i) {
     if (i >= NWT) return gb[i - NWT];
     if (!g32) return (float)g16[i];
     float s = g32[i];
 #pragma unroll
-    for (int k = 1; k < WG_SLABS; ++k) s += g32[(size_t)k * NWT + i];
+    for (int k = 1; k < SLABS; ++k) s += g32[(size_t)k * NWT + i];
     return s;
 }
 
@@ -222,6 +223,8 @@ constexpr int PART_FLAGS = 256, PART_SNAP = 512;          // `part` [DWP_PARTS]:
 static_assert(DWP_PARTS >= PART_SNAP + 8, "part buffer");
 constexpr int GS_BLOCKS = 256;          // partial sums of squares, one per block, in `part`; dwp_adam's blocks add them up (no atomics: 256
                                         // adds on one word are served one after the other and were most of this kernel's 12 us)
+// SLABS: the slabs of g32 -- DWP_WGRAD_SLABS as dwp_wgrad leaves them, or 1: the ranks' averaged gradient in dwp_grad_bucket's bucket
+template <int SLABS>
 __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__ g16, float *__restrict__ gb, float *__restrict__ state, float *__restrict__ part,
                                                     float *__restrict__ pbuf, const float *__restrict__ g32) {
     __shared__ float red[4];
@@ -235,12 +238,12 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
         // latency long, not one per piece: 6.5 -> 4 us)
         constexpr int NQ = NWT / 4, PER = (NQ + GS_BLOCKS * 256 - 1) / (GS_BLOCKS * 256);
         static_assert(NWT % 4 == 0 && NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0, "a piece of four never crosses a net or a tensor");
-        f4 a[PER][WG_SLABS];
+        f4 a[PER][SLABS];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int q = t + u * GS_BLOCKS * 256, qc = q < NQ ? q : 0;
 #pragma unroll
-            for (int k = 0; k < WG_SLABS; ++k) a[u][k] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT)[qc];
+            for (int k = 0; k < SLABS; ++k) a[u][k] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT)[qc];
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
             if (q < NQ) {
                 f4 s4 = a[u][0];
 #pragma unroll
-                for (int k = 1; k < WG_SLABS; ++k) s4 += a[u][k];          // (the same order as scaled_grad / dwp_adam: the sums are the same numbers)
+                for (int k = 1; k < SLABS; ++k) s4 += a[u][k];          // (the same order as scaled_grad / dwp_adam: the sums are the same numbers)
                 const int net = net_of(4 * q);
                 float s2 = 0.0f;
                 int bad = 0;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
             for (int w = 0; w < PBK; ++w) pc[(size_t)w * 2 * PBW] = 0.0f;
             g = s0;
             gb[q] = g;
-        } else g = scaled_grad(g16, g32, gb, i);
+        } else g = scaled_grad<SLABS>(g16, g32, gb, i);
         if (!isfinite(g)) { if (net) bad1 = 1; else bad0 = 1; }
         const float u = g * inv;
         if (net == 0) sq += u * u;
@@ -298,6 +301,35 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
     }
     if (bad0) state[DWP_S_FOUND_INF] = 1.0f;
     if (bad1) state[DWP_S_FOUND_INF + 1] = 1.0f;
+}
+
+// Sharded training (one process per GPU): this rank's (still scaled) gradient as ONE contiguous bucket for ONE all-reduce -- weights: the
+// sum of dwp_wgrad's slabs, in dwp_grad_stats' order; biases: the sums over dwp_mlp's buckets (cleared here, as dwp_grad_stats would) --
+// times 1 / world, so that the ranks' SUM is the average the reference's Horovod optimizer.synchronize() forms
+// (learning/rl_games_custom/a2c_continuous_seperate.py:171-173) before unscale_ / clip / step.  An inf or nan of any rank survives the
+// sum, so every rank's dwp_grad_stats finds it and every rank skips alike.
+__global__ __launch_bounds__(256) void k_grad_bucket(const float *__restrict__ g32, float *__restrict__ pbuf, float *__restrict__ bucket, float inv_world) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    constexpr int NQ = NWT / 4;
+    if (t < NQ) {
+        f4 a[WG_SLABS];
+#pragma unroll
+        for (int k = 0; k < WG_SLABS; ++k) a[k] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT)[t];
+        f4 s4 = a[0];
+#pragma unroll
+        for (int k = 1; k < WG_SLABS; ++k) s4 += a[k];
+        reinterpret_cast<f4 *>(bucket)[t] = s4 * inv_world;
+    } else if (t - NQ < NBT) {
+        const int q = t - NQ, net = net_of(NWT + q);
+        const int col = q < NB1 ? PB_B1 + q % HID : (q < NB1 + NB2 ? PB_B2 + (q - NB1) % HID : PB_B3 + (q - NB1 - NB2) % OUTP);
+        float *pc = pbuf + (size_t)net * PBW + col;
+        float s0 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < PBK; ++w) s0 += pc[(size_t)w * 2 * PBW];
+#pragma unroll
+        for (int w = 0; w < PBK; ++w) pc[(size_t)w * 2 * PBW] = 0.0f;
+        bucket[NWT + q] = s0 * inv_world;
+    }
 }
 
 // the end of an update, by ONE block of 256 threads (all of them arrive): logged means, GradScaler.update, step counts, minibatch index
@@ -357,7 +389,7 @@ static_assert(NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0 && NB1 % 8 == 0 && NB
 // FIN: the launch also finishes the update (dwp_adam_finish: one graph node less).  Its blocks then read the loss scale, step counts,
 // learning rates and inf / nan flags from `part`, where dwp_grad_stats left them, because block 0 rewrites `state` while the others run.
 struct FinArgs { int B, nmb, growth_interval; float *pbuf; };
-template <bool FIN>
+template <bool FIN, int SLABS>
 __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v,
                                               const _Float16 *__restrict__ g16, const float *__restrict__ gb, float *__restrict__ state, const float *__restrict__ part,
                                               float max_norm, _Float16 *__restrict__ p16f, const float *__restrict__ g32, float *__restrict__ p32f, FinArgs fin) {
@@ -374,13 +406,13 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
 #pragma unroll
         for (int q = 0; q < 8; ++q) gs[q] = gb[ic - NWT + q];
     } else if (g32) {
-        f4 a[WG_SLABS][2];
+        f4 a[SLABS][2];
 #pragma unroll
-        for (int k = 0; k < WG_SLABS; ++k) { a[k][0] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[0]; a[k][1] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[1]; }
+        for (int k = 0; k < SLABS; ++k) { a[k][0] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[0]; a[k][1] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[1]; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) gs[q] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < WG_SLABS; ++k) {
+        for (int k = 0; k < SLABS; ++k) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { gs[q] += a[k][0][q]; gs[4 + q] += a[k][1][q]; }
         }
@@ -923,10 +955,17 @@ __global__ __launch_bounds__(256) void k_gae(const float *__restrict__ fdones, c
 // What play_steps does between the policy's forward and the env step, and after it (learning/rl_games_custom/a2c_common_dyros.py:629-703):
 // sample the action, its neglogp, the step's row of every rollout buffer; then the shaped reward with the time-out bootstrap, the logged
 // reward terms, the new dones and observations.  ~30 torch kernels per step otherwise, for a few KB of arithmetic and two 32 MB copies.
-struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs, env_major_steps, obs_half; };
+struct RollPre { const float *mu, *value, *noise, *obs, *dones, *logstd; const long long *n; float *mb_obs, *mb_act, *mb_mu, *mb_nlp, *mb_val, *mb_done, *act; int N, nobs, env_major_steps, obs_half, H; };
 __global__ __launch_bounds__(256) void k_roll_pre(const RollPre A) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)*A.n, N = A.N;
     const size_t nf4 = N * A.nobs / 4;          // (N * nobs is a multiple of 4: checked by the launcher)
+    // the row counter lives on the device (a replayed graph advances it): a caller that forgot to rewind it must not write past the H rows of
+    // the rollout buffers.  Such a step records nothing and still hands the env its clipped action (checked on the host: RolloutRecorder.rows()).
+    const bool in_rows = (long long)*A.n >= 0 && n < (size_t)A.H;
+    if (!in_rows) {
+        if (i < N * ACT) { const int k = (int)(i % ACT); A.act[i] = fminf(fmaxf(A.mu[i] + expf(A.logstd[k]) * A.noise[i], -1.0f), 1.0f); }
+        return;
+    }
     if (A.obs_half) {
         // mb_obs: halves [N][H][INP] -- what the update's first layer reads (autocast's cast of the Linear input, done here once instead of in
         // every one of the five passes over the batch); a thread = eight consecutive words of a row -> one 16-byte piece (the row's last
@@ -978,26 +1017,29 @@ __global__ __launch_bounds__(256) void k_roll_pre(const RollPre A) {
         A.mb_done[n * N + i] = A.dones[i];
     }
 }
-struct RollPost { const float *rew, *value, *stacked, *new_obs; const long long *time_outs, *done, *n; float *mb_rew, *terms, *g_dones, *g_obs; int N, nobs, nterms, ncols; float scale, gamma; };
+constexpr int ROLL_TERMS_MAX = DWP_ROLL_TERMS_MAX;          // logged reward columns dwp_rollout_post reduces (one thread each)
+struct RollPost { const float *rew, *value, *stacked, *new_obs; const long long *time_outs, *done, *n; float *mb_rew, *terms, *g_dones, *g_obs; int N, nobs, nterms, ncols; float scale, gamma; int H; };
 __global__ __launch_bounds__(256) void k_roll_post(const RollPost A) {
-    __shared__ float red[4][16];
+    __shared__ float red[4][ROLL_TERMS_MAX];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)*A.n, N = A.N;
     const size_t nf4 = N * A.nobs / 4;
+    const bool in_rows = (long long)*A.n >= 0 && n < (size_t)A.H;          // (as k_roll_pre: a row past the buffers is not written)
     if (A.g_obs != A.new_obs && i < nf4) reinterpret_cast<f4 *>(A.g_obs)[i] = reinterpret_cast<const f4 *>(A.new_obs)[i];
     if (i < N) {
         float r = A.rew[i] * A.scale;
         if (A.time_outs) r = r + A.gamma * A.value[i] * (float)A.time_outs[i];          // value_bootstrap (:656-659)
-        A.mb_rew[n * N + i] = r;
+        if (in_rows) A.mb_rew[n * N + i] = r;
         A.g_dones[i] = (float)A.done[i];
     }
-    // the logged reward terms: mean over the envs of the first nterms columns, added to the epoch's sums (blocks that hold envs only)
-    if ((size_t)blockIdx.x * 256 < N && A.terms) {
-        for (int c = 0; c < A.nterms && c < 16; ++c) {
+    // the logged reward terms: mean over the envs of the first nterms columns, added to the epoch's sums (blocks that hold envs only).  With a
+    // terrain curriculum the env reports 15 + terrain types columns (tasks/dyros_dynamic_walk.py:417-421): up to ROLL_TERMS_MAX of them
+    if ((size_t)blockIdx.x * 256 < N && A.terms && in_rows) {
+        for (int c = 0; c < A.nterms && c < ROLL_TERMS_MAX; ++c) {
             const float t = wave_sum(i < N ? A.stacked[i * A.ncols + c] : 0.0f);
             if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = t;
         }
         __syncthreads();
-        if (threadIdx.x < A.nterms && threadIdx.x < 16) atomicAdd(&A.terms[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)N);
+        if (threadIdx.x < A.nterms && threadIdx.x < ROLL_TERMS_MAX) atomicAdd(&A.terms[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)N);
     }
 }
 
@@ -1157,25 +1199,43 @@ int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B
     return done("dwp_relu_bwd");
 }
 
-int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, void *stream) {
-    if ((!g16 && !g32) || !gb || !state || !part) return fail("dwp_grad_stats: bad argument");
-    hipLaunchKernelGGL(k_grad_stats, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part, pbuf, g32);
+static bool slabs_ok(const float *g32, int32_t g32_slabs) { return !g32 || g32_slabs == WG_SLABS || g32_slabs == 1; }
+
+int dwp_grad_stats(const uint16_t *g16, float *gb, float *state, float *part, float *pbuf, const float *g32, int32_t g32_slabs, void *stream) {
+    if ((!g16 && !g32) || !gb || !state || !part || !slabs_ok(g32, g32_slabs)) return fail("dwp_grad_stats: bad argument");
+    if (g32 && g32_slabs == 1) hipLaunchKernelGGL(k_grad_stats<1>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part, pbuf, g32);
+    else hipLaunchKernelGGL(k_grad_stats<WG_SLABS>, dim3(GS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)g16, gb, state, part, pbuf, g32);
     return done("dwp_grad_stats");
 }
 
+int dwp_grad_bucket(const float *g32, float *pbuf, float *bucket, float inv_world, void *stream) {
+    if (!g32 || !pbuf || !bucket || !(inv_world > 0.0f) || inv_world > 1.0f) return fail("dwp_grad_bucket: bad argument");
+    hipLaunchKernelGGL(k_grad_bucket, dim3((NWT / 4 + NBT + 255) / 256), dim3(256), 0, (hipStream_t)stream, g32, pbuf, bucket, inv_world);
+    return done("dwp_grad_bucket");
+}
+
 int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t,
-             const float *g32, float *p32f, void *stream) {
-    if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part) return fail("dwp_adam: bad argument");
-    hipLaunchKernelGGL(k_adam<false>, dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
-                       (_Float16 *)p16t, g32, p32f, FinArgs{0, 0, 0, nullptr});
+             const float *g32, int32_t g32_slabs, float *p32f, void *stream) {
+    if (!p || !p16 || !m || !v || (!g16 && !g32) || !gb || !state || !part || !slabs_ok(g32, g32_slabs)) return fail("dwp_adam: bad argument");
+    if (g32 && g32_slabs == 1)
+        hipLaunchKernelGGL((k_adam<false, 1>), dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
+                           (_Float16 *)p16t, g32, p32f, FinArgs{0, 0, 0, nullptr});
+    else
+        hipLaunchKernelGGL((k_adam<false, WG_SLABS>), dim3((NP / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)g16, gb, state, part, max_norm,
+                           (_Float16 *)p16t, g32, p32f, FinArgs{0, 0, 0, nullptr});
     return done("dwp_adam");
 }
 
 int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16t, const float *g32,
-                    float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream) {
-    if (!p || !p16 || !m || !v || !g32 || !gb || !state || !part || !pbuf || B < 1 || num_minibatches < 1 || growth_interval < 1) return fail("dwp_adam_finish: bad argument");
-    hipLaunchKernelGGL(k_adam<true>, dim3((NP / 8 + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
-                       (_Float16 *)p16t, g32, p32f, FinArgs{B, num_minibatches, growth_interval, pbuf});
+                    int32_t g32_slabs, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream) {
+    if (!p || !p16 || !m || !v || !g32 || !gb || !state || !part || !pbuf || B < 1 || num_minibatches < 1 || growth_interval < 1 || !slabs_ok(g32, g32_slabs))
+        return fail("dwp_adam_finish: bad argument");
+    if (g32_slabs == 1)
+        hipLaunchKernelGGL((k_adam<true, 1>), dim3((NP / 8 + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
+                           (_Float16 *)p16t, g32, p32f, FinArgs{B, num_minibatches, growth_interval, pbuf});
+    else
+        hipLaunchKernelGGL((k_adam<true, WG_SLABS>), dim3((NP / 8 + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
+                           (_Float16 *)p16t, g32, p32f, FinArgs{B, num_minibatches, growth_interval, pbuf});
     return done("dwp_adam_finish");
 }
 
@@ -1203,24 +1263,25 @@ int dwp_gae(const float *fdones, const float *last_values, const float *mb_fdone
 
 int dwp_rollout_pre(const float *mu, const float *value, const float *noise, const float *obs, const float *dones, const float *logstd, const int64_t *n, int32_t N,
                     int32_t num_obs, float *mb_obs, float *mb_act, float *mb_mu, float *mb_nlp, float *mb_val, float *mb_done, float *act, int32_t env_major_steps,
-                    int32_t obs_half, void *stream) {
+                    int32_t obs_half, int32_t H, void *stream) {
     if (!mu || !value || !noise || !obs || !dones || !logstd || !n || !mb_obs || !mb_act || !mb_mu || !mb_nlp || !mb_val || !mb_done || !act || N < 1 || num_obs < ACT ||
-        env_major_steps < 0 || (obs_half && (env_major_steps < 1 || num_obs > INP)))
+        env_major_steps < 0 || (obs_half && (env_major_steps < 1 || num_obs > INP)) || H < 1 || (env_major_steps && env_major_steps != H))
         return fail("dwp_rollout_pre: bad argument");
     if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_pre: N * num_obs must be a multiple of 4");
-    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs, env_major_steps, obs_half};
+    RollPre A{mu, value, noise, obs, dones, logstd, (const long long *)n, mb_obs, mb_act, mb_mu, mb_nlp, mb_val, mb_done, act, N, num_obs, env_major_steps, obs_half, H};
     hipLaunchKernelGGL(k_roll_pre, dim3((unsigned)(((size_t)N * num_obs / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     return done("dwp_rollout_pre");
 }
 
 int dwp_rollout_post(const float *rew, const float *value, const int64_t *time_outs, const float *stacked, int32_t stacked_cols, const int64_t *done_buf, const float *new_obs,
                      const int64_t *n, int32_t N, int32_t num_obs, float reward_scale, float gamma, float *mb_rew, float *terms, int32_t num_terms, float *g_dones,
-                     float *g_obs, void *stream) {
-    if (!rew || !value || !done_buf || !new_obs || !n || !mb_rew || !g_dones || !g_obs || N < 1 || (terms && (!stacked || num_terms < 1 || num_terms > 16 || stacked_cols < num_terms)))
+                     float *g_obs, int32_t H, void *stream) {
+    if (!rew || !value || !done_buf || !new_obs || !n || !mb_rew || !g_dones || !g_obs || N < 1 || H < 1 ||
+        (terms && (!stacked || num_terms < 1 || num_terms > ROLL_TERMS_MAX || stacked_cols < num_terms)))
         return fail("dwp_rollout_post: bad argument");
     if (((size_t)N * num_obs) % 4) return fail("dwp_rollout_post: N * num_obs must be a multiple of 4");
     RollPost A{rew, value, stacked, new_obs, (const long long *)time_outs, (const long long *)done_buf, (const long long *)n, mb_rew, terms, g_dones, g_obs, N, num_obs,
-               num_terms, stacked_cols, reward_scale, gamma};
+               num_terms, stacked_cols, reward_scale, gamma, H};
     // (without the observation copy -- the caller's policy reads the env's own buffer -- the launch covers the envs only)
     const size_t work = g_obs != new_obs ? (size_t)N * num_obs / 4 : (size_t)N;
     hipLaunchKernelGGL(k_roll_post, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);

@@ -229,3 +229,148 @@ def test_operand_order_layouts_are_bijections():
     assert len(np.unique(pos)) == U.HID * U.OUTP and pos.max() < U.HID * 32
     nw = 2 * (U.HID * U.INP + U.HID * U.HID + U.OUTP * U.HID)
     assert U.K["DWP_P32F_WORDS"] == nw and U.K["DWP_P16F_WORDS"] == nw + 2 * U.HID * U.HID + 2 * U.HID * 32
+
+
+def _c_kinds(args: str):
+    """'const float *p, int32_t B, float x, void *stream' -> ['ptr', 'int', 'float', 'ptr']"""
+    kinds = []
+    for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
+        kinds.append("ptr" if "*" in a else ("float" if a.split()[0] == "float" else "int"))
+    return kinds
+
+
+def test_ppo_ctypes_prototypes_match_the_header():
+    """ctypes passes arguments by position and checks nothing: a C signature that gained a parameter while the binding kept the old list hands a
+    kernel the NEXT argument as its pointer (the r5m4 memory fault).  Every dwp_* prototype of include/dyros_ppo.h against
+    the argtypes ppo_update.declare() sets: same count, and pointer / int32 / float in the same places."""
+    import ctypes as C
+    import re
+    from isaacgymdyros_amd import build, ppo_update as U
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dyros_ppo.h")).read(), flags=re.S)
+    protos = {m.group(2): (m.group(1).strip(), m.group(3)) for m in re.finditer(r"\b(int|const char \*)\s*(dwp_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", src)}
+    assert sorted(protos) == sorted("dwp_" + n for n in U.EXPORTS)
+    api = U.declare(C.CDLL(build.build()))
+    for name, (ret, args) in protos.items():
+        f = api[name[4:]]
+        got = ["ptr" if (t is C.c_void_p or t is C.c_char_p or hasattr(t, "contents") or issubclass(t, C._Pointer)) else ("float" if t is C.c_float else "int") for t in f.argtypes]
+        assert got == _c_kinds(args), (name, got, _c_kinds(args))
+        assert (f.restype is C.c_char_p) == (ret != "int"), name
+
+
+def test_kernel_pointer_arguments_are_checked_before_a_launch():
+    """ppo_update._req: what RolloutRecorder.pre / post, FusedPpoUpdate.policy and bind_batch run on every tensor whose data_ptr() goes to a
+    kernel.  A bool mask where the kernel reads int64 would be read 8 x out of bounds: refused on the host, with ValueError."""
+    from isaacgymdyros_amd import ppo_update as U
+    ok = torch.zeros(8, dtype=torch.int64)
+    for bad, kw in ((torch.zeros(8, dtype=torch.bool), dict(numel=8)),          # TocabiAMPLower's timeout_buf as time_outs
+                    (torch.zeros(8, dtype=torch.int32), dict(numel=8)),
+                    (ok[::2], dict(numel=4)),                                      # not contiguous
+                    (ok, dict(numel=16)),                                          # too short for the launch
+                    (torch.zeros(4, 2, dtype=torch.int64), dict(shape=(8, 1))),
+                    ([0] * 8, dict(numel=8))):                                     # not a tensor
+        with pytest.raises(ValueError):
+            U._req("time_outs", bad, torch.int64, **kw)
+    with pytest.raises(ValueError, match="GPU"):
+        U._req("time_outs", ok, torch.int64, 8)          # right type and size, but host memory: no kernel may see its address
+
+
+def test_sharded_fused_update_averages_gradients_with_one_collective_on_gloo(tmp_path):
+    """The N > 1 path of the four-launch update (FusedPpoUpdate(world=2)): dwp_mlp | dwp_wgrad | dwp_grad_bucket | ONE all-reduce of the
+    [weights | biases] bucket | dwp_grad_stats | dwp_adam_finish, the gradients averaged BEFORE the statistics and the step
+    (a2c_continuous_seperate.py:171-180).  CPU, gloo, world 2; the library is a stand-in that works on the raw addresses it is handed (the
+    kernels themselves are GPU tests): each rank's 'weight gradient' depends on its rank, and both ranks must apply the same average."""
+    worker = tmp_path / "w.py"
+    worker.write_text('''
+import ctypes, importlib.util, json, os, sys, types
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from isaacgymdyros_amd import dist as dwdist, ppo_update as U
+spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(%r, "examples", "ppo_consumer.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+rank, _, world = dwdist.init_from_env("gloo")
+NWT, NBT, SL = U.NWT, U.NBT, U.K["DWP_WGRAD_SLABS"]
+view = lambda ptr, n: np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr))
+calls = []
+def wgrad(xf, h1f, h2f, doutf, dz2f, dz1f, st, g32, B, s):
+    calls.append("wgrad")
+    g = view(g32, SL * NWT).reshape(SL, NWT)
+    for k in range(SL):
+        g[k] = (rank + 1) * (k + 1) * (1.0 + (np.arange(NWT) %% 7))          # this rank's partial gradients
+    return 0
+def mlp(args, s):
+    calls.append("mlp")
+    a = ctypes.cast(args, ctypes.POINTER(U.DwpMlp)).contents
+    view(a.pbuf, U.K["DWP_PBUF_BUCKETS"] * 2 * U.K["DWP_PBUF_WORDS"])[:] = 0.25 * (rank + 1)          # bias-gradient buckets
+    return 0
+def grad_bucket(g32, pbuf, bucket, inv_world, s):
+    calls.append("grad_bucket")
+    b = view(bucket, NWT + NBT)
+    b[:NWT] = view(g32, SL * NWT).reshape(SL, NWT).sum(0) * inv_world
+    pb = view(pbuf, U.K["DWP_PBUF_BUCKETS"] * 2 * U.K["DWP_PBUF_WORDS"])
+    b[NWT:] = U.K["DWP_PBUF_BUCKETS"] * pb[0] * inv_world
+    pb[:] = 0.0
+    return 0
+seen = {}
+def grad_stats(g16, gb, st, part, pbuf, g32, slabs, s):
+    calls.append("grad_stats"); seen["stats"] = (g16, gb, pbuf, g32, slabs)
+    return 0
+def adam_finish(p, p16, mm, v, gb, st, part, max_norm, p16t, g32, slabs, p32f, B, nmb, gi, pbuf, s):
+    calls.append("adam_finish"); seen["adam"] = (gb, g32, slabs)
+    view(p, NWT + NBT)[:] -= 0.125 * np.concatenate([view(g32, NWT), view(gb, NBT)])
+    return 0
+noop = lambda *a: 0
+stub = dict(mlp=mlp, wgrad=wgrad, grad_bucket=grad_bucket, grad_stats=grad_stats, adam_finish=adam_finish, retile=noop, retile32=noop,
+            last_error=lambda: b"stub")
+U._lib.load = lambda: (None, None)
+U.declare = lambda lib: stub
+torch.cuda.current_stream = lambda d=None: types.SimpleNamespace(cuda_stream=0)
+n_coll = [0]
+real = dist.all_reduce
+def counted(t, *a, **k):
+    n_coll[0] += 1; seen["numel"] = t.numel()
+    return real(t, *a, **k)
+dist.all_reduce = counted
+torch.manual_seed(0)
+net = m.DyrosActorCritic(U.IN, U.ACT, m.TRAIN_CFG["network"])
+f = U.FusedPpoUpdate(net, dict(m.TRAIN_CFG["config"]), 64, 2, "cpu", rowmajor=False, world=world)
+z = torch.zeros(128)
+f.src = (torch.zeros(128, U.INP, dtype=torch.float16), torch.zeros(128, U.ACT), z, torch.zeros(128, U.ACT), z, z)
+p0 = f.p.clone()
+f.update(); f.update()
+mine = f.p.clone()
+both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+gavg = sum((r + 1) * 10.0 for r in range(world)) / world * (1.0 + (torch.arange(NWT) %% 7).float())          # sum over slabs k + 1 = 10
+bavg = sum(0.25 * (r + 1) for r in range(world)) / world * U.K["DWP_PBUF_BUCKETS"]
+ok_w = bool(torch.allclose(p0[:NWT] - mine[:NWT], 2 * 0.125 * gavg, rtol=1e-6))
+ok_b = bool(torch.allclose(p0[NWT:] - mine[NWT:], torch.full((NBT,), 2 * 0.125 * bavg), rtol=1e-6))
+gb_expected = f.bucket.data_ptr() + 4 * NWT
+json.dump({"same": bool(torch.equal(both[0], both[1])), "ok_w": ok_w, "ok_b": ok_b, "collectives": n_coll[0], "numel": seen["numel"],
+           "order": calls[:5], "stats_args_ok": seen["stats"] == (None, gb_expected, None, f.bucket.data_ptr(), 1),
+           "adam_args_ok": seen["adam"] == (gb_expected, f.bucket.data_ptr(), 1)}, open(os.path.join(sys.argv[1], "f%%d.json" %% rank), "w"))
+dist.barrier(); dist.destroy_process_group()
+''' % (ROOT, ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29747", str(worker), str(tmp_path)], timeout=600, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from isaacgymdyros_amd import ppo_update as U
+    for k in range(2):
+        o = json.load(open(tmp_path / ("f%d.json" % k)))
+        assert o["same"] and o["ok_w"] and o["ok_b"], o
+        assert o["collectives"] == 2 and o["numel"] == U.NWT + U.NBT, o          # ONE all-reduce per update, of the whole bucket
+        assert o["order"] == ["mlp", "wgrad", "grad_bucket", "grad_stats", "adam_finish"] and o["stats_args_ok"] and o["adam_args_ok"], o
+
+
+def test_fused_update_refuses_a_world_it_cannot_serve():
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _mod()
+    c = dict(ppo.TRAIN_CFG["config"])
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"])
+    with pytest.raises(ValueError):
+        U.FusedPpoUpdate(net, c, 4096, 4, "cpu", world=0)
+    with pytest.raises(ValueError):          # the library-GEMM form has no sharded path
+        U.FusedPpoUpdate(net, c, 4096, 4, "cpu", mfma=False, world=2)
+    with pytest.raises(ValueError):          # no process group
+        U.FusedPpoUpdate(net, c, 4096, 4, "cpu", world=2)

@@ -499,3 +499,133 @@ def test_policy_forward_equals_the_module_in_fp32():
                 p_.mul_(1.01)
     f.refresh_copies()
     check()
+
+
+@pytest.mark.gpu
+def test_sharded_form_of_the_update_on_one_rank_is_bit_identical():
+    """FusedPpoUpdate(collective=True): dwp_mlp | dwp_wgrad | dwp_grad_bucket | (all-reduce: nothing to do on one rank) | dwp_grad_stats and
+    dwp_adam_finish on the ONE-slab bucket -- against the plain four launches from the same parameters on the same batch, over clean updates
+    and one that overflows the critic only: weights, moments, every copy of the weights and the state word for word (1 / world = 1 is exact and
+    the slabs are summed in dwp_grad_stats' order); biases to the rounding of their buckets' atomic adds, as everywhere."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(13)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 1024, 4
+    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev)
+    fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, collective=True)
+    assert fb.bucket is not None and fb.bucket.numel() == U.NWT + U.NBT and fa.bucket is None
+    batch = list(_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
+    batch[5] = batch[5].clone()
+    batch[5][2 * B:3 * B] = 3.0e4          # (returns of the third minibatch: the critic's output gradient overflows fp16)
+    for f in (fa, fb):
+        f.set_learning_rates(3e-5, 5e-5)
+        f.bind_batch(*batch)
+    skipped = []
+    for _ in range(nmb + 1):
+        fa.update(); fb.update()
+        torch.cuda.synchronize()
+        skipped.append(fb.logged()[7].item())
+        nw = U.NWT
+        if skipped[-1] == 0.0:          # (an overflowing update has inf / nan entries, which compare unequal to themselves)
+            assert torch.equal(fa.g32, fb.g32)
+            assert torch.equal(fb.bucket[:nw], ((fb.g32[0] + fb.g32[1]) + fb.g32[2]) + fb.g32[3])
+        assert torch.equal(fa.p[:nw], fb.p[:nw]) and torch.equal(fa.m[:nw], fb.m[:nw]) and torch.equal(fa.v[:nw], fb.v[:nw])
+        assert torch.equal(fa.p16[:nw], fb.p16[:nw]) and torch.equal(fa.p16t, fb.p16t) and torch.equal(fa.p32f, fb.p32f)
+        assert float((fa.p[nw:] - fb.p[nw:]).abs().max()) <= 1e-7
+        sa, sb = fa.state.cpu(), fb.state.cpu()
+        o = U.K["DWP_S_OUT"]
+        keep = [i for i in range(U.K["DWP_S_WORDS"]) if not (o <= i < o + 6)]
+        assert torch.equal(sa[keep], sb[keep]), (sa.tolist(), sb.tolist())
+        assert torch.allclose(sa[o:o + 6], sb[o:o + 6], rtol=1e-5, atol=1e-7)
+    assert skipped == [0.0, 0.0, 1.0, 0.0, 0.0]
+    # the bucket path also through the consumer's two replayed graphs with the collective's place between them: same first epochs
+    a = ppo.train(num_envs=256, epochs=2, horizon=16, device=dev, log=lambda s: None, graph_rollout=True, fused_update=True)
+    b = ppo.train(num_envs=256, epochs=2, horizon=16, device=dev, log=lambda s: None, graph_rollout=True, fused_update=True, fused_collective=True)
+    # (the first rollout is the same bits; after it the bias gradients' atomic adds round in launch order, as between two runs of one path)
+    assert a[0]["mean_reward"] == b[0]["mean_reward"]
+    for x, y in zip(a, b):
+        assert abs(x["mean_reward"] - y["mean_reward"]) <= 1e-4 and abs(x["a_loss"] - y["a_loss"]) <= 1e-4 and abs(x["kl"] - y["kl"]) <= 1e-4, (x, y)
+
+
+@pytest.mark.gpu
+def test_update_without_learning_rates_or_batch_is_refused():
+    """a zero learning rate used to advance Adam's moments and step counts while no parameter moved, silently.  The rates now start at
+    the cfg's; a cfg without them must be completed by set_learning_rates() before update()."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    f = U.FusedPpoUpdate(copy.deepcopy(net), c, 64, 2, dev)
+    assert f.state[U.K["DWP_S_LR"]:U.K["DWP_S_LR"] + 2].tolist() == pytest.approx([c["learning_rate"], c["critic_lr"]])
+    with pytest.raises(RuntimeError, match="bind_batch"):
+        f.update()
+    c2 = {k: v for k, v in c.items() if k not in ("learning_rate", "critic_lr")}
+    g = U.FusedPpoUpdate(copy.deepcopy(net), c2, 64, 2, dev)
+    g.bind_batch(*_batch(ppo, copy.deepcopy(net), U, 128, dev))
+    with pytest.raises(RuntimeError, match="learning rates"):
+        g.update()
+    g.set_learning_rates(1e-4, 1e-4)
+    g.update()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_rollout_recorder_refuses_bad_arguments_and_drops_rows_past_the_buffers():
+    """every per-call tensor of pre / post is checked for dtype, size, contiguity and device before its address reaches a
+    kernel -- a bool time-out mask (TocabiAMPLower's timeout_buf) would be read as int64, 8 x out of bounds --; and the device row counter is
+    bounded by H inside the kernels: a replayed rollout graph whose caller forgot to rewind n records nothing instead of writing past every
+    rollout buffer.  Also: 35 logged reward columns (a terrain curriculum's 15 + 20 types) are reduced, where 16 was the limit."""
+    from isaacgymdyros_amd.ppo_update import RolloutRecorder, ACT
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(3)
+    H, N, NOBS, COLS = 3, 512, 487, 35
+    mk = lambda *sh: torch.zeros(*sh, device=dev)
+    mb = dict(obs=mk(H, N, NOBS), act=mk(H, N, ACT), neglogp=mk(H, N), val=mk(H, N, 1), rew=mk(H, N, 1), done=mk(H, N), mu=mk(H, N, ACT))
+    n = torch.zeros(1, dtype=torch.long, device=dev)
+    logstd = torch.full((ACT,), -2.0, device=dev)
+    rec = RolloutRecorder(mb, n, logstd, 1.0, 0.99, True)
+    rnd = lambda *sh: torch.randn(*sh, generator=g, device=dev)
+    mu, value, noise, obs, dones = rnd(N, ACT), rnd(N, 1), rnd(N, ACT), rnd(N, NOBS), mk(N)
+    rew, stacked, new_obs = rnd(N), rnd(N, COLS), rnd(N, NOBS)
+    tout, d = (torch.rand(N, generator=g, device=dev) < 0.1).long(), (torch.rand(N, generator=g, device=dev) < 0.2).long()
+    terms, g_dones, g_obs = mk(COLS), mk(N), mk(N, NOBS)
+    for bad in (dict(mu=mu[:, :12].contiguous()), dict(noise=noise.double()), dict(obs=obs[:, :480].contiguous()), dict(dones=dones.long()), dict(value=value.cpu())):
+        with pytest.raises(ValueError):
+            rec.pre(**dict(dict(mu=mu, value=value, noise=noise, obs=obs, dones=dones), **bad))
+    ok = dict(rew=rew, value=value, time_outs=tout, stacked=stacked, done_buf=d, new_obs=new_obs, terms=terms, g_dones=g_dones, g_obs=g_obs)
+    for bad in (dict(time_outs=tout.bool()), dict(done_buf=d.int()), dict(stacked=stacked.t()), dict(terms=mk(COLS + 1)), dict(terms=mk(65)), dict(rew=rew[:-1]), dict(g_obs=g_obs.half())):
+        with pytest.raises(ValueError):
+            rec.post(**dict(ok, **bad))
+    with pytest.raises(ValueError):
+        RolloutRecorder(dict(mb, act=mk(H, N, 12)), n, logstd, 1.0, 0.99, True)
+    with pytest.raises(ValueError):
+        RolloutRecorder(mb, n.int(), logstd, 1.0, 0.99, True)
+    # H good steps, then two more without a rewind
+    for step in range(H + 2):
+        act = rec.pre(mu, value, noise, obs, dones)
+        rec.post(**ok)
+        n += 1
+        if step == H - 1:
+            torch.cuda.synchronize()
+            assert rec.rows() == H
+            snap = {k: v.clone() for k, v in mb.items()}
+            t_snap = terms.clone()
+    torch.cuda.synchronize()
+    assert float((terms[:COLS] - H * stacked.mean(0)).abs().max()) <= 1e-5 and torch.equal(terms, t_snap)          # (35 columns; nothing added past H)
+    for k in mb:
+        assert torch.equal(mb[k], snap[k]), k
+    assert torch.equal(mb["obs"][H - 1], obs) and float(mb["rew"].abs().max()) > 0
+    assert float((act - torch.clamp(mu + torch.exp(logstd) * noise, -1.0, 1.0)).abs().max()) <= 2e-7          # (the env still gets its action)
+    assert torch.equal(g_obs, new_obs) and torch.equal(g_dones, d.float())
+    with pytest.raises(RuntimeError, match="row counter"):
+        rec.rows()
+    n.fill_(-1)
+    rec.pre(mu, value, noise, obs, dones); rec.post(**ok)
+    torch.cuda.synchronize()
+    for k in mb:
+        assert torch.equal(mb[k], snap[k]), k
