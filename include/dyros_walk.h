@@ -318,7 +318,12 @@ int dw_bind(DwHandle *h, const DwBuffers *buffers);
 int dw_simulate(DwHandle *h, const float *tau, const float *push_xy, void *stream);
 
 /* One VecTask.step.  actions [N,13] (clamped to +-1 inside, vec_task.py:304-307); noise [N,DW_NOISE_WORDS]
- * or NULL; step_index = number of dw_step calls made before this one. */
+ * or NULL; step_index = number of dw_step calls made before this one.  It is expected to advance by ONE per call on a handle: the counter-based
+ * generator is keyed by it, and two pieces of cross-env bookkeeping rotate three slots by it (slot = step_index % 3: this step adds, the next slot is
+ * cleared, the previous one is read) -- the perturbation gate's sums in the CALLER's gate_acc, and the terrain curriculum's logging sums in a
+ * library-owned table.  A repeated or jumped index is legal (replays do it): the library then clears the terrain slot the launch adds into; gate_acc is
+ * caller state like every other bound buffer -- whoever rewinds the step index restores it together with env_state (DyrosDynamicWalk.state_dict /
+ * load_state_dict do), otherwise the gate sees the sums of whatever step last used the slot. */
 int dw_step(DwHandle *h, const float *actions, const float *noise, int64_t step_index, void *stream);
 
 /* The same step with the step counter in DEVICE memory (int64, caller-owned, initialised by the caller): the kernel reads it and

@@ -23,4 +23,5 @@ struct DwHandle {
     int             bound;
     int             has_task;
     int             device;
+    long long       next_step = -1; // host-supplied step index the next dw_step is expected to carry (dw_hip.hip launch_step); -1 = none yet
 };

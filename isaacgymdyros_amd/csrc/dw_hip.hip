@@ -229,6 +229,19 @@ static int launch_step(DwHandle *h, const float *actions, const float *noise, lo
     if (!actions) return fail(DW_EINVAL, "dw_step: actions is null");
     if (step_index < 0) return fail(DW_EINVAL, "dw_step: negative step index");
     DeviceGuard guard(h->device);
+    // The curriculum's logging table rotates three slots by step index: step s adds into slot s % 3 and clears slot (s + 1) % 3, which is
+    // right while the index advances by one per launch.  A caller that repeats or jumps the index would add into a slot nobody cleared (and
+    // repeated adds could carry the 32-bit level sum into the count): the library owns the table, so it clears the slot this launch adds into.
+    // (With a device counter the index advances by itself.  The perturbation gate's slots live in the caller's gate_acc and are the caller's
+    // to restore together with the rest of the state: include/dyros_walk.h.)
+    if (!step_dev) {
+        if (h->d_lvl_acc && h->next_step >= 0 && step_index != h->next_step) {
+            const size_t row = (size_t)h->cfg.terrain_num_types * dw::LVL_BUCKETS;
+            hipError_t e0 = hipMemsetAsync(h->d_lvl_acc + (size_t)(step_index % 3) * row, 0, row * sizeof(unsigned long long), (hipStream_t)stream);
+            if (e0 != hipSuccess) return fail_hip("dw_step: clearing the terrain log slot", e0);
+        }
+        h->next_step = step_index + 1;
+    }
     // (the kernels take the buffer table by value: this launch's copy may name another observation buffer)
     DwBuffers bufs = h->buf;
     if (obs_out) bufs.obs_buf = obs_out;

@@ -43,8 +43,8 @@ using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEO
 
 // Index type of the per-env streams.  Every buffer of the table is addressed as uniform base + 32-bit element index, which the
 // compiler turns into the scalar-base + 32-bit vector-offset form of the global instructions (no 64-bit address arithmetic in the
-// vector pipe: 522 such instructions in the listing of round 4).  The largest stream is obs_buf, 1 948 B per env: the byte offset fits
-// 32 bits up to 2.2 M envs per GPU; config.validate_cfg / dw_create refuse more than 2^20.
+// vector pipe: 522 such instructions in the listing of round 4).  The largest stream is obs_history, 2 960 B per env (obs_buf: 1 948 B): the
+// byte offset fits 32 bits up to 1.45 M envs per GPU; config.validate_cfg / dw_create refuse more than 2^20.
 #if defined(OQ_IX64)
 using OQ_IX = size_t;
 #else

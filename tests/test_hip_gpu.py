@@ -751,8 +751,10 @@ def test_terrain_full_size_rollout_properties():
             if t == 60:          # (a caller's edit of the table between steps is seen by the next step's logging columns)
                 env.terrain_levels[::7] = (env.terrain_levels[::7] + 3) % 10
                 before = env.terrain_levels.clone()
+            if t in (70, 77):    # (a repeated / jumped step index -- a replay -- must not add into a logging slot nobody cleared: ADVICE r5)
+                env._step_count += -1 if t == 70 else 5
             obs, rew, done, extras = env.step(torch.rand(4096, 13, generator=g, device="cuda") * 2 - 1)
-            if t % 10 == 0 or t > 76:
+            if t % 10 == 0 or t > 75:
                 # the curriculum's logging columns as the reference forms them (tasks/dyros_dynamic_walk.py:417-421), from the levels the
                 # step found (compute_reward runs before reset_idx)
                 cols = []
