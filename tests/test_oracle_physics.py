@@ -273,3 +273,169 @@ def test_reset_poses_are_clear_of_self_collision(model):
         assert np.abs(cf[:, 17:]).max() == 0, amp
         if amp == 0.03:
             assert np.abs(cf).max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ pendulum closed forms
+# The oracle is built for the TOCABI tree, so the pendulums are cut out of it: every joint but the one or two under test is locked by an
+# armature of 1e12 kg m^2 (qdd = u / D -> 0), and the base is made an inertial frame by a mass scale of 1e9 (measured: the closed forms
+# are then met to 1e-7; with 1e7 / 1e9 the base's reaction shows at 4e-6).  Parameters of the closed forms come straight from the model JSON (masses, centres of mass, inertias, joint offsets), by the
+# parallel-axis theorem -- none of the oracle's own code.
+L_KNEE, L_ANKLE_PITCH = 3, 4          # dof indices (moving bodies 4, 5): both hinges about +y, so the shank and the foot assembly move in the x-z plane
+
+
+def _ry2(th, v):
+    """Rotation about +y by th of a vector (x, z) of the x-z plane."""
+    x, z = v
+    return np.array([x * np.cos(th) + z * np.sin(th), -x * np.sin(th) + z * np.cos(th)])
+
+
+def _planar_link(model, mvs, origin_mv):
+    """Mass, centre of mass (x, z) and I_yy about that centre of the rigid assembly of moving bodies `mvs` (their joints at 0), in the frame
+    of moving body origin_mv.  The leg's frames are parallel at q = 0 (mv_rot0 = identity there)."""
+    off = {origin_mv: np.zeros(3)}
+    for mv in sorted(mvs):
+        if mv != origin_mv:
+            assert np.allclose(np.array(model.mv_rot0[mv]), np.eye(3))
+            off[mv] = off[model.mv_parent[mv]] + np.array(model.mv_pos[mv])
+    m, mc, recs = 0.0, np.zeros(3), []
+    for i, mv in enumerate(model.inert_mv):
+        if mv in mvs:
+            c = off[mv] + np.array(model.inert_com[i])
+            recs.append((model.inert_mass[i], c, np.array(model.inert_I[i])))
+            m += model.inert_mass[i]; mc += model.inert_mass[i] * c
+    com = mc / m
+    Iyy = sum(I[1][1] + mi * ((c[0] - com[0]) ** 2 + (c[2] - com[2]) ** 2) for mi, c, I in recs)
+    return m, np.array([com[0], com[2]]), Iyy
+
+
+BASE_SCALE = 1e9
+
+
+def _cut_out(sim, free_dofs, base_scale=BASE_SCALE):
+    sim.buf["dof_armature"][:] = 1e12
+    for d in free_dofs:
+        sim.buf["dof_armature"][:, d] = 0.02          # (a value of its own: armature is part of the closed form's inertia)
+    sim.buf["dof_damping"][:] = 0.0
+    sim.buf["mass_scale"][:, sim.model.inert_gym[0]] = base_scale
+    sim.buf["root_states"][:, 2] = 5.0
+
+
+def test_single_pendulum_period_is_the_elliptic_integral(model):
+    """The left shank with its locked foot assembly, hanging from the knee of a base that is pushed with F = M g_eff (gravity off): in the base's
+    frame a physical pendulum in a field g_eff along -x.  Closed form: T = 4 sqrt(I / (m g d)) K(sin^2(A / 2)), I = sum of I_yy + m r^2
+    about the knee axis + armature.  Checks joint-space inertia incl. armature, the gravity-equivalent generalised force and the integrator
+    (semi-implicit Euler's period error is O(dt^2))."""
+    from scipy.special import ellipk
+    sim = OracleSim(1, double=True, gravity=(0.0, 0.0, 0.0), self_collision=0)
+    _cut_out(sim, [L_KNEE])
+    m, com, Icom = _planar_link(model, {4, 5, 6}, 4)
+    d = float(np.hypot(*com))
+    I = Icom + m * d * d + 0.02
+    g_eff = 4.0
+    M_total = float(sum(mi * (BASE_SCALE if model.inert_gym[i] == model.inert_gym[0] else 1.0) for i, mi in enumerate(model.inert_mass)))
+    push = np.array([[M_total * g_eff, 0.0]])
+    # potential V = m g x_w(theta), x_w = X cos + Z sin: stable where the centre of mass points along -x
+    th_eq = float(np.arctan2(-com[1], -com[0]))          # x_w = d cos(theta - atan2(Z, X)) minimal at theta = atan2(Z, X) + pi
+    th_eq = (th_eq + np.pi) % (2 * np.pi) - np.pi
+    A = 0.6
+    sim.buf["dof_state"][0, L_KNEE, 0] = th_eq + A
+    T_closed = 4.0 * np.sqrt(I / (m * g_eff * d)) * ellipk(np.sin(A / 2.0) ** 2)
+    dt, ts, th = 0.002, [], []
+    n = int(2.6 * T_closed / dt)
+    tau = np.zeros((1, 33), np.float32)
+    for k in range(n):
+        sim.simulate(tau, push)
+        ts.append((k + 1) * dt); th.append(float(sim.buf["dof_state"][0, L_KNEE, 0]) - th_eq)
+    th = np.array(th)
+    # downward zero crossings, linearly interpolated: two of them are one period apart
+    idx = [k for k in range(1, n) if th[k - 1] > 0 >= th[k]]
+    assert len(idx) >= 2
+    cross = [ts[k - 1] + (ts[k] - ts[k - 1]) * th[k - 1] / (th[k - 1] - th[k]) for k in idx[:2]]
+    T_sim = cross[1] - cross[0]
+    assert abs(T_sim - T_closed) <= 2e-3 * T_closed, (T_sim, T_closed)
+    assert abs(th.max() - A) <= 2e-3 and abs(th.min() + A) <= 5e-3          # (energy: the amplitude is kept over 2.6 periods)
+    assert np.abs(np.delete(sim.buf["dof_state"][0, :, 0], L_KNEE)).max() < 1e-6          # the locked joints stay locked
+    # the small-angle limit of the same formula, T0 = 2 pi sqrt(I / (m g d)), from a 0.02 rad swing
+    sim2 = OracleSim(1, double=True, gravity=(0.0, 0.0, 0.0), self_collision=0)
+    _cut_out(sim2, [L_KNEE])
+    sim2.buf["dof_state"][0, L_KNEE, 0] = th_eq + 0.02
+    th2 = []
+    T0 = 2 * np.pi * np.sqrt(I / (m * g_eff * d))
+    for k in range(int(1.6 * T0 / dt)):
+        sim2.simulate(tau, push)
+        th2.append(float(sim2.buf["dof_state"][0, L_KNEE, 0]) - th_eq)
+    i2 = [k for k in range(1, len(th2)) if th2[k - 1] > 0 >= th2[k]] + [k for k in range(1, len(th2)) if th2[k - 1] < 0 <= th2[k]]
+    i2.sort()
+    c2 = [(k - 1 + th2[k - 1] / (th2[k - 1] - th2[k])) * dt for k in i2[:2]]
+    assert abs(2.0 * (c2[1] - c2[0]) - T0) <= 2e-3 * T0
+
+
+def test_double_pendulum_accelerations_match_the_closed_form(model):
+    """Shank (knee) + foot assembly (ankle pitch): the compound planar double pendulum.  With absolute angles a = q1, b = q1 + q2, r = the ankle
+    in the shank's frame, c1 / c2 the centres of mass and h(q2) = r . R(q2) c2:
+        M_aa = I1 + m1 |c1|^2 + m2 |r|^2,  M_bb = I2 + m2 |c2|^2,  M_ab = m2 h,
+        M_aa a'' + M_ab b'' + m2 h' b'^2 = tau1 - tau2,   M_ab a'' + M_bb b'' - m2 h' a'^2 = tau2
+    (Lagrange, no gravity), plus armature and the implicit joint damping of DESIGN.md section 3 on the relative coordinates.  Against the oracle's
+    forward dynamics at random states and torques: mass matrix, centrifugal coupling, armature and damping in one go."""
+    rng = np.random.default_rng(5)
+    sim = OracleSim(4, double=True, gravity=(0.0, 0.0, 0.0), self_collision=0)
+    _cut_out(sim, [L_KNEE, L_ANKLE_PITCH])
+    m1, c1, I1 = _planar_link(model, {4}, 4)
+    m2, c2, I2 = _planar_link(model, {5, 6}, 5)
+    r = np.array([model.mv_pos[5][0], model.mv_pos[5][2]])
+    damp = np.array([0.7, 1.9])
+    sim.buf["dof_damping"][:, L_KNEE], sim.buf["dof_damping"][:, L_ANKLE_PITCH] = damp
+    dt = 0.002
+    for e in range(4):
+        q = rng.uniform(-1.5, 1.5, size=2); qd = rng.uniform(-3, 3, size=2); tau2 = rng.uniform(-30, 30, size=2)
+        sim.buf["dof_state"][e, [L_KNEE, L_ANKLE_PITCH], 0] = q
+        sim.buf["dof_state"][e, [L_KNEE, L_ANKLE_PITCH], 1] = qd
+        tau = np.zeros(33, np.float32); tau[[L_KNEE, L_ANKLE_PITCH]] = tau2
+        qdd, a0 = sim.forward_dynamics(e, tau)
+        # (what the oracle was handed: the buffers are float32)
+        tau2 = tau[[L_KNEE, L_ANKLE_PITCH]].astype(float)
+        q = sim.buf["dof_state"][e, [L_KNEE, L_ANKLE_PITCH], 0].astype(float); qd = sim.buf["dof_state"][e, [L_KNEE, L_ANKLE_PITCH], 1].astype(float)
+        damp = sim.buf["dof_damping"][e, [L_KNEE, L_ANKLE_PITCH]].astype(float); arm = sim.buf["dof_armature"][e, [L_KNEE, L_ANKLE_PITCH]].astype(float)
+        h = float(r @ _ry2(q[1], c2))
+        hp = float(r @ np.array([-c2[0] * np.sin(q[1]) + c2[1] * np.cos(q[1]), -c2[0] * np.cos(q[1]) - c2[1] * np.sin(q[1])]))
+        Maa, Mbb, Mab = I1 + m1 * c1 @ c1 + m2 * r @ r, I2 + m2 * c2 @ c2, m2 * h
+        ad, bd = qd[0], qd[0] + qd[1]
+        ca, cb = m2 * hp * bd * bd, -m2 * hp * ad * ad
+        # relative coordinates: q'' = J^-1 (a'', b''), J = [[1, 0], [1, 1]]
+        Mrel = np.array([[Maa + 2 * Mab + Mbb, Mab + Mbb], [Mab + Mbb, Mbb]]) + np.diag(arm + dt * damp)
+        rhs = tau2 - damp * qd - np.array([ca + cb, cb])
+        want = np.linalg.solve(Mrel, rhs)
+        got = qdd[[L_KNEE, L_ANKLE_PITCH]]
+        assert np.abs(got - want).max() <= 5e-7 * max(1.0, np.abs(want).max()), (e, got, want)
+        assert np.abs(np.delete(qdd, [L_KNEE, L_ANKLE_PITCH])).max() < 1e-5 and np.abs(a0).max() < 1e-4          # locked joints, inertial base
+
+
+def test_double_support_load_agrees_with_the_mocap_force_columns(model):
+    """The one reference-held number the contact model can be held to: the mocap table's foot-force targets (columns 34, 35 of
+    assets/DeepMimic/processed_data_tocabi_walk.txt, loaded at tasks/dyros_dynamic_walk.py:112, compared with the measured sole loads after
+    scaling by total_mass / 104.48 at :917).  Over the double-support rows of the gait (:877-879) they are a standing robot's load per foot;
+    the oracle's static stance under PD must carry the same -- plausibility of contact normal force and mass model, not a trajectory pin."""
+    from isaacgymdyros_amd.task_constants import load_task_constants
+    tc = load_task_constants()
+    mocap = np.asarray(tc["mocap"], dtype=np.float64).reshape(-1, 36)
+    target = -mocap[:, 34:36]
+    # the file's own consistency: in every row the two targets add up to the weight of the 104.48 kg robot; in single support one foot has it
+    # all, over the double-support windows (:877-879) it passes from one foot to the other, and at their middle each foot has half
+    assert np.abs(target.sum(1) - 104.48 * 9.81).max() <= 0.01 * 104.48 * 9.81
+    assert np.abs(target[600:1200] - np.array([0.0, 1025.0])).max() < 1.0 and np.abs(target[2400:3000] - np.array([1025.0, 0.0])).max() < 1.0
+    per_foot_ref = float(target[1650:1950].mean())
+    assert abs(per_foot_ref - 0.5 * 104.48 * 9.81) <= 0.01 * per_foot_ref and np.abs(target[1650:1950].mean(0) - per_foot_ref).max() < 0.01 * per_foot_ref
+    sim = OracleSim(1, double=False, self_collision=0)
+    kp, kv = np.asarray(KP_RAW, np.float32), np.asarray(KV_RAW, np.float32)          # (full-strength PD, as test_static_stance_carries_the_weight)
+    q0 = np.asarray(INITIAL_DOF_POS, np.float32)
+    sim.buf["dof_state"][0, :, 0] = q0
+    loads = []
+    for k in range(1500):
+        q, qd = sim.buf["dof_state"][0, :, 0], sim.buf["dof_state"][0, :, 1]
+        sim.simulate((kp * (q0 - q) - kv * qd)[None, :].astype(np.float32))
+        if k >= 1000:
+            loads.append([sim.buf["contact_forces"][0, model.left_foot_idx, 2], sim.buf["contact_forces"][0, model.right_foot_idx, 2]])
+    loads = np.array(loads).mean(0)
+    scale = float(sim.buf["total_mass"][0]) / 104.48          # weight_scale of :917
+    assert abs(loads.sum() - 2 * scale * per_foot_ref) <= 0.02 * 2 * per_foot_ref, (loads, per_foot_ref)
+    assert np.abs(loads - scale * per_foot_ref).max() <= 0.10 * per_foot_ref, (loads, per_foot_ref)          # (a symmetric stance: each foot half, as the table's mid-DSP rows)
