@@ -9,10 +9,9 @@
 // every lane read from the same LDS word into a scalar-register value so that loops and branches that
 // contain regions are provably wave-uniform.
 //
-// The second definition below is NOT a product path: it lets the identical kernel source be compiled
-// by g++ into a lane-loop emulation (tests/emul/), so indexing and synchronisation mistakes are found
-// by the CPU test-suite (and by ASan/UBSan on the host) instead of by a GPU fault that can take a
-// whole node down.  The shipped library (libdyroswalk_hip.so) is built by hipcc from the first one only.
+// This header holds DEVICE code only.  The test-suite compiles the identical kernel source with g++ into a lane-loop emulation, so that
+// indexing and synchronisation mistakes are found on the CPU (and by ASan/UBSan) instead of by a GPU fault that can take a whole node
+// down; that second definition of `Wave` lives with the tests (tests/emul/dw_wave_host.h, named by -DDW_HOST_SHIM_HEADER).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -50,22 +49,8 @@ template <int J> DW_HD float half_bcast(float x) { return __builtin_bit_cast(flo
 DW_HD float lane_bcast(float x, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane)); }
 }  // namespace dw
 #else
-#include <type_traits>
-#define DW_HD static inline
-#define DW_OPAQUE(i) ((void)0)
-#include "dw_quad_wave.h"          // host half: one fiber per lane, run_wave / emu_xchg
-namespace dw {
-struct Wave {
-    template <class F> void par(F &&f) const {
-        for (int lane = 0; lane < 64; ++lane) f(lane);
-    }
-    template <class F> void simt(F &&f) const {
-        using Fn = typename std::remove_reference<F>::type;
-        if (!dwq::run_wave([](void *a, int lane) { (*static_cast<Fn *>(a))(lane); }, (void *)&f)) abort();
-    }
-};
-static inline int uniform(int x) { return x; }
-template <int J> static inline float half_bcast(float x) { return dwq::emu_xchg(x, (dwq::lane_id() & 32) | J); }
-static inline float lane_bcast(float x, int lane) { return dwq::emu_xchg(x, lane); }
-}  // namespace dw
+#if !defined(DW_HOST_SHIM_HEADER)
+#error "dw_wave.h is device code (hipcc).  The host emulation is test infrastructure: tests/emul/dw_wave_host.h, selected with -DDW_HOST_SHIM_HEADER (tests/emul/Makefile)"
+#endif
+#include DW_HOST_SHIM_HEADER
 #endif
