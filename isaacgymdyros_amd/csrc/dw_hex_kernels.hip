@@ -13,6 +13,8 @@
 // slot reads under the previous step's arithmetic (A/B at 4096 envs: -1.7 %; 3 steps per iteration: +2.6 %, 4: as 2; the octet build
 // for two waves per SIMD loses 2 % to it -- a second wave hides that latency already and the longer code costs instruction fetch).
 #define OCT_CHAIN_UNROLL 2
+// spatial 6-vectors of the chain passes and the contact phase as three register pairs on the packed fp32 instructions (dw_limb.h V6)
+#define OQ_PACKED 1
 #include "dw_params.h"
 #include "dw_oct_kernels.h"
 

@@ -42,6 +42,43 @@ DQ_HD F4 ld4(const F4 &p) { return p; }
 #endif
 DQ_HD int f2i(float f) { return __builtin_bit_cast(int, f); }
 
+// ---- spatial 6-vectors as THREE PAIRS (round 6).  gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- two fp32 operations per lane
+// and instruction -- at 5.6 cycles per SIMD where two plain instructions take 9.3 (tools/valu_issue.hip), and the step kernel is bound by
+// vector issue.  The SLP vectoriser forms such pairs from scalar code at the price of moves and registers (612 B of
+// scratch); written as 2-vectors the pairs are the data's own layout -- a 6-vector is (v0 v1)(v2 v3)(v4 v5), a slot row's .xy / .zw are
+// pairs as they come from LDS -- and a scalar factor is the instruction's op_sel broadcast: no moves.  dot6 is then 3 packed + 1 add
+// (instead of 6), a scaled add 3 (instead of 6).  Summation order of a dot product: (0, 2, 4) and (1, 3, 5) side by side, then their sum.
+// OQ_PACKED (set by the translation unit): 1 = the pairs are 2-vectors and compile to the packed instructions -- the hex instantiation
+// (dw_hex_kernels.hip), whose lone wave per SIMD issues a packed instruction in 6.1 cycles against 11.0 for two plain ones: -1.9 % of the
+// step at 4096 envs (same-box A/B, profiles/r06_r6d_packed_ab.txt).  0 = the same arithmetic in the same order on two scalars -- the octet
+// kernels: at two waves per SIMD the count of vector instructions fell 3.8 % (27.0 k -> 26.0 k per wave) and the step time not at all
+// (0.1385 ms both; a packed instruction costs 5.6 cycles there, wait cycles rose 5 %), and the two-waves height-field kernels went from
+// 168 to 208 B of scratch.  (hipcc 7.2 also crashes in the register allocator on dw_k_simulate_oct<true, 2> with the pairs as 2-vectors
+// under -amdgpu-sched-strategy=iterative-ilp.)
+#if !defined(OQ_PACKED)
+#define OQ_PACKED 0
+#endif
+#if defined(__HIPCC__) && OQ_PACKED
+typedef float P2 __attribute__((ext_vector_type(2)));
+DQ_HD P2 mk2(float a, float b) { P2 r = {a, b}; return r; }
+DQ_HD P2 pk_fma(P2 a, P2 b, P2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct P2 { float x, y; };
+DQ_HD P2 mk2(float a, float b) { P2 r; r.x = a; r.y = b; return r; }
+DQ_HD P2 operator*(P2 a, P2 b) { return mk2(a.x * b.x, a.y * b.y); }
+DQ_HD P2 operator+(P2 a, P2 b) { return mk2(a.x + b.x, a.y + b.y); }
+DQ_HD P2 pk_fma(P2 a, P2 b, P2 c) { return mk2(a.x * b.x + c.x, a.y * b.y + c.y); }
+#endif
+struct V6 { P2 a, b, c; };
+DQ_HD V6 v6(float x0, float x1, float x2, float x3, float x4, float x5) { V6 r; r.a = mk2(x0, x1); r.b = mk2(x2, x3); r.c = mk2(x4, x5); return r; }
+DQ_HD V6 v6_zero() { return v6(0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f); }
+DQ_HD V6 v6_from(const float *x) { return v6(x[0], x[1], x[2], x[3], x[4], x[5]); }
+DQ_HD void v6_to(const V6 &v, float *x) { x[0] = v.a.x; x[1] = v.a.y; x[2] = v.b.x; x[3] = v.b.y; x[4] = v.c.x; x[5] = v.c.y; }
+DQ_HD float v6_dot(const V6 &u, const V6 &v) { P2 t = u.a * v.a; t = pk_fma(u.b, v.b, t); t = pk_fma(u.c, v.c, t); return t.x + t.y; }
+DQ_HD void v6_axpy(V6 &y, const V6 &x, float s) { const P2 ss = mk2(s, s); y.a = pk_fma(x.a, ss, y.a); y.b = pk_fma(x.b, ss, y.b); y.c = pk_fma(x.c, ss, y.c); }
+DQ_HD V6 v6_scale(const V6 &x, float s) { const P2 ss = mk2(s, s); V6 r; r.a = x.a * ss; r.b = x.b * ss; r.c = x.c * ss; return r; }
+DQ_HD void v6_add(V6 &y, const V6 &x) { y.a = y.a + x.a; y.b = y.b + x.b; y.c = y.c + x.c; }
+
 // sin and cos for |x| up to a few turns (joint half-angles): Cody-Waite reduction to [-pi/4, pi/4], the classic single-
 // precision minimax polynomials there (~1 ulp).  libm's sincosf spends >100 instructions on arguments this code never sees.
 DQ_HD void sincos_fast(float x, float *s, float *c) {

@@ -35,7 +35,7 @@
 namespace OCT_NS {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
-using dwq::F4; using dwq::mk4; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
+using dwq::F4; using dwq::mk4; using dwq::P2; using dwq::V6; using dwq::v6; using dwq::v6_zero; using dwq::v6_from; using dwq::v6_to; using dwq::v6_dot; using dwq::v6_axpy; using dwq::v6_scale; using dwq::v6_add; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
 using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::oct_take_lo; using dwq::oct_take_hi; using dwq::hex_xor8; using dwq::quarter_take; using dwq::quarter0_all; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
@@ -142,8 +142,14 @@ DQ_HD OPos icode(const QHot &H, int el, int b) {              // a body
     const int co = H.owner[b];
     return pcode_cell(el, co >> 6, co & 63);
 }
+// What a body's four slot rows hold between the inward pass and the end of the substep (round 6: spatial vectors as pairs, dw_limb.h V6 --
+// a row's .xy and .zw are the register pairs of the packed instructions):
+//   row 0 {S0 S1 S2 S3}   row 1 {S4 S5 1/D u}   row 2 {U0 U1 U2 U3}   row 3 {U4 U5 qd *}
+// (S = joint axis as a spatial vector, angular part first; U = IA S).  Outward pass 2 puts the free joint velocity over qd and clears u, the
+// impulse up-sweep puts its d where u was, the final pass leaves row 0 = {q_lo, qd_new, q_hi, *} for the integration.
 #define OQ_SLOT(st, q, p) (*reinterpret_cast<F4 *>(reinterpret_cast<char *>(&L.slot[0][0]) + (((q) & 1) ? (p).o : (p).e) + ((st) * 4 + (q)) * ROWB))
 #define OQ_LD(b, q, p) ldp(OQ_SLOT(b, q, p))
+#define OQ_S6(r0, r1) v6((r0).x, (r0).y, (r0).z, (r0).w, (r1).x, (r1).y)          // S from rows 0, 1 / U from rows 2, 3
 // the loops over the schedule steps stay loops: unrolled, one substep is 100 KB of straight-line code that every wave streams
 // through the 64 KB instruction cache (measured: +5 % step time)
 #if defined(__HIPCC__) && defined(OCT_CHAIN_UNROLL)
@@ -751,10 +757,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
                 DQ_UNROLL for (int r = 0; r < 3; ++r) pO[r] = pa[r];
                 if (X.prim) {          // (half 0: own = angular, oth = linear)
-                    OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(So[0], So[1], So[2], Dinv);
-                    OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(St[0], St[1], St[2], u);
-                    OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(Uo[0], Uo[1], Uo[2], qd_);
-                    OQ_SLOT(T - 1 - sr, 3, X.pos) = mk4(Ut[0], Ut[1], Ut[2], 0.0f);
+                    OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(So[0], So[1], So[2], St[0]);
+                    OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(St[1], St[2], Dinv, u);
+                    OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(Uo[0], Uo[1], Uo[2], Ut[0]);
+                    OQ_SLOT(T - 1 - sr, 3, X.pos) = mk4(Ut[1], Ut[2], qd_, 0.0f);
                 }
             }
         }
@@ -843,10 +849,10 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 }
                 DQ_UNROLL for (int r = 0; r < 6; ++r) pA[r] = pa[r];
                 if (X.prim) {
-                    OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(S[0], S[1], S[2], Dinv);
-                    OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(S[3], S[4], S[5], u);
-                    OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(U[0], U[1], U[2], Mb.qd);
-                    OQ_SLOT(T - 1 - sr, 3, X.pos) = mk4(U[3], U[4], U[5], 0.0f);
+                    OQ_SLOT(T - 1 - sr, 0, X.pos) = mk4(S[0], S[1], S[2], S[3]);
+                    OQ_SLOT(T - 1 - sr, 1, X.pos) = mk4(S[4], S[5], Dinv, u);
+                    OQ_SLOT(T - 1 - sr, 2, X.pos) = mk4(U[0], U[1], U[2], U[3]);
+                    OQ_SLOT(T - 1 - sr, 3, X.pos) = mk4(U[4], U[5], Mb.qd, 0.0f);
                 }
             }
         }
@@ -1024,17 +1030,20 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
             wave_sync();
             {
-                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
-                const float Dinv = s0.w, u = s1.w, qd = s2.w;
+                const V6 S = OQ_S6(s0, s1), U = OQ_S6(s2, s3);
+                const float Dinv = s1.z, u = s1.w, qd = s3.z;
+                V6 aV = v6_from(ar), vV = v6_from(vr);
+                const V6 mV = v6_scale(S, qd);
                 float m[6], c[6];
-                DQ_UNROLL for (int i = 0; i < 6; ++i) m[i] = S[i] * qd;
+                v6_to(mV, m);
                 dw::motion_cross(vr, m, c);                  // parent twist x S qd  (= body twist x S qd)
-                DQ_UNROLL for (int i = 0; i < 6; ++i) { ar[i] += c[i]; vr[i] += m[i]; }
-                const float qdd = (u - dot6(U, ar)) * Dinv;
-                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * qdd;
+                v6_add(aV, v6_from(c)); v6_add(vV, mV);
+                const float qdd = (u - v6_dot(U, aV)) * Dinv;
+                v6_axpy(aV, S, qdd);
+                v6_to(aV, ar); v6_to(vV, vr);
                 if (b >= 0) {
-                    OQ_SLOT(s, 2, X.pos) = mk4(U[0], U[1], U[2], qd + dt * qdd);      // free velocity
-                    OQ_SLOT(s, 1, X.pos) = mk4(S[3], S[4], S[5], 0.0f);                // u is dead: the word becomes the impulse-sweep d
+                    OQ_SLOT(s, 3, X.pos) = mk4(s3.x, s3.y, qd + dt * qdd, 0.0f);      // free velocity
+                    OQ_SLOT(s, 1, X.pos) = mk4(s1.x, s1.y, Dinv, 0.0f);                // u is dead: the word becomes the impulse-sweep d
                 }
             }
         }
@@ -1109,16 +1118,15 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         // ---- free twist of foot f: base + sum over the leg of S qdf (leg lane), shared with the partner ----
         float twf[6];
         {
-            float acc[6] = {wwf[0], wwf[1], wwf[2], vowf[0], vowf[1], vowf[2]};
+            V6 accV = v6(wwf[0], wwf[1], wwf[2], vowf[0], vowf[1], vowf[2]);
             const OPos posf = pcode(H, X.el, f);
             DQ_UNROLL for (int i = 1; i <= 6; ++i) {
                 const int b = T - 7 + i;          // (the legs are right-aligned in the schedule: hip .. sole = steps T - 6 .. T - 1)
-                F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf);
-                OQ_KEEP2(s0, s1);
-                acc[0] += s0.x * s2.w; acc[1] += s0.y * s2.w; acc[2] += s0.z * s2.w;
-                acc[3] += s1.x * s2.w; acc[4] += s1.y * s2.w; acc[5] += s1.z * s2.w;
+                F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s3 = OQ_LD(b, 3, posf);
+                OQ_KEEP2(s1, s3);
+                v6_axpy(accV, OQ_S6(s0, s1), s3.z);
             }
-            DQ_UNROLL for (int i = 0; i < 6; ++i) twf[i] = acc[i];
+            v6_to(accV, twf);
         }
         DQ_STAMP(B, SB + 7);
         // @phase contact_W
@@ -1128,30 +1136,34 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         const int g = X.h ^ f;
         const int mrow_id = X.o < 6 ? X.o : X.o - 6;
         float mrow[6];
-        float Wg[3][6];
+        V6 Wg[3];
         {
-            float dp[3][6], dc[3][6];
-            DQ_UNROLL for (int c = 0; c < 3; ++c) DQ_UNROLL for (int i = 0; i < 6; ++i) dp[c][i] = (i == 3 * part + c) ? -1.0f : 0.0f;
+            V6 dp[3];
+            float dc[3][6];
+            DQ_UNROLL for (int c = 0; c < 3; ++c) { float t[6]; DQ_UNROLL for (int i = 0; i < 6; ++i) t[i] = (i == 3 * part + c) ? -1.0f : 0.0f; dp[c] = v6_from(t); }
             const OPos posf = pcode(H, X.el, f);
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
                 DQ_SCHED_FENCE();
                 const int b = T - 7 + i;
                 F4 s0 = OQ_LD(b, 0, posf), s1 = OQ_LD(b, 1, posf), s2 = OQ_LD(b, 2, posf), s3 = OQ_LD(b, 3, posf);
-                OQ_KEEP3(s1, s2, s3);
-                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                OQ_KEEP2(s1, s3);
+                const V6 S = OQ_S6(s0, s1), U = OQ_S6(s2, s3);
                 DQ_UNROLL for (int c = 0; c < 3; ++c) {
-                    const float d = -dot6(S, dp[c]);
+                    const float d = -v6_dot(S, dp[c]);
                     dc[c][i - 1] = (g == f) ? d : 0.0f;          // (the other leg carries no wrench of its own)
-                    const float k = d * s0.w;
-                    DQ_UNROLL for (int r = 0; r < 6; ++r) dp[c][r] += U[r] * k;
+                    v6_axpy(dp[c], U, d * s1.z);
                 }
             }
-            DQ_UNROLL for (int c = 0; c < 3; ++c)
+            DQ_UNROLL for (int c = 0; c < 3; ++c) {
+                float dpc[6], wr_[6];
+                v6_to(dp[c], dpc);
                 DQ_UNROLL for (int r = 0; r < 6; ++r) {
                     float acc = 0.0f;
-                    DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[sym6(r, k)] * dp[c][k];
-                    Wg[c][r] = acc;
+                    DQ_UNROLL for (int k = 0; k < 6; ++k) acc -= Minv[sym6(r, k)] * dpc[k];
+                    wr_[r] = acc;
                 }
+                Wg[c] = v6_from(wr_);
+            }
             DQ_UNROLL for (int c = 0; c < 6; ++c) {
                 float v = Minv[sym6(0, c)];
                 DQ_UNROLL for (int r = 1; r < 6; ++r) v = (mrow_id == r) ? Minv[sym6(r, c)] : v;
@@ -1162,12 +1174,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 DQ_SCHED_FENCE();
                 const int b = T - 7 + i;
                 F4 s0 = OQ_LD(b, 0, posg), s1 = OQ_LD(b, 1, posg), s2 = OQ_LD(b, 2, posg), s3 = OQ_LD(b, 3, posg);
-                OQ_KEEP3(s1, s2, s3);
-                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
+                OQ_KEEP2(s1, s3);
+                const V6 S = OQ_S6(s0, s1), U = OQ_S6(s2, s3);
                 DQ_UNROLL for (int c = 0; c < 3; ++c) {
-                    const float ua = dot6(U, Wg[c]);
-                    const float qdd = (dc[c][i - 1] - ua) * s0.w;
-                    DQ_UNROLL for (int r = 0; r < 6; ++r) Wg[c][r] += S[r] * qdd;
+                    const float ua = v6_dot(U, Wg[c]);
+                    v6_axpy(Wg[c], S, (dc[c][i - 1] - ua) * s1.z);
                 }
             }
         }
@@ -1188,7 +1199,8 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 const float *r = rk[k];
                 float Tm[3][3];
                 DQ_UNROLL for (int t = 0; t < 3; ++t) {
-                    const float *w = Wg[t];
+                    float w[6];
+                    v6_to(Wg[t], w);
                     Tm[t][0] = w[3] + (w[1] * r[2] - w[2] * r[1]);
                     Tm[t][1] = w[4] + (w[2] * r[0] - w[0] * r[2]);
                     Tm[t][2] = w[5] + (w[0] * r[1] - w[1] * r[0]);
@@ -1238,9 +1250,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
             float lv[6];
             DQ_UNROLL for (int i = 0; i < 6; ++i) lv[i] = quad_xor1_hi(lam[i]);          // (half 1: the other foot's wrench)
+            const V6 lvV = v6_from(lv);
             DQ_UNROLL for (int r = 0; r < 3; ++r) {
-                float acc = 0.0f;
-                DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wg[r][c] * lv[c];
+                const float acc = v6_dot(Wg[r], lvV);
                 tw3[r] = (part ? twf[3 + r] : twf[r]) + (acc + oct_xor4(acc));
             }
         }
@@ -1291,9 +1303,9 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                     cross3(r, d, lam);
                     lam[3] = d[0]; lam[4] = d[1]; lam[5] = d[2];
                     DQ_UNROLL for (int i = 0; i < 6; ++i) lmv[i] = quad_xor1_hi(lam[i]);
+                    const V6 lmV = v6_from(lmv);
                     DQ_UNROLL for (int rr = 0; rr < 3; ++rr) {
-                        float acc = 0.0f;
-                        DQ_UNROLL for (int c = 0; c < 6; ++c) acc += Wg[rr][c] * lmv[c];
+                        const float acc = v6_dot(Wg[rr], lmV);
                         tw3[rr] += acc + oct_xor4(acc);
                     }
                 }
@@ -1316,18 +1328,16 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
                 cross3(rk[k], pw, t);
                 DQ_UNROLL for (int i = 0; i < 3; ++i) { Fs[i] += pw[i]; Nm[i] += t[i]; }
             }
-            float dp[6] = {-Nm[0], -Nm[1], -Nm[2], -Fs[0], -Fs[1], -Fs[2]};
+            V6 dp = v6(-Nm[0], -Nm[1], -Nm[2], -Fs[0], -Fs[1], -Fs[2]);
             DQ_UNROLL for (int i = 6; i >= 1; --i) {
                 const int b = T - 7 + i;
                 F4 s0 = OQ_LD(b, 0, X.pos), s1 = OQ_LD(b, 1, X.pos), s2 = OQ_LD(b, 2, X.pos), s3 = OQ_LD(b, 3, X.pos);
-                OQ_KEEP3(s1, s2, s3);
-                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
-                const float d = -dot6(S, dp);
-                const float k = d * s0.w;
-                DQ_UNROLL for (int r = 0; r < 6; ++r) dp[r] += U[r] * k;
-                OQ_SLOT(b, 1, X.pos) = mk4(S[3], S[4], S[5], d);
+                OQ_KEEP2(s1, s3);
+                const float d = -v6_dot(OQ_S6(s0, s1), dp);
+                v6_axpy(dp, OQ_S6(s2, s3), d * s1.z);
+                OQ_SLOT(b, 1, X.pos) = mk4(s1.x, s1.y, s1.z, d);
             }
-            DQ_UNROLL for (int i = 0; i < 6; ++i) dpb[i] = dp[i];
+            v6_to(dp, dpb);
         }
         {
             float tot[6];
@@ -1381,10 +1391,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             }
             wave_sync();
             {
-                const float S[6] = {s0.x, s0.y, s0.z, s1.x, s1.y, s1.z}, U[6] = {s2.x, s2.y, s2.z, s3.x, s3.y, s3.z};
-                const float dq = (s1.w - dot6(U, ar)) * s0.w;
-                DQ_UNROLL for (int i = 0; i < 6; ++i) ar[i] += S[i] * dq;
-                float qd = s2.w + dq;
+                V6 aV = v6_from(ar);
+                const float dq = (s1.w - v6_dot(OQ_S6(s2, s3), aV)) * s1.z;
+                v6_axpy(aV, OQ_S6(s0, s1), dq);
+                v6_to(aV, ar);
+                float qd = s3.z + dq;
                 if (qd > rc.vmax) qd = rc.vmax;
                 if (qd < -rc.vmax) qd = -rc.vmax;
                 if (b >= 0) OQ_SLOT(s, 0, X.pos) = mk4(rc.qlo, qd, rc.qhi, 0.0f);        // joint range and new velocity for integrate_joints

@@ -104,7 +104,11 @@ void launch_simulate(bool terrain, int wave_build, int num_envs, hipStream_t str
     const dim3 grid(groups(num_envs)), block(64 * WPG);
     const bool sp = spread(num_envs, wave_build);
     if (terrain && sp) hipLaunchKernelGGL((dw_k_simulate_oct<true, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+#if defined(OCT_SKIP_TSIM2)          // (A/B builds only)
+    else if (terrain) hipLaunchKernelGGL((dw_k_simulate_oct<true, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+#else
     else if (terrain) hipLaunchKernelGGL((dw_k_simulate_oct<true, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+#endif
     else if (sp) hipLaunchKernelGGL((dw_k_simulate_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
     else hipLaunchKernelGGL((dw_k_simulate_oct<false, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
 }
