@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 8
+#define DW_ABI_VERSION 9
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -473,6 +473,15 @@ int dw_amp_step_mid(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, co
  * with device_draws = 1); reads the bound root_states / dof_state / contact_forces of h */
 int dw_amp_step_end(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *z, int substep, const float *rootvel_noise,
                     void *stream);
+/* The same step -- dw_amp_step_begin, `substeps` x dw_simulate with dw_amp_step_mid between them, dw_amp_step_end -- as ONE launch (ABI 9; plane
+ * only): the task's code around the octet kernels' physics substep inside one kernel (csrc/dw_oct_kernels.hip dw_k_amp_step_oct), a workgroup of two
+ * wavefronts per 16 envs; what tasks/amp/tocabi_amp_lower_base.py:642-804 does between two policy forwards.  Same arithmetic on the same state in the
+ * same order as the separate entry points: the results are the same bits (tests/test_amp_gpu.py).  z: `substeps` device pointers to the [N,33] encoder
+ * draws of the substeps, in order (the draws do not depend on the physics, so the caller makes them up front, in the order it would have between the
+ * launches); NULL (or NULL entries) with noise = 0 or device_draws = 1.  The handle's step torques are DwAmpBuffers.tau; applied forces (push) are
+ * not part of this entry point, as they are not of the three kernels. */
+int dw_amp_step(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u,
+                const float *const *z, int substeps, const float *rootvel_noise, void *stream);
 /* reset_idx of the listed envs (tasks/amp/tocabi_amp_lower_base.py:238-305 with the default state initialisation, then
  * tasks/tocabi_amp_lower.py:144-147,258-272) as ONE launch instead of ~60 indexed assignments: a wavefront per listed env writes its rows
  * of the Gym tensors (initial pose, zero contact), the reset observation (computed from the episode's last encoder reading, as the

@@ -231,6 +231,31 @@ int dw_amp_step_end(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, co
     return launched("dw_amp_step_end: launch");
 }
 
+// the whole step in one launch (dw_oct_kernels.hip: dw_k_amp_step_oct)
+}  // extern "C"
+namespace dwo {
+void launch_amp_step(int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers &Bf, const DwAmpConfig &C,
+                     const DwAmpBuffers &B, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z, int K, const float *rootvel_noise);
+}
+extern "C" {
+int dw_amp_step(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z,
+                int substeps, const float *rootvel_noise, void *stream) {
+    if (!amp_args_ok(c, b) || !actions_in || substeps < 1 || substeps > 8) return fail(DW_EINVAL, "dw_amp_step: bad configuration, null argument or substeps not in 1..8");
+    if (const char *m = handle_ok(h, c)) { char t[160]; snprintf(t, sizeof t, "dw_amp_step: %s", m); return fail(h && !h->bound ? DW_ESTATE : DW_EINVAL, t); }
+    if (h->cfg.terrain) return fail(DW_EINVAL, "dw_amp_step: the one-launch step is built for the plane (use dw_amp_step_begin / _mid / _end around dw_simulate on terrain)");
+    if (c->vel_change && !c->device_draws && (!ramp_dur || !ramp_u)) return fail(DW_EINVAL, "dw_amp_step: vel_change needs the ramp draws (or device_draws)");
+    if (c->pd_control && (!b->pd_action_offset || !b->pd_action_scale)) return fail(DW_EINVAL, "dw_amp_step: pd_control needs the action offset / scale");
+    if (!c->device_draws) {
+        if (!rootvel_noise) return fail(DW_EINVAL, "dw_amp_step: the root-velocity draws are missing (or device_draws)");
+        if (c->noise) {
+            if (!z) return fail(DW_EINVAL, "dw_amp_step: noise needs the encoder draws of every substep (or device_draws)");
+            for (int k = 0; k < substeps; ++k) if (!z[k]) return fail(DW_EINVAL, "dw_amp_step: noise needs the encoder draws of every substep (or device_draws)");
+        }
+    }
+    dwo::launch_amp_step(c->num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, *c, *b, actions_in, ramp_dur, ramp_u, z, substeps, rootvel_noise);
+    return launched("dw_amp_step: launch");
+}
+
 int dw_amp_reset_rows(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const int64_t *ids, int n, const float *power_scale,
                       const float *rootvel_noise, const float *cmd_x, const float *cmd_y, const float *cmd_yaw, const float *qpos_bias,
                       const float *quat_bias, const int64_t *perturb_timing, const int64_t *delay_idx, void *stream) {

@@ -113,25 +113,31 @@ DW_HD int hist_phys(int head, int logical, int nh) { const int p = head + logica
 // (env, history column), (env, word) -- spread over all threads, so a launch of 16384 envs is 1024 workgroups of four full waves
 // instead of 16384 workgroups of one wave with half its lanes idle (dw_amp_step_begin 20 -> 11 us at 16384 envs).  A region
 // (EnvGroup::par) ends with a workgroup barrier; the same discipline as above holds for what may be read and written where.
+// The group's thread count is a parameter of the group type (round 6): 256 for the three step kernels, 128 = the two wavefronts of an octet
+// workgroup for the one-launch step (dw_k_amp_step_oct, dw_oct_kernels.hip), whose 16 envs are the same 16.  Every function below takes the
+// group as a template argument and names its thread count GT.
 constexpr int GT = 256, GE = 16;
 #if defined(__HIPCC__)
-struct EnvGroup {
+template <int GT_> struct EnvGroupT {
+    static constexpr int GT = GT_;
     template <class F> DW_HD void par(F &&f) const { f((int)threadIdx.x); __syncthreads(); }
 };
 #else
-struct EnvGroup {
-    template <class F> void par(F &&f) const { for (int t = 0; t < GT; ++t) f(t); }
+template <int GT_> struct EnvGroupT {
+    static constexpr int GT = GT_;
+    template <class F> void par(F &&f) const { for (int t = 0; t < GT_; ++t) f(t); }
 };
 #endif
-
-static_assert(GE * 12 + GE * 3 <= GT, "dw_amp_step_begin: one thread per (env, action) and per (env, command component)");
+using EnvGroup = EnvGroupT<GT>;
 struct BeginLds {
     long long i64[GE][2];
 };
 
 // the torques of one substep into DwAmpBuffers.tau (:696-724), items (env, joint).  A later region moves the FIFO counter
 // (every leg item of the env read it).
-DW_HD void torques(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, int e0) {
+template <class WG>
+DW_HD void torques(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, int e0) {
+    constexpr int GT = WG::GT;
     const int N = C.num_envs;
     W.par([&](int t) {
         for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
@@ -177,7 +183,9 @@ DW_HD void torques(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &
 
 // the encoder model after one substep (:728-736), items (env, joint): z = the caller's normal draws [N,33] or nullptr (device
 // draws / no noise)
-DW_HD void encoder(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int e0) {
+template <class WG>
+DW_HD void encoder(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int e0) {
+    constexpr int GT = WG::GT;
     const int N = C.num_envs;
     W.par([&](int t) {
         for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
@@ -199,11 +207,14 @@ DW_HD void encoder(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &
 }
 
 // dw_amp_step_begin: action clamp + record + action history, command ramp (:642-693), then the torques of the first substep.
-DW_HD void step_begin(const EnvGroup &W, BeginLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *actions_in,
+template <class WG>
+DW_HD void step_begin(const WG &W, BeginLds &S, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *actions_in,
                       const int64_t *ramp_dur, const float *ramp_u, int group) {
+    constexpr int GT = WG::GT;
     const int N = C.num_envs, e0 = group * GE, NH = C.num_his * C.num_skip;
-    W.par([&](int t) {
-        // items (env, action): clamp, record, history.  A thread owns column k of the env's action history, so the shifting layout
+    W.par([&](int t0) {
+      for (int t = t0; t < GE * 12 + GE * 3; t += GT) {
+        // items (env, action): clamp, record, history.  An item owns column k of the env's action history, so the shifting layout
         // moves in place without a hazard between threads; the ring writes one slot (its head moves in the next region).
         if (t < GE * 12) {
             const int el = t / 12, k = t - 12 * el, e = e0 + el;
@@ -244,6 +255,7 @@ DW_HD void step_begin(const EnvGroup &W, BeginLds &S, const DwAmpConfig &C, cons
                 if (l == 0) { S.i64[el][0] = dur; S.i64[el][1] = cur + (mask ? 1 : 0); }
             }
         }
+      }
     });
     W.par([&](int t) {
         const int e = e0 + t;
@@ -255,7 +267,8 @@ DW_HD void step_begin(const EnvGroup &W, BeginLds &S, const DwAmpConfig &C, cons
 }
 
 // dw_amp_step_mid: between two substeps -- the encoder model of the one that ended, the torques of the one that starts
-DW_HD void step_mid(const EnvGroup &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int group) {
+template <class WG>
+DW_HD void step_mid(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int group) {
     encoder(W, C, B, dof_state, z, substep, group * GE);
     torques(W, C, B, dof_state, group * GE);
 }
@@ -282,8 +295,11 @@ struct GroupLds {
     int   touch[GE], head[GE][2];
 };
 
-DW_HD void step_end(const EnvGroup &W, GroupLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G, const float *z,
+template <class WG>
+DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G, const float *z,
                     int substep, const float *rootvel_noise, int group) {
+    constexpr int GT = WG::GT;
+    static_assert(GT % 64 == 0 && GT >= 64, "whole wavefronts");
     const int N = C.num_envs, e0 = group * GE;
     const int NH = C.num_his * C.num_skip;
     const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
@@ -354,10 +370,12 @@ DW_HD void step_end(const EnvGroup &W, GroupLds &S, const dw::DevModel &M, const
         }
     });
     // ---- the serial functions, lane = env, one function per wave; counters (:751-752; epi_len: the last line of pre_physics_step)
+    // (four roles; a group of fewer than four wavefronts gives a wavefront several of them in turn)
     W.par([&](int t) {
-        const int el = t & 63, role = t >> 6, e = e0 + el;
+        const int el = t & 63, e = e0 + el;
         if (el >= GE || e >= N) return;
         float *r = S.row[el];
+      for (int role = t >> 6; role < 4; role += GT / 64) {
         if (role == 0 || role == 3) {
             const int f = role == 0 ? 0 : 1;
             float p[3];
@@ -374,11 +392,13 @@ DW_HD void step_end(const EnvGroup &W, GroupLds &S, const dw::DevModel &M, const
             reward_row(r + GR_ROOT, r + GR_DS + 1, 2, r + GR_DVP, r + GR_CMD, r + GR_ACT, r + GR_ACTP, S.eff, r[GR_FZ], r[GR_FZ + 1], B.total_mass[e],
                        B.rew_buf + e, B.reward_values + 9 * (size_t)e);
         }
+      }
     });
     W.par([&](int t) {
-        const int el = t & 63, role = t >> 6, e = e0 + el;
+        const int el = t & 63, e = e0 + el;
         if (el >= GE || e >= N) return;
         const float *r = S.row[el];
+      for (int role = t >> 6; role < 4; role += GT / 64) {
         if (role == 0) {          // termination (:1025-1069)
             const int64_t prog = B.progress_buf[e];
             int64_t term = 0;
@@ -398,6 +418,7 @@ DW_HD void step_end(const EnvGroup &W, GroupLds &S, const dw::DevModel &M, const
         } else if (role == 3) {   // the discriminator observation (tasks/tocabi_amp_lower.py:310-350)
             disc_observations_row(r + GR_ROOT, r + GR_DS, r + GR_DS + 1, 2, C.local_root_obs, r + GR_FOOT, 2, S.row[el] + GR_AMP);
         }
+      }
     });
     // ---- what goes back to memory, items over all threads.  Histories: a thread owns a COLUMN of an env's history (slot s, word k
     //      for all s), so the shifting layout moves in place without a hazard between threads; the ring writes one slot.

@@ -6,6 +6,7 @@
 
 #include "dw_params.h"
 #include "dw_oct_kernels.h"
+#include "dw_amp_step.h"
 
 // The whole VecTask.step of 8 envs per wavefront, 8 lanes per env; a workgroup is two wavefronts that share one copy of the
 // hot tables and nothing else (grid = ceil(N / 16) workgroups of 128 threads).  40 KB of LDS per workgroup: 4 workgroups =
@@ -44,6 +45,34 @@ void dw_k_simulate_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel
     __shared__ dwo::OLds L;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     dwo::oct_simulate<TERRAIN>(L.w[w], L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, make_obuf(HB, &P->B), tau, push, (int)blockIdx.x * dwo::WPG + w);
+}
+
+// The whole TocabiAMPLower step in ONE launch (row f-3; tasks/amp/tocabi_amp_lower_base.py:642-804): the task's regions (dw_amp_step.h:
+// action clamp / history / command ramp / torques | encoder model + next torques | encoder model, counters, foot positions, observation,
+// reward, termination, discriminator observation, histories) around K physics substeps of the octet kernels.  An octet workgroup is two
+// wavefronts = 16 envs, and so is the task code's env group: the same 16 envs, so what one part leaves in the envs' rows in global memory
+// the next part of the same workgroup finds there after a workgroup barrier -- no grid-wide hand-over, no launch boundary.  The task
+// regions run with 128 threads per group (EnvGroupT<128>; the four serial per-env functions two to a wavefront) instead of the 256 of the
+// three separate kernels; LDS is the octet slots and the task's staging rows in turn (a union: 40.9 KB, 8 waves per CU as before).
+// Until round 6 a step was begin | simulate | mid | simulate | end = five launches of a replayed graph (0.206 ms at 16384 envs).
+struct AmpZ { const float *z[8]; };          // the caller's encoder draws, one [N, 33] array per substep (NULL: device draws / no noise)
+__global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dw_k_amp_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwHot HB,
+                       const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u,
+                       const AmpZ Z, const float *rootvel_noise, int K) {
+    static_assert(dwo::WPG == 2 && dwo::EPO * dwo::WPG == dwa::GE, "an octet workgroup and an env group are the same 16 envs");
+    union Lds { dwo::OLds L; dwa::GroupLds G; dwa::BeginLds Bg; __device__ Lds() {} };
+    __shared__ Lds S;
+    using WG = dwa::EnvGroupT<64 * dwo::WPG>;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), group = (int)blockIdx.x;
+    dwa::step_begin(WG(), S.Bg, C, B, G.dof_state, actions_in, ramp_dur, ramp_u, group);
+    for (int k = 0; k < K; ++k) {
+        // (every region ends with a workgroup barrier: the torques of the group's envs are in DwAmpBuffers.tau, the state in the Gym tensors)
+        dwo::oct_simulate<false>(S.L.w[w], S.L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, make_obuf(HB, &P->B), B.tau, nullptr, group * dwo::WPG + w);
+        __syncthreads();
+        if (k + 1 < K) dwa::step_mid(WG(), C, B, G.dof_state, Z.z[k], k, group);
+    }
+    dwa::step_end(WG(), S.G, *M, C, B, G, Z.z[K - 1], K - 1, rootvel_noise, group);
 }
 
 namespace dwq {
@@ -111,6 +140,13 @@ void launch_simulate(bool terrain, int wave_build, int num_envs, hipStream_t str
 #endif
     else if (sp) hipLaunchKernelGGL((dw_k_simulate_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
     else hipLaunchKernelGGL((dw_k_simulate_oct<false, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
+}
+void launch_amp_step(int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers &Bf, const DwAmpConfig &C,
+                     const DwAmpBuffers &B, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z, int K, const float *rootvel_noise) {
+    AmpZ Z;
+    for (int k = 0; k < 8; ++k) Z.z[k] = (z && k < K) ? z[k] : nullptr;
+    const dwa::GymRows G{Bf.root_states, Bf.dof_state, Bf.contact_forces, Bf.dof_damping, Bf.dof_armature};
+    hipLaunchKernelGGL(dw_k_amp_step_oct, dim3(groups(num_envs)), dim3(64 * WPG), 0, stream, QM, M, P, make_hot(Bf), C, B, G, actions_in, ramp_dur, ramp_u, Z, rootvel_noise, K);
 }
 int oct_lds_bytes() { return (int)sizeof(OLds); }
 int sc_park_words() { return SC_PARK_WORDS; }

@@ -302,6 +302,21 @@ class TocabiAMPLower(VecTask):
             raise ValueError("sim.mi355.amp_device_draws needs amp_fused (step and reset)")
         if self._device_draws and self._state_init != "Default":
             raise ValueError("sim.mi355.amp_device_draws: the fused reset covers stateInit 'Default' only")
+        # cfg sim.mi355.amp_one_launch (fused step on the plane; default OFF): the whole step -- the three task kernels and the K physics substeps
+        # between them -- as ONE launch (dw_amp_step, include/dyros_walk.h): same arithmetic in the same order, same bits
+        # (tests/test_amp_gpu.py).  Measured at 16384 envs in a replayed graph: 0.238 ms against 0.206 ms for the five launches
+        # (profiles/r06_amp_one_launch.txt) -- the task code is item loops with a dependent global load per iteration, which the separate
+        # kernels run with 16 wavefronts per CU in flight and the octet workgroup with 8 (its 256 registers per lane allow no more): what the
+        # launch boundaries cost (~20 us) is less than what the lost occupancy costs (~50 us).  Kept as an entry point and a negative result
+        # (DESIGN.md section 9); a win would need the task code rewritten in the walk task's form (requests batched per phase, hot rows in LDS).
+        # (A handle of at most 4096 envs takes the hex instantiation for dw_simulate, whose sums round differently from the octet substep the
+        #  one-launch step carries: comparisons pin sim.mi355.debug_wave_build = 2.)
+        self._one_launch = bool(mi.get("amp_one_launch", False)) and self._fused
+        if self._one_launch and (self._phys.custom_origins or self.control_freq_inv > 8):
+            if "amp_one_launch" in mi and bool(mi["amp_one_launch"]):
+                raise ValueError("sim.mi355.amp_one_launch: the one-launch step is built for the plane and at most 8 substeps")
+            self._one_launch = False
+        self._z_ptrs = None
         self._hist_head = torch.zeros(N, 2, dtype=torch.int32, device=dev)
         self._draw_ctr = torch.zeros(N, dtype=torch.int64, device=dev)
         self._tau = torch.zeros(N, 33, **f)
@@ -737,19 +752,31 @@ class TocabiAMPLower(VecTask):
         if self.vel_change and not dd:
             rd = self._rng.randint(1, 250, (N,))
             ru = torch.stack((self._rand(N), self._rand(N), self._rand(N)), dim=-1).contiguous()
-        self._chk(api["amp_step_begin"](h, C.byref(c), C.byref(b), _p(a), _p(rd), _p(ru), st))
         K = self.control_freq_inv
-        z = None
-        for k in range(K):
-            self._simulate(self._tau, None)
-            z = self._rng.normal((N, 33), 0.00016 / 3.0).contiguous() if self.noise and not dd else None
-            if k + 1 < K:
-                self._chk(api["amp_step_mid"](h, C.byref(c), C.byref(b), _p(z), k + 1, st))
-        self.time_step += 1
-        nz = None
-        if not dd:
-            nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
-        self._chk(api["amp_step_end"](h, C.byref(c), C.byref(b), _p(z), K - 1, _p(nz), st))
+        if self._one_launch:
+            # ONE launch.  The draws do not depend on the physics, so they are made up front, in the order the separate launches make them
+            # between the substeps (z of substep 0 .. K - 1, then the root-velocity noise): the same numbers.
+            zs = [self._rng.normal((N, 33), 0.00016 / 3.0).contiguous() if self.noise and not dd else None for _ in range(K)]
+            nz = None
+            if not dd:
+                nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
+            zp = (C.c_void_p * K)(*[_p(z) for z in zs])
+            self._z_keep = (zs, zp, nz, a, rd, ru)          # (alive until the launch has read them; a captured step keeps them for its replays)
+            self._chk(api["amp_step"](h, C.byref(c), C.byref(b), _p(a), _p(rd), _p(ru), zp, K, _p(nz), st))
+            self.time_step += 1
+        else:
+            self._chk(api["amp_step_begin"](h, C.byref(c), C.byref(b), _p(a), _p(rd), _p(ru), st))
+            z = None
+            for k in range(K):
+                self._simulate(self._tau, None)
+                z = self._rng.normal((N, 33), 0.00016 / 3.0).contiguous() if self.noise and not dd else None
+                if k + 1 < K:
+                    self._chk(api["amp_step_mid"](h, C.byref(c), C.byref(b), _p(z), k + 1, st))
+            self.time_step += 1
+            nz = None
+            if not dd:
+                nz = self._rand(N, 6) * 0.05 - 0.025 if self.noise else torch.zeros(N, 6, device=self._tdev)
+            self._chk(api["amp_step_end"](h, C.byref(c), C.byref(b), _p(z), K - 1, _p(nz), st))
         self.extras["reward_names"] = list(REWARD_NAMES)
         self.extras["reward_values"] = self._reward_values
         self.extras["terminate"] = self._terminate_buf
@@ -776,11 +803,21 @@ class TocabiAMPLower(VecTask):
         (dw_amp_reset_done acts on the envs whose reset_buf is set), queued before the host asks which envs those were."""
         if not (self._device_draws and self._state_init == "Default"):
             return super().reset_done()
+        # The ids go back to the host as a tensor of their own length, so the host has to learn the count: it is asked for BEFORE the reset
+        # launch is queued (a sum into pinned memory + an event), the host then waits for that event only -- the reset kernel runs meanwhile --
+        # and the ids are gathered with the known size (torch.nonzero_static: no second round trip).  (Round 5: done.nonzero() behind the
+        # reset launch, i.e. the host waited for the reset kernel too: 0.094 -> 0.07 ms per call at 16384 envs.)
         done = self.reset_buf.clone()
+        if getattr(self, "_cnt_pin", None) is None:
+            self._cnt_pin = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self._cnt_evt = torch.cuda.Event()
+        self._cnt_pin.copy_(done.ne(0).sum().reshape(1), non_blocking=True)
+        self._cnt_evt.record(torch.cuda.current_stream(self._tdev))
         c, b = self._fused_tables()
         self._chk(self._api["amp_reset_done"](self._phys._h, C.byref(c), C.byref(b), None, self._stream()))
         self.obs_dict["obs"] = self._obs_out
-        ids = done.nonzero(as_tuple=False).flatten()
+        self._cnt_evt.synchronize()
+        ids = torch.nonzero_static(done, size=int(self._cnt_pin[0])).flatten()
         if len(ids) > 0:
             self.time_step = 0          # (as reset_idx: only when some env was reset)
             self._reset_default_env_ids = ids

@@ -541,9 +541,12 @@ def test_tocabi_amp_lower_graph_step_equals_eager():
         e.close()
 
 
+@pytest.mark.parametrize("one_launch", [False, True], ids=["three_kernels", "one_launch"])
 @pytest.mark.parametrize("pd_control,plain", [(False, False), (True, False), (False, True)])
-def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
-    """cfg sim.mi355.amp_fused: the step's bookkeeping in three HIP kernels (dw_amp_step_begin / _mid / _end; histories as rings, in the
+def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain, one_launch):
+    """one_launch (round 6): the whole step -- those three kernels AND the physics substeps between them -- as ONE launch (dw_amp_step; the octet
+    kernels' substep inside, so both envs are pinned to that build of the physics): still the torch form's bits.
+    cfg sim.mi355.amp_fused: the step's bookkeeping in three HIP kernels (dw_amp_step_begin / _mid / _end; histories as rings, in the
     `plain` case in the reference's shifting layout) against the torch implementation of the same class (the branch of the command ramp that draws for every env; itself pinned to the
     reference class by the replay tests above): same seeds and actions for 80 steps with resets in between -- every output and
     every piece of state must be bit-identical.  Episode length 40 so that time-outs and the command ramp (episode step 9) occur."""
@@ -555,10 +558,12 @@ def test_tocabi_amp_lower_fused_step_equals_torch_step(pd_control, plain):
         cfg["env"].update({"episodeLength": 40, "pdControl": pd_control, "numAMPObsSteps": 3})
         if plain:          # no encoder / observation noise, no command ramp, no randomisation: the entry points then get no draws at all
             cfg["task"]["noise"], cfg["task"]["randomize"], cfg["env"]["velChange"] = False, False, False
-        cfg["sim"]["mi355"] = dict({"amp_fused": fused}, **({"amp_hist_ring": not plain} if fused else {}))          # (the rings exist with the fused step only)
+        cfg["sim"]["mi355"] = dict({"amp_fused": fused}, **({"amp_hist_ring": not plain, "amp_one_launch": one_launch} if fused else {}))          # (the rings exist with the fused step only)
+        if one_launch:
+            cfg["sim"]["mi355"]["debug_wave_build"] = 2          # (201 envs would take the hex instantiation: the one-launch step carries the octet substep)
         envs.append(TocabiAMPLower(cfg, "cuda:0", 0, True))
     a, b = envs
-    assert a._hist_ring == (not plain) and not b._hist_ring
+    assert a._hist_ring == (not plain) and not b._hist_ring and a._one_launch == one_launch
     b._capturing = True
     g = torch.Generator(device="cuda").manual_seed(4)
 
@@ -792,7 +797,9 @@ def test_fused_amp_kernels_with_device_draws_equal_their_host_emulation():
              "epi_len", "power_scale", "delay_idx", "simul_len", "qpos_bias", "quat_bias", "progress_buf", "randomize_buf", "reset_buf", "terminate_buf",
              "timeout_buf", "epi_len_log", "perturbation_count", "perturb_timing", "pert_on", "hist_head", "draw_ctr", "action_history", "action_log", "tau",
              "dof_vel_pre", "rigid_body_rot"]
-    close = {"qpos_noise": 2e-9, "qvel_noise": 2e-6, "qpos_pre": 2e-9, "obs1": 2e-5, "obs_buf": 2e-5, "obs_out": 2e-5, "obs_history": 2e-5, "reward_values": 2e-6, "rew_buf": 2e-6, "amp_obs_buf": 2e-6, "amp_obs1": 2e-6, "foot_pos": 2e-6, "rigid_body_pos": 2e-6}
+    # (encoder state: q + noise, where the two sides' noise differs by the rounding of the fast log / cos, ~1e-11 -- enough to round the SUM to the
+    #  neighbouring float now and then: one ulp of a joint angle below 2 rad, 1.2e-7, and that over dt = 0.002 in the rate)
+    close = {"qpos_noise": 1.2e-7, "qvel_noise": 6e-5, "qpos_pre": 1.2e-7, "obs1": 2e-5, "obs_buf": 2e-5, "obs_out": 2e-5, "obs_history": 2e-5, "reward_values": 2e-6, "rew_buf": 2e-6, "amp_obs_buf": 2e-6, "amp_obs1": 2e-6, "foot_pos": 2e-6, "rigid_body_pos": 2e-6}
     rng = np.random.default_rng(5)
     resets = 0
 
