@@ -36,7 +36,7 @@ namespace OCT_NS {
 
 using namespace dw;       // DevModel, PhysParams, small vector helpers
 using dwq::F4; using dwq::mk4; using dwq::P2; using dwq::V6; using dwq::v6; using dwq::v6_zero; using dwq::v6_from; using dwq::v6_to; using dwq::v6_dot; using dwq::v6_axpy; using dwq::v6_scale; using dwq::v6_add; using dwq::ld4; using dwq::f2i; using dwq::QHot; using dwq::QuadModel; using dwq::QInRec;
-using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::oct_take_lo; using dwq::oct_take_hi; using dwq::hex_xor8; using dwq::quarter_take; using dwq::quarter0_all; using dwq::wave_any; using dwq::wave_ballot;
+using dwq::lane_id; using dwq::quad_bcast; using dwq::quad_xor1; using dwq::quad_xor2; using dwq::quad_xor1_hi; using dwq::oct_fetch; using dwq::half_bits_to_float; using dwq::quad_pair_lo; using dwq::quad_pair_hi; using dwq::oct_xor4; using dwq::oct_lo; using dwq::oct_hi; using dwq::oct_take_lo; using dwq::oct_take_hi; using dwq::rs_take; using dwq::rs_all; using dwq::hex_xor8; using dwq::quarter_take; using dwq::quarter0_all; using dwq::wave_any; using dwq::wave_ballot;
 using dwq::wave_sync; using dwq::wave_sync_global; using dwq::atomic_add_u64; using dwq::rcp_fast; using dwq::sincos_fast; using dwq::qmul; using dwq::quad_bcast_arr; using dwq::quad_take_arr; using dwq::over_1n;
 using dwq::geom_force; using dwq::rigid_inertia; using dwq::rigid_inertia_pre; using dwq::add_rigid; using dwq::seg_seg; using dwq::seg_dist2_fast; using dwq::capsule_pair;
 using dwq::QS_MAX; using dwq::QMAX_OWN; using dwq::QMAX_GYM; using dwq::QMAX_GEOM;
@@ -90,8 +90,9 @@ constexpr int NQ = LPE / 4;          // quads ("halves" / quarters) of an env
 #endif
 constexpr int WPG = OCT_WPG;         // wavefronts per workgroup (they share the hot tables, nothing else)
 // The articulated recursion of the inward pass with its spatial ROWS split between the two halves of a limb (octet layout; round 6):
-// half 0 keeps the angular rows of IA / pA, half 1 the linear rows (dw_oct.h "inward pass").  The hex instantiation keeps the mirrored form.
-#if OCT_LPE == 8 && !defined(OCT_NO_ROWSPLIT)
+// half 0 keeps the angular rows of IA / pA, half 1 the linear rows (dw_oct.h "inward pass").  In the hex instantiation quarters 0 and 1 of an env
+// are that pair (quarters 2 and 3 run the same instructions on values nobody reads); -DOCT_NO_ROWSPLIT builds the mirrored form of round 5.
+#if !defined(OCT_NO_ROWSPLIT)
 #define OQ_ROWSPLIT 1
 #else
 #define OQ_ROWSPLIT 0
@@ -524,7 +525,7 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
     DQ_UNROLL for (int i = 0; i < 6; ++i) Dm[i] = 0.0f;
     DQ_UNROLL for (int i = 0; i < 9; ++i) Om[i] = 0.0f;
     DQ_UNROLL for (int i = 0; i < 3; ++i) pO[i] = 0.0f;
-    const float hsgn = X.h ? -1.0f : 1.0f;          // my off-diagonal block of a rigid inertia is skew(ho) (half 0) or its transpose (half 1)
+    const float hsgn = (X.q & 1) ? -1.0f : 1.0f;          // my off-diagonal block of a rigid inertia is skew(ho) (half 0) or its transpose (half 1)
 #else
     float IA[21], pA[6];          // running reflected inertia / bias (no lane parks a second one: build_quadmodel(accumulate))
     DQ_UNROLL for (int i = 0; i < 21; ++i) IA[i] = 0.0f;
@@ -649,34 +650,27 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
         wave_sync();          // every map has read its slot rows before the recursion overwrites any
         OQ_TOCK(tq_map); OQ_TICK();
 #if OQ_ROWSPLIT
-        // ---- recursion: step s on half 0's map, then step s + 1 on half 1's, rows split over the halves ----
-        DQ_UNROLL for (int t2 = 0; t2 < 2; ++t2) {
+        // ---- recursion: step s + t2 on the map quarter t2 made, rows split over the working pair ----
+        DQ_UNROLL for (int t2 = 0; t2 < NQ; ++t2) {
             const int sr = s + t2;
             if (sr >= T) break;
-            // the step's map in own / oth form: made by half t2, taken by the other half
+            // the step's map in own / oth form: made by quarter t2, taken by the pair's two lanes (rs_take: a for half 0, b for half 1)
             float So[3], St[3], co[3], ct[3], pvo[3], Da[6], hs[3], tt_, dd_, qd_;
-            if (t2 == 0) {
-                DQ_UNROLL for (int i = 0; i < 3; ++i) {
-                    So[i] = oct_take_lo(Mb.S[i], Mb.S[3 + i]);   St[i] = oct_take_lo(Mb.S[3 + i], Mb.S[i]);
-                    co[i] = oct_take_lo(Mb.cb[i], Mb.cb[3 + i]); ct[i] = oct_take_lo(Mb.cb[3 + i], Mb.cb[i]);
-                    pvo[i] = oct_take_lo(Mb.pv[i], Mb.pv[3 + i]);
-                    hs[i] = hsgn * oct_lo(Mb.ho[i]);
-                }
-                // (my diagonal block of the rigid inertia: Ao in half 0, mass * 1 in half 1)
-                Da[0] = oct_take_lo(Mb.Ao[0], Mb.mass); Da[3] = oct_take_lo(Mb.Ao[3], Mb.mass); Da[5] = oct_take_lo(Mb.Ao[5], Mb.mass);
-                Da[1] = X.h ? 0.0f : Mb.Ao[1]; Da[2] = X.h ? 0.0f : Mb.Ao[2]; Da[4] = X.h ? 0.0f : Mb.Ao[4];
-                tt_ = oct_lo(Mb.tt); dd_ = oct_lo(Mb.dd); qd_ = Mb.qd;
-            } else {
-                DQ_UNROLL for (int i = 0; i < 3; ++i) {
-                    So[i] = oct_take_hi(Mb.S[3 + i], Mb.S[i]);   St[i] = oct_take_hi(Mb.S[i], Mb.S[3 + i]);
-                    co[i] = oct_take_hi(Mb.cb[3 + i], Mb.cb[i]); ct[i] = oct_take_hi(Mb.cb[i], Mb.cb[3 + i]);
-                    pvo[i] = oct_take_hi(Mb.pv[3 + i], Mb.pv[i]);
-                    hs[i] = hsgn * oct_hi(Mb.ho[i]);
-                }
-                Da[0] = oct_take_hi(Mb.mass, Mb.Ao[0]); Da[3] = oct_take_hi(Mb.mass, Mb.Ao[3]); Da[5] = oct_take_hi(Mb.mass, Mb.Ao[5]);
-                Da[1] = oct_take_hi(0.0f, Mb.Ao[1]); Da[2] = oct_take_hi(0.0f, Mb.Ao[2]); Da[4] = oct_take_hi(0.0f, Mb.Ao[4]);
-                tt_ = oct_hi(Mb.tt); dd_ = oct_hi(Mb.dd); qd_ = oct_hi(Mb.qd);
+            auto take = [&](float a, float b) {
+                return t2 == 0 ? rs_take<LPE, 0>(a, b) : (t2 == 1 ? rs_take<LPE, 1>(a, b) : (t2 == 2 ? rs_take<LPE, (LPE == 16 ? 2 : 0)>(a, b) : rs_take<LPE, (LPE == 16 ? 3 : 0)>(a, b)));
+            };
+            DQ_UNROLL for (int i = 0; i < 3; ++i) {
+                So[i] = take(Mb.S[i], Mb.S[3 + i]);   St[i] = take(Mb.S[3 + i], Mb.S[i]);
+                co[i] = take(Mb.cb[i], Mb.cb[3 + i]); ct[i] = take(Mb.cb[3 + i], Mb.cb[i]);
+                pvo[i] = take(Mb.pv[i], Mb.pv[3 + i]);
+                hs[i] = hsgn * take(Mb.ho[i], Mb.ho[i]);
             }
+            {   // (my diagonal block of the rigid inertia: Ao in half 0, mass * 1 in half 1)
+                const float zero = 0.0f;
+                Da[0] = take(Mb.Ao[0], Mb.mass); Da[3] = take(Mb.Ao[3], Mb.mass); Da[5] = take(Mb.Ao[5], Mb.mass);
+                Da[1] = take(Mb.Ao[1], zero); Da[2] = take(Mb.Ao[2], zero); Da[4] = take(Mb.Ao[4], zero);
+            }
+            tt_ = take(Mb.tt, Mb.tt); dd_ = take(Mb.dd, Mb.dd); qd_ = take(Mb.qd, Mb.qd);
             const int bits = f2i(H.in[sr][j][0]);
             const int b = (bits & 255) - 1;
             const int flags = b >= 0 ? ((bits >> 8) & 7) : 0;
@@ -889,11 +883,11 @@ DQ_HD void oct_substep(OSlots &L, const QHot &H, const QuadModel &QM, const DevM
             DQ_UNROLL for (int r = 0; r < 3; ++r) {
                 DQ_UNROLL for (int c = r; c < 3; ++c) {
                     const int k = r == 0 ? c : (r == 1 ? 2 + c : 5);
-                    I0[sym6(r, c)] = oct_lo(Dg[k]);
-                    I0[sym6(3 + r, 3 + c)] = oct_hi(Dg[k]);
+                    I0[sym6(r, c)] = rs_all<LPE, 0>(Dg[k]);
+                    I0[sym6(3 + r, 3 + c)] = rs_all<LPE, 1>(Dg[k]);
                 }
-                DQ_UNROLL for (int c = 0; c < 3; ++c) I0[sym6(r, 3 + c)] = oct_lo(Og[3 * r + c]);
-                p0[r] = oct_lo(pg[r]); p0[3 + r] = oct_hi(pg[r]);
+                DQ_UNROLL for (int c = 0; c < 3; ++c) I0[sym6(r, 3 + c)] = rs_all<LPE, 0>(Og[3 * r + c]);
+                p0[r] = rs_all<LPE, 0>(pg[r]); p0[3 + r] = rs_all<LPE, 1>(pg[r]);
             }
         }
 #else

@@ -111,6 +111,36 @@ DQ_HD float quarter0_all(float x) {
     r = __builtin_amdgcn_update_dpp(r, xi, 0x11C, 0xF, 0x8, false);               // row_shr:12 into bank 3
     return __builtin_bit_cast(float, r);
 }
+// The row-split recursion's hand-over for both layouts.  An env's working PAIR is its quarters 0 and 1 (LPE = 8: its two halves); the lane of
+// half 0 wants register a, the lane of half 1 register b, of the lane of quarter K of its limb (K < LPE / 4).  One move per word where the
+// source quarter is in the pair (it keeps its own), two where it is not (hex, K = 2, 3); quarters 2, 3 of a hex env get values nobody reads.
+template <int LPE_, int K> DQ_HD float rs_take(float a, float b) {
+    static_assert((LPE_ == 8 && K < 2) || (LPE_ == 16 && K < 4), "rs_take: quarter out of range");
+    const int ai = __builtin_bit_cast(int, a), bi = __builtin_bit_cast(int, b);
+    int r;
+    if (LPE_ == 8) {
+        r = K == 0 ? __builtin_amdgcn_update_dpp(ai, bi, 0x114, 0xF, 0xA, false) : __builtin_amdgcn_update_dpp(bi, ai, 0x104, 0xF, 0x5, false);
+    } else if (K == 0) {
+        r = __builtin_amdgcn_update_dpp(ai, bi, 0x114, 0xF, 0x2, false);          // quarter 1 takes b of lane l - 4
+    } else if (K == 1) {
+        r = __builtin_amdgcn_update_dpp(bi, ai, 0x104, 0xF, 0x1, false);          // quarter 0 takes a of lane l + 4
+    } else {
+        r = __builtin_amdgcn_update_dpp(ai, ai, 0x100 + 4 * K, 0xF, 0x1, false);          // quarter 0: a of lane l + 4 K
+        r = __builtin_amdgcn_update_dpp(r, bi, 0x100 + 4 * (K - 1), 0xF, 0x2, false);       // quarter 1: b of lane l + 4 (K - 1)
+    }
+    return __builtin_bit_cast(float, r);
+}
+// x of the quarter-K lane of my limb in EVERY lane of the env (K = 0, 1: the working pair's two lanes)
+template <int LPE_, int K> DQ_HD float rs_all(float x) {
+    static_assert(K < 2, "rs_all: the pair's quarters");
+    if (LPE_ == 8) return K == 0 ? oct_lo(x) : oct_hi(x);
+    if (K == 0) return quarter0_all(x);
+    const int xi = __builtin_bit_cast(int, x);
+    int r = __builtin_amdgcn_update_dpp(xi, xi, 0x104, 0xF, 0x1, false);          // row_shl:4 into quarter 0
+    r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0x4, false);               // row_shr:4 into quarter 2
+    r = __builtin_amdgcn_update_dpp(r, xi, 0x118, 0xF, 0x8, false);               // row_shr:8 into quarter 3
+    return __builtin_bit_cast(float, r);
+}
 DQ_HD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 DQ_HD unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // bit l = p of lane l, the same in every lane
 DQ_HD void wave_sync() {

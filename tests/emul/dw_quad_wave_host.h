@@ -152,6 +152,15 @@ DQ_HD float oct_lo(float x) { return emu_xchg(x, g_emu->cur & ~4); }
 DQ_HD float oct_hi(float x) { return emu_xchg(x, g_emu->cur | 4); }
 DQ_HD float oct_take_lo(float own, float src) { const float t = emu_xchg(src, g_emu->cur & ~4); return (g_emu->cur & 4) ? t : own; }
 DQ_HD float oct_take_hi(float own, float src) { const float t = emu_xchg(src, g_emu->cur | 4); return (g_emu->cur & 4) ? own : t; }
+template <int LPE_, int K> DQ_HD float rs_take(float a, float b) {
+    const int l = g_emu->cur, q = (l >> 2) & (LPE_ / 4 - 1), src = l - 4 * q + 4 * K;
+    const float ta = emu_xchg(a, src), tb = emu_xchg(b, src);
+    return q >= 2 ? a : ((q & 1) ? tb : ta);          // (quarters 2, 3 of a hex env: a value nobody reads)
+}
+template <int LPE_, int K> DQ_HD float rs_all(float x) {
+    const int l = g_emu->cur, q = (l >> 2) & (LPE_ / 4 - 1);
+    return emu_xchg(x, l - 4 * q + 4 * K);
+}
 DQ_HD float quad_xor1_hi(float x) { return emu_xchg(x, (g_emu->cur & 4) ? (g_emu->cur ^ 1) : g_emu->cur); }
 DQ_HD float oct_fetch(float x, int src) { return emu_xchg(x, (g_emu->cur & ~7) | src); }
 DQ_HD float half_bits_to_float(int h) {          // (positive normal numbers and zero: all the tables hold)
