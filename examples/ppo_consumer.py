@@ -221,7 +221,10 @@ def _sync(device):
 # ------------------------------------------------------------------------------------------------ the loop
 ROLL_CHAIN = int(os.environ.get("DW_PPO_ROLL_CHAIN", "8"))          # rollout steps per replayed graph
 UPD_CHAIN = int(os.environ.get("DW_PPO_CHAIN", "16"))          # fused updates per replayed graph
-GRAPH_COLLECTIVE = os.environ.get("DW_PPO_GRAPH_COLLECTIVE", "0") == "1"          # sharded fused update: the all-reduce captured inside the graph of updates
+# sharded fused update: the all-reduce captured inside the graph of updates (default; an RCCL all-reduce is accepted by a hipGraph capture on this
+# stack, profiles/r06_graph_collective_probe.txt) -- if the capture is refused, or with DW_PPO_GRAPH_COLLECTIVE=0, the update is two graphs with
+# the collective enqueued between them (measured on one rank at 16384 envs: 14.51 M captured, 12.05 M split, 14.68 M unsharded)
+GRAPH_COLLECTIVE = os.environ.get("DW_PPO_GRAPH_COLLECTIVE", "1") == "1"
 
 
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
@@ -236,8 +239,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     fused_update: the same update as FOUR launches on the matrix cores (include/dyros_ppo.h, isaacgymdyros_amd/ppo_update.py), captured once
     and replayed; GPU only.  Sharded (world > 1) every update carries ONE all-reduce of the ranks' 1.61 MB gradient bucket between the
     weight-gradient launch and the statistics (FusedPpoUpdate.allreduce: where the reference's Horovod optimizer.synchronize() stands,
-    a2c_continuous_seperate.py:171-180): by default the update is then two replayed graphs with the collective enqueued between them;
-    DW_PPO_GRAPH_COLLECTIVE=1 captures the collective inside the chain of updates instead (one replay per UPD_CHAIN updates).
+    a2c_continuous_seperate.py:171-180), captured inside the chain of updates (one replay per UPD_CHAIN updates); if the capture of the
+    collective is refused, or with DW_PPO_GRAPH_COLLECTIVE=0, the update is two replayed graphs with the collective enqueued between them.
     fused_collective=True runs that sharded form of the update on ONE rank too (tests: same bits as the plain four launches)."""
     from isaacgymdyros_amd.config import default_cfg
     from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
@@ -475,24 +478,33 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                         done_upd += 1
                 torch.cuda.current_stream(device).wait_stream(side_u)
                 torch.cuda.synchronize()
-                if done_upd < n_upd and fused.collective and not GRAPH_COLLECTIVE:
+                split = fused.collective and not GRAPH_COLLECTIVE
+                if done_upd < n_upd and not split:
+                    try:
+                        upd_graph = torch.cuda.CUDAGraph()
+                        with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
+                            fused.update()
+                        # (the minibatch index lives on the device, so a graph may hold any number of updates: UPD_CHAIN of them back to back
+                        #  have no gap between graph launches inside)
+                        if n_upd >= 2 * UPD_CHAIN:
+                            upd_chain = torch.cuda.CUDAGraph()
+                            with torch.no_grad(), torch.cuda.graph(upd_chain, stream=side_u):
+                                for _ in range(UPD_CHAIN):
+                                    fused.update()
+                    except RuntimeError as err:          # (a collective the capture refuses: fall back to the split form below)
+                        if fused.world <= 1:
+                            raise
+                        log("fused update: the capture of the all-reduce was refused (%s); two graphs per update instead" % str(err).split("\n")[0])
+                        torch.cuda.synchronize()
+                        upd_graph = upd_chain = None
+                        split = True
+                if done_upd < n_upd and split:
                     # sharded, the collective outside the graphs: head (dwp_mlp, dwp_wgrad, dwp_grad_bucket) | all-reduce | tail (statistics, Adam)
                     upd_graph, upd_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                     with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
                         fused.update_head()
                     with torch.no_grad(), torch.cuda.graph(upd_tail, stream=side_u):
                         fused.update_tail()
-                elif done_upd < n_upd:
-                    upd_graph = torch.cuda.CUDAGraph()
-                    with torch.no_grad(), torch.cuda.graph(upd_graph, stream=side_u):
-                        fused.update()
-                    # (the minibatch index lives on the device, so a graph may hold any number of updates: UPD_CHAIN of them back to back
-                    #  have no gap between graph launches inside)
-                    if n_upd >= 2 * UPD_CHAIN:
-                        upd_chain = torch.cuda.CUDAGraph()
-                        with torch.no_grad(), torch.cuda.graph(upd_chain, stream=side_u):
-                            for _ in range(UPD_CHAIN):
-                                fused.update()
             left = n_upd - done_upd
             while upd_chain is not None and left >= UPD_CHAIN:
                 upd_chain.replay()

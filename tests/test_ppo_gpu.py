@@ -542,9 +542,12 @@ def test_sharded_form_of_the_update_on_one_rank_is_bit_identical():
         assert torch.equal(sa[keep], sb[keep]), (sa.tolist(), sb.tolist())
         assert torch.allclose(sa[o:o + 6], sb[o:o + 6], rtol=1e-5, atol=1e-7)
     assert skipped == [0.0, 0.0, 1.0, 0.0, 0.0]
-    # the bucket path also through the consumer's two replayed graphs with the collective's place between them: same first epochs
+    # the bucket path also through the consumer: the collective's place captured inside the chain of updates, then as two replayed graphs
     a = ppo.train(num_envs=256, epochs=2, horizon=16, device=dev, log=lambda s: None, graph_rollout=True, fused_update=True)
     b = ppo.train(num_envs=256, epochs=2, horizon=16, device=dev, log=lambda s: None, graph_rollout=True, fused_update=True, fused_collective=True)
+    ppo.GRAPH_COLLECTIVE = False          # (the fall-back when a capture refuses the collective: head graph | all-reduce | tail graph)
+    b2 = ppo.train(num_envs=256, epochs=2, horizon=16, device=dev, log=lambda s: None, graph_rollout=True, fused_update=True, fused_collective=True)
+    assert a[0]["mean_reward"] == b2[0]["mean_reward"] and all(abs(x["a_loss"] - y["a_loss"]) <= 1e-4 for x, y in zip(a, b2))
     # (the first rollout is the same bits; after it the bias gradients' atomic adds round in launch order, as between two runs of one path)
     assert a[0]["mean_reward"] == b[0]["mean_reward"]
     for x, y in zip(a, b):
