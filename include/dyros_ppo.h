@@ -71,6 +71,9 @@ extern "C" {
 #define DWP_S_STEP       10  /* [2] Adam step counts of the actor / the critic               */
 #define DWP_S_LR         12  /* [2] learning rates (the caller's schedule writes them)       */
 #define DWP_S_MB         14  /* index of the minibatch the next update takes (as a float)    */
+#define DWP_S_G16        15  /* non-zero: dwp_grad_stats / dwp_adam round dwp_wgrad's summed WEIGHT gradients through fp16 first -- what a backward under
+                              * autocast hands unscale_ (inf beyond 65 504, so found_inf and the loss scale move as the reference's would); 0: the
+                              * fp32 sums as they are (default: more bits, found_inf from the fp16 output / activation gradients only)             */
 #define DWP_S_OUT        16  /* [8] published by dwp_finish: a_loss, c_loss, b_loss, clip fraction, kl, grad norm, scale, skipped */
 #define DWP_S_WORDS      32
 
@@ -96,7 +99,7 @@ int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const flo
 /* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */
 int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
 
-#define DWP_PARTS 768   /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates */
+#define DWP_PARTS 768   /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates, the G16 switch */
 #define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
 #define DWP_P32F_WORDS 401408   /* floats of p32f, the fp32 weights in the order dwp_policy's matrix instructions take them (csrc/dw_ppo.hip frag32_pos) */
 #define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
     __shared__ float red[4];
     __shared__ int redf[4];
     const float inv = 1.0f / state[DWP_S_SCALE];
+    const bool g16r = g32 && state[DWP_S_G16] != 0.0f;          // the summed weight gradients through fp16 first (autocast's rounding and its overflow at 65 504)
     float sq = 0.0f;
     int bad0 = 0, bad1 = 0;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
                 float s2 = 0.0f;
                 int bad = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { const float g = s4[c]; bad |= !isfinite(g); const float w = g * inv; s2 += w * w; }
+                for (int c = 0; c < 4; ++c) { const float g = g16r ? (float)(_Float16)s4[c] : s4[c]; bad |= !isfinite(g); const float w = g * inv; s2 += w * w; }
                 if (net == 0) sq += s2;
                 if (bad) { if (net) bad1 = 1; else bad0 = 1; }
             }
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void k_grad_stats(const _Float16 *__restrict__
             part[PART_SNAP + 0] = state[DWP_S_SCALE];
             part[PART_SNAP + 1] = state[DWP_S_STEP]; part[PART_SNAP + 2] = state[DWP_S_STEP + 1];
             part[PART_SNAP + 3] = state[DWP_S_LR]; part[PART_SNAP + 4] = state[DWP_S_LR + 1];
+            part[PART_SNAP + 5] = state[DWP_S_G16];
         }
     }
     if (bad0) state[DWP_S_FOUND_INF] = 1.0f;
@@ -420,6 +422,10 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
         const h8 gh = *reinterpret_cast<const h8 *>(g16 + ic);
 #pragma unroll
         for (int q = 0; q < 8; ++q) gs[q] = (float)gh[q];
+    }
+    if (g32 && ic < NWT && (FIN ? part[PART_SNAP + 5] : state[DWP_S_G16]) != 0.0f) {          // (as dwp_grad_stats saw them)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = (float)(_Float16)gs[q];
     }
     const float my_part = part[threadIdx.x];
     const int fl = FIN ? (int)part[PART_FLAGS + threadIdx.x] : 0;

@@ -213,7 +213,7 @@ class FusedPpoUpdate:
     be captured in a hipGraph once and replayed)."""
 
     def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True, rowmajor: bool = True, split_tail: bool = False,
-                 world: int = 1, group=None, collective: bool = None):
+                 world: int = 1, group=None, collective: bool = None, fp16_grads: bool = False):
         """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp + dwp_wgrad; the minibatch must be a multiple of 32, else the library-GEMM form runs) instead
         of eight library GEMM launches with six kernels between them.  rowmajor (mfma only): dwp_mlp also writes its activations and their
         gradients as plain [2, B, 256] / [B, 512] matrices (x16, h1, h2, dh2, dh1: what the tests read); a trainer passes False.
@@ -221,7 +221,10 @@ class FusedPpoUpdate:
         world, group (mfma only): the ranks that train together (torch.distributed, backend nccl = RCCL) -- every update then averages the
         ranks' gradients with ONE all-reduce of the 1.61 MB bucket between dwp_wgrad and dwp_grad_stats (`update()` =
         `update_head()`, `allreduce()`, `update_tail()`).  collective: run that bucket path although world == 1 (tests: bit-identical to the
-        plain four launches; default: only when world > 1).  The learning rates start at cfg's learning_rate / critic_lr."""
+        plain four launches; default: only when world > 1).  The learning rates start at cfg's learning_rate / critic_lr.
+        fp16_grads (mfma only): the summed weight gradients are rounded through fp16 before unscale / clip / Adam -- the arithmetic type a backward
+        under autocast gives them (inf beyond 65 504), so found_inf and the loss scale move exactly as the reference's GradScaler would; default
+        off: the fp32 sums as they are (include/dyros_ppo.h DWP_S_G16)."""
         c = cfg
         if bool(c.get("clip_value")) or float(c.get("entropy_coef", 0.0)) != 0.0 or float(c.get("bounds_loss_coef", 0.0)) != 0.0:
             raise ValueError("the fused update is written for clip_value False, entropy_coef 0, bounds_loss_coef 0 (DyrosDynamicWalkPPO.yaml)")
@@ -259,6 +262,7 @@ class FusedPpoUpdate:
         self.state = torch.zeros(K["DWP_S_WORDS"], **f32)
         self.part = torch.zeros(K["DWP_PARTS"], **f32)
         self.state[K["DWP_S_SCALE"]] = 65536.0
+        self.state[K["DWP_S_G16"]] = 1.0 if fp16_grads else 0.0
         # (the learning rates live in the device state; a caller's schedule overwrites them: set_learning_rates.  Left at zero, update() would
         #  advance Adam's moments and step counts while no parameter moves, without any error)
         self._lr_set = False

@@ -632,3 +632,53 @@ def test_rollout_recorder_refuses_bad_arguments_and_drops_rows_past_the_buffers(
     torch.cuda.synchronize()
     for k in mb:
         assert torch.equal(mb[k], snap[k]), k
+
+
+@pytest.mark.gpu
+def test_fp16_grads_switch_gives_the_weight_gradients_autocasts_overflow():
+    """the four-launch form keeps the weight gradients as fp32 sums, so with gradients beyond the fp16 range its found_inf stays
+    down where a backward under autocast (and the library-GEMM form, whose GEMMs write fp16) overflows at 65 504.  FusedPpoUpdate(fp16_grads=True)
+    rounds the summed weight gradients through fp16 before the statistics and Adam (DWP_S_G16): same skip, same back-off as the GEMM form.  A loss
+    scale of 2^21 over a minibatch of 4096 keeps the output gradients within fp16 per sample and puts their sums over the samples beyond 65 504."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(17)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 4096, 2
+    S0 = float(2 ** 21)
+    batch = _batch(ppo, copy.deepcopy(net), U, B * nmb, dev)
+    fs = {"plain": U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev), "fp16": U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, fp16_grads=True),
+          "gemm": U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, mfma=False)}
+    for f in fs.values():
+        f.state[U.K["DWP_S_SCALE"]] = S0
+        f.bind_batch(*batch)
+        f.update()
+    torch.cuda.synchronize()
+    lg = {k: f.logged().cpu().tolist() for k, f in fs.items()}
+    steps = {k: f.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() for k, f in fs.items()}
+    scale = {k: float(f.state[U.K["DWP_S_SCALE"]]) for k, f in fs.items()}
+    # the CRITIC is the clean case: its output gradient scale * (value - return) / B is in range for every sample (the actor's, (a - mu) / sigma^2
+    # times the advantage, has tails that overflow by themselves at this scale -- in every form alike)
+    assert torch.isfinite(fs["plain"].dout[1].float()).all()
+    assert steps["gemm"][1] == 0.0 and lg["gemm"][7] == 1.0 and scale["gemm"] == S0 / 2, (lg["gemm"], steps, scale)          # autocast's arithmetic overflows in the weight gradients ...
+    assert steps["plain"][1] == 1.0, steps          # ... the fp32 sums do not: the critic steps ...
+    assert steps["fp16"] == steps["gemm"] and lg["fp16"][7] == 1.0 and scale["fp16"] == scale["gemm"]          # ... and with the switch they do, net by net
+    # back in range (the halved scale is still too high here, so lower it): the switch then only rounds -- both mfma forms take the step
+    for f in fs.values():
+        f.state[U.K["DWP_S_SCALE"]] = 1024.0
+        f.update()
+    torch.cuda.synchronize()
+    assert all(f.logged()[7].item() == 0.0 for f in fs.values())
+    assert all(bool(torch.isfinite(f.p).all()) for f in fs.values())
+    # (the switch by itself, from equal parameters: the rounded gradients differ from the fp32 sums by 2^-11 relative -- a different, close step)
+    fa, fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev), U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, fp16_grads=True)
+    for f in (fa, fb):
+        f.state[U.K["DWP_S_SCALE"]] = 256.0
+        f.bind_batch(*batch)
+        f.update()
+    torch.cuda.synchronize()
+    d = (fa.p - fb.p).abs().max().item()
+    assert fa.logged()[7].item() == 0.0 and fb.logged()[7].item() == 0.0 and 0.0 < d < 1e-4, d
