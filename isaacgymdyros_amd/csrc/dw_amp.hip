@@ -234,8 +234,9 @@ int dw_amp_step_end(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, co
 // the whole step in one launch (dw_oct_kernels.hip: dw_k_amp_step_oct)
 }  // extern "C"
 namespace dwo {
-void launch_amp_step(int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers &Bf, const DwAmpConfig &C,
-                     const DwAmpBuffers &B, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z, int K, const float *rootvel_noise);
+void launch_amp_step(int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers &Bf, const void *d_args,
+                     const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z, int K, const float *rootvel_noise);
+int amp_args_to_device(DwHandle *h, const DwAmpConfig &C, const DwAmpBuffers &B, hipStream_t stream);
 }
 extern "C" {
 int dw_amp_step(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z,
@@ -252,7 +253,8 @@ int dw_amp_step(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const 
             for (int k = 0; k < substeps; ++k) if (!z[k]) return fail(DW_EINVAL, "dw_amp_step: noise needs the encoder draws of every substep (or device_draws)");
         }
     }
-    dwo::launch_amp_step(c->num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, *c, *b, actions_in, ramp_dur, ramp_u, z, substeps, rootvel_noise);
+    if (const int rc = dwo::amp_args_to_device(h, *c, *b, (hipStream_t)stream)) return fail(rc, "dw_amp_step: could not place the task's tables in device memory");
+    dwo::launch_amp_step(c->num_envs, (hipStream_t)stream, h->d_qmodel, h->d_model, h->d_params, h->buf, h->d_amp_args, actions_in, ramp_dur, ramp_u, z, substeps, rootvel_noise);
     return launched("dw_amp_step: launch");
 }
 

@@ -30,6 +30,17 @@
 #pragma clang fp contract(off)
 #endif
 
+#if defined(__HIPCC__)
+#define DWA_UNROLL _Pragma("unroll")
+// a region's body is a lambda that captures the kernel's by-value argument structs by reference: left to the inliner's size heuristics it
+// stays a function of its own once its loops are unrolled, and the structs -- 600 B of kernel arguments -- are then copied to scratch and
+// every field read from there (the one-launch kernel: 1 140 B of scratch, 153 stores at its entry).  Regions are always inlined.
+#define DWA_INL __attribute__((always_inline))
+#else
+#define DWA_UNROLL
+#define DWA_INL
+#endif
+
 namespace dwa {
 
 #if defined(__HIPCC__)
@@ -95,7 +106,7 @@ DW_HD DrawKey draw_key(const DwAmpConfig &C, const DwAmpBuffers &B, int e) {
 
 // ---------------------------------------------------------------------------------------------------------------------- pieces
 DW_HD void stage_leg_model(const EnvWave &W, StepLds &S, const dw::DevModel &M) {
-    W.par([&](int l) {
+    W.par([&](int l) DWA_INL {
         for (int i = l; i < LegModel::NBODY * 16; i += 64) {
             const int b = i >> 4, k = i & 15;
             if (k < 3) S.LM.pos[b][k] = M.pos[b][k];
@@ -135,35 +146,91 @@ struct BeginLds {
 
 // the torques of one substep into DwAmpBuffers.tau (:696-724), items (env, joint).  A later region moves the FIFO counter
 // (every leg item of the env read it).
+// Every item loop of the step regions is written in TWO PHASES (round 6): first every global request of the thread's items, then the arithmetic
+// and the stores.  As one loop -- load, compute, store, next item -- a store between two items' loads makes the compiler wait for memory once
+// per item (it may not move a load over a store into tables it cannot tell apart), and with 3 .. 5 items per thread that was 3 .. 5 memory
+// round trips per loop, ~140 per step.  An item beyond the group's envs requests row 0 of its tables (valid memory) and stores nothing.
+constexpr int LOG_MAX = 8;          // FIFO slots the two-phase torque loop keeps in registers (a longer FIFO takes the serial loop)
+
 template <class WG>
 DW_HD void torques(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, int e0) {
     constexpr int GT = WG::GT;
-    const int N = C.num_envs;
-    W.par([&](int t) {
-        for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
+    constexpr int NIT = (GE * DW_NUM_DOF + GT - 1) / GT;
+    const int N = C.num_envs, LS = C.log_slots;
+    const bool fifo = !C.pd_control && LS <= LOG_MAX;
+    W.par([&](int t) DWA_INL {
+        if (!C.pd_control && !fifo) {          // (a FIFO longer than LOG_MAX: the serial form)
+            for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
+                const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
+                if (e >= N) continue;
+                const float q = dof_state[((size_t)DW_NUM_DOF * e + l) * 2], qd = dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1];
+                float tau;
+                if (l >= 12) tau = B.p_gains[l] * (B.init_angle[l] - q) + B.d_gains[l] * (-qd);
+                else {
+                    const int64_t sl0 = B.simul_len[e], dl = B.delay_idx[e];
+                    const float m = B.motor_efforts[l];
+                    float lower = B.actions[12 * (size_t)e + l] * m * B.power_scale[12 * (size_t)e + l];
+                    lower = fmaxf(fminf(lower, m), -m);
+                    float *col = B.action_log + (size_t)LS * 12 * e + l;
+                    int64_t sl = sl0 + 1;
+                    sl = sl > LS ? LS : (sl < 0 ? 0 : sl);
+                    float delayed = 0.0f;
+                    for (int s = 0; s < LS; ++s) {
+                        const float v = s + 1 < LS ? col[(size_t)12 * (s + 1)] : lower;
+                        col[(size_t)12 * s] = v;
+                        const int64_t want = sl > dl ? dl : (int64_t)LS - sl;
+                        if (s == want) delayed = v;
+                    }
+                    tau = C.noise ? delayed : lower;
+                }
+                B.tau[(size_t)DW_NUM_DOF * e + l] = tau;
+            }
+            return;
+        }
+        // ---- phase 1: requests
+        float q[NIT], qd[NIT], act[NIT], ps[NIT], col[NIT][LOG_MAX];
+        int64_t sl0[NIT], dl[NIT];
+        DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+            const int i = t + GT * k, ic = i < GE * DW_NUM_DOF ? i : 0;
+            const int el = ic / DW_NUM_DOF, l = ic - DW_NUM_DOF * el, e = e0 + el < N ? e0 + el : N - 1;
+            q[k] = dof_state[((size_t)DW_NUM_DOF * e + l) * 2]; qd[k] = dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1];
+            act[k] = 0.0f; ps[k] = 0.0f; sl0[k] = 0; dl[k] = 0;
+            DWA_UNROLL for (int s = 0; s < LOG_MAX; ++s) col[k][s] = 0.0f;
+            if (l < 12) {          // (the legs: the action, and with the delayed-torque model the env's FIFO column)
+                act[k] = B.actions[12 * (size_t)e + l];
+                if (fifo) {
+                    ps[k] = B.power_scale[12 * (size_t)e + l];
+                    sl0[k] = B.simul_len[e]; dl[k] = B.delay_idx[e];
+                    const float *cl = B.action_log + (size_t)LS * 12 * e + l;
+                    DWA_UNROLL for (int s = 0; s < LOG_MAX; ++s) if (s < LS) col[k][s] = cl[(size_t)12 * s];
+                }
+            }
+        }
+        // ---- phase 2: arithmetic and stores (the expressions of the serial form above, :696-724)
+        DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+            const int i = t + GT * k;
             const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
-            if (e >= N) continue;
-            const float q = dof_state[((size_t)DW_NUM_DOF * e + l) * 2], qd = dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1];
+            if (i >= GE * DW_NUM_DOF || e >= N) continue;
             float tau;
             if (l >= 12) {
-                tau = B.p_gains[l] * (B.init_angle[l] - q) + B.d_gains[l] * (-qd);          // upper body: PD to the initial pose (:696)
+                tau = B.p_gains[l] * (B.init_angle[l] - q[k]) + B.d_gains[l] * (-qd[k]);          // upper body: PD to the initial pose (:696)
             } else if (C.pd_control) {
-                const float tar = B.pd_action_offset[l] + B.pd_action_scale[l] * B.actions[12 * (size_t)e + l];
-                tau = B.p_gains[l] * (tar - q) + B.d_gains[l] * (-qd);
+                const float tar = B.pd_action_offset[l] + B.pd_action_scale[l] * act[k];
+                tau = B.p_gains[l] * (tar - q[k]) + B.d_gains[l] * (-qd[k]);
             } else {
-                const int64_t sl0 = B.simul_len[e], dl = B.delay_idx[e];
                 const float m = B.motor_efforts[l];
-                float lower = B.actions[12 * (size_t)e + l] * m * B.power_scale[12 * (size_t)e + l];
+                float lower = act[k] * m * ps[k];
                 lower = fmaxf(fminf(lower, m), -m);
                 // delayed-torque FIFO (:712-724), column l: shift, append, read `delay_idx` back once the FIFO has filled that far
-                float *col = B.action_log + (size_t)C.log_slots * 12 * e + l;
-                int64_t sl = sl0 + 1;
-                sl = sl > C.log_slots ? C.log_slots : (sl < 0 ? 0 : sl);
+                float *cl = B.action_log + (size_t)LS * 12 * e + l;
+                int64_t sl = sl0[k] + 1;
+                sl = sl > LS ? LS : (sl < 0 ? 0 : sl);
+                const int64_t want = sl > dl[k] ? dl[k] : (int64_t)LS - sl;
                 float delayed = 0.0f;
-                for (int s = 0; s < C.log_slots; ++s) {
-                    const float v = s + 1 < C.log_slots ? col[(size_t)12 * (s + 1)] : lower;
-                    col[(size_t)12 * s] = v;
-                    const int64_t want = sl > dl ? dl : (int64_t)C.log_slots - sl;
+                DWA_UNROLL for (int s = 0; s < LOG_MAX; ++s) {
+                    if (s >= LS) break;
+                    const float v = s + 1 < LS ? col[k][s + 1 < LOG_MAX ? s + 1 : LOG_MAX - 1] : lower;
+                    cl[(size_t)12 * s] = v;
                     if (s == want) delayed = v;
                 }
                 tau = C.noise ? delayed : lower;
@@ -172,7 +239,7 @@ DW_HD void torques(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, con
         }
     });
     if (!C.pd_control) {
-        W.par([&](int t) {
+        W.par([&](int t) DWA_INL {
             const int e = e0 + t;
             if (t >= GE || e >= N) return;
             const int64_t sl = B.simul_len[e] + 1;
@@ -186,19 +253,32 @@ DW_HD void torques(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, con
 template <class WG>
 DW_HD void encoder(const WG &W, const DwAmpConfig &C, const DwAmpBuffers &B, const float *dof_state, const float *z, int substep, int e0) {
     constexpr int GT = WG::GT;
+    constexpr int NIT = (GE * DW_NUM_DOF + GT - 1) / GT;
     const int N = C.num_envs;
-    W.par([&](int t) {
-        for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
-            const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
-            if (e >= N) continue;
+    W.par([&](int t) DWA_INL {
+        float q[NIT], zz[NIT], pre[NIT];
+        unsigned long long ctr[NIT];
+        DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+            const int i = t + GT * k, ic = i < GE * DW_NUM_DOF ? i : 0;
+            const int el = ic / DW_NUM_DOF, l = ic - DW_NUM_DOF * el, e = e0 + el < N ? e0 + el : N - 1;
             const size_t g = (size_t)DW_NUM_DOF * e + l;
-            const float q = dof_state[g * 2];
-            float qn = q;
+            q[k] = dof_state[g * 2];
+            pre[k] = B.qpos_pre[g];
+            zz[k] = (C.noise && z) ? z[g] : 0.0f;
+            ctr[k] = (C.noise && !z && C.device_draws) ? (unsigned long long)B.draw_ctr[e] : 0ull;
+        }
+        DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+            const int i = t + GT * k;
+            const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
+            if (i >= GE * DW_NUM_DOF || e >= N) continue;
+            const size_t g = (size_t)DW_NUM_DOF * e + l;
+            float qn = q[k];
             if (C.noise) {
-                const float zz = z ? z[g] : draw_enc_normal(draw_key(C, B, e), DS_ENC + (unsigned int)substep, l);
-                qn = q + fminf(fmaxf(zz, -0.00016f), 0.00016f);
+                DrawKey dk; dk.seed = C.seed; dk.env = (unsigned int)e; dk.ctr = ctr[k];
+                const float zk = z ? zz[k] : draw_enc_normal(dk, DS_ENC + (unsigned int)substep, l);
+                qn = q[k] + fminf(fmaxf(zk, -0.00016f), 0.00016f);
             }
-            const float d = qn - B.qpos_pre[g];
+            const float d = qn - pre[k];
             B.qpos_noise[g] = qn;
             B.qvel_noise[g] = C.gpu_div ? d * C.inv_dt : d / C.dt;
             B.qpos_pre[g] = qn;
@@ -212,7 +292,7 @@ DW_HD void step_begin(const WG &W, BeginLds &S, const DwAmpConfig &C, const DwAm
                       const int64_t *ramp_dur, const float *ramp_u, int group) {
     constexpr int GT = WG::GT;
     const int N = C.num_envs, e0 = group * GE, NH = C.num_his * C.num_skip;
-    W.par([&](int t0) {
+    W.par([&](int t0) DWA_INL {
       for (int t = t0; t < GE * 12 + GE * 3; t += GT) {
         // items (env, action): clamp, record, history.  An item owns column k of the env's action history, so the shifting layout
         // moves in place without a hazard between threads; the ring writes one slot (its head moves in the next region).
@@ -257,7 +337,7 @@ DW_HD void step_begin(const WG &W, BeginLds &S, const DwAmpConfig &C, const DwAm
         }
       }
     });
-    W.par([&](int t) {
+    W.par([&](int t) DWA_INL {
         const int e = e0 + t;
         if (t >= GE || e >= N) return;
         if (C.vel_change) { B.vel_change_duration[e] = S.i64[t][0]; B.cur_vel_change_duration[e] = S.i64[t][1]; }
@@ -303,7 +383,7 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
     const int N = C.num_envs, e0 = group * GE;
     const int NH = C.num_his * C.num_skip;
     const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
-    W.par([&](int t) {
+    W.par([&](int t) DWA_INL {
         for (int i = t; i < LegModel::NBODY * 16; i += GT) {
             const int b = i >> 4, k = i & 15;
             if (k < 3) S.LM.pos[b][k] = M.pos[b][k];
@@ -318,60 +398,116 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
             if (C.hist_ring && e0 + t < N) { S.head[t][0] = B.hist_head[2 * (size_t)(e0 + t)]; S.head[t][1] = B.hist_head[2 * (size_t)(e0 + t) + 1]; }
         }
     });
-    // ---- the encoder model of the substep that ended (:728-736) and the rows the functions below read, items over all threads
-    W.par([&](int t) {
-        for (int i = t; i < GE * DW_NUM_DOF; i += GT) {
-            const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
-            if (e >= N) continue;
-            const size_t g = (size_t)DW_NUM_DOF * e + l;
-            const float q = G.dof_state[g * 2], qd = G.dof_state[g * 2 + 1];
-            float qn = q;
-            if (C.noise) {
-                const float zz = z ? z[g] : draw_enc_normal(draw_key(C, B, e), DS_ENC + (unsigned int)substep, l);
-                qn = q + fminf(fmaxf(zz, -0.00016f), 0.00016f);
+    // ---- the encoder model of the substep that ended (:728-736) and the rows the functions below read, items over all threads; every
+    //      loop in two phases (all requests, then arithmetic and stores: see torques())
+    W.par([&](int t) DWA_INL {
+        {
+            constexpr int NIT = (GE * DW_NUM_DOF + GT - 1) / GT;
+            float q[NIT], qd[NIT], zz[NIT], pre[NIT], dvp[NIT];
+            unsigned long long ctr[NIT];
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k, ic = i < GE * DW_NUM_DOF ? i : 0;
+                const int el = ic / DW_NUM_DOF, l = ic - DW_NUM_DOF * el, e = e0 + el < N ? e0 + el : N - 1;
+                const size_t g = (size_t)DW_NUM_DOF * e + l;
+                q[k] = G.dof_state[g * 2]; qd[k] = G.dof_state[g * 2 + 1];
+                pre[k] = B.qpos_pre[g]; dvp[k] = B.dof_vel_pre[g];
+                zz[k] = (C.noise && z) ? z[g] : 0.0f;
+                ctr[k] = (C.noise && !z && C.device_draws) ? (unsigned long long)B.draw_ctr[e] : 0ull;
             }
-            const float d = qn - B.qpos_pre[g];
-            const float qv = C.gpu_div ? d * C.inv_dt : d / C.dt;
-            B.qpos_noise[g] = qn;
-            B.qvel_noise[g] = qv;
-            B.qpos_pre[g] = qn;
-            float *r = S.row[el];
-            if (l < 12) { r[GR_QN + l] = qn; r[GR_QV + l] = qv; }
-            r[GR_DS + 2 * l] = q; r[GR_DS + 2 * l + 1] = qd;
-            r[GR_DVP + l] = B.dof_vel_pre[g];
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k;
+                const int el = i / DW_NUM_DOF, l = i - DW_NUM_DOF * el, e = e0 + el;
+                if (i >= GE * DW_NUM_DOF || e >= N) continue;
+                const size_t g = (size_t)DW_NUM_DOF * e + l;
+                float qn = q[k];
+                if (C.noise) {
+                    DrawKey dk; dk.seed = C.seed; dk.env = (unsigned int)e; dk.ctr = ctr[k];
+                    const float zk = z ? zz[k] : draw_enc_normal(dk, DS_ENC + (unsigned int)substep, l);
+                    qn = q[k] + fminf(fmaxf(zk, -0.00016f), 0.00016f);
+                }
+                const float d = qn - pre[k];
+                const float qv = C.gpu_div ? d * C.inv_dt : d / C.dt;
+                B.qpos_noise[g] = qn;
+                B.qvel_noise[g] = qv;
+                B.qpos_pre[g] = qn;
+                float *r = S.row[el];
+                if (l < 12) { r[GR_QN + l] = qn; r[GR_QV + l] = qv; }
+                r[GR_DS + 2 * l] = q[k]; r[GR_DS + 2 * l + 1] = qd[k];
+                r[GR_DVP + l] = dvp[k];
+            }
         }
-        for (int i = t; i < GE * 16; i += GT) {                 // root state (13) + the three words of quat_bias
-            const int el = i >> 4, k = i & 15, e = e0 + el;
-            if (e >= N) continue;
-            if (k < 13) S.row[el][GR_ROOT + k] = G.root_states[13 * (size_t)e + k];
-            else S.row[el][GR_QB + (k - 13)] = B.quat_bias[3 * (size_t)e + (k - 13)];
+        {   // root state (13) + the three words of quat_bias
+            constexpr int NIT = (GE * 16 + GT - 1) / GT;
+            float v[NIT];
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k, ic = i < GE * 16 ? i : 0;
+                const int el = ic >> 4, w = ic & 15, e = e0 + el < N ? e0 + el : N - 1;
+                v[k] = w < 13 ? G.root_states[13 * (size_t)e + w] : B.quat_bias[3 * (size_t)e + (w - 13)];
+            }
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k;
+                const int el = i >> 4, w = i & 15, e = e0 + el;
+                if (i >= GE * 16 || e >= N) continue;
+                if (w < 13) S.row[el][GR_ROOT + w] = v[k];
+                else S.row[el][GR_QB + (w - 13)] = v[k];
+            }
         }
-        for (int i = t; i < GE * 48; i += GT) {                 // qpos_bias, actions, actions_pre (12 each), root-velocity noise (6), command (3), foot forces (2)
-            const int el = i / 48, k = i - 48 * el, e = e0 + el;
-            if (e >= N) continue;
-            float *r = S.row[el];
-            if (k < 12) r[GR_BIAS + k] = B.qpos_bias[12 * (size_t)e + k];
-            else if (k < 24) r[GR_ACT + (k - 12)] = B.actions[12 * (size_t)e + (k - 12)];
-            else if (k < 36) r[GR_ACTP + (k - 24)] = B.actions_pre[12 * (size_t)e + (k - 24)];
-            else if (k < 42) {
-                const int l = k - 36;
-                float nz = 0.0f;
-                if (rootvel_noise) nz = rootvel_noise[6 * (size_t)e + l];
-                else if (C.noise && C.device_draws) nz = draw_uniform(draw_key(C, B, e), DS_ROOTVEL, l) * 0.05f - 0.025f;
-                r[GR_NZ + l] = nz;
-            } else if (k < 45) r[GR_CMD + (k - 42)] = B.commands[3 * (size_t)e + (k - 42)];
-            else if (k < 47) r[GR_FZ + (k - 45)] = G.contact_forces[((size_t)DW_NUM_BODIES * e + (k == 45 ? 8 : 16)) * 3 + 2];
+        {   // qpos_bias, actions, actions_pre (12 each), root-velocity noise (6), command (3), foot forces (2)
+            constexpr int NIT = (GE * 48 + GT - 1) / GT;
+            float v[NIT];
+            unsigned long long ctr[NIT];
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k, ic = i < GE * 48 ? i : 0;
+                const int el = ic / 48, w = ic - 48 * el, e = e0 + el < N ? e0 + el : N - 1;
+                float x = 0.0f;
+                ctr[k] = 0ull;
+                if (w < 12) x = B.qpos_bias[12 * (size_t)e + w];
+                else if (w < 24) x = B.actions[12 * (size_t)e + (w - 12)];
+                else if (w < 36) x = B.actions_pre[12 * (size_t)e + (w - 24)];
+                else if (w < 42) {
+                    if (rootvel_noise) x = rootvel_noise[6 * (size_t)e + (w - 36)];
+                    else if (C.noise && C.device_draws) ctr[k] = (unsigned long long)B.draw_ctr[e];
+                } else if (w < 45) x = B.commands[3 * (size_t)e + (w - 42)];
+                else if (w < 47) x = G.contact_forces[((size_t)DW_NUM_BODIES * e + (w == 45 ? 8 : 16)) * 3 + 2];
+                v[k] = x;
+            }
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k;
+                const int el = i / 48, w = i - 48 * el, e = e0 + el;
+                if (i >= GE * 48 || e >= N) continue;
+                float *r = S.row[el];
+                if (w < 12) r[GR_BIAS + w] = v[k];
+                else if (w < 24) r[GR_ACT + (w - 12)] = v[k];
+                else if (w < 36) r[GR_ACTP + (w - 24)] = v[k];
+                else if (w < 42) {
+                    float nz = 0.0f;
+                    if (rootvel_noise) nz = v[k];
+                    else if (C.noise && C.device_draws) { DrawKey dk; dk.seed = C.seed; dk.env = (unsigned int)e; dk.ctr = ctr[k]; nz = draw_uniform(dk, DS_ROOTVEL, w - 36) * 0.05f - 0.025f; }
+                    r[GR_NZ + (w - 36)] = nz;
+                } else if (w < 45) r[GR_CMD + (w - 42)] = v[k];
+                else if (w < 47) r[GR_FZ + (w - 45)] = v[k];
+            }
         }
-        for (int i = t; i < GE * DW_NUM_BODIES; i += GT) {      // non-foot bodies in contact
-            const int el = i / DW_NUM_BODIES, l = i - DW_NUM_BODIES * el, e = e0 + el;
-            if (e >= N || l == 8 || l == 16) continue;
-            const float *cf = G.contact_forces + ((size_t)DW_NUM_BODIES * e + l) * 3;
-            if (cf[0] > 1.0f || cf[1] > 1.0f || cf[2] > 1.0f) S.touch[el] = 1;
+        {   // non-foot bodies in contact
+            constexpr int NIT = (GE * DW_NUM_BODIES + GT - 1) / GT;
+            float c0[NIT], c1[NIT], c2[NIT];
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k, ic = i < GE * DW_NUM_BODIES ? i : 0;
+                const int el = ic / DW_NUM_BODIES, l = ic - DW_NUM_BODIES * el, e = e0 + el < N ? e0 + el : N - 1;
+                const float *cf = G.contact_forces + ((size_t)DW_NUM_BODIES * e + l) * 3;
+                c0[k] = cf[0]; c1[k] = cf[1]; c2[k] = cf[2];
+            }
+            DWA_UNROLL for (int k = 0; k < NIT; ++k) {
+                const int i = t + GT * k;
+                const int el = i / DW_NUM_BODIES, l = i - DW_NUM_BODIES * el, e = e0 + el;
+                if (i >= GE * DW_NUM_BODIES || e >= N || l == 8 || l == 16) continue;
+                if (c0[k] > 1.0f || c1[k] > 1.0f || c2[k] > 1.0f) S.touch[el] = 1;
+            }
         }
     });
     // ---- the serial functions, lane = env, one function per wave; counters (:751-752; epi_len: the last line of pre_physics_step)
     // (four roles; a group of fewer than four wavefronts gives a wavefront several of them in turn)
-    W.par([&](int t) {
+    W.par([&](int t) DWA_INL {
         const int el = t & 63, e = e0 + el;
         if (el >= GE || e >= N) return;
         float *r = S.row[el];
@@ -394,7 +530,7 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
         }
       }
     });
-    W.par([&](int t) {
+    W.par([&](int t) DWA_INL {
         const int el = t & 63, e = e0 + el;
         if (el >= GE || e >= N) return;
         const float *r = S.row[el];
@@ -422,7 +558,7 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
     });
     // ---- what goes back to memory, items over all threads.  Histories: a thread owns a COLUMN of an env's history (slot s, word k
     //      for all s), so the shifting layout moves in place without a hazard between threads; the ring writes one slot.
-    W.par([&](int t) {
+    W.par([&](int t) DWA_INL {
         for (int i = t; i < GE * 64; i += GT) {
             const int el = i >> 6, k = i & 63, e = e0 + el;
             if (e >= N) continue;
@@ -444,22 +580,31 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
                 }
             }
             if (k < AW) {
-                // discriminator observation history (tasks/tocabi_amp_lower.py:88-96): slot s -> s + 1, the newest into slot 0
+                // discriminator observation history (tasks/tocabi_amp_lower.py:88-96): slot s -> s + 1, the newest into slot 0 (every slot of
+                // the column requested before the first is overwritten: one round trip instead of amp_steps - 1)
                 float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
-                for (int s = C.amp_steps - 1; s >= 1; --s) ab[(size_t)s * AW + k] = ab[(size_t)(s - 1) * AW + k];
+                constexpr int AS_MAX = 8;
+                if (C.amp_steps <= AS_MAX) {
+                    float old_[AS_MAX];
+                    DWA_UNROLL for (int s2 = 0; s2 < AS_MAX; ++s2) old_[s2] = s2 + 1 < C.amp_steps ? ab[(size_t)s2 * AW + k] : 0.0f;
+                    DWA_UNROLL for (int s2 = 0; s2 < AS_MAX; ++s2) if (s2 + 1 < C.amp_steps) ab[(size_t)(s2 + 1) * AW + k] = old_[s2];
+                } else {
+                    for (int s2 = C.amp_steps - 1; s2 >= 1; --s2) ab[(size_t)s2 * AW + k] = ab[(size_t)(s2 - 1) * AW + k];
+                }
                 ab[k] = r[GR_AMP + k];
                 B.amp_obs1[(size_t)AW * e + k] = r[GR_AMP + k];
             }
         }
     });
-    // the stacked observation (:540-580): obs slots S (i + 1) - 1, action slots S (i + 1), i < H - 1.  Four items per thread at a
+    // the stacked observation (:540-580): obs slots S (i + 1) - 1, action slots S (i + 1), i < H - 1.  Eight items per thread at a
     // time, every load before the first store (the compiler may not move a load over a store into the same table)
-    W.par([&](int t) {
-        for (int i0 = t; i0 < GE * num_obs; i0 += 4 * GT) {
-            float v[4];
-            size_t dst[4];
-            bool ok[4];
-            for (int u = 0; u < 4; ++u) {
+    W.par([&](int t) DWA_INL {
+        constexpr int SB = 8;          // items per thread in flight (four until round 6)
+        for (int i0 = t; i0 < GE * num_obs; i0 += SB * GT) {
+            float v[SB];
+            size_t dst[SB];
+            bool ok[SB];
+            DWA_UNROLL for (int u = 0; u < SB; ++u) {
                 const int i = i0 + u * GT;
                 const int el = i / num_obs, w = i - num_obs * el, e = e0 + el;
                 ok[u] = i < GE * num_obs && e < N;
@@ -477,14 +622,14 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
                 }
                 dst[u] = (size_t)num_obs * e + w;
             }
-            for (int u = 0; u < 4; ++u) {
+            DWA_UNROLL for (int u = 0; u < SB; ++u) {
                 if (!ok[u]) continue;
                 B.obs_buf[dst[u]] = v[u];
                 B.obs_out[dst[u]] = fminf(fmaxf(v[u], -C.clip_obs), C.clip_obs);
             }
         }
     });
-    W.par([&](int t) {
+    W.par([&](int t) DWA_INL {
         const int e = e0 + t;
         if (t >= GE || e >= N) return;
         if (C.hist_ring) { const int h = S.head[t][1] + 1; B.hist_head[2 * (size_t)e + 1] = h >= NH ? 0 : h; }
@@ -512,7 +657,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
     const int NH = C.num_his * C.num_skip;
     const bool dev = C.device_draws != 0;
     stage_leg_model(W, S, M);
-    W.par([&](int l) {
+    W.par([&](int l) DWA_INL {
         const DrawKey k = draw_key(C, B, e);
         // what the reset observation is made of: the episode's LAST encoder reading, biases and command (the reference computes it
         // before it draws the new ones, :253 before :266-279)
@@ -555,7 +700,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
             }
         }
     });
-    W.par([&](int l) {
+    W.par([&](int l) DWA_INL {
         const float *r = S.root, *ds = S.ds;
         if (l < 2) {          // the rigid-body rows of the new state
             float p[3];
@@ -573,7 +718,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         if (R.dr && C.randomize && l == 63 && B.randomize_buf[e] >= (int64_t)C.dr_frequency) B.randomize_buf[e] = 0;
     });
     const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
-    W.par([&](int l) {
+    W.par([&](int l) DWA_INL {
         if (l == 1) disc_observations_row(S.root, S.ds, S.ds + 1, 2, C.local_root_obs, S.foot, 2, S.amp);
         if (l >= 2 && l < 2 + DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + (l - 2)] = S.obs[l - 2];
         // the reset env's observation: every history slot shows the reset observation, the action slots what the action history
@@ -589,7 +734,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
             if (B.obs_out && R.dr) B.obs_out[(size_t)num_obs * e + i] = fminf(fmaxf(v, -C.clip_obs), C.clip_obs);
         }
     });
-    W.par([&](int l) {
+    W.par([&](int l) DWA_INL {
         const DrawKey k = draw_key(C, B, e);
         for (int i = l; i < NH * DW_AMP_NUM_OBS1; i += 64) B.obs_history[(size_t)NH * DW_AMP_NUM_OBS1 * e + i] = 0.0f;
         for (int i = l; i < NH * 12; i += 64) B.action_history[(size_t)NH * 12 * e + i] = 0.0f;
@@ -636,7 +781,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         for (int i = l; i < C.amp_steps * AW; i += 64) ab[i] = S.amp[i % AW];
         if (l < AW) B.amp_obs1[(size_t)AW * e + l] = S.amp[l];
     });
-    if (dev) W.par([&](int l) { if (l == 0) B.draw_ctr[e] += 1; });
+    if (dev) W.par([&](int l) DWA_INL { if (l == 0) B.draw_ctr[e] += 1; });
 }
 
 }  // namespace dwa

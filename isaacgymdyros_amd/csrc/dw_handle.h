@@ -23,5 +23,11 @@ struct DwHandle {
     int             bound;
     int             has_task;
     int             device;
-    long long       next_step = -1; // host-supplied step index the next dw_step is expected to carry (dw_hip.hip launch_step); -1 = none yet
+    long long       next_step;      // host-supplied step index the next dw_step is expected to carry (dw_hip.hip launch_step; dw_create: -1 = none yet)
+    // the one-launch sibling-task step (dw_amp_step): its two argument tables as they were last copied to the device, and that copy.  The
+    // kernel reads them through a pointer (scalar loads): as by-value kernel arguments next to the octet substep they were demoted to
+    // scratch, 600 B per lane read field by field.
+    void           *d_amp_args;
+    unsigned char   amp_args_host[1024];
+    int             amp_args_valid;
 };

@@ -94,6 +94,7 @@ int dw_create(const DwConfig *cfg, const DwModel *model, const DwTaskConst *task
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(DW_EHIP, "dw_create: no HIP device visible (this library has no CPU path)");
     DwHandle *h = (DwHandle *)calloc(1, sizeof(DwHandle));
+    if (h) h->next_step = -1;
     if (!h) return fail(DW_ENOMEM, "dw_create: out of host memory");
     h->cfg = *cfg;
     h->params = dw::make_task_params(cfg);
@@ -159,6 +160,7 @@ int dw_destroy(DwHandle *h) {
     if (h->d_sc_park) (void)hipFree(h->d_sc_park);
     if (h->d_hmax) (void)hipFree(h->d_hmax);
     if (h->d_lvl_acc) (void)hipFree(h->d_lvl_acc);
+    if (h->d_amp_args) (void)hipFree(h->d_amp_args);
     free(h);
     return DW_OK;
 }

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "dw_params.h"
+#include "dw_handle.h"
 #include "dw_oct_kernels.h"
 #include "dw_amp_step.h"
 
@@ -55,11 +58,24 @@ void dw_k_simulate_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel
 // regions run with 128 threads per group (EnvGroupT<128>; the four serial per-env functions two to a wavefront) instead of the 256 of the
 // three separate kernels; LDS is the octet slots and the task's staging rows in turn (a union: 40.9 KB, 8 waves per CU as before).
 // Until round 6 a step was begin | simulate | mid | simulate | end = five launches of a replayed graph (0.206 ms at 16384 envs).
+// (the k-th of eight pointers held in registers: selects, no indexed private array)
+__device__ __forceinline__ const float *zsel(const float *const (&z)[8], int k) {
+    const float *r = z[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r = k == i ? z[i] : r;
+    return r;
+}
 struct AmpZ { const float *z[8]; };          // the caller's encoder draws, one [N, 33] array per substep (NULL: device draws / no noise)
+struct AmpArgs { DwAmpConfig C; DwAmpBuffers B; };          // the task's two tables in device memory (DwHandle::d_amp_args)
+static_assert(sizeof(AmpArgs) <= sizeof(((DwHandle *)nullptr)->amp_args_host), "DwHandle::amp_args_host holds the task's tables");
 __global__ __launch_bounds__(64 * dwo::WPG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dw_k_amp_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel *__restrict__ M, const dw::DevParams *__restrict__ P, const DwHot HB,
-                       const DwAmpConfig C, const DwAmpBuffers B, const dwa::GymRows G, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u,
-                       const AmpZ Z, const float *rootvel_noise, int K) {
+                       const AmpArgs *__restrict__ A, const dwa::GymRows G, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u,
+                       const float *z0, const float *z1, const float *z2, const float *z3, const float *z4, const float *z5, const float *z6, const float *z7,
+                       const float *rootvel_noise, int K) {
+    const DwAmpConfig &C = A->C;
+    const DwAmpBuffers &B = A->B;
+    const float *const zs[8] = {z0, z1, z2, z3, z4, z5, z6, z7};
     static_assert(dwo::WPG == 2 && dwo::EPO * dwo::WPG == dwa::GE, "an octet workgroup and an env group are the same 16 envs");
     union Lds { dwo::OLds L; dwa::GroupLds G; dwa::BeginLds Bg; __device__ Lds() {} };
     __shared__ Lds S;
@@ -70,9 +86,9 @@ void dw_k_amp_step_oct(const dwq::QuadModel *__restrict__ QM, const dw::DevModel
         // (every region ends with a workgroup barrier: the torques of the group's envs are in DwAmpBuffers.tau, the state in the Gym tensors)
         dwo::oct_simulate<false>(S.L.w[w], S.L.hot, *QM, *M, P->C.phys, P->C.friction, P->C.num_envs, make_obuf(HB, &P->B), B.tau, nullptr, group * dwo::WPG + w);
         __syncthreads();
-        if (k + 1 < K) dwa::step_mid(WG(), C, B, G.dof_state, Z.z[k], k, group);
+        if (k + 1 < K) dwa::step_mid(WG(), C, B, G.dof_state, zsel(zs, k), k, group);
     }
-    dwa::step_end(WG(), S.G, *M, C, B, G, Z.z[K - 1], K - 1, rootvel_noise, group);
+    dwa::step_end(WG(), S.G, *M, C, B, G, zsel(zs, K - 1), K - 1, rootvel_noise, group);
 }
 
 namespace dwq {
@@ -141,12 +157,27 @@ void launch_simulate(bool terrain, int wave_build, int num_envs, hipStream_t str
     else if (sp) hipLaunchKernelGGL((dw_k_simulate_oct<false, 1>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
     else hipLaunchKernelGGL((dw_k_simulate_oct<false, 2>), grid, block, 0, stream, QM, M, P, make_hot(B), tau, push);
 }
-void launch_amp_step(int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers &Bf, const DwAmpConfig &C,
-                     const DwAmpBuffers &B, const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z, int K, const float *rootvel_noise) {
+void launch_amp_step(int num_envs, hipStream_t stream, const dwq::QuadModel *QM, const dw::DevModel *M, const dw::DevParams *P, const DwBuffers &Bf, const void *d_args,
+                     const float *actions_in, const int64_t *ramp_dur, const float *ramp_u, const float *const *z, int K, const float *rootvel_noise) {
     AmpZ Z;
     for (int k = 0; k < 8; ++k) Z.z[k] = (z && k < K) ? z[k] : nullptr;
     const dwa::GymRows G{Bf.root_states, Bf.dof_state, Bf.contact_forces, Bf.dof_damping, Bf.dof_armature};
-    hipLaunchKernelGGL(dw_k_amp_step_oct, dim3(groups(num_envs)), dim3(64 * WPG), 0, stream, QM, M, P, make_hot(Bf), C, B, G, actions_in, ramp_dur, ramp_u, Z, rootvel_noise, K);
+    hipLaunchKernelGGL(dw_k_amp_step_oct, dim3(groups(num_envs)), dim3(64 * WPG), 0, stream, QM, M, P, make_hot(Bf), (const AmpArgs *)d_args, G, actions_in, ramp_dur, ramp_u,
+                       Z.z[0], Z.z[1], Z.z[2], Z.z[3], Z.z[4], Z.z[5], Z.z[6], Z.z[7], rootvel_noise, K);
+}
+// the task's tables in the handle's device copy: copied when they differ from what is there (in steady state never: the tables of an env do
+// not change between steps), on the launch's stream so that the launch behind it reads the new ones
+int amp_args_to_device(DwHandle *h, const DwAmpConfig &C, const DwAmpBuffers &B, hipStream_t stream) {
+    AmpArgs a;
+    memset(&a, 0, sizeof a);
+    a.C = C; a.B = B;
+    if (!h->d_amp_args && hipMalloc(&h->d_amp_args, sizeof(AmpArgs)) != hipSuccess) return DW_ENOMEM;
+    if (!h->amp_args_valid || memcmp(h->amp_args_host, &a, sizeof a) != 0) {
+        memcpy(h->amp_args_host, &a, sizeof a);
+        if (hipMemcpyAsync(h->d_amp_args, h->amp_args_host, sizeof a, hipMemcpyHostToDevice, stream) != hipSuccess) { h->amp_args_valid = 0; return DW_EHIP; }
+        h->amp_args_valid = 1;
+    }
+    return DW_OK;
 }
 int oct_lds_bytes() { return (int)sizeof(OLds); }
 int sc_park_words() { return SC_PARK_WORDS; }

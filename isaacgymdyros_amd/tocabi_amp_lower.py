@@ -304,11 +304,10 @@ class TocabiAMPLower(VecTask):
             raise ValueError("sim.mi355.amp_device_draws: the fused reset covers stateInit 'Default' only")
         # cfg sim.mi355.amp_one_launch (fused step on the plane; default OFF): the whole step -- the three task kernels and the K physics substeps
         # between them -- as ONE launch (dw_amp_step, include/dyros_walk.h): same arithmetic in the same order, same bits
-        # (tests/test_amp_gpu.py).  Measured at 16384 envs in a replayed graph: 0.238 ms against 0.206 ms for the five launches
-        # (profiles/r06_amp_one_launch.txt) -- the task code is item loops with a dependent global load per iteration, which the separate
-        # kernels run with 16 wavefronts per CU in flight and the octet workgroup with 8 (its 256 registers per lane allow no more): what the
-        # launch boundaries cost (~20 us) is less than what the lost occupancy costs (~50 us).  Kept as an entry point and a negative result
-        # (DESIGN.md section 9); a win would need the task code rewritten in the walk task's form (requests batched per phase, hot rows in LDS).
+        # (tests/test_amp_gpu.py).  Measured at 16384 envs in a replayed graph: 0.254 ms against 0.194 ms for the five launches
+        # (profiles/r06_amp_one_launch.txt) -- the task regions run with 16 wavefronts per CU and ~70 registers as kernels of their own, with 8
+        # wavefronts per CU under the substep's 256-register budget inside the octet workgroup: what the launch boundaries cost (~20 us) is
+        # less than what the fusion loses (~60 us).  Kept as an entry point and a negative result.
         # (A handle of at most 4096 envs takes the hex instantiation for dw_simulate, whose sums round differently from the octet substep the
         #  one-launch step carries: comparisons pin sim.mi355.debug_wave_build = 2.)
         self._one_launch = bool(mi.get("amp_one_launch", False)) and self._fused

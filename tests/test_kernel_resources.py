@@ -104,9 +104,11 @@ def test_small_kernels_do_not_spill(usage):
     seen = 0
     for k, r in usage.items():
         if "dw_k_amp_step_oct" in k:
-            # (the one-launch step of round 6, off by default: the task regions' registers next to the octet substep's spill 140 B at two waves per
-            #  SIMD -- part of why it measured slower than the five launches, isaacgymdyros_amd/tocabi_amp_lower.py amp_one_launch; bounded here)
-            assert r["ScratchSize"] <= 160 and r["Occupancy"] == 2 and r["LDS Size"] <= 40960, (k, r)
+            # (the one-launch step of round 6, off by default: the compiler hoists the task tables' ~150 invariant fields out of the regions and
+            #  spills them around the octet substep's 256 registers -- 528 B, reloaded once per region; with the tables as by-value kernel
+            #  arguments the whole 1 140 B went to scratch.  Part of why it measured slower than the five launches,
+            #  isaacgymdyros_amd/tocabi_amp_lower.py amp_one_launch; bounded here)
+            assert r["ScratchSize"] <= 560 and r["Occupancy"] == 2 and r["LDS Size"] <= 40960, (k, r)
         elif "dw_k_amp" in k or "dw_k_newwalk" in k or "dw_k_body_positions" in k:
             seen += 1
             assert r["ScratchSize"] == 0, (k, r)

@@ -9,6 +9,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]) if args else 16384
 cfg = default_amp_cfg(N, "cuda:0")
 cfg["sim"]["mi355"] = {"amp_fused": "--fused" in sys.argv, "amp_device_draws": "--draws" in sys.argv, "amp_hist_ring": "--noring" not in sys.argv}
+if os.environ.get("DW_AMP_ONE"):          # the whole step as one launch (dw_amp_step)
+    cfg["sim"]["mi355"]["amp_one_launch"] = True
 env = TocabiAMPLower(cfg, "cuda:0", 0, True)
 env.reset_done()
 if GRAPH:
