@@ -108,8 +108,11 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     r = run(a.samples, a.seed, a.corner, a.ranges, (a.leg, a.upper))
-    if a.out:
-        json.dump(r, open(a.out, "w"), indent=1)
+    if a.out:          # (one pair per line)
+        pairs = r.pop("pairs")
+        with open(a.out, "w") as f:
+            f.write(json.dumps(r)[:-1] + ', "pairs": [\n' + ",\n".join(json.dumps(p) for p in pairs) + "\n]}\n")
+        r["pairs"] = pairs
     print("samples %d, with a touch %d (%.2f %%), with a touch no proxy pair covers %d (%.2f %%)" % (
         r["samples"], r["samples_with_a_touch"], 100.0 * r["samples_with_a_touch"] / r["samples"], r["samples_with_an_uncovered_touch"],
         100.0 * r["samples_with_an_uncovered_touch"] / r["samples"]))
