@@ -56,7 +56,7 @@ def usage():
             u.update(r)
     # (the tracked record under profiles/ is refreshed on request only: DW_WRITE_PROFILES=1 python -m pytest tests/test_kernel_resources.py)
     if os.environ.get("DW_WRITE_PROFILES") == "1":
-        json.dump(u, open(os.path.join(ROOT, "profiles", "r05_kernel_resources.json"), "w"), indent=1, sort_keys=True)
+        json.dump(u, open(os.path.join(ROOT, "profiles", "r06_kernel_resources.json"), "w"), indent=1, sort_keys=True)
     return u
 
 
