@@ -228,7 +228,7 @@ GRAPH_COLLECTIVE = os.environ.get("DW_PPO_GRAPH_COLLECTIVE", "1") == "1"
 
 
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
-          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False, fused_update=False, fused_collective=None):
+          rank=0, world=1, seed=42, graph_rollout=False, graph_update=False, fused_update=False, fused_collective=None, global_gate=False):
     """`epochs` PPO epochs of the DYROS configuration on `num_envs` envs of this rank.  Returns one stats dict per epoch.
     graph_rollout: one rollout step (policy inference, sampling, env step, bookkeeping) is captured once in a hipGraph and
     replayed `horizon` times per epoch -- possible because dw_step_dev keeps the step counter in device memory, so a replayed
@@ -241,7 +241,9 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
     weight-gradient launch and the statistics (FusedPpoUpdate.allreduce: where the reference's Horovod optimizer.synchronize() stands,
     a2c_continuous_seperate.py:171-180), captured inside the chain of updates (one replay per UPD_CHAIN updates); if the capture of the
     collective is refused, or with DW_PPO_GRAPH_COLLECTIVE=0, the update is two replayed graphs with the collective enqueued between them.
-    fused_collective=True runs that sharded form of the update on ONE rank too (tests: same bits as the plain four launches)."""
+    fused_collective=True runs that sharded form of the update on ONE rank too (tests: same bits as the plain four launches).
+    global_gate (sharded runs): once per horizon the ranks' push-perturbation gates latch on the means over ALL envs
+    (env.sync_perturbation_gate: one all-reduce of 3 doubles) instead of per rank as in the reference's Horovod layout."""
     from isaacgymdyros_amd.config import default_cfg
     from isaacgymdyros_amd.dyros_dynamic_walk import DyrosDynamicWalk
     cfg = cfg or TRAIN_CFG
@@ -411,6 +413,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
             else:
                 advs = discount_values(dones, last_values, mb["done"], mb["val"], mb["rew"], c["gamma"], c["tau"])
             returns = advs + mb["val"]
+        if global_gate and world > 1 and hasattr(env, "sync_perturbation_gate"):
+            env.sync_perturbation_gate()
         if graph is not None and recorder is not None:
             recorder.rows()                                                     # (the device row counter must stand at H: a host read, next to the sync below)
         _sync(device)                                                           # (the rollout's device work is part of play_time in both modes)

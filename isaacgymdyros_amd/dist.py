@@ -1,7 +1,9 @@
 """Multi-GPU layout: one process per GPU, each with its own block of environments (the reference's Horovod
 layout, utils/rlgames_utils.py:71-81).  Environments are physically independent, so `step` needs no exchange;
 the only collective is a logging one, issued once per rollout horizon: an all-gather of finished-episode
-statistics over RCCL/xGMI (backend "nccl" on ROCm) -- or gloo on CPU tensors in the tests."""
+statistics over RCCL/xGMI (backend "nccl" on ROCm) -- or gloo on CPU tensors in the tests.  Optional, also once per horizon:
+`sync_perturbation_gate`, which lets the ranks' push-perturbation gates latch on the GLOBAL population means, as one simulation of
+all the envs would."""
 from __future__ import annotations
 
 import os
@@ -61,3 +63,27 @@ def summarize(stats: torch.Tensor) -> dict:
     n = max(s[2], 1.0)
     return {"mean_episode_return": s[0] / n, "mean_episode_length": s[1] / n, "envs_with_episode": int(s[2]),
             "episodes": int(s[3])}
+
+
+def sync_perturbation_gate(gate_acc: torch.Tensor, steps_done: int, num_envs: int, max_episode_length: float = 8000.0,
+                           pert_period: float = 2000.0, group=None) -> torch.Tensor:
+    """The one cross-env coupling of the step is the perturbation gate: pushes start once mean(epi_len_log) > max_episode_length - period
+    (6000) AND mean(contact_reward_mean) > 0.165 over ALL envs (tasks/dyros_dynamic_walk.py:489), and stay on (the latch).  Sharded, every rank
+    takes those means over its own envs -- the reference's Horovod layout.  This is the optional emulation of ONE simulation of all the envs
+    (SURVEY.md section 8e): an all-reduce of the newest step's two sums and the env count (3 doubles), the condition evaluated on the global
+    means, the latch word of every rank's gate_acc set if it holds.  Call it once per rollout horizon, after `steps_done` steps (the sums of
+    step s are in slot s % 3 of gate_acc: include/dyros_walk.h DW_GATE_*).  No host sync: everything stays on gate_acc's device.
+    Returns the 0-d bool tensor `gate is open globally`."""
+    nb, latch = abi.K["DW_GATE_BUCKETS"], abi.K["DW_GATE_LATCH"]
+    if gate_acc.dtype != torch.int64 or gate_acc.numel() <= latch:
+        raise ValueError("sync_perturbation_gate: gate_acc must be the int64 [DW_GATE_WORDS] buffer of the env")
+    if steps_done < 1:
+        raise ValueError("sync_perturbation_gate: no step has filled a slot yet")
+    slot = (int(steps_done) - 1) % 3
+    sums = gate_acc[slot * nb * 2:(slot + 1) * nb * 2].view(nb, 2).sum(0).double()          # (sum of epi_len_log, sum of contact_reward_mean * 2^32)
+    vec = torch.cat([sums, torch.tensor([float(num_envs)], dtype=torch.float64, device=gate_acc.device)])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(vec, group=group)
+    is_open = (vec[0] / vec[2] > float(max_episode_length) - float(pert_period)) & (vec[1] / 4294967296.0 / vec[2] > 0.165)
+    gate_acc[latch] = torch.maximum(gate_acc[latch], is_open.to(torch.int64))
+    return is_open

@@ -386,6 +386,18 @@ class DyrosDynamicWalk(VecTask):
             self._step_count = int(self._step_dev.item())
         return self._step_count
 
+    def sync_perturbation_gate(self, group=None):
+        """Optional, sharded runs only: lets this rank's push-perturbation gate latch on the means over ALL ranks' envs
+        (tasks/dyros_dynamic_walk.py:489 as ONE simulation of every env would evaluate it) instead of its own -- one all-reduce of 3 doubles,
+        called once per rollout horizon (isaacgymdyros_amd/dist.py sync_perturbation_gate).  Without it the gates are per rank, which is the
+        reference's Horovod layout.  Reads the step counter (a host sync with sim.mi355.device_step_counter)."""
+        from . import dist as dwdist
+        steps = self._current_step()
+        if steps < 1:
+            return None
+        dtp = float(self.cfg["sim"]["dt"]) * float(self.cfg["env"].get("controlFrequencyInv", 2))
+        return dwdist.sync_perturbation_gate(self._buf["gate_acc"], steps, self.num_envs, float(self.max_episode_length), 8.0 / dtp, group)
+
     def kernel_info(self) -> dict:
         """Which device kernel one step() launches (bench.py names it in its roofline object; the rocprofv3 summaries under
         profiles/ carry the same name)."""

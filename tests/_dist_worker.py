@@ -21,7 +21,26 @@ abi.es_view(es, "epi_len_log")[:] = ids + 1.0
 abi.es_view(es, "episodes_finished")[:] = (torch.arange(lo, hi) % 2 == 0).int() * 3   # even envs finished 3 episodes
 stats = dwdist.gather_episode_stats(es)
 summ = dwdist.summarize(stats)
-out = dict(rank=rank, world=world, lo=lo, hi=hi, stats_shape=list(stats.shape), summary=summ)
+
+# the optional global perturbation gate (dist.sync_perturbation_gate): rank r's newest slot holds the sums of n envs whose mean episode
+# length is 5000 + 1500 r and whose mean contact reward is 0.15 + 0.03 r, spread over the 32 buckets.  Case A: steps_done = 5 -> slot 1;
+# case B: slot 2 with every rank below both thresholds
+def gate_with(steps_done, mean_len, mean_crm):
+    g = torch.zeros(abi.K["DW_GATE_WORDS"], dtype=torch.int64)
+    slot = (steps_done - 1) % 3
+    nb = abi.K["DW_GATE_BUCKETS"]
+    for e in range(n):
+        g[(slot * nb + e % nb) * 2] += int(mean_len)
+        g[(slot * nb + e % nb) * 2 + 1] += int(round(mean_crm * 4294967296.0))
+    return g
+gA = gate_with(5, 5000 + 1500 * rank, 0.15 + 0.03 * rank)
+openA = bool(dwdist.sync_perturbation_gate(gA, 5, n))
+gB = gate_with(6, 3000 + 100 * rank, 0.10)
+openB = bool(dwdist.sync_perturbation_gate(gB, 6, n))
+gC = gate_with(6, 3000, 0.10); gC[abi.K["DW_GATE_LATCH"]] = 1          # an already latched gate stays latched
+dwdist.sync_perturbation_gate(gC, 6, n)
+gate = dict(openA=openA, latchA=int(gA[abi.K["DW_GATE_LATCH"]]), openB=openB, latchB=int(gB[abi.K["DW_GATE_LATCH"]]), latchC=int(gC[abi.K["DW_GATE_LATCH"]]), n=n)
+out = dict(rank=rank, world=world, lo=lo, hi=hi, stats_shape=list(stats.shape), summary=summ, gate=gate)
 with open(os.path.join(sys.argv[1], "rank%d.json" % rank), "w") as f:
     json.dump(out, f)
 dist.barrier()

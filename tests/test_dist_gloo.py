@@ -38,5 +38,16 @@ def test_episode_stats_all_gather_gloo(tmp_path, world):
         assert s["envs_with_episode"] == len(even)
         assert s["episodes"] == 3 * len(even)
         assert s["mean_episode_return"] == pytest.approx(sum(2.0 * e for e in even) / len(even))
+    # the optional global perturbation gate: the condition of tasks/dyros_dynamic_walk.py:489 on the means over ALL ranks' envs
+    ns = [o["gate"]["n"] for o in outs]
+    glen = sum(nr * (5000 + 1500 * r) for r, nr in enumerate(ns)) / sum(ns)
+    gcrm = sum(nr * (0.15 + 0.03 * r) for r, nr in enumerate(ns)) / sum(ns)
+    want = glen > 6000 and gcrm > 0.165
+    alone = [(5000 + 1500 * r) > 6000 and (0.15 + 0.03 * r) > 0.165 for r in range(world)]
+    assert any(a != want for a in alone), "the case must tell the global gate from some rank's own"
+    for o in outs:
+        g = o["gate"]
+        assert g["openA"] == want and g["latchA"] == int(want), (g, glen, gcrm)          # every rank decides alike, on the global means
+        assert not g["openB"] and g["latchB"] == 0 and g["latchC"] == 1
         assert s["mean_episode_length"] == pytest.approx(sum(e + 1.0 for e in even) / len(even))
     assert sorted((o["lo"], o["hi"]) for o in outs) == [dwdist.shard_range(total, r, world) for r in range(world)]
