@@ -445,6 +445,19 @@ def test_perturbation_gate_on_device():
     slot = 1
     tot_epi = acc[slot * 64: slot * 64 + 64: 2].sum()
     assert tot_epi == 7000 * N
+    # the optional global gate of sharded runs (dist.sync_perturbation_gate), here on one rank: it reads the slot the newest step filled and
+    # sets the latch by the same condition -- on a fresh env after ONE step with the statistics raised by hand, before the kernel's own gate
+    # (which reads the PREVIOUS step's sums) has opened
+    env2 = make_env(N, debug_freeze_physics=True)
+    env2.epi_len_log[:] = 7000.0
+    env2.contact_reward_mean[:] = 0.18
+    env2.step(a)
+    torch.cuda.synchronize()
+    assert int(env2._buf["gate_acc"][abi.K["DW_GATE_LATCH"]]) == 0
+    assert bool(env2.sync_perturbation_gate()) and int(env2._buf["gate_acc"][abi.K["DW_GATE_LATCH"]]) == 1
+    env3 = make_env(N, debug_freeze_physics=True)
+    env3.step(a)
+    assert not bool(env3.sync_perturbation_gate()) and int(env3._buf["gate_acc"][abi.K["DW_GATE_LATCH"]]) == 0
 
 
 def test_state_dict_roundtrip_resumes_bitwise():
