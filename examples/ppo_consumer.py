@@ -225,6 +225,10 @@ UPD_CHAIN = int(os.environ.get("DW_PPO_CHAIN", "16"))          # fused updates p
 # stack, profiles/r06_graph_collective_probe.txt) -- if the capture is refused, or with DW_PPO_GRAPH_COLLECTIVE=0, the update is two graphs with
 # the collective enqueued between them (measured on one rank at 16384 envs: 14.51 M captured, 12.05 M split, 14.68 M unsharded)
 GRAPH_COLLECTIVE = os.environ.get("DW_PPO_GRAPH_COLLECTIVE", "1") == "1"
+# the update's statistics + Adam + scaler as ONE launch with a grid barrier (dwp_stats_adam_finish) -- three launches per update; 0: as two
+MERGED_TAIL = os.environ.get("DW_PPO_MERGED_TAIL", "0") == "1"
+# the rollout policy's fp32 operand-order copy of the weights: rewritten by every update's Adam launch (1), or once per epoch after the updates (0)
+POLICY_COPY_PER_UPDATE = os.environ.get("DW_PPO_POLICY_COPY_PER_UPDATE", "0") == "1"
 
 
 def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cfg=None, max_epochs=None, env=None,
@@ -272,7 +276,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
         _m = min(int(c["minibatch_size"]), _b)
         # (re-points the module's parameters at its master buffer: before any capture.  Sharded: every rank starts from the same weights --
         #  the seed above -- and applies the same averaged gradient, so the ranks stay in step without a broadcast)
-        fused = FusedPpoUpdate(net, c, _m, _b // _m, device, rowmajor=False, world=world, collective=fused_collective)
+        fused = FusedPpoUpdate(net, c, _m, _b // _m, device, rowmajor=False, merged_tail=MERGED_TAIL, policy_copy_per_update=POLICY_COPY_PER_UPDATE,
+                               world=world, collective=fused_collective)
         graph_update = False
     if graph_update:        # (learning rates as device tensors: the schedule writes them in place and the captured step reads them)
         opt_a = torch.optim.Adam(net.actor_parameters(), lr=torch.tensor(float(c["learning_rate"]), device=device), eps=1e-8, fused=True, capturable=True)
@@ -518,6 +523,8 @@ def train(num_envs=16384, epochs=2, horizon=None, device="cuda:0", log=print, cf
                 if upd_tail is not None:
                     fused.allreduce()
                     upd_tail.replay()
+            if not fused.policy_copy_per_update:
+                fused.sync_policy_copy()          # (the next rollout's dwp_policy reads the weights in its own operand order: one launch per epoch)
             lg = fused.logged()
             a_l, c_l, b_l, cf, kl = lg[0], lg[1], lg[2], lg[3], lg[4]
         srcs = (B["obs"], B["act"], B["neglogp"], B["mu"], adv, ret, val)

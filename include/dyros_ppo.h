@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DWP_ABI_VERSION 7
+#define DWP_ABI_VERSION 8
 #define DWP_IN    487   /* observation words (DyrosDynamicWalk.yaml numObservations)        */
 #define DWP_INP   512   /* ... padded: rows of the input matrix and of W1 (zero columns), so that the GEMMs see aligned rows */
 #define DWP_HID   256   /* cfg/train/DyrosDynamicWalkPPO.yaml:27 units [256, 256]            */
@@ -99,7 +99,7 @@ int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const flo
 /* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */
 int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
 
-#define DWP_PARTS 768   /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates, the G16 switch */
+#define DWP_PARTS 2048  /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates, the G16 switch */
 #define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
 #define DWP_P32F_WORDS 401408   /* floats of p32f, the fp32 weights in the order dwp_policy's matrix instructions take them (csrc/dw_ppo.hip frag32_pos) */
 #define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */
@@ -137,6 +137,18 @@ int dwp_adam(float *p, uint16_t *p16, float *m, float *v, const uint16_t *g16, c
  * dwp_grad_stats overwrites it) */
 int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb, float *state, const float *part, float max_norm, uint16_t *p16f,
                     const float *g32, int32_t g32_slabs, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, void *stream);
+
+/* dwp_grad_stats and dwp_adam_finish in ONE launch (ABI 8): every Adam block keeps its eight parameters' gradients in registers, publishes its share of
+ * the actor's norm and its inf / nan flags as one tagged 64-bit word, and every block waits for all 197 shares before the first parameter moves (198
+ * blocks of 256 threads: co-resident whenever the launch has the device to itself).  The wait is bounded: a thread that does not see its share within
+ * 32 768 polls takes both nets as non-finite (its block skips), sets part[642] and goes on, so the grid always drains; DWP_S_OUT[7] then reads 2 and the
+ * caller should treat the update as failed (part[642] stays set).  part: as dwp_grad_stats, plus words [640, 643) and [1024, 1536) that the caller
+ * zero-initialises with the rest and never touches.  pbuf_bias: dwp_mlp's accumulators if the bias gradients are still in their buckets (the plain form:
+ * = pbuf), or NULL if gb holds them already (the sharded form: gb = bucket + weights).  Same arithmetic as the two launches except the ORDER of the
+ * norm's partial sums (per Adam block here): norm2 and the actor's clipped step may differ from theirs in the last place; the critic's step, the flags
+ * and the scaler are the same bits. */
+int dwp_stats_adam_finish(float *p, uint16_t *p16, float *m, float *v, float *gb, float *state, float *part, float max_norm, uint16_t *p16f, const float *g32,
+                          int32_t g32_slabs, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, float *pbuf_bias, void *stream);
 
 /* GradScaler.update (growth 2.0 every growth_interval clean updates, backoff 0.5), step counts, logged means (divided by B),
  * accumulators and gb cleared, minibatch index advanced modulo num_minibatches.  pbuf (or NULL): dwp_mlp's accumulators, whose logged-sum

@@ -388,6 +388,56 @@ __global__ __launch_bounds__(256) void k_finish(float *__restrict__ state, float
 // 8), and it is exactly one fragment of the forward operand order -- so the master, the moments, the row-major fp16 copy and the forward
 // fragment copy move as 16- / 32-byte pieces; only the input-gradient copies of W2 / W3 (k = the OUTPUT index) are eight scattered halves.
 static_assert(NW1 % 8 == 0 && NW2 % 8 == 0 && NW3 % 8 == 0 && NB1 % 8 == 0 && NB2 % 8 == 0 && NB3 % 8 == 0 && INP % 8 == 0 && HID % 8 == 0, "runs of eight");
+// the Adam step of eight consecutive parameters held in registers (gs: their still-scaled gradients) and every copy of the weights
+__device__ __forceinline__ void adam_apply(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v, _Float16 *__restrict__ p16f,
+                                           float *__restrict__ p32f, int i0, int net, f4 (&pv)[2], f4 (&mv)[2], f4 (&vv)[2], const float (&gs)[8], float scale, float step, float lr,
+                                           float norm2, float max_norm) {
+    const float inv = 1.0f / scale;
+    const float coef = net == 0 ? fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f) : 1.0f;          // torch.nn.utils.clip_grad_norm_ (the actor only)
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float bc1 = 1.0f - powf(b1, step), sq2 = sqrtf(1.0f - powf(b2, step)), ss = lr / bc1;
+    h8 ph;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float g = gs[q] * inv * coef;
+        const float mq = mv[q >> 2][q & 3], vq = vv[q >> 2][q & 3];
+        const float mi = mq + (g - mq) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = b2 * vq + (1.0f - b2) * g * g;
+        const float denom = sqrtf(vi) / sq2 + eps;
+        float pi = pv[q >> 2][q & 3] - ss * (mi / denom);
+        mv[q >> 2][q & 3] = mi; vv[q >> 2][q & 3] = vi; pv[q >> 2][q & 3] = pi;
+        // the fp16 copies are the STORED fp32 value rounded (what a cast of the master gives, e.g. after a checkpoint is loaded): without the
+        // opaque touch the compiler rounds the multiply-add once, straight to fp16 (v_fma_mixlo_f16), and ties fall the other way
+        asm volatile("" : "+v"(pi));
+        ph[q] = (_Float16)pi;
+    }
+    reinterpret_cast<f4 *>(p + i0)[0] = pv[0]; reinterpret_cast<f4 *>(p + i0)[1] = pv[1];
+    reinterpret_cast<f4 *>(m + i0)[0] = mv[0]; reinterpret_cast<f4 *>(m + i0)[1] = mv[1];
+    reinterpret_cast<f4 *>(v + i0)[0] = vv[0]; reinterpret_cast<f4 *>(v + i0)[1] = vv[1];
+    *reinterpret_cast<h8 *>(p16 + i0) = ph;
+    if (p32f && i0 < NWT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) write_frag32(p32f, i0 + q, pv[q >> 2][q & 3]);          // (the rollout's fp32 policy reads the masters in ITS operand order)
+    }
+    if (p16f && i0 < NWT) {
+        // forward operand order: my eight are one fragment (frag_pos of the first, k & 7 = 0); input-gradient order: one half each
+        int i = i0;
+        if (i < NW1) { const int nn = i / (HID * INP), o = (i / INP) % HID, k = i % INP; *reinterpret_cast<h8 *>(p16f + F_W1 + nn * HID * INP + frag_pos(HID / 16, o, k)) = ph; }
+        else if ((i -= NW1) < NW2) {
+            const int nn = i / (HID * HID), o = (i / HID) % HID, k = i % HID;
+            *reinterpret_cast<h8 *>(p16f + F_W2 + nn * HID * HID + frag_pos(HID / 16, o, k)) = ph;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p16f[F_W2T + nn * HID * HID + frag_pos(HID / 16, k + q, o)] = ph[q];
+        } else {
+            i -= NW2;
+            const int nn = i / (OUTP * HID), o = (i / HID) % OUTP, k = i % HID;
+            *reinterpret_cast<h8 *>(p16f + F_W3 + nn * OUTP * HID + frag_pos(1, o, k)) = ph;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p16f[F_W3T + nn * HID * 32 + frag_pos(HID / 16, k + q, o)] = ph[q];
+        }
+    }
+}
+
 // FIN: the launch also finishes the update (dwp_adam_finish: one graph node less).  Its blocks then read the loss scale, step counts,
 // learning rates and inf / nan flags from `part`, where dwp_grad_stats left them, because block 0 rewrites `state` while the others run.
 struct FinArgs { int B, nmb, growth_interval; float *pbuf; };
@@ -460,50 +510,7 @@ __global__ __launch_bounds__(256) void k_adam(float *__restrict__ p, _Float16 *_
     } else if (blockIdx.x == 0 && threadIdx.x == 0) state[DWP_S_NORM2] = norm2;
     if (i0 >= NP) return;
     if (skip) return;          // GradScaler.step: this optimiser's step is skipped
-    const float inv = 1.0f / scale;
-    const float coef = net == 0 ? fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f) : 1.0f;          // torch.nn.utils.clip_grad_norm_ (the actor only)
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    const float bc1 = 1.0f - powf(b1, step), sq2 = sqrtf(1.0f - powf(b2, step)), ss = lr / bc1;
-    h8 ph;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float g = gs[q] * inv * coef;
-        const float mq = mv[q >> 2][q & 3], vq = vv[q >> 2][q & 3];
-        const float mi = mq + (g - mq) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = b2 * vq + (1.0f - b2) * g * g;
-        const float denom = sqrtf(vi) / sq2 + eps;
-        float pi = pv[q >> 2][q & 3] - ss * (mi / denom);
-        mv[q >> 2][q & 3] = mi; vv[q >> 2][q & 3] = vi; pv[q >> 2][q & 3] = pi;
-        // the fp16 copies are the STORED fp32 value rounded (what a cast of the master gives, e.g. after a checkpoint is loaded): without the
-        // opaque touch the compiler rounds the multiply-add once, straight to fp16 (v_fma_mixlo_f16), and ties fall the other way
-        asm volatile("" : "+v"(pi));
-        ph[q] = (_Float16)pi;
-    }
-    reinterpret_cast<f4 *>(p + i0)[0] = pv[0]; reinterpret_cast<f4 *>(p + i0)[1] = pv[1];
-    reinterpret_cast<f4 *>(m + i0)[0] = mv[0]; reinterpret_cast<f4 *>(m + i0)[1] = mv[1];
-    reinterpret_cast<f4 *>(v + i0)[0] = vv[0]; reinterpret_cast<f4 *>(v + i0)[1] = vv[1];
-    *reinterpret_cast<h8 *>(p16 + i0) = ph;
-    if (p32f && i0 < NWT) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) write_frag32(p32f, i0 + q, pv[q >> 2][q & 3]);          // (the rollout's fp32 policy reads the masters in ITS operand order)
-    }
-    if (p16f && i0 < NWT) {
-        // forward operand order: my eight are one fragment (frag_pos of the first, k & 7 = 0); input-gradient order: one half each
-        int i = i0;
-        if (i < NW1) { const int nn = i / (HID * INP), o = (i / INP) % HID, k = i % INP; *reinterpret_cast<h8 *>(p16f + F_W1 + nn * HID * INP + frag_pos(HID / 16, o, k)) = ph; }
-        else if ((i -= NW1) < NW2) {
-            const int nn = i / (HID * HID), o = (i / HID) % HID, k = i % HID;
-            *reinterpret_cast<h8 *>(p16f + F_W2 + nn * HID * HID + frag_pos(HID / 16, o, k)) = ph;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) p16f[F_W2T + nn * HID * HID + frag_pos(HID / 16, k + q, o)] = ph[q];
-        } else {
-            i -= NW2;
-            const int nn = i / (OUTP * HID), o = (i / HID) % OUTP, k = i % HID;
-            *reinterpret_cast<h8 *>(p16f + F_W3 + nn * OUTP * HID + frag_pos(1, o, k)) = ph;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) p16f[F_W3T + nn * HID * 32 + frag_pos(HID / 16, k + q, o)] = ph[q];
-        }
-    }
+    adam_apply(p, p16, m, v, p16f, p32f, i0, net, pv, mv, vv, gs, scale, step, lr, norm2, max_norm);
 }
 
 // ------------------------------------------------------------------------------------------------ dwp_mlp: forward, loss, input gradients
@@ -957,6 +964,169 @@ __global__ __launch_bounds__(256) void k_gae(const float *__restrict__ fdones, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ statistics + Adam + finish in ONE launch
+// dwp_grad_stats and dwp_adam_finish read the same gradients twice and are a launch apart only because clip_grad_norm_ needs the norm over
+// ALL of the actor's gradients before the first parameter moves.  Here every Adam block holds its eight parameters' gradients in registers
+// and PUBLISHES its share of the norm and its inf / nan flags; every thread t of every block then waits for block t's share, and the block
+// sums the 197 shares (always the same way) and steps its parameters.  The grid barrier is in the data:
+//   * a share is ONE 64-bit word {partial sum, tag}, tag = the update's number (+ 1, 30 bits) | flags << 30, written with one agent-scope
+//     store (an sc1 access: it lands at the memory side of the eight XCDs' L2s) and polled with agent-scope loads -- no counter, no
+//     read-modify-write, no fence: a share is complete the moment its tag reads right.  What was measured on the way (profiles/r06_ppo_tail_forms.txt):
+//     an arrival counter under agent-scope release / acquire fences costs +120 us per update (every block writes back and invalidates the whole L2);
+//     the counter with waitcnt-only ordering, in one level or two, makes the launch exactly as long as the two it replaces (a store's
+//     acknowledgement, one or two serialised atomics, a poll and the partials' read are five round trips to the memory side);
+//   * 197 + 1 blocks of 256 threads on 256 CUs are co-resident whenever the launch has the device to itself (the update's launches are a chain
+//     on one stream), which is what waiting on each other needs; the wait is nevertheless BOUNDED: a thread that does not see its share within
+//     32 768 polls (tens of ms) takes the inf flags of both nets as set (its block skips its step), leaves a mark in part[642] and goes on, so the
+//     grid always drains; the finishing block then backs the loss scale off and publishes DWP_S_OUT[7] = 2.  (Blocks that saw every share before
+//     another gave up have stepped: a timed-out update is a fault to report, not a state to train on -- hence the mark.)
+//   * the update's number lives in part[641] (as unsigned), advanced by the finishing block; nothing is reset between updates.
+// Every block reads what it needs of `state` BEFORE it publishes (s_waitcnt vmcnt(0) in every thread), and the finishing block rewrites `state`
+// only after it has seen every share.  The norm's partial sums are per Adam block here and per dwp_grad_stats block there: the same terms in
+// another order, so norm2 -- and through the clip coefficient the actor's step -- may differ from the two-launch form in the last place.
+constexpr int SA_BLOCKS = (NP / 8 + 255) / 256;          // Adam blocks; one more finishes the update
+static_assert(SA_BLOCKS <= 256, "one share per thread");
+constexpr int PART_BAR = 640;          // `part` word 641 (as unsigned): the update's number; 642: non-zero once a wait timed out
+constexpr int PART_SHARES = 1024;          // `part` words [1024, 1024 + 2 x 256): the blocks' shares, 64 bits each
+static_assert(DWP_PARTS >= PART_SHARES + 2 * 256 && PART_SHARES % 2 == 0, "part buffer");
+template <int SLABS>
+__global__ __launch_bounds__(256) void k_stats_adam(float *__restrict__ p, _Float16 *__restrict__ p16, float *__restrict__ m, float *__restrict__ v, float *__restrict__ gb,
+                                                    float *__restrict__ state, float *__restrict__ part, float max_norm, _Float16 *__restrict__ p16f,
+                                                    const float *__restrict__ g32, float *__restrict__ p32f, FinArgs fin, float *__restrict__ pbuf) {
+    __shared__ float red[4];
+    __shared__ int redf[4];
+    __shared__ __attribute__((aligned(16))) float bsum[NBT];
+    __shared__ f4 btail[8][PBK];
+    unsigned *bar = reinterpret_cast<unsigned *>(part + PART_BAR);
+    unsigned long long *shares = reinterpret_cast<unsigned long long *>(part + PART_SHARES);
+    const bool finisher = blockIdx.x == SA_BLOCKS;
+    // what every block needs of `state`, read BEFORE the barrier: the finishing block rewrites these words behind it
+    const float scale = state[DWP_S_SCALE], g16r = state[DWP_S_G16];
+    const float st0 = state[DWP_S_STEP], st1 = state[DWP_S_STEP + 1], lr0 = state[DWP_S_LR], lr1 = state[DWP_S_LR + 1];
+    const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8, ic = (!finisher && i0 < NP) ? i0 : 0;
+    const int net = net_of(ic);
+    f4 pv[2] = {reinterpret_cast<const f4 *>(p + ic)[0], reinterpret_cast<const f4 *>(p + ic)[1]};
+    f4 mv[2] = {reinterpret_cast<const f4 *>(m + ic)[0], reinterpret_cast<const f4 *>(m + ic)[1]};
+    f4 vv[2] = {reinterpret_cast<const f4 *>(v + ic)[0], reinterpret_cast<const f4 *>(v + ic)[1]};
+    float gs[8];
+    if (blockIdx.x == SA_BLOCKS - 1 && pbuf) {
+        // Bias gradients of the dwp_mlp path (all 1056 belong to this block's first 132 threads): the columns' sums over the 32 buckets, cleared
+        // for the next update and left in gb.  By the WHOLE block, four columns per thread and every bucket row requested at once -- a thread
+        // that walks its own eight columns pays eight round trips to memory one after the other while 197 blocks wait at the barrier (+25 us).
+        // The last eight quads: one bucket row per thread, added up in bucket order from LDS.
+        static_assert(NBT % 4 == 0 && NBT / 4 == 256 + 8 && PBK == 32 && PBW % 4 == 0 && SA_BLOCKS * 2048 >= NP && (SA_BLOCKS - 1) * 2048 == NWT, "the bias block");
+        auto quad = [&](int j) -> float * {
+            const int qq = 4 * j;
+            const int col = qq < NB1 ? PB_B1 + qq % HID : (qq < NB1 + NB2 ? PB_B2 + (qq - NB1) % HID : PB_B3 + (qq - NB1 - NB2) % OUTP);
+            return pbuf + (size_t)net_of(NWT + qq) * PBW + col;
+        };
+        float *pc = quad(threadIdx.x), *pt = quad(256 + (threadIdx.x >> 5)) + (size_t)(threadIdx.x & 31) * 2 * PBW;
+        f4 a[PBK];
+#pragma unroll
+        for (int w = 0; w < PBK; ++w) a[w] = *reinterpret_cast<const f4 *>(pc + (size_t)w * 2 * PBW);
+        btail[threadIdx.x >> 5][threadIdx.x & 31] = *reinterpret_cast<const f4 *>(pt);
+        f4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w = 0; w < PBK; ++w) s4 += a[w];
+        const f4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w = 0; w < PBK; ++w) *reinterpret_cast<f4 *>(pc + (size_t)w * 2 * PBW) = z4;
+        *reinterpret_cast<f4 *>(pt) = z4;
+        *reinterpret_cast<f4 *>(bsum + 4 * threadIdx.x) = s4;
+        *reinterpret_cast<f4 *>(gb + 4 * threadIdx.x) = s4;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            f4 t4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int w = 0; w < PBK; ++w) t4 += btail[threadIdx.x][w];
+            *reinterpret_cast<f4 *>(bsum + 4 * (256 + threadIdx.x)) = t4;
+            *reinterpret_cast<f4 *>(gb + 4 * (256 + threadIdx.x)) = t4;
+        }
+        __syncthreads();
+    }
+    if (ic >= NWT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = pbuf ? bsum[ic - NWT + q] : gb[ic - NWT + q];
+    } else {
+        f4 a[SLABS][2];
+#pragma unroll
+        for (int k = 0; k < SLABS; ++k) { a[k][0] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[0]; a[k][1] = reinterpret_cast<const f4 *>(g32 + (size_t)k * NWT + ic)[1]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < SLABS; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { gs[q] += a[k][0][q]; gs[4 + q] += a[k][1][q]; }
+        }
+        if (g16r != 0.0f) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gs[q] = (float)(_Float16)gs[q];
+        }
+    }
+    // ---- this block's share of the statistics
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (every word of `state` this thread asked for has arrived: see above)
+    {
+        const float inv = 1.0f / scale;
+        float sq = 0.0f;
+        int bad = 0;
+        if (!finisher && i0 < NP) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { bad |= !isfinite(gs[q]); const float w = gs[q] * inv; sq += w * w; }
+        }
+        if (net != 0) sq = 0.0f;
+        const float s = wave_sum(sq);
+        const unsigned long long w0 = __ballot(bad && net == 0), w1 = __ballot(bad && net != 0);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redf[threadIdx.x >> 6] = (w0 ? 1 : 0) | (w1 ? 2 : 0); }
+        __syncthreads();
+        if (threadIdx.x == 0 && !finisher) {
+            const unsigned tag = ((gen + 1u) & 0x3fffffffu) | ((unsigned)(redf[0] | redf[1] | redf[2] | redf[3]) << 30);
+            const unsigned long long share = ((unsigned long long)tag << 32) | __float_as_uint(red[0] + red[1] + red[2] + red[3]);
+            __hip_atomic_store(shares + blockIdx.x, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- the norm and the flags of the whole gradient: thread t waits for block t's share
+    float my_part = 0.0f;
+    int fl = 0;
+    if (threadIdx.x < SA_BLOCKS) {
+        const unsigned want = (gen + 1u) & 0x3fffffffu;
+        int spins = 0;
+        for (;;) {
+            const unsigned long long w = __hip_atomic_load(shares + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned tag = (unsigned)(w >> 32);
+            if ((tag & 0x3fffffffu) == want) { my_part = __uint_as_float((unsigned)w); fl = (int)(tag >> 30); break; }
+            if (++spins > (1 << 15)) { fl = 4 | 3; break; }          // (never reached when the blocks are co-resident)
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (fl & 4) __hip_atomic_store(part + PART_BAR + 2, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+        const float s = wave_sum(my_part);
+        const unsigned long long w0 = __ballot(fl & 1), w1 = __ballot(fl & 2), w2 = __ballot(fl & 4);
+        __syncthreads();          // (red / redf are reused)
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redf[threadIdx.x >> 6] = (w0 ? 1 : 0) | (w1 ? 2 : 0) | (w2 ? 4 : 0); }
+        __syncthreads();
+    }
+    const float norm2 = red[0] + red[1] + red[2] + red[3];
+    const int flags = redf[0] | redf[1] | redf[2] | redf[3];
+    const bool met = !(flags & 4);
+    if (finisher) {
+        if (threadIdx.x == 0) {
+            state[DWP_S_NORM2] = norm2;
+            if (flags & 1) state[DWP_S_FOUND_INF] = 1.0f;
+            if (flags & 2) state[DWP_S_FOUND_INF + 1] = 1.0f;
+            __hip_atomic_store(bar + 1, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        finish_update(state, fin.B, fin.nmb, fin.growth_interval, fin.pbuf);
+        if (!met && threadIdx.x == 0) state[DWP_S_OUT + 7] = 2.0f;          // (the barrier timed out: that is why the update was skipped)
+        return;
+    }
+    if (i0 >= NP) return;
+    if ((flags >> net) & 1) return;          // GradScaler.step: this optimiser's step is skipped
+    adam_apply(p, p16, m, v, p16f, p32f, i0, net, pv, mv, vv, gs, scale, (net ? st1 : st0) + 1.0f, net ? lr1 : lr0, norm2, max_norm);
+}
+
 // ------------------------------------------------------------------------------------------------ the rollout's bookkeeping around env.step
 // What play_steps does between the policy's forward and the env step, and after it (learning/rl_games_custom/a2c_common_dyros.py:629-703):
 // sample the action, its neglogp, the step's row of every rollout buffer; then the shaped reward with the time-out bootstrap, the logged
@@ -1243,6 +1413,19 @@ int dwp_adam_finish(float *p, uint16_t *p16, float *m, float *v, const float *gb
         hipLaunchKernelGGL((k_adam<true, WG_SLABS>), dim3((NP / 8 + 255) / 256 + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, (const _Float16 *)nullptr, gb, state, part, max_norm,
                            (_Float16 *)p16t, g32, p32f, FinArgs{B, num_minibatches, growth_interval, pbuf});
     return done("dwp_adam_finish");
+}
+
+int dwp_stats_adam_finish(float *p, uint16_t *p16, float *m, float *v, float *gb, float *state, float *part, float max_norm, uint16_t *p16t, const float *g32,
+                          int32_t g32_slabs, float *p32f, int32_t B, int32_t num_minibatches, int32_t growth_interval, float *pbuf, float *pbuf_bias, void *stream) {
+    if (!p || !p16 || !m || !v || !g32 || !gb || !state || !part || !pbuf || B < 1 || num_minibatches < 1 || growth_interval < 1 || !slabs_ok(g32, g32_slabs))
+        return fail("dwp_stats_adam_finish: bad argument");
+    if (g32_slabs == 1)
+        hipLaunchKernelGGL((k_stats_adam<1>), dim3(SA_BLOCKS + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, gb, state, part, max_norm, (_Float16 *)p16t, g32, p32f,
+                           FinArgs{B, num_minibatches, growth_interval, pbuf}, pbuf_bias);
+    else
+        hipLaunchKernelGGL((k_stats_adam<WG_SLABS>), dim3(SA_BLOCKS + 1), dim3(256), 0, (hipStream_t)stream, p, (_Float16 *)p16, m, v, gb, state, part, max_norm, (_Float16 *)p16t, g32, p32f,
+                           FinArgs{B, num_minibatches, growth_interval, pbuf}, pbuf_bias);
+    return done("dwp_stats_adam_finish");
 }
 
 int dwp_wgrad(const uint16_t *xf, const uint16_t *h1f, const uint16_t *h2f, const uint16_t *doutf, const uint16_t *dz2f, const uint16_t *dz1f, const float *state,

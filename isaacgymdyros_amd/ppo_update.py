@@ -39,7 +39,7 @@ def _constants() -> dict:
 
 
 K = _constants()
-EXPORTS = ["abi_version", "last_error", "sizeof_mlp", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "grad_bucket", "adam", "adam_finish", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
+EXPORTS = ["abi_version", "last_error", "sizeof_mlp", "stage_obs", "bias_relu", "loss", "relu_bwd", "grad_stats", "grad_bucket", "adam", "adam_finish", "stats_adam_finish", "finish", "retile", "mlp", "wgrad", "gae", "rollout_pre", "rollout_post", "policy", "retile32"]
 IN, INP, HID, OUTP, ACT = K["DWP_IN"], K["DWP_INP"], K["DWP_HID"], K["DWP_OUTP"], K["DWP_ACT"]
 NW1, NW2, NW3 = 2 * HID * INP, 2 * HID * HID, 2 * OUTP * HID
 NWT = NW1 + NW2 + NW3
@@ -91,6 +91,7 @@ def declare(lib: C.CDLL) -> dict:
     api["adam"] = fn("adam", C.c_int, P, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int32, P, P)
     api["policy"] = fn("policy", C.c_int, P, P, P, C.c_int32, P, P, P)
     api["retile32"] = fn("retile32", C.c_int, P, P, P)
+    api["stats_adam_finish"] = fn("stats_adam_finish", C.c_int, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P, P, P)
     api["adam_finish"] = fn("adam_finish", C.c_int, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["finish"] = fn("finish", C.c_int, P, P, C.c_int32, C.c_int32, C.c_int32, P, P)
     api["retile"] = fn("retile", C.c_int, P, P, P)
@@ -213,10 +214,17 @@ class FusedPpoUpdate:
     be captured in a hipGraph once and replayed)."""
 
     def __init__(self, net, cfg: dict, minibatch: int, num_minibatches: int, device, mfma: bool = True, rowmajor: bool = True, split_tail: bool = False,
-                 world: int = 1, group=None, collective: bool = None, fp16_grads: bool = False):
+                 merged_tail: bool = False, policy_copy_per_update: bool = True, world: int = 1, group=None, collective: bool = None, fp16_grads: bool = False):
         """mfma: forward, loss and input gradients in ONE launch on the matrix cores (dwp_mlp + dwp_wgrad; the minibatch must be a multiple of 32, else the library-GEMM form runs) instead
         of eight library GEMM launches with six kernels between them.  rowmajor (mfma only): dwp_mlp also writes its activations and their
         gradients as plain [2, B, 256] / [B, 512] matrices (x16, h1, h2, dh2, dh1: what the tests read); a trainer passes False.
+        merged_tail (mfma only): dwp_grad_stats and dwp_adam_finish as ONE launch whose blocks wait for each other's share of the norm,
+        dwp_stats_adam_finish -- three launches per update (plus dwp_grad_bucket and the all-reduce when sharded).  Measured: exactly as long as the
+        two launches it replaces (profiles/r06_ppo_tail_forms.txt), so it is off by default; the actor's step may differ from theirs in the last place
+        (the norm's partial sums are taken in another order).  barrier_timed_out() reports the one way the merged launch can fail.
+        policy_copy_per_update (mfma only): every update's Adam launch also rewrites the fp32 operand-order copy dwp_policy reads (401 408 scattered
+        words, 1.1 us of the launch).  False: the updates leave that copy alone and `sync_policy_copy()` -- one launch -- brings it up to date; a
+        trainer calls it once after an epoch's updates.  `policy()` refuses to run on a copy it knows to be stale.
         split_tail (mfma only): the last launch, dwp_adam_finish, as dwp_adam + dwp_finish (five launches: what a test compares the merged one with).
         world, group (mfma only): the ranks that train together (torch.distributed, backend nccl = RCCL) -- every update then averages the
         ranks' gradients with ONE all-reduce of the 1.61 MB bucket between dwp_wgrad and dwp_grad_stats (`update()` =
@@ -239,6 +247,9 @@ class FusedPpoUpdate:
         self.dev = torch.device(device)
         self.B, self.nmb = int(minibatch), int(num_minibatches)
         self.split_tail = bool(split_tail)
+        self.merged_tail = bool(merged_tail) and not self.split_tail
+        self.policy_copy_per_update = bool(policy_copy_per_update)
+        self._policy_copy_stale = False
         self.world, self.group = int(world), group
         if self.world < 1:
             raise ValueError("FusedPpoUpdate: world must be at least 1")
@@ -340,8 +351,17 @@ class FusedPpoUpdate:
         if mu is None:
             mu, value = torch.empty(N, ACT, device=self.dev), torch.empty(N, 1, device=self.dev)
         _req("FusedPpoUpdate.policy: mu", mu, torch.float32, shape=(N, ACT)); _req("FusedPpoUpdate.policy: value", value, torch.float32, N)
+        if self._policy_copy_stale:
+            raise RuntimeError("FusedPpoUpdate.policy: updates ran with policy_copy_per_update=False and sync_policy_copy() was not called since")
         self._chk(self.api["policy"](obs.data_ptr(), self.p.data_ptr(), self.p32f.data_ptr(), N, mu.data_ptr(), value.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
         return mu, value
+
+    def sync_policy_copy(self):
+        """policy_copy_per_update=False: bring dwp_policy's fp32 operand-order copy of the weights up to date with the masters (one launch, dwp_retile32;
+        on the current stream).  Call it after the last update and before the next policy() -- also after REPLAYING a captured update, which this
+        object cannot see."""
+        self._chk(self.api["retile32"](self.p.data_ptr(), self.p32f.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream))
+        self._policy_copy_stale = False
 
     def refresh_copies(self):
         """After the module's parameters were written from outside (a checkpoint loaded into the network: they are views of the master buffer):
@@ -429,24 +449,37 @@ class FusedPpoUpdate:
             dist.all_reduce(self.bucket, group=self.group)
 
     def update_tail(self):
-        """Four-launch form, second part: dwp_grad_stats and dwp_adam_finish on the (averaged) gradient."""
+        """Second part: statistics, clip, Adam and the scaler on the (averaged) gradient -- dwp_stats_adam_finish, or dwp_grad_stats and dwp_adam_finish."""
         api, st, B = self.api, self.state.data_ptr(), self.B
         s = torch.cuda.current_stream(self.dev).cuda_stream
+        p32f = self.p32f.data_ptr() if self.policy_copy_per_update else None
+        self._policy_copy_stale = not self.policy_copy_per_update
+        if self.merged_tail:
+            g, gb, nsl = (self.bucket.data_ptr(), self.bucket.data_ptr() + 4 * NWT, 1) if self.collective else (self.g32.data_ptr(), self.gb.data_ptr(), K["DWP_WGRAD_SLABS"])
+            self._chk(api["stats_adam_finish"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), gb, st, self.part.data_ptr(), self.max_norm,
+                                               self.p16t.data_ptr(), g, nsl, p32f, B, self.nmb, 2000, self.pbuf.data_ptr(),
+                                               None if self.collective else self.pbuf.data_ptr(), s))
+            return
         if self.collective:
             gb = self.bucket.data_ptr() + 4 * NWT
             self._chk(api["grad_stats"](None, gb, st, self.part.data_ptr(), None, self.bucket.data_ptr(), 1, s))
             self._chk(api["adam_finish"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), gb, st, self.part.data_ptr(),
-                                         self.max_norm, self.p16t.data_ptr(), self.bucket.data_ptr(), 1, self.p32f.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
+                                         self.max_norm, self.p16t.data_ptr(), self.bucket.data_ptr(), 1, p32f, B, self.nmb, 2000, self.pbuf.data_ptr(), s))
             return
         nsl = K["DWP_WGRAD_SLABS"]
         self._chk(api["grad_stats"](None, self.gb.data_ptr(), st, self.part.data_ptr(), self.pbuf.data_ptr(), self.g32.data_ptr(), nsl, s))
         if self.split_tail:
             self._chk(api["adam"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), None, self.gb.data_ptr(), st,
-                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), nsl, self.p32f.data_ptr(), s))
+                                  self.part.data_ptr(), self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), nsl, p32f, s))
             self._chk(api["finish"](st, self.gb.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
             return
         self._chk(api["adam_finish"](self.p.data_ptr(), self.p16.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.gb.data_ptr(), st, self.part.data_ptr(),
-                                     self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), nsl, self.p32f.data_ptr(), B, self.nmb, 2000, self.pbuf.data_ptr(), s))
+                                     self.max_norm, self.p16t.data_ptr(), self.g32.data_ptr(), nsl, p32f, B, self.nmb, 2000, self.pbuf.data_ptr(), s))
+
+    def barrier_timed_out(self) -> bool:
+        """True once a block of dwp_stats_adam_finish gave up waiting at its grid barrier (the launch did not have the device to itself for tens of
+        ms): that update was published as skipped (DWP_S_OUT[7] = 2) but some blocks may have stepped -- reload a checkpoint.  Synchronises."""
+        return bool(self.part[642].item() != 0.0)
 
     def update(self):
         """Enqueue one minibatch update on the current stream."""

@@ -275,8 +275,8 @@ def test_kernel_pointer_arguments_are_checked_before_a_launch():
 
 
 def test_sharded_fused_update_averages_gradients_with_one_collective_on_gloo(tmp_path):
-    """The N > 1 path of the four-launch update (FusedPpoUpdate(world=2)): dwp_mlp | dwp_wgrad | dwp_grad_bucket | ONE all-reduce of the
-    [weights | biases] bucket | dwp_grad_stats | dwp_adam_finish, the gradients averaged BEFORE the statistics and the step
+    """The N > 1 path of the fused update (FusedPpoUpdate(world=2)): dwp_mlp | dwp_wgrad | dwp_grad_bucket | ONE all-reduce of the
+    [weights | biases] bucket | dwp_stats_adam_finish (or dwp_grad_stats | dwp_adam_finish), the gradients averaged BEFORE the statistics and the step
     (a2c_continuous_seperate.py:171-180).  CPU, gloo, world 2; the library is a stand-in that works on the raw addresses it is handed (the
     kernels themselves are GPU tests): each rank's 'weight gradient' depends on its rank, and both ranks must apply the same average."""
     worker = tmp_path / "w.py"
@@ -318,8 +318,12 @@ def adam_finish(p, p16, mm, v, gb, st, part, max_norm, p16t, g32, slabs, p32f, B
     calls.append("adam_finish"); seen["adam"] = (gb, g32, slabs)
     view(p, NWT + NBT)[:] -= 0.125 * np.concatenate([view(g32, NWT), view(gb, NBT)])
     return 0
+def stats_adam_finish(p, p16, mm, v, gb, st, part, max_norm, p16t, g32, slabs, p32f, B, nmb, gi, pbuf, pbuf_bias, s):
+    calls.append("stats_adam_finish"); seen["stats"] = (None, gb, pbuf_bias, g32, slabs); seen["adam"] = (gb, g32, slabs)
+    view(p, NWT + NBT)[:] -= 0.125 * np.concatenate([view(g32, NWT), view(gb, NBT)])
+    return 0
 noop = lambda *a: 0
-stub = dict(mlp=mlp, wgrad=wgrad, grad_bucket=grad_bucket, grad_stats=grad_stats, adam_finish=adam_finish, retile=noop, retile32=noop,
+stub = dict(mlp=mlp, wgrad=wgrad, grad_bucket=grad_bucket, grad_stats=grad_stats, adam_finish=adam_finish, stats_adam_finish=stats_adam_finish, retile=noop, retile32=noop,
             last_error=lambda: b"stub")
 U._lib.load = lambda: (None, None)
 U.declare = lambda lib: stub
@@ -332,7 +336,7 @@ def counted(t, *a, **k):
 dist.all_reduce = counted
 torch.manual_seed(0)
 net = m.DyrosActorCritic(U.IN, U.ACT, m.TRAIN_CFG["network"])
-f = U.FusedPpoUpdate(net, dict(m.TRAIN_CFG["config"]), 64, 2, "cpu", rowmajor=False, world=world)
+f = U.FusedPpoUpdate(net, dict(m.TRAIN_CFG["config"]), 64, 2, "cpu", rowmajor=False, world=world, merged_tail=sys.argv[2] == "merged")
 z = torch.zeros(128)
 f.src = (torch.zeros(128, U.INP, dtype=torch.float16), torch.zeros(128, U.ACT), z, torch.zeros(128, U.ACT), z, z)
 p0 = f.p.clone()
@@ -346,21 +350,22 @@ ok_w = bool(torch.allclose(p0[:NWT] - mine[:NWT], 2 * 0.125 * gavg, rtol=1e-6))
 ok_b = bool(torch.allclose(p0[NWT:] - mine[NWT:], torch.full((NBT,), 2 * 0.125 * bavg), rtol=1e-6))
 gb_expected = f.bucket.data_ptr() + 4 * NWT
 json.dump({"same": bool(torch.equal(both[0], both[1])), "ok_w": ok_w, "ok_b": ok_b, "collectives": n_coll[0], "numel": seen["numel"],
-           "order": calls[:5], "stats_args_ok": seen["stats"] == (None, gb_expected, None, f.bucket.data_ptr(), 1),
+           "order": calls[:len(calls) // 2], "stats_args_ok": seen["stats"] == (None, gb_expected, None, f.bucket.data_ptr(), 1),
            "adam_args_ok": seen["adam"] == (gb_expected, f.bucket.data_ptr(), 1)}, open(os.path.join(sys.argv[1], "f%%d.json" %% rank), "w"))
 dist.barrier(); dist.destroy_process_group()
 ''' % (ROOT, ROOT))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OMP_NUM_THREADS"] = "1"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29747", str(worker), str(tmp_path)], timeout=600, env=env, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
     from isaacgymdyros_amd import ppo_update as U
-    for k in range(2):
-        o = json.load(open(tmp_path / ("f%d.json" % k)))
-        assert o["same"] and o["ok_w"] and o["ok_b"], o
-        assert o["collectives"] == 2 and o["numel"] == U.NWT + U.NBT, o          # ONE all-reduce per update, of the whole bucket
-        assert o["order"] == ["mlp", "wgrad", "grad_bucket", "grad_stats", "adam_finish"] and o["stats_args_ok"] and o["adam_args_ok"], o
+    for form, tail in (("merged", ["stats_adam_finish"]), ("two", ["grad_stats", "adam_finish"])):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29747", str(worker), str(tmp_path), form], timeout=600, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        for k in range(2):
+            o = json.load(open(tmp_path / ("f%d.json" % k)))
+            assert o["same"] and o["ok_w"] and o["ok_b"], o
+            assert o["collectives"] == 2 and o["numel"] == U.NWT + U.NBT, o          # ONE all-reduce per update, of the whole bucket
+            assert o["order"] == ["mlp", "wgrad", "grad_bucket"] + tail and o["stats_args_ok"] and o["adam_args_ok"], (form, o)
 
 
 def test_fused_update_refuses_a_world_it_cannot_serve():

@@ -341,7 +341,7 @@ def test_adam_finish_equals_adam_then_finish():
     net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
     _lively(net)
     B, nmb = 1024, 4
-    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev)
+    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=False)
     fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, split_tail=True)
     batch = list(_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
     batch[5] = batch[5].clone()
@@ -365,6 +365,128 @@ def test_adam_finish_equals_adam_then_finish():
         assert torch.allclose(sa[o:o + 6], sb[o:o + 6], rtol=1e-5, atol=1e-7)
     assert skipped == [0.0, 0.0, 1.0, 0.0, 0.0]
     assert fa.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2].tolist() == [5.0, 4.0] and float(fa.state[U.K["DWP_S_SCALE"]]) == 32768.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sharded", [False, True], ids=["plain", "bucket_form"])
+def test_stats_adam_finish_against_the_two_launches(sharded):
+    """The three-launch update (merged_tail=True: dwp_stats_adam_finish: statistics, a grid barrier, clip + Adam + scaler in ONE launch) against dwp_grad_stats |
+    dwp_adam_finish from the same parameters, over clean updates and one that overflows the critic only.  The critic's weights, moments and
+    copies and the scaler's words are the same bits; the actor's are equal to the last place of the clip coefficient (the norm's partial sums
+    are per Adam block in one form and per statistics block in the other); the barrier never timed out."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(12)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 1024, 4
+    kw = dict(collective=True) if sharded else {}
+    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=True, **kw)
+    fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=False, **kw)
+    assert fa.merged_tail and not fb.merged_tail
+    batch = list(_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
+    batch[5] = batch[5].clone()
+    batch[5][2 * B:3 * B] = 3.0e4
+    for f in (fa, fb):
+        f.set_learning_rates(3e-5, 5e-5)
+        f.bind_batch(*batch)
+    skipped = []
+    o = U.K["DWP_S_OUT"]
+    for it in range(nmb + 1):
+        # every update starts from the SAME parameters and moments (a last-place difference of the actor's would otherwise feed the next forward)
+        with torch.no_grad():
+            fb.p.copy_(fa.p); fb.m.copy_(fa.m); fb.v.copy_(fa.v); fb.p16.copy_(fa.p16); fb.p16t.copy_(fa.p16t); fb.p32f.copy_(fa.p32f)
+        fa.update(); fb.update()
+        torch.cuda.synchronize()
+        skipped.append(fa.logged()[7].item())
+        for name in ("W1", "W2", "W3"):
+            assert torch.equal(fa.views[name][1], fb.views[name][1]) and torch.equal(fa.views16[name][1], fb.views16[name][1]), (it, name)
+            da = (fa.views[name][0] - fb.views[name][0]).abs().max().item()
+            assert da <= 2e-7, (it, name, da)          # (steps of ~3e-5 equal to ~1e-7 of themselves: at most the last place of a weight of size ~1)
+        for name in ("b1", "b2", "b3"):          # (biases: to the rounding of their buckets' atomic adds, in both nets)
+            assert float((fa.views[name] - fb.views[name]).abs().max()) <= 1e-7, (it, name)
+        assert float((fa.m - fb.m).abs().max()) <= 1e-6 * float(fa.m.abs().max()) + 1e-12
+        assert float((fa.v - fb.v).abs().max()) <= 1e-6 * float(fa.v.abs().max()) + 1e-12
+        sa, sb = fa.state.cpu(), fb.state.cpu()
+        keep = [i for i in range(U.K["DWP_S_WORDS"]) if not (o <= i < o + 6)]
+        assert torch.equal(sa[keep], sb[keep]), (it, sa.tolist(), sb.tolist())
+        assert torch.allclose(sa[o:o + 6], sb[o:o + 6], rtol=1e-5, atol=1e-7), (it, sa[o:o + 6].tolist(), sb[o:o + 6].tolist())
+    assert skipped == [0.0, 0.0, 1.0, 0.0, 0.0]
+    assert not fa.barrier_timed_out()
+    assert int(fa.part.view(torch.int32)[641].item()) == nmb + 1
+
+
+@pytest.mark.gpu
+def test_stats_adam_finish_in_a_replayed_graph():
+    """The merged launch captured in a hipGraph with the rest of the update and replayed: the barrier's arrival count carries over from one replay
+    to the next (monotonic, nothing to reset), the minibatch index advances, the barrier never times out."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(13)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 512, 4
+    fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=True)
+    fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=True)
+    batch = list(_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
+    for f in (fa, fb):
+        f.bind_batch(*batch)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fa.update()          # (warm-up outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    fb.update()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fa.update()
+    for _ in range(11):
+        g.replay(); fb.update()
+    torch.cuda.synchronize()
+    assert torch.equal(fa.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2], fb.state[U.K["DWP_S_STEP"]:U.K["DWP_S_STEP"] + 2])
+    assert float((fa.p - fb.p).abs().max()) <= 1e-5          # (the bias gradients' atomic adds land in another order from run to run)
+    assert fa.state[U.K["DWP_S_STEP"]].item() == 12.0 and not fa.barrier_timed_out() and int(fa.part.view(torch.int32)[641].item()) == 12
+
+
+@pytest.mark.gpu
+def test_policy_copy_once_per_epoch_equals_per_update():
+    """policy_copy_per_update=False: the updates leave dwp_policy's fp32 operand-order copy alone, policy() refuses to read it while stale, and after
+    sync_policy_copy() the copy -- and the policy's outputs -- are the same bits as with a copy rewritten by every update."""
+    from isaacgymdyros_amd import ppo_update as U
+    ppo = _ppo()
+    c = dict(ppo.TRAIN_CFG["config"])
+    dev = "cuda:0"
+    torch.manual_seed(14)
+    net = ppo.DyrosActorCritic(U.IN, U.ACT, ppo.TRAIN_CFG["network"]).to(dev)
+    _lively(net)
+    B, nmb = 512, 4
+    batch = list(_batch(ppo, copy.deepcopy(net), U, B * nmb, dev))
+    obs = batch[0][:1000].contiguous()
+    for merged in (False, True):
+        fa = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=merged)
+        fb = U.FusedPpoUpdate(copy.deepcopy(net), c, B, nmb, dev, merged_tail=merged, policy_copy_per_update=False)
+        for f in (fa, fb):
+            f.bind_batch(*batch)
+        before = fb.p32f.clone()
+        for _ in range(3):
+            with torch.no_grad():
+                fb.p.copy_(fa.p); fb.m.copy_(fa.m); fb.v.copy_(fa.v); fb.p16.copy_(fa.p16); fb.p16t.copy_(fa.p16t)
+            fa.update(); fb.update()
+        torch.cuda.synchronize()
+        assert torch.equal(fb.p32f, before) and not torch.equal(fa.p32f, before)
+        with pytest.raises(RuntimeError):
+            fb.policy(obs)
+        with torch.no_grad():
+            fb.p.copy_(fa.p)          # (bias gradients' atomic adds land in another order from run to run)
+        fb.sync_policy_copy()
+        torch.cuda.synchronize()
+        assert torch.equal(fa.p32f, fb.p32f)
+        (mu_a, v_a), (mu_b, v_b) = fa.policy(obs), fb.policy(obs)
+        assert torch.equal(mu_a, mu_b) and torch.equal(v_a, v_b)
 
 
 @pytest.mark.gpu
