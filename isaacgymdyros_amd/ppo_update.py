@@ -7,7 +7,9 @@ grad_norm 0.5 on the actor, e_clip 0.2, clip_value False, entropy_coef 0, bounds
   * the default (`mfma=True`), FOUR launches on the matrix cores: dwp_mlp | dwp_wgrad | dwp_grad_stats | dwp_adam_finish.  Sharded over
     several ranks (`world > 1`): dwp_mlp | dwp_wgrad | dwp_grad_bucket | ONE all-reduce of the 1.61 MB gradient bucket | dwp_grad_stats |
     dwp_adam_finish -- the still-scaled gradients are averaged before unscale / clip / step, as the reference's Horovod
-    `optimizer.synchronize()` does (a2c_continuous_seperate.py:171-180).
+    `optimizer.synchronize()` does (a2c_continuous_seperate.py:171-180).  `merged_tail=True` runs the last two launches as one
+    (dwp_stats_adam_finish: the same time, off by default); `policy_copy_per_update=False` leaves the rollout policy's fp32 copy of the
+    weights to one `sync_policy_copy()` per epoch (what examples/ppo_consumer.py does).
   * the library-GEMM form (`mfma=False`), 17 launches:
     stage (1 launch) | 3 batched GEMMs + 2 bias-relu | loss (1) | 5 batched GEMMs + 2 relu-backward | grad stats, Adam, finish (3)
 
