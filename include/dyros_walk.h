@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 9
+#define DW_ABI_VERSION 10
 
 /* ---- fixed sizes of the TOCABI model (reference: assets/mjcf/dyros_tocabi/xml/dyros_tocabi.xml) ---- */
 #define DW_NUM_BODIES   38   /* Gym rigid bodies, XML depth-first                         */
@@ -503,6 +503,11 @@ typedef struct DwAmpResetDraws {
     const int64_t *perturb_timing, *delay_idx;
 } DwAmpResetDraws;
 int dw_amp_reset_done(DwHandle *h, const DwAmpConfig *c, const DwAmpBuffers *b, const DwAmpResetDraws *draws, void *stream);
+/* The other half of VecTask.reset_done (tasks/base/vec_task.py:381, `done_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)`): the ids of
+ * the envs whose reset_buf [n] is non-zero, ascending, into ids [n], and their number into *count (device memory) and -- if given -- *count_host
+ * (pinned host memory mapped to the device: the caller waits for an event recorded behind this launch and reads the number there, without a copy
+ * of its own).  One launch; queue it BEFORE dw_amp_reset_done, which clears the flags.  ABI 10. */
+int dw_amp_reset_ids(const int64_t *reset_buf, int n, int64_t *ids, int64_t *count, int64_t *count_host, void *stream);
 
 
 #ifdef __cplusplus

@@ -159,6 +159,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
         api["amp_step_end"] = fn("amp_step_end", C.c_int, H, AC, AB, P, C.c_int, P, P)
         if prefix == "dw_":          # (the one-launch step lives with the octet kernels' entry points: HIP library only)
             api["amp_step"] = fn("amp_step", C.c_int, H, AC, AB, P, P, P, C.POINTER(C.c_void_p), C.c_int, P, P)
+            api["amp_reset_ids"] = fn("amp_reset_ids", C.c_int, P, C.c_int, P, P, P, P)
         api["amp_reset_rows"] = fn("amp_reset_rows", C.c_int, H, AC, AB, P, C.c_int, P, P, P, P, P, P, P, P, P, P)
         api["amp_reset_done"] = fn("amp_reset_done", C.c_int, H, AC, AB, C.POINTER(DwAmpResetDraws), P)
 
@@ -184,7 +185,7 @@ def declare(lib: C.CDLL, prefix: str = "dw_"):
 
 EXPORTS = ["abi_version", "last_error", "default_config", "create", "destroy", "bind", "simulate", "step", "step_dev", "step_obs",
            "terrain_log", "reset_idx", "amp_observations", "amp_disc_observations", "amp_reward", "amp_reset", "newwalk_reward", "body_positions",
-           "amp_step_begin", "amp_step_mid", "amp_step_end", "amp_step", "amp_reset_rows", "amp_reset_done"]
+           "amp_step_begin", "amp_step_mid", "amp_step_end", "amp_step", "amp_reset_rows", "amp_reset_done", "amp_reset_ids"]
 
 
 # name -> (per-env shape, numpy dtype string); gate_acc is the one buffer without an env dimension

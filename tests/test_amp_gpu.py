@@ -659,6 +659,37 @@ def test_fused_step_with_a_motion_start_keeps_the_shifting_histories(tmp_path):
         e.close()
 
 
+def test_amp_reset_ids_equals_nonzero():
+    """dw_amp_reset_ids against `reset_buf.nonzero()` (tasks/base/vec_task.py:381): ids ascending, the count on the device and in pinned host
+    memory, for no flag, every flag, one flag at either end, random flags, at sizes that are and are not multiples of the workgroup; a count
+    pointer that is plain pageable host memory is refused before the launch."""
+    from isaacgymdyros_amd import _lib
+    lib, api = _lib.load()
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(5)
+    pin = torch.zeros(1, dtype=torch.int64).pin_memory()
+    s = torch.cuda.current_stream().cuda_stream
+    for n in (1, 7, 1024, 1025, 4096, 16384, 50001):
+        cases = [torch.zeros(n, dtype=torch.int64, device=dev), torch.ones(n, dtype=torch.int64, device=dev)]
+        one = torch.zeros(n, dtype=torch.int64, device=dev); one[0] = 1; cases.append(one)
+        last = torch.zeros(n, dtype=torch.int64, device=dev); last[n - 1] = 5; cases.append(last)
+        for pr in (0.01, 0.5):
+            cases.append((torch.rand(n, generator=g, device=dev) < pr).to(torch.int64))
+        for flags in cases:
+            ids = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            cnt = torch.full((1,), -1, dtype=torch.int64, device=dev)
+            pin[0] = -1
+            assert api["amp_reset_ids"](flags.data_ptr(), n, ids.data_ptr(), cnt.data_ptr(), pin.data_ptr(), s) == 0, lib.dw_last_error()
+            torch.cuda.synchronize()
+            ref = flags.nonzero(as_tuple=False).squeeze(-1)
+            assert int(cnt[0]) == len(ref) == int(pin[0]), (n, int(cnt[0]), len(ref), int(pin[0]))
+            assert torch.equal(ids[:len(ref)], ref) and bool((ids[len(ref):] == -1).all())
+    import numpy as np
+    pageable = np.zeros(1, dtype=np.int64)
+    assert api["amp_reset_ids"](flags.data_ptr(), n, ids.data_ptr(), cnt.data_ptr(), pageable.ctypes.data, s) != 0 and b"pinned" in lib.dw_last_error()
+    assert api["amp_reset_ids"](None, n, ids.data_ptr(), cnt.data_ptr(), None, s) != 0
+
+
 def test_amp_step_argument_checks():
     """The fused entry points refuse a table with a missing buffer, sizes beyond what a wave stages, missing draws or a handle of
     another size, with an error code and a message, before anything is launched."""
