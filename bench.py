@@ -462,7 +462,8 @@ def main():
                 acfg["sim"]["mi355"] = {"amp_fused": True, "amp_device_draws": True}
                 aenv = TocabiAMPLower(acfg, dev, 0, True)
                 aenv.reset_done()
-                aenv.enable_graph_step()
+                # (no enable_graph_step(): with the draws made in the kernels a step is five launches and nothing else, and five plain launches
+                #  run closer together than five nodes of a replayed hipGraph -- 0.184 against 0.192 ms, profiles/r06_amp_eager_vs_graph.txt)
                 ag = torch.Generator(device=dev).manual_seed(1)
                 aact = [(torch.rand(args.envs_per_gpu, 12, generator=ag, device=dev) * 2 - 1) * 0.3 for _ in range(8)]
                 for i in range(30):
@@ -476,8 +477,8 @@ def main():
                 aenv.close()
                 out["amp_lower"] = {"value": args.envs_per_gpu * ka / wa, "unit": "env-steps/s", "ms_per_step": wa / ka * 1e3, "resets_per_step": nres / ka,
                                     "note": "TocabiAMPLower (tasks/amp/tocabi_amp_lower_base.py + tasks/tocabi_amp_lower.py) on dw_simulate: step() with the "
-                                            "bookkeeping in three HIP kernels around the two dw_simulate launches (ring histories, draws made in the kernels), recorded in "
-                                            "a hipGraph, + reset_done() every step as one launch (returns the ids: one host sync per step)"}
+                                            "bookkeeping in three HIP kernels around the two dw_simulate launches (ring histories, draws made in the kernels): five plain "
+                                            "launches, + reset_done() every step as two launches (ids by dw_amp_reset_ids, then the reset; returns the ids: one host sync per step)"}
             except Exception as e:
                 out["amp_lower"] = {"error": str(e)}
     if rank == 0:
