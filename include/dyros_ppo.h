@@ -99,7 +99,8 @@ int dwp_loss(uint16_t *out16, const uint16_t *b3_16, const float *act, const flo
 /* dh16 [2][B][HID] *= (h16 > 0), and gb_layer [2][HID] += column sums of the result (fp32) */
 int dwp_relu_bwd(const uint16_t *h16, uint16_t *dh16, float *gb_layer, int32_t B, void *stream);
 
-#define DWP_PARTS 2048  /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates, the G16 switch */
+#define DWP_PARTS 2048  /* words of `part`: [0,256) sums of squares, [256,512) inf / nan flags, [512,520) scale, steps, learning rates, the G16 switch;
+                         * dwp_stats_adam_finish only: [641] the update's number, [642] set once a wait timed out, [1024,1536) the blocks' 64-bit shares */
 #define DWP_P16F_WORDS 548864   /* halves of p16f, the weights once more in the order dwp_mlp's matrix instructions take them (csrc/dw_ppo.hip frag_pos) */
 #define DWP_P32F_WORDS 401408   /* floats of p32f, the fp32 weights in the order dwp_policy's matrix instructions take them (csrc/dw_ppo.hip frag32_pos) */
 #define DWP_WGRAD_SLABS 4    /* dwp_wgrad splits the samples into this many slabs: g32 is [DWP_WGRAD_SLABS][weights] partial gradients */
