@@ -653,29 +653,56 @@ struct ResetSrc {
 // tasks/tocabi_amp_lower.py:144-147,258-272)
 DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G,
                      const ResetSrc &R, int e) {
-    enum { SO_QN = 0, SO_QV = 12, SO_BIAS = 24, SO_QB = 36, SO_CMD = 39, SO_NZ = 42 };
+    // Four regions (six until round 6, each ending in a drain of the wave's outstanding memory operations): (1) EVERY global read of the
+    // reset -- the leg model, the old episode's last readings, the action-history words the reset observation shows, counters -- and the
+    // stores that depend on nothing else; (2) the serial functions and the stores that must follow the reads of (1); (3) what needs (2)'s
+    // rows; (4) what needs (3)'s.  Same values, same arithmetic, same order of the draws as the reference's reset_idx.
+    enum { SO_QN = 0, SO_QV = 12, SO_BIAS = 24, SO_QB = 36, SO_CMD = 39, SO_NZ = 42, SO_EPI = 48 };
     const int NH = C.num_his * C.num_skip;
     const bool dev = C.device_draws != 0;
-    stage_leg_model(W, S, M);
+    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
+    const int obs_part = DW_AMP_NUM_OBS1 * C.num_his;          // the stacked observation: [0, obs_part) observation slots, then action slots
     W.par([&](int l) DWA_INL {
-        const DrawKey k = draw_key(C, B, e);
-        // what the reset observation is made of: the episode's LAST encoder reading, biases and command (the reference computes it
-        // before it draws the new ones, :253 before :266-279)
-        if (l < 12) {
-            S.small[SO_QN + l] = B.qpos_noise[(size_t)DW_NUM_DOF * e + l]; S.small[SO_QV + l] = B.qvel_noise[(size_t)DW_NUM_DOF * e + l];
-            S.small[SO_BIAS + l] = B.qpos_bias[12 * (size_t)e + l];
+        // ---- requests
+        const unsigned long long ctr = dev ? (unsigned long long)B.draw_ctr[e] : 0ull;
+        const int ah_head = C.hist_ring ? B.hist_head[2 * (size_t)e] : 0;
+        float qn = 0.0f, qv = 0.0f, bias = 0.0f, qb = 0.0f, cmd = 0.0f, nzs = 0.0f, root = 0.0f, q0 = 0.0f, epi = 0.0f;
+        if (l < 12) { qn = B.qpos_noise[(size_t)DW_NUM_DOF * e + l]; qv = B.qvel_noise[(size_t)DW_NUM_DOF * e + l]; bias = B.qpos_bias[12 * (size_t)e + l]; }
+        if (l < 3) { qb = B.quat_bias[3 * (size_t)e + l]; cmd = B.commands[3 * (size_t)e + l]; }
+        if (l < 6 && R.rootvel_noise) nzs = R.rootvel_noise[6 * (size_t)e + l];
+        if (l < 13) root = B.initial_root_states[13 * (size_t)e + l];
+        if (l < DW_NUM_DOF) q0 = B.init_angle[l];
+        if (l == 63) epi = B.epi_len[e];
+        const bool drr = R.dr && C.randomize && B.randomize_buf[e] >= (int64_t)C.dr_frequency;
+        for (int i = l; i < LegModel::NBODY * 16; i += 64) {
+            const int b = i >> 4, k = i & 15;
+            if (k < 3) S.LM.pos[b][k] = M.pos[b][k];
+            else if (k < 6) S.LM.axis[b][k - 3] = M.axis[b][k - 3];
+            else if (k < 15) S.LM.rot0[b][k - 6] = M.rot0[b][k - 6];
+            else S.LM.parent[b] = M.parent[b];
         }
-        if (l < 3) { S.small[SO_QB + l] = B.quat_bias[3 * (size_t)e + l]; S.small[SO_CMD + l] = B.commands[3 * (size_t)e + l]; }
+        // the action slots of the reset observation: what the action history holds NOW (it is zeroed in the next region)
+        const float *ah = B.action_history + (size_t)NH * 12 * e;
+        for (int i = obs_part + l; i < num_obs; i += 64) {
+            const int j = i - obs_part, slot = j / 12, kk = j - 12 * slot;
+            S.hist[j] = ah[(size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + kk];
+        }
+        // ---- what the reset observation is made of: the episode's LAST encoder reading, biases and command (the reference computes it
+        //      before it draws the new ones, :253 before :266-279)
+        DrawKey k; k.seed = C.seed; k.env = (unsigned int)e; k.ctr = ctr;
+        if (l == 0) { S.i64[0] = (long long)ctr; S.touch = drr ? 1 : 0; }
+        if (l < 12) { S.small[SO_QN + l] = qn; S.small[SO_QV + l] = qv; S.small[SO_BIAS + l] = bias; }
+        if (l < 3) { S.small[SO_QB + l] = qb; S.small[SO_CMD + l] = cmd; }
         if (l < 6) {
             float nz = 0.0f;
-            if (R.rootvel_noise) nz = R.rootvel_noise[6 * (size_t)e + l];
+            if (R.rootvel_noise) nz = nzs;
             else if (C.noise && dev) nz = draw_uniform(k, DS_RESET, 40 + l) * 0.05f - 0.025f;
             S.small[SO_NZ + l] = nz;
         }
+        if (l == 63) S.small[SO_EPI] = epi;
         // the Gym tensors' rows: initial root state, initial pose at rest, no contact (_reset_actors, :611-626)
-        if (l < 13) { const float v = B.initial_root_states[13 * (size_t)e + l]; S.root[l] = v; G.root_states[13 * (size_t)e + l] = v; }
+        if (l < 13) { S.root[l] = root; G.root_states[13 * (size_t)e + l] = root; }
         if (l < DW_NUM_DOF) {
-            const float q0 = B.init_angle[l];
             S.ds[2 * l] = q0; S.ds[2 * l + 1] = 0.0f;
             G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2] = q0; G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1] = 0.0f;
         }
@@ -689,7 +716,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         // dof properties (apply_randomizations, tasks/base/vec_task.py:519-733): additive damping, scaled armature, from the
         // nominal values, for a resetting env whose randomize_buf has reached the frequency
         // (only under task.randomize, as the torch class and the reference: apply_randomizations is what resets randomize_buf)
-        if (R.dr && C.randomize && l < DW_NUM_DOF && B.randomize_buf[e] >= (int64_t)C.dr_frequency) {
+        if (drr && l < DW_NUM_DOF) {
             if (C.dr_damping) {
                 const float u = R.damp ? R.damp[(size_t)DW_NUM_DOF * R.row + l] : draw_uniform(k, DS_DR, l);
                 G.dof_damping[(size_t)DW_NUM_DOF * e + l] = B.nominal_damping[l] + ((C.dr_damping_range[1] - C.dr_damping_range[0]) * u + C.dr_damping_range[0]);
@@ -715,33 +742,16 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         }
         if (l >= 4 && l < 7) B.rigid_body_pos[(size_t)DW_NUM_BODIES * 3 * e + (l - 4)] = r[l - 4];
         if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
-        if (R.dr && C.randomize && l == 63 && B.randomize_buf[e] >= (int64_t)C.dr_frequency) B.randomize_buf[e] = 0;
-    });
-    const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
-    W.par([&](int l) DWA_INL {
-        if (l == 1) disc_observations_row(S.root, S.ds, S.ds + 1, 2, C.local_root_obs, S.foot, 2, S.amp);
-        if (l >= 2 && l < 2 + DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + (l - 2)] = S.obs[l - 2];
-        // the reset env's observation: every history slot shows the reset observation, the action slots what the action history
-        // still holds; only then are the two histories zeroed (:296-297)
-        const float *ah = B.action_history + (size_t)NH * 12 * e;
-        const int ah_head = C.hist_ring ? B.hist_head[2 * (size_t)e] : 0;
-        float *ob = B.obs_buf + (size_t)num_obs * e;
-        for (int i = l; i < num_obs; i += 64) {
-            float v;
-            if (i < DW_AMP_NUM_OBS1 * C.num_his) v = S.obs[i % DW_AMP_NUM_OBS1];
-            else { const int j = i - DW_AMP_NUM_OBS1 * C.num_his, slot = j / 12, kk = j - 12 * slot; v = ah[(size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + kk]; }
-            ob[i] = v;
-            if (B.obs_out && R.dr) B.obs_out[(size_t)num_obs * e + i] = fminf(fmaxf(v, -C.clip_obs), C.clip_obs);
-        }
-    });
-    W.par([&](int l) DWA_INL {
-        const DrawKey k = draw_key(C, B, e);
+        if (l == 63 && S.touch) B.randomize_buf[e] = 0;
+        // ---- the new episode's buffers (:296-297 and what follows): region (1) has read what the reset observation shows of the old ones
+        DrawKey k; k.seed = C.seed; k.env = (unsigned int)e; k.ctr = (unsigned long long)S.i64[0];
         for (int i = l; i < NH * DW_AMP_NUM_OBS1; i += 64) B.obs_history[(size_t)NH * DW_AMP_NUM_OBS1 * e + i] = 0.0f;
         for (int i = l; i < NH * 12; i += 64) B.action_history[(size_t)NH * 12 * e + i] = 0.0f;
         for (int i = l; i < C.log_slots * 12; i += 64) B.action_log[(size_t)C.log_slots * 12 * e + i] = 0.0f;
         if (l < DW_NUM_DOF) {
             const size_t g = (size_t)DW_NUM_DOF * e + l;
-            B.dof_vel_pre[g] = 0.0f; B.qpos_noise[g] = B.init_angle[l]; B.qpos_pre[g] = B.init_angle[l]; B.qvel_noise[g] = 0.0f;
+            const float q0 = S.ds[2 * l];
+            B.dof_vel_pre[g] = 0.0f; B.qpos_noise[g] = q0; B.qpos_pre[g] = q0; B.qvel_noise[g] = 0.0f;
         }
         if (l < 12) {
             B.actions_pre[12 * (size_t)e + l] = 0.0f;
@@ -769,19 +779,32 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         }
         if (l == 63) {
             B.progress_buf[e] = 0; B.reset_buf[e] = 0; B.terminate_buf[e] = 0;
-            B.epi_len_log[e] = B.epi_len[e]; B.epi_len[e] = 0.0f;
+            B.epi_len_log[e] = S.small[SO_EPI]; B.epi_len[e] = 0.0f;
             B.perturbation_count[e] = 0; B.pert_on[e] = 0;
             B.perturb_timing[e] = R.ptime ? R.ptime[R.row] : draw_int(k, DS_RESET, 32, 0, (long long)(8 / 0.002));
             B.delay_idx[e] = R.didx ? R.didx[R.row] : draw_int(k, DS_RESET, 33, C.delay_idx_range[0], C.delay_idx_range[1]);
             B.simul_len[e] = 0;
             if (C.hist_ring) { B.hist_head[2 * (size_t)e] = 0; B.hist_head[2 * (size_t)e + 1] = 0; }
         }
+    });
+    W.par([&](int l) DWA_INL {
+        if (l == 1) disc_observations_row(S.root, S.ds, S.ds + 1, 2, C.local_root_obs, S.foot, 2, S.amp);
+        if (l >= 2 && l < 2 + DW_AMP_NUM_OBS1) B.obs1[DW_AMP_NUM_OBS1 * (size_t)e + (l - 2)] = S.obs[l - 2];
+        // the reset env's observation: every history slot shows the reset observation, the action slots what the action history held
+        float *ob = B.obs_buf + (size_t)num_obs * e;
+        for (int i = l; i < num_obs; i += 64) {
+            const float v = i < obs_part ? S.obs[i % DW_AMP_NUM_OBS1] : S.hist[i - obs_part];
+            ob[i] = v;
+            if (B.obs_out && R.dr) B.obs_out[(size_t)num_obs * e + i] = fminf(fmaxf(v, -C.clip_obs), C.clip_obs);
+        }
+    });
+    W.par([&](int l) DWA_INL {
         // discriminator history of a default start: every slot the current observation (tasks/tocabi_amp_lower.py:258-272)
         float *ab = B.amp_obs_buf + (size_t)C.amp_steps * AW * e;
         for (int i = l; i < C.amp_steps * AW; i += 64) ab[i] = S.amp[i % AW];
         if (l < AW) B.amp_obs1[(size_t)AW * e + l] = S.amp[l];
+        if (dev && l == 0) B.draw_ctr[e] = (long long)((unsigned long long)S.i64[0] + 1ull);
     });
-    if (dev) W.par([&](int l) DWA_INL { if (l == 0) B.draw_ctr[e] += 1; });
 }
 
 }  // namespace dwa
