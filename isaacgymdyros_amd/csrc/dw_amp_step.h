@@ -68,6 +68,7 @@ struct StepLds {
     float hist[HIST_STAGE];                       // a row on its way (linear histories, the discriminator history)
     long long i64[4];
     int   touch, head[2];
+    unsigned int draws[29 * 4];                   // reset_env: the env's generator blocks (12 of DS_RESET, 17 of DS_DR), one per lane
 };
 enum { SM_NZ = 0, SM_BIAS = 6, SM_QB = 18, SM_CMD = 21, SM_ACT = 24, SM_ACTP = 36, SM_EFF = 48 };          // words of StepLds::small
 
@@ -98,6 +99,9 @@ DW_HD float draw_enc_normal(const DrawKey &k, unsigned int stream, int w) {
 DW_HD long long draw_int(const DrawKey &k, unsigned int stream, int w, long long lo, long long hi) {
     return lo + (long long)(draw_u32(k, stream, w) % (unsigned int)(hi - lo));
 }
+// the same two conversions from a word a lane did not draw itself (reset_env: one block per lane, the words through LDS)
+DW_HD float u32_uniform(unsigned int u) { return (float)(u >> 8) * 5.9604644775390625e-08f; }
+DW_HD long long u32_int(unsigned int u, long long lo, long long hi) { return lo + (long long)(u % (unsigned int)(hi - lo)); }
 DW_HD DrawKey draw_key(const DwAmpConfig &C, const DwAmpBuffers &B, int e) {
     DrawKey k;
     k.seed = C.seed; k.env = (unsigned int)e; k.ctr = C.device_draws ? (unsigned long long)B.draw_ctr[e] : 0ull;
@@ -653,15 +657,17 @@ struct ResetSrc {
 // tasks/tocabi_amp_lower.py:144-147,258-272)
 DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const DwAmpConfig &C, const DwAmpBuffers &B, const GymRows &G,
                      const ResetSrc &R, int e) {
-    // Four regions (six until round 6, each ending in a drain of the wave's outstanding memory operations): (1) EVERY global read of the
-    // reset -- the leg model, the old episode's last readings, the action-history words the reset observation shows, counters -- and the
-    // stores that depend on nothing else; (2) the serial functions and the stores that must follow the reads of (1); (3) what needs (2)'s
-    // rows; (4) what needs (3)'s.  Same values, same arithmetic, same order of the draws as the reference's reset_idx.
+    // Five regions (six until round 6, each ending in a drain of the wave's outstanding memory operations): (1) EVERY global read of the
+    // reset -- the leg model, the old episode's last readings, the action-history words the reset observation shows, counters -- and every
+    // generator block the reset draws from, one per lane; (2) the stores that depend on nothing else; (3) the serial functions and the stores
+    // that must follow the reads of (1); (4) what needs (3)'s rows; (5) what needs (4)'s.  Same values, same arithmetic, same order of the draws as the reference's reset_idx.
     enum { SO_QN = 0, SO_QV = 12, SO_BIAS = 24, SO_QB = 36, SO_CMD = 39, SO_NZ = 42, SO_EPI = 48 };
     const int NH = C.num_his * C.num_skip;
     const bool dev = C.device_draws != 0;
     const int num_obs = (DW_AMP_NUM_OBS1 + 12) * C.num_his - 12;
     const int obs_part = DW_AMP_NUM_OBS1 * C.num_his;          // the stacked observation: [0, obs_part) observation slots, then action slots
+    // word w of the env's generator stream (DS_RESET: blocks 0 .. 11, DS_DR: 12 .. 28), drawn by lane `block` in region (1)
+    auto word = [&](unsigned int stream, int w) -> unsigned int { return S.draws[4 * ((stream == DS_RESET ? 0 : 12) + (w >> 2)) + (w & 3)]; };
     W.par([&](int l) DWA_INL {
         // ---- requests
         const unsigned long long ctr = dev ? (unsigned long long)B.draw_ctr[e] : 0ull;
@@ -681,48 +687,52 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
             else if (k < 15) S.LM.rot0[b][k - 6] = M.rot0[b][k - 6];
             else S.LM.parent[b] = M.parent[b];
         }
-        // the action slots of the reset observation: what the action history holds NOW (it is zeroed in the next region)
+        // the action slots of the reset observation: what the action history holds NOW (it is zeroed two regions on)
         const float *ah = B.action_history + (size_t)NH * 12 * e;
         for (int i = obs_part + l; i < num_obs; i += 64) {
             const int j = i - obs_part, slot = j / 12, kk = j - 12 * slot;
             S.hist[j] = ah[(size_t)hist_phys(ah_head, C.num_skip * (slot + 1), NH) * 12 + kk];
         }
+        // the env's generator blocks, ONE per lane (29 of them: every draw of the reset; lanes that each drew what they needed ran the
+        // generator nine times one after the other, in divergent branches)
+        if (l < 29) {          // (without device_draws the counter reads 0 and every draw is the caller's: the entry points insist on their arrays)
+            DrawKey k; k.seed = C.seed; k.env = (unsigned int)e; k.ctr = ctr;
+            unsigned int c4[4];
+            draw_block(k, l < 12 ? (unsigned int)DS_RESET : (unsigned int)DS_DR, (unsigned int)(l < 12 ? l : l - 12), c4);
+            for (int i = 0; i < 4; ++i) S.draws[4 * l + i] = c4[i];
+        }
         // ---- what the reset observation is made of: the episode's LAST encoder reading, biases and command (the reference computes it
         //      before it draws the new ones, :253 before :266-279)
-        DrawKey k; k.seed = C.seed; k.env = (unsigned int)e; k.ctr = ctr;
         if (l == 0) { S.i64[0] = (long long)ctr; S.touch = drr ? 1 : 0; }
         if (l < 12) { S.small[SO_QN + l] = qn; S.small[SO_QV + l] = qv; S.small[SO_BIAS + l] = bias; }
         if (l < 3) { S.small[SO_QB + l] = qb; S.small[SO_CMD + l] = cmd; }
-        if (l < 6) {
-            float nz = 0.0f;
-            if (R.rootvel_noise) nz = nzs;
-            else if (C.noise && dev) nz = draw_uniform(k, DS_RESET, 40 + l) * 0.05f - 0.025f;
-            S.small[SO_NZ + l] = nz;
-        }
+        if (l < 6) S.small[SO_NZ + l] = nzs;
         if (l == 63) S.small[SO_EPI] = epi;
+        if (l < 13) S.root[l] = root;
+        if (l < DW_NUM_DOF) { S.ds[2 * l] = q0; S.ds[2 * l + 1] = 0.0f; }
+    });
+    W.par([&](int l) DWA_INL {
+        if (l < 6 && !R.rootvel_noise) S.small[SO_NZ + l] = (C.noise && dev) ? u32_uniform(word(DS_RESET, 40 + l)) * 0.05f - 0.025f : 0.0f;
         // the Gym tensors' rows: initial root state, initial pose at rest, no contact (_reset_actors, :611-626)
-        if (l < 13) { S.root[l] = root; G.root_states[13 * (size_t)e + l] = root; }
-        if (l < DW_NUM_DOF) {
-            S.ds[2 * l] = q0; S.ds[2 * l + 1] = 0.0f;
-            G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2] = q0; G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1] = 0.0f;
-        }
+        if (l < 13) G.root_states[13 * (size_t)e + l] = S.root[l];
+        if (l < DW_NUM_DOF) { G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2] = S.ds[2 * l]; G.dof_state[((size_t)DW_NUM_DOF * e + l) * 2 + 1] = 0.0f; }
         for (int i = l; i < DW_NUM_BODIES * 3; i += 64) G.contact_forces[(size_t)DW_NUM_BODIES * 3 * e + i] = 0.0f;
         // (the draws arrive as raw uniforms; the values are formed with torch's arithmetic: `(hi - lo) * u + lo` with the scalars
         //  rounded to float32 first, `x / s` as a multiplication by 1.0f / s on a GPU and a division on a CPU)
         if (R.power && l < 12) {
-            const float u = R.ps ? R.ps[12 * R.row + l] : draw_uniform(k, DS_RESET, l);
+            const float u = R.ps ? R.ps[12 * R.row + l] : u32_uniform(word(DS_RESET, l));
             B.power_scale[12 * (size_t)e + l] = (float)(1.2 - 0.8) * u + (float)0.8;
         }
         // dof properties (apply_randomizations, tasks/base/vec_task.py:519-733): additive damping, scaled armature, from the
         // nominal values, for a resetting env whose randomize_buf has reached the frequency
         // (only under task.randomize, as the torch class and the reference: apply_randomizations is what resets randomize_buf)
-        if (drr && l < DW_NUM_DOF) {
+        if (S.touch && l < DW_NUM_DOF) {
             if (C.dr_damping) {
-                const float u = R.damp ? R.damp[(size_t)DW_NUM_DOF * R.row + l] : draw_uniform(k, DS_DR, l);
+                const float u = R.damp ? R.damp[(size_t)DW_NUM_DOF * R.row + l] : u32_uniform(word(DS_DR, l));
                 G.dof_damping[(size_t)DW_NUM_DOF * e + l] = B.nominal_damping[l] + ((C.dr_damping_range[1] - C.dr_damping_range[0]) * u + C.dr_damping_range[0]);
             }
             if (C.dr_armature) {
-                const float u = R.arm ? R.arm[(size_t)DW_NUM_DOF * R.row + l] : draw_uniform(k, DS_DR, DW_NUM_DOF + l);
+                const float u = R.arm ? R.arm[(size_t)DW_NUM_DOF * R.row + l] : u32_uniform(word(DS_DR, DW_NUM_DOF + l));
                 G.dof_armature[(size_t)DW_NUM_DOF * e + l] = B.nominal_armature[l] * ((C.dr_armature_range[1] - C.dr_armature_range[0]) * u + C.dr_armature_range[0]);
             }
         }
@@ -744,7 +754,6 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         if (l >= 8 && l < 12) B.rigid_body_rot[(size_t)DW_NUM_BODIES * 4 * e + (l - 8)] = r[3 + (l - 8)];
         if (l == 63 && S.touch) B.randomize_buf[e] = 0;
         // ---- the new episode's buffers (:296-297 and what follows): region (1) has read what the reset observation shows of the old ones
-        DrawKey k; k.seed = C.seed; k.env = (unsigned int)e; k.ctr = (unsigned long long)S.i64[0];
         for (int i = l; i < NH * DW_AMP_NUM_OBS1; i += 64) B.obs_history[(size_t)NH * DW_AMP_NUM_OBS1 * e + i] = 0.0f;
         for (int i = l; i < NH * 12; i += 64) B.action_history[(size_t)NH * 12 * e + i] = 0.0f;
         for (int i = l; i < C.log_slots * 12; i += 64) B.action_log[(size_t)C.log_slots * 12 * e + i] = 0.0f;
@@ -757,7 +766,7 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
             B.actions_pre[12 * (size_t)e + l] = 0.0f;
             float v = 0.0f;
             if (C.noise) {
-                const float u = R.qb ? R.qb[12 * R.row + l] : draw_uniform(k, DS_RESET, 12 + l);
+                const float u = R.qb ? R.qb[12 * R.row + l] : u32_uniform(word(DS_RESET, 12 + l));
                 const float x = u * 6.28f;
                 v = (C.gpu_div ? x * (1.0f / 100.0f) : x / 100.0f) - (float)(3.14 / 100);
             }
@@ -765,13 +774,13 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
         }
         if (l < 3) {
             float u;
-            if (l == 0) u = R.cx ? R.cx[R.row] : draw_uniform(k, DS_RESET, 24);
-            else if (l == 1) u = R.cy ? R.cy[R.row] : draw_uniform(k, DS_RESET, 25);
-            else u = R.cyaw ? R.cyaw[R.row] : draw_uniform(k, DS_RESET, 26);
+            if (l == 0) u = R.cx ? R.cx[R.row] : u32_uniform(word(DS_RESET, 24));
+            else if (l == 1) u = R.cy ? R.cy[R.row] : u32_uniform(word(DS_RESET, 25));
+            else u = R.cyaw ? R.cyaw[R.row] : u32_uniform(word(DS_RESET, 26));
             B.commands[3 * (size_t)e + l] = C.cmd_scale[l] * u + C.cmd_lo[l];
             float v = 0.0f;
             if (C.noise) {
-                const float uq = R.quatb ? R.quatb[3 * R.row + l] : draw_uniform(k, DS_RESET, 28 + l);
+                const float uq = R.quatb ? R.quatb[3 * R.row + l] : u32_uniform(word(DS_RESET, 28 + l));
                 const float x = uq * 6.28f;
                 v = (C.gpu_div ? x * (1.0f / 150.0f) : x / 150.0f) - (float)(3.14 / 150);
             }
@@ -781,8 +790,8 @@ DW_HD void reset_env(const EnvWave &W, StepLds &S, const dw::DevModel &M, const 
             B.progress_buf[e] = 0; B.reset_buf[e] = 0; B.terminate_buf[e] = 0;
             B.epi_len_log[e] = S.small[SO_EPI]; B.epi_len[e] = 0.0f;
             B.perturbation_count[e] = 0; B.pert_on[e] = 0;
-            B.perturb_timing[e] = R.ptime ? R.ptime[R.row] : draw_int(k, DS_RESET, 32, 0, (long long)(8 / 0.002));
-            B.delay_idx[e] = R.didx ? R.didx[R.row] : draw_int(k, DS_RESET, 33, C.delay_idx_range[0], C.delay_idx_range[1]);
+            B.perturb_timing[e] = R.ptime ? R.ptime[R.row] : u32_int(word(DS_RESET, 32), 0, (long long)(8 / 0.002));
+            B.delay_idx[e] = R.didx ? R.didx[R.row] : u32_int(word(DS_RESET, 33), C.delay_idx_range[0], C.delay_idx_range[1]);
             B.simul_len[e] = 0;
             if (C.hist_ring) { B.hist_head[2 * (size_t)e] = 0; B.hist_head[2 * (size_t)e + 1] = 0; }
         }
