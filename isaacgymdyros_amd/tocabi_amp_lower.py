@@ -809,18 +809,20 @@ class TocabiAMPLower(VecTask):
         if getattr(self, "_cnt_pin", None) is None:
             self._cnt_pin = torch.zeros(1, dtype=torch.int64).pin_memory()
             self._cnt_dev = torch.zeros(1, dtype=torch.int64, device=self._tdev)
-            self._ids_buf = torch.zeros(self.num_envs, dtype=torch.int64, device=self._tdev)
             self._cnt_evt = torch.cuda.Event()
         if self.reset_buf.dtype != torch.int64 or not self.reset_buf.is_contiguous():
             raise ValueError("reset_done: reset_buf must be a contiguous int64 tensor")
-        self._chk(self._api["amp_reset_ids"](self.reset_buf.data_ptr(), self.num_envs, self._ids_buf.data_ptr(), self._cnt_dev.data_ptr(),
+        # (the ids land in a tensor of this call's own -- room for every env, 8 B each, recycled by torch's allocator when the caller lets go of
+        #  the slice it gets: no copy into a right-sized tensor afterwards, which was one more launch on the stream)
+        ids_all = torch.empty(self.num_envs, dtype=torch.int64, device=self._tdev)
+        self._chk(self._api["amp_reset_ids"](self.reset_buf.data_ptr(), self.num_envs, ids_all.data_ptr(), self._cnt_dev.data_ptr(),
                                              self._cnt_pin.data_ptr(), self._stream()))
         self._cnt_evt.record(torch.cuda.current_stream(self._tdev))
         c, b = self._fused_tables()
         self._chk(self._api["amp_reset_done"](self._phys._h, C.byref(c), C.byref(b), None, self._stream()))
         self.obs_dict["obs"] = self._obs_out
         self._cnt_evt.synchronize()
-        ids = self._ids_buf[:int(self._cnt_pin[0])].clone()          # (the caller's own tensor: the buffer is rewritten by the next call)
+        ids = ids_all[:int(self._cnt_pin[0])]
         if len(ids) > 0:
             self.time_step = 0          # (as reset_idx: only when some env was reset)
             self._reset_default_env_ids = ids
