@@ -131,7 +131,10 @@ DW_HD int hist_phys(int head, int logical, int nh) { const int p = head + logica
 // The group's thread count is a parameter of the group type (round 6): 256 for the three step kernels, 128 = the two wavefronts of an octet
 // workgroup for the one-launch step (dw_k_amp_step_oct, dw_oct_kernels.hip), whose 16 envs are the same 16.  Every function below takes the
 // group as a template argument and names its thread count GT.
-constexpr int GT = 256, GE = 16;
+#if !defined(DWA_GE)
+#define DWA_GE 16          // (A/B builds only: envs per group of the three step kernels)
+#endif
+constexpr int GT = 256, GE = DWA_GE;
 #if defined(__HIPCC__)
 template <int GT_> struct EnvGroupT {
     static constexpr int GT = GT_;

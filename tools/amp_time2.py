@@ -3,6 +3,8 @@ usage: python tools/amp_time2.py [N] [--graph] [--fused] [--draws] [--noring]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from isaacgymdyros_amd import _lib
+_lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)          # (A/B builds under isaacgymdyros_amd/_ab/, tools/tu_lib.sh)
 from isaacgymdyros_amd.tocabi_amp_lower import TocabiAMPLower, default_amp_cfg
 GRAPH = "--graph" in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
