@@ -606,7 +606,10 @@ DW_HD void step_end(const WG &W, GroupLds &S, const dw::DevModel &M, const DwAmp
     // the stacked observation (:540-580): obs slots S (i + 1) - 1, action slots S (i + 1), i < H - 1.  Eight items per thread at a
     // time, every load before the first store (the compiler may not move a load over a store into the same table)
     W.par([&](int t) DWA_INL {
-        constexpr int SB = 8;          // items per thread in flight (four until round 6)
+#if !defined(DWA_SB)
+#define DWA_SB 8          // (A/B builds only)
+#endif
+        constexpr int SB = DWA_SB;          // items per thread in flight (four until round 6)
         for (int i0 = t; i0 < GE * num_obs; i0 += SB * GT) {
             float v[SB];
             size_t dst[SB];
