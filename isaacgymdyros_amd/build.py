@@ -13,9 +13,14 @@ LIB = os.path.join(PKG, "libdyroswalk_hip.so")
 # pays directly (0.1477 -> 0.1444 ms at 16384 envs, 0.1188 -> 0.1176 at 4096, no scratch in the flat kernels; max-ilp,
 # iterative-minreg and the default max-occupancy scheduler lose; A/Bs of round 3).  The small kernels keep
 # the compiler's default.
+# Round 6 (a sweep of backend switches on the final sources, same-box A/Bs: profiles/r06_flag_sweep.txt): no SDWA peephole (the sub-dword forms
+# are 8-byte encodings: same instruction count, fewer instruction-fetch waits: 0.1391 -> 0.1366 ms at 16384 envs) and no loop strength
+# reduction (its induction variables cost the chain loops registers: 0.1369 -> 0.1356 ms, the height-field kernels' scratch 156 -> 116 / 136 B);
+# together flat 0.1394 -> 0.1360 ms, height field 0.1617 -> 0.1582 ms, 4096 envs (hex) 0.0977 -> 0.0967 ms.
+KERNEL_UNIT = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-amdgpu-sdwa-peephole=false", "-mllvm", "-disable-lsr"]
 SOURCES = [("dw_hip.hip", []),
-           ("dw_oct_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
-           ("dw_hex_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]), ("dw_amp.hip", []), ("dw_ppo.hip", ["-munsafe-fp-atomics"])]
+           ("dw_oct_kernels.hip", KERNEL_UNIT),
+           ("dw_hex_kernels.hip", KERNEL_UNIT), ("dw_amp.hip", []), ("dw_ppo.hip", ["-munsafe-fp-atomics"])]
 HEADERS = ["dw_wave.h", "dw_devmodel.h", "dw_physics.h", "dw_task.h", "dw_params.h", "dw_quad_wave.h", "dw_quad_model.h",
            "dw_limb.h", "dw_bufg.h", "dw_oct.h", "dw_oct_kernels.h", "dw_oct_post.h", "dw_handle.h", "dw_amp.h", "dw_amp_step.h"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 math into v_pk_*_f32 pairs: in the octet step kernel 1 920
