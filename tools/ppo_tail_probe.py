@@ -4,6 +4,8 @@ import copy, importlib.util, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from isaacgymdyros_amd import _lib
+_lib.LIB_PATH = os.environ.get("DW_LIB", _lib.LIB_PATH)          # (A/B builds under isaacgymdyros_amd/_ab/, tools/tu_lib.sh)
 spec = importlib.util.spec_from_file_location("ppo_consumer", os.path.join(ROOT, "examples", "ppo_consumer.py"))
 ppo = importlib.util.module_from_spec(spec); spec.loader.exec_module(ppo)
 from isaacgymdyros_amd import ppo_update as U
