@@ -212,7 +212,7 @@ def main():
         if not plumbing:
             torch.cuda.synchronize()
 
-    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False, warm_seconds=None):
+    def run(envs, steps, warmup, alias_obs=False, mi=None, friction_dr=False, terrain=False, warm_seconds=None, fresh_actions=False):
         """K steps of VecTask.step on `envs` envs of this rank.  alias_obs = False is the product's default contract (step() returns
         a fresh observation tensor, as the reference's torch.clamp does); True returns the view of obs_buf, so that the stream
         holds nothing but the step kernel."""
@@ -268,7 +268,10 @@ def main():
         if not plumbing:
             e0.record()
         for i in range(steps):
-            env.step(pool[i % len(pool)])
+            if fresh_actions:          # (SURVEY 8d's wording: the batch is regenerated on the device every step -- one torch kernel more on the stream)
+                env.step(torch.empty(envs, 13, device=dev).uniform_(-1.0, 1.0, generator=g))
+            else:
+                env.step(pool[i % len(pool)])
             if (i + 1) % HORIZON == 0:
                 dwdist.gather_episode_stats(env._buf["env_state"])      # logging only, once per horizon
         if not plumbing:
@@ -398,6 +401,11 @@ def main():
             ach2 = A_STEP_BYTES * 4096 / (a2["kernel_ms"] * 1e-3) / 1e9
             out["num_envs_4096"] = {"value": 4096 * n2 / r2["wall"], "ms_per_step": r2["wall"] / n2 * 1e3, "kernel_ms": a2["kernel_ms"],
                                     "roofline_frac": ach2 / HBM_PEAK_GBS}
+        if not args.no_config5:                 #  the head leg with its actions regenerated every step instead of taken from a resident pool
+            nf = max(args.steps, 256)
+            rf = run(args.envs_per_gpu, nf, args.warmup, fresh_actions=True)
+            out["fresh_actions_each_step"] = {"value": args.envs_per_gpu * nf / rf["wall"], "ms_per_step": rf["wall"] / nf * 1e3,
+                                              "note": "as the head leg, but every step's action batch is drawn on the device inside the timed region (one torch uniform_ kernel per step)"}
         if not args.no_config5:                 # BASELINE config 5: friction DR next to mass / damping / armature, pushes forced on
             r5 = run(args.envs_per_gpu, n2, args.warmup, mi={"force_perturb_start": True}, friction_dr=True)
             out["config5_dr_friction_pushes"] = {"value": args.envs_per_gpu * n2 / r5["wall"], "ms_per_step": r5["wall"] / n2 * 1e3,
